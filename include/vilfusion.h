@@ -1,0 +1,251 @@
+/*
+ * vilfusion.h — C ABI of the MI355X-native sliding-window back-end for VIL_Fusion.
+ *
+ * Drop-in boundary for ONE hot path of RichExplor/VIL_Fusion (reference paths are relative to
+ * src/visual_inertial_lidar/):
+ *   - Estimator::optimization()            vins_estimator/estimator.cpp:689-1050
+ *   - MarginalizationInfo                  vins_estimator/factor/marginalization_factor.{h,cpp}
+ *   - EstimationMapping::optimation_processing   feature_tracker/include/EstimationMapping.hpp:235-296
+ *
+ * Plain C: POD structs, caller-owned host buffers, library-owned device state, int status codes,
+ * never throws / never aborts (reference error convention: Evaluate() always returns true, solver
+ * failures are not checked — estimator.cpp:852-855).
+ *
+ * Memory-layout conventions are the reference's:
+ *   pose block   [tx ty tz qx qy qz qw]            (estimator.cpp:509-516)
+ *   speed-bias   [vx vy vz bax bay baz bgx bgy bgz] (estimator.cpp:518-528)
+ *   quaternions in structs: x y z w   (Eigen coeffs order)
+ *   matrices: row-major
+ *   scan-to-map pose [qx qy qz qw tx ty tz]        (EstimationMapping.hpp:383-385)
+ *
+ * Parameter-block ids replace the reference's address keys (marginalization_factor.h:59-62):
+ *   Pose[i] -> i,  SpeedBias[i] -> NF+i,  Ex_Pose -> 2NF,  Td -> 2NF+1,  Feature[k] -> 2NF+2+k
+ * with NF = window_size+1 frames.
+ */
+#ifndef VILFUSION_H
+#define VILFUSION_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VILF_MAX_FRAMES 11         /* WINDOW_SIZE + 1, vins_estimator/parameters.h:24 */
+#define VILF_MAX_FEATURES 1000     /* NUM_OF_F, parameters.h:26 */
+#define VILF_PRIOR_MAX_DIM 160     /* 10 poses*6 + 10 speedbias*9 + ex 6 + td 1 = 157 */
+#define VILF_PRIOR_MAX_BLOCKS 24
+
+/* status codes */
+#define VILF_OK 0
+#define VILF_ERR_INVALID_ARGUMENT (-1)
+#define VILF_ERR_DEVICE (-2)
+#define VILF_ERR_UNSUPPORTED (-3)
+#define VILF_ERR_NO_GPU (-4)
+#define VILF_SOLVER_ABNORMAL 1     /* >0: solver terminated abnormally (summary tells why) */
+
+/* marginalization_flag, estimator.h:63-67 */
+#define VILF_MARGIN_OLD 0
+#define VILF_MARGIN_SECOND_NEW 1
+
+/* termination types (mirrors ceres::TerminationType semantics for the configured minimizer) */
+#define VILF_TERM_NO_CONVERGENCE 0    /* max_num_iterations reached */
+#define VILF_TERM_CONVERGENCE_FUNCTION 1
+#define VILF_TERM_CONVERGENCE_PARAMETER 2
+#define VILF_TERM_CONVERGENCE_GRADIENT 3
+#define VILF_TERM_FAILURE 4           /* too many invalid steps / min radius */
+
+typedef struct vilf_handle vilf_handle;
+
+/* Options ≙ the globals read by readParameters() (vins_estimator/parameters.cpp:45-155) plus the
+ * solver options set in estimator.cpp:838-850. */
+typedef struct vilf_options {
+    int window_size;          /* WINDOW_SIZE = 10 */
+    int max_num_iterations;   /* NUM_ITERATIONS = 8 (kitti_config.yaml:74) */
+    double max_solver_time;   /* SOLVER_TIME seconds; <= 0 disables the wall-clock limit (parity runs) */
+    double focal_length;      /* FOCAL_LENGTH = 460; sqrt_info = focal/1.5 * I2 (estimator.cpp:17) */
+    double cauchy_a;          /* CauchyLoss(1.0) (estimator.cpp:694) */
+    double G[3];              /* global G (parameters.cpp:14,77) */
+    int estimate_extrinsic;   /* ESTIMATE_EXTRINSIC */
+    int estimate_td;          /* ESTIMATE_TD */
+    int use_lidar_const;      /* #define USE_LIDAR_CONST (parameters.h:56) */
+    double RIC[9], TIC[3];    /* imu^R_cam, imu^T_cam   (globals used by lidarFactor) */
+    double RCL[9], TCL[3];    /* cam^R_lidar, cam^T_lidar */
+    double TR, ROW;           /* rolling shutter read-out time, image rows */
+    double init_depth;        /* INIT_DEPTH = 5.0 (parameters.cpp:132), feature_manager.cpp:205-208 */
+    /* scan-to-map (velodyne_param_64.yaml:22-23, EstimationMapping.hpp:263,277,327) */
+    double edge_leaf_size;    /* 0.4 */
+    double surf_leaf_size;    /* 0.8 */
+    double huber_a;           /* 0.1 */
+    int s2m_outer_iterations; /* 2 */
+    int s2m_max_iterations;   /* 4 */
+    double s2m_crop_half;     /* 100.0 */
+} vilf_options;
+
+/* IntegrationBase state consumed by IMUFactor (factor/integration_base.h:188-207) */
+typedef struct vilf_imu_preint {
+    double sum_dt;
+    double delta_p[3];
+    double delta_q[4];        /* x y z w */
+    double delta_v[3];
+    double linearized_ba[3];
+    double linearized_bg[3];
+    double jacobian[225];     /* 15x15 row-major */
+    double covariance[225];   /* 15x15 row-major */
+} vilf_imu_preint;
+
+/* lidarConstraintsBase (factor/lidarConstraint_base.h:24-25) */
+typedef struct vilf_lidar_constraint {
+    double q[4];              /* x y z w */
+    double t[3];
+} vilf_lidar_constraint;
+
+/* One window ≙ the members optimization() reads (estimator.h:70-146). */
+typedef struct vilf_window_in {
+    int n_frames;                         /* window_size + 1 */
+    const double *para_pose;              /* [n_frames][7] */
+    const double *para_speed_bias;        /* [n_frames][9] */
+    double para_ex_pose[7];
+    double para_td;
+    int n_features;                       /* f_manager.getFeatureCount() */
+    const double *para_feature;           /* [n_features] inverse depth (feature_manager.cpp:194-216) */
+    const uint8_t *feature_const;         /* [n_features] lidar_depth_flag (estimator.cpp:780,789) */
+    const int32_t *feature_start_frame;   /* [n_features] */
+    const int32_t *feature_obs_offset;    /* [n_features+1] CSR into obs_*; obs k of a feature is in frame start+k */
+    int n_obs;
+    const double *obs_point;              /* [n_obs][3] feature_per_frame[k].point */
+    const double *obs_velocity;           /* [n_obs][2] or NULL (td factor only) */
+    const double *obs_cur_td;             /* [n_obs]    or NULL */
+    const double *obs_row;                /* [n_obs] uv.y() or NULL */
+    const vilf_imu_preint *imu;           /* [n_frames]; entry j = pre_integrations[j], j >= 1 used */
+    const vilf_lidar_constraint *lidar;   /* [n_frames]; entry j = lidarConstraints[j], j >= 1 used; may be NULL if !use_lidar_const */
+    int marginalization_flag;
+    const double *gauge_R0;               /* optional Rs[0] (9, row-major) override for double2vector (failure_occur path); NULL: from para_pose[0] */
+    const double *gauge_P0;               /* optional Ps[0] override; NULL: from para_pose[0] */
+} vilf_window_in;
+
+typedef struct vilf_summary {
+    int num_iterations;        /* trust-region iterations executed (excluding iteration 0) */
+    int num_successful_steps;
+    int num_linear_solves;     /* dense Schur solves (rejected steps re-use the previous one) */
+    int termination;           /* VILF_TERM_* */
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+    double usec_solve;         /* wall time spent in the solve, microseconds */
+} vilf_summary;
+
+/* State after Solve + double2vector() (estimator.cpp:549-638). Caller-owned buffers. */
+typedef struct vilf_window_out {
+    double *para_pose;         /* [n_frames][7]   raw solver output (before gauge fix); may be NULL */
+    double *para_speed_bias;   /* [n_frames][9]   may be NULL */
+    double *para_feature;      /* [n_features]    may be NULL */
+    double *Ps;                /* [n_frames][3] */
+    double *Rs;                /* [n_frames][9] */
+    double *Vs;                /* [n_frames][3] */
+    double *Bas;               /* [n_frames][3] */
+    double *Bgs;               /* [n_frames][3] */
+    double tic[3], ric[9];
+    double td;
+    vilf_summary summary;
+} vilf_window_out;
+
+/* Marginalization prior ≙ MarginalizationInfo after marginalize()+getParameterBlocks()
+ * (marginalization_factor.h:58-70). Block ids are already shifted (estimator.cpp:960-971). */
+typedef struct vilf_prior {
+    int valid;
+    int n;                                       /* rows = kept local dimension */
+    int m;                                       /* marginalized local dimension (informative) */
+    int n_blocks;
+    int block_id[VILF_PRIOR_MAX_BLOCKS];
+    int block_size[VILF_PRIOR_MAX_BLOCKS];       /* global size (7 / 9 / 1) */
+    int block_idx[VILF_PRIOR_MAX_BLOCKS];        /* local column offset = keep_block_idx - m */
+    double block_x0[VILF_PRIOR_MAX_BLOCKS][9];   /* keep_block_data */
+    double linearized_residuals[VILF_PRIOR_MAX_DIM];
+    double linearized_jacobians[VILF_PRIOR_MAX_DIM * VILF_PRIOR_MAX_DIM]; /* n x n row-major, leading dim n */
+} vilf_prior;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+void vilf_default_options(vilf_options *opts);                 /* KITTI config values */
+/* hip_stream: a hipStream_t (as void*) all work is enqueued on, or NULL for the library's own stream. */
+int vilf_create(const vilf_options *opts, int device, void *hip_stream, vilf_handle **out);
+void vilf_destroy(vilf_handle *h);
+int vilf_reset(vilf_handle *h);                                /* drop priors ≙ clearState(), estimator.cpp:72-77 */
+const char *vilf_last_error(const vilf_handle *h);
+const char *vilf_version(void);
+
+/* ---- single-window drop-in (≙ Estimator::optimization()) ------------------------------- */
+/* estimator.cpp:689-860: build problem, Solve, double2vector. Uses/keeps the prior of slot 0. */
+int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out);
+/* estimator.cpp:863-1046: marginalization of the just-solved window (slot 0); new prior stays on device. */
+int vilf_window_marginalize(vilf_handle *h);
+
+/* ---- batched windows (independent window snapshots resident in HBM) -------------------- */
+/* Pack + upload n windows into slots 0..n-1 (inputs stay resident until the next upload). */
+int vilf_batch_upload(vilf_handle *h, int n_windows, const vilf_window_in *wins);
+/* Solve every resident window (all kernels enqueued on the handle's stream). sync!=0 waits. */
+int vilf_batch_solve(vilf_handle *h, int sync);
+/* Re-arm the resident windows with their uploaded initial state (bench loop: repeated identical steps). */
+int vilf_batch_rewind(vilf_handle *h);
+int vilf_batch_marginalize(vilf_handle *h, int sync);
+int vilf_batch_download(vilf_handle *h, int first, int n_windows, vilf_window_out *outs);
+int vilf_batch_summaries(vilf_handle *h, int first, int n_windows, vilf_summary *sums);
+int vilf_synchronize(vilf_handle *h);
+/* newest-frame pose per resident window: [stamp x y z qx qy qz qw] (8 doubles each) into a DEVICE buffer
+ * (feeds the RCCL gather for global_fusion, poseGraphOptimization.cpp:116-121). */
+int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8);
+
+/* ---- prior import / export (tests, snapshots) ------------------------------------------ */
+int vilf_prior_export(vilf_handle *h, int slot, vilf_prior *out);
+int vilf_prior_import(vilf_handle *h, int slot, const vilf_prior *prior);
+
+/* ---- fine-grained hooks in the reference's Ceres layout -------------------------------- */
+/* bool Evaluate(double const *const *parameters, double *residuals, double **jacobians): row-major
+ * jacobians in GLOBAL size (pose: 7 columns, last = 0); jacobians / jacobians[i] may be NULL. All run on
+ * the device through the same device functions the solve kernels use. */
+int vilf_eval_projection(vilf_handle *h, const double *const *parameters, const double pts_i[3],
+                         const double pts_j[3], double *residuals, double **jacobians);   /* projection_factor.cpp:21 */
+int vilf_eval_imu(vilf_handle *h, const double *const *parameters, const vilf_imu_preint *pre,
+                  double *residuals, double **jacobians);                                   /* imu_factor.h:19 */
+int vilf_eval_lidar_between(vilf_handle *h, const double *const *parameters,
+                            const vilf_lidar_constraint *c, double *residuals, double **jacobians); /* lidar_factor.h:19 */
+int vilf_eval_prior(vilf_handle *h, const vilf_prior *prior, const double *const *parameters,
+                    double *residuals, double **jacobians);                                 /* marginalization_factor.cpp:333 */
+int vilf_eval_edge(vilf_handle *h, const double pose_qt[7], const double curr_point[3], const double point_a[3],
+                   const double point_b[3], double residuals[3], double *jacobian /*3x7 or NULL*/);   /* lidarFactor.hpp:21 */
+int vilf_eval_surf(vilf_handle *h, const double pose_qt[7], const double curr_point[3], const double norm[3],
+                   double negative_OA_dot_norm, double residuals[1], double *jacobian /*1x7 or NULL*/); /* lidarFactor.hpp:79 */
+int vilf_pose_plus(vilf_handle *h, const double x[7], const double delta[6], double x_plus_delta[7]); /* pose_local_parameterization.cpp:3 */
+int vilf_se3_plus(vilf_handle *h, const double x[7], const double delta[6], double x_plus_delta[7]);  /* EstimationMapping.hpp:34 */
+
+/* ---- IMU pre-integration (host; ≙ IntegrationBase, integration_base.h:30-158) ---------- */
+typedef struct vilf_imu_noise { double acc_n, gyr_n, acc_w, gyr_w; } vilf_imu_noise;
+int vilf_imu_preintegrate(const vilf_imu_noise *noise, const double acc_0[3], const double gyr_0[3],
+                          const double linearized_ba[3], const double linearized_bg[3], int n_samples,
+                          const double *dt, const double *acc /*[n][3]*/, const double *gyr /*[n][3]*/,
+                          vilf_imu_preint *out);
+
+/* ---- scan-to-map (≙ EstimationMapping) -------------------------------------------------- */
+/* points are float xyzi (pcl::PointXYZI without padding): [n][4] */
+int vilf_scan2map_init(vilf_handle *h, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);   /* localMapInited, :105 */
+/* optimation_processing(:235): in/out pose_qt = parameter_opti [qx qy qz qw tx ty tz] is kept in the handle
+ * (globalOdom / globalOdom_last); returns the new global pose and the frame-to-frame relative pose T_ij. */
+typedef struct vilf_scan2map_result {
+    double pose_qt[7];          /* globalOdom after the step */
+    double rel_q[4], rel_t[3];  /* globalOdom_last^-1 * globalOdom: the /Odometry message (feature_tracker_node.cpp:400-415) */
+    int n_edge_ds, n_surf_ds;   /* after voxel down-sampling */
+    int n_edge_factors[2];      /* accepted edge factors in association pass 0/1 */
+    int n_surf_factors[2];
+    int iterations[2];          /* solver iterations per pass */
+    double final_cost[2];
+    int map_edge_size, map_surf_size;
+} vilf_scan2map_result;
+int vilf_scan2map_step(vilf_handle *h, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf,
+                       vilf_scan2map_result *res);
+int vilf_scan2map_get_map(vilf_handle *h, int which /*0 edge, 1 surf*/, float *xyzi_out, int capacity, int *n_out);
+int vilf_scan2map_set_pose(vilf_handle *h, const double pose_qt[7], const double pose_last_qt[7]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VILFUSION_H */

@@ -1,0 +1,93 @@
+"""Loader for the CPU oracle (TEST INFRASTRUCTURE). Only tests/, smoke() and bench.py's cpu_baseline leg use it."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+from vil_fusion_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_lib = None
+
+dpp = C.POINTER(abi.c_double_p)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "-j8"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "liboracle_vilf.so")
+        if not os.path.exists(so):
+            build()
+        _lib = C.CDLL(so)
+        _lib.vilo_default_options.argtypes = [C.POINTER(abi.Options)]
+        _lib.vilo_default_options.restype = None
+        _lib.vilo_window_solve.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.WindowIn), C.POINTER(abi.Prior), C.POINTER(abi.WindowOut)]
+        _lib.vilo_window_marginalize.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.WindowIn), C.POINTER(abi.WindowOut), C.POINTER(abi.Prior), C.POINTER(abi.Prior)]
+        _lib.vilo_last_trace.argtypes = [abi.c_double_p, C.c_int]
+    return _lib
+
+
+def default_options():
+    o = abi.Options()
+    lib().vilo_default_options(C.byref(o))
+    return o
+
+
+def window_solve(opts, win, prior=None):
+    res = abi.WindowResult(win.n_frames, win.n_features)
+    s = win.as_struct()
+    rc = lib().vilo_window_solve(C.byref(opts), C.byref(s), C.byref(prior) if prior is not None else None, C.byref(res.struct))
+    assert rc == 0, rc
+    return res.finish()
+
+
+def last_trace():
+    buf = np.zeros((64, 9))
+    n = lib().vilo_last_trace(abi.dptr(buf), 64)
+    return buf[:n].copy()
+
+
+def window_marginalize(opts, win, solved, prior=None):
+    out = abi.Prior()
+    s = win.as_struct()
+    rc = lib().vilo_window_marginalize(C.byref(opts), C.byref(s), C.byref(solved.struct), C.byref(prior) if prior is not None else None, C.byref(out))
+    assert rc == 0, rc
+    return out
+
+
+def _params(arrs):
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+    p = (abi.c_double_p * len(arrs))(*[abi.dptr(a) for a in arrs])
+    return arrs, p
+
+
+def eval_factor(kind, opts, params, *consts, sizes, nres, want_jac=True):
+    """Call a Ceres-layout hook; returns (residuals, [jacobians row-major nres x size])."""
+    L = lib()
+    arrs, p = _params(params)
+    r = np.zeros(nres)
+    jacs = [np.zeros((nres, s)) for s in sizes]
+    jp = (abi.c_double_p * len(sizes))(*[abi.dptr(j) for j in jacs]) if want_jac else None
+    fn = getattr(L, "vilo_eval_" + kind)
+    fn.restype = C.c_int
+    args = []
+    if kind != "prior":
+        args.append(C.byref(opts))
+    else:
+        args.append(C.byref(consts[0])); consts = consts[1:]
+    args.append(p)
+    for c in consts:
+        if isinstance(c, np.ndarray):
+            args.append(abi.dptr(np.ascontiguousarray(c, dtype=np.float64)))
+        elif isinstance(c, float):
+            args.append(C.c_double(c))
+        else:
+            args.append(C.byref(c))
+    args += [abi.dptr(r), jp]
+    rc = fn(*args)
+    assert rc == 0
+    return r, jacs

@@ -1,0 +1,307 @@
+"""Pins the CPU oracle's factors the only way the reference itself endorses:
+ProjectionFactor::check() — analytic Jacobian vs forward differences with eps = 1e-6 along the SAME local
+perturbation the solver uses (pose: p += dp, q = q ⊗ deltaQ(dθ); projection_factor.cpp:176-224), extended to every
+factor type, plus closed-form / numpy cross-checks. CPU only.
+"""
+import ctypes as C
+import numpy as np
+import pytest
+from vil_fusion_amd import abi, synth
+
+
+def rand_pose(rng, scale=1.0):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    return np.concatenate([rng.normal(0, scale, 3), q])
+
+
+def pose_plus_ref(x, d):
+    """PoseLocalParameterization::Plus restated in numpy (pose_local_parameterization.cpp:3-19)."""
+    dq = np.array([d[3] / 2, d[4] / 2, d[5] / 2, 1.0])
+    q = synth.q_mul(x[3:], dq)
+    return np.concatenate([x[:3] + d[:3], q / np.linalg.norm(q)])
+
+
+def numeric_jac(f, params, sizes, kinds, eps=1e-6):
+    """forward differences in the tangent space; kinds[i] in {'pose','se3','euclid'}"""
+    r0 = f(params)
+    out = []
+    for i, (sz, kind) in enumerate(zip(sizes, kinds)):
+        loc = 6 if kind in ("pose", "se3") else sz
+        J = np.zeros((r0.size, loc))
+        for k in range(loc):
+            d = np.zeros(loc); d[k] = eps
+            pp = [p.copy() for p in params]
+            if kind == "pose":
+                pp[i] = pose_plus_ref(params[i], d)
+            elif kind == "se3":
+                pp[i] = se3_plus_np(params[i], d)
+            else:
+                pp[i] = params[i] + d
+            J[:, k] = (f(pp) - r0) / eps
+        out.append(J)
+    return out
+
+
+def so3_exp(w):
+    th = np.linalg.norm(w)
+    K = synth.skew(w)
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def se3_plus_np(x, d):
+    """LocalSE3Parameterization::Plus restated with a textbook SE(3) exponential (left perturbation)."""
+    w, u = d[:3], d[3:]
+    th = np.linalg.norm(w)
+    R = so3_exp(w)
+    K = synth.skew(w)
+    Jl = np.eye(3) if th < 1e-12 else np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * K @ K
+    dq = synth.q_exp(w)
+    q = synth.q_mul(dq, x[:4])
+    t = R @ x[4:] + Jl @ u
+    return np.concatenate([q, t])
+
+
+def test_projection_factor_check(oracle, opts):
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        Pi = rand_pose(rng); Pj = rand_pose(rng); Pj[:3] = Pi[:3] + rng.normal(0, 0.5, 3)
+        # keep the point in front of camera j: small relative rotation
+        Pj[3:] = synth.q_mul(Pi[3:], synth.q_exp(rng.normal(0, 0.1, 3)))
+        ex = np.concatenate([np.array(opts.TIC[:]), synth.R_to_q(np.array(opts.RIC[:]).reshape(3, 3))])
+        lam = np.array([1.0 / rng.uniform(4, 30)])
+        pts_i = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.2), 1.0])
+        pts_j = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.2), 1.0])
+        params = [Pi, Pj, ex, lam]
+        f = lambda pp: oracle.eval_factor("projection", opts, pp, pts_i, pts_j, sizes=[7, 7, 7, 1], nres=2, want_jac=False)[0]
+        r, J = oracle.eval_factor("projection", opts, params, pts_i, pts_j, sizes=[7, 7, 7, 1], nres=2)
+        Jn = numeric_jac(f, params, [7, 7, 7, 1], ["pose", "pose", "pose", "euclid"])
+        for a, b, sz in zip(J, Jn, [7, 7, 7, 1]):
+            loc = 6 if sz == 7 else sz
+            scale = max(1.0, np.abs(b).max())
+            assert np.abs(a[:, :loc] - b).max() / scale < 2e-4, (trial, a[:, :loc], b)
+            if sz == 7:
+                assert np.all(a[:, 6] == 0)
+        # closed form residual: normalised-plane reprojection error * 460/1.5
+        Ri, Rj, Ric = synth.q_to_R(Pi[3:]), synth.q_to_R(Pj[3:]), synth.q_to_R(ex[3:])
+        pc = Ric.T @ (Rj.T @ (Ri @ (Ric @ (pts_i / lam[0]) + ex[:3]) + Pi[:3] - Pj[:3]) - ex[:3])
+        assert np.allclose(r, 460.0 / 1.5 * (pc[:2] / pc[2] - pts_j[:2]), rtol=1e-11, atol=1e-11)
+
+
+def _imu_setup(rng, opts):
+    win, _, truth = synth.make_window(int(rng.integers(1 << 30)), opts, synth.SynthConfig(n_features=20, with_prior=False))
+    j = int(rng.integers(1, win.n_frames))
+    pre = abi.ImuPreint.from_buffer_copy(win.imu[j].tobytes())
+    params = [win.para_pose[j - 1].copy(), win.para_speed_bias[j - 1].copy(), win.para_pose[j].copy(), win.para_speed_bias[j].copy()]
+    return win, j, pre, params
+
+
+def test_imu_factor_check(oracle, opts):
+    rng = np.random.default_rng(1)
+    for trial in range(6):
+        win, j, pre, params = _imu_setup(rng, opts)
+        f = lambda pp: oracle.eval_factor("imu", opts, pp, pre, sizes=[7, 9, 7, 9], nres=15, want_jac=False)[0]
+        r, J = oracle.eval_factor("imu", opts, params, pre, sizes=[7, 9, 7, 9], nres=15)
+        # whitened forward differences are noisy (sqrt_info ~1e6): use a smaller relative tolerance on a scaled problem
+        Jn = numeric_jac(f, params, [7, 9, 7, 9], ["pose", "euclid", "pose", "euclid"], eps=1e-7)
+        for a, b, sz in zip(J, Jn, [7, 9, 7, 9]):
+            loc = 6 if sz == 7 else sz
+            scale = np.abs(b).max()
+            assert np.abs(a[:, :loc] - b).max() / scale < 5e-4, (trial, np.abs(a[:, :loc] - b).max(), scale)
+
+
+def test_imu_sqrt_info_is_llt_of_inverse(oracle, opts):
+    rng = np.random.default_rng(2)
+    win, j, pre, params = _imu_setup(rng, opts)
+    out = np.zeros(225)
+    oracle.lib().vilo_imu_sqrt_info(C.byref(pre), abi.dptr(out))
+    S = out.reshape(15, 15)
+    cov = np.array(pre.covariance[:]).reshape(15, 15)
+    L = np.linalg.cholesky(np.linalg.inv(cov))
+    assert np.allclose(S, L.T, rtol=1e-6, atol=1e-6 * np.abs(L).max())
+    assert np.allclose(S.T @ S @ cov, np.eye(15), atol=1e-6)
+
+
+def test_imu_preintegration_matches_independent_numpy(oracle, opts):
+    """oracle IntegrationBase vs the generator's vectorised numpy restatement (two independent implementations)."""
+    rng = np.random.default_rng(3)
+    S = 10
+    acc = rng.normal(0, 1, (1, S + 1, 3)) + np.array([0, 0, 9.8]); gyr = rng.normal(0, 0.2, (1, S + 1, 3))
+    ba = rng.normal(0, 0.02, (1, 3)); bg = rng.normal(0, 0.002, (1, 3))
+    ref = synth.preintegrate(acc, gyr, 0.01, ba, bg)[0]
+    nz = abi.ImuNoise(synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)
+    out = abi.ImuPreint()
+    dts = np.full(S, 0.01)
+    a1 = np.ascontiguousarray(acc[0, 1:]); g1 = np.ascontiguousarray(gyr[0, 1:])
+    oracle.lib().vilo_imu_preintegrate(C.byref(nz), abi.dptr(np.ascontiguousarray(acc[0, 0])), abi.dptr(np.ascontiguousarray(gyr[0, 0])),
+                                       abi.dptr(np.ascontiguousarray(ba[0])), abi.dptr(np.ascontiguousarray(bg[0])), S,
+                                       abi.dptr(dts), abi.dptr(a1), abi.dptr(g1), C.byref(out))
+    got = np.frombuffer(bytes(out), dtype=np.float64)
+    assert np.allclose(got[:17], ref[:17], rtol=1e-12, atol=1e-14)
+    assert np.allclose(got[17:242], ref[17:242], rtol=1e-10, atol=1e-14)
+    assert np.allclose(got[242:], ref[242:], rtol=1e-9, atol=1e-22)
+
+
+def test_lidar_between_factor_check_and_quirk(oracle, opts):
+    rng = np.random.default_rng(4)
+    for trial in range(10):
+        Pi = rand_pose(rng); Pj = rand_pose(rng)
+        Pj[3:] = synth.q_mul(Pi[3:], synth.q_exp(rng.normal(0, 0.05, 3))); Pj[:3] = Pi[:3] + rng.normal(0, 1, 3)
+        c = abi.LidarConstraint()
+        q = synth.q_exp(rng.normal(0, 0.05, 3))
+        for k in range(4):
+            c.q[k] = q[k]
+        t = rng.normal(0, 1, 3)
+        for k in range(3):
+            c.t[k] = t[k]
+        params = [Pi, Pj]
+        f = lambda pp: oracle.eval_factor("lidar_between", opts, pp, c, sizes=[7, 7], nres=6, want_jac=False)[0]
+        r, J = oracle.eval_factor("lidar_between", opts, params, c, sizes=[7, 7], nres=6)
+        Jn = numeric_jac(f, params, [7, 7], ["pose", "pose"])
+        # Reference quirk (lidar_factor.h:39-42 vs :44-75): residual is scaled by diag(10,10,10,100,100,100), the
+        # analytic jacobian is NOT. So analytic == numeric / weights.
+        wts = np.array([10, 10, 10, 100, 100, 100.0])[:, None]
+        for a, b in zip(J, Jn):
+            assert np.abs(a[:, :6] - b / wts).max() < 5e-5, (trial, a[:, :6], b / wts)
+
+
+def test_lidar_between_zero_residual_at_truth(oracle, opts):
+    win, _, truth = synth.make_window(11, opts, synth.SynthConfig(n_features=10, with_prior=False))
+    # noise-free constraint recomputed from the true poses must give ~0 residual
+    RIC = np.array(opts.RIC[:]).reshape(3, 3); RCL = np.array(opts.RCL[:]).reshape(3, 3)
+    TIC = np.array(opts.TIC[:]); TCL = np.array(opts.TCL[:])
+    Ril = RIC @ RCL; til = RIC @ TCL + TIC
+    R, P = truth["R"], truth["P"]
+    j = 3
+    Rij = R[j - 1].T @ R[j]; Pij = R[j - 1].T @ (P[j] - P[j - 1])
+    c = abi.LidarConstraint()
+    q = synth.R_to_q(Ril.T @ Rij @ Ril); t = Ril.T @ (Rij @ til + Pij - til)
+    for k in range(4):
+        c.q[k] = q[k]
+    for k in range(3):
+        c.t[k] = t[k]
+    params = [np.concatenate([P[j - 1], truth["Q"][j - 1]]), np.concatenate([P[j], truth["Q"][j]])]
+    r, _ = oracle.eval_factor("lidar_between", opts, params, c, sizes=[7, 7], nres=6)
+    assert np.abs(r).max() < 1e-9
+
+
+def test_edge_surf_factor_check(oracle, opts):
+    rng = np.random.default_rng(5)
+    L = oracle.lib()
+    for trial in range(10):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        pose = np.concatenate([q, rng.normal(0, 2, 3)])
+        cp = rng.normal(0, 5, 3); a = rng.normal(0, 5, 3); b = a + rng.normal(0, 0.2, 3)
+        r = np.zeros(3); J = np.zeros((3, 7))
+        L.vilo_eval_edge(abi.dptr(pose), abi.dptr(cp), abi.dptr(a), abi.dptr(b), abi.dptr(r), abi.dptr(J))
+
+        def fe(pp):
+            rr = np.zeros(3)
+            L.vilo_eval_edge(abi.dptr(np.ascontiguousarray(pp[0])), abi.dptr(cp), abi.dptr(a), abi.dptr(b), abi.dptr(rr), None)
+            return rr
+        Jn = numeric_jac(fe, [pose], [7], ["se3"])[0]
+        assert np.abs(J[:, :6] - Jn).max() / max(1, np.abs(Jn).max()) < 1e-4
+        assert np.all(J[:, 6] == 0)
+        # closed form: point-to-line distance vector
+        lp = synth.q_to_R(q) @ cp + pose[4:]
+        assert np.allclose(r, np.cross(lp - a, lp - b) / np.linalg.norm(a - b), rtol=1e-12, atol=1e-12)
+        n = rng.normal(size=3); n /= np.linalg.norm(n); d = float(rng.normal())
+        rs = np.zeros(1); Js = np.zeros((1, 7))
+        L.vilo_eval_surf.argtypes = [abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_double, abi.c_double_p, abi.c_double_p]
+        L.vilo_eval_surf(abi.dptr(pose), abi.dptr(cp), abi.dptr(n), d, abi.dptr(rs), abi.dptr(Js))
+
+        def fs(pp):
+            rr = np.zeros(1)
+            L.vilo_eval_surf(abi.dptr(np.ascontiguousarray(pp[0])), abi.dptr(cp), abi.dptr(n), d, abi.dptr(rr), None)
+            return rr
+        Jn = numeric_jac(fs, [pose], [7], ["se3"])[0]
+        assert np.abs(Js[:, :6] - Jn).max() / max(1, np.abs(Jn).max()) < 1e-4
+        assert np.allclose(rs[0], n @ lp + d)
+
+
+def test_pose_and_se3_plus(oracle):
+    rng = np.random.default_rng(6)
+    L = oracle.lib()
+    for _ in range(10):
+        x = rand_pose(rng); d = rng.normal(0, 0.1, 6); out = np.zeros(7)
+        L.vilo_pose_plus(abi.dptr(x), abi.dptr(d), abi.dptr(out))
+        assert np.allclose(out, pose_plus_ref(x, d), atol=1e-15)
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        xs = np.concatenate([q, rng.normal(0, 3, 3)]); out2 = np.zeros(7)
+        L.vilo_se3_plus(abi.dptr(xs), abi.dptr(d), abi.dptr(out2))
+        assert np.allclose(out2, se3_plus_np(xs, d), atol=1e-12)
+    # tiny-angle branch (common.h:150-155,166-169)
+    d = np.array([1e-12, 0, 0, 0.5, -0.2, 0.1]); out2 = np.zeros(7)
+    L.vilo_se3_plus(abi.dptr(xs), abi.dptr(d), abi.dptr(out2))
+    assert np.allclose(out2[4:], xs[4:] + d[3:], atol=1e-9)
+
+
+def test_corrector_matches_gradient_of_robust_cost(oracle):
+    """Corrected 0.5*|r~|^2 must have the gradient of 0.5*rho(|r|^2)."""
+    rng = np.random.default_rng(7)
+    L = oracle.lib()
+    for loss, a in ((0, 1.0), (1, 0.1), (1, 10.0)):
+        for _ in range(5):
+            r = rng.normal(0, 2, 2); J = rng.normal(0, 1, (2, 5))
+            r2 = r.copy(); J2 = J.copy(); rho = np.zeros(3)
+            L.vilo_corrector.argtypes = [C.c_int, C.c_double, C.c_int, abi.c_double_p, C.c_int, abi.c_double_p, abi.c_double_p]
+            L.vilo_corrector(loss, a, 2, abi.dptr(r2), 5, abi.dptr(J2), abi.dptr(rho))
+            s = r @ r
+            if loss == 0:
+                assert np.isclose(rho[0], a * a * np.log(1 + s / (a * a)))
+            g_robust = rho[1] * (J.T @ r)
+            assert np.allclose(J2.T @ r2, g_robust, rtol=1e-12)
+
+
+def test_prior_factor(oracle):
+    rng = np.random.default_rng(8)
+    o = oracle.default_options()
+    win, prior, _ = synth.make_window(5, o)
+    J0, r0, blocks = abi.prior_to_numpy(prior)
+    params = []
+    for b in blocks:
+        params.append(win.para_pose[b["id"]] if b["size"] == 7 and b["id"] < 11 else (win.para_ex_pose if b["size"] == 7 else win.para_speed_bias[b["id"] - 11]))
+    sizes = [b["size"] for b in blocks]
+    r, J = oracle.eval_factor("prior", None, params, prior, sizes=sizes, nres=prior.n)
+    # residual at x0 equals r0 and jacobian equals J0 columns (marginalization_factor.cpp:364-376)
+    p0 = [b["x0"] for b in blocks]
+    r_at0, _ = oracle.eval_factor("prior", None, p0, prior, sizes=sizes, nres=prior.n)
+    assert np.allclose(r_at0, r0, atol=1e-12)
+    for b, Jb in zip(blocks, J):
+        loc = 6 if b["size"] == 7 else b["size"]
+        assert np.array_equal(Jb[:, :loc], J0[:, b["idx"]:b["idx"] + loc])
+        if b["size"] == 7:
+            assert np.all(Jb[:, 6] == 0)
+    # dx restated in numpy
+    dx = np.zeros(prior.n)
+    for b, x in zip(blocks, params):
+        if b["size"] == 7:
+            dq = synth.q_mul(synth.q_conj(b["x0"][3:]), x[3:])
+            dx[b["idx"]:b["idx"] + 3] = x[:3] - b["x0"][:3]
+            dx[b["idx"] + 3:b["idx"] + 6] = 2 * dq[:3] * (1 if dq[3] >= 0 else -1)
+        else:
+            dx[b["idx"]:b["idx"] + b["size"]] = x - b["x0"]
+    assert np.allclose(r, r0 + J0 @ dx, rtol=1e-10, atol=1e-10)
+
+
+def test_small_linear_algebra_vs_numpy(oracle):
+    rng = np.random.default_rng(9)
+    L = oracle.lib()
+    for n in (3, 15, 60, 130):
+        A = rng.normal(size=(n, n)); A = A @ A.T
+        if n > 15:
+            A[:, :5] *= 1e-7; A[:5, :] *= 1e-7      # near-singular directions like a marginalization Amm
+        w = np.zeros(n); V = np.zeros((n, n))
+        L.vilo_sym_eigen(n, abi.dptr(np.ascontiguousarray(A)), abi.dptr(w), abi.dptr(V))
+        wn = np.linalg.eigvalsh(A)
+        assert np.allclose(w, wn, rtol=1e-9, atol=1e-12 * abs(wn).max())
+        assert np.allclose(V @ np.diag(w) @ V.T, A, atol=1e-10 * abs(A).max())
+        assert np.allclose(V.T @ V, np.eye(n), atol=1e-12)
+    for _ in range(20):
+        R = synth.q_to_R(synth.q_exp(rng.normal(0, 2, 3)))
+        q = np.zeros(4); L.vilo_quat_from_R(abi.dptr(np.ascontiguousarray(R)), abi.dptr(q))
+        assert np.allclose(synth.q_to_R(q), R, atol=1e-14)
+        ypr = np.zeros(3); R2 = np.zeros((3, 3))
+        L.vilo_R2ypr(abi.dptr(np.ascontiguousarray(R)), abi.dptr(ypr)); L.vilo_ypr2R(abi.dptr(ypr), abi.dptr(R2))
+        assert np.allclose(R2, R, atol=1e-12)
