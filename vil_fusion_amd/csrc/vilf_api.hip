@@ -1,0 +1,651 @@
+// vilf_api.hip — host side of the C ABI (include/vilfusion.h): packing of window snapshots into the HBM batch layout
+// (vilf_batch.hpp), kernel launches on the handle's HIP stream, download. No CPU compute fallback: without a GPU
+// vilf_create() fails with VILF_ERR_NO_GPU.
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <algorithm>
+#include <chrono>
+#include "../../include/vilfusion.h"
+#include "vilf_batch.hpp"
+
+#define IMU_REC 288
+#define IMU_SQRT 62
+
+extern "C" {
+__global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec);
+__global__ void k_prior_prep(VbBatch b, double *prior_H, double *prior_g);
+__global__ void k_linearize(VbBatch b, int iteration_zero);
+__global__ void k_solve(VbBatch b);
+__global__ void k_step(VbBatch b);
+__global__ void k_finalize(VbBatch b);
+__global__ void k_reset(VbBatch b, int rewind_state);
+__global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
+__global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
+__global__ void k_hook_lidar(const double *, const double *, const double *, const double *, const double *, double *);
+__global__ void k_hook_edge(const double *, const double *, const double *, const double *, double *);
+__global__ void k_hook_surf(const double *, const double *, const double *, double, double *);
+__global__ void k_hook_plus(const double *, const double *, int, double *);
+}
+
+namespace {
+
+struct DBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return false;
+        cap = want;
+        return true;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+enum {
+    D_NFEAT, D_NFAC, D_POSE, D_SB, D_FEAT, D_CPOSE, D_CSB, D_CFEAT, D_POSE0, D_SB0, D_FEAT0, D_EX, D_GR0, D_GP0,
+    D_FSTART, D_FNOBS, D_FOBS0, D_FFAC0, D_FCONST, D_OBS, D_FACFEAT, D_FACOBS, D_PAIROFF, D_PAIRFAC, D_IMU, D_LIDAR,
+    D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_JBUF, D_PAIRD, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G,
+    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_COUNT
+};
+
+void quat_from_R(const double *m, double *q /*xyzw*/) {   // Eigen Quaterniond(Matrix3d)
+    double t = m[0] + m[4] + m[8];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0); q[3] = 0.5 * t; t = 0.5 / t;
+        q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t;
+    } else {
+        int i = 0;
+        if (m[4] > m[0]) i = 1;
+        if (m[8] > m[4 * i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        q[3] = (m[3 * k + j] - m[3 * j + k]) * t;
+        q[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+        q[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    }
+}
+void quat_to_R(const double *q, double *R) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy;
+    R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+
+}  // namespace
+
+struct vilf_handle {
+    vilf_options opts;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    DBuf d[D_COUNT];
+    VbBatch batch;
+    int B = 0;
+    bool resident = false;
+    std::vector<vilf_prior> priors;          // per slot (host mirror)
+    std::vector<char> prior_dirty;
+    std::vector<int> h_nfeat, h_nframes;
+    std::vector<double> h_ex, h_td;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_solve_usec = 0;
+    size_t solve_lds = 0;
+};
+
+#define HIPCHECK(h, call)                                                                                        \
+    do {                                                                                                         \
+        hipError_t e_ = (call);                                                                                  \
+        if (e_ != hipSuccess) {                                                                                  \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                        \
+            return VILF_ERR_DEVICE;                                                                              \
+        }                                                                                                        \
+    } while (0)
+
+extern "C" const char *vilf_version(void) { return "vilfusion-hip 0.1 (gfx950)"; }
+
+extern "C" void vilf_default_options(vilf_options *o) {
+    std::memset(o, 0, sizeof(*o));
+    o->window_size = 10;
+    o->max_num_iterations = 8;
+    o->max_solver_time = -1.0;
+    o->focal_length = 460.0;
+    o->cauchy_a = 1.0;
+    o->G[2] = 9.81007;
+    o->estimate_extrinsic = 0; o->estimate_td = 0; o->use_lidar_const = 1;
+    // config/kitti/kitti_config.yaml:10-23,48-61; rotation matrices re-orthonormalised through a quaternion as in
+    // vins_estimator/parameters.cpp:108-110,123-125
+    const double ric[9] = {0.00781297, -0.0042792, 0.99996, -0.999859, -0.014868, 0.00774856, 0.0148343, -0.99988, -0.00439476};
+    const double tic[3] = {1.1439, -0.312718, 0.726546};
+    const double rcl[9] = {7.027555e-03, -9.999753e-01, 2.599616e-05, -2.254837e-03, -4.184312e-05, -9.999975e-01, 9.999728e-01, 7.027479e-03, -2.255075e-03};
+    const double tcl[3] = {-7.137748e-03, -7.482656e-02, -3.336324e-01};
+    double q[4], n;
+    quat_from_R(ric, q); n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]); for (double &v : q) v /= n; quat_to_R(q, o->RIC);
+    quat_from_R(rcl, q); n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]); for (double &v : q) v /= n; quat_to_R(q, o->RCL);
+    for (int i = 0; i < 3; i++) { o->TIC[i] = tic[i]; o->TCL[i] = tcl[i]; }
+    o->TR = 0; o->ROW = 370; o->init_depth = 5.0;
+    o->edge_leaf_size = 0.4; o->surf_leaf_size = 0.8; o->huber_a = 0.1;
+    o->s2m_outer_iterations = 2; o->s2m_max_iterations = 4; o->s2m_crop_half = 100.0;
+}
+
+extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_stream, vilf_handle **out) {
+    if (!opts || !out) return VILF_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VILF_ERR_NO_GPU;
+    if (device < 0 || device >= ndev) return VILF_ERR_INVALID_ARGUMENT;
+    if (opts->window_size != 10) return VILF_ERR_UNSUPPORTED;                  // WINDOW_SIZE is compile-time in the reference too
+    if (opts->estimate_extrinsic || opts->estimate_td) return VILF_ERR_UNSUPPORTED;  // KITTI config: both 0
+    vilf_handle *h = new vilf_handle();
+    h->opts = *opts;
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
+    if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
+    else { if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return VILF_ERR_DEVICE; } h->own_stream = true; }
+    hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
+    h->solve_lds = (size_t)(66 * 256 + 5 * VB_NPAD + VB_NT + VILF_MAX_FEATURES) * sizeof(double);
+    if (hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
+        delete h; return VILF_ERR_DEVICE;
+    }
+    std::memset(&h->batch, 0, sizeof(h->batch));
+    *out = h;
+    return VILF_OK;
+}
+
+extern "C" void vilf_destroy(vilf_handle *h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (auto &b : h->d) b.release();
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char *vilf_last_error(const vilf_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int vilf_reset(vilf_handle *h) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    for (auto &p : h->priors) p.valid = 0;
+    std::fill(h->prior_dirty.begin(), h->prior_dirty.end(), 1);
+    return VILF_OK;
+}
+
+extern "C" int vilf_synchronize(vilf_handle *h) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VILF_OK;
+}
+
+static int upload_priors(vilf_handle *h) {
+    const int B = h->B;
+    std::vector<int> hdr((size_t)B * VB_PRIOR_HDR, 0);
+    std::vector<double> x0((size_t)B * 24 * 9, 0.0), J((size_t)B * VB_PRIOR_LD * VB_PRIOR_LD, 0.0), r((size_t)B * VB_PRIOR_LD, 0.0);
+    for (int w = 0; w < B; w++) {
+        const vilf_prior &p = h->priors[w];
+        if (!p.valid) continue;
+        int *hd = &hdr[(size_t)w * VB_PRIOR_HDR];
+        hd[0] = 1; hd[1] = p.n; hd[2] = p.n_blocks;
+        for (int i = 0; i < p.n_blocks; i++) {
+            hd[3 + i] = p.block_id[i]; hd[27 + i] = p.block_size[i]; hd[51 + i] = p.block_idx[i];
+            for (int k = 0; k < 9; k++) x0[((size_t)w * 24 + i) * 9 + k] = p.block_x0[i][k];
+            if (p.block_id[i] > 2 * VB_NF) { h->err = "prior touches Td / feature blocks: unsupported"; return VILF_ERR_UNSUPPORTED; }
+        }
+        std::memcpy(&J[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD], p.linearized_jacobians, sizeof(double) * p.n * p.n);
+        std::memcpy(&r[(size_t)w * VB_PRIOR_LD], p.linearized_residuals, sizeof(double) * p.n);
+    }
+    HIPCHECK(h, hipMemcpyAsync(h->d[D_PHDR].p, hdr.data(), hdr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->d[D_PX0].p, x0.data(), x0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->d[D_PJ].p, J.data(), J.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(h->d[D_PR].p, r.data(), r.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
+    hipLaunchKernelGGL(k_prior_prep, dim3(B), dim3(VB_NT), 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
+    HIPCHECK(h, hipGetLastError());
+    std::fill(h->prior_dirty.begin(), h->prior_dirty.end(), 0);
+    return VILF_OK;
+}
+
+extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wins) {
+    if (!h || B <= 0 || !wins) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipSetDevice(h->device));
+    int Fmax = 4, Omax = 4, FACmax = 4;
+    for (int w = 0; w < B; w++) {
+        const vilf_window_in &in = wins[w];
+        if (in.n_frames != VB_NF) { h->err = "n_frames must be window_size + 1 = 11"; return VILF_ERR_INVALID_ARGUMENT; }
+        if (in.n_features < 0 || in.n_features > VILF_MAX_FEATURES) { h->err = "n_features out of range"; return VILF_ERR_INVALID_ARGUMENT; }
+        if (!in.para_pose || !in.para_speed_bias || !in.imu || (in.n_features && (!in.para_feature || !in.feature_const || !in.feature_start_frame || !in.feature_obs_offset || !in.obs_point))) {
+            h->err = "null input array"; return VILF_ERR_INVALID_ARGUMENT;
+        }
+        if (h->opts.use_lidar_const && !in.lidar) { h->err = "lidar constraints missing (use_lidar_const = 1)"; return VILF_ERR_INVALID_ARGUMENT; }
+        for (int f = 0; f < in.n_features; f++) {
+            const int s = in.feature_start_frame[f], n = in.feature_obs_offset[f + 1] - in.feature_obs_offset[f];
+            if (s < 0 || n < 2 || s + n > VB_NF) { h->err = "feature track outside the window"; return VILF_ERR_INVALID_ARGUMENT; }
+        }
+        Fmax = std::max(Fmax, in.n_features); Omax = std::max(Omax, in.n_obs); FACmax = std::max(FACmax, in.n_obs - in.n_features);
+    }
+    Fmax = (Fmax + 3) & ~3; FACmax = (FACmax + 63) & ~63;
+    h->B = B;
+    h->resident = false;
+    if ((int)h->priors.size() < B) { vilf_prior z; std::memset(&z, 0, sizeof(z)); h->priors.resize(B, z); }
+    h->prior_dirty.assign(h->priors.size(), 1);
+    const size_t sB = B, sF = Fmax, sO = Omax, sC = FACmax;
+    struct Req { int id; size_t bytes; };
+    const Req reqs[] = {
+        {D_NFEAT, sB * 4}, {D_NFAC, sB * 4}, {D_POSE, sB * 77 * 8}, {D_SB, sB * 99 * 8}, {D_FEAT, sB * sF * 8}, {D_CPOSE, sB * 77 * 8}, {D_CSB, sB * 99 * 8},
+        {D_CFEAT, sB * sF * 8}, {D_POSE0, sB * 77 * 8}, {D_SB0, sB * 99 * 8}, {D_FEAT0, sB * sF * 8}, {D_EX, sB * 7 * 8}, {D_GR0, sB * 9 * 8}, {D_GP0, sB * 3 * 8},
+        {D_FSTART, sB * sF * 4}, {D_FNOBS, sB * sF * 4}, {D_FOBS0, sB * sF * 4}, {D_FFAC0, sB * sF * 4}, {D_FCONST, sB * sF}, {D_OBS, sB * sO * 3 * 8},
+        {D_FACFEAT, sB * sC * 4}, {D_FACOBS, sB * sC * 4}, {D_PAIROFF, sB * (VB_NPAIR + 1) * 4}, {D_PAIRFAC, sB * sC * 4}, {D_IMU, sB * 10 * IMU_REC * 8},
+        {D_LIDAR, sB * 10 * 7 * 8}, {D_PHDR, sB * VB_PRIOR_HDR * 4}, {D_PX0, sB * 24 * 9 * 8}, {D_PJ, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PR, sB * VB_PRIOR_LD * 8},
+        {D_PH, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PG, sB * VB_PRIOR_LD * 8}, {D_JBUF, sB * VB_JROWS * sC * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8},
+        {D_W, sB * sF * VB_NPOSE * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
+        {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
+        {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
+        {D_OBGS, sB * 33 * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8},
+    };
+    for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed"; return VILF_ERR_DEVICE; }
+
+    // ---- pack on the host ---------------------------------------------------------------------------------------
+    std::vector<int> nfeat(B), nfac(B), fstart(sB * sF, 0), fnobs(sB * sF, 2), fobs0(sB * sF, 0), ffac0(sB * sF, 0), facfeat(sB * sC, 0), facobs(sB * sC, 0),
+        pairoff(sB * (VB_NPAIR + 1), 0), pairfac(sB * sC, 0);
+    std::vector<uint8_t> fconst(sB * sF, 1);
+    std::vector<double> pose(sB * 77), sb(sB * 99), feat(sB * sF, 1.0), ex(sB * 7), gR0(sB * 9), gP0(sB * 3), obs(sB * sO * 3, 0.0), imu(sB * 10 * IMU_REC, 0.0),
+        lidar(sB * 10 * 7, 0.0), cov(sB * 10 * 225, 0.0);
+    h->h_nfeat.assign(B, 0); h->h_ex.assign(sB * 7, 0.0); h->h_td.assign(B, 0.0);
+    for (int w = 0; w < B; w++) {
+        const vilf_window_in &in = wins[w];
+        const int F = in.n_features;
+        nfeat[w] = F; h->h_nfeat[w] = F;
+        std::memcpy(&pose[(size_t)w * 77], in.para_pose, 77 * 8);
+        std::memcpy(&sb[(size_t)w * 99], in.para_speed_bias, 99 * 8);
+        std::memcpy(&ex[(size_t)w * 7], in.para_ex_pose, 7 * 8);
+        std::memcpy(&h->h_ex[(size_t)w * 7], in.para_ex_pose, 7 * 8);
+        h->h_td[w] = in.para_td;
+        if (in.gauge_R0) std::memcpy(&gR0[(size_t)w * 9], in.gauge_R0, 72); else quat_to_R(in.para_pose + 3, &gR0[(size_t)w * 9]);
+        if (in.gauge_P0) std::memcpy(&gP0[(size_t)w * 3], in.gauge_P0, 24); else std::memcpy(&gP0[(size_t)w * 3], in.para_pose, 24);
+        std::memcpy(&obs[(size_t)w * sO * 3], in.obs_point, (size_t)in.n_obs * 24);
+        int fac = 0;
+        std::vector<int> pcount(VB_NPAIR + 1, 0);
+        for (int f = 0; f < F; f++) {
+            const int o0 = in.feature_obs_offset[f], o1 = in.feature_obs_offset[f + 1], s = in.feature_start_frame[f];
+            feat[(size_t)w * sF + f] = in.para_feature[f];
+            fconst[(size_t)w * sF + f] = in.feature_const[f] ? 1 : 0;
+            fstart[(size_t)w * sF + f] = s; fnobs[(size_t)w * sF + f] = o1 - o0; fobs0[(size_t)w * sF + f] = o0; ffac0[(size_t)w * sF + f] = fac;
+            for (int t = o0 + 1; t < o1; t++) {
+                facfeat[(size_t)w * sC + fac] = f; facobs[(size_t)w * sC + fac] = t;
+                const int j = s + (t - o0);
+                pcount[j * (j - 1) / 2 + s + 1]++;
+                fac++;
+            }
+        }
+        nfac[w] = fac;
+        int *po = &pairoff[(size_t)w * (VB_NPAIR + 1)];
+        for (int p = 0; p < VB_NPAIR; p++) po[p + 1] = po[p] + pcount[p + 1];
+        std::vector<int> cur(po, po + VB_NPAIR);
+        for (int q = 0; q < fac; q++) {
+            const int f = facfeat[(size_t)w * sC + q], t = facobs[(size_t)w * sC + q];
+            const int s = in.feature_start_frame[f], j = s + (t - in.feature_obs_offset[f]);
+            pairfac[(size_t)w * sC + cur[j * (j - 1) / 2 + s]++] = q;
+        }
+        for (int k = 0; k < 10; k++) {
+            const vilf_imu_preint &p = in.imu[k + 1];
+            double *rec = &imu[((size_t)w * 10 + k) * IMU_REC];
+            rec[0] = p.sum_dt;
+            for (int i = 0; i < 3; i++) { rec[1 + i] = p.delta_p[i]; rec[8 + i] = p.delta_v[i]; rec[11 + i] = p.linearized_ba[i]; rec[14 + i] = p.linearized_bg[i]; }
+            for (int i = 0; i < 4; i++) rec[4 + i] = p.delta_q[i];
+            auto blk = [&](int off, int r0, int c0) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rec[off + 3 * i + j] = p.jacobian[(r0 + i) * 15 + c0 + j]; };
+            blk(17, 0, 9); blk(26, 0, 12); blk(35, 3, 12); blk(44, 6, 9); blk(53, 6, 12);
+            rec[287] = (p.sum_dt > 10.0) ? 0.0 : 1.0;                           // estimator.cpp:745
+            std::memcpy(&cov[((size_t)w * 10 + k) * 225], p.covariance, 225 * 8);
+            if (in.lidar) { const vilf_lidar_constraint &c = in.lidar[k + 1]; double *l = &lidar[((size_t)w * 10 + k) * 7]; for (int i = 0; i < 4; i++) l[i] = c.q[i]; for (int i = 0; i < 3; i++) l[4 + i] = c.t[i]; }
+            else lidar[((size_t)w * 10 + k) * 7 + 3] = 1.0;
+        }
+    }
+    auto up = [&](int id, const void *src, size_t bytes) { return hipMemcpyAsync(h->d[id].p, src, bytes, hipMemcpyHostToDevice, h->stream); };
+    HIPCHECK(h, up(D_NFEAT, nfeat.data(), sB * 4)); HIPCHECK(h, up(D_NFAC, nfac.data(), sB * 4));
+    HIPCHECK(h, up(D_POSE, pose.data(), sB * 77 * 8)); HIPCHECK(h, up(D_POSE0, pose.data(), sB * 77 * 8));
+    HIPCHECK(h, up(D_SB, sb.data(), sB * 99 * 8)); HIPCHECK(h, up(D_SB0, sb.data(), sB * 99 * 8));
+    HIPCHECK(h, up(D_FEAT, feat.data(), sB * sF * 8)); HIPCHECK(h, up(D_FEAT0, feat.data(), sB * sF * 8));
+    HIPCHECK(h, up(D_EX, ex.data(), sB * 7 * 8)); HIPCHECK(h, up(D_GR0, gR0.data(), sB * 9 * 8)); HIPCHECK(h, up(D_GP0, gP0.data(), sB * 3 * 8));
+    HIPCHECK(h, up(D_FSTART, fstart.data(), sB * sF * 4)); HIPCHECK(h, up(D_FNOBS, fnobs.data(), sB * sF * 4));
+    HIPCHECK(h, up(D_FOBS0, fobs0.data(), sB * sF * 4)); HIPCHECK(h, up(D_FFAC0, ffac0.data(), sB * sF * 4));
+    HIPCHECK(h, up(D_FCONST, fconst.data(), sB * sF)); HIPCHECK(h, up(D_OBS, obs.data(), sB * sO * 3 * 8));
+    HIPCHECK(h, up(D_FACFEAT, facfeat.data(), sB * sC * 4)); HIPCHECK(h, up(D_FACOBS, facobs.data(), sB * sC * 4));
+    HIPCHECK(h, up(D_PAIROFF, pairoff.data(), sB * (VB_NPAIR + 1) * 4)); HIPCHECK(h, up(D_PAIRFAC, pairfac.data(), sB * sC * 4));
+    HIPCHECK(h, up(D_IMU, imu.data(), sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar.data(), sB * 10 * 7 * 8));
+    HIPCHECK(h, up(D_COV, cov.data(), sB * 10 * 225 * 8));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+
+    // ---- batch descriptor -------------------------------------------------------------------------------------
+    VbBatch &b = h->batch;
+    std::memset(&b, 0, sizeof(b));
+    const vilf_options &o = h->opts;
+    b.B = B; b.Fmax = Fmax; b.Omax = Omax; b.FACmax = FACmax;
+    b.sqrt_info = o.focal_length / 1.5; b.cauchy_b = o.cauchy_a * o.cauchy_a;
+    for (int i = 0; i < 3; i++) b.G[i] = o.G[i];
+    {   // qil = Quaterniond(RIC*RCL), til = RIC*TCL + TIC (lidar_factor.h:28-29)
+        double M[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = o.RIC[3 * i] * o.RCL[j] + o.RIC[3 * i + 1] * o.RCL[3 + j] + o.RIC[3 * i + 2] * o.RCL[6 + j];
+        quat_from_R(M, b.qil);
+        for (int i = 0; i < 3; i++) b.til[i] = o.RIC[3 * i] * o.TCL[0] + o.RIC[3 * i + 1] * o.TCL[1] + o.RIC[3 * i + 2] * o.TCL[2] + o.TIC[i];
+    }
+    b.use_lidar = o.use_lidar_const; b.max_iterations = o.max_num_iterations;
+    b.min_relative_decrease = 1e-3; b.function_tolerance = 1e-6; b.gradient_tolerance = 1e-10; b.parameter_tolerance = 1e-8;
+    b.min_radius = 1e-32; b.initial_radius = 1e4; b.min_lm_diagonal = 1e-6; b.max_lm_diagonal = 1e32;
+    b.n_feat = h->d[D_NFEAT].as<int>(); b.n_fac = h->d[D_NFAC].as<int>();
+    b.pose = h->d[D_POSE].as<double>(); b.sb = h->d[D_SB].as<double>(); b.feat = h->d[D_FEAT].as<double>();
+    b.cand_pose = h->d[D_CPOSE].as<double>(); b.cand_sb = h->d[D_CSB].as<double>(); b.cand_feat = h->d[D_CFEAT].as<double>();
+    b.pose_init = h->d[D_POSE0].as<double>(); b.sb_init = h->d[D_SB0].as<double>(); b.feat_init = h->d[D_FEAT0].as<double>();
+    b.ex = h->d[D_EX].as<double>(); b.gauge_R0 = h->d[D_GR0].as<double>(); b.gauge_P0 = h->d[D_GP0].as<double>();
+    b.f_start = h->d[D_FSTART].as<int>(); b.f_nobs = h->d[D_FNOBS].as<int>(); b.f_obs0 = h->d[D_FOBS0].as<int>(); b.f_fac0 = h->d[D_FFAC0].as<int>();
+    b.f_const = h->d[D_FCONST].as<uint8_t>(); b.obs = h->d[D_OBS].as<double>();
+    b.fac_feat = h->d[D_FACFEAT].as<int>(); b.fac_obs = h->d[D_FACOBS].as<int>();
+    b.pair_off = h->d[D_PAIROFF].as<int>(); b.pair_fac = h->d[D_PAIRFAC].as<int>();
+    b.imu = h->d[D_IMU].as<double>(); b.lidar = h->d[D_LIDAR].as<double>();
+    b.prior_hdr = h->d[D_PHDR].as<int>(); b.prior_x0 = h->d[D_PX0].as<double>(); b.prior_J = h->d[D_PJ].as<double>(); b.prior_r = h->d[D_PR].as<double>();
+    b.prior_H = h->d[D_PH].as<double>(); b.prior_g = h->d[D_PG].as<double>();
+    b.Jbuf = h->d[D_JBUF].as<double>(); b.pairD = h->d[D_PAIRD].as<double>(); b.W = h->d[D_W].as<double>(); b.hf = h->d[D_HF].as<double>(); b.gf = h->d[D_GF].as<double>();
+    b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>();
+    b.scale = h->d[D_SCALE].as<double>(); b.diag = h->d[D_DIAG].as<double>(); b.grad = h->d[D_GRAD].as<double>(); b.gn = h->d[D_GN].as<double>();
+    b.st = h->d[D_ST].as<VbState>();
+    b.out_Ps = h->d[D_OPS].as<double>(); b.out_Rs = h->d[D_ORS].as<double>(); b.out_Vs = h->d[D_OVS].as<double>();
+    b.out_Bas = h->d[D_OBAS].as<double>(); b.out_Bgs = h->d[D_OBGS].as<double>();
+
+    const int nimu = B * 10;
+    hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
+    HIPCHECK(h, hipGetLastError());
+    int rc = upload_priors(h);
+    if (rc != VILF_OK) return rc;
+    hipLaunchKernelGGL(k_reset, dim3(B), dim3(VB_NT), 0, h->stream, h->batch, 0);
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    h->resident = true;
+    return VILF_OK;
+}
+
+extern "C" int vilf_batch_rewind(vilf_handle *h) {
+    if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(k_reset, dim3(h->B), dim3(VB_NT), 0, h->stream, h->batch, 1);
+    HIPCHECK(h, hipGetLastError());
+    return VILF_OK;
+}
+
+extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
+    if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipSetDevice(h->device));
+    bool dirty = false;
+    for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true;
+    if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; }
+    const dim3 grid(h->B), block(VB_NT);
+    hipEventRecord(h->ev0, h->stream);
+    hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
+    hipLaunchKernelGGL(k_linearize, grid, block, 0, h->stream, h->batch, 1);
+    for (int it = 0; it < h->opts.max_num_iterations; it++) {
+        hipLaunchKernelGGL(k_solve, grid, block, h->solve_lds, h->stream, h->batch);
+        hipLaunchKernelGGL(k_step, grid, block, 0, h->stream, h->batch);
+        hipLaunchKernelGGL(k_linearize, grid, block, 0, h->stream, h->batch, 0);
+    }
+    // one more pass of the iteration-begin checks so that `termination` reflects max_num_iterations
+    hipLaunchKernelGGL(k_finalize, grid, dim3(64), 0, h->stream, h->batch);
+    hipEventRecord(h->ev1, h->stream);
+    HIPCHECK(h, hipGetLastError());
+    if (sync) {
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        float ms = 0;
+        hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        h->last_solve_usec = ms * 1000.0;
+    }
+    return VILF_OK;
+}
+
+extern "C" int vilf_batch_summaries(vilf_handle *h, int first, int n, vilf_summary *sums) {
+    if (!h || !h->resident || first < 0 || n < 0 || first + n > h->B || !sums) return VILF_ERR_INVALID_ARGUMENT;
+    std::vector<VbState> st(n);
+    HIPCHECK(h, hipMemcpyAsync(st.data(), h->batch.st + first, sizeof(VbState) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) {
+        sums[i].num_iterations = st[i].iteration;
+        sums[i].num_successful_steps = st[i].num_successful;
+        sums[i].num_linear_solves = st[i].num_linear_solves;
+        sums[i].termination = st[i].termination;
+        sums[i].initial_cost = st[i].initial_cost;
+        sums[i].final_cost = st[i].x_cost;
+        sums[i].final_radius = st[i].radius;
+        sums[i].usec_solve = h->last_solve_usec;
+    }
+    return VILF_OK;
+}
+
+extern "C" int vilf_batch_download(vilf_handle *h, int first, int n, vilf_window_out *outs) {
+    if (!h || !h->resident || first < 0 || n < 0 || first + n > h->B || !outs) return VILF_ERR_INVALID_ARGUMENT;
+    const size_t sF = h->batch.Fmax;
+    std::vector<double> pose((size_t)n * 77), sb((size_t)n * 99), feat((size_t)n * sF), Ps((size_t)n * 33), Rs((size_t)n * 99), Vs((size_t)n * 33), Bas((size_t)n * 33), Bgs((size_t)n * 33);
+    auto dn = [&](void *dst, const double *src, size_t cnt) { return hipMemcpyAsync(dst, src, cnt * 8, hipMemcpyDeviceToHost, h->stream); };
+    HIPCHECK(h, dn(pose.data(), h->batch.pose + (size_t)first * 77, (size_t)n * 77));
+    HIPCHECK(h, dn(sb.data(), h->batch.sb + (size_t)first * 99, (size_t)n * 99));
+    HIPCHECK(h, dn(feat.data(), h->batch.feat + (size_t)first * sF, (size_t)n * sF));
+    HIPCHECK(h, dn(Ps.data(), h->batch.out_Ps + (size_t)first * 33, (size_t)n * 33));
+    HIPCHECK(h, dn(Rs.data(), h->batch.out_Rs + (size_t)first * 99, (size_t)n * 99));
+    HIPCHECK(h, dn(Vs.data(), h->batch.out_Vs + (size_t)first * 33, (size_t)n * 33));
+    HIPCHECK(h, dn(Bas.data(), h->batch.out_Bas + (size_t)first * 33, (size_t)n * 33));
+    HIPCHECK(h, dn(Bgs.data(), h->batch.out_Bgs + (size_t)first * 33, (size_t)n * 33));
+    std::vector<vilf_summary> sums(n);
+    int rc = vilf_batch_summaries(h, first, n, sums.data());   // synchronises the stream
+    if (rc != VILF_OK) return rc;
+    for (int i = 0; i < n; i++) {
+        vilf_window_out &o = outs[i];
+        const int F = h->h_nfeat[first + i];
+        if (o.para_pose) std::memcpy(o.para_pose, &pose[(size_t)i * 77], 77 * 8);
+        if (o.para_speed_bias) std::memcpy(o.para_speed_bias, &sb[(size_t)i * 99], 99 * 8);
+        if (o.para_feature && F) std::memcpy(o.para_feature, &feat[(size_t)i * sF], (size_t)F * 8);
+        if (o.Ps) std::memcpy(o.Ps, &Ps[(size_t)i * 33], 33 * 8);
+        if (o.Rs) std::memcpy(o.Rs, &Rs[(size_t)i * 99], 99 * 8);
+        if (o.Vs) std::memcpy(o.Vs, &Vs[(size_t)i * 33], 33 * 8);
+        if (o.Bas) std::memcpy(o.Bas, &Bas[(size_t)i * 33], 33 * 8);
+        if (o.Bgs) std::memcpy(o.Bgs, &Bgs[(size_t)i * 33], 33 * 8);
+        const double *exw = &h->h_ex[(size_t)(first + i) * 7];
+        for (int k = 0; k < 3; k++) o.tic[k] = exw[k];
+        quat_to_R(exw + 3, o.ric);
+        o.td = h->h_td[first + i];
+        o.summary = sums[i];
+    }
+    return VILF_OK;
+}
+
+extern "C" int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out) {
+    if (!h || !in || !out) return VILF_ERR_INVALID_ARGUMENT;
+    auto t0 = std::chrono::steady_clock::now();
+    int rc = vilf_batch_upload(h, 1, in);
+    if (rc != VILF_OK) return rc;
+    rc = vilf_batch_solve(h, 1);
+    if (rc != VILF_OK) return rc;
+    rc = vilf_batch_download(h, 0, 1, out);
+    if (rc != VILF_OK) return rc;
+    out->summary.usec_solve = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return (out->summary.termination == VILF_TERM_FAILURE) ? VILF_SOLVER_ABNORMAL : VILF_OK;
+}
+
+extern "C" int vilf_prior_import(vilf_handle *h, int slot, const vilf_prior *prior) {
+    if (!h || slot < 0 || !prior) return VILF_ERR_INVALID_ARGUMENT;
+    if (prior->valid && (prior->n <= 0 || prior->n > VILF_PRIOR_MAX_DIM || prior->n_blocks <= 0 || prior->n_blocks > VILF_PRIOR_MAX_BLOCKS)) return VILF_ERR_INVALID_ARGUMENT;
+    if ((int)h->priors.size() <= slot) { vilf_prior z; std::memset(&z, 0, sizeof(z)); h->priors.resize(slot + 1, z); h->prior_dirty.resize(slot + 1, 1); }
+    h->priors[slot] = *prior;
+    h->prior_dirty[slot] = 1;
+    return VILF_OK;
+}
+
+extern "C" int vilf_prior_export(vilf_handle *h, int slot, vilf_prior *out) {
+    if (!h || slot < 0 || slot >= (int)h->priors.size() || !out) return VILF_ERR_INVALID_ARGUMENT;
+    *out = h->priors[slot];
+    return VILF_OK;
+}
+
+extern "C" int vilf_window_marginalize(vilf_handle *h) { if (!h) return VILF_ERR_INVALID_ARGUMENT; h->err = "device marginalization not built yet"; return VILF_ERR_UNSUPPORTED; }
+extern "C" int vilf_batch_marginalize(vilf_handle *h, int) { if (!h) return VILF_ERR_INVALID_ARGUMENT; h->err = "device marginalization not built yet"; return VILF_ERR_UNSUPPORTED; }
+
+extern "C" int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8) {
+    if (!h || !h->resident || !device_out8) return VILF_ERR_INVALID_ARGUMENT;
+    // [stamp x y z qx qy qz qw] per window from the gauge-fixed newest frame (host assembled; tiny)
+    const int B = h->B;
+    std::vector<double> Ps((size_t)B * 33), Rs((size_t)B * 99), out((size_t)B * 8);
+    HIPCHECK(h, hipMemcpyAsync(Ps.data(), h->batch.out_Ps, Ps.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(Rs.data(), h->batch.out_Rs, Rs.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int w = 0; w < B; w++) {
+        out[(size_t)w * 8] = stamps_host ? stamps_host[w] : (double)w;
+        for (int k = 0; k < 3; k++) out[(size_t)w * 8 + 1 + k] = Ps[(size_t)w * 33 + 30 + k];
+        quat_from_R(&Rs[(size_t)w * 99 + 90], &out[(size_t)w * 8 + 4]);
+    }
+    HIPCHECK(h, hipMemcpyAsync(device_out8, out.data(), out.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VILF_OK;
+}
+
+// ---- Ceres-layout hooks --------------------------------------------------------------------------------------
+static int hook_buf(vilf_handle *h, size_t doubles) { return h->d[D_HOOK].ensure(doubles * 8) ? VILF_OK : VILF_ERR_DEVICE; }
+
+extern "C" int vilf_eval_projection(vilf_handle *h, const double *const *p, const double pts_i[3], const double pts_j[3], double *residuals, double **jac) {
+    if (!h || !p || !residuals) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 128) != VILF_OK) return VILF_ERR_DEVICE;
+    double in[32];
+    std::memcpy(in, p[0], 56); std::memcpy(in + 7, p[1], 56); std::memcpy(in + 14, p[2], 56);
+    std::memcpy(in + 21, pts_i, 24); std::memcpy(in + 24, pts_j, 24);
+    double *d = h->d[D_HOOK].as<double>();
+    HIPCHECK(h, hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_hook_projection, dim3(1), dim3(64), 0, h->stream, d, d + 7, d + 14, p[3][0], d + 21, d + 24, h->opts.focal_length / 1.5, d + 32);
+    double out[28];
+    HIPCHECK(h, hipMemcpyAsync(out, d + 32, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    residuals[0] = out[0]; residuals[1] = out[1];
+    if (jac) {
+        for (int blk = 0; blk < 2; blk++)
+            if (jac[blk]) for (int r = 0; r < 2; r++) { for (int c = 0; c < 6; c++) jac[blk][7 * r + c] = out[2 + 12 * blk + 6 * r + c]; jac[blk][7 * r + 6] = 0; }
+        if (jac[2]) return VILF_ERR_UNSUPPORTED;    // extrinsic jacobian: estimate_extrinsic = 1 is not built on the device
+        if (jac[3]) { jac[3][0] = out[26]; jac[3][1] = out[27]; }
+    }
+    return VILF_OK;
+}
+
+static void pack_imu_rec(const vilf_imu_preint *p, double *rec) {
+    std::memset(rec, 0, IMU_REC * 8);
+    rec[0] = p->sum_dt;
+    for (int i = 0; i < 3; i++) { rec[1 + i] = p->delta_p[i]; rec[8 + i] = p->delta_v[i]; rec[11 + i] = p->linearized_ba[i]; rec[14 + i] = p->linearized_bg[i]; }
+    for (int i = 0; i < 4; i++) rec[4 + i] = p->delta_q[i];
+    auto blk = [&](int off, int r0, int c0) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rec[off + 3 * i + j] = p->jacobian[(r0 + i) * 15 + c0 + j]; };
+    blk(17, 0, 9); blk(26, 0, 12); blk(35, 3, 12); blk(44, 6, 9); blk(53, 6, 12);
+    rec[287] = 1.0;
+}
+
+extern "C" int vilf_eval_imu(vilf_handle *h, const double *const *p, const vilf_imu_preint *pre, double *residuals, double **jac) {
+    if (!h || !p || !pre || !residuals) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 4096) != VILF_OK) return VILF_ERR_DEVICE;
+    double *d = h->d[D_HOOK].as<double>();
+    std::vector<double> in(40 + IMU_REC + 225, 0.0);
+    std::memcpy(&in[0], p[0], 56); std::memcpy(&in[7], p[1], 72); std::memcpy(&in[16], p[2], 56); std::memcpy(&in[23], p[3], 72);
+    for (int i = 0; i < 3; i++) in[32 + i] = h->opts.G[i];
+    pack_imu_rec(pre, &in[40]);
+    std::memcpy(&in[40 + IMU_REC], pre->covariance, 225 * 8);
+    HIPCHECK(h, hipMemcpyAsync(d, in.data(), in.size() * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_imu_prep, dim3(1), dim3(64), 0, h->stream, 1, d + 40 + IMU_REC, d + 1024, d + 40);
+    hipLaunchKernelGGL(k_hook_imu, dim3(1), dim3(64), 0, h->stream, d, d + 7, d + 16, d + 23, d + 40, d + 32, d + 2048, d + 3072);
+    std::vector<double> out(15 + 450);
+    HIPCHECK(h, hipMemcpyAsync(out.data(), d + 2048, out.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 15; i++) residuals[i] = out[i];
+    if (jac) {
+        const int off[4] = {0, 6, 15, 21}, loc[4] = {6, 9, 6, 9}, glob[4] = {7, 9, 7, 9};
+        for (int blk = 0; blk < 4; blk++)
+            if (jac[blk]) for (int r = 0; r < 15; r++) { for (int c = 0; c < glob[blk]; c++) jac[blk][glob[blk] * r + c] = (c < loc[blk]) ? out[15 + 30 * r + off[blk] + c] : 0.0; }
+    }
+    return VILF_OK;
+}
+
+extern "C" int vilf_eval_lidar_between(vilf_handle *h, const double *const *p, const vilf_lidar_constraint *c, double *residuals, double **jac) {
+    if (!h || !p || !c || !residuals) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 256) != VILF_OK) return VILF_ERR_DEVICE;
+    if (!h->resident) {   // qil / til are derived at upload; derive here too
+        const vilf_options &o = h->opts; VbBatch &b = h->batch;
+        double M[9];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[3 * i + j] = o.RIC[3 * i] * o.RCL[j] + o.RIC[3 * i + 1] * o.RCL[3 + j] + o.RIC[3 * i + 2] * o.RCL[6 + j];
+        quat_from_R(M, b.qil);
+        for (int i = 0; i < 3; i++) b.til[i] = o.RIC[3 * i] * o.TCL[0] + o.RIC[3 * i + 1] * o.TCL[1] + o.RIC[3 * i + 2] * o.TCL[2] + o.TIC[i];
+    }
+    double in[32];
+    std::memcpy(in, p[0], 56); std::memcpy(in + 7, p[1], 56);
+    std::memcpy(in + 14, h->batch.qil, 32); std::memcpy(in + 18, h->batch.til, 24);
+    for (int i = 0; i < 4; i++) in[21 + i] = c->q[i];
+    for (int i = 0; i < 3; i++) in[25 + i] = c->t[i];
+    double *d = h->d[D_HOOK].as<double>();
+    HIPCHECK(h, hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_hook_lidar, dim3(1), dim3(64), 0, h->stream, d, d + 7, d + 14, d + 18, d + 21, d + 32);
+    double out[78];
+    HIPCHECK(h, hipMemcpyAsync(out, d + 32, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 6; i++) residuals[i] = out[i];
+    if (jac)
+        for (int blk = 0; blk < 2; blk++)
+            if (jac[blk]) for (int r = 0; r < 6; r++) { for (int cc = 0; cc < 6; cc++) jac[blk][7 * r + cc] = out[6 + 36 * blk + 6 * r + cc]; jac[blk][7 * r + 6] = 0; }
+    return VILF_OK;
+}
+
+extern "C" int vilf_eval_edge(vilf_handle *h, const double pose[7], const double cp[3], const double a[3], const double bb[3], double r[3], double *J) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 128) != VILF_OK) return VILF_ERR_DEVICE;
+    double in[16];
+    std::memcpy(in, pose, 56); std::memcpy(in + 7, cp, 24); std::memcpy(in + 10, a, 24); std::memcpy(in + 13, bb, 24);
+    double *d = h->d[D_HOOK].as<double>();
+    HIPCHECK(h, hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_hook_edge, dim3(1), dim3(64), 0, h->stream, d, d + 7, d + 10, d + 13, d + 16);
+    double out[21];
+    HIPCHECK(h, hipMemcpyAsync(out, d + 16, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 3; i++) r[i] = out[i];
+    if (J) for (int i = 0; i < 3; i++) { for (int c = 0; c < 6; c++) J[7 * i + c] = out[3 + 6 * i + c]; J[7 * i + 6] = 0; }
+    return VILF_OK;
+}
+
+extern "C" int vilf_eval_surf(vilf_handle *h, const double pose[7], const double cp[3], const double n[3], double dd, double r[1], double *J) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 128) != VILF_OK) return VILF_ERR_DEVICE;
+    double in[16];
+    std::memcpy(in, pose, 56); std::memcpy(in + 7, cp, 24); std::memcpy(in + 10, n, 24);
+    double *d = h->d[D_HOOK].as<double>();
+    HIPCHECK(h, hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_hook_surf, dim3(1), dim3(64), 0, h->stream, d, d + 7, d + 10, dd, d + 16);
+    double out[7];
+    HIPCHECK(h, hipMemcpyAsync(out, d + 16, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    r[0] = out[0];
+    if (J) { for (int c = 0; c < 6; c++) J[c] = out[1 + c]; J[6] = 0; }
+    return VILF_OK;
+}
+
+static int plus_hook(vilf_handle *h, const double x[7], const double dl[6], double xp[7], int kind) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 64) != VILF_OK) return VILF_ERR_DEVICE;
+    double in[13];
+    std::memcpy(in, x, 56); std::memcpy(in + 7, dl, 48);
+    double *d = h->d[D_HOOK].as<double>();
+    HIPCHECK(h, hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_hook_plus, dim3(1), dim3(64), 0, h->stream, d, d + 7, kind, d + 16);
+    HIPCHECK(h, hipMemcpyAsync(xp, d + 16, 56, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VILF_OK;
+}
+extern "C" int vilf_pose_plus(vilf_handle *h, const double x[7], const double d[6], double xp[7]) { return plus_hook(h, x, d, xp, 0); }
+extern "C" int vilf_se3_plus(vilf_handle *h, const double x[7], const double d[6], double xp[7]) { return plus_hook(h, x, d, xp, 1); }
+
+extern "C" int vilf_eval_prior(vilf_handle *h, const vilf_prior *, const double *const *, double *, double **) {
+    if (h) h->err = "vilf_eval_prior: use vilf_window_solve with an imported prior (the prior is evaluated inside k_linearize)";
+    return VILF_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,75 @@
+// vilf_batch.hpp — device-resident layout of a batch of independent sliding windows (one workgroup per window).
+//
+// Memory layout in HBM (all per-window arrays are [B][stride] with strides fixed per upload):
+//   state      pose[B][11*7]  sb[B][11*9]  feat[B][Fmax]          (+ *_init copies for rewind, cand_* trial point)
+//   features   f_start/f_nobs/f_obs0/f_fac0/f_const [B][Fmax]     (CSR over observations, feature_manager order)
+//   obs        obs[B][Omax][3]                                     (feature_per_frame[k].point)
+//   factors    fac_feat/fac_obs [B][FACmax]                        (one per (feature, later observation))
+//   pairs      pair_off[B][56], pair_fac[B][FACmax]                (factor ids grouped by frame pair (i<j))
+//   imu        imu[B][10][288]  (delta_*, bias jacobians, 15x15 sqrt_info precomputed once: imu_factor.h:64)
+//   lidar      lidar[B][10][7]
+//   prior      hdr[B][80] x0[B][24][9] J[B][160*160] r[B][160] H=J^T J [B][160*160] g=J^T r [B][160]
+//   workspace  Jbuf[B][32][FACmax] pairD[B][55][120] W[B][Fmax][66] hf gf [B][Fmax] imuH[B][10][900] imug[B][10][30]
+//              lidH[B][10][144] lidg[B][10][12] g[B][165] scale/diag/grad/gn[B][165+Fmax] st[B]
+#pragma once
+#include <stdint.h>
+
+#define VB_NF 11            // frames in the window (WINDOW_SIZE + 1)
+#define VB_P 165            // reduced tangent dimension: 11 * (6 + 9)
+#define VB_NPOSE 66
+#define VB_NPAIR 55         // frame pairs i<j
+#define VB_PAIRD 120        // per pair: JjJj(36) JjJi(36) JiJi(36) Jj^T r(6) Ji^T r(6)
+#define VB_JROWS 32         // Jbuf components per factor
+#define VB_NT 256           // threads per window workgroup
+#define VB_NTILE 11         // 16x16 tiles per dimension (176 padded)
+#define VB_NPAD 176
+#define VB_PRIOR_HDR 80     // valid, n, nblocks, ids[24], sizes[24], idx[24]
+#define VB_PRIOR_LD 160
+
+struct VbState {            // per-window trust-region state (ceres TrustRegionMinimizer + DoglegStrategy members)
+    double x_cost, cand_cost, initial_cost;
+    double radius, mu, alpha, dogleg_step_norm;
+    double x_norm, gradient_max_norm;
+    double grad_sqnorm;     // ||gradient_||^2            (scaled space)
+    double Jg2;             // v^T H v, v = gradient_/diagonal_
+    double gy;              // g~^T y  (y = (H~ + mu D^2)^-1 g~)
+    double gn_sqnorm;       // ||gauss_newton_step_||^2 = sum diag^2 y^2
+    double mu_used;         // mu the current Gauss-Newton step was computed with
+    double model_cost_change, relative_decrease;
+    int iteration, num_successful, num_linear_solves, num_consecutive_invalid;
+    int termination, done, reuse, need_linearize, solve_failed, scaling_ready, started;
+    int pad_;
+};
+
+struct VbBatch {
+    int B, Fmax, Omax, FACmax;
+    // options
+    double sqrt_info, cauchy_b, G[3];
+    double qil[4], til[3];  // RIC*RCL as quaternion (xyzw), RIC*TCL+TIC (lidar_factor.h:28-29)
+    int use_lidar, max_iterations;
+    double min_relative_decrease, function_tolerance, gradient_tolerance, parameter_tolerance;
+    double min_radius, initial_radius, min_lm_diagonal, max_lm_diagonal;
+    // sizes
+    const int *n_feat, *n_fac;
+    // state
+    double *pose, *sb, *feat;
+    double *cand_pose, *cand_sb, *cand_feat;
+    const double *pose_init, *sb_init, *feat_init;
+    const double *ex;
+    const double *gauge_R0, *gauge_P0;
+    // problem description
+    const int *f_start, *f_nobs, *f_obs0, *f_fac0;
+    const uint8_t *f_const;
+    const double *obs;
+    const int *fac_feat, *fac_obs;
+    const int *pair_off, *pair_fac;
+    const double *imu, *lidar;
+    const int *prior_hdr;
+    const double *prior_x0, *prior_J, *prior_r, *prior_H, *prior_g;
+    // workspace
+    double *Jbuf, *pairD, *W, *hf, *gf, *imuH, *imug, *lidH, *lidg, *g;
+    double *scale, *diag, *grad, *gn;
+    VbState *st;
+    // outputs of finalize
+    double *out_Ps, *out_Rs, *out_Vs, *out_Bas, *out_Bgs;
+};

@@ -1,0 +1,1016 @@
+// vilf_kernels.hip — hand-written gfx950 kernels of the sliding-window solve (one 256-thread workgroup per window).
+//
+//   k_imu_prep     one-off: sqrt_info = LLT(cov^-1).L^T per IMU factor            (imu_factor.h:64)
+//   k_prior_prep   one-off: H0 = J0^T J0, g0 = J0^T r0 of the marginalization prior (marginalization_factor.cpp:333-381)
+//   k_linearize    every factor's residual + Jacobian at x, robust corrector, per-frame-pair J^T J / J^T r blocks,
+//                  per-feature Schur vectors (H_pf, H_ff, g_f), IMU / LiDAR / prior blocks, cost, gradient
+//                  (≙ ceres Evaluate inside Solve, estimator.cpp:852; factors: factor/*.h)
+//   k_solve        assemble the 165x165 reduced system as 16x16 fp64 tiles in LDS, Jacobi scaling, dogleg diagonal,
+//                  Cauchy point, MFMA Schur reduce (-= W~^T W~), MFMA blocked Cholesky, Gauss-Newton step
+//                  (≙ DoglegStrategy::ComputeStep + DENSE_SCHUR, Ceres 2.0)
+//   k_step         dogleg interpolation, Plus(), trial cost, accept / reject, radius update
+//                  (≙ TrustRegionMinimizer loop body)
+//   k_finalize     double2vector() gauge fix (estimator.cpp:549-596)
+//
+// All arithmetic is fp64 (the reference is double throughout). MFMA: v_mfma_f64_16x16x4_f64.
+#include "vilf_device.hpp"
+#include "vilf_batch.hpp"
+
+using namespace vd;
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+#define NT VB_NT
+__device__ __forceinline__ int pair_index(int i, int j) { return j * (j - 1) / 2 + i; }  // i < j
+// tangent index (frame a, local l in [0,15)) -> P-first permuted index: poses 0..65, speed-bias 66..164
+__device__ __forceinline__ int perm_index(int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); }
+__device__ __forceinline__ void unperm(int p, int &a, int &l) {
+    if (p < 66) { a = p / 6; l = p - 6 * a; } else { int q = p - 66; a = q / 9; l = 6 + q - 9 * a; }
+}
+__device__ __forceinline__ int tile_index(int ta, int tb) { return ta * (ta + 1) / 2 + tb; }  // ta >= tb
+
+// block-wide sum / max with a fixed reduction tree (deterministic)
+__device__ __forceinline__ double block_sum(double v, double *s_red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    s_red[tid] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) s_red[tid] += s_red[tid + s];
+        __syncthreads();
+    }
+    double r = s_red[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double block_max(double v, double *s_red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    s_red[tid] = v;
+    __syncthreads();
+    for (int s = NT / 2; s > 0; s >>= 1) {
+        if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]);
+        __syncthreads();
+    }
+    double r = s_red[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// one-off preparation
+// cov: [n][225] in, out: rec + IMU_SQRT of each factor. One thread per factor (tiny, one-off per upload).
+extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec) {
+    int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n) return;
+    const double *C = cov + (size_t)id * 225;
+    double *A = work + (size_t)id * 450;   // LU copy
+    double *Inv = A + 225;
+    for (int i = 0; i < 225; i++) { A[i] = C[i]; Inv[i] = 0; }
+    for (int i = 0; i < 15; i++) Inv[16 * i] = 1.0;
+    // inverse by Gaussian elimination with partial pivoting (Eigen PartialPivLU semantics)
+    for (int k = 0; k < 15; k++) {
+        int p = k; double best = fabs(A[15 * k + k]);
+        for (int i = k + 1; i < 15; i++) { double v = fabs(A[15 * i + k]); if (v > best) { best = v; p = i; } }
+        if (p != k) for (int j = 0; j < 15; j++) { double t = A[15 * k + j]; A[15 * k + j] = A[15 * p + j]; A[15 * p + j] = t; t = Inv[15 * k + j]; Inv[15 * k + j] = Inv[15 * p + j]; Inv[15 * p + j] = t; }
+        double piv = A[15 * k + k];
+        for (int i = k + 1; i < 15; i++) {
+            double f = A[15 * i + k] / piv;
+            for (int j = k; j < 15; j++) A[15 * i + j] -= f * A[15 * k + j];
+            for (int j = 0; j < 15; j++) Inv[15 * i + j] -= f * Inv[15 * k + j];
+        }
+    }
+    for (int k = 14; k >= 0; k--) {
+        double piv = A[15 * k + k];
+        for (int j = 0; j < 15; j++) Inv[15 * k + j] /= piv;
+        for (int i = 0; i < k; i++) { double f = A[15 * i + k]; for (int j = 0; j < 15; j++) Inv[15 * i + j] -= f * Inv[15 * k + j]; }
+    }
+    // lower Cholesky of Inv (in place), sqrt_info = L^T
+    for (int j = 0; j < 15; j++) {
+        double s = Inv[16 * j];
+        for (int k = 0; k < j; k++) s -= Inv[15 * j + k] * Inv[15 * j + k];
+        double l = sqrt(s);
+        Inv[16 * j] = l;
+        for (int i = j + 1; i < 15; i++) {
+            double t = Inv[15 * i + j];
+            for (int k = 0; k < j; k++) t -= Inv[15 * i + k] * Inv[15 * j + k];
+            Inv[15 * i + j] = t / l;
+        }
+    }
+    double *S = imu_rec + (size_t)id * IMU_REC + IMU_SQRT;
+    for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) S[15 * i + j] = (j >= i) ? Inv[15 * j + i] : 0.0;
+}
+
+extern "C" __global__ __launch_bounds__(NT) void k_prior_prep(VbBatch b, double *prior_H, double *prior_g) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    if (!hdr[0]) return;
+    const int n = hdr[1];
+    const double *J = b.prior_J + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
+    const double *r = b.prior_r + (size_t)w * VB_PRIOR_LD;
+    double *H = prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
+    double *g = prior_g + (size_t)w * VB_PRIOR_LD;
+    for (int e = tid; e < n * n; e += NT) {
+        int i = e / n, j = e - i * n;
+        double s = 0;
+        for (int k = 0; k < n; k++) s += J[k * n + i] * J[k * n + j];
+        H[i * VB_PRIOR_LD + j] = s;
+    }
+    for (int i = tid; i < n; i += NT) {
+        double s = 0;
+        for (int k = 0; k < n; k++) s += J[k * n + i] * r[k];
+        g[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// prior helpers: column map (tangent index frame-major -> prior column) and dx (marginalization_factor.cpp:345-363)
+__device__ void prior_setup(const VbBatch &b, int w, const double *pose, const double *sb, int *s_pcol, double *s_dx, int tid) {
+    const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    for (int i = tid; i < VB_P; i += NT) s_pcol[i] = -1;
+    for (int i = tid; i < VB_PRIOR_LD; i += NT) s_dx[i] = 0.0;
+    __syncthreads();
+    if (!hdr[0]) return;
+    const int nb = hdr[2];
+    if (tid < nb) {
+        const int id = hdr[3 + tid], size = hdr[27 + tid], idx = hdr[51 + tid];
+        const double *x0 = b.prior_x0 + ((size_t)w * 24 + tid) * 9;
+        if (id < VB_NF) {
+            const double *x = pose + 7 * id;
+            for (int k = 0; k < 3; k++) s_dx[idx + k] = x[k] - x0[k];
+            Q dq = q_mul(q_inv(q_load(x0 + 3)), q_load(x + 3));
+            double sgn = (dq.w >= 0) ? 2.0 : -2.0;
+            s_dx[idx + 3] = sgn * dq.x; s_dx[idx + 4] = sgn * dq.y; s_dx[idx + 5] = sgn * dq.z;
+            for (int k = 0; k < 6; k++) s_pcol[15 * id + k] = idx + k;
+        } else if (id < 2 * VB_NF) {
+            const int a = id - VB_NF;
+            const double *x = sb + 9 * a;
+            for (int k = 0; k < 9; k++) { s_dx[idx + k] = x[k] - x0[k]; s_pcol[15 * a + 6 + k] = idx + k; }
+        } else if (id == 2 * VB_NF) {
+            // Ex_Pose: constant in the solve (estimate_extrinsic = 0): contributes dx to the residual only
+            const double *x = b.ex + (size_t)w * 7;
+            for (int k = 0; k < 3; k++) s_dx[idx + k] = x[k] - x0[k];
+            Q dq = q_mul(q_inv(q_load(x0 + 3)), q_load(x + 3));
+            double sgn = (dq.w >= 0) ? 2.0 : -2.0;
+            s_dx[idx + 3] = sgn * dq.x; s_dx[idx + 4] = sgn * dq.y; s_dx[idx + 5] = sgn * dq.z;
+        }
+        (void)size;
+    }
+    __syncthreads();
+}
+
+// 0.5 * || r0 + J0 dx ||^2 summed over the block's threads (each thread returns its partial)
+__device__ double prior_cost_partial(const VbBatch &b, int w, const double *s_dx, int tid) {
+    const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    if (!hdr[0]) return 0.0;
+    const int n = hdr[1];
+    const double *J = b.prior_J + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
+    const double *r0 = b.prior_r + (size_t)w * VB_PRIOR_LD;
+    double acc = 0;
+    for (int row = tid; row < n; row += NT) {
+        double s = r0[row];
+        for (int k = 0; k < n; k++) s += J[row * n + k] * s_dx[k];
+        acc += 0.5 * s * s;
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_linearize
+extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    VbState *st = b.st + w;
+    if (!iteration_zero) { if (st->done || !st->need_linearize) return; }
+
+    __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3];
+    __shared__ double s_imuJr[10 * 450], s_imuJ[10 * 450], s_imur[176], s_imurw[160];
+    __shared__ double s_lidJ[10 * 72], s_lidr[64];
+    __shared__ double s_dx[VB_PRIOR_LD];
+    __shared__ int s_pcol[VB_P];
+    __shared__ double s_red[NT];
+
+    const int F = b.n_feat[w], nfac = b.n_fac[w];
+    const size_t FM = b.Fmax, FC = b.FACmax;
+    const double *pose_g = b.pose + (size_t)w * 77, *sb_g = b.sb + (size_t)w * 99;
+    const double *feat = b.feat + (size_t)w * FM;
+    const double *ex = b.ex + (size_t)w * 7;
+
+    if (tid < 77) s_pose[tid] = pose_g[tid];
+    if (tid < 99) s_sb[tid] = sb_g[tid];
+    __syncthreads();
+    if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
+    if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
+    prior_setup(b, w, s_pose, s_sb, s_pcol, s_dx, tid);   // contains __syncthreads
+
+    // ---- visual factors: one thread per factor (projection_factor.cpp:21-121 + Cauchy corrector) -----------------
+    const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
+    const uint8_t *f_const = b.f_const + (size_t)w * FM;
+    const int *fac_feat = b.fac_feat + (size_t)w * FC, *fac_obs = b.fac_obs + (size_t)w * FC;
+    const double *obs = b.obs + (size_t)w * b.Omax * 3;
+    double *Jb = b.Jbuf + (size_t)w * VB_JROWS * FC;
+    double cost_local = 0;
+    for (int fac = tid; fac < nfac; fac += NT) {
+        const int f = fac_feat[fac], oj = fac_obs[fac];
+        const int fi = f_start[f], o0 = f_obs0[f], fj = fi + (oj - o0);
+        double r[2], Ji[12], Jj[12], Jf[2];
+        projection_eval<true>(s_pose + 7 * fi, s_R + 9 * fi, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_tic, obs + 3 * o0, obs + 3 * oj,
+                              feat[f], b.sqrt_info, r, Ji, Jj, Jf);
+        double rho0, sw;
+        cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
+        cost_local += 0.5 * rho0;
+        const double fw = f_const[f] ? 0.0 : sw;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { Jb[(size_t)k * FC + fac] = sw * Ji[k]; Jb[(size_t)(12 + k) * FC + fac] = sw * Jj[k]; }
+        Jb[(size_t)24 * FC + fac] = fw * Jf[0]; Jb[(size_t)25 * FC + fac] = fw * Jf[1];
+        Jb[(size_t)26 * FC + fac] = sw * r[0]; Jb[(size_t)27 * FC + fac] = sw * r[1];
+    }
+    // ---- IMU (wave 0, lanes 0..9) and LiDAR between-factors (wave 1, lanes 0..9): raw evaluation -----------------
+    if (tid < 10) {
+        const double *rec = b.imu + ((size_t)w * 10 + tid) * IMU_REC;
+        if (rec[287] != 0.0) imu_raw_eval<true>(s_pose + 7 * tid, s_sb + 9 * tid, s_pose + 7 * (tid + 1), s_sb + 9 * (tid + 1), rec, b.G, s_imur + 16 * tid, s_imuJr + 450 * tid);
+        else { for (int k = 0; k < 450; k++) s_imuJr[450 * tid + k] = 0; for (int k = 0; k < 15; k++) s_imur[16 * tid + k] = 0; }
+    }
+    if (tid >= 64 && tid < 74) {
+        const int k = tid - 64;
+        if (b.use_lidar) {
+            const double *lc = b.lidar + ((size_t)w * 10 + k) * 7;
+            double Ji[36], Jj[36];
+            lidar_between_eval<true>(s_pose + 7 * k, s_pose + 7 * (k + 1), q_load(b.qil), b.til, q_load(lc), lc + 4, s_lidr + 6 * k, Ji, Jj);
+            for (int rr = 0; rr < 6; rr++) for (int c = 0; c < 6; c++) { s_lidJ[72 * k + 12 * rr + c] = Ji[6 * rr + c]; s_lidJ[72 * k + 12 * rr + 6 + c] = Jj[6 * rr + c]; }
+        } else {
+            for (int e = 0; e < 72; e++) s_lidJ[72 * k + e] = 0;
+            for (int e = 0; e < 6; e++) s_lidr[6 * k + e] = 0;
+        }
+    }
+    __syncthreads();
+    // ---- IMU: left-multiply by sqrt_info (imu_factor.h:64,93,126,145,160) ------------------------------------------
+    for (int idx = tid; idx < 10 * 450; idx += NT) {
+        const int k = idx / 450, e = idx - 450 * k, row = e / 30, col = e - 30 * row;
+        const double *S = b.imu + ((size_t)w * 10 + k) * IMU_REC + IMU_SQRT + 15 * row;
+        const double *Jr = s_imuJr + 450 * k + col;
+        double s = 0;
+#pragma unroll
+        for (int m = 0; m < 15; m++) s += S[m] * Jr[30 * m];
+        s_imuJ[idx] = s;
+    }
+    if (tid < 150) {
+        const int k = tid / 15, row = tid - 15 * k;
+        const double *S = b.imu + ((size_t)w * 10 + k) * IMU_REC + IMU_SQRT + 15 * row;
+        double s = 0;
+        for (int m = 0; m < 15; m++) s += S[m] * s_imur[16 * k + m];
+        s_imurw[16 * k + row] = s;
+    }
+    __syncthreads();
+    // ---- IMU / LiDAR normal-equation blocks ------------------------------------------------------------------------
+    {
+        double *imuH = b.imuH + (size_t)w * 9000, *imug = b.imug + (size_t)w * 300;
+        for (int idx = tid; idx < 9000; idx += NT) {
+            const int k = idx / 900, e = idx - 900 * k, p = e / 30, q = e - 30 * p;
+            const double *J = s_imuJ + 450 * k;
+            double s = 0;
+#pragma unroll
+            for (int row = 0; row < 15; row++) s += J[30 * row + p] * J[30 * row + q];
+            imuH[idx] = s;
+        }
+        for (int idx = tid; idx < 300; idx += NT) {
+            const int k = idx / 30, p = idx - 30 * k;
+            double s = 0;
+            for (int row = 0; row < 15; row++) s += s_imuJ[450 * k + 30 * row + p] * s_imurw[16 * k + row];
+            imug[idx] = s;
+        }
+        double *lidH = b.lidH + (size_t)w * 1440, *lidg = b.lidg + (size_t)w * 120;
+        for (int idx = tid; idx < 1440; idx += NT) {
+            const int k = idx / 144, e = idx - 144 * k, p = e / 12, q = e - 12 * p;
+            double s = 0;
+            for (int row = 0; row < 6; row++) s += s_lidJ[72 * k + 12 * row + p] * s_lidJ[72 * k + 12 * row + q];
+            lidH[idx] = s;
+        }
+        for (int idx = tid; idx < 120; idx += NT) {
+            const int k = idx / 12, p = idx - 12 * k;
+            double s = 0;
+            for (int row = 0; row < 6; row++) s += s_lidJ[72 * k + 12 * row + p] * s_lidr[6 * k + row];
+            lidg[idx] = s;
+        }
+    }
+    if (tid < 10) { double s = 0; for (int m = 0; m < 15; m++) s += s_imurw[16 * tid + m] * s_imurw[16 * tid + m]; cost_local += 0.5 * s; }
+    if (tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
+    cost_local += prior_cost_partial(b, w, s_dx, tid);
+    __syncthreads();   // Jbuf written by this block is visible to the block
+    // ---- per frame-pair J^T J / J^T r (block-sparse accumulate, owner-computes: deterministic) ---------------------
+    {
+        const int *pair_off = b.pair_off + (size_t)w * (VB_NPAIR + 1), *pair_fac = b.pair_fac + (size_t)w * FC;
+        double *pairD = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
+        for (int t = tid; t < VB_NPAIR * VB_PAIRD; t += NT) {
+            const int p = t / VB_PAIRD, e = t - VB_PAIRD * p;
+            int ra, rb;   // Jbuf component rows of the two operands for residual row 0 (row 1 = +6)
+            if (e < 36) { ra = 12 + e / 6; rb = 12 + e % 6; }
+            else if (e < 72) { ra = 12 + (e - 36) / 6; rb = (e - 36) % 6; }
+            else if (e < 108) { ra = (e - 72) / 6; rb = (e - 72) % 6; }
+            else if (e < 114) { ra = 12 + (e - 108); rb = 26; }
+            else { ra = (e - 114); rb = 26; }
+            const int step_b = (e < 108) ? 6 : 1;
+            double s = 0;
+            for (int q = pair_off[p]; q < pair_off[p + 1]; q++) {
+                const int fac = pair_fac[q];
+                s += Jb[(size_t)ra * FC + fac] * Jb[(size_t)rb * FC + fac] + Jb[(size_t)(ra + 6) * FC + fac] * Jb[(size_t)(rb + step_b) * FC + fac];
+            }
+            pairD[t] = s;
+        }
+    }
+    // ---- per-feature Schur vectors: H_ff, g_f, H_pf row (W) --------------------------------------------------------
+    {
+        const int *f_nobs = b.f_nobs + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
+        double *W = b.W + (size_t)w * FM * VB_NPOSE, *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+        for (int f = tid; f < F; f += NT) {
+            if (f_const[f]) { hf[f] = 0; gf[f] = 0; continue; }
+            double *Wr = W + (size_t)f * VB_NPOSE;
+            for (int k = 0; k < VB_NPOSE; k++) Wr[k] = 0;
+            const int fi = f_start[f], n = f_nobs[f] - 1, f0 = f_fac0[f];
+            double h = 0, g = 0, wi[6] = {0, 0, 0, 0, 0, 0};
+            for (int t = 0; t < n; t++) {
+                const int fac = f0 + t;
+                const double jf0 = Jb[(size_t)24 * FC + fac], jf1 = Jb[(size_t)25 * FC + fac];
+                h += jf0 * jf0 + jf1 * jf1;
+                g += jf0 * Jb[(size_t)26 * FC + fac] + jf1 * Jb[(size_t)27 * FC + fac];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    wi[c] += Jb[(size_t)c * FC + fac] * jf0 + Jb[(size_t)(6 + c) * FC + fac] * jf1;
+                    Wr[6 * (fi + 1 + t) + c] = Jb[(size_t)(12 + c) * FC + fac] * jf0 + Jb[(size_t)(18 + c) * FC + fac] * jf1;
+                }
+            }
+            for (int c = 0; c < 6; c++) Wr[6 * fi + c] = wi[c];
+            hf[f] = h; gf[f] = g;
+        }
+    }
+    __syncthreads();
+    // ---- gradient g = J^T r over the reduced camera/IMU block (frame-major order) ---------------------------------
+    double gmax = 0, xsq = 0;
+    double *gout = b.g + (size_t)w * VB_P;
+    if (tid < VB_P) {
+        const int a = tid / 15, l = tid - 15 * a;
+        const double *pairD = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
+        const double *imug = b.imug + (size_t)w * 300, *lidg = b.lidg + (size_t)w * 120;
+        double s = 0;
+        if (l < 6) {
+            for (int i = 0; i < a; i++) s += pairD[pair_index(i, a) * VB_PAIRD + 108 + l];
+            for (int j = a + 1; j < VB_NF; j++) s += pairD[pair_index(a, j) * VB_PAIRD + 114 + l];
+            if (a >= 1) s += lidg[12 * (a - 1) + 6 + l];
+            if (a <= 9) s += lidg[12 * a + l];
+        }
+        if (a >= 1) s += imug[30 * (a - 1) + 15 + l];
+        if (a <= 9) s += imug[30 * a + l];
+        const int pc = s_pcol[tid];
+        if (pc >= 0) {
+            const int n = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + 1];
+            const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
+            double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
+            for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];
+            s += t;
+        }
+        gout[tid] = s;
+        s_imur[tid] = s;     // reuse as scratch for the gradient-max-norm pass (IMU residual no longer needed)
+    }
+    __syncthreads();
+    // gradient_max_norm = || x - Plus(x, -g) ||_inf (trust_region_minimizer.cc), x_norm = ||x||
+    if (tid < VB_NF) {
+        const double *gp = s_imur + 15 * tid;
+        double d[6] = {-gp[0], -gp[1], -gp[2], -gp[3], -gp[4], -gp[5]}, xp[7];
+        pose_plus(s_pose + 7 * tid, d, xp);
+        for (int k = 0; k < 7; k++) { gmax = fmax(gmax, fabs(s_pose[7 * tid + k] - xp[k])); xsq += s_pose[7 * tid + k] * s_pose[7 * tid + k]; }
+        for (int k = 0; k < 9; k++) { gmax = fmax(gmax, fabs(gp[6 + k])); xsq += s_sb[9 * tid + k] * s_sb[9 * tid + k]; }
+    }
+    {
+        const double *gf = b.gf + (size_t)w * FM;
+        for (int f = tid; f < F; f += NT) if (!f_const[f]) { gmax = fmax(gmax, fabs(gf[f])); xsq += feat[f] * feat[f]; }
+    }
+    const double cost = block_sum(cost_local, s_red);
+    const double gm = block_max(gmax, s_red);
+    const double xs = block_sum(xsq, s_red);
+    if (tid == 0) {
+        st->x_cost = cost;
+        st->gradient_max_norm = gm;
+        st->x_norm = sqrt(xs);
+        st->need_linearize = 0;
+        st->reuse = 0;
+        if (iteration_zero) { st->initial_cost = cost; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// reduced-system entry H[(a,l),(b,m)] (unscaled), a >= b, from the blocks k_linearize wrote
+__device__ __forceinline__ double h_entry(int a, int l, int b_, int m, const double *pairD, const double *imuH, const double *lidH,
+                                          const double *priorH, const int *s_pcol) {
+    if (a < b_) { int t = a; a = b_; b_ = t; t = l; l = m; m = t; }
+    double s = 0;
+    const bool pp = (l < 6 && m < 6);
+    if (a == b_) {
+        if (pp) {
+            for (int i = 0; i < a; i++) s += pairD[pair_index(i, a) * VB_PAIRD + 6 * l + m];
+            for (int j = a + 1; j < VB_NF; j++) s += pairD[pair_index(a, j) * VB_PAIRD + 72 + 6 * l + m];
+            if (a >= 1) s += lidH[144 * (a - 1) + 12 * (6 + l) + 6 + m];
+            if (a <= 9) s += lidH[144 * a + 12 * l + m];
+        }
+        if (a >= 1) s += imuH[900 * (a - 1) + 30 * (15 + l) + 15 + m];
+        if (a <= 9) s += imuH[900 * a + 30 * l + m];
+    } else {
+        if (pp) s += pairD[pair_index(b_, a) * VB_PAIRD + 36 + 6 * l + m];
+        if (a == b_ + 1) {
+            s += imuH[900 * b_ + 30 * (15 + l) + m];
+            if (pp) s += lidH[144 * b_ + 12 * (6 + l) + m];
+        }
+    }
+    const int pa = s_pcol[15 * a + l], pb = s_pcol[15 * b_ + m];
+    if (pa >= 0 && pb >= 0) s += priorH[pa * VB_PRIOR_LD + pb];
+    return s;
+}
+
+// 16x16 lower Cholesky of the diagonal tile by ONE wave, tile held in registers (4 doubles / lane), column broadcasts by
+// ds_bpermute. Lane l holds rows r = l&15, columns c = (l>>4) + 4q. Returns false if a pivot is not positive (Eigen LLT).
+__device__ bool potrf_tile_wave(double *T, double *s_invd, int lane) {
+    const int r = lane & 15, cq = lane >> 4;
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) v[q] = T[16 * r + cq + 4 * q];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const int jq = j >> 2, jl = j & 3;
+        const double djj = __shfl(v[jq], jl * 16 + j, 64);
+        if (!(djj > 0.0)) ok = false;
+        const double d = sqrt(djj);
+        const double inv = 1.0 / d;
+        const double Lrj = __shfl(v[jq], jl * 16 + r, 64) * inv;
+        double Lcj[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) Lcj[q] = __shfl(v[jq], jl * 16 + ((cq + 4 * q) & 15), 64) * inv;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = cq + 4 * q;
+            if (c > j && r >= c) v[q] -= Lrj * Lcj[q];
+        }
+        if (cq == jl && r >= j) v[jq] = Lrj;
+        if (lane == 0) s_invd[j] = inv;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int c = cq + 4 * q; T[16 * r + c] = (c <= r) ? v[q] : 0.0; }
+    return ok;
+}
+
+extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    VbState *st = b.st + w;
+    extern __shared__ double s_dyn[];
+    double *s_T = s_dyn;                      // 66 tiles * 256
+    double *s_g = s_T + 66 * 256;             // g~ (permuted, padded to 176)
+    double *s_diag = s_g + VB_NPAD;
+    double *s_scale = s_diag + VB_NPAD;
+    double *s_y = s_scale + VB_NPAD;          // rhs -> solution
+    double *s_invd = s_y + VB_NPAD;           // 1 / L_jj
+    double *s_red = s_invd + VB_NPAD;         // NT
+    double *s_cf = s_red + NT;                // per non-constant feature: s_f / sqrt(h~' )   (<= 1000)
+    __shared__ int s_pcol[VB_P];
+    __shared__ double s_dx[VB_PRIOR_LD];
+    __shared__ int s_flag[4];
+
+    // ---- iteration begin: FinalizeIterationAndCheckIfMinimizerCanContinue() of the previous iteration -------------
+    if (tid == 0) {
+        int go = 1;
+        if (st->done) go = 0;
+        else if (st->iteration >= b.max_iterations) { st->done = 1; st->termination = 0; go = 0; }
+        else if (st->gradient_max_norm <= b.gradient_tolerance) { st->done = 1; st->termination = 3; go = 0; }
+        else if (st->radius <= b.min_radius) { st->done = 1; st->termination = 4; go = 0; }
+        if (go) st->iteration += 1;
+        s_flag[0] = go;
+        s_flag[1] = go ? st->reuse : 1;
+    }
+    __syncthreads();
+    if (!s_flag[0] || s_flag[1]) return;     // done, or the previous Gauss-Newton step is re-used (rejected step)
+
+    const int F = b.n_feat[w];
+    const size_t FM = b.Fmax;
+    const double *pairD = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
+    const double *imuH = b.imuH + (size_t)w * 9000, *lidH = b.lidH + (size_t)w * 1440;
+    const double *priorH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
+    const double *W = b.W + (size_t)w * FM * VB_NPOSE, *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+    const uint8_t *f_const = b.f_const + (size_t)w * FM;
+    double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
+    double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
+    const double *g_in = b.g + (size_t)w * VB_P;
+
+    prior_setup(b, w, b.pose + (size_t)w * 77, b.sb + (size_t)w * 99, s_pcol, s_dx, tid);
+
+    // Jacobi scaling (trust_region_minimizer.cc: computed once at iteration 0): 1 / (1 + sqrt(diag(J^T J)))
+    const int scaling_ready = st->scaling_ready;
+    if (tid < VB_NPAD) {
+        double sc = 1.0;
+        if (tid < VB_P) {
+            if (scaling_ready) sc = scale_g[tid];
+            else { int a, l; unperm(tid, a, l); sc = 1.0 / (1.0 + sqrt(h_entry(a, l, a, l, pairD, imuH, lidH, priorH, s_pcol))); scale_g[tid] = sc; }
+        }
+        s_scale[tid] = sc;
+    }
+    if (!scaling_ready) for (int f = tid; f < F; f += NT) scale_g[VB_P + f] = f_const[f] ? 1.0 : 1.0 / (1.0 + sqrt(hf[f]));
+    __syncthreads();
+
+    double mu = st->mu;
+    int tries = 0;
+    bool solved = false;
+    double Jg2 = 0, G2 = 0;
+    for (;;) {
+        // ---- assemble H~ = S H S into 16x16 tiles (lower block triangle, diagonal tiles full) ---------------------
+        for (int t = 0; t < 66; t++) {
+            int ta = 0; while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
+            const int tb = t - ta * (ta + 1) / 2;
+            const int pr = 16 * ta + (tid >> 4), pc = 16 * tb + (tid & 15);
+            double v = 0;
+            if (pr < VB_P && pc < VB_P) {
+                int a, l, bb, m;
+                unperm(pr, a, l); unperm(pc, bb, m);
+                v = h_entry(a, l, bb, m, pairD, imuH, lidH, priorH, s_pcol) * s_scale[pr] * s_scale[pc];
+            } else if (pr == pc) v = 1.0;
+            s_T[t * 256 + tid] = v;
+        }
+        if (tid < VB_NPAD) {
+            double gv = 0;
+            if (tid < VB_P) { int a, l; unperm(tid, a, l); gv = g_in[15 * a + l] * s_scale[tid]; }
+            s_g[tid] = gv;
+        }
+        __syncthreads();
+        if (tries == 0) {
+            // dogleg diagonal_ = sqrt(clamp(diag(H~))), gradient_ = g~ / diagonal_ (dogleg_strategy.cc)
+            double g2 = 0;
+            if (tid < VB_NPAD) {
+                double d = 1.0;
+                if (tid < VB_P) {
+                    const int tt = tid >> 4, e = tid & 15;
+                    d = sqrt(fmin(fmax(s_T[tile_index(tt, tt) * 256 + 17 * e], b.min_lm_diagonal), b.max_lm_diagonal));
+                    diag_g[tid] = d;
+                    const double gr = s_g[tid] / d;
+                    grad_g[tid] = gr;
+                    g2 += gr * gr;
+                }
+                s_diag[tid] = d;
+            }
+            for (int f = tid; f < F; f += NT) {
+                if (f_const[f]) continue;
+                const double sf = scale_g[VB_P + f];
+                const double d = sqrt(fmin(fmax(sf * sf * hf[f], b.min_lm_diagonal), b.max_lm_diagonal));
+                diag_g[VB_P + f] = d;
+                const double gr = sf * gf[f] / d;
+                grad_g[VB_P + f] = gr;
+                g2 += gr * gr;
+            }
+            G2 = block_sum(g2, s_red);
+            // Cauchy point: alpha = ||gradient_||^2 / || J~ (gradient_ ./ diagonal_) ||^2 ; v = g~ ./ diagonal_^2
+            // v^T H~ v = v_p^T H~_pp v_p + 2 sum_f v_f (w~_f . v_p) + sum_f h~_f v_f^2
+            double part = 0;
+            if (tid < VB_P) {
+                double t = 0;
+                const int ta = tid >> 4, ea = tid & 15;
+                for (int c = 0; c < VB_P; c++) {
+                    const int tb = c >> 4, eb = c & 15;
+                    const double hv = (ta >= tb) ? s_T[tile_index(ta, tb) * 256 + 16 * ea + eb] : s_T[tile_index(tb, ta) * 256 + 16 * eb + ea];
+                    t += hv * (s_g[c] / (s_diag[c] * s_diag[c]));
+                }
+                part = t * (s_g[tid] / (s_diag[tid] * s_diag[tid]));
+            }
+            for (int f = tid; f < F; f += NT) {
+                if (f_const[f]) continue;
+                const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
+                const double vf = sf * gf[f] / (df * df);
+                const double *Wr = W + (size_t)f * VB_NPOSE;
+                double dotp = 0;
+                for (int p = 0; p < VB_NPOSE; p++) dotp += Wr[p] * s_scale[p] * (s_g[p] / (s_diag[p] * s_diag[p]));
+                part += vf * (2.0 * sf * dotp + sf * sf * hf[f] * vf);
+            }
+            Jg2 = block_sum(part, s_red);
+        }
+        // ---- LM regularisation mu * diagonal_^2 on the reduced block; per-feature coefficients ----------------------
+        if (tid < VB_P) { const int tt = tid >> 4, e = tid & 15; s_T[tile_index(tt, tt) * 256 + 17 * e] += mu * s_diag[tid] * s_diag[tid]; }
+        // compact list of non-constant features is implicit: constant features get coefficient 0
+        for (int f = tid; f < F; f += NT) {
+            double c = 0;
+            if (!f_const[f]) {
+                const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
+                c = sf / sqrt(sf * sf * hf[f] + mu * df * df);
+            }
+            s_cf[f] = c;
+        }
+        if (tid < VB_NPAD) s_y[tid] = s_g[tid];
+        __syncthreads();
+        // rhs_p -= sum_f u_f[p] * (g~_f / sqrt(h~'_f)),  u_f = c_f * S_p * W_f
+        if (tid < VB_NPOSE) {
+            double acc = 0;
+            for (int f = 0; f < F; f++) { const double c = s_cf[f]; if (c != 0.0) acc += W[(size_t)f * VB_NPOSE + tid] * c * c * gf[f]; }
+            s_y[tid] -= acc * s_scale[tid];
+        }
+        // ---- MFMA Schur reduce: H~_pp -= U^T U over the 5x5 pose tile block (columns 0..79, pose columns 0..65) ----
+        {
+            const int Fk = (F + 3) & ~3;
+            for (int tp = wave; tp < 15; tp += 4) {
+                int ta = 0; while ((ta + 1) * (ta + 2) / 2 <= tp) ta++;
+                const int tb = tp - ta * (ta + 1) / 2;
+                const int ca = 16 * ta + (lane & 15), cb = 16 * tb + (lane & 15);
+                const double sa = (ca < VB_NPOSE) ? s_scale[ca] : 0.0, sb2 = (cb < VB_NPOSE) ? s_scale[cb] : 0.0;
+                double4_t acc = {0, 0, 0, 0};
+                for (int f0 = 0; f0 < Fk; f0 += 4) {
+                    const int f = f0 + (lane >> 4);
+                    double av = 0, bv = 0;
+                    if (f < F) {
+                        const double c = s_cf[f];
+                        if (c != 0.0) {
+                            const double *Wr = W + (size_t)f * VB_NPOSE;
+                            if (ca < VB_NPOSE) av = Wr[ca] * c * sa;
+                            if (cb < VB_NPOSE) bv = Wr[cb] * c * sb2;
+                        }
+                    }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+                double *T = s_T + tile_index(ta, tb) * 256;
+#pragma unroll
+                for (int q = 0; q < 4; q++) T[16 * ((lane >> 4) + 4 * q) + (lane & 15)] -= acc[q];
+            }
+        }
+        __syncthreads();
+        // ---- blocked Cholesky (lower), 11 tile steps: POTRF (wave 0) -> TRSM (row per thread) -> MFMA trailing update
+        bool ok = true;
+        for (int k = 0; k < VB_NTILE; k++) {
+            double *Tkk = s_T + tile_index(k, k) * 256;
+            if (wave == 0) { bool o = potrf_tile_wave(Tkk, s_invd + 16 * k, lane); if (lane == 0) s_flag[2] = o ? 1 : 0; }
+            __syncthreads();
+            if (!s_flag[2]) { ok = false; break; }
+            const int nrows = (VB_NTILE - 1 - k) * 16;
+            if (tid < nrows) {
+                const int ti = k + 1 + (tid >> 4), rr = tid & 15;
+                double *row = s_T + tile_index(ti, k) * 256 + 16 * rr;
+                double x[16];
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    double s = row[c];
+#pragma unroll
+                    for (int p = 0; p < c; p++) s -= x[p] * Tkk[16 * c + p];
+                    x[c] = s * s_invd[16 * k + c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; c++) row[c] = x[c];
+            }
+            __syncthreads();
+            const int nt = VB_NTILE - 1 - k, ntile = nt * (nt + 1) / 2;
+            for (int tt = wave; tt < ntile; tt += 4) {
+                int ii = 0; while ((ii + 1) * (ii + 2) / 2 <= tt) ii++;
+                const int jj = tt - ii * (ii + 1) / 2;
+                const int ti = k + 1 + ii, tj = k + 1 + jj;
+                double *C = s_T + tile_index(ti, tj) * 256;
+                const double *A = s_T + tile_index(ti, k) * 256, *Bm = s_T + tile_index(tj, k) * 256;
+                double4_t acc;
+#pragma unroll
+                for (int q = 0; q < 4; q++) acc[q] = C[16 * ((lane >> 4) + 4 * q) + (lane & 15)];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const double av = -A[16 * (lane & 15) + 4 * s4 + (lane >> 4)];
+                    const double bv = Bm[16 * (lane & 15) + 4 * s4 + (lane >> 4)];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) C[16 * ((lane >> 4) + 4 * q) + (lane & 15)] = acc[q];
+            }
+            __syncthreads();
+        }
+        tries++;
+        if (ok) { solved = true; break; }
+        mu *= 10.0;                                 // dogleg_strategy.cc: mu_ *= mu_increase_factor_
+        if (!(mu < 1.0)) break;                     // max_mu_
+        __syncthreads();
+    }
+    if (!solved) {
+        if (tid == 0) { st->solve_failed = 1; st->mu = mu; st->num_linear_solves += tries; st->scaling_ready = 1; st->grad_sqnorm = G2; st->Jg2 = Jg2; }
+        return;
+    }
+    // ---- forward / backward substitution on the tiles (rhs in s_y) --------------------------------------------------
+    for (int k = 0; k < VB_NTILE; k++) {            // L z = rhs
+        if (wave == 0) {
+            const double *Tkk = s_T + tile_index(k, k) * 256;
+            double x = (lane < 16) ? s_y[16 * k + lane] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const double xj = __shfl(x, j, 64) * s_invd[16 * k + j];
+                if (lane == j) x = xj;
+                else if (lane > j && lane < 16) x -= Tkk[16 * lane + j] * xj;
+            }
+            if (lane < 16) s_y[16 * k + lane] = x;
+        }
+        __syncthreads();
+        const int nrows = (VB_NTILE - 1 - k) * 16;
+        if (tid < nrows) {
+            const int ti = k + 1 + (tid >> 4), rr = tid & 15;
+            const double *row = s_T + tile_index(ti, k) * 256 + 16 * rr;
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < 16; c++) s += row[c] * s_y[16 * k + c];
+            s_y[16 * ti + rr] -= s;
+        }
+        __syncthreads();
+    }
+    for (int k = VB_NTILE - 1; k >= 0; k--) {       // L^T y = z
+        if (wave == 0) {
+            const double *Tkk = s_T + tile_index(k, k) * 256;
+            double x = (lane < 16) ? s_y[16 * k + lane] : 0.0;
+#pragma unroll
+            for (int j = 15; j >= 0; j--) {
+                const double xj = __shfl(x, j, 64) * s_invd[16 * k + j];
+                if (lane == j) x = xj;
+                else if (lane < j) x -= Tkk[16 * j + lane] * xj;
+            }
+            if (lane < 16) s_y[16 * k + lane] = x;
+        }
+        __syncthreads();
+        const int ncols = k * 16;                    // rows above: y_i -= sum_r L[16k+r][i] * y[16k+r]
+        if (tid < ncols) {
+            const int tj = tid >> 4, cc = tid & 15;
+            const double *T = s_T + tile_index(k, tj) * 256;
+            double s = 0;
+#pragma unroll
+            for (int r2 = 0; r2 < 16; r2++) s += T[16 * r2 + cc] * s_y[16 * k + r2];
+            s_y[16 * tj + cc] -= s;
+        }
+        __syncthreads();
+    }
+    // ---- back-substitute the features, Gauss-Newton step = -diagonal_ .* y, reductions ------------------------------
+    double gy = 0, gn2 = 0;
+    if (tid < VB_P) {
+        const double y = s_y[tid], d = s_diag[tid];
+        gn_g[tid] = -d * y;
+        gy += s_g[tid] * y;
+        gn2 += d * d * y * y;
+    }
+    for (int f = tid; f < F; f += NT) {
+        if (f_const[f]) continue;
+        const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
+        const double hp = sf * sf * hf[f] + mu * df * df;
+        const double *Wr = W + (size_t)f * VB_NPOSE;
+        double dotp = 0;
+        for (int p = 0; p < VB_NPOSE; p++) dotp += Wr[p] * s_scale[p] * s_y[p];
+        const double gt = sf * gf[f];
+        const double y = (gt - sf * dotp) / hp;
+        gn_g[VB_P + f] = -df * y;
+        gy += gt * y;
+        gn2 += df * df * y * y;
+    }
+    gy = block_sum(gy, s_red);
+    gn2 = block_sum(gn2, s_red);
+    if (tid == 0) {
+        st->grad_sqnorm = G2; st->Jg2 = Jg2; st->alpha = G2 / Jg2;
+        st->gy = gy; st->gn_sqnorm = gn2; st->mu = mu; st->mu_used = mu;
+        st->num_linear_solves += tries; st->solve_failed = 0; st->reuse = 1; st->scaling_ready = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_step
+extern "C" __global__ __launch_bounds__(NT) void k_step(VbBatch b) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    VbState *st = b.st + w;
+    if (st->done) return;
+    __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3], s_step[VB_P];
+    __shared__ double s_red[NT], s_dx[VB_PRIOR_LD], s_coef[4];
+    __shared__ int s_pcol[VB_P], s_flag[2];
+    const int F = b.n_feat[w], nfac = b.n_fac[w];
+    const size_t FM = b.Fmax, FC = b.FACmax;
+    double *pose_g = b.pose + (size_t)w * 77, *sb_g = b.sb + (size_t)w * 99, *feat = b.feat + (size_t)w * FM;
+    double *cpose = b.cand_pose + (size_t)w * 77, *csb = b.cand_sb + (size_t)w * 99, *cfeat = b.cand_feat + (size_t)w * FM;
+    const uint8_t *f_const = b.f_const + (size_t)w * FM;
+    const double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
+    const double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
+
+    // ---- DoglegStrategy::ComputeTraditionalDoglegStep + model cost change (thread 0) --------------------------------
+    if (tid == 0) {
+        int valid = 1;
+        double ca = 0, cb = 0;
+        if (st->solve_failed) valid = 0;
+        else {
+            const double radius = st->radius, alpha = st->alpha;
+            const double gradient_norm = sqrt(st->grad_sqnorm), gn_norm = sqrt(st->gn_sqnorm);
+            double norm;
+            if (gn_norm <= radius) { ca = 0; cb = 1; norm = gn_norm; }
+            else if (gradient_norm * alpha >= radius) { ca = -(radius / gradient_norm); cb = 0; norm = radius; }
+            else {
+                const double b_dot_a = alpha * st->gy;                  // -alpha * gradient_ . gauss_newton_step_
+                const double a_sq = (alpha * gradient_norm) * (alpha * gradient_norm);
+                const double bma = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+                const double c = b_dot_a - a_sq;
+                const double d = sqrt(c * c + bma * (radius * radius - a_sq));
+                const double beta = (c <= 0) ? (d - c) / bma : (radius * radius - a_sq) / (d + c);
+                ca = -alpha * (1.0 - beta); cb = beta;
+                norm = sqrt(ca * ca * st->grad_sqnorm - 2 * ca * cb * st->gy + cb * cb * st->gn_sqnorm);
+            }
+            st->dogleg_step_norm = norm;
+            // step = ca * v - cb * y ; model_cost_change = -step.g~ - 0.5 step^T H~ step, with (H~ + mu D^2) y = g~
+            const double mu = st->mu_used, G2 = st->grad_sqnorm;
+            const double sg = ca * G2 - cb * st->gy;
+            const double vHy = G2 - mu * st->gy;
+            const double yHy = st->gy - mu * st->gn_sqnorm;
+            const double sHs = ca * ca * st->Jg2 - 2 * ca * cb * vHy + cb * cb * yHy;
+            const double mcc = -sg - 0.5 * sHs;
+            st->model_cost_change = mcc;
+            if (!(mcc > 0.0)) valid = 0;
+        }
+        if (!valid) {   // HandleInvalidStep + DoglegStrategy::StepIsInvalid
+            st->num_consecutive_invalid += 1;
+            st->mu *= 10.0;
+            st->reuse = 0;
+            st->solve_failed = 0;
+            if (st->num_consecutive_invalid >= 5) { st->done = 1; st->termination = 4; }
+        } else st->num_consecutive_invalid = 0;
+        s_flag[0] = valid;
+        s_coef[0] = ca; s_coef[1] = cb;
+    }
+    if (tid < 77) s_pose[tid] = pose_g[tid];
+    if (tid < 99) s_sb[tid] = sb_g[tid];
+    __syncthreads();
+    if (!s_flag[0]) return;
+    const double ca = s_coef[0], cb = s_coef[1];
+    // delta = (ca * gradient_ + cb * gauss_newton_step_) ./ diagonal_ .* jacobian_scaling
+    if (tid < VB_P) {
+        int a, l; unperm(tid, a, l);
+        s_step[15 * a + l] = (ca * grad_g[tid] + cb * gn_g[tid]) / diag_g[tid] * scale_g[tid];
+    }
+    __syncthreads();
+    double stepsq = 0;
+    if (tid < VB_NF) {
+        double xp[7];
+        pose_plus(s_pose + 7 * tid, s_step + 15 * tid, xp);
+        for (int k = 0; k < 7; k++) { const double d = s_pose[7 * tid + k] - xp[k]; stepsq += d * d; cpose[7 * tid + k] = xp[k]; s_pose[7 * tid + k] = xp[k]; }
+        for (int k = 0; k < 9; k++) { const double d = s_step[15 * tid + 6 + k]; stepsq += d * d; const double v = s_sb[9 * tid + k] + d; csb[9 * tid + k] = v; s_sb[9 * tid + k] = v; }
+    }
+    for (int f = tid; f < F; f += NT) {
+        double v = feat[f];
+        if (!f_const[f]) {
+            const double d = (ca * grad_g[VB_P + f] + cb * gn_g[VB_P + f]) / diag_g[VB_P + f] * scale_g[VB_P + f];
+            stepsq += d * d;
+            v += d;
+        }
+        cfeat[f] = v;
+    }
+    __syncthreads();
+    // ---- cost at the candidate (residual-only evaluation of every factor) --------------------------------------------
+    const double *ex = b.ex + (size_t)w * 7;
+    if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
+    if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
+    prior_setup(b, w, s_pose, s_sb, s_pcol, s_dx, tid);
+    double cost_local = 0;
+    {
+        const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
+        const int *fac_feat = b.fac_feat + (size_t)w * FC, *fac_obs = b.fac_obs + (size_t)w * FC;
+        const double *obs = b.obs + (size_t)w * b.Omax * 3;
+        for (int fac = tid; fac < nfac; fac += NT) {
+            const int f = fac_feat[fac], oj = fac_obs[fac];
+            const int fi = f_start[f], o0 = f_obs0[f], fj = fi + (oj - o0);
+            double r[2];
+            projection_eval<false>(s_pose + 7 * fi, s_R + 9 * fi, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_tic, obs + 3 * o0, obs + 3 * oj,
+                                   cfeat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);
+            double rho0, sw;
+            cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
+            cost_local += 0.5 * rho0;
+        }
+    }
+    if (tid < 10) {
+        const double *rec = b.imu + ((size_t)w * 10 + tid) * IMU_REC;
+        if (rec[287] != 0.0) {
+            double r[15];
+            imu_raw_eval<false>(s_pose + 7 * tid, s_sb + 9 * tid, s_pose + 7 * (tid + 1), s_sb + 9 * (tid + 1), rec, b.G, r, nullptr);
+            double acc = 0;
+            for (int i = 0; i < 15; i++) { double s = 0; for (int m = i; m < 15; m++) s += rec[IMU_SQRT + 15 * i + m] * r[m]; acc += s * s; }
+            cost_local += 0.5 * acc;
+        }
+    }
+    if (tid >= 64 && tid < 74 && b.use_lidar) {
+        const int k = tid - 64;
+        const double *lc = b.lidar + ((size_t)w * 10 + k) * 7;
+        double r[6];
+        lidar_between_eval<false>(s_pose + 7 * k, s_pose + 7 * (k + 1), q_load(b.qil), b.til, q_load(lc), lc + 4, r, nullptr, nullptr);
+        double acc = 0;
+        for (int m = 0; m < 6; m++) acc += r[m] * r[m];
+        cost_local += 0.5 * acc;
+    }
+    cost_local += prior_cost_partial(b, w, s_dx, tid);
+    const double cand_cost = block_sum(cost_local, s_red);
+    const double step_norm = sqrt(block_sum(stepsq, s_red));
+    // ---- accept / reject (trust_region_minimizer.cc) ------------------------------------------------------------------
+    if (tid == 0) {
+        int accept = 0;
+        st->cand_cost = cand_cost;
+        const double x_cost = st->x_cost;
+        if (step_norm <= b.parameter_tolerance * (st->x_norm + b.parameter_tolerance)) { st->done = 1; st->termination = 2; }
+        else if (fabs(x_cost - cand_cost) <= b.function_tolerance * x_cost) { st->done = 1; st->termination = 1; }
+        else {
+            const double rd = (x_cost - cand_cost) / st->model_cost_change;
+            st->relative_decrease = rd;
+            if (rd > b.min_relative_decrease) {
+                accept = 1;
+                // DoglegStrategy::StepAccepted
+                if (rd < 0.25) st->radius *= 0.5;
+                if (rd > 0.75) st->radius = fmax(st->radius, 3.0 * st->dogleg_step_norm);
+                st->mu = fmax(1e-8, 2.0 * st->mu / 10.0);
+                st->reuse = 0;
+                st->need_linearize = 1;
+                st->num_successful += 1;
+            } else {
+                st->radius *= 0.5;     // StepRejected
+                st->reuse = 1;
+            }
+        }
+        s_flag[1] = accept;
+    }
+    __syncthreads();
+    if (s_flag[1]) {
+        if (tid < 77) pose_g[tid] = s_pose[tid];
+        if (tid < 99) sb_g[tid] = s_sb[tid];
+        for (int f = tid; f < F; f += NT) feat[f] = cfeat[f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// double2vector(): yaw / position gauge fix of the whole window (estimator.cpp:549-596)
+extern "C" __global__ void k_finalize(VbBatch b) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (tid >= VB_NF) return;
+    const double *pose = b.pose + (size_t)w * 77, *sb = b.sb + (size_t)w * 99;
+    const double *R0b = b.gauge_R0 + (size_t)w * 9, *P0b = b.gauge_P0 + (size_t)w * 3;
+    double R00[9], y0[3], y00[3], rot[9];
+    q_toR(q_load(pose + 3), R00);
+    R2ypr(R0b, y0); R2ypr(R00, y00);
+    double yd[3] = {y0[0] - y00[0], 0, 0};
+    ypr2R(yd, rot);
+    if (fabs(fabs(y0[1]) - 90) < 1.0 || fabs(fabs(y00[1]) - 90) < 1.0) {
+        // rot_diff = Rs[0] * R00^T
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rot[3 * i + j] = R0b[3 * i] * R00[3 * j] + R0b[3 * i + 1] * R00[3 * j + 1] + R0b[3 * i + 2] * R00[3 * j + 2];
+    }
+    double Ri[9], Ro[9], d[3], o[3];
+    q_toR(q_normalized(q_load(pose + 7 * tid + 3)), Ri);
+    m3_mul(rot, Ri, Ro);
+    for (int k = 0; k < 9; k++) b.out_Rs[((size_t)w * VB_NF + tid) * 9 + k] = Ro[k];
+    d[0] = pose[7 * tid] - pose[0]; d[1] = pose[7 * tid + 1] - pose[1]; d[2] = pose[7 * tid + 2] - pose[2];
+    m3_vec(rot, d, o);
+    for (int k = 0; k < 3; k++) b.out_Ps[((size_t)w * VB_NF + tid) * 3 + k] = o[k] + P0b[k];
+    m3_vec(rot, sb + 9 * tid, o);
+    for (int k = 0; k < 3; k++) {
+        b.out_Vs[((size_t)w * VB_NF + tid) * 3 + k] = o[k];
+        b.out_Bas[((size_t)w * VB_NF + tid) * 3 + k] = sb[9 * tid + 3 + k];
+        b.out_Bgs[((size_t)w * VB_NF + tid) * 3 + k] = sb[9 * tid + 6 + k];
+    }
+}
+
+// reset of the per-window solver state (≙ TrustRegionMinimizer::Init + DoglegStrategy ctor) and state rewind
+extern "C" __global__ void k_reset(VbBatch b, int rewind_state) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (rewind_state) {
+        if (tid < 77) b.pose[(size_t)w * 77 + tid] = b.pose_init[(size_t)w * 77 + tid];
+        if (tid < 99) b.sb[(size_t)w * 99 + tid] = b.sb_init[(size_t)w * 99 + tid];
+        for (int f = tid; f < b.Fmax; f += blockDim.x) b.feat[(size_t)w * b.Fmax + f] = b.feat_init[(size_t)w * b.Fmax + f];
+    }
+    if (tid == 0) {
+        VbState s;
+        s.x_cost = 0; s.cand_cost = 0; s.initial_cost = 0;
+        s.radius = b.initial_radius; s.mu = 1e-8; s.alpha = 0; s.dogleg_step_norm = 0;
+        s.x_norm = 0; s.gradient_max_norm = 1e300; s.grad_sqnorm = 0; s.Jg2 = 0; s.gy = 0; s.gn_sqnorm = 0; s.mu_used = 1e-8;
+        s.model_cost_change = 0; s.relative_decrease = 0;
+        s.iteration = 0; s.num_successful = 0; s.num_linear_solves = 0; s.num_consecutive_invalid = 0;
+        s.termination = 0; s.done = 0; s.reuse = 0; s.need_linearize = 1; s.solve_failed = 0; s.scaling_ready = 0; s.started = 1; s.pad_ = 0;
+        b.st[w] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ceres-layout test hooks: one thread evaluates one factor through the same device functions as above
+extern "C" __global__ void k_hook_projection(const double *p0, const double *p1, const double *p2, double lam, const double *pi, const double *pj,
+                                             double sqrt_info, double *out /* r[2] Ji[12] Jj[12] Jf[2] */) {
+    if (threadIdx.x) return;
+    double Ri[9], Rj[9], ric[9];
+    q_toR(q_load(p0 + 3), Ri); q_toR(q_load(p1 + 3), Rj); q_toR(q_load(p2 + 3), ric);
+    projection_eval<true>(p0, Ri, p1, Rj, ric, p2, pi, pj, lam, sqrt_info, out, out + 2, out + 14, out + 26);
+}
+extern "C" __global__ void k_hook_imu(const double *p0, const double *p1, const double *p2, const double *p3, const double *rec, const double *G,
+                                      double *out /* r[15] (whitened) J[15*30] (whitened) */, double *scratch /* 450 + 16 */) {
+    if (threadIdx.x) return;
+    double *Jr = scratch, *rr = scratch + 450;
+    imu_raw_eval<true>(p0, p1, p2, p3, rec, G, rr, Jr);
+    const double *S = rec + IMU_SQRT;
+    for (int i = 0; i < 15; i++) { double s = 0; for (int m = 0; m < 15; m++) s += S[15 * i + m] * rr[m]; out[i] = s; }
+    for (int i = 0; i < 15; i++) for (int c = 0; c < 30; c++) { double s = 0; for (int m = 0; m < 15; m++) s += S[15 * i + m] * Jr[30 * m + c]; out[15 + 30 * i + c] = s; }
+}
+extern "C" __global__ void k_hook_lidar(const double *p0, const double *p1, const double *qil, const double *til, const double *lc, double *out /* r[6] Ji[36] Jj[36] */) {
+    if (threadIdx.x) return;
+    lidar_between_eval<true>(p0, p1, q_load(qil), til, q_load(lc), lc + 4, out, out + 6, out + 42);
+}
+extern "C" __global__ void k_hook_edge(const double *pose, const double *cp, const double *pa, const double *pb, double *out /* r[3] J[18] */) {
+    if (threadIdx.x) return;
+    edge_eval<true>(pose, cp, pa, pb, out, out + 3);
+}
+extern "C" __global__ void k_hook_surf(const double *pose, const double *cp, const double *n, double d, double *out /* r[1] J[6] */) {
+    if (threadIdx.x) return;
+    surf_eval<true>(pose, cp, n, d, out, out + 1);
+}
+extern "C" __global__ void k_hook_plus(const double *x, const double *d, int kind, double *out) {
+    if (threadIdx.x) return;
+    if (kind == 0) pose_plus(x, d, out); else se3_plus(x, d, out);
+}

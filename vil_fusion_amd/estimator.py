@@ -1,0 +1,176 @@
+"""Host-side mirror of the reference's operator surface for the hot path.
+
+`BackendSolver.optimization(window)` ≙ Estimator::optimization() (vins_estimator/estimator.cpp:689-1050): solve on the
+MI355X through the C ABI, gauge fix, then (optionally) marginalization; the prior lives on the device between calls like
+`last_marginalization_info` (estimator.h:123-124). `BackendSolver.batch_*` drive many independent window snapshots.
+Errors: the C ABI returns status ints; this wrapper raises VilfError for status < 0 (invalid argument / device error /
+unsupported) and returns the summary for status >= 0, mirroring the reference where solver failures are not checked
+(estimator.cpp:852-855).
+"""
+import ctypes as C
+import numpy as np
+from . import abi
+from .lib import lib, VilfError, default_options
+
+
+class BackendSolver:
+    def __init__(self, options=None, device=0, stream=None):
+        self._L = lib()
+        self.options = options if options is not None else default_options()
+        h = C.c_void_p()
+        rc = self._L.vilf_create(C.byref(self.options), int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise VilfError(f"vilf_create failed with status {rc}" + (" (no GPU visible: the solve path has no CPU fallback)" if rc == abi.VILF_ERR_NO_GPU else ""))
+        self._h = h
+        self._keep = None
+        self._n = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vilf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise VilfError(f"{what}: status {rc}: {self._L.vilf_last_error(self._h).decode()}")
+        return rc
+
+    # ---- single window (drop-in for Estimator::optimization) -----------------------------------------------------
+    def set_prior(self, prior, slot=0):
+        """≙ last_marginalization_info / last_marginalization_parameter_blocks"""
+        if prior is None:
+            prior = abi.Prior()
+        self._check(self._L.vilf_prior_import(self._h, slot, C.byref(prior)), "vilf_prior_import")
+
+    def get_prior(self, slot=0):
+        p = abi.Prior()
+        self._check(self._L.vilf_prior_export(self._h, slot, C.byref(p)), "vilf_prior_export")
+        return p
+
+    def optimization(self, window):
+        res = abi.WindowResult(window.n_frames, window.n_features)
+        s = window.as_struct()
+        self._check(self._L.vilf_window_solve(self._h, C.byref(s), C.byref(res.struct)), "vilf_window_solve")
+        return res.finish()
+
+    def marginalize(self):
+        self._check(self._L.vilf_window_marginalize(self._h), "vilf_window_marginalize")
+
+    def reset(self):
+        """≙ Estimator::clearState() for the prior (estimator.cpp:72-77)"""
+        self._check(self._L.vilf_reset(self._h), "vilf_reset")
+
+    # ---- batch of independent window snapshots -------------------------------------------------------------------
+    def batch_upload(self, windows, priors=None):
+        n = len(windows)
+        arr = (abi.WindowIn * n)()
+        for i, w in enumerate(windows):
+            arr[i] = w.as_struct()
+        if priors is not None:
+            for i, p in enumerate(priors):
+                self.set_prior(p, i)
+        self._keep = (windows, arr)
+        self._check(self._L.vilf_batch_upload(self._h, n, arr), "vilf_batch_upload")
+        self._n = n
+        self._shapes = [(w.n_frames, w.n_features) for w in windows]
+
+    def batch_solve(self, sync=True):
+        self._check(self._L.vilf_batch_solve(self._h, 1 if sync else 0), "vilf_batch_solve")
+
+    def batch_rewind(self):
+        self._check(self._L.vilf_batch_rewind(self._h), "vilf_batch_rewind")
+
+    def synchronize(self):
+        self._check(self._L.vilf_synchronize(self._h), "vilf_synchronize")
+
+    def batch_marginalize(self, sync=True):
+        self._check(self._L.vilf_batch_marginalize(self._h, 1 if sync else 0), "vilf_batch_marginalize")
+
+    def batch_summaries(self, first=0, n=None):
+        n = self._n - first if n is None else n
+        arr = (abi.Summary * n)()
+        self._check(self._L.vilf_batch_summaries(self._h, first, n, arr), "vilf_batch_summaries")
+        return arr
+
+    def batch_download(self, first=0, n=None):
+        n = self._n - first if n is None else n
+        results = [abi.WindowResult(*self._shapes[first + i]) for i in range(n)]
+        arr = (abi.WindowOut * n)()
+        for i, r in enumerate(results):
+            arr[i] = r.struct
+        self._check(self._L.vilf_batch_download(self._h, first, n, arr), "vilf_batch_download")
+        for i, r in enumerate(results):
+            r.struct = arr[i]
+            r.finish()
+        return results
+
+    def newest_poses_to_device(self, stamps, device_ptr):
+        st = np.ascontiguousarray(stamps, dtype=np.float64)
+        self._check(self._L.vilf_batch_newest_poses_device(self._h, abi.dptr(st), C.c_void_p(device_ptr)), "vilf_batch_newest_poses_device")
+
+    # ---- Ceres-layout hooks (same signatures as the reference's Evaluate) ----------------------------------------
+    def _params(self, arrs):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+        return arrs, (abi.c_double_p * len(arrs))(*[abi.dptr(a) for a in arrs])
+
+    def eval_projection(self, params, pts_i, pts_j, want_ex_jacobian=False):
+        arrs, p = self._params(params)
+        r = np.zeros(2)
+        jacs = [np.zeros((2, 7)), np.zeros((2, 7)), np.zeros((2, 7)), np.zeros((2, 1))]
+        ptrs = [abi.dptr(jacs[0]), abi.dptr(jacs[1]), abi.dptr(jacs[2]) if want_ex_jacobian else abi.c_double_p(), abi.dptr(jacs[3])]
+        jp = (abi.c_double_p * 4)(*ptrs)
+        self._check(self._L.vilf_eval_projection(self._h, p, abi.dptr(np.ascontiguousarray(pts_i, dtype=np.float64)),
+                                                 abi.dptr(np.ascontiguousarray(pts_j, dtype=np.float64)), abi.dptr(r), jp), "vilf_eval_projection")
+        return r, jacs
+
+    def eval_imu(self, params, pre):
+        arrs, p = self._params(params)
+        r = np.zeros(15)
+        jacs = [np.zeros((15, 7)), np.zeros((15, 9)), np.zeros((15, 7)), np.zeros((15, 9))]
+        jp = (abi.c_double_p * 4)(*[abi.dptr(j) for j in jacs])
+        self._check(self._L.vilf_eval_imu(self._h, p, C.byref(pre), abi.dptr(r), jp), "vilf_eval_imu")
+        return r, jacs
+
+    def eval_lidar_between(self, params, c):
+        arrs, p = self._params(params)
+        r = np.zeros(6)
+        jacs = [np.zeros((6, 7)), np.zeros((6, 7))]
+        jp = (abi.c_double_p * 2)(*[abi.dptr(j) for j in jacs])
+        self._check(self._L.vilf_eval_lidar_between(self._h, p, C.byref(c), abi.dptr(r), jp), "vilf_eval_lidar_between")
+        return r, jacs
+
+    def eval_edge(self, pose, cp, a, b):
+        r = np.zeros(3); J = np.zeros((3, 7))
+        f = lambda x: abi.dptr(np.ascontiguousarray(x, dtype=np.float64))
+        self._check(self._L.vilf_eval_edge(self._h, f(pose), f(cp), f(a), f(b), abi.dptr(r), abi.dptr(J)), "vilf_eval_edge")
+        return r, J
+
+    def eval_surf(self, pose, cp, n, d):
+        r = np.zeros(1); J = np.zeros((1, 7))
+        f = lambda x: abi.dptr(np.ascontiguousarray(x, dtype=np.float64))
+        self._check(self._L.vilf_eval_surf(self._h, f(pose), f(cp), f(n), float(d), abi.dptr(r), abi.dptr(J)), "vilf_eval_surf")
+        return r, J
+
+    def pose_plus(self, x, d, se3=False):
+        out = np.zeros(7)
+        f = lambda v: abi.dptr(np.ascontiguousarray(v, dtype=np.float64))
+        fn = self._L.vilf_se3_plus if se3 else self._L.vilf_pose_plus
+        self._check(fn(self._h, f(x), f(d), abi.dptr(out)), "vilf_pose_plus")
+        return out
+
+
+def imu_preintegrate(noise, acc_0, gyr_0, ba, bg, dt, acc, gyr):
+    """≙ IntegrationBase (host): returns an abi.ImuPreint."""
+    out = abi.ImuPreint()
+    f = lambda v: abi.dptr(np.ascontiguousarray(v, dtype=np.float64))
+    dt = np.ascontiguousarray(dt, dtype=np.float64)
+    rc = lib().vilf_imu_preintegrate(C.byref(noise), f(acc_0), f(gyr_0), f(ba), f(bg), len(dt), abi.dptr(dt), f(acc), f(gyr), C.byref(out))
+    if rc != 0:
+        raise VilfError(f"vilf_imu_preintegrate: status {rc}")
+    return out

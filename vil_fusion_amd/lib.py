@@ -1,0 +1,83 @@
+"""ctypes loader for libvilfusion_hip.so (the product). Fails loudly: there is no CPU fallback."""
+import ctypes as C
+import os
+import subprocess
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libvilfusion_hip.so")
+_lib = None
+
+EXPORTED = [
+    "vilf_default_options", "vilf_create", "vilf_destroy", "vilf_reset", "vilf_last_error", "vilf_version",
+    "vilf_window_solve", "vilf_window_marginalize", "vilf_batch_upload", "vilf_batch_solve", "vilf_batch_rewind",
+    "vilf_batch_marginalize", "vilf_batch_download", "vilf_batch_summaries", "vilf_synchronize",
+    "vilf_batch_newest_poses_device", "vilf_prior_export", "vilf_prior_import", "vilf_eval_projection", "vilf_eval_imu",
+    "vilf_eval_lidar_between", "vilf_eval_prior", "vilf_eval_edge", "vilf_eval_surf", "vilf_pose_plus", "vilf_se3_plus",
+    "vilf_imu_preintegrate", "vilf_scan2map_init", "vilf_scan2map_step", "vilf_scan2map_get_map", "vilf_scan2map_set_pose",
+]
+
+
+class VilfError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """hipcc --offload-arch=gfx950 build of the HIP library (cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"]))
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise VilfError(f"{SO_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                        "There is no CPU fallback for the solve path.")
+    L = C.CDLL(SO_PATH)
+    vp = C.c_void_p
+    dpp = C.POINTER(abi.c_double_p)
+    L.vilf_version.restype = C.c_char_p
+    L.vilf_last_error.restype = C.c_char_p
+    L.vilf_last_error.argtypes = [vp]
+    L.vilf_default_options.argtypes = [C.POINTER(abi.Options)]
+    L.vilf_default_options.restype = None
+    L.vilf_create.argtypes = [C.POINTER(abi.Options), C.c_int, vp, C.POINTER(vp)]
+    L.vilf_destroy.argtypes = [vp]
+    L.vilf_destroy.restype = None
+    L.vilf_reset.argtypes = [vp]
+    L.vilf_window_solve.argtypes = [vp, C.POINTER(abi.WindowIn), C.POINTER(abi.WindowOut)]
+    L.vilf_window_marginalize.argtypes = [vp]
+    L.vilf_batch_upload.argtypes = [vp, C.c_int, C.POINTER(abi.WindowIn)]
+    L.vilf_batch_solve.argtypes = [vp, C.c_int]
+    L.vilf_batch_rewind.argtypes = [vp]
+    L.vilf_batch_marginalize.argtypes = [vp, C.c_int]
+    L.vilf_batch_download.argtypes = [vp, C.c_int, C.c_int, C.POINTER(abi.WindowOut)]
+    L.vilf_batch_summaries.argtypes = [vp, C.c_int, C.c_int, C.POINTER(abi.Summary)]
+    L.vilf_synchronize.argtypes = [vp]
+    L.vilf_batch_newest_poses_device.argtypes = [vp, abi.c_double_p, vp]
+    L.vilf_prior_export.argtypes = [vp, C.c_int, C.POINTER(abi.Prior)]
+    L.vilf_prior_import.argtypes = [vp, C.c_int, C.POINTER(abi.Prior)]
+    L.vilf_eval_projection.argtypes = [vp, dpp, abi.c_double_p, abi.c_double_p, abi.c_double_p, dpp]
+    L.vilf_eval_imu.argtypes = [vp, dpp, C.POINTER(abi.ImuPreint), abi.c_double_p, dpp]
+    L.vilf_eval_lidar_between.argtypes = [vp, dpp, C.POINTER(abi.LidarConstraint), abi.c_double_p, dpp]
+    L.vilf_eval_edge.argtypes = [vp, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p]
+    L.vilf_eval_surf.argtypes = [vp, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_double, abi.c_double_p, abi.c_double_p]
+    L.vilf_pose_plus.argtypes = [vp, abi.c_double_p, abi.c_double_p, abi.c_double_p]
+    L.vilf_se3_plus.argtypes = [vp, abi.c_double_p, abi.c_double_p, abi.c_double_p]
+    L.vilf_imu_preintegrate.argtypes = [C.POINTER(abi.ImuNoise), abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_int,
+                                        abi.c_double_p, abi.c_double_p, abi.c_double_p, C.POINTER(abi.ImuPreint)]
+    L.vilf_scan2map_init.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int]
+    L.vilf_scan2map_step.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(abi.Scan2MapResult)]
+    L.vilf_scan2map_get_map.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    L.vilf_scan2map_set_pose.argtypes = [vp, abi.c_double_p, abi.c_double_p]
+    _lib = L
+    return L
+
+
+def default_options():
+    o = abi.Options()
+    lib().vilf_default_options(C.byref(o))
+    return o
