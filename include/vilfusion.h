@@ -191,6 +191,9 @@ int vilf_batch_marginalize(vilf_handle *h, int sync);
 int vilf_batch_download(vilf_handle *h, int first, int n_windows, vilf_window_out *outs);
 int vilf_batch_summaries(vilf_handle *h, int first, int n_windows, vilf_summary *sums);
 int vilf_synchronize(vilf_handle *h);
+/* per-kernel timing by HIP events on the handle's stream (kind 0 linearize, 1 reduce+solve, 2 step, 3 other); needs sync solves */
+int vilf_set_profiling(vilf_handle *h, int on);
+int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]);
 /* newest-frame pose per resident window: [stamp x y z qx qy qz qw] (8 doubles each) into a DEVICE buffer
  * (feeds the RCCL gather for global_fusion, poseGraphOptimization.cpp:116-121). */
 int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8);

@@ -1,0 +1,24 @@
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+from vil_fusion_amd import synth
+from vil_fusion_amd.estimator import BackendSolver
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+s = BackendSolver()
+wins, priors = synth.make_batch(7, B, s.options, distinct=16)
+s.batch_upload(wins, priors)
+s.batch_solve()
+for rep in range(3):
+    s.batch_rewind(); t = time.time(); s.batch_solve(); dt = time.time() - t
+    its = sum(x.num_iterations for x in s.batch_summaries())
+    print("B", B, "solve ms", dt * 1e3, "iter/s", its / dt)
+import os, ctypes as C
+if os.environ.get("VILF_DEBUG_STAMPS"):
+    buf = (C.c_longlong * 96)()
+    s._L.vilf_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_longlong)]
+    s._L.vilf_debug_stamps(s._h, buf)
+    a = np.array(buf[:]).reshape(3, 32)
+    for k, name in enumerate(["linearize", "solve", "step"]):
+        v = a[k]; v = v[v != 0]
+        if len(v) > 1:
+            print(name, "phase cycles:", np.diff(v), "total", v[-1] - v[0])

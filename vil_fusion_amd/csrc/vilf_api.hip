@@ -9,6 +9,7 @@
 #include <cmath>
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include "../../include/vilfusion.h"
 #include "vilf_batch.hpp"
 
@@ -53,7 +54,7 @@ enum {
     D_NFEAT, D_NFAC, D_POSE, D_SB, D_FEAT, D_CPOSE, D_CSB, D_CFEAT, D_POSE0, D_SB0, D_FEAT0, D_EX, D_GR0, D_GP0,
     D_FSTART, D_FNOBS, D_FOBS0, D_FFAC0, D_FCONST, D_OBS, D_FACFEAT, D_FACOBS, D_PAIROFF, D_PAIRFAC, D_IMU, D_LIDAR,
     D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_JBUF, D_PAIRD, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G,
-    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_COUNT
+    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_COUNT
 };
 
 void quat_from_R(const double *m, double *q /*xyzw*/) {   // Eigen Quaterniond(Matrix3d)
@@ -99,6 +100,10 @@ struct vilf_handle {
     std::vector<int> h_nfeat, h_nframes;
     std::vector<double> h_ex, h_td;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int profiling = 0;                       // per-kernel HIP-event timing of the solve launches
+    std::vector<hipEvent_t> pev;
+    double kernel_ms[4] = {0, 0, 0, 0};      // linearize, solve, step, other (accumulated since last reset)
+    long kernel_launches[4] = {0, 0, 0, 0};
     double last_solve_usec = 0;
     size_t solve_lds = 0;
 };
@@ -360,6 +365,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.st = h->d[D_ST].as<VbState>();
     b.out_Ps = h->d[D_OPS].as<double>(); b.out_Rs = h->d[D_ORS].as<double>(); b.out_Vs = h->d[D_OVS].as<double>();
     b.out_Bas = h->d[D_OBAS].as<double>(); b.out_Bgs = h->d[D_OBGS].as<double>();
+    b.dbg = nullptr;
+    if (getenv("VILF_DEBUG_STAMPS")) { if (!h->d[D_DBG].ensure(3 * 32 * 8)) return VILF_ERR_DEVICE; hipMemset(h->d[D_DBG].p, 0, 3 * 32 * 8); b.dbg = h->d[D_DBG].as<long long>(); }
 
     const int nimu = B * 10;
     hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
@@ -370,6 +377,12 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, hipGetLastError());
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     h->resident = true;
+    return VILF_OK;
+}
+
+extern "C" int vilf_debug_stamps(vilf_handle *h, long long *out96) {
+    if (!h || !h->batch.dbg) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipMemcpy(out96, h->batch.dbg, 96 * 8, hipMemcpyDeviceToHost));
     return VILF_OK;
 }
 
@@ -387,16 +400,28 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true;
     if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; }
     const dim3 grid(h->B), block(VB_NT);
+    const int nlaunch = 3 * h->opts.max_num_iterations + 3;
+    const bool prof = h->profiling != 0;
+    if (prof && (int)h->pev.size() < nlaunch + 1) { while ((int)h->pev.size() < nlaunch + 1) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); } }
+    std::vector<int> kinds;
+    int ne = 0;
+    auto mark = [&](int kind) { if (prof) { hipEventRecord(h->pev[ne++], h->stream); kinds.push_back(kind); } };
     hipEventRecord(h->ev0, h->stream);
+    mark(3);
     hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
+    mark(0);
     hipLaunchKernelGGL(k_linearize, grid, block, 0, h->stream, h->batch, 1);
     for (int it = 0; it < h->opts.max_num_iterations; it++) {
+        mark(1);
         hipLaunchKernelGGL(k_solve, grid, block, h->solve_lds, h->stream, h->batch);
+        mark(2);
         hipLaunchKernelGGL(k_step, grid, block, 0, h->stream, h->batch);
+        mark(0);
         hipLaunchKernelGGL(k_linearize, grid, block, 0, h->stream, h->batch, 0);
     }
-    // one more pass of the iteration-begin checks so that `termination` reflects max_num_iterations
+    mark(3);
     hipLaunchKernelGGL(k_finalize, grid, dim3(64), 0, h->stream, h->batch);
+    if (prof) hipEventRecord(h->pev[ne++], h->stream);
     hipEventRecord(h->ev1, h->stream);
     HIPCHECK(h, hipGetLastError());
     if (sync) {
@@ -404,7 +429,21 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
         float ms = 0;
         hipEventElapsedTime(&ms, h->ev0, h->ev1);
         h->last_solve_usec = ms * 1000.0;
-    }
+        if (prof) for (size_t i = 0; i < kinds.size(); i++) { float t = 0; hipEventElapsedTime(&t, h->pev[i], h->pev[i + 1]); h->kernel_ms[kinds[i]] += t; h->kernel_launches[kinds[i]] += 1; }
+    } else if (prof) { h->err = "profiling needs sync != 0"; return VILF_ERR_INVALID_ARGUMENT; }
+    return VILF_OK;
+}
+
+// per-kernel timing with HIP events on the handle's stream (bench.py roofline). kind: 0 linearize, 1 solve, 2 step, 3 other
+extern "C" int vilf_set_profiling(vilf_handle *h, int on) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    h->profiling = on;
+    for (int i = 0; i < 4; i++) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
+    return VILF_OK;
+}
+extern "C" int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]) {
+    if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 4; i++) { ms_out[i] = h->kernel_ms[i]; launches_out[i] = h->kernel_launches[i]; }
     return VILF_OK;
 }
 

@@ -72,4 +72,5 @@ struct VbBatch {
     VbState *st;
     // outputs of finalize
     double *out_Ps, *out_Rs, *out_Vs, *out_Bas, *out_Bgs;
+    long long *dbg;         // optional phase stamps (s_memtime) of window 0: [kernel 0..2][32]; NULL in production
 };

@@ -21,6 +21,7 @@ using namespace vd;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define NT VB_NT
+#define STAMP(kid, i) do { if (b.dbg && blockIdx.x == 0 && threadIdx.x == 0) b.dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 __device__ __forceinline__ int pair_index(int i, int j) { return j * (j - 1) / 2 + i; }  // i < j
 // tangent index (frame a, local l in [0,15)) -> P-first permuted index: poses 0..65, speed-bias 66..164
 __device__ __forceinline__ int perm_index(int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); }
@@ -189,6 +190,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     __shared__ int s_pcol[VB_P];
     __shared__ double s_red[NT];
 
+    STAMP(0, 0);
     const int F = b.n_feat[w], nfac = b.n_fac[w];
     const size_t FM = b.Fmax, FC = b.FACmax;
     const double *pose_g = b.pose + (size_t)w * 77, *sb_g = b.sb + (size_t)w * 99;
@@ -202,6 +204,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
     prior_setup(b, w, s_pose, s_sb, s_pcol, s_dx, tid);   // contains __syncthreads
 
+    STAMP(0, 1);
     // ---- visual factors: one thread per factor (projection_factor.cpp:21-121 + Cauchy corrector) -----------------
     const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
@@ -224,6 +227,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         Jb[(size_t)24 * FC + fac] = fw * Jf[0]; Jb[(size_t)25 * FC + fac] = fw * Jf[1];
         Jb[(size_t)26 * FC + fac] = sw * r[0]; Jb[(size_t)27 * FC + fac] = sw * r[1];
     }
+    STAMP(0, 2);
     // ---- IMU (wave 0, lanes 0..9) and LiDAR between-factors (wave 1, lanes 0..9): raw evaluation -----------------
     if (tid < 10) {
         const double *rec = b.imu + ((size_t)w * 10 + tid) * IMU_REC;
@@ -243,6 +247,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         }
     }
     __syncthreads();
+    STAMP(0, 3);
     // ---- IMU: left-multiply by sqrt_info (imu_factor.h:64,93,126,145,160) ------------------------------------------
     for (int idx = tid; idx < 10 * 450; idx += NT) {
         const int k = idx / 450, e = idx - 450 * k, row = e / 30, col = e - 30 * row;
@@ -261,6 +266,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         s_imurw[16 * k + row] = s;
     }
     __syncthreads();
+    STAMP(0, 4);
     // ---- IMU / LiDAR normal-equation blocks ------------------------------------------------------------------------
     {
         double *imuH = b.imuH + (size_t)w * 9000, *imug = b.imug + (size_t)w * 300;
@@ -296,6 +302,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     if (tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
     cost_local += prior_cost_partial(b, w, s_dx, tid);
     __syncthreads();   // Jbuf written by this block is visible to the block
+    STAMP(0, 5);
     // ---- per frame-pair J^T J / J^T r (block-sparse accumulate, owner-computes: deterministic) ---------------------
     {
         const int *pair_off = b.pair_off + (size_t)w * (VB_NPAIR + 1), *pair_fac = b.pair_fac + (size_t)w * FC;
@@ -317,6 +324,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             pairD[t] = s;
         }
     }
+    STAMP(0, 6);
     // ---- per-feature Schur vectors: H_ff, g_f, H_pf row (W) --------------------------------------------------------
     {
         const int *f_nobs = b.f_nobs + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
@@ -343,6 +351,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         }
     }
     __syncthreads();
+    STAMP(0, 7);
     // ---- gradient g = J^T r over the reduced camera/IMU block (frame-major order) ---------------------------------
     double gmax = 0, xsq = 0;
     double *gout = b.g + (size_t)w * VB_P;
@@ -383,6 +392,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         const double *gf = b.gf + (size_t)w * FM;
         for (int f = tid; f < F; f += NT) if (!f_const[f]) { gmax = fmax(gmax, fabs(gf[f])); xsq += feat[f] * feat[f]; }
     }
+    STAMP(0, 8);
     const double cost = block_sum(cost_local, s_red);
     const double gm = block_max(gmax, s_red);
     const double xs = block_sum(xsq, s_red);
@@ -394,6 +404,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         st->reuse = 0;
         if (iteration_zero) { st->initial_cost = cost; }
     }
+    STAMP(0, 9);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -486,6 +497,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
     __syncthreads();
     if (!s_flag[0] || s_flag[1]) return;     // done, or the previous Gauss-Newton step is re-used (rejected step)
 
+    STAMP(1, 0);
     const int F = b.n_feat[w];
     const size_t FM = b.Fmax;
     const double *pairD = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
@@ -512,6 +524,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
     if (!scaling_ready) for (int f = tid; f < F; f += NT) scale_g[VB_P + f] = f_const[f] ? 1.0 : 1.0 / (1.0 + sqrt(hf[f]));
     __syncthreads();
 
+    STAMP(1, 1);
     double mu = st->mu;
     int tries = 0;
     bool solved = false;
@@ -536,6 +549,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             s_g[tid] = gv;
         }
         __syncthreads();
+        STAMP(1, 2);
         if (tries == 0) {
             // dogleg diagonal_ = sqrt(clamp(diag(H~))), gradient_ = g~ / diagonal_ (dogleg_strategy.cc)
             double g2 = 0;
@@ -585,6 +599,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             }
             Jg2 = block_sum(part, s_red);
         }
+        STAMP(1, 3);
         // ---- LM regularisation mu * diagonal_^2 on the reduced block; per-feature coefficients ----------------------
         if (tid < VB_P) { const int tt = tid >> 4, e = tid & 15; s_T[tile_index(tt, tt) * 256 + 17 * e] += mu * s_diag[tid] * s_diag[tid]; }
         // compact list of non-constant features is implicit: constant features get coefficient 0
@@ -604,6 +619,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             for (int f = 0; f < F; f++) { const double c = s_cf[f]; if (c != 0.0) acc += W[(size_t)f * VB_NPOSE + tid] * c * c * gf[f]; }
             s_y[tid] -= acc * s_scale[tid];
         }
+        STAMP(1, 4);
         // ---- MFMA Schur reduce: H~_pp -= U^T U over the 5x5 pose tile block (columns 0..79, pose columns 0..65) ----
         {
             const int Fk = (F + 3) & ~3;
@@ -632,6 +648,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             }
         }
         __syncthreads();
+        STAMP(1, 5);
         // ---- blocked Cholesky (lower), 11 tile steps: POTRF (wave 0) -> TRSM (row per thread) -> MFMA trailing update
         bool ok = true;
         for (int k = 0; k < VB_NTILE; k++) {
@@ -676,6 +693,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             }
             __syncthreads();
         }
+        STAMP(1, 6);
         tries++;
         if (ok) { solved = true; break; }
         mu *= 10.0;                                 // dogleg_strategy.cc: mu_ *= mu_increase_factor_
@@ -735,6 +753,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
         }
         __syncthreads();
     }
+    STAMP(1, 7);
     // ---- back-substitute the features, Gauss-Newton step = -diagonal_ .* y, reductions ------------------------------
     double gy = 0, gn2 = 0;
     if (tid < VB_P) {
@@ -763,6 +782,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
         st->gy = gy; st->gn_sqnorm = gn2; st->mu = mu; st->mu_used = mu;
         st->num_linear_solves += tries; st->solve_failed = 0; st->reuse = 1; st->scaling_ready = 1;
     }
+    STAMP(1, 8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -89,6 +89,15 @@ class BackendSolver:
     def synchronize(self):
         self._check(self._L.vilf_synchronize(self._h), "vilf_synchronize")
 
+    def set_profiling(self, on=True):
+        self._check(self._L.vilf_set_profiling(self._h, 1 if on else 0), "vilf_set_profiling")
+
+    def get_profile(self):
+        ms = (C.c_double * 4)(); n = (C.c_long * 4)()
+        self._check(self._L.vilf_get_profile(self._h, ms, n), "vilf_get_profile")
+        names = ["k_linearize", "k_solve", "k_step", "other"]
+        return {names[i]: dict(ms=ms[i], launches=n[i]) for i in range(4)}
+
     def batch_marginalize(self, sync=True):
         self._check(self._L.vilf_batch_marginalize(self._h, 1 if sync else 0), "vilf_batch_marginalize")
 
