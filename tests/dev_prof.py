@@ -22,3 +22,5 @@ if os.environ.get("VILF_DEBUG_STAMPS"):
         v = a[k]; v = v[v != 0]
         if len(v) > 1:
             print(name, "phase cycles:", np.diff(v), "total", v[-1] - v[0])
+if os.environ.get("VILF_DEBUG_STAMPS"):
+    print("linearize chunk-loop (wave 0): eval", a[2][16], "sync1", a[2][17], "mfma", a[2][18], "sync2", a[2][19])

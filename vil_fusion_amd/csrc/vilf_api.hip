@@ -52,9 +52,9 @@ struct DBuf {
 
 enum {
     D_NFEAT, D_NFAC, D_POSE, D_SB, D_FEAT, D_CPOSE, D_CSB, D_CFEAT, D_POSE0, D_SB0, D_FEAT0, D_EX, D_GR0, D_GP0,
-    D_FSTART, D_FNOBS, D_FOBS0, D_FFAC0, D_FCONST, D_OBS, D_FACFEAT, D_FACOBS, D_PAIROFF, D_PAIRFAC, D_IMU, D_LIDAR,
-    D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_JBUF, D_PAIRD, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G,
-    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_COUNT
+    D_FSTART, D_FNOBS, D_FOBS0, D_FFAC0, D_FCONST, D_OBS, D_PSFEAT, D_PSOBS, D_PSSLOT, D_PAIROFF, D_IMU, D_LIDAR,
+    D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_FACW, D_HPP, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G,
+    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV, D_COUNT
 };
 
 void quat_from_R(const double *m, double *q /*xyzw*/) {   // Eigen Quaterniond(Matrix3d)
@@ -105,7 +105,7 @@ struct vilf_handle {
     double kernel_ms[4] = {0, 0, 0, 0};      // linearize, solve, step, other (accumulated since last reset)
     long kernel_launches[4] = {0, 0, 0, 0};
     double last_solve_usec = 0;
-    size_t solve_lds = 0;
+    size_t solve_lds = 0, lin_lds = 0;
 };
 
 #define HIPCHECK(h, call)                                                                                        \
@@ -158,8 +158,10 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
     else { if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return VILF_ERR_DEVICE; } h->own_stream = true; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
-    h->solve_lds = (size_t)(66 * 256 + 5 * VB_NPAD + VB_NT + VILF_MAX_FEATURES) * sizeof(double);
-    if (hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
+    h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + VB_NT + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
+    h->lin_lds = (size_t)(2 * VB_CHUNK * VB_XLD + VB_NPAIR * VB_PAIRD) * sizeof(double);
+    if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
         delete h; return VILF_ERR_DEVICE;
     }
     std::memset(&h->batch, 0, sizeof(h->batch));
@@ -250,10 +252,10 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_NFEAT, sB * 4}, {D_NFAC, sB * 4}, {D_POSE, sB * 77 * 8}, {D_SB, sB * 99 * 8}, {D_FEAT, sB * sF * 8}, {D_CPOSE, sB * 77 * 8}, {D_CSB, sB * 99 * 8},
         {D_CFEAT, sB * sF * 8}, {D_POSE0, sB * 77 * 8}, {D_SB0, sB * 99 * 8}, {D_FEAT0, sB * sF * 8}, {D_EX, sB * 7 * 8}, {D_GR0, sB * 9 * 8}, {D_GP0, sB * 3 * 8},
         {D_FSTART, sB * sF * 4}, {D_FNOBS, sB * sF * 4}, {D_FOBS0, sB * sF * 4}, {D_FFAC0, sB * sF * 4}, {D_FCONST, sB * sF}, {D_OBS, sB * sO * 3 * 8},
-        {D_FACFEAT, sB * sC * 4}, {D_FACOBS, sB * sC * 4}, {D_PAIROFF, sB * (VB_NPAIR + 1) * 4}, {D_PAIRFAC, sB * sC * 4}, {D_IMU, sB * 10 * IMU_REC * 8},
+        {D_PSFEAT, sB * sC * 4}, {D_PSOBS, sB * sC * 4}, {D_PSSLOT, sB * sC * 4}, {D_PAIROFF, sB * (VB_NPAIR + 1) * 4}, {D_IMU, sB * 10 * IMU_REC * 8},
         {D_LIDAR, sB * 10 * 7 * 8}, {D_PHDR, sB * VB_PRIOR_HDR * 4}, {D_PX0, sB * 24 * 9 * 8}, {D_PJ, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PR, sB * VB_PRIOR_LD * 8},
-        {D_PH, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PG, sB * VB_PRIOR_LD * 8}, {D_JBUF, sB * VB_JROWS * sC * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8},
-        {D_W, sB * sF * VB_NPOSE * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
+        {D_PH, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PG, sB * VB_PRIOR_LD * 8}, {D_FACW, sB * VB_FACW * sC * 8}, {D_HPP, sB * 66 * 36 * 8},
+        {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
         {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
         {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
         {D_OBGS, sB * 33 * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8},
@@ -262,7 +264,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
 
     // ---- pack on the host ---------------------------------------------------------------------------------------
     std::vector<int> nfeat(B), nfac(B), fstart(sB * sF, 0), fnobs(sB * sF, 2), fobs0(sB * sF, 0), ffac0(sB * sF, 0), facfeat(sB * sC, 0), facobs(sB * sC, 0),
-        pairoff(sB * (VB_NPAIR + 1), 0), pairfac(sB * sC, 0);
+        pairoff(sB * (VB_NPAIR + 1), 0), psfeat(sB * sC, 0), psobs(sB * sC, 0), psslot(sB * sC, 0);
     std::vector<uint8_t> fconst(sB * sF, 1);
     std::vector<double> pose(sB * 77), sb(sB * 99), feat(sB * sF, 1.0), ex(sB * 7), gR0(sB * 9), gP0(sB * 3), obs(sB * sO * 3, 0.0), imu(sB * 10 * IMU_REC, 0.0),
         lidar(sB * 10 * 7, 0.0), cov(sB * 10 * 225, 0.0);
@@ -300,7 +302,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         for (int q = 0; q < fac; q++) {
             const int f = facfeat[(size_t)w * sC + q], t = facobs[(size_t)w * sC + q];
             const int s = in.feature_start_frame[f], j = s + (t - in.feature_obs_offset[f]);
-            pairfac[(size_t)w * sC + cur[j * (j - 1) / 2 + s]++] = q;
+            const int pos = cur[j * (j - 1) / 2 + s]++;
+            psfeat[(size_t)w * sC + pos] = f; psobs[(size_t)w * sC + pos] = t; psslot[(size_t)w * sC + pos] = q;
         }
         for (int k = 0; k < 10; k++) {
             const vilf_imu_preint &p = in.imu[k + 1];
@@ -325,8 +328,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, up(D_FSTART, fstart.data(), sB * sF * 4)); HIPCHECK(h, up(D_FNOBS, fnobs.data(), sB * sF * 4));
     HIPCHECK(h, up(D_FOBS0, fobs0.data(), sB * sF * 4)); HIPCHECK(h, up(D_FFAC0, ffac0.data(), sB * sF * 4));
     HIPCHECK(h, up(D_FCONST, fconst.data(), sB * sF)); HIPCHECK(h, up(D_OBS, obs.data(), sB * sO * 3 * 8));
-    HIPCHECK(h, up(D_FACFEAT, facfeat.data(), sB * sC * 4)); HIPCHECK(h, up(D_FACOBS, facobs.data(), sB * sC * 4));
-    HIPCHECK(h, up(D_PAIROFF, pairoff.data(), sB * (VB_NPAIR + 1) * 4)); HIPCHECK(h, up(D_PAIRFAC, pairfac.data(), sB * sC * 4));
+    HIPCHECK(h, up(D_PSFEAT, psfeat.data(), sB * sC * 4)); HIPCHECK(h, up(D_PSOBS, psobs.data(), sB * sC * 4)); HIPCHECK(h, up(D_PSSLOT, psslot.data(), sB * sC * 4));
+    HIPCHECK(h, up(D_PAIROFF, pairoff.data(), sB * (VB_NPAIR + 1) * 4));
     HIPCHECK(h, up(D_IMU, imu.data(), sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar.data(), sB * 10 * 7 * 8));
     HIPCHECK(h, up(D_COV, cov.data(), sB * 10 * 225 * 8));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -354,12 +357,12 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.ex = h->d[D_EX].as<double>(); b.gauge_R0 = h->d[D_GR0].as<double>(); b.gauge_P0 = h->d[D_GP0].as<double>();
     b.f_start = h->d[D_FSTART].as<int>(); b.f_nobs = h->d[D_FNOBS].as<int>(); b.f_obs0 = h->d[D_FOBS0].as<int>(); b.f_fac0 = h->d[D_FFAC0].as<int>();
     b.f_const = h->d[D_FCONST].as<uint8_t>(); b.obs = h->d[D_OBS].as<double>();
-    b.fac_feat = h->d[D_FACFEAT].as<int>(); b.fac_obs = h->d[D_FACOBS].as<int>();
-    b.pair_off = h->d[D_PAIROFF].as<int>(); b.pair_fac = h->d[D_PAIRFAC].as<int>();
+    b.ps_feat = h->d[D_PSFEAT].as<int>(); b.ps_obs = h->d[D_PSOBS].as<int>(); b.ps_slot = h->d[D_PSSLOT].as<int>();
+    b.pair_off = h->d[D_PAIROFF].as<int>();
     b.imu = h->d[D_IMU].as<double>(); b.lidar = h->d[D_LIDAR].as<double>();
     b.prior_hdr = h->d[D_PHDR].as<int>(); b.prior_x0 = h->d[D_PX0].as<double>(); b.prior_J = h->d[D_PJ].as<double>(); b.prior_r = h->d[D_PR].as<double>();
     b.prior_H = h->d[D_PH].as<double>(); b.prior_g = h->d[D_PG].as<double>();
-    b.Jbuf = h->d[D_JBUF].as<double>(); b.pairD = h->d[D_PAIRD].as<double>(); b.W = h->d[D_W].as<double>(); b.hf = h->d[D_HF].as<double>(); b.gf = h->d[D_GF].as<double>();
+    b.facw = h->d[D_FACW].as<double>(); b.Hpp = h->d[D_HPP].as<double>(); b.W = h->d[D_W].as<double>(); b.hf = h->d[D_HF].as<double>(); b.gf = h->d[D_GF].as<double>();
     b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>();
     b.scale = h->d[D_SCALE].as<double>(); b.diag = h->d[D_DIAG].as<double>(); b.grad = h->d[D_GRAD].as<double>(); b.gn = h->d[D_GN].as<double>();
     b.st = h->d[D_ST].as<VbState>();
@@ -368,6 +371,28 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.dbg = nullptr;
     if (getenv("VILF_DEBUG_STAMPS")) { if (!h->d[D_DBG].ensure(3 * 32 * 8)) return VILF_ERR_DEVICE; hipMemset(h->d[D_DBG].p, 0, 3 * 32 * 8); b.dbg = h->d[D_DBG].as<long long>(); }
 
+    HIPCHECK(h, hipMemsetAsync(h->d[D_W].p, 0, sB * sF * VB_WLD * 8, h->stream));   // W rows are zero outside the rewritten ranges
+    {   // static scatter tables of the tile assembly (same for every window): source element -> LDS offset, -1 = not stored
+        auto perm = [](int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); };
+        auto off = [](int r, int c) { const int tr = r >> 4, tc = c >> 4; if (tr < tc) return -1; return (tr * (tr + 1) / 2 + tc) * 256 + 16 * (r & 15) + ((c & 15) ^ (r & 15)); };
+        std::vector<int> li(9000), ll(1440), lv(2 * 2376);
+        for (int k = 0; k < 10; k++) {
+            for (int e = 0; e < 900; e++) { const int p = e / 30, q = e % 30; li[900 * k + e] = off(perm(k + p / 15, p % 15), perm(k + q / 15, q % 15)); }
+            for (int e = 0; e < 144; e++) { const int p = e / 12, q = e % 12; ll[144 * k + e] = off(perm(k + p / 6, p % 6), perm(k + q / 6, q % 6)); }
+        }
+        for (int t = 0; t < 2376; t++) {
+            const int blk = t / 36, e = t % 36, l = e / 6, m = e % 6;
+            int a = 0; while ((a + 1) * (a + 2) / 2 <= blk) a++;
+            const int bb = blk - a * (a + 1) / 2, r = 6 * a + l, c = 6 * bb + m;
+            lv[2 * t] = off(r, c);
+            lv[2 * t + 1] = (a != bb && (r >> 4) == (c >> 4)) ? off(c, r) : -1;
+        }
+        if (!h->d[D_LUTI].ensure(li.size() * 4) || !h->d[D_LUTL].ensure(ll.size() * 4) || !h->d[D_LUTV].ensure(lv.size() * 4)) return VILF_ERR_DEVICE;
+        HIPCHECK(h, hipMemcpy(h->d[D_LUTI].p, li.data(), li.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(h, hipMemcpy(h->d[D_LUTL].p, ll.data(), ll.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(h, hipMemcpy(h->d[D_LUTV].p, lv.data(), lv.size() * 4, hipMemcpyHostToDevice));
+        h->batch.lut_imu = h->d[D_LUTI].as<int>(); h->batch.lut_lid = h->d[D_LUTL].as<int>(); h->batch.lut_vis = h->d[D_LUTV].as<int>();
+    }
     const int nimu = B * 10;
     hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
     HIPCHECK(h, hipGetLastError());
@@ -410,14 +435,14 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     mark(3);
     hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
     mark(0);
-    hipLaunchKernelGGL(k_linearize, grid, block, 0, h->stream, h->batch, 1);
+    hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 1);
     for (int it = 0; it < h->opts.max_num_iterations; it++) {
         mark(1);
         hipLaunchKernelGGL(k_solve, grid, block, h->solve_lds, h->stream, h->batch);
         mark(2);
         hipLaunchKernelGGL(k_step, grid, block, 0, h->stream, h->batch);
         mark(0);
-        hipLaunchKernelGGL(k_linearize, grid, block, 0, h->stream, h->batch, 0);
+        hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 0);
     }
     mark(3);
     hipLaunchKernelGGL(k_finalize, grid, dim3(64), 0, h->stream, h->batch);

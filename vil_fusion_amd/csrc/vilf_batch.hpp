@@ -4,13 +4,17 @@
 //   state      pose[B][11*7]  sb[B][11*9]  feat[B][Fmax]          (+ *_init copies for rewind, cand_* trial point)
 //   features   f_start/f_nobs/f_obs0/f_fac0/f_const [B][Fmax]     (CSR over observations, feature_manager order)
 //   obs        obs[B][Omax][3]                                     (feature_per_frame[k].point)
-//   factors    fac_feat/fac_obs [B][FACmax]                        (one per (feature, later observation))
-//   pairs      pair_off[B][56], pair_fac[B][FACmax]                (factor ids grouped by frame pair (i<j))
+//   factors    ps_feat/ps_obs/ps_slot [B][FACmax]                  (one per (feature, later observation), SORTED BY FRAME PAIR
+//                                                                   (i<j); ps_slot = index in feature-major order)
+//   pairs      pair_off[B][56]                                     (CSR over the pair-sorted factor list)
 //   imu        imu[B][10][288]  (delta_*, bias jacobians, 15x15 sqrt_info precomputed once: imu_factor.h:64)
 //   lidar      lidar[B][10][7]
 //   prior      hdr[B][80] x0[B][24][9] J[B][160*160] r[B][160] H=J^T J [B][160*160] g=J^T r [B][160]
-//   workspace  Jbuf[B][32][FACmax] pairD[B][55][120] W[B][Fmax][66] hf gf [B][Fmax] imuH[B][10][900] imug[B][10][30]
-//              lidH[B][10][144] lidg[B][10][12] g[B][165] scale/diag/grad/gn[B][165+Fmax] st[B]
+//   workspace  facw[B][8][FACmax] (per factor: Ji^T Jf (6), Jf^T Jf, Jf^T r)  Hpp[B][66][36] (visual pose-pose blocks)
+//              W[B][Fmax][80] (H_pf rows zero-initialised at upload; the feature's frame range + column 66 = g_f are
+//              rewritten every linearization) hf gf [B][Fmax]
+//              imuH[B][10][900] imug[B][10][30] lidH[B][10][144] lidg[B][10][12] g[B][165]
+//              scale/diag/grad/gn[B][165+Fmax] st[B]
 #pragma once
 #include <stdint.h>
 
@@ -19,7 +23,10 @@
 #define VB_NPOSE 66
 #define VB_NPAIR 55         // frame pairs i<j
 #define VB_PAIRD 120        // per pair: JjJj(36) JjJi(36) JiJi(36) Jj^T r(6) Ji^T r(6)
-#define VB_JROWS 32         // Jbuf components per factor
+#define VB_FACW 8           // per-factor Schur partials
+#define VB_WLD 80           // row stride of W: 66 pose columns, column 66 = g_f, 67..79 zero (5 MFMA column tiles)
+#define VB_XLD 17           // LDS row stride (doubles) of the factor chunk [Jj(6) Ji(6) r pad]
+#define VB_CHUNK 256        // factors per LDS chunk (one per thread)
 #define VB_NT 256           // threads per window workgroup
 #define VB_NTILE 11         // 16x16 tiles per dimension (176 padded)
 #define VB_NPAD 176
@@ -61,13 +68,14 @@ struct VbBatch {
     const int *f_start, *f_nobs, *f_obs0, *f_fac0;
     const uint8_t *f_const;
     const double *obs;
-    const int *fac_feat, *fac_obs;
-    const int *pair_off, *pair_fac;
+    const int *ps_feat, *ps_obs, *ps_slot;
+    const int *pair_off;
     const double *imu, *lidar;
+    const int *lut_imu, *lut_lid, *lut_vis;   // static scatter tables: source element -> LDS tile offset (or -1)
     const int *prior_hdr;
     const double *prior_x0, *prior_J, *prior_r, *prior_H, *prior_g;
     // workspace
-    double *Jbuf, *pairD, *W, *hf, *gf, *imuH, *imug, *lidH, *lidg, *g;
+    double *facw, *Hpp, *W, *hf, *gf, *imuH, *imug, *lidH, *lidg, *g;
     double *scale, *diag, *grad, *gn;
     VbState *st;
     // outputs of finalize

@@ -147,6 +147,21 @@ VD void ypr2R(const double *ypr, double *R) {
 // ---- robust losses (Ceres loss_function.cc) -----------------------------------------------------------
 // Cauchy(a): rho0 = b log(1+s/b), rho1 = 1/(1+s/b); rho2 < 0 always => the Corrector reduces to sqrt(rho1) scaling
 // (marginalization_factor.cpp:45-49 / ceres corrector.cc).
+// 1/sqrt(x) in fp64: v_rsq_f64 seed (~2^-23 relative) + two Newton steps
+VD double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+// broadcast lane `src` (compile-time constant after unrolling) of a double through SGPRs (v_readlane_b32 x2)
+VD double readlane_f64(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
 VD void cauchy(double s, double b, double &rho0, double &sqrt_rho1) {
     double sum = 1.0 + s / b;
     rho0 = b * log(sum);
@@ -224,6 +239,79 @@ VD void projection_eval(const double *Pi, const double *Ri, const double *Pj, co
     }
 }
 
+// ---- ProjectionFactor through per-frame-pair geometry tables ---------------------------------------------------------
+// Everything in projection_factor.cpp:36-40,66-110 that depends only on the frame pair (i, j) and the extrinsic is hoisted
+// into a 42-double table per pair: A = ric^T Rj^T, ARi = A Ri, Rji = Rj^T Ri, tji = Rj^T (Pi - Pj), Rc = ric^T Rji ric,
+// tc = ric^T (Rji tic + tji - tic). A factor is then pts_camera_j = Rc (pts_i / lambda) + tc plus a few 2x3 products.
+#define PT_LD 42
+VD void pair_table(const double *Pi, const double *Ri, const double *Pj, const double *Rj, const double *ric, const double *tic, double *pt) {
+    double A[9], ARi[9], Rji[9], tji[3], T[9], Rc[9], d[3], u[3], tc[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) A[3 * i + j] = ric[i] * Rj[3 * j] + ric[3 + i] * Rj[3 * j + 1] + ric[6 + i] * Rj[3 * j + 2];
+    m3_mul(A, Ri, ARi);
+    m3_mulT(Rj, Ri, Rji);
+    d[0] = Pi[0] - Pj[0]; d[1] = Pi[1] - Pj[1]; d[2] = Pi[2] - Pj[2];
+    m3T_vec(Rj, d, tji);
+    m3_mul(Rji, ric, T);
+    m3_mulT(ric, T, Rc);
+    m3_vec(Rji, tic, u);
+    u[0] += tji[0] - tic[0]; u[1] += tji[1] - tic[1]; u[2] += tji[2] - tic[2];
+    m3T_vec(ric, u, tc);
+#pragma unroll
+    for (int k = 0; k < 9; k++) { pt[k] = A[k]; pt[9 + k] = ARi[k]; pt[18 + k] = Rji[k]; pt[30 + k] = Rc[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { pt[27 + k] = tji[k]; pt[39 + k] = tc[k]; }
+}
+template <bool JAC>
+VD void projection_eval_pair(const double *pt, const double *ric, const double *tic, const double *pts_i, const double *pts_j, double inv_dep,
+                             double sqrt_info, double *r, double *Ji, double *Jj, double *Jf) {
+    const double il = 1.0 / inv_dep;
+    const double pc_i[3] = {pts_i[0] * il, pts_i[1] * il, pts_i[2] * il};
+    double pc_j[3];
+    m3_vec(pt + 30, pc_i, pc_j);
+    pc_j[0] += pt[39]; pc_j[1] += pt[40]; pc_j[2] += pt[41];
+    const double inv_z = 1.0 / pc_j[2];
+    r[0] = sqrt_info * (pc_j[0] * inv_z - pts_j[0]);
+    r[1] = sqrt_info * (pc_j[1] * inv_z - pts_j[1]);
+    if (JAC) {
+        const double r00 = sqrt_info * inv_z, r02 = -sqrt_info * pc_j[0] * inv_z * inv_z, r12 = -sqrt_info * pc_j[1] * inv_z * inv_z;
+        const double *A = pt, *ARi = pt + 9, *Rji = pt + 18;
+        double p_imu_i[3], p_imu_j[3];
+        m3_vec(ric, pc_i, p_imu_i);
+        p_imu_i[0] += tic[0]; p_imu_i[1] += tic[1]; p_imu_i[2] += tic[2];
+        m3_vec(Rji, p_imu_i, p_imu_j);
+        p_imu_j[0] += pt[27]; p_imu_j[1] += pt[28]; p_imu_j[2] += pt[29];
+        double M[6], M2[6], N[6];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            M[j] = r00 * A[j] + r02 * A[6 + j]; M[3 + j] = r00 * A[3 + j] + r12 * A[6 + j];
+            M2[j] = r00 * ARi[j] + r02 * ARi[6 + j]; M2[3 + j] = r00 * ARi[3 + j] + r12 * ARi[6 + j];
+            N[j] = r00 * ric[3 * j] + r02 * ric[3 * j + 2]; N[3 + j] = r00 * ric[3 * j + 1] + r12 * ric[3 * j + 2];
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const double *m = M + 3 * rr, *m2 = M2 + 3 * rr, *n = N + 3 * rr;
+            double *ji = Ji + 6 * rr, *jj = Jj + 6 * rr;
+            ji[0] = m[0]; ji[1] = m[1]; ji[2] = m[2];
+            ji[3] = -(m2[1] * p_imu_i[2] - m2[2] * p_imu_i[1]);
+            ji[4] = -(-m2[0] * p_imu_i[2] + m2[2] * p_imu_i[0]);
+            ji[5] = -(m2[0] * p_imu_i[1] - m2[1] * p_imu_i[0]);
+            jj[0] = -m[0]; jj[1] = -m[1]; jj[2] = -m[2];
+            jj[3] = n[1] * p_imu_j[2] - n[2] * p_imu_j[1];
+            jj[4] = -n[0] * p_imu_j[2] + n[2] * p_imu_j[0];
+            jj[5] = n[0] * p_imu_j[1] - n[1] * p_imu_j[0];
+        }
+        // Jf = reduce * (ric^T Rj^T Ri ric) * pts_i * (-1/lambda^2) = reduce * Rc * pts_i * (-1/lambda^2)
+        double rp[3];
+        m3_vec(pt + 30, pts_i, rp);
+        const double s = -il * il;
+        Jf[0] = (r00 * rp[0] + r02 * rp[2]) * s;
+        Jf[1] = (r00 * rp[1] + r12 * rp[2]) * s;
+    }
+}
+
 // ---- lidarFactor (lidar_factor.h:19-78) -----------------------------------------------------------------
 // consts: qil (unit), til, lidar_q, lidar_t. Jacobians LOCAL 6x6 each, NOT weighted (reference quirk), residual weighted.
 template <bool JAC>
@@ -272,8 +360,8 @@ VD void lidar_between_eval(const double *posei, const double *posej, const Q &qi
 // [17..25] dp_dba, [26..34] dp_dbg, [35..43] dq_dbg, [44..52] dv_dba, [53..61] dv_dbg, [62..286] sqrt_info 15x15, [287] valid
 #define IMU_REC 288
 #define IMU_SQRT 62
-// Jraw: 15 x 30 row-major, columns [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9]
-template <bool JAC>
+// Jraw: 15 x LD row-major (LD >= 30), columns [pose_i 6 | sb_i 9 | pose_j 6 | sb_j 9]; ZERO: clear the 15 x 30 block first
+template <bool JAC, int LD = 30, bool ZERO = true>
 VD void imu_raw_eval(const double *posei, const double *sbi, const double *posej, const double *sbj, const double *rec, const double *G,
                      double *r, double *Jraw) {
     const double dt = rec[0];
@@ -305,11 +393,11 @@ VD void imu_raw_eval(const double *posei, const double *sbi, const double *posej
     r[6] = rb[0] - cdv[0]; r[7] = rb[1] - cdv[1]; r[8] = rb[2] - cdv[2];
     for (int k = 0; k < 3; k++) { r[9 + k] = sbj[3 + k] - sbi[3 + k]; r[12 + k] = sbj[6 + k] - sbi[6 + k]; }
     if (JAC) {
-        for (int k = 0; k < 450; k++) Jraw[k] = 0;
+        if (ZERO) for (int k = 0; k < 450; k++) Jraw[k] = 0;
         double RiT[9], S[9], B[9];
         q_toR(Qi_inv, RiT);
         auto put = [&](int r0, int c0, const double *m, double s) {
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jraw[(r0 + i) * 30 + c0 + j] = s * m[3 * i + j];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jraw[(r0 + i) * LD + c0 + j] = s * m[3 * i + j];
         };
         const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         // pose_i (cols 0..5)

@@ -21,6 +21,7 @@ using namespace vd;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define NT VB_NT
+#define VILF_MAX_FEATURES_DEV 1000
 #define STAMP(kid, i) do { if (b.dbg && blockIdx.x == 0 && threadIdx.x == 0) b.dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 __device__ __forceinline__ int pair_index(int i, int j) { return j * (j - 1) / 2 + i; }  // i < j
 // tangent index (frame a, local l in [0,15)) -> P-first permuted index: poses 0..65, speed-bias 66..164
@@ -29,6 +30,9 @@ __device__ __forceinline__ void unperm(int p, int &a, int &l) {
     if (p < 66) { a = p / 6; l = p - 6 * a; } else { int q = p - 66; a = q / 9; l = 6 + q - 9 * a; }
 }
 __device__ __forceinline__ int tile_index(int ta, int tb) { return ta * (ta + 1) / 2 + tb; }  // ta >= tb
+// XOR swizzle inside a 16x16 fp64 tile: element (r, c) at 16*r + (c ^ r). Row reads stay one contiguous 128-B line, column reads
+// (fixed c, 16 rows) hit 16 distinct bank pairs instead of 2 (ds_read_b64: 64 banks x 4 B; unswizzled row stride = 128 B).
+#define TIX(r, c) (16 * (r) + ((c) ^ (r)))
 
 // block-wide sum / max with a fixed reduction tree (deterministic)
 __device__ __forceinline__ double block_sum(double v, double *s_red) {
@@ -178,16 +182,42 @@ __device__ double prior_cost_partial(const VbBatch &b, int w, const double *s_dx
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_linearize
+//
+// LDS plan (dynamic): s_X  [2*VB_CHUNK rows][VB_XLD]  the chunk of robustified factor rows [Jj(6) | Ji(6) | r | 0 0 0]
+//                     s_U  union { IMU stage: 10 x [16 rows][32 cols] = [S*Jraw | S*r | 0] ;  pairD: 55 x 120 }
+// Factors arrive SORTED BY FRAME PAIR (host), so each pair's rows are contiguous in a chunk and
+//   [Jj Ji r]^T [Jj Ji r]  (13 x 13: JjJj, JjJi, JiJi, Jj^T r, Ji^T r)
+// is one v_mfma_f64_16x16x4_f64 accumulation per 4 rows: the block-sparse J^T J / J^T r accumulate on the matrix cores,
+// deterministic (each pair is owned by one wave, fixed order).
+#define LIN_LDS_DOUBLES (2 * VB_CHUNK * VB_XLD + VB_NPAIR * VB_PAIRD)
+
+__device__ __forceinline__ int pair_elem(int row, int col) {   // element of the 16x16 X^T X tile -> slot in pairD (or -1)
+    if (row < 6) {
+        if (col < 6) return 6 * row + col;
+        if (col < 12) return 36 + 6 * row + (col - 6);
+        if (col == 12) return 108 + row;
+        return -1;
+    }
+    if (row < 12) {
+        if (col >= 6 && col < 12) return 72 + 6 * (row - 6) + (col - 6);
+        if (col == 12) return 114 + (row - 6);
+    }
+    return -1;
+}
+
 extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) {
-    const int w = blockIdx.x, tid = threadIdx.x;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     VbState *st = b.st + w;
     if (!iteration_zero) { if (st->done || !st->need_linearize) return; }
 
+    extern __shared__ double s_dyn[];
+    double *s_X = s_dyn;
+    double *s_U = s_X + 2 * VB_CHUNK * VB_XLD;
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3];
-    __shared__ double s_imuJr[10 * 450], s_imuJ[10 * 450], s_imur[176], s_imurw[160];
-    __shared__ double s_lidJ[10 * 72], s_lidr[64];
+    __shared__ double s_lidJ[10 * 72], s_lidr[64], s_grad[176];
+    __shared__ double s_pt[VB_NPAIR * PT_LD];
     __shared__ double s_dx[VB_PRIOR_LD];
-    __shared__ int s_pcol[VB_P];
+    __shared__ int s_pcol[VB_P], s_poff[VB_NPAIR + 1];
     __shared__ double s_red[NT];
 
     STAMP(0, 0);
@@ -199,40 +229,30 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 
     if (tid < 77) s_pose[tid] = pose_g[tid];
     if (tid < 99) s_sb[tid] = sb_g[tid];
+    if (tid <= VB_NPAIR) s_poff[tid] = b.pair_off[(size_t)w * (VB_NPAIR + 1) + tid];
+    for (int i = tid; i < 10 * 512; i += NT) s_U[i] = 0.0;
     __syncthreads();
     if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
     if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
     prior_setup(b, w, s_pose, s_sb, s_pcol, s_dx, tid);   // contains __syncthreads
-
-    STAMP(0, 1);
-    // ---- visual factors: one thread per factor (projection_factor.cpp:21-121 + Cauchy corrector) -----------------
-    const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
-    const uint8_t *f_const = b.f_const + (size_t)w * FM;
-    const int *fac_feat = b.fac_feat + (size_t)w * FC, *fac_obs = b.fac_obs + (size_t)w * FC;
-    const double *obs = b.obs + (size_t)w * b.Omax * 3;
-    double *Jb = b.Jbuf + (size_t)w * VB_JROWS * FC;
-    double cost_local = 0;
-    for (int fac = tid; fac < nfac; fac += NT) {
-        const int f = fac_feat[fac], oj = fac_obs[fac];
-        const int fi = f_start[f], o0 = f_obs0[f], fj = fi + (oj - o0);
-        double r[2], Ji[12], Jj[12], Jf[2];
-        projection_eval<true>(s_pose + 7 * fi, s_R + 9 * fi, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_tic, obs + 3 * o0, obs + 3 * oj,
-                              feat[f], b.sqrt_info, r, Ji, Jj, Jf);
-        double rho0, sw;
-        cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
-        cost_local += 0.5 * rho0;
-        const double fw = f_const[f] ? 0.0 : sw;
-#pragma unroll
-        for (int k = 0; k < 12; k++) { Jb[(size_t)k * FC + fac] = sw * Ji[k]; Jb[(size_t)(12 + k) * FC + fac] = sw * Jj[k]; }
-        Jb[(size_t)24 * FC + fac] = fw * Jf[0]; Jb[(size_t)25 * FC + fac] = fw * Jf[1];
-        Jb[(size_t)26 * FC + fac] = sw * r[0]; Jb[(size_t)27 * FC + fac] = sw * r[1];
+    if (tid >= 128 && tid < 128 + VB_NPAIR) {               // per-frame-pair geometry tables (wave 2)
+        const int p = tid - 128;
+        int j = 1; while (j * (j + 1) / 2 <= p) j++;
+        const int i = p - j * (j - 1) / 2;
+        pair_table(s_pose + 7 * i, s_R + 9 * i, s_pose + 7 * j, s_R + 9 * j, s_ric, s_tic, s_pt + PT_LD * p);
     }
-    STAMP(0, 2);
-    // ---- IMU (wave 0, lanes 0..9) and LiDAR between-factors (wave 1, lanes 0..9): raw evaluation -----------------
-    if (tid < 10) {
-        const double *rec = b.imu + ((size_t)w * 10 + tid) * IMU_REC;
-        if (rec[287] != 0.0) imu_raw_eval<true>(s_pose + 7 * tid, s_sb + 9 * tid, s_pose + 7 * (tid + 1), s_sb + 9 * (tid + 1), rec, b.G, s_imur + 16 * tid, s_imuJr + 450 * tid);
-        else { for (int k = 0; k < 450; k++) s_imuJr[450 * tid + k] = 0; for (int k = 0; k < 15; k++) s_imur[16 * tid + k] = 0; }
+    STAMP(0, 1);
+
+    double cost_local = 0;
+    // ---- IMU raw (wave 3, lanes 0..9) and LiDAR between-factors (wave 1, lanes 0..9) ------------------------------
+    if (tid >= 192 && tid < 202) {
+        const int k = tid - 192;
+        const double *rec = b.imu + ((size_t)w * 10 + k) * IMU_REC;
+        if (rec[287] != 0.0) {
+            double r[15];
+            imu_raw_eval<true, 32, false>(s_pose + 7 * k, s_sb + 9 * k, s_pose + 7 * (k + 1), s_sb + 9 * (k + 1), rec, b.G, r, s_U + 512 * k);
+            for (int m = 0; m < 15; m++) s_U[512 * k + 32 * m + 30] = r[m];
+        }
     }
     if (tid >= 64 && tid < 74) {
         const int k = tid - 64;
@@ -247,42 +267,47 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         }
     }
     __syncthreads();
-    STAMP(0, 3);
-    // ---- IMU: left-multiply by sqrt_info (imu_factor.h:64,93,126,145,160) ------------------------------------------
-    for (int idx = tid; idx < 10 * 450; idx += NT) {
-        const int k = idx / 450, e = idx - 450 * k, row = e / 30, col = e - 30 * row;
-        const double *S = b.imu + ((size_t)w * 10 + k) * IMU_REC + IMU_SQRT + 15 * row;
-        const double *Jr = s_imuJr + 450 * k + col;
-        double s = 0;
+    STAMP(0, 2);
+    // ---- IMU: X = sqrt_info * [Jraw | r] on MFMA, in place (imu_factor.h:64,93,126,145,160) -------------------------
+    for (int task = wave; task < 20; task += 4) {
+        const int k = task >> 1, ct = task & 1;
+        double *Xk = s_U + 512 * k;
+        const double *S = b.imu + ((size_t)w * 10 + k) * IMU_REC + IMU_SQRT;
+        double av[4], bv[4];
 #pragma unroll
-        for (int m = 0; m < 15; m++) s += S[m] * Jr[30 * m];
-        s_imuJ[idx] = s;
-    }
-    if (tid < 150) {
-        const int k = tid / 15, row = tid - 15 * k;
-        const double *S = b.imu + ((size_t)w * 10 + k) * IMU_REC + IMU_SQRT + 15 * row;
-        double s = 0;
-        for (int m = 0; m < 15; m++) s += S[m] * s_imur[16 * k + m];
-        s_imurw[16 * k + row] = s;
+        for (int s4 = 0; s4 < 4; s4++) {
+            const int i = lane & 15, kk = 4 * s4 + (lane >> 4);
+            av[s4] = (i < 15 && kk < 15) ? S[15 * i + kk] : 0.0;
+            bv[s4] = Xk[32 * kk + 16 * ct + (lane & 15)];
+        }
+        double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Xk[32 * ((lane >> 4) + 4 * q) + 16 * ct + (lane & 15)] = acc[q];
     }
     __syncthreads();
-    STAMP(0, 4);
-    // ---- IMU / LiDAR normal-equation blocks ------------------------------------------------------------------------
+    STAMP(0, 3);
+    // ---- IMU: [J r]^T [J r] on MFMA -> imuH (30x30), imug (30), cost; LiDAR blocks on the VALU ------------------------
     {
         double *imuH = b.imuH + (size_t)w * 9000, *imug = b.imug + (size_t)w * 300;
-        for (int idx = tid; idx < 9000; idx += NT) {
-            const int k = idx / 900, e = idx - 900 * k, p = e / 30, q = e - 30 * p;
-            const double *J = s_imuJ + 450 * k;
-            double s = 0;
+        for (int task = wave; task < 30; task += 4) {
+            const int k = task / 3, tt = task - 3 * k;
+            const int ti = (tt == 0) ? 0 : 1, tj = (tt == 2) ? 1 : 0;
+            const double *Xk = s_U + 512 * k;
+            double4_t acc = {0, 0, 0, 0};
 #pragma unroll
-            for (int row = 0; row < 15; row++) s += J[30 * row + p] * J[30 * row + q];
-            imuH[idx] = s;
-        }
-        for (int idx = tid; idx < 300; idx += NT) {
-            const int k = idx / 30, p = idx - 30 * k;
-            double s = 0;
-            for (int row = 0; row < 15; row++) s += s_imuJ[450 * k + 30 * row + p] * s_imurw[16 * k + row];
-            imug[idx] = s;
+            for (int s4 = 0; s4 < 4; s4++) {
+                const int row = 4 * s4 + (lane >> 4);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xk[32 * row + 16 * ti + (lane & 15)], Xk[32 * row + 16 * tj + (lane & 15)], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int p = 16 * ti + (lane >> 4) + 4 * q, c = 16 * tj + (lane & 15);
+                if (p < 30 && c < 30) { imuH[900 * k + 30 * p + c] = acc[q]; if (ti != tj) imuH[900 * k + 30 * c + p] = acc[q]; }
+                if (p == 30 && c < 30) imug[30 * k + c] = acc[q];
+                if (p == 30 && c == 30) cost_local += 0.5 * acc[q];
+            }
         }
         double *lidH = b.lidH + (size_t)w * 1440, *lidg = b.lidg + (size_t)w * 120;
         for (int idx = tid; idx < 1440; idx += NT) {
@@ -298,56 +323,119 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             lidg[idx] = s;
         }
     }
-    if (tid < 10) { double s = 0; for (int m = 0; m < 15; m++) s += s_imurw[16 * tid + m] * s_imurw[16 * tid + m]; cost_local += 0.5 * s; }
     if (tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
     cost_local += prior_cost_partial(b, w, s_dx, tid);
-    __syncthreads();   // Jbuf written by this block is visible to the block
-    STAMP(0, 5);
-    // ---- per frame-pair J^T J / J^T r (block-sparse accumulate, owner-computes: deterministic) ---------------------
-    {
-        const int *pair_off = b.pair_off + (size_t)w * (VB_NPAIR + 1), *pair_fac = b.pair_fac + (size_t)w * FC;
-        double *pairD = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
-        for (int t = tid; t < VB_NPAIR * VB_PAIRD; t += NT) {
-            const int p = t / VB_PAIRD, e = t - VB_PAIRD * p;
-            int ra, rb;   // Jbuf component rows of the two operands for residual row 0 (row 1 = +6)
-            if (e < 36) { ra = 12 + e / 6; rb = 12 + e % 6; }
-            else if (e < 72) { ra = 12 + (e - 36) / 6; rb = (e - 36) % 6; }
-            else if (e < 108) { ra = (e - 72) / 6; rb = (e - 72) % 6; }
-            else if (e < 114) { ra = 12 + (e - 108); rb = 26; }
-            else { ra = (e - 114); rb = 26; }
-            const int step_b = (e < 108) ? 6 : 1;
-            double s = 0;
-            for (int q = pair_off[p]; q < pair_off[p + 1]; q++) {
-                const int fac = pair_fac[q];
-                s += Jb[(size_t)ra * FC + fac] * Jb[(size_t)rb * FC + fac] + Jb[(size_t)(ra + 6) * FC + fac] * Jb[(size_t)(rb + step_b) * FC + fac];
+    __syncthreads();
+    for (int i = tid; i < VB_NPAIR * VB_PAIRD; i += NT) s_U[i] = 0.0;     // s_U becomes pairD
+    __syncthreads();
+    STAMP(0, 4);
+    // ---- visual factors: chunks of 256 pair-sorted factors -> LDS rows -> MFMA X^T X per pair ------------------------
+    const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
+    const uint8_t *f_const = b.f_const + (size_t)w * FM;
+    const int *ps_feat = b.ps_feat + (size_t)w * FC, *ps_obs = b.ps_obs + (size_t)w * FC, *ps_slot = b.ps_slot + (size_t)w * FC;
+    const double *obs = b.obs + (size_t)w * b.Omax * 3;
+    double *facw = b.facw + (size_t)w * VB_FACW * FC;
+    double *W = b.W + (size_t)w * FM * VB_WLD;
+    long long t_eval = 0, t_sync1 = 0, t_mfma = 0, t_sync2 = 0, t_a = 0;
+    for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
+        t_a = __builtin_readcyclecounter();
+        const int q = c0 + tid;
+        double *x0 = s_X + (2 * tid) * VB_XLD, *x1 = x0 + VB_XLD;
+        if (q < nfac) {
+            const int f = ps_feat[q], oj = ps_obs[q], slot = ps_slot[q];
+            const int fi = f_start[f], o0 = f_obs0[f], fj = fi + (oj - o0);
+            double r[2], Ji[12], Jj[12], Jf[2];
+            projection_eval_pair<true>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, obs + 3 * o0, obs + 3 * oj, feat[f], b.sqrt_info, r, Ji, Jj, Jf);
+            double rho0, sw;
+            cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
+            cost_local += 0.5 * rho0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) { x0[c] = sw * Jj[c]; x0[6 + c] = sw * Ji[c]; x1[c] = sw * Jj[6 + c]; x1[6 + c] = sw * Ji[6 + c]; }
+            x0[12] = sw * r[0]; x1[12] = sw * r[1];
+            x0[13] = 0; x0[14] = 0; x0[15] = 0; x1[13] = 0; x1[14] = 0; x1[15] = 0;
+            if (!f_const[f]) {
+                const double jf0 = sw * Jf[0], jf1 = sw * Jf[1];
+                double *Wr = W + (size_t)f * VB_WLD + 6 * fj;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    Wr[c] = x0[c] * jf0 + x1[c] * jf1;                                 // H_pf block of frame j (exclusive owner)
+                    facw[(size_t)c * FC + slot] = x0[6 + c] * jf0 + x1[6 + c] * jf1;   // partial of the anchor-frame block
+                }
+                facw[(size_t)6 * FC + slot] = jf0 * jf0 + jf1 * jf1;
+                facw[(size_t)7 * FC + slot] = jf0 * x0[12] + jf1 * x1[12];
             }
-            pairD[t] = s;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; c++) { x0[c] = 0; x1[c] = 0; }
+        }
+        { long long t_b = __builtin_readcyclecounter(); t_eval += t_b - t_a; t_a = t_b; }
+        __syncthreads();
+        { long long t_b = __builtin_readcyclecounter(); t_sync1 += t_b - t_a; t_a = t_b; }
+        const int cend = min(c0 + VB_CHUNK, nfac);
+        for (int p = wave; p < VB_NPAIR; p += 4) {
+            const int lo = max(s_poff[p], c0), hi = min(s_poff[p + 1], cend);
+            if (lo >= hi) continue;
+            const int r_hi = 2 * (hi - c0);
+            double4_t acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            for (int r0 = 2 * (lo - c0); r0 < r_hi; r0 += 16) {
+                double a[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int row = r0 + 4 * u + (lane >> 4);
+                    a[u] = (row < r_hi) ? s_X[row * VB_XLD + (lane & 15)] : 0.0;
+                }
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], acc1, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) acc[q4] += acc1[q4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                const int e = pair_elem((lane >> 4) + 4 * q4, lane & 15);
+                if (e >= 0) s_U[p * VB_PAIRD + e] += acc[q4];
+            }
+        }
+        { long long t_b = __builtin_readcyclecounter(); t_mfma += t_b - t_a; t_a = t_b; }
+        __syncthreads();
+        { long long t_b = __builtin_readcyclecounter(); t_sync2 += t_b - t_a; t_a = t_b; }
+    }
+    if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
+    STAMP(0, 5);
+    // ---- visual pose-pose blocks (frame-block lower triangle) -> Hpp[66][36] ------------------------------------------
+    {
+        double *Hpp = b.Hpp + (size_t)w * 66 * 36;
+        for (int t = tid; t < 66 * 36; t += NT) {
+            const int blk = t / 36, e = t - 36 * blk;
+            int a = 0; while ((a + 1) * (a + 2) / 2 <= blk) a++;
+            const int bb = blk - a * (a + 1) / 2;
+            double s = 0;
+            if (a == bb) {
+                for (int i = 0; i < a; i++) s += s_U[pair_index(i, a) * VB_PAIRD + e];
+                for (int j = a + 1; j < VB_NF; j++) s += s_U[pair_index(a, j) * VB_PAIRD + 72 + e];
+            } else s = s_U[pair_index(bb, a) * VB_PAIRD + 36 + e];
+            Hpp[t] = s;
         }
     }
     STAMP(0, 6);
-    // ---- per-feature Schur vectors: H_ff, g_f, H_pf row (W) --------------------------------------------------------
+    // ---- per-feature Schur vectors: H_ff, g_f, anchor block of the H_pf row -------------------------------------------
     {
         const int *f_nobs = b.f_nobs + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
-        double *W = b.W + (size_t)w * FM * VB_NPOSE, *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+        double *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
         for (int f = tid; f < F; f += NT) {
             if (f_const[f]) { hf[f] = 0; gf[f] = 0; continue; }
-            double *Wr = W + (size_t)f * VB_NPOSE;
-            for (int k = 0; k < VB_NPOSE; k++) Wr[k] = 0;
-            const int fi = f_start[f], n = f_nobs[f] - 1, f0 = f_fac0[f];
-            double h = 0, g = 0, wi[6] = {0, 0, 0, 0, 0, 0};
+            const int n = f_nobs[f] - 1, f0 = f_fac0[f];
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int t = 0; t < n; t++) {
-                const int fac = f0 + t;
-                const double jf0 = Jb[(size_t)24 * FC + fac], jf1 = Jb[(size_t)25 * FC + fac];
-                h += jf0 * jf0 + jf1 * jf1;
-                g += jf0 * Jb[(size_t)26 * FC + fac] + jf1 * Jb[(size_t)27 * FC + fac];
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    wi[c] += Jb[(size_t)c * FC + fac] * jf0 + Jb[(size_t)(6 + c) * FC + fac] * jf1;
-                    Wr[6 * (fi + 1 + t) + c] = Jb[(size_t)(12 + c) * FC + fac] * jf0 + Jb[(size_t)(18 + c) * FC + fac] * jf1;
-                }
+                for (int c = 0; c < 8; c++) acc[c] += facw[(size_t)c * FC + f0 + t];
             }
-            for (int c = 0; c < 6; c++) Wr[6 * fi + c] = wi[c];
-            hf[f] = h; gf[f] = g;
+            double *Wr = W + (size_t)f * VB_WLD;
+#pragma unroll
+            for (int c = 0; c < 6; c++) Wr[6 * f_start[f] + c] = acc[c];
+            Wr[VB_NPOSE] = acc[7];                      // column 66 carries g_f through the Schur MFMA
+            hf[f] = acc[6]; gf[f] = acc[7];
         }
     }
     __syncthreads();
@@ -357,12 +445,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     double *gout = b.g + (size_t)w * VB_P;
     if (tid < VB_P) {
         const int a = tid / 15, l = tid - 15 * a;
-        const double *pairD = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
         const double *imug = b.imug + (size_t)w * 300, *lidg = b.lidg + (size_t)w * 120;
         double s = 0;
         if (l < 6) {
-            for (int i = 0; i < a; i++) s += pairD[pair_index(i, a) * VB_PAIRD + 108 + l];
-            for (int j = a + 1; j < VB_NF; j++) s += pairD[pair_index(a, j) * VB_PAIRD + 114 + l];
+            for (int i = 0; i < a; i++) s += s_U[pair_index(i, a) * VB_PAIRD + 108 + l];
+            for (int j = a + 1; j < VB_NF; j++) s += s_U[pair_index(a, j) * VB_PAIRD + 114 + l];
             if (a >= 1) s += lidg[12 * (a - 1) + 6 + l];
             if (a <= 9) s += lidg[12 * a + l];
         }
@@ -377,12 +464,12 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             s += t;
         }
         gout[tid] = s;
-        s_imur[tid] = s;     // reuse as scratch for the gradient-max-norm pass (IMU residual no longer needed)
+        s_grad[tid] = s;
     }
     __syncthreads();
     // gradient_max_norm = || x - Plus(x, -g) ||_inf (trust_region_minimizer.cc), x_norm = ||x||
     if (tid < VB_NF) {
-        const double *gp = s_imur + 15 * tid;
+        const double *gp = s_grad + 15 * tid;
         double d[6] = {-gp[0], -gp[1], -gp[2], -gp[3], -gp[4], -gp[5]}, xp[7];
         pose_plus(s_pose + 7 * tid, d, xp);
         for (int k = 0; k < 7; k++) { gmax = fmax(gmax, fabs(s_pose[7 * tid + k] - xp[k])); xsq += s_pose[7 * tid + k] * s_pose[7 * tid + k]; }
@@ -408,48 +495,23 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// reduced-system entry H[(a,l),(b,m)] (unscaled), a >= b, from the blocks k_linearize wrote
-__device__ __forceinline__ double h_entry(int a, int l, int b_, int m, const double *pairD, const double *imuH, const double *lidH,
-                                          const double *priorH, const int *s_pcol) {
-    if (a < b_) { int t = a; a = b_; b_ = t; t = l; l = m; m = t; }
-    double s = 0;
-    const bool pp = (l < 6 && m < 6);
-    if (a == b_) {
-        if (pp) {
-            for (int i = 0; i < a; i++) s += pairD[pair_index(i, a) * VB_PAIRD + 6 * l + m];
-            for (int j = a + 1; j < VB_NF; j++) s += pairD[pair_index(a, j) * VB_PAIRD + 72 + 6 * l + m];
-            if (a >= 1) s += lidH[144 * (a - 1) + 12 * (6 + l) + 6 + m];
-            if (a <= 9) s += lidH[144 * a + 12 * l + m];
-        }
-        if (a >= 1) s += imuH[900 * (a - 1) + 30 * (15 + l) + 15 + m];
-        if (a <= 9) s += imuH[900 * a + 30 * l + m];
-    } else {
-        if (pp) s += pairD[pair_index(b_, a) * VB_PAIRD + 36 + 6 * l + m];
-        if (a == b_ + 1) {
-            s += imuH[900 * b_ + 30 * (15 + l) + m];
-            if (pp) s += lidH[144 * b_ + 12 * (6 + l) + m];
-        }
-    }
-    const int pa = s_pcol[15 * a + l], pb = s_pcol[15 * b_ + m];
-    if (pa >= 0 && pb >= 0) s += priorH[pa * VB_PRIOR_LD + pb];
-    return s;
-}
+// k_solve helpers
 
 // 16x16 lower Cholesky of the diagonal tile by ONE wave, tile held in registers (4 doubles / lane), column broadcasts by
-// ds_bpermute. Lane l holds rows r = l&15, columns c = (l>>4) + 4q. Returns false if a pivot is not positive (Eigen LLT).
+// ds_bpermute, pivots through v_rsq_f64 + Newton (no fp64 sqrt / divide sequences on the critical path).
+// Lane l holds rows r = l&15, columns c = (l>>4) + 4q. Returns false if a pivot is not positive (Eigen LLT semantics).
 __device__ bool potrf_tile_wave(double *T, double *s_invd, int lane) {
     const int r = lane & 15, cq = lane >> 4;
     double v[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = T[16 * r + cq + 4 * q];
+    for (int q = 0; q < 4; q++) v[q] = T[TIX(r, cq + 4 * q)];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const int jq = j >> 2, jl = j & 3;
-        const double djj = __shfl(v[jq], jl * 16 + j, 64);
+        const double djj = readlane_f64(v[jq], jl * 16 + j);
         if (!(djj > 0.0)) ok = false;
-        const double d = sqrt(djj);
-        const double inv = 1.0 / d;
+        const double inv = rsqrt_nr(djj);
         const double Lrj = __shfl(v[jq], jl * 16 + r, 64) * inv;
         double Lcj[4];
 #pragma unroll
@@ -463,8 +525,14 @@ __device__ bool potrf_tile_wave(double *T, double *s_invd, int lane) {
         if (lane == 0) s_invd[j] = inv;
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int c = cq + 4 * q; T[16 * r + c] = (c <= r) ? v[q] : 0.0; }
+    for (int q = 0; q < 4; q++) { const int c = cq + 4 * q; T[TIX(r, c)] = (c <= r) ? v[q] : 0.0; }
     return ok;
+}
+
+// scatter-add one element of a symmetric source block into the tile matrix (lower block triangle, diagonal tiles full)
+__device__ __forceinline__ void tile_add(double *s_T, int r, int c, double v) {
+    const int tr = r >> 4, tc = c >> 4;
+    if (tr >= tc) s_T[tile_index(tr, tc) * 256 + TIX(r & 15, c & 15)] += v;
 }
 
 extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
@@ -477,9 +545,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
     double *s_scale = s_diag + VB_NPAD;
     double *s_y = s_scale + VB_NPAD;          // rhs -> solution
     double *s_invd = s_y + VB_NPAD;           // 1 / L_jj
-    double *s_red = s_invd + VB_NPAD;         // NT
-    double *s_cf = s_red + NT;                // per non-constant feature: s_f / sqrt(h~' )   (<= 1000)
-    __shared__ int s_pcol[VB_P];
+    double *s_v = s_invd + VB_NPAD;           // v = g~ ./ diagonal_^2
+    double *s_red = s_v + VB_NPAD;            // NT
+    double *s_cf = s_red + NT;                // per feature: s_f / sqrt(h~')   (0 for constant features)   [<= 1000]
+    int *s_rng = (int *)(s_cf + VILF_MAX_FEATURES_DEV);   // per feature: 6*start | (6*(start+nobs)) << 16
+    __shared__ int s_pcol[VB_P], s_pinv[VB_PRIOR_LD];
     __shared__ double s_dx[VB_PRIOR_LD];
     __shared__ int s_flag[4];
 
@@ -500,48 +570,97 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
     STAMP(1, 0);
     const int F = b.n_feat[w];
     const size_t FM = b.Fmax;
-    const double *pairD = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
+    const double *Hpp = b.Hpp + (size_t)w * 66 * 36;
     const double *imuH = b.imuH + (size_t)w * 9000, *lidH = b.lidH + (size_t)w * 1440;
     const double *priorH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
-    const double *W = b.W + (size_t)w * FM * VB_NPOSE, *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+    const double *W = b.W + (size_t)w * FM * VB_WLD, *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
+    const int *f_start = b.f_start + (size_t)w * FM, *f_nobs = b.f_nobs + (size_t)w * FM;
     double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
     double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
     const double *g_in = b.g + (size_t)w * VB_P;
+    const int *phdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    const int pn = phdr[0] ? phdr[1] : 0;
 
     prior_setup(b, w, b.pose + (size_t)w * 77, b.sb + (size_t)w * 99, s_pcol, s_dx, tid);
-
-    // Jacobi scaling (trust_region_minimizer.cc: computed once at iteration 0): 1 / (1 + sqrt(diag(J^T J)))
-    const int scaling_ready = st->scaling_ready;
-    if (tid < VB_NPAD) {
-        double sc = 1.0;
-        if (tid < VB_P) {
-            if (scaling_ready) sc = scale_g[tid];
-            else { int a, l; unperm(tid, a, l); sc = 1.0 / (1.0 + sqrt(h_entry(a, l, a, l, pairD, imuH, lidH, priorH, s_pcol))); scale_g[tid] = sc; }
-        }
-        s_scale[tid] = sc;
-    }
-    if (!scaling_ready) for (int f = tid; f < F; f += NT) scale_g[VB_P + f] = f_const[f] ? 1.0 : 1.0 / (1.0 + sqrt(hf[f]));
+    // inverse map: prior column -> permuted reduced index (-1: Ex_Pose columns, constant in the solve)
+    if (tid < VB_PRIOR_LD) s_pinv[tid] = -1;
     __syncthreads();
-
-    STAMP(1, 1);
+    if (tid < VB_P) { const int pc = s_pcol[tid]; if (pc >= 0) { const int a = tid / 15, l = tid - 15 * a; s_pinv[pc] = perm_index(a, l); } }
+    for (int f = tid; f < F; f += NT) s_rng[f] = (6 * f_start[f]) | ((6 * (f_start[f] + f_nobs[f])) << 16);
+    const int scaling_ready = st->scaling_ready;
     double mu = st->mu;
     int tries = 0;
     bool solved = false;
     double Jg2 = 0, G2 = 0;
+    STAMP(1, 1);
     for (;;) {
-        // ---- assemble H~ = S H S into 16x16 tiles (lower block triangle, diagonal tiles full) ---------------------
+        // ---- streaming assembly of H (unscaled) into 16x16 tiles: every source block is read coalesced once ------------
+        for (int i = tid; i < 66 * 256; i += NT) s_T[i] = 0.0;
+        __syncthreads();
+        if (tid < VB_NPAD - VB_P) s_T[tile_index(10, 10) * 256 + TIX(5 + tid, 5 + tid)] = 1.0;     // padding rows 165..175
+        {                                                                                     // visual pose-pose blocks
+            const int2 *lv = (const int2 *)b.lut_vis;
+            for (int t0 = tid; t0 < 66 * 36; t0 += 4 * NT) {
+                double v[4]; int2 o[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int t = t0 + u * NT; const bool in = t < 66 * 36; v[u] = in ? Hpp[t] : 0.0; o[u] = in ? lv[t] : make_int2(-1, -1); }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { if (o[u].x >= 0) s_T[o[u].x] += v[u]; if (o[u].y >= 0) s_T[o[u].y] += v[u]; }
+            }
+        }
+        __syncthreads();
+        for (int par = 0; par < 2; par++) {                                                   // IMU + LiDAR factors k = par, par+2, ...
+            for (int t0 = tid; t0 < 5 * 900; t0 += 6 * NT) {
+                double v[6]; int o[6];
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int t = t0 + u * NT; const bool in = t < 5 * 900;
+                    const int k2 = t / 900, src = 900 * (2 * k2 + par) + (t - 900 * k2);
+                    o[u] = in ? b.lut_imu[src] : -1; v[u] = in ? imuH[src] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 6; u++) if (o[u] >= 0) s_T[o[u]] += v[u];
+            }
+            for (int t = tid; t < 5 * 144; t += NT) {
+                const int k2 = t / 144, src = 144 * (2 * k2 + par) + (t - 144 * k2);
+                const int o0 = b.lut_lid[src];
+                if (o0 >= 0) s_T[o0] += lidH[src];
+            }
+            __syncthreads();
+        }
+        for (int t0 = tid; t0 < pn * pn; t0 += 4 * NT) {                                       // marginalization prior J0^T J0
+            double v[4]; int o[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int t = t0 + u * NT;
+                o[u] = -1; v[u] = 0.0;
+                if (t < pn * pn) {
+                    const int i = t / pn, j = t - pn * i;
+                    const int r = s_pinv[i], c = s_pinv[j];
+                    if (r >= 0 && c >= 0 && (r >> 4) >= (c >> 4)) { o[u] = tile_index(r >> 4, c >> 4) * 256 + TIX(r & 15, c & 15); v[u] = priorH[i * VB_PRIOR_LD + j]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (o[u] >= 0) s_T[o[u]] += v[u];
+        }
+        __syncthreads();
+        STAMP(1, 2);
+        // Jacobi scaling (trust_region_minimizer.cc: computed once, at iteration 0): 1 / (1 + sqrt(diag(J^T J)))
+        if (tid < VB_NPAD) {
+            double sc = 1.0;
+            if (tid < VB_P) {
+                if (scaling_ready || tries > 0) sc = scale_g[tid];
+                else { sc = 1.0 / (1.0 + sqrt(s_T[tile_index(tid >> 4, tid >> 4) * 256 + TIX(tid & 15, tid & 15)])); scale_g[tid] = sc; }
+            }
+            s_scale[tid] = sc;
+        }
+        if (!scaling_ready && tries == 0) for (int f = tid; f < F; f += NT) scale_g[VB_P + f] = f_const[f] ? 1.0 : 1.0 / (1.0 + sqrt(hf[f]));
+        __syncthreads();
         for (int t = 0; t < 66; t++) {
             int ta = 0; while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
             const int tb = t - ta * (ta + 1) / 2;
-            const int pr = 16 * ta + (tid >> 4), pc = 16 * tb + (tid & 15);
-            double v = 0;
-            if (pr < VB_P && pc < VB_P) {
-                int a, l, bb, m;
-                unperm(pr, a, l); unperm(pc, bb, m);
-                v = h_entry(a, l, bb, m, pairD, imuH, lidH, priorH, s_pcol) * s_scale[pr] * s_scale[pc];
-            } else if (pr == pc) v = 1.0;
-            s_T[t * 256 + tid] = v;
+            s_T[t * 256 + TIX(tid >> 4, tid & 15)] *= s_scale[16 * ta + (tid >> 4)] * s_scale[16 * tb + (tid & 15)];
         }
         if (tid < VB_NPAD) {
             double gv = 0;
@@ -549,21 +668,42 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             s_g[tid] = gv;
         }
         __syncthreads();
-        STAMP(1, 2);
         if (tries == 0) {
             // dogleg diagonal_ = sqrt(clamp(diag(H~))), gradient_ = g~ / diagonal_ (dogleg_strategy.cc)
             double g2 = 0;
             if (tid < VB_NPAD) {
-                double d = 1.0;
+                double d = 1.0, vv = 0.0;
                 if (tid < VB_P) {
                     const int tt = tid >> 4, e = tid & 15;
-                    d = sqrt(fmin(fmax(s_T[tile_index(tt, tt) * 256 + 17 * e], b.min_lm_diagonal), b.max_lm_diagonal));
+                    d = sqrt(fmin(fmax(s_T[tile_index(tt, tt) * 256 + TIX(e, e)], b.min_lm_diagonal), b.max_lm_diagonal));
                     diag_g[tid] = d;
                     const double gr = s_g[tid] / d;
                     grad_g[tid] = gr;
                     g2 += gr * gr;
+                    vv = gr / d;
                 }
                 s_diag[tid] = d;
+                s_v[tid] = vv;
+            }
+            __syncthreads();
+            // Cauchy point: alpha = ||gradient_||^2 / || J~ (gradient_ ./ diagonal_) ||^2 ; v = g~ ./ diagonal_^2
+            // v^T H~ v = v_p^T H~_pp v_p + 2 sum_f v_f (w~_f . v_p) + sum_f h~_f v_f^2
+            double part = 0;
+            if (tid < VB_P) {
+                double t = 0;
+                const int ta = tid >> 4, ea = tid & 15;
+                for (int tb = 0; tb < VB_NTILE; tb++) {
+                    if (ta >= tb) {
+                        const double *T = s_T + tile_index(ta, tb) * 256;
+#pragma unroll
+                        for (int e = 0; e < 16; e++) t += T[TIX(ea, e)] * s_v[16 * tb + e];
+                    } else {
+                        const double *T = s_T + tile_index(tb, ta) * 256;
+#pragma unroll
+                        for (int e = 0; e < 16; e++) t += T[TIX(e, ea)] * s_v[16 * tb + e];
+                    }
+                }
+                part = t * s_v[tid];
             }
             for (int f = tid; f < F; f += NT) {
                 if (f_const[f]) continue;
@@ -573,78 +713,87 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
                 const double gr = sf * gf[f] / d;
                 grad_g[VB_P + f] = gr;
                 g2 += gr * gr;
-            }
-            G2 = block_sum(g2, s_red);
-            // Cauchy point: alpha = ||gradient_||^2 / || J~ (gradient_ ./ diagonal_) ||^2 ; v = g~ ./ diagonal_^2
-            // v^T H~ v = v_p^T H~_pp v_p + 2 sum_f v_f (w~_f . v_p) + sum_f h~_f v_f^2
-            double part = 0;
-            if (tid < VB_P) {
-                double t = 0;
-                const int ta = tid >> 4, ea = tid & 15;
-                for (int c = 0; c < VB_P; c++) {
-                    const int tb = c >> 4, eb = c & 15;
-                    const double hv = (ta >= tb) ? s_T[tile_index(ta, tb) * 256 + 16 * ea + eb] : s_T[tile_index(tb, ta) * 256 + 16 * eb + ea];
-                    t += hv * (s_g[c] / (s_diag[c] * s_diag[c]));
-                }
-                part = t * (s_g[tid] / (s_diag[tid] * s_diag[tid]));
-            }
-            for (int f = tid; f < F; f += NT) {
-                if (f_const[f]) continue;
-                const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
-                const double vf = sf * gf[f] / (df * df);
-                const double *Wr = W + (size_t)f * VB_NPOSE;
+                const double vf = gr / d;
+                const double *Wr = W + (size_t)f * VB_WLD;
+                const int lo = s_rng[f] & 0xffff, hi = s_rng[f] >> 16;
                 double dotp = 0;
-                for (int p = 0; p < VB_NPOSE; p++) dotp += Wr[p] * s_scale[p] * (s_g[p] / (s_diag[p] * s_diag[p]));
+                for (int p = lo; p < hi; p += 6) {
+                    double wv[6];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) wv[c] = Wr[p + c];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) dotp += wv[c] * s_scale[p + c] * s_v[p + c];
+                }
                 part += vf * (2.0 * sf * dotp + sf * sf * hf[f] * vf);
             }
+            G2 = block_sum(g2, s_red);
             Jg2 = block_sum(part, s_red);
         }
         STAMP(1, 3);
         // ---- LM regularisation mu * diagonal_^2 on the reduced block; per-feature coefficients ----------------------
-        if (tid < VB_P) { const int tt = tid >> 4, e = tid & 15; s_T[tile_index(tt, tt) * 256 + 17 * e] += mu * s_diag[tid] * s_diag[tid]; }
-        // compact list of non-constant features is implicit: constant features get coefficient 0
+        if (tid < VB_P) { const int tt = tid >> 4, e = tid & 15; s_T[tile_index(tt, tt) * 256 + TIX(e, e)] += mu * s_diag[tid] * s_diag[tid]; }
         for (int f = tid; f < F; f += NT) {
             double c = 0;
             if (!f_const[f]) {
                 const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
-                c = sf / sqrt(sf * sf * hf[f] + mu * df * df);
+                c = sf * rsqrt_nr(sf * sf * hf[f] + mu * df * df);
             }
             s_cf[f] = c;
         }
         if (tid < VB_NPAD) s_y[tid] = s_g[tid];
         __syncthreads();
-        // rhs_p -= sum_f u_f[p] * (g~_f / sqrt(h~'_f)),  u_f = c_f * S_p * W_f
-        if (tid < VB_NPOSE) {
-            double acc = 0;
-            for (int f = 0; f < F; f++) { const double c = s_cf[f]; if (c != 0.0) acc += W[(size_t)f * VB_NPOSE + tid] * c * c * gf[f]; }
-            s_y[tid] -= acc * s_scale[tid];
-        }
         STAMP(1, 4);
-        // ---- MFMA Schur reduce: H~_pp -= U^T U over the 5x5 pose tile block (columns 0..79, pose columns 0..65) ----
+        // ---- MFMA Schur reduce: H~_pp -= U^T U and rhs_p -= U^T t over the 5x5 pose tile block -------------------------
+        // U row f: columns 0..65 = c_f * S_p * W_f[p] (inside the feature's frame range), column 66 = c_f * g_f (the rhs
+        // rides along as one extra column of the same MFMA); columns 67..79 = 0.
         {
             const int Fk = (F + 3) & ~3;
-            for (int tp = wave; tp < 15; tp += 4) {
-                int ta = 0; while ((ta + 1) * (ta + 2) / 2 <= tp) ta++;
-                const int tb = tp - ta * (ta + 1) / 2;
-                const int ca = 16 * ta + (lane & 15), cb = 16 * tb + (lane & 15);
-                const double sa = (ca < VB_NPOSE) ? s_scale[ca] : 0.0, sb2 = (cb < VB_NPOSE) ? s_scale[cb] : 0.0;
-                double4_t acc = {0, 0, 0, 0};
-                for (int f0 = 0; f0 < Fk; f0 += 4) {
-                    const int f = f0 + (lane >> 4);
-                    double av = 0, bv = 0;
-                    if (f < F) {
-                        const double c = s_cf[f];
-                        if (c != 0.0) {
-                            const double *Wr = W + (size_t)f * VB_NPOSE;
-                            if (ca < VB_NPOSE) av = Wr[ca] * c * sa;
-                            if (cb < VB_NPOSE) bv = Wr[cb] * c * sb2;
-                        }
-                    }
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            const int c16 = lane & 15;
+            double sc5[5];
+#pragma unroll
+            for (int t5 = 0; t5 < 5; t5++) { const int col = 16 * t5 + c16; sc5[t5] = (col < VB_NPOSE) ? s_scale[col] : (col == VB_NPOSE ? 1.0 : 0.0); }
+            // tile pairs of this wave: tp = wave, wave+4, ... (15 pairs: (ta,tb), ta >= tb, over 5 column tiles)
+            double4_t acc[4];
+            int pta[4], ptb[4], npair = 0;
+            for (int tp = wave; tp < 15; tp += 4) { int ta = 0; while ((ta + 1) * (ta + 2) / 2 <= tp) ta++; pta[npair] = ta; ptb[npair] = tp - ta * (ta + 1) / 2; npair++; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = double4_t{0, 0, 0, 0};
+            // unconditional coalesced loads of the zero-padded W rows (80 doubles), software-pipelined one k-step ahead
+            double un[5];
+            {
+                const int f = lane >> 4;
+                const double c = (f < F) ? s_cf[f] : 0.0;
+                const double *Wr = W + (size_t)f * VB_WLD + c16;
+#pragma unroll
+                for (int t5 = 0; t5 < 5; t5++) un[t5] = Wr[16 * t5] * c * sc5[t5];
+            }
+            for (int f0 = 0; f0 < Fk; f0 += 4) {
+                double u[5];
+#pragma unroll
+                for (int t5 = 0; t5 < 5; t5++) u[t5] = un[t5];
+                if (f0 + 4 < Fk) {
+                    const int f = f0 + 4 + (lane >> 4);
+                    const double c = (f < F) ? s_cf[f] : 0.0;
+                    const double *Wr = W + (size_t)f * VB_WLD + c16;
+#pragma unroll
+                    for (int t5 = 0; t5 < 5; t5++) un[t5] = Wr[16 * t5] * c * sc5[t5];
                 }
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (i < npair) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[pta[i]], u[ptb[i]], acc[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (i >= npair) continue;
+                const int ta = pta[i], tb = ptb[i];
                 double *T = s_T + tile_index(ta, tb) * 256;
 #pragma unroll
-                for (int q = 0; q < 4; q++) T[16 * ((lane >> 4) + 4 * q) + (lane & 15)] -= acc[q];
+                for (int q = 0; q < 4; q++) {
+                    const int row = 16 * ta + (lane >> 4) + 4 * q, col = 16 * tb + c16;
+                    if (row < VB_NPOSE) {
+                        if (col < VB_NPOSE) T[TIX(row & 15, c16)] -= acc[i][q];
+                    } else if (row == VB_NPOSE && col < VB_NPOSE) s_y[col] -= acc[i][q];   // row 66 = t^T U: the rhs reduction
+                }
             }
         }
         __syncthreads();
@@ -659,17 +808,19 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             const int nrows = (VB_NTILE - 1 - k) * 16;
             if (tid < nrows) {
                 const int ti = k + 1 + (tid >> 4), rr = tid & 15;
-                double *row = s_T + tile_index(ti, k) * 256 + 16 * rr;
+                double *Tik = s_T + tile_index(ti, k) * 256;
                 double x[16];
 #pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    double s = row[c];
+                for (int c = 0; c < 16; c++) x[c] = Tik[TIX(rr, c)];
 #pragma unroll
-                    for (int p = 0; p < c; p++) s -= x[p] * Tkk[16 * c + p];
+                for (int c = 0; c < 16; c++) {
+                    double s = x[c];
+#pragma unroll
+                    for (int p = 0; p < c; p++) s -= x[p] * Tkk[TIX(c, p)];
                     x[c] = s * s_invd[16 * k + c];
                 }
 #pragma unroll
-                for (int c = 0; c < 16; c++) row[c] = x[c];
+                for (int c = 0; c < 16; c++) Tik[TIX(rr, c)] = x[c];
             }
             __syncthreads();
             const int nt = VB_NTILE - 1 - k, ntile = nt * (nt + 1) / 2;
@@ -681,15 +832,15 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
                 const double *A = s_T + tile_index(ti, k) * 256, *Bm = s_T + tile_index(tj, k) * 256;
                 double4_t acc;
 #pragma unroll
-                for (int q = 0; q < 4; q++) acc[q] = C[16 * ((lane >> 4) + 4 * q) + (lane & 15)];
+                for (int q = 0; q < 4; q++) acc[q] = C[TIX((lane >> 4) + 4 * q, lane & 15)];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; s4++) {
-                    const double av = -A[16 * (lane & 15) + 4 * s4 + (lane >> 4)];
-                    const double bv = Bm[16 * (lane & 15) + 4 * s4 + (lane >> 4)];
+                    const double av = -A[TIX(lane & 15, 4 * s4 + (lane >> 4))];
+                    const double bv = Bm[TIX(lane & 15, 4 * s4 + (lane >> 4))];
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) C[16 * ((lane >> 4) + 4 * q) + (lane & 15)] = acc[q];
+                for (int q = 0; q < 4; q++) C[TIX((lane >> 4) + 4 * q, lane & 15)] = acc[q];
             }
             __syncthreads();
         }
@@ -704,16 +855,20 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
         if (tid == 0) { st->solve_failed = 1; st->mu = mu; st->num_linear_solves += tries; st->scaling_ready = 1; st->grad_sqnorm = G2; st->Jg2 = Jg2; }
         return;
     }
-    // ---- forward / backward substitution on the tiles (rhs in s_y) --------------------------------------------------
+    // ---- forward / backward substitution on the tiles (rhs in s_y); diagonal tiles by wave 0 through SGPR broadcasts ----
     for (int k = 0; k < VB_NTILE; k++) {            // L z = rhs
         if (wave == 0) {
             const double *Tkk = s_T + tile_index(k, k) * 256;
-            double x = (lane < 16) ? s_y[16 * k + lane] : 0.0;
+            const int l16 = lane & 15;
+            double Lr[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) Lr[j] = Tkk[TIX(l16, j)];
+            double x = s_y[16 * k + l16];
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                const double xj = __shfl(x, j, 64) * s_invd[16 * k + j];
-                if (lane == j) x = xj;
-                else if (lane > j && lane < 16) x -= Tkk[16 * lane + j] * xj;
+                const double xj = readlane_f64(x, j) * s_invd[16 * k + j];
+                if (l16 == j) x = xj;
+                else if (l16 > j) x -= Lr[j] * xj;
             }
             if (lane < 16) s_y[16 * k + lane] = x;
         }
@@ -721,10 +876,10 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
         const int nrows = (VB_NTILE - 1 - k) * 16;
         if (tid < nrows) {
             const int ti = k + 1 + (tid >> 4), rr = tid & 15;
-            const double *row = s_T + tile_index(ti, k) * 256 + 16 * rr;
+            const double *Tik = s_T + tile_index(ti, k) * 256;
             double s = 0;
 #pragma unroll
-            for (int c = 0; c < 16; c++) s += row[c] * s_y[16 * k + c];
+            for (int c = 0; c < 16; c++) s += Tik[TIX(rr, c)] * s_y[16 * k + c];
             s_y[16 * ti + rr] -= s;
         }
         __syncthreads();
@@ -732,12 +887,16 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
     for (int k = VB_NTILE - 1; k >= 0; k--) {       // L^T y = z
         if (wave == 0) {
             const double *Tkk = s_T + tile_index(k, k) * 256;
-            double x = (lane < 16) ? s_y[16 * k + lane] : 0.0;
+            const int l16 = lane & 15;
+            double Lc[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) Lc[j] = Tkk[TIX(j, l16)];
+            double x = s_y[16 * k + l16];
 #pragma unroll
             for (int j = 15; j >= 0; j--) {
-                const double xj = __shfl(x, j, 64) * s_invd[16 * k + j];
-                if (lane == j) x = xj;
-                else if (lane < j) x -= Tkk[16 * j + lane] * xj;
+                const double xj = readlane_f64(x, j) * s_invd[16 * k + j];
+                if (l16 == j) x = xj;
+                else if (l16 < j) x -= Lc[j] * xj;
             }
             if (lane < 16) s_y[16 * k + lane] = x;
         }
@@ -748,7 +907,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
             const double *T = s_T + tile_index(k, tj) * 256;
             double s = 0;
 #pragma unroll
-            for (int r2 = 0; r2 < 16; r2++) s += T[16 * r2 + cc] * s_y[16 * k + r2];
+            for (int r2 = 0; r2 < 16; r2++) s += T[TIX(r2, cc)] * s_y[16 * k + r2];
             s_y[16 * tj + cc] -= s;
         }
         __syncthreads();
@@ -766,9 +925,16 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
         if (f_const[f]) continue;
         const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
         const double hp = sf * sf * hf[f] + mu * df * df;
-        const double *Wr = W + (size_t)f * VB_NPOSE;
+        const double *Wr = W + (size_t)f * VB_WLD;
+        const int lo = s_rng[f] & 0xffff, hi = s_rng[f] >> 16;
         double dotp = 0;
-        for (int p = 0; p < VB_NPOSE; p++) dotp += Wr[p] * s_scale[p] * s_y[p];
+        for (int p = lo; p < hi; p += 6) {
+            double wv[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) wv[c] = Wr[p + c];
+#pragma unroll
+            for (int c = 0; c < 6; c++) dotp += wv[c] * s_scale[p + c] * s_y[p + c];
+        }
         const double gt = sf * gf[f];
         const double y = (gt - sf * dotp) / hp;
         gn_g[VB_P + f] = -df * y;
@@ -792,7 +958,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_step(VbBatch b) {
     VbState *st = b.st + w;
     if (st->done) return;
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3], s_step[VB_P];
-    __shared__ double s_red[NT], s_dx[VB_PRIOR_LD], s_coef[4];
+    __shared__ double s_red[NT], s_dx[VB_PRIOR_LD], s_coef[4], s_pt[VB_NPAIR * PT_LD];
     __shared__ int s_pcol[VB_P], s_flag[2];
     const int F = b.n_feat[w], nfac = b.n_fac[w];
     const size_t FM = b.Fmax, FC = b.FACmax;
@@ -877,17 +1043,23 @@ extern "C" __global__ __launch_bounds__(NT) void k_step(VbBatch b) {
     if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
     if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
     prior_setup(b, w, s_pose, s_sb, s_pcol, s_dx, tid);
+    if (tid >= 128 && tid < 128 + VB_NPAIR) {
+        const int p = tid - 128;
+        int j = 1; while (j * (j + 1) / 2 <= p) j++;
+        const int i = p - j * (j - 1) / 2;
+        pair_table(s_pose + 7 * i, s_R + 9 * i, s_pose + 7 * j, s_R + 9 * j, s_ric, s_tic, s_pt + PT_LD * p);
+    }
+    __syncthreads();
     double cost_local = 0;
     {
         const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
-        const int *fac_feat = b.fac_feat + (size_t)w * FC, *fac_obs = b.fac_obs + (size_t)w * FC;
+        const int *fac_feat = b.ps_feat + (size_t)w * FC, *fac_obs = b.ps_obs + (size_t)w * FC;
         const double *obs = b.obs + (size_t)w * b.Omax * 3;
         for (int fac = tid; fac < nfac; fac += NT) {
             const int f = fac_feat[fac], oj = fac_obs[fac];
             const int fi = f_start[f], o0 = f_obs0[f], fj = fi + (oj - o0);
             double r[2];
-            projection_eval<false>(s_pose + 7 * fi, s_R + 9 * fi, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_tic, obs + 3 * o0, obs + 3 * oj,
-                                   cfeat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);
+            projection_eval_pair<false>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, obs + 3 * o0, obs + 3 * oj, cfeat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             cost_local += 0.5 * rho0;
@@ -1005,9 +1177,10 @@ extern "C" __global__ void k_reset(VbBatch b, int rewind_state) {
 extern "C" __global__ void k_hook_projection(const double *p0, const double *p1, const double *p2, double lam, const double *pi, const double *pj,
                                              double sqrt_info, double *out /* r[2] Ji[12] Jj[12] Jf[2] */) {
     if (threadIdx.x) return;
-    double Ri[9], Rj[9], ric[9];
+    double Ri[9], Rj[9], ric[9], pt[PT_LD];
     q_toR(q_load(p0 + 3), Ri); q_toR(q_load(p1 + 3), Rj); q_toR(q_load(p2 + 3), ric);
-    projection_eval<true>(p0, Ri, p1, Rj, ric, p2, pi, pj, lam, sqrt_info, out, out + 2, out + 14, out + 26);
+    pair_table(p0, Ri, p1, Rj, ric, p2, pt);
+    projection_eval_pair<true>(pt, ric, p2, pi, pj, lam, sqrt_info, out, out + 2, out + 14, out + 26);
 }
 extern "C" __global__ void k_hook_imu(const double *p0, const double *p1, const double *p2, const double *p3, const double *rec, const double *G,
                                       double *out /* r[15] (whitened) J[15*30] (whitened) */, double *scratch /* 450 + 16 */) {
