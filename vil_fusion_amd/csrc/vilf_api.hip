@@ -24,6 +24,9 @@ __global__ void k_solve(VbBatch b);
 __global__ void k_step(VbBatch b);
 __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
+__global__ void k_marg_prepare(VbBatch b, VbMarg g);
+__global__ void k_marg_schur(VbBatch b, VbMarg g);
+__global__ void k_marg_finish(VbBatch b, VbMarg g);
 __global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
 __global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
 __global__ void k_hook_lidar(const double *, const double *, const double *, const double *, const double *, double *);
@@ -54,7 +57,8 @@ enum {
     D_NFEAT, D_NFAC, D_POSE, D_SB, D_FEAT, D_CPOSE, D_CSB, D_CFEAT, D_POSE0, D_SB0, D_FEAT0, D_EX, D_GR0, D_GP0,
     D_FSTART, D_FNOBS, D_FOBS0, D_FFAC0, D_FCONST, D_OBS, D_PSFEAT, D_PSOBS, D_PSSLOT, D_PAIROFF, D_IMU, D_LIDAR,
     D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_FACW, D_HPP, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G,
-    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV, D_COUNT
+    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV,
+    D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR, D_COUNT
 };
 
 void quat_from_R(const double *m, double *q /*xyzw*/) {   // Eigen Quaterniond(Matrix3d)
@@ -97,6 +101,11 @@ struct vilf_handle {
     bool resident = false;
     std::vector<vilf_prior> priors;          // per slot (host mirror)
     std::vector<char> prior_dirty;
+    std::vector<char> prior_dev_newer;       // slot's prior was produced on the device (marginalize) and not yet mirrored
+    std::vector<int> h_mflag;
+    int mg_Mcap = 0;
+    VbMarg marg;
+    size_t marg_lds_schur = 0, marg_lds_finish = 0;
     std::vector<int> h_nfeat, h_nframes;
     std::vector<double> h_ex, h_td;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -160,6 +169,10 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + VB_NT + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
     h->lin_lds = (size_t)(2 * VB_CHUNK * VB_XLD + VB_NPAIR * VB_PAIRD) * sizeof(double);
+    h->marg_lds_schur = (size_t)MG_MLDS * MG_MLDS * sizeof(double);
+    h->marg_lds_finish = (size_t)2 * (MG_NK + 2) * (MG_NK + 2) * sizeof(double);
+    if (hipFuncSetAttribute((const void *)k_marg_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_schur) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
         delete h; return VILF_ERR_DEVICE;
@@ -186,6 +199,7 @@ extern "C" int vilf_reset(vilf_handle *h) {
     if (!h) return VILF_ERR_INVALID_ARGUMENT;
     for (auto &p : h->priors) p.valid = 0;
     std::fill(h->prior_dirty.begin(), h->prior_dirty.end(), 1);
+    std::fill(h->prior_dev_newer.begin(), h->prior_dev_newer.end(), 0);
     return VILF_OK;
 }
 
@@ -195,7 +209,29 @@ extern "C" int vilf_synchronize(vilf_handle *h) {
     return VILF_OK;
 }
 
+static int pull_device_priors(vilf_handle *h) {
+    if (!h->resident) return VILF_OK;
+    for (int w = 0; w < h->B && w < (int)h->prior_dev_newer.size(); w++) {
+        if (!h->prior_dev_newer[w]) continue;
+        vilf_prior &p = h->priors[w];
+        std::memset(&p, 0, sizeof(p));
+        int hdr[VB_PRIOR_HDR];
+        HIPCHECK(h, hipMemcpy(hdr, h->d[D_PHDR].as<int>() + (size_t)w * VB_PRIOR_HDR, sizeof(hdr), hipMemcpyDeviceToHost));
+        p.valid = hdr[0]; p.n = hdr[1]; p.n_blocks = hdr[2];
+        if (p.valid) {
+            std::vector<double> x0(24 * 9);
+            HIPCHECK(h, hipMemcpy(x0.data(), h->d[D_PX0].as<double>() + (size_t)w * 24 * 9, x0.size() * 8, hipMemcpyDeviceToHost));
+            for (int i = 0; i < p.n_blocks; i++) { p.block_id[i] = hdr[3 + i]; p.block_size[i] = hdr[27 + i]; p.block_idx[i] = hdr[51 + i]; for (int k = 0; k < 9; k++) p.block_x0[i][k] = x0[i * 9 + k]; }
+            HIPCHECK(h, hipMemcpy(p.linearized_jacobians, h->d[D_PJ].as<double>() + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, sizeof(double) * p.n * p.n, hipMemcpyDeviceToHost));
+            HIPCHECK(h, hipMemcpy(p.linearized_residuals, h->d[D_PR].as<double>() + (size_t)w * VB_PRIOR_LD, sizeof(double) * p.n, hipMemcpyDeviceToHost));
+        }
+        h->prior_dev_newer[w] = 0;
+    }
+    return VILF_OK;
+}
+
 static int upload_priors(vilf_handle *h) {
+    { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
     const int B = h->B;
     std::vector<int> hdr((size_t)B * VB_PRIOR_HDR, 0);
     std::vector<double> x0((size_t)B * 24 * 9, 0.0), J((size_t)B * VB_PRIOR_LD * VB_PRIOR_LD, 0.0), r((size_t)B * VB_PRIOR_LD, 0.0);
@@ -226,6 +262,7 @@ static int upload_priors(vilf_handle *h) {
 extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wins) {
     if (!h || B <= 0 || !wins) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipSetDevice(h->device));
+    { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
     int Fmax = 4, Omax = 4, FACmax = 4;
     for (int w = 0; w < B; w++) {
         const vilf_window_in &in = wins[w];
@@ -246,6 +283,17 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     h->resident = false;
     if ((int)h->priors.size() < B) { vilf_prior z; std::memset(&z, 0, sizeof(z)); h->priors.resize(B, z); }
     h->prior_dirty.assign(h->priors.size(), 1);
+    h->prior_dev_newer.assign(h->priors.size(), 0);
+    h->h_mflag.assign(B, 0);
+    int Mcap = 2;
+    for (int w = 0; w < B; w++) {
+        int mf = 0;
+        for (int f = 0; f < wins[w].n_features; f++) if (wins[w].feature_start_frame[f] == 0) mf++;
+        Mcap = std::max(Mcap, MG_MD + mf + 1);
+        h->h_mflag[w] = wins[w].marginalization_flag;
+    }
+    Mcap = (Mcap + 1) & ~1;
+    h->mg_Mcap = Mcap;
     const size_t sB = B, sF = Fmax, sO = Omax, sC = FACmax;
     struct Req { int id; size_t bytes; };
     const Req reqs[] = {
@@ -258,7 +306,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
         {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
         {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
-        {D_OBGS, sB * 33 * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8},
+        {D_OBGS, sB * 33 * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed"; return VILF_ERR_DEVICE; }
 
@@ -332,6 +380,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, up(D_PAIROFF, pairoff.data(), sB * (VB_NPAIR + 1) * 4));
     HIPCHECK(h, up(D_IMU, imu.data(), sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar.data(), sB * 10 * 7 * 8));
     HIPCHECK(h, up(D_COV, cov.data(), sB * 10 * 225 * 8));
+    HIPCHECK(h, up(D_MFLAG, h->h_mflag.data(), sB * 4));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
 
     // ---- batch descriptor -------------------------------------------------------------------------------------
@@ -545,17 +594,59 @@ extern "C" int vilf_prior_import(vilf_handle *h, int slot, const vilf_prior *pri
     if ((int)h->priors.size() <= slot) { vilf_prior z; std::memset(&z, 0, sizeof(z)); h->priors.resize(slot + 1, z); h->prior_dirty.resize(slot + 1, 1); }
     h->priors[slot] = *prior;
     h->prior_dirty[slot] = 1;
+    if ((int)h->prior_dev_newer.size() <= slot) h->prior_dev_newer.resize(slot + 1, 0);
+    h->prior_dev_newer[slot] = 0;
     return VILF_OK;
 }
 
 extern "C" int vilf_prior_export(vilf_handle *h, int slot, vilf_prior *out) {
     if (!h || slot < 0 || slot >= (int)h->priors.size() || !out) return VILF_ERR_INVALID_ARGUMENT;
+    { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
     *out = h->priors[slot];
     return VILF_OK;
 }
 
-extern "C" int vilf_window_marginalize(vilf_handle *h) { if (!h) return VILF_ERR_INVALID_ARGUMENT; h->err = "device marginalization not built yet"; return VILF_ERR_UNSUPPORTED; }
-extern "C" int vilf_batch_marginalize(vilf_handle *h, int) { if (!h) return VILF_ERR_INVALID_ARGUMENT; h->err = "device marginalization not built yet"; return VILF_ERR_UNSUPPORTED; }
+extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
+    if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipSetDevice(h->device));
+    { bool dirty = false; for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true; if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; } }
+    const size_t sB = h->B, sF = h->batch.Fmax, sC = h->batch.FACmax, M = h->mg_Mcap;
+    struct Req { int id; size_t bytes; };
+    const Req reqs[] = {
+        {D_MINFO, sB * MG_INFO * 4}, {D_MF0, sB * sF * 4}, {D_MSTP, sB * 77 * 8}, {D_MSTS, sB * 99 * 8}, {D_MSTF, sB * sF * 8}, {D_MSTE, sB * 7 * 8},
+        {D_MBUF, sB * MG_MROW * sC * 8}, {D_MHD, sB * MG_ND * MG_ND * 8}, {D_MGD, sB * MG_ND * 8}, {D_MWF, sB * sF * MG_ND * 8}, {D_MHF, sB * sF * 8},
+        {D_MGF, sB * sF * 8}, {D_MAMM, (M > MG_MLDS ? sB * M * M * 8 : 8)}, {D_MX, sB * M * (MG_NK + 1) * 8}, {D_MROT, sB * MG_SWEEPS * (M - 1) * M * 8},
+        {D_MLAM, sB * M * 8}, {D_MAR, sB * MG_NK * MG_NK * 8}, {D_MBR, sB * MG_NK * 8},
+    };
+    for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed (marginalization workspace)"; return VILF_ERR_DEVICE; }
+    VbMarg &g = h->marg;
+    g.Mcap = (int)M; g.init_depth = h->opts.init_depth;
+    g.mflag = h->d[D_MFLAG].as<int>(); g.info = h->d[D_MINFO].as<int>(); g.f0rank = h->d[D_MF0].as<int>();
+    g.st_pose = h->d[D_MSTP].as<double>(); g.st_sb = h->d[D_MSTS].as<double>(); g.st_feat = h->d[D_MSTF].as<double>(); g.st_ex = h->d[D_MSTE].as<double>();
+    g.Mbuf = h->d[D_MBUF].as<double>(); g.Hd = h->d[D_MHD].as<double>(); g.gd = h->d[D_MGD].as<double>(); g.Wf = h->d[D_MWF].as<double>();
+    g.hfm = h->d[D_MHF].as<double>(); g.gfm = h->d[D_MGF].as<double>(); g.Amm = h->d[D_MAMM].as<double>(); g.X = h->d[D_MX].as<double>();
+    g.rot = h->d[D_MROT].as<double>(); g.lam = h->d[D_MLAM].as<double>(); g.Ar = h->d[D_MAR].as<double>(); g.br = h->d[D_MBR].as<double>();
+    g.prior_hdr_out = h->d[D_PHDR].as<int>(); g.prior_x0_out = h->d[D_PX0].as<double>(); g.prior_J_out = h->d[D_PJ].as<double>(); g.prior_r_out = h->d[D_PR].as<double>();
+    const dim3 grid(h->B), block(VB_NT);
+    hipLaunchKernelGGL(k_marg_prepare, grid, block, 0, h->stream, h->batch, g);
+    hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g);
+    hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g);
+    hipLaunchKernelGGL(k_prior_prep, grid, block, 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
+    HIPCHECK(h, hipGetLastError());
+    for (int w = 0; w < h->B; w++) { h->prior_dev_newer[w] = 1; h->prior_dirty[w] = 0; }
+    if (sync) {
+        std::vector<int> info(sB * MG_INFO);
+        HIPCHECK(h, hipMemcpyAsync(info.data(), g.info, info.size() * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        for (int w = 0; w < h->B; w++) {
+            const int st = info[(size_t)w * MG_INFO];
+            if (st == 2) h->prior_dev_newer[w] = 0;     // SECOND_NEW without Pose[WINDOW_SIZE-1] in the prior: prior unchanged (estimator.cpp:982-983)
+            if (st == 3) { h->err = "marginalization: block table / dimension outside the supported range"; return VILF_ERR_UNSUPPORTED; }
+        }
+    }
+    return VILF_OK;
+}
+extern "C" int vilf_window_marginalize(vilf_handle *h) { return vilf_batch_marginalize(h, 1); }
 
 extern "C" int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8) {
     if (!h || !h->resident || !device_out8) return VILF_ERR_INVALID_ARGUMENT;

@@ -48,6 +48,36 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
     int pad_;
 };
 
+// ---- marginalization workspace (vilf_marg.hip) ---------------------------------------------------------------------
+#define MG_MD 21            // dropped non-feature variables: Pose[0] 6 + Pose[1] 6 (USE_LIDAR_CONST, estimator.cpp:891) + SpeedBias[0] 9
+#define MG_NK 96            // kept (prior) dimension capacity; the reference's prior never exceeds 75 + td
+#define MG_ND (MG_MD + MG_NK)
+#define MG_MROW 40          // per visual factor: J_P0[12] J_Pj[12] J_Ex[12] J_f[2] r[2]
+#define MG_PAIRM 400        // per pair (0,j): 19x19 (+19 rhs) products, stored 20x20
+#define MG_MLDS 136         // largest Amm held in LDS by the Jacobi eigen-solver
+#define MG_INFO 128         // per window: [0] status [1] md [2] mf [3] n [4] m [5] nblocks [6] M(padded) [8..31] shifted ids [32..55] sizes
+                            //             [56..79] idx [80..103] original ids
+#define MG_SWEEPS 24
+struct VbMarg {
+    int Mcap;               // capacity (padded, even) of m = md + mf over the batch
+    double init_depth;
+    const int *mflag;       // [B] marginalization_flag
+    int *info;              // [B][MG_INFO]
+    int *f0rank;            // [B][Fmax] rank among the start-frame-0 features, or -1
+    double *st_pose, *st_sb, *st_feat, *st_ex;   // linearization point = vector2double() of the post-gauge state
+    double *Mbuf;           // [B][MG_MROW][FACmax]   (feature-major slot order)
+    double *Hd, *gd;        // [B][MG_ND*MG_ND], [B][MG_ND]    dense-variable normal equations
+    double *Wf;             // [B][Fmax][MG_ND]  arrow rows of the start-0 features (indexed by rank)
+    double *hfm, *gfm;      // [B][Fmax]
+    double *Amm;            // [B][Mcap*Mcap]    only used when m > MG_MLDS
+    double *X;              // [B][Mcap][MG_NK+1]
+    double *rot;            // [B][MG_SWEEPS][Mcap-1][Mcap]   (c,s) log of the Jacobi rotations
+    double *lam;            // [B][Mcap]
+    double *Ar, *br;        // [B][MG_NK*MG_NK], [B][MG_NK]
+    int *prior_hdr_out;     // = batch prior arrays (written by k_marg_finish)
+    double *prior_x0_out, *prior_J_out, *prior_r_out;
+};
+
 struct VbBatch {
     int B, Fmax, Omax, FACmax;
     // options

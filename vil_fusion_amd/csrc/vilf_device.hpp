@@ -179,7 +179,7 @@ VD void huber(double s, double a, double &rho0, double &sqrt_rho1) {
 template <bool JAC>
 VD void projection_eval(const double *Pi, const double *Ri, const double *Pj, const double *Rj, const double *ric, const double *tic,
                         const double *pts_i, const double *pts_j, double inv_dep, double sqrt_info,
-                        double *r, double *Ji, double *Jj, double *Jf) {
+                        double *r, double *Ji, double *Jj, double *Jf, double *Jex = nullptr) {
     double pc_i[3] = {pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep};
     double p_imu_i[3], pw[3], d[3], p_imu_j[3], e[3], pc_j[3];
     m3_vec(ric, pc_i, p_imu_i);
@@ -236,6 +236,31 @@ VD void projection_eval(const double *Pi, const double *Ri, const double *Pj, co
         const double s = -1.0 / (inv_dep * inv_dep);
         Jf[0] = (M2[0] * rp[0] + M2[1] * rp[1] + M2[2] * rp[2]) * s;
         Jf[1] = (M2[3] * rp[0] + M2[4] * rp[1] + M2[5] * rp[2]) * s;
+        if (Jex) {   // projection_factor.cpp:98-107 (extrinsic block; needed by the marginalization, where Ex_Pose is never constant)
+            double RjtRi[9], L[9], tmp_r[9], T1[9], S1[9], S2[9], S3[9], v[3], u[3], wv[3];
+            m3_mulT(Rj, Ri, RjtRi);
+            double Dm[9];
+            for (int k = 0; k < 9; k++) Dm[k] = RjtRi[k];
+            Dm[0] -= 1; Dm[4] -= 1; Dm[8] -= 1;
+            m3_mulT(ric, Dm, L);                         // ric^T (Rj^T Ri - I)
+            m3_mul(RjtRi, ric, T1);
+            m3_mulT(ric, T1, tmp_r);                     // ric^T Rj^T Ri ric
+            skew3(pc_i, S1);
+            m3_mul(tmp_r, S1, T1);                       // tmp_r * skew(pts_camera_i)
+            m3_vec(tmp_r, pc_i, v); skew3(v, S2);
+            m3_vec(Ri, tic, u);
+            u[0] += Pi[0] - Pj[0]; u[1] += Pi[1] - Pj[1]; u[2] += Pi[2] - Pj[2];
+            m3T_vec(Rj, u, wv);
+            wv[0] -= tic[0]; wv[1] -= tic[1]; wv[2] -= tic[2];
+            m3T_vec(ric, wv, v); skew3(v, S3);
+            double Rr[9];
+            for (int k = 0; k < 9; k++) Rr[k] = -T1[k] + S2[k] + S3[k];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                Jex[j] = r00 * L[j] + r02 * L[6 + j];           Jex[6 + j] = r00 * L[3 + j] + r12 * L[6 + j];
+                Jex[3 + j] = r00 * Rr[j] + r02 * Rr[6 + j];     Jex[9 + j] = r00 * Rr[3 + j] + r12 * Rr[6 + j];
+            }
+        }
     }
 }
 

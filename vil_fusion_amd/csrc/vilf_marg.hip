@@ -1,0 +1,486 @@
+// vilf_marg.hip — device marginalization ≙ estimator.cpp:863-1046 + MarginalizationInfo::{preMarginalize, marginalize,
+// getParameterBlocks} (factor/marginalization_factor.cpp:110-319). One 256-thread workgroup per window.
+//
+//   k_marg_prepare  vector2double() of the post-gauge state; evaluate the factors touching the dropped blocks (prior,
+//                   lidarFactor[1], IMUFactor[1], every ProjectionFactor whose feature starts in frame 0) with the Cauchy
+//                   corrector; dense-variable normal equations Hd/gd + per-feature arrow rows (the features are 1-dim blocks
+//                   coupled only to Pose[0], Pose[j], Ex_Pose and themselves)
+//   k_marg_schur    Amm = 0.5 (Amm + Amm^T); eigen-decomposition by a parallel cyclic Jacobi resident in LDS; pseudo-inverse
+//                   with the reference's eps = 1e-8 (:267-272); A = Arr - Arm Amm^+ Amr, b = brr - Arm Amm^+ bmm (:275-281),
+//                   computed as X'^T f(L) X' with X' = V^T [Amr | bmm] obtained by replaying the rotations (no eigenvector
+//                   matrix is formed)
+//   k_marg_finish   second eigen-decomposition (with eigenvectors), J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b (:283-291); block table
+//                   with the address shift (estimator.cpp:960-971 / :1016-1037); the new prior stays on the device
+// Block ordering: dropped blocks then kept blocks, both ascending in block id (the reference iterates address-keyed
+// unordered_maps; any order is a permutation of the same result — SURVEY.md §7 "address-keyed bookkeeping").
+#include "vilf_device.hpp"
+#include "vilf_batch.hpp"
+
+using namespace vd;
+#define NT VB_NT
+__device__ __forceinline__ int pair_index_c(int i, int j) { return j * (j - 1) / 2 + i; }  // i < j
+
+__device__ __forceinline__ void rr_pair(int round, int k, int M, int &p, int &q) {   // round-robin tournament pairing
+    int a = (k == 0) ? (M - 1) : (round + k) % (M - 1);
+    int c = (round - k + (M - 1)) % (M - 1);
+    p = min(a, c); q = max(a, c);
+}
+
+// Parallel two-sided cyclic Jacobi on a symmetric M x M matrix (M even, row stride ld). WITH_V: accumulate V <- V J.
+// rotlog (optional): (c, s) of every pair of every round, [sweep][round][M/2][2]. Returns the number of sweeps run.
+template <bool WITH_V>
+__device__ int jacobi_eig(double *A, int M, int ld, double *V, double *rotlog, double *s_cs, int *s_flag) {
+    const int tid = threadIdx.x, H = M / 2;
+    int sweep = 0;
+    for (; sweep < MG_SWEEPS; sweep++) {
+        if (tid == 0) *s_flag = 0;
+        __syncthreads();
+        for (int round = 0; round < M - 1; round++) {
+            for (int k = tid; k < H; k += NT) {
+                int p, q; rr_pair(round, k, M, p, q);
+                const double app = A[p * ld + p], aqq = A[q * ld + q], apq = A[p * ld + q];
+                double c = 1.0, s = 0.0;
+                const double g = 100.0 * fabs(apq);
+                if (apq != 0.0) {
+                    if (sweep > 3 && fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq)) { A[p * ld + q] = 0.0; A[q * ld + p] = 0.0; }
+                    else {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+                        *s_flag = 1;
+                    }
+                }
+                s_cs[2 * k] = c; s_cs[2 * k + 1] = s;
+                if (rotlog) { double *l = rotlog + ((size_t)(sweep * (M - 1) + round) * H + k) * 2; l[0] = c; l[1] = s; }
+            }
+            __syncthreads();
+            for (int it = tid; it < H * M; it += NT) {            // rows p, q  <-  J^T A
+                const int k = it / M, j = it - k * M;
+                int p, q; rr_pair(round, k, M, p, q);
+                const double c = s_cs[2 * k], s = s_cs[2 * k + 1];
+                const double a = A[p * ld + j], bq = A[q * ld + j];
+                A[p * ld + j] = c * a - s * bq; A[q * ld + j] = s * a + c * bq;
+            }
+            __syncthreads();
+            for (int it = tid; it < H * M; it += NT) {            // columns p, q  <-  (.) J
+                const int i = it / H, k = it - i * H;
+                int p, q; rr_pair(round, k, M, p, q);
+                const double c = s_cs[2 * k], s = s_cs[2 * k + 1];
+                const double a = A[i * ld + p], bq = A[i * ld + q];
+                A[i * ld + p] = c * a - s * bq; A[i * ld + q] = s * a + c * bq;
+                if (WITH_V) { const double va = V[i * ld + p], vb = V[i * ld + q]; V[i * ld + p] = c * va - s * vb; V[i * ld + q] = s * va + c * vb; }
+            }
+            __syncthreads();
+        }
+        if (!*s_flag) { sweep++; break; }
+        __syncthreads();
+    }
+    return sweep;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMarg g) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    __shared__ double s_pose[77], s_sb[99], s_R[99], s_ex[7], s_ric[9], s_dx[VB_PRIOR_LD], s_J[15 * 32], s_r[16], s_lJ[72], s_lr[8];
+    __shared__ double s_pm[10 * MG_PAIRM];
+    __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_pmap[VB_PRIOR_LD], s_hdr[8], s_poff[VB_NPAIR + 1];
+    int *info = g.info + (size_t)w * MG_INFO;
+    const int F = b.n_feat[w];
+    const size_t FM = b.Fmax, FC = b.FACmax;
+    const int *phdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    const int mode = g.mflag[w];
+    const int have_prior = phdr[0];
+    const int *f_start = b.f_start + (size_t)w * FM, *f_nobs = b.f_nobs + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
+    int *f0rank = g.f0rank + (size_t)w * FM;
+    double *st_feat = g.st_feat + (size_t)w * FM;
+
+    // ---- vector2double() of the post-gauge state (estimator.cpp:866; feature_manager.cpp:150-168,194-216) --------------
+    if (tid < VB_NF) {
+        const double *P = b.out_Ps + ((size_t)w * VB_NF + tid) * 3, *R = b.out_Rs + ((size_t)w * VB_NF + tid) * 9;
+        for (int k = 0; k < 3; k++) s_pose[7 * tid + k] = P[k];
+        q_store(s_pose + 7 * tid + 3, q_fromR(R));
+        for (int k = 0; k < 9; k++) s_R[9 * tid + k] = R[k];
+        for (int k = 0; k < 3; k++) { s_sb[9 * tid + k] = b.out_Vs[((size_t)w * VB_NF + tid) * 3 + k]; s_sb[9 * tid + 3 + k] = b.out_Bas[((size_t)w * VB_NF + tid) * 3 + k]; s_sb[9 * tid + 6 + k] = b.out_Bgs[((size_t)w * VB_NF + tid) * 3 + k]; }
+    }
+    if (tid == 32) {
+        const double *ex = b.ex + (size_t)w * 7;
+        q_toR(q_load(ex + 3), s_ric);
+        for (int k = 0; k < 3; k++) s_ex[k] = ex[k];
+        q_store(s_ex + 3, q_fromR(s_ric));
+    }
+    for (int f = tid; f < F; f += NT) {
+        const double est = 1.0 / b.feat[(size_t)w * FM + f];
+        st_feat[f] = est > 0 ? 1.0 / est : 1.0 / g.init_depth;
+    }
+    if (tid <= VB_NPAIR) s_poff[tid] = b.pair_off[(size_t)w * (VB_NPAIR + 1) + tid];
+    __syncthreads();
+    if (tid < 77) g.st_pose[(size_t)w * 77 + tid] = s_pose[tid];
+    if (tid < 99) g.st_sb[(size_t)w * 99 + tid] = s_sb[tid];
+    if (tid < 7) g.st_ex[(size_t)w * 7 + tid] = s_ex[tid];
+
+    // ---- variable tables (thread 0): dense variables = dropped non-feature blocks, then kept blocks ascending in id ------
+    if (tid == 0) {
+        int status = 0, md = 0, mf = 0, n = 0, nb = 0;
+        bool present[2 * VB_NF + 2];
+        for (int i = 0; i < 2 * VB_NF + 2; i++) present[i] = false;
+        bool drop[2 * VB_NF + 2];
+        for (int i = 0; i < 2 * VB_NF + 2; i++) drop[i] = false;
+        if (have_prior) for (int i = 0; i < phdr[2]; i++) present[phdr[3 + i]] = true;
+        if (mode == 0) {     // MARGIN_OLD
+            present[0] = present[1] = true; drop[0] = true;
+            present[VB_NF] = true; drop[VB_NF] = true;
+            if (b.use_lidar) drop[1] = true;                                           // estimator.cpp:886-895 drop_set {0,1}
+            const double *rec = b.imu + ((size_t)w * 10) * IMU_REC;
+            if (rec[0] < 10.0) present[VB_NF + 1] = true;                                // :896-905
+            for (int f = 0; f < F; f++) {
+                if (f_start[f] != 0) { f0rank[f] = -1; continue; }
+                f0rank[f] = mf++;
+                for (int j = 1; j < f_nobs[f]; j++) present[j] = true;
+                present[2 * VB_NF] = true;
+            }
+        } else {             // MARGIN_SECOND_NEW: only the prior, drop Pose[WINDOW_SIZE-1] (:986-1003)
+            for (int f = 0; f < F; f++) f0rank[f] = -1;
+            if (!have_prior || !present[VB_NF - 2]) status = 2;                          // nothing to do: prior stays as it is
+            drop[VB_NF - 2] = true;
+        }
+        int off = 0;
+        for (int a = 0; a < VB_NF; a++) s_off_pose[a] = -1;
+        s_off_sb[0] = s_off_sb[1] = -1; s_off_ex = -1;
+        for (int id = 0; id < 2 * VB_NF + 1 && status == 0; id++) if (present[id] && drop[id]) {
+            if (id < VB_NF) { s_off_pose[id] = off; off += 6; } else if (id < 2 * VB_NF) { if (id - VB_NF < 2) s_off_sb[id - VB_NF] = off; else status = 3; off += 9; }
+        }
+        md = off;
+        for (int id = 0; id < 2 * VB_NF + 1 && status == 0; id++) if (present[id] && !drop[id]) {
+            int size = 7, loc = 6, sid;
+            if (id < VB_NF) { s_off_pose[id] = off; }
+            else if (id < 2 * VB_NF) { if (id - VB_NF < 2) s_off_sb[id - VB_NF] = off; else status = 3; size = 9; loc = 9; }
+            else s_off_ex = off;
+            // address shift (estimator.cpp:960-971 MARGIN_OLD: frame i -> i-1; :1016-1037 SECOND_NEW: frame WINDOW_SIZE -> WINDOW_SIZE-1)
+            if (id == 2 * VB_NF) sid = id;
+            else if (mode == 0) sid = id - 1;
+            else { const int fr = id < VB_NF ? id : id - VB_NF; sid = (fr == VB_NF - 1) ? id - 1 : id; }
+            if (nb >= 24) { status = 3; break; }
+            info[8 + nb] = sid; info[32 + nb] = size; info[56 + nb] = off - md; info[80 + nb] = id;
+            nb++;
+            off += loc;
+        }
+        n = off - md;
+        if (n > MG_NK || md > MG_MD) status = 3;
+        int M = md + mf; M += (M & 1);
+        if (M > g.Mcap) status = 3;
+        info[0] = status; info[1] = md; info[2] = mf; info[3] = n; info[4] = md + mf; info[5] = nb; info[6] = M;
+        s_hdr[0] = status; s_hdr[1] = md; s_hdr[2] = mf; s_hdr[3] = n;
+    }
+    __syncthreads();
+    if (s_hdr[0] != 0) return;
+    const int md = s_hdr[1], n = s_hdr[3], nd = md + n;
+    double *Hd = g.Hd + (size_t)w * MG_ND * MG_ND, *gd = g.gd + (size_t)w * MG_ND;
+    for (int i = tid; i < MG_ND * MG_ND; i += NT) Hd[i] = 0.0;
+    for (int i = tid; i < MG_ND; i += NT) gd[i] = 0.0;
+    // ---- prior factor: dx (marginalization_factor.cpp:345-363) and column map -------------------------------------------
+    if (tid < VB_PRIOR_LD) { s_dx[tid] = 0.0; s_pmap[tid] = -1; }
+    __syncthreads();
+    if (have_prior && tid < phdr[2]) {
+        const int id = phdr[3 + tid], size = phdr[27 + tid], idx = phdr[51 + tid];
+        const double *x0 = b.prior_x0 + ((size_t)w * 24 + tid) * 9;
+        const double *x = id < VB_NF ? s_pose + 7 * id : (id < 2 * VB_NF ? s_sb + 9 * (id - VB_NF) : s_ex);
+        const int doff = id < VB_NF ? s_off_pose[id] : (id < 2 * VB_NF ? s_off_sb[id - VB_NF] : s_off_ex);
+        if (size == 7) {
+            for (int k = 0; k < 3; k++) s_dx[idx + k] = x[k] - x0[k];
+            Q dq = q_mul(q_inv(q_load(x0 + 3)), q_load(x + 3));
+            const double sgn = (dq.w >= 0) ? 2.0 : -2.0;
+            s_dx[idx + 3] = sgn * dq.x; s_dx[idx + 4] = sgn * dq.y; s_dx[idx + 5] = sgn * dq.z;
+            for (int k = 0; k < 6; k++) s_pmap[idx + k] = doff + k;
+        } else for (int k = 0; k < size; k++) { s_dx[idx + k] = x[k] - x0[k]; s_pmap[idx + k] = doff + k; }
+    }
+    // ---- lidarFactor[1] and IMUFactor[1] (MARGIN_OLD) ---------------------------------------------------------------------
+    for (int i = tid; i < 15 * 32; i += NT) s_J[i] = 0.0;
+    if (tid < 72) s_lJ[tid] = 0.0;
+    if (tid < 16) s_r[tid] = 0.0;
+    if (tid < 8) s_lr[tid] = 0.0;
+    __syncthreads();
+    if (mode == 0) {
+        if (tid == 0) {
+            const double *rec = b.imu + ((size_t)w * 10) * IMU_REC;
+            if (rec[0] < 10.0) {
+                double r[15];
+                imu_raw_eval<true, 32, false>(s_pose, s_sb, s_pose + 7, s_sb + 9, rec, b.G, r, s_J);
+                for (int k = 0; k < 15; k++) s_J[32 * k + 30] = r[k];
+            }
+        }
+        if (tid == 64 && b.use_lidar) {
+            const double *lc = b.lidar + ((size_t)w * 10) * 7;
+            double Ji[36], Jj[36];
+            lidar_between_eval<true>(s_pose, s_pose + 7, q_load(b.qil), b.til, q_load(lc), lc + 4, s_lr, Ji, Jj);
+            for (int rr = 0; rr < 6; rr++) for (int c = 0; c < 6; c++) { s_lJ[12 * rr + c] = Ji[6 * rr + c]; s_lJ[12 * rr + 6 + c] = Jj[6 * rr + c]; }
+        }
+    }
+    __syncthreads();
+    // sqrt_info multiplication of the IMU block (31 columns incl. the residual), in registers then back
+    {
+        const double *S = b.imu + ((size_t)w * 10) * IMU_REC + IMU_SQRT;
+        double acc[2] = {0, 0};
+        int e0 = tid, e1 = tid + NT;
+        for (int t = 0; t < 2; t++) {
+            const int e = t ? e1 : e0;
+            if (e < 15 * 31) { const int row = e / 31, col = e - 31 * row; double s = 0; for (int m2 = row; m2 < 15; m2++) s += S[15 * row + m2] * s_J[32 * m2 + col]; acc[t] = s; }
+        }
+        __syncthreads();
+        if (e0 < 15 * 31) s_J[32 * (e0 / 31) + (e0 % 31)] = acc[0];
+        if (e1 < 15 * 31) s_J[32 * (e1 / 31) + (e1 % 31)] = acc[1];
+    }
+    __syncthreads();
+    // ---- visual factors of the start-frame-0 features: thread per factor -> Mbuf (slot order) ---------------------------
+    double *Mb = g.Mbuf + (size_t)w * MG_MROW * FC;
+    const double *obs = b.obs + (size_t)w * b.Omax * 3;
+    if (mode == 0) {
+        const int nfac = b.n_fac[w];
+        const int *ps_feat = b.ps_feat + (size_t)w * FC, *ps_obs = b.ps_obs + (size_t)w * FC, *ps_slot = b.ps_slot + (size_t)w * FC;
+        for (int q = tid; q < nfac; q += NT) {
+            const int f = ps_feat[q];
+            if (f_start[f] != 0) continue;
+            const int oj = ps_obs[q], slot = ps_slot[q], o0 = f_obs0[f], fj = oj - o0;
+            double r[2], Ji[12], Jj[12], Jf[2], Jex[12];
+            projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, obs + 3 * o0, obs + 3 * oj, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
+            double rho0, sw;
+            cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
+            for (int k = 0; k < 12; k++) { Mb[(size_t)k * FC + slot] = sw * Ji[k]; Mb[(size_t)(12 + k) * FC + slot] = sw * Jj[k]; Mb[(size_t)(24 + k) * FC + slot] = sw * Jex[k]; }
+            Mb[(size_t)36 * FC + slot] = sw * Jf[0]; Mb[(size_t)37 * FC + slot] = sw * Jf[1];
+            Mb[(size_t)38 * FC + slot] = sw * r[0]; Mb[(size_t)39 * FC + slot] = sw * r[1];
+        }
+    }
+    __syncthreads();
+    // ---- per pair (0, j): [J0 Jj Jex r]^T [J0 Jj Jex r] (19 x 19) gathered over the pair's factors ------------------------
+    if (mode == 0) {
+        const int *ps_slot = b.ps_slot + (size_t)w * FC;
+        for (int t = tid; t < 10 * MG_PAIRM; t += NT) {
+            const int jj = t / MG_PAIRM, e = t - MG_PAIRM * jj, u = e / 20, v = e - 20 * u;
+            double s = 0;
+            if (u < 19 && v < 19 && u <= v) {
+                const int p = pair_index_c(0, jj + 1);
+                // column u of X: 0..5 J0, 6..11 Jj, 12..17 Jex, 18 r  -> Mbuf component rows (row0, row1)
+                const int cu0 = (u < 18) ? (12 * (u / 6) + (u % 6)) : 38, cu1 = (u < 18) ? cu0 + 6 : 39;
+                const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : 38, cv1 = (v < 18) ? cv0 + 6 : 39;
+                for (int q = s_poff[p]; q < s_poff[p + 1]; q++) {
+                    const int slot = ps_slot[q];
+                    s += Mb[(size_t)cu0 * FC + slot] * Mb[(size_t)cv0 * FC + slot] + Mb[(size_t)cu1 * FC + slot] * Mb[(size_t)cv1 * FC + slot];
+                }
+            }
+            s_pm[t] = s;
+        }
+    }
+    __syncthreads();
+    // ---- dense-variable normal equations: owner-computes over the (nd x nd) entries ---------------------------------------
+    {
+        const int opose0 = s_off_pose[0], opose1 = s_off_pose[1], osb0 = s_off_sb[0], osb1 = s_off_sb[1], oex = s_off_ex;
+        // IMU block variable offsets (local 30 columns): P0 6, SB0 9, P1 6, SB1 9
+        auto imu_off = [&](int c) -> int { if (c < 6) return opose0 + c; if (c < 15) return osb0 + (c - 6); if (c < 21) return opose1 + (c - 15); return osb1 < 0 ? -1 : osb1 + (c - 21); };
+        for (int e = tid; e < 31 * 30; e += NT) {     // IMU J^T [J r]
+            const int u = e / 31, v = e - 31 * u;
+            double s = 0;
+            for (int row = 0; row < 15; row++) s += s_J[32 * row + u] * s_J[32 * row + (v < 30 ? v : 30)];
+            const int du = imu_off(u);
+            if (du < 0) continue;
+            if (v < 30) { const int dv = imu_off(v); if (dv >= 0) Hd[du * MG_ND + dv] += s; }
+            else gd[du] += s;
+        }
+        __syncthreads();
+        for (int e = tid; e < 13 * 12; e += NT) {     // LiDAR between-factor (unweighted jacobian, weighted residual: reference quirk)
+            const int u = e / 13, v = e - 13 * u;
+            double s = 0;
+            for (int row = 0; row < 6; row++) s += s_lJ[12 * row + u] * (v < 12 ? s_lJ[12 * row + v] : s_lr[row]);
+            const int du = (u < 6) ? opose0 + u : opose1 + (u - 6);
+            if (v < 12) { const int dv = (v < 6) ? opose0 + v : opose1 + (v - 6); Hd[du * MG_ND + dv] += s; }
+            else gd[du] += s;
+        }
+        (void)oex;
+    }
+    __syncthreads();
+    // every pass above/below writes each address at most once and passes are separated by barriers: the summation order per
+    // address is fixed (IMU, LiDAR, prior, visual) => bit-reproducible.
+    if (have_prior) {
+        const int pn = phdr[1];
+        const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *pg = b.prior_g + (size_t)w * VB_PRIOR_LD;
+        for (int e = tid; e < pn * pn; e += NT) {
+            const int i = e / pn, j = e - pn * i;
+            const int di = s_pmap[i], dj = s_pmap[j];
+            if (di >= 0 && dj >= 0) Hd[di * MG_ND + dj] += pH[i * VB_PRIOR_LD + j];
+        }
+        for (int i = tid; i < pn; i += NT) {
+            const int di = s_pmap[i];
+            if (di < 0) continue;
+            double s = pg[i];
+            for (int k = 0; k < pn; k++) s += pH[i * VB_PRIOR_LD + k] * s_dx[k];
+            gd[di] += s;
+        }
+    }
+    __syncthreads();
+    if (mode == 0) {
+        // visual dense blocks: P0 x P0, P0 x Pj, P0 x Ex, Pj x Pj, Pj x Ex, Ex x Ex (+ rhs), summed over j in fixed order
+        const int o0 = s_off_pose[0], oex = s_off_ex;
+        for (int e = tid; e < nd * (nd + 1); e += NT) {
+            const int du = e / (nd + 1), dv = e - (nd + 1) * du;      // dv == nd: rhs
+            double s = 0;
+            bool any = false;
+            for (int jj = 0; jj < 10; jj++) {
+                const int oj = s_off_pose[jj + 1];
+                if (s_poff[pair_index_c(0, jj + 1) + 1] == s_poff[pair_index_c(0, jj + 1)]) continue;
+                auto xcol = [&](int d) -> int { if (d >= o0 && d < o0 + 6) return d - o0; if (oj >= 0 && d >= oj && d < oj + 6) return 6 + d - oj; if (oex >= 0 && d >= oex && d < oex + 6) return 12 + d - oex; return -1; };
+                const int u = xcol(du), v = (dv == nd) ? 18 : xcol(dv);
+                if (u < 0 || v < 0) continue;
+                s += (u <= v) ? s_pm[jj * MG_PAIRM + 20 * u + v] : s_pm[jj * MG_PAIRM + 20 * v + u];
+                any = true;
+            }
+            if (!any) continue;
+            if (dv == nd) gd[du] += s; else Hd[du * MG_ND + dv] += s;
+        }
+        // per-feature arrow rows
+        double *Wf = g.Wf + (size_t)w * FM * MG_ND, *hfm = g.hfm + (size_t)w * FM, *gfm = g.gfm + (size_t)w * FM;
+        for (int f = tid; f < F; f += NT) {
+            const int rk = f0rank[f];
+            if (rk < 0) continue;
+            double *Wr = Wf + (size_t)rk * MG_ND;
+            for (int k = 0; k < nd; k++) Wr[k] = 0.0;
+            double h = 0, gg = 0, w0[6] = {0, 0, 0, 0, 0, 0}, wex[6] = {0, 0, 0, 0, 0, 0};
+            const int nf = f_nobs[f] - 1, f0 = f_fac0[f];
+            for (int t = 0; t < nf; t++) {
+                const int slot = f0 + t;
+                const double jf0 = Mb[(size_t)36 * FC + slot], jf1 = Mb[(size_t)37 * FC + slot];
+                h += jf0 * jf0 + jf1 * jf1;
+                gg += jf0 * Mb[(size_t)38 * FC + slot] + jf1 * Mb[(size_t)39 * FC + slot];
+                const int oj = s_off_pose[1 + t];
+                for (int c = 0; c < 6; c++) {
+                    w0[c] += Mb[(size_t)c * FC + slot] * jf0 + Mb[(size_t)(6 + c) * FC + slot] * jf1;
+                    wex[c] += Mb[(size_t)(24 + c) * FC + slot] * jf0 + Mb[(size_t)(30 + c) * FC + slot] * jf1;
+                    Wr[oj + c] = Mb[(size_t)(12 + c) * FC + slot] * jf0 + Mb[(size_t)(18 + c) * FC + slot] * jf1;
+                }
+            }
+            for (int c = 0; c < 6; c++) { Wr[o0 + c] = w0[c]; Wr[oex + c] = wex[c]; }
+            hfm[rk] = h; gfm[rk] = gg;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+#define MG_LDS_DOUBLES (MG_MLDS * MG_MLDS)
+extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg g) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int *info = g.info + (size_t)w * MG_INFO;
+    if (info[0] != 0) return;
+    extern __shared__ double s_dyn[];
+    __shared__ double s_cs[2 * 512];
+    __shared__ int s_flag;
+    const int md = info[1], mf = info[2], n = info[3], m = info[4], M = info[6], H = M / 2;
+    const size_t FM = b.Fmax;
+    const double *Hd = g.Hd + (size_t)w * MG_ND * MG_ND, *gd = g.gd + (size_t)w * MG_ND;
+    const double *Wf = g.Wf + (size_t)w * FM * MG_ND, *hfm = g.hfm + (size_t)w * FM, *gfm = g.gfm + (size_t)w * FM;
+    double *A = (M <= MG_MLDS) ? s_dyn : g.Amm + (size_t)w * g.Mcap * g.Mcap;
+    const int XL = n + 1;
+    double *Xg = g.X + (size_t)w * g.Mcap * (MG_NK + 1);
+    // Amm = 0.5 (Amm + Amm^T) (marginalization_factor.cpp:267), arrow structure: dense md x md block, feature diagonal
+    for (int e = tid; e < M * M; e += NT) {
+        const int i = e / M, j = e - M * i;
+        double v = 0;
+        if (i < m && j < m) {
+            if (i < md && j < md) v = 0.5 * (Hd[i * MG_ND + j] + Hd[j * MG_ND + i]);
+            else if (i < md) v = Wf[(size_t)(j - md) * MG_ND + i];
+            else if (j < md) v = Wf[(size_t)(i - md) * MG_ND + j];
+            else if (i == j) v = hfm[i - md];
+        }
+        A[e] = v;
+    }
+    for (int e = tid; e < M * XL; e += NT) {        // X = [Amr | bmm]
+        const int i = e / XL, k = e - XL * i;
+        double v = 0;
+        if (i < md) v = (k < n) ? Hd[i * MG_ND + md + k] : gd[i];
+        else if (i < m) v = (k < n) ? Wf[(size_t)(i - md) * MG_ND + md + k] : gfm[i - md];
+        Xg[e] = v;
+    }
+    __syncthreads();
+    double *rot = g.rot + (size_t)w * MG_SWEEPS * (size_t)(g.Mcap - 1) * g.Mcap;
+    const int sweeps = jacobi_eig<false>(A, M, M, nullptr, rot, s_cs, &s_flag);
+    double *lam = g.lam + (size_t)w * g.Mcap;
+    for (int i = tid; i < M; i += NT) lam[i] = A[i * M + i];
+    __syncthreads();
+    // replay the rotations on X (X' = V^T X); X lives in LDS when it fits
+    double *X = (M * XL <= MG_LDS_DOUBLES) ? s_dyn : Xg;
+    if (X != Xg) { for (int e = tid; e < M * XL; e += NT) X[e] = Xg[e]; }
+    __syncthreads();
+    for (int sw = 0; sw < sweeps; sw++)
+        for (int round = 0; round < M - 1; round++) {
+            const double *l = rot + ((size_t)(sw * (M - 1) + round) * H) * 2;
+            for (int it = tid; it < H * XL; it += NT) {
+                const int k = it / XL, j = it - k * XL;
+                int p, q; rr_pair(round, k, M, p, q);
+                const double c = l[2 * k], s = l[2 * k + 1];
+                const double a = X[p * XL + j], bq = X[q * XL + j];
+                X[p * XL + j] = c * a - s * bq; X[q * XL + j] = s * a + c * bq;
+            }
+            __syncthreads();
+        }
+    // A = Arr - Arm Amm^+ Amr ; b = brr - Arm Amm^+ bmm  with Amm^+ = V diag(lam > eps ? 1/lam : 0) V^T  (:267-281)
+    const double eps = 1e-8;
+    double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
+    for (int e = tid; e < n * XL; e += NT) {
+        const int i = e / XL, j = e - XL * i;
+        double s = 0;
+        for (int t = 0; t < M; t++) { const double lt = lam[t]; if (lt > eps) s += X[t * XL + i] * X[t * XL + j] / lt; }
+        if (j < n) Ar[i * MG_NK + j] = Hd[(md + i) * MG_ND + md + j] - s;
+        else br[i] = gd[md + i] - s;
+    }
+    (void)mf;
+}
+
+extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg g) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int *info = g.info + (size_t)w * MG_INFO;
+    if (info[0] != 0) return;
+    extern __shared__ double s_dyn[];
+    __shared__ double s_cs[2 * 64], s_lam[MG_NK + 2], s_br[MG_NK + 2];
+    __shared__ int s_rank[MG_NK + 2], s_flag;
+    const int n = info[3], nb = info[5], N = n + (n & 1);
+    double *A = s_dyn, *V = s_dyn + N * N;
+    const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
+    for (int e = tid; e < N * N; e += NT) {
+        const int i = e / N, j = e - N * i;
+        A[e] = (i < n && j < n) ? 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]) : 0.0;
+        V[e] = (i == j) ? 1.0 : 0.0;
+    }
+    if (tid < n) s_br[tid] = br[tid];
+    __syncthreads();
+    jacobi_eig<true>(A, N, N, V, nullptr, s_cs, &s_flag);
+    if (tid < n) s_lam[tid] = A[tid * N + tid];
+    __syncthreads();
+    if (tid < n) {      // ascending order like Eigen::SelfAdjointEigenSolver
+        int rk = 0;
+        for (int j = 0; j < n; j++) if (s_lam[j] < s_lam[tid] || (s_lam[j] == s_lam[tid] && j < tid)) rk++;
+        s_rank[tid] = rk;
+    }
+    __syncthreads();
+    const double eps = 1e-8;
+    double *Jo = g.prior_J_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *ro = g.prior_r_out + (size_t)w * VB_PRIOR_LD;
+    for (int e = tid; e < n * n; e += NT) {          // linearized_jacobians = sqrt(S) V^T  (:283-290), leading dimension n
+        const int i = e / n, k = e - n * i;
+        const double S = s_lam[i] > eps ? s_lam[i] : 0.0;
+        Jo[(size_t)s_rank[i] * n + k] = sqrt(S) * V[k * N + i];
+    }
+    if (tid < n) {                                  // linearized_residuals = S^-1/2 V^T b  (:291)
+        const double Sinv = s_lam[tid] > eps ? 1.0 / s_lam[tid] : 0.0;
+        double s = 0;
+        for (int k = 0; k < n; k++) s += V[k * N + tid] * s_br[k];
+        ro[s_rank[tid]] = sqrt(Sinv) * s;
+    }
+    // block table with the address shift + x0 = parameter_block_data (getParameterBlocks, :299-319)
+    int *hdr = g.prior_hdr_out + (size_t)w * VB_PRIOR_HDR;
+    if (tid == 0) { hdr[0] = 1; hdr[1] = n; hdr[2] = nb; }
+    if (tid < 24) {
+        hdr[3 + tid] = tid < nb ? info[8 + tid] : 0; hdr[27 + tid] = tid < nb ? info[32 + tid] : 0; hdr[51 + tid] = tid < nb ? info[56 + tid] : 0;
+        if (tid < nb) {
+            const int id = info[80 + tid];
+            const double *x = id < VB_NF ? g.st_pose + (size_t)w * 77 + 7 * id : (id < 2 * VB_NF ? g.st_sb + (size_t)w * 99 + 9 * (id - VB_NF) : g.st_ex + (size_t)w * 7);
+            double *x0 = g.prior_x0_out + ((size_t)w * 24 + tid) * 9;
+            const int size = info[32 + tid];
+            for (int k = 0; k < 9; k++) x0[k] = k < size ? x[k] : 0.0;
+        }
+    }
+}
