@@ -91,3 +91,49 @@ def eval_factor(kind, opts, params, *consts, sizes, nres, want_jac=True):
     rc = fn(*args)
     assert rc == 0
     return r, jacs
+
+
+class OracleS2M:
+    """stateful CPU mirror of EstimationMapping (oracle/scan2map.cpp)"""
+
+    def __init__(self, opts):
+        L = lib()
+        L.vilo_s2m_create.restype = C.c_void_p
+        L.vilo_s2m_create.argtypes = [C.POINTER(abi.Options)]
+        L.vilo_s2m_destroy.argtypes = [C.c_void_p]
+        fp = C.POINTER(C.c_float)
+        L.vilo_s2m_init.argtypes = [C.c_void_p, fp, C.c_int, fp, C.c_int]
+        L.vilo_s2m_step.argtypes = [C.c_void_p, fp, C.c_int, fp, C.c_int, C.POINTER(abi.Scan2MapResult)]
+        L.vilo_s2m_get_map.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]
+        L.vilo_s2m_set_pose.argtypes = [C.c_void_p, abi.c_double_p, abi.c_double_p]
+        self.L = L
+        self.h = L.vilo_s2m_create(C.byref(opts))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.vilo_s2m_destroy(self.h); self.h = None
+
+    @staticmethod
+    def _fp(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def init(self, edge, surf):
+        e, ep = self._fp(edge); s, sp = self._fp(surf)
+        assert self.L.vilo_s2m_init(self.h, ep, len(e), sp, len(s)) == 0
+
+    def step(self, edge, surf):
+        e, ep = self._fp(edge); s, sp = self._fp(surf)
+        res = abi.Scan2MapResult()
+        assert self.L.vilo_s2m_step(self.h, ep, len(e), sp, len(s), C.byref(res)) == 0
+        return res
+
+    def get_map(self, which):
+        n = C.c_int(0)
+        self.L.vilo_s2m_get_map(self.h, which, None, 0, C.byref(n))
+        out = np.zeros((max(n.value, 1), 4), dtype=np.float32)
+        self.L.vilo_s2m_get_map(self.h, which, out.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n))
+        return out[:n.value]
+
+    def set_pose(self, pose, pose_last):
+        self.L.vilo_s2m_set_pose(self.h, abi.dptr(np.ascontiguousarray(pose, dtype=np.float64)), abi.dptr(np.ascontiguousarray(pose_last, dtype=np.float64)))

@@ -10,8 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
-#include "../../include/vilfusion.h"
-#include "vilf_batch.hpp"
+#include "vilf_internal.hpp"
 
 #define IMU_REC 288
 #define IMU_SQRT 62
@@ -36,30 +35,6 @@ __global__ void k_hook_plus(const double *, const double *, int, double *);
 }
 
 namespace {
-
-struct DBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    bool ensure(size_t bytes) {
-        if (bytes <= cap) return true;
-        if (p) hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        if (hipMalloc(&p, want) != hipSuccess) return false;
-        cap = want;
-        return true;
-    }
-    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T *as() { return reinterpret_cast<T *>(p); }
-};
-
-enum {
-    D_NFEAT, D_NFAC, D_POSE, D_SB, D_FEAT, D_CPOSE, D_CSB, D_CFEAT, D_POSE0, D_SB0, D_FEAT0, D_EX, D_GR0, D_GP0,
-    D_FSTART, D_FNOBS, D_FOBS0, D_FFAC0, D_FCONST, D_OBS, D_PSFEAT, D_PSOBS, D_PSSLOT, D_PAIROFF, D_IMU, D_LIDAR,
-    D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_FACW, D_HPP, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G,
-    D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV,
-    D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR, D_COUNT
-};
 
 void quat_from_R(const double *m, double *q /*xyzw*/) {   // Eigen Quaterniond(Matrix3d)
     double t = m[0] + m[4] + m[8];
@@ -88,43 +63,6 @@ void quat_to_R(const double *q, double *R) {
 }
 
 }  // namespace
-
-struct vilf_handle {
-    vilf_options opts;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err;
-    DBuf d[D_COUNT];
-    VbBatch batch;
-    int B = 0;
-    bool resident = false;
-    std::vector<vilf_prior> priors;          // per slot (host mirror)
-    std::vector<char> prior_dirty;
-    std::vector<char> prior_dev_newer;       // slot's prior was produced on the device (marginalize) and not yet mirrored
-    std::vector<int> h_mflag;
-    int mg_Mcap = 0;
-    VbMarg marg;
-    size_t marg_lds_schur = 0, marg_lds_finish = 0;
-    std::vector<int> h_nfeat, h_nframes;
-    std::vector<double> h_ex, h_td;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int profiling = 0;                       // per-kernel HIP-event timing of the solve launches
-    std::vector<hipEvent_t> pev;
-    double kernel_ms[4] = {0, 0, 0, 0};      // linearize, solve, step, other (accumulated since last reset)
-    long kernel_launches[4] = {0, 0, 0, 0};
-    double last_solve_usec = 0;
-    size_t solve_lds = 0, lin_lds = 0;
-};
-
-#define HIPCHECK(h, call)                                                                                        \
-    do {                                                                                                         \
-        hipError_t e_ = (call);                                                                                  \
-        if (e_ != hipSuccess) {                                                                                  \
-            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                        \
-            return VILF_ERR_DEVICE;                                                                              \
-        }                                                                                                        \
-    } while (0)
 
 extern "C" const char *vilf_version(void) { return "vilfusion-hip 0.1 (gfx950)"; }
 
@@ -186,6 +124,7 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     if (!h) return;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    vilf_s2m_release(h);
     for (auto &b : h->d) b.release();
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);

@@ -103,8 +103,3 @@ extern "C" int vilf_imu_preintegrate(const vilf_imu_noise *nz, const double acc_
     return VILF_OK;
 }
 
-// ---- scan-to-map entry points: device path not built yet (round-1 work in progress) — fail loudly, never fall back ----
-extern "C" int vilf_scan2map_init(vilf_handle *, const float *, int, const float *, int) { return VILF_ERR_UNSUPPORTED; }
-extern "C" int vilf_scan2map_step(vilf_handle *, const float *, int, const float *, int, vilf_scan2map_result *) { return VILF_ERR_UNSUPPORTED; }
-extern "C" int vilf_scan2map_get_map(vilf_handle *, int, float *, int, int *) { return VILF_ERR_UNSUPPORTED; }
-extern "C" int vilf_scan2map_set_pose(vilf_handle *, const double[7], const double[7]) { return VILF_ERR_UNSUPPORTED; }

@@ -183,3 +183,39 @@ def imu_preintegrate(noise, acc_0, gyr_0, ba, bg, dt, acc, gyr):
     if rc != 0:
         raise VilfError(f"vilf_imu_preintegrate: status {rc}")
     return out
+
+
+class Scan2Map:
+    """Host mirror of EstimationMapping (feature_tracker/include/EstimationMapping.hpp): localMapInited / optimation_processing /
+    getMapCloud over the device path. One LiDAR stream per BackendSolver handle."""
+
+    def __init__(self, solver):
+        self.s = solver
+        self._L = solver._L
+
+    @staticmethod
+    def _fp(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] == 4
+        return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def localMapInited(self, edge_xyzi, surf_xyzi):
+        e, ep = self._fp(edge_xyzi); s, sp = self._fp(surf_xyzi)
+        self.s._check(self._L.vilf_scan2map_init(self.s._h, ep, len(e), sp, len(s)), "vilf_scan2map_init")
+
+    def optimation_processing(self, edge_xyzi, surf_xyzi):
+        e, ep = self._fp(edge_xyzi); s, sp = self._fp(surf_xyzi)
+        res = abi.Scan2MapResult()
+        self.s._check(self._L.vilf_scan2map_step(self.s._h, ep, len(e), sp, len(s), C.byref(res)), "vilf_scan2map_step")
+        return res
+
+    def getMapCloud(self, which):
+        n = C.c_int(0)
+        self.s._check(self._L.vilf_scan2map_get_map(self.s._h, which, None, 0, C.byref(n)), "vilf_scan2map_get_map")
+        out = np.zeros((max(n.value, 1), 4), dtype=np.float32)
+        self.s._check(self._L.vilf_scan2map_get_map(self.s._h, which, out.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)), "vilf_scan2map_get_map")
+        return out[:n.value]
+
+    def set_pose(self, pose_qt, pose_last_qt):
+        f = lambda v: abi.dptr(np.ascontiguousarray(v, dtype=np.float64))
+        self.s._check(self._L.vilf_scan2map_set_pose(self.s._h, f(pose_qt), f(pose_last_qt)), "vilf_scan2map_set_pose")

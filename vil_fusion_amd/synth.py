@@ -357,3 +357,72 @@ def make_batch(seed, n_windows, opts, cfg=None, distinct=None):
     wins = [base[i % distinct][0] for i in range(n_windows)]
     priors = [base[i % distinct][1] for i in range(n_windows)]
     return wins, priors
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Synthetic LiDAR scene for the scan-to-map path: ground plane, 4 walls and vertical poles in a box,
+# a 64-ring / 1800-azimuth scan pattern ray-cast from the moving sensor. Pole hits are handed out as "edge" features, ground /
+# wall hits as "surf" features (the LOAM curvature front-end that does this classification in the reference,
+# featureExtraction.hpp, is out of scope: its outputs are the inputs of the hot path).
+class LidarScene:
+    def __init__(self, seed=0, half=100.0, n_poles=40, sensor_height=1.73, rings=64, azimuths=1800, max_range=90.0, min_range=3.0, noise=0.02):
+        rng = np.random.default_rng(seed)
+        self.rng = rng
+        self.half, self.h = half, sensor_height
+        self.poles = np.column_stack([rng.uniform(-half * 0.9, half * 0.9, n_poles), rng.uniform(-half * 0.9, half * 0.9, n_poles)])
+        self.pole_r = rng.uniform(0.1, 0.25, n_poles)
+        el = np.deg2rad(np.linspace(-24.8, 2.0, rings))
+        az = np.linspace(-np.pi, np.pi, azimuths, endpoint=False)
+        E, A = np.meshgrid(el, az, indexing="ij")
+        self.dirs = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
+        self.max_range, self.min_range, self.noise = max_range, min_range, noise
+
+    def scan(self, R_wl, t_wl, edge_keep=0.5, surf_keep=0.06):
+        """ray-cast one scan; returns (edge_xyzi, surf_xyzi) float32 in the LiDAR frame"""
+        rng = self.rng
+        d = self.dirs @ R_wl.T                     # world directions
+        o = t_wl
+        n = d.shape[0]
+        best = np.full(n, np.inf); kind = np.zeros(n, dtype=np.int8)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = (0.0 - o[2]) / d[:, 2]            # ground z = 0
+            ok = (tg > 0) & (tg < best); best[ok] = tg[ok]; kind[ok] = 1
+            for axis in (0, 1):
+                for sgn in (-1.0, 1.0):
+                    tw = (sgn * self.half - o[axis]) / d[:, axis]
+                    hit = o + tw[:, None] * d
+                    ok = (tw > 0) & (tw < best) & (hit[:, 2] > 0) & (hit[:, 2] < 12.0) & (np.abs(hit[:, 1 - axis]) <= self.half)
+                    best[ok] = tw[ok]; kind[ok] = 1
+            # vertical cylinders (poles), height 0..8 m
+            dxy2 = d[:, 0] ** 2 + d[:, 1] ** 2
+            for (px, py), r in zip(self.poles, self.pole_r):
+                ox, oy = o[0] - px, o[1] - py
+                bq = ox * d[:, 0] + oy * d[:, 1]
+                cq = ox * ox + oy * oy - r * r
+                disc = bq * bq - dxy2 * cq
+                tc = (-bq - np.sqrt(np.where(disc > 0, disc, np.nan))) / dxy2
+                z = o[2] + tc * d[:, 2]
+                ok = (disc > 0) & (tc > 0) & (tc < best) & (z > 0) & (z < 8.0)
+                best[ok] = tc[ok]; kind[ok] = 2
+        ok = np.isfinite(best) & (best > self.min_range) & (best < self.max_range)
+        rngs = best + rng.normal(0, self.noise, n)
+        pts_l = self.dirs * rngs[:, None]          # LiDAR frame
+        e_idx = np.where(ok & (kind == 2))[0]
+        s_idx = np.where(ok & (kind == 1))[0]
+        e_idx = e_idx[rng.uniform(size=e_idx.size) < edge_keep]
+        s_idx = s_idx[rng.uniform(size=s_idx.size) < surf_keep]
+        mk = lambda idx: np.ascontiguousarray(np.column_stack([pts_l[idx], np.ones(idx.size)]).astype(np.float32))
+        return mk(e_idx), mk(s_idx)
+
+
+def make_lidar_sequence(seed, n_frames, speed=8.0, dt=0.1, yaw_rate=0.05, **kw):
+    """returns (scans [(edge, surf)], poses [(R_wl, t_wl)]) for a vehicle driving through a LidarScene"""
+    scene = LidarScene(seed, **kw)
+    scans, poses = [], []
+    for k in range(n_frames):
+        yaw = yaw_rate * k * dt * 10
+        R = euler_R(np.array(yaw), np.array(0.0), np.array(0.0))
+        t = np.array([-30.0 + speed * dt * k, 5.0 * np.sin(0.1 * k), scene.h])
+        scans.append(scene.scan(R, t))
+        poses.append((R, t))
+    return scans, poses
