@@ -86,6 +86,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from vil_fusion_amd import synth
+    from vil_fusion_amd import dist as vdist
     from vil_fusion_amd.estimator import BackendSolver
     stream = torch.cuda.current_stream().cuda_stream
     solver = BackendSolver(device=local_rank, stream=stream)
@@ -95,7 +96,6 @@ def main():
     wins, priors = synth.make_batch(1000 + rank, B, opts, cfg, distinct=args.distinct)
     solver.batch_upload(wins, priors)              # inputs resident in HBM before the timed region
     poses = torch.zeros((B, 8), dtype=torch.float64, device="cuda")
-    gathered = torch.zeros((world * B, 8), dtype=torch.float64, device="cuda") if world > 1 else None
     stamps = np.arange(B, dtype=np.float64)
 
     def step():
@@ -103,7 +103,7 @@ def main():
         solver.batch_solve(sync=True)
         if world > 1:
             solver.newest_poses_to_device(stamps, poses.data_ptr())
-            dist.all_gather_into_tensor(gathered, poses)     # RCCL: 64 B per solved window to every rank (rank 0 feeds global_fusion)
+            vdist.gather_poses(poses)                         # RCCL all_gather: 64 B per solved window (rank 0 feeds global_fusion)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,50 @@
+"""Multi-GPU: independent window snapshots / sequence segments shard over ranks (one process per GPU); no intra-solve
+communication. The only exchange is the gather of newest-frame poses [stamp x y z qx qy qz qw] (64 B per solved window) that
+feeds the global_fusion pose graph (src/global_fusion/poseGraphOptimization.cpp:116-121 expects position + quaternion + stamp).
+Backend "nccl" is RCCL on ROCm (xGMI point-to-point links; the message is latency-bound), "gloo" on CPU for tests.
+"""
+import numpy as np
+
+
+def shard_range(n_units, rank, world_size):
+    """contiguous block assignment: units [lo, hi) of rank; sizes differ by at most one, every unit assigned exactly once"""
+    base, rem = divmod(n_units, world_size)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def shard_counts(n_units, world_size):
+    return [shard_range(n_units, r, world_size)[1] - shard_range(n_units, r, world_size)[0] for r in range(world_size)]
+
+
+def gather_poses(local_poses, n_units=None, group=None):
+    """All-gather of per-rank pose rows (torch tensor [n_local, 8], float64, on the backend's device).
+    Equal shard sizes use one all_gather_into_tensor (single RCCL call); ragged shards pad to the largest shard.
+    Returns a [n_total, 8] tensor ordered by rank then local index (= global unit order under shard_range)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n_local = local_poses.shape[0]
+    if n_units is None:
+        out = torch.empty((world * n_local, 8), dtype=local_poses.dtype, device=local_poses.device)
+        dist.all_gather_into_tensor(out, local_poses.contiguous(), group=group)
+        return out
+    counts = shard_counts(n_units, world)
+    m = max(counts)
+    padded = torch.zeros((m, 8), dtype=local_poses.dtype, device=local_poses.device)
+    padded[:n_local] = local_poses
+    out = torch.empty((world * m, 8), dtype=local_poses.dtype, device=local_poses.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * m: r * m + counts[r]] for r in range(world)], dim=0)
+
+
+def newest_poses_rows(results, stamps):
+    """[stamp x y z qx qy qz qw] rows from solved windows (host side, for CPU tests): newest frame = last frame of the window."""
+    from .synth import R_to_q
+    rows = np.zeros((len(results), 8))
+    for i, r in enumerate(results):
+        rows[i, 0] = stamps[i]
+        rows[i, 1:4] = r.Ps[-1]
+        rows[i, 4:8] = R_to_q(r.Rs[-1])
+    return rows
