@@ -24,3 +24,9 @@ if os.environ.get("VILF_DEBUG_STAMPS"):
             print(name, "phase cycles:", np.diff(v), "total", v[-1] - v[0])
 if os.environ.get("VILF_DEBUG_STAMPS"):
     print("linearize chunk-loop (wave 0): eval", a[2][16], "sync1", a[2][17], "mfma", a[2][18], "sync2", a[2][19])
+if os.environ.get("VILF_DEBUG_STAMPS"):
+    v = a[1]
+    print("schur sub-stamps rel to stamp4: setup->", int(v[16] - v[4]), "mfma loop end->", int(v[15] - v[4]), "end->", int(v[5] - v[4]))
+
+if os.environ.get("VILF_DEBUG_STAMPS"):
+    print("cholesky (wave 0): potrf0", a[2][20], "trsm", a[2][21], "phase1", a[2][22], "phase2(potrf||rest)", a[2][23])

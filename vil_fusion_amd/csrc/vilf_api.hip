@@ -105,7 +105,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
     else { if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return VILF_ERR_DEVICE; } h->own_stream = true; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
-    h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + VB_NT + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
+    h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + 512 + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
     h->lin_lds = (size_t)(2 * VB_CHUNK * VB_XLD + VB_NPAIR * VB_PAIRD) * sizeof(double);
     h->marg_lds_schur = (size_t)MG_MLDS * MG_MLDS * sizeof(double);
     h->marg_lds_finish = (size_t)2 * (MG_NK + 2) * (MG_NK + 2) * sizeof(double);
@@ -243,7 +243,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_LIDAR, sB * 10 * 7 * 8}, {D_PHDR, sB * VB_PRIOR_HDR * 4}, {D_PX0, sB * 24 * 9 * 8}, {D_PJ, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PR, sB * VB_PRIOR_LD * 8},
         {D_PH, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PG, sB * VB_PRIOR_LD * 8}, {D_FACW, sB * VB_FACW * sC * 8}, {D_HPP, sB * 66 * 36 * 8},
         {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
-        {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
+        {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_DIAGH, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
         {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
         {D_OBGS, sB * 33 * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
     };
@@ -351,7 +351,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.prior_hdr = h->d[D_PHDR].as<int>(); b.prior_x0 = h->d[D_PX0].as<double>(); b.prior_J = h->d[D_PJ].as<double>(); b.prior_r = h->d[D_PR].as<double>();
     b.prior_H = h->d[D_PH].as<double>(); b.prior_g = h->d[D_PG].as<double>();
     b.facw = h->d[D_FACW].as<double>(); b.Hpp = h->d[D_HPP].as<double>(); b.W = h->d[D_W].as<double>(); b.hf = h->d[D_HF].as<double>(); b.gf = h->d[D_GF].as<double>();
-    b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>();
+    b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>(); b.diagH = h->d[D_DIAGH].as<double>();
     b.scale = h->d[D_SCALE].as<double>(); b.diag = h->d[D_DIAG].as<double>(); b.grad = h->d[D_GRAD].as<double>(); b.gn = h->d[D_GN].as<double>();
     b.st = h->d[D_ST].as<VbState>();
     b.out_Ps = h->d[D_OPS].as<double>(); b.out_Rs = h->d[D_ORS].as<double>(); b.out_Vs = h->d[D_OVS].as<double>();
@@ -362,7 +362,9 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, hipMemsetAsync(h->d[D_W].p, 0, sB * sF * VB_WLD * 8, h->stream));   // W rows are zero outside the rewritten ranges
     {   // static scatter tables of the tile assembly (same for every window): source element -> LDS offset, -1 = not stored
         auto perm = [](int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); };
-        auto off = [](int r, int c) { const int tr = r >> 4, tc = c >> 4; if (tr < tc) return -1; return (tr * (tr + 1) / 2 + tc) * 256 + 16 * (r & 15) + ((c & 15) ^ (r & 15)); };
+        // packed entry: bits 0..14 = LDS offset + 1 (0: element not stored, upper block triangle), bits 15..22 = row, bits 23..30 = column
+        auto off1 = [](int r, int c) { const int tr = r >> 4, tc = c >> 4; if (tr < tc) return 0; return (tr * (tr + 1) / 2 + tc) * 256 + 16 * (r & 15) + ((c & 15) ^ (r & 15)) + 1; };
+        auto off = [&](int r, int c) { return off1(r, c) | (r << 15) | (c << 23); };
         std::vector<int> li(9000), ll(1440), lv(2 * 2376);
         for (int k = 0; k < 10; k++) {
             for (int e = 0; e < 900; e++) { const int p = e / 30, q = e % 30; li[900 * k + e] = off(perm(k + p / 15, p % 15), perm(k + q / 15, q % 15)); }
@@ -373,7 +375,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             int a = 0; while ((a + 1) * (a + 2) / 2 <= blk) a++;
             const int bb = blk - a * (a + 1) / 2, r = 6 * a + l, c = 6 * bb + m;
             lv[2 * t] = off(r, c);
-            lv[2 * t + 1] = (a != bb && (r >> 4) == (c >> 4)) ? off(c, r) : -1;
+            lv[2 * t + 1] = (a != bb && (r >> 4) == (c >> 4)) ? off1(c, r) : 0;
         }
         if (!h->d[D_LUTI].ensure(li.size() * 4) || !h->d[D_LUTL].ensure(ll.size() * 4) || !h->d[D_LUTV].ensure(lv.size() * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemcpy(h->d[D_LUTI].p, li.data(), li.size() * 4, hipMemcpyHostToDevice));
@@ -426,7 +428,7 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 1);
     for (int it = 0; it < h->opts.max_num_iterations; it++) {
         mark(1);
-        hipLaunchKernelGGL(k_solve, grid, block, h->solve_lds, h->stream, h->batch);
+        hipLaunchKernelGGL(k_solve, grid, dim3(512), h->solve_lds, h->stream, h->batch);
         mark(2);
         hipLaunchKernelGGL(k_step, grid, block, 0, h->stream, h->batch);
         mark(0);

@@ -106,6 +106,7 @@ struct VbBatch {
     const double *prior_x0, *prior_J, *prior_r, *prior_H, *prior_g;
     // workspace
     double *facw, *Hpp, *W, *hf, *gf, *imuH, *imug, *lidH, *lidg, *g;
+    double *diagH;          // [B][165] diagonal of the (unscaled) reduced system, frame-major (Jacobi scaling / dogleg diagonal)
     double *scale, *diag, *grad, *gn;
     VbState *st;
     // outputs of finalize

@@ -206,7 +206,7 @@ __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the
 }
 
 extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) {
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     VbState *st = b.st + w;
     if (!iteration_zero) { if (st->done || !st->need_linearize) return; }
 
@@ -337,6 +337,9 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     double *facw = b.facw + (size_t)w * VB_FACW * FC;
     double *W = b.W + (size_t)w * FM * VB_WLD;
     long long t_eval = 0, t_sync1 = 0, t_mfma = 0, t_sync2 = 0, t_a = 0;
+    int pe[4];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; q4++) pe[q4] = pair_elem((lane >> 4) + 4 * q4, lane & 15);   // C-tile register -> pairD slot (fixed per lane)
     for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
         t_a = __builtin_readcyclecounter();
         const int q = c0 + tid;
@@ -373,29 +376,34 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         { long long t_b = __builtin_readcyclecounter(); t_sync1 += t_b - t_a; t_a = t_b; }
         const int cend = min(c0 + VB_CHUNK, nfac);
         for (int p = wave; p < VB_NPAIR; p += 4) {
-            const int lo = max(s_poff[p], c0), hi = min(s_poff[p + 1], cend);
+            const int lo = __builtin_amdgcn_readfirstlane(max(s_poff[p], c0)), hi = __builtin_amdgcn_readfirstlane(min(s_poff[p + 1], cend));
             if (lo >= hi) continue;
             const int r_hi = 2 * (hi - c0);
             double4_t acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            for (int r0 = 2 * (lo - c0); r0 < r_hi; r0 += 16) {
-                double a[4];
+            auto ld4 = [&](int r0, double *a) {         // unconditional LDS reads (clamped row), masked afterwards: no exec-masked loads
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int row = r0 + 4 * u + (lane >> 4);
-                    a[u] = (row < r_hi) ? s_X[row * VB_XLD + (lane & 15)] : 0.0;
+                    const double v = s_X[min(row, 2 * VB_CHUNK - 1) * VB_XLD + (lane & 15)];
+                    a[u] = (row < r_hi) ? v : 0.0;
                 }
+            };
+            double a[4], an[4];
+            ld4(2 * (lo - c0), a);
+            for (int r0 = 2 * (lo - c0); r0 < r_hi; r0 += 16) {
+                ld4(r0 + 16, an);                         // prefetch the next 16 rows while the 4 MFMAs below execute
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], acc1, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], acc, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], acc1, 0, 0, 0);
-            }
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) acc[q4] += acc1[q4];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) {
-                const int e = pair_elem((lane >> 4) + 4 * q4, lane & 15);
-                if (e >= 0) s_U[p * VB_PAIRD + e] += acc[q4];
+                for (int u = 0; u < 4; u++) a[u] = an[u];
             }
+            double old4[4];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) old4[q4] = s_U[p * VB_PAIRD + max(pe[q4], 0)];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) s_U[p * VB_PAIRD + pe[q4]] = old4[q4] + (acc[q4] + acc1[q4]);
         }
         { long long t_b = __builtin_readcyclecounter(); t_mfma += t_b - t_a; t_a = t_b; }
         __syncthreads();
@@ -465,6 +473,19 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         }
         gout[tid] = s;
         s_grad[tid] = s;
+        // diagonal of J^T J for this reduced variable
+        const double *imuHg = b.imuH + (size_t)w * 9000, *lidHg = b.lidH + (size_t)w * 1440;
+        double dg = 0;
+        if (l < 6) {
+            for (int i = 0; i < a; i++) dg += s_U[pair_index(i, a) * VB_PAIRD + 7 * l];
+            for (int j = a + 1; j < VB_NF; j++) dg += s_U[pair_index(a, j) * VB_PAIRD + 72 + 7 * l];
+            if (a >= 1) dg += lidHg[144 * (a - 1) + 13 * (6 + l)];
+            if (a <= 9) dg += lidHg[144 * a + 13 * l];
+        }
+        if (a >= 1) dg += imuHg[900 * (a - 1) + 31 * (15 + l)];
+        if (a <= 9) dg += imuHg[900 * a + 31 * l];
+        if (pc >= 0) dg += b.prior_H[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * (VB_PRIOR_LD + 1)];
+        b.diagH[(size_t)w * VB_P + tid] = dg;
     }
     __syncthreads();
     // gradient_max_norm = || x - Plus(x, -g) ||_inf (trust_region_minimizer.cc), x_norm = ||x||
@@ -497,35 +518,38 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 // ------------------------------------------------------------------------------------------------------------------
 // k_solve helpers
 
-// 16x16 lower Cholesky of the diagonal tile by ONE wave, tile held in registers (4 doubles / lane), column broadcasts by
-// ds_bpermute, pivots through v_rsq_f64 + Newton (no fp64 sqrt / divide sequences on the critical path).
-// Lane l holds rows r = l&15, columns c = (l>>4) + 4q. Returns false if a pivot is not positive (Eigen LLT semantics).
+// 16x16 lower Cholesky of the diagonal tile by ONE wave. Lane r (< 16; the other lanes mirror lane r & 15) holds row r in 16
+// registers. Left-looking column sweep: for column j the pivot row L[j][0..j-1] is broadcast through SGPRs (v_readlane with a
+// compile-time lane), so there is no LDS / ds_bpermute round trip on the pivot chain; the update terms of column j+1 that do not
+// depend on pivot j are issued while the v_rsq_f64 + Newton chain of pivot j is in flight. Returns false if a pivot is not
+// positive (Eigen LLT semantics).
 __device__ bool potrf_tile_wave(double *T, double *s_invd, int lane) {
-    const int r = lane & 15, cq = lane >> 4;
-    double v[4];
+    const int r = lane & 15;
+    double v[16];
 #pragma unroll
-    for (int q = 0; q < 4; q++) v[q] = T[TIX(r, cq + 4 * q)];
+    for (int c = 0; c < 16; c++) v[c] = T[TIX(r, c)];
     bool ok = true;
+    double myinv = 1.0;
+    // s[c] accumulates A[r][c] - sum_{p < j} L[r][p] L[c][p] for the columns still to be factorised; kept in v[c] itself.
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const int jq = j >> 2, jl = j & 3;
-        const double djj = readlane_f64(v[jq], jl * 16 + j);
+        const double djj = readlane_f64(v[j], j);
         if (!(djj > 0.0)) ok = false;
-        const double inv = rsqrt_nr(djj);
-        const double Lrj = __shfl(v[jq], jl * 16 + r, 64) * inv;
-        double Lcj[4];
+        const double inv = rsqrt_nr(djj);                       // long dependent chain: independent work below hides it
+        // L[r][j] for r >= j; rows r < j keep junk in v[j] (upper triangle, never read)
+        const double lrj = v[j] * inv;
+        v[j] = lrj;
+        if (r == j) myinv = inv;
+        // right-looking update of the remaining columns with the broadcast column entries L[c][j], c > j
 #pragma unroll
-        for (int q = 0; q < 4; q++) Lcj[q] = __shfl(v[jq], jl * 16 + ((cq + 4 * q) & 15), 64) * inv;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int c = cq + 4 * q;
-            if (c > j && r >= c) v[q] -= Lrj * Lcj[q];
+        for (int c = j + 1; c < 16; c++) {
+            const double lcj = readlane_f64(lrj, c);
+            v[c] -= lrj * lcj;
         }
-        if (cq == jl && r >= j) v[jq] = Lrj;
-        if (lane == 0) s_invd[j] = inv;
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int c = cq + 4 * q; T[TIX(r, c)] = (c <= r) ? v[q] : 0.0; }
+    for (int c = 0; c < 16; c++) if (lane < 16) T[TIX(r, c)] = (c <= r) ? v[c] : 0.0;
+    if (lane < 16) s_invd[r] = myinv;
     return ok;
 }
 
@@ -535,8 +559,131 @@ __device__ __forceinline__ void tile_add(double *s_T, int r, int c, double v) {
     if (tr >= tc) s_T[tile_index(tr, tc) * 256 + TIX(r & 15, c & 15)] += v;
 }
 
-extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define SNT 512
+#define SNW (SNT / 64)
+__device__ __forceinline__ double block_sum_s(double v, double *s_red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    s_red[tid] = v;
+    __syncthreads();
+    for (int s = SNT / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
+    const double r = s_red[0];
+    __syncthreads();
+    return r;
+}
+
+
+// MFMA Schur reduce of the eliminated inverse depths:  H~_pp -= U^T U,  rhs_p -= U^T t  over the 5x5 pose tile block.
+// U row f: columns 0..65 = c_f * S_p * W_f[p], column 66 = c_f * g_f (the rhs rides along as one more column), 67..79 = 0.
+// K (the features) is split over 4 wave groups; the two waves of a group (HALF = 0 / 1) own 8 / 7 of the 15 tile pairs — tile
+// indices are compile-time, so operands are plain register picks. Loads are unconditional, coalesced (zero-padded 80-wide rows,
+// rows >= F are zero) and prefetched three k-steps ahead with no arithmetic on them until they are consumed. Group results are
+// subtracted in fixed group order (bit-reproducible).
+template <int HALF>
+__device__ __forceinline__ void schur_mfma(const double *W, int F, const double *s_cf, const double *s_scale, double *s_T, double *s_y, int lane, int wave) {
+    constexpr int TA[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
+    constexpr int TB[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4};
+    constexpr int NP = HALF ? 7 : 8, PB = HALF ? 8 : 0;
+    const int c16 = lane & 15, grp = wave >> 1, g4 = lane >> 4;
+    const int nsteps = ((F + 3) & ~3) / 4;
+    double sc5[5];
+#pragma unroll
+    for (int t5 = 0; t5 < 5; t5++) { const int col = 16 * t5 + c16; sc5[t5] = (col < VB_NPOSE) ? s_scale[col] : (col == VB_NPOSE ? 1.0 : 0.0); }
+    double4_t acc[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) acc[i] = double4_t{0, 0, 0, 0};
+    double r0[5], r1[5], r2[5], r3[5], c0, c1, c2, c3;
+#define SCHUR_LOAD(ST, R, C)                                                                 \
+    {                                                                                        \
+        const int st_ = min((ST), nsteps - 1);                                               \
+        const int f_ = 4 * st_ + g4;                                                         \
+        C = s_cf[f_];                                                                        \
+        const double *Wr_ = W + (size_t)f_ * VB_WLD + c16;                                   \
+        _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) R[t5] = Wr_[16 * t5];               \
+    }
+    SCHUR_LOAD(grp, r0, c0) SCHUR_LOAD(grp + 4, r1, c1) SCHUR_LOAD(grp + 8, r2, c2)
+    for (int st = grp; st < nsteps; st += 4) {
+        SCHUR_LOAD(st + 12, r3, c3)
+        double u[5];
+#pragma unroll
+        for (int t5 = 0; t5 < 5; t5++) u[t5] = r0[t5] * c0 * sc5[t5];
+#pragma unroll
+        for (int i = 0; i < NP; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[TA[PB + i]], u[TB[PB + i]], acc[i], 0, 0, 0);
+#pragma unroll
+        for (int t5 = 0; t5 < 5; t5++) { r0[t5] = r1[t5]; r1[t5] = r2[t5]; r2[t5] = r3[t5]; }
+        c0 = c1; c1 = c2; c2 = c3;
+    }
+#undef SCHUR_LOAD
+    for (int gsel = 0; gsel < 4; gsel++) {
+        if (grp == gsel) {
+            double tv[NP][4];
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                constexpr int dummy = 0; (void)dummy;
+                const int ta = TA[PB + i], tb = TB[PB + i];
+                double *T = s_T + tile_index(ta, tb) * 256;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int rl = g4 + 4 * q;                        // row inside the tile
+                    if (ta < 4) tv[i][q] = T[TIX(rl, c16)];
+                    else tv[i][q] = (rl < 2) ? T[TIX(rl, c16)] : ((rl == 2) ? s_y[16 * tb + c16] : 0.0);   // tile row 4: rows 64, 65 | row 66 = rhs
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const int ta = TA[PB + i], tb = TB[PB + i];
+                double *T = s_T + tile_index(ta, tb) * 256;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int rl = g4 + 4 * q, col = 16 * tb + c16;
+                    const double nv = tv[i][q] - acc[i][q];
+                    if (ta < 4) { if (col < VB_NPOSE) T[TIX(rl, c16)] = nv; }
+                    else if (col < VB_NPOSE) { if (rl < 2) T[TIX(rl, c16)] = nv; else if (rl == 2) s_y[col] = nv; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dot(W~_f[0..65], vec) for every feature, 16 lanes per feature (4 features per wave per round), coalesced 80-wide rows;
+// result per feature is written to out[f] (only for non-constant features, others 0). vec lives in LDS (>= 80 entries, 66.. = 0).
+__device__ __forceinline__ void feature_dots(const double *W, int F, const uint8_t *f_const, const double *s_sv /*scale .* vec, 80 entries*/, double *out, int tid) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g = lane >> 4;
+    double sv[5];
+#pragma unroll
+    for (int t5 = 0; t5 < 5; t5++) sv[t5] = s_sv[16 * t5 + c16];
+    const int Fk4 = (F + 3) & ~3;                       // rows F..Fk4-1 of W are zero (never written)
+    double wn[5];
+    {
+        const int f = min(4 * wave + g, Fk4 - 1);
+        const double *Wr = W + (size_t)f * VB_WLD + c16;
+#pragma unroll
+        for (int t5 = 0; t5 < 5; t5++) wn[t5] = Wr[16 * t5];
+    }
+    for (int f0 = 4 * wave; f0 < F; f0 += 4 * SNW) {
+        const int f = f0 + g;
+        double wv[5];
+#pragma unroll
+        for (int t5 = 0; t5 < 5; t5++) wv[t5] = wn[t5];
+        {
+            const int fn = min(f0 + 4 * SNW + g, Fk4 - 1);
+            const double *Wr = W + (size_t)fn * VB_WLD + c16;
+#pragma unroll
+            for (int t5 = 0; t5 < 5; t5++) wn[t5] = Wr[16 * t5];
+        }
+        double acc = 0;
+#pragma unroll
+        for (int t5 = 0; t5 < 5; t5++) acc += wv[t5] * sv[t5];
+        if (!(f < F) || f_const[min(f, F - 1)]) acc = 0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (c16 == 0 && f < F) out[f] = acc;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     VbState *st = b.st + w;
     extern __shared__ double s_dyn[];
     double *s_T = s_dyn;                      // 66 tiles * 256
@@ -547,7 +694,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
     double *s_invd = s_y + VB_NPAD;           // 1 / L_jj
     double *s_v = s_invd + VB_NPAD;           // v = g~ ./ diagonal_^2
     double *s_red = s_v + VB_NPAD;            // NT
-    double *s_cf = s_red + NT;                // per feature: s_f / sqrt(h~')   (0 for constant features)   [<= 1000]
+    double *s_cf = s_red + SNT;                // per feature: s_f / sqrt(h~')   (0 for constant features)   [<= 1000]
     int *s_rng = (int *)(s_cf + VILF_MAX_FEATURES_DEV);   // per feature: 6*start | (6*(start+nobs)) << 16
     __shared__ int s_pcol[VB_P], s_pinv[VB_PRIOR_LD];
     __shared__ double s_dx[VB_PRIOR_LD];
@@ -587,224 +734,176 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
     if (tid < VB_PRIOR_LD) s_pinv[tid] = -1;
     __syncthreads();
     if (tid < VB_P) { const int pc = s_pcol[tid]; if (pc >= 0) { const int a = tid / 15, l = tid - 15 * a; s_pinv[pc] = perm_index(a, l); } }
-    for (int f = tid; f < F; f += NT) s_rng[f] = (6 * f_start[f]) | ((6 * (f_start[f] + f_nobs[f])) << 16);
     const int scaling_ready = st->scaling_ready;
     double mu = st->mu;
     int tries = 0;
     bool solved = false;
     double Jg2 = 0, G2 = 0;
+    // ---- Jacobi scaling (computed once, iteration 0: 1/(1+sqrt(diag J^T J))), dogleg diagonal_, gradient_, v = g~ ./ diagonal_^2 --------
+    double g2 = 0;
+    if (tid < VB_NPAD) {
+        double sc = 1.0, d = 1.0, gs = 0.0, vv = 0.0;
+        if (tid < VB_P) {
+            int a, l; unperm(tid, a, l);
+            const double dh = b.diagH[(size_t)w * VB_P + 15 * a + l];
+            if (scaling_ready) sc = scale_g[tid]; else { sc = 1.0 / (1.0 + sqrt(dh)); scale_g[tid] = sc; }
+            d = sqrt(fmin(fmax(sc * sc * dh, b.min_lm_diagonal), b.max_lm_diagonal));
+            gs = g_in[15 * a + l] * sc;
+            diag_g[tid] = d;
+            const double gr = gs / d;
+            grad_g[tid] = gr;
+            g2 = gr * gr;
+            vv = gr / d;
+        }
+        s_scale[tid] = sc; s_diag[tid] = d; s_g[tid] = gs; s_v[tid] = vv;
+    }
+    // per-feature scalars (registers: <= 2 features per thread): scale, diagonal, gradient, v_f
+    double f_sf[2] = {0, 0}, f_df[2] = {1, 1}, f_hf[2] = {0, 0}, f_gf[2] = {0, 0};
+    bool f_on[2] = {false, false};
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int f = tid + u * SNT;
+        if (f < F) {
+            s_rng[f] = (6 * f_start[f]) | ((6 * (f_start[f] + f_nobs[f])) << 16);
+            if (!f_const[f]) {
+                f_on[u] = true;
+                f_hf[u] = hf[f]; f_gf[u] = gf[f];
+                double sf;
+                if (scaling_ready) sf = scale_g[VB_P + f]; else { sf = 1.0 / (1.0 + sqrt(f_hf[u])); scale_g[VB_P + f] = sf; }
+                const double d = sqrt(fmin(fmax(sf * sf * f_hf[u], b.min_lm_diagonal), b.max_lm_diagonal));
+                f_sf[u] = sf; f_df[u] = d;
+                diag_g[VB_P + f] = d;
+                const double gr = sf * f_gf[u] / d;
+                grad_g[VB_P + f] = gr;
+                g2 += gr * gr;
+            }
+        }
+    }
+    __syncthreads();
     STAMP(1, 1);
     for (;;) {
-        // ---- streaming assembly of H (unscaled) into 16x16 tiles: every source block is read coalesced once ------------
-        for (int i = tid; i < 66 * 256; i += NT) s_T[i] = 0.0;
+        // ---- streaming assembly of the SCALED H~ into 16x16 tiles; v^T H~_pp v accumulated on the fly (tries == 0) ------------
+        double part = 0;
+        for (int i = tid; i < 66 * 256; i += SNT) s_T[i] = 0.0;
         __syncthreads();
         if (tid < VB_NPAD - VB_P) s_T[tile_index(10, 10) * 256 + TIX(5 + tid, 5 + tid)] = 1.0;     // padding rows 165..175
         {                                                                                     // visual pose-pose blocks
             const int2 *lv = (const int2 *)b.lut_vis;
-            for (int t0 = tid; t0 < 66 * 36; t0 += 4 * NT) {
-                double v[4]; int2 o[4];
+            for (int t0 = tid; t0 < 66 * 36; t0 += 5 * SNT) {
+                double v[5]; int2 o[5];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const int t = t0 + u * NT; const bool in = t < 66 * 36; v[u] = in ? Hpp[t] : 0.0; o[u] = in ? lv[t] : make_int2(-1, -1); }
+                for (int u = 0; u < 5; u++) { const int t = min(t0 + u * SNT, 66 * 36 - 1); v[u] = Hpp[t]; o[u] = lv[t]; }
 #pragma unroll
-                for (int u = 0; u < 4; u++) { if (o[u].x >= 0) s_T[o[u].x] += v[u]; if (o[u].y >= 0) s_T[o[u].y] += v[u]; }
+                for (int u = 0; u < 5; u++) {
+                    if (t0 + u * SNT >= 66 * 36) continue;
+                    const int r = (o[u].x >> 15) & 255, c = (o[u].x >> 23) & 255;
+                    const double val = v[u] * s_scale[r] * s_scale[c];
+                    const int off = (o[u].x & 0x7fff) - 1;
+                    if (off >= 0) s_T[off] += val;
+                    if (o[u].y > 0) s_T[o[u].y - 1] += val;                                   // diagonal tiles hold both triangles
+                    part += (((r / 6) != (c / 6)) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
+                }
             }
         }
         __syncthreads();
         for (int par = 0; par < 2; par++) {                                                   // IMU + LiDAR factors k = par, par+2, ...
-            for (int t0 = tid; t0 < 5 * 900; t0 += 6 * NT) {
-                double v[6]; int o[6];
+            for (int t0 = tid; t0 < 5 * 900; t0 += 9 * SNT) {
+                double v[9]; int o[9];
 #pragma unroll
-                for (int u = 0; u < 6; u++) {
-                    const int t = t0 + u * NT; const bool in = t < 5 * 900;
+                for (int u = 0; u < 9; u++) {
+                    const int t = min(t0 + u * SNT, 5 * 900 - 1);
                     const int k2 = t / 900, src = 900 * (2 * k2 + par) + (t - 900 * k2);
-                    o[u] = in ? b.lut_imu[src] : -1; v[u] = in ? imuH[src] : 0.0;
+                    o[u] = b.lut_imu[src]; v[u] = imuH[src];
                 }
 #pragma unroll
-                for (int u = 0; u < 6; u++) if (o[u] >= 0) s_T[o[u]] += v[u];
+                for (int u = 0; u < 9; u++) {
+                    if (t0 + u * SNT >= 5 * 900) continue;
+                    const int r = (o[u] >> 15) & 255, c = (o[u] >> 23) & 255;
+                    const double val = v[u] * s_scale[r] * s_scale[c];
+                    const int off = (o[u] & 0x7fff) - 1;
+                    if (off >= 0) s_T[off] += val;
+                    part += s_v[r] * val * s_v[c];
+                }
             }
-            for (int t = tid; t < 5 * 144; t += NT) {
+            for (int t = tid; t < 5 * 144; t += SNT) {
                 const int k2 = t / 144, src = 144 * (2 * k2 + par) + (t - 144 * k2);
                 const int o0 = b.lut_lid[src];
-                if (o0 >= 0) s_T[o0] += lidH[src];
+                const int r = (o0 >> 15) & 255, c = (o0 >> 23) & 255;
+                const double val = lidH[src] * s_scale[r] * s_scale[c];
+                const int off = (o0 & 0x7fff) - 1;
+                if (off >= 0) s_T[off] += val;
+                part += s_v[r] * val * s_v[c];
             }
             __syncthreads();
         }
-        for (int t0 = tid; t0 < pn * pn; t0 += 4 * NT) {                                       // marginalization prior J0^T J0
-            double v[4]; int o[4];
+        if (pn > 0) for (int t0 = tid; t0 < pn * pn; t0 += 6 * SNT) {                          // marginalization prior J0^T J0
+            double v[6]; int rr[6], cc[6];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int t = t0 + u * NT;
-                o[u] = -1; v[u] = 0.0;
-                if (t < pn * pn) {
-                    const int i = t / pn, j = t - pn * i;
-                    const int r = s_pinv[i], c = s_pinv[j];
-                    if (r >= 0 && c >= 0 && (r >> 4) >= (c >> 4)) { o[u] = tile_index(r >> 4, c >> 4) * 256 + TIX(r & 15, c & 15); v[u] = priorH[i * VB_PRIOR_LD + j]; }
-                }
+            for (int u = 0; u < 6; u++) {
+                const int t = min(t0 + u * SNT, pn * pn - 1);
+                const int i = t / pn, j = t - pn * i;
+                rr[u] = s_pinv[i]; cc[u] = s_pinv[j]; v[u] = priorH[i * VB_PRIOR_LD + j];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (o[u] >= 0) s_T[o[u]] += v[u];
+            for (int u = 0; u < 6; u++) {
+                const int r = rr[u], c = cc[u];
+                if (t0 + u * SNT >= pn * pn || r < 0 || c < 0) continue;
+                const double val = v[u] * s_scale[r] * s_scale[c];
+                if ((r >> 4) >= (c >> 4)) s_T[tile_index(r >> 4, c >> 4) * 256 + TIX(r & 15, c & 15)] += val;
+                part += s_v[r] * val * s_v[c];
+            }
         }
         __syncthreads();
         STAMP(1, 2);
-        // Jacobi scaling (trust_region_minimizer.cc: computed once, at iteration 0): 1 / (1 + sqrt(diag(J^T J)))
-        if (tid < VB_NPAD) {
-            double sc = 1.0;
-            if (tid < VB_P) {
-                if (scaling_ready || tries > 0) sc = scale_g[tid];
-                else { sc = 1.0 / (1.0 + sqrt(s_T[tile_index(tid >> 4, tid >> 4) * 256 + TIX(tid & 15, tid & 15)])); scale_g[tid] = sc; }
-            }
-            s_scale[tid] = sc;
-        }
-        if (!scaling_ready && tries == 0) for (int f = tid; f < F; f += NT) scale_g[VB_P + f] = f_const[f] ? 1.0 : 1.0 / (1.0 + sqrt(hf[f]));
-        __syncthreads();
-        for (int t = 0; t < 66; t++) {
-            int ta = 0; while ((ta + 1) * (ta + 2) / 2 <= t) ta++;
-            const int tb = t - ta * (ta + 1) / 2;
-            s_T[t * 256 + TIX(tid >> 4, tid & 15)] *= s_scale[16 * ta + (tid >> 4)] * s_scale[16 * tb + (tid & 15)];
-        }
-        if (tid < VB_NPAD) {
-            double gv = 0;
-            if (tid < VB_P) { int a, l; unperm(tid, a, l); gv = g_in[15 * a + l] * s_scale[tid]; }
-            s_g[tid] = gv;
-        }
-        __syncthreads();
         if (tries == 0) {
-            // dogleg diagonal_ = sqrt(clamp(diag(H~))), gradient_ = g~ / diagonal_ (dogleg_strategy.cc)
-            double g2 = 0;
-            if (tid < VB_NPAD) {
-                double d = 1.0, vv = 0.0;
-                if (tid < VB_P) {
-                    const int tt = tid >> 4, e = tid & 15;
-                    d = sqrt(fmin(fmax(s_T[tile_index(tt, tt) * 256 + TIX(e, e)], b.min_lm_diagonal), b.max_lm_diagonal));
-                    diag_g[tid] = d;
-                    const double gr = s_g[tid] / d;
-                    grad_g[tid] = gr;
-                    g2 += gr * gr;
-                    vv = gr / d;
-                }
-                s_diag[tid] = d;
-                s_v[tid] = vv;
-            }
+            // Cauchy point: alpha = ||gradient_||^2 / || J~ (gradient_ ./ diagonal_) ||^2
+            // v^T H~ v = v_p^T H~_pp v_p (accumulated above) + 2 sum_f v_f (w~_f . v_p) + sum_f h~_f v_f^2
+            if (tid < 80) s_y[tid] = (tid < VB_NPOSE) ? s_scale[tid] * s_v[tid] : 0.0;     // s_y is free until the LM step
             __syncthreads();
-            // Cauchy point: alpha = ||gradient_||^2 / || J~ (gradient_ ./ diagonal_) ||^2 ; v = g~ ./ diagonal_^2
-            // v^T H~ v = v_p^T H~_pp v_p + 2 sum_f v_f (w~_f . v_p) + sum_f h~_f v_f^2
-            double part = 0;
-            if (tid < VB_P) {
-                double t = 0;
-                const int ta = tid >> 4, ea = tid & 15;
-                for (int tb = 0; tb < VB_NTILE; tb++) {
-                    if (ta >= tb) {
-                        const double *T = s_T + tile_index(ta, tb) * 256;
+            feature_dots(W, F, f_const, s_y, s_cf, tid);                                     // s_cf temporarily holds W_f . (S v)_p
+            __syncthreads();
 #pragma unroll
-                        for (int e = 0; e < 16; e++) t += T[TIX(ea, e)] * s_v[16 * tb + e];
-                    } else {
-                        const double *T = s_T + tile_index(tb, ta) * 256;
-#pragma unroll
-                        for (int e = 0; e < 16; e++) t += T[TIX(e, ea)] * s_v[16 * tb + e];
-                    }
-                }
-                part = t * s_v[tid];
+            for (int u = 0; u < 2; u++) if (f_on[u]) {
+                const int f = tid + u * SNT;
+                const double vf = f_sf[u] * f_gf[u] / (f_df[u] * f_df[u]);
+                part += vf * (2.0 * f_sf[u] * s_cf[f] + f_sf[u] * f_sf[u] * f_hf[u] * vf);
             }
-            for (int f = tid; f < F; f += NT) {
-                if (f_const[f]) continue;
-                const double sf = scale_g[VB_P + f];
-                const double d = sqrt(fmin(fmax(sf * sf * hf[f], b.min_lm_diagonal), b.max_lm_diagonal));
-                diag_g[VB_P + f] = d;
-                const double gr = sf * gf[f] / d;
-                grad_g[VB_P + f] = gr;
-                g2 += gr * gr;
-                const double vf = gr / d;
-                const double *Wr = W + (size_t)f * VB_WLD;
-                const int lo = s_rng[f] & 0xffff, hi = s_rng[f] >> 16;
-                double dotp = 0;
-                for (int p = lo; p < hi; p += 6) {
-                    double wv[6];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) wv[c] = Wr[p + c];
-#pragma unroll
-                    for (int c = 0; c < 6; c++) dotp += wv[c] * s_scale[p + c] * s_v[p + c];
-                }
-                part += vf * (2.0 * sf * dotp + sf * sf * hf[f] * vf);
-            }
-            G2 = block_sum(g2, s_red);
-            Jg2 = block_sum(part, s_red);
+            G2 = block_sum_s(g2, s_red);
+            Jg2 = block_sum_s(part, s_red);
         }
         STAMP(1, 3);
         // ---- LM regularisation mu * diagonal_^2 on the reduced block; per-feature coefficients ----------------------
         if (tid < VB_P) { const int tt = tid >> 4, e = tid & 15; s_T[tile_index(tt, tt) * 256 + TIX(e, e)] += mu * s_diag[tid] * s_diag[tid]; }
-        for (int f = tid; f < F; f += NT) {
-            double c = 0;
-            if (!f_const[f]) {
-                const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
-                c = sf * rsqrt_nr(sf * sf * hf[f] + mu * df * df);
-            }
-            s_cf[f] = c;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int f = tid + u * SNT;
+            if (f < F) { double c = 0; if (!f_const[f]) { const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f]; c = sf * rsqrt_nr(sf * sf * hf[f] + mu * df * df); } s_cf[f] = c; }
         }
         if (tid < VB_NPAD) s_y[tid] = s_g[tid];
         __syncthreads();
         STAMP(1, 4);
         // ---- MFMA Schur reduce: H~_pp -= U^T U and rhs_p -= U^T t over the 5x5 pose tile block -------------------------
-        // U row f: columns 0..65 = c_f * S_p * W_f[p] (inside the feature's frame range), column 66 = c_f * g_f (the rhs
-        // rides along as one extra column of the same MFMA); columns 67..79 = 0.
-        {
-            const int Fk = (F + 3) & ~3;
-            const int c16 = lane & 15;
-            double sc5[5];
-#pragma unroll
-            for (int t5 = 0; t5 < 5; t5++) { const int col = 16 * t5 + c16; sc5[t5] = (col < VB_NPOSE) ? s_scale[col] : (col == VB_NPOSE ? 1.0 : 0.0); }
-            // tile pairs of this wave: tp = wave, wave+4, ... (15 pairs: (ta,tb), ta >= tb, over 5 column tiles)
-            double4_t acc[4];
-            int pta[4], ptb[4], npair = 0;
-            for (int tp = wave; tp < 15; tp += 4) { int ta = 0; while ((ta + 1) * (ta + 2) / 2 <= tp) ta++; pta[npair] = ta; ptb[npair] = tp - ta * (ta + 1) / 2; npair++; }
-#pragma unroll
-            for (int i = 0; i < 4; i++) acc[i] = double4_t{0, 0, 0, 0};
-            // unconditional coalesced loads of the zero-padded W rows (80 doubles), software-pipelined one k-step ahead
-            double un[5];
-            {
-                const int f = lane >> 4;
-                const double c = (f < F) ? s_cf[f] : 0.0;
-                const double *Wr = W + (size_t)f * VB_WLD + c16;
-#pragma unroll
-                for (int t5 = 0; t5 < 5; t5++) un[t5] = Wr[16 * t5] * c * sc5[t5];
-            }
-            for (int f0 = 0; f0 < Fk; f0 += 4) {
-                double u[5];
-#pragma unroll
-                for (int t5 = 0; t5 < 5; t5++) u[t5] = un[t5];
-                if (f0 + 4 < Fk) {
-                    const int f = f0 + 4 + (lane >> 4);
-                    const double c = (f < F) ? s_cf[f] : 0.0;
-                    const double *Wr = W + (size_t)f * VB_WLD + c16;
-#pragma unroll
-                    for (int t5 = 0; t5 < 5; t5++) un[t5] = Wr[16 * t5] * c * sc5[t5];
-                }
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (i < npair) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[pta[i]], u[ptb[i]], acc[i], 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (i >= npair) continue;
-                const int ta = pta[i], tb = ptb[i];
-                double *T = s_T + tile_index(ta, tb) * 256;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int row = 16 * ta + (lane >> 4) + 4 * q, col = 16 * tb + c16;
-                    if (row < VB_NPOSE) {
-                        if (col < VB_NPOSE) T[TIX(row & 15, c16)] -= acc[i][q];
-                    } else if (row == VB_NPOSE && col < VB_NPOSE) s_y[col] -= acc[i][q];   // row 66 = t^T U: the rhs reduction
-                }
-            }
-        }
+        for (int f = F + tid; f < ((F + 3) & ~3); f += SNT) s_cf[f] = 0.0;
         __syncthreads();
+        if (wave & 1) schur_mfma<1>(W, F, s_cf, s_scale, s_T, s_y, lane, wave); else schur_mfma<0>(W, F, s_cf, s_scale, s_T, s_y, lane, wave);
         STAMP(1, 5);
-        // ---- blocked Cholesky (lower), 11 tile steps: POTRF (wave 0) -> TRSM (row per thread) -> MFMA trailing update
+        // ---- blocked Cholesky (lower), 11 tile steps: TRSM (row per thread) -> MFMA trailing update, POTRF by wave 0 ------------
+        // The reduced rhs rides along as row 165 (first padding row) of the lower-triangular storage: after the factorisation
+        // L[165][0..164] = L^-1 rhs, i.e. the forward substitution is done by the TRSMs. Its diagonal is set large enough to
+        // stay positive (it only has to exceed rhs^T S^-1 rhs).
+        if (tid < VB_P) s_T[tile_index(10, tid >> 4) * 256 + TIX(5, tid & 15)] = s_y[tid];
+        if (tid == 0) s_T[tile_index(10, 10) * 256 + TIX(5, 5)] = 1e250;
+        __syncthreads();
+        // Lookahead: after the TRSM of step k, column k+1 of the trailing matrix is updated first; then wave 0 factorises the
+        // next diagonal tile while waves 1..7 update the remaining columns.
         bool ok = true;
+        long long tc_a = __builtin_readcyclecounter(), tc_trsm = 0, tc_p1 = 0, tc_p2 = 0, tc_potrf0 = 0;
+        if (wave == 0) { bool o = potrf_tile_wave(s_T + tile_index(0, 0) * 256, s_invd, lane); if (lane == 0) s_flag[2] = o ? 1 : 0; }
+        __syncthreads();
+        { long long t = __builtin_readcyclecounter(); tc_potrf0 = t - tc_a; tc_a = t; }
         for (int k = 0; k < VB_NTILE; k++) {
-            double *Tkk = s_T + tile_index(k, k) * 256;
-            if (wave == 0) { bool o = potrf_tile_wave(Tkk, s_invd + 16 * k, lane); if (lane == 0) s_flag[2] = o ? 1 : 0; }
-            __syncthreads();
             if (!s_flag[2]) { ok = false; break; }
+            const double *Tkk = s_T + tile_index(k, k) * 256;
             const int nrows = (VB_NTILE - 1 - k) * 16;
             if (tid < nrows) {
                 const int ti = k + 1 + (tid >> 4), rr = tid & 15;
@@ -823,27 +922,43 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
                 for (int c = 0; c < 16; c++) Tik[TIX(rr, c)] = x[c];
             }
             __syncthreads();
-            const int nt = VB_NTILE - 1 - k, ntile = nt * (nt + 1) / 2;
-            for (int tt = wave; tt < ntile; tt += 4) {
-                int ii = 0; while ((ii + 1) * (ii + 2) / 2 <= tt) ii++;
-                const int jj = tt - ii * (ii + 1) / 2;
-                const int ti = k + 1 + ii, tj = k + 1 + jj;
+            { long long t = __builtin_readcyclecounter(); tc_trsm += t - tc_a; tc_a = t; }
+            if (k == VB_NTILE - 1) break;
+            const int nt = VB_NTILE - 1 - k;
+            auto update_tile = [&](int ti, int tj) {
                 double *C = s_T + tile_index(ti, tj) * 256;
                 const double *A = s_T + tile_index(ti, k) * 256, *Bm = s_T + tile_index(tj, k) * 256;
                 double4_t acc;
+                double av[4], bv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) acc[q] = C[TIX((lane >> 4) + 4 * q, lane & 15)];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) {
-                    const double av = -A[TIX(lane & 15, 4 * s4 + (lane >> 4))];
-                    const double bv = Bm[TIX(lane & 15, 4 * s4 + (lane >> 4))];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
+                for (int s4 = 0; s4 < 4; s4++) { av[s4] = -A[TIX(lane & 15, 4 * s4 + (lane >> 4))]; bv[s4] = Bm[TIX(lane & 15, 4 * s4 + (lane >> 4))]; }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; q++) C[TIX((lane >> 4) + 4 * q, lane & 15)] = acc[q];
+            };
+            // phase 1: column k+1 (tiles (k+1+ii, k+1), ii = 0..nt-1)
+            for (int ii = wave; ii < nt; ii += SNW) update_tile(k + 1 + ii, k + 1);
+            __syncthreads();
+            { long long t = __builtin_readcyclecounter(); tc_p1 += t - tc_a; tc_a = t; }
+            // phase 2: wave 0 factorises tile (k+1, k+1); the other waves update the remaining columns
+            if (wave == 0) {
+                bool o = potrf_tile_wave(s_T + tile_index(k + 1, k + 1) * 256, s_invd + 16 * (k + 1), lane);
+                if (lane == 0) s_flag[2] = o ? 1 : 0;
+            } else {
+                const int nrest = (nt - 1) * nt / 2;            // tiles (ii, jj) with 1 <= jj <= ii <= nt-1
+                for (int tt = wave - 1; tt < nrest; tt += SNW - 1) {
+                    int ii = 0; while ((ii + 1) * (ii + 2) / 2 <= tt) ii++;
+                    const int jj = tt - ii * (ii + 1) / 2;
+                    update_tile(k + 2 + ii, k + 2 + jj);
+                }
             }
             __syncthreads();
+            { long long t = __builtin_readcyclecounter(); tc_p2 += t - tc_a; tc_a = t; }
         }
+        if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 20] = tc_potrf0; b.dbg[64 + 21] = tc_trsm; b.dbg[64 + 22] = tc_p1; b.dbg[64 + 23] = tc_p2; }
         STAMP(1, 6);
         tries++;
         if (ok) { solved = true; break; }
@@ -855,63 +970,44 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
         if (tid == 0) { st->solve_failed = 1; st->mu = mu; st->num_linear_solves += tries; st->scaling_ready = 1; st->grad_sqnorm = G2; st->Jg2 = Jg2; }
         return;
     }
-    // ---- forward / backward substitution on the tiles (rhs in s_y); diagonal tiles by wave 0 through SGPR broadcasts ----
-    for (int k = 0; k < VB_NTILE; k++) {            // L z = rhs
-        if (wave == 0) {
+    // ---- forward / backward substitution by ONE wave, wave-synchronous (no block barriers): the rhs lives in s_y, each lane owns
+    // rows {lane, lane+64, lane+128}; diagonal tiles are solved through SGPR broadcasts (v_readlane) ----------------------------------
+    if (tid < VB_P) s_y[tid] = s_T[tile_index(10, tid >> 4) * 256 + TIX(5, tid & 15)];       // z = L^-1 rhs (row 165 of L)
+    if (tid >= VB_P && tid < VB_NPAD) s_y[tid] = 0.0;
+    __syncthreads();
+    if (tid < 16) { if (tid == 5) s_T[tile_index(10, 10) * 256 + TIX(5, 5)] = 1.0; if (tid < 5) s_T[tile_index(10, 10) * 256 + TIX(5, tid)] = 0.0; }   // restore the padding row
+    if (tid >= 16 && tid < 16 + 160) { const int c = tid - 16; s_T[tile_index(10, c >> 4) * 256 + TIX(5, c & 15)] = 0.0; }
+    if (tid == 0) s_invd[165] = 1.0;
+    __syncthreads();
+    if (wave == 0) {
+        const int l16 = lane & 15;
+        for (int k = VB_NTILE - 1; k >= 0; k--) {       // L^T y = z
             const double *Tkk = s_T + tile_index(k, k) * 256;
-            const int l16 = lane & 15;
-            double Lr[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) Lr[j] = Tkk[TIX(l16, j)];
-            double x = s_y[16 * k + l16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const double xj = readlane_f64(x, j) * s_invd[16 * k + j];
-                if (l16 == j) x = xj;
-                else if (l16 > j) x -= Lr[j] * xj;
-            }
-            if (lane < 16) s_y[16 * k + lane] = x;
-        }
-        __syncthreads();
-        const int nrows = (VB_NTILE - 1 - k) * 16;
-        if (tid < nrows) {
-            const int ti = k + 1 + (tid >> 4), rr = tid & 15;
-            const double *Tik = s_T + tile_index(ti, k) * 256;
-            double s = 0;
-#pragma unroll
-            for (int c = 0; c < 16; c++) s += Tik[TIX(rr, c)] * s_y[16 * k + c];
-            s_y[16 * ti + rr] -= s;
-        }
-        __syncthreads();
-    }
-    for (int k = VB_NTILE - 1; k >= 0; k--) {       // L^T y = z
-        if (wave == 0) {
-            const double *Tkk = s_T + tile_index(k, k) * 256;
-            const int l16 = lane & 15;
             double Lc[16];
 #pragma unroll
             for (int j = 0; j < 16; j++) Lc[j] = Tkk[TIX(j, l16)];
             double x = s_y[16 * k + l16];
+            const double myinv = s_invd[16 * k + l16];
+            double xs[16];
 #pragma unroll
             for (int j = 15; j >= 0; j--) {
-                const double xj = readlane_f64(x, j) * s_invd[16 * k + j];
-                if (l16 == j) x = xj;
-                else if (l16 < j) x -= Lc[j] * xj;
+                if (l16 == j) x *= myinv;
+                xs[j] = readlane_f64(x, j);
+                if (l16 < j) x -= Lc[j] * xs[j];
             }
             if (lane < 16) s_y[16 * k + lane] = x;
-        }
-        __syncthreads();
-        const int ncols = k * 16;                    // rows above: y_i -= sum_r L[16k+r][i] * y[16k+r]
-        if (tid < ncols) {
-            const int tj = tid >> 4, cc = tid & 15;
-            const double *T = s_T + tile_index(k, tj) * 256;
-            double s = 0;
+            for (int col = lane; col < 16 * k; col += 64) {         // rows above: y_i -= sum_r L[16k+r][i] * y[16k+r]
+                const double *T = s_T + tile_index(k, col >> 4) * 256;
+                double sacc = 0;
 #pragma unroll
-            for (int r2 = 0; r2 < 16; r2++) s += T[TIX(r2, cc)] * s_y[16 * k + r2];
-            s_y[16 * tj + cc] -= s;
+                for (int r2 = 0; r2 < 16; r2++) sacc += T[TIX(r2, col & 15)] * xs[r2];
+                s_y[col] -= sacc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
     }
+    __syncthreads();
     STAMP(1, 7);
     // ---- back-substitute the features, Gauss-Newton step = -diagonal_ .* y, reductions ------------------------------
     double gy = 0, gn2 = 0;
@@ -921,28 +1017,24 @@ extern "C" __global__ __launch_bounds__(NT) void k_solve(VbBatch b) {
         gy += s_g[tid] * y;
         gn2 += d * d * y * y;
     }
-    for (int f = tid; f < F; f += NT) {
-        if (f_const[f]) continue;
+    if (tid < 80) s_v[tid] = (tid < VB_NPOSE) ? s_scale[tid] * s_y[tid] : 0.0;
+    __syncthreads();
+    feature_dots(W, F, f_const, s_v, s_cf, tid);                                             // s_cf <- W_f . (S y)_p
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int f = tid + u * SNT;
+        if (f >= F || f_const[f]) continue;
         const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
         const double hp = sf * sf * hf[f] + mu * df * df;
-        const double *Wr = W + (size_t)f * VB_WLD;
-        const int lo = s_rng[f] & 0xffff, hi = s_rng[f] >> 16;
-        double dotp = 0;
-        for (int p = lo; p < hi; p += 6) {
-            double wv[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++) wv[c] = Wr[p + c];
-#pragma unroll
-            for (int c = 0; c < 6; c++) dotp += wv[c] * s_scale[p + c] * s_y[p + c];
-        }
         const double gt = sf * gf[f];
-        const double y = (gt - sf * dotp) / hp;
+        const double y = (gt - sf * s_cf[f]) / hp;
         gn_g[VB_P + f] = -df * y;
         gy += gt * y;
         gn2 += df * df * y * y;
     }
-    gy = block_sum(gy, s_red);
-    gn2 = block_sum(gn2, s_red);
+    gy = block_sum_s(gy, s_red);
+    gn2 = block_sum_s(gn2, s_red);
     if (tid == 0) {
         st->grad_sqnorm = G2; st->Jg2 = Jg2; st->alpha = G2 / Jg2;
         st->gy = gy; st->gn_sqnorm = gn2; st->mu = mu; st->mu_used = mu;
