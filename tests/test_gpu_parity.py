@@ -186,3 +186,21 @@ def test_solve_marginalize_solve_chain(solver, oracle, opts):
     assert got2.summary["num_iterations"] == ref2.summary["num_iterations"]
     assert abs(got2.summary["final_cost"] - ref2.summary["final_cost"]) <= 1e-5 * ref2.summary["final_cost"]
     assert np.abs(got2.Ps - ref2.Ps).max() < 1e-5 and np.abs(got2.Rs - ref2.Rs).max() < 1e-6
+
+
+def test_replicas_and_reruns_are_bit_identical(solver, opts):
+    """Race detector: 512 resident windows tiled from 8 distinct ones; every replica and every re-run after a rewind must be
+    bit-identical (LDS scatter-adds of different factor families into the same tile entry must be barrier-separated)."""
+    wins, priors = synth.make_batch(5, 512, opts, synth.SynthConfig(n_features=80), distinct=8)
+    solver.batch_upload(wins, priors)
+    base = None
+    for rep in range(6):
+        if rep:
+            solver.batch_rewind()
+        solver.batch_solve()
+        P = np.stack([np.concatenate([r.Ps.ravel(), r.Vs.ravel(), r.Bas.ravel(), r.Bgs.ravel()]) for r in solver.batch_download()])
+        if base is None:
+            base = P
+            assert all(np.array_equal(P[i], P[i % 8]) for i in range(512)), "replicas of the same window differ"
+        else:
+            assert np.array_equal(P, base), f"re-run {rep} differs"

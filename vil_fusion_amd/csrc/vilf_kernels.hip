@@ -825,6 +825,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
                     part += s_v[r] * val * s_v[c];
                 }
             }
+            __syncthreads();                      // LiDAR factor k adds into the same pose entries as IMU factor k
             for (int t = tid; t < 5 * 144; t += SNT) {
                 const int k2 = t / 144, src = 144 * (2 * k2 + par) + (t - 144 * k2);
                 const int o0 = b.lut_lid[src];
