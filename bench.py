@@ -135,6 +135,16 @@ def main():
         dom = max(("k_linearize", "k_solve", "k_step"), key=lambda k: prof[k]["ms"])
         avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
         achieved = abytes * B / (avg_ms * 1e-3) / 1e9
+        # HBM traffic per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this
+        # same command; gfx950-corrected as MI355X_MICROARCH.md prescribes) — only when they were taken on this configuration
+        traffic = None
+        try:
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
+            if pmc["config"]["windows_per_gpu"] == B and pmc["config"]["features_per_window"] == cfg.n_features:
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "sliding-window solve iters/sec (10 KF, ~5.5k factors) @1/2/4/8 GPU vs CPU",
             "value": its_total / dt_max, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -146,7 +156,7 @@ def main():
                        "features_per_window": float(np.mean([w.n_features for w in wins[:args.distinct]])), "max_iterations": int(opts.max_num_iterations),
                        "parallelism": f"{world} x independent window shards (no data-path collective; RCCL all_gather of 64 B poses)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_window_iteration": abytes,
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_window_iteration": abytes,
                          "kernels_ms": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()}},
         }
         if not args.no_cpu_baseline:
