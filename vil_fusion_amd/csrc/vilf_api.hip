@@ -156,7 +156,7 @@ static int pull_device_priors(vilf_handle *h) {
         std::memset(&p, 0, sizeof(p));
         int hdr[VB_PRIOR_HDR];
         HIPCHECK(h, hipMemcpy(hdr, h->d[D_PHDR].as<int>() + (size_t)w * VB_PRIOR_HDR, sizeof(hdr), hipMemcpyDeviceToHost));
-        p.valid = hdr[0]; p.n = hdr[1]; p.n_blocks = hdr[2];
+        p.valid = hdr[0]; p.n = hdr[1]; p.n_blocks = hdr[2]; p.m = hdr[75];
         if (p.valid) {
             std::vector<double> x0(24 * 9);
             HIPCHECK(h, hipMemcpy(x0.data(), h->d[D_PX0].as<double>() + (size_t)w * 24 * 9, x0.size() * 8, hipMemcpyDeviceToHost));
@@ -178,7 +178,7 @@ static int upload_priors(vilf_handle *h) {
         const vilf_prior &p = h->priors[w];
         if (!p.valid) continue;
         int *hd = &hdr[(size_t)w * VB_PRIOR_HDR];
-        hd[0] = 1; hd[1] = p.n; hd[2] = p.n_blocks;
+        hd[0] = 1; hd[1] = p.n; hd[2] = p.n_blocks; hd[75] = p.m;
         for (int i = 0; i < p.n_blocks; i++) {
             hd[3 + i] = p.block_id[i]; hd[27 + i] = p.block_size[i]; hd[51 + i] = p.block_idx[i];
             for (int k = 0; k < 9; k++) x0[((size_t)w * 24 + i) * 9 + k] = p.block_x0[i][k];

@@ -30,7 +30,7 @@ enum {
     D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR, D_COUNT
 };
 
-struct S2MCtx;
+struct S2B;
 
 struct vilf_handle {
     vilf_options opts;
@@ -58,7 +58,7 @@ struct vilf_handle {
     long kernel_launches[4] = {0, 0, 0, 0};
     double last_solve_usec = 0;
     size_t solve_lds = 0, lin_lds = 0;
-    S2MCtx *s2m = nullptr;                   // scan-to-map state (vilf_s2m.hip)
+    S2B *s2m = nullptr, *s2b = nullptr;      // scan-to-map state: single stream / batched streams (vilf_s2m.hip)
 };
 
 #define HIPCHECK(h, call)                                                                                        \

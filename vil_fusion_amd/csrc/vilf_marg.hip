@@ -472,7 +472,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg
     }
     // block table with the address shift + x0 = parameter_block_data (getParameterBlocks, :299-319)
     int *hdr = g.prior_hdr_out + (size_t)w * VB_PRIOR_HDR;
-    if (tid == 0) { hdr[0] = 1; hdr[1] = n; hdr[2] = nb; }
+    if (tid == 0) { hdr[0] = 1; hdr[1] = n; hdr[2] = nb; hdr[75] = info[4]; }     // [75] = m (marginalized dimension, informative)
     if (tid < 24) {
         hdr[3 + tid] = tid < nb ? info[8 + tid] : 0; hdr[27 + tid] = tid < nb ? info[32 + tid] : 0; hdr[51 + tid] = tid < nb ? info[56 + tid] : 0;
         if (tid < nb) {

@@ -14,6 +14,9 @@
 //                            -> ONE persistent 1024-thread workgroup: residual + jacobian of every factor, fixed-tree reduction of
 //                               the 6x6 normal equations, Cholesky, accept / reject, radius update (Ceres 2.0 LM semantics)
 //   createSubMap (:298-352)  -> transform + append, crop-box compaction (order preserving), voxel grid
+//
+// The implementation is batched over S independent LiDAR streams (fixed-capacity segments, device-side counters, one global
+// radix sort with the stream id in the high key bits); the reference's single EstimationMapping object is the S = 1 case.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <string.h>
@@ -25,12 +28,31 @@
 using namespace vd;
 
 // ---------------------------------------------------------------------------------------------------------------------
-// kernels
-struct MinMax { float mn[3], mx[3]; int minb[3]; long long mul1, mul2; };
+// Batched layout. S independent LiDAR streams (S = 1 for the single-stream ABI) live side by side in fixed-capacity segments:
+//   cloud set   pts[S][cap] (float4 xyzi), n[S] (device counters)
+// Every kernel is launched over (ceil(cap / 256), S) or S workgroups and reads its stream's count from device memory, so a whole
+// step (voxel grids, index build, 2 x (associate + LM solve), sub-map maintenance) is enqueued without a host round trip.
+// Sorts are ONE rocPRIM radix sort over all segments with the stream id in the high key bits; padding entries carry the largest
+// key of their stream and stay at the end of their own segment.
+struct CSet { float4 *p; int *n; int cap; };
+struct MinMax { float mn[3], mx[3]; int minb[3]; int pad_; long long mul1, mul2; };
+struct HashEntry { unsigned long long key; int start, end; };
+struct S2BRes {                       // per-stream result of one step (device)
+    double pose[7], prev[7];
+    double cost[2];
+    int n_ds[2], nfe[2], nfs[2], its[2], map_n[2];
+    int err, do_opt;
+};
+#define S2B_VOXBITS 42                // pcl::VoxelGrid leaf index (a + b*dx + c*dx*dy) must stay below 2^42 - 1
+#define S2B_CELLBITS 30               // 1 m cells, 10 bits per axis relative to the stream's map minimum
+#define S2B_ERR_MAPCAP 1
+#define S2B_ERR_EXTENT 2
+#define S2B_ERR_VOXEL 4
 
-__global__ void s2m_minmax(const float4 *p, int n, float inv, MinMax *out) {
+__global__ void b_minmax(CSet in, float inv, MinMax *mm) {
     __shared__ float s[6][1024];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
+    const float4 *p = in.p + (size_t)sid * in.cap;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = tid; i < n; i += blockDim.x) {
         const float4 q = p[i];
@@ -44,6 +66,7 @@ __global__ void s2m_minmax(const float4 *p, int n, float inv, MinMax *out) {
         __syncthreads();
     }
     if (tid == 0) {
+        MinMax *out = mm + sid;
         int divb[3];
         for (int k = 0; k < 3; k++) {
             out->mn[k] = s[k][0]; out->mx[k] = s[3 + k][0];
@@ -53,69 +76,94 @@ __global__ void s2m_minmax(const float4 *p, int n, float inv, MinMax *out) {
         out->mul1 = divb[0]; out->mul2 = (long long)divb[0] * divb[1];
     }
 }
-__global__ void s2m_voxel_keys(const float4 *p, int n, float inv, const MinMax *mm, unsigned long long *keys, int *vals) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 q = p[i];
-    const long long a = (long long)floorf(__fmul_rn(q.x, inv)) - mm->minb[0], b = (long long)floorf(__fmul_rn(q.y, inv)) - mm->minb[1], c = (long long)floorf(__fmul_rn(q.z, inv)) - mm->minb[2];
-    keys[i] = (unsigned long long)(a + b * mm->mul1 + c * mm->mul2);
-    vals[i] = i;
+__global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, unsigned long long *keys, int *vals, int *err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= in.cap) return;
+    const size_t g = (size_t)sid * in.cap + i;
+    unsigned long long k = (1ULL << S2B_VOXBITS) - 1;
+    if (i < in.n[sid]) {
+        const float4 q = in.p[g];
+        const MinMax *m = mm + sid;
+        const long long a = (long long)floorf(__fmul_rn(q.x, inv)) - m->minb[0], b = (long long)floorf(__fmul_rn(q.y, inv)) - m->minb[1], c = (long long)floorf(__fmul_rn(q.z, inv)) - m->minb[2];
+        unsigned long long v = (unsigned long long)(a + b * m->mul1 + c * m->mul2);
+        if (v >= k) { atomicOr(err + sid, S2B_ERR_VOXEL); v = k - 1; }
+        k = v;
+    }
+    keys[g] = ((unsigned long long)sid << S2B_VOXBITS) | k;
+    vals[g] = i;
 }
-__global__ void s2m_heads(const unsigned long long *keys, int n, int *head) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+// after the sort the n[s] valid entries of stream s are the first n[s] of its segment
+__global__ void b_heads(const unsigned long long *keys, CSet in, int *head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= in.cap) return;
+    const size_t g = (size_t)sid * in.cap + i;
+    head[g] = (i < in.n[sid] && (i == 0 || keys[g] != keys[g - 1])) ? 1 : 0;
 }
-__global__ void s2m_centroids(const float4 *p, const unsigned long long *keys, const int *vals, const int *head, const int *seg, int n, float4 *out, int *n_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (i == n - 1) *n_out = seg[i] + head[i];
-    if (!head[i]) return;
+__global__ void b_centroids(CSet in, const unsigned long long *keys, const int *vals, const int *head, const int *seg, CSet out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= in.cap) return;
+    const size_t base = (size_t)sid * in.cap, g = base + i;
+    const int seg0 = seg[base];
+    if (i == in.cap - 1) out.n[sid] = seg[g] + head[g] - seg0;
+    if (!head[g]) return;
     float cx = 0, cy = 0, cz = 0, ci = 0; int cnt = 0;
-    const unsigned long long k = keys[i];
-    for (int j = i; j < n && keys[j] == k; j++) { const float4 q = p[vals[j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
+    const unsigned long long k = keys[g];
+    const int n = in.n[sid];
+    for (int j = i; j < n && keys[base + j] == k; j++) { const float4 q = in.p[base + vals[base + j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
     const float nn = (float)cnt;
-    out[seg[i]] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+    out.p[(size_t)sid * out.cap + (seg[g] - seg0)] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
 }
-// 1 m cell key: 21 bits per axis
-__device__ __forceinline__ unsigned long long cell_key(int ix, int iy, int iz) {
-    return ((unsigned long long)(ix + (1 << 20)) << 42) | ((unsigned long long)(iy + (1 << 20)) << 21) | (unsigned long long)(iz + (1 << 20));
+// ---- radix-hashed voxel neighbour index: 1 m cells, key relative to the stream's map minimum ----
+__device__ __forceinline__ unsigned int hash30(unsigned int k) { k ^= k >> 16; k *= 0x7feb352dU; k ^= k >> 15; k *= 0x846ca68bU; k ^= k >> 16; return k; }
+__global__ void b_cell_keys(CSet map, const MinMax *mm, unsigned long long *keys, int *vals, int *cellbase, int *err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= map.cap) return;
+    const size_t g = (size_t)sid * map.cap + i;
+    const int bx = (int)floorf(mm[sid].mn[0]), by = (int)floorf(mm[sid].mn[1]), bz = (int)floorf(mm[sid].mn[2]);
+    if (i == 0) { cellbase[4 * sid] = bx; cellbase[4 * sid + 1] = by; cellbase[4 * sid + 2] = bz; }
+    unsigned long long k = (1ULL << S2B_CELLBITS) - 1;
+    if (i < map.n[sid]) {
+        const float4 q = map.p[g];
+        int cx = (int)floorf(q.x) - bx, cy = (int)floorf(q.y) - by, cz = (int)floorf(q.z) - bz;
+        if (cx > 1022 || cy > 1022 || cz > 1022) { atomicOr(err + sid, S2B_ERR_EXTENT); cx = min(cx, 1022); cy = min(cy, 1022); cz = min(cz, 1022); }
+        k = ((unsigned long long)cx << 20) | ((unsigned long long)cy << 10) | (unsigned long long)cz;
+    }
+    keys[g] = ((unsigned long long)sid << S2B_CELLBITS) | k;
+    vals[g] = i;
 }
-__global__ void s2m_cell_keys(const float4 *p, int n, unsigned long long *keys, int *vals) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void b_gather_hash(CSet map, const unsigned long long *keys, const int *vals, float4 *sorted, HashEntry *table, unsigned int mask) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    const int n = map.n[sid];
     if (i >= n) return;
-    const float4 q = p[i];
-    keys[i] = cell_key((int)floorf(q.x), (int)floorf(q.y), (int)floorf(q.z));
-    vals[i] = i;
-}
-struct HashEntry { unsigned long long key; int start, end; };
-__device__ __forceinline__ unsigned int hash64(unsigned long long k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return (unsigned int)k; }
-__global__ void s2m_gather_hash(const float4 *p, const unsigned long long *keys, const int *vals, int n, float4 *sorted, HashEntry *table, unsigned int mask) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 q = p[vals[i]];
-    q.w = __int_as_float(vals[i]);               // original map index (tie-break like a linear scan)
-    sorted[i] = q;
-    if (i == 0 || keys[i] != keys[i - 1]) {
-        const unsigned long long k = keys[i];
+    const size_t base = (size_t)sid * map.cap, g = base + i;
+    float4 q = map.p[base + vals[g]];
+    q.w = __int_as_float(vals[g]);               // original map index (tie-break like a linear scan)
+    sorted[g] = q;
+    if (i == 0 || keys[g] != keys[g - 1]) {
+        const unsigned long long kk = keys[g];
         int e = i + 1;
-        while (e < n && keys[e] == k) e++;
-        unsigned int s = hash64(k) & mask;
+        while (e < n && keys[base + e] == kk) e++;
+        const unsigned long long k = kk & ((1ULL << S2B_CELLBITS) - 1);
+        HashEntry *T = table + (size_t)sid * (mask + 1);
+        unsigned int s = hash30((unsigned int)k) & mask;
         for (;;) {
-            const unsigned long long prev = atomicCAS(&table[s].key, ~0ULL, k);
-            if (prev == ~0ULL) { table[s].start = i; table[s].end = e; break; }
+            const unsigned long long prev = atomicCAS(&T[s].key, ~0ULL, k);
+            if (prev == ~0ULL) { T[s].start = i; T[s].end = e; break; }
             s = (s + 1) & mask;
         }
     }
 }
 // exact 5-NN within the 27-cell block: pos[] = positions in the cell-sorted array, ordered by (squared distance, original index)
-__device__ void knn5_cells(const float4 *sorted, const HashEntry *table, unsigned int mask, float qx, float qy, float qz, int pos[5], float d2[5]) {
+__device__ void knn5_cells(const float4 *sorted, const HashEntry *table, unsigned int mask, const int *cellbase, float qx, float qy, float qz, int pos[5], float d2[5]) {
     int oid[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { pos[k] = -1; oid[k] = 0x7fffffff; d2[k] = 3.0e38f; }
-    const int cx = (int)floorf(qx), cy = (int)floorf(qy), cz = (int)floorf(qz);
+    const int cx = (int)floorf(qx) - cellbase[0], cy = (int)floorf(qy) - cellbase[1], cz = (int)floorf(qz) - cellbase[2];
     for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
-        const unsigned long long k = cell_key(cx + dx, cy + dy, cz + dz);
-        unsigned int s = hash64(k) & mask;
+        const int ax = cx + dx, ay = cy + dy, az = cz + dz;
+        if ((unsigned)ax > 1022u || (unsigned)ay > 1022u || (unsigned)az > 1022u) continue;      // no map point can live there
+        const unsigned long long k = ((unsigned long long)ax << 20) | ((unsigned long long)ay << 10) | (unsigned long long)az;
+        unsigned int s = hash30((unsigned int)k) & mask;
         int st = 0, en = 0;
         for (;;) {
             const unsigned long long tk = table[s].key;
@@ -136,6 +184,7 @@ __device__ void knn5_cells(const float4 *sorted, const HashEntry *table, unsigne
         }
     }
 }
+
 // 3x3 symmetric eigen-decomposition by cyclic Jacobi: eigenvalues ascending, V columns
 __device__ void eig3(const double *Ain, double *w, double *V) {
     double A[9];
@@ -197,13 +246,20 @@ __device__ void qr_solve_5x3(const double *Ain, const double *bin, double *x) {
     for (int k = 0; k < 3; k++) x[perm[k]] = z[k];
 }
 
-// factor record: [kind (0 invalid, 1 edge, 2 surf)] cp[3] then edge: pa[3] pb[3] / surf: n[3] d  -> 10 doubles + kind
+// factor record: cp[3] then edge: pa[3] pb[3] / surf: n[3] d  -> 10 doubles; kind (0 invalid, 1 edge, 2 surf) separately
 #define S2M_FREC 10
-__global__ void s2m_associate(const float4 *pts, int n, int is_surf, const double *pose, const float4 *sorted, const HashEntry *table, unsigned int mask, int nmap,
-                              double *frec, int *fkind) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
+// one thread per query point of one stream. Edge queries write records [0, n_ds_edge), surf queries [n_ds_edge, n_ds_edge + n_ds_surf).
+__global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const double *pose_all, CSet map, const float4 *sorted_all, const HashEntry *table_all,
+                            unsigned int mask, const int *cellbase_all, const S2BRes *res, double *frec_all, int *fkind_all, int capq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= ds.n[sid] || !res[sid].do_opt) return;
+    const double *pose = pose_all + 24 * sid;
+    const float4 *sorted = sorted_all + (size_t)sid * map.cap;
+    const HashEntry *table = table_all + (size_t)sid * (mask + 1);
+    const int nmap = map.n[sid];
+    const int slot = is_surf ? n_ds_edge[sid] + i : i;
+    double *frec = frec_all + ((size_t)sid * capq + slot) * S2M_FREC;
+    const float4 p = ds.p[(size_t)sid * ds.cap + i];
     const double cp[3] = {p.x, p.y, p.z};
     double pw[3];
     q_rot(q_load(pose), cp, pw);
@@ -212,7 +268,7 @@ __global__ void s2m_associate(const float4 *pts, int n, int is_surf, const doubl
     double rec[S2M_FREC] = {cp[0], cp[1], cp[2], 0, 0, 0, 0, 0, 0, 0};
     int idx[5]; float d2[5];
     if (nmap >= 5) {
-        knn5_cells(sorted, table, mask, qx, qy, qz, idx, d2);
+        knn5_cells(sorted, table, mask, cellbase_all + 4 * sid, qx, qy, qz, idx, d2);
         if (d2[4] < 1.0f) {
             double nb[5][3];
             for (int t = 0; t < 5; t++) { const float4 m = sorted[idx[t]]; nb[t][0] = m.x; nb[t][1] = m.y; nb[t][2] = m.z; }
@@ -241,12 +297,11 @@ __global__ void s2m_associate(const float4 *pts, int n, int is_surf, const doubl
             }
         }
     }
-    fkind[i] = kind;
-    for (int k = 0; k < S2M_FREC; k++) frec[(size_t)i * S2M_FREC + k] = rec[k];
+    fkind_all[(size_t)sid * capq + slot] = kind;
+    for (int k = 0; k < S2M_FREC; k++) frec[k] = rec[k];
 }
 
 // ---- the persistent LM solve -------------------------------------------------------------------------------------------
-struct S2MSolveOut { double pose[7]; double final_cost; int iterations; int n_edge, n_surf; int pad; };
 
 #define S2M_NT 1024
 __device__ double s2m_block_sum(double v, double *s_red) {
@@ -295,8 +350,15 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
     for (int k = JAC ? 0 : 27; k < 28; k++) { const double v = s2m_block_sum(acc[k], s_red); if (threadIdx.x == 0) s_out[k] = v; }
     __syncthreads();
 }
-
-__global__ __launch_bounds__(S2M_NT) void s2m_solve(const double *pose_in, const double *frec, const int *fkind, int n_edge_q, int n_surf_q, double huber_a, int max_it, S2MSolveOut *out) {
+// ONE persistent 1024-thread workgroup per stream; the optimised pose is written back to the stream's pose slot.
+__global__ __launch_bounds__(S2M_NT) void b_solve(double *pose_all, const double *frec_all, const int *fkind_all, int capq, const int *n_ds_edge, const int *n_ds_surf, double huber_a, int max_it, int pass, S2BRes *res) {
+    const int sid = blockIdx.x;
+    if (!res[sid].do_opt) return;
+    double *pose_in = pose_all + 24 * sid;
+    const double *frec = frec_all + (size_t)sid * capq * S2M_FREC;
+    const int *fkind = fkind_all + (size_t)sid * capq;
+    const int n_edge_q = n_ds_edge[sid], n_surf_q = n_ds_surf[sid];
+    S2BRes *out = res + sid;
     __shared__ double s_red[S2M_NT], s_ev[28], s_cand[28], s_x[7], s_c[7], s_scale[6], s_diag[6], s_step[6];
     __shared__ int s_ctl[4];
     const int tid = threadIdx.x, nfac = n_edge_q + n_surf_q;
@@ -304,7 +366,7 @@ __global__ __launch_bounds__(S2M_NT) void s2m_solve(const double *pose_in, const
     int ne = 0, ns = 0;
     for (int i = tid; i < nfac; i += S2M_NT) { const int k = fkind[i]; if (k == 1) ne++; else if (k == 2) ns++; }
     const int tne = (int)(s2m_block_sum((double)ne, s_red) + 0.5), tns = (int)(s2m_block_sum((double)ns, s_red) + 0.5);
-    if (tne + tns == 0) { if (tid == 0) { for (int k = 0; k < 7; k++) out->pose[k] = s_x[k]; out->final_cost = 0; out->iterations = 0; out->n_edge = 0; out->n_surf = 0; } return; }
+    if (tne + tns == 0) { if (tid == 0) { out->cost[pass] = 0; out->its[pass] = 0; out->nfe[pass] = 0; out->nfs[pass] = 0; } return; }
     __syncthreads();
     s2m_evaluate<true>(s_x, frec, fkind, nfac, huber_a, s_red, s_ev);
     // thread-0 scalars of the trust-region loop (trust_region_minimizer.cc + levenberg_marquardt_strategy.cc)
@@ -409,37 +471,55 @@ __global__ __launch_bounds__(S2M_NT) void s2m_solve(const double *pose_in, const
         }
     }
     if (tid == 0) {
-        for (int k = 0; k < 7; k++) out->pose[k] = s_x[k];
-        out->final_cost = x_cost; out->iterations = iteration; out->n_edge = tne; out->n_surf = tns;
+        for (int k = 0; k < 7; k++) pose_in[k] = s_x[k];
+        out->cost[pass] = x_cost; out->its[pass] = iteration; out->nfe[pass] = tne; out->nfs[pass] = tns;
     }
 }
 
-__global__ void s2m_transform_append(const float4 *pts, int n, const double *pose, float4 *dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
+// ---- createSubMap (:298-352): transform + append, crop box, voxel grid -------------------------------------------------
+__global__ void b_transform_append(CSet ds, const double *pose_all, CSet map, int *err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= ds.n[sid]) return;
+    const double *pose = pose_all + 24 * sid;
+    const int dst = map.n[sid] + i;
+    if (dst >= map.cap) { atomicOr(err + sid, S2B_ERR_MAPCAP); return; }
+    const float4 p = ds.p[(size_t)sid * ds.cap + i];
     const double cp[3] = {p.x, p.y, p.z};
     double pw[3];
     q_rot(q_load(pose), cp, pw);
-    dst[i] = make_float4((float)(pw[0] + pose[4]), (float)(pw[1] + pose[5]), (float)(pw[2] + pose[6]), p.w);
+    map.p[(size_t)sid * map.cap + dst] = make_float4((float)(pw[0] + pose[4]), (float)(pw[1] + pose[5]), (float)(pw[2] + pose[6]), p.w);
 }
-__global__ void s2m_crop_flags(const float4 *p, int n, const double *pose, double half, int *flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 q = p[i];
-    const float mnx = (float)(pose[4] - half), mny = (float)(pose[5] - half), mnz = (float)(pose[6] - half);
-    const float mxx = (float)(pose[4] + half), mxy = (float)(pose[5] + half), mxz = (float)(pose[6] + half);
-    flag[i] = !(q.x < mnx || q.y < mny || q.z < mnz || q.x > mxx || q.y > mxy || q.z > mxz) ? 1 : 0;
+__global__ void b_bump(CSet map, CSet ds, int S) {
+    const int sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid < S) map.n[sid] = min(map.n[sid] + ds.n[sid], map.cap);
 }
-__global__ void s2m_compact(const float4 *p, const int *flag, const int *pos, int n, float4 *out, int *n_out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (flag[i]) out[pos[i]] = p[i];
-    if (i == n - 1) *n_out = pos[i] + flag[i];
+__global__ void b_crop_flags(CSet map, const double *pose_all, double half, int *flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= map.cap) return;
+    const size_t g = (size_t)sid * map.cap + i;
+    int f = 0;
+    if (i < map.n[sid]) {
+        const double *pose = pose_all + 24 * sid;
+        const float4 q = map.p[g];
+        const float mnx = (float)(pose[4] - half), mny = (float)(pose[5] - half), mnz = (float)(pose[6] - half);
+        const float mxx = (float)(pose[4] + half), mxy = (float)(pose[5] + half), mxz = (float)(pose[6] + half);
+        f = !(q.x < mnx || q.y < mny || q.z < mnz || q.x > mxx || q.y > mxy || q.z > mxz) ? 1 : 0;
+    }
+    flag[g] = f;
 }
-__global__ void s2m_predict(double *pose, double *pose_last, double *prev) {
-    // globalOdom_est = globalOdom * (globalOdom_last^-1 * globalOdom) (EstimationMapping.hpp:238-243), rotation via matrices
-    if (threadIdx.x) return;
+__global__ void b_compact(CSet map, const int *flag, const int *pos, CSet out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= map.cap) return;
+    const size_t base = (size_t)sid * map.cap, g = base + i;
+    const int p0 = pos[base];
+    if (flag[g]) out.p[(size_t)sid * out.cap + (pos[g] - p0)] = map.p[g];
+    if (i == map.cap - 1) out.n[sid] = pos[g] + flag[g] - p0;
+}
+// globalOdom_est = globalOdom * (globalOdom_last^-1 * globalOdom) (EstimationMapping.hpp:238-243), rotation via matrices
+__global__ void b_predict(double *pose_all, int S) {
+    const int sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= S) return;
+    double *pose = pose_all + 24 * sid, *pose_last = pose + 8, *prev = pose + 16;
     double R[9], Rl[9], Rrel[9], Re[9], d[3], trel[3], te[3];
     q_toR(q_load(pose), R); q_toR(q_load(pose_last), Rl);
     m3_mulT(Rl, R, Rrel);
@@ -451,216 +531,378 @@ __global__ void s2m_predict(double *pose, double *pose_last, double *prev) {
     q_store(pose, q_fromR(Re));
     for (int k = 0; k < 3; k++) pose[4 + k] = te[k] + prev[4 + k];
 }
+// optimisation gate of optimation_processing (:254: both maps big enough) + result reset
+__global__ void b_gate(const int *n_map_e, const int *n_map_s, const int *n_ds_e, const int *n_ds_s, S2BRes *res, int *err, int S) {
+    const int sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= S) return;
+    S2BRes r;
+    memset(&r, 0, sizeof(r));
+    r.n_ds[0] = n_ds_e[sid]; r.n_ds[1] = n_ds_s[sid];
+    r.do_opt = (n_map_e[sid] > 10 && n_map_s[sid] > 50 && n_ds_e[sid] + n_ds_s[sid] > 0) ? 1 : 0;
+    res[sid] = r;
+}
+__global__ void b_finish(const double *pose_all, const int *n_map_e, const int *n_map_s, const int *err, S2BRes *res, int S) {
+    const int sid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sid >= S) return;
+    const double *pose = pose_all + 24 * sid;
+    for (int k = 0; k < 7; k++) { res[sid].pose[k] = pose[k]; res[sid].prev[k] = pose[16 + k]; }
+    res[sid].map_n[0] = n_map_e[sid]; res[sid].map_n[1] = n_map_s[sid];
+    res[sid].err = err[sid];
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host
-struct DCloud { DBuf buf; int n = 0; float4 *p() { return buf.as<float4>(); } };
-struct KnnIndex { DBuf sorted, table; unsigned int mask = 0; int n = 0; };
-
-struct S2MCtx {
-    DCloud mapEdge, mapSurf, tmpA, tmpB, dsEdge, dsSurf, inE, inS;
-    KnnIndex idxEdge, idxSurf;
-    DBuf keys, keys2, vals, vals2, head, seg, temp, mm, counter, frec, fkind, pose, solve_out, flag;
-    size_t temp_bytes = 0;
-    double h_pose[7] = {0, 0, 0, 1, 0, 0, 0}, h_last[7] = {0, 0, 0, 1, 0, 0, 0};
+struct S2B {
+    int S = 0;
+    int capScan[2] = {0, 0}, capMap[2] = {0, 0};
+    DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], nMap[2], tmpB, nTmp, sorted[2], table[2], cellbase[2];
+    unsigned int mask[2] = {0, 0};
+    DBuf keys, keys2, vals, vals2, head, seg, temp, mm, frec, fkind, pose, res, err;
+    DBuf map0[2], nMap0[2], pose0;
+    bool has_snapshot = false, scan_dirty = true;
+    size_t temp_bytes = 0, work_n = 0;
+    std::vector<int> h_nScan[2], h_nMap[2];
+    std::vector<S2BRes> h_res;
+    CSet cs_scan(int w) { return CSet{scan[w].as<float4>(), nScan[w].as<int>(), capScan[w]}; }
+    CSet cs_ds(int w) { return CSet{ds[w].as<float4>(), nDs[w].as<int>(), capScan[w]}; }
+    CSet cs_map(int w) { return CSet{map[w].as<float4>(), nMap[w].as<int>(), capMap[w]}; }
+    CSet cs_tmp(int w) { return CSet{tmpB.as<float4>(), nTmp.as<int>(), capMap[w]}; }
+    void release() {
+        DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
+                       &table[0], &table[1], &cellbase[0], &cellbase[1], &keys, &keys2, &vals, &vals2, &head, &seg, &temp, &mm, &frec, &fkind, &pose, &res, &err,
+                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0};
+        for (DBuf *b : all) b->release();
+    }
 };
 
-static S2MCtx *ctx(vilf_handle *h) {
-    if (!h->s2m) {
-        h->s2m = new S2MCtx();
-        h->s2m->pose.ensure(32 * 8); h->s2m->mm.ensure(sizeof(MinMax)); h->s2m->counter.ensure(64); h->s2m->solve_out.ensure(sizeof(S2MSolveOut));
-        hipMemcpy(h->s2m->pose.p, h->s2m->h_pose, 56, hipMemcpyHostToDevice);
-        hipMemcpy(h->s2m->pose.as<double>() + 8, h->s2m->h_last, 56, hipMemcpyHostToDevice);
-    }
-    return h->s2m;
-}
 void vilf_s2m_release(vilf_handle *h) {
-    if (!h->s2m) return;
-    S2MCtx *c = h->s2m;
-    DBuf *all[] = {&c->mapEdge.buf, &c->mapSurf.buf, &c->tmpA.buf, &c->tmpB.buf, &c->dsEdge.buf, &c->dsSurf.buf, &c->inE.buf, &c->inS.buf, &c->idxEdge.sorted, &c->idxEdge.table,
-                   &c->idxSurf.sorted, &c->idxSurf.table, &c->keys, &c->keys2, &c->vals, &c->vals2, &c->head, &c->seg, &c->temp, &c->mm, &c->counter, &c->frec, &c->fkind, &c->pose, &c->solve_out, &c->flag};
-    for (DBuf *b : all) b->release();
-    delete c;
-    h->s2m = nullptr;
+    for (S2B **pc : {&h->s2m, &h->s2b}) if (*pc) { (*pc)->release(); delete *pc; *pc = nullptr; }
 }
 
-#define GRID(n) dim3(((n) + 255) / 256), dim3(256)
+#define GRID2(cap, S) dim3(((cap) + 255) / 256, (S)), dim3(256)
+#define GRIDS(S) dim3(((S) + 63) / 64), dim3(64)
 
-static int ensure_sort(vilf_handle *h, S2MCtx *c, int n) {
-    if (!c->keys.ensure((size_t)n * 8) || !c->keys2.ensure((size_t)n * 8) || !c->vals.ensure((size_t)n * 4) || !c->vals2.ensure((size_t)n * 4) || !c->head.ensure((size_t)n * 4) || !c->seg.ensure((size_t)n * 4)) return VILF_ERR_DEVICE;
-    size_t need = 0, need2 = 0;
-    rocprim::radix_sort_pairs(nullptr, need, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), (size_t)n, 0, 64, h->stream);
-    rocprim::exclusive_scan(nullptr, need2, c->head.as<int>(), c->seg.as<int>(), 0, (size_t)n, rocprim::plus<int>(), h->stream);
-    need = std::max(need, need2) + 256;
-    if (!c->temp.ensure(need)) return VILF_ERR_DEVICE;
-    c->temp_bytes = c->temp.cap;
+static int sbits_of(int S) { int b = 0; while ((1 << b) < S) b++; return b; }
+
+// (Re)size the context. Map contents, counters and poses survive a capacity growth; a change of S starts from scratch.
+static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS, int capMapE, int capMapS) {
+    const int wantScan[2] = {std::max(capScanE, 1), std::max(capScanS, 1)}, wantMap[2] = {std::max(capMapE, 1), std::max(capMapS, 1)};
+    if (S != c->S) {
+        c->release();
+        c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false;
+        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4)) return VILF_ERR_DEVICE;
+        for (int w = 0; w < 2; w++) {
+            if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->cellbase[w].ensure((size_t)S * 16)) return VILF_ERR_DEVICE;
+            HIPCHECK(h, hipMemsetAsync(c->nScan[w].p, 0, (size_t)S * 4, h->stream));
+            HIPCHECK(h, hipMemsetAsync(c->nDs[w].p, 0, (size_t)S * 4, h->stream));
+            HIPCHECK(h, hipMemsetAsync(c->nMap[w].p, 0, (size_t)S * 4, h->stream));
+            c->h_nScan[w].assign(S, 0); c->h_nMap[w].assign(S, 0);
+        }
+        std::vector<double> ident((size_t)S * 24, 0.0);
+        for (int s = 0; s < S; s++) { ident[24 * s + 3] = 1.0; ident[24 * s + 11] = 1.0; ident[24 * s + 19] = 1.0; }
+        HIPCHECK(h, hipMemcpyAsync(c->pose.p, ident.data(), ident.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        c->h_res.assign(S, S2BRes{});
+    }
+    bool grew = false;
+    for (int w = 0; w < 2; w++) {
+        if (wantScan[w] > c->capScan[w]) {
+            const int nc = c->capScan[w] ? std::max(wantScan[w], 2 * c->capScan[w]) : wantScan[w];
+            if (!c->scan[w].ensure((size_t)S * nc * 16) || !c->ds[w].ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
+            c->capScan[w] = nc; grew = true; c->scan_dirty = true;
+        }
+        if (wantMap[w] > c->capMap[w]) {
+            const int oc = c->capMap[w], nc = oc ? std::max(wantMap[w], 2 * oc) : wantMap[w];
+            DBuf nb;
+            if (!nb.ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
+            if (oc) {
+                HIPCHECK(h, hipMemcpy2DAsync(nb.p, (size_t)nc * 16, c->map[w].p, (size_t)oc * 16, (size_t)oc * 16, S, hipMemcpyDeviceToDevice, h->stream));
+                HIPCHECK(h, hipStreamSynchronize(h->stream));
+            }
+            c->map[w].release();
+            c->map[w] = nb;
+            c->capMap[w] = nc; grew = true; c->has_snapshot = false;
+            unsigned int T = 64;
+            while (T < (unsigned int)nc + (unsigned int)nc / 2) T <<= 1;
+            c->mask[w] = T - 1;
+            if (!c->sorted[w].ensure((size_t)S * nc * 16) || !c->table[w].ensure((size_t)S * T * sizeof(HashEntry))) return VILF_ERR_DEVICE;
+        }
+    }
+    if (grew) {
+        const int maxMap = std::max(c->capMap[0], c->capMap[1]);
+        const size_t n = (size_t)S * std::max(std::max(c->capScan[0], c->capScan[1]), maxMap);
+        if (!c->tmpB.ensure((size_t)S * maxMap * 16)) return VILF_ERR_DEVICE;
+        const size_t capq = (size_t)c->capScan[0] + c->capScan[1];
+        if (!c->frec.ensure((size_t)S * capq * S2M_FREC * 8) || !c->fkind.ensure((size_t)S * capq * 4)) return VILF_ERR_DEVICE;
+        if (n > c->work_n) {
+            if (!c->keys.ensure(n * 8) || !c->keys2.ensure(n * 8) || !c->vals.ensure(n * 4) || !c->vals2.ensure(n * 4) || !c->head.ensure(n * 4) || !c->seg.ensure(n * 4)) return VILF_ERR_DEVICE;
+            size_t need = 0, need2 = 0;
+            rocprim::radix_sort_pairs(nullptr, need, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, 64, h->stream);
+            rocprim::exclusive_scan(nullptr, need2, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream);
+            need = std::max(need, need2) + 256;
+            if (!c->temp.ensure(need)) return VILF_ERR_DEVICE;
+            c->temp_bytes = c->temp.cap;
+            c->work_n = n;
+        }
+    }
     return VILF_OK;
 }
 
-// pcl::VoxelGrid: in -> out (device), returns out.n
-static int voxel_grid(vilf_handle *h, S2MCtx *c, DCloud &in, float leaf, DCloud &out) {
-    out.n = 0;
-    if (in.n == 0) return VILF_OK;
-    const int n = in.n;
-    int rc = ensure_sort(h, c, n);
-    if (rc != VILF_OK) return rc;
-    if (!out.buf.ensure((size_t)n * 16)) return VILF_ERR_DEVICE;
+// pcl::VoxelGrid over every stream: in -> out (device counters)
+static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
+    const int S = c->S;
+    const size_t n = (size_t)S * in.cap;
     const float inv = 1.0f / leaf;
-    hipLaunchKernelGGL(s2m_minmax, dim3(1), dim3(1024), 0, h->stream, in.p(), n, inv, c->mm.as<MinMax>());
-    hipLaunchKernelGGL(s2m_voxel_keys, GRID(n), 0, h->stream, in.p(), n, inv, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>());
+    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, in, inv, c->mm.as<MinMax>());
+    hipLaunchKernelGGL(b_voxel_keys, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->err.as<int>());
     size_t tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), (size_t)n, 0, 64, h->stream));
-    hipLaunchKernelGGL(s2m_heads, GRID(n), 0, h->stream, c->keys2.as<unsigned long long>(), n, c->head.as<int>());
+    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, S2B_VOXBITS + sbits_of(S), h->stream));
+    hipLaunchKernelGGL(b_heads, GRID2(in.cap, S), 0, h->stream, c->keys2.as<unsigned long long>(), in, c->head.as<int>());
     tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->head.as<int>(), c->seg.as<int>(), 0, (size_t)n, rocprim::plus<int>(), h->stream));
-    hipLaunchKernelGGL(s2m_centroids, GRID(n), 0, h->stream, in.p(), c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->head.as<int>(), c->seg.as<int>(), n, out.p(), c->counter.as<int>());
-    HIPCHECK(h, hipMemcpyAsync(&out.n, c->counter.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream));
+    hipLaunchKernelGGL(b_centroids, GRID2(in.cap, S), 0, h->stream, in, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->head.as<int>(), c->seg.as<int>(), out);
     return VILF_OK;
 }
 
-static int build_index(vilf_handle *h, S2MCtx *c, DCloud &map, KnnIndex &ix) {
-    ix.n = map.n;
-    if (map.n == 0) return VILF_OK;
-    const int n = map.n;
-    int rc = ensure_sort(h, c, n);
-    if (rc != VILF_OK) return rc;
-    unsigned int T = 64;
-    while (T < 2u * (unsigned int)n) T <<= 1;
-    ix.mask = T - 1;
-    if (!ix.sorted.ensure((size_t)n * 16) || !ix.table.ensure((size_t)T * sizeof(HashEntry))) return VILF_ERR_DEVICE;
-    HIPCHECK(h, hipMemsetAsync(ix.table.p, 0xff, (size_t)T * sizeof(HashEntry), h->stream));
-    hipLaunchKernelGGL(s2m_cell_keys, GRID(n), 0, h->stream, map.p(), n, c->keys.as<unsigned long long>(), c->vals.as<int>());
+static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
+    const int S = c->S;
+    CSet map = c->cs_map(w);
+    const size_t n = (size_t)S * map.cap;
+    HIPCHECK(h, hipMemsetAsync(c->table[w].p, 0xff, (size_t)S * (c->mask[w] + 1) * sizeof(HashEntry), h->stream));
+    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, map, 1.0f, c->mm.as<MinMax>());
+    hipLaunchKernelGGL(b_cell_keys, GRID2(map.cap, S), 0, h->stream, map, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->cellbase[w].as<int>(), c->err.as<int>());
     size_t tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), (size_t)n, 0, 64, h->stream));
-    hipLaunchKernelGGL(s2m_gather_hash, GRID(n), 0, h->stream, map.p(), c->keys2.as<unsigned long long>(), c->vals2.as<int>(), n, ix.sorted.as<float4>(), ix.table.as<HashEntry>(), ix.mask);
+    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, S2B_CELLBITS + sbits_of(S), h->stream));
+    hipLaunchKernelGGL(b_gather_hash, GRID2(map.cap, S), 0, h->stream, map, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->sorted[w].as<float4>(), c->table[w].as<HashEntry>(), c->mask[w]);
+    return VILF_OK;
+}
+
+// one optimation_processing() for every stream; everything is enqueued on the handle's stream, no host round trip
+static int s2b_step(vilf_handle *h, S2B *c) {
+    const int S = c->S;
+    int rc;
+    if (c->scan_dirty) {
+        for (int w = 0; w < 2; w++) HIPCHECK(h, hipMemcpyAsync(c->nScan[w].p, c->h_nScan[w].data(), (size_t)S * 4, hipMemcpyHostToDevice, h->stream));
+        c->scan_dirty = false;
+    }
+    double *d_pose = c->pose.as<double>();
+    S2BRes *d_res = c->res.as<S2BRes>();
+    int *d_err = c->err.as<int>();
+    hipLaunchKernelGGL(b_predict, GRIDS(S), 0, h->stream, d_pose, S);
+    const float leaf[2] = {(float)h->opts.edge_leaf_size, (float)h->opts.surf_leaf_size};
+    for (int w = 0; w < 2; w++) if ((rc = s2b_voxel(h, c, c->cs_scan(w), leaf[w], c->cs_ds(w))) != VILF_OK) return rc;
+    hipLaunchKernelGGL(b_gate, GRIDS(S), 0, h->stream, c->nMap[0].as<int>(), c->nMap[1].as<int>(), c->nDs[0].as<int>(), c->nDs[1].as<int>(), d_res, d_err, S);
+    for (int w = 0; w < 2; w++) if ((rc = s2b_build_index(h, c, w)) != VILF_OK) return rc;
+    const int capq = c->capScan[0] + c->capScan[1];
+    for (int pass = 0; pass < h->opts.s2m_outer_iterations && pass < 2; pass++) {
+        for (int w = 0; w < 2; w++)
+            hipLaunchKernelGGL(b_associate, GRID2(c->capScan[w], S), 0, h->stream, c->cs_ds(w), w, c->nDs[0].as<int>(), d_pose, c->cs_map(w), c->sorted[w].as<float4>(), c->table[w].as<HashEntry>(),
+                               c->mask[w], c->cellbase[w].as<int>(), d_res, c->frec.as<double>(), c->fkind.as<int>(), capq);
+        hipLaunchKernelGGL(b_solve, dim3(S), dim3(S2M_NT), 0, h->stream, d_pose, c->frec.as<double>(), c->fkind.as<int>(), capq, c->nDs[0].as<int>(), c->nDs[1].as<int>(), h->opts.huber_a,
+                           h->opts.s2m_max_iterations, pass, d_res);
+    }
+    for (int w = 0; w < 2; w++) {     // createSubMap: append registered points, crop, voxel grid
+        CSet map = c->cs_map(w), dsw = c->cs_ds(w), tmp = c->cs_tmp(w);
+        const size_t n = (size_t)S * map.cap;
+        hipLaunchKernelGGL(b_transform_append, GRID2(dsw.cap, S), 0, h->stream, dsw, d_pose, map, d_err);
+        hipLaunchKernelGGL(b_bump, GRIDS(S), 0, h->stream, map, dsw, S);
+        hipLaunchKernelGGL(b_crop_flags, GRID2(map.cap, S), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, c->head.as<int>());
+        size_t tb = c->temp_bytes;
+        HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream));
+        hipLaunchKernelGGL(b_compact, GRID2(map.cap, S), 0, h->stream, map, c->head.as<int>(), c->seg.as<int>(), tmp);
+        if ((rc = s2b_voxel(h, c, tmp, leaf[w], map)) != VILF_OK) return rc;
+    }
+    hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
     HIPCHECK(h, hipGetLastError());
     return VILF_OK;
 }
 
-static int upload_cloud(vilf_handle *h, DCloud &c, const float *xyzi, int n) {
-    c.n = n;
-    if (n == 0) return VILF_OK;
-    if (!c.buf.ensure((size_t)n * 16)) return VILF_ERR_DEVICE;
-    HIPCHECK(h, hipMemcpyAsync(c.buf.p, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+static void s2b_fill_result(const S2BRes &r, vilf_scan2map_result *res) {
+    std::memset(res, 0, sizeof(*res));
+    std::memcpy(res->pose_qt, r.pose, 56);
+    res->n_edge_ds = r.n_ds[0]; res->n_surf_ds = r.n_ds[1];
+    for (int k = 0; k < 2; k++) { res->n_edge_factors[k] = r.nfe[k]; res->n_surf_factors[k] = r.nfs[k]; res->iterations[k] = r.its[k]; res->final_cost[k] = r.cost[k]; }
+    res->map_edge_size = r.map_n[0]; res->map_surf_size = r.map_n[1];
+    // /Odometry relative pose: q_last^-1 * q, q_last^-1 * (t - t_last) (feature_tracker_node.cpp:392-394)
+    const double *pv = r.prev, *q = r.pose;
+    const double n2 = pv[0] * pv[0] + pv[1] * pv[1] + pv[2] * pv[2] + pv[3] * pv[3];
+    const double qi[4] = {-pv[0] / n2, -pv[1] / n2, -pv[2] / n2, pv[3] / n2};
+    res->rel_q[0] = qi[3] * q[0] + qi[0] * q[3] + qi[1] * q[2] - qi[2] * q[1];
+    res->rel_q[1] = qi[3] * q[1] + qi[1] * q[3] + qi[2] * q[0] - qi[0] * q[2];
+    res->rel_q[2] = qi[3] * q[2] + qi[2] * q[3] + qi[0] * q[1] - qi[1] * q[0];
+    res->rel_q[3] = qi[3] * q[3] - qi[0] * q[0] - qi[1] * q[1] - qi[2] * q[2];
+    const double v[3] = {q[4] - pv[4], q[5] - pv[5], q[6] - pv[6]};
+    const double ux = 2 * (qi[1] * v[2] - qi[2] * v[1]), uy = 2 * (qi[2] * v[0] - qi[0] * v[2]), uz = 2 * (qi[0] * v[1] - qi[1] * v[0]);
+    res->rel_t[0] = v[0] + qi[3] * ux + (qi[1] * uz - qi[2] * uy);
+    res->rel_t[1] = v[1] + qi[3] * uy + (qi[2] * ux - qi[0] * uz);
+    res->rel_t[2] = v[2] + qi[3] * uz + (qi[0] * uy - qi[1] * ux);
+}
+static int s2b_err_to_rc(vilf_handle *h, int err) {
+    if (!err) return VILF_OK;
+    h->err = std::string("scan2map: ") + ((err & S2B_ERR_MAPCAP) ? "local-map capacity exceeded; " : "") + ((err & S2B_ERR_EXTENT) ? "local map spans more than 1022 m; " : "") +
+             ((err & S2B_ERR_VOXEL) ? "voxel index overflow (leaf too small for the cloud extent); " : "");
+    return VILF_ERR_UNSUPPORTED;
+}
+static int s2b_set_cloud(vilf_handle *h, S2B *c, DBuf &buf, int cap, int sid, int offset, const float *xyzi, int n) {
+    if (n > 0) HIPCHECK(h, hipMemcpyAsync(buf.as<float4>() + (size_t)sid * cap + offset, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
     return VILF_OK;
 }
-static int append_cloud(vilf_handle *h, DCloud &dst, const DCloud &src) {    // dst += src (device copy)
-    if (src.n == 0) return VILF_OK;
-    if ((size_t)(dst.n + src.n) * 16 > dst.buf.cap) {
-        DBuf nb;
-        if (!nb.ensure((size_t)(dst.n + src.n) * 16 * 2)) return VILF_ERR_DEVICE;
-        if (dst.n) HIPCHECK(h, hipMemcpyAsync(nb.p, dst.buf.p, (size_t)dst.n * 16, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHECK(h, hipStreamSynchronize(h->stream));
-        dst.buf.release();
-        dst.buf = nb;
-    }
-    HIPCHECK(h, hipMemcpyAsync(dst.p() + dst.n, src.buf.p, (size_t)src.n * 16, hipMemcpyDeviceToDevice, h->stream));
-    dst.n += src.n;
-    return VILF_OK;
-}
+
+// ---- single-stream ABI (S = 1, capacities grow on demand) ---------------------------------------------------------------
+static S2B *single(vilf_handle *h) { if (!h->s2m) h->s2m = new S2B(); return h->s2m; }
 
 extern "C" int vilf_scan2map_init(vilf_handle *h, const float *e, int ne, const float *s, int ns) {
     if (!h || ne < 0 || ns < 0 || (ne && !e) || (ns && !s)) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipSetDevice(h->device));
-    S2MCtx *c = ctx(h);
-    int rc;
-    if ((rc = upload_cloud(h, c->inE, e, ne)) != VILF_OK || (rc = upload_cloud(h, c->inS, s, ns)) != VILF_OK) return rc;
-    if ((rc = append_cloud(h, c->mapEdge, c->inE)) != VILF_OK || (rc = append_cloud(h, c->mapSurf, c->inS)) != VILF_OK) return rc;
+    S2B *c = single(h);
+    const int oe = c->S ? c->h_nMap[0][0] : 0, os = c->S ? c->h_nMap[1][0] : 0;
+    int rc = s2b_reserve(h, c, 1, ne, ns, oe + ne, os + ns);
+    if (rc != VILF_OK) return rc;
+    const float *src[2] = {e, s}; const int nn[2] = {ne, ns};                       // localMapInited (:105): map += cloud
+    for (int w = 0; w < 2; w++) {
+        if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], 0, c->h_nMap[w][0], src[w], nn[w])) != VILF_OK) return rc;
+        c->h_nMap[w][0] += nn[w];
+        HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->h_nMap[w].data(), 4, hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     return VILF_OK;
 }
 
 extern "C" int vilf_scan2map_set_pose(vilf_handle *h, const double p[7], const double pl[7]) {
     if (!h || !p || !pl) return VILF_ERR_INVALID_ARGUMENT;
-    S2MCtx *c = ctx(h);
-    std::memcpy(c->h_pose, p, 56); std::memcpy(c->h_last, pl, 56);
+    HIPCHECK(h, hipSetDevice(h->device));
+    S2B *c = single(h);
+    int rc = s2b_reserve(h, c, 1, c->capScan[0], c->capScan[1], c->capMap[0], c->capMap[1]);
+    if (rc != VILF_OK) return rc;
     HIPCHECK(h, hipMemcpy(c->pose.p, p, 56, hipMemcpyHostToDevice));
     HIPCHECK(h, hipMemcpy(c->pose.as<double>() + 8, pl, 56, hipMemcpyHostToDevice));
     return VILF_OK;
 }
 
-extern "C" int vilf_scan2map_get_map(vilf_handle *h, int which, float *out, int cap, int *n_out) {
-    if (!h || !n_out) return VILF_ERR_INVALID_ARGUMENT;
-    S2MCtx *c = ctx(h);
-    DCloud &m = which == 0 ? c->mapEdge : c->mapSurf;
-    *n_out = m.n;
-    const int k = std::min(cap, m.n);
-    if (k > 0 && out) HIPCHECK(h, hipMemcpy(out, m.buf.p, (size_t)k * 16, hipMemcpyDeviceToHost));
+static int s2b_get_map(vilf_handle *h, S2B *c, int sid, int which, float *out, int cap, int *n_out) {
+    int n = 0;
+    if (c->S) HIPCHECK(h, hipMemcpy(&n, c->nMap[which].as<int>() + sid, 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    const int k = std::min(cap, n);
+    if (k > 0 && out) HIPCHECK(h, hipMemcpy(out, c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)k * 16, hipMemcpyDeviceToHost));
     return VILF_OK;
+}
+extern "C" int vilf_scan2map_get_map(vilf_handle *h, int which, float *out, int cap, int *n_out) {
+    if (!h || !n_out || which < 0 || which > 1) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipSetDevice(h->device));
+    return s2b_get_map(h, single(h), 0, which, out, cap, n_out);
 }
 
 extern "C" int vilf_scan2map_step(vilf_handle *h, const float *e, int ne, const float *s, int ns, vilf_scan2map_result *res) {
     if (!h || !res || ne < 0 || ns < 0 || (ne && !e) || (ns && !s)) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipSetDevice(h->device));
-    S2MCtx *c = ctx(h);
+    S2B *c = single(h);
     std::memset(res, 0, sizeof(*res));
-    double *d_pose = c->pose.as<double>(), *d_last = d_pose + 8, *d_prev = d_pose + 16;
-    hipLaunchKernelGGL(s2m_predict, dim3(1), dim3(64), 0, h->stream, d_pose, d_last, d_prev);
+    const int oe = c->S ? c->h_nMap[0][0] : 0, os = c->S ? c->h_nMap[1][0] : 0;
+    int rc = s2b_reserve(h, c, 1, ne, ns, oe + ne, os + ns);
+    if (rc != VILF_OK) return rc;
+    const float *src[2] = {e, s}; const int nn[2] = {ne, ns};
+    for (int w = 0; w < 2; w++) {
+        if ((rc = s2b_set_cloud(h, c, c->scan[w], c->capScan[w], 0, 0, src[w], nn[w])) != VILF_OK) return rc;
+        c->h_nScan[w][0] = nn[w];
+    }
+    c->scan_dirty = true;
+    if ((rc = s2b_step(h, c)) != VILF_OK) return rc;
+    HIPCHECK(h, hipMemcpyAsync(c->h_res.data(), c->res.p, sizeof(S2BRes), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    const S2BRes &r = c->h_res[0];
+    c->h_nMap[0][0] = r.map_n[0]; c->h_nMap[1][0] = r.map_n[1];
+    s2b_fill_result(r, res);
+    if (r.err) { HIPCHECK(h, hipMemsetAsync(c->err.p, 0, 4, h->stream)); }
+    return s2b_err_to_rc(h, r.err);
+}
+
+// ---- batched ABI: S independent LiDAR streams with fixed capacities ------------------------------------------------------
+extern "C" int vilf_scan2map_batch_create(vilf_handle *h, int n_streams, int cap_scan_edge, int cap_scan_surf, int cap_map_edge, int cap_map_surf) {
+    if (!h || n_streams < 1 || n_streams > 65535 || cap_scan_edge < 1 || cap_scan_surf < 1 || cap_map_edge < 1 || cap_map_surf < 1) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (h->s2b) { h->s2b->release(); delete h->s2b; h->s2b = nullptr; }
+    h->s2b = new S2B();
+    return s2b_reserve(h, h->s2b, n_streams, cap_scan_edge, cap_scan_surf, cap_map_edge, cap_map_surf);
+}
+#define S2B_CHECK(h, sid)                                                                   \
+    if (!(h) || !(h)->s2b) return VILF_ERR_INVALID_ARGUMENT;                                \
+    S2B *c = (h)->s2b;                                                                      \
+    if ((sid) < 0 || (sid) >= c->S) return VILF_ERR_INVALID_ARGUMENT;                       \
+    HIPCHECK(h, hipSetDevice((h)->device));
+
+extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float *e, int ne, const float *s, int ns, const double *pose_qt) {
+    S2B_CHECK(h, stream)
+    if (ne < 0 || ns < 0 || ne > c->capMap[0] || ns > c->capMap[1] || (ne && !e) || (ns && !s)) return VILF_ERR_INVALID_ARGUMENT;
+    const float *src[2] = {e, s}; const int nn[2] = {ne, ns};
     int rc;
-    if ((rc = upload_cloud(h, c->inE, e, ne)) != VILF_OK || (rc = upload_cloud(h, c->inS, s, ns)) != VILF_OK) return rc;
-    if ((rc = voxel_grid(h, c, c->inE, (float)h->opts.edge_leaf_size, c->dsEdge)) != VILF_OK) return rc;
-    if ((rc = voxel_grid(h, c, c->inS, (float)h->opts.surf_leaf_size, c->dsSurf)) != VILF_OK) return rc;
-    res->n_edge_ds = c->dsEdge.n; res->n_surf_ds = c->dsSurf.n;
-    const int nq = c->dsEdge.n + c->dsSurf.n;
-    if (c->mapEdge.n > 10 && c->mapSurf.n > 50 && nq > 0) {
-        if ((rc = build_index(h, c, c->mapEdge, c->idxEdge)) != VILF_OK || (rc = build_index(h, c, c->mapSurf, c->idxSurf)) != VILF_OK) return rc;
-        if (!c->frec.ensure((size_t)nq * S2M_FREC * 8) || !c->fkind.ensure((size_t)nq * 4)) return VILF_ERR_DEVICE;
-        for (int iter = 0; iter < h->opts.s2m_outer_iterations && iter < 2; iter++) {
-            if (c->dsEdge.n) hipLaunchKernelGGL(s2m_associate, GRID(c->dsEdge.n), 0, h->stream, c->dsEdge.p(), c->dsEdge.n, 0, d_pose, c->idxEdge.sorted.as<float4>(), c->idxEdge.table.as<HashEntry>(), c->idxEdge.mask, c->mapEdge.n, c->frec.as<double>(), c->fkind.as<int>());
-            if (c->dsSurf.n) hipLaunchKernelGGL(s2m_associate, GRID(c->dsSurf.n), 0, h->stream, c->dsSurf.p(), c->dsSurf.n, 1, d_pose, c->idxSurf.sorted.as<float4>(), c->idxSurf.table.as<HashEntry>(), c->idxSurf.mask, c->mapSurf.n, c->frec.as<double>() + (size_t)c->dsEdge.n * S2M_FREC, c->fkind.as<int>() + c->dsEdge.n);
-            hipLaunchKernelGGL(s2m_solve, dim3(1), dim3(S2M_NT), 0, h->stream, d_pose, c->frec.as<double>(), c->fkind.as<int>(), c->dsEdge.n, c->dsSurf.n, h->opts.huber_a, h->opts.s2m_max_iterations, c->solve_out.as<S2MSolveOut>());
-            S2MSolveOut so;
-            HIPCHECK(h, hipMemcpyAsync(&so, c->solve_out.p, sizeof(so), hipMemcpyDeviceToHost, h->stream));
-            HIPCHECK(h, hipMemcpyAsync(d_pose, c->solve_out.p, 56, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHECK(h, hipStreamSynchronize(h->stream));
-            res->n_edge_factors[iter] = so.n_edge; res->n_surf_factors[iter] = so.n_surf; res->iterations[iter] = so.iterations; res->final_cost[iter] = so.final_cost;
-        }
+    for (int w = 0; w < 2; w++) {                                                   // the stream's local map := cloud
+        if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], stream, 0, src[w], nn[w])) != VILF_OK) return rc;
+        c->h_nMap[w][stream] = nn[w];
+        HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + stream, &c->h_nMap[w][stream], 4, hipMemcpyHostToDevice, h->stream));
     }
-    // createSubMap: append registered points, crop, voxel grid
-    for (int which = 0; which < 2; which++) {
-        DCloud &ds = which ? c->dsSurf : c->dsEdge, &map = which ? c->mapSurf : c->mapEdge;
-        const float leaf = (float)(which ? h->opts.surf_leaf_size : h->opts.edge_leaf_size);
-        if (ds.n) {
-            if (!c->tmpA.buf.ensure((size_t)ds.n * 16)) return VILF_ERR_DEVICE;
-            hipLaunchKernelGGL(s2m_transform_append, GRID(ds.n), 0, h->stream, ds.p(), ds.n, d_pose, c->tmpA.p());
-            c->tmpA.n = ds.n;
-            if ((rc = append_cloud(h, map, c->tmpA)) != VILF_OK) return rc;
-        }
-        if (map.n == 0) continue;
-        const int n = map.n;
-        if ((rc = ensure_sort(h, c, n)) != VILF_OK) return rc;
-        if (!c->flag.ensure((size_t)n * 4) || !c->tmpB.buf.ensure((size_t)n * 16)) return VILF_ERR_DEVICE;
-        hipLaunchKernelGGL(s2m_crop_flags, GRID(n), 0, h->stream, map.p(), n, d_pose, h->opts.s2m_crop_half, c->flag.as<int>());
-        size_t tb = c->temp_bytes;
-        HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->flag.as<int>(), c->seg.as<int>(), 0, (size_t)n, rocprim::plus<int>(), h->stream));
-        hipLaunchKernelGGL(s2m_compact, GRID(n), 0, h->stream, map.p(), c->flag.as<int>(), c->seg.as<int>(), n, c->tmpB.p(), c->counter.as<int>());
-        HIPCHECK(h, hipMemcpyAsync(&c->tmpB.n, c->counter.p, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipStreamSynchronize(h->stream));
-        DCloud out;
-        if ((rc = voxel_grid(h, c, c->tmpB, leaf, out)) != VILF_OK) return rc;
-        map.buf.release();
-        map.buf = out.buf; map.n = out.n;
-    }
-    double hp[24];
-    HIPCHECK(h, hipMemcpy(hp, d_pose, sizeof(hp), hipMemcpyDeviceToHost));
-    std::memcpy(c->h_pose, hp, 56); std::memcpy(c->h_last, hp + 8, 56);
-    std::memcpy(res->pose_qt, hp, 56);
-    {   // /Odometry relative pose: q_last^-1 * q, q_last^-1 * (t - t_last) (feature_tracker_node.cpp:392-394)
-        const double *pv = hp + 16;
-        const double n2 = pv[0] * pv[0] + pv[1] * pv[1] + pv[2] * pv[2] + pv[3] * pv[3];
-        const double qi[4] = {-pv[0] / n2, -pv[1] / n2, -pv[2] / n2, pv[3] / n2};
-        const double *q = hp;
-        res->rel_q[0] = qi[3] * q[0] + qi[0] * q[3] + qi[1] * q[2] - qi[2] * q[1];
-        res->rel_q[1] = qi[3] * q[1] + qi[1] * q[3] + qi[2] * q[0] - qi[0] * q[2];
-        res->rel_q[2] = qi[3] * q[2] + qi[2] * q[3] + qi[0] * q[1] - qi[1] * q[0];
-        res->rel_q[3] = qi[3] * q[3] - qi[0] * q[0] - qi[1] * q[1] - qi[2] * q[2];
-        const double v[3] = {hp[4] - pv[4], hp[5] - pv[5], hp[6] - pv[6]};
-        const double ux = 2 * (qi[1] * v[2] - qi[2] * v[1]), uy = 2 * (qi[2] * v[0] - qi[0] * v[2]), uz = 2 * (qi[0] * v[1] - qi[1] * v[0]);
-        res->rel_t[0] = v[0] + qi[3] * ux + (qi[1] * uz - qi[2] * uy);
-        res->rel_t[1] = v[1] + qi[3] * uy + (qi[2] * ux - qi[0] * uz);
-        res->rel_t[2] = v[2] + qi[3] * uz + (qi[0] * uy - qi[1] * ux);
-    }
-    res->map_edge_size = c->mapEdge.n; res->map_surf_size = c->mapSurf.n;
+    double p[24] = {0};
+    p[3] = p[11] = p[19] = 1.0;
+    if (pose_qt) for (int k = 0; k < 7; k++) p[k] = p[8 + k] = p[16 + k] = pose_qt[k];
+    HIPCHECK(h, hipMemcpyAsync(c->pose.as<double>() + 24 * (size_t)stream, p, sizeof(p), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
     return VILF_OK;
+}
+extern "C" int vilf_scan2map_batch_set_scan(vilf_handle *h, int stream, const float *e, int ne, const float *s, int ns) {
+    S2B_CHECK(h, stream)
+    if (ne < 0 || ns < 0 || ne > c->capScan[0] || ns > c->capScan[1] || (ne && !e) || (ns && !s)) return VILF_ERR_INVALID_ARGUMENT;
+    const float *src[2] = {e, s}; const int nn[2] = {ne, ns};
+    int rc;
+    for (int w = 0; w < 2; w++) {
+        if ((rc = s2b_set_cloud(h, c, c->scan[w], c->capScan[w], stream, 0, src[w], nn[w])) != VILF_OK) return rc;
+        c->h_nScan[w][stream] = nn[w];
+    }
+    c->scan_dirty = true;
+    HIPCHECK(h, hipStreamSynchronize(h->stream));          // the caller's buffers may be re-used after return
+    return VILF_OK;
+}
+extern "C" int vilf_scan2map_batch_step(vilf_handle *h, int sync) {
+    S2B_CHECK(h, 0)
+    int rc = s2b_step(h, c);
+    if (rc != VILF_OK) return rc;
+    if (sync) HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VILF_OK;
+}
+extern "C" int vilf_scan2map_batch_snapshot(vilf_handle *h) {
+    S2B_CHECK(h, 0)
+    for (int w = 0; w < 2; w++) {
+        if (!c->map0[w].ensure((size_t)c->S * c->capMap[w] * 16) || !c->nMap0[w].ensure((size_t)c->S * 4)) return VILF_ERR_DEVICE;
+        HIPCHECK(h, hipMemcpyAsync(c->map0[w].p, c->map[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(c->nMap0[w].p, c->nMap[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (!c->pose0.ensure((size_t)c->S * 24 * 8)) return VILF_ERR_DEVICE;
+    HIPCHECK(h, hipMemcpyAsync(c->pose0.p, c->pose.p, (size_t)c->S * 24 * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    c->has_snapshot = true;
+    return VILF_OK;
+}
+extern "C" int vilf_scan2map_batch_rewind(vilf_handle *h) {
+    S2B_CHECK(h, 0)
+    if (!c->has_snapshot) { h->err = "scan2map_batch_rewind: no snapshot"; return VILF_ERR_INVALID_ARGUMENT; }
+    for (int w = 0; w < 2; w++) {
+        HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->nMap0[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHECK(h, hipMemcpyAsync(c->pose.p, c->pose0.p, (size_t)c->S * 24 * 8, hipMemcpyDeviceToDevice, h->stream));
+    return VILF_OK;
+}
+extern "C" int vilf_scan2map_batch_results(vilf_handle *h, int first, int n, vilf_scan2map_result *out) {
+    S2B_CHECK(h, first)
+    if (n < 0 || first + n > c->S || (n && !out)) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipMemcpyAsync(c->h_res.data() + first, c->res.as<S2BRes>() + first, (size_t)n * sizeof(S2BRes), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    int err = 0;
+    for (int i = 0; i < n; i++) { s2b_fill_result(c->h_res[first + i], out + i); err |= c->h_res[first + i].err; }
+    return s2b_err_to_rc(h, err);
+}
+extern "C" int vilf_scan2map_batch_get_map(vilf_handle *h, int stream, int which, float *out, int cap, int *n_out) {
+    S2B_CHECK(h, stream)
+    if (!n_out || which < 0 || which > 1) return VILF_ERR_INVALID_ARGUMENT;
+    return s2b_get_map(h, c, stream, which, out, cap, n_out);
 }

@@ -219,3 +219,46 @@ class Scan2Map:
     def set_pose(self, pose_qt, pose_last_qt):
         f = lambda v: abi.dptr(np.ascontiguousarray(v, dtype=np.float64))
         self.s._check(self._L.vilf_scan2map_set_pose(self.s._h, f(pose_qt), f(pose_last_qt)), "vilf_scan2map_set_pose")
+
+
+class Scan2MapBatch:
+    """n_streams independent EstimationMapping objects (one per LiDAR stream / replayed segment) stepped together on the
+    device: fixed per-stream capacities, device-side counters, no host round trip inside a step."""
+
+    def __init__(self, solver, n_streams, cap_scan_edge, cap_scan_surf, cap_map_edge, cap_map_surf):
+        self.s = solver
+        self._L = solver._L
+        self.n = int(n_streams)
+        self.s._check(self._L.vilf_scan2map_batch_create(self.s._h, self.n, int(cap_scan_edge), int(cap_scan_surf), int(cap_map_edge), int(cap_map_surf)),
+                      "vilf_scan2map_batch_create")
+
+    def localMapInited(self, stream, edge_xyzi, surf_xyzi, pose_qt=None):
+        e, ep = Scan2Map._fp(edge_xyzi); s, sp = Scan2Map._fp(surf_xyzi)
+        pp = None if pose_qt is None else abi.dptr(np.ascontiguousarray(pose_qt, dtype=np.float64))
+        self.s._check(self._L.vilf_scan2map_batch_init(self.s._h, stream, ep, len(e), sp, len(s), pp), "vilf_scan2map_batch_init")
+
+    def set_scan(self, stream, edge_xyzi, surf_xyzi):
+        e, ep = Scan2Map._fp(edge_xyzi); s, sp = Scan2Map._fp(surf_xyzi)
+        self.s._check(self._L.vilf_scan2map_batch_set_scan(self.s._h, stream, ep, len(e), sp, len(s)), "vilf_scan2map_batch_set_scan")
+
+    def step(self, sync=True):
+        self.s._check(self._L.vilf_scan2map_batch_step(self.s._h, 1 if sync else 0), "vilf_scan2map_batch_step")
+
+    def snapshot(self):
+        self.s._check(self._L.vilf_scan2map_batch_snapshot(self.s._h), "vilf_scan2map_batch_snapshot")
+
+    def rewind(self):
+        self.s._check(self._L.vilf_scan2map_batch_rewind(self.s._h), "vilf_scan2map_batch_rewind")
+
+    def results(self, first=0, n=None):
+        n = self.n - first if n is None else n
+        arr = (abi.Scan2MapResult * n)()
+        self.s._check(self._L.vilf_scan2map_batch_results(self.s._h, first, n, arr), "vilf_scan2map_batch_results")
+        return list(arr)
+
+    def getMapCloud(self, stream, which):
+        n = C.c_int(0)
+        self.s._check(self._L.vilf_scan2map_batch_get_map(self.s._h, stream, which, None, 0, C.byref(n)), "vilf_scan2map_batch_get_map")
+        out = np.zeros((max(n.value, 1), 4), dtype=np.float32)
+        self.s._check(self._L.vilf_scan2map_batch_get_map(self.s._h, stream, which, out.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)), "vilf_scan2map_batch_get_map")
+        return out[:n.value]

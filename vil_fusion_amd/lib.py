@@ -16,6 +16,8 @@ EXPORTED = [
     "vilf_batch_newest_poses_device", "vilf_prior_export", "vilf_prior_import", "vilf_eval_projection", "vilf_eval_imu",
     "vilf_eval_lidar_between", "vilf_eval_prior", "vilf_eval_edge", "vilf_eval_surf", "vilf_pose_plus", "vilf_se3_plus",
     "vilf_imu_preintegrate", "vilf_scan2map_init", "vilf_scan2map_step", "vilf_scan2map_get_map", "vilf_scan2map_set_pose",
+    "vilf_scan2map_batch_create", "vilf_scan2map_batch_init", "vilf_scan2map_batch_set_scan", "vilf_scan2map_batch_step", "vilf_scan2map_batch_snapshot",
+    "vilf_scan2map_batch_rewind", "vilf_scan2map_batch_results", "vilf_scan2map_batch_get_map",
 ]
 
 
@@ -75,6 +77,15 @@ def lib():
     L.vilf_scan2map_step.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(abi.Scan2MapResult)]
     L.vilf_scan2map_get_map.argtypes = [vp, C.c_int, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     L.vilf_scan2map_set_pose.argtypes = [vp, abi.c_double_p, abi.c_double_p]
+    fpp = C.POINTER(C.c_float)
+    L.vilf_scan2map_batch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.vilf_scan2map_batch_init.argtypes = [vp, C.c_int, fpp, C.c_int, fpp, C.c_int, abi.c_double_p]
+    L.vilf_scan2map_batch_set_scan.argtypes = [vp, C.c_int, fpp, C.c_int, fpp, C.c_int]
+    L.vilf_scan2map_batch_step.argtypes = [vp, C.c_int]
+    L.vilf_scan2map_batch_snapshot.argtypes = [vp]
+    L.vilf_scan2map_batch_rewind.argtypes = [vp]
+    L.vilf_scan2map_batch_results.argtypes = [vp, C.c_int, C.c_int, C.POINTER(abi.Scan2MapResult)]
+    L.vilf_scan2map_batch_get_map.argtypes = [vp, C.c_int, C.c_int, fpp, C.c_int, C.POINTER(C.c_int)]
     _lib = L
     return L
 
