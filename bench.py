@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
 """bench.py — sliding-window solve iterations/s on MI355X (BASELINE.json metric), one process per GPU.
 
-A "step" = one pass of the hot path over one batch of synthetic input: every rank re-arms its B HBM-resident window
-snapshots (state rewind) and runs the full Estimator::optimization() solve (Ceres-configured dogleg, max 8 iterations,
-time limit off) on all of them, then gathers the newest-frame poses over RCCL (the global_fusion input). Windows are
-independent units, sharded over ranks with no data-path collective => weak scaling.
+A "step" = one pass of the hot path over one batch of synthetic input. The unit is a FRAME of BASELINE.json configs[2]:
+  * the LiDAR stage: one scan-to-map step (EstimationMapping::optimation_processing) — voxel down-sampling, radix-hashed
+    voxel 5-NN, ~1.2 k edge + ~2.8 k plane queries -> ~3-4 k edge/plane factors, 2 x <= 4 LM iterations, local-map update
+    against a ~30 k + ~78 k point local map;
+  * the back-end: the full Estimator::optimization() solve of the 11-frame window (~1.5 k visual factors, 10 IMU, 10 LiDAR
+    between-factors, prior; Ceres-configured dogleg, max 8 iterations, time limit off).
+Every rank re-arms its B HBM-resident frames (window snapshots + LiDAR streams), runs both stages on all of them, then gathers
+the newest-frame poses over RCCL (the global_fusion input). Frames are independent units, sharded over ranks with no data-path
+collective => weak scaling. `value` counts the window solver's iterations only; the LiDAR stage is inside the timed region.
 
   python bench.py --gpus 1 --steps 10 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -21,8 +26,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def algorithmic_bytes_per_iteration(win, prior):
-    """fused-minimum bytes of one solver iteration (inputs read once, reduced system written once)."""
+def algorithmic_bytes_per_iteration(win, prior, part="all"):
+    """fused-minimum bytes of one solver iteration (inputs read once, reduced system written once).
+    part: "all" (the §8d figure, charged to the linearisation kernel), "reduced" (the reduced system + per-feature terms the
+    solve kernel consumes), "inputs" (factor inputs + prior + state the step kernel re-reads for the candidate cost)."""
     n_vis = win.n_factors
     n_imu = win.n_frames - 1
     n_lid = win.n_frames - 1 if win.lidar is not None else 0
@@ -30,34 +37,40 @@ def algorithmic_bytes_per_iteration(win, prior):
     k_p = prior.n_blocks if (prior is not None and prior.valid) else 0
     F = win.n_features
     P = 15 * win.n_frames
-    return (60 * n_vis + 2296 * n_imu + 56 * n_lid + 8 * (n_p * n_p + n_p + 7 * k_p)
-            + 8 * (16 * win.n_frames + 8 + F) + 16 * F + 8 * (P * P + P))
+    inputs = 60 * n_vis + 2296 * n_imu + 56 * n_lid + 8 * (n_p * n_p + n_p + 7 * k_p) + 8 * (16 * win.n_frames + 8 + F)
+    reduced = 16 * F + 8 * (P * P + P)
+    return {"all": inputs + reduced, "reduced": reduced + 8 * (n_p * n_p + n_p), "inputs": inputs}[part]
 
 
-def cpu_baseline(opts_unused, wins, priors, seconds_target=12.0):
-    """The CPU restatement (oracle/, 'port') timed on this box's host cores on a bounded sample of the same windows."""
-    import ctypes as C
+def cpu_baseline(opts_unused, wins, priors, lidar_cases, seconds_target=12.0):
+    """The CPU restatement (oracle/, 'port') timed on this box's host cores on a bounded sample of the same frames."""
+    import numpy as np
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     oracle_lib.build()
     o = oracle_lib.default_options()
     cores = max(1, min(16, os.cpu_count() or 1))
-    # calibrate on one solve
-    t0 = time.perf_counter()
-    r = oracle_lib.window_solve(o, wins[0], priors[0])
-    t1 = time.perf_counter() - t0
-    n = int(max(cores, min(32768, seconds_target * cores / max(t1, 1e-4))))
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
 
-    def work(i):
+    def frame(i):
+        if lidar_cases:
+            me, ms, se, ss, pl = lidar_cases[i % len(lidar_cases)]
+            m = oracle_lib.OracleS2M(o); m.init(me, ms); m.set_pose(ident, pl); m.step(se, ss)
         res = oracle_lib.window_solve(o, wins[i % len(wins)], priors[i % len(priors)])
         return res.summary["num_iterations"]
     t0 = time.perf_counter()
+    frame(0)                                   # calibrate on one frame
+    t1 = time.perf_counter() - t0
+    n = int(max(cores, min(32768, seconds_target * cores / max(t1, 1e-4))))
+    t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
-        its = sum(ex.map(work, range(n)))
+        its = sum(ex.map(frame, range(n)))
     dt = time.perf_counter() - t0
+    what = "scan-to-map step (1 m grid 5-NN) + window solve" if lidar_cases else "window solve"
     return dict(value=its / dt, unit="iterations/s", cores=cores, kind="port",
-                sample=f"{n} window solves ({its} iterations) of the same synthetic windows by oracle/ (C++ -O3, one solve per thread, {cores} threads), {dt:.1f} s")
+                sample=f"{n} frames ({its} window iterations; per frame: {what}) of the same synthetic input by oracle/ "
+                       f"(C++ -O3, one frame per thread, {cores} threads), {dt:.1f} s")
 
 
 def main():
@@ -65,8 +78,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=2048, help="window snapshots resident per GPU")
+    ap.add_argument("--windows", type=int, default=2048, help="frames (window snapshot + LiDAR stream) resident per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic windows (tiled to --windows)")
+    ap.add_argument("--distinct-lidar", type=int, default=4, help="distinct synthetic LiDAR scenes (tiled to --windows)")
+    ap.add_argument("--no-lidar-stage", action="store_true", help="configs[1]-style run: back-end window solve only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -87,7 +102,7 @@ def main():
 
     from vil_fusion_amd import synth
     from vil_fusion_amd import dist as vdist
-    from vil_fusion_amd.estimator import BackendSolver
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
     stream = torch.cuda.current_stream().cuda_stream
     solver = BackendSolver(device=local_rank, stream=stream)
     opts = solver.options
@@ -95,11 +110,24 @@ def main():
     cfg = synth.SynthConfig(n_features=230)        # ~1.5 k visual factors + 10 IMU + 10 LiDAR between-factors + prior (n = 75)
     wins, priors = synth.make_batch(1000 + rank, B, opts, cfg, distinct=args.distinct)
     solver.batch_upload(wins, priors)              # inputs resident in HBM before the timed region
+    lidar_cases, s2m = [], None
+    if not args.no_lidar_stage:                    # one LiDAR stream per frame: dense local map + one 64-ring scan, resident in HBM
+        lidar_cases = [synth.make_lidar_bench_case(7000 + 31 * rank + k) for k in range(args.distinct_lidar)]
+        cap = lambda a, b: max(len(c[a]) + (len(c[b]) if b is not None else 0) for c in lidar_cases) + 64
+        s2m = Scan2MapBatch(solver, B, cap(2, None), cap(3, None), cap(0, 2), cap(1, 3))
+        for i in range(B):
+            me, ms, se, ss, pl = lidar_cases[i % len(lidar_cases)]
+            s2m.localMapInited(i, me, ms, None, pl)
+            s2m.set_scan(i, se, ss)
+        s2m.snapshot()
     poses = torch.zeros((B, 8), dtype=torch.float64, device="cuda")
     stamps = np.arange(B, dtype=np.float64)
 
     def step():
         solver.batch_rewind()
+        if s2m is not None:
+            s2m.rewind()
+            s2m.step(sync=False)                   # same HIP stream as the window solve: the sync below covers both stages
         solver.batch_solve(sync=True)
         if world > 1:
             solver.newest_poses_to_device(stamps, poses.data_ptr())
@@ -122,6 +150,14 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = solver.get_profile()
+    lid = None
+    if s2m is not None:
+        prof.update(solver.get_profile_scan2map())
+        rs = s2m.results()
+        nq = float(np.mean([r.n_edge_ds + r.n_surf_ds for r in rs]))
+        lid = dict(queries=nq, factors=float(np.mean([r.n_edge_factors[1] + r.n_surf_factors[1] for r in rs])),
+                   lm_iterations=float(np.mean([r.iterations[0] + r.iterations[1] for r in rs])),
+                   map_points=float(np.mean([len(c[0]) + len(c[1]) for c in lidar_cases])), scan_points=float(np.mean([len(c[2]) + len(c[3]) for c in lidar_cases])))
     t = torch.tensor([dt, float(its_local)], dtype=torch.float64, device="cuda")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -132,16 +168,30 @@ def main():
 
     if rank == 0:
         abytes = float(np.mean([algorithmic_bytes_per_iteration(w, p) for w, p in zip(wins[:args.distinct], priors[:args.distinct])]))
-        dom = max(("k_linearize", "k_solve", "k_step"), key=lambda k: prof[k]["ms"])
+        # algorithmic bytes per STEP (all B frames) per kernel / launch group; for the window kernels
+        # every launch is one solver iteration of all B windows, so bytes-per-step / ms-per-step == bytes-per-launch / ms-per-launch
+        lps = {k: v["launches"] / args.steps for k, v in prof.items()}
+        part = lambda what: float(np.mean([algorithmic_bytes_per_iteration(w, p, what) for w, p in zip(wins[:args.distinct], priors[:args.distinct])]))
+        alg = {"k_linearize": abytes * B * lps["k_linearize"], "k_solve": part("reduced") * B * lps["k_solve"], "k_step": part("inputs") * B * lps["k_step"]}
+        if lid is not None:
+            nm, ns, nq = lid["map_points"], lid["scan_points"], lid["queries"]
+            alg.update({
+                "s2m_associate": B * 2 * nq * (12 + 27 * 2.0 * 16),      # 2 passes over all queries: point + 27 cells x c̄ = 2 pts x 16 B
+                "s2m_neighbour_index": B * nm * 16 * 2,                  # both maps: read points, write them cell-sorted
+                "s2m_radix_sort": B * (2 * nm + ns + nq) * 12 * 2,       # 6 sorts (2 scan grids, 2 indices, 2 map grids) priced as ONE pass over (key, index)
+                "s2m_voxel_grid": B * (nm + ns + nq) * 16 * 2,           # 4 grids: read points, write centroids
+                "s2m_lm_solve": B * nq * 84.0 * 2 * 4,                   # factor records (80 B + kind), 2 passes x ~4 evaluations
+                "s2m_submap": B * nm * 16 * 2})
+        dom = max(alg, key=lambda k: prof[k]["ms"])
         avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
-        achieved = abytes * B / (avg_ms * 1e-3) / 1e9
+        achieved = alg[dom] / max(lps[dom], 1e-9) / (avg_ms * 1e-3) / 1e9
         # HBM traffic per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this
         # same command; gfx950-corrected as MI355X_MICROARCH.md prescribes) — only when they were taken on this configuration
         traffic = None
         try:
             import glob
             pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-            if pmc["config"]["windows_per_gpu"] == B and pmc["config"]["features_per_window"] == cfg.n_features:
+            if pmc["config"]["windows_per_gpu"] == B and pmc["config"]["features_per_window"] == cfg.n_features and dom in pmc["kernels"]:
                 traffic = pmc["kernels"][dom]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
@@ -150,17 +200,23 @@ def main():
             "value": its_total / dt_max, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2] back-end: 10-keyframe window (11 frames), visual+IMU+LiDAR between-factors+prior, "
-                                   "batched independent window snapshots; scan-to-map edge/plane stage not in the timed region yet",
+            "config": {"workload": ("configs[2]: per frame one scan-to-map step (voxel-kNN, edge/plane factors, 2 x <=4 LM iterations, map update) + "
+                                    "the 10-keyframe window solve (11 frames, visual+IMU+LiDAR between-factors+prior, <=8 dogleg iterations); "
+                                    "batched independent frames") if lid is not None else
+                                   "configs[1]-style: 10-keyframe window solve only (visual+IMU+LiDAR between-factors+prior), batched independent windows",
+                       "frames_per_gpu": B, "lidar_stage": lid,
                        "windows_per_gpu": B, "distinct_windows": args.distinct, "visual_factors_per_window": float(np.mean([w.n_factors for w in wins[:args.distinct]])),
                        "features_per_window": float(np.mean([w.n_features for w in wins[:args.distinct]])), "max_iterations": int(opts.max_num_iterations),
                        "parallelism": f"{world} x independent window shards (no data-path collective; RCCL all_gather of 64 B poses)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_window_iteration": abytes,
-                         "kernels_ms": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()}},
+                         "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": lps[dom], "algorithmic_bytes_per_launch": alg[dom] / max(lps[dom], 1e-9),
+                         "algorithmic_bytes_per_window_iteration": abytes,
+                         "kernels_ms": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
+                         "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+                         "kernels_achieved_GBps": {k: alg[k] / max(prof[k]["ms"] / args.steps, 1e-9) / 1e6 for k in alg}},
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct])
+            out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

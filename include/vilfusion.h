@@ -194,6 +194,9 @@ int vilf_synchronize(vilf_handle *h);
 /* per-kernel timing by HIP events on the handle's stream (kind 0 linearize, 1 reduce+solve, 2 step, 3 other); needs sync solves */
 int vilf_set_profiling(vilf_handle *h, int on);
 int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]);
+/* same switch, scan-to-map launches by group: 0 voxel grid, 1 radix sort, 2 neighbour index, 3 associate (5-NN + fits),
+ * 4 LM solve, 5 sub-map maintenance, 6 other, 7 unused */
+int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long launches_out[8]);
 /* newest-frame pose per resident window: [stamp x y z qx qy qz qw] (8 doubles each) into a DEVICE buffer
  * (feeds the RCCL gather for global_fusion, poseGraphOptimization.cpp:116-121). */
 int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8);
@@ -253,8 +256,10 @@ int vilf_scan2map_set_pose(vilf_handle *h, const double pose_qt[7], const double
  * reports VILF_ERR_UNSUPPORTED through vilf_scan2map_batch_results). Stream i's result equals what a single-stream
  * handle fed with the same clouds returns. */
 int vilf_scan2map_batch_create(vilf_handle *h, int n_streams, int cap_scan_edge, int cap_scan_surf, int cap_map_edge, int cap_map_surf);
-/* localMapInited (:105) of one stream: its local map := the clouds; pose_qt (or NULL = identity) -> globalOdom = globalOdom_last */
-int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf, const double *pose_qt);
+/* localMapInited (:105) of one stream: its local map := the clouds; pose_qt (NULL = identity) -> globalOdom,
+ * pose_last_qt (NULL = pose_qt) -> globalOdom_last (the constant-velocity prediction of the first step, :238-243) */
+int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf,
+                             const double *pose_qt, const double *pose_last_qt);
 /* the scan the next vilf_scan2map_batch_step consumes for this stream (stays resident in HBM until replaced) */
 int vilf_scan2map_batch_set_scan(vilf_handle *h, int stream, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);
 int vilf_scan2map_batch_step(vilf_handle *h, int sync);                 /* optimation_processing (:235) for every stream */

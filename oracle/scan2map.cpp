@@ -3,7 +3,9 @@
 //   EstimationMapping::{localMapInited, optimation_processing, EdgeCostFactor, SurfCostFactor, createSubMap, pointAssociaToMap}
 //   (feature_tracker/include/EstimationMapping.hpp:105-363) with
 //   pcl::VoxelGrid (centroid per leaf, output in ascending leaf index), pcl::CropBox (inclusive box), and
-//   pcl::KdTreeFLANN::nearestKSearch(k = 5) replaced by an exact brute-force 5-NN (squared float distances, ascending).
+//   pcl::KdTreeFLANN::nearestKSearch(k = 5) replaced by an exact 5-NN (squared float distances, ascending): brute force is the
+//   definition (knn5); the step uses a 1 m cell grid (GridIndex, built once per map per step like the reference's kd-tree) that
+//   returns the same neighbours whenever the 5th squared distance is < 1 — the only case the reference uses (:129,189).
 #include "oracle_api.h"
 #include "solver.hpp"
 #include <cstdint>
@@ -65,6 +67,39 @@ void knn5(const Cloud &map, float qx, float qy, float qz, int idx[5], float d2[5
     }
 }
 
+// 1 m cell grid over the map: (cell key, point index) sorted by key; a query scans the 27 cells around it. Every point closer
+// than 1 m lies in that block, so whenever d2[4] < 1 the result equals knn5(); otherwise the caller rejects the query anyway.
+struct GridIndex {
+    const Cloud *map = nullptr;
+    std::vector<std::pair<uint64_t, int>> cells;
+    static uint64_t key(int x, int y, int z) { return ((uint64_t)(uint32_t)(x + (1 << 20)) << 42) | ((uint64_t)(uint32_t)(y + (1 << 20)) << 21) | (uint64_t)(uint32_t)(z + (1 << 20)); }
+    void build(const Cloud &m) {
+        map = &m;
+        cells.resize(m.size());
+        for (size_t i = 0; i < m.size(); i++) cells[i] = {key((int)std::floor(m[i].x), (int)std::floor(m[i].y), (int)std::floor(m[i].z)), (int)i};
+        std::sort(cells.begin(), cells.end());
+    }
+    void knn5(float qx, float qy, float qz, int idx[5], float d2[5]) const {
+        for (int k = 0; k < 5; k++) { idx[k] = 0x7fffffff; d2[k] = std::numeric_limits<float>::max(); }
+        const int cx = (int)std::floor(qx), cy = (int)std::floor(qy), cz = (int)std::floor(qz);
+        for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
+            const uint64_t k = key(cx + dx, cy + dy, cz + dz);
+            auto it = std::lower_bound(cells.begin(), cells.end(), std::make_pair(k, 0));
+            for (; it != cells.end() && it->first == k; ++it) {
+                const P4 &m = (*map)[it->second];
+                const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
+                const float d = ex * ex + ey * ey + ez * ez;
+                const int oi = it->second;
+                if (d < d2[4] || (d == d2[4] && oi < idx[4])) {
+                    int kk = 4;
+                    while (kk > 0 && (d < d2[kk - 1] || (d == d2[kk - 1] && oi < idx[kk - 1]))) { d2[kk] = d2[kk - 1]; idx[kk] = idx[kk - 1]; kk--; }
+                    d2[kk] = d; idx[kk] = oi;
+                }
+            }
+        }
+    }
+};
+
 inline void associate_point(const double pose[7], const P4 &p, float out[3]) {   // pointAssociaToMap (:354-362)
     Q4 q = Q4::from_xyzw(pose);
     V3 pw = q * V3(p.x, p.y, p.z) + V3(pose + 4);
@@ -72,12 +107,12 @@ inline void associate_point(const double pose[7], const P4 &p, float out[3]) {  
 }
 
 // EdgeCostFactor (:117-172): returns true and the line end points if the 5-NN pass the 1 m gate and the PCA line test
-bool edge_association(const Cloud &map, const double pose[7], const P4 &p, V3 &pa, V3 &pb) {
+bool edge_association(const Cloud &map, const GridIndex *gi, const double pose[7], const P4 &p, V3 &pa, V3 &pb) {
     if (map.size() < 5) return false;
     float c[3];
     associate_point(pose, p, c);
     int idx[5]; float d2[5];
-    knn5(map, c[0], c[1], c[2], idx, d2);
+    if (gi) gi->knn5(c[0], c[1], c[2], idx, d2); else knn5(map, c[0], c[1], c[2], idx, d2);
     if (!(d2[4] < 1.0f)) return false;
     V3 near[5], center;
     for (int j = 0; j < 5; j++) { near[j] = V3(map[idx[j]].x, map[idx[j]].y, map[idx[j]].z); center = center + near[j]; }
@@ -94,12 +129,12 @@ bool edge_association(const Cloud &map, const double pose[7], const P4 &p, V3 &p
 }
 
 // SurfCostFactor (:174-232)
-bool surf_association(const Cloud &map, const double pose[7], const P4 &p, V3 &nrm, double &d) {
+bool surf_association(const Cloud &map, const GridIndex *gi, const double pose[7], const P4 &p, V3 &nrm, double &d) {
     if (map.size() < 5) return false;
     float c[3];
     associate_point(pose, p, c);
     int idx[5]; float d2[5];
-    knn5(map, c[0], c[1], c[2], idx, d2);
+    if (gi) gi->knn5(c[0], c[1], c[2], idx, d2); else knn5(map, c[0], c[1], c[2], idx, d2);
     if (!(d2[4] < 1.0f)) return false;
     double A[15], B[5] = {-1, -1, -1, -1, -1};
     for (int j = 0; j < 5; j++) { A[3 * j] = map[idx[j]].x; A[3 * j + 1] = map[idx[j]].y; A[3 * j + 2] = map[idx[j]].z; }
@@ -160,14 +195,16 @@ extern "C" int vilo_s2m_step(vilo_s2m *s, const float *e, int ne, const float *f
     voxel_grid(to_cloud(f, nf), (float)s->o.surf_leaf_size, vs);
     res->n_edge_ds = (int)ve.size(); res->n_surf_ds = (int)vs.size();
     if (s->mapEdge.size() > 10 && s->mapSurf.size() > 50) {
+        GridIndex ge, gs;                              // ≙ kdtreeEdgeMap / kdtreeSurfMap ->setInputCloud (:256-257)
+        ge.build(s->mapEdge); gs.build(s->mapSurf);
         for (int iter = 0; iter < s->o.s2m_outer_iterations && iter < 2; iter++) {
             HuberLoss loss(s->o.huber_a);
             Problem pb;
             int blk = pb.add_parameter_block(s->pose, 7, PARAM_SE3);
             std::vector<std::unique_ptr<CostFunction>> costs;
             int nef = 0, nsf = 0;
-            for (const P4 &p : ve) { V3 a, b; if (edge_association(s->mapEdge, s->pose, p, a, b)) { costs.emplace_back(new EdgeCostFunction(V3(p.x, p.y, p.z), a, b)); pb.add_residual_block(costs.back().get(), &loss, {blk}); nef++; } }
-            for (const P4 &p : vs) { V3 nn; double d; if (surf_association(s->mapSurf, s->pose, p, nn, d)) { costs.emplace_back(new SurfCostFunction(V3(p.x, p.y, p.z), nn, d)); pb.add_residual_block(costs.back().get(), &loss, {blk}); nsf++; } }
+            for (const P4 &p : ve) { V3 a, b; if (edge_association(s->mapEdge, &ge, s->pose, p, a, b)) { costs.emplace_back(new EdgeCostFunction(V3(p.x, p.y, p.z), a, b)); pb.add_residual_block(costs.back().get(), &loss, {blk}); nef++; } }
+            for (const P4 &p : vs) { V3 nn; double d; if (surf_association(s->mapSurf, &gs, s->pose, p, nn, d)) { costs.emplace_back(new SurfCostFunction(V3(p.x, p.y, p.z), nn, d)); pb.add_residual_block(costs.back().get(), &loss, {blk}); nsf++; } }
             res->n_edge_factors[iter] = nef; res->n_surf_factors[iter] = nsf;
             SolverOptions so;
             so.strategy = STRATEGY_LM;                 // Ceres default trust-region strategy; DENSE_QR on one 6-dof block
@@ -203,6 +240,12 @@ extern "C" int vilo_knn5_bruteforce(const float *map, int nm, const float *q, in
     for (int i = 0; i < nq; i++) knn5(c, q[3 * i], q[3 * i + 1], q[3 * i + 2], idx5 + 5 * i, d5 + 5 * i);
     return VILF_OK;
 }
+extern "C" int vilo_knn5_grid(const float *map, int nm, const float *q, int nq, int *idx5, float *d5) {
+    Cloud c = to_cloud(map, nm);
+    GridIndex g; g.build(c);
+    for (int i = 0; i < nq; i++) g.knn5(q[3 * i], q[3 * i + 1], q[3 * i + 2], idx5 + 5 * i, d5 + 5 * i);
+    return VILF_OK;
+}
 extern "C" int vilo_voxel_grid(const float *xyzi, int n, float leaf, float *out, int cap, int *n_out) {
     Cloud o; voxel_grid(to_cloud(xyzi, n), leaf, o);
     *n_out = (int)o.size();
@@ -211,11 +254,11 @@ extern "C" int vilo_voxel_grid(const float *xyzi, int n, float leaf, float *out,
 }
 extern "C" int vilo_s2m_associate_edge(const float *map, int nm, const float *pts, int np, const double pose[7], unsigned char *valid, double *pa, double *pb) {
     Cloud c = to_cloud(map, nm), p = to_cloud(pts, np);
-    for (int i = 0; i < np; i++) { V3 a, b; valid[i] = edge_association(c, pose, p[i], a, b) ? 1 : 0; if (valid[i]) { pa[3 * i] = a.x; pa[3 * i + 1] = a.y; pa[3 * i + 2] = a.z; pb[3 * i] = b.x; pb[3 * i + 1] = b.y; pb[3 * i + 2] = b.z; } }
+    for (int i = 0; i < np; i++) { V3 a, b; valid[i] = edge_association(c, nullptr, pose, p[i], a, b) ? 1 : 0; if (valid[i]) { pa[3 * i] = a.x; pa[3 * i + 1] = a.y; pa[3 * i + 2] = a.z; pb[3 * i] = b.x; pb[3 * i + 1] = b.y; pb[3 * i + 2] = b.z; } }
     return VILF_OK;
 }
 extern "C" int vilo_s2m_associate_surf(const float *map, int nm, const float *pts, int np, const double pose[7], unsigned char *valid, double *nrm, double *d) {
     Cloud c = to_cloud(map, nm), p = to_cloud(pts, np);
-    for (int i = 0; i < np; i++) { V3 n; double dd; valid[i] = surf_association(c, pose, p[i], n, dd) ? 1 : 0; if (valid[i]) { nrm[3 * i] = n.x; nrm[3 * i + 1] = n.y; nrm[3 * i + 2] = n.z; d[i] = dd; } }
+    for (int i = 0; i < np; i++) { V3 n; double dd; valid[i] = surf_association(c, nullptr, pose, p[i], n, dd) ? 1 : 0; if (valid[i]) { nrm[3 * i] = n.x; nrm[3 * i + 1] = n.y; nrm[3 * i + 2] = n.z; d[i] = dd; } }
     return VILF_OK;
 }

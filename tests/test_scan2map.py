@@ -150,3 +150,26 @@ def test_scan2map_batch_matches_single_stream_and_oracle(oracle, opts):
     for hs, _ in singles:
         hs.close()
     s.close()
+
+
+def test_oracle_grid_knn_equals_bruteforce_inside_the_gate(oracle):
+    """The oracle's 1 m cell grid (what its scan-to-map step uses, like the reference's kd-tree) must return exactly the brute-force
+    neighbours — indices, order and squared distances — for every query whose 5th neighbour is closer than 1 m, and agree that
+    the others fail the gate."""
+    rng = np.random.default_rng(7)
+    mp = np.column_stack([rng.uniform(-15, 15, 6000), rng.uniform(-15, 15, 6000), rng.uniform(-1, 2, 6000), np.ones(6000)]).astype(np.float32)
+    mp[100:140, :3] = mp[100, :3]                                         # exact duplicates: ties resolved by index
+    q = np.concatenate([rng.uniform(-16, 16, (500, 3)), mp[90:150, :3] + 1e-3]).astype(np.float32)
+    L = oracle.lib()
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    outs = []
+    for fn in (L.vilo_knn5_bruteforce, L.vilo_knn5_grid):
+        fn.argtypes = [fp, C.c_int, fp, C.c_int, ip, fp]
+        idx = np.zeros((len(q), 5), dtype=np.int32); d5 = np.zeros((len(q), 5), dtype=np.float32)
+        fn(mp.ctypes.data_as(fp), len(mp), q.ctypes.data_as(fp), len(q), idx.ctypes.data_as(ip), d5.ctypes.data_as(fp))
+        outs.append((idx, d5))
+    (ib, db), (ig, dg) = outs
+    inside = db[:, 4] < 1.0
+    assert inside.sum() > 100 and (~inside).sum() > 10
+    assert np.array_equal(ib[inside], ig[inside]) and np.array_equal(db[inside], dg[inside])
+    assert np.all(dg[~inside, 4] >= 1.0)

@@ -454,6 +454,7 @@ extern "C" int vilf_set_profiling(vilf_handle *h, int on) {
     if (!h) return VILF_ERR_INVALID_ARGUMENT;
     h->profiling = on;
     for (int i = 0; i < 4; i++) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
+    for (int i = 0; i < 8; i++) { h->s2m_ms[i] = 0; h->s2m_launches[i] = 0; }
     return VILF_OK;
 }
 extern "C" int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]) {

@@ -56,6 +56,10 @@ struct vilf_handle {
     std::vector<hipEvent_t> pev;
     double kernel_ms[4] = {0, 0, 0, 0};      // linearize, solve, step, other (accumulated since last reset)
     long kernel_launches[4] = {0, 0, 0, 0};
+    std::vector<hipEvent_t> s2m_ev;         // scan-to-map profiling (same switch): group of launches -> ms
+    std::vector<int> s2m_groups;
+    double s2m_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long s2m_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double last_solve_usec = 0;
     size_t solve_lds = 0, lin_lds = 0;
     S2B *s2m = nullptr, *s2b = nullptr;      // scan-to-map state: single stream / batched streams (vilf_s2m.hip)

@@ -43,13 +43,15 @@ struct S2BRes {                       // per-stream result of one step (device)
     int n_ds[2], nfe[2], nfs[2], its[2], map_n[2];
     int err, do_opt;
 };
-#define S2B_VOXBITS 42                // pcl::VoxelGrid leaf index (a + b*dx + c*dx*dy) must stay below 2^42 - 1
-#define S2B_CELLBITS 30               // 1 m cells, 10 bits per axis relative to the stream's map minimum
+// Sort keys are as narrow as the data allows: the leaf-index width / the per-axis cell widths are reduced over all streams on the
+// device (b_minmax) and read back (16 bytes) before the keys are built, so a pass of the radix sort is not spent on zero bits.
 #define S2B_ERR_MAPCAP 1
 #define S2B_ERR_EXTENT 2
 #define S2B_ERR_VOXEL 4
 
-__global__ void b_minmax(CSet in, float inv, MinMax *mm) {
+__device__ __forceinline__ int bits_of(long long v) { return v <= 0 ? 0 : 64 - __clzll(v); }
+// bits[0]: width of the largest leaf index (+1) over all streams; bits[1..3]: widths of the 1 m cell extents (inv == 1)
+__global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
     __shared__ float s[6][1024];
     const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
     const float4 *p = in.p + (size_t)sid * in.cap;
@@ -74,22 +76,24 @@ __global__ void b_minmax(CSet in, float inv, MinMax *mm) {
             divb[k] = (int)floorf(__fmul_rn(s[3 + k][0], inv)) - out->minb[k] + 1;
         }
         out->mul1 = divb[0]; out->mul2 = (long long)divb[0] * divb[1];
+        if (n > 0) {
+            atomicMax(bits, bits_of((long long)divb[0] * divb[1] * divb[2]));
+            for (int k = 0; k < 3; k++) atomicMax(bits + 1 + k, bits_of(divb[k]));
+        }
     }
 }
-__global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, unsigned long long *keys, int *vals, int *err) {
+__global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, unsigned long long *keys, int *vals, int *err, int vbits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
     if (i >= in.cap) return;
     const size_t g = (size_t)sid * in.cap + i;
-    unsigned long long k = (1ULL << S2B_VOXBITS) - 1;
+    unsigned long long k = (1ULL << vbits) - 1;                 // padding: larger than every leaf index of the stream
     if (i < in.n[sid]) {
         const float4 q = in.p[g];
         const MinMax *m = mm + sid;
         const long long a = (long long)floorf(__fmul_rn(q.x, inv)) - m->minb[0], b = (long long)floorf(__fmul_rn(q.y, inv)) - m->minb[1], c = (long long)floorf(__fmul_rn(q.z, inv)) - m->minb[2];
-        unsigned long long v = (unsigned long long)(a + b * m->mul1 + c * m->mul2);
-        if (v >= k) { atomicOr(err + sid, S2B_ERR_VOXEL); v = k - 1; }
-        k = v;
+        k = (unsigned long long)(a + b * m->mul1 + c * m->mul2);
     }
-    keys[g] = ((unsigned long long)sid << S2B_VOXBITS) | k;
+    keys[g] = ((unsigned long long)sid << vbits) | k;
     vals[g] = i;
 }
 // after the sort the n[s] valid entries of stream s are the first n[s] of its segment
@@ -115,23 +119,22 @@ __global__ void b_centroids(CSet in, const unsigned long long *keys, const int *
 }
 // ---- radix-hashed voxel neighbour index: 1 m cells, key relative to the stream's map minimum ----
 __device__ __forceinline__ unsigned int hash30(unsigned int k) { k ^= k >> 16; k *= 0x7feb352dU; k ^= k >> 15; k *= 0x846ca68bU; k ^= k >> 16; return k; }
-__global__ void b_cell_keys(CSet map, const MinMax *mm, unsigned long long *keys, int *vals, int *cellbase, int *err) {
+__global__ void b_cell_keys(CSet map, const MinMax *mm, unsigned long long *keys, int *vals, int *cellbase, int *err, int by, int bz, int cbits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
     if (i >= map.cap) return;
     const size_t g = (size_t)sid * map.cap + i;
-    const int bx = (int)floorf(mm[sid].mn[0]), by = (int)floorf(mm[sid].mn[1]), bz = (int)floorf(mm[sid].mn[2]);
-    if (i == 0) { cellbase[4 * sid] = bx; cellbase[4 * sid + 1] = by; cellbase[4 * sid + 2] = bz; }
-    unsigned long long k = (1ULL << S2B_CELLBITS) - 1;
+    const int bx0 = (int)floorf(mm[sid].mn[0]), by0 = (int)floorf(mm[sid].mn[1]), bz0 = (int)floorf(mm[sid].mn[2]);
+    if (i == 0) { cellbase[4 * sid] = bx0; cellbase[4 * sid + 1] = by0; cellbase[4 * sid + 2] = bz0; }
+    unsigned long long k = (1ULL << cbits) - 1;
     if (i < map.n[sid]) {
         const float4 q = map.p[g];
-        int cx = (int)floorf(q.x) - bx, cy = (int)floorf(q.y) - by, cz = (int)floorf(q.z) - bz;
-        if (cx > 1022 || cy > 1022 || cz > 1022) { atomicOr(err + sid, S2B_ERR_EXTENT); cx = min(cx, 1022); cy = min(cy, 1022); cz = min(cz, 1022); }
-        k = ((unsigned long long)cx << 20) | ((unsigned long long)cy << 10) | (unsigned long long)cz;
+        const int cx = (int)floorf(q.x) - bx0, cy = (int)floorf(q.y) - by0, cz = (int)floorf(q.z) - bz0;
+        k = ((unsigned long long)cx << (by + bz)) | ((unsigned long long)cy << bz) | (unsigned long long)cz;
     }
-    keys[g] = ((unsigned long long)sid << S2B_CELLBITS) | k;
+    keys[g] = ((unsigned long long)sid << cbits) | k;
     vals[g] = i;
 }
-__global__ void b_gather_hash(CSet map, const unsigned long long *keys, const int *vals, float4 *sorted, HashEntry *table, unsigned int mask) {
+__global__ void b_gather_hash(CSet map, const unsigned long long *keys, const int *vals, float4 *sorted, HashEntry *table, unsigned int mask, int cbits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
     const int n = map.n[sid];
     if (i >= n) return;
@@ -143,9 +146,9 @@ __global__ void b_gather_hash(CSet map, const unsigned long long *keys, const in
         const unsigned long long kk = keys[g];
         int e = i + 1;
         while (e < n && keys[base + e] == kk) e++;
-        const unsigned long long k = kk & ((1ULL << S2B_CELLBITS) - 1);
+        const unsigned long long k = kk & ((1ULL << cbits) - 1);
         HashEntry *T = table + (size_t)sid * (mask + 1);
-        unsigned int s = hash30((unsigned int)k) & mask;
+        unsigned int s = hash30((unsigned int)k ^ (unsigned int)(k >> 32)) & mask;
         for (;;) {
             const unsigned long long prev = atomicCAS(&T[s].key, ~0ULL, k);
             if (prev == ~0ULL) { T[s].start = i; T[s].end = e; break; }
@@ -154,16 +157,17 @@ __global__ void b_gather_hash(CSet map, const unsigned long long *keys, const in
     }
 }
 // exact 5-NN within the 27-cell block: pos[] = positions in the cell-sorted array, ordered by (squared distance, original index)
-__device__ void knn5_cells(const float4 *sorted, const HashEntry *table, unsigned int mask, const int *cellbase, float qx, float qy, float qz, int pos[5], float d2[5]) {
+struct CellBits { int bx, by, bz; };
+__device__ void knn5_cells(const float4 *sorted, const HashEntry *table, unsigned int mask, const int *cellbase, CellBits cb, float qx, float qy, float qz, int pos[5], float d2[5]) {
     int oid[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { pos[k] = -1; oid[k] = 0x7fffffff; d2[k] = 3.0e38f; }
     const int cx = (int)floorf(qx) - cellbase[0], cy = (int)floorf(qy) - cellbase[1], cz = (int)floorf(qz) - cellbase[2];
     for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
         const int ax = cx + dx, ay = cy + dy, az = cz + dz;
-        if ((unsigned)ax > 1022u || (unsigned)ay > 1022u || (unsigned)az > 1022u) continue;      // no map point can live there
-        const unsigned long long k = ((unsigned long long)ax << 20) | ((unsigned long long)ay << 10) | (unsigned long long)az;
-        unsigned int s = hash30((unsigned int)k) & mask;
+        if (ax < 0 || ay < 0 || az < 0 || ax >= (1 << cb.bx) - 1 || ay >= (1 << cb.by) - 1 || az >= (1 << cb.bz) - 1) continue;      // outside every map's extent
+        const unsigned long long k = ((unsigned long long)ax << (cb.by + cb.bz)) | ((unsigned long long)ay << cb.bz) | (unsigned long long)az;
+        unsigned int s = hash30((unsigned int)k ^ (unsigned int)(k >> 32)) & mask;
         int st = 0, en = 0;
         for (;;) {
             const unsigned long long tk = table[s].key;
@@ -250,7 +254,7 @@ __device__ void qr_solve_5x3(const double *Ain, const double *bin, double *x) {
 #define S2M_FREC 10
 // one thread per query point of one stream. Edge queries write records [0, n_ds_edge), surf queries [n_ds_edge, n_ds_edge + n_ds_surf).
 __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const double *pose_all, CSet map, const float4 *sorted_all, const HashEntry *table_all,
-                            unsigned int mask, const int *cellbase_all, const S2BRes *res, double *frec_all, int *fkind_all, int capq) {
+                            unsigned int mask, const int *cellbase_all, CellBits cb, const S2BRes *res, double *frec_all, int *fkind_all, int capq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
     if (i >= ds.n[sid] || !res[sid].do_opt) return;
     const double *pose = pose_all + 24 * sid;
@@ -268,7 +272,7 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
     double rec[S2M_FREC] = {cp[0], cp[1], cp[2], 0, 0, 0, 0, 0, 0, 0};
     int idx[5]; float d2[5];
     if (nmap >= 5) {
-        knn5_cells(sorted, table, mask, cellbase_all + 4 * sid, qx, qy, qz, idx, d2);
+        knn5_cells(sorted, table, mask, cellbase_all + 4 * sid, cb, qx, qy, qz, idx, d2);
         if (d2[4] < 1.0f) {
             double nb[5][3];
             for (int t = 0; t < 5; t++) { const float4 m = sorted[idx[t]]; nb[t][0] = m.x; nb[t][1] = m.y; nb[t][2] = m.z; }
@@ -557,8 +561,9 @@ struct S2B {
     int capScan[2] = {0, 0}, capMap[2] = {0, 0};
     DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], nMap[2], tmpB, nTmp, sorted[2], table[2], cellbase[2];
     unsigned int mask[2] = {0, 0};
-    DBuf keys, keys2, vals, vals2, head, seg, temp, mm, frec, fkind, pose, res, err;
+    DBuf keys, keys2, vals, vals2, head, seg, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0;
+    CellBits cb[2] = {{1, 1, 1}, {1, 1, 1}};
     bool has_snapshot = false, scan_dirty = true;
     size_t temp_bytes = 0, work_n = 0;
     std::vector<int> h_nScan[2], h_nMap[2];
@@ -569,7 +574,7 @@ struct S2B {
     CSet cs_tmp(int w) { return CSet{tmpB.as<float4>(), nTmp.as<int>(), capMap[w]}; }
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
-                       &table[0], &table[1], &cellbase[0], &cellbase[1], &keys, &keys2, &vals, &vals2, &head, &seg, &temp, &mm, &frec, &fkind, &pose, &res, &err,
+                       &table[0], &table[1], &cellbase[0], &cellbase[1], &keys, &keys2, &vals, &vals2, &head, &seg, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
                        &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0};
         for (DBuf *b : all) b->release();
     }
@@ -579,6 +584,16 @@ void vilf_s2m_release(vilf_handle *h) {
     for (S2B **pc : {&h->s2m, &h->s2b}) if (*pc) { (*pc)->release(); delete *pc; *pc = nullptr; }
 }
 
+// profiling (vilf_set_profiling): HIP events between groups of launches on the handle's stream.
+// group 0 voxel grid, 1 radix sort (rocPRIM), 2 neighbour index (cell keys, hash build), 3 associate (5-NN + fits), 4 LM solve,
+// 5 sub-map (append, crop, compact), 6 other
+static void s2m_prof_mark(vilf_handle *h, int group) {
+    const size_t k = h->s2m_groups.size();
+    if (h->s2m_ev.size() <= k) { hipEvent_t e; hipEventCreate(&e); h->s2m_ev.push_back(e); }
+    hipEventRecord(h->s2m_ev[k], h->stream);
+    h->s2m_groups.push_back(group);
+}
+#define PROF(g) if (h->profiling) s2m_prof_mark(h, (g));
 #define GRID2(cap, S) dim3(((cap) + 255) / 256, (S)), dim3(256)
 #define GRIDS(S) dim3(((S) + 63) / 64), dim3(64)
 
@@ -590,7 +605,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
     if (S != c->S) {
         c->release();
         c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false;
-        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4)) return VILF_ERR_DEVICE;
+        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64)) return VILF_ERR_DEVICE;
         for (int w = 0; w < 2; w++) {
             if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->cellbase[w].ensure((size_t)S * 16)) return VILF_ERR_DEVICE;
             HIPCHECK(h, hipMemsetAsync(c->nScan[w].p, 0, (size_t)S * 4, h->stream));
@@ -654,14 +669,24 @@ static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
     const int S = c->S;
     const size_t n = (size_t)S * in.cap;
     const float inv = 1.0f / leaf;
-    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, in, inv, c->mm.as<MinMax>());
-    hipLaunchKernelGGL(b_voxel_keys, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->err.as<int>());
+    int hb[4];
+    HIPCHECK(h, hipMemsetAsync(c->bits.p, 0, 16, h->stream));
+    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->bits.as<int>());
+    HIPCHECK(h, hipMemcpyAsync(hb, c->bits.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    const int vbits = std::max(hb[0], 1);
+    if (vbits + sbits_of(S) > 63) { h->err = "scan2map: voxel index too wide (leaf size too small for the cloud extent)"; return VILF_ERR_UNSUPPORTED; }
+    PROF(0)
+    hipLaunchKernelGGL(b_voxel_keys, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->err.as<int>(), vbits);
+    PROF(0)
     size_t tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, S2B_VOXBITS + sbits_of(S), h->stream));
+    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, vbits + sbits_of(S), h->stream));
+    PROF(1)
     hipLaunchKernelGGL(b_heads, GRID2(in.cap, S), 0, h->stream, c->keys2.as<unsigned long long>(), in, c->head.as<int>());
     tb = c->temp_bytes;
     HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream));
     hipLaunchKernelGGL(b_centroids, GRID2(in.cap, S), 0, h->stream, in, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->head.as<int>(), c->seg.as<int>(), out);
+    PROF(0)
     return VILF_OK;
 }
 
@@ -670,11 +695,22 @@ static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
     CSet map = c->cs_map(w);
     const size_t n = (size_t)S * map.cap;
     HIPCHECK(h, hipMemsetAsync(c->table[w].p, 0xff, (size_t)S * (c->mask[w] + 1) * sizeof(HashEntry), h->stream));
-    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, map, 1.0f, c->mm.as<MinMax>());
-    hipLaunchKernelGGL(b_cell_keys, GRID2(map.cap, S), 0, h->stream, map, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->cellbase[w].as<int>(), c->err.as<int>());
+    int hb[4];
+    HIPCHECK(h, hipMemsetAsync(c->bits.p, 0, 16, h->stream));
+    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, map, 1.0f, c->mm.as<MinMax>(), c->bits.as<int>());
+    HIPCHECK(h, hipMemcpyAsync(hb, c->bits.p, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    c->cb[w] = CellBits{std::max(hb[1], 1), std::max(hb[2], 1), std::max(hb[3], 1)};
+    const int cbits = c->cb[w].bx + c->cb[w].by + c->cb[w].bz;
+    if (cbits + sbits_of(S) > 63) { h->err = "scan2map: local map extent too large"; return VILF_ERR_UNSUPPORTED; }
+    PROF(2)
+    hipLaunchKernelGGL(b_cell_keys, GRID2(map.cap, S), 0, h->stream, map, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->cellbase[w].as<int>(), c->err.as<int>(), c->cb[w].by, c->cb[w].bz, cbits);
+    PROF(2)
     size_t tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, S2B_CELLBITS + sbits_of(S), h->stream));
-    hipLaunchKernelGGL(b_gather_hash, GRID2(map.cap, S), 0, h->stream, map, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->sorted[w].as<float4>(), c->table[w].as<HashEntry>(), c->mask[w]);
+    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, cbits + sbits_of(S), h->stream));
+    PROF(1)
+    hipLaunchKernelGGL(b_gather_hash, GRID2(map.cap, S), 0, h->stream, map, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->sorted[w].as<float4>(), c->table[w].as<HashEntry>(), c->mask[w], cbits);
+    PROF(2)
     return VILF_OK;
 }
 
@@ -689,18 +725,24 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     double *d_pose = c->pose.as<double>();
     S2BRes *d_res = c->res.as<S2BRes>();
     int *d_err = c->err.as<int>();
+    h->s2m_groups.clear();
+    PROF(6)
     hipLaunchKernelGGL(b_predict, GRIDS(S), 0, h->stream, d_pose, S);
+    PROF(6)
     const float leaf[2] = {(float)h->opts.edge_leaf_size, (float)h->opts.surf_leaf_size};
     for (int w = 0; w < 2; w++) if ((rc = s2b_voxel(h, c, c->cs_scan(w), leaf[w], c->cs_ds(w))) != VILF_OK) return rc;
     hipLaunchKernelGGL(b_gate, GRIDS(S), 0, h->stream, c->nMap[0].as<int>(), c->nMap[1].as<int>(), c->nDs[0].as<int>(), c->nDs[1].as<int>(), d_res, d_err, S);
+    PROF(6)
     for (int w = 0; w < 2; w++) if ((rc = s2b_build_index(h, c, w)) != VILF_OK) return rc;
     const int capq = c->capScan[0] + c->capScan[1];
     for (int pass = 0; pass < h->opts.s2m_outer_iterations && pass < 2; pass++) {
         for (int w = 0; w < 2; w++)
             hipLaunchKernelGGL(b_associate, GRID2(c->capScan[w], S), 0, h->stream, c->cs_ds(w), w, c->nDs[0].as<int>(), d_pose, c->cs_map(w), c->sorted[w].as<float4>(), c->table[w].as<HashEntry>(),
-                               c->mask[w], c->cellbase[w].as<int>(), d_res, c->frec.as<double>(), c->fkind.as<int>(), capq);
+                               c->mask[w], c->cellbase[w].as<int>(), c->cb[w], d_res, c->frec.as<double>(), c->fkind.as<int>(), capq);
+        PROF(3)
         hipLaunchKernelGGL(b_solve, dim3(S), dim3(S2M_NT), 0, h->stream, d_pose, c->frec.as<double>(), c->fkind.as<int>(), capq, c->nDs[0].as<int>(), c->nDs[1].as<int>(), h->opts.huber_a,
                            h->opts.s2m_max_iterations, pass, d_res);
+        PROF(4)
     }
     for (int w = 0; w < 2; w++) {     // createSubMap: append registered points, crop, voxel grid
         CSet map = c->cs_map(w), dsw = c->cs_ds(w), tmp = c->cs_tmp(w);
@@ -711,10 +753,20 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         size_t tb = c->temp_bytes;
         HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream));
         hipLaunchKernelGGL(b_compact, GRID2(map.cap, S), 0, h->stream, map, c->head.as<int>(), c->seg.as<int>(), tmp);
+        PROF(5)
         if ((rc = s2b_voxel(h, c, tmp, leaf[w], map)) != VILF_OK) return rc;
     }
     hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
+    PROF(6)
     HIPCHECK(h, hipGetLastError());
+    if (h->profiling) {
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        for (size_t i = 1; i < h->s2m_groups.size(); i++) {
+            float t = 0;
+            hipEventElapsedTime(&t, h->s2m_ev[i - 1], h->s2m_ev[i]);
+            h->s2m_ms[h->s2m_groups[i]] += t; h->s2m_launches[h->s2m_groups[i]] += 1;
+        }
+    }
     return VILF_OK;
 }
 
@@ -832,7 +884,7 @@ extern "C" int vilf_scan2map_batch_create(vilf_handle *h, int n_streams, int cap
     if ((sid) < 0 || (sid) >= c->S) return VILF_ERR_INVALID_ARGUMENT;                       \
     HIPCHECK(h, hipSetDevice((h)->device));
 
-extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float *e, int ne, const float *s, int ns, const double *pose_qt) {
+extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float *e, int ne, const float *s, int ns, const double *pose_qt, const double *pose_last_qt) {
     S2B_CHECK(h, stream)
     if (ne < 0 || ns < 0 || ne > c->capMap[0] || ns > c->capMap[1] || (ne && !e) || (ns && !s)) return VILF_ERR_INVALID_ARGUMENT;
     const float *src[2] = {e, s}; const int nn[2] = {ne, ns};
@@ -845,6 +897,7 @@ extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float 
     double p[24] = {0};
     p[3] = p[11] = p[19] = 1.0;
     if (pose_qt) for (int k = 0; k < 7; k++) p[k] = p[8 + k] = p[16 + k] = pose_qt[k];
+    if (pose_last_qt) for (int k = 0; k < 7; k++) p[8 + k] = pose_last_qt[k];
     HIPCHECK(h, hipMemcpyAsync(c->pose.as<double>() + 24 * (size_t)stream, p, sizeof(p), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     return VILF_OK;
@@ -867,6 +920,11 @@ extern "C" int vilf_scan2map_batch_step(vilf_handle *h, int sync) {
     int rc = s2b_step(h, c);
     if (rc != VILF_OK) return rc;
     if (sync) HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VILF_OK;
+}
+extern "C" int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long launches_out[8]) {
+    if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 8; i++) { ms_out[i] = h->s2m_ms[i]; launches_out[i] = h->s2m_launches[i]; }
     return VILF_OK;
 }
 extern "C" int vilf_scan2map_batch_snapshot(vilf_handle *h) {

@@ -98,6 +98,13 @@ class BackendSolver:
         names = ["k_linearize", "k_solve", "k_step", "other"]
         return {names[i]: dict(ms=ms[i], launches=n[i]) for i in range(4)}
 
+    S2M_GROUPS = ("s2m_voxel_grid", "s2m_radix_sort", "s2m_neighbour_index", "s2m_associate", "s2m_lm_solve", "s2m_submap", "s2m_other")
+
+    def get_profile_scan2map(self):
+        ms = (C.c_double * 8)(); n = (C.c_long * 8)()
+        self._check(self._L.vilf_get_profile_scan2map(self._h, ms, n), "vilf_get_profile_scan2map")
+        return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(self.S2M_GROUPS)}
+
     def batch_marginalize(self, sync=True):
         self._check(self._L.vilf_batch_marginalize(self._h, 1 if sync else 0), "vilf_batch_marginalize")
 
@@ -232,10 +239,11 @@ class Scan2MapBatch:
         self.s._check(self._L.vilf_scan2map_batch_create(self.s._h, self.n, int(cap_scan_edge), int(cap_scan_surf), int(cap_map_edge), int(cap_map_surf)),
                       "vilf_scan2map_batch_create")
 
-    def localMapInited(self, stream, edge_xyzi, surf_xyzi, pose_qt=None):
+    def localMapInited(self, stream, edge_xyzi, surf_xyzi, pose_qt=None, pose_last_qt=None):
         e, ep = Scan2Map._fp(edge_xyzi); s, sp = Scan2Map._fp(surf_xyzi)
-        pp = None if pose_qt is None else abi.dptr(np.ascontiguousarray(pose_qt, dtype=np.float64))
-        self.s._check(self._L.vilf_scan2map_batch_init(self.s._h, stream, ep, len(e), sp, len(s), pp), "vilf_scan2map_batch_init")
+        keep = [None if v is None else np.ascontiguousarray(v, dtype=np.float64) for v in (pose_qt, pose_last_qt)]
+        pp, pl = [None if v is None else abi.dptr(v) for v in keep]
+        self.s._check(self._L.vilf_scan2map_batch_init(self.s._h, stream, ep, len(e), sp, len(s), pp, pl), "vilf_scan2map_batch_init")
 
     def set_scan(self, stream, edge_xyzi, surf_xyzi):
         e, ep = Scan2Map._fp(edge_xyzi); s, sp = Scan2Map._fp(surf_xyzi)

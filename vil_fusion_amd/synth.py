@@ -415,6 +415,51 @@ class LidarScene:
         return mk(e_idx), mk(s_idx)
 
 
+    def sample_map(self, R_wl, t_wl, ground_step=0.8, wall_step=0.8, pole_dz=0.25, pole_az=1, noise=0.02):
+        """A dense local map of the scene as a long mapping run would have accumulated it (ground lattice, walls, pole surfaces),
+        expressed in the LiDAR frame (R_wl, t_wl) — the frame scan-to-map calls "world" when that pose is its first one.
+        Returns (edge_xyzi, surf_xyzi) float32."""
+        rng = self.rng
+        h = self.half
+        g = np.arange(-h + 0.5 * ground_step, h, ground_step)
+        gx, gy = np.meshgrid(g, g, indexing="ij")
+        ground = np.column_stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)])
+        wz = np.arange(0.4, 12.0, wall_step)
+        wl = np.arange(-h + 0.5 * wall_step, h, wall_step)
+        a, z = np.meshgrid(wl, wz, indexing="ij")
+        walls = []
+        for sgn in (-1.0, 1.0):
+            walls.append(np.column_stack([np.full(a.size, sgn * h), a.ravel(), z.ravel()]))
+            walls.append(np.column_stack([a.ravel(), np.full(a.size, sgn * h), z.ravel()]))
+        surf = np.concatenate([ground] + walls)
+        surf = surf + rng.normal(0, noise, surf.shape) + rng.uniform(-0.25, 0.25, surf.shape) * np.array([1.0, 1.0, 0.0]) * (np.arange(len(surf)) < len(ground))[:, None]
+        pz = np.arange(0.2, 8.0, pole_dz)
+        ang = np.linspace(0, 2 * np.pi, pole_az, endpoint=False)
+        edge = []
+        for (px, py), r in zip(self.poles, self.pole_r):
+            for th in ang + rng.uniform(0, 2 * np.pi):
+                edge.append(np.column_stack([np.full(pz.size, px + r * np.cos(th)), np.full(pz.size, py + r * np.sin(th)), pz]))
+        edge = np.concatenate(edge) + rng.normal(0, noise, (len(edge) * pz.size, 3))
+        to_l = lambda P: (P - t_wl) @ R_wl                      # R^T (p - t)
+        mk = lambda P: np.ascontiguousarray(np.column_stack([to_l(P), np.ones(len(P))]).astype(np.float32))
+        return mk(edge), mk(surf)
+
+
+def make_lidar_bench_case(seed, n_poles=900, edge_keep=0.14, surf_keep=0.16, speed=8.0, dt=0.1):
+    """SURVEY.md §8(d) config 3 LiDAR stage: one 64-ring scan (≈1.2 k edge + ≈2.8 k surf queries after the 0.4 / 0.8 m voxel
+    grids) against a dense local map (≈30 k edge + ≈60 k surf points). Returns (map_edge, map_surf, scan_edge, scan_surf): the
+    map is expressed in the frame of pose 0 (where scan-to-map starts with the identity pose), the scan is taken one frame later."""
+    scene = LidarScene(seed, n_poles=n_poles)
+    R0 = euler_R(np.array(0.0), np.array(0.0), np.array(0.0)); t0 = np.array([-30.0, 0.0, scene.h])
+    yaw = 0.05 * dt * 10
+    R1 = euler_R(np.array(yaw), np.array(0.0), np.array(0.0)); t1 = np.array([-30.0 + speed * dt, 5.0 * np.sin(0.1), scene.h])
+    Rm = euler_R(np.array(-yaw), np.array(0.0), np.array(0.0)); tm = np.array([-30.0 - speed * dt, 5.0 * np.sin(-0.1), scene.h])
+    me, ms = scene.sample_map(R0, t0)
+    se, ss = scene.scan(R1, t1, edge_keep=edge_keep, surf_keep=surf_keep)
+    pose_last = np.concatenate([R_to_q(R0.T @ Rm), R0.T @ (tm - t0)])
+    return me, ms, se, ss, pose_last
+
+
 def make_lidar_sequence(seed, n_frames, speed=8.0, dt=0.1, yaw_rate=0.05, **kw):
     """returns (scans [(edge, surf)], poses [(R_wl, t_wl)]) for a vehicle driving through a LidarScene"""
     scene = LidarScene(seed, **kw)
