@@ -11,7 +11,7 @@
 //   EdgeCostFactor / SurfCostFactor (:117-232) -> one thread per query: 5-NN, PCA line fit (3x3 Jacobi) / 5x3 column-pivoted QR
 //                               plane fit, validity tests
 //   ceres::Solve (DENSE_QR, default Levenberg-Marquardt, HuberLoss(0.1), <= 4 iterations, one SE(3) block)
-//                            -> ONE persistent 1024-thread workgroup: residual + jacobian of every factor, fixed-tree reduction of
+//                            -> ONE persistent 256-thread workgroup per stream: residual + jacobian of every factor, fixed-order reduction of
 //                               the 6x6 normal equations, Cholesky, accept / reject, radius update (Ceres 2.0 LM semantics)
 //   createSubMap (:298-352)  -> transform + append, crop-box compaction (order preserving), voxel grid
 //
@@ -36,7 +36,6 @@ using namespace vd;
 // key of their stream and stay at the end of their own segment.
 struct CSet { float4 *p; int *n; int cap; };
 struct MinMax { float mn[3], mx[3]; int minb[3]; int pad_; long long mul1, mul2; };
-struct HashEntry { unsigned long long key; int start, end; };
 struct S2BRes {                       // per-stream result of one step (device)
     double pose[7], prev[7];
     double cost[2];
@@ -117,73 +116,86 @@ __global__ void b_centroids(CSet in, const unsigned long long *keys, const int *
     const float nn = (float)cnt;
     out.p[(size_t)sid * out.cap + (seg[g] - seg0)] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
 }
-// ---- radix-hashed voxel neighbour index: 1 m cells, key relative to the stream's map minimum ----
-__device__ __forceinline__ unsigned int hash30(unsigned int k) { k ^= k >> 16; k *= 0x7feb352dU; k ^= k >> 15; k *= 0x846ca68bU; k ^= k >> 16; return k; }
-__global__ void b_cell_keys(CSet map, const MinMax *mm, unsigned long long *keys, int *vals, int *cellbase, int *err, int by, int bz, int cbits) {
+// ---- radix-hashed voxel neighbour index -----------------------------------------------------------------------------------
+// A map point hashes to a bucket by the low 8 bits of its 1 m cell coordinates in x and y: bucket = (ix & 255) << 8 | (iy & 255)
+// (a 16-bit radix digit; cells 256 m apart alias, z is not part of the key). The index is a single-pass counting (radix) sort of
+// the stream's points by that digit: count -> per-stream exclusive scan -> scatter. A query scans the 3 x 3 buckets around its
+// own cell; every map point within 1 m lies in one of them (aliased far points are rejected by their true distance), so the
+// 5-NN is exact whenever the 5th squared distance is < 1 — the only case the reference uses (EstimationMapping.hpp:129,189).
+// The order inside a bucket is irrelevant: candidates are ranked by (squared distance, original map index).
+#define S2B_NB 65536
+#define S2B_NBS (S2B_NB + 4)      // row stride of start[] (keeps int4 accesses aligned)
+__device__ __forceinline__ int bucket_of(int ix, int iy) { return ((ix & 255) << 8) | (iy & 255); }    // y-minor: neighbouring points of a voxel row (x fastest) hit counters in different cache lines
+__global__ void b_bucket_count(CSet map, int *cnt, int *bkt, int *err) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= map.cap) return;
+    if (i >= map.n[sid]) return;
     const size_t g = (size_t)sid * map.cap + i;
-    const int bx0 = (int)floorf(mm[sid].mn[0]), by0 = (int)floorf(mm[sid].mn[1]), bz0 = (int)floorf(mm[sid].mn[2]);
-    if (i == 0) { cellbase[4 * sid] = bx0; cellbase[4 * sid + 1] = by0; cellbase[4 * sid + 2] = bz0; }
-    unsigned long long k = (1ULL << cbits) - 1;
-    if (i < map.n[sid]) {
-        const float4 q = map.p[g];
-        const int cx = (int)floorf(q.x) - bx0, cy = (int)floorf(q.y) - by0, cz = (int)floorf(q.z) - bz0;
-        k = ((unsigned long long)cx << (by + bz)) | ((unsigned long long)cy << bz) | (unsigned long long)cz;
-    }
-    keys[g] = ((unsigned long long)sid << cbits) | k;
-    vals[g] = i;
+    const float4 q = map.p[g];
+    const int b = bucket_of((int)floorf(q.x), (int)floorf(q.y));
+    const int rank = atomicAdd(cnt + (size_t)sid * S2B_NB + b, 1);      // arrival rank inside the bucket: the scatter needs no second atomic
+    bkt[g] = (int)(((unsigned int)b << 16) | ((unsigned int)rank & 0xffffu));
+    if (rank > 0xffff) atomicOr(err + sid, S2B_ERR_EXTENT);               // > 65535 points in one bucket: unsupported (reported, result invalid)
 }
-__global__ void b_gather_hash(CSet map, const unsigned long long *keys, const int *vals, float4 *sorted, HashEntry *table, unsigned int mask, int cbits) {
+// one workgroup per stream: exclusive scan of the 65536 bucket counts -> start[S][65536 + 1 (+3 pad)]
+__global__ __launch_bounds__(1024) void b_bucket_scan(int *cnt, int *start) {
+    __shared__ int s_w[16], s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
+    int *c = cnt + (size_t)sid * S2B_NB, *st = start + (size_t)sid * S2B_NBS;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < S2B_NB; base += 4096) {
+        int4 v = *reinterpret_cast<const int4 *>(c + base + 4 * tid);
+        const int t = v.x + v.y + v.z + v.w;
+        int incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int k = 0; k < wave; k++) woff += s_w[k];
+        const int carry = s_carry;
+        const int e0 = carry + woff + incl - t;
+        const int4 o4 = make_int4(e0, e0 + v.x, e0 + v.x + v.y, e0 + v.x + v.y + v.z);
+        *reinterpret_cast<int4 *>(st + base + 4 * tid) = o4;
+        __syncthreads();
+        if (tid == 1023) s_carry = e0 + t;
+        __syncthreads();
+    }
+    if (tid == 0) st[S2B_NB] = s_carry;
+}
+__global__ void b_bucket_scatter(CSet map, const int *start, const int *bkt, float4 *sorted) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    const int n = map.n[sid];
-    if (i >= n) return;
+    if (i >= map.n[sid]) return;
     const size_t base = (size_t)sid * map.cap, g = base + i;
-    float4 q = map.p[base + vals[g]];
-    q.w = __int_as_float(vals[g]);               // original map index (tie-break like a linear scan)
-    sorted[g] = q;
-    if (i == 0 || keys[g] != keys[g - 1]) {
-        const unsigned long long kk = keys[g];
-        int e = i + 1;
-        while (e < n && keys[base + e] == kk) e++;
-        const unsigned long long k = kk & ((1ULL << cbits) - 1);
-        HashEntry *T = table + (size_t)sid * (mask + 1);
-        unsigned int s = hash30((unsigned int)k ^ (unsigned int)(k >> 32)) & mask;
-        for (;;) {
-            const unsigned long long prev = atomicCAS(&T[s].key, ~0ULL, k);
-            if (prev == ~0ULL) { T[s].start = i; T[s].end = e; break; }
-            s = (s + 1) & mask;
-        }
-    }
+    float4 q = map.p[g];
+    q.w = __int_as_float(i);                      // original map index (tie-break like a linear scan)
+    const unsigned int br = (unsigned int)bkt[g];
+    const int pos = start[(size_t)sid * S2B_NBS + (br >> 16)] + (int)(br & 0xffffu);
+    if (pos < map.cap) sorted[base + pos] = q;
 }
-// exact 5-NN within the 27-cell block: pos[] = positions in the cell-sorted array, ordered by (squared distance, original index)
-struct CellBits { int bx, by, bz; };
-__device__ void knn5_cells(const float4 *sorted, const HashEntry *table, unsigned int mask, const int *cellbase, CellBits cb, float qx, float qy, float qz, int pos[5], float d2[5]) {
+// exact 5-NN within the 3 x 3 bucket block: pos[] = positions in the bucket-sorted array, ordered by (squared distance, original index)
+__device__ void knn5_cells(const float4 *sorted, const int *start, float qx, float qy, float qz, int pos[5], float d2[5]) {
     int oid[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) { pos[k] = -1; oid[k] = 0x7fffffff; d2[k] = 3.0e38f; }
-    const int cx = (int)floorf(qx) - cellbase[0], cy = (int)floorf(qy) - cellbase[1], cz = (int)floorf(qz) - cellbase[2];
-    for (int dz = -1; dz <= 1; dz++) for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) {
-        const int ax = cx + dx, ay = cy + dy, az = cz + dz;
-        if (ax < 0 || ay < 0 || az < 0 || ax >= (1 << cb.bx) - 1 || ay >= (1 << cb.by) - 1 || az >= (1 << cb.bz) - 1) continue;      // outside every map's extent
-        const unsigned long long k = ((unsigned long long)ax << (cb.by + cb.bz)) | ((unsigned long long)ay << cb.bz) | (unsigned long long)az;
-        unsigned int s = hash30((unsigned int)k ^ (unsigned int)(k >> 32)) & mask;
-        int st = 0, en = 0;
-        for (;;) {
-            const unsigned long long tk = table[s].key;
-            if (tk == k) { st = table[s].start; en = table[s].end; break; }
-            if (tk == ~0ULL) break;
-            s = (s + 1) & mask;
-        }
-        for (int j = st; j < en; j++) {
-            const float4 m = sorted[j];
-            const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
-            const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
-            const int oi = __float_as_int(m.w);
-            if (d < d2[4] || (d == d2[4] && oi < oid[4])) {
-                int kk = 4;
-                while (kk > 0 && (d < d2[kk - 1] || (d == d2[kk - 1] && oi < oid[kk - 1]))) { d2[kk] = d2[kk - 1]; oid[kk] = oid[kk - 1]; pos[kk] = pos[kk - 1]; kk--; }
-                d2[kk] = d; oid[kk] = oi; pos[kk] = j;
+    const int cx = (int)floorf(qx), cy = (int)floorf(qy);
+    const int yl = (cy - 1) & 255, ym = cy & 255;
+    const bool one_span = yl < ym && ym < 255;           // the three y-buckets of a column are adjacent unless the digit wraps
+    for (int dx = -1; dx <= 1; dx++) {
+        const int row = ((cx + dx) & 255) << 8;
+        for (int part = 0; part < (one_span ? 1 : 3); part++) {
+            const int b0 = one_span ? (row | yl) : (row | ((cy - 1 + part) & 255)), b1 = one_span ? b0 + 2 : b0;
+            const int st = start[b0], en = start[b1 + 1];
+            for (int j = st; j < en; j++) {
+                const float4 m = sorted[j];
+                const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
+                const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+                const int oi = __float_as_int(m.w);
+                if (d < d2[4] || (d == d2[4] && oi < oid[4])) {
+                    int kk = 4;
+                    while (kk > 0 && (d < d2[kk - 1] || (d == d2[kk - 1] && oi < oid[kk - 1]))) { d2[kk] = d2[kk - 1]; oid[kk] = oid[kk - 1]; pos[kk] = pos[kk - 1]; kk--; }
+                    d2[kk] = d; oid[kk] = oi; pos[kk] = j;
+                }
             }
         }
     }
@@ -253,13 +265,13 @@ __device__ void qr_solve_5x3(const double *Ain, const double *bin, double *x) {
 // factor record: cp[3] then edge: pa[3] pb[3] / surf: n[3] d  -> 10 doubles; kind (0 invalid, 1 edge, 2 surf) separately
 #define S2M_FREC 10
 // one thread per query point of one stream. Edge queries write records [0, n_ds_edge), surf queries [n_ds_edge, n_ds_edge + n_ds_surf).
-__global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const double *pose_all, CSet map, const float4 *sorted_all, const HashEntry *table_all,
-                            unsigned int mask, const int *cellbase_all, CellBits cb, const S2BRes *res, double *frec_all, int *fkind_all, int capq) {
+__global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const double *pose_all, CSet map, const float4 *sorted_all, const int *start_all,
+                            const S2BRes *res, double *frec_all, int *fkind_all, int capq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
     if (i >= ds.n[sid] || !res[sid].do_opt) return;
     const double *pose = pose_all + 24 * sid;
     const float4 *sorted = sorted_all + (size_t)sid * map.cap;
-    const HashEntry *table = table_all + (size_t)sid * (mask + 1);
+    const int *start = start_all + (size_t)sid * S2B_NBS;
     const int nmap = map.n[sid];
     const int slot = is_surf ? n_ds_edge[sid] + i : i;
     double *frec = frec_all + ((size_t)sid * capq + slot) * S2M_FREC;
@@ -272,7 +284,7 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
     double rec[S2M_FREC] = {cp[0], cp[1], cp[2], 0, 0, 0, 0, 0, 0, 0};
     int idx[5]; float d2[5];
     if (nmap >= 5) {
-        knn5_cells(sorted, table, mask, cellbase_all + 4 * sid, cb, qx, qy, qz, idx, d2);
+        knn5_cells(sorted, start, qx, qy, qz, idx, d2);
         if (d2[4] < 1.0f) {
             double nb[5][3];
             for (int t = 0; t < 5; t++) { const float4 m = sorted[idx[t]]; nb[t][0] = m.x; nb[t][1] = m.y; nb[t][2] = m.z; }
@@ -307,15 +319,23 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
 
 // ---- the persistent LM solve -------------------------------------------------------------------------------------------
 
-#define S2M_NT 1024
+#define S2M_NT 256
+#define S2M_NW (S2M_NT / 64)
+// block sum with a fixed order: butterfly inside each wave, then the per-wave partials in wave order (two barriers)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 __device__ double s2m_block_sum(double v, double *s_red) {
     const int tid = threadIdx.x;
+    v = wave_sum(v);
     __syncthreads();
-    s_red[tid] = v;
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
-    for (int s = S2M_NT / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-    const double r = s_red[0];
-    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int w = 0; w < S2M_NW; w++) r += s_red[w];
     return r;
 }
 // cost (and, JAC: gradient g[6], hessian H[21] lower-packed) at pose x over all valid factors
@@ -351,10 +371,15 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
             }
         }
     }
-    for (int k = JAC ? 0 : 27; k < 28; k++) { const double v = s2m_block_sum(acc[k], s_red); if (threadIdx.x == 0) s_out[k] = v; }
+    // 28 sums at once: wave butterflies, per-wave partials to LDS, thread k adds the partials of sum k in wave order
+    __syncthreads();
+#pragma unroll
+    for (int k = JAC ? 0 : 27; k < 28; k++) { const double v = wave_sum(acc[k]); if ((threadIdx.x & 63) == 0) s_red[(threadIdx.x >> 6) * 28 + k] = v; }
+    __syncthreads();
+    if (threadIdx.x < 28 && (JAC || threadIdx.x == 27)) { double r = 0; for (int w = 0; w < S2M_NW; w++) r += s_red[w * 28 + threadIdx.x]; s_out[threadIdx.x] = r; }
     __syncthreads();
 }
-// ONE persistent 1024-thread workgroup per stream; the optimised pose is written back to the stream's pose slot.
+// ONE persistent 256-thread workgroup per stream; the optimised pose is written back to the stream's pose slot.
 __global__ __launch_bounds__(S2M_NT) void b_solve(double *pose_all, const double *frec_all, const int *fkind_all, int capq, const int *n_ds_edge, const int *n_ds_surf, double huber_a, int max_it, int pass, S2BRes *res) {
     const int sid = blockIdx.x;
     if (!res[sid].do_opt) return;
@@ -363,7 +388,7 @@ __global__ __launch_bounds__(S2M_NT) void b_solve(double *pose_all, const double
     const int *fkind = fkind_all + (size_t)sid * capq;
     const int n_edge_q = n_ds_edge[sid], n_surf_q = n_ds_surf[sid];
     S2BRes *out = res + sid;
-    __shared__ double s_red[S2M_NT], s_ev[28], s_cand[28], s_x[7], s_c[7], s_scale[6], s_diag[6], s_step[6];
+    __shared__ double s_red[S2M_NW * 28], s_ev[28], s_cand[28], s_x[7], s_c[7], s_scale[6], s_diag[6], s_step[6];
     __shared__ int s_ctl[4];
     const int tid = threadIdx.x, nfac = n_edge_q + n_surf_q;
     if (tid < 7) s_x[tid] = pose_in[tid];
@@ -559,11 +584,9 @@ __global__ void b_finish(const double *pose_all, const int *n_map_e, const int *
 struct S2B {
     int S = 0;
     int capScan[2] = {0, 0}, capMap[2] = {0, 0};
-    DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], nMap[2], tmpB, nTmp, sorted[2], table[2], cellbase[2];
-    unsigned int mask[2] = {0, 0};
+    DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], nMap[2], tmpB, nTmp, sorted[2], bstart[2], bcnt;
     DBuf keys, keys2, vals, vals2, head, seg, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0;
-    CellBits cb[2] = {{1, 1, 1}, {1, 1, 1}};
     bool has_snapshot = false, scan_dirty = true;
     size_t temp_bytes = 0, work_n = 0;
     std::vector<int> h_nScan[2], h_nMap[2];
@@ -574,7 +597,7 @@ struct S2B {
     CSet cs_tmp(int w) { return CSet{tmpB.as<float4>(), nTmp.as<int>(), capMap[w]}; }
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
-                       &table[0], &table[1], &cellbase[0], &cellbase[1], &keys, &keys2, &vals, &vals2, &head, &seg, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
+                       &bstart[0], &bstart[1], &bcnt, &keys, &keys2, &vals, &vals2, &head, &seg, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
                        &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0};
         for (DBuf *b : all) b->release();
     }
@@ -605,9 +628,9 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
     if (S != c->S) {
         c->release();
         c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false;
-        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64)) return VILF_ERR_DEVICE;
+        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64) || !c->bcnt.ensure((size_t)S * S2B_NB * 4)) return VILF_ERR_DEVICE;
         for (int w = 0; w < 2; w++) {
-            if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->cellbase[w].ensure((size_t)S * 16)) return VILF_ERR_DEVICE;
+            if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->bstart[w].ensure((size_t)S * S2B_NBS * 4)) return VILF_ERR_DEVICE;
             HIPCHECK(h, hipMemsetAsync(c->nScan[w].p, 0, (size_t)S * 4, h->stream));
             HIPCHECK(h, hipMemsetAsync(c->nDs[w].p, 0, (size_t)S * 4, h->stream));
             HIPCHECK(h, hipMemsetAsync(c->nMap[w].p, 0, (size_t)S * 4, h->stream));
@@ -638,10 +661,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
             c->map[w].release();
             c->map[w] = nb;
             c->capMap[w] = nc; grew = true; c->has_snapshot = false;
-            unsigned int T = 64;
-            while (T < (unsigned int)nc + (unsigned int)nc / 2) T <<= 1;
-            c->mask[w] = T - 1;
-            if (!c->sorted[w].ensure((size_t)S * nc * 16) || !c->table[w].ensure((size_t)S * T * sizeof(HashEntry))) return VILF_ERR_DEVICE;
+            if (!c->sorted[w].ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
         }
     }
     if (grew) {
@@ -693,23 +713,10 @@ static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
 static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
     const int S = c->S;
     CSet map = c->cs_map(w);
-    const size_t n = (size_t)S * map.cap;
-    HIPCHECK(h, hipMemsetAsync(c->table[w].p, 0xff, (size_t)S * (c->mask[w] + 1) * sizeof(HashEntry), h->stream));
-    int hb[4];
-    HIPCHECK(h, hipMemsetAsync(c->bits.p, 0, 16, h->stream));
-    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, map, 1.0f, c->mm.as<MinMax>(), c->bits.as<int>());
-    HIPCHECK(h, hipMemcpyAsync(hb, c->bits.p, 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
-    c->cb[w] = CellBits{std::max(hb[1], 1), std::max(hb[2], 1), std::max(hb[3], 1)};
-    const int cbits = c->cb[w].bx + c->cb[w].by + c->cb[w].bz;
-    if (cbits + sbits_of(S) > 63) { h->err = "scan2map: local map extent too large"; return VILF_ERR_UNSUPPORTED; }
-    PROF(2)
-    hipLaunchKernelGGL(b_cell_keys, GRID2(map.cap, S), 0, h->stream, map, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->cellbase[w].as<int>(), c->err.as<int>(), c->cb[w].by, c->cb[w].bz, cbits);
-    PROF(2)
-    size_t tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, cbits + sbits_of(S), h->stream));
-    PROF(1)
-    hipLaunchKernelGGL(b_gather_hash, GRID2(map.cap, S), 0, h->stream, map, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->sorted[w].as<float4>(), c->table[w].as<HashEntry>(), c->mask[w], cbits);
+    HIPCHECK(h, hipMemsetAsync(c->bcnt.p, 0, (size_t)S * S2B_NB * 4, h->stream));
+    hipLaunchKernelGGL(b_bucket_count, GRID2(map.cap, S), 0, h->stream, map, c->bcnt.as<int>(), c->vals.as<int>(), c->err.as<int>());
+    hipLaunchKernelGGL(b_bucket_scan, dim3(S), dim3(1024), 0, h->stream, c->bcnt.as<int>(), c->bstart[w].as<int>());
+    hipLaunchKernelGGL(b_bucket_scatter, GRID2(map.cap, S), 0, h->stream, map, c->bstart[w].as<int>(), c->vals.as<int>(), c->sorted[w].as<float4>());
     PROF(2)
     return VILF_OK;
 }
@@ -737,8 +744,8 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     const int capq = c->capScan[0] + c->capScan[1];
     for (int pass = 0; pass < h->opts.s2m_outer_iterations && pass < 2; pass++) {
         for (int w = 0; w < 2; w++)
-            hipLaunchKernelGGL(b_associate, GRID2(c->capScan[w], S), 0, h->stream, c->cs_ds(w), w, c->nDs[0].as<int>(), d_pose, c->cs_map(w), c->sorted[w].as<float4>(), c->table[w].as<HashEntry>(),
-                               c->mask[w], c->cellbase[w].as<int>(), c->cb[w], d_res, c->frec.as<double>(), c->fkind.as<int>(), capq);
+            hipLaunchKernelGGL(b_associate, GRID2(c->capScan[w], S), 0, h->stream, c->cs_ds(w), w, c->nDs[0].as<int>(), d_pose, c->cs_map(w), c->sorted[w].as<float4>(), c->bstart[w].as<int>(),
+                               d_res, c->frec.as<double>(), c->fkind.as<int>(), capq);
         PROF(3)
         hipLaunchKernelGGL(b_solve, dim3(S), dim3(S2M_NT), 0, h->stream, d_pose, c->frec.as<double>(), c->fkind.as<int>(), capq, c->nDs[0].as<int>(), c->nDs[1].as<int>(), h->opts.huber_a,
                            h->opts.s2m_max_iterations, pass, d_res);
@@ -792,7 +799,7 @@ static void s2b_fill_result(const S2BRes &r, vilf_scan2map_result *res) {
 }
 static int s2b_err_to_rc(vilf_handle *h, int err) {
     if (!err) return VILF_OK;
-    h->err = std::string("scan2map: ") + ((err & S2B_ERR_MAPCAP) ? "local-map capacity exceeded; " : "") + ((err & S2B_ERR_EXTENT) ? "local map spans more than 1022 m; " : "") +
+    h->err = std::string("scan2map: ") + ((err & S2B_ERR_MAPCAP) ? "local-map capacity exceeded; " : "") + ((err & S2B_ERR_EXTENT) ? "more than 65535 local-map points in one 1 m column bucket; " : "") +
              ((err & S2B_ERR_VOXEL) ? "voxel index overflow (leaf too small for the cloud extent); " : "");
     return VILF_ERR_UNSUPPORTED;
 }
