@@ -95,83 +95,140 @@ __global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, unsigned long
     keys[g] = ((unsigned long long)sid << vbits) | k;
     vals[g] = i;
 }
-// after the sort the n[s] valid entries of stream s are the first n[s] of its segment
-__global__ void b_heads(const unsigned long long *keys, CSet in, int *head) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= in.cap) return;
-    const size_t g = (size_t)sid * in.cap + i;
-    head[g] = (i < in.n[sid] && (i == 0 || keys[g] != keys[g - 1])) ? 1 : 0;
+// Fused heads + scan + centroids: ONE workgroup per stream walks its sorted (leaf, index) pairs in tiles of 1024, ranks the run
+// heads with a block scan and lets each head thread sum its run in sorted (= input) order — same float sums as pcl::VoxelGrid.
+#define S2B_VT 1024
+__device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int &total) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    __syncthreads();
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int x = s_w[k]; if (k < wave) off += x; tot += x; }
+    total = tot;
+    return off + incl - v;
 }
-__global__ void b_centroids(CSet in, const unsigned long long *keys, const int *vals, const int *head, const int *seg, CSet out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= in.cap) return;
-    const size_t base = (size_t)sid * in.cap, g = base + i;
-    const int seg0 = seg[base];
-    if (i == in.cap - 1) out.n[sid] = seg[g] + head[g] - seg0;
-    if (!head[g]) return;
-    float cx = 0, cy = 0, cz = 0, ci = 0; int cnt = 0;
-    const unsigned long long k = keys[g];
-    const int n = in.n[sid];
-    for (int j = i; j < n && keys[base + j] == k; j++) { const float4 q = in.p[base + vals[base + j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
-    const float nn = (float)cnt;
-    out.p[(size_t)sid * out.cap + (seg[g] - seg0)] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+__global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const unsigned long long *keys_all, const int *vals_all, CSet out) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
+    const size_t base = (size_t)sid * in.cap;
+    const unsigned long long *keys = keys_all + base;
+    const int *vals = vals_all + base;
+    const float4 *p = in.p + base;
+    float4 *o = out.p + (size_t)sid * out.cap;
+    int carry = 0;
+    for (int t0 = 0; t0 < n; t0 += S2B_VT) {
+        const int i = t0 + tid;
+        unsigned long long k = 0;
+        int head = 0;
+        if (i < n) { k = keys[i]; head = (i == 0 || keys[i - 1] != k) ? 1 : 0; }
+        int total;
+        const int pos = carry + block_excl_scan_1024(head, s_w, total);
+        if (head) {
+            float cx = 0, cy = 0, cz = 0, ci = 0; int cnt = 0;
+            for (int j = i; j < n && keys[j] == k; j++) { const float4 q = p[vals[j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
+            const float nn = (float)cnt;
+            o[pos] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+        }
+        carry += total;
+    }
+    if (tid == 0) out.n[sid] = carry;
 }
+// Fused crop flags + scan + compaction (pcl::CropBox, order preserving): one workgroup per stream
+__global__ __launch_bounds__(S2B_VT) void b_crop_compact(CSet map, const double *pose_all, double half, CSet out) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, sid = blockIdx.x, n = map.n[sid];
+    const double *pose = pose_all + 24 * sid;
+    const float4 *p = map.p + (size_t)sid * map.cap;
+    float4 *o = out.p + (size_t)sid * out.cap;
+    const float mnx = (float)(pose[4] - half), mny = (float)(pose[5] - half), mnz = (float)(pose[6] - half);
+    const float mxx = (float)(pose[4] + half), mxy = (float)(pose[5] + half), mxz = (float)(pose[6] + half);
+    int carry = 0;
+    for (int t0 = 0; t0 < n; t0 += S2B_VT) {
+        const int i = t0 + tid;
+        float4 q = make_float4(0, 0, 0, 0);
+        int f = 0;
+        if (i < n) { q = p[i]; f = !(q.x < mnx || q.y < mny || q.z < mnz || q.x > mxx || q.y > mxy || q.z > mxz) ? 1 : 0; }
+        int total;
+        const int pos = carry + block_excl_scan_1024(f, s_w, total);
+        if (f) o[pos] = q;
+        carry += total;
+    }
+    if (tid == 0) out.n[sid] = carry;
+}
+
 // ---- radix-hashed voxel neighbour index -----------------------------------------------------------------------------------
 // A map point hashes to a bucket by the low 8 bits of its 1 m cell coordinates in x and y: bucket = (ix & 255) << 8 | (iy & 255)
 // (a 16-bit radix digit; cells 256 m apart alias, z is not part of the key). The index is a single-pass counting (radix) sort of
-// the stream's points by that digit: count -> per-stream exclusive scan -> scatter. A query scans the 3 x 3 buckets around its
+// the stream's points by that digit (count -> exclusive scan -> scatter), done by one workgroup per stream in LDS. A query scans the 3 x 3 buckets around its
 // own cell; every map point within 1 m lies in one of them (aliased far points are rejected by their true distance), so the
 // 5-NN is exact whenever the 5th squared distance is < 1 — the only case the reference uses (EstimationMapping.hpp:129,189).
 // The order inside a bucket is irrelevant: candidates are ranked by (squared distance, original map index).
 #define S2B_NB 65536
 #define S2B_NBS (S2B_NB + 4)      // row stride of start[] (keeps int4 accesses aligned)
 __device__ __forceinline__ int bucket_of(int ix, int iy) { return ((ix & 255) << 8) | (iy & 255); }    // y-minor: neighbouring points of a voxel row (x fastest) hit counters in different cache lines
-__global__ void b_bucket_count(CSet map, int *cnt, int *bkt, int *err) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= map.n[sid]) return;
-    const size_t g = (size_t)sid * map.cap + i;
-    const float4 q = map.p[g];
-    const int b = bucket_of((int)floorf(q.x), (int)floorf(q.y));
-    const int rank = atomicAdd(cnt + (size_t)sid * S2B_NB + b, 1);      // arrival rank inside the bucket: the scatter needs no second atomic
-    bkt[g] = (int)(((unsigned int)b << 16) | ((unsigned int)rank & 0xffffu));
-    if (rank > 0xffff) atomicOr(err + sid, S2B_ERR_EXTENT);               // > 65535 points in one bucket: unsupported (reported, result invalid)
-}
-// one workgroup per stream: exclusive scan of the 65536 bucket counts -> start[S][65536 + 1 (+3 pad)]
-__global__ __launch_bounds__(1024) void b_bucket_scan(int *cnt, int *start) {
-    __shared__ int s_w[16], s_carry;
+// ONE workgroup per stream builds the whole index: 16-bit bucket counters packed two per LDS word (128 KB), LDS atomics return
+// the arrival rank of a point inside its bucket, the workgroup scans the 65536 counts itself and scatters the points to
+// start[bucket] + rank. No global atomics, no separate scan / memset launches.
+#define S2B_IT 1024
+__global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all, int *start_all, float4 *sorted_all, int *err) {
+    extern __shared__ unsigned int s_hist[];          // [32768] two 16-bit counters per word, then [16] wave partials
+    __shared__ int s_w[S2B_IT / 64], s_total;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
-    int *c = cnt + (size_t)sid * S2B_NB, *st = start + (size_t)sid * S2B_NBS;
-    if (tid == 0) s_carry = 0;
+    const int n = map.n[sid];
+    const size_t base = (size_t)sid * map.cap;
+    const float4 *p = map.p + base;
+    int *bkt = bkt_all + base, *start = start_all + (size_t)sid * S2B_NBS;
+    float4 *sorted = sorted_all + base;
+    for (int i = tid; i < S2B_NB / 2; i += S2B_IT) s_hist[i] = 0;
     __syncthreads();
-    for (int base = 0; base < S2B_NB; base += 4096) {
-        int4 v = *reinterpret_cast<const int4 *>(c + base + 4 * tid);
-        const int t = v.x + v.y + v.z + v.w;
-        int incl = t;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wave; k++) woff += s_w[k];
-        const int carry = s_carry;
-        const int e0 = carry + woff + incl - t;
-        const int4 o4 = make_int4(e0, e0 + v.x, e0 + v.x + v.y, e0 + v.x + v.y + v.z);
-        *reinterpret_cast<int4 *>(st + base + 4 * tid) = o4;
-        __syncthreads();
-        if (tid == 1023) s_carry = e0 + t;
-        __syncthreads();
+    bool over = false;
+    for (int i = tid; i < n; i += S2B_IT) {
+        const float4 q = p[i];
+        const int b = bucket_of((int)floorf(q.x), (int)floorf(q.y));
+        const int sh = 16 * (b & 1);
+        const unsigned int old = atomicAdd(&s_hist[b >> 1], 1u << sh);
+        const unsigned int rank = (old >> sh) & 0xffffu;
+        if (rank == 0xffffu) over = true;              // the 65536th point of a bucket would carry into its neighbour
+        bkt[i] = (int)(((unsigned int)b << 16) | rank);
     }
-    if (tid == 0) st[S2B_NB] = s_carry;
-}
-__global__ void b_bucket_scatter(CSet map, const int *start, const int *bkt, float4 *sorted) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= map.n[sid]) return;
-    const size_t base = (size_t)sid * map.cap, g = base + i;
-    float4 q = map.p[g];
-    q.w = __int_as_float(i);                      // original map index (tie-break like a linear scan)
-    const unsigned int br = (unsigned int)bkt[g];
-    const int pos = start[(size_t)sid * S2B_NBS + (br >> 16)] + (int)(br & 0xffffu);
-    if (pos < map.cap) sorted[base + pos] = q;
+    if (over) atomicOr(err + sid, S2B_ERR_EXTENT);
+    __syncthreads();
+    // exclusive scan: thread t owns buckets [64 t, 64 t + 64) = words [32 t, 32 t + 32)
+    int local = 0;
+    for (int k = 0; k < 32; k++) { const unsigned int w = s_hist[32 * tid + ((k + tid) & 31)]; local += (int)(w & 0xffffu) + (int)(w >> 16); }   // rotated: no bank conflicts
+    int incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int off = incl - local;
+    for (int k = 0; k < wave; k++) off += s_w[k];
+    if (tid == S2B_IT - 1) s_total = off + local;
+    for (int k = 0; k < 32; k += 2) {
+        const unsigned int w0 = s_hist[32 * tid + k], w1 = s_hist[32 * tid + k + 1];
+        int4 o4;
+        o4.x = off; off += (int)(w0 & 0xffffu);
+        o4.y = off; off += (int)(w0 >> 16);
+        o4.z = off; off += (int)(w1 & 0xffffu);
+        o4.w = off; off += (int)(w1 >> 16);
+        *reinterpret_cast<int4 *>(start + 64 * tid + 2 * k) = o4;
+    }
+    __syncthreads();
+    if (tid == 0) start[S2B_NB] = s_total;
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < n; i += S2B_IT) {
+        float4 q = p[i];
+        q.w = __int_as_float(i);                       // original map index (tie-break like a linear scan)
+        const unsigned int br = (unsigned int)bkt[i];
+        const int pos = start[br >> 16] + (int)(br & 0xffffu);
+        if (pos < map.cap) sorted[pos] = q;
+    }
 }
 // exact 5-NN within the 3 x 3 bucket block: pos[] = positions in the bucket-sorted array, ordered by (squared distance, original index)
 __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, float qy, float qz, int pos[5], float d2[5]) {
@@ -522,28 +579,6 @@ __global__ void b_bump(CSet map, CSet ds, int S) {
     const int sid = blockIdx.x * blockDim.x + threadIdx.x;
     if (sid < S) map.n[sid] = min(map.n[sid] + ds.n[sid], map.cap);
 }
-__global__ void b_crop_flags(CSet map, const double *pose_all, double half, int *flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= map.cap) return;
-    const size_t g = (size_t)sid * map.cap + i;
-    int f = 0;
-    if (i < map.n[sid]) {
-        const double *pose = pose_all + 24 * sid;
-        const float4 q = map.p[g];
-        const float mnx = (float)(pose[4] - half), mny = (float)(pose[5] - half), mnz = (float)(pose[6] - half);
-        const float mxx = (float)(pose[4] + half), mxy = (float)(pose[5] + half), mxz = (float)(pose[6] + half);
-        f = !(q.x < mnx || q.y < mny || q.z < mnz || q.x > mxx || q.y > mxy || q.z > mxz) ? 1 : 0;
-    }
-    flag[g] = f;
-}
-__global__ void b_compact(CSet map, const int *flag, const int *pos, CSet out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= map.cap) return;
-    const size_t base = (size_t)sid * map.cap, g = base + i;
-    const int p0 = pos[base];
-    if (flag[g]) out.p[(size_t)sid * out.cap + (pos[g] - p0)] = map.p[g];
-    if (i == map.cap - 1) out.n[sid] = pos[g] + flag[g] - p0;
-}
 // globalOdom_est = globalOdom * (globalOdom_last^-1 * globalOdom) (EstimationMapping.hpp:238-243), rotation via matrices
 __global__ void b_predict(double *pose_all, int S) {
     const int sid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -585,7 +620,7 @@ struct S2B {
     int S = 0;
     int capScan[2] = {0, 0}, capMap[2] = {0, 0};
     DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], nMap[2], tmpB, nTmp, sorted[2], bstart[2], bcnt;
-    DBuf keys, keys2, vals, vals2, head, seg, temp, mm, frec, fkind, pose, res, err, bits;
+    DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0;
     bool has_snapshot = false, scan_dirty = true;
     size_t temp_bytes = 0, work_n = 0;
@@ -597,7 +632,7 @@ struct S2B {
     CSet cs_tmp(int w) { return CSet{tmpB.as<float4>(), nTmp.as<int>(), capMap[w]}; }
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
-                       &bstart[0], &bstart[1], &bcnt, &keys, &keys2, &vals, &vals2, &head, &seg, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
+                       &bstart[0], &bstart[1], &bcnt, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
                        &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0};
         for (DBuf *b : all) b->release();
     }
@@ -628,7 +663,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
     if (S != c->S) {
         c->release();
         c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false;
-        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64) || !c->bcnt.ensure((size_t)S * S2B_NB * 4)) return VILF_ERR_DEVICE;
+        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64)) return VILF_ERR_DEVICE;
         for (int w = 0; w < 2; w++) {
             if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->bstart[w].ensure((size_t)S * S2B_NBS * 4)) return VILF_ERR_DEVICE;
             HIPCHECK(h, hipMemsetAsync(c->nScan[w].p, 0, (size_t)S * 4, h->stream));
@@ -640,6 +675,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         for (int s = 0; s < S; s++) { ident[24 * s + 3] = 1.0; ident[24 * s + 11] = 1.0; ident[24 * s + 19] = 1.0; }
         HIPCHECK(h, hipMemcpyAsync(c->pose.p, ident.data(), ident.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_bucket_index), hipFuncAttributeMaxDynamicSharedMemorySize, S2B_NB * 2));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         c->h_res.assign(S, S2BRes{});
     }
@@ -671,11 +707,10 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         const size_t capq = (size_t)c->capScan[0] + c->capScan[1];
         if (!c->frec.ensure((size_t)S * capq * S2M_FREC * 8) || !c->fkind.ensure((size_t)S * capq * 4)) return VILF_ERR_DEVICE;
         if (n > c->work_n) {
-            if (!c->keys.ensure(n * 8) || !c->keys2.ensure(n * 8) || !c->vals.ensure(n * 4) || !c->vals2.ensure(n * 4) || !c->head.ensure(n * 4) || !c->seg.ensure(n * 4)) return VILF_ERR_DEVICE;
-            size_t need = 0, need2 = 0;
+            if (!c->keys.ensure(n * 8) || !c->keys2.ensure(n * 8) || !c->vals.ensure(n * 4) || !c->vals2.ensure(n * 4)) return VILF_ERR_DEVICE;
+            size_t need = 0;
             rocprim::radix_sort_pairs(nullptr, need, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, 64, h->stream);
-            rocprim::exclusive_scan(nullptr, need2, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream);
-            need = std::max(need, need2) + 256;
+            need += 256;
             if (!c->temp.ensure(need)) return VILF_ERR_DEVICE;
             c->temp_bytes = c->temp.cap;
             c->work_n = n;
@@ -702,21 +737,14 @@ static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
     size_t tb = c->temp_bytes;
     HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, vbits + sbits_of(S), h->stream));
     PROF(1)
-    hipLaunchKernelGGL(b_heads, GRID2(in.cap, S), 0, h->stream, c->keys2.as<unsigned long long>(), in, c->head.as<int>());
-    tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream));
-    hipLaunchKernelGGL(b_centroids, GRID2(in.cap, S), 0, h->stream, in, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), c->head.as<int>(), c->seg.as<int>(), out);
+    hipLaunchKernelGGL(b_voxel_reduce, dim3(S), dim3(S2B_VT), 0, h->stream, in, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), out);
     PROF(0)
     return VILF_OK;
 }
 
 static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
-    const int S = c->S;
     CSet map = c->cs_map(w);
-    HIPCHECK(h, hipMemsetAsync(c->bcnt.p, 0, (size_t)S * S2B_NB * 4, h->stream));
-    hipLaunchKernelGGL(b_bucket_count, GRID2(map.cap, S), 0, h->stream, map, c->bcnt.as<int>(), c->vals.as<int>(), c->err.as<int>());
-    hipLaunchKernelGGL(b_bucket_scan, dim3(S), dim3(1024), 0, h->stream, c->bcnt.as<int>(), c->bstart[w].as<int>());
-    hipLaunchKernelGGL(b_bucket_scatter, GRID2(map.cap, S), 0, h->stream, map, c->bstart[w].as<int>(), c->vals.as<int>(), c->sorted[w].as<float4>());
+    hipLaunchKernelGGL(b_bucket_index, dim3(c->S), dim3(S2B_IT), (size_t)S2B_NB * 2, h->stream, map, c->vals.as<int>(), c->bstart[w].as<int>(), c->sorted[w].as<float4>(), c->err.as<int>());
     PROF(2)
     return VILF_OK;
 }
@@ -753,13 +781,9 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     }
     for (int w = 0; w < 2; w++) {     // createSubMap: append registered points, crop, voxel grid
         CSet map = c->cs_map(w), dsw = c->cs_ds(w), tmp = c->cs_tmp(w);
-        const size_t n = (size_t)S * map.cap;
         hipLaunchKernelGGL(b_transform_append, GRID2(dsw.cap, S), 0, h->stream, dsw, d_pose, map, d_err);
         hipLaunchKernelGGL(b_bump, GRIDS(S), 0, h->stream, map, dsw, S);
-        hipLaunchKernelGGL(b_crop_flags, GRID2(map.cap, S), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, c->head.as<int>());
-        size_t tb = c->temp_bytes;
-        HIPCHECK(h, rocprim::exclusive_scan(c->temp.p, tb, c->head.as<int>(), c->seg.as<int>(), 0, n, rocprim::plus<int>(), h->stream));
-        hipLaunchKernelGGL(b_compact, GRID2(map.cap, S), 0, h->stream, map, c->head.as<int>(), c->seg.as<int>(), tmp);
+        hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp);
         PROF(5)
         if ((rc = s2b_voxel(h, c, tmp, leaf[w], map)) != VILF_OK) return rc;
     }
