@@ -204,3 +204,23 @@ def test_replicas_and_reruns_are_bit_identical(solver, opts):
             assert all(np.array_equal(P[i], P[i % 8]) for i in range(512)), "replicas of the same window differ"
         else:
             assert np.array_equal(P, base), f"re-run {rep} differs"
+
+
+def test_prior_factor_hook(solver, oracle, opts):
+    """MarginalizationFactor::Evaluate on the device vs the oracle: residual r0 + J0 dx (quaternion sign flip) and J0 column blocks."""
+    rng = np.random.default_rng(12)
+    win, prior, _ = synth.make_window(5, opts)
+    _, _, blocks = abi.prior_to_numpy(prior)
+    params = []
+    for b in blocks:
+        x = win.para_pose[b["id"]] if b["size"] == 7 and b["id"] < 11 else (win.para_ex_pose if b["size"] == 7 else win.para_speed_bias[b["id"] - 11])
+        x = np.array(x, dtype=np.float64)
+        if b["size"] == 7 and rng.uniform() < 0.5:
+            x[3:] = -x[3:]                      # same rotation, opposite quaternion sign: exercises the w < 0 branch
+        params.append(x)
+    sizes = [b["size"] for b in blocks]
+    r, J = solver.eval_prior(prior, params)
+    r0, J0 = oracle.eval_factor("prior", None, params, prior, sizes=sizes, nres=prior.n)
+    assert np.allclose(r, r0, rtol=1e-11, atol=1e-10 * max(1.0, np.abs(r0).max()))
+    for a, b in zip(J, J0):
+        assert np.array_equal(a, b)

@@ -742,7 +742,33 @@ static int plus_hook(vilf_handle *h, const double x[7], const double dl[6], doub
 extern "C" int vilf_pose_plus(vilf_handle *h, const double x[7], const double d[6], double xp[7]) { return plus_hook(h, x, d, xp, 0); }
 extern "C" int vilf_se3_plus(vilf_handle *h, const double x[7], const double d[6], double xp[7]) { return plus_hook(h, x, d, xp, 1); }
 
-extern "C" int vilf_eval_prior(vilf_handle *h, const vilf_prior *, const double *const *, double *, double **) {
-    if (h) h->err = "vilf_eval_prior: use vilf_window_solve with an imported prior (the prior is evaluated inside k_linearize)";
-    return VILF_ERR_UNSUPPORTED;
+extern "C" __global__ void k_hook_prior(const int *hdr, const double *x0, const double *x, const double *J0, const double *r0, double *out);
+extern "C" int vilf_eval_prior(vilf_handle *h, const vilf_prior *p, const double *const *params, double *residuals, double **jac) {
+    if (!h || !p || !params || !residuals || !p->valid || p->n < 1 || p->n > VILF_PRIOR_MAX_DIM || p->n_blocks < 1 || p->n_blocks > VILF_PRIOR_MAX_BLOCKS) return VILF_ERR_INVALID_ARGUMENT;
+    const int n = p->n, nb = p->n_blocks;
+    const size_t doubles = 32 + 2 * 24 * 9 + (size_t)n * n + 2 * (size_t)n + 16;
+    if (hook_buf(h, doubles) != VILF_OK) return VILF_ERR_DEVICE;
+    std::vector<double> in(32 + 2 * 24 * 9 + (size_t)n * n + n, 0.0);
+    int *hdr = reinterpret_cast<int *>(in.data());             // 64 ints in the first 32 doubles
+    hdr[0] = n; hdr[1] = nb;
+    for (int i = 0; i < nb; i++) {
+        hdr[2 + i] = p->block_size[i]; hdr[26 + i] = p->block_idx[i];
+        if (!params[i]) return VILF_ERR_INVALID_ARGUMENT;
+        for (int k = 0; k < p->block_size[i] && k < 9; k++) { in[32 + 9 * i + k] = p->block_x0[i][k]; in[32 + 216 + 9 * i + k] = params[i][k]; }
+    }
+    std::memcpy(&in[32 + 432], p->linearized_jacobians, sizeof(double) * n * n);
+    std::memcpy(&in[32 + 432 + (size_t)n * n], p->linearized_residuals, sizeof(double) * n);
+    double *d = h->d[D_HOOK].as<double>();
+    HIPCHECK(h, hipMemcpyAsync(d, in.data(), in.size() * 8, hipMemcpyHostToDevice, h->stream));
+    double *d_out = d + in.size();
+    hipLaunchKernelGGL(k_hook_prior, dim3(1), dim3(256), 0, h->stream, reinterpret_cast<const int *>(d), d + 32, d + 32 + 216, d + 32 + 432, d + 32 + 432 + (size_t)n * n, d_out);
+    HIPCHECK(h, hipMemcpyAsync(residuals, d_out, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (jac)                                                   // jacobians[i] = J0[:, idx : idx + local] in global size (pose: 7th column 0), :364-376
+        for (int i = 0; i < nb; i++) {
+            if (!jac[i]) continue;
+            const int gs = p->block_size[i], ls = gs == 7 ? 6 : gs, idx = p->block_idx[i];
+            for (int r = 0; r < n; r++) for (int c = 0; c < gs; c++) jac[i][(size_t)r * gs + c] = c < ls ? p->linearized_jacobians[(size_t)r * n + idx + c] : 0.0;
+        }
+    return VILF_OK;
 }

@@ -1288,6 +1288,32 @@ extern "C" __global__ void k_hook_lidar(const double *p0, const double *p1, cons
     if (threadIdx.x) return;
     lidar_between_eval<true>(p0, p1, q_load(qil), til, q_load(lc), lc + 4, out, out + 6, out + 42);
 }
+// MarginalizationFactor::Evaluate (marginalization_factor.cpp:333-381): dx per kept block (pose: dp, 2 vec(q0^-1 q) with the
+// w-sign flip), r = r0 + J0 dx. in: [n, nb][sizes 24][idx 24] as ints; x0[24][9]; x[24][9]; J0 (n x n); r0. out: r[n]
+extern "C" __global__ void k_hook_prior(const int *hdr, const double *x0, const double *x, const double *J0, const double *r0, double *out) {
+    __shared__ double s_dx[VB_PRIOR_LD];
+    const int tid = threadIdx.x, n = hdr[0], nb = hdr[1];
+    if (tid < VB_PRIOR_LD) s_dx[tid] = 0.0;
+    __syncthreads();
+    if (tid < nb) {
+        const int size = hdr[2 + tid], idx = hdr[26 + tid];
+        const double *a0 = x0 + 9 * tid, *a = x + 9 * tid;
+        if (size == 7) {
+            for (int k = 0; k < 3; k++) s_dx[idx + k] = a[k] - a0[k];
+            Q dq = q_mul(q_inv(q_load(a0 + 3)), q_load(a + 3));
+            const double sgn = (dq.w >= 0) ? 2.0 : -2.0;
+            s_dx[idx + 3] = sgn * dq.x; s_dx[idx + 4] = sgn * dq.y; s_dx[idx + 5] = sgn * dq.z;
+        } else {
+            for (int k = 0; k < size; k++) s_dx[idx + k] = a[k] - a0[k];
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += blockDim.x) {
+        double acc = r0[r];
+        for (int c = 0; c < n; c++) acc += J0[(size_t)r * n + c] * s_dx[c];
+        out[r] = acc;
+    }
+}
 extern "C" __global__ void k_hook_edge(const double *pose, const double *cp, const double *pa, const double *pb, double *out /* r[3] J[18] */) {
     if (threadIdx.x) return;
     edge_eval<true>(pose, cp, pa, pb, out, out + 3);

@@ -81,7 +81,8 @@ __global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
         }
     }
 }
-__global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, unsigned long long *keys, int *vals, int *err, int vbits) {
+template <typename KeyT>
+__global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, KeyT *keys, int *vals, int *err, int vbits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
     if (i >= in.cap) return;
     const size_t g = (size_t)sid * in.cap + i;
@@ -92,7 +93,7 @@ __global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, unsigned long
         const long long a = (long long)floorf(__fmul_rn(q.x, inv)) - m->minb[0], b = (long long)floorf(__fmul_rn(q.y, inv)) - m->minb[1], c = (long long)floorf(__fmul_rn(q.z, inv)) - m->minb[2];
         k = (unsigned long long)(a + b * m->mul1 + c * m->mul2);
     }
-    keys[g] = ((unsigned long long)sid << vbits) | k;
+    keys[g] = (KeyT)(((unsigned long long)sid << vbits) | k);
     vals[g] = i;
 }
 // Fused heads + scan + centroids: ONE workgroup per stream walks its sorted (leaf, index) pairs in tiles of 1024, ranks the run
@@ -112,18 +113,19 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int &total)
     total = tot;
     return off + incl - v;
 }
-__global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const unsigned long long *keys_all, const int *vals_all, CSet out) {
+template <typename KeyT>
+__global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const KeyT *keys_all, const int *vals_all, CSet out) {
     __shared__ int s_w[16];
     const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
     const size_t base = (size_t)sid * in.cap;
-    const unsigned long long *keys = keys_all + base;
+    const KeyT *keys = keys_all + base;
     const int *vals = vals_all + base;
     const float4 *p = in.p + base;
     float4 *o = out.p + (size_t)sid * out.cap;
     int carry = 0;
     for (int t0 = 0; t0 < n; t0 += S2B_VT) {
         const int i = t0 + tid;
-        unsigned long long k = 0;
+        KeyT k = 0;
         int head = 0;
         if (i < n) { k = keys[i]; head = (i == 0 || keys[i - 1] != k) ? 1 : 0; }
         int total;
@@ -619,10 +621,12 @@ __global__ void b_finish(const double *pose_all, const int *n_map_e, const int *
 struct S2B {
     int S = 0;
     int capScan[2] = {0, 0}, capMap[2] = {0, 0};
-    DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], nMap[2], tmpB, nTmp, sorted[2], bstart[2], bcnt;
+    DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], mapAlt[2], nMap[2], tmpB, nTmp, sorted[2], bstart[2], bcnt;   // map: current local maps; mapAlt: where the next step writes its maps
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0;
     bool has_snapshot = false, scan_dirty = true;
+    bool snap_live = false;            // the snapshot's maps still live in a map / mapAlt buffer (rewind = pointer swap, no copy)
+    void *snap_ptr[2] = {nullptr, nullptr};
     size_t temp_bytes = 0, work_n = 0;
     std::vector<int> h_nScan[2], h_nMap[2];
     std::vector<S2BRes> h_res;
@@ -630,8 +634,9 @@ struct S2B {
     CSet cs_ds(int w) { return CSet{ds[w].as<float4>(), nDs[w].as<int>(), capScan[w]}; }
     CSet cs_map(int w) { return CSet{map[w].as<float4>(), nMap[w].as<int>(), capMap[w]}; }
     CSet cs_tmp(int w) { return CSet{tmpB.as<float4>(), nTmp.as<int>(), capMap[w]}; }
+    CSet cs_mapout(int w) { return CSet{mapAlt[w].as<float4>(), nMap[w].as<int>(), capMap[w]}; }
     void release() {
-        DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
+        DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &mapAlt[0], &mapAlt[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
                        &bstart[0], &bstart[1], &bcnt, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
                        &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0};
         for (DBuf *b : all) b->release();
@@ -696,8 +701,8 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
             }
             c->map[w].release();
             c->map[w] = nb;
-            c->capMap[w] = nc; grew = true; c->has_snapshot = false;
-            if (!c->sorted[w].ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
+            c->capMap[w] = nc; grew = true; c->has_snapshot = false; c->snap_live = false;
+            if (!c->sorted[w].ensure((size_t)S * nc * 16) || !c->mapAlt[w].ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
         }
     }
     if (grew) {
@@ -732,12 +737,23 @@ static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
     const int vbits = std::max(hb[0], 1);
     if (vbits + sbits_of(S) > 63) { h->err = "scan2map: voxel index too wide (leaf size too small for the cloud extent)"; return VILF_ERR_UNSUPPORTED; }
     PROF(0)
-    hipLaunchKernelGGL(b_voxel_keys, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->keys.as<unsigned long long>(), c->vals.as<int>(), c->err.as<int>(), vbits);
-    PROF(0)
+    const int kbits = vbits + sbits_of(S);
     size_t tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, vbits + sbits_of(S), h->stream));
-    PROF(1)
-    hipLaunchKernelGGL(b_voxel_reduce, dim3(S), dim3(S2B_VT), 0, h->stream, in, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), out);
+    if (kbits <= 32) {                                 // 32-bit keys: a third less sort traffic per pass
+        unsigned int *k1 = c->keys.as<unsigned int>(), *k2 = c->keys2.as<unsigned int>();
+        hipLaunchKernelGGL(b_voxel_keys<unsigned int>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits);
+        PROF(0)
+        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), n, 0, kbits, h->stream));
+        PROF(1)
+        hipLaunchKernelGGL(b_voxel_reduce<unsigned int>, dim3(S), dim3(S2B_VT), 0, h->stream, in, k2, c->vals2.as<int>(), out);
+    } else {
+        unsigned long long *k1 = c->keys.as<unsigned long long>(), *k2 = c->keys2.as<unsigned long long>();
+        hipLaunchKernelGGL(b_voxel_keys<unsigned long long>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits);
+        PROF(0)
+        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), n, 0, kbits, h->stream));
+        PROF(1)
+        hipLaunchKernelGGL(b_voxel_reduce<unsigned long long>, dim3(S), dim3(S2B_VT), 0, h->stream, in, k2, c->vals2.as<int>(), out);
+    }
     PROF(0)
     return VILF_OK;
 }
@@ -785,8 +801,19 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         hipLaunchKernelGGL(b_bump, GRIDS(S), 0, h->stream, map, dsw, S);
         hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp);
         PROF(5)
-        if ((rc = s2b_voxel(h, c, tmp, leaf[w], map)) != VILF_OK) return rc;
+        // the new map goes to the other buffer (the old one stays intact up to its old count: a snapshot taken on it can be
+        // restored by swapping back). If that other buffer is where a live snapshot sits, save the snapshot first.
+        if (c->has_snapshot && c->snap_live && c->mapAlt[w].p == c->snap_ptr[w]) {
+            for (int v = 0; v < 2; v++) {
+                if (!c->map0[v].ensure((size_t)S * c->capMap[v] * 16)) return VILF_ERR_DEVICE;
+                void *src = (c->map[v].p == c->snap_ptr[v]) ? c->map[v].p : c->mapAlt[v].p;
+                HIPCHECK(h, hipMemcpyAsync(c->map0[v].p, src, (size_t)S * c->capMap[v] * 16, hipMemcpyDeviceToDevice, h->stream));
+            }
+            c->snap_live = false;
+        }
+        if ((rc = s2b_voxel(h, c, tmp, leaf[w], c->cs_mapout(w))) != VILF_OK) return rc;
     }
+    for (int w = 0; w < 2; w++) std::swap(c->map[w], c->mapAlt[w]);
     hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
     PROF(6)
     HIPCHECK(h, hipGetLastError());
@@ -960,25 +987,27 @@ extern "C" int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long 
 }
 extern "C" int vilf_scan2map_batch_snapshot(vilf_handle *h) {
     S2B_CHECK(h, 0)
-    for (int w = 0; w < 2; w++) {
-        if (!c->map0[w].ensure((size_t)c->S * c->capMap[w] * 16) || !c->nMap0[w].ensure((size_t)c->S * 4)) return VILF_ERR_DEVICE;
-        HIPCHECK(h, hipMemcpyAsync(c->map0[w].p, c->map[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+    for (int w = 0; w < 2; w++) {                 // the maps are not copied: a step never overwrites its input maps (see s2b_step)
+        if (!c->nMap0[w].ensure((size_t)c->S * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemcpyAsync(c->nMap0[w].p, c->nMap[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
+        c->snap_ptr[w] = c->map[w].p;
     }
     if (!c->pose0.ensure((size_t)c->S * 24 * 8)) return VILF_ERR_DEVICE;
     HIPCHECK(h, hipMemcpyAsync(c->pose0.p, c->pose.p, (size_t)c->S * 24 * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    c->has_snapshot = true;
+    c->has_snapshot = true; c->snap_live = true;
     return VILF_OK;
 }
 extern "C" int vilf_scan2map_batch_rewind(vilf_handle *h) {
     S2B_CHECK(h, 0)
     if (!c->has_snapshot) { h->err = "scan2map_batch_rewind: no snapshot"; return VILF_ERR_INVALID_ARGUMENT; }
     for (int w = 0; w < 2; w++) {
-        HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+        if (c->snap_live) { if (c->map[w].p != c->snap_ptr[w]) std::swap(c->map[w], c->mapAlt[w]); }
+        else HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->nMap0[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
     }
     HIPCHECK(h, hipMemcpyAsync(c->pose.p, c->pose0.p, (size_t)c->S * 24 * 8, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)c->S * 4, h->stream));
     return VILF_OK;
 }
 extern "C" int vilf_scan2map_batch_results(vilf_handle *h, int first, int n, vilf_scan2map_result *out) {

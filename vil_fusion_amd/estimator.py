@@ -161,6 +161,16 @@ class BackendSolver:
         self._check(self._L.vilf_eval_lidar_between(self._h, p, C.byref(c), abi.dptr(r), jp), "vilf_eval_lidar_between")
         return r, jacs
 
+    def eval_prior(self, prior, params):
+        """MarginalizationFactor::Evaluate (marginalization_factor.cpp:333-381) on the device: residuals [n], jacobians [n x size_i]"""
+        arrs, p = self._params(params)
+        sizes = [prior.block_size[i] for i in range(prior.n_blocks)]
+        r = np.zeros(prior.n)
+        jacs = [np.zeros((prior.n, s)) for s in sizes]
+        jp = (abi.c_double_p * len(sizes))(*[abi.dptr(j) for j in jacs])
+        self._check(self._L.vilf_eval_prior(self._h, C.byref(prior), p, abi.dptr(r), jp), "vilf_eval_prior")
+        return r, jacs
+
     def eval_edge(self, pose, cp, a, b):
         r = np.zeros(3); J = np.zeros((3, 7))
         f = lambda x: abi.dptr(np.ascontiguousarray(x, dtype=np.float64))
