@@ -52,6 +52,7 @@ int vilo_ypr2R(const double ypr[3], double R[9]);
 typedef struct vilo_s2m vilo_s2m;
 vilo_s2m *vilo_s2m_create(const vilf_options *o);
 void vilo_s2m_destroy(vilo_s2m *s);
+vilo_s2m *vilo_s2m_clone(const vilo_s2m *s);
 int vilo_s2m_init(vilo_s2m *s, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);
 int vilo_s2m_step(vilo_s2m *s, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf, vilf_scan2map_result *res);
 int vilo_s2m_get_map(vilo_s2m *s, int which, float *xyzi_out, int capacity, int *n_out);

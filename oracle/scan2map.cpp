@@ -157,6 +157,7 @@ struct vilo_s2m {
 
 extern "C" vilo_s2m *vilo_s2m_create(const vilf_options *o) { vilo_s2m *s = new vilo_s2m(); s->o = *o; return s; }
 extern "C" void vilo_s2m_destroy(vilo_s2m *s) { delete s; }
+extern "C" vilo_s2m *vilo_s2m_clone(const vilo_s2m *s) { return new vilo_s2m(*s); }      // copy of maps + poses (replays from a prepared state)
 extern "C" int vilo_s2m_set_pose(vilo_s2m *s, const double p[7], const double pl[7]) { std::memcpy(s->pose, p, 56); std::memcpy(s->pose_last, pl, 56); return VILF_OK; }
 
 static Cloud to_cloud(const float *xyzi, int n) { Cloud c(n); for (int i = 0; i < n; i++) c[i] = P4{xyzi[4 * i], xyzi[4 * i + 1], xyzi[4 * i + 2], xyzi[4 * i + 3]}; return c; }

@@ -96,8 +96,10 @@ def eval_factor(kind, opts, params, *consts, sizes, nres, want_jac=True):
 class OracleS2M:
     """stateful CPU mirror of EstimationMapping (oracle/scan2map.cpp)"""
 
-    def __init__(self, opts):
+    def __init__(self, opts, _handle=None):
         L = lib()
+        L.vilo_s2m_clone.restype = C.c_void_p
+        L.vilo_s2m_clone.argtypes = [C.c_void_p]
         L.vilo_s2m_create.restype = C.c_void_p
         L.vilo_s2m_create.argtypes = [C.POINTER(abi.Options)]
         L.vilo_s2m_destroy.argtypes = [C.c_void_p]
@@ -107,7 +109,12 @@ class OracleS2M:
         L.vilo_s2m_get_map.argtypes = [C.c_void_p, C.c_int, fp, C.c_int, C.POINTER(C.c_int)]
         L.vilo_s2m_set_pose.argtypes = [C.c_void_p, abi.c_double_p, abi.c_double_p]
         self.L = L
-        self.h = L.vilo_s2m_create(C.byref(opts))
+        self.opts = opts
+        self.h = _handle if _handle is not None else L.vilo_s2m_create(C.byref(opts))
+
+    def clone(self):
+        """independent copy of the maps and poses (replay from a prepared state)"""
+        return OracleS2M(self.opts, _handle=self.L.vilo_s2m_clone(self.h))
 
     def __del__(self):
         if getattr(self, "h", None):

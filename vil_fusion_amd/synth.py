@@ -445,19 +445,20 @@ class LidarScene:
         return mk(edge), mk(surf)
 
 
-def make_lidar_bench_case(seed, n_poles=900, edge_keep=0.14, surf_keep=0.16, speed=8.0, dt=0.1):
-    """SURVEY.md §8(d) config 3 LiDAR stage: one 64-ring scan (≈1.2 k edge + ≈2.8 k surf queries after the 0.4 / 0.8 m voxel
-    grids) against a dense local map (≈30 k edge + ≈60 k surf points). Returns (map_edge, map_surf, scan_edge, scan_surf): the
-    map is expressed in the frame of pose 0 (where scan-to-map starts with the identity pose), the scan is taken one frame later."""
+def make_lidar_bench_case(seed, n_poles=1500, edge_keep=0.11, surf_keep=0.25, speed=8.0, dt=0.1):
+    """SURVEY.md §8(d) config 3 LiDAR stage. Returns (map_edge, map_surf, scans, pose_last_qt):
+      * map_*: a dense raw local map in the frame of pose 0 (where scan-to-map starts with the identity pose) — localMapInited input;
+      * scans[0]: the 64-ring scan one frame later — the WARM-UP step that turns the raw map into the steady-state voxelised local
+        map (≈ 30 k edge + ≈ 60 k surf points, ascending leaf order) and gives the constant-velocity model its two poses;
+      * scans[1]: the scan of the frame after that — the measured step (≈ 1.2 k edge + ≈ 2.8 k surf queries after the 0.4 / 0.8 m grids);
+      * pose_last_qt: the pose one frame before pose 0 [qx qy qz qw tx ty tz] (globalOdom_last of the first prediction)."""
     scene = LidarScene(seed, n_poles=n_poles)
-    R0 = euler_R(np.array(0.0), np.array(0.0), np.array(0.0)); t0 = np.array([-30.0, 0.0, scene.h])
-    yaw = 0.05 * dt * 10
-    R1 = euler_R(np.array(yaw), np.array(0.0), np.array(0.0)); t1 = np.array([-30.0 + speed * dt, 5.0 * np.sin(0.1), scene.h])
-    Rm = euler_R(np.array(-yaw), np.array(0.0), np.array(0.0)); tm = np.array([-30.0 - speed * dt, 5.0 * np.sin(-0.1), scene.h])
-    me, ms = scene.sample_map(R0, t0)
-    se, ss = scene.scan(R1, t1, edge_keep=edge_keep, surf_keep=surf_keep)
+    pose = lambda k: (euler_R(np.array(0.05 * k * dt * 10), np.array(0.0), np.array(0.0)), np.array([-30.0 + speed * dt * k, 5.0 * np.sin(0.1 * k), scene.h]))
+    (R0, t0), (Rm, tm) = pose(0), pose(-1)
+    me, ms = scene.sample_map(R0, t0, ground_step=0.55, pole_dz=0.2)
+    scans = [scene.scan(*pose(k), edge_keep=edge_keep, surf_keep=surf_keep) for k in (1, 2)]
     pose_last = np.concatenate([R_to_q(R0.T @ Rm), R0.T @ (tm - t0)])
-    return me, ms, se, ss, pose_last
+    return me, ms, scans, pose_last
 
 
 def make_lidar_sequence(seed, n_frames, speed=8.0, dt=0.1, yaw_rate=0.05, **kw):
