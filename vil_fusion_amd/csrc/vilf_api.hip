@@ -384,7 +384,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         h->batch.lut_imu = h->d[D_LUTI].as<int>(); h->batch.lut_lid = h->d[D_LUTL].as<int>(); h->batch.lut_vis = h->d[D_LUTV].as<int>();
     }
     const int nimu = B * 10;
-    hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
+    hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
     HIPCHECK(h, hipGetLastError());
     int rc = upload_priors(h);
     if (rc != VILF_OK) return rc;

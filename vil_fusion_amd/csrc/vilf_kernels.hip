@@ -64,46 +64,45 @@ __device__ __forceinline__ double block_max(double v, double *s_red) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // one-off preparation
-// cov: [n][225] in, out: rec + IMU_SQRT of each factor. One thread per factor (tiny, one-off per upload).
-extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec) {
-    int id = blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n) return;
-    const double *C = cov + (size_t)id * 225;
-    double *A = work + (size_t)id * 450;   // LU copy
-    double *Inv = A + 225;
-    for (int i = 0; i < 225; i++) { A[i] = C[i]; Inv[i] = 0; }
-    for (int i = 0; i < 15; i++) Inv[16 * i] = 1.0;
-    // inverse by Gaussian elimination with partial pivoting (Eigen PartialPivLU semantics)
+// cov: [n][225] in, out: rec + IMU_SQRT of each factor: sqrt_info = LLT(cov^-1).L^T (imu_factor.h:64), once per upload.
+// 16 lanes per factor (lane = matrix row, 4 factors per 64-thread block), matrices in LDS; every element sees the same sequence
+// of operations as the row-serial algorithm (Gauss-Jordan with partial pivoting = Eigen PartialPivLU inverse, left-looking LLT).
+extern "C" __global__ __launch_bounds__(64) void k_imu_prep(int n, const double *cov, double *work, double *imu_rec) {
+    __shared__ double sA[4][15][16], sI[4][15][16], s_piv[4];
+    const int grp = threadIdx.x >> 4, r = threadIdx.x & 15, id = blockIdx.x * 4 + grp;
+    const bool row = id < n && r < 15;
+    (void)work;
+    if (row) for (int j = 0; j < 15; j++) { sA[grp][r][j] = cov[(size_t)id * 225 + 15 * r + j]; sI[grp][r][j] = (j == r) ? 1.0 : 0.0; }
+    __syncthreads();
     for (int k = 0; k < 15; k++) {
-        int p = k; double best = fabs(A[15 * k + k]);
-        for (int i = k + 1; i < 15; i++) { double v = fabs(A[15 * i + k]); if (v > best) { best = v; p = i; } }
-        if (p != k) for (int j = 0; j < 15; j++) { double t = A[15 * k + j]; A[15 * k + j] = A[15 * p + j]; A[15 * p + j] = t; t = Inv[15 * k + j]; Inv[15 * k + j] = Inv[15 * p + j]; Inv[15 * p + j] = t; }
-        double piv = A[15 * k + k];
-        for (int i = k + 1; i < 15; i++) {
-            double f = A[15 * i + k] / piv;
-            for (int j = k; j < 15; j++) A[15 * i + j] -= f * A[15 * k + j];
-            for (int j = 0; j < 15; j++) Inv[15 * i + j] -= f * Inv[15 * k + j];
+        if (id < n && r == 0) {                       // partial pivoting: first row with the largest |A[i][k]|, i >= k
+            int p = k; double best = fabs(sA[grp][k][k]);
+            for (int i = k + 1; i < 15; i++) { const double v = fabs(sA[grp][i][k]); if (v > best) { best = v; p = i; } }
+            if (p != k) for (int j = 0; j < 15; j++) { double t = sA[grp][k][j]; sA[grp][k][j] = sA[grp][p][j]; sA[grp][p][j] = t; t = sI[grp][k][j]; sI[grp][k][j] = sI[grp][p][j]; sI[grp][p][j] = t; }
+            s_piv[grp] = sA[grp][k][k];
         }
+        __syncthreads();
+        if (row && r > k) {
+            const double f = sA[grp][r][k] / s_piv[grp];
+            for (int j = k; j < 15; j++) sA[grp][r][j] -= f * sA[grp][k][j];
+            for (int j = 0; j < 15; j++) sI[grp][r][j] -= f * sI[grp][k][j];
+        }
+        __syncthreads();
     }
     for (int k = 14; k >= 0; k--) {
-        double piv = A[15 * k + k];
-        for (int j = 0; j < 15; j++) Inv[15 * k + j] /= piv;
-        for (int i = 0; i < k; i++) { double f = A[15 * i + k]; for (int j = 0; j < 15; j++) Inv[15 * i + j] -= f * Inv[15 * k + j]; }
+        if (row && r == k) { const double piv = sA[grp][k][k]; for (int j = 0; j < 15; j++) sI[grp][k][j] /= piv; }
+        __syncthreads();
+        if (row && r < k) { const double f = sA[grp][r][k]; for (int j = 0; j < 15; j++) sI[grp][r][j] -= f * sI[grp][k][j]; }
+        __syncthreads();
     }
-    // lower Cholesky of Inv (in place), sqrt_info = L^T
+    // lower Cholesky of the inverse (in place), sqrt_info = L^T
     for (int j = 0; j < 15; j++) {
-        double s = Inv[16 * j];
-        for (int k = 0; k < j; k++) s -= Inv[15 * j + k] * Inv[15 * j + k];
-        double l = sqrt(s);
-        Inv[16 * j] = l;
-        for (int i = j + 1; i < 15; i++) {
-            double t = Inv[15 * i + j];
-            for (int k = 0; k < j; k++) t -= Inv[15 * i + k] * Inv[15 * j + k];
-            Inv[15 * i + j] = t / l;
-        }
+        if (row && r == j) { double sacc = sI[grp][j][j]; for (int k = 0; k < j; k++) sacc -= sI[grp][j][k] * sI[grp][j][k]; sI[grp][j][j] = sqrt(sacc); }
+        __syncthreads();
+        if (row && r > j) { double t = sI[grp][r][j]; for (int k = 0; k < j; k++) t -= sI[grp][r][k] * sI[grp][j][k]; sI[grp][r][j] = t / sI[grp][j][j]; }
+        __syncthreads();
     }
-    double *S = imu_rec + (size_t)id * IMU_REC + IMU_SQRT;
-    for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) S[15 * i + j] = (j >= i) ? Inv[15 * j + i] : 0.0;
+    if (row) { double *S = imu_rec + (size_t)id * IMU_REC + IMU_SQRT; for (int j = 0; j < 15; j++) S[15 * r + j] = (j >= r) ? sI[grp][j][r] : 0.0; }
 }
 
 extern "C" __global__ __launch_bounds__(NT) void k_prior_prep(VbBatch b, double *prior_H, double *prior_g) {

@@ -18,6 +18,7 @@
 
 using namespace vd;
 #define NT VB_NT
+#define VILF_MAX_FEATURES_DEV 1000
 __device__ __forceinline__ int pair_index_c(int i, int j) { return j * (j - 1) / 2 + i; }  // i < j
 
 __device__ __forceinline__ void rr_pair(int round, int k, int M, int &p, int &q) {   // round-robin tournament pairing
@@ -377,6 +378,79 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
     double *A = (M <= MG_MLDS) ? s_dyn : g.Amm + (size_t)w * g.Mcap * g.Mcap;
     const int XL = n + 1;
     double *Xg = g.X + (size_t)w * g.Mcap * (MG_NK + 1);
+    // ---- arrow fast path -------------------------------------------------------------------------------------------------
+    // Amm = [[Hdd, Wd^T], [Wd, D]] with D = diag(h_f): when Amm is positive definite with every eigenvalue above the reference's
+    // threshold (1e-8, marginalization_factor.cpp:270) the pseudo-inverse IS the inverse and X^T Amm^-1 X follows from eliminating
+    // the diagonal D and a Cholesky of the md x md Schur complement S — no eigen-decomposition of the (md + mf)-dimensional block.
+    // Guard: D > 0, S > 0 (Cholesky pivots) and trace(Amm^-1) < 1e8 (the trace bounds the largest eigenvalue of the inverse, i.e.
+    // lambda_min(Amm) > 1e-8: nothing would be truncated). Otherwise fall through to the Jacobi path below.
+    {
+        double *s_S = s_dyn, *s_Y = s_S + MG_MD * MG_MD, *s_ih = s_Y + MG_MD * (MG_NK + 1), *s_red = s_ih + VILF_MAX_FEATURES_DEV;   // [md][md], [md][XL], [mf], [NT]
+        __shared__ int s_ok;
+        if (tid == 0) s_ok = (md > 0 && md <= MG_MD && mf <= VILF_MAX_FEATURES_DEV) ? 1 : 0;
+        __syncthreads();
+        for (int f = tid; f < mf; f += NT) { const double h = hfm[f]; if (!(h > 0.0)) s_ok = 0; s_ih[f] = 1.0 / h; }
+        __syncthreads();
+        if (s_ok) {
+            for (int e = tid; e < md * md; e += NT) {
+                const int i = e / md, j = e - md * i;
+                double v = 0.5 * (Hd[i * MG_ND + j] + Hd[j * MG_ND + i]);
+                for (int f = 0; f < mf; f++) v -= Wf[(size_t)f * MG_ND + i] * Wf[(size_t)f * MG_ND + j] * s_ih[f];
+                s_S[e] = v;
+            }
+            for (int e = tid; e < md * XL; e += NT) {
+                const int i = e / XL, k = e - XL * i;
+                double v = (k < n) ? Hd[i * MG_ND + md + k] : gd[i];
+                for (int f = 0; f < mf; f++) v -= Wf[(size_t)f * MG_ND + i] * ((k < n) ? Wf[(size_t)f * MG_ND + md + k] : gfm[f]) * s_ih[f];
+                s_Y[e] = v;
+            }
+            __syncthreads();
+            for (int j = 0; j < md; j++) {                      // in-place lower Cholesky of S (md <= 21)
+                if (tid == 0) { const double d = s_S[j * md + j]; if (!(d > 0.0)) s_ok = 0; s_S[j * md + j] = sqrt(d > 0.0 ? d : 1.0); }
+                __syncthreads();
+                if (tid > j && tid < md) s_S[tid * md + j] /= s_S[j * md + j];
+                __syncthreads();
+                for (int e = tid; e < md * md; e += NT) { const int r = e / md, c = e - md * r; if (c > j && r >= c) s_S[e] -= s_S[r * md + j] * s_S[c * md + j]; }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (s_ok) {
+            // Z = L^-1 Y (one column per thread), trace(Amm^-1) = |L^-1|_F^2 + sum_f (1/h_f + |L^-1 w_f|^2 / h_f^2)
+            for (int k = tid; k < XL; k += NT)
+                for (int i = 0; i < md; i++) { double v = s_Y[i * XL + k]; for (int t = 0; t < i; t++) v -= s_S[i * md + t] * s_Y[t * XL + k]; s_Y[i * XL + k] = v / s_S[i * md + i]; }
+            double tr = 0;
+            for (int c = tid; c < md + mf; c += NT) {
+                double z[MG_MD];
+                double sq = 0;
+                for (int i = 0; i < md; i++) {
+                    double v = (c < md) ? (i == c ? 1.0 : 0.0) : Wf[(size_t)(c - md) * MG_ND + i];
+                    for (int t = 0; t < i; t++) v -= s_S[i * md + t] * z[t];
+                    z[i] = v / s_S[i * md + i];
+                    sq += z[i] * z[i];
+                }
+                tr += (c < md) ? sq : s_ih[c - md] + sq * s_ih[c - md] * s_ih[c - md];
+            }
+            s_red[tid] = tr;
+            __syncthreads();
+            for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) s_red[tid] += s_red[tid + st]; __syncthreads(); }
+            if (tid == 0 && !(s_red[0] < 1e8)) s_ok = 0;
+            __syncthreads();
+        }
+        if (s_ok) {
+            double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
+            for (int e = tid; e < n * XL; e += NT) {
+                const int i = e / XL, j = e - XL * i;
+                double sacc = 0;
+                for (int f = 0; f < mf; f++) sacc += Wf[(size_t)f * MG_ND + md + i] * ((j < n) ? Wf[(size_t)f * MG_ND + md + j] : gfm[f]) * s_ih[f];
+                for (int t = 0; t < md; t++) sacc += s_Y[t * XL + i] * s_Y[t * XL + j];
+                if (j < n) Ar[i * MG_NK + j] = Hd[(md + i) * MG_ND + md + j] - sacc;
+                else br[i] = gd[md + i] - sacc;
+            }
+            return;
+        }
+        __syncthreads();
+    }
     // Amm = 0.5 (Amm + Amm^T) (marginalization_factor.cpp:267), arrow structure: dense md x md block, feature diagonal
     for (int e = tid; e < M * M; e += NT) {
         const int i = e / M, j = e - M * i;
