@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic windows (tiled to --windows)")
     ap.add_argument("--distinct-lidar", type=int, default=4, help="distinct synthetic LiDAR scenes (tiled to --windows)")
     ap.add_argument("--no-lidar-stage", action="store_true", help="configs[1]-style run: back-end window solve only")
+    ap.add_argument("--no-marginalize", action="store_true", help="leave lines 863-1046 of Estimator::optimization() (marginalization) out of the frame")
     ap.add_argument("--overlap", action="store_true", help="run the LiDAR stage on its own handle / HIP stream / host thread, concurrently with the "
                     "window solve (like the reference's separate nodes); ~7 %% more frames/s, but per-kernel timings then include contention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,8 +160,10 @@ def main():
             th.start()
         elif s2m is not None:
             lidar_stage()                               # same handle, same HIP stream: LiDAR stage, then the window solve
-        solver.batch_rewind()
+        solver.batch_rewind()                           # state AND priors back to the uploaded snapshot
         solver.batch_solve(sync=True)
+        if not args.no_marginalize:
+            solver.batch_marginalize(sync=True)         # estimator.cpp:863-1046: the new priors stay on the device
         if th is not None:
             th.join()
         if world > 1:
@@ -186,6 +189,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = solver.get_profile()
+    if not args.no_marginalize:
+        prof.update(solver.get_profile_marginalize())
     lid = None
     if s2m is not None:
         prof.update(lidar_handle.get_profile_scan2map())
@@ -210,6 +215,9 @@ def main():
         lps = {k: v["launches"] / args.steps for k, v in prof.items()}
         part = lambda what: float(np.mean([algorithmic_bytes_per_iteration(w, p, what) for w, p in zip(wins[:args.distinct], priors[:args.distinct])]))
         alg = {"k_linearize": abytes * B * lps["k_linearize"], "k_solve": part("reduced") * B * lps["k_solve"], "k_step": part("inputs") * B * lps["k_step"]}
+        if not args.no_marginalize:           # per frame: re-evaluate the dropped factors once, n_p^2 prior in, n x n prior out
+            mbytes = part("inputs") + 8.0 * 75 * 76
+            alg.update({"k_marg_prepare": part("inputs") * B, "k_marg_schur": 8.0 * (96 * 97 + 117 * 118) * B, "k_marg_finish": 8.0 * 75 * 76 * 2 * B, "k_prior_prep": 8.0 * 75 * 76 * 2 * B})
         if lid is not None:
             nm, ns, nq = lid["map_points"], lid["scan_points"], lid["queries"]
             alg.update({

@@ -108,7 +108,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + 512 + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
     h->lin_lds = (size_t)(2 * VB_CHUNK * VB_XLD + VB_NPAIR * VB_PAIRD) * sizeof(double);
     h->marg_lds_schur = (size_t)MG_MLDS * MG_MLDS * sizeof(double);
-    h->marg_lds_finish = (size_t)2 * (MG_NK + 2) * (MG_NK + 2) * sizeof(double);
+    h->marg_lds_finish = (size_t)(MG_NK + 2) * (MG_NK + 2) * sizeof(double);
     if (hipFuncSetAttribute((const void *)k_marg_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_schur) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
@@ -171,6 +171,7 @@ static int pull_device_priors(vilf_handle *h) {
 
 static int upload_priors(vilf_handle *h) {
     { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
+    h->prior_backup_valid = false;
     const int B = h->B;
     std::vector<int> hdr((size_t)B * VB_PRIOR_HDR, 0);
     std::vector<double> x0((size_t)B * 24 * 9, 0.0), J((size_t)B * VB_PRIOR_LD * VB_PRIOR_LD, 0.0), r((size_t)B * VB_PRIOR_LD, 0.0);
@@ -405,6 +406,15 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_reset, dim3(h->B), dim3(VB_NT), 0, h->stream, h->batch, 1);
     HIPCHECK(h, hipGetLastError());
+    bool newer = false;
+    for (int w = 0; w < h->B; w++) if (h->prior_dev_newer[w]) newer = true;
+    if (newer && h->prior_backup_valid) {          // a marginalization replaced the priors: restore them as uploaded
+        const size_t sB = h->B;
+        const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
+        const size_t bytes[6] = {sB * VB_PRIOR_HDR * 4, sB * 24 * 9 * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8};
+        for (int k = 0; k < 6; k++) HIPCHECK(h, hipMemcpyAsync(h->d[live[k]].p, h->d[bak[k]].p, bytes[k], hipMemcpyDeviceToDevice, h->stream));
+        for (int w = 0; w < h->B; w++) h->prior_dev_newer[w] = 0;
+    }
     return VILF_OK;
 }
 
@@ -455,11 +465,18 @@ extern "C" int vilf_set_profiling(vilf_handle *h, int on) {
     h->profiling = on;
     for (int i = 0; i < 4; i++) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
     for (int i = 0; i < 8; i++) { h->s2m_ms[i] = 0; h->s2m_launches[i] = 0; }
+    for (int i = 0; i < 4; i++) { h->marg_ms[i] = 0; h->marg_launches[i] = 0; }
     return VILF_OK;
 }
 extern "C" int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]) {
     if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
     for (int i = 0; i < 4; i++) { ms_out[i] = h->kernel_ms[i]; launches_out[i] = h->kernel_launches[i]; }
+    return VILF_OK;
+}
+
+extern "C" int vilf_get_profile_marginalize(vilf_handle *h, double ms_out[4], long launches_out[4]) {
+    if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 4; i++) { ms_out[i] = h->marg_ms[i]; launches_out[i] = h->marg_launches[i]; }
     return VILF_OK;
 }
 
@@ -569,12 +586,32 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     g.hfm = h->d[D_MHF].as<double>(); g.gfm = h->d[D_MGF].as<double>(); g.Amm = h->d[D_MAMM].as<double>(); g.X = h->d[D_MX].as<double>();
     g.rot = h->d[D_MROT].as<double>(); g.lam = h->d[D_MLAM].as<double>(); g.Ar = h->d[D_MAR].as<double>(); g.br = h->d[D_MBR].as<double>();
     g.prior_hdr_out = h->d[D_PHDR].as<int>(); g.prior_x0_out = h->d[D_PX0].as<double>(); g.prior_J_out = h->d[D_PJ].as<double>(); g.prior_r_out = h->d[D_PR].as<double>();
+    if (!h->prior_backup_valid) {      // keep the priors as uploaded: vilf_batch_rewind re-arms them after this call overwrites them
+        const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
+        const size_t bytes[6] = {sB * VB_PRIOR_HDR * 4, sB * 24 * 9 * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8};
+        for (int k = 0; k < 6; k++) {
+            if (!h->d[bak[k]].ensure(bytes[k])) { h->err = "hipMalloc failed (prior backup)"; return VILF_ERR_DEVICE; }
+            HIPCHECK(h, hipMemcpyAsync(h->d[bak[k]].p, h->d[live[k]].p, bytes[k], hipMemcpyDeviceToDevice, h->stream));
+        }
+        h->prior_backup_valid = true;
+    }
     const dim3 grid(h->B), block(VB_NT);
+    const bool prof = h->profiling != 0 && sync;
+    if (prof) while (h->pev.size() < 5) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
+    if (prof) hipEventRecord(h->pev[0], h->stream);
     hipLaunchKernelGGL(k_marg_prepare, grid, block, 0, h->stream, h->batch, g);
+    if (prof) hipEventRecord(h->pev[1], h->stream);
     hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g);
+    if (prof) hipEventRecord(h->pev[2], h->stream);
     hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g);
+    if (prof) hipEventRecord(h->pev[3], h->stream);
     hipLaunchKernelGGL(k_prior_prep, grid, block, 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
+    if (prof) hipEventRecord(h->pev[4], h->stream);
     HIPCHECK(h, hipGetLastError());
+    if (prof) {
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        for (int k = 0; k < 4; k++) { float t = 0; hipEventElapsedTime(&t, h->pev[k], h->pev[k + 1]); h->marg_ms[k] += t; h->marg_launches[k] += 1; }
+    }
     for (int w = 0; w < h->B; w++) { h->prior_dev_newer[w] = 1; h->prior_dirty[w] = 0; }
     if (sync) {
         std::vector<int> info(sB * MG_INFO);

@@ -27,7 +27,9 @@ enum {
     D_FSTART, D_FNOBS, D_FOBS0, D_FFAC0, D_FCONST, D_OBS, D_PSFEAT, D_PSOBS, D_PSSLOT, D_PAIROFF, D_IMU, D_LIDAR,
     D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_FACW, D_HPP, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G, D_DIAGH,
     D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV,
-    D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR, D_COUNT
+    D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR,
+    D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0,      // priors as uploaded (restored by vilf_batch_rewind after a marginalization)
+    D_COUNT
 };
 
 struct S2B;
@@ -46,6 +48,7 @@ struct vilf_handle {
     std::vector<char> prior_dirty;
     std::vector<char> prior_dev_newer;       // slot's prior was produced on the device (marginalize) and not yet mirrored
     std::vector<int> h_mflag;
+    bool prior_backup_valid = false;         // D_P*0 hold the priors as last uploaded
     int mg_Mcap = 0;
     VbMarg marg;
     size_t marg_lds_schur = 0, marg_lds_finish = 0;
@@ -58,6 +61,8 @@ struct vilf_handle {
     long kernel_launches[4] = {0, 0, 0, 0};
     std::vector<hipEvent_t> s2m_ev;         // scan-to-map profiling (same switch): group of launches -> ms
     std::vector<int> s2m_groups;
+    double marg_ms[4] = {0, 0, 0, 0};        // k_marg_prepare, k_marg_schur, k_marg_finish, k_prior_prep
+    long marg_launches[4] = {0, 0, 0, 0};
     double s2m_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long s2m_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double last_solve_usec = 0;

@@ -505,25 +505,169 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
     (void)mf;
 }
 
+// Symmetric eigen-decomposition of the n x n matrix held in V (LDS, row-major, leading dimension ld) by Householder
+// tridiagonalisation + implicit QL — the EISPACK tred2 / tql2 pair the CPU restatement uses (oracle/omath.cpp sym_eigen), restated
+// for one workgroup: the O(n^2) inner loops of every step run across the threads with the SAME per-element operation order
+// (ascending-k dot products), the three length-i reductions of a tred2 step by wave 0, the scalar QL recurrence by thread 0 and
+// the rotations of one QL iteration applied to all rows of V in parallel. On exit V(:, j) is eigenvector j of eigenvalue d[j]
+// (unsorted). d, e: LDS arrays of n doubles; s_cs: 2 n doubles; s_sc: 4 doubles; s_ctl: 2 ints.
+__device__ __forceinline__ double mg_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, double *s_cs, double *s_sc, int *s_ctl) {
+    const int tid = threadIdx.x;
+#define VV(r, c) V[(r) * ld + (c)]
+    if (tid < n) d[tid] = VV(n - 1, tid);
+    __syncthreads();
+    for (int i = n - 1; i > 0; i--) {
+        if (tid < 64) { double a = 0; for (int k = tid; k < i; k += 64) a += fabs(d[k]); a = mg_wave_sum(a); if (tid == 0) s_sc[0] = a; }
+        __syncthreads();
+        const double scale = s_sc[0];
+        if (scale == 0.0) {
+            if (tid == 0) e[i] = d[i - 1];
+            __syncthreads();
+            if (tid < i) { d[tid] = VV(i - 1, tid); VV(i, tid) = 0.0; VV(tid, i) = 0.0; }
+            if (tid == 0) d[i] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        if (tid < i) d[tid] /= scale;
+        __syncthreads();
+        if (tid < 64) {
+            double a = 0; for (int k = tid; k < i; k += 64) a += d[k] * d[k];
+            a = mg_wave_sum(a);
+            if (tid == 0) { double h = a; const double f = d[i - 1]; double gq = sqrt(h); if (f > 0) gq = -gq; e[i] = scale * gq; h = h - f * gq; d[i - 1] = f - gq; s_sc[1] = h; }
+        }
+        __syncthreads();
+        const double h = s_sc[1];
+        if (tid < i) {                       // e = A_sub d with the symmetric matrix read from its lower triangle; V(:, i) keeps the reflector
+            const int j = tid;
+            double gq = 0;
+            for (int k = 0; k <= j; k++) gq += VV(j, k) * d[k];
+            for (int k = j + 1; k < i; k++) gq += VV(k, j) * d[k];
+            e[j] = gq / h;
+            VV(j, i) = d[j];
+        }
+        __syncthreads();
+        if (tid < 64) { double a = 0; for (int k = tid; k < i; k += 64) a += e[k] * d[k]; a = mg_wave_sum(a); if (tid == 0) s_sc[2] = a / (h + h); }
+        __syncthreads();
+        const double hh = s_sc[2];
+        if (tid < i) e[tid] -= hh * d[tid];
+        __syncthreads();
+        for (int t = tid; t < i * i; t += NT) { const int k = t / i, j = t - k * i; if (j <= k) VV(k, j) -= (d[j] * e[k] + e[j] * d[k]); }
+        __syncthreads();
+        if (tid < i) { d[tid] = VV(i - 1, tid); VV(i, tid) = 0.0; }
+        if (tid == 0) d[i] = h;
+        __syncthreads();
+    }
+    for (int i = 0; i < n - 1; i++) {        // accumulate the transformations
+        if (tid == 0) { VV(n - 1, i) = VV(i, i); VV(i, i) = 1.0; }
+        const double h = d[i + 1];
+        __syncthreads();
+        if (h != 0.0) {
+            if (tid <= i) d[tid] = VV(tid, i + 1) / h;
+            __syncthreads();
+            if (tid <= i) {
+                const int j = tid;
+                double gq = 0;
+                for (int k = 0; k <= i; k++) gq += VV(k, i + 1) * VV(k, j);
+                for (int k = 0; k <= i; k++) VV(k, j) -= gq * d[k];
+            }
+            __syncthreads();
+        }
+        if (tid <= i) VV(tid, i + 1) = 0.0;
+        __syncthreads();
+    }
+    if (tid < n) { d[tid] = VV(n - 1, tid); VV(n - 1, tid) = 0.0; }
+    __syncthreads();
+    if (tid == 0) { VV(n - 1, n - 1) = 1.0; for (int i = 1; i < n; i++) e[i - 1] = e[i]; e[n - 1] = 0.0; }
+    __syncthreads();
+    double f = 0.0, tst1 = 0.0;              // live in thread 0 only
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; l++) {
+        if (tid == 0) {
+            tst1 = fmax(tst1, fabs(d[l]) + fabs(e[l]));
+            int m = l;
+            while (m < n) { if (fabs(e[m]) <= eps * tst1) break; m++; }
+            s_ctl[0] = m;
+        }
+        __syncthreads();
+        const int m = s_ctl[0];
+        if (m > l) {
+            int iter = 0;
+            for (;;) {
+                if (tid == 0) {
+                    iter++;
+                    double gq = d[l];
+                    double p = (d[l + 1] - gq) / (2.0 * e[l]);
+                    double r = hypot(p, 1.0);
+                    if (p < 0) r = -r;
+                    d[l] = e[l] / (p + r);
+                    d[l + 1] = e[l] * (p + r);
+                    const double dl1 = d[l + 1];
+                    double hq = gq - d[l];
+                    for (int i = l + 2; i < n; i++) d[i] -= hq;
+                    f += hq;
+                    p = d[m];
+                    double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                    const double el1 = e[l + 1];
+                    for (int i = m - 1; i >= l; i--) {
+                        c3 = c2; c2 = c; s2 = s;
+                        gq = c * e[i];
+                        hq = c * p;
+                        r = hypot(p, e[i]);
+                        e[i + 1] = s * r;
+                        s = e[i] / r;
+                        c = p / r;
+                        p = c * d[i] - s * gq;
+                        d[i + 1] = hq + s * (c * gq + s * d[i]);
+                        s_cs[2 * i] = c; s_cs[2 * i + 1] = s;
+                    }
+                    p = -s * s2 * c3 * el1 * e[l] / dl1;
+                    e[l] = s * p;
+                    d[l] = c * p;
+                    s_ctl[1] = (fabs(e[l]) > eps * tst1 && iter < 64) ? 1 : 0;
+                }
+                __syncthreads();
+                const int more = s_ctl[1];
+                if (tid < n) {
+                    const int k = tid;
+                    for (int i = m - 1; i >= l; i--) {
+                        const double c = s_cs[2 * i], sn = s_cs[2 * i + 1];
+                        const double hq = VV(k, i + 1), vi = VV(k, i);
+                        VV(k, i + 1) = sn * vi + c * hq;
+                        VV(k, i) = c * vi - sn * hq;
+                    }
+                }
+                __syncthreads();
+                if (!more) break;
+            }
+        }
+        if (tid == 0) { d[l] += f; e[l] = 0.0; }
+        __syncthreads();
+    }
+#undef VV
+}
+
 extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg g) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *info = g.info + (size_t)w * MG_INFO;
     if (info[0] != 0) return;
     extern __shared__ double s_dyn[];
-    __shared__ double s_cs[2 * 64], s_lam[MG_NK + 2], s_br[MG_NK + 2];
-    __shared__ int s_rank[MG_NK + 2], s_flag;
-    const int n = info[3], nb = info[5], N = n + (n & 1);
-    double *A = s_dyn, *V = s_dyn + N * N;
+    __shared__ double s_cs[2 * (MG_NK + 2)], s_lam[MG_NK + 2], s_e[MG_NK + 2], s_br[MG_NK + 2], s_sc[4];
+    __shared__ int s_rank[MG_NK + 2], s_ctl[2];
+    const int n = info[3], nb = info[5], N = n | 1;          // odd leading dimension: row / column walks stay off the same LDS banks
+    double *V = s_dyn;
     const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
-    for (int e = tid; e < N * N; e += NT) {
-        const int i = e / N, j = e - N * i;
-        A[e] = (i < n && j < n) ? 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]) : 0.0;
-        V[e] = (i == j) ? 1.0 : 0.0;
+    for (int e = tid; e < n * n; e += NT) {
+        const int i = e / n, j = e - n * i;
+        V[i * N + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]);
     }
     if (tid < n) s_br[tid] = br[tid];
     __syncthreads();
-    jacobi_eig<true>(A, N, N, V, nullptr, s_cs, &s_flag);
-    if (tid < n) s_lam[tid] = A[tid * N + tid];
+    tred2_tql2(V, n, N, s_lam, s_e, s_cs, s_sc, s_ctl);     // eigenvalues -> s_lam, eigenvectors -> columns of V
     __syncthreads();
     if (tid < n) {      // ascending order like Eigen::SelfAdjointEigenSolver
         int rk = 0;

@@ -105,6 +105,11 @@ class BackendSolver:
         self._check(self._L.vilf_get_profile_scan2map(self._h, ms, n), "vilf_get_profile_scan2map")
         return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(self.S2M_GROUPS)}
 
+    def get_profile_marginalize(self):
+        ms = (C.c_double * 4)(); n = (C.c_long * 4)()
+        self._check(self._L.vilf_get_profile_marginalize(self._h, ms, n), "vilf_get_profile_marginalize")
+        return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(("k_marg_prepare", "k_marg_schur", "k_marg_finish", "k_prior_prep"))}
+
     def batch_marginalize(self, sync=True):
         self._check(self._L.vilf_batch_marginalize(self._h, 1 if sync else 0), "vilf_batch_marginalize")
 
