@@ -42,7 +42,7 @@ def algorithmic_bytes_per_iteration(win, prior, part="all"):
     return {"all": inputs + reduced, "reduced": reduced + 8 * (n_p * n_p + n_p), "inputs": inputs}[part]
 
 
-def cpu_baseline(opts_unused, wins, priors, lidar_cases, seconds_target=12.0):
+def cpu_baseline(opts_unused, wins, priors, lidar_cases, marginalize, seconds_target=12.0):
     """The CPU restatement (oracle/, 'port') timed on this box's host cores on a bounded sample of the same frames."""
     import numpy as np
     from concurrent.futures import ThreadPoolExecutor
@@ -63,6 +63,8 @@ def cpu_baseline(opts_unused, wins, priors, lidar_cases, seconds_target=12.0):
             m, (se, ss) = prepared[i % len(prepared)]
             m.clone().step(se, ss)
         res = oracle_lib.window_solve(o, wins[i % len(wins)], priors[i % len(priors)])
+        if marginalize:
+            oracle_lib.window_marginalize(o, wins[i % len(wins)], res, priors[i % len(priors)])
         return res.summary["num_iterations"]
     t0 = time.perf_counter()
     frame(0)                                   # calibrate on one frame
@@ -72,7 +74,7 @@ def cpu_baseline(opts_unused, wins, priors, lidar_cases, seconds_target=12.0):
     with ThreadPoolExecutor(cores) as ex:
         its = sum(ex.map(frame, range(n)))
     dt = time.perf_counter() - t0
-    what = "scan-to-map step (1 m grid 5-NN) + window solve" if lidar_cases else "window solve"
+    what = ("scan-to-map step (1 m grid 5-NN) + " if lidar_cases else "") + "window solve" + (" + marginalization" if marginalize else "")
     return dict(value=its / dt, unit="iterations/s", cores=cores, kind="port",
                 sample=f"{n} frames ({its} window iterations; per frame: {what}) of the same synthetic input by oracle/ "
                        f"(C++ -O3, one frame per thread, {cores} threads), {dt:.1f} s")
@@ -227,6 +229,7 @@ def main():
                 "s2m_voxel_grid": B * (nm + ns + nq) * 16 * 2,           # 4 grids: read points, write centroids
                 "s2m_lm_solve": B * nq * 84.0 * 2 * 4,                   # factor records (80 B + kind), 2 passes x ~4 evaluations
                 "s2m_submap": B * nm * 16 * 2})
+        workload_tag = ("lidar+" if lid is not None else "") + "solve" + ("" if args.no_marginalize else "+marginalize")
         dom = max(alg, key=lambda k: prof[k]["ms"])
         avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
         achieved = alg[dom] / max(lps[dom], 1e-9) / (avg_ms * 1e-3) / 1e9
@@ -236,8 +239,8 @@ def main():
         try:
             import glob
             pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-            if pmc["config"]["windows_per_gpu"] == B and pmc["config"]["features_per_window"] == cfg.n_features and dom in pmc["kernels"]:
-                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch_corrected"]
+            if pmc.get("config", {}).get("frames_per_gpu") == B and pmc["config"].get("workload_tag") == workload_tag:
+                traffic = pmc["groups"][dom]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
         out = {
@@ -249,7 +252,7 @@ def main():
                                     "the 10-keyframe window solve (11 frames, visual+IMU+LiDAR between-factors+prior, <=8 dogleg iterations); "
                                     "batched independent frames") if lid is not None else
                                    "configs[1]-style: 10-keyframe window solve only (visual+IMU+LiDAR between-factors+prior), batched independent windows",
-                       "frames_per_gpu": B, "lidar_stage": lid,
+                       "frames_per_gpu": B, "workload_tag": workload_tag, "lidar_stage": lid,
                        "windows_per_gpu": B, "distinct_windows": args.distinct, "visual_factors_per_window": float(np.mean([w.n_factors for w in wins[:args.distinct]])),
                        "features_per_window": float(np.mean([w.n_features for w in wins[:args.distinct]])), "max_iterations": int(opts.max_num_iterations),
                        "parallelism": f"{world} x independent window shards (no data-path collective; RCCL all_gather of 64 B poses)"},
@@ -261,7 +264,7 @@ def main():
                          "kernels_achieved_GBps": {k: alg[k] / max(prof[k]["ms"] / args.steps, 1e-9) / 1e6 for k in alg}},
         }
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases)
+            out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

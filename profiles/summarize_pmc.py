@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Summarise two rocprofv3 PMC passes of bench.py (--pmc FETCH_SIZE and --pmc WRITE_SIZE, each with --kernel-trace
+--output-format csv) into per-kernel and per-launch-group HBM traffic.
+
+    python profiles/summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up> <out prefix>
+
+Counter unit: KB per dispatch. gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-counts wide coalesced reads by 2x,
+so corrected bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; raw = (FETCH_SIZE + WRITE_SIZE) * 1024. Groups are bench.py's launch
+groups (vilf_get_profile*): traffic per group launch = group bytes per step / group launches per step."""
+import collections
+import csv
+import json
+import sys
+
+GROUPS = {   # kernel-name prefix -> bench.py launch group
+    "k_linearize": "k_linearize", "k_solve": "k_solve", "k_step": "k_step",
+    "k_marg_prepare": "k_marg_prepare", "k_marg_schur": "k_marg_schur", "k_marg_finish": "k_marg_finish", "k_prior_prep": "k_prior_prep",
+    "b_minmax": "s2m_voxel_grid", "b_voxel_keys": "s2m_voxel_grid", "void b_voxel_keys": "s2m_voxel_grid", "void b_voxel_reduce": "s2m_voxel_grid",
+    "void b_voxel_merge": "s2m_voxel_grid", "void b_voxel_keys_split": "s2m_voxel_grid",
+    "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
+    "b_crop_compact": "s2m_submap", "b_transform_append": "s2m_submap", "b_bump": "s2m_submap",
+}
+LAUNCHES_PER_STEP = {"k_linearize": 9, "k_solve": 8, "k_step": 8, "k_marg_prepare": 1, "k_marg_schur": 1, "k_marg_finish": 1, "k_prior_prep": 1,
+                     "s2m_voxel_grid": 10, "s2m_radix_sort": 4, "s2m_neighbour_index": 2, "s2m_associate": 4, "s2m_lm_solve": 2, "s2m_submap": 2}
+
+
+def group_of(name):
+    for k, g in GROUPS.items():
+        if name.startswith(k):
+            return g
+    return None
+
+
+def main():
+    fetch_csv, write_csv, steps, prefix = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
+    for cname, path in (("FETCH_SIZE", fetch_csv), ("WRITE_SIZE", write_csv)):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == cname:
+                per_kernel[r["Kernel_Name"].split("(")[0][:80]][cname].append(float(r["Counter_Value"]))
+    out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py --steps S --warmup W --no-cpu-baseline (two passes)",
+           "note": __doc__.split("Counter unit:")[1].strip(), "steps_in_run": steps, "kernels": {}, "groups": {}}
+    rows = []
+    groups = collections.defaultdict(lambda: [0.0, 0.0])
+    for k, d in sorted(per_kernel.items()):
+        f, w = d.get("FETCH_SIZE", []), d.get("WRITE_SIZE", [])
+        fs, ws = sum(f), sum(w)
+        rows.append((k, len(f), fs / max(len(f), 1), ws / max(len(w), 1)))
+        g = group_of(k)
+        if g:
+            groups[g][0] += fs; groups[g][1] += ws
+        if k.startswith(("k_", "b_", "void b_")):
+            out["kernels"][k] = {"dispatches": len(f), "FETCH_SIZE_KB_mean": fs / max(len(f), 1), "WRITE_SIZE_KB_mean": ws / max(len(w), 1),
+                                 "hbm_bytes_per_launch_corrected": (2 * fs / max(len(f), 1) + ws / max(len(w), 1)) * 1024}
+    for g, (fs, ws) in groups.items():
+        lps = LAUNCHES_PER_STEP.get(g, 1)
+        out["groups"][g] = {"hbm_bytes_per_step_corrected": (2 * fs + ws) * 1024 / steps, "hbm_bytes_per_step_raw": (fs + ws) * 1024 / steps,
+                            "launches_per_step": lps, "hbm_bytes_per_launch_corrected": (2 * fs + ws) * 1024 / steps / lps}
+    json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
+    with open(prefix + "_pmc_summary.csv", "w") as fh:
+        fh.write("kernel,dispatches,mean_FETCH_SIZE_KB,mean_WRITE_SIZE_KB\n")
+        for r in rows:
+            fh.write('"%s",%d,%.3f,%.3f\n' % r)
+    print(json.dumps(out["groups"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
