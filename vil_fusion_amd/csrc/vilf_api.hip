@@ -25,7 +25,7 @@ __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
 __global__ void k_marg_prepare(VbBatch b, VbMarg g);
 __global__ void k_marg_schur(VbBatch b, VbMarg g);
-__global__ void k_marg_finish(VbBatch b, VbMarg g);
+__global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
 __global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
 __global__ void k_hook_lidar(const double *, const double *, const double *, const double *, const double *, double *);
@@ -603,7 +603,8 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     if (prof) hipEventRecord(h->pev[1], h->stream);
     hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g);
     if (prof) hipEventRecord(h->pev[2], h->stream);
-    hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g);
+    hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
+    hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
     if (prof) hipEventRecord(h->pev[3], h->stream);
     hipLaunchKernelGGL(k_prior_prep, grid, block, 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
     if (prof) hipEventRecord(h->pev[4], h->stream);

@@ -65,7 +65,7 @@ struct VbMarg {
     int *info;              // [B][MG_INFO]
     int *f0rank;            // [B][Fmax] rank among the start-frame-0 features, or -1
     double *st_pose, *st_sb, *st_feat, *st_ex;   // linearization point = vector2double() of the post-gauge state
-    double *Mbuf;           // [B][MG_MROW][FACmax]   (feature-major slot order)
+    double *Mbuf;           // [B][FACmax][MG_MROW]   (one 40-double record per visual factor, feature-major slot order)
     double *Hd, *gd;        // [B][MG_ND*MG_ND], [B][MG_ND]    dense-variable normal equations
     double *Wf;             // [B][Fmax][MG_ND]  arrow rows of the start-0 features (indexed by rank)
     double *hfm, *gfm;      // [B][Fmax]

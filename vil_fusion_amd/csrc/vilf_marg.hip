@@ -119,6 +119,31 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
     if (tid < 99) g.st_sb[(size_t)w * 99 + tid] = s_sb[tid];
     if (tid < 7) g.st_ex[(size_t)w * 7 + tid] = s_ex[tid];
 
+    // ---- start-frame-0 features: rank (order of appearance) and longest track, all threads ----------------------------------
+    __shared__ int s_fw[NT / 64], s_mf, s_maxobs;
+    if (tid == 0) { s_mf = 0; s_maxobs = 0; }
+    __syncthreads();
+    if (mode == 0) {
+        for (int f0 = 0; f0 < F; f0 += NT) {
+            const int f = f0 + tid;
+            const int flag = (f < F && f_start[f] == 0) ? 1 : 0;
+            const int nob = flag ? f_nobs[f] : 0;
+            int incl = flag, mx = nob;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if ((tid & 63) >= o) incl += u; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+            if ((tid & 63) == 63) s_fw[tid >> 6] = incl;
+            if ((tid & 63) == 0 && mx > 0) atomicMax(&s_maxobs, mx);
+            __syncthreads();
+            int off = s_mf;
+            for (int k = 0; k < (tid >> 6); k++) off += s_fw[k];
+            if (f < F) f0rank[f] = flag ? off + incl - 1 : -1;
+            __syncthreads();
+            if (tid == 0) { int t = 0; for (int k = 0; k < NT / 64; k++) t += s_fw[k]; s_mf += t; }
+            __syncthreads();
+        }
+    } else for (int f = tid; f < F; f += NT) f0rank[f] = -1;
     // ---- variable tables (thread 0): dense variables = dropped non-feature blocks, then kept blocks ascending in id ------
     if (tid == 0) {
         int status = 0, md = 0, mf = 0, n = 0, nb = 0;
@@ -133,14 +158,10 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             if (b.use_lidar) drop[1] = true;                                           // estimator.cpp:886-895 drop_set {0,1}
             const double *rec = b.imu + ((size_t)w * 10) * IMU_REC;
             if (rec[0] < 10.0) present[VB_NF + 1] = true;                                // :896-905
-            for (int f = 0; f < F; f++) {
-                if (f_start[f] != 0) { f0rank[f] = -1; continue; }
-                f0rank[f] = mf++;
-                for (int j = 1; j < f_nobs[f]; j++) present[j] = true;
-                present[2 * VB_NF] = true;
-            }
+            mf = s_mf;                                                                   // features observed from frame 0 (:921-950)
+            for (int j = 1; j < s_maxobs && j < VB_NF; j++) present[j] = true;
+            if (mf > 0) present[2 * VB_NF] = true;
         } else {             // MARGIN_SECOND_NEW: only the prior, drop Pose[WINDOW_SIZE-1] (:986-1003)
-            for (int f = 0; f < F; f++) f0rank[f] = -1;
             if (!have_prior || !present[VB_NF - 2]) status = 2;                          // nothing to do: prior stays as it is
             drop[VB_NF - 2] = true;
         }
@@ -245,9 +266,9 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, obs + 3 * o0, obs + 3 * oj, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
-            for (int k = 0; k < 12; k++) { Mb[(size_t)k * FC + slot] = sw * Ji[k]; Mb[(size_t)(12 + k) * FC + slot] = sw * Jj[k]; Mb[(size_t)(24 + k) * FC + slot] = sw * Jex[k]; }
-            Mb[(size_t)36 * FC + slot] = sw * Jf[0]; Mb[(size_t)37 * FC + slot] = sw * Jf[1];
-            Mb[(size_t)38 * FC + slot] = sw * r[0]; Mb[(size_t)39 * FC + slot] = sw * r[1];
+            for (int k = 0; k < 12; k++) { Mb[(size_t)slot * MG_MROW + (k)] = sw * Ji[k]; Mb[(size_t)slot * MG_MROW + (12 + k)] = sw * Jj[k]; Mb[(size_t)slot * MG_MROW + (24 + k)] = sw * Jex[k]; }
+            Mb[(size_t)slot * MG_MROW + (36)] = sw * Jf[0]; Mb[(size_t)slot * MG_MROW + (37)] = sw * Jf[1];
+            Mb[(size_t)slot * MG_MROW + (38)] = sw * r[0]; Mb[(size_t)slot * MG_MROW + (39)] = sw * r[1];
         }
     }
     __syncthreads();
@@ -264,7 +285,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
                 const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : 38, cv1 = (v < 18) ? cv0 + 6 : 39;
                 for (int q = s_poff[p]; q < s_poff[p + 1]; q++) {
                     const int slot = ps_slot[q];
-                    s += Mb[(size_t)cu0 * FC + slot] * Mb[(size_t)cv0 * FC + slot] + Mb[(size_t)cu1 * FC + slot] * Mb[(size_t)cv1 * FC + slot];
+                    s += Mb[(size_t)slot * MG_MROW + (cu0)] * Mb[(size_t)slot * MG_MROW + (cv0)] + Mb[(size_t)slot * MG_MROW + (cu1)] * Mb[(size_t)slot * MG_MROW + (cv1)];
                 }
             }
             s_pm[t] = s;
@@ -346,14 +367,14 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             const int nf = f_nobs[f] - 1, f0 = f_fac0[f];
             for (int t = 0; t < nf; t++) {
                 const int slot = f0 + t;
-                const double jf0 = Mb[(size_t)36 * FC + slot], jf1 = Mb[(size_t)37 * FC + slot];
+                const double jf0 = Mb[(size_t)slot * MG_MROW + (36)], jf1 = Mb[(size_t)slot * MG_MROW + (37)];
                 h += jf0 * jf0 + jf1 * jf1;
-                gg += jf0 * Mb[(size_t)38 * FC + slot] + jf1 * Mb[(size_t)39 * FC + slot];
+                gg += jf0 * Mb[(size_t)slot * MG_MROW + (38)] + jf1 * Mb[(size_t)slot * MG_MROW + (39)];
                 const int oj = s_off_pose[1 + t];
                 for (int c = 0; c < 6; c++) {
-                    w0[c] += Mb[(size_t)c * FC + slot] * jf0 + Mb[(size_t)(6 + c) * FC + slot] * jf1;
-                    wex[c] += Mb[(size_t)(24 + c) * FC + slot] * jf0 + Mb[(size_t)(30 + c) * FC + slot] * jf1;
-                    Wr[oj + c] = Mb[(size_t)(12 + c) * FC + slot] * jf0 + Mb[(size_t)(18 + c) * FC + slot] * jf1;
+                    w0[c] += Mb[(size_t)slot * MG_MROW + (c)] * jf0 + Mb[(size_t)slot * MG_MROW + (6 + c)] * jf1;
+                    wex[c] += Mb[(size_t)slot * MG_MROW + (24 + c)] * jf0 + Mb[(size_t)slot * MG_MROW + (30 + c)] * jf1;
+                    Wr[oj + c] = Mb[(size_t)slot * MG_MROW + (12 + c)] * jf0 + Mb[(size_t)slot * MG_MROW + (18 + c)] * jf1;
                 }
             }
             for (int c = 0; c < 6; c++) { Wr[o0 + c] = w0[c]; Wr[oex + c] = wex[c]; }
@@ -651,10 +672,12 @@ __device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, doubl
 #undef VV
 }
 
-extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg g) {
+// launched twice: windows with n_lo <= n < n_hi only. The usual kept dimension (n <= 77) needs < 48 KB of LDS for its n x n matrix,
+// so three workgroups share a CU; the rare larger priors go through the second launch with the full-size allocation.
+extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *info = g.info + (size_t)w * MG_INFO;
-    if (info[0] != 0) return;
+    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
     extern __shared__ double s_dyn[];
     __shared__ double s_cs[2 * (MG_NK + 2)], s_lam[MG_NK + 2], s_e[MG_NK + 2], s_br[MG_NK + 2], s_sc[4];
     __shared__ int s_rank[MG_NK + 2], s_ctl[2];
