@@ -501,7 +501,7 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
     __syncthreads();
 }
 // ONE persistent 256-thread workgroup per stream; the optimised pose is written back to the stream's pose slot.
-__global__ __launch_bounds__(S2M_NT) void b_solve(double *pose_all, const double *frec_all, const int *fkind_all, int capq, const int *n_ds_edge, const int *n_ds_surf, double huber_a, int max_it, int pass, S2BRes *res) {
+__global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const double *frec_all, const int *fkind_all, int capq, const int *n_ds_edge, const int *n_ds_surf, double huber_a, int max_it, int pass, S2BRes *res) {
     const int sid = blockIdx.x;
     if (!res[sid].do_opt) return;
     double *pose_in = pose_all + 24 * sid;
@@ -510,6 +510,7 @@ __global__ __launch_bounds__(S2M_NT) void b_solve(double *pose_all, const double
     const int n_edge_q = n_ds_edge[sid], n_surf_q = n_ds_surf[sid];
     S2BRes *out = res + sid;
     __shared__ double s_red[S2M_NW * 28], s_ev[28], s_cand[28], s_x[7], s_c[7], s_scale[6], s_diag[6], s_step[6];
+    __shared__ double Hs[36], L[36], gs[6], y[6];          // thread 0's 6 x 6 workspace lives in LDS: it must not set the kernel's register count
     __shared__ int s_ctl[4];
     const int tid = threadIdx.x, nfac = n_edge_q + n_surf_q;
     if (tid < 7) s_x[tid] = pose_in[tid];
@@ -545,10 +546,8 @@ __global__ __launch_bounds__(S2M_NT) void b_solve(double *pose_all, const double
             if (go) {
                 iteration++;
                 // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system
-                double Hs[36], gs[6];
                 for (int a = 0; a < 6; a++) { gs[a] = s_ev[21 + a] * s_scale[a]; for (int b2 = 0; b2 <= a; b2++) { const double v = s_ev[a * (a + 1) / 2 + b2] * s_scale[a] * s_scale[b2]; Hs[6 * a + b2] = v; Hs[6 * b2 + a] = v; } }
                 if (!reuse_diagonal) for (int c = 0; c < 6; c++) s_diag[c] = fmin(fmax(Hs[7 * c], 1e-6), 1e32);
-                double L[36], y[6];
                 for (int k = 0; k < 36; k++) L[k] = Hs[k];
                 for (int c = 0; c < 6; c++) L[7 * c] += s_diag[c] / radius;
                 bool ok = true;
