@@ -224,3 +224,25 @@ def test_prior_factor_hook(solver, oracle, opts):
     assert np.allclose(r, r0, rtol=1e-11, atol=1e-10 * max(1.0, np.abs(r0).max()))
     for a, b in zip(J, J0):
         assert np.array_equal(a, b)
+
+
+def test_marginalization_exact_path(solver, oracle, opts, monkeypatch):
+    """The arrow fast path is what well-conditioned windows take; VILF_MARG_FORCE_EXACT sends them through the exact path instead
+    (Jacobi eigen-decomposition of Amm with the reference's 1e-8 truncation). Both must agree with the oracle and with each other."""
+    win, prior, _ = synth.make_window(22, opts, synth.SynthConfig(with_prior=True, n_features=120))
+    res = {}
+    for tag in ("fast", "exact"):
+        if tag == "exact":
+            monkeypatch.setenv("VILF_MARG_FORCE_EXACT", "1")
+        solver.set_prior(prior)
+        solver.optimization(win)
+        solver.marginalize()
+        res[tag] = _prior_products(solver.get_prior())
+    monkeypatch.delenv("VILF_MARG_FORCE_EXACT")
+    ref = oracle.window_solve(opts, win, prior)
+    Lr, br_, _ = _prior_products(oracle.window_marginalize(opts, win, ref, prior))
+    for tag in ("fast", "exact"):
+        Lg, bg, _ = res[tag]
+        assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5, tag
+    assert np.abs(res["fast"][0] - res["exact"][0]).max() / np.abs(Lr).max() < 2e-5
+    assert not np.array_equal(res["fast"][0], res["exact"][0]), "the hook did not switch paths (two different algorithms cannot agree bit for bit)"

@@ -24,7 +24,7 @@ __global__ void k_step(VbBatch b);
 __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
 __global__ void k_marg_prepare(VbBatch b, VbMarg g);
-__global__ void k_marg_schur(VbBatch b, VbMarg g);
+__global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
 __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
 __global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
@@ -601,7 +601,9 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     if (prof) hipEventRecord(h->pev[0], h->stream);
     hipLaunchKernelGGL(k_marg_prepare, grid, block, 0, h->stream, h->batch, g);
     if (prof) hipEventRecord(h->pev[1], h->stream);
-    hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g);
+    hipLaunchKernelGGL(k_marg_schur, grid, block, (size_t)(MG_MD * MG_MD + MG_MD * (MG_NK + 1) + 1000 + VB_NT) * sizeof(double), h->stream, h->batch, g,
+                       std::getenv("VILF_MARG_FORCE_EXACT") ? 2 : 0);      // test hook: exercise the Jacobi path on well-conditioned windows too
+    hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g, 1);
     if (prof) hipEventRecord(h->pev[2], h->stream);
     hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
     hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);

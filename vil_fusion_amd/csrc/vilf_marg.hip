@@ -385,10 +385,14 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
 
 // ------------------------------------------------------------------------------------------------------------------
 #define MG_LDS_DOUBLES (MG_MLDS * MG_MLDS)
-extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg g) {
+// launched twice: exact == 0 runs the arrow fast path in ~30 KB of LDS (five workgroups per CU) and flags the windows whose guard
+// fails (info[7] = 1); exact == 1 runs the Jacobi path, with the full-size LDS allocation, for the flagged windows only.
+extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg g, int exact) {
     const int w = blockIdx.x, tid = threadIdx.x;
-    const int *info = g.info + (size_t)w * MG_INFO;
+    int *info = g.info + (size_t)w * MG_INFO;
     if (info[0] != 0) return;
+    if (exact == 2) { if (tid == 0) info[7] = 1; return; }      // test hook: send every window through the exact path
+    if (exact && info[7] != 1) return;
     extern __shared__ double s_dyn[];
     __shared__ double s_cs[2 * 512];
     __shared__ int s_flag;
@@ -405,7 +409,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
     // the diagonal D and a Cholesky of the md x md Schur complement S — no eigen-decomposition of the (md + mf)-dimensional block.
     // Guard: D > 0, S > 0 (Cholesky pivots) and trace(Amm^-1) < 1e8 (the trace bounds the largest eigenvalue of the inverse, i.e.
     // lambda_min(Amm) > 1e-8: nothing would be truncated). Otherwise fall through to the Jacobi path below.
-    {
+    if (!exact) {
         double *s_S = s_dyn, *s_Y = s_S + MG_MD * MG_MD, *s_ih = s_Y + MG_MD * (MG_NK + 1), *s_red = s_ih + VILF_MAX_FEATURES_DEV;   // [md][md], [md][XL], [mf], [NT]
         __shared__ int s_ok;
         if (tid == 0) s_ok = (md > 0 && md <= MG_MD && mf <= VILF_MAX_FEATURES_DEV) ? 1 : 0;
@@ -468,9 +472,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                 if (j < n) Ar[i * MG_NK + j] = Hd[(md + i) * MG_ND + md + j] - sacc;
                 else br[i] = gd[md + i] - sacc;
             }
+            if (tid == 0) info[7] = 0;
             return;
         }
-        __syncthreads();
+        if (tid == 0) info[7] = 1;      // guard failed: the exact launch takes this window
+        return;
     }
     // Amm = 0.5 (Amm + Amm^T) (marginalization_factor.cpp:267), arrow structure: dense md x md block, feature diagonal
     for (int e = tid; e < M * M; e += NT) {
