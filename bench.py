@@ -243,6 +243,21 @@ def main():
                 traffic = pmc["groups"][dom]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
+        # the dense reduce (k_solve: MFMA Schur reduce + blocked Cholesky) against the fp64 MFMA roofline: flop count per dispatch from the
+        # committed PMC pass (SQ_INSTS_VALU_MFMA_F64 x 2048 flop, same 2048-window / 230-feature configuration), time from this run
+        mfma = None
+        try:
+            import glob
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))[-1]))
+            if B == 2048 and cfg.n_features == 230:
+                mfma = {}
+                for kk in ("k_solve", "k_linearize"):
+                    fl = pm["kernels"][kk]["mfma_flop_per_dispatch"]
+                    ms = prof[kk]["ms"] / max(prof[kk]["launches"], 1)
+                    mfma[kk] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / 78.6,
+                                "mfma_flop_per_launch": fl, "avg_launch_ms": ms, "pmc_MfmaUtil_percent": pm["kernels"][kk]["MfmaUtil_percent"]}
+        except Exception:
+            mfma = None
         out = {
             "metric": "sliding-window solve iters/sec (10 KF, ~5.5k factors) @1/2/4/8 GPU vs CPU",
             "value": its_total / dt_max, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -263,6 +278,8 @@ def main():
                          "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                          "kernels_achieved_GBps": {k: alg[k] / max(prof[k]["ms"] / args.steps, 1e-9) / 1e6 for k in alg}},
         }
+        if mfma is not None:
+            out["roofline_mfma"] = mfma
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))
