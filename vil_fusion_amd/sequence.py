@@ -1,0 +1,432 @@
+"""sequence.py — host-side sliding-window loop around the back-end.
+
+A Python mirror of the reference's per-frame host logic, so whole multi-frame sequences can be replayed through either back-end
+(the HIP path or the CPU oracle) and their trajectories compared:
+
+    FeatureManager            ≙ vins_estimator/feature_manager.cpp (addFeatureCheckParallax :45-109, getFeatureCount :28-43,
+                                setDepth :150-168, removeFailures :170-180, getDepthVector :194-216, triangulate :218-276,
+                                removeBackShiftDepth :292-349, removeBack :351-366, removeFront :368-388, compensatedParallax2 :390-423)
+    SlidingWindowEstimator    ≙ vins_estimator/estimator.cpp: processOdometry :90-101, processIMU :103-137, processImage :139-234
+                                (steady-state NON_LINEAR branch; the SfM initialisation :237-459 is out of scope — the window is
+                                bootstrapped from given states), solveOdometry :492-503, vector2double :505-547, slideWindow :1052-1186
+    write_tum                 ≙ utility/visualization.cpp:159-172 (t x y z qx qy qz qw, time relative to the first frame)
+
+The back-end is pluggable: `backend.solve(window) -> WindowResult` and `backend.marginalize(window, result)`; see HipBackend /
+adapters in tests. Everything here is host bookkeeping — no arithmetic of the hot path lives in this file.
+"""
+import numpy as np
+
+from . import abi, synth
+
+WINDOW_SIZE = 10
+MIN_PARALLAX = 10.0 / 460.0          # kitti_config.yaml keyframe_parallax / FOCAL_LENGTH (parameters.cpp:119)
+INIT_DEPTH = 5.0
+MARGIN_OLD, MARGIN_SECOND_NEW = abi.MARGIN_OLD, abi.MARGIN_SECOND_NEW
+
+
+class FeaturePerFrame:
+    __slots__ = ("point", "uv", "velocity", "depth", "cur_td")
+
+    def __init__(self, p8, td):
+        self.point = np.array(p8[0:3], dtype=np.float64)
+        self.uv = np.array(p8[3:5], dtype=np.float64)
+        self.velocity = np.array(p8[5:7], dtype=np.float64)
+        self.depth = float(p8[7])
+        self.cur_td = td
+
+
+class FeaturePerId:
+    def __init__(self, feature_id, start_frame, measured_depth):
+        self.feature_id, self.start_frame = feature_id, start_frame
+        self.feature_per_frame = []
+        self.used_num, self.solve_flag = 0, 0
+        self.estimated_depth, self.lidar_depth_flag = (measured_depth, True) if measured_depth > 0 else (-1.0, False)
+
+    def end_frame(self):
+        return self.start_frame + len(self.feature_per_frame) - 1
+
+
+class FeatureManager:
+    def __init__(self):
+        self.feature = []            # insertion order, like the reference's std::list
+        self.last_track_num = 0
+
+    def _used(self, it):
+        it.used_num = len(it.feature_per_frame)
+        return it.used_num >= 2 and it.start_frame < WINDOW_SIZE - 2
+
+    def get_feature_count(self):
+        return sum(1 for it in self.feature if self._used(it))
+
+    def add_feature_check_parallax(self, frame_count, image, td):
+        parallax_sum, parallax_num = 0.0, 0
+        self.last_track_num = 0
+        by_id = {it.feature_id: it for it in self.feature}
+        for feature_id, p8 in image.items():          # std::map: ascending id
+            f = FeaturePerFrame(p8, td)
+            it = by_id.get(feature_id)
+            if it is None:
+                it = FeaturePerId(feature_id, frame_count, f.depth)
+                it.feature_per_frame.append(f)
+                self.feature.append(it); by_id[feature_id] = it
+            else:
+                it.feature_per_frame.append(f)
+                self.last_track_num += 1
+                if f.depth > 0 and not it.lidar_depth_flag:
+                    it.estimated_depth = f.depth
+                    it.lidar_depth_flag = True
+                    it.feature_per_frame[0].depth = f.depth
+        if frame_count < 2 or self.last_track_num < 20:
+            return True
+        for it in self.feature:
+            if it.start_frame <= frame_count - 2 and it.start_frame + len(it.feature_per_frame) - 1 >= frame_count - 1:
+                parallax_sum += self.compensated_parallax2(it, frame_count)
+                parallax_num += 1
+        if parallax_num == 0:
+            return True
+        return parallax_sum / parallax_num >= MIN_PARALLAX
+
+    @staticmethod
+    def compensated_parallax2(it, frame_count):
+        pi = it.feature_per_frame[frame_count - 2 - it.start_frame].point
+        pj = it.feature_per_frame[frame_count - 1 - it.start_frame].point
+        du, dv = pi[0] / pi[2] - pj[0], pi[1] / pi[2] - pj[1]
+        return max(0.0, float(np.sqrt(du * du + dv * dv)))
+
+    def set_depth(self, x):
+        k = -1
+        for it in self.feature:
+            if not self._used(it):
+                continue
+            k += 1
+            it.estimated_depth = 1.0 / x[k]
+            it.solve_flag = 2 if it.estimated_depth < 0 else 1
+
+    def remove_failures(self):
+        self.feature = [it for it in self.feature if it.solve_flag != 2]
+
+    def get_depth_vector(self):
+        return np.array([1.0 / it.estimated_depth if it.estimated_depth > 0 else 1.0 / INIT_DEPTH for it in self.feature if self._used(it)])
+
+    def triangulate(self, Ps, Rs, tic, ric):
+        for it in self.feature:
+            if not self._used(it) or it.estimated_depth > 0:
+                continue
+            i = it.start_frame
+            t0, R0 = Ps[i] + Rs[i] @ tic, Rs[i] @ ric
+            rows = []
+            for k, fpf in enumerate(it.feature_per_frame):
+                j = i + k
+                t1, R1 = Ps[j] + Rs[j] @ tic, Rs[j] @ ric
+                t, R = R0.T @ (t1 - t0), R0.T @ R1
+                P = np.hstack([R.T, (-R.T @ t)[:, None]])
+                f = fpf.point / np.linalg.norm(fpf.point)
+                rows.append(f[0] * P[2] - f[2] * P[0]); rows.append(f[1] * P[2] - f[2] * P[1])
+            v = np.linalg.svd(np.array(rows))[2][-1]
+            it.estimated_depth = v[2] / v[3]
+            if it.estimated_depth < 0.1:
+                it.estimated_depth = INIT_DEPTH
+
+    def remove_back_shift_depth(self, marg_R, marg_P, new_R, new_P):
+        keep = []
+        for it in self.feature:
+            if it.start_frame != 0:
+                it.start_frame -= 1
+                keep.append(it); continue
+            uv_i = it.feature_per_frame[0].point
+            depth = -1.0
+            if it.feature_per_frame[0].depth > 0:
+                depth = it.feature_per_frame[0].depth
+            elif it.estimated_depth > 0:
+                depth = it.estimated_depth
+            del it.feature_per_frame[0]
+            if len(it.feature_per_frame) < 2:
+                continue
+            pts_j = new_R.T @ (marg_R @ (uv_i * depth) + marg_P - new_P)
+            if it.feature_per_frame[0].depth > 0:
+                it.estimated_depth, it.lidar_depth_flag = it.feature_per_frame[0].depth, True
+            elif pts_j[2] > 0:
+                it.estimated_depth, it.lidar_depth_flag = float(pts_j[2]), False
+            else:
+                it.estimated_depth, it.lidar_depth_flag = INIT_DEPTH, False
+            keep.append(it)
+        self.feature = keep
+
+    def remove_front(self, frame_count):
+        keep = []
+        for it in self.feature:
+            if it.start_frame == frame_count:
+                it.start_frame -= 1
+            else:
+                j = WINDOW_SIZE - 1 - it.start_frame
+                if it.end_frame() >= frame_count - 1:
+                    del it.feature_per_frame[j]
+                    if len(it.feature_per_frame) == 0:
+                        continue
+            keep.append(it)
+        self.feature = keep
+
+
+class Integration:
+    """≙ IntegrationBase: the sample buffers + linearisation biases; the pre-integrated row is computed on demand."""
+
+    def __init__(self, acc_0, gyr_0, ba, bg):
+        self.acc = [np.array(acc_0, dtype=np.float64)]; self.gyr = [np.array(gyr_0, dtype=np.float64)]
+        self.dt = []
+        self.ba, self.bg = np.array(ba, dtype=np.float64), np.array(bg, dtype=np.float64)
+
+    def push_back(self, dt, acc, gyr):
+        self.dt.append(float(dt)); self.acc.append(np.array(acc, dtype=np.float64)); self.gyr.append(np.array(gyr, dtype=np.float64))
+
+    def row(self):
+        if not self.dt:
+            r = np.zeros(abi.IMU_DOUBLES); r[synth.IMU_OFF["delta_q"][0] + 3] = 1.0
+            return r
+        dt = self.dt[0]
+        assert np.allclose(self.dt, dt)
+        return synth.preintegrate(np.array(self.acc)[None], np.array(self.gyr)[None], dt, self.ba[None], self.bg[None])[0]
+
+
+class SlidingWindowEstimator:
+    """Steady-state (NON_LINEAR) Estimator loop. `backend.solve(window) -> abi.WindowResult`, `backend.marginalize(window, result)`."""
+
+    def __init__(self, opts, backend):
+        self.o, self.backend = opts, backend
+        n = WINDOW_SIZE + 1
+        self.Ps = np.zeros((n, 3)); self.Vs = np.zeros((n, 3)); self.Rs = np.tile(np.eye(3), (n, 1, 1))
+        self.Bas = np.zeros((n, 3)); self.Bgs = np.zeros((n, 3))
+        self.stamps = np.zeros(n)
+        self.pre = [None] * n
+        self.lidar = [(np.array([0, 0, 0, 1.0]), np.zeros(3)) for _ in range(n)]
+        self.g = np.array(opts.G[:])
+        self.ric = np.array(opts.RIC[:]).reshape(3, 3); self.tic = np.array(opts.TIC[:])
+        self.td = 0.0
+        self.f = FeatureManager()
+        self.frame_count = 0
+        self.first_imu = False
+        self.acc_0 = np.zeros(3); self.gyr_0 = np.zeros(3)
+        self.marginalization_flag = MARGIN_OLD
+        self.trajectory = []            # (stamp, P[3], q[4] xyzw) of the newest frame after every solved frame
+        self.flags = []
+        self.summaries = []
+
+    # estimator.cpp:90-101
+    def process_odometry(self, q, t):
+        if self.frame_count != 0:
+            self.lidar[self.frame_count] = (np.array(q, dtype=np.float64), np.array(t, dtype=np.float64))
+
+    # estimator.cpp:103-137
+    def process_imu(self, dt, acc, gyr):
+        acc, gyr = np.array(acc, dtype=np.float64), np.array(gyr, dtype=np.float64)
+        if not self.first_imu:
+            self.first_imu = True
+            self.acc_0, self.gyr_0 = acc, gyr
+        j = self.frame_count
+        if self.pre[j] is None:
+            self.pre[j] = Integration(self.acc_0, self.gyr_0, self.Bas[j], self.Bgs[j])
+        if j != 0:
+            self.pre[j].push_back(dt, acc, gyr)
+            un_acc_0 = self.Rs[j] @ (self.acc_0 - self.Bas[j]) - self.g
+            un_gyr = 0.5 * (self.gyr_0 + gyr) - self.Bgs[j]
+            th = un_gyr * dt
+            dq = np.array([th[0] / 2, th[1] / 2, th[2] / 2, 1.0])                  # Utility::deltaQ
+            self.Rs[j] = self.Rs[j] @ synth.q_to_R(dq / np.linalg.norm(dq))
+            un_acc = 0.5 * (un_acc_0 + self.Rs[j] @ (acc - self.Bas[j]) - self.g)
+            self.Ps[j] = self.Ps[j] + dt * self.Vs[j] + 0.5 * dt * dt * un_acc
+            self.Vs[j] = self.Vs[j] + dt * un_acc
+        self.acc_0, self.gyr_0 = acc, gyr
+
+    # estimator.cpp:139-234. `init_state` = (P, R, V, ba, bg) of this frame while the window is being filled (replaces the SfM start-up)
+    def process_image(self, image, stamp, init_state=None):
+        j = self.frame_count
+        keyframe = self.f.add_feature_check_parallax(j, dict(sorted(image.items())), self.td)
+        self.marginalization_flag = MARGIN_OLD if keyframe else MARGIN_SECOND_NEW
+        self.stamps[j] = stamp
+        if init_state is not None:
+            self.Ps[j], self.Rs[j], self.Vs[j], self.Bas[j], self.Bgs[j] = [np.array(x, dtype=np.float64) for x in init_state]
+            if self.pre[j] is not None:       # ≙ repropagate() with the start-up biases (initial_aligment.cpp / estimator.cpp:437-440)
+                self.pre[j].ba, self.pre[j].bg = self.Bas[j].copy(), self.Bgs[j].copy()
+        if j < WINDOW_SIZE:
+            self.frame_count += 1
+            return None
+        # solveOdometry (:492-503)
+        self.f.triangulate(self.Ps, self.Rs, self.tic, self.ric)
+        res = self.optimization()
+        self.slide_window()
+        self.f.remove_failures()
+        q = synth.R_to_q(self.Rs[WINDOW_SIZE])
+        self.trajectory.append((self.stamps[WINDOW_SIZE], self.Ps[WINDOW_SIZE].copy(), q))
+        self.flags.append(self.marginalization_flag)
+        return res
+
+    # estimator.cpp:505-547 + the factor walk :722-794 -> the ABI's window description
+    def make_window(self):
+        n = WINDOW_SIZE + 1
+        para_pose = np.zeros((n, 7)); para_sb = np.zeros((n, 9))
+        for i in range(n):
+            para_pose[i, :3] = self.Ps[i]; para_pose[i, 3:] = synth.R_to_q(self.Rs[i])
+            para_sb[i, :3], para_sb[i, 3:6], para_sb[i, 6:] = self.Vs[i], self.Bas[i], self.Bgs[i]
+        ex = np.concatenate([self.tic, synth.R_to_q(self.ric)])
+        used = [it for it in self.f.feature if self.f._used(it)]
+        depth = self.f.get_depth_vector()
+        starts = np.array([it.start_frame for it in used], dtype=np.int32)
+        const = np.array([1 if it.lidar_depth_flag else 0 for it in used], dtype=np.uint8)
+        offs, pts = [0], []
+        for it in used:
+            pts.extend(fp.point for fp in it.feature_per_frame)
+            offs.append(len(pts))
+        imu = np.zeros((n, abi.IMU_DOUBLES)); imu[0, synth.IMU_OFF["delta_q"][0] + 3] = 1.0
+        lid = np.zeros((n, 7)); lid[:, 3] = 1.0
+        for k in range(1, n):
+            imu[k] = self.pre[k].row()
+            lid[k, :4], lid[k, 4:] = self.lidar[k]
+        return abi.Window(para_pose, para_sb, ex, depth, const, starts, np.array(offs, dtype=np.int32), np.array(pts).reshape(-1, 3), imu,
+                          lidar=lid, para_td=self.td, marginalization_flag=self.marginalization_flag)
+
+    # estimator.cpp:689-1050
+    def optimization(self):
+        win = self.make_window()
+        res = self.backend.solve(win)
+        # double2vector (:549-638) happened inside the back-end: take the gauge-fixed state
+        self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs = res.Ps.copy(), res.Rs.copy(), res.Vs.copy(), res.Bas.copy(), res.Bgs.copy()
+        self.f.set_depth(res.para_feature)
+        self.backend.marginalize(win, res)
+        self.summaries.append(res.summary)
+        return res
+
+    # estimator.cpp:1052-1186
+    def slide_window(self):
+        W = WINDOW_SIZE
+        if self.marginalization_flag == MARGIN_OLD:
+            back_R0, back_P0 = self.Rs[0].copy(), self.Ps[0].copy()
+            for arr in (self.Ps, self.Vs, self.Rs, self.Bas, self.Bgs, self.stamps):
+                arr[:W] = arr[1:].copy()
+            self.pre = self.pre[1:] + [None]
+            self.lidar = self.lidar[1:] + [(np.array([0, 0, 0, 1.0]), np.zeros(3))]
+            self.pre[W] = Integration(self.acc_0, self.gyr_0, self.Bas[W], self.Bgs[W])
+            # slideWindowOld (:1169-1186), solver_flag == NON_LINEAR
+            R0, P0 = back_R0 @ self.ric, back_P0 + back_R0 @ self.tic
+            R1, P1 = self.Rs[0] @ self.ric, self.Ps[0] + self.Rs[0] @ self.tic
+            self.f.remove_back_shift_depth(R0, P0, R1, P1)
+        else:
+            last, prev = self.pre[W], self.pre[W - 1]
+            for dt, a, w in zip(last.dt, last.acc[1:], last.gyr[1:]):
+                prev.push_back(dt, a, w)
+            for arr in (self.Ps, self.Vs, self.Rs, self.Bas, self.Bgs, self.stamps):
+                arr[W - 1] = arr[W].copy()
+            (qa, ta), (qb, tb) = self.lidar[W - 1], self.lidar[W]
+            self.lidar[W - 1] = (synth.q_mul(qa, qb), synth.q_to_R(qa) @ tb + ta)         # merge the two LiDAR between-constraints (:1131-1134)
+            self.pre[W] = Integration(self.acc_0, self.gyr_0, self.Bas[W], self.Bgs[W])
+            self.lidar[W] = (np.array([0, 0, 0, 1.0]), np.zeros(3))
+            self.f.remove_front(W)       # slideWindowNew (:1163-1167)
+
+
+def write_tum(path, trajectory):
+    """utility/visualization.cpp:159-172: `t x y z qx qy qz qw`, time relative to the first pose, precision 9 / 5."""
+    t0 = trajectory[0][0]
+    with open(path, "w") as fh:
+        for t, P, q in trajectory:
+            fh.write("%.9f %.5f %.5f %.5f %.5f %.5f %.5f %.5f\n" % (t - t0, P[0], P[1], P[2], q[0], q[1], q[2], q[3]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# synthetic multi-frame sequence (same motion / camera / IMU model as synth.make_window, feature tracks with ids)
+def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, pixel_sigma=0.5 / 460.0, state_noise=(0.05, np.deg2rad(0.5), 0.05)):
+    """Returns a dict: stamps[n], imu[k] = (dt, acc[S,3], gyr[S,3]) for the interval ending at frame k (k >= 1, first-ever sample in
+    imu0), images[k] = {feature_id: 8-vector}, lidar[k] = (q, t) relative LiDAR pose k-1 -> k, truth P/R/V, and `init[k]` = noisy
+    (P, R, V, ba, bg) for the first WINDOW_SIZE + 1 frames (stands in for the reference's SfM initialisation)."""
+    rng = np.random.default_rng(seed)
+    RIC = np.array(opts.RIC[:]).reshape(3, 3); TIC = np.array(opts.TIC[:])
+    RCL = np.array(opts.RCL[:]).reshape(3, 3); TCL = np.array(opts.TCL[:])
+    G = np.array(opts.G[:])
+    S, dt = 10, 0.01
+    nt = (n_frames - 1) * S + 1
+    t = np.arange(nt) * dt
+    speed = rng.uniform(8.0, 12.0)
+    Ay, wy, py = rng.uniform(0.05, 0.3), rng.uniform(0.3, 1.0), rng.uniform(0, 2 * np.pi)
+    Ap, wp, pp = rng.uniform(0.0, 0.03), rng.uniform(0.5, 2.0), rng.uniform(0, 2 * np.pi)
+    Ar, wr, pr = rng.uniform(0.0, 0.03), rng.uniform(0.5, 2.0), rng.uniform(0, 2 * np.pi)
+    yaw0 = rng.uniform(-np.pi, np.pi)
+
+    def kin(tt):
+        yaw = yaw0 + Ay * np.sin(wy * tt + py); dyaw = Ay * wy * np.cos(wy * tt + py)
+        pit = Ap * np.sin(wp * tt + pp); dpit = Ap * wp * np.cos(wp * tt + pp)
+        rol = Ar * np.sin(wr * tt + pr); drol = Ar * wr * np.cos(wr * tt + pr)
+        R = synth.euler_R(yaw, pit, rol)
+        w_b = np.stack([drol - dyaw * np.sin(pit), dpit * np.cos(rol) + dyaw * np.sin(rol) * np.cos(pit), -dpit * np.sin(rol) + dyaw * np.cos(rol) * np.cos(pit)], -1)
+        v = speed * R[..., :, 0]
+        a = speed * np.einsum('...ij,...j->...i', R, np.cross(w_b, np.array([1.0, 0, 0])))
+        return R, w_b, v, a
+
+    fine = 10
+    tf = np.arange((nt - 1) * fine + 1) * (dt / fine)
+    vf = kin(tf)[2]
+    h = dt / fine
+    seg = (vf[0:-2:2] + 4 * vf[1:-1:2] + vf[2::2]) * (h / 3.0)
+    p2 = np.concatenate([np.zeros((1, 3)), np.cumsum(seg, axis=0)])
+    P_imu = rng.uniform(-50, 50, 3) * np.array([1, 1, 0.02]) + p2[:: fine // 2][:nt]
+    R_imu, w_b, v_imu, a_w = kin(t)
+    ba_true = rng.normal(0, 0.02, 3); bg_true = rng.normal(0, 0.002, 3)
+    acc_m = np.einsum('tji,tj->ti', R_imu, a_w + G) + ba_true + rng.normal(0, synth.ACC_N, (nt, 3))
+    gyr_m = w_b + bg_true + rng.normal(0, synth.GYR_N, (nt, 3))
+    fidx = np.arange(n_frames) * S
+    Pw, Rw, Vw = P_imu[fidx], R_imu[fidx], v_imu[fidx]
+    Rc = Rw @ RIC
+    Pc = Pw + np.einsum('kij,j->ki', Rw, TIC)
+
+    images, active, next_id = [], {}, 0          # active: id -> (Xw, has_lidar_depth)
+    for k in range(n_frames):
+        img = {}
+        for fid in list(active):
+            Xw, has_d = active[fid]
+            pc = Rc[k].T @ (Xw - Pc[k])
+            if pc[2] < 1.0 or abs(pc[0] / pc[2]) > 1.3 or abs(pc[1] / pc[2]) > 0.6:
+                del active[fid]; continue
+            x, y = pc[0] / pc[2] + rng.normal(0, pixel_sigma), pc[1] / pc[2] + rng.normal(0, pixel_sigma)
+            img[fid] = np.array([x, y, 1.0, synth.FX * x + synth.CX, synth.FY * y + synth.CY, 0.0, 0.0, pc[2] + rng.normal(0, 0.05) if has_d else -1.0])
+        tries = 0
+        while len(img) < max_cnt and tries < 20 * max_cnt:
+            tries += 1
+            u, v = rng.uniform(0, synth.IMG_W), rng.uniform(0, synth.IMG_H)
+            d = rng.uniform(5.0, 50.0)
+            ray = np.array([(u - synth.CX) / synth.FX, (v - synth.CY) / synth.FY, 1.0])
+            Xw = Rc[k] @ (d * ray) + Pc[k]
+            has_d = bool(rng.uniform() < lidar_depth_fraction)
+            active[next_id] = (Xw, has_d)
+            x, y = ray[0] + rng.normal(0, pixel_sigma), ray[1] + rng.normal(0, pixel_sigma)
+            img[next_id] = np.array([x, y, 1.0, u, v, 0.0, 0.0, d + rng.normal(0, 0.05) if has_d else -1.0])
+            next_id += 1
+        images.append(img)
+
+    Ril = RIC @ RCL; til = RIC @ TCL + TIC
+    lidar = [None]
+    for k in range(1, n_frames):
+        Rij = Rw[k - 1].T @ Rw[k]; Pij = Rw[k - 1].T @ (Pw[k] - Pw[k - 1])
+        Rl = Ril.T @ Rij @ Ril
+        tl = Ril.T @ (Rij @ til + Pij - til)
+        ql = synth.q_mul(synth.R_to_q(Rl), synth.q_exp(rng.normal(0, np.deg2rad(0.1), 3)))
+        lidar.append((ql / np.linalg.norm(ql), tl + rng.normal(0, 0.02, 3)))
+
+    sp, sr, sv = state_noise
+    ba_est = ba_true + rng.normal(0, 0.005, 3); bg_est = bg_true + rng.normal(0, 0.0005, 3)
+    init = []
+    for k in range(min(n_frames, WINDOW_SIZE + 1)):
+        Rn = Rw[k] @ synth.q_to_R(synth.q_exp(rng.normal(0, sr, 3)))
+        init.append((Pw[k] + rng.normal(0, sp, 3), Rn, Vw[k] + rng.normal(0, sv, 3), ba_est, bg_est))
+    imu = [None] + [(dt, acc_m[(k - 1) * S + 1: k * S + 1], gyr_m[(k - 1) * S + 1: k * S + 1]) for k in range(1, n_frames)]
+    return dict(stamps=fidx * dt, imu0=(acc_m[0], gyr_m[0]), imu=imu, images=images, lidar=lidar, init=init, P=Pw, R=Rw, V=Vw, ba=ba_true, bg=bg_true)
+
+
+def run_sequence(seq, opts, backend, n_frames=None):
+    """Feed a make_sequence() dict through SlidingWindowEstimator; returns the estimator (trajectory, flags, summaries)."""
+    est = SlidingWindowEstimator(opts, backend)
+    n = len(seq["images"]) if n_frames is None else n_frames
+    est.process_imu(0.0, *seq["imu0"])                 # first sample: only latches acc_0 / gyr_0 (frame_count == 0)
+    for k in range(n):
+        if k >= 1:
+            dt, acc, gyr = seq["imu"][k]
+            for a, w in zip(acc, gyr):
+                est.process_imu(dt, a, w)
+            est.process_odometry(*seq["lidar"][k])
+        est.process_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if k < len(seq["init"]) else None)
+    return est
