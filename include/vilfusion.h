@@ -213,6 +213,11 @@ int vilf_prior_import(vilf_handle *h, int slot, const vilf_prior *prior);
  * the device through the same device functions the solve kernels use. */
 int vilf_eval_projection(vilf_handle *h, const double *const *parameters, const double pts_i[3],
                          const double pts_j[3], double *residuals, double **jacobians);   /* projection_factor.cpp:21 */
+/* ProjectionTdFactor (5 blocks: Pose_i, Pose_j, Ex_Pose, inverse depth, td); row_* = uv.y of the two observations, TR / ROW from the options.
+ * Factor-level only: the device solve does not estimate td / the extrinsic (estimate_td, estimate_extrinsic -> VILF_ERR_UNSUPPORTED). */
+int vilf_eval_projection_td(vilf_handle *h, const double *const *parameters, const double pts_i[3], const double pts_j[3],
+                            const double velocity_i[2], const double velocity_j[2], double td_i, double td_j, double row_i, double row_j,
+                            double *residuals, double **jacobians);                          /* projection_td_factor.cpp:34 */
 int vilf_eval_imu(vilf_handle *h, const double *const *parameters, const vilf_imu_preint *pre,
                   double *residuals, double **jacobians);                                   /* imu_factor.h:19 */
 int vilf_eval_lidar_between(vilf_handle *h, const double *const *parameters,

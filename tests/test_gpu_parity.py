@@ -246,3 +246,16 @@ def test_marginalization_exact_path(solver, oracle, opts, monkeypatch):
         assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5, tag
     assert np.abs(res["fast"][0] - res["exact"][0]).max() / np.abs(Lr).max() < 2e-5
     assert not np.array_equal(res["fast"][0], res["exact"][0]), "the hook did not switch paths (two different algorithms cannot agree bit for bit)"
+
+
+def test_projection_td_factor_hook(solver, oracle, opts):
+    """ProjectionTdFactor on the device (factor level; the device solve itself does not estimate td) vs the oracle, all five blocks."""
+    import test_oracle_factors as tof
+    rng = np.random.default_rng(22)
+    for _ in range(10):
+        params, pi, pj, vi, vj, tdi, tdj, ri, rj = tof._td_case(rng, opts)
+        r, J = solver.eval_projection_td(params, pi, pj, vi, vj, tdi, tdj, ri, rj)
+        r0, J0 = oracle.eval_factor("projection_td", opts, params, pi, pj, vi, vj, tdi, tdj, ri, rj, sizes=[7, 7, 7, 1, 1], nres=2)
+        assert np.allclose(r, r0, rtol=1e-11, atol=1e-10)
+        for a, b in zip(J, J0):
+            assert np.allclose(a, b, rtol=1e-10, atol=1e-9 * max(1, np.abs(b).max()))

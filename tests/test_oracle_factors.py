@@ -305,3 +305,30 @@ def test_small_linear_algebra_vs_numpy(oracle):
         ypr = np.zeros(3); R2 = np.zeros((3, 3))
         L.vilo_R2ypr(abi.dptr(np.ascontiguousarray(R)), abi.dptr(ypr)); L.vilo_ypr2R(abi.dptr(ypr), abi.dptr(R2))
         assert np.allclose(R2, R, atol=1e-12)
+
+
+def _td_case(rng, opts):
+    Pi = np.concatenate([rng.normal(0, 1, 3), synth.q_exp(rng.normal(0, 0.3, 3))])
+    Pj = np.concatenate([Pi[:3] + rng.normal(0, 0.5, 3), synth.q_mul(Pi[3:], synth.q_exp(rng.normal(0, 0.1, 3)))])
+    ex = np.concatenate([np.array(opts.TIC[:]), synth.R_to_q(np.array(opts.RIC[:]).reshape(3, 3))])
+    lam = np.array([1.0 / rng.uniform(4, 30)]); td = np.array([rng.normal(0, 0.01)])
+    pi = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.2), 1.0]); pj = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.2, 0.2), 1.0])
+    vi, vj = rng.normal(0, 0.5, 2), rng.normal(0, 0.5, 2)
+    return [Pi, Pj, ex, lam, td], pi, pj, vi, vj, float(rng.normal(0, 0.01)), float(rng.normal(0, 0.01)), float(rng.uniform(0, 370)), float(rng.uniform(0, 370))
+
+
+def test_projection_td_factor(oracle):
+    """ProjectionTdFactor (projection_td_factor.cpp:34-141): equals ProjectionFactor for zero pixel velocity; d/dtd by finite differences."""
+    rng = np.random.default_rng(21)
+    o = oracle.default_options()
+    o.TR = 0.02
+    for _ in range(5):
+        params, pi, pj, vi, vj, tdi, tdj, ri, rj = _td_case(rng, o)
+        r, J = oracle.eval_factor("projection_td", o, params, pi, pj, vi, vj, tdi, tdj, ri, rj, sizes=[7, 7, 7, 1, 1], nres=2)
+        r0, J0 = oracle.eval_factor("projection_td", o, params, pi, pj, np.zeros(2), np.zeros(2), tdi, tdj, ri, rj, sizes=[7, 7, 7, 1, 1], nres=2)
+        rp, Jp = oracle.eval_factor("projection", o, params[:4], pi, pj, sizes=[7, 7, 7, 1], nres=2)
+        assert np.allclose(r0, rp, atol=1e-12) and all(np.allclose(a, b, atol=1e-10) for a, b in zip(J0[:4], Jp)) and np.all(J0[4] == 0)
+        eps = 1e-7
+        p2 = [x.copy() for x in params]; p2[4] = params[4] + eps
+        r2, _ = oracle.eval_factor("projection_td", o, p2, pi, pj, vi, vj, tdi, tdj, ri, rj, sizes=[7, 7, 7, 1, 1], nres=2, want_jac=False)
+        assert np.allclose((r2 - r) / eps, J[4][:, 0], rtol=1e-4, atol=1e-3)

@@ -673,6 +673,34 @@ extern "C" int vilf_eval_projection(vilf_handle *h, const double *const *p, cons
     return VILF_OK;
 }
 
+extern "C" __global__ void k_hook_projection_td(const double *in, double *out);
+extern "C" int vilf_eval_projection_td(vilf_handle *h, const double *const *p, const double pts_i[3], const double pts_j[3], const double vel_i[2], const double vel_j[2],
+                                       double td_i, double td_j, double row_i, double row_j, double *residuals, double **jac) {
+    if (!h || !p || !residuals || !pts_i || !pts_j || !vel_i || !vel_j) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 128) != VILF_OK) return VILF_ERR_DEVICE;
+    double in[40];
+    std::memcpy(in, p[0], 56); std::memcpy(in + 7, p[1], 56); std::memcpy(in + 14, p[2], 56);
+    std::memcpy(in + 21, pts_i, 24); std::memcpy(in + 24, pts_j, 24); std::memcpy(in + 27, vel_i, 16); std::memcpy(in + 29, vel_j, 16);
+    const double ROW = h->opts.ROW;
+    in[31] = p[3][0]; in[32] = p[4][0]; in[33] = td_i; in[34] = td_j; in[35] = row_i - ROW / 2; in[36] = row_j - ROW / 2;      // projection_td_factor.cpp:19-20
+    in[37] = h->opts.TR / ROW; in[38] = h->opts.focal_length / 1.5;
+    double *d = h->d[D_HOOK].as<double>();
+    HIPCHECK(h, hipMemcpyAsync(d, in, sizeof(in), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_hook_projection_td, dim3(1), dim3(64), 0, h->stream, d, d + 40);
+    double out[42];
+    HIPCHECK(h, hipMemcpyAsync(out, d + 40, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    residuals[0] = out[0]; residuals[1] = out[1];
+    if (jac) {
+        const int off[3] = {2, 14, 26};
+        for (int blk = 0; blk < 3; blk++)
+            if (jac[blk]) for (int r = 0; r < 2; r++) { for (int c = 0; c < 6; c++) jac[blk][7 * r + c] = out[off[blk] + 6 * r + c]; jac[blk][7 * r + 6] = 0; }
+        if (jac[3]) { jac[3][0] = out[38]; jac[3][1] = out[39]; }
+        if (jac[4]) { jac[4][0] = out[40]; jac[4][1] = out[41]; }
+    }
+    return VILF_OK;
+}
+
 static void pack_imu_rec(const vilf_imu_preint *p, double *rec) {
     std::memset(rec, 0, IMU_REC * 8);
     rec[0] = p->sum_dt;

@@ -173,13 +173,21 @@ VD void huber(double s, double a, double &rho0, double &sqrt_rho1) {
     else { rho0 = s; sqrt_rho1 = 1.0; }
 }
 
+// ---- ProjectionTdFactor (projection_td_factor.cpp:34-141): ProjectionFactor on observations shifted by the pixel velocity over the
+// time offset (+ rolling-shutter row time), plus the 2x1 jacobian with respect to td. row_*_c = uv.y - ROW / 2 (:19-20).
+template <bool JAC>
+VD void projection_td_eval(const double *Pi, const double *Ri, const double *Pj, const double *Rj, const double *ric, const double *tic,
+                           const double *pts_i, const double *pts_j, const double *vel_i, const double *vel_j, double td, double td_i, double td_j,
+                           double row_i_c, double row_j_c, double tr_over_row, double inv_dep, double sqrt_info,
+                           double *r, double *Ji, double *Jj, double *Jf, double *Jex, double *Jtd);
+
 // ---- ProjectionFactor (projection_factor.cpp:21-121) --------------------------------------------------
 // Ri, Rj, ric are rotation matrices of the (unit) parameter quaternions. Outputs the LOCAL (tangent) jacobians:
 // Ji, Jj: 2x6 row-major [dp | dtheta], Jf: 2x1. JAC=false: residual only.
 template <bool JAC>
 VD void projection_eval(const double *Pi, const double *Ri, const double *Pj, const double *Rj, const double *ric, const double *tic,
                         const double *pts_i, const double *pts_j, double inv_dep, double sqrt_info,
-                        double *r, double *Ji, double *Jj, double *Jf, double *Jex = nullptr) {
+                        double *r, double *Ji, double *Jj, double *Jf, double *Jex = nullptr, double *M2out = nullptr) {
     double pc_i[3] = {pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep};
     double p_imu_i[3], pw[3], d[3], p_imu_j[3], e[3], pc_j[3];
     m3_vec(ric, pc_i, p_imu_i);
@@ -211,6 +219,7 @@ VD void projection_eval(const double *Pi, const double *Ri, const double *Pj, co
             M2[j] = M[0] * Ri[j] + M[1] * Ri[3 + j] + M[2] * Ri[6 + j];
             M2[3 + j] = M[3] * Ri[j] + M[4] * Ri[3 + j] + M[5] * Ri[6 + j];
         }
+        if (M2out) for (int k = 0; k < 6; k++) M2out[k] = M2[k];       // reduce * ric^T Rj^T Ri (ProjectionTdFactor needs it for d/dtd)
         // N = reduce * ric^T
         double N[6];
 #pragma unroll
@@ -508,4 +517,23 @@ VD void se3_plus(const double *x, const double *d, double *o) {
     o[4] = rt[0] + dt[0]; o[5] = rt[1] + dt[1]; o[6] = rt[2] + dt[2];
 }
 
+
+template <bool JAC>
+VD void projection_td_eval(const double *Pi, const double *Ri, const double *Pj, const double *Rj, const double *ric, const double *tic,
+                           const double *pts_i, const double *pts_j, const double *vel_i, const double *vel_j, double td, double td_i, double td_j,
+                           double row_i_c, double row_j_c, double tr_over_row, double inv_dep, double sqrt_info,
+                           double *r, double *Ji, double *Jj, double *Jf, double *Jex, double *Jtd) {
+    const double si = td - td_i + tr_over_row * row_i_c, sj = td - td_j + tr_over_row * row_j_c;
+    const double pi_td[3] = {pts_i[0] - si * vel_i[0], pts_i[1] - si * vel_i[1], pts_i[2]};
+    const double pj_td[3] = {pts_j[0] - sj * vel_j[0], pts_j[1] - sj * vel_j[1], pts_j[2]};
+    double M2[6];
+    projection_eval<JAC>(Pi, Ri, Pj, Rj, ric, tic, pi_td, pj_td, inv_dep, sqrt_info, r, Ji, Jj, Jf, Jex, M2);
+    if (JAC) {
+        const double v3[3] = {vel_i[0], vel_i[1], 0.0};
+        double rv[3];
+        m3_vec(ric, v3, rv);
+        Jtd[0] = (M2[0] * rv[0] + M2[1] * rv[1] + M2[2] * rv[2]) / inv_dep * -1.0 + sqrt_info * vel_j[0];
+        Jtd[1] = (M2[3] * rv[0] + M2[4] * rv[1] + M2[5] * rv[2]) / inv_dep * -1.0 + sqrt_info * vel_j[1];
+    }
+}
 }  // namespace vd

@@ -1274,6 +1274,14 @@ extern "C" __global__ void k_hook_projection(const double *p0, const double *p1,
     pair_table(p0, Ri, p1, Rj, ric, p2, pt);
     projection_eval_pair<true>(pt, ric, p2, pi, pj, lam, sqrt_info, out, out + 2, out + 14, out + 26);
 }
+// in: p0 p1 p2 (poses i, j, ex) [21] | pi pj [6] | vel_i vel_j [4] | lam td td_i td_j row_i_c row_j_c tr_over_row sqrt_info [8]; out: r[2] Ji[12] Jj[12] Jex[12] Jf[2] Jtd[2]
+extern "C" __global__ void k_hook_projection_td(const double *in, double *out) {
+    if (threadIdx.x) return;
+    const double *p0 = in, *p1 = in + 7, *p2 = in + 14, *pi = in + 21, *pj = in + 24, *vi = in + 27, *vj = in + 29, *sc = in + 31;
+    double Ri[9], Rj[9], ric[9];
+    q_toR(q_load(p0 + 3), Ri); q_toR(q_load(p1 + 3), Rj); q_toR(q_load(p2 + 3), ric);
+    projection_td_eval<true>(p0, Ri, p1, Rj, ric, p2, pi, pj, vi, vj, sc[1], sc[2], sc[3], sc[4], sc[5], sc[6], sc[0], sc[7], out, out + 2, out + 14, out + 38, out + 26, out + 40);
+}
 extern "C" __global__ void k_hook_imu(const double *p0, const double *p1, const double *p2, const double *p3, const double *rec, const double *G,
                                       double *out /* r[15] (whitened) J[15*30] (whitened) */, double *scratch /* 450 + 16 */) {
     if (threadIdx.x) return;

@@ -166,6 +166,19 @@ class BackendSolver:
         self._check(self._L.vilf_eval_lidar_between(self._h, p, C.byref(c), abi.dptr(r), jp), "vilf_eval_lidar_between")
         return r, jacs
 
+    def eval_projection_td(self, params, pts_i, pts_j, vel_i, vel_j, td_i, td_j, row_i, row_j):
+        """ProjectionTdFactor::Evaluate on the device: params = [Pose_i, Pose_j, Ex_Pose, [inv depth], [td]]"""
+        arrs, p = self._params(params)
+        r = np.zeros(2)
+        jacs = [np.zeros((2, 7)), np.zeros((2, 7)), np.zeros((2, 7)), np.zeros((2, 1)), np.zeros((2, 1))]
+        jp = (abi.c_double_p * 5)(*[abi.dptr(j) for j in jacs])
+        f = lambda v: abi.dptr(np.ascontiguousarray(v, dtype=np.float64))
+        self._L.vilf_eval_projection_td.argtypes = [C.c_void_p, C.c_void_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p,
+                                                    C.c_double, C.c_double, C.c_double, C.c_double, abi.c_double_p, C.c_void_p]
+        self._check(self._L.vilf_eval_projection_td(self._h, p, f(pts_i), f(pts_j), f(vel_i), f(vel_j), float(td_i), float(td_j), float(row_i), float(row_j),
+                                                    abi.dptr(r), jp), "vilf_eval_projection_td")
+        return r, jacs
+
     def eval_prior(self, prior, params):
         """MarginalizationFactor::Evaluate (marginalization_factor.cpp:333-381) on the device: residuals [n], jacobians [n x size_i]"""
         arrs, p = self._params(params)
