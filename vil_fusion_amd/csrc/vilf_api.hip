@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <thread>
 #include "vilf_internal.hpp"
 
 #define IMU_REC 288
@@ -169,40 +170,78 @@ static int pull_device_priors(vilf_handle *h) {
     return VILF_OK;
 }
 
+// host -> device for the slots whose host mirror changed (vilf_prior_import, first upload). Slots whose prior was produced on the
+// device (marginalization) or is unchanged are left alone: in the running system the prior never crosses PCIe.
 static int upload_priors(vilf_handle *h) {
-    { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
-    h->prior_backup_valid = false;
     const int B = h->B;
-    std::vector<int> hdr((size_t)B * VB_PRIOR_HDR, 0);
-    std::vector<double> x0((size_t)B * 24 * 9, 0.0), J((size_t)B * VB_PRIOR_LD * VB_PRIOR_LD, 0.0), r((size_t)B * VB_PRIOR_LD, 0.0);
-    for (int w = 0; w < B; w++) {
+    std::vector<int> dirty;
+    for (int w = 0; w < B; w++) if (h->prior_dirty[w]) dirty.push_back(w);
+    if (dirty.empty()) return VILF_OK;
+    h->prior_backup_valid = false;
+    for (int w : dirty) {
         const vilf_prior &p = h->priors[w];
-        if (!p.valid) continue;
-        int *hd = &hdr[(size_t)w * VB_PRIOR_HDR];
+        h->prior_dev_newer[w] = 0;
+        if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > 2 * VB_NF) { h->err = "prior touches Td / feature blocks: unsupported"; return VILF_ERR_UNSUPPORTED; }
+    }
+    auto fill = [&](const vilf_prior &p, int *hd, double *x0) {
+        std::memset(hd, 0, VB_PRIOR_HDR * sizeof(int)); std::memset(x0, 0, 24 * 9 * sizeof(double));
+        if (!p.valid) return;
         hd[0] = 1; hd[1] = p.n; hd[2] = p.n_blocks; hd[75] = p.m;
         for (int i = 0; i < p.n_blocks; i++) {
             hd[3 + i] = p.block_id[i]; hd[27 + i] = p.block_size[i]; hd[51 + i] = p.block_idx[i];
-            for (int k = 0; k < 9; k++) x0[((size_t)w * 24 + i) * 9 + k] = p.block_x0[i][k];
-            if (p.block_id[i] > 2 * VB_NF) { h->err = "prior touches Td / feature blocks: unsupported"; return VILF_ERR_UNSUPPORTED; }
+            for (int k = 0; k < 9; k++) x0[i * 9 + k] = p.block_x0[i][k];
         }
-        std::memcpy(&J[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD], p.linearized_jacobians, sizeof(double) * p.n * p.n);
-        std::memcpy(&r[(size_t)w * VB_PRIOR_LD], p.linearized_residuals, sizeof(double) * p.n);
+    };
+    if ((int)dirty.size() * 4 > B) {          // most slots: one bulk copy per array
+        std::vector<int> hdr((size_t)B * VB_PRIOR_HDR, 0);
+        std::vector<double> x0((size_t)B * 24 * 9, 0.0), J((size_t)B * VB_PRIOR_LD * VB_PRIOR_LD, 0.0), r((size_t)B * VB_PRIOR_LD, 0.0);
+        if ((int)dirty.size() < B) {           // keep what the other slots hold on the device
+            { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
+            for (int w = 0; w < B; w++) h->prior_dirty[w] = 1;
+        }
+        for (int w = 0; w < B; w++) {
+            const vilf_prior &p = h->priors[w];
+            fill(p, &hdr[(size_t)w * VB_PRIOR_HDR], &x0[(size_t)w * 24 * 9]);
+            if (!p.valid) continue;
+            std::memcpy(&J[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD], p.linearized_jacobians, sizeof(double) * p.n * p.n);
+            std::memcpy(&r[(size_t)w * VB_PRIOR_LD], p.linearized_residuals, sizeof(double) * p.n);
+        }
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_PHDR].p, hdr.data(), hdr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_PX0].p, x0.data(), x0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_PJ].p, J.data(), J.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_PR].p, r.data(), r.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
+    } else {                                   // a few slots: per-slot copies
+        for (int w : dirty) {
+            const vilf_prior &p = h->priors[w];
+            int hd[VB_PRIOR_HDR]; double x0[24 * 9];
+            fill(p, hd, x0);
+            HIPCHECK(h, hipMemcpyAsync(h->d[D_PHDR].as<int>() + (size_t)w * VB_PRIOR_HDR, hd, sizeof(hd), hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(h->d[D_PX0].as<double>() + (size_t)w * 24 * 9, x0, sizeof(x0), hipMemcpyHostToDevice, h->stream));
+            if (p.valid) {
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_PJ].as<double>() + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, p.linearized_jacobians, sizeof(double) * p.n * p.n, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_PR].as<double>() + (size_t)w * VB_PRIOR_LD, p.linearized_residuals, sizeof(double) * p.n, hipMemcpyHostToDevice, h->stream));
+            }
+            HIPCHECK(h, hipStreamSynchronize(h->stream));   // hd / x0 are stack buffers
+        }
     }
-    HIPCHECK(h, hipMemcpyAsync(h->d[D_PHDR].p, hdr.data(), hdr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->d[D_PX0].p, x0.data(), x0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->d[D_PJ].p, J.data(), J.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(h->d[D_PR].p, r.data(), r.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));   // host vectors go out of scope
     hipLaunchKernelGGL(k_prior_prep, dim3(B), dim3(VB_NT), 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
     HIPCHECK(h, hipGetLastError());
-    std::fill(h->prior_dirty.begin(), h->prior_dirty.end(), 0);
+    for (int w = 0; w < B; w++) h->prior_dirty[w] = 0;
+    h->prior_slots_valid = std::max(h->prior_slots_valid, B);
     return VILF_OK;
 }
 
 extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wins) {
     if (!h || B <= 0 || !wins) return VILF_ERR_INVALID_ARGUMENT;
+    const bool timing = std::getenv("VILF_DEBUG_TIMING") != nullptr;
+    auto tnow = []() { return std::chrono::steady_clock::now(); };
+    auto t_a = tnow();
+    auto lap = [&](const char *what) { if (timing) { auto t = tnow(); fprintf(stderr, "[vilf_batch_upload] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_a).count()); t_a = t; } };
     HIPCHECK(h, hipSetDevice(h->device));
-    { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
+    // the device-resident priors of slots 0..B-1 survive this call unless the slot range grows (buffers may be re-allocated)
+    const bool keep_priors = h->resident && B <= h->prior_slots_valid;
+    if (!keep_priors) { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
     int Fmax = 4, Omax = 4, FACmax = 4;
     for (int w = 0; w < B; w++) {
         const vilf_window_in &in = wins[w];
@@ -222,8 +261,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     h->B = B;
     h->resident = false;
     if ((int)h->priors.size() < B) { vilf_prior z; std::memset(&z, 0, sizeof(z)); h->priors.resize(B, z); }
-    h->prior_dirty.assign(h->priors.size(), 1);
-    h->prior_dev_newer.assign(h->priors.size(), 0);
+    if (!keep_priors) { h->prior_dirty.assign(h->priors.size(), 1); h->prior_dev_newer.assign(h->priors.size(), 0); h->prior_slots_valid = 0; }
+    h->prior_dirty.resize(h->priors.size(), 1); h->prior_dev_newer.resize(h->priors.size(), 0);
     h->h_mflag.assign(B, 0);
     int Mcap = 2;
     for (int w = 0; w < B; w++) {
@@ -250,6 +289,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed"; return VILF_ERR_DEVICE; }
 
+    lap("validate + device buffers");
     // ---- pack on the host ---------------------------------------------------------------------------------------
     std::vector<int> nfeat(B), nfac(B), fstart(sB * sF, 0), fnobs(sB * sF, 2), fobs0(sB * sF, 0), ffac0(sB * sF, 0), facfeat(sB * sC, 0), facobs(sB * sC, 0),
         pairoff(sB * (VB_NPAIR + 1), 0), psfeat(sB * sC, 0), psobs(sB * sC, 0), psslot(sB * sC, 0);
@@ -257,7 +297,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     std::vector<double> pose(sB * 77), sb(sB * 99), feat(sB * sF, 1.0), ex(sB * 7), gR0(sB * 9), gP0(sB * 3), obs(sB * sO * 3, 0.0), imu(sB * 10 * IMU_REC, 0.0),
         lidar(sB * 10 * 7, 0.0), cov(sB * 10 * 225, 0.0);
     h->h_nfeat.assign(B, 0); h->h_ex.assign(sB * 7, 0.0); h->h_td.assign(B, 0.0);
-    for (int w = 0; w < B; w++) {
+    lap("host vectors");
+    auto pack_one = [&](int w) {        // every window writes its own slices only: packed by several host threads below
         const vilf_window_in &in = wins[w];
         const int F = in.n_features;
         nfeat[w] = F; h->h_nfeat[w] = F;
@@ -306,7 +347,17 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             if (in.lidar) { const vilf_lidar_constraint &c = in.lidar[k + 1]; double *l = &lidar[((size_t)w * 10 + k) * 7]; for (int i = 0; i < 4; i++) l[i] = c.q[i]; for (int i = 0; i < 3; i++) l[4 + i] = c.t[i]; }
             else lidar[((size_t)w * 10 + k) * 7 + 3] = 1.0;
         }
+    };
+    {
+        const int nthr = B >= 64 ? (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency())) : 1;
+        if (nthr <= 1) { for (int w = 0; w < B; w++) pack_one(w); }
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; t++) pool.emplace_back([&, t]() { for (int w = t; w < B; w += nthr) pack_one(w); });
+            for (std::thread &th : pool) th.join();
+        }
     }
+    lap("pack (threads)");
     auto up = [&](int id, const void *src, size_t bytes) { return hipMemcpyAsync(h->d[id].p, src, bytes, hipMemcpyHostToDevice, h->stream); };
     HIPCHECK(h, up(D_NFEAT, nfeat.data(), sB * 4)); HIPCHECK(h, up(D_NFAC, nfac.data(), sB * 4));
     HIPCHECK(h, up(D_POSE, pose.data(), sB * 77 * 8)); HIPCHECK(h, up(D_POSE0, pose.data(), sB * 77 * 8));
@@ -322,6 +373,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, up(D_COV, cov.data(), sB * 10 * 225 * 8));
     HIPCHECK(h, up(D_MFLAG, h->h_mflag.data(), sB * 4));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    lap("H2D copies + sync");
 
     // ---- batch descriptor -------------------------------------------------------------------------------------
     VbBatch &b = h->batch;

@@ -48,6 +48,7 @@ struct vilf_handle {
     std::vector<char> prior_dirty;
     std::vector<char> prior_dev_newer;       // slot's prior was produced on the device (marginalize) and not yet mirrored
     std::vector<int> h_mflag;
+    int prior_slots_valid = 0;               // the device prior arrays hold slots 0 .. prior_slots_valid-1 (survive a re-upload of the windows)
     bool prior_backup_valid = false;         // D_P*0 hold the priors as last uploaded
     int mg_Mcap = 0;
     VbMarg marg;
