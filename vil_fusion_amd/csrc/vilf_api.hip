@@ -107,7 +107,8 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     else { if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return VILF_ERR_DEVICE; } h->own_stream = true; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + 512 + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
-    h->lin_lds = (size_t)(2 * VB_CHUNK * VB_XLD + VB_NPAIR * VB_PAIRD) * sizeof(double);
+    h->lin_lds = (size_t)VB_LIN_LDS_DOUBLES * sizeof(double);
+    static_assert(VB_LIN_LDS_DOUBLES >= 10 * 512, "IMU staging area");
     h->marg_lds_schur = (size_t)MG_MLDS * MG_MLDS * sizeof(double);
     h->marg_lds_finish = (size_t)(MG_NK + 2) * (MG_NK + 2) * sizeof(double);
     if (hipFuncSetAttribute((const void *)k_marg_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_schur) != hipSuccess ||
@@ -285,7 +286,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
         {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_DIAGH, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
         {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
-        {D_OBGS, sB * 33 * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
+        {D_OBGS, sB * 33 * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8}, {D_FACREC, sB * sC * 64}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed"; return VILF_ERR_DEVICE; }
 
@@ -295,7 +296,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         pairoff(sB * (VB_NPAIR + 1), 0), psfeat(sB * sC, 0), psobs(sB * sC, 0), psslot(sB * sC, 0);
     std::vector<uint8_t> fconst(sB * sF, 1);
     std::vector<double> pose(sB * 77), sb(sB * 99), feat(sB * sF, 1.0), ex(sB * 7), gR0(sB * 9), gP0(sB * 3), obs(sB * sO * 3, 0.0), imu(sB * 10 * IMU_REC, 0.0),
-        lidar(sB * 10 * 7, 0.0), cov(sB * 10 * 225, 0.0);
+        lidar(sB * 10 * 7, 0.0), cov(sB * 10 * 225, 0.0), facrec(sB * sC * 8, 0.0);
     h->h_nfeat.assign(B, 0); h->h_ex.assign(sB * 7, 0.0); h->h_td.assign(B, 0.0);
     lap("host vectors");
     auto pack_one = [&](int w) {        // every window writes its own slices only: packed by several host threads below
@@ -333,6 +334,12 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             const int s = in.feature_start_frame[f], j = s + (t - in.feature_obs_offset[f]);
             const int pos = cur[j * (j - 1) / 2 + s]++;
             psfeat[(size_t)w * sC + pos] = f; psobs[(size_t)w * sC + pos] = t; psslot[(size_t)w * sC + pos] = q;
+            double *rec = &facrec[((size_t)w * sC + pos) * 8];
+            const double *pi = in.obs_point + 3 * (size_t)in.feature_obs_offset[f], *pj = in.obs_point + 3 * (size_t)t;
+            for (int k = 0; k < 3; k++) { rec[k] = pi[k]; rec[3 + k] = pj[k]; }
+            const unsigned long long a = (unsigned long long)(unsigned)f | ((unsigned long long)(unsigned)q << 32);
+            const unsigned long long b2 = (unsigned long long)s | ((unsigned long long)j << 8) | ((unsigned long long)(in.feature_const[f] ? 1 : 0) << 16);
+            std::memcpy(&rec[6], &a, 8); std::memcpy(&rec[7], &b2, 8);
         }
         for (int k = 0; k < 10; k++) {
             const vilf_imu_preint &p = in.imu[k + 1];
@@ -369,6 +376,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, up(D_FCONST, fconst.data(), sB * sF)); HIPCHECK(h, up(D_OBS, obs.data(), sB * sO * 3 * 8));
     HIPCHECK(h, up(D_PSFEAT, psfeat.data(), sB * sC * 4)); HIPCHECK(h, up(D_PSOBS, psobs.data(), sB * sC * 4)); HIPCHECK(h, up(D_PSSLOT, psslot.data(), sB * sC * 4));
     HIPCHECK(h, up(D_PAIROFF, pairoff.data(), sB * (VB_NPAIR + 1) * 4));
+    HIPCHECK(h, up(D_FACREC, facrec.data(), sB * sC * 64));
     HIPCHECK(h, up(D_IMU, imu.data(), sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar.data(), sB * 10 * 7 * 8));
     HIPCHECK(h, up(D_COV, cov.data(), sB * 10 * 225 * 8));
     HIPCHECK(h, up(D_MFLAG, h->h_mflag.data(), sB * 4));
@@ -399,12 +407,12 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.f_start = h->d[D_FSTART].as<int>(); b.f_nobs = h->d[D_FNOBS].as<int>(); b.f_obs0 = h->d[D_FOBS0].as<int>(); b.f_fac0 = h->d[D_FFAC0].as<int>();
     b.f_const = h->d[D_FCONST].as<uint8_t>(); b.obs = h->d[D_OBS].as<double>();
     b.ps_feat = h->d[D_PSFEAT].as<int>(); b.ps_obs = h->d[D_PSOBS].as<int>(); b.ps_slot = h->d[D_PSSLOT].as<int>();
-    b.pair_off = h->d[D_PAIROFF].as<int>();
+    b.pair_off = h->d[D_PAIROFF].as<int>(); b.facrec = h->d[D_FACREC].as<double>();
     b.imu = h->d[D_IMU].as<double>(); b.lidar = h->d[D_LIDAR].as<double>();
     b.prior_hdr = h->d[D_PHDR].as<int>(); b.prior_x0 = h->d[D_PX0].as<double>(); b.prior_J = h->d[D_PJ].as<double>(); b.prior_r = h->d[D_PR].as<double>();
     b.prior_H = h->d[D_PH].as<double>(); b.prior_g = h->d[D_PG].as<double>();
     b.facw = h->d[D_FACW].as<double>(); b.Hpp = h->d[D_HPP].as<double>(); b.W = h->d[D_W].as<double>(); b.hf = h->d[D_HF].as<double>(); b.gf = h->d[D_GF].as<double>();
-    b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>(); b.diagH = h->d[D_DIAGH].as<double>();
+    b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>(); b.diagH = h->d[D_DIAGH].as<double>(); b.pairD = h->d[D_PAIRD].as<double>();
     b.scale = h->d[D_SCALE].as<double>(); b.diag = h->d[D_DIAG].as<double>(); b.grad = h->d[D_GRAD].as<double>(); b.gn = h->d[D_GN].as<double>();
     b.st = h->d[D_ST].as<VbState>();
     b.out_Ps = h->d[D_OPS].as<double>(); b.out_Rs = h->d[D_ORS].as<double>(); b.out_Vs = h->d[D_OVS].as<double>();

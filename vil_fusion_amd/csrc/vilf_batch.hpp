@@ -25,8 +25,10 @@
 #define VB_PAIRD 120        // per pair: JjJj(36) JjJi(36) JiJi(36) Jj^T r(6) Ji^T r(6)
 #define VB_FACW 8           // per-factor Schur partials
 #define VB_WLD 80           // row stride of W: 66 pose columns, column 66 = g_f, 67..79 zero (5 MFMA column tiles)
-#define VB_XLD 17           // LDS row stride (doubles) of the factor chunk [Jj(6) Ji(6) r pad]
-#define VB_CHUNK 256        // factors per LDS chunk (one per thread)
+#define VB_XLD 13           // LDS row stride (doubles) of the factor chunk [Jj(6) Ji(6) r]; the MFMA operand load masks columns 13..15
+#define VB_CHUNK 224        // factors per LDS chunk (one per thread, threads 224..255 sit the evaluation out): 448 rows x 13 doubles = 46.6 KB
+                            // -> k_linearize needs < 80 KB of LDS and two workgroups share a CU
+#define VB_LIN_LDS_DOUBLES (2 * VB_CHUNK * VB_XLD + 8)   // >= 10 * 512 (the IMU staging area that precedes the chunk loop)
 #define VB_NT 256           // threads per window workgroup
 #define VB_NTILE 11         // 16x16 tiles per dimension (176 padded)
 #define VB_NPAD 176
@@ -100,12 +102,15 @@ struct VbBatch {
     const double *obs;
     const int *ps_feat, *ps_obs, *ps_slot;
     const int *pair_off;
+    const double *facrec;   // [B][FACmax][8]: per pair-sorted factor {pts_i[3], pts_j[3], (feature | slot << 32), (frame_i | frame_j << 8 | const << 16)} — one
+                            // coalesced 64-byte record instead of five dependent gathers
     const double *imu, *lidar;
     const int *lut_imu, *lut_lid, *lut_vis;   // static scatter tables: source element -> LDS tile offset (or -1)
     const int *prior_hdr;
     const double *prior_x0, *prior_J, *prior_r, *prior_H, *prior_g;
     // workspace
     double *facw, *Hpp, *W, *hf, *gf, *imuH, *imug, *lidH, *lidg, *g;
+    double *pairD;          // [B][55][120] per-frame-pair visual products (accumulated over the factor chunks; L2-resident)
     double *diagH;          // [B][165] diagonal of the (unscaled) reduced system, frame-major (Jacobi scaling / dogleg diagonal)
     double *scale, *diag, *grad, *gn;
     VbState *st;

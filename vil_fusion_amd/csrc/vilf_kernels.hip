@@ -182,13 +182,15 @@ __device__ double prior_cost_partial(const VbBatch &b, int w, const double *s_dx
 // ------------------------------------------------------------------------------------------------------------------
 // k_linearize
 //
-// LDS plan (dynamic): s_X  [2*VB_CHUNK rows][VB_XLD]  the chunk of robustified factor rows [Jj(6) | Ji(6) | r | 0 0 0]
-//                     s_U  union { IMU stage: 10 x [16 rows][32 cols] = [S*Jraw | S*r | 0] ;  pairD: 55 x 120 }
+// LDS plan (dynamic, one 46.6 KB region; with the static arrays the kernel stays under 80 KB => two workgroups per CU):
+//                     s_U  IMU stage: 10 x [16 rows][32 cols] = [S*Jraw | S*r | 0], then the same region becomes
+//                     s_X  [2*VB_CHUNK rows][VB_XLD]  the chunk of robustified factor rows [Jj(6) | Ji(6) | r]
+// pairD (55 x 120 per-frame-pair products) is accumulated in global memory (L2-resident, 53 KB per window).
 // Factors arrive SORTED BY FRAME PAIR (host), so each pair's rows are contiguous in a chunk and
 //   [Jj Ji r]^T [Jj Ji r]  (13 x 13: JjJj, JjJi, JiJi, Jj^T r, Ji^T r)
 // is one v_mfma_f64_16x16x4_f64 accumulation per 4 rows: the block-sparse J^T J / J^T r accumulate on the matrix cores,
 // deterministic (each pair is owned by one wave, fixed order).
-#define LIN_LDS_DOUBLES (2 * VB_CHUNK * VB_XLD + VB_NPAIR * VB_PAIRD)
+#define LIN_LDS_DOUBLES VB_LIN_LDS_DOUBLES
 
 __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the 16x16 X^T X tile -> slot in pairD (or -1)
     if (row < 6) {
@@ -211,7 +213,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 
     extern __shared__ double s_dyn[];
     double *s_X = s_dyn;
-    double *s_U = s_X + 2 * VB_CHUNK * VB_XLD;
+    double *s_U = s_dyn;                      // the IMU staging area (10 x 512) shares the region with the factor chunk that follows it
+    double *pd = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3];
     __shared__ double s_lidJ[10 * 72], s_lidr[64], s_grad[176];
     __shared__ double s_pt[VB_NPAIR * PT_LD];
@@ -324,15 +327,12 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     }
     if (tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
     cost_local += prior_cost_partial(b, w, s_dx, tid);
-    __syncthreads();
-    for (int i = tid; i < VB_NPAIR * VB_PAIRD; i += NT) s_U[i] = 0.0;     // s_U becomes pairD
-    __syncthreads();
+    __syncthreads();                                                       // the IMU staging area is dead: the region becomes s_X
     STAMP(0, 4);
     // ---- visual factors: chunks of 256 pair-sorted factors -> LDS rows -> MFMA X^T X per pair ------------------------
-    const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
+    const int *f_start = b.f_start + (size_t)w * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
-    const int *ps_feat = b.ps_feat + (size_t)w * FC, *ps_obs = b.ps_obs + (size_t)w * FC, *ps_slot = b.ps_slot + (size_t)w * FC;
-    const double *obs = b.obs + (size_t)w * b.Omax * 3;
+    const double *facrec = b.facrec + (size_t)w * FC * 8;
     double *facw = b.facw + (size_t)w * VB_FACW * FC;
     double *W = b.W + (size_t)w * FM * VB_WLD;
     long long t_eval = 0, t_sync1 = 0, t_mfma = 0, t_sync2 = 0, t_a = 0;
@@ -342,33 +342,38 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
         t_a = __builtin_readcyclecounter();
         const int q = c0 + tid;
-        double *x0 = s_X + (2 * tid) * VB_XLD, *x1 = x0 + VB_XLD;
-        if (q < nfac) {
-            const int f = ps_feat[q], oj = ps_obs[q], slot = ps_slot[q];
-            const int fi = f_start[f], o0 = f_obs0[f], fj = fi + (oj - o0);
+        double *x0 = s_X + (2 * min(tid, VB_CHUNK - 1)) * VB_XLD, *x1 = x0 + VB_XLD;
+        if (tid >= VB_CHUNK) {
+        } else if (q < nfac) {
+            // one coalesced 64-byte record per factor (points, feature, slot, frames, const flag); only the inverse depth is a gather
+            const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)q * 8);
+            const double4_t ra = rp[0], rb = rp[1];
+            const double pts_i[3] = {ra[0], ra[1], ra[2]}, pts_j[3] = {ra[3], rb[0], rb[1]};
+            const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
+            const int f = (int)(ia & 0xffffffffu), slot = (int)(ia >> 32), fi = (int)(ib & 0xff), fj = (int)((ib >> 8) & 0xff);
+            const bool fc = ((ib >> 16) & 1) != 0;
             double r[2], Ji[12], Jj[12], Jf[2];
-            projection_eval_pair<true>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, obs + 3 * o0, obs + 3 * oj, feat[f], b.sqrt_info, r, Ji, Jj, Jf);
+            projection_eval_pair<true>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, pts_i, pts_j, feat[f], b.sqrt_info, r, Ji, Jj, Jf);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             cost_local += 0.5 * rho0;
 #pragma unroll
             for (int c = 0; c < 6; c++) { x0[c] = sw * Jj[c]; x0[6 + c] = sw * Ji[c]; x1[c] = sw * Jj[6 + c]; x1[6 + c] = sw * Ji[6 + c]; }
             x0[12] = sw * r[0]; x1[12] = sw * r[1];
-            x0[13] = 0; x0[14] = 0; x0[15] = 0; x1[13] = 0; x1[14] = 0; x1[15] = 0;
-            if (!f_const[f]) {
+            if (!fc) {
                 const double jf0 = sw * Jf[0], jf1 = sw * Jf[1];
                 double *Wr = W + (size_t)f * VB_WLD + 6 * fj;
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
                     Wr[c] = x0[c] * jf0 + x1[c] * jf1;                                 // H_pf block of frame j (exclusive owner)
-                    facw[(size_t)c * FC + slot] = x0[6 + c] * jf0 + x1[6 + c] * jf1;   // partial of the anchor-frame block
+                    facw[(size_t)slot * VB_FACW + c] = x0[6 + c] * jf0 + x1[6 + c] * jf1;   // partial of the anchor-frame block (one 64-byte record per factor)
                 }
-                facw[(size_t)6 * FC + slot] = jf0 * jf0 + jf1 * jf1;
-                facw[(size_t)7 * FC + slot] = jf0 * x0[12] + jf1 * x1[12];
+                facw[(size_t)slot * VB_FACW + 6] = jf0 * jf0 + jf1 * jf1;
+                facw[(size_t)slot * VB_FACW + 7] = jf0 * x0[12] + jf1 * x1[12];
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 16; c++) { x0[c] = 0; x1[c] = 0; }
+            for (int c = 0; c < VB_XLD; c++) { x0[c] = 0; x1[c] = 0; }
         }
         { long long t_b = __builtin_readcyclecounter(); t_eval += t_b - t_a; t_a = t_b; }
         __syncthreads();
@@ -383,8 +388,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int row = r0 + 4 * u + (lane >> 4);
-                    const double v = s_X[min(row, 2 * VB_CHUNK - 1) * VB_XLD + (lane & 15)];
-                    a[u] = (row < r_hi) ? v : 0.0;
+                    const double v = s_X[min(row, 2 * VB_CHUNK - 1) * VB_XLD + (lane & 15)];      // columns 13..15 read into the next row: masked
+                    a[u] = (row < r_hi && (lane & 15) < VB_XLD) ? v : 0.0;
                 }
             };
             double a[4], an[4];
@@ -398,11 +403,13 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #pragma unroll
                 for (int u = 0; u < 4; u++) a[u] = an[u];
             }
+            // pairD lives in global memory (L2): the first chunk of a pair writes, later chunks of the same pair (same wave) add
+            const bool first = __builtin_amdgcn_readfirstlane(s_poff[p]) >= c0;
             double old4[4];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) old4[q4] = s_U[p * VB_PAIRD + max(pe[q4], 0)];
+            for (int q4 = 0; q4 < 4; q4++) old4[q4] = pd[p * VB_PAIRD + max(pe[q4], 0)];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) s_U[p * VB_PAIRD + pe[q4]] = old4[q4] + (acc[q4] + acc1[q4]);
+            for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = (first ? 0.0 : old4[q4]) + (acc[q4] + acc1[q4]);
         }
         { long long t_b = __builtin_readcyclecounter(); t_mfma += t_b - t_a; t_a = t_b; }
         __syncthreads();
@@ -411,6 +418,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
     STAMP(0, 5);
     // ---- visual pose-pose blocks (frame-block lower triangle) -> Hpp[66][36] ------------------------------------------
+    // a pair without factors was never written: it reads as zero
+#define PD(p, e) ((s_poff[(p) + 1] > s_poff[(p)]) ? pd[(p) * VB_PAIRD + (e)] : 0.0)
     {
         double *Hpp = b.Hpp + (size_t)w * 66 * 36;
         for (int t = tid; t < 66 * 36; t += NT) {
@@ -419,9 +428,9 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             const int bb = blk - a * (a + 1) / 2;
             double s = 0;
             if (a == bb) {
-                for (int i = 0; i < a; i++) s += s_U[pair_index(i, a) * VB_PAIRD + e];
-                for (int j = a + 1; j < VB_NF; j++) s += s_U[pair_index(a, j) * VB_PAIRD + 72 + e];
-            } else s = s_U[pair_index(bb, a) * VB_PAIRD + 36 + e];
+                for (int i = 0; i < a; i++) s += PD(pair_index(i, a), e);
+                for (int j = a + 1; j < VB_NF; j++) s += PD(pair_index(a, j), 72 + e);
+            } else s = PD(pair_index(bb, a), 36 + e);
             Hpp[t] = s;
         }
     }
@@ -436,7 +445,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int t = 0; t < n; t++) {
 #pragma unroll
-                for (int c = 0; c < 8; c++) acc[c] += facw[(size_t)c * FC + f0 + t];
+                for (int c = 0; c < 8; c++) acc[c] += facw[(size_t)(f0 + t) * VB_FACW + c];
             }
             double *Wr = W + (size_t)f * VB_WLD;
 #pragma unroll
@@ -455,8 +464,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         const double *imug = b.imug + (size_t)w * 300, *lidg = b.lidg + (size_t)w * 120;
         double s = 0;
         if (l < 6) {
-            for (int i = 0; i < a; i++) s += s_U[pair_index(i, a) * VB_PAIRD + 108 + l];
-            for (int j = a + 1; j < VB_NF; j++) s += s_U[pair_index(a, j) * VB_PAIRD + 114 + l];
+            for (int i = 0; i < a; i++) s += PD(pair_index(i, a), 108 + l);
+            for (int j = a + 1; j < VB_NF; j++) s += PD(pair_index(a, j), 114 + l);
             if (a >= 1) s += lidg[12 * (a - 1) + 6 + l];
             if (a <= 9) s += lidg[12 * a + l];
         }
@@ -476,8 +485,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         const double *imuHg = b.imuH + (size_t)w * 9000, *lidHg = b.lidH + (size_t)w * 1440;
         double dg = 0;
         if (l < 6) {
-            for (int i = 0; i < a; i++) dg += s_U[pair_index(i, a) * VB_PAIRD + 7 * l];
-            for (int j = a + 1; j < VB_NF; j++) dg += s_U[pair_index(a, j) * VB_PAIRD + 72 + 7 * l];
+            for (int i = 0; i < a; i++) dg += PD(pair_index(i, a), 7 * l);
+            for (int j = a + 1; j < VB_NF; j++) dg += PD(pair_index(a, j), 72 + 7 * l);
             if (a >= 1) dg += lidHg[144 * (a - 1) + 13 * (6 + l)];
             if (a <= 9) dg += lidHg[144 * a + 13 * l];
         }
@@ -1144,14 +1153,15 @@ extern "C" __global__ __launch_bounds__(NT) void k_step(VbBatch b) {
     __syncthreads();
     double cost_local = 0;
     {
-        const int *f_start = b.f_start + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM;
-        const int *fac_feat = b.ps_feat + (size_t)w * FC, *fac_obs = b.ps_obs + (size_t)w * FC;
-        const double *obs = b.obs + (size_t)w * b.Omax * 3;
+        const double *facrec = b.facrec + (size_t)w * FC * 8;
         for (int fac = tid; fac < nfac; fac += NT) {
-            const int f = fac_feat[fac], oj = fac_obs[fac];
-            const int fi = f_start[f], o0 = f_obs0[f], fj = fi + (oj - o0);
+            const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)fac * 8);
+            const double4_t ra = rp[0], rb = rp[1];
+            const double pts_i[3] = {ra[0], ra[1], ra[2]}, pts_j[3] = {ra[3], rb[0], rb[1]};
+            const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
+            const int f = (int)(ia & 0xffffffffu), fi = (int)(ib & 0xff), fj = (int)((ib >> 8) & 0xff);
             double r[2];
-            projection_eval_pair<false>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, obs + 3 * o0, obs + 3 * oj, cfeat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);
+            projection_eval_pair<false>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, pts_i, pts_j, cfeat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             cost_local += 0.5 * rho0;
