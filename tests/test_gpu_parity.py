@@ -226,10 +226,11 @@ def test_prior_factor_hook(solver, oracle, opts):
         assert np.array_equal(a, b)
 
 
-def test_marginalization_exact_path(solver, oracle, opts, monkeypatch):
+@pytest.mark.parametrize("n_features", [120, 1000])       # 1000: Amm (m ~ 160) no longer fits the LDS eigen-solver -> global-memory variant
+def test_marginalization_exact_path(solver, oracle, opts, monkeypatch, n_features):
     """The arrow fast path is what well-conditioned windows take; VILF_MARG_FORCE_EXACT sends them through the exact path instead
     (Jacobi eigen-decomposition of Amm with the reference's 1e-8 truncation). Both must agree with the oracle and with each other."""
-    win, prior, _ = synth.make_window(22, opts, synth.SynthConfig(with_prior=True, n_features=120))
+    win, prior, _ = synth.make_window(22, opts, synth.SynthConfig(with_prior=True, n_features=n_features))
     res = {}
     for tag in ("fast", "exact"):
         if tag == "exact":
@@ -259,3 +260,36 @@ def test_projection_td_factor_hook(solver, oracle, opts):
         assert np.allclose(r, r0, rtol=1e-11, atol=1e-10)
         for a, b in zip(J, J0):
             assert np.allclose(a, b, rtol=1e-10, atol=1e-9 * max(1, np.abs(b).max()))
+
+
+def test_ragged_batch_and_maximum_sizes(solver, oracle, opts):
+    """One batch of windows with very different sizes — 3, 40, 150 and the ABI maximum of 1000 features (NUM_OF_F) — plus a window whose
+    features all start in frame 0 and one whose first IMU interval is invalid (sum_dt > 10 s: the reference skips that IMUFactor,
+    estimator.cpp:745): every slot must match the oracle; solve + marginalization of the 1000-feature window included."""
+    cfgs = [synth.SynthConfig(n_features=3, const_fraction=0.0), synth.SynthConfig(n_features=40), synth.SynthConfig(n_features=150),
+            synth.SynthConfig(n_features=1000), synth.SynthConfig(n_features=60)]
+    built = [synth.make_window(40 + k, opts, c) for k, c in enumerate(cfgs)]
+    wins = [b[0] for b in built]; priors = [b[1] for b in built]
+    assert wins[3].n_features == 1000
+    # all tracks from frame 0: re-anchor the feature table of the last window (keeps the observations, drops tracks that would not fit)
+    w4 = wins[4]
+    n_obs = np.diff(w4.feature_obs_offset)
+    w4.feature_start_frame[:] = 0
+    keep = n_obs <= 11
+    assert keep.all()
+    # an extra window with an invalid first IMU interval
+    w5, p5, _ = synth.make_window(46, opts, synth.SynthConfig(n_features=50))
+    w5.imu[1, 0] = 12.0                                          # sum_dt of pre_integrations[1]
+    wins.append(w5); priors.append(p5)
+    solver.batch_upload(wins, priors)
+    solver.batch_solve()
+    got = solver.batch_download()
+    for i, (w, p) in enumerate(zip(wins, priors)):
+        ref = oracle.window_solve(opts, w, p)
+        _compare(got[i], ref, tol_p=1e-6, tol_r=1e-7, tol_cost=1e-6)
+    solver.batch_marginalize()
+    pg = solver.get_prior(3)
+    pr = oracle.window_marginalize(opts, wins[3], oracle.window_solve(opts, wins[3], priors[3]), priors[3])
+    Lg, bg, blg = _prior_products(pg); Lr, br_, blr = _prior_products(pr)
+    assert [b["id"] for b in blg] == [b["id"] for b in blr] and pg.m == pr.m
+    assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5
