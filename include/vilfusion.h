@@ -275,6 +275,13 @@ int vilf_scan2map_batch_rewind(vilf_handle *h);                         /* ... a
 int vilf_scan2map_batch_results(vilf_handle *h, int first, int n, vilf_scan2map_result *res);
 int vilf_scan2map_batch_get_map(vilf_handle *h, int stream, int which, float *xyzi_out, int capacity, int *n_out);
 
+/* ---- LiDAR feature extraction (≙ featureExtraction::extractFeature, feature_tracker/include/featureExtraction.hpp:54-232) ----
+ * raw scan (xyzi, firing order) -> edge / surf feature clouds, the inputs of vilf_scan2map_*: ring assignment from the vertical
+ * angle (n_scans 16 / 32 / 64), per-ring 10-neighbour curvature, six sectors per ring, <= 20 edge picks per sector with +-5
+ * neighbour suppression, the remaining points as surf. Outputs are truncated to the capacities; the counts are always complete. */
+int vilf_lidar_extract_features(vilf_handle *h, const float *xyzi, int n_points, int n_scans, double min_range, double max_range,
+                                double edge_threshold, float *edge_xyzi_out, int cap_edge, int *n_edge,
+                                float *surf_xyzi_out, int cap_surf, int *n_surf);
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,9 @@ int vilo_s2m_set_pose(vilo_s2m *s, const double pose_qt[7], const double pose_la
 int vilo_knn5_bruteforce(const float *map_xyzi, int n_map, const float *query_xyz3, int n_query, int *idx5, float *sqdist5);
 /* PCL VoxelGrid (centroid per leaf) restatement */
 int vilo_voxel_grid(const float *xyzi, int n, float leaf, float *out_xyzi, int capacity, int *n_out);
+/* featureExtraction::extractFeature (featureExtraction.hpp:54-232): raw scan -> edge / surf feature clouds */
+int vilo_extract_features(const float *xyzi, int n, int n_scans, double min_range, double max_range, double edge_threshold,
+                          float *edge_out, int cap_edge, int *n_edge, float *surf_out, int cap_surf, int *n_surf);
 /* association products for one query set at a given pose (EdgeCostFactor / SurfCostFactor :117-232) */
 int vilo_s2m_associate_edge(const float *map_xyzi, int n_map, const float *pts_xyzi, int n_pts, const double pose_qt[7],
                             unsigned char *valid, double *point_a /*[n][3]*/, double *point_b /*[n][3]*/);

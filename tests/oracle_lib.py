@@ -144,3 +144,17 @@ class OracleS2M:
 
     def set_pose(self, pose, pose_last):
         self.L.vilo_s2m_set_pose(self.h, abi.dptr(np.ascontiguousarray(pose, dtype=np.float64)), abi.dptr(np.ascontiguousarray(pose_last, dtype=np.float64)))
+
+
+def extract_features(xyzi, n_scans=64, min_range=3.0, max_range=100.0, edge_threshold=0.1):
+    """featureExtraction::extractFeature on the oracle: (edge_xyzi, surf_xyzi)"""
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.vilo_extract_features.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, fp, C.c_int, C.POINTER(C.c_int), fp, C.c_int, C.POINTER(C.c_int)]
+    a = np.ascontiguousarray(xyzi, dtype=np.float32)
+    n = len(a)
+    e = np.zeros((max(n, 1), 4), dtype=np.float32); s = np.zeros((max(n, 1), 4), dtype=np.float32)
+    ne, ns = C.c_int(0), C.c_int(0)
+    rc = L.vilo_extract_features(a.ctypes.data_as(fp), n, n_scans, min_range, max_range, edge_threshold, e.ctypes.data_as(fp), n, C.byref(ne), s.ctypes.data_as(fp), n, C.byref(ns))
+    assert rc == 0, rc
+    return e[:ne.value].copy(), s[:ns.value].copy()

@@ -33,6 +33,7 @@ enum {
 };
 
 struct S2B;
+struct FeatCtx;
 
 struct vilf_handle {
     vilf_options opts;
@@ -68,6 +69,7 @@ struct vilf_handle {
     long s2m_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     double last_solve_usec = 0;
     size_t solve_lds = 0, lin_lds = 0;
+    FeatCtx *feat = nullptr;                 // LiDAR feature extraction workspace (vilf_feat.hip)
     S2B *s2m = nullptr, *s2b = nullptr;      // scan-to-map state: single stream / batched streams (vilf_s2m.hip)
 };
 
@@ -82,3 +84,4 @@ struct vilf_handle {
 
 
 void vilf_s2m_release(vilf_handle *h);
+void vilf_feat_release(vilf_handle *h);

@@ -298,3 +298,26 @@ class Scan2MapBatch:
         out = np.zeros((max(n.value, 1), 4), dtype=np.float32)
         self.s._check(self._L.vilf_scan2map_batch_get_map(self.s._h, stream, which, out.ctypes.data_as(C.POINTER(C.c_float)), n.value, C.byref(n)), "vilf_scan2map_batch_get_map")
         return out[:n.value]
+
+
+class FeatureExtraction:
+    """Host mirror of featureExtraction (feature_tracker/include/featureExtraction.hpp): extractFeature(raw scan) -> (edge, surf)
+    over the device path. Parameters ≙ initParam (:43-52; velodyne_param_64.yaml)."""
+
+    def __init__(self, solver, n_scans=64, min_range=3.0, max_range=100.0, edge_threshold=0.1):
+        self.s, self._L = solver, solver._L
+        self.n_scans, self.min_range, self.max_range, self.edge_threshold = int(n_scans), float(min_range), float(max_range), float(edge_threshold)
+        fp = C.POINTER(C.c_float)
+        self._L.vilf_lidar_extract_features.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, fp, C.c_int, C.POINTER(C.c_int),
+                                                        fp, C.c_int, C.POINTER(C.c_int)]
+
+    def extractFeature(self, cloud_xyzi):
+        a = np.ascontiguousarray(cloud_xyzi, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] == 4
+        n = len(a)
+        fp = C.POINTER(C.c_float)
+        e = np.zeros((max(n, 1), 4), dtype=np.float32); s = np.zeros((max(n, 1), 4), dtype=np.float32)
+        ne, ns = C.c_int(0), C.c_int(0)
+        self.s._check(self._L.vilf_lidar_extract_features(self.s._h, a.ctypes.data_as(fp), n, self.n_scans, self.min_range, self.max_range, self.edge_threshold,
+                                                          e.ctypes.data_as(fp), n, C.byref(ne), s.ctypes.data_as(fp), n, C.byref(ns)), "vilf_lidar_extract_features")
+        return e[:ne.value].copy(), s[:ns.value].copy()

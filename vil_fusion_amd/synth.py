@@ -371,7 +371,10 @@ class LidarScene:
         self.half, self.h = half, sensor_height
         self.poles = np.column_stack([rng.uniform(-half * 0.9, half * 0.9, n_poles), rng.uniform(-half * 0.9, half * 0.9, n_poles)])
         self.pole_r = rng.uniform(0.1, 0.25, n_poles)
-        el = np.deg2rad(np.linspace(-24.8, 2.0, rings))
+        if rings == 64:      # HDL-64E: 1/3 deg spacing above -8.83 deg, 1/2 deg below — the model featureExtraction.hpp:92-101 inverts
+            el = np.deg2rad(np.array([2.0 - r / 3.0 if r <= 32 else -8.83 - (r - 32) / 2.0 for r in range(64)]))
+        else:
+            el = np.deg2rad(np.linspace(-24.8, 2.0, rings))
         az = np.linspace(-np.pi, np.pi, azimuths, endpoint=False)
         E, A = np.meshgrid(el, az, indexing="ij")
         self.dirs = np.stack([np.cos(E) * np.cos(A), np.cos(E) * np.sin(A), np.sin(E)], -1).reshape(-1, 3)
@@ -414,6 +417,37 @@ class LidarScene:
         mk = lambda idx: np.ascontiguousarray(np.column_stack([pts_l[idx], np.ones(idx.size)]).astype(np.float32))
         return mk(e_idx), mk(s_idx)
 
+
+    def scan_raw(self, R_wl, t_wl):
+        """ray-cast one full scan; returns every valid return (xyzi float32, LiDAR frame) in firing order (ring-major, azimuth
+        ascending) — the input of the LOAM feature extraction (featureExtraction.hpp)."""
+        rng = self.rng
+        d = self.dirs @ R_wl.T
+        o = t_wl
+        n = d.shape[0]
+        best = np.full(n, np.inf)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tg = (0.0 - o[2]) / d[:, 2]
+            ok = (tg > 0) & (tg < best); best[ok] = tg[ok]
+            for axis in (0, 1):
+                for sgn in (-1.0, 1.0):
+                    tw = (sgn * self.half - o[axis]) / d[:, axis]
+                    hit = o + tw[:, None] * d
+                    ok = (tw > 0) & (tw < best) & (hit[:, 2] > 0) & (hit[:, 2] < 12.0) & (np.abs(hit[:, 1 - axis]) <= self.half)
+                    best[ok] = tw[ok]
+            dxy2 = d[:, 0] ** 2 + d[:, 1] ** 2
+            for (px, py), r in zip(self.poles, self.pole_r):
+                ox, oy = o[0] - px, o[1] - py
+                bq = ox * d[:, 0] + oy * d[:, 1]
+                disc = bq * bq - dxy2 * (ox * ox + oy * oy - r * r)
+                tc = (-bq - np.sqrt(np.where(disc > 0, disc, np.nan))) / dxy2
+                z = o[2] + tc * d[:, 2]
+                ok = (disc > 0) & (tc > 0) & (tc < best) & (z > 0) & (z < 8.0)
+                best[ok] = tc[ok]
+        ok = np.isfinite(best) & (best > self.min_range) & (best < self.max_range)
+        pts = self.dirs * (best + rng.normal(0, self.noise, n))[:, None]
+        idx = np.where(ok)[0]
+        return np.ascontiguousarray(np.column_stack([pts[idx], np.ones(idx.size)]).astype(np.float32))
 
     def sample_map(self, R_wl, t_wl, ground_step=0.8, wall_step=0.8, pole_dz=0.25, pole_az=1, noise=0.02):
         """A dense local map of the scene as a long mapping run would have accumulated it (ground lattice, walls, pole surfaces),
