@@ -282,6 +282,10 @@ int vilf_scan2map_batch_get_map(vilf_handle *h, int stream, int which, float *xy
 int vilf_lidar_extract_features(vilf_handle *h, const float *xyzi, int n_points, int n_scans, double min_range, double max_range,
                                 double edge_threshold, float *edge_xyzi_out, int cap_edge, int *n_edge,
                                 float *surf_xyzi_out, int cap_surf, int *n_surf);
+/* LiDAR depth of the tracked visual features ≙ getFeatureDepth (feature_tracker/feature_tracker_node.cpp:54-163): depth cloud in the
+ * camera frame (xyzi), features as normalised image points (x, y, z = 1); depth_out[i] = depth of feature i (what the estimator
+ * receives as point(7), estimator_node.cpp) or -1 when the 3 nearest returns do not support one. */
+int vilf_feature_depth(vilf_handle *h, const float *depth_cloud_xyzi, int n_points, const float *features_xyz, int n_features, float *depth_out);
 #ifdef __cplusplus
 }
 #endif

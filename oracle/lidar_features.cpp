@@ -83,3 +83,52 @@ extern "C" int vilo_extract_features(const float *xyzi, int n, int n_scans, doub
     for (size_t i = 0; i < surf.size() && (int)i < cap_surf; i++) { surf_out[4 * i] = surf[i].x; surf_out[4 * i + 1] = surf[i].y; surf_out[4 * i + 2] = surf[i].z; surf_out[4 * i + 3] = surf[i].i; }
     return VILF_OK;
 }
+
+// getFeatureDepth (feature_tracker/feature_tracker_node.cpp:54-163): LiDAR depth for the tracked visual features. Features and the
+// depth cloud (camera frame) are projected onto the unit sphere; per feature the 3 nearest cloud points (kd-tree in the reference,
+// exact brute force here: float squared distance, ties by index) span a plane that the feature ray is intersected with.
+// All arithmetic is FLOAT as in the reference (Eigen::Vector3f, PointXYZI); the threshold is pow(sin(0.5 deg) * 5, 2) cast to float.
+extern "C" int vilo_feature_depth(const float *cloud_xyzi, int n, const float *feat_xyz, int m, float *depth_out) {
+    if (n < 0 || m < 0 || (m && (!feat_xyz || !depth_out))) return VILF_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < m; i++) depth_out[i] = -1.0f;
+    std::vector<P4> unit(n);
+    for (int i = 0; i < n; i++) {
+        P4 p{cloud_xyzi[4 * i], cloud_xyzi[4 * i + 1], cloud_xyzi[4 * i + 2], cloud_xyzi[4 * i + 3]};
+        const float range = std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z);
+        p.x /= range; p.y /= range; p.z /= range; p.i = range;
+        unit[i] = p;
+    }
+    if (n < 10) return VILF_OK;
+    const float bin_res = 180.0 / (float)360;
+    const float thr = (float)std::pow(std::sin(bin_res / 180.0 * M_PI) * 5.0, 2);
+    for (int f = 0; f < m; f++) {
+        float vx = feat_xyz[3 * f], vy = feat_xyz[3 * f + 1], vz = feat_xyz[3 * f + 2];
+        const float nrm = std::sqrt(vx * vx + vy * vy + vz * vz);
+        vx /= nrm; vy /= nrm; vz /= nrm;
+        int idx[3] = {-1, -1, -1}; float d2[3] = {3.0e38f, 3.0e38f, 3.0e38f};
+        for (int i = 0; i < n; i++) {
+            const float ex = unit[i].x - vx, ey = unit[i].y - vy, ez = unit[i].z - vz;
+            const float d = ex * ex + ey * ey + ez * ez;
+            if (d < d2[2]) {
+                int k = 2;
+                while (k > 0 && d < d2[k - 1]) { d2[k] = d2[k - 1]; idx[k] = idx[k - 1]; k--; }
+                d2[k] = d; idx[k] = i;
+            }
+        }
+        if (idx[2] < 0 || !(d2[2] < thr)) continue;
+        const float r1 = unit[idx[0]].i, r2 = unit[idx[1]].i, r3 = unit[idx[2]].i;
+        const float A[3] = {unit[idx[0]].x * r1, unit[idx[0]].y * r1, unit[idx[0]].z * r1};
+        const float B[3] = {unit[idx[1]].x * r2, unit[idx[1]].y * r2, unit[idx[1]].z * r2};
+        const float Cc[3] = {unit[idx[2]].x * r3, unit[idx[2]].y * r3, unit[idx[2]].z * r3};
+        const float a[3] = {A[0] - B[0], A[1] - B[1], A[2] - B[2]}, b[3] = {B[0] - Cc[0], B[1] - Cc[1], B[2] - Cc[2]};
+        const float N[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+        float s = (N[0] * A[0] + N[1] * A[1] + N[2] * A[2]) / (N[0] * vx + N[1] * vy + N[2] * vz);
+        const float mn = std::min(r1, std::min(r2, r3)), mx = std::max(r1, std::max(r2, r3));
+        if (mx - mn > 2 || s <= 0.5) continue;
+        else if (s - mx > 0) s = mx;
+        else if (s - mn < 0) s = mn;
+        const float inten = vz * s;                               // the estimator wants the depth of the z = 1 normalised feature
+        if (inten > 2.0) depth_out[f] = inten;
+    }
+    return VILF_OK;
+}

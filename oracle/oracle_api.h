@@ -62,6 +62,8 @@ int vilo_knn5_bruteforce(const float *map_xyzi, int n_map, const float *query_xy
 /* PCL VoxelGrid (centroid per leaf) restatement */
 int vilo_voxel_grid(const float *xyzi, int n, float leaf, float *out_xyzi, int capacity, int *n_out);
 /* featureExtraction::extractFeature (featureExtraction.hpp:54-232): raw scan -> edge / surf feature clouds */
+/* getFeatureDepth (feature_tracker_node.cpp:54-163): LiDAR depth of the visual features (camera-frame cloud, features with z = 1); -1 = none */
+int vilo_feature_depth(const float *cloud_xyzi, int n, const float *feat_xyz, int m, float *depth_out);
 int vilo_extract_features(const float *xyzi, int n, int n_scans, double min_range, double max_range, double edge_threshold,
                           float *edge_out, int cap_edge, int *n_edge, float *surf_out, int cap_surf, int *n_surf);
 /* association products for one query set at a given pose (EdgeCostFactor / SurfCostFactor :117-232) */

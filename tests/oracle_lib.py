@@ -158,3 +158,14 @@ def extract_features(xyzi, n_scans=64, min_range=3.0, max_range=100.0, edge_thre
     rc = L.vilo_extract_features(a.ctypes.data_as(fp), n, n_scans, min_range, max_range, edge_threshold, e.ctypes.data_as(fp), n, C.byref(ne), s.ctypes.data_as(fp), n, C.byref(ns))
     assert rc == 0, rc
     return e[:ne.value].copy(), s[:ns.value].copy()
+
+
+def feature_depth(cloud_xyzi, feat_xyz):
+    """getFeatureDepth on the oracle: depth per feature (-1 = none)"""
+    L = lib()
+    fp = C.POINTER(C.c_float)
+    L.vilo_feature_depth.argtypes = [fp, C.c_int, fp, C.c_int, fp]
+    c = np.ascontiguousarray(cloud_xyzi, dtype=np.float32); f = np.ascontiguousarray(feat_xyz, dtype=np.float32)
+    out = np.zeros(max(len(f), 1), dtype=np.float32)
+    assert L.vilo_feature_depth(c.ctypes.data_as(fp), len(c), f.ctypes.data_as(fp), len(f), out.ctypes.data_as(fp)) == 0
+    return out[:len(f)].copy()

@@ -58,3 +58,44 @@ def test_hip_feature_extraction_matches_oracle(oracle, opts, seed, rings):
     ge3, gs3 = fe.extractFeature(np.zeros((0, 4), dtype=np.float32))
     assert len(ge3) == 0 and len(gs3) == 0
     s.close()
+
+
+def _depth_case(seed, opts):
+    """camera-frame depth cloud from a raw scan (points in front of the camera, inside its field of view) + normalised features"""
+    _, _, _, raw = _raw_scan(seed)
+    RCL = np.array(opts.RCL[:]).reshape(3, 3); TCL = np.array(opts.TCL[:])
+    pc = raw[:, :3].astype(np.float64) @ RCL.T + TCL                          # camera <- LiDAR
+    front = (pc[:, 2] > 1.0) & (np.abs(pc[:, 0] / pc[:, 2]) < 0.9) & (np.abs(pc[:, 1] / pc[:, 2]) < 0.3)
+    cloud = np.column_stack([pc[front], np.ones(front.sum())]).astype(np.float32)
+    rng = np.random.default_rng(seed)
+    feats = np.column_stack([rng.uniform(-0.85, 0.85, 200), rng.uniform(-0.25, 0.25, 200), np.ones(200)]).astype(np.float32)
+    return cloud, feats
+
+
+def test_oracle_feature_depth(oracle, opts):
+    cloud, feats = _depth_case(5, opts)
+    assert len(cloud) > 1000
+    d = oracle.feature_depth(cloud, feats)
+    ok = d > 0
+    assert 20 < ok.sum() < 200 and np.all(d[ok] > 2.0) and np.all(d[~ok] == -1.0)
+    # a fronto-parallel wall at z = 10: every feature that gets a depth gets ~10
+    gx, gy = np.meshgrid(np.linspace(-9, 9, 300), np.linspace(-3, 3, 100))
+    wall = np.column_stack([gx.ravel(), gy.ravel(), np.full(gx.size, 10.0), np.ones(gx.size)]).astype(np.float32)
+    dw = oracle.feature_depth(wall, feats)
+    assert (dw > 0).sum() > 150 and np.allclose(dw[dw > 0], 10.0, atol=1e-3)
+    assert np.all(oracle.feature_depth(wall[:9], feats) == -1.0)           # fewer than 10 points: no depth at all
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [5, 8])
+def test_hip_feature_depth_matches_oracle(oracle, opts, seed):
+    from vil_fusion_amd.estimator import BackendSolver, FeatureExtraction
+    cloud, feats = _depth_case(seed, opts)
+    s = BackendSolver(opts); fe = FeatureExtraction(s)
+    got = fe.getFeatureDepth(cloud, feats)
+    ref = oracle.feature_depth(cloud, feats)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "depths must be bit-identical"
+    assert np.all(fe.getFeatureDepth(cloud[:9], feats) == -1.0)
+    dup = np.concatenate([cloud[:50], cloud[:50], cloud])                   # exact duplicates: ties resolved by index
+    assert np.array_equal(fe.getFeatureDepth(dup, feats).view(np.uint32), oracle.feature_depth(dup, feats).view(np.uint32))
+    s.close()

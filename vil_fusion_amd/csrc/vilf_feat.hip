@@ -28,6 +28,7 @@
 
 struct FeatCtx {
     DBuf pts, keys, keys2, vals, vals2, temp, rpts, curv, rstart, etmp, stmp, ecnt, scnt, eoff, soff, oute, outs, tot;
+    DBuf dcloud, dunit, dfeat, dout;          // getFeatureDepth
     size_t temp_bytes = 0;
     int cap = 0, scans = 0;
 };
@@ -173,10 +174,74 @@ __global__ void fe_emit(const float4 *etmp, const float4 *stmp, const int *ecnt,
     for (int k = tid; k < scnt[sec]; k += blockDim.x) outs[soff[sec] + k] = stmp[(size_t)sec * FE_MAXSEC + k];
 }
 
+// ---- getFeatureDepth (feature_tracker/feature_tracker_node.cpp:54-163) -------------------------------------------------------
+// unit-sphere projection of the depth cloud (one lane per point), then ONE workgroup per visual feature: every lane keeps the 3
+// nearest cloud points of its strided share (float squared distance, ties by index), the per-lane triples are merged through LDS,
+// lane 0 intersects the feature ray with the plane of the 3 winners. FLOAT arithmetic with explicit roundings, as the reference.
+__global__ void fd_unit(const float4 *p, int n, float4 *u) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = p[i];
+    const float range = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(q.x, q.x), __fmul_rn(q.y, q.y)), __fmul_rn(q.z, q.z)));
+    u[i] = make_float4(__fdiv_rn(q.x, range), __fdiv_rn(q.y, range), __fdiv_rn(q.z, range), range);
+}
+__device__ __forceinline__ void fd_insert(float d, int i, float d2[3], int idx[3]) {
+    if (d < d2[2] || (d == d2[2] && i < idx[2])) {
+        int k = 2;
+        while (k > 0 && (d < d2[k - 1] || (d == d2[k - 1] && i < idx[k - 1]))) { d2[k] = d2[k - 1]; idx[k] = idx[k - 1]; k--; }
+        d2[k] = d; idx[k] = i;
+    }
+}
+__global__ __launch_bounds__(256) void fd_depth(const float4 *u, int n, const float *feat, int m, float thr, float *out) {
+    __shared__ float s_d[256 * 3];
+    __shared__ int s_i[256 * 3];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    float vx = feat[3 * f], vy = feat[3 * f + 1], vz = feat[3 * f + 2];
+    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
+    vx = __fdiv_rn(vx, nrm); vy = __fdiv_rn(vy, nrm); vz = __fdiv_rn(vz, nrm);
+    float d2[3] = {3.0e38f, 3.0e38f, 3.0e38f}; int idx[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff};
+    for (int i = tid; i < n; i += 256) {
+        const float4 q = u[i];
+        const float ex = __fsub_rn(q.x, vx), ey = __fsub_rn(q.y, vy), ez = __fsub_rn(q.z, vz);
+        fd_insert(__fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)), i, d2, idx);
+    }
+    for (int k = 0; k < 3; k++) { s_d[3 * tid + k] = d2[k]; s_i[3 * tid + k] = idx[k]; }
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {          // tree merge of the per-lane triples
+        if (tid < st) {
+            for (int k = 0; k < 3; k++) { d2[k] = s_d[3 * tid + k]; idx[k] = s_i[3 * tid + k]; }
+            for (int k = 0; k < 3; k++) if (s_i[3 * (tid + st) + k] != 0x7fffffff) fd_insert(s_d[3 * (tid + st) + k], s_i[3 * (tid + st) + k], d2, idx);
+            for (int k = 0; k < 3; k++) { s_d[3 * tid + k] = d2[k]; s_i[3 * tid + k] = idx[k]; }
+        }
+        __syncthreads();
+    }
+    if (tid) return;
+    float res = -1.0f;
+    if (idx[2] != 0x7fffffff && d2[2] < thr) {
+        const float4 p1 = u[idx[0]], p2 = u[idx[1]], p3 = u[idx[2]];
+        const float r1 = p1.w, r2 = p2.w, r3 = p3.w;
+        const float A[3] = {__fmul_rn(p1.x, r1), __fmul_rn(p1.y, r1), __fmul_rn(p1.z, r1)};
+        const float B[3] = {__fmul_rn(p2.x, r2), __fmul_rn(p2.y, r2), __fmul_rn(p2.z, r2)};
+        const float Cc[3] = {__fmul_rn(p3.x, r3), __fmul_rn(p3.y, r3), __fmul_rn(p3.z, r3)};
+        const float a[3] = {__fsub_rn(A[0], B[0]), __fsub_rn(A[1], B[1]), __fsub_rn(A[2], B[2])}, b[3] = {__fsub_rn(B[0], Cc[0]), __fsub_rn(B[1], Cc[1]), __fsub_rn(B[2], Cc[2])};
+        const float N[3] = {__fsub_rn(__fmul_rn(a[1], b[2]), __fmul_rn(a[2], b[1])), __fsub_rn(__fmul_rn(a[2], b[0]), __fmul_rn(a[0], b[2])), __fsub_rn(__fmul_rn(a[0], b[1]), __fmul_rn(a[1], b[0]))};
+        float sc = __fdiv_rn(__fadd_rn(__fadd_rn(__fmul_rn(N[0], A[0]), __fmul_rn(N[1], A[1])), __fmul_rn(N[2], A[2])),
+                             __fadd_rn(__fadd_rn(__fmul_rn(N[0], vx), __fmul_rn(N[1], vy)), __fmul_rn(N[2], vz)));
+        const float mn = fminf(r1, fminf(r2, r3)), mx = fmaxf(r1, fmaxf(r2, r3));
+        if (!(__fsub_rn(mx, mn) > 2 || sc <= 0.5)) {
+            if (__fsub_rn(sc, mx) > 0) sc = mx;
+            else if (__fsub_rn(sc, mn) < 0) sc = mn;
+            const float inten = __fmul_rn(vz, sc);
+            if (inten > 2.0) res = inten;
+        }
+    }
+    out[f] = res;
+}
+
 void vilf_feat_release(vilf_handle *h) {
     if (!h->feat) return;
     FeatCtx *c = h->feat;
-    DBuf *all[] = {&c->pts, &c->keys, &c->keys2, &c->vals, &c->vals2, &c->temp, &c->rpts, &c->curv, &c->rstart, &c->etmp, &c->stmp, &c->ecnt, &c->scnt, &c->eoff, &c->soff, &c->oute, &c->outs, &c->tot};
+    DBuf *all[] = {&c->pts, &c->keys, &c->keys2, &c->vals, &c->vals2, &c->temp, &c->rpts, &c->curv, &c->rstart, &c->etmp, &c->stmp, &c->ecnt, &c->scnt, &c->eoff, &c->soff, &c->oute, &c->outs, &c->tot, &c->dcloud, &c->dunit, &c->dfeat, &c->dout};
     for (DBuf *b : all) b->release();
     delete c;
     h->feat = nullptr;
@@ -225,6 +290,26 @@ extern "C" int vilf_lidar_extract_features(vilf_handle *h, const float *xyzi, in
     *n_edge = tot[0]; *n_surf = tot[1];
     if (edge_out && tot[0] > 0) HIPCHECK(h, hipMemcpyAsync(edge_out, c->oute.p, (size_t)std::min(tot[0], cap_edge) * 16, hipMemcpyDeviceToHost, h->stream));
     if (surf_out && tot[1] > 0) HIPCHECK(h, hipMemcpyAsync(surf_out, c->outs.p, (size_t)std::min(tot[1], cap_surf) * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VILF_OK;
+}
+
+extern "C" int vilf_feature_depth(vilf_handle *h, const float *cloud_xyzi, int n, const float *feat_xyz, int m, float *depth_out) {
+    if (!h || n < 0 || m < 0 || (n && !cloud_xyzi) || (m && (!feat_xyz || !depth_out))) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipSetDevice(h->device));
+    for (int i = 0; i < m; i++) depth_out[i] = -1.0f;
+    if (m == 0 || n < 10) return VILF_OK;                         // "depth cloud is too few" (:97-101)
+    if (!h->feat) h->feat = new FeatCtx();
+    FeatCtx *c = h->feat;
+    if (!c->dcloud.ensure((size_t)n * 16) || !c->dunit.ensure((size_t)n * 16) || !c->dfeat.ensure((size_t)m * 12) || !c->dout.ensure((size_t)m * 4)) { h->err = "hipMalloc failed (feature depth)"; return VILF_ERR_DEVICE; }
+    const float bin_res = 180.0 / (float)360;
+    const float thr = (float)std::pow(std::sin(bin_res / 180.0 * M_PI) * 5.0, 2);
+    HIPCHECK(h, hipMemcpyAsync(c->dcloud.p, cloud_xyzi, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(c->dfeat.p, feat_xyz, (size_t)m * 12, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(fd_unit, dim3((n + 255) / 256), dim3(256), 0, h->stream, c->dcloud.as<float4>(), n, c->dunit.as<float4>());
+    hipLaunchKernelGGL(fd_depth, dim3(m), dim3(256), 0, h->stream, c->dunit.as<float4>(), n, c->dfeat.as<float>(), m, thr, c->dout.as<float>());
+    HIPCHECK(h, hipGetLastError());
+    HIPCHECK(h, hipMemcpyAsync(depth_out, c->dout.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     return VILF_OK;
 }

@@ -321,3 +321,13 @@ class FeatureExtraction:
         self.s._check(self._L.vilf_lidar_extract_features(self.s._h, a.ctypes.data_as(fp), n, self.n_scans, self.min_range, self.max_range, self.edge_threshold,
                                                           e.ctypes.data_as(fp), n, C.byref(ne), s.ctypes.data_as(fp), n, C.byref(ns)), "vilf_lidar_extract_features")
         return e[:ne.value].copy(), s[:ns.value].copy()
+
+    def getFeatureDepth(self, depth_cloud_xyzi, features_xyz):
+        """≙ getFeatureDepth (feature_tracker_node.cpp:54-163): LiDAR depth per visual feature, -1 = none"""
+        c = np.ascontiguousarray(depth_cloud_xyzi, dtype=np.float32); f = np.ascontiguousarray(features_xyz, dtype=np.float32)
+        assert c.ndim == 2 and c.shape[1] == 4 and f.ndim == 2 and f.shape[1] == 3
+        fp = C.POINTER(C.c_float)
+        self._L.vilf_feature_depth.argtypes = [C.c_void_p, fp, C.c_int, fp, C.c_int, fp]
+        out = np.zeros(max(len(f), 1), dtype=np.float32)
+        self.s._check(self._L.vilf_feature_depth(self.s._h, c.ctypes.data_as(fp), len(c), f.ctypes.data_as(fp), len(f), out.ctypes.data_as(fp)), "vilf_feature_depth")
+        return out[:len(f)].copy()
