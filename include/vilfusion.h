@@ -238,6 +238,11 @@ int vilf_imu_preintegrate(const vilf_imu_noise *noise, const double acc_0[3], co
                           const double *dt, const double *acc /*[n][3]*/, const double *gyr /*[n][3]*/,
                           vilf_imu_preint *out);
 
+/* the same integration for n intervals at once on the device (one lane per interval): all inputs are [n][...] host arrays with
+ * max_samples slots per interval (n_samples[i] of them used); out[n] */
+int vilf_imu_preintegrate_batch(vilf_handle *h, int n, const vilf_imu_noise *noise, const double *acc_0 /*[n][3]*/, const double *gyr_0,
+                                const double *linearized_ba, const double *linearized_bg, const int *n_samples, int max_samples,
+                                const double *dt /*[n][max]*/, const double *acc /*[n][max][3]*/, const double *gyr, vilf_imu_preint *out);
 /* ---- scan-to-map (≙ EstimationMapping) -------------------------------------------------- */
 /* points are float xyzi (pcl::PointXYZI without padding): [n][4] */
 int vilf_scan2map_init(vilf_handle *h, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);   /* localMapInited, :105 */

@@ -293,3 +293,26 @@ def test_ragged_batch_and_maximum_sizes(solver, oracle, opts):
     Lg, bg, blg = _prior_products(pg); Lr, br_, blr = _prior_products(pr)
     assert [b["id"] for b in blg] == [b["id"] for b in blr] and pg.m == pr.m
     assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5
+
+
+def test_device_preintegration_batch(solver, opts):
+    """IntegrationBase for many intervals on the device (one lane per interval, the same routine as the host
+    vilf_imu_preintegrate) against the independent numpy restatement: ragged sample counts, including an empty interval."""
+    from vil_fusion_amd.estimator import imu_preintegrate_batch
+    rng = np.random.default_rng(31)
+    n, mx, dt = 37, 20, 0.01
+    ns = rng.integers(0, mx + 1, n); ns[0] = 0; ns[1] = mx
+    acc = rng.normal(0, 1.0, (n, mx + 1, 3)) + np.array([0, 0, 9.8]); gyr = rng.normal(0, 0.2, (n, mx + 1, 3))
+    ba = rng.normal(0, 0.02, (n, 3)); bg = rng.normal(0, 0.002, (n, 3))
+    noise = abi.ImuNoise(synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)
+    got = imu_preintegrate_batch(solver, noise, acc[:, 0], gyr[:, 0], ba, bg, ns, np.full((n, mx), dt), acc[:, 1:], gyr[:, 1:])
+    for i in range(n):
+        k = int(ns[i])
+        if k == 0:
+            ref = np.zeros(abi.IMU_DOUBLES); ref[abi.IMU_OFF["delta_q"][0] + 3] = 1.0
+            ref[abi.IMU_OFF["linearized_ba"][0]:abi.IMU_OFF["linearized_ba"][1]] = ba[i]; ref[abi.IMU_OFF["linearized_bg"][0]:abi.IMU_OFF["linearized_bg"][1]] = bg[i]
+            j0 = abi.IMU_OFF["jacobian"][0]
+            ref[j0:j0 + 225] = np.eye(15).ravel()
+        else:
+            ref = synth.preintegrate(acc[i:i + 1, :k + 1], gyr[i:i + 1, :k + 1], dt, ba[i:i + 1], bg[i:i + 1])[0]
+        assert np.allclose(got[i], ref, rtol=1e-11, atol=1e-13 * max(1.0, np.abs(ref).max())), i

@@ -220,6 +220,22 @@ def imu_preintegrate(noise, acc_0, gyr_0, ba, bg, dt, acc, gyr):
     return out
 
 
+def imu_preintegrate_batch(solver, noise, acc_0, gyr_0, ba, bg, n_samples, dt, acc, gyr):
+    """≙ IntegrationBase for many intervals at once on the device (vilf_imu_preintegrate_batch). acc_0 / gyr_0 / ba / bg: (n, 3);
+    n_samples: (n,); dt: (n, max); acc / gyr: (n, max, 3). Returns an (n, 467) array of vilf_imu_preint rows."""
+    f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+    acc_0, gyr_0, ba, bg, dt, acc, gyr = [f64(v) for v in (acc_0, gyr_0, ba, bg, dt, acc, gyr)]
+    ns = np.ascontiguousarray(n_samples, dtype=np.int32)
+    n, mx = len(ns), dt.shape[1] if dt.ndim == 2 else 0
+    out = np.zeros((max(n, 1), abi.IMU_DOUBLES))
+    L = solver._L
+    L.vilf_imu_preintegrate_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.ImuNoise), abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p,
+                                              C.POINTER(C.c_int), C.c_int, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_void_p]
+    solver._check(L.vilf_imu_preintegrate_batch(solver._h, n, C.byref(noise), abi.dptr(acc_0), abi.dptr(gyr_0), abi.dptr(ba), abi.dptr(bg),
+                                                ns.ctypes.data_as(C.POINTER(C.c_int)), mx, abi.dptr(dt), abi.dptr(acc), abi.dptr(gyr), out.ctypes.data), "vilf_imu_preintegrate_batch")
+    return out[:n]
+
+
 class Scan2Map:
     """Host mirror of EstimationMapping (feature_tracker/include/EstimationMapping.hpp): localMapInited / optimation_processing /
     getMapCloud over the device path. One LiDAR stream per BackendSolver handle."""
