@@ -22,7 +22,14 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define NT VB_NT
 #define VILF_MAX_FEATURES_DEV 1000
+// In-kernel phase stamps are a diagnostic build only (make HIPFLAGS+=-DVILF_STAMPS): the production kernels carry no clock reads.
+#ifdef VILF_STAMPS
 #define STAMP(kid, i) do { if (b.dbg && blockIdx.x == 0 && threadIdx.x == 0) b.dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define TICK() __builtin_readcyclecounter()
+#else
+#define STAMP(kid, i) do { } while (0)
+#define TICK() 0LL
+#endif
 __device__ __forceinline__ int pair_index(int i, int j) { return j * (j - 1) / 2 + i; }  // i < j
 // tangent index (frame a, local l in [0,15)) -> P-first permuted index: poses 0..65, speed-bias 66..164
 __device__ __forceinline__ int perm_index(int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); }
@@ -340,7 +347,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #pragma unroll
     for (int q4 = 0; q4 < 4; q4++) pe[q4] = pair_elem((lane >> 4) + 4 * q4, lane & 15);   // C-tile register -> pairD slot (fixed per lane)
     for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
-        t_a = __builtin_readcyclecounter();
+        t_a = TICK();
         const int q = c0 + tid;
         double *x0 = s_X + (2 * min(tid, VB_CHUNK - 1)) * VB_XLD, *x1 = x0 + VB_XLD;
         if (tid >= VB_CHUNK) {
@@ -375,9 +382,9 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #pragma unroll
             for (int c = 0; c < VB_XLD; c++) { x0[c] = 0; x1[c] = 0; }
         }
-        { long long t_b = __builtin_readcyclecounter(); t_eval += t_b - t_a; t_a = t_b; }
+        { long long t_b = TICK(); t_eval += t_b - t_a; t_a = t_b; }
         __syncthreads();
-        { long long t_b = __builtin_readcyclecounter(); t_sync1 += t_b - t_a; t_a = t_b; }
+        { long long t_b = TICK(); t_sync1 += t_b - t_a; t_a = t_b; }
         const int cend = min(c0 + VB_CHUNK, nfac);
         for (int p = wave; p < VB_NPAIR; p += 4) {
             const int lo = __builtin_amdgcn_readfirstlane(max(s_poff[p], c0)), hi = __builtin_amdgcn_readfirstlane(min(s_poff[p + 1], cend));
@@ -411,9 +418,9 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = (first ? 0.0 : old4[q4]) + (acc[q4] + acc1[q4]);
         }
-        { long long t_b = __builtin_readcyclecounter(); t_mfma += t_b - t_a; t_a = t_b; }
+        { long long t_b = TICK(); t_mfma += t_b - t_a; t_a = t_b; }
         __syncthreads();
-        { long long t_b = __builtin_readcyclecounter(); t_sync2 += t_b - t_a; t_a = t_b; }
+        { long long t_b = TICK(); t_sync2 += t_b - t_a; t_a = t_b; }
     }
     if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
     STAMP(0, 5);
@@ -906,10 +913,10 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
         // Lookahead: after the TRSM of step k, column k+1 of the trailing matrix is updated first; then wave 0 factorises the
         // next diagonal tile while waves 1..7 update the remaining columns.
         bool ok = true;
-        long long tc_a = __builtin_readcyclecounter(), tc_trsm = 0, tc_p1 = 0, tc_p2 = 0, tc_potrf0 = 0;
+        long long tc_a = TICK(), tc_trsm = 0, tc_p1 = 0, tc_p2 = 0, tc_potrf0 = 0;
         if (wave == 0) { bool o = potrf_tile_wave(s_T + tile_index(0, 0) * 256, s_invd, lane); if (lane == 0) s_flag[2] = o ? 1 : 0; }
         __syncthreads();
-        { long long t = __builtin_readcyclecounter(); tc_potrf0 = t - tc_a; tc_a = t; }
+        { long long t = TICK(); tc_potrf0 = t - tc_a; tc_a = t; }
         for (int k = 0; k < VB_NTILE; k++) {
             if (!s_flag[2]) { ok = false; break; }
             const double *Tkk = s_T + tile_index(k, k) * 256;
@@ -931,7 +938,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
                 for (int c = 0; c < 16; c++) Tik[TIX(rr, c)] = x[c];
             }
             __syncthreads();
-            { long long t = __builtin_readcyclecounter(); tc_trsm += t - tc_a; tc_a = t; }
+            { long long t = TICK(); tc_trsm += t - tc_a; tc_a = t; }
             if (k == VB_NTILE - 1) break;
             const int nt = VB_NTILE - 1 - k;
             auto update_tile = [&](int ti, int tj) {
@@ -951,7 +958,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
             // phase 1: column k+1 (tiles (k+1+ii, k+1), ii = 0..nt-1)
             for (int ii = wave; ii < nt; ii += SNW) update_tile(k + 1 + ii, k + 1);
             __syncthreads();
-            { long long t = __builtin_readcyclecounter(); tc_p1 += t - tc_a; tc_a = t; }
+            { long long t = TICK(); tc_p1 += t - tc_a; tc_a = t; }
             // phase 2: wave 0 factorises tile (k+1, k+1); the other waves update the remaining columns
             if (wave == 0) {
                 bool o = potrf_tile_wave(s_T + tile_index(k + 1, k + 1) * 256, s_invd + 16 * (k + 1), lane);
@@ -965,7 +972,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
                 }
             }
             __syncthreads();
-            { long long t = __builtin_readcyclecounter(); tc_p2 += t - tc_a; tc_a = t; }
+            { long long t = TICK(); tc_p2 += t - tc_a; tc_a = t; }
         }
         if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 20] = tc_potrf0; b.dbg[64 + 21] = tc_trsm; b.dbg[64 + 22] = tc_p1; b.dbg[64 + 23] = tc_p2; }
         STAMP(1, 6);
