@@ -204,6 +204,13 @@ def test_replicas_and_reruns_are_bit_identical(solver, opts):
             assert all(np.array_equal(P[i], P[i % 8]) for i in range(512)), "replicas of the same window differ"
         else:
             assert np.array_equal(P, base), f"re-run {rep} differs"
+    # the marginalization of replicas (fast path: fixed summation orders, no atomics) is bit-identical too, and a rewind restores the priors
+    solver.batch_marginalize()
+    pri = [solver.get_prior(i) for i in (0, 8, 16, 3, 11)]
+    assert bytes(pri[0]) == bytes(pri[1]) == bytes(pri[2]) and bytes(pri[3]) == bytes(pri[4]) and bytes(pri[0]) != bytes(pri[3])
+    solver.batch_rewind(); solver.batch_solve()
+    P2 = np.stack([np.concatenate([r.Ps.ravel(), r.Vs.ravel(), r.Bas.ravel(), r.Bgs.ravel()]) for r in solver.batch_download()])
+    assert np.array_equal(P2, base), "rewind after a marginalization must restore the uploaded priors"
 
 
 def test_prior_factor_hook(solver, oracle, opts):

@@ -179,7 +179,7 @@ static int upload_priors(vilf_handle *h) {
     std::vector<int> dirty;
     for (int w = 0; w < B; w++) if (h->prior_dirty[w]) dirty.push_back(w);
     if (dirty.empty()) return VILF_OK;
-    h->prior_backup_valid = false;
+    h->prior_backup_valid = false; h->prior_restore_needed = false;
     for (int w : dirty) {
         const vilf_prior &p = h->priors[w];
         h->prior_dev_newer[w] = 0;
@@ -467,14 +467,14 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_reset, dim3(h->B), dim3(VB_NT), 0, h->stream, h->batch, 1);
     HIPCHECK(h, hipGetLastError());
-    bool newer = false;
-    for (int w = 0; w < h->B; w++) if (h->prior_dev_newer[w]) newer = true;
-    if (newer && h->prior_backup_valid) {          // a marginalization replaced the priors: restore them as uploaded
+    if (h->prior_restore_needed && h->prior_backup_valid) {          // a marginalization replaced the priors: restore them as uploaded
         const size_t sB = h->B;
         const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
         const size_t bytes[6] = {sB * VB_PRIOR_HDR * 4, sB * 24 * 9 * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8};
         for (int k = 0; k < 6; k++) HIPCHECK(h, hipMemcpyAsync(h->d[live[k]].p, h->d[bak[k]].p, bytes[k], hipMemcpyDeviceToDevice, h->stream));
-        for (int w = 0; w < h->B; w++) h->prior_dev_newer[w] = 0;
+        // the device now holds the authoritative priors; the host mirror may have seen the marginalized ones through an export
+        for (int w = 0; w < h->B; w++) { h->prior_dev_newer[w] = 1; h->prior_dirty[w] = 0; }
+        h->prior_restore_needed = false;
     }
     return VILF_OK;
 }
@@ -677,6 +677,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
         for (int k = 0; k < 4; k++) { float t = 0; hipEventElapsedTime(&t, h->pev[k], h->pev[k + 1]); h->marg_ms[k] += t; h->marg_launches[k] += 1; }
     }
     for (int w = 0; w < h->B; w++) { h->prior_dev_newer[w] = 1; h->prior_dirty[w] = 0; }
+    h->prior_restore_needed = true;
     if (sync) {
         std::vector<int> info(sB * MG_INFO);
         HIPCHECK(h, hipMemcpyAsync(info.data(), g.info, info.size() * 4, hipMemcpyDeviceToHost, h->stream));

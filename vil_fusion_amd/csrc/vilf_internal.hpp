@@ -51,6 +51,7 @@ struct vilf_handle {
     std::vector<int> h_mflag;
     int prior_slots_valid = 0;               // the device prior arrays hold slots 0 .. prior_slots_valid-1 (survive a re-upload of the windows)
     bool prior_backup_valid = false;         // D_P*0 hold the priors as last uploaded
+    bool prior_restore_needed = false;       // a marginalization has overwritten the device priors since that backup
     int mg_Mcap = 0;
     VbMarg marg;
     size_t marg_lds_schur = 0, marg_lds_finish = 0;

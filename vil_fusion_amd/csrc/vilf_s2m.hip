@@ -302,20 +302,37 @@ __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, flo
     const int cx = (int)floorf(qx), cy = (int)floorf(qy);
     const int yl = (cy - 1) & 255, ym = cy & 255;
     const bool one_span = yl < ym && ym < 255;           // the three y-buckets of a column are adjacent unless the digit wraps
-    for (int dx = -1; dx <= 1; dx++) {
-        const int row = ((cx + dx) & 255) << 8;
-        for (int part = 0; part < (one_span ? 1 : 3); part++) {
+    // all span bounds first (independent loads), then the candidates four at a time (clamped, unconditional loads): the lane keeps
+    // several loads in flight instead of one dependent load per candidate
+    int st[9], en[9];
+    const int nspan = one_span ? 3 : 9;
+#pragma unroll
+    for (int sp = 0; sp < 9; sp++) {
+        if (sp < nspan) {
+            const int dx = one_span ? sp - 1 : sp / 3 - 1, part = one_span ? 0 : sp % 3;
+            const int row = ((cx + dx) & 255) << 8;
             const int b0 = one_span ? (row | yl) : (row | ((cy - 1 + part) & 255)), b1 = one_span ? b0 + 2 : b0;
-            const int st = start[b0], en = start[b1 + 1];
-            for (int j = st; j < en; j++) {
-                const float4 m = sorted[j];
+            st[sp] = start[b0]; en[sp] = start[b1 + 1];
+        } else { st[sp] = 0; en[sp] = 0; }
+    }
+#pragma unroll
+    for (int sp = 0; sp < 9; sp++) {
+        if (sp >= nspan) break;
+        for (int j0 = st[sp]; j0 < en[sp]; j0 += 4) {
+            float4 m4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) m4[u] = sorted[min(j0 + u, en[sp] - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (j0 + u >= en[sp]) break;
+                const float4 m = m4[u];
                 const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
                 const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
                 const int oi = __float_as_int(m.w);
                 if (d < d2[4] || (d == d2[4] && oi < oid[4])) {
                     int kk = 4;
                     while (kk > 0 && (d < d2[kk - 1] || (d == d2[kk - 1] && oi < oid[kk - 1]))) { d2[kk] = d2[kk - 1]; oid[kk] = oid[kk - 1]; pos[kk] = pos[kk - 1]; kk--; }
-                    d2[kk] = d; oid[kk] = oi; pos[kk] = j;
+                    d2[kk] = d; oid[kk] = oi; pos[kk] = j0 + u;
                 }
             }
         }
