@@ -199,6 +199,10 @@ __device__ double prior_cost_partial(const VbBatch &b, int w, const double *s_dx
 // deterministic (each pair is owned by one wave, fixed order).
 #define LIN_LDS_DOUBLES VB_LIN_LDS_DOUBLES
 
+// pairD element of pair p, zero when the pair has no factor (unconditional load + select: a conditional load would serialise on
+// vmcnt(0); untouched slots hold garbage that never becomes an arithmetic input)
+__device__ __forceinline__ double pd_get(const double *pd, const int *s_poff, int p, int e) { const double v = pd[p * VB_PAIRD + e]; return (s_poff[p + 1] > s_poff[p]) ? v : 0.0; }
+
 __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the 16x16 X^T X tile -> slot in pairD (or -1)
     if (row < 6) {
         if (col < 6) return 6 * row + col;
@@ -411,12 +415,14 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
                 for (int u = 0; u < 4; u++) a[u] = an[u];
             }
             // pairD lives in global memory (L2): the first chunk of a pair writes, later chunks of the same pair (same wave) add
-            const bool first = __builtin_amdgcn_readfirstlane(s_poff[p]) >= c0;
-            double old4[4];
+            const bool first = __builtin_amdgcn_readfirstlane(s_poff[p]) >= c0;      // wave-uniform: most pairs live in one chunk and never read back
+            double old4[4] = {0.0, 0.0, 0.0, 0.0};
+            if (!first) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) old4[q4] = pd[p * VB_PAIRD + max(pe[q4], 0)];
+                for (int q4 = 0; q4 < 4; q4++) old4[q4] = pd[p * VB_PAIRD + max(pe[q4], 0)];
+            }
 #pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = (first ? 0.0 : old4[q4]) + (acc[q4] + acc1[q4]);
+            for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = old4[q4] + (acc[q4] + acc1[q4]);
         }
         { long long t_b = TICK(); t_mfma += t_b - t_a; t_a = t_b; }
         __syncthreads();
@@ -426,7 +432,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     STAMP(0, 5);
     // ---- visual pose-pose blocks (frame-block lower triangle) -> Hpp[66][36] ------------------------------------------
     // a pair without factors was never written: it reads as zero
-#define PD(p, e) ((s_poff[(p) + 1] > s_poff[(p)]) ? pd[(p) * VB_PAIRD + (e)] : 0.0)
+#define PD(p, e) pd_get(pd, s_poff, (p), (e))
     {
         double *Hpp = b.Hpp + (size_t)w * 66 * 36;
         for (int t = tid; t < 66 * 36; t += NT) {
