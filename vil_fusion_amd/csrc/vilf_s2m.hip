@@ -136,15 +136,19 @@ __global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const KeyT *ke
     float4 *o = out.p + (size_t)sid * out.cap;
     int carry = 0;
     for (int t0 = 0; t0 < n; t0 += S2B_VT) {
-        const int i = t0 + tid;
-        KeyT k = 0;
-        int head = 0;
-        if (i < n) { k = keys[i]; head = (i == 0 || keys[i - 1] != k) ? 1 : 0; }
+        const int i = t0 + tid, ic = min(i, n - 1);
+        // everything a lane needs for its own element is requested up front (clamped, unconditional loads): the keys before and
+        // after, the point index, the point. A leaf with one point — the common case of an already voxelised map — then needs no
+        // further memory round trip after the scan.
+        const KeyT k = keys[ic], kprev = keys[max(ic - 1, 0)], knext = keys[min(ic + 1, n - 1)];
+        const float4 q0 = p[vals[ic]];
+        const int head = (i < n && (i == 0 || kprev != k)) ? 1 : 0;
         int total;
         const int pos = carry + block_excl_scan_1024(head, s_w, total);
         if (head) {
-            float cx = 0, cy = 0, cz = 0, ci = 0; int cnt = 0;
-            for (int j = i; j < n && keys[j] == k; j++) { const float4 q = p[vals[j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
+            float cx = __fadd_rn(0.0f, q0.x), cy = __fadd_rn(0.0f, q0.y), cz = __fadd_rn(0.0f, q0.z), ci = __fadd_rn(0.0f, q0.w); int cnt = 1;   // accumulate from +0 like the reference (keeps the sign of a zero sum)
+            if (i + 1 < n && knext == k)
+                for (int j = i + 1; j < n && keys[j] == k; j++) { const float4 q = p[vals[j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
             const float nn = (float)cnt;
             o[pos] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
         }
