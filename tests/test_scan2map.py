@@ -173,3 +173,39 @@ def test_oracle_grid_knn_equals_bruteforce_inside_the_gate(oracle):
     assert inside.sum() > 100 and (~inside).sum() > 10
     assert np.array_equal(ib[inside], ig[inside]) and np.array_equal(db[inside], dg[inside])
     assert np.all(dg[~inside, 4] >= 1.0)
+
+
+@pytest.mark.gpu
+def test_scan2map_bench_size_parity_and_invariants(oracle, opts):
+    """BASELINE configs[2] LiDAR stage at its full size (≈ 1.2 k edge + ≈ 2.8 k surf queries against a ≈ 30 k + ≈ 59 k point local map):
+    HIP == oracle on the warm-up frame and on the measured frame, plus size-independent properties of the maintained maps:
+    ascending leaf order, one point per leaf (a voxel grid is idempotent), every point inside the crop box."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
+    me, ms, scans, pl = synth.make_lidar_bench_case(7000)
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    ref = oracle.OracleS2M(opts); ref.init(me, ms); ref.set_pose(ident, pl)
+    s = BackendSolver(opts)
+    S = 3
+    b = Scan2MapBatch(s, S, len(scans[0][0]) + len(scans[1][0]) + 64, len(scans[0][1]) + len(scans[1][1]) + 64, len(me) + len(scans[0][0]) + 64, len(ms) + len(scans[0][1]) + 64)
+    for i in range(S):
+        b.localMapInited(i, me, ms, None, pl)
+    for f in range(2):
+        for i in range(S):
+            b.set_scan(i, *scans[f])
+        b.step()
+        r = ref.step(*scans[f])
+        for g in b.results():
+            assert (g.n_edge_ds, g.n_surf_ds, list(g.n_edge_factors), list(g.n_surf_factors), list(g.iterations), g.map_edge_size, g.map_surf_size) == \
+                   (r.n_edge_ds, r.n_surf_ds, list(r.n_edge_factors), list(r.n_surf_factors), list(r.iterations), r.map_edge_size, r.map_surf_size)
+            assert np.abs(np.array(g.pose_qt[:]) - np.array(r.pose_qt[:])).max() < 1e-9
+    assert r.n_edge_ds > 900 and r.n_surf_ds > 2000 and r.map_edge_size > 25000 and r.map_surf_size > 50000
+    pose_t = np.array(r.pose_qt[4:])
+    for which, leaf in ((0, np.float32(opts.edge_leaf_size)), (1, np.float32(opts.surf_leaf_size))):
+        m = b.getMapCloud(1, which)
+        assert np.array_equal(m, ref.get_map(which))
+        inv = np.float32(1.0) / leaf
+        ijk = np.floor(m[:, :3] * inv).astype(np.int64)
+        key = ijk[:, 2] * (1 << 42) + ijk[:, 1] * (1 << 21) + ijk[:, 0]            # lexicographic (z, y, x) = PCL's leaf order for any min corner
+        assert np.all(np.diff(key) > 0), "ascending leaf order, one point per leaf"
+        assert np.all(np.abs(m[:, :3] - pose_t.astype(np.float32)) <= np.float32(opts.s2m_crop_half) + 1e-3)
+    s.close()
