@@ -1,5 +1,6 @@
 """GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on identical seeded inputs.
 Run on the MI355X box: python -m pytest tests -m gpu."""
+import copy
 import ctypes as C
 import numpy as np
 import pytest
@@ -323,3 +324,35 @@ def test_device_preintegration_batch(solver, opts):
         else:
             ref = synth.preintegrate(acc[i:i + 1, :k + 1], gyr[i:i + 1, :k + 1], dt, ba[i:i + 1], bg[i:i + 1])[0]
         assert np.allclose(got[i], ref, rtol=1e-11, atol=1e-13 * max(1.0, np.abs(ref).max())), i
+
+
+@pytest.mark.gpu
+def test_benchmark_windows_translation_equivariance_and_cost_descent(solver, oracle, opts):
+    """Size-independent properties at the benchmark's window configuration (230 features, IMU + LiDAR between-factors, no prior):
+    every factor is relative, so moving the whole window by t moves the solution by t and leaves every cost unchanged; the trust-region
+    solve never raises the cost; and one of the windows is checked against the oracle outright."""
+    cfg = synth.SynthConfig(n_features=230, with_prior=False)
+    base = [synth.make_window(300 + k, opts, cfg)[0] for k in range(4)]
+    shifts = [np.zeros(3), np.array([100.0, -50.0, 7.0]), np.array([-1234.5, 987.25, -60.0])]
+    wins = []
+    for w in base:
+        for t in shifts:
+            v = copy.deepcopy(w)
+            v.para_pose[:, :3] += t
+            if v.gauge_P0 is not None:
+                v.gauge_P0 = v.gauge_P0 + t
+            wins.append(v)
+    solver.batch_upload(wins, [None] * len(wins))
+    solver.batch_solve()
+    got = solver.batch_download()
+    for k in range(len(base)):
+        g0 = got[3 * k]
+        assert g0.summary["final_cost"] <= g0.summary["initial_cost"]
+        for j in (1, 2):
+            g = got[3 * k + j]
+            assert g.summary["num_iterations"] == g0.summary["num_iterations"]
+            assert abs(g.summary["final_cost"] - g0.summary["final_cost"]) <= 1e-7 * g0.summary["final_cost"]
+            assert np.abs((g.Ps - shifts[j]) - g0.Ps).max() < 1e-7           # metres, at |t| ~ 1.5 km: eps * |t| * condition
+            assert np.abs(g.Rs - g0.Rs).max() < 1e-8 and np.abs(g.Vs - g0.Vs).max() < 1e-7
+    _compare(got[0], oracle.window_solve(opts, wins[0], None))
+    _compare(got[5], oracle.window_solve(opts, wins[5], None))
