@@ -243,6 +243,19 @@ int vilf_imu_preintegrate(const vilf_imu_noise *noise, const double acc_0[3], co
 int vilf_imu_preintegrate_batch(vilf_handle *h, int n, const vilf_imu_noise *noise, const double *acc_0 /*[n][3]*/, const double *gyr_0,
                                 const double *linearized_ba, const double *linearized_bg, const int *n_samples, int max_samples,
                                 const double *dt /*[n][max]*/, const double *acc /*[n][max][3]*/, const double *gyr, vilf_imu_preint *out);
+/* ---- visual-inertial alignment before the first window solve (≙ VisualIMUAlignment, initial/initial_aligment.cpp:199-207; device) ----
+ * n_frames frames of all_image_frame in time order: frame_R[k] = c0_R_bk (ImageFrame::R), frame_T[k] = c0_T_ck up to scale (ImageFrame::T),
+ * and the n_frames - 1 raw IMU intervals between them (interval k joins frames k and k + 1 = frame k + 1's pre_integration; arrays as in
+ * vilf_imu_preintegrate_batch), first integrated at lin_ba / lin_bg. TIC and G come from the handle's options.
+ *   solveGyroscopeBias (:3)  -> delta_bg (the caller adds it to every Bgs[i]); every interval is re-integrated at (0, bgs0 + delta_bg) -> pre_out[n-1]
+ *   LinearAlignment (:125) + RefineGravity (:55) -> g (c0 frame), x = [v_0 .. v_{n-1} in the body frames, 2 tangent coefficients, s], *n_x = 3 n + 3
+ *   (3 n + 4 = [v.., g, 100 s] when the |g| / s gate at :184 fails), *ok = the reference's bool result. */
+int vilf_visual_imu_alignment(vilf_handle *h, int n_frames, const double *frame_R /*[n][9]*/, const double *frame_T /*[n][3]*/,
+                              const vilf_imu_noise *noise, const double *acc_0 /*[n-1][3]*/, const double *gyr_0, const double *lin_ba, const double *lin_bg,
+                              const int *n_samples /*[n-1]*/, int max_samples, const double *dt /*[n-1][max]*/, const double *acc /*[n-1][max][3]*/, const double *gyr,
+                              const double bgs0[3], double delta_bg[3], double g[3], double *x /*[3 n + 4]*/, int *n_x, vilf_imu_preint *pre_out /*[n-1] or NULL*/,
+                              int *ok);
+
 /* ---- scan-to-map (≙ EstimationMapping) -------------------------------------------------- */
 /* points are float xyzi (pcl::PointXYZI without padding): [n][4] */
 int vilf_scan2map_init(vilf_handle *h, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);   /* localMapInited, :105 */

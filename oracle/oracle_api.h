@@ -40,6 +40,16 @@ int vilo_se3_plus(const double x[7], const double delta[6], double xp[7]);
 int vilo_imu_sqrt_info(const vilf_imu_preint *pre, double out225[225]);
 int vilo_imu_preintegrate(const vilf_imu_noise *noise, const double acc_0[3], const double gyr_0[3], const double ba[3], const double bg[3],
                           int n, const double *dt, const double *acc, const double *gyr, vilf_imu_preint *out);
+/* VisualIMUAlignment (initial_aligment.cpp:199): n frames (R = c0_R_bk, T = c0_T_ck up to scale), n - 1 raw IMU intervals (interval k joins
+ * frames k and k + 1; [n-1][max_samples] sample slots), first integrated at lin_ba / lin_bg. Out: delta_bg (added to every Bgs[i] by the
+ * caller), the intervals re-integrated at (0, bgs0 + delta_bg), refined gravity g in the c0 frame, x = [v_0 .. v_{n-1} (body frames), 2 tangent
+ * coefficients, s] (n_x = 3 n + 3; 3 n + 4 with [.., g, 100 s] when the first gate fails), ok = the reference's bool result. */
+/* A.ldlt().solve(b) as restated in initial_alignment.cpp (n x n row-major, lower triangle read) */
+int vilo_ldlt_solve(int n, const double *A, const double *b, double *x);
+int vilo_visual_imu_alignment(const vilf_options *o, const vilf_imu_noise *noise, int n_frames, const double *frame_R, const double *frame_T,
+                              const double *acc_0, const double *gyr_0, const double *lin_ba, const double *lin_bg, const int *n_samples,
+                              int max_samples, const double *dt, const double *acc, const double *gyr, const double bgs0[3],
+                              double delta_bg[3], double g[3], double *x, int *n_x, vilf_imu_preint *pre_out, int *ok);
 /* robust corrector on one residual block: loss 0 = Cauchy(a), 1 = Huber(a) */
 int vilo_corrector(int loss, double a, int nres, double *residuals, int ncols, double *jacobian, double rho_out[3]);
 /* small linear algebra used by the path (for numpy cross-checks) */

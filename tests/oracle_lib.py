@@ -169,3 +169,33 @@ def feature_depth(cloud_xyzi, feat_xyz):
     out = np.zeros(max(len(f), 1), dtype=np.float32)
     assert L.vilo_feature_depth(c.ctypes.data_as(fp), len(c), f.ctypes.data_as(fp), len(f), out.ctypes.data_as(fp)) == 0
     return out[:len(f)].copy()
+
+
+def visual_imu_alignment(opts, noise, frame_R, frame_T, acc_0, gyr_0, lin_ba, lin_bg, n_samples, dt, acc, gyr, bgs0):
+    """VisualIMUAlignment on the oracle: dict(ok, delta_bg, g, x, pre[(n-1, 467)])"""
+    L = lib()
+    dp = abi.c_double_p
+    L.vilo_visual_imu_alignment.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.ImuNoise), C.c_int, dp, dp, dp, dp, dp, dp, C.POINTER(C.c_int), C.c_int, dp, dp, dp,
+                                            dp, dp, dp, dp, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
+    f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+    frame_R, frame_T, acc_0, gyr_0, lin_ba, lin_bg, dt, acc, gyr, bgs0 = [f64(v) for v in (frame_R, frame_T, acc_0, gyr_0, lin_ba, lin_bg, dt, acc, gyr, bgs0)]
+    ns = np.ascontiguousarray(n_samples, dtype=np.int32)
+    n = len(frame_R)
+    dbg, g, x = np.zeros(3), np.zeros(3), np.zeros(3 * n + 4)
+    pre = np.zeros((max(n - 1, 1), abi.IMU_DOUBLES))
+    nx, ok = C.c_int(0), C.c_int(0)
+    rc = L.vilo_visual_imu_alignment(C.byref(opts), C.byref(noise), n, abi.dptr(frame_R), abi.dptr(frame_T), abi.dptr(acc_0), abi.dptr(gyr_0), abi.dptr(lin_ba), abi.dptr(lin_bg),
+                                     ns.ctypes.data_as(C.POINTER(C.c_int)), dt.shape[1], abi.dptr(dt), abi.dptr(acc), abi.dptr(gyr), abi.dptr(bgs0),
+                                     abi.dptr(dbg), abi.dptr(g), abi.dptr(x), C.byref(nx), pre.ctypes.data, C.byref(ok))
+    assert rc == 0, rc
+    return dict(ok=bool(ok.value), delta_bg=dbg, g=g, x=x[:nx.value].copy(), pre=pre[:n - 1])
+
+
+def imu_preintegrate(noise, acc_0, gyr_0, ba, bg, dt, acc, gyr):
+    """IntegrationBase on the oracle: 467 doubles in vilf_imu_preint order"""
+    L = lib()
+    f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+    acc_0, gyr_0, ba, bg, dt, acc, gyr = [f64(v) for v in (acc_0, gyr_0, ba, bg, dt, acc, gyr)]
+    out = abi.ImuPreint()
+    L.vilo_imu_preintegrate(C.byref(noise), abi.dptr(acc_0), abi.dptr(gyr_0), abi.dptr(ba), abi.dptr(bg), len(dt), abi.dptr(dt), abi.dptr(acc), abi.dptr(gyr), C.byref(out))
+    return np.frombuffer(bytes(out), dtype=np.float64).copy()

@@ -236,6 +236,30 @@ def imu_preintegrate_batch(solver, noise, acc_0, gyr_0, ba, bg, n_samples, dt, a
     return out[:n]
 
 
+def visual_imu_alignment(solver, noise, frame_R, frame_T, acc_0, gyr_0, lin_ba, lin_bg, n_samples, dt, acc, gyr, bgs0):
+    """≙ VisualIMUAlignment(all_image_frame, Bgs, g, x) (initial/initial_aligment.cpp:199) on the device (vilf_visual_imu_alignment).
+    frame_R (n, 3, 3) = c0_R_bk, frame_T (n, 3) = c0_T_ck up to scale, the n - 1 raw IMU intervals as in imu_preintegrate_batch.
+    Returns dict(ok, delta_bg, g, x, pre): the reference's bool, the gyro-bias correction, refined gravity in c0, x = [body velocities,
+    2 tangent coefficients, scale] and the intervals re-integrated at (0, bgs0 + delta_bg) as (n - 1, 467) vilf_imu_preint rows."""
+    f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+    frame_R, frame_T, acc_0, gyr_0, lin_ba, lin_bg, dt, acc, gyr, bgs0 = [f64(v) for v in (frame_R, frame_T, acc_0, gyr_0, lin_ba, lin_bg, dt, acc, gyr, bgs0)]
+    ns = np.ascontiguousarray(n_samples, dtype=np.int32)
+    n = len(frame_R)
+    assert frame_R.size == 9 * n and frame_T.size == 3 * n and len(ns) == n - 1
+    dbg, g, x = np.zeros(3), np.zeros(3), np.zeros(3 * n + 4)
+    pre = np.zeros((max(n - 1, 1), abi.IMU_DOUBLES))
+    nx, ok = C.c_int(0), C.c_int(0)
+    L = solver._L
+    dp = abi.c_double_p
+    L.vilf_visual_imu_alignment.argtypes = [C.c_void_p, C.c_int, dp, dp, C.POINTER(abi.ImuNoise), dp, dp, dp, dp, C.POINTER(C.c_int), C.c_int, dp, dp, dp,
+                                            dp, dp, dp, dp, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
+    solver._check(L.vilf_visual_imu_alignment(solver._h, n, abi.dptr(frame_R), abi.dptr(frame_T), C.byref(noise), abi.dptr(acc_0), abi.dptr(gyr_0), abi.dptr(lin_ba),
+                                              abi.dptr(lin_bg), ns.ctypes.data_as(C.POINTER(C.c_int)), dt.shape[1] if dt.ndim == 2 else 0, abi.dptr(dt), abi.dptr(acc),
+                                              abi.dptr(gyr), abi.dptr(bgs0), abi.dptr(dbg), abi.dptr(g), abi.dptr(x), C.byref(nx), pre.ctypes.data, C.byref(ok)),
+                  "vilf_visual_imu_alignment")
+    return dict(ok=bool(ok.value), delta_bg=dbg, g=g, x=x[:nx.value].copy(), pre=pre[:n - 1])
+
+
 class Scan2Map:
     """Host mirror of EstimationMapping (feature_tracker/include/EstimationMapping.hpp): localMapInited / optimation_processing /
     getMapCloud over the device path. One LiDAR stream per BackendSolver handle."""

@@ -331,7 +331,8 @@ def write_tum(path, trajectory):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # synthetic multi-frame sequence (same motion / camera / IMU model as synth.make_window, feature tracks with ids)
-def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, pixel_sigma=0.5 / 460.0, state_noise=(0.05, np.deg2rad(0.5), 0.05)):
+def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, pixel_sigma=0.5 / 460.0, state_noise=(0.05, np.deg2rad(0.5), 0.05),
+                  imu_noise_scale=1.0, bias_scale=1.0, yaw_amplitude=None):
     """Returns a dict: stamps[n], imu[k] = (dt, acc[S,3], gyr[S,3]) for the interval ending at frame k (k >= 1, first-ever sample in
     imu0), images[k] = {feature_id: 8-vector}, lidar[k] = (q, t) relative LiDAR pose k-1 -> k, truth P/R/V, and `init[k]` = noisy
     (P, R, V, ba, bg) for the first WINDOW_SIZE + 1 frames (stands in for the reference's SfM initialisation)."""
@@ -344,6 +345,8 @@ def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, p
     t = np.arange(nt) * dt
     speed = rng.uniform(8.0, 12.0)
     Ay, wy, py = rng.uniform(0.05, 0.3), rng.uniform(0.3, 1.0), rng.uniform(0, 2 * np.pi)
+    if yaw_amplitude is not None:
+        Ay, wy = yaw_amplitude, 2.0
     Ap, wp, pp = rng.uniform(0.0, 0.03), rng.uniform(0.5, 2.0), rng.uniform(0, 2 * np.pi)
     Ar, wr, pr = rng.uniform(0.0, 0.03), rng.uniform(0.5, 2.0), rng.uniform(0, 2 * np.pi)
     yaw0 = rng.uniform(-np.pi, np.pi)
@@ -366,9 +369,9 @@ def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, p
     p2 = np.concatenate([np.zeros((1, 3)), np.cumsum(seg, axis=0)])
     P_imu = rng.uniform(-50, 50, 3) * np.array([1, 1, 0.02]) + p2[:: fine // 2][:nt]
     R_imu, w_b, v_imu, a_w = kin(t)
-    ba_true = rng.normal(0, 0.02, 3); bg_true = rng.normal(0, 0.002, 3)
-    acc_m = np.einsum('tji,tj->ti', R_imu, a_w + G) + ba_true + rng.normal(0, synth.ACC_N, (nt, 3))
-    gyr_m = w_b + bg_true + rng.normal(0, synth.GYR_N, (nt, 3))
+    ba_true = rng.normal(0, 0.02, 3) * bias_scale; bg_true = rng.normal(0, 0.002, 3) * bias_scale
+    acc_m = np.einsum('tji,tj->ti', R_imu, a_w + G) + ba_true + rng.normal(0, synth.ACC_N, (nt, 3)) * imu_noise_scale
+    gyr_m = w_b + bg_true + rng.normal(0, synth.GYR_N, (nt, 3)) * imu_noise_scale
     fidx = np.arange(n_frames) * S
     Pw, Rw, Vw = P_imu[fidx], R_imu[fidx], v_imu[fidx]
     Rc = Rw @ RIC
@@ -430,3 +433,30 @@ def run_sequence(seq, opts, backend, n_frames=None):
             est.process_odometry(*seq["lidar"][k])
         est.process_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if k < len(seq["init"]) else None)
     return est
+
+
+def make_alignment_case(seed, opts, n_frames=14, scale=3.7, rot_noise=np.deg2rad(0.05), pos_noise=0.01, **seq_kw):
+    """Inputs of VisualIMUAlignment (initial_aligment.cpp:199) from a synthetic drive: what the reference's SfM hands over — every
+    frame's body orientation c0_R_bk and camera position c0_T_ck in the frame of a reference camera c0, positions up to an unknown
+    scale — plus the raw IMU samples of every interval, first integrated at zero biases. Returns (inputs dict, truth dict)."""
+    seq = make_sequence(seed, n_frames, opts, max_cnt=1, **seq_kw)
+    rng = np.random.default_rng(seed + 77)
+    RIC = np.array(opts.RIC[:]).reshape(3, 3); TIC = np.array(opts.TIC[:]); G = np.array(opts.G[:])
+    Rw, Pw, Vw = seq["R"], seq["P"], seq["V"]
+    l = n_frames // 2
+    R_c0_w = (Rw[l] @ RIC).T
+    Pc = Pw + np.einsum('kij,j->ki', Rw, TIC)
+    frame_R = np.stack([R_c0_w @ Rw[k] @ synth.q_to_R(synth.q_exp(rng.normal(0, rot_noise, 3))) for k in range(n_frames)])
+    frame_T = np.stack([(R_c0_w @ (Pc[k] - Pc[l]) + rng.normal(0, pos_noise, 3)) / scale for k in range(n_frames)])
+    m = n_frames - 1
+    S = max(len(seq["imu"][k][1]) for k in range(1, n_frames)) + 2
+    dt = np.zeros((m, S)); acc = np.zeros((m, S, 3)); gyr = np.zeros((m, S, 3)); ns = np.zeros(m, dtype=np.int32)
+    acc_0 = np.zeros((m, 3)); gyr_0 = np.zeros((m, 3))
+    for k in range(1, n_frames):
+        d, a, g = seq["imu"][k]
+        ns[k - 1] = len(a); dt[k - 1, :len(a)] = d; acc[k - 1, :len(a)] = a; gyr[k - 1, :len(a)] = g
+        acc_0[k - 1], gyr_0[k - 1] = (seq["imu0"] if k == 1 else (seq["imu"][k - 1][1][-1], seq["imu"][k - 1][2][-1]))
+    inputs = dict(frame_R=frame_R, frame_T=frame_T, acc_0=acc_0, gyr_0=gyr_0, lin_ba=np.zeros((m, 3)), lin_bg=np.zeros((m, 3)), n_samples=ns,
+                  dt=dt, acc=acc, gyr=gyr, bgs0=np.zeros(3))
+    truth = dict(scale=scale, g=R_c0_w @ G, v_body=np.einsum('kji,kj->ki', Rw, Vw), bg=seq["bg"], ba=seq["ba"], l=l)
+    return inputs, truth
