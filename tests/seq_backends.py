@@ -9,6 +9,10 @@ class OracleBackend:
     def solve(self, win):
         return oracle_lib.window_solve(self.o, win, self.prior)
 
+    def align(self, inputs):
+        from vil_fusion_amd import abi, synth
+        return oracle_lib.visual_imu_alignment(self.o, abi.ImuNoise(synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W), **inputs)
+
     def marginalize(self, win, res):
         p = oracle_lib.window_marginalize(self.o, win, res, self.prior)
         self.prior = p if p.valid else None
@@ -21,6 +25,11 @@ class HipBackend:
 
     def solve(self, win):
         return self.s.optimization(win)         # uses / keeps the device-resident prior of slot 0
+
+    def align(self, inputs):
+        from vil_fusion_amd import abi, synth
+        from vil_fusion_amd.estimator import visual_imu_alignment
+        return visual_imu_alignment(self.s, abi.ImuNoise(synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W), **inputs)
 
     def marginalize(self, win, res):
         self.s.marginalize()

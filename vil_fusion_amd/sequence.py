@@ -167,6 +167,41 @@ class FeatureManager:
         self.feature = keep
 
 
+def R2ypr(R):
+    """Utility::R2ypr (utility.h:70-85), degrees"""
+    n, o, a = R[:, 0], R[:, 1], R[:, 2]
+    y = np.arctan2(n[1], n[0])
+    p = np.arctan2(-n[2], n[0] * np.cos(y) + n[1] * np.sin(y))
+    r = np.arctan2(a[0] * np.sin(y) - a[1] * np.cos(y), -o[0] * np.sin(y) + o[1] * np.cos(y))
+    return np.array([y, p, r]) / np.pi * 180.0
+
+
+def ypr2R(ypr):
+    """Utility::ypr2R (utility.h:88-117), degrees"""
+    y, p, r = np.asarray(ypr, dtype=np.float64) / 180.0 * np.pi
+    Rz = np.array([[np.cos(y), -np.sin(y), 0], [np.sin(y), np.cos(y), 0], [0, 0, 1]])
+    Ry = np.array([[np.cos(p), 0, np.sin(p)], [0, 1, 0], [-np.sin(p), 0, np.cos(p)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(r), -np.sin(r)], [0, np.sin(r), np.cos(r)]])
+    return Rz @ Ry @ Rx
+
+
+def g2R(g):
+    """Utility::g2R (utility.cpp:3-13): the rotation taking g to +z (Quaternion::FromTwoVectors), yaw removed"""
+    a = np.asarray(g, dtype=np.float64) / np.linalg.norm(g)
+    b = np.array([0.0, 0.0, 1.0])
+    c = float(a @ b)
+    if c < -1.0 + 1e-12:                      # antiparallel: FromTwoVectors falls back to an SVD-chosen axis; any axis orthogonal to a
+        ax = np.cross(a, np.array([1.0, 0, 0])); ax /= np.linalg.norm(ax)
+        q = np.array([ax[0], ax[1], ax[2], 0.0])
+    else:
+        ax = np.cross(a, b)
+        sN = np.sqrt((1.0 + c) * 2.0)
+        q = np.array([ax[0] / sN, ax[1] / sN, ax[2] / sN, sN * 0.5])
+    R0 = synth.q_to_R(q)
+    yaw = R2ypr(R0)[0]
+    return ypr2R(np.array([-yaw, 0.0, 0.0])) @ R0
+
+
 class Integration:
     """≙ IntegrationBase: the sample buffers + linearisation biases; the pre-integrated row is computed on demand."""
 
@@ -209,6 +244,7 @@ class SlidingWindowEstimator:
         self.trajectory = []            # (stamp, P[3], q[4] xyzw) of the newest frame after every solved frame
         self.flags = []
         self.summaries = []
+        self.initial_ok, self.alignment = None, None
 
     # estimator.cpp:90-101
     def process_odometry(self, q, t):
@@ -237,7 +273,9 @@ class SlidingWindowEstimator:
         self.acc_0, self.gyr_0 = acc, gyr
 
     # estimator.cpp:139-234. `init_state` = (P, R, V, ba, bg) of this frame while the window is being filled (replaces the SfM start-up)
-    def process_image(self, image, stamp, init_state=None):
+    def process_image(self, image, stamp, init_state=None, sfm_frames=None):
+        """`sfm_frames` (only looked at when the window has just filled): the output of initialStructure's SfM + PnP stage (estimator.cpp:237-371),
+        a time-ordered list of dict(stamp, R = c0_R_bk, T = c0_T_ck up to scale, pre = that frame's Integration) -> visualInitialAlign runs first."""
         j = self.frame_count
         keyframe = self.f.add_feature_check_parallax(j, dict(sorted(image.items())), self.td)
         self.marginalization_flag = MARGIN_OLD if keyframe else MARGIN_SECOND_NEW
@@ -249,6 +287,11 @@ class SlidingWindowEstimator:
         if j < WINDOW_SIZE:
             self.frame_count += 1
             return None
+        if sfm_frames is not None:
+            self.initial_ok = self.visual_initial_align(sfm_frames)
+            if not self.initial_ok:             # the reference slides the window and retries on the next frame (:201-216)
+                self.slide_window()
+                return None
         # solveOdometry (:492-503)
         self.f.triangulate(self.Ps, self.Rs, self.tic, self.ric)
         res = self.optimization()
@@ -258,6 +301,61 @@ class SlidingWindowEstimator:
         self.trajectory.append((self.stamps[WINDOW_SIZE], self.Ps[WINDOW_SIZE].copy(), q))
         self.flags.append(self.marginalization_flag)
         return res
+
+    # estimator.cpp:383-459
+    def visual_initial_align(self, frames):
+        n, m = len(frames), len(frames) - 1
+        S = max(len(fr["pre"].dt) for fr in frames[1:])
+        dt = np.zeros((m, S)); acc = np.zeros((m, S, 3)); gyr = np.zeros((m, S, 3)); ns = np.zeros(m, dtype=np.int32)
+        acc_0 = np.zeros((m, 3)); gyr_0 = np.zeros((m, 3)); lin_ba = np.zeros((m, 3)); lin_bg = np.zeros((m, 3))
+        for k, fr in enumerate(frames[1:]):
+            it = fr["pre"]
+            ns[k] = len(it.dt); dt[k, :ns[k]] = it.dt; acc[k, :ns[k]] = it.acc[1:]; gyr[k, :ns[k]] = it.gyr[1:]
+            acc_0[k], gyr_0[k], lin_ba[k], lin_bg[k] = it.acc[0], it.gyr[0], it.ba, it.bg
+        r = self.backend.align(dict(frame_R=np.array([fr["R"] for fr in frames]), frame_T=np.array([fr["T"] for fr in frames]), acc_0=acc_0, gyr_0=gyr_0,
+                                    lin_ba=lin_ba, lin_bg=lin_bg, n_samples=ns, dt=dt, acc=acc, gyr=gyr, bgs0=self.Bgs[0].copy()))
+        self.alignment = r
+        self.Bgs = self.Bgs + r["delta_bg"]                                   # solveGyroscopeBias (initial_aligment.cpp:29-30)
+        for fr in frames[1:]:
+            fr["pre"].ba, fr["pre"].bg = np.zeros(3), self.Bgs[0].copy()      # repropagate(0, Bgs[0]) (:32-36)
+        if not r["ok"]:
+            return False
+        x, g = r["x"], r["g"].copy()
+        by_stamp = {fr["stamp"]: fr for fr in frames}
+        fc = self.frame_count
+        for i in range(fc + 1):                                               # :396-403
+            fr = by_stamp[self.stamps[i]]
+            self.Ps[i], self.Rs[i] = np.array(fr["T"], dtype=np.float64), np.array(fr["R"], dtype=np.float64)
+            fr["is_key_frame"] = True
+        for it in self.f.feature:                                             # clearDepth(-1) (:405-408, feature_manager.cpp:181-192)
+            if self._used_f(it):
+                it.estimated_depth, it.lidar_depth_flag = -1.0, False
+        self.f.triangulate(self.Ps, self.Rs, np.zeros(3), self.ric)           # on the camera positions, no tic (:410-416)
+        s = x[-1]
+        for i in range(WINDOW_SIZE + 1):                                      # :419-422
+            if self.pre[i] is not None:
+                self.pre[i].ba, self.pre[i].bg = np.zeros(3), self.Bgs[i].copy()
+        P0 = s * self.Ps[0] - self.Rs[0] @ self.tic
+        for i in range(fc, -1, -1):                                           # :423-424
+            self.Ps[i] = s * self.Ps[i] - self.Rs[i] @ self.tic - P0
+        kv = -1
+        for fr in frames:                                                     # :425-434 (x is indexed by the key-frame counter, as the reference does)
+            if fr.get("is_key_frame"):
+                kv += 1
+                self.Vs[kv] = np.array(fr["R"]) @ x[3 * kv: 3 * kv + 3]
+        for it in self.f.feature:                                             # :435-441
+            if self._used_f(it):
+                it.estimated_depth *= s
+        R0 = g2R(g)                                                           # :443-454
+        yaw = R2ypr(R0 @ self.Rs[0])[0]
+        R0 = ypr2R(np.array([-yaw, 0.0, 0.0])) @ R0
+        self.g = R0 @ g
+        for i in range(fc + 1):
+            self.Ps[i] = R0 @ self.Ps[i]; self.Rs[i] = R0 @ self.Rs[i]; self.Vs[i] = R0 @ self.Vs[i]
+        return True
+
+    def _used_f(self, it):
+        return self.f._used(it)
 
     # estimator.cpp:505-547 + the factor walk :722-794 -> the ABI's window description
     def make_window(self):
@@ -420,8 +518,28 @@ def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, p
     return dict(stamps=fidx * dt, imu0=(acc_m[0], gyr_m[0]), imu=imu, images=images, lidar=lidar, init=init, P=Pw, R=Rw, V=Vw, ba=ba_true, bg=bg_true)
 
 
-def run_sequence(seq, opts, backend, n_frames=None):
-    """Feed a make_sequence() dict through SlidingWindowEstimator; returns the estimator (trajectory, flags, summaries)."""
+def make_sfm_frames(seq, opts, est, seed=0, scale=3.7, rot_noise=np.deg2rad(0.02), pos_noise=0.005):
+    """Stand-in for initialStructure's SfM + PnP output (estimator.cpp:237-371) for the frames now in the window: body orientation and camera
+    position of every frame in the frame of a reference camera c0 (the window's middle frame), positions divided by an unknown scale."""
+    import copy
+    rng = np.random.default_rng(seed + 4242)
+    RIC = np.array(opts.RIC[:]).reshape(3, 3); TIC = np.array(opts.TIC[:])
+    n = est.frame_count + 1
+    Rw, Pw = seq["R"][:n], seq["P"][:n]
+    l = n // 2
+    R_c0_w = (Rw[l] @ RIC).T
+    Pc = Pw + np.einsum('kij,j->ki', Rw, TIC)
+    frames = []
+    for k in range(n):
+        frames.append(dict(stamp=est.stamps[k], R=R_c0_w @ Rw[k] @ synth.q_to_R(synth.q_exp(rng.normal(0, rot_noise, 3))),
+                           T=(R_c0_w @ (Pc[k] - Pc[l]) + rng.normal(0, pos_noise, 3)) / scale, pre=copy.deepcopy(est.pre[k])))
+    return frames
+
+
+def run_sequence(seq, opts, backend, n_frames=None, startup=None):
+    """Feed a make_sequence() dict through SlidingWindowEstimator; returns the estimator (trajectory, flags, summaries).
+    startup=None: the first WINDOW_SIZE + 1 frames take seq["init"] (a state already initialised). startup=dict(make_sfm_frames kwargs): the
+    window fills from a zero state and visualInitialAlign (SfM stand-in + VisualIMUAlignment on the back-end) initialises it."""
     est = SlidingWindowEstimator(opts, backend)
     n = len(seq["images"]) if n_frames is None else n_frames
     est.process_imu(0.0, *seq["imu0"])                 # first sample: only latches acc_0 / gyr_0 (frame_count == 0)
@@ -431,7 +549,13 @@ def run_sequence(seq, opts, backend, n_frames=None):
             for a, w in zip(acc, gyr):
                 est.process_imu(dt, a, w)
             est.process_odometry(*seq["lidar"][k])
-        est.process_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if k < len(seq["init"]) else None)
+        if startup is None:
+            est.process_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if k < len(seq["init"]) else None)
+        elif k == WINDOW_SIZE:
+            est.stamps[k] = seq["stamps"][k]
+            est.process_image(seq["images"][k], seq["stamps"][k], None, sfm_frames=make_sfm_frames(seq, opts, est, **startup))
+        else:
+            est.process_image(seq["images"][k], seq["stamps"][k], None)
     return est
 
 
