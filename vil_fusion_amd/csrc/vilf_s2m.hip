@@ -229,6 +229,291 @@ __global__ __launch_bounds__(S2B_VT) void b_crop_compact(CSet map, const double 
     if (tid == 0) out.n[sid] = carry;
 }
 
+// ---- fused steady-state map update: crop box + voxel grid of (leaf-ordered old map ++ appended scan) in ONE pass -------------
+// createSubMap (:298-352) on a map that is already a voxel grid: the old map is in ascending leaf order (one point per leaf, up to
+// rounding), only the few thousand appended points are not. One workgroup per stream:
+//   A. the appended tail: crop, ABSOLUTE leaf key (z | y | x leaf coordinates, AXB bits each — lexicographic = pcl::VoxelGrid's index order
+//      for any min corner), packed with the tail index into one 64-bit word, bitonic-sorted in LDS; sorted points -> scratch; the
+//      index bits are then replaced by the number of distinct tail leaves before that position.
+//   B. one streaming sweep over the old map (MU_E points per thread and tile, neighbours i - 1 / i + 1 from cache): crop test, leaf key,
+//      binary search of the key in the LDS tail. An old leaf goes to (#old leaves before) + (#tail leaves before) - (#old leaves before
+//      that also occur in the tail) — the first and third counts come from one packed block scan. A tail run with the same leaf is summed
+//      into the old point (old first, then the tail in index order = the stable order of a full sort); tail leaves that fall strictly
+//      between two old keys are emitted by the thread of the upper key, the ones beyond the last old key afterwards.
+// HBM traffic: the map is read once and written once (the unfused path: crop copy, keys, merge, gather + write: ~3.5 x that).
+// Streams whose tail does not fit the LDS buffer are handled by the BIG instantiation (tail in global memory), launched only when the
+// scan capacity allows such tails; each instantiation skips the other's streams.
+#define MU_T 1024
+#define MU_E 2
+#define MU_TILE (MU_T * MU_E)
+#define MU_LDS_TAIL 8192
+#define MU_QCAP (2 * MU_TILE)
+#define S2B_ERR_ORDER 8
+template <int AXB>
+__device__ __forceinline__ bool mu_leaf(const float4 q, float inv, unsigned long long &k) {
+    const float fx = floorf(__fmul_rn(q.x, inv)), fy = floorf(__fmul_rn(q.y, inv)), fz = floorf(__fmul_rn(q.z, inv));
+    const float lim = (float)(1 << (AXB - 1));
+    const bool ok = fx >= -lim && fx < lim - 1.0f && fy >= -lim && fy < lim - 1.0f && fz >= -lim && fz < lim - 1.0f;   // false for NaN
+    const int off = 1 << (AXB - 1);
+    const unsigned long long ix = (unsigned long long)((int)fx + off), iy = (unsigned long long)((int)fy + off), iz = (unsigned long long)((int)fz + off);
+    k = ok ? ((iz << (2 * AXB)) | (iy << AXB) | ix) : 0ULL;
+    return ok;
+}
+struct MuBox { float mnx, mny, mnz, mxx, mxy, mxz; };
+__device__ __forceinline__ bool mu_inside(const float4 q, const MuBox &b) { return !(q.x < b.mnx || q.y < b.mny || q.z < b.mnz || q.x > b.mxx || q.y > b.mxy || q.z > b.mxz); }
+__device__ __forceinline__ void mu_acc(float4 &s, const float4 q) { s.x = __fadd_rn(s.x, q.x); s.y = __fadd_rn(s.y, q.y); s.z = __fadd_rn(s.z, q.z); s.w = __fadd_rn(s.w, q.w); }
+__device__ __forceinline__ float4 mu_centroid(const float4 *ts, int a, int e) {
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int j = a; j < e; j++) mu_acc(s, ts[j]);
+    const float nn = (float)(e - a);
+    return make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn);
+}
+// the uncommon old point of the sweep (old index i; H / M = old leaves / matched old leaves before it): tail leaves to emit between the
+// previous old key and this one, a tail run in this leaf, or a leaf that holds several old points. Such points are queued during the
+// sweep and handled afterwards, one per lane, from global memory — their dependent loads never sit on the sweep's critical path.
+template <int AXB, int IDXB>
+__device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, int nOld, const float4 *p, float4 *o, const float4 *ts, const unsigned long long *T, int ntv, int THtot,
+                                        float inv, const MuBox &box) {
+    constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
+    auto lower = [&](unsigned long long k) { int lo = 0, hi = ntv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T[mid] >> IDXB) < k) lo = mid + 1; else hi = mid; } return lo; };
+    auto thp = [&](int j) { return j < ntv ? (int)(T[j] & LOW) : THtot; };
+    const float4 q = p[i], qp = p[max(i - 1, 0)];
+    unsigned long long key, kp;
+    mu_leaf<AXB>(q, inv, key); mu_leaf<AXB>(qp, inv, kp);
+    const bool sv = mu_inside(q, box), hasp = i > 0, first = !hasp || kp != key;
+    const int jlo = lower(key);
+    int jup = jlo;
+    while (jup < ntv && (T[jup] >> IDXB) == key) jup++;
+    const bool tm = jup > jlo;
+    if (first) {
+        for (int jj = hasp ? lower(kp + 1) : 0; jj < jlo;) {
+            const unsigned long long lf = T[jj] >> IDXB;
+            int f = jj + 1;
+            while (f < jlo && (T[f] >> IDXB) == lf) f++;
+            o[H + thp(jj) - M] = mu_centroid(ts, jj, f);
+            jj = f;
+        }
+        if (tm && !sv) {                                     // the tail has this leaf; the old run may have no survivor at all -> a new leaf
+            bool any = false;
+            for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, kr); if (kr != key) break; if (mu_inside(r, box)) { any = true; break; } }
+            if (!any) o[H + thp(jlo) - M] = mu_centroid(ts, jlo, jup);
+        }
+    }
+    if (head) {
+        float4 s = make_float4(__fadd_rn(0.0f, q.x), __fadd_rn(0.0f, q.y), __fadd_rn(0.0f, q.z), __fadd_rn(0.0f, q.w));
+        int cnt = 1;
+        for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, kr); if (kr != key) break; if (mu_inside(r, box)) { mu_acc(s, r); cnt++; } }
+        for (int jj = jlo; jj < jup; jj++) { mu_acc(s, ts[jj]); cnt++; }
+        const float nn = (float)cnt;
+        o[H + thp(jlo) - M] = make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn);
+    }
+}
+template <bool BIG>
+__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, CSet out, float4 *ts_all, int ts_stride,
+                                                       unsigned long long *gT_all, int gT_stride, int lds_cap, int *err) {
+    constexpr int AXB = BIG ? 16 : 17, IDXB = BIG ? 16 : 13;
+    constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
+    extern __shared__ unsigned long long s_T[];
+    __shared__ int s_w[MU_E][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
+    const int n = map.n[sid], nOld = min(max(n_old[sid], 0), n), nt = n - nOld;
+    if ((nt > lds_cap) != BIG) return;
+    unsigned long long *T = BIG ? gT_all + (size_t)sid * gT_stride : s_T;
+    const float4 *p = map.p + (size_t)sid * map.cap;
+    float4 *o = out.p + (size_t)sid * out.cap;
+    float4 *ts = ts_all + (size_t)sid * ts_stride;
+    const double *pose = pose_all + 24 * sid;
+    MuBox box;
+    box.mnx = (float)(pose[4] - half); box.mny = (float)(pose[5] - half); box.mnz = (float)(pose[6] - half);
+    box.mxx = (float)(pose[4] + half); box.mxy = (float)(pose[5] + half); box.mxz = (float)(pose[6] + half);
+    int bad = 0;
+
+    // ---- A. tail: crop, key, sort, points in sorted order, distinct-leaf prefix
+    int P2 = 2;
+    while (P2 < nt) P2 <<= 1;
+    int myvalid = 0;
+    for (int j = tid; j < P2; j += MU_T) {
+        unsigned long long w = ~0ULL;
+        if (j < nt) {
+            const float4 q = p[nOld + j];
+            unsigned long long k;
+            if (mu_inside(q, box)) { if (mu_leaf<AXB>(q, inv, k)) { w = (k << IDXB) | (unsigned long long)j; myvalid++; } else bad |= S2B_ERR_VOXEL; }
+        }
+        T[j] = w;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (P2 >> 1); t += MU_T) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const unsigned long long a = T[i], b = T[l];
+                if ((a > b) == ((i & k) == 0)) { T[i] = b; T[l] = a; }
+            }
+            __syncthreads();
+        }
+    int ntv;
+    { int tot; block_excl_scan_1024(myvalid, s_w[0], tot); ntv = tot; }
+    for (int j = tid; j < ntv; j += MU_T) ts[j] = p[nOld + (int)(T[j] & LOW)];
+    __syncthreads();
+    int THtot = 0;
+    {   // thp(j) = number of distinct leaves among tail positions < j (blocked chunks of C positions per thread)
+        const int C = (P2 + MU_T - 1) / MU_T, j0 = tid * C;
+        int cnt = 0;
+        for (int j = j0; j < j0 + C && j < ntv; j++) cnt += (j == 0 || (T[j - 1] >> IDXB) != (T[j] >> IDXB)) ? 1 : 0;
+        int tot;
+        int run = block_excl_scan_1024(cnt, s_w[1], tot);
+        THtot = tot;
+        // flags are re-derived from the leaf bits, which the rewrite of the low bits does not touch
+        unsigned long long prev = (j0 > 0 && j0 <= ntv) ? (T[j0 - 1] >> IDXB) : ~0ULL;
+        __syncthreads();
+        for (int j = j0; j < j0 + C && j < ntv; j++) {
+            const unsigned long long lf = T[j] >> IDXB;
+            const int hd = (j == 0 || prev != lf) ? 1 : 0;
+            T[j] = (lf << IDXB) | (unsigned long long)run;
+            run += hd; prev = lf;
+        }
+    }
+    __syncthreads();
+    auto lower = [&](unsigned long long k) { int lo = 0, hi = ntv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T[mid] >> IDXB) < k) lo = mid + 1; else hi = mid; } return lo; };
+    auto thp = [&](int j) { return j < ntv ? (int)(T[j] & LOW) : THtot; };
+
+    // ---- B. sweep over the old map. Per tile: keys (+ survivor bit 63) go through LDS, so the neighbours i - 1 / i + 1 cost no global
+    // load; the next tile's points are requested before this tile is processed. The common case — an old leaf that survives, alone in
+    // its leaf, no tail point in it, no tail leaf between it and its predecessor — is handled inline; everything else is flagged and
+    // done by mu_rare() from LDS state (kept out of the unrolled body: registers).
+    unsigned long long *s_key = s_T + (BIG ? 0 : lds_cap);
+    int *s_te = reinterpret_cast<int *>(s_key + MU_TILE), *s_qi = s_te + MU_TILE, *s_qh = s_qi + MU_QCAP, *s_qm = s_qh + MU_QCAP;   // queue of uncommon points: index (| head bit 30), H, M
+    __shared__ int s_qn;
+    if (tid == 0) s_qn = 0;
+    auto flush = [&]() {
+        __syncthreads();
+        const int qn = s_qn;
+        for (int k = tid; k < qn; k += MU_T) mu_rare<AXB, IDXB>(s_qi[k] & 0x3fffffff, s_qh[k], s_qm[k], (s_qi[k] >> 30) & 1, nOld, p, o, ts, T, ntv, THtot, inv, box);
+        __syncthreads();
+        if (tid == 0) s_qn = 0;
+        __syncthreads();
+    };
+    constexpr unsigned long long SVB = 1ULL << 63;
+    int carryH = 0, carryM = 0, carryTE = 0;
+    unsigned long long carryK = 0;
+    float4 qn[MU_E];
+#pragma unroll
+    for (int u = 0; u < MU_E; u++) qn[u] = p[min(u * MU_T + tid, max(nOld - 1, 0))];
+    for (int t0 = 0; t0 < nOld; t0 += MU_TILE) {
+        float4 q[MU_E];
+        unsigned long long key[MU_E];
+        int tb[MU_E], flag[MU_E], incl[MU_E];
+        unsigned hm = 0, fm = 0, tmm = 0, cm = 0;                    // per-element bit masks: head, first of its run, tail has the leaf, needs mu_rare
+#pragma unroll
+        for (int u = 0; u < MU_E; u++) { q[u] = qn[u]; qn[u] = p[min(t0 + MU_TILE + u * MU_T + tid, nOld - 1)]; }
+#pragma unroll
+        for (int u = 0; u < MU_E; u++) {
+            const int i = t0 + u * MU_T + tid;
+            const bool valid = i < nOld;
+            if (!mu_leaf<AXB>(q[u], inv, key[u]) && valid) bad |= S2B_ERR_VOXEL;
+            const bool sv = valid && mu_inside(q[u], box);
+            s_key[u * MU_T + tid] = valid ? (key[u] | (sv ? SVB : 0ULL)) : ~0ULL;
+            if (sv) hm |= 1u << u;
+        }
+        __syncthreads();
+        const unsigned long long lastK = s_key[MU_TILE - 1];
+#pragma unroll
+        for (int u = 0; u < MU_E; u++) {
+            const int e = u * MU_T + tid, i = t0 + e;
+            const bool valid = i < nOld, hasp = i > 0, hasn = i + 1 < nOld;
+            const unsigned long long wp = e > 0 ? s_key[e - 1] : carryK;
+            unsigned long long wn = e + 1 < MU_TILE ? s_key[e + 1] : 0ULL;
+            if (e + 1 == MU_TILE && hasn) { unsigned long long kx; const float4 r = p[i + 1]; mu_leaf<AXB>(r, inv, kx); wn = kx; }
+            const unsigned long long kp = wp & ~SVB, kn = wn & ~SVB;
+            if (valid && hasp && kp > key[u]) bad |= S2B_ERR_ORDER;
+            if (valid && (!hasp || kp != key[u])) fm |= 1u << u;
+            if (valid && hasn && kn == key[u]) cm |= 1u << u;       // the leaf continues: summed by mu_rare
+            if (((hm >> u) & 1) && hasp && kp == key[u]) {          // an earlier survivor of the same leaf owns it (rare: rounding put two centroids in one leaf)
+                bool mine = !(wp & SVB);
+                if (mine) for (int b = i - 2; b >= 0; b--) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, kr); if (kr != key[u]) break; if (mu_inside(r, box)) { mine = false; break; } }
+                if (!mine) hm &= ~(1u << u);
+            }
+        }
+        {   // the searches of a lane advance together (independent LDS reads in flight)
+            int lo[MU_E], hi[MU_E];
+#pragma unroll
+            for (int u = 0; u < MU_E; u++) { lo[u] = 0; hi[u] = ntv; }
+            for (int span = ntv; span > 0; span >>= 1) {
+#pragma unroll
+                for (int u = 0; u < MU_E; u++) if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if ((T[mid] >> IDXB) < key[u]) lo[u] = mid + 1; else hi[u] = mid; }
+            }
+#pragma unroll
+            for (int u = 0; u < MU_E; u++) {
+                const bool valid = t0 + u * MU_T + tid < nOld;
+                const bool tm = valid && lo[u] < ntv && (T[lo[u]] >> IDXB) == key[u];
+                if (tm) { tmm |= 1u << u; cm |= 1u << u; }
+                tb[u] = thp(lo[u]);                                  // tail leaves before this key
+                s_te[u * MU_T + tid] = tb[u] + (tm ? 1 : 0);         // ... up to and including it
+                const bool head = (hm >> u) & 1;
+                flag[u] = (head ? 1 : 0) | ((head && tm) ? (1 << 16) : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < MU_E; u++) {
+            incl[u] = flag[u];
+#pragma unroll
+            for (int of = 1; of < 64; of <<= 1) { const int v = __shfl_up(incl[u], of, 64); if (lane >= of) incl[u] += v; }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int u = 0; u < MU_E; u++) s_w[u][wave] = incl[u];
+        }
+        __syncthreads();
+        int base = 0;
+#pragma unroll
+        for (int u = 0; u < MU_E; u++) {
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { const int x = s_w[u][k]; if (k < wave) off += x; tot += x; }
+            const int ex = base + off + incl[u] - flag[u];
+            base += tot;
+            const int e = u * MU_T + tid;
+            const int te_prev = e > 0 ? s_te[e - 1] : carryTE;
+            if (((fm >> u) & 1) && tb[u] > te_prev) cm |= 1u << u;   // tail leaves strictly between the previous old key and this one
+            const int H = carryH + (ex & 0xffff), M = carryM + (ex >> 16);
+            if ((cm >> u) & 1) { const int k = atomicAdd(&s_qn, 1); s_qi[k] = (t0 + e) | (((hm >> u) & 1) << 30); s_qh[k] = H; s_qm[k] = M; }
+            else if ((hm >> u) & 1)                                  // the common case: the old point is its leaf's centroid, sum from +0 as the reference does
+                o[H + tb[u] - M] = make_float4(__fadd_rn(0.0f, q[u].x), __fadd_rn(0.0f, q[u].y), __fadd_rn(0.0f, q[u].z), __fadd_rn(0.0f, q[u].w));
+        }
+        const int nextTE = s_te[MU_TILE - 1];
+        carryH += base & 0xffff; carryM += base >> 16;
+        carryTE = nextTE; carryK = lastK;
+        __syncthreads();                                             // s_key / s_te / s_w are rewritten by the next tile
+        if (s_qn > MU_QCAP - MU_TILE) flush();                     // uniform: every thread reads the same counter after the barrier
+    }
+    flush();
+    // ---- tail leaves beyond the last old key (all of them when there is no old map)
+    int jlast = 0;
+    if (nOld > 0) { unsigned long long kl; mu_leaf<AXB>(p[nOld - 1], inv, kl); jlast = lower(kl + 1); }
+    for (int jj = jlast + tid; jj < ntv; jj += MU_T) {
+        const unsigned long long lf = T[jj] >> IDXB;
+        if (jj > jlast && (T[jj - 1] >> IDXB) == lf) continue;
+        int e = jj + 1;
+        while (e < ntv && (T[e] >> IDXB) == lf) e++;
+        o[carryH + thp(jj) - carryM] = mu_centroid(ts, jj, e);
+    }
+    if (tid == 0) out.n[sid] = carryH + THtot - carryM;
+    if (bad) atomicOr(err + sid, bad);
+}
+// the old maps of every stream are in non-decreasing leaf order with leaf coordinates inside the AXB-bit range? flag[0] |= 1 if not
+__global__ void b_check_order(CSet map, float inv, int axb, int *flag) {
+    const int sid = blockIdx.y, n = map.n[sid];
+    const float4 *p = map.p + (size_t)sid * map.cap;
+    bool bad = false;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        unsigned long long k, kp = 0;
+        const bool ok = axb == 16 ? mu_leaf<16>(p[i], inv, k) : mu_leaf<17>(p[i], inv, k);
+        if (i > 0) { if (axb == 16) mu_leaf<16>(p[i - 1], inv, kp); else mu_leaf<17>(p[i - 1], inv, kp); }
+        if (!ok || kp > k) bad = true;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
 // ---- radix-hashed voxel neighbour index -----------------------------------------------------------------------------------
 // A map point hashes to a bucket by the low 8 bits of its 1 m cell coordinates in x and y: bucket = (ix & 255) << 8 | (iy & 255)
 // (a 16-bit radix digit; cells 256 m apart alias, z is not part of the key). The index is a single-pass counting (radix) sort of
@@ -706,7 +991,8 @@ struct S2B {
     DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], mapAlt[2], nMap[2], tmpB, nTmp, sorted[2], bstart[2], bcnt;   // map: current local maps; mapAlt: where the next step writes its maps
     DBuf tkeys, tkeys2, tvals, tvals2, nOld, mOld;      // steady-state map grids: the unsorted tails, old / surviving-old counts
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
-    DBuf map0[2], nMap0[2], pose0;
+    DBuf map0[2], nMap0[2], pose0, muT;
+    int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
     bool has_snapshot = false, scan_dirty = true;
     bool snap_live = false;            // the snapshot's maps still live in a map / mapAlt buffer (rewind = pointer swap, no copy)
     void *snap_ptr[2] = {nullptr, nullptr};
@@ -721,7 +1007,7 @@ struct S2B {
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &mapAlt[0], &mapAlt[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
                        &bstart[0], &bstart[1], &bcnt, &tkeys, &tkeys2, &tvals, &tvals2, &nOld, &mOld, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
-                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0};
+                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT};
         for (DBuf *b : all) b->release();
     }
 };
@@ -750,7 +1036,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
     const int wantScan[2] = {std::max(capScanE, 1), std::max(capScanS, 1)}, wantMap[2] = {std::max(capMapE, 1), std::max(capMapS, 1)};
     if (S != c->S) {
         c->release();
-        c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false;
+        c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false; c->order_state[0] = c->order_state[1] = 0;
         if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64) || !c->nOld.ensure((size_t)S * 4) || !c->mOld.ensure((size_t)S * 4)) return VILF_ERR_DEVICE;
         for (int w = 0; w < 2; w++) {
             if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->bstart[w].ensure((size_t)S * S2B_NBS * 4)) return VILF_ERR_DEVICE;
@@ -764,6 +1050,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         HIPCHECK(h, hipMemcpyAsync(c->pose.p, ident.data(), ident.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_bucket_index), hipFuncAttributeMaxDynamicSharedMemorySize, S2B_NB * 2));
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12 + MU_QCAP * 12));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned int, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned long long, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -861,6 +1148,21 @@ static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
     return VILF_OK;
 }
 
+static int mu_lds_cap(int cap_scan) { int p2 = 2; while (p2 < cap_scan) p2 <<= 1; return std::min(p2, MU_LDS_TAIL); }
+// is every stream's local map w in ascending leaf order (a voxel grid of an earlier step)? One check + 4-byte read-back when unknown
+// (after an init); a step always leaves the maps ordered, so the steady state never comes here.
+static int s2b_resolve_order(vilf_handle *h, S2B *c, int w) {
+    if (c->order_state[w] != 0) return VILF_OK;
+    const float leaf = (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
+    int flag = 0;
+    HIPCHECK(h, hipMemsetAsync(c->bits.p, 0, 4, h->stream));
+    hipLaunchKernelGGL(b_check_order, dim3(64, c->S), dim3(256), 0, h->stream, c->cs_map(w), 1.0f / leaf, c->capScan[w] > mu_lds_cap(c->capScan[w]) ? 16 : 17, c->bits.as<int>());
+    HIPCHECK(h, hipMemcpyAsync(&flag, c->bits.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    c->order_state[w] = flag ? 2 : 1;
+    return VILF_OK;
+}
+
 // one optimation_processing() for every stream; everything is enqueued on the handle's stream, no host round trip
 static int s2b_step(vilf_handle *h, S2B *c) {
     const int S = c->S;
@@ -893,9 +1195,9 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     }
     for (int w = 0; w < 2; w++) {     // createSubMap: append registered points, crop, voxel grid
         CSet map = c->cs_map(w), dsw = c->cs_ds(w), tmp = c->cs_tmp(w);
+        if ((rc = s2b_resolve_order(h, c, w)) != VILF_OK) return rc;
         hipLaunchKernelGGL(b_transform_append, GRID2(dsw.cap, S), 0, h->stream, dsw, d_pose, map, d_err);
         hipLaunchKernelGGL(b_bump, GRIDS(S), 0, h->stream, map, dsw, c->nOld.as<int>(), S);
-        hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp, c->nOld.as<int>(), c->mOld.as<int>());
         PROF(5)
         // the new map goes to the other buffer (the old one stays intact up to its old count: a snapshot taken on it can be
         // restored by swapping back). If that other buffer is where a live snapshot sits, save the snapshot first.
@@ -907,7 +1209,23 @@ static int s2b_step(vilf_handle *h, S2B *c) {
             }
             c->snap_live = false;
         }
-        if ((rc = s2b_voxel(h, c, tmp, leaf[w], c->cs_mapout(w), c->mOld.as<int>(), c->capScan[w])) != VILF_OK) return rc;
+        if (c->order_state[w] == 1) {  // steady state: one fused pass (crop + merge of the sorted tail + centroids), no host round trip
+            const int lds_cap = mu_lds_cap(c->capScan[w]);
+            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12 + (size_t)MU_QCAP * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+                               c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, lds_cap, d_err);
+            if (c->capScan[w] > lds_cap) {
+                int p2 = 2; while (p2 < c->capScan[w]) p2 <<= 1;
+                if (!c->muT.ensure((size_t)S * p2 * 8)) return VILF_ERR_DEVICE;
+                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12 + (size_t)MU_QCAP * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+                                   c->tmpB.as<float4>(), c->capScan[w], c->muT.as<unsigned long long>(), p2, lds_cap, d_err);
+            }
+            PROF(0)
+        } else {                       // a map that is not a voxel grid yet (as initialised): crop copy + full sort
+            hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp, c->nOld.as<int>(), c->mOld.as<int>());
+            PROF(5)
+            if ((rc = s2b_voxel(h, c, tmp, leaf[w], c->cs_mapout(w))) != VILF_OK) return rc;
+        }
+        c->order_state[w] = 1;
     }
     for (int w = 0; w < 2; w++) std::swap(c->map[w], c->mapAlt[w]);
     hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
@@ -947,7 +1265,8 @@ static void s2b_fill_result(const S2BRes &r, vilf_scan2map_result *res) {
 static int s2b_err_to_rc(vilf_handle *h, int err) {
     if (!err) return VILF_OK;
     h->err = std::string("scan2map: ") + ((err & S2B_ERR_MAPCAP) ? "local-map capacity exceeded; " : "") + ((err & S2B_ERR_EXTENT) ? "more than 65535 local-map points in one 1 m column bucket; " : "") +
-             ((err & S2B_ERR_VOXEL) ? "voxel index overflow (leaf too small for the cloud extent); " : "");
+             ((err & S2B_ERR_VOXEL) ? "voxel index overflow (leaf too small for the cloud extent); " : "") +
+             ((err & S2B_ERR_ORDER) ? "local map not in leaf order (internal); " : "");
     return VILF_ERR_UNSUPPORTED;
 }
 static int s2b_set_cloud(vilf_handle *h, S2B *c, DBuf &buf, int cap, int sid, int offset, const float *xyzi, int n) {
@@ -968,7 +1287,7 @@ extern "C" int vilf_scan2map_init(vilf_handle *h, const float *e, int ne, const 
     const float *src[2] = {e, s}; const int nn[2] = {ne, ns};                       // localMapInited (:105): map += cloud
     for (int w = 0; w < 2; w++) {
         if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], 0, c->h_nMap[w][0], src[w], nn[w])) != VILF_OK) return rc;
-        c->h_nMap[w][0] += nn[w];
+        c->h_nMap[w][0] += nn[w]; c->order_state[w] = 0;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->h_nMap[w].data(), 4, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -1045,7 +1364,7 @@ extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float 
     int rc;
     for (int w = 0; w < 2; w++) {                                                   // the stream's local map := cloud
         if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], stream, 0, src[w], nn[w])) != VILF_OK) return rc;
-        c->h_nMap[w][stream] = nn[w];
+        c->h_nMap[w][stream] = nn[w]; c->order_state[w] = 0;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + stream, &c->h_nMap[w][stream], 4, hipMemcpyHostToDevice, h->stream));
     }
     double p[24] = {0};
@@ -1084,6 +1403,9 @@ extern "C" int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long 
 extern "C" int vilf_scan2map_batch_snapshot(vilf_handle *h) {
     S2B_CHECK(h, 0)
     for (int w = 0; w < 2; w++) {                 // the maps are not copied: a step never overwrites its input maps (see s2b_step)
+        int rc = s2b_resolve_order(h, c, w);
+        if (rc != VILF_OK) return rc;
+        c->snap_order[w] = c->order_state[w];
         if (!c->nMap0[w].ensure((size_t)c->S * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemcpyAsync(c->nMap0[w].p, c->nMap[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
         c->snap_ptr[w] = c->map[w].p;
@@ -1101,6 +1423,7 @@ extern "C" int vilf_scan2map_batch_rewind(vilf_handle *h) {
         if (c->snap_live) { if (c->map[w].p != c->snap_ptr[w]) std::swap(c->map[w], c->mapAlt[w]); }
         else HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->nMap0[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
+        c->order_state[w] = c->snap_order[w];
     }
     HIPCHECK(h, hipMemcpyAsync(c->pose.p, c->pose0.p, (size_t)c->S * 24 * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)c->S * 4, h->stream));
