@@ -209,3 +209,46 @@ def test_scan2map_bench_size_parity_and_invariants(oracle, opts):
         assert np.all(np.diff(key) > 0), "ascending leaf order, one point per leaf"
         assert np.all(np.abs(m[:, :3] - pose_t.astype(np.float32)) <= np.float32(opts.s2m_crop_half) + 1e-3)
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_scan,leaf", [(3000, 0.8), (24000, 0.25)])
+def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
+    """createSubMap (EstimationMapping.hpp:298-352) in isolation: with <= 10 edge points in the map the reference skips the optimisation
+    (:250) and still updates the maps, so the pose is the constant-velocity prediction on both sides and the surf map sees: a crop box
+    (half 6 m) that moves 1.5 m per frame across the cloud (old leaves leave, leaves straddle the boundary), scan points falling into
+    existing leaves, between them and beyond both ends, exact duplicates, and — second case — more than 8192 new leaves per frame
+    (the fused update's global-memory variant). Maps must stay bit-identical to the oracle over 5 frames; the first frame also
+    exercises the unsorted-map path."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
+    o = oracle.default_options()
+    o.s2m_crop_half = 6.0
+    o.surf_leaf_size = leaf
+    rng = np.random.default_rng(n_scan)
+    S = 3
+    cloud = lambda n, c, h: np.concatenate([rng.uniform(-h, h, (n, 3)) + c, rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    s = BackendSolver(o)
+    b = Scan2MapBatch(s, S, 64, n_scan + 64, 256, 200000)
+    refs = [oracle.OracleS2M(o) for _ in range(S)]
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0]); last = np.array([0, 0, 0, 1, -1.5, 0.3, 0.0])
+    for i in range(S):
+        me, ms = cloud(5, np.zeros(3), 1.0), cloud(4000 + 500 * i, np.zeros(3), 8.0)
+        b.localMapInited(i, me, ms, ident, last)
+        refs[i].init(me, ms); refs[i].set_pose(ident, last)
+    for f in range(5):
+        for i in range(S):
+            sc = cloud(n_scan - 100 * i, np.zeros(3), 7.0)
+            sc[:50] = sc[50:100]                                       # exact duplicates
+            e = cloud(1, np.zeros(3), 1.0)
+            b.set_scan(i, e, sc)
+            r = refs[i].step(e, sc)
+        b.step()
+        got = b.results()
+        for i in range(S):
+            assert list(got[i].iterations) == [0, 0]
+            m, mr = b.getMapCloud(i, 1), refs[i].get_map(1)
+            assert m.shape == mr.shape, (f, i, m.shape, mr.shape)
+            assert np.array_equal(m, mr), (f, i)
+            assert np.array_equal(b.getMapCloud(i, 0), refs[i].get_map(0))
+    assert got[0].map_surf_size > (8192 if n_scan > 20000 else 500)
+    s.close()
