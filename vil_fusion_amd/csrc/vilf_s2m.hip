@@ -125,36 +125,59 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int &total)
     total = tot;
     return off + incl - v;
 }
+// Two launches over (tile, stream): b_voxel_heads counts the run heads of every 1024-pair tile, b_voxel_reduce turns the counts of the
+// stream's earlier tiles into its output offset (a handful of ints) and then works on its tile alone — every tile of every stream is
+// an independent workgroup, instead of one workgroup walking a stream's tiles one after the other.
 template <typename KeyT>
-__global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const KeyT *keys_all, const int *vals_all, CSet out) {
+__global__ __launch_bounds__(S2B_VT) void b_voxel_heads(CSet in, const KeyT *keys_all, int *tile_heads, int ntiles) {
     __shared__ int s_w[16];
-    const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
+    const int tid = threadIdx.x, sid = blockIdx.y, t = blockIdx.x, n = in.n[sid];
+    const int i = t * S2B_VT + tid;
+    int head = 0;
+    if (t * S2B_VT < n) {
+        const KeyT *keys = keys_all + (size_t)sid * in.cap;
+        const int ic = min(i, n - 1);
+        const KeyT k = keys[ic], kprev = keys[max(ic - 1, 0)];
+        head = (i < n && (i == 0 || kprev != k)) ? 1 : 0;
+    }
+    int total;
+    block_excl_scan_1024(head, s_w, total);
+    if (tid == 0) tile_heads[(size_t)sid * ntiles + t] = total;
+}
+template <typename KeyT>
+__global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const KeyT *keys_all, const int *vals_all, CSet out, const int *tile_heads, int ntiles) {
+    __shared__ int s_w[16];
+    const int tid = threadIdx.x, sid = blockIdx.y, t = blockIdx.x, n = in.n[sid];
+    const int t0 = t * S2B_VT;
+    if (t0 >= n) { if (t == 0 && tid == 0) out.n[sid] = 0; return; }
     const size_t base = (size_t)sid * in.cap;
     const KeyT *keys = keys_all + base;
     const int *vals = vals_all + base;
     const float4 *p = in.p + base;
     float4 *o = out.p + (size_t)sid * out.cap;
+    const int i = t0 + tid, ic = min(i, n - 1);
+    // everything a lane needs for its own element is requested up front (clamped, unconditional loads): the keys before and
+    // after, the point index, the point. A leaf with one point then needs no further memory round trip after the scan.
+    const KeyT k = keys[ic], kprev = keys[max(ic - 1, 0)], knext = keys[min(ic + 1, n - 1)];
+    const float4 q0 = p[vals[ic]];
     int carry = 0;
-    for (int t0 = 0; t0 < n; t0 += S2B_VT) {
-        const int i = t0 + tid, ic = min(i, n - 1);
-        // everything a lane needs for its own element is requested up front (clamped, unconditional loads): the keys before and
-        // after, the point index, the point. A leaf with one point — the common case of an already voxelised map — then needs no
-        // further memory round trip after the scan.
-        const KeyT k = keys[ic], kprev = keys[max(ic - 1, 0)], knext = keys[min(ic + 1, n - 1)];
-        const float4 q0 = p[vals[ic]];
-        const int head = (i < n && (i == 0 || kprev != k)) ? 1 : 0;
-        int total;
-        const int pos = carry + block_excl_scan_1024(head, s_w, total);
-        if (head) {
-            float cx = __fadd_rn(0.0f, q0.x), cy = __fadd_rn(0.0f, q0.y), cz = __fadd_rn(0.0f, q0.z), ci = __fadd_rn(0.0f, q0.w); int cnt = 1;   // accumulate from +0 like the reference (keeps the sign of a zero sum)
-            if (i + 1 < n && knext == k)
-                for (int j = i + 1; j < n && keys[j] == k; j++) { const float4 q = p[vals[j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
-            const float nn = (float)cnt;
-            o[pos] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
-        }
-        carry += total;
+    {
+        const int *th = tile_heads + (size_t)sid * ntiles;
+        for (int u = tid; u < t; u += S2B_VT) carry += th[u];
+        if (t > 1) { int tot; block_excl_scan_1024(carry, s_w, tot); carry = tot; __syncthreads(); }   // t <= 1: only lane 0 holds a value ...
+        else carry = t == 1 ? th[0] : 0;                                                                // ... which every lane can read itself
     }
-    if (tid == 0) out.n[sid] = carry;
+    const int head = (i < n && (i == 0 || kprev != k)) ? 1 : 0;
+    int total;
+    const int pos = carry + block_excl_scan_1024(head, s_w, total);
+    if (head) {
+        float cx = __fadd_rn(0.0f, q0.x), cy = __fadd_rn(0.0f, q0.y), cz = __fadd_rn(0.0f, q0.z), ci = __fadd_rn(0.0f, q0.w); int cnt = 1;   // accumulate from +0 like the reference (keeps the sign of a zero sum)
+        if (i + 1 < n && knext == k)
+            for (int j = i + 1; j < n && keys[j] == k; j++) { const float4 q = p[vals[j]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); cnt++; }
+        const float nn = (float)cnt;
+        o[pos] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+    }
+    if (t0 + S2B_VT >= n && tid == 0) out.n[sid] = carry + total;
 }
 // ---- map grids in steady state: the cropped old map is already in leaf order, only the appended points are not ------------
 // keys of the sorted prefix stay in place (index = position), the tail goes to a compact [S][cap_tail] array that is radix-sorted,
@@ -991,7 +1014,7 @@ struct S2B {
     DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], mapAlt[2], nMap[2], tmpB, nTmp, sorted[2], bstart[2], bcnt;   // map: current local maps; mapAlt: where the next step writes its maps
     DBuf tkeys, tkeys2, tvals, tvals2, nOld, mOld;      // steady-state map grids: the unsorted tails, old / surviving-old counts
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
-    DBuf map0[2], nMap0[2], pose0, muT;
+    DBuf map0[2], nMap0[2], pose0, muT, tileHeads;
     int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
     bool has_snapshot = false, scan_dirty = true;
     bool snap_live = false;            // the snapshot's maps still live in a map / mapAlt buffer (rewind = pointer swap, no copy)
@@ -1007,7 +1030,7 @@ struct S2B {
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &mapAlt[0], &mapAlt[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
                        &bstart[0], &bstart[1], &bcnt, &tkeys, &tkeys2, &tvals, &tvals2, &nOld, &mOld, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
-                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT};
+                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads};
         for (DBuf *b : all) b->release();
     }
 };
@@ -1119,7 +1142,10 @@ static int s2b_voxel_typed(vilf_handle *h, S2B *c, CSet in, float inv, CSet out,
         HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
         PROF(1)
     }
-    hipLaunchKernelGGL(b_voxel_reduce<KeyT>, dim3(S), dim3(S2B_VT), 0, h->stream, in, k2, c->vals2.as<int>(), out);
+    const int ntiles = (in.cap + S2B_VT - 1) / S2B_VT;
+    if (!c->tileHeads.ensure((size_t)S * ntiles * 4)) return VILF_ERR_DEVICE;
+    hipLaunchKernelGGL(b_voxel_heads<KeyT>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, k2, c->tileHeads.as<int>(), ntiles);
+    hipLaunchKernelGGL(b_voxel_reduce<KeyT>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, k2, c->vals2.as<int>(), out, c->tileHeads.as<int>(), ntiles);
     PROF(0)
     return VILF_OK;
 }
