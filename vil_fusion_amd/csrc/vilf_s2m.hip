@@ -916,7 +916,9 @@ __global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const dou
         __syncthreads();
         if (!go) break;
         if (!valid) continue;
-        s2m_evaluate<false>(s_c, frec, fkind, nfac, huber_a, s_red, s_cand);
+        // cost AND linearisation at the candidate in one sweep over the factor records: an accepted step (the usual case) then needs no
+        // second sweep; a rejected one leaves s_ev (the linearisation at x) untouched
+        s2m_evaluate<true>(s_c, frec, fkind, nfac, huber_a, s_red, s_cand);
         if (tid == 0) {
             const double cand = s_cand[27];
             double sn = 0;
@@ -943,9 +945,9 @@ __global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const dou
         __syncthreads();
         if (stop) break;
         if (accept) {     // a rejected step keeps the linearisation at x (s_ev) for the next ComputeStep
-            s2m_evaluate<true>(s_x, frec, fkind, nfac, huber_a, s_red, s_ev);
-            if (tid == 0) x_cost = s_ev[27];
+            if (tid < 28) s_ev[tid] = s_cand[tid];
             __syncthreads();
+            if (tid == 0) x_cost = s_ev[27];
         }
     }
     if (tid == 0) {
