@@ -644,10 +644,15 @@ __device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, doubl
                         c3 = c2; c2 = c; s2 = s;
                         gq = c * e[i];
                         hq = c * p;
-                        r = hypot(p, e[i]);
-                        e[i + 1] = s * r;
-                        s = e[i] / r;
-                        c = p / r;
+                        {   // r = hypot(p, e[i]), s = e[i] / r, c = p / r through one reciprocal square root: this recurrence is the serial
+                            // critical path of the whole decomposition (the magnitudes here are far from overflow)
+                            const double ei = e[i], rr = p * p + ei * ei;
+                            const double inv = rr > 0.0 ? rsqrt_nr(rr) : 0.0;
+                            r = rr * inv;
+                            e[i + 1] = s * r;
+                            s = ei * inv;
+                            c = p * inv;
+                        }
                         p = c * d[i] - s * gq;
                         d[i + 1] = hq + s * (c * gq + s * d[i]);
                         s_cs[2 * i] = c; s_cs[2 * i + 1] = s;
@@ -659,14 +664,16 @@ __device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, doubl
                 }
                 __syncthreads();
                 const int more = s_ctl[1];
-                if (tid < n) {
+                if (tid < n) {                   // row k of the eigenvector matrix through the whole rotation sequence; the running column stays in a register
                     const int k = tid;
+                    double hq = VV(k, m);
                     for (int i = m - 1; i >= l; i--) {
                         const double c = s_cs[2 * i], sn = s_cs[2 * i + 1];
-                        const double hq = VV(k, i + 1), vi = VV(k, i);
+                        const double vi = VV(k, i);
                         VV(k, i + 1) = sn * vi + c * hq;
-                        VV(k, i) = c * vi - sn * hq;
+                        hq = c * vi - sn * hq;
                     }
+                    VV(k, l) = hq;
                 }
                 __syncthreads();
                 if (!more) break;
