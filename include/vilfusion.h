@@ -256,6 +256,23 @@ int vilf_visual_imu_alignment(vilf_handle *h, int n_frames, const double *frame_
                               const double bgs0[3], double delta_bg[3], double g[3], double *x /*[3 n + 4]*/, int *n_x, vilf_imu_preint *pre_out /*[n-1] or NULL*/,
                               int *ok);
 
+/* ---- pose-graph back-end of global_fusion (≙ poseGraphOptimization.cpp: the gtsam graph + isam update, :349-374, :560-587, :433-436; device) ----
+ * Nodes = key-frame poses [qx qy qz qw tx ty tz] (gtsam::Pose3), node 0 carries the PriorFactor (its pose as handed in, sigma = prior_sigma).
+ * Edges = BetweenFactor<Pose3>(i, j, measured = T_i^-1 T_j) with a Diagonal noise model given as sigmas in gtsam's tangent order
+ * [rot x y z, trans x y z] (the reference: odometry variances 1e-6 / 1e-4, loop variances 0.5) and robust = 1 for
+ * noiseModel::Robust(Cauchy(1), ...) (the ICP loop edges). Every consecutive pair (k, k + 1) needs at least one edge (the odometry
+ * chain); all other edges are loop closures. ISAM2's incremental Gauss-Newton is run as batch Gauss-Newton to convergence:
+ * at most max_iterations steps, stop when max |delta| < tol. poses_qt is updated in place. */
+typedef struct vilf_pg_edge {
+    int i, j;
+    double q[4], t[3];        /* measured relative pose, x y z w */
+    double sigma[6];
+    int robust;
+    int pad_;
+} vilf_pg_edge;
+int vilf_posegraph_optimize(vilf_handle *h, int n_nodes, double *poses_qt /*[n][7] in/out*/, const double prior_sigma[6], int n_edges, const vilf_pg_edge *edges,
+                            int max_iterations, double tol, int *iterations_out, double *final_cost);
+
 /* ---- scan-to-map (≙ EstimationMapping) -------------------------------------------------- */
 /* points are float xyzi (pcl::PointXYZI without padding): [n][4] */
 int vilf_scan2map_init(vilf_handle *h, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);   /* localMapInited, :105 */

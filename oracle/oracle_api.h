@@ -50,6 +50,12 @@ int vilo_visual_imu_alignment(const vilf_options *o, const vilf_imu_noise *noise
                               const double *acc_0, const double *gyr_0, const double *lin_ba, const double *lin_bg, const int *n_samples,
                               int max_samples, const double *dt, const double *acc, const double *gyr, const double bgs0[3],
                               double delta_bg[3], double g[3], double *x, int *n_x, vilf_imu_preint *pre_out, int *ok);
+/* global_fusion pose graph (poseGraphOptimization.cpp): batch Gauss-Newton over PriorFactor + BetweenFactor<Pose3> (see pose_graph.cpp) */
+int vilo_posegraph_optimize(int n_nodes, double *poses_qt, const double prior_sigma[6], int n_edges, const vilf_pg_edge *edges, int max_iterations, double tol,
+                            int *iterations_out, double *final_cost);
+/* one whitened (robust: re-weighted) BetweenFactor: e[6], A = de/d(delta_i), B = de/d(delta_j) (row-major 6x6), cost = rho / 2 */
+int vilo_pg_between(const double pi_qt[7], const double pj_qt[7], const double meas_qt[7], const double sigma[6], int robust, double e[6], double A36[36], double B36[36], double *cost);
+int vilo_pg_retract(const double p_qt[7], const double delta[6], double out_qt[7]);   /* Pose3::retract = p * Expmap(delta) */
 /* robust corrector on one residual block: loss 0 = Cauchy(a), 1 = Huber(a) */
 int vilo_corrector(int loss, double a, int nres, double *residuals, int ncols, double *jacobian, double rho_out[3]);
 /* small linear algebra used by the path (for numpy cross-checks) */

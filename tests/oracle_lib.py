@@ -199,3 +199,47 @@ def imu_preintegrate(noise, acc_0, gyr_0, ba, bg, dt, acc, gyr):
     out = abi.ImuPreint()
     L.vilo_imu_preintegrate(C.byref(noise), abi.dptr(acc_0), abi.dptr(gyr_0), abi.dptr(ba), abi.dptr(bg), len(dt), abi.dptr(dt), abi.dptr(acc), abi.dptr(gyr), C.byref(out))
     return np.frombuffer(bytes(out), dtype=np.float64).copy()
+
+
+def pg_between(pi, pj, meas, sigma, robust=0):
+    """one whitened BetweenFactor<Pose3>: (e[6], A[6,6], B[6,6], cost)"""
+    L = lib()
+    dp = abi.c_double_p
+    L.vilo_pg_between.argtypes = [dp, dp, dp, dp, C.c_int, dp, dp, dp, dp]
+    f64 = lambda v: np.ascontiguousarray(v, dtype=np.float64)
+    pi, pj, meas, sigma = f64(pi), f64(pj), f64(meas), f64(sigma)
+    e, A, B, c = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6)), np.zeros(1)
+    assert L.vilo_pg_between(abi.dptr(pi), abi.dptr(pj), abi.dptr(meas), abi.dptr(sigma), robust, abi.dptr(e), abi.dptr(A), abi.dptr(B), abi.dptr(c)) == 0
+    return e, A, B, c[0]
+
+
+def pg_retract(p, delta):
+    L = lib()
+    dp = abi.c_double_p
+    L.vilo_pg_retract.argtypes = [dp, dp, dp]
+    out = np.zeros(7)
+    L.vilo_pg_retract(abi.dptr(np.ascontiguousarray(p, dtype=np.float64)), abi.dptr(np.ascontiguousarray(delta, dtype=np.float64)), abi.dptr(out))
+    return out
+
+
+def make_pg_edges(edges):
+    """edges: iterable of (i, j, q[4], t[3], sigma[6], robust) -> ctypes array of abi.PgEdge"""
+    arr = (abi.PgEdge * max(len(edges), 1))()
+    for k, (i, j, q, t, sg, rb) in enumerate(edges):
+        arr[k].i, arr[k].j, arr[k].robust = int(i), int(j), int(rb)
+        arr[k].q[:] = list(map(float, q)); arr[k].t[:] = list(map(float, t)); arr[k].sigma[:] = list(map(float, sg))
+    return arr
+
+
+def posegraph_optimize(poses_qt, prior_sigma, edges, max_iterations=30, tol=1e-10):
+    """batch Gauss-Newton on the oracle: (poses[n,7], iterations, cost)"""
+    L = lib()
+    dp = abi.c_double_p
+    L.vilo_posegraph_optimize.argtypes = [C.c_int, dp, dp, C.c_int, C.POINTER(abi.PgEdge), C.c_int, C.c_double, C.POINTER(C.c_int), dp]
+    x = np.ascontiguousarray(poses_qt, dtype=np.float64).copy()
+    ps = np.ascontiguousarray(prior_sigma, dtype=np.float64)
+    arr = make_pg_edges(edges)
+    it, cost = C.c_int(0), np.zeros(1)
+    rc = L.vilo_posegraph_optimize(len(x), abi.dptr(x), abi.dptr(ps), len(edges), arr, max_iterations, tol, C.byref(it), abi.dptr(cost))
+    assert rc == 0, rc
+    return x, it.value, cost[0]

@@ -1,0 +1,121 @@
+"""the global_fusion pose-graph back-end (poseGraphOptimization.cpp) — PriorFactor + BetweenFactor<Pose3> graph with
+robust loop edges, ISAM2 restated as batch Gauss-Newton. CPU: the oracle's factor against finite differences, its solve against a dense
+numpy Gauss-Newton built from the same factors, loop closure removes odometry drift. GPU: HIP == oracle."""
+import numpy as np
+import pytest
+from vil_fusion_amd import posegraph, synth
+
+PRIOR_SIGMA = np.full(6, 1e-6)                                   # variances 1e-12 (poseGraphOptimization.cpp:123-126)
+ODOM_SIGMA = np.sqrt(np.array([1e-6] * 3 + [1e-4] * 3))          # :128-130
+LOOP_SIGMA = np.sqrt(np.full(6, 0.5))                            # :132-138
+
+
+def rand_pose(rng, rot=1.0, trans=5.0):
+    q = synth.q_exp(rng.normal(0, rot, 3))
+    return np.concatenate([q / np.linalg.norm(q), rng.normal(0, trans, 3)])
+
+
+def test_oracle_between_factor_against_finite_differences(oracle):
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        pi, pj = rand_pose(rng), rand_pose(rng)
+        meas = posegraph.between(pi, pj) if trial % 2 else rand_pose(rng, 0.5, 2.0)
+        if trial % 2:                                             # a measurement close to the truth: small residual
+            meas = oracle.pg_retract(meas, rng.normal(0, 0.05, 6))
+        sigma = rng.uniform(0.1, 2.0, 6)
+        for robust in (0, 1):
+            e, A, B, c = oracle.pg_between(pi, pj, meas, sigma, robust)
+            if not robust:
+                assert abs(c - 0.5 * e @ e) < 1e-12
+                h = 1e-6
+                for k in range(6):
+                    d = np.zeros(6); d[k] = h
+                    ep = oracle.pg_between(oracle.pg_retract(pi, d), pj, meas, sigma, 0)[0]; em = oracle.pg_between(oracle.pg_retract(pi, -d), pj, meas, sigma, 0)[0]
+                    assert np.abs((ep - em) / (2 * h) - A[:, k]).max() < 2e-7 * max(1.0, np.abs(A).max())
+                    ep = oracle.pg_between(pi, oracle.pg_retract(pj, d), meas, sigma, 0)[0]; em = oracle.pg_between(pi, oracle.pg_retract(pj, -d), meas, sigma, 0)[0]
+                    assert np.abs((ep - em) / (2 * h) - B[:, k]).max() < 2e-7 * max(1.0, np.abs(B).max())
+            else:                                                 # Robust(Cauchy(1)): the whitened factor scaled by sqrt(1 / (1 + r^2))
+                e0, A0, B0, c0 = oracle.pg_between(pi, pj, meas, sigma, 0)
+                w = np.sqrt(1.0 / (1.0 + e0 @ e0))
+                assert np.allclose(e, w * e0, rtol=1e-13) and np.allclose(A, w * A0, rtol=1e-13) and np.allclose(B, w * B0, rtol=1e-13)
+                assert abs(c - 0.5 * np.log1p(e0 @ e0)) < 1e-12
+
+
+def _dense_gauss_newton(oracle, x, edges, iters):
+    """reference solve: the same factors (through the oracle's factor hook), dense normal equations with numpy"""
+    x = x.copy(); K = len(x); x0 = x[0].copy()
+    for _ in range(iters):
+        H = np.zeros((6 * K, 6 * K)); g = np.zeros(6 * K)
+        ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+        e, A, B, _ = oracle.pg_between(x0, x[0], ident, PRIOR_SIGMA, 0)          # prior = between(prior pose, x0) with identity measurement: B is its Jacobian
+        H[:6, :6] += B.T @ B; g[:6] -= B.T @ e
+        for (i, j, q, t, sg, rb) in edges:
+            e, A, B, _ = oracle.pg_between(x[i], x[j], np.concatenate([q, t]), sg, rb)
+            si, sj = slice(6 * i, 6 * i + 6), slice(6 * j, 6 * j + 6)
+            H[si, si] += A.T @ A; H[sj, sj] += B.T @ B; H[si, sj] += A.T @ B; H[sj, si] += B.T @ A
+            g[si] -= A.T @ e; g[sj] -= B.T @ e
+        d = np.linalg.solve(H, g)
+        for k in range(K):
+            x[k] = oracle.pg_retract(x[k], d[6 * k: 6 * k + 6])
+    return x
+
+
+def test_oracle_solve_matches_dense_numpy_gauss_newton(oracle):
+    truth, x0, edges = posegraph.make_synthetic_graph(3, 24, loops=[(2, 20), (5, 23), (0, 12)], odom_noise=(0.01, 0.05), loop_noise=(0.002, 0.01))
+    for iters in (1, 3):
+        got, it, _ = oracle.posegraph_optimize(x0, PRIOR_SIGMA, edges, max_iterations=iters, tol=0.0)
+        ref = _dense_gauss_newton(oracle, x0, edges, iters)
+        assert it == iters
+        assert np.abs(got[:, 4:] - ref[:, 4:]).max() < 1e-8 and posegraph.max_rotation_difference(got, ref) < 1e-9
+
+
+def test_oracle_loop_closure_removes_drift(oracle):
+    truth, x0, edges = posegraph.make_synthetic_graph(7, 200, loops=[(3, 190), (10, 199), (40, 150)], odom_noise=(0.002, 0.02), loop_noise=(0.0005, 0.005))
+    drift0 = np.linalg.norm(x0[-1, 4:] - truth[-1, 4:])
+    got, it, cost = oracle.posegraph_optimize(x0, PRIOR_SIGMA, edges, max_iterations=30, tol=1e-9)
+    drift1 = np.linalg.norm(got[-1, 4:] - truth[-1, 4:])
+    # the reference's loop noise (variance 0.5, Cauchy) is weak against 190 odometry edges of variance 1e-4 / 1e-6: a partial correction
+    assert it < 30 and drift0 > 0.5 and drift1 < 0.7 * drift0, (it, drift0, drift1)
+    # the same loops trusted like odometry close the loop properly
+    tight = [(i, j, q, t, sg if abs(i - j) == 1 else ODOM_SIGMA, 0) for (i, j, q, t, sg, rb) in edges]
+    got2, it2, _ = oracle.posegraph_optimize(x0, PRIOR_SIGMA, tight, max_iterations=30, tol=1e-9)
+    assert it2 < 30 and np.linalg.norm(got2[-1, 4:] - truth[-1, 4:]) < 0.1 * drift0
+    # without loop edges the optimum is the odometry chain itself: nothing moves
+    chain = [e for e in edges if abs(e[0] - e[1]) == 1]
+    same, it3, cost2 = oracle.posegraph_optimize(x0, PRIOR_SIGMA, chain, max_iterations=5, tol=1e-9)
+    assert it3 <= 2 and np.abs(same - x0).max() < 1e-8 and cost2 < 1e-12
+
+
+def test_keyframe_gate_and_tum_writer(tmp_path):
+    """key-frame selection (2 m / 10 deg accumulated since the last key frame, poseGraphOptimization.cpp:517-536) and the TUM writer (:88-110)"""
+    pg = posegraph.PoseGraph(backend=None)
+    poses = []
+    for k in range(40):
+        yaw = 0.02 * k
+        q = synth.R_to_q(synth.euler_R(np.array(yaw), np.array(0.0), np.array(0.0)))
+        poses.append(np.concatenate([q, [0.5 * k, 0.0, 0.0]]))
+    keys = [pg.add_odometry(0.1 * k, p) for k, p in enumerate(poses)]
+    # first frame is always a key frame (the accumulators start huge, :50-51); then every 5th (4 x 0.5 m = 2 m is not > 2 m)
+    assert keys[0] and [k for k, f in enumerate(keys) if f][:4] == [0, 5, 10, 15]
+    assert len(pg.edges) == len(pg.nodes) - 1 and all(e[0] + 1 == e[1] for e in pg.edges)
+    pg.add_loop(0, len(pg.nodes) - 1, np.array([0, 0, 0, 1, 0.1, 0, 0.0]))
+    assert pg.edges[-1][5] == 1 and np.allclose(pg.edges[-1][4], LOOP_SIGMA)
+    path = tmp_path / "fs_loam_loop.txt"
+    pg.save_tum(str(path))
+    rows = np.loadtxt(str(path))
+    assert rows.shape == (len(pg.nodes), 8) and np.allclose(rows[:, 0], [n["stamp"] for n in pg.nodes], atol=1e-9)
+    assert np.allclose(rows[:, 1], [n["pose"][0] for n in pg.nodes], atol=1e-5) and np.allclose(np.linalg.norm(rows[:, 4:], axis=1), 1.0, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,loops", [(1, []), (2, []), (24, [(2, 20), (5, 23), (0, 12)]), (400, [(3, 390), (10, 399), (40, 150), (41, 151), (100, 300)]), (1500, [(k, 1490 - k) for k in range(0, 400, 10)])])
+def test_posegraph_matches_oracle(oracle, K, loops):
+    from vil_fusion_amd.estimator import BackendSolver, posegraph_optimize
+    truth, x0, edges = posegraph.make_synthetic_graph(11 + K, K, loops=loops, odom_noise=(0.002, 0.02), loop_noise=(0.0005, 0.005))
+    ref, it_ref, cost_ref = oracle.posegraph_optimize(x0, PRIOR_SIGMA, edges, max_iterations=30, tol=1e-9)
+    s = BackendSolver()
+    got, it, cost = posegraph_optimize(s, x0, PRIOR_SIGMA, edges, max_iterations=30, tol=1e-9)
+    s.close()
+    assert it == it_ref
+    assert np.abs(got[:, 4:] - ref[:, 4:]).max() < 1e-7 and posegraph.max_rotation_difference(got, ref) < 1e-9
+    assert abs(cost - cost_ref) <= 1e-6 * max(cost_ref, 1e-9)

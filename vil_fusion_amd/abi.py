@@ -94,6 +94,10 @@ class Prior(C.Structure):
     ]
 
 
+class PgEdge(C.Structure):
+    _fields_ = [("i", C.c_int), ("j", C.c_int), ("q", C.c_double * 4), ("t", C.c_double * 3), ("sigma", C.c_double * 6), ("robust", C.c_int), ("pad_", C.c_int)]
+
+
 class ImuNoise(C.Structure):
     _fields_ = [("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double)]
 
