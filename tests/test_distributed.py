@@ -65,3 +65,19 @@ def test_two_rank_gloo_pose_gather(tmp_path, n_units):
     win, prior, _ = synth.make_window(100 + n_units - 1, opts, synth.SynthConfig(n_features=30))
     ref = oracle_lib.window_solve(opts, win, prior)
     assert np.allclose(a[-1, 1:4], ref.Ps[-1], atol=1e-12)
+
+
+def test_gathered_poses_feed_the_pose_graph(tmp_path):
+    """the consumer of the gathered poses: rank 0's rows go through the key-frame gate into the pose graph"""
+    import torch.multiprocessing as mp
+    import oracle_lib
+    from vil_fusion_amd import posegraph
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, 6, str(tmp_path)), nprocs=2, join=True)
+    rows = np.load(tmp_path / "gather_0.npy")
+    pg = posegraph.PoseGraph(backend=lambda x, ps, e: oracle_lib.posegraph_optimize(x, ps, e)[0])
+    keys = [pg.add_odometry(r[0], np.concatenate([r[4:8], r[1:4]])) for r in rows]
+    assert keys[0] and len(pg.nodes) >= 1 and len(pg.edges) == len(pg.nodes) - 1
+    before = np.array([pg._qt(n["pose"]) for n in pg.nodes])
+    after = pg.update()
+    assert np.abs(after[:, 4:] - before[:, 4:]).max() < 1e-8        # an odometry chain without loop edges is its own optimum

@@ -128,6 +128,7 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     hipStreamSynchronize(h->stream);
     vilf_s2m_release(h);
     vilf_feat_release(h);
+    vilf_pg_release(h);
     for (auto &b : h->d) b.release();
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);

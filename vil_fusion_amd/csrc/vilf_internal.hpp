@@ -34,6 +34,7 @@ enum {
 
 struct S2B;
 struct FeatCtx;
+struct PgCtx;
 
 struct vilf_handle {
     vilf_options opts;
@@ -72,6 +73,7 @@ struct vilf_handle {
     size_t solve_lds = 0, lin_lds = 0;
     FeatCtx *feat = nullptr;                 // LiDAR feature extraction workspace (vilf_feat.hip)
     S2B *s2m = nullptr, *s2b = nullptr;      // scan-to-map state: single stream / batched streams (vilf_s2m.hip)
+    PgCtx *pg = nullptr;                     // pose-graph workspace (vilf_pg.hip)
 };
 
 #define HIPCHECK(h, call)                                                                                        \
@@ -86,3 +88,4 @@ struct vilf_handle {
 
 void vilf_s2m_release(vilf_handle *h);
 void vilf_feat_release(vilf_handle *h);
+void vilf_pg_release(vilf_handle *h);

@@ -260,6 +260,23 @@ def visual_imu_alignment(solver, noise, frame_R, frame_T, acc_0, gyr_0, lin_ba, 
     return dict(ok=bool(ok.value), delta_bg=dbg, g=g, x=x[:nx.value].copy(), pre=pre[:n - 1])
 
 
+def posegraph_optimize(solver, poses_qt, prior_sigma, edges, max_iterations=30, tol=1e-9):
+    """≙ the gtsam graph + isam update of global_fusion (poseGraphOptimization.cpp:349-374, :560-587, :433-436) on the device
+    (vilf_posegraph_optimize). poses_qt (n, 7) [qx qy qz qw tx ty tz]; edges: iterable of (i, j, q[4], t[3], sigma[6], robust).
+    Returns (poses (n, 7), iterations, cost)."""
+    x = np.ascontiguousarray(poses_qt, dtype=np.float64).copy()
+    ps = np.ascontiguousarray(prior_sigma, dtype=np.float64)
+    arr = (abi.PgEdge * max(len(edges), 1))()
+    for k, (i, j, q, t, sg, rb) in enumerate(edges):
+        arr[k].i, arr[k].j, arr[k].robust = int(i), int(j), int(rb)
+        arr[k].q[:] = [float(v) for v in q]; arr[k].t[:] = [float(v) for v in t]; arr[k].sigma[:] = [float(v) for v in sg]
+    it, cost = C.c_int(0), np.zeros(1)
+    L = solver._L
+    L.vilf_posegraph_optimize.argtypes = [C.c_void_p, C.c_int, abi.c_double_p, abi.c_double_p, C.c_int, C.POINTER(abi.PgEdge), C.c_int, C.c_double, C.POINTER(C.c_int), abi.c_double_p]
+    solver._check(L.vilf_posegraph_optimize(solver._h, len(x), abi.dptr(x), abi.dptr(ps), len(edges), arr, max_iterations, tol, C.byref(it), abi.dptr(cost)), "vilf_posegraph_optimize")
+    return x, it.value, cost[0]
+
+
 class Scan2Map:
     """Host mirror of EstimationMapping (feature_tracker/include/EstimationMapping.hpp): localMapInited / optimation_processing /
     getMapCloud over the device path. One LiDAR stream per BackendSolver handle."""
