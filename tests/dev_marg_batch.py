@@ -10,3 +10,6 @@ for rep in range(3):
     s.batch_upload(wins, priors)
     t0 = time.perf_counter(); s.batch_solve(); t1 = time.perf_counter(); s.batch_marginalize(); t2 = time.perf_counter()
     print(f"solve {1e3*(t1-t0):.1f} ms  marginalize {1e3*(t2-t1):.1f} ms")
+s.set_profiling(1)
+s.batch_upload(wins, priors); s.batch_solve(); s.batch_marginalize()
+print("marg profile", {k: round(v["ms"], 3) for k, v in s.get_profile_marginalize().items()})

@@ -56,6 +56,7 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
 #define MG_ND (MG_MD + MG_NK)
 #define MG_MROW 40          // per visual factor: J_P0[12] J_Pj[12] J_Ex[12] J_f[2] r[2]
 #define MG_PAIRM 400        // per pair (0,j): 19x19 (+19 rhs) products, stored 20x20
+#define MG_GCH 48           // factor rows staged per chunk in the pair gather of k_marg_prepare (15 KB of LDS)
 #define MG_MLDS 136         // largest Amm held in LDS by the Jacobi eigen-solver
 #define MG_INFO 128         // per window: [0] status [1] md [2] mf [3] n [4] m [5] nblocks [6] M(padded) [8..31] shifted ids [32..55] sizes
                             //             [56..79] idx [80..103] original ids

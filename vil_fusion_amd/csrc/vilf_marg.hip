@@ -272,23 +272,28 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
         }
     }
     __syncthreads();
-    // ---- per pair (0, j): [J0 Jj Jex r]^T [J0 Jj Jex r] (19 x 19) gathered over the pair's factors ------------------------
+    // ---- per pair (0, j): [J0 Jj Jex r]^T [J0 Jj Jex r] (19 x 19, upper triangle) over the pair's factors. The factor rows of a pair
+    // are staged through LDS in chunks (one coalesced 320-byte row per factor) and every entry is one thread's running sum over the
+    // factors in pair order — the same summation order as a per-entry gather from global memory, without its dependent loads.
     if (mode == 0) {
+        __shared__ double s_rows[MG_GCH * MG_MROW];
         const int *ps_slot = b.ps_slot + (size_t)w * FC;
-        for (int t = tid; t < 10 * MG_PAIRM; t += NT) {
-            const int jj = t / MG_PAIRM, e = t - MG_PAIRM * jj, u = e / 20, v = e - 20 * u;
-            double s = 0;
-            if (u < 19 && v < 19 && u <= v) {
-                const int p = pair_index_c(0, jj + 1);
-                // column u of X: 0..5 J0, 6..11 Jj, 12..17 Jex, 18 r  -> Mbuf component rows (row0, row1)
-                const int cu0 = (u < 18) ? (12 * (u / 6) + (u % 6)) : 38, cu1 = (u < 18) ? cu0 + 6 : 39;
-                const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : 38, cv1 = (v < 18) ? cv0 + 6 : 39;
-                for (int q = s_poff[p]; q < s_poff[p + 1]; q++) {
-                    const int slot = ps_slot[q];
-                    s += Mb[(size_t)slot * MG_MROW + (cu0)] * Mb[(size_t)slot * MG_MROW + (cv0)] + Mb[(size_t)slot * MG_MROW + (cu1)] * Mb[(size_t)slot * MG_MROW + (cv1)];
-                }
+        int u = 0, v = 0;
+        if (tid < 190) { int e = tid; while (e >= 19 - u) { e -= 19 - u; u++; } v = u + e; }      // upper-triangle entry tid -> (u <= v)
+        // column u of X: 0..5 J0, 6..11 Jj, 12..17 Jex, 18 r  -> Mbuf component rows (row0, row1)
+        const int cu0 = (u < 18) ? (12 * (u / 6) + (u % 6)) : 38, cu1 = (u < 18) ? cu0 + 6 : 39;
+        const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : 38, cv1 = (v < 18) ? cv0 + 6 : 39;
+        for (int jj = 0; jj < 10; jj++) {
+            const int p = pair_index_c(0, jj + 1), q0 = s_poff[p], q1 = s_poff[p + 1];
+            double sum = 0;
+            for (int c0 = q0; c0 < q1; c0 += MG_GCH) {
+                const int nr = min(MG_GCH, q1 - c0);
+                for (int idx = tid; idx < nr * MG_MROW; idx += NT) { const int r = idx / MG_MROW, comp = idx - MG_MROW * r; s_rows[idx] = Mb[(size_t)ps_slot[c0 + r] * MG_MROW + comp]; }
+                __syncthreads();
+                if (tid < 190) for (int r = 0; r < nr; r++) { const double *row = s_rows + r * MG_MROW; sum += row[cu0] * row[cv0] + row[cu1] * row[cv1]; }
+                __syncthreads();
             }
-            s_pm[t] = s;
+            if (tid < 190) s_pm[jj * MG_PAIRM + 20 * u + v] = sum;
         }
     }
     __syncthreads();
