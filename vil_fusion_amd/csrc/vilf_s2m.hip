@@ -551,59 +551,84 @@ __device__ __forceinline__ int bucket_of(int ix, int iy) { return ((ix & 255) <<
 // the arrival rank of a point inside its bucket, the workgroup scans the 65536 counts itself and scatters the points to
 // start[bucket] + rank. No global atomics, no separate scan / memset launches.
 #define S2B_IT 1024
+#define S2B_HW(w) ((w) + ((w) >> 5))     // LDS word index with one pad word per 32: a thread's 32 consecutive words and its neighbours' stay on different banks
+#define S2B_HWORDS (S2B_NB / 2 + S2B_NB / 64)
 __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all, int *start_all, float4 *sorted_all, int *err) {
-    extern __shared__ unsigned int s_hist[];          // [32768] two 16-bit counters per word, then [16] wave partials
-    __shared__ int s_w[S2B_IT / 64], s_total;
+    extern __shared__ unsigned int s_hist[];          // [S2B_HWORDS] two 16-bit counters per word (padded), then s_base[1024]
+    __shared__ int s_w[S2B_IT / 64], s_total, s_big;
+    int *s_base = reinterpret_cast<int *>(s_hist + S2B_HWORDS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
     const int n = map.n[sid];
     const size_t base = (size_t)sid * map.cap;
     const float4 *p = map.p + base;
-    int *bkt = bkt_all + base, *start = start_all + (size_t)sid * S2B_NBS;
+    unsigned short *rk = reinterpret_cast<unsigned short *>(bkt_all) + base;      // arrival rank of every point inside its bucket
+    int *start = start_all + (size_t)sid * S2B_NBS;
     float4 *sorted = sorted_all + base;
-    for (int i = tid; i < S2B_NB / 2; i += S2B_IT) s_hist[i] = 0;
+    for (int i = tid; i < S2B_HWORDS; i += S2B_IT) s_hist[i] = 0;
+    if (tid == 0) s_big = 0;
     __syncthreads();
     bool over = false;
-    for (int i = tid; i < n; i += S2B_IT) {
-        const float4 q = p[i];
-        const int b = bucket_of((int)floorf(q.x), (int)floorf(q.y));
-        const int sh = 16 * (b & 1);
-        const unsigned int old = atomicAdd(&s_hist[b >> 1], 1u << sh);
-        const unsigned int rank = (old >> sh) & 0xffffu;
-        if (rank == 0xffffu) over = true;              // the 65536th point of a bucket would carry into its neighbour
-        bkt[i] = (int)(((unsigned int)b << 16) | rank);
+    for (int i0 = tid; i0 < n; i0 += 4 * S2B_IT) {    // four points per lane in flight
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) q[u] = p[min(i0 + u * S2B_IT, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * S2B_IT;
+            if (i >= n) continue;
+            const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
+            const int sh = 16 * (b & 1);
+            const unsigned int old = atomicAdd(&s_hist[S2B_HW(b >> 1)], 1u << sh);
+            const unsigned int rank = (old >> sh) & 0xffffu;
+            if (rank == 0xffffu) over = true;          // the 65536th point of a bucket would carry into its neighbour
+            rk[i] = (unsigned short)rank;
+        }
     }
     if (over) atomicOr(err + sid, S2B_ERR_EXTENT);
     __syncthreads();
-    // exclusive scan: thread t owns buckets [64 t, 64 t + 64) = words [32 t, 32 t + 32)
+    // exclusive scan: thread t owns buckets [64 t, 64 t + 64) = words [32 t, 32 t + 32) (padded position 33 t + k)
     int local = 0;
-    for (int k = 0; k < 32; k++) { const unsigned int w = s_hist[32 * tid + ((k + tid) & 31)]; local += (int)(w & 0xffffu) + (int)(w >> 16); }   // rotated: no bank conflicts
+    for (int k = 0; k < 32; k++) { const unsigned int w = s_hist[33 * tid + k]; local += (int)(w & 0xffffu) + (int)(w >> 16); }
     int incl = local;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
     if (lane == 63) s_w[wave] = incl;
+    if (local > 0xffff) s_big = 1;                    // a 64-bucket group beyond 16 bits: the scatter pass reads the 32-bit starts from global memory
     __syncthreads();
     int off = incl - local;
     for (int k = 0; k < wave; k++) off += s_w[k];
     if (tid == S2B_IT - 1) s_total = off + local;
+    s_base[tid] = off;
+    int run = 0;                                       // the counters become exclusive prefixes inside the thread's group (16 bits each)
     for (int k = 0; k < 32; k += 2) {
-        const unsigned int w0 = s_hist[32 * tid + k], w1 = s_hist[32 * tid + k + 1];
+        const unsigned int w0 = s_hist[33 * tid + k], w1 = s_hist[33 * tid + k + 1];
+        const int c0 = (int)(w0 & 0xffffu), c1 = (int)(w0 >> 16), c2 = (int)(w1 & 0xffffu), c3 = (int)(w1 >> 16);
         int4 o4;
-        o4.x = off; off += (int)(w0 & 0xffffu);
-        o4.y = off; off += (int)(w0 >> 16);
-        o4.z = off; off += (int)(w1 & 0xffffu);
-        o4.w = off; off += (int)(w1 >> 16);
+        o4.x = off + run; o4.y = o4.x + c0; o4.z = o4.y + c1; o4.w = o4.z + c2;
         *reinterpret_cast<int4 *>(start + 64 * tid + 2 * k) = o4;
+        s_hist[33 * tid + k] = (unsigned int)(run & 0xffff) | ((unsigned int)((run + c0) & 0xffff) << 16);
+        s_hist[33 * tid + k + 1] = (unsigned int)((run + c0 + c1) & 0xffff) | ((unsigned int)((run + c0 + c1 + c2) & 0xffff) << 16);
+        run += c0 + c1 + c2 + c3;
     }
     __syncthreads();
     if (tid == 0) start[S2B_NB] = s_total;
+    const bool big = s_big != 0;
     __threadfence_block();
     __syncthreads();
-    for (int i = tid; i < n; i += S2B_IT) {
-        float4 q = p[i];
-        q.w = __int_as_float(i);                       // original map index (tie-break like a linear scan)
-        const unsigned int br = (unsigned int)bkt[i];
-        const int pos = start[br >> 16] + (int)(br & 0xffffu);
-        if (pos < map.cap) sorted[pos] = q;
+    for (int i0 = tid; i0 < n; i0 += 4 * S2B_IT) {
+        float4 q[4]; unsigned short r4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int ic = min(i0 + u * S2B_IT, n - 1); q[u] = p[ic]; r4[u] = rk[ic]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * S2B_IT;
+            if (i >= n) continue;
+            const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
+            const int st = big ? start[b] : s_base[b >> 6] + (int)((s_hist[S2B_HW(b >> 1)] >> (16 * (b & 1))) & 0xffffu);
+            const int pos = st + (int)r4[u];
+            q[u].w = __int_as_float(i);                // original map index (tie-break like a linear scan)
+            if (pos < map.cap) sorted[pos] = q[u];
+        }
     }
 }
 // exact 5-NN within the 3 x 3 bucket block: pos[] = positions in the bucket-sorted array, ordered by (squared distance, original index)
@@ -1074,7 +1099,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         for (int s = 0; s < S; s++) { ident[24 * s + 3] = 1.0; ident[24 * s + 11] = 1.0; ident[24 * s + 19] = 1.0; }
         HIPCHECK(h, hipMemcpyAsync(c->pose.p, ident.data(), ident.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
-        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_bucket_index), hipFuncAttributeMaxDynamicSharedMemorySize, S2B_NB * 2));
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_bucket_index), hipFuncAttributeMaxDynamicSharedMemorySize, S2B_HWORDS * 4 + S2B_IT * 4));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12 + MU_QCAP * 12));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned int, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned long long, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -1171,7 +1196,7 @@ static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out, cons
 
 static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
     CSet map = c->cs_map(w);
-    hipLaunchKernelGGL(b_bucket_index, dim3(c->S), dim3(S2B_IT), (size_t)S2B_NB * 2, h->stream, map, c->vals.as<int>(), c->bstart[w].as<int>(), c->sorted[w].as<float4>(), c->err.as<int>());
+    hipLaunchKernelGGL(b_bucket_index, dim3(c->S), dim3(S2B_IT), (size_t)S2B_HWORDS * 4 + S2B_IT * 4, h->stream, map, c->vals.as<int>(), c->bstart[w].as<int>(), c->sorted[w].as<float4>(), c->err.as<int>());
     PROF(2)
     return VILF_OK;
 }
