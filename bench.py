@@ -225,10 +225,10 @@ def main():
             alg.update({
                 "s2m_associate": B * 2 * nq * (12 + 27 * 2.0 * 16),      # 2 passes over all queries: point + 27 cells x c̄ = 2 pts x 16 B
                 "s2m_neighbour_index": B * nm * 16 * 2,                  # both maps: read points, write them cell-sorted
-                "s2m_radix_sort": B * (2 * nm + ns + nq) * 12 * 2,       # 6 sorts (2 scan grids, 2 indices, 2 map grids) priced as ONE pass over (key, index)
+                "s2m_radix_sort": B * ns * 12 * 2,                       # the 2 scan grids (the map grids merge a sorted tail in LDS), priced as ONE pass over (key, index)
                 "s2m_voxel_grid": B * (nm + ns + nq) * 16 * 2,           # 4 grids: read points, write centroids
                 "s2m_lm_solve": B * nq * 84.0 * 2 * 4,                   # factor records (80 B + kind), 2 passes x ~4 evaluations
-                "s2m_submap": B * nm * 16 * 2})
+                "s2m_submap": B * nq * 16 * 2})                         # transform + append of the registered scan (crop and grid are in s2m_voxel_grid)
         workload_tag = ("lidar+" if lid is not None else "") + "solve" + ("" if args.no_marginalize else "+marginalize")
         dom = max(alg, key=lambda k: prof[k]["ms"])
         avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)

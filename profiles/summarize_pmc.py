@@ -2,7 +2,7 @@
 """Summarise two rocprofv3 PMC passes of bench.py (--pmc FETCH_SIZE and --pmc WRITE_SIZE, each with --kernel-trace
 --output-format csv) into per-kernel and per-launch-group HBM traffic.
 
-    python profiles/summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up> <out prefix>
+    python profiles/summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up> <out prefix> [frames_per_gpu] [workload_tag]
 
 Counter unit: KB per dispatch. gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-counts wide coalesced reads by 2x,
 so corrected bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; raw = (FETCH_SIZE + WRITE_SIZE) * 1024. Groups are bench.py's launch
@@ -16,12 +16,13 @@ GROUPS = {   # kernel-name prefix -> bench.py launch group
     "k_linearize": "k_linearize", "k_solve": "k_solve", "k_step": "k_step",
     "k_marg_prepare": "k_marg_prepare", "k_marg_schur": "k_marg_schur", "k_marg_finish": "k_marg_finish", "k_prior_prep": "k_prior_prep",
     "b_minmax": "s2m_voxel_grid", "b_voxel_keys": "s2m_voxel_grid", "void b_voxel_keys": "s2m_voxel_grid", "void b_voxel_reduce": "s2m_voxel_grid",
-    "void b_voxel_merge": "s2m_voxel_grid", "void b_voxel_keys_split": "s2m_voxel_grid",
+    "void b_voxel_merge": "s2m_voxel_grid", "void b_voxel_keys_split": "s2m_voxel_grid", "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_voxel_grid",
+    "b_check_order": "s2m_voxel_grid",
     "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
     "b_crop_compact": "s2m_submap", "b_transform_append": "s2m_submap", "b_bump": "s2m_submap",
 }
 LAUNCHES_PER_STEP = {"k_linearize": 9, "k_solve": 8, "k_step": 8, "k_marg_prepare": 1, "k_marg_schur": 1, "k_marg_finish": 1, "k_prior_prep": 1,
-                     "s2m_voxel_grid": 10, "s2m_radix_sort": 4, "s2m_neighbour_index": 2, "s2m_associate": 4, "s2m_lm_solve": 2, "s2m_submap": 2}
+                     "s2m_voxel_grid": 8, "s2m_radix_sort": 2, "s2m_neighbour_index": 2, "s2m_associate": 4, "s2m_lm_solve": 2, "s2m_submap": 2}
 
 
 def group_of(name):
@@ -33,13 +34,15 @@ def group_of(name):
 
 def main():
     fetch_csv, write_csv, steps, prefix = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    frames = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
+    tag = sys.argv[6] if len(sys.argv) > 6 else "lidar+solve+marginalize"
     per_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
     for cname, path in (("FETCH_SIZE", fetch_csv), ("WRITE_SIZE", write_csv)):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == cname:
                 per_kernel[r["Kernel_Name"].split("(")[0][:80]][cname].append(float(r["Counter_Value"]))
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py --steps S --warmup W --no-cpu-baseline (two passes)",
-           "note": __doc__.split("Counter unit:")[1].strip(), "steps_in_run": steps, "kernels": {}, "groups": {}}
+           "note": __doc__.split("Counter unit:")[1].strip(), "steps_in_run": steps, "config": {"frames_per_gpu": frames, "workload_tag": tag}, "kernels": {}, "groups": {}}
     rows = []
     groups = collections.defaultdict(lambda: [0.0, 0.0])
     for k, d in sorted(per_kernel.items()):
