@@ -613,7 +613,7 @@ __device__ __forceinline__ void schur_mfma(const double *W, int F, const double 
     double4_t acc[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) acc[i] = double4_t{0, 0, 0, 0};
-    double r0[5], r1[5], r2[5], r3[5], c0, c1, c2, c3;
+    double r0[5], r1[5], r2[5], c0, c1, c2;
 #define SCHUR_LOAD(ST, R, C)                                                                 \
     {                                                                                        \
         const int st_ = min((ST), nsteps - 1);                                               \
@@ -622,42 +622,36 @@ __device__ __forceinline__ void schur_mfma(const double *W, int F, const double 
         const double *Wr_ = W + (size_t)f_ * VB_WLD + c16;                                   \
         _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) R[t5] = Wr_[16 * t5];               \
     }
-    SCHUR_LOAD(grp, r0, c0) SCHUR_LOAD(grp + 4, r1, c1) SCHUR_LOAD(grp + 8, r2, c2)
+    SCHUR_LOAD(grp, r0, c0) SCHUR_LOAD(grp + 4, r1, c1)
     for (int st = grp; st < nsteps; st += 4) {
-        SCHUR_LOAD(st + 12, r3, c3)
+        SCHUR_LOAD(st + 8, r2, c2)
         double u[5];
 #pragma unroll
         for (int t5 = 0; t5 < 5; t5++) u[t5] = r0[t5] * c0 * sc5[t5];
 #pragma unroll
         for (int i = 0; i < NP; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[TA[PB + i]], u[TB[PB + i]], acc[i], 0, 0, 0);
 #pragma unroll
-        for (int t5 = 0; t5 < 5; t5++) { r0[t5] = r1[t5]; r1[t5] = r2[t5]; r2[t5] = r3[t5]; }
-        c0 = c1; c1 = c2; c2 = c3;
+        for (int t5 = 0; t5 < 5; t5++) { r0[t5] = r1[t5]; r1[t5] = r2[t5]; }
+        c0 = c1; c1 = c2;
     }
 #undef SCHUR_LOAD
     for (int gsel = 0; gsel < 4; gsel++) {
         if (grp == gsel) {
-            double tv[NP][4];
 #pragma unroll
-            for (int i = 0; i < NP; i++) {
-                constexpr int dummy = 0; (void)dummy;
+            for (int i = 0; i < NP; i++) {       // one tile at a time: 4 LDS reads in flight, subtract, write back (keeps the epilogue's register need at one tile)
                 const int ta = TA[PB + i], tb = TB[PB + i];
                 double *T = s_T + tile_index(ta, tb) * 256;
+                double tv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int rl = g4 + 4 * q;                        // row inside the tile
-                    if (ta < 4) tv[i][q] = T[TIX(rl, c16)];
-                    else tv[i][q] = (rl < 2) ? T[TIX(rl, c16)] : ((rl == 2) ? s_y[16 * tb + c16] : 0.0);   // tile row 4: rows 64, 65 | row 66 = rhs
+                    if (ta < 4) tv[q] = T[TIX(rl, c16)];
+                    else tv[q] = (rl < 2) ? T[TIX(rl, c16)] : ((rl == 2) ? s_y[16 * tb + c16] : 0.0);   // tile row 4: rows 64, 65 | row 66 = rhs
                 }
-            }
-#pragma unroll
-            for (int i = 0; i < NP; i++) {
-                const int ta = TA[PB + i], tb = TB[PB + i];
-                double *T = s_T + tile_index(ta, tb) * 256;
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int rl = g4 + 4 * q, col = 16 * tb + c16;
-                    const double nv = tv[i][q] - acc[i][q];
+                    const double nv = tv[q] - acc[i][q];
                     if (ta < 4) { if (col < VB_NPOSE) T[TIX(rl, c16)] = nv; }
                     else if (col < VB_NPOSE) { if (rl < 2) T[TIX(rl, c16)] = nv; else if (rl == 2) s_y[col] = nv; }
                 }
@@ -778,23 +772,19 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
         }
         s_scale[tid] = sc; s_diag[tid] = d; s_g[tid] = gs; s_v[tid] = vv;
     }
-    // per-feature scalars (registers: <= 2 features per thread): scale, diagonal, gradient, v_f
-    double f_sf[2] = {0, 0}, f_df[2] = {1, 1}, f_hf[2] = {0, 0}, f_gf[2] = {0, 0};
-    bool f_on[2] = {false, false};
+    // per-feature scalars (<= 2 features per thread): scale, diagonal, gradient -> global (re-read where they are needed)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int f = tid + u * SNT;
         if (f < F) {
             s_rng[f] = (6 * f_start[f]) | ((6 * (f_start[f] + f_nobs[f])) << 16);
             if (!f_const[f]) {
-                f_on[u] = true;
-                f_hf[u] = hf[f]; f_gf[u] = gf[f];
+                const double hfv = hf[f], gfv = gf[f];
                 double sf;
-                if (scaling_ready) sf = scale_g[VB_P + f]; else { sf = 1.0 / (1.0 + sqrt(f_hf[u])); scale_g[VB_P + f] = sf; }
-                const double d = sqrt(fmin(fmax(sf * sf * f_hf[u], b.min_lm_diagonal), b.max_lm_diagonal));
-                f_sf[u] = sf; f_df[u] = d;
+                if (scaling_ready) sf = scale_g[VB_P + f]; else { sf = 1.0 / (1.0 + sqrt(hfv)); scale_g[VB_P + f] = sf; }
+                const double d = sqrt(fmin(fmax(sf * sf * hfv, b.min_lm_diagonal), b.max_lm_diagonal));
                 diag_g[VB_P + f] = d;
-                const double gr = sf * f_gf[u] / d;
+                const double gr = sf * gfv / d;
                 grad_g[VB_P + f] = gr;
                 g2 += gr * gr;
             }
@@ -828,16 +818,16 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
         }
         __syncthreads();
         for (int par = 0; par < 2; par++) {                                                   // IMU + LiDAR factors k = par, par+2, ...
-            for (int t0 = tid; t0 < 5 * 900; t0 += 9 * SNT) {
-                double v[9]; int o[9];
+            for (int t0 = tid; t0 < 5 * 900; t0 += 5 * SNT) {
+                double v[5]; int o[5];
 #pragma unroll
-                for (int u = 0; u < 9; u++) {
+                for (int u = 0; u < 5; u++) {
                     const int t = min(t0 + u * SNT, 5 * 900 - 1);
                     const int k2 = t / 900, src = 900 * (2 * k2 + par) + (t - 900 * k2);
                     o[u] = b.lut_imu[src]; v[u] = imuH[src];
                 }
 #pragma unroll
-                for (int u = 0; u < 9; u++) {
+                for (int u = 0; u < 5; u++) {
                     if (t0 + u * SNT >= 5 * 900) continue;
                     const int r = (o[u] >> 15) & 255, c = (o[u] >> 23) & 255;
                     const double val = v[u] * s_scale[r] * s_scale[c];
@@ -885,10 +875,13 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
             feature_dots(W, F, f_const, s_y, s_cf, tid);                                     // s_cf temporarily holds W_f . (S v)_p
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 2; u++) if (f_on[u]) {
+            for (int u = 0; u < 2; u++) {          // the per-feature scalars are re-read (this thread wrote them above): nothing stays live across the assembly
                 const int f = tid + u * SNT;
-                const double vf = f_sf[u] * f_gf[u] / (f_df[u] * f_df[u]);
-                part += vf * (2.0 * f_sf[u] * s_cf[f] + f_sf[u] * f_sf[u] * f_hf[u] * vf);
+                if (f < F && !f_const[f]) {
+                    const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f], hfv = hf[f], gfv = gf[f];
+                    const double vf = sf * gfv / (df * df);
+                    part += vf * (2.0 * sf * s_cf[f] + sf * sf * hfv * vf);
+                }
             }
             G2 = block_sum_s(g2, s_red);
             Jg2 = block_sum_s(part, s_red);
