@@ -666,23 +666,33 @@ __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, flo
                 const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
                 const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
                 const int oi = __float_as_int(m.w);
-                if (d < d2[4] || (d == d2[4] && oi < oid[4])) {
-                    int kk = 4;
-                    while (kk > 0 && (d < d2[kk - 1] || (d == d2[kk - 1] && oi < oid[kk - 1]))) { d2[kk] = d2[kk - 1]; oid[kk] = oid[kk - 1]; pos[kk] = pos[kk - 1]; kk--; }
-                    d2[kk] = d; oid[kk] = oi; pos[kk] = j0 + u;
+                if (d < d2[4] || (d == d2[4] && oi < oid[4])) {       // sorted insertion with compile-time indices only (the five best stay in registers)
+                    bool lt[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) lt[k] = d < d2[k] || (d == d2[k] && oi < oid[k]);
+#pragma unroll
+                    for (int k = 4; k >= 1; k--) {
+                        d2[k] = lt[k - 1] ? d2[k - 1] : (lt[k] ? d : d2[k]);
+                        oid[k] = lt[k - 1] ? oid[k - 1] : (lt[k] ? oi : oid[k]);
+                        pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? j0 + u : pos[k]);
+                    }
+                    if (lt[0]) { d2[0] = d; oid[0] = oi; pos[0] = j0 + u; }
                 }
             }
         }
     }
 }
 
-// 3x3 symmetric eigen-decomposition by cyclic Jacobi: eigenvalues ascending, V columns
-__device__ void eig3(const double *Ain, double *w, double *V) {
+// 3x3 symmetric eigen-decomposition by cyclic Jacobi: eigenvalues ascending, V columns. Every array index is a compile-time constant
+// after unrolling, so A / V stay in registers (a dynamically indexed local array would live in scratch memory).
+__device__ __forceinline__ void eig3(const double *Ain, double *w, double *V) {
     double A[9];
+#pragma unroll
     for (int k = 0; k < 9; k++) { A[k] = Ain[k]; V[k] = (k % 4 == 0) ? 1.0 : 0.0; }
     for (int sweep = 0; sweep < 30; sweep++) {
         const double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
         if (off == 0.0) break;
+#pragma unroll
         for (int pq = 0; pq < 3; pq++) {
             const int p = (pq == 2) ? 1 : 0, q = (pq == 0) ? 1 : 2;
             const double apq = A[3 * p + q];
@@ -692,49 +702,79 @@ __device__ void eig3(const double *Ain, double *w, double *V) {
             if (sweep > 3 && fabs(app) + g == fabs(app) && fabs(aqq) + g == fabs(aqq)) { A[3 * p + q] = 0; A[3 * q + p] = 0; continue; }
             const double theta = (aqq - app) / (2.0 * apq);
             const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            for (int j = 0; j < 3; j++) { const double a = A[3 * p + j], b = A[3 * q + j]; A[3 * p + j] = c * a - s * b; A[3 * q + j] = s * a + c * b; }
-            for (int i = 0; i < 3; i++) { const double a = A[3 * i + p], b = A[3 * i + q]; A[3 * i + p] = c * a - s * b; A[3 * i + q] = s * a + c * b; const double va = V[3 * i + p], vb = V[3 * i + q]; V[3 * i + p] = c * va - s * vb; V[3 * i + q] = s * va + c * vb; }
+            const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+            for (int j = 0; j < 3; j++) { const double a = A[3 * p + j], b = A[3 * q + j]; A[3 * p + j] = c * a - sn * b; A[3 * q + j] = sn * a + c * b; }
+#pragma unroll
+            for (int i = 0; i < 3; i++) { const double a = A[3 * i + p], b = A[3 * i + q]; A[3 * i + p] = c * a - sn * b; A[3 * i + q] = sn * a + c * b; const double va = V[3 * i + p], vb = V[3 * i + q]; V[3 * i + p] = c * va - sn * vb; V[3 * i + q] = sn * va + c * vb; }
         }
     }
-    int o[3] = {0, 1, 2};
-    double d[3] = {A[0], A[4], A[8]};
-    for (int i = 0; i < 2; i++) for (int j = 0; j < 2 - i; j++) if (d[o[j]] > d[o[j + 1]]) { int t = o[j]; o[j] = o[j + 1]; o[j + 1] = t; }
-    double Vt[9];
-    for (int k = 0; k < 9; k++) Vt[k] = V[k];
-    for (int c = 0; c < 3; c++) { w[c] = d[o[c]]; for (int r = 0; r < 3; r++) V[3 * r + c] = Vt[3 * r + o[c]]; }
+    double d0 = A[0], d1 = A[4], d2 = A[8];
+    // ascending order by the comparators (0,1) (1,2) (0,1) of a bubble sort, columns of V move with their eigenvalue
+#define EIG3_CSWAP(da, db, ca, cb) if (da > db) { const double t_ = da; da = db; db = t_; _Pragma("unroll") for (int r = 0; r < 3; r++) { const double v_ = V[3 * r + ca]; V[3 * r + ca] = V[3 * r + cb]; V[3 * r + cb] = v_; } }
+    EIG3_CSWAP(d0, d1, 0, 1) EIG3_CSWAP(d1, d2, 1, 2) EIG3_CSWAP(d0, d1, 0, 1)
+#undef EIG3_CSWAP
+    w[0] = d0; w[1] = d1; w[2] = d2;
 }
-// 5x3 least squares by column-pivoted Householder QR (Eigen colPivHouseholderQr().solve)
-__device__ void qr_solve_5x3(const double *Ain, const double *bin, double *x) {
+// 5x3 least squares by column-pivoted Householder QR (Eigen colPivHouseholderQr().solve); fully unrolled, static indices only
+__device__ __forceinline__ void qr_solve_5x3(const double *Ain, const double *bin, double *x) {
     double a[5][3], b[5];
+#pragma unroll
     for (int i = 0; i < 5; i++) { for (int j = 0; j < 3; j++) a[i][j] = Ain[3 * i + j]; b[i] = bin[i]; }
     int perm[3] = {0, 1, 2};
     double rdiag[3] = {0, 0, 0}, maxpivot = 0;
+#pragma unroll
     for (int k = 0; k < 3; k++) {
         int best = k; double bn = -1, cn[3] = {0, 0, 0};
+#pragma unroll
         for (int j = k; j < 3; j++) { double s = 0; for (int i = k; i < 5; i++) s += a[i][j] * a[i][j]; cn[j] = s; if (s > bn) { bn = s; best = j; } }
-        if (best != k) { for (int i = 0; i < 5; i++) { double t = a[i][k]; a[i][k] = a[i][best]; a[i][best] = t; } int t = perm[k]; perm[k] = perm[best]; perm[best] = t; cn[best] = cn[k]; cn[k] = bn; }
+#pragma unroll
+        for (int c = k + 1; c < 3; c++) if (best == c) {          // swap columns k <-> c (c is a compile-time constant here)
+#pragma unroll
+            for (int i = 0; i < 5; i++) { const double t = a[i][k]; a[i][k] = a[i][c]; a[i][c] = t; }
+            const int t = perm[k]; perm[k] = perm[c]; perm[c] = t; cn[c] = cn[k]; cn[k] = bn;
+        }
         const double nrm = sqrt(cn[k]);
         if (nrm == 0.0) { rdiag[k] = 0; continue; }
         const double alpha = a[k][k] > 0 ? -nrm : nrm;
         double v[5] = {0, 0, 0, 0, 0};
         v[k] = a[k][k] - alpha;
+#pragma unroll
         for (int i = k + 1; i < 5; i++) v[i] = a[i][k];
-        double vtv = 0; for (int i = k; i < 5; i++) vtv += v[i] * v[i];
+        double vtv = 0;
+#pragma unroll
+        for (int i = k; i < 5; i++) vtv += v[i] * v[i];
         if (vtv > 0) {
+#pragma unroll
             for (int j = k; j < 3; j++) { double s = 0; for (int i = k; i < 5; i++) s += v[i] * a[i][j]; s = 2 * s / vtv; for (int i = k; i < 5; i++) a[i][j] -= s * v[i]; }
-            double s = 0; for (int i = k; i < 5; i++) s += v[i] * b[i]; s = 2 * s / vtv; for (int i = k; i < 5; i++) b[i] -= s * v[i];
+            double s = 0;
+#pragma unroll
+            for (int i = k; i < 5; i++) s += v[i] * b[i];
+            s = 2 * s / vtv;
+#pragma unroll
+            for (int i = k; i < 5; i++) b[i] -= s * v[i];
         }
         rdiag[k] = a[k][k];
         if (fabs(rdiag[k]) > maxpivot) maxpivot = fabs(rdiag[k]);
     }
     const double thresh = 2.220446049250313e-16 * 3.0 * maxpivot;
     int rank = 0;
+#pragma unroll
     for (int k = 0; k < 3; k++) if (fabs(rdiag[k]) > thresh) rank++;
     double z[3] = {0, 0, 0};
-    for (int k = rank - 1; k >= 0; k--) { double s = b[k]; for (int j = k + 1; j < rank; j++) s -= a[k][j] * z[j]; z[k] = s / a[k][k]; }
+#pragma unroll
+    for (int k = 2; k >= 0; k--) if (k < rank) {
+        double s = b[k];
+#pragma unroll
+        for (int j = k + 1; j < 3; j++) if (j < rank) s -= a[k][j] * z[j];
+        z[k] = s / a[k][k];
+    }
     x[0] = x[1] = x[2] = 0;
-    for (int k = 0; k < 3; k++) x[perm[k]] = z[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) if (perm[k] == c) x[c] = z[k];
+    }
 }
 
 // factor record: cp[3] then edge: pa[3] pb[3] / surf: n[3] d  -> 10 doubles; kind (0 invalid, 1 edge, 2 surf) separately
@@ -823,17 +863,20 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
         const int kind = fkind[i];
         if (!kind) continue;
         const double *rec = frec + (size_t)i * S2M_FREC;
-        double r[3], J[18];
-        int nr;
-        if (kind == 1) { edge_eval<JAC>(x, rec, rec + 3, rec + 6, r, J); nr = 3; }
-        else { surf_eval<JAC>(x, rec, rec + 3, rec[6], r, J); nr = 1; }
+        // the two factor kinds are separate code paths with compile-time row counts: r / J keep static indices (registers, no scratch)
+        double r[3] = {0, 0, 0}, J[18];
+        if (kind == 1) edge_eval<JAC>(x, rec, rec + 3, rec + 6, r, J);
+        else surf_eval<JAC>(x, rec, rec + 3, rec[6], r, J);
         double s = 0;
-        for (int k = 0; k < nr; k++) s += r[k] * r[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { if (k > 0 && kind != 1) break; s += r[k] * r[k]; }
         double rho0, sw;
         huber(s, huber_a, rho0, sw);
         acc[27] += 0.5 * rho0;
         if (JAC) {
-            for (int k = 0; k < nr; k++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k > 0 && kind != 1) break;
                 const double rk = sw * r[k];
                 double jr[6];
 #pragma unroll
