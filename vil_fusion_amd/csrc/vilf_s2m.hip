@@ -270,7 +270,6 @@ __global__ __launch_bounds__(S2B_VT) void b_crop_compact(CSet map, const double 
 #define MU_E 2
 #define MU_TILE (MU_T * MU_E)
 #define MU_LDS_TAIL 8192
-#define MU_QCAP (2 * MU_TILE)
 #define S2B_ERR_ORDER 8
 template <int AXB>
 __device__ __forceinline__ bool mu_leaf(const float4 q, float inv, unsigned long long &k) {
@@ -333,14 +332,14 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, int nOld
 }
 template <bool BIG>
 __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, CSet out, float4 *ts_all, int ts_stride,
-                                                       unsigned long long *gT_all, int gT_stride, int lds_cap, int *err) {
+                                                       unsigned long long *gT_all, int gT_stride, int lds_lo, int lds_cap, int *gq_all, size_t gq_stride, int *err) {
     constexpr int AXB = BIG ? 16 : 17, IDXB = BIG ? 16 : 13;
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
     extern __shared__ unsigned long long s_T[];
     __shared__ int s_w[MU_E][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
     const int n = map.n[sid], nOld = min(max(n_old[sid], 0), n), nt = n - nOld;
-    if ((nt > lds_cap) != BIG) return;
+    if (BIG ? nt <= lds_cap : (nt <= lds_lo || nt > lds_cap)) return;          // each launch takes the streams of its tail-size class
     unsigned long long *T = BIG ? gT_all + (size_t)sid * gT_stride : s_T;
     const float4 *p = map.p + (size_t)sid * map.cap;
     float4 *o = out.p + (size_t)sid * out.cap;
@@ -405,17 +404,10 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     // its leaf, no tail point in it, no tail leaf between it and its predecessor — is handled inline; everything else is flagged and
     // done by mu_rare() from LDS state (kept out of the unrolled body: registers).
     unsigned long long *s_key = s_T + (BIG ? 0 : lds_cap);
-    int *s_te = reinterpret_cast<int *>(s_key + MU_TILE), *s_qi = s_te + MU_TILE, *s_qh = s_qi + MU_QCAP, *s_qm = s_qh + MU_QCAP;   // queue of uncommon points: index (| head bit 30), H, M
+    int *s_te = reinterpret_cast<int *>(s_key + MU_TILE);
+    int *gq = gq_all + (size_t)sid * gq_stride;      // queue of uncommon points in global memory (3 ints each: index | head bit 30, H, M): room for every old point
     __shared__ int s_qn;
     if (tid == 0) s_qn = 0;
-    auto flush = [&]() {
-        __syncthreads();
-        const int qn = s_qn;
-        for (int k = tid; k < qn; k += MU_T) mu_rare<AXB, IDXB>(s_qi[k] & 0x3fffffff, s_qh[k], s_qm[k], (s_qi[k] >> 30) & 1, nOld, p, o, ts, T, ntv, THtot, inv, box);
-        __syncthreads();
-        if (tid == 0) s_qn = 0;
-        __syncthreads();
-    };
     constexpr unsigned long long SVB = 1ULL << 63;
     int carryH = 0, carryM = 0, carryTE = 0;
     unsigned long long carryK = 0;
@@ -499,7 +491,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             const int te_prev = e > 0 ? s_te[e - 1] : carryTE;
             if (((fm >> u) & 1) && tb[u] > te_prev) cm |= 1u << u;   // tail leaves strictly between the previous old key and this one
             const int H = carryH + (ex & 0xffff), M = carryM + (ex >> 16);
-            if ((cm >> u) & 1) { const int k = atomicAdd(&s_qn, 1); s_qi[k] = (t0 + e) | (((hm >> u) & 1) << 30); s_qh[k] = H; s_qm[k] = M; }
+            if ((cm >> u) & 1) { const int k = atomicAdd(&s_qn, 1); gq[3 * k] = (t0 + e) | (((hm >> u) & 1) << 30); gq[3 * k + 1] = H; gq[3 * k + 2] = M; }
             else if ((hm >> u) & 1)                                  // the common case: the old point is its leaf's centroid, sum from +0 as the reference does
                 o[H + tb[u] - M] = make_float4(__fadd_rn(0.0f, q[u].x), __fadd_rn(0.0f, q[u].y), __fadd_rn(0.0f, q[u].z), __fadd_rn(0.0f, q[u].w));
         }
@@ -507,9 +499,13 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         carryH += base & 0xffff; carryM += base >> 16;
         carryTE = nextTE; carryK = lastK;
         __syncthreads();                                             // s_key / s_te / s_w are rewritten by the next tile
-        if (s_qn > MU_QCAP - MU_TILE) flush();                     // uniform: every thread reads the same counter after the barrier
     }
-    flush();
+    __syncthreads();
+    {   // the queued points, one per lane: their dependent global loads run in parallel here instead of stalling a tile of the sweep
+        const int qn = s_qn;
+        for (int k = tid; k < qn; k += MU_T) mu_rare<AXB, IDXB>(gq[3 * k] & 0x3fffffff, gq[3 * k + 1], gq[3 * k + 2], (gq[3 * k] >> 30) & 1, nOld, p, o, ts, T, ntv, THtot, inv, box);
+    }
+    __syncthreads();
     // ---- tail leaves beyond the last old key (all of them when there is no old map)
     int jlast = 0;
     if (nOld > 0) { unsigned long long kl; mu_leaf<AXB>(p[nOld - 1], inv, kl); jlast = lower(kl + 1); }
@@ -1143,7 +1139,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         HIPCHECK(h, hipMemcpyAsync(c->pose.p, ident.data(), ident.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_bucket_index), hipFuncAttributeMaxDynamicSharedMemorySize, S2B_HWORDS * 4 + S2B_IT * 4));
-        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12 + MU_QCAP * 12));
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned int, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned long long, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -1306,14 +1302,21 @@ static int s2b_step(vilf_handle *h, S2B *c) {
             c->snap_live = false;
         }
         if (c->order_state[w] == 1) {  // steady state: one fused pass (crop + merge of the sorted tail + centroids), no host round trip
-            const int lds_cap = mu_lds_cap(c->capScan[w]);
-            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12 + (size_t)MU_QCAP * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
-                               c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, lds_cap, d_err);
+            // tail-size classes: <= 4096 new points (32 KB of LDS for the sorted tail: two workgroups per CU), <= 8192 (64 KB), larger (global memory).
+            // The bucket-sorted copy of this map is dead by now (the next step rebuilds it): its buffer holds the queue of uncommon points.
+            const int lds_cap = mu_lds_cap(c->capScan[w]), lds_half = std::min(lds_cap, MU_LDS_TAIL / 2);
+            int *gq = c->sorted[w].as<int>();
+            const size_t gq_stride = (size_t)c->capMap[w] * 4;
+            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_half * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+                               c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, -1, lds_half, gq, gq_stride, d_err);
+            if (lds_cap > lds_half)
+                hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+                                   c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, lds_half, lds_cap, gq, gq_stride, d_err);
             if (c->capScan[w] > lds_cap) {
                 int p2 = 2; while (p2 < c->capScan[w]) p2 <<= 1;
                 if (!c->muT.ensure((size_t)S * p2 * 8)) return VILF_ERR_DEVICE;
-                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12 + (size_t)MU_QCAP * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
-                                   c->tmpB.as<float4>(), c->capScan[w], c->muT.as<unsigned long long>(), p2, lds_cap, d_err);
+                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+                                   c->tmpB.as<float4>(), c->capScan[w], c->muT.as<unsigned long long>(), p2, 0, lds_cap, gq, gq_stride, d_err);
             }
             PROF(0)
         } else {                       // a map that is not a voxel grid yet (as initialised): crop copy + full sort
