@@ -252,6 +252,179 @@ __global__ __launch_bounds__(S2B_VT) void b_crop_compact(CSet map, const double 
     if (tid == 0) out.n[sid] = carry;
 }
 
+// ---- pcl::VoxelGrid of one scan cloud entirely inside one workgroup -------------------------------------------------------------
+// A raw scan cloud (<= ~19 k points) fits the LDS as 32-bit leaf keys + two 16-bit index arrays, so its voxel grid needs no global
+// sort, no key / value arrays in HBM and no key-width agreement between streams (no host round trip): the points are read twice from
+// HBM / L2 (bounding box, keys), the indices are radix-sorted in LDS (8-bit digits, only as many passes as this cloud's key has bits;
+// stable: every wave owns a contiguous segment and ranks a 64-lane strip by ballot matching), and each leaf is summed in index order.
+#define SV_T 1024
+#define SV_MAXPTS32 19200              // 32-bit keys: 8 bytes of LDS per point
+#define SV_MAXPTS24 22000              // 24 stored key bits: 7 bytes per point (a wider key's top byte is recomputed from the point when needed)
+__device__ __forceinline__ int sv_bits(int v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }     // bits for values 0 .. v-1
+template <bool K24>
+__global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet out, int cap, int *err) {
+    extern __shared__ unsigned int sv_lds[];
+    // K24: lo16[cap] a[cap] b[cap] (u16) hi8[cap] (u8) cnt;   else: key32[cap] a[cap] b[cap] cnt      (cap is a multiple of 16)
+    unsigned int *s_key = sv_lds;
+    unsigned short *s_lo = reinterpret_cast<unsigned short *>(sv_lds);
+    unsigned short *s_a = K24 ? s_lo + cap : reinterpret_cast<unsigned short *>(s_key + cap), *s_b = s_a + cap;
+    unsigned char *s_hi = reinterpret_cast<unsigned char *>(s_b + cap);
+    unsigned short *s_cnt = K24 ? reinterpret_cast<unsigned short *>(s_hi + cap) : s_b + cap;     // [256 digits][16 waves]
+    __shared__ float s_mm[6][16];
+    __shared__ int s_w2[2][16], s_geo[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
+    const int n = min(in.n[sid], cap);
+    const float4 *p = in.p + (size_t)sid * in.cap;
+    float4 *o = out.p + (size_t)sid * out.cap;
+    if (n <= 0) { if (tid == 0) out.n[sid] = 0; return; }
+    // ---- A. bounding box
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = tid; i < n; i += SV_T) {
+        const float4 q = p[i];
+        mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
+        mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], of, 64)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], of, 64)); }
+        if (lane == 0) { s_mm[k][wave] = mn[k]; s_mm[3 + k][wave] = mx[k]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int vb = 0;
+        for (int k = 0; k < 3; k++) {
+            float a = s_mm[k][0], b = s_mm[3 + k][0];
+            for (int w2 = 1; w2 < 16; w2++) { a = fminf(a, s_mm[k][w2]); b = fmaxf(b, s_mm[3 + k][w2]); }
+            const int minb = (int)floorf(__fmul_rn(a, inv)), divb = (int)floorf(__fmul_rn(b, inv)) - minb + 1;
+            s_geo[k] = minb; s_geo[3 + k] = sv_bits(divb);
+            vb += s_geo[3 + k];
+        }
+        s_geo[6] = vb;
+        if (vb > 32) atomicOr(err + sid, S2B_ERR_VOXEL);
+    }
+    __syncthreads();
+    const int mb0 = s_geo[0], mb1 = s_geo[1], mb2 = s_geo[2], bx = s_geo[3], by = s_geo[4], vbits = min(s_geo[6], 32);
+    // leaf coordinates packed z | y | x (the order of pcl's leaf index)
+    auto key_of = [&](const float4 q) -> unsigned int {
+        const unsigned int a = (unsigned int)((int)floorf(__fmul_rn(q.x, inv)) - mb0), b = (unsigned int)((int)floorf(__fmul_rn(q.y, inv)) - mb1), c = (unsigned int)((int)floorf(__fmul_rn(q.z, inv)) - mb2);
+        return (bx + by < 32 ? (c << (bx + by)) : 0u) | (b << bx) | a;
+    };
+    auto key_at = [&](int idx) -> unsigned int {                   // the full key of point idx
+        if (!K24) return s_key[idx];
+        unsigned int k = (unsigned int)s_lo[idx] | ((unsigned int)s_hi[idx] << 16);
+        if (vbits > 24) k |= key_of(p[idx]) & 0xff000000u;         // rare: the top byte is not stored
+        return k;
+    };
+    auto digit_at = [&](int idx, int shift) -> int {
+        if (!K24) return (int)((s_key[idx] >> shift) & 255);
+        if (shift == 0) return s_lo[idx] & 255;
+        if (shift == 8) return s_lo[idx] >> 8;
+        if (shift == 16) return s_hi[idx];
+        return (int)(key_of(p[idx]) >> 24);
+    };
+    // ---- B. keys, index array = identity
+    for (int i = tid; i < n; i += SV_T) {
+        const unsigned int k = key_of(p[i]);
+        if (K24) { s_lo[i] = (unsigned short)(k & 0xffffu); s_hi[i] = (unsigned char)((k >> 16) & 0xffu); } else s_key[i] = k;
+        s_a[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    // ---- C. stable LSD radix sort of the indices by key, 8 bits per pass
+    unsigned short *src = s_a, *dst = s_b;
+    const int seg = (n + 15) >> 4, lo = wave * seg, hi = min(n, lo + seg);
+    unsigned int *cnt32 = reinterpret_cast<unsigned int *>(s_cnt);
+    for (int shift = 0; shift < vbits; shift += 8) {
+        for (int t = tid; t < 2048; t += SV_T) cnt32[t] = 0;
+        __syncthreads();
+        for (int base = lo; base < hi; base += 64) {       // per-wave digit counts: lanes with the same digit elect a leader (ballot matching) — neighbouring
+            const int j = base + lane;                     // points share leaves, so per-lane LDS atomics on one counter would serialise
+            const bool valid = j < hi;
+            const int d = valid ? digit_at(src[j], shift) : 0;
+            unsigned long long mask = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) { const unsigned long long bal = __ballot((d >> b) & 1); mask &= ((d >> b) & 1) ? bal : ~bal; }
+            if (valid && (mask & ((1ULL << lane) - 1ULL)) == 0) s_cnt[d * 16 + wave] += (unsigned short)__popcll(mask);
+        }
+        __syncthreads();
+        {   // exclusive scan in (digit, wave) order: thread t owns entries 4 t .. 4 t + 3 of [digit][wave]
+            int c4[4], loc = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { c4[u] = s_cnt[4 * tid + u]; loc += c4[u]; }
+            int tot;
+            int run = block_excl_scan_1024(loc, s_w2[0], tot);
+#pragma unroll
+            for (int u = 0; u < 4; u++) { s_cnt[4 * tid + u] = (unsigned short)run; run += c4[u]; }
+        }
+        __syncthreads();
+        for (int base = lo; base < hi; base += 64) {       // a wave walks its own segment in order: its counter column needs no synchronisation
+            const int j = base + lane;
+            const bool valid = j < hi;
+            const unsigned short idx = valid ? src[j] : (unsigned short)0;
+            const int d = valid ? digit_at(idx, shift) : 0;
+            unsigned long long mask = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) { const unsigned long long bal = __ballot((d >> b) & 1); mask &= ((d >> b) & 1) ? bal : ~bal; }
+            if (valid) {
+                const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
+                const int off = s_cnt[d * 16 + wave];
+                dst[off + rank] = idx;
+                if (rank == 0) s_cnt[d * 16 + wave] = (unsigned short)(off + __popcll(mask));
+            }
+        }
+        __syncthreads();
+        unsigned short *t = src; src = dst; dst = t;
+    }
+    // ---- D. run heads, output ranks (two sorted positions per lane and tile), centroids in index order. The tile's points and keys are staged
+    // in LDS (the index buffer the sort no longer needs, the counter array): a leaf with dozens of points — dense near-range ground — is then
+    // summed from LDS by its head lane instead of through a chain of dependent global gathers that the whole workgroup would wait for.
+    float4 *s_tq = (cap * 2 >= 2 * SV_T * 16) ? reinterpret_cast<float4 *>(dst) : reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(s_cnt) + 8192);
+    unsigned int *s_tk = reinterpret_cast<unsigned int *>(s_cnt);
+    int carry = 0;
+    for (int t0 = 0; t0 < n; t0 += 2 * SV_T) {
+        int head[2], incl[2];
+        unsigned int key[2];
+        float4 q0[2];
+        const int tile_n = min(2 * SV_T, n - t0);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = t0 + u * SV_T + tid, jc = min(j, n - 1);
+            const unsigned short idx = src[jc];
+            key[u] = key_at(idx);
+            q0[u] = p[idx];
+            head[u] = (j < n && (j == 0 || key_at(src[max(jc - 1, 0)]) != key[u])) ? 1 : 0;
+            incl[u] = head[u];
+#pragma unroll
+            for (int of = 1; of < 64; of <<= 1) { const int v = __shfl_up(incl[u], of, 64); if (lane >= of) incl[u] += v; }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) { s_tq[u * SV_T + tid] = q0[u]; s_tk[u * SV_T + tid] = key[u]; }
+        if (lane == 63) { s_w2[0][wave] = incl[0]; s_w2[1][wave] = incl[1]; }
+        __syncthreads();
+        int base = carry;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            int off = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) { const int x = s_w2[u][k]; if (k < wave) off += x; tot += x; }
+            if (head[u]) {
+                const int e = u * SV_T + tid, j = t0 + e;
+                float cx = __fadd_rn(0.0f, q0[u].x), cy = __fadd_rn(0.0f, q0[u].y), cz = __fadd_rn(0.0f, q0[u].z), ci = __fadd_rn(0.0f, q0[u].w);
+                int len = 1;
+                while (e + len < tile_n && s_tk[e + len] == key[u]) { const float4 q = s_tq[e + len]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); len++; }
+                if (e + len == tile_n)          // the leaf continues past the tile: the rest comes from global memory
+                    while (j + len < n && key_at(src[j + len]) == key[u]) { const float4 q = p[src[j + len]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); len++; }
+                const float nn = (float)len;
+                o[base + off + incl[u] - 1] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+            }
+            base += tot;
+        }
+        carry = base;
+        __syncthreads();                         // the staging arrays and s_w2 are rewritten by the next tile
+    }
+    if (tid == 0) out.n[sid] = carry;
+}
+
 // ---- fused steady-state map update: crop box + voxel grid of (leaf-ordered old map ++ appended scan) in ONE pass -------------
 // createSubMap (:298-352) on a map that is already a voxel grid: the old map is in ascending leaf order (one point per leaf, up to
 // rounding), only the few thousand appended points are not. One workgroup per stream:
@@ -1139,6 +1312,8 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         HIPCHECK(h, hipMemcpyAsync(c->pose.p, ident.data(), ident.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_bucket_index), hipFuncAttributeMaxDynamicSharedMemorySize, S2B_HWORDS * 4 + S2B_IT * 4));
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS32 * 8 + 8192));
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS24 * 7 + 8192));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned int, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned long long, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -1271,7 +1446,15 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     hipLaunchKernelGGL(b_predict, GRIDS(S), 0, h->stream, d_pose, S);
     PROF(6)
     const float leaf[2] = {(float)h->opts.edge_leaf_size, (float)h->opts.surf_leaf_size};
-    for (int w = 0; w < 2; w++) if ((rc = s2b_voxel(h, c, c->cs_scan(w), leaf[w], c->cs_ds(w))) != VILF_OK) return rc;
+    for (int w = 0; w < 2; w++) {
+        if (c->capScan[w] <= SV_MAXPTS24) {    // the cloud fits the LDS: one workgroup per stream does the whole grid, no host round trip
+            const int cap = (c->capScan[w] + 15) & ~15;
+            const size_t stage = (cap * 2 >= 2 * SV_T * 16) ? 0 : (size_t)2 * SV_T * 16;      // small clouds: the tile staging area gets its own LDS
+            if (cap <= SV_MAXPTS32) hipLaunchKernelGGL(b_scan_voxel<false>, dim3(S), dim3(SV_T), (size_t)cap * 8 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
+            else hipLaunchKernelGGL(b_scan_voxel<true>, dim3(S), dim3(SV_T), (size_t)cap * 7 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
+            PROF(0)
+        } else if ((rc = s2b_voxel(h, c, c->cs_scan(w), leaf[w], c->cs_ds(w))) != VILF_OK) return rc;
+    }
     hipLaunchKernelGGL(b_gate, GRIDS(S), 0, h->stream, c->nMap[0].as<int>(), c->nMap[1].as<int>(), c->nDs[0].as<int>(), c->nDs[1].as<int>(), d_res, d_err, S);
     PROF(6)
     for (int w = 0; w < 2; w++) if ((rc = s2b_build_index(h, c, w)) != VILF_OK) return rc;
