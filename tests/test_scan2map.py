@@ -212,14 +212,16 @@ def test_scan2map_bench_size_parity_and_invariants(oracle, opts):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_scan,leaf", [(3000, 0.8), (24000, 0.25)])
+@pytest.mark.parametrize("n_scan,leaf", [(3000, 0.8), (24000, 0.25), (20500, 0.25), (20500, 0.02), (3000, 0.02)])
 def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
     """createSubMap (EstimationMapping.hpp:298-352) in isolation: with <= 10 edge points in the map the reference skips the optimisation
     (:250) and still updates the maps, so the pose is the constant-velocity prediction on both sides and the surf map sees: a crop box
     (half 6 m) that moves 1.5 m per frame across the cloud (old leaves leave, leaves straddle the boundary), scan points falling into
     existing leaves, between them and beyond both ends, exact duplicates, and — second case — more than 8192 new leaves per frame
     (the fused update's global-memory variant). Maps must stay bit-identical to the oracle over 5 frames; the first frame also
-    exercises the unsorted-map path."""
+    exercises the unsorted-map path. The scan sizes / leaf sizes also walk the scan voxel grid through its variants: 32-bit keys in LDS
+    (3000 points; leaf 0.02 m: 30 key bits = 4 radix passes), the 24-bit layout (20500 points; leaf 0.02 m: top key byte recomputed from
+    the points), and the global-sort path (24000 points)."""
     from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
     o = oracle.default_options()
     o.s2m_crop_half = 6.0
@@ -250,5 +252,5 @@ def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
             assert m.shape == mr.shape, (f, i, m.shape, mr.shape)
             assert np.array_equal(m, mr), (f, i)
             assert np.array_equal(b.getMapCloud(i, 0), refs[i].get_map(0))
-    assert got[0].map_surf_size > (8192 if n_scan > 20000 else 500)
+    assert got[0].map_surf_size > (8192 if n_scan > 20000 and leaf > 0.1 else 500)
     s.close()
