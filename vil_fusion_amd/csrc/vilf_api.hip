@@ -26,7 +26,10 @@ __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
 __global__ void k_marg_prepare(VbBatch b, VbMarg g);
 __global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
-__global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi);
+__global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged);
+__global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
+__global__ void k_mf_ql(VbBatch b, VbMarg g);
+__global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
 __global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
 __global__ void k_hook_lidar(const double *, const double *, const double *, const double *, const double *, double *);
@@ -112,7 +115,10 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     h->marg_lds_schur = (size_t)MG_MLDS * MG_MLDS * sizeof(double);
     h->marg_lds_finish = (size_t)(MG_NK + 2) * (MG_NK + 2) * sizeof(double);
     if (hipFuncSetAttribute((const void *)k_marg_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_schur) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
+        hipFuncSetAttribute((const void *)k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_mf_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_mf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * 64 * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
         delete h; return VILF_ERR_DEVICE;
@@ -638,6 +644,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
         {D_MBUF, sB * MG_MROW * sC * 8}, {D_MHD, sB * MG_ND * MG_ND * 8}, {D_MGD, sB * MG_ND * 8}, {D_MWF, sB * sF * MG_ND * 8}, {D_MHF, sB * sF * 8},
         {D_MGF, sB * sF * 8}, {D_MAMM, (M > MG_MLDS ? sB * M * M * 8 : 8)}, {D_MX, sB * M * (MG_NK + 1) * 8}, {D_MROT, sB * MG_SWEEPS * (M - 1) * M * 8},
         {D_MLAM, sB * M * 8}, {D_MAR, sB * MG_NK * MG_NK * 8}, {D_MBR, sB * MG_NK * 8},
+        {D_QLV, sB * MG_NK * (MG_NK + 1) * 8}, {D_QLD, sB * 2 * (MG_NK + 2) * 8}, {D_QLLOG, sB * 2 * QL_RCAP * 8}, {D_QLIT, sB * QL_ICAP * 4}, {D_QLINFO, sB * 4 * 4},
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed (marginalization workspace)"; return VILF_ERR_DEVICE; }
     VbMarg &g = h->marg;
@@ -647,6 +654,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     g.Mbuf = h->d[D_MBUF].as<double>(); g.Hd = h->d[D_MHD].as<double>(); g.gd = h->d[D_MGD].as<double>(); g.Wf = h->d[D_MWF].as<double>();
     g.hfm = h->d[D_MHF].as<double>(); g.gfm = h->d[D_MGF].as<double>(); g.Amm = h->d[D_MAMM].as<double>(); g.X = h->d[D_MX].as<double>();
     g.rot = h->d[D_MROT].as<double>(); g.lam = h->d[D_MLAM].as<double>(); g.Ar = h->d[D_MAR].as<double>(); g.br = h->d[D_MBR].as<double>();
+    g.qlV = h->d[D_QLV].as<double>(); g.qlD = h->d[D_QLD].as<double>(); g.qlLog = h->d[D_QLLOG].as<double>(); g.qlIt = h->d[D_QLIT].as<int>(); g.qlInfo = h->d[D_QLINFO].as<int>();
     g.prior_hdr_out = h->d[D_PHDR].as<int>(); g.prior_x0_out = h->d[D_PX0].as<double>(); g.prior_J_out = h->d[D_PJ].as<double>(); g.prior_r_out = h->d[D_PR].as<double>();
     if (!h->prior_backup_valid) {      // keep the priors as uploaded: vilf_batch_rewind re-arms them after this call overwrites them
         const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
@@ -667,8 +675,15 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
                        std::getenv("VILF_MARG_FORCE_EXACT") ? 2 : 0);      // test hook: exercise the Jacobi path on well-conditioned windows too
     hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g, 1);
     if (prof) hipEventRecord(h->pev[2], h->stream);
-    hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
-    hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
+    // eigen-solver of the kept block in three launches (tred2 per workgroup, the QL recurrence of every window one lane each, rotation replay +
+    // prior output per workgroup); k_marg_finish (everything in one workgroup) only takes windows whose rotation log overflowed
+    hipLaunchKernelGGL(k_mf_tridiag, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
+    hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
+    hipLaunchKernelGGL(k_mf_ql, dim3((h->B + 63) / 64), dim3(64), (size_t)2 * (MG_NK + 2) * 64 * sizeof(double), h->stream, h->batch, g);
+    hipLaunchKernelGGL(k_mf_apply, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
+    hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
+    hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, 1);
+    hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, 1);
     if (prof) hipEventRecord(h->pev[3], h->stream);
     hipLaunchKernelGGL(k_prior_prep, grid, block, 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
     if (prof) hipEventRecord(h->pev[4], h->stream);

@@ -56,6 +56,8 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
 #define MG_ND (MG_MD + MG_NK)
 #define MG_MROW 40          // per visual factor: J_P0[12] J_Pj[12] J_Ex[12] J_f[2] r[2]
 #define MG_PAIRM 400        // per pair (0,j): 19x19 (+19 rhs) products, stored 20x20
+#define QL_RCAP 12288        // rotations logged per window by k_mf_ql (typical: ~5 k for n = 75)
+#define QL_ICAP 768          // QL iterations logged per window
 #define MG_GCH 48           // factor rows staged per chunk in the pair gather of k_marg_prepare (15 KB of LDS)
 #define MG_MLDS 136         // largest Amm held in LDS by the Jacobi eigen-solver
 #define MG_INFO 128         // per window: [0] status [1] md [2] mf [3] n [4] m [5] nblocks [6] M(padded) [8..31] shifted ids [32..55] sizes
@@ -77,6 +79,8 @@ struct VbMarg {
     double *rot;            // [B][MG_SWEEPS][Mcap-1][Mcap]   (c,s) log of the Jacobi rotations
     double *lam;            // [B][Mcap]
     double *Ar, *br;        // [B][MG_NK*MG_NK], [B][MG_NK]
+    double *qlV, *qlD, *qlLog;   // eigen-solver split: [B][MG_NK*(MG_NK+1)] tridiagonalising transform, [B][2*(MG_NK+2)] d / e, [B][2*QL_RCAP] (c, s) rotations
+    int *qlIt, *qlInfo;     // [B][QL_ICAP] l | m << 8 per QL iteration, [B][4] iterations, rotations, overflow
     int *prior_hdr_out;     // = batch prior arrays (written by k_marg_finish)
     double *prior_x0_out, *prior_J_out, *prior_r_out;
 };

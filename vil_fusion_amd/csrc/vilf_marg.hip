@@ -548,9 +548,10 @@ __device__ __forceinline__ double mg_wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, double *s_cs, double *s_sc, int *s_ctl) {
-    const int tid = threadIdx.x;
 #define VV(r, c) V[(r) * ld + (c)]
+// Householder tridiagonalisation with accumulated transformations (EISPACK tred2): d = diagonal, e[0 .. n-2] = sub-diagonal, V = Q
+__device__ void tred2_part(double *V, int n, int ld, double *d, double *e, double *s_sc) {
+    const int tid = threadIdx.x;
     if (tid < n) d[tid] = VV(n - 1, tid);
     __syncthreads();
     for (int i = n - 1; i > 0; i--) {
@@ -616,6 +617,10 @@ __device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, doubl
     __syncthreads();
     if (tid == 0) { VV(n - 1, n - 1) = 1.0; for (int i = 1; i < n; i++) e[i - 1] = e[i]; e[n - 1] = 0.0; }
     __syncthreads();
+}
+// implicit QL on the tridiagonal matrix, rotations applied to the rows of V (EISPACK tql2), one workgroup
+__device__ void tql2_part(double *V, int n, int ld, double *d, double *e, double *s_cs, int *s_ctl) {
+    const int tid = threadIdx.x;
     double f = 0.0, tst1 = 0.0;              // live in thread 0 only
     const double eps = 2.220446049250313e-16;
     for (int l = 0; l < n; l++) {
@@ -687,29 +692,17 @@ __device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, doubl
         if (tid == 0) { d[l] += f; e[l] = 0.0; }
         __syncthreads();
     }
-#undef VV
+}
+__device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, double *s_cs, double *s_sc, int *s_ctl) {
+    tred2_part(V, n, ld, d, e, s_sc);
+    tql2_part(V, n, ld, d, e, s_cs, s_ctl);
 }
 
 // launched twice: windows with n_lo <= n < n_hi only. The usual kept dimension (n <= 77) needs < 48 KB of LDS for its n x n matrix,
 // so three workgroups share a CU; the rare larger priors go through the second launch with the full-size allocation.
-extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    const int *info = g.info + (size_t)w * MG_INFO;
-    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
-    extern __shared__ double s_dyn[];
-    __shared__ double s_cs[2 * (MG_NK + 2)], s_lam[MG_NK + 2], s_e[MG_NK + 2], s_br[MG_NK + 2], s_sc[4];
-    __shared__ int s_rank[MG_NK + 2], s_ctl[2];
-    const int n = info[3], nb = info[5], N = n | 1;          // odd leading dimension: row / column walks stay off the same LDS banks
-    double *V = s_dyn;
-    const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
-    for (int e = tid; e < n * n; e += NT) {
-        const int i = e / n, j = e - n * i;
-        V[i * N + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]);
-    }
-    if (tid < n) s_br[tid] = br[tid];
-    __syncthreads();
-    tred2_tql2(V, n, N, s_lam, s_e, s_cs, s_sc, s_ctl);     // eigenvalues -> s_lam, eigenvectors -> columns of V
-    __syncthreads();
+// eigenvalues in s_lam, eigenvectors in the columns of V -> the new prior: J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b, block table, x0
+__device__ void mf_tail(const VbBatch &b, const VbMarg &g, int w, const double *V, int N, int n, int nb, const int *info, const double *s_lam, const double *s_br, int *s_rank) {
+    const int tid = threadIdx.x;
     if (tid < n) {      // ascending order like Eigen::SelfAdjointEigenSolver
         int rk = 0;
         for (int j = 0; j < n; j++) if (s_lam[j] < s_lam[tid] || (s_lam[j] == s_lam[tid] && j < tid)) rk++;
@@ -743,3 +736,157 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg
         }
     }
 }
+
+// ---- the eigen-solver split in three launches --------------------------------------------------------------------------------------
+// tql2's rotation recurrence is one lane's serial chain: inside k_marg_finish the other 255 lanes of the window's workgroup wait for it
+// (~70 % of that kernel). The recurrence touches only d / e — not V — so it runs here for EVERY window at once, one lane per window
+// (k_mf_ql), logging the (c, s) rotations; k_mf_tridiag before it does tred2 per workgroup, k_mf_apply after it replays the log on the
+// rows of V (no dependent chain left) and writes the prior. Same arithmetic, same order, per window. A window whose log does not fit
+// is flagged and taken by k_marg_finish.
+extern "C" __global__ __launch_bounds__(NT) void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int *info = g.info + (size_t)w * MG_INFO;
+    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
+    extern __shared__ double s_dyn[];
+    __shared__ double s_lam[MG_NK + 2], s_e[MG_NK + 2], s_sc[4];
+    const int n = info[3], N = n | 1;
+    double *V = s_dyn;
+    const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK;
+    for (int e = tid; e < n * n; e += NT) { const int i = e / n, j = e - n * i; V[i * N + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]); }
+    __syncthreads();
+    tred2_part(V, n, N, s_lam, s_e, s_sc);
+    double *Vg = g.qlV + (size_t)w * MG_NK * (MG_NK + 1), *dg = g.qlD + (size_t)w * 2 * (MG_NK + 2);
+    for (int e = tid; e < n * N; e += NT) Vg[e] = V[e];
+    if (tid < n) { dg[tid] = s_lam[tid]; dg[MG_NK + 2 + tid] = s_e[tid]; }
+}
+// one lane per window; d / e live in LDS as [i][lane]
+extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g) {
+    extern __shared__ double s_de[];
+    const int lane = threadIdx.x, w = blockIdx.x * 64 + lane;
+    if (w >= b.B) return;
+    const int *info = g.info + (size_t)w * MG_INFO;
+    int *qi = g.qlInfo + (size_t)w * 4;
+    qi[0] = 0; qi[1] = 0; qi[2] = 0;
+    if (info[0] != 0) return;
+    const int n = info[3];
+    double *d = s_de + lane, *e = s_de + (MG_NK + 2) * 64 + lane;          // element i at [64 * i]
+    double *dg = g.qlD + (size_t)w * 2 * (MG_NK + 2);
+    for (int i = 0; i < n; i++) { d[64 * i] = dg[i]; e[64 * i] = dg[MG_NK + 2 + i]; }
+    double *lg = g.qlLog + (size_t)w * 2 * QL_RCAP;
+    int *itab = g.qlIt + (size_t)w * QL_ICAP;
+    int ni = 0, nr = 0;
+    bool over = false;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n && !over; l++) {
+        tst1 = fmax(tst1, fabs(d[64 * l]) + fabs(e[64 * l]));
+        int m = l;
+        while (m < n) { if (fabs(e[64 * m]) <= eps * tst1) break; m++; }
+        if (m > l) {
+            int iter = 0;
+            for (;;) {
+                if (ni >= QL_ICAP || nr + (m - l) > QL_RCAP) { over = true; break; }
+                iter++;
+                double gq = d[64 * l];
+                double p = (d[64 * (l + 1)] - gq) / (2.0 * e[64 * l]);
+                double r = hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[64 * l] = e[64 * l] / (p + r);
+                d[64 * (l + 1)] = e[64 * l] * (p + r);
+                const double dl1 = d[64 * (l + 1)];
+                double hq = gq - d[64 * l];
+                for (int i = l + 2; i < n; i++) d[64 * i] -= hq;
+                f += hq;
+                p = d[64 * m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[64 * (l + 1)];
+                double ei = e[64 * (m - 1)], di = d[64 * (m - 1)];           // operands of the next step are fetched one step ahead: the LDS
+                for (int i = m - 1; i >= l; i--) {                            // latency stays off the dependent chain p -> rr -> inv -> c -> p
+                    const int ip = max(i - 1, l);
+                    const double ei_n = e[64 * ip], di_n = d[64 * ip];
+                    c3 = c2; c2 = c; s2 = s;
+                    gq = c * ei;
+                    hq = c * p;
+                    const double rr = p * p + ei * ei;
+                    const double inv = rr > 0.0 ? rsqrt_nr(rr) : 0.0;
+                    r = rr * inv;
+                    e[64 * (i + 1)] = s * r;
+                    s = ei * inv;
+                    c = p * inv;
+                    p = c * di - s * gq;
+                    d[64 * (i + 1)] = hq + s * (c * gq + s * di);
+                    *reinterpret_cast<double2 *>(lg + 2 * nr) = make_double2(c, s); nr++;   // rotation of columns (i, i + 1), logged in application order
+                    ei = ei_n; di = di_n;
+                }
+                p = -s * s2 * c3 * el1 * e[64 * l] / dl1;
+                e[64 * l] = s * p;
+                d[64 * l] = c * p;
+                itab[ni++] = l | (m << 8);
+                if (!(fabs(e[64 * l]) > eps * tst1 && iter < 64)) break;
+            }
+        }
+        if (!over) { d[64 * l] += f; e[64 * l] = 0.0; }
+    }
+    for (int i = 0; i < n; i++) dg[i] = d[64 * i];                          // eigenvalues
+    qi[0] = ni; qi[1] = nr; qi[2] = over ? 1 : 0;
+}
+extern "C" __global__ __launch_bounds__(NT) void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int *info = g.info + (size_t)w * MG_INFO;
+    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
+    const int *qi = g.qlInfo + (size_t)w * 4;
+    if (qi[2]) return;                                                      // log overflow: k_marg_finish redoes this window
+    extern __shared__ double s_dyn[];
+    __shared__ double s_lam[MG_NK + 2], s_br[MG_NK + 2];
+    __shared__ int s_rank[MG_NK + 2];
+    const int n = info[3], nb = info[5], N = n | 1;
+    double *V = s_dyn;
+    const double *Vg = g.qlV + (size_t)w * MG_NK * (MG_NK + 1), *dg = g.qlD + (size_t)w * 2 * (MG_NK + 2), *br = g.br + (size_t)w * MG_NK;
+    for (int e = tid; e < n * N; e += NT) V[e] = Vg[e];
+    if (tid < n) { s_lam[tid] = dg[tid]; s_br[tid] = br[tid]; }
+    __syncthreads();
+    if (tid < n) {                                                          // row k through every logged rotation; rows are independent
+        const int k = tid, ld = N;
+        const double *lg = g.qlLog + (size_t)w * 2 * QL_RCAP;
+        const int *itab = g.qlIt + (size_t)w * QL_ICAP;
+        const int ni = qi[0];
+        int pos = 0;
+        for (int it = 0; it < ni; it++) {
+            const int lm = itab[it], l = lm & 255, m = lm >> 8;
+            double hq = VV(k, m);
+            for (int i = m - 1; i >= l; i--, pos++) {
+                const double c = lg[2 * pos], sn = lg[2 * pos + 1];
+                const double vi = VV(k, i);
+                VV(k, i + 1) = sn * vi + c * hq;
+                hq = c * vi - sn * hq;
+            }
+            VV(k, l) = hq;
+        }
+    }
+    __syncthreads();
+    mf_tail(b, g, w, V, N, n, nb, info, s_lam, s_br, s_rank);
+}
+
+extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int *info = g.info + (size_t)w * MG_INFO;
+    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
+    if (only_flagged && !g.qlInfo[(size_t)w * 4 + 2]) return;
+    extern __shared__ double s_dyn[];
+    __shared__ double s_cs[2 * (MG_NK + 2)], s_lam[MG_NK + 2], s_e[MG_NK + 2], s_br[MG_NK + 2], s_sc[4];
+    __shared__ int s_rank[MG_NK + 2], s_ctl[2];
+    const int n = info[3], nb = info[5], N = n | 1;          // odd leading dimension: row / column walks stay off the same LDS banks
+    double *V = s_dyn;
+    const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
+    for (int e = tid; e < n * n; e += NT) {
+        const int i = e / n, j = e - n * i;
+        V[i * N + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]);
+    }
+    if (tid < n) s_br[tid] = br[tid];
+    __syncthreads();
+    tred2_tql2(V, n, N, s_lam, s_e, s_cs, s_sc, s_ctl);     // eigenvalues -> s_lam, eigenvectors -> columns of V
+    __syncthreads();
+    mf_tail(b, g, w, V, N, n, nb, info, s_lam, s_br, s_rank);
+}
+
+#undef VV
