@@ -854,7 +854,15 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_apply(VbBatch b, VbMarg g,
         for (int it = 0; it < ni; it++) {
             const int lm = itab[it], l = lm & 255, m = lm >> 8;
             double hq = VV(k, m);
-            for (int i = m - 1; i >= l; i--, pos++) {
+            int i = m - 1;
+            for (; i - 3 >= l; i -= 4, pos += 4) {                          // four rotations per trip: their operands are independent loads, only hq chains
+                double2 cs[4]; double vi[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { cs[u] = *reinterpret_cast<const double2 *>(lg + 2 * (pos + u)); vi[u] = VV(k, i - u); }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { VV(k, i - u + 1) = cs[u].y * vi[u] + cs[u].x * hq; hq = cs[u].x * vi[u] - cs[u].y * hq; }
+            }
+            for (; i >= l; i--, pos++) {
                 const double c = lg[2 * pos], sn = lg[2 * pos + 1];
                 const double vi = VV(k, i);
                 VV(k, i + 1) = sn * vi + c * hq;
