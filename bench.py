@@ -102,13 +102,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
+    # VILF_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives — rehearses the N > 1 code path on a one-GPU box (never a measurement)
+    rehearse = os.environ.get("VILF_BENCH_REHEARSAL") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from vil_fusion_amd import synth
     from vil_fusion_amd import dist as vdist
@@ -170,7 +177,7 @@ def main():
             th.join()
         if world > 1:
             solver.newest_poses_to_device(stamps, poses.data_ptr())
-            vdist.gather_poses(poses)                         # RCCL all_gather: 64 B per solved window (rank 0 feeds global_fusion)
+            vdist.gather_poses(poses.cpu() if rehearse else poses)   # RCCL all_gather: 64 B per solved window (rank 0 feeds global_fusion)
 
     def barrier():
         if world > 1:
@@ -202,7 +209,7 @@ def main():
                    lm_iterations=float(np.mean([r.iterations[0] + r.iterations[1] for r in rs])),
                    map_points=float(np.mean([len(c[0]) + len(c[1]) for c in lidar_cases])), scan_points=float(np.mean([len(c[2][0]) + len(c[2][1]) for c in lidar_cases])),
                    map_edge_points=float(np.mean([len(c[0]) for c in lidar_cases])), map_surf_points=float(np.mean([len(c[1]) for c in lidar_cases])))
-    t = torch.tensor([dt, float(its_local)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, float(its_local)], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
