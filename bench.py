@@ -80,6 +80,13 @@ def cpu_baseline(opts_unused, wins, priors, lidar_cases, marginalize, seconds_ta
                        f"(C++ -O3, one frame per thread, {cores} threads), {dt:.1f} s")
 
 
+def _profile_order(path):
+    """profiles/rNN_vMM_*: round, then version, numerically (r01_v10 after r01_v9)"""
+    import re
+    m = re.search(r"r(\d+)_v(\d+)", os.path.basename(path))
+    return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,7 +252,7 @@ def main():
         traffic = None
         try:
             import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=_profile_order)[-1]))
             if pmc.get("config", {}).get("frames_per_gpu") == B and pmc["config"].get("workload_tag") == workload_tag:
                 traffic = pmc["groups"][dom]["hbm_bytes_per_launch_corrected"]
         except Exception:
@@ -255,7 +262,7 @@ def main():
         mfma = None
         try:
             import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))[-1]))
+            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")), key=_profile_order)[-1]))
             if cfg.n_features == 230:      # per-window flop count is independent of the batch size: scale the 2048-window PMC figure
                 mfma = {}
                 for kk in ("k_solve", "k_linearize"):
