@@ -356,3 +356,19 @@ def test_benchmark_windows_translation_equivariance_and_cost_descent(solver, ora
             assert np.abs(g.Rs - g0.Rs).max() < 1e-8 and np.abs(g.Vs - g0.Vs).max() < 1e-7
     _compare(got[0], oracle.window_solve(opts, wins[0], None))
     _compare(got[5], oracle.window_solve(opts, wins[5], None))
+
+
+def test_marginalization_eigen_solver_fallback(solver, oracle, opts, monkeypatch):
+    """the eigen-solver runs in three launches with a bounded rotation log; a window whose log overflows is redone by the
+    single-workgroup kernel. Force that path (VILF_MARG_FORCE_QL_FALLBACK) and compare both with the oracle and with the split path."""
+    wins, priors = synth.make_batch(77, 6, opts, synth.SynthConfig(n_features=120), distinct=6)
+    solver.batch_upload(wins, priors); solver.batch_solve(); solver.batch_marginalize()
+    split = [_prior_products(solver.get_prior(i)) for i in range(6)]
+    monkeypatch.setenv("VILF_MARG_FORCE_QL_FALLBACK", "1")
+    solver.batch_upload(wins, priors); solver.batch_solve(); solver.batch_marginalize()
+    for i in range(6):
+        Lg, bg, _ = _prior_products(solver.get_prior(i))
+        pr = oracle.window_marginalize(opts, wins[i], oracle.window_solve(opts, wins[i], priors[i]), priors[i])
+        Lr, br_, _ = _prior_products(pr)
+        assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5
+        assert np.abs(Lg - split[i][0]).max() / np.abs(Lr).max() < 1e-9        # same arithmetic in both paths up to FMA contraction of the replay

@@ -28,7 +28,7 @@ __global__ void k_marg_prepare(VbBatch b, VbMarg g);
 __global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
 __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged);
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
-__global__ void k_mf_ql(VbBatch b, VbMarg g);
+__global__ void k_mf_ql(VbBatch b, VbMarg g, int force_overflow);
 __global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
 __global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
@@ -679,7 +679,8 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     // prior output per workgroup); k_marg_finish (everything in one workgroup) only takes windows whose rotation log overflowed
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
-    hipLaunchKernelGGL(k_mf_ql, dim3((h->B + 63) / 64), dim3(64), (size_t)2 * (MG_NK + 2) * 64 * sizeof(double), h->stream, h->batch, g);
+    hipLaunchKernelGGL(k_mf_ql, dim3((h->B + 63) / 64), dim3(64), (size_t)2 * (MG_NK + 2) * 64 * sizeof(double), h->stream, h->batch, g,
+                       std::getenv("VILF_MARG_FORCE_QL_FALLBACK") ? 1 : 0);        // test hook
     hipLaunchKernelGGL(k_mf_apply, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
     hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
     hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, 1);
