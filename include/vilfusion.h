@@ -102,7 +102,8 @@ typedef struct vilf_lidar_constraint {
 
 /* One window ≙ the members optimization() reads (estimator.h:70-146). */
 typedef struct vilf_window_in {
-    int n_frames;                         /* window_size + 1 */
+    int n_frames;                         /* options.window_size + 1. 11 = the reference's WINDOW_SIZE: batched LDS kernels; any other size: the general
+                                             single-window path (vilf_window_solve only; no prior, no marginalization) — BASELINE configs[4] */
     const double *para_pose;              /* [n_frames][7] */
     const double *para_speed_bias;        /* [n_frames][9] */
     double para_ex_pose[7];

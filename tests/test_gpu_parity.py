@@ -372,3 +372,26 @@ def test_marginalization_eigen_solver_fallback(solver, oracle, opts, monkeypatch
         Lr, br_, _ = _prior_products(pr)
         assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5
         assert np.abs(Lg - split[i][0]).max() / np.abs(Lr).max() < 1e-9        # same arithmetic in both paths up to FMA contraction of the replay
+
+
+@pytest.mark.parametrize("n_frames,n_features,tol", [(21, 400, 1e-7), (51, 2500, 1e-6)])
+def test_large_window_solve_matches_oracle(oracle, n_frames, n_features, tol):
+    """BASELINE configs[4]: the synthetic 51-frame / ~50 k-factor stress window (reduced system 765 x 765) — and a 21-frame one — through
+    vilf_window_solve's general path (one window spread over the device: factor lanes with fp64 atomics, rocBLAS SYRK Schur reduce,
+    rocSOLVER Cholesky, trust-region logic on the host) against the oracle. The atomics' summation order is free: tolerances, not bits."""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    o.window_size = n_frames - 1
+    cfg = synth.SynthConfig(n_frames=n_frames, n_features=n_features, with_prior=False)
+    win, _, _ = synth.make_window(60 + n_frames, o, cfg)
+    nfac = len(win.obs_point) - win.n_features
+    assert nfac > (40000 if n_frames == 51 else 3000)
+    ref = oracle.window_solve(o, win, None)
+    s = BackendSolver(o)
+    got = s.optimization(win)
+    s.close()
+    assert got.summary["num_iterations"] == ref.summary["num_iterations"] and got.summary["num_successful_steps"] == ref.summary["num_successful_steps"]
+    assert abs(got.summary["initial_cost"] - ref.summary["initial_cost"]) <= 1e-9 * ref.summary["initial_cost"]
+    assert abs(got.summary["final_cost"] - ref.summary["final_cost"]) <= 1e-6 * ref.summary["final_cost"]
+    assert np.abs(got.Ps - ref.Ps).max() < tol and np.abs(got.Rs - ref.Rs).max() < tol and np.abs(got.Vs - ref.Vs).max() < 10 * tol
+    assert np.abs(1.0 / got.para_feature - 1.0 / ref.para_feature).max() < 1e-4

@@ -100,7 +100,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VILF_ERR_NO_GPU;
     if (device < 0 || device >= ndev) return VILF_ERR_INVALID_ARGUMENT;
-    if (opts->window_size != 10) return VILF_ERR_UNSUPPORTED;                  // WINDOW_SIZE is compile-time in the reference too
+    if (opts->window_size < 1 || opts->window_size > 4096) return VILF_ERR_UNSUPPORTED;   // 10 = the reference's compile-time WINDOW_SIZE (batched LDS kernels); other sizes: single-window general path (vilf_lw.hip)
     if (opts->estimate_extrinsic || opts->estimate_td) return VILF_ERR_UNSUPPORTED;  // KITTI config: both 0
     vilf_handle *h = new vilf_handle();
     h->opts = *opts;
@@ -135,6 +135,7 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     vilf_s2m_release(h);
     vilf_feat_release(h);
     vilf_pg_release(h);
+    vilf_lw_release(h);
     for (auto &b : h->d) b.release();
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -604,6 +605,10 @@ extern "C" int vilf_batch_download(vilf_handle *h, int first, int n, vilf_window
 
 extern "C" int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out) {
     if (!h || !in || !out) return VILF_ERR_INVALID_ARGUMENT;
+    if (in->n_frames != VB_NF) {          // not the reference's WINDOW_SIZE = 10: the general path (one window spread over the device, no prior)
+        if (in->n_frames != h->opts.window_size + 1) { h->err = "n_frames must be options.window_size + 1"; return VILF_ERR_INVALID_ARGUMENT; }
+        return vilf_lw_window_solve(h, in, out);
+    }
     auto t0 = std::chrono::steady_clock::now();
     int rc = vilf_batch_upload(h, 1, in);
     if (rc != VILF_OK) return rc;

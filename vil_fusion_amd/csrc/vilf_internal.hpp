@@ -35,6 +35,7 @@ enum {
 struct S2B;
 struct FeatCtx;
 struct PgCtx;
+struct LwCtx;
 
 struct vilf_handle {
     vilf_options opts;
@@ -74,6 +75,7 @@ struct vilf_handle {
     FeatCtx *feat = nullptr;                 // LiDAR feature extraction workspace (vilf_feat.hip)
     S2B *s2m = nullptr, *s2b = nullptr;      // scan-to-map state: single stream / batched streams (vilf_s2m.hip)
     PgCtx *pg = nullptr;                     // pose-graph workspace (vilf_pg.hip)
+    LwCtx *lw = nullptr;                     // large-window solve workspace (vilf_lw.hip)
 };
 
 #define HIPCHECK(h, call)                                                                                        \
@@ -89,3 +91,5 @@ struct vilf_handle {
 void vilf_s2m_release(vilf_handle *h);
 void vilf_feat_release(vilf_handle *h);
 void vilf_pg_release(vilf_handle *h);
+void vilf_lw_release(vilf_handle *h);
+int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out);   // window sizes other than 10 (vilf_lw.hip)

@@ -1,0 +1,487 @@
+// vilf_lw.hip — Estimator::optimization()'s solve for window sizes other than the reference's WINDOW_SIZE = 10 (BASELINE configs[4]:
+// the synthetic 51-frame / ~50 k-factor stress window; reduced camera / IMU system P = 15 * 51 = 765).
+// The 11-frame kernels keep a window's whole reduced system in one workgroup's LDS; a 765 x 765 system does not fit, so this path
+// spreads ONE window over the device instead:
+//   lw_visual / lw_imu / lw_lidar   one lane per factor: residual + Jacobians (the same device functions as the 11-frame kernels), Cauchy
+//                                   corrector, J^T J / J^T r scattered with hardware fp64 atomics into the dense reduced blocks
+//                                   Hpp (P x P), W (F x P, one row per feature), h_f, g_f, g_p
+//   lw_scale, lw_schur_prep         Jacobi scaling; LM-regularised reduced system and the row-scaled W for the Schur product
+//   rocBLAS dsyrk / dgemv           S = Hpp' + mu D^2 - Wn^T Wn (the fp64 MFMA Schur reduce: 2 F P^2 = 2.9 GFLOP per solve), matrix-vector products
+//   rocSOLVER dpotrf / dpotrs       dense Cholesky of the reduced system
+// and keeps the trust-region logic (Ceres 2.0 TrustRegionMinimizer + traditional dogleg + Jacobi scaling, the same restatement as
+// k_solve / k_step) on the host: per iteration only vectors of P + F doubles cross PCIe. No marginalization prior on this path.
+// Summation order of the atomics is not fixed: results are reproducible to rounding (~1e-12 relative), not bit for bit.
+#include <hip/hip_runtime.h>
+#include <rocsolver/rocsolver.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "vilf_internal.hpp"
+#include "vilf_device.hpp"
+
+extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec);
+
+struct LwCtx {
+    rocblas_handle blas = nullptr;
+    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den;
+    void release() {
+        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den};
+        for (DBuf *b : all) b->release();
+        if (blas) { rocblas_destroy_handle(blas); blas = nullptr; }
+    }
+};
+void vilf_lw_release(vilf_handle *h) { if (h->lw) { h->lw->release(); delete h->lw; h->lw = nullptr; } }
+
+namespace {
+using namespace vd;
+
+struct LwVis { double pi[3], pj[3]; int f, i, j, cst; };     // one ProjectionFactor: feature, start frame, observing frame
+
+__device__ __forceinline__ void add(double *p, double v) { unsafeAtomicAdd(p, v); }
+
+// x layout: pose[NF][7] | sb[NF][9] | feat[F]
+__global__ void lw_visual(int n, const LwVis *vis, const double *x, const double *ex, int NF, int F, double sqrt_info, double cauchy_b, int jac,
+                          double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    double c = 0;
+    if (t < n) {
+        const LwVis v = vis[t];
+        const int P = 15 * NF;
+        const double *pi = x + 7 * v.i, *pj = x + 7 * v.j;
+        double Ri[9], Rj[9], ric[9];
+        q_toR(q_load(pi + 3), Ri); q_toR(q_load(pj + 3), Rj); q_toR(q_load(ex + 3), ric);
+        double r[2], Ji[12], Jj[12], Jf[2];
+        const double inv_dep = x[16 * NF + v.f];
+        if (jac) projection_eval<true>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, inv_dep, sqrt_info, r, Ji, Jj, Jf);
+        else projection_eval<false>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, inv_dep, sqrt_info, r, Ji, Jj, Jf);
+        double rho0, sw;
+        cauchy(r[0] * r[0] + r[1] * r[1], cauchy_b, rho0, sw);
+        c = 0.5 * rho0;
+        if (jac) {
+            const int ci = 15 * v.i, cj = 15 * v.j;
+            double J[2][12];
+            for (int k = 0; k < 6; k++) { J[0][k] = sw * Ji[k]; J[1][k] = sw * Ji[6 + k]; J[0][6 + k] = sw * Jj[k]; J[1][6 + k] = sw * Jj[6 + k]; }
+            const double r0 = sw * r[0], r1 = sw * r[1];
+            for (int a = 0; a < 12; a++) {
+                const int ca = (a < 6 ? ci + a : cj + a - 6);
+                add(gp + ca, J[0][a] * r0 + J[1][a] * r1);
+                for (int b = 0; b < 12; b++) { const int cb = (b < 6 ? ci + b : cj + b - 6); add(Hpp + (size_t)ca * P + cb, J[0][a] * J[0][b] + J[1][a] * J[1][b]); }
+            }
+            if (!v.cst) {
+                const double f0 = sw * Jf[0], f1 = sw * Jf[1];
+                add(hf + v.f, f0 * f0 + f1 * f1);
+                add(gf + v.f, f0 * r0 + f1 * r1);
+                for (int a = 0; a < 12; a++) add(W + (size_t)v.f * P + (a < 6 ? ci + a : cj + a - 6), J[0][a] * f0 + J[1][a] * f1);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c != 0.0) add(cost, c);
+}
+// IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair
+__global__ void lw_imu_lidar(int NF, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
+                             double *Hpp, double *gp, double *cost) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= NF - 1) return;
+    const int P = 15 * NF, c0 = 15 * k;
+    const double *pi = x + 7 * k, *pj = x + 7 * (k + 1), *sbi = x + 7 * NF + 9 * k, *sbj = sbi + 9;
+    double c = 0;
+    const double *rec = imu_rec + (size_t)k * IMU_REC;
+    if (rec[287] != 0.0) {
+        double r[15], Jr[15 * 30], rw[15];
+        if (jac) imu_raw_eval<true, 30, true>(pi, sbi, pj, sbj, rec, G, r, Jr); else imu_raw_eval<false, 30, true>(pi, sbi, pj, sbj, rec, G, r, Jr);
+        const double *S = rec + IMU_SQRT;                      // upper-triangular sqrt_info (15 x 15, row-major)
+        for (int a = 0; a < 15; a++) { double s = 0; for (int m = a; m < 15; m++) s += S[15 * a + m] * r[m]; rw[a] = s; c += 0.5 * s * s; }
+        if (jac) {
+            for (int col = 0; col < 30; col++) {               // Jw(:, col) = S Jraw(:, col); then the column's products with all earlier-or-equal columns
+                double jw[15];
+                for (int a = 0; a < 15; a++) { double s = 0; for (int m = a; m < 15; m++) s += S[15 * a + m] * Jr[30 * m + col]; jw[a] = s; }
+                for (int a = 0; a < 15; a++) Jr[30 * a + col] = jw[a];   // rows a >= ... of this column are final: columns are processed left to right and
+            }                                                            // S is applied to a whole column at once (reads rows m >= a of the raw column only)
+            for (int a = 0; a < 30; a++) {
+                double s = 0;
+                for (int m = 0; m < 15; m++) s += Jr[30 * m + a] * rw[m];
+                add(gp + c0 + a, s);
+                for (int b = 0; b < 30; b++) { double h = 0; for (int m = 0; m < 15; m++) h += Jr[30 * m + a] * Jr[30 * m + b]; add(Hpp + (size_t)(c0 + a) * P + c0 + b, h); }
+            }
+        }
+    }
+    if (use_lidar) {
+        double r[6], Ji[36], Jj[36];
+        const double *lc = lid + 7 * (size_t)k;
+        if (jac) lidar_between_eval<true>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, r, Ji, Jj); else lidar_between_eval<false>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, r, Ji, Jj);
+        for (int a = 0; a < 6; a++) c += 0.5 * r[a] * r[a];
+        if (jac) {
+            const int ci = c0, cj = c0 + 15;
+            for (int a = 0; a < 12; a++) {
+                const double *Ja = a < 6 ? Ji : Jj; const int aa = a < 6 ? a : a - 6, ca = a < 6 ? ci + a : cj + a - 6;
+                double s = 0;
+                for (int m = 0; m < 6; m++) s += Ja[6 * m + aa] * r[m];
+                add(gp + ca, s);
+                for (int b = 0; b < 12; b++) {
+                    const double *Jb = b < 6 ? Ji : Jj; const int bb = b < 6 ? b : b - 6, cb = b < 6 ? ci + b : cj + b - 6;
+                    double hh = 0;
+                    for (int m = 0; m < 6; m++) hh += Ja[6 * m + aa] * Jb[6 * m + bb];
+                    add(Hpp + (size_t)ca * P + cb, hh);
+                }
+            }
+        }
+    }
+    add(cost, c);
+}
+// Jacobi scaling in place: Hpp(i, j) *= s_i s_j, W(f, c) *= s_f s_c, h_f *= s_f^2, g *= s. s = [P pose/speed-bias entries | F features]
+__global__ void lw_scale(int P, int F, const double *s, double *Hpp, double *W, double *hf, double *gp, double *gf) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
+    if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); Hpp[t] *= s[i] * s[j]; }
+    else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P), c = (int)(u % P); W[u] *= s[P + f] * s[c]; }
+    else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); hf[f] *= s[P + f] * s[P + f]; gf[f] *= s[P + f]; }
+    else if (t < nH + nW + F + P) { const int i = (int)(t - nH - nW - F); gp[i] *= s[i]; }
+}
+// S = Hpp + diag(lm_p^2); den_f = h_f + lm_f^2 (1 for constant features: their rows of W are zero); Wn = W / sqrt(den); tmpF = g_f / sqrt(den)
+__global__ void lw_schur_prep(int P, int F, const double *Hpp, const double *W, const double *hf, const double *gf, const double *lm, const unsigned char *fconst,
+                              double *S, double *Wn, double *den, double *tmpF) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
+    if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); S[t] = Hpp[t] + (i == j ? lm[i] * lm[i] : 0.0); }
+    else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; Wn[u] = W[u] / sqrt(d); }
+    else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; den[f] = d; tmpF[f] = gf[f] / sqrt(d); }
+}
+__global__ void lw_feature_back(int F, const double *gf, const double *Wy, const double *den, double *yf) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < F) yf[f] = (gf[f] - Wy[f]) / den[f];
+}
+
+// ---- host-side manifold helpers (PoseLocalParameterization, utility.h) ------------------------------------------------------------
+struct HQ { double x, y, z, w; };
+inline HQ hq_mul(const HQ &a, const HQ &b) { return HQ{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z}; }
+inline void h_pose_plus(const double *x, const double *d, double *o) {      // pose_local_parameterization.cpp:3-17
+    for (int k = 0; k < 3; k++) o[k] = x[k] + d[k];
+    HQ q{x[3], x[4], x[5], x[6]}, dq{d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0};
+    HQ r = hq_mul(q, dq);
+    const double n = std::sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+    o[3] = r.x / n; o[4] = r.y / n; o[5] = r.z / n; o[6] = r.w / n;
+}
+inline void h_q2R(const double *q_xyzw, double *R) {
+    const double n = std::sqrt(q_xyzw[0] * q_xyzw[0] + q_xyzw[1] * q_xyzw[1] + q_xyzw[2] * q_xyzw[2] + q_xyzw[3] * q_xyzw[3]);
+    const double x = q_xyzw[0] / n, y = q_xyzw[1] / n, z = q_xyzw[2] / n, w = q_xyzw[3] / n;
+    R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+    R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+    R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+inline void h_R2ypr(const double *R, double *ypr) {
+    const double y = std::atan2(R[3], R[0]);
+    const double p = std::atan2(-R[6], R[0] * std::cos(y) + R[3] * std::sin(y));
+    const double r = std::atan2(R[2] * std::sin(y) - R[5] * std::cos(y), -R[1] * std::sin(y) + R[4] * std::cos(y));
+    ypr[0] = y / M_PI * 180.0; ypr[1] = p / M_PI * 180.0; ypr[2] = r / M_PI * 180.0;
+}
+inline void h_ypr2R(const double *ypr, double *R) {
+    const double y = ypr[0] / 180.0 * M_PI, p = ypr[1] / 180.0 * M_PI, r = ypr[2] / 180.0 * M_PI;
+    const double Rz[9] = {std::cos(y), -std::sin(y), 0, std::sin(y), std::cos(y), 0, 0, 0, 1}, Ry[9] = {std::cos(p), 0, std::sin(p), 0, 1, 0, -std::sin(p), 0, std::cos(p)},
+                 Rx[9] = {1, 0, 0, 0, std::cos(r), -std::sin(r), 0, std::sin(r), std::cos(r)};
+    double T[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += Rz[3 * i + k] * Ry[3 * k + j]; T[3 * i + j] = s; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += T[3 * i + k] * Rx[3 * k + j]; R[3 * i + j] = s; }
+}
+}  // namespace
+
+#define RB(call) do { if ((call) != rocblas_status_success) { h->err = "rocBLAS / rocSOLVER call failed (large-window solve)"; return VILF_ERR_DEVICE; } } while (0)
+
+int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const int NF = in->n_frames, F = in->n_features, P = 15 * NF, N = P + F;
+    if (NF < 2 || F < 0 || !in->para_pose || !in->para_speed_bias || !in->imu || (F && (!in->para_feature || !in->feature_const || !in->feature_start_frame || !in->feature_obs_offset || !in->obs_point)))
+        return VILF_ERR_INVALID_ARGUMENT;
+    if (h->opts.estimate_extrinsic || h->opts.estimate_td) { h->err = "estimate_extrinsic / estimate_td are not supported by the device solve"; return VILF_ERR_UNSUPPORTED; }
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (!h->lw) h->lw = new LwCtx();
+    LwCtx *c = h->lw;
+    if (!c->blas) { if (rocblas_create_handle(&c->blas) != rocblas_status_success) { h->err = "rocblas_create_handle failed"; return VILF_ERR_DEVICE; } rocblas_set_stream(c->blas, h->stream); }
+    // ---- pack the factors
+    std::vector<LwVis> vis;
+    for (int f = 0; f < F; f++) {
+        const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
+        if (s < 0 || s + (o1 - o0) > NF) { h->err = "feature track leaves the window"; return VILF_ERR_INVALID_ARGUMENT; }
+        for (int t = o0 + 1; t < o1; t++) {
+            LwVis v;
+            for (int k = 0; k < 3; k++) { v.pi[k] = in->obs_point[3 * (size_t)o0 + k]; v.pj[k] = in->obs_point[3 * (size_t)t + k]; }
+            v.f = f; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
+            vis.push_back(v);
+        }
+    }
+    const int nvis = (int)vis.size(), nimu = NF - 1;
+    std::vector<double> imu((size_t)nimu * IMU_REC, 0.0), cov((size_t)nimu * 225), lid((size_t)nimu * 7, 0.0);
+    for (int k = 0; k < nimu; k++) {
+        const vilf_imu_preint &p = in->imu[k + 1];
+        double *rec = &imu[(size_t)k * IMU_REC];
+        rec[0] = p.sum_dt;
+        for (int i = 0; i < 3; i++) { rec[1 + i] = p.delta_p[i]; rec[8 + i] = p.delta_v[i]; rec[11 + i] = p.linearized_ba[i]; rec[14 + i] = p.linearized_bg[i]; }
+        for (int i = 0; i < 4; i++) rec[4 + i] = p.delta_q[i];
+        auto blk = [&](int off, int r0, int c0) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rec[off + 3 * i + j] = p.jacobian[(r0 + i) * 15 + c0 + j]; };
+        blk(17, 0, 9); blk(26, 0, 12); blk(35, 3, 12); blk(44, 6, 9); blk(53, 6, 12);
+        rec[287] = (p.sum_dt > 10.0) ? 0.0 : 1.0;
+        std::memcpy(&cov[(size_t)k * 225], p.covariance, 225 * 8);
+        if (in->lidar) { const vilf_lidar_constraint &l = in->lidar[k + 1]; for (int i = 0; i < 4; i++) lid[7 * k + i] = l.q[i]; for (int i = 0; i < 3; i++) lid[7 * k + 4 + i] = l.t[i]; }
+        else lid[7 * k + 3] = 1.0;
+    }
+    const bool use_lidar = h->opts.use_lidar_const && in->lidar;
+    // extrinsic-derived constants (lidar_factor.h:28-29): q_il = RIC RCL, t_il = RIC TCL + TIC
+    double Ril[9], qil[4], til[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += h->opts.RIC[3 * i + k] * h->opts.RCL[3 * k + j]; Ril[3 * i + j] = s; }
+    for (int i = 0; i < 3; i++) { double s = h->opts.TIC[i]; for (int k = 0; k < 3; k++) s += h->opts.RIC[3 * i + k] * h->opts.TCL[k]; til[i] = s; }
+    {   // rotation matrix -> quaternion (Eigen's branch on the trace)
+        const double *m = Ril; const double tr = m[0] + m[4] + m[8];
+        double q[4];
+        if (tr > 0) { double t = std::sqrt(tr + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t; }
+        else { int i = 0; if (m[4] > m[0]) i = 1; if (m[8] > m[4 * i]) i = 2; const int j = (i + 1) % 3, k = (j + 1) % 3; double t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t; q[3] = (m[3 * k + j] - m[3 * j + k]) * t; q[j] = (m[3 * j + i] + m[3 * i + j]) * t; q[k] = (m[3 * k + i] + m[3 * i + k]) * t; }
+        for (int k = 0; k < 4; k++) qil[k] = q[k];
+    }
+    // ---- device buffers
+    const size_t sP = P, sF = std::max(F, 1), sN = N;
+    if (!c->x.ensure((16 * (size_t)NF + sF) * 8) || !c->ex.ensure(7 * 8 + 64) || !c->vis.ensure(std::max<size_t>(nvis, 1) * sizeof(LwVis)) || !c->imu.ensure(imu.size() * 8) || !c->cov.ensure(cov.size() * 8) ||
+        !c->lid.ensure(lid.size() * 8) || !c->Hpp.ensure(sP * sP * 8) || !c->W.ensure(sF * sP * 8) || !c->hf.ensure(sF * 8) || !c->gp.ensure(sP * 8) || !c->gf.ensure(sF * 8) || !c->S.ensure(sP * sP * 8) ||
+        !c->Wn.ensure(sF * sP * 8) || !c->rhs.ensure(sP * 8) || !c->tmpP.ensure(sP * 8) || !c->tmpF.ensure(sF * 8) || !c->vec.ensure(2 * sN * 8) || !c->scal.ensure(256) || !c->info.ensure(64) ||
+        !c->fconst.ensure(sF) || !c->den.ensure(sF * 8)) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
+    double geo[7 + 3 + 4];
+    for (int k = 0; k < 4; k++) geo[k] = qil[k];
+    for (int k = 0; k < 3; k++) geo[4 + k] = til[k];
+    for (int k = 0; k < 3; k++) geo[7 + k] = h->opts.G[k];
+    HIPCHECK(h, hipMemcpyAsync(c->ex.p, in->para_ex_pose, 56, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(c->scal.as<double>() + 1, geo, 10 * 8, hipMemcpyHostToDevice, h->stream));        // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
+    if (nvis) HIPCHECK(h, hipMemcpyAsync(c->vis.p, vis.data(), (size_t)nvis * sizeof(LwVis), hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(c->imu.p, imu.data(), imu.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(c->cov.p, cov.data(), cov.size() * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(c->lid.p, lid.data(), lid.size() * 8, hipMemcpyHostToDevice, h->stream));
+    if (F) HIPCHECK(h, hipMemcpyAsync(c->fconst.p, in->feature_const, F, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, c->cov.as<double>(), c->tmpP.as<double>(), c->imu.as<double>());
+    double *scal = c->scal.as<double>();
+    const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = 1.0 / (h->opts.cauchy_a * h->opts.cauchy_a);
+
+    // ---- host state: x = pose | sb | feat
+    std::vector<double> x(16 * (size_t)NF + F), cand(x.size());
+    std::memcpy(&x[0], in->para_pose, 7 * NF * 8); std::memcpy(&x[7 * NF], in->para_speed_bias, 9 * NF * 8);
+    for (int f = 0; f < F; f++) x[16 * NF + f] = in->para_feature[f];
+    double R0b[9], P0b[3];
+    if (in->gauge_R0) std::memcpy(R0b, in->gauge_R0, 72); else h_q2R(&x[3], R0b);
+    if (in->gauge_P0) std::memcpy(P0b, in->gauge_P0, 24); else std::memcpy(P0b, &x[0], 24);
+    auto xnorm = [&](const std::vector<double> &v) { double s = 0; for (int i = 0; i < 16 * NF; i++) s += v[i] * v[i]; for (int f = 0; f < F; f++) if (!in->feature_const[f]) s += v[16 * NF + f] * v[16 * NF + f]; return std::sqrt(s); };
+    // tangent vector d[N] = [15 per frame: pose 6, speed-bias 9 | F] applied to the state
+    auto plus = [&](const std::vector<double> &xx, const std::vector<double> &d, std::vector<double> &o) {
+        o = xx;
+        for (int i = 0; i < NF; i++) { h_pose_plus(&xx[7 * i], &d[15 * i], &o[7 * i]); for (int k = 0; k < 9; k++) o[7 * NF + 9 * i + k] = xx[7 * NF + 9 * i + k] + d[15 * i + 6 + k]; }
+        for (int f = 0; f < F; f++) o[16 * NF + f] = xx[16 * NF + f] + (in->feature_const[f] ? 0.0 : d[P + f]);
+    };
+    auto evaluate = [&](const std::vector<double> &xx, bool jac, double &cost) -> int {
+        HIPCHECK(h, hipMemcpyAsync(c->x.p, xx.data(), xx.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemsetAsync(scal, 0, 8, h->stream));
+        if (jac) {
+            HIPCHECK(h, hipMemsetAsync(c->Hpp.p, 0, sP * sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->W.p, 0, sF * sP * 8, h->stream));
+            HIPCHECK(h, hipMemsetAsync(c->hf.p, 0, sF * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gp.p, 0, sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gf.p, 0, sF * 8, h->stream));
+        }
+        if (nvis) hipLaunchKernelGGL(lw_visual, dim3((nvis + 255) / 256), dim3(256), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->ex.as<double>(), NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
+                                     c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
+        hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
+                           c->Hpp.as<double>(), c->gp.as<double>(), scal);
+        HIPCHECK(h, hipGetLastError());
+        HIPCHECK(h, hipMemcpyAsync(&cost, scal, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        return VILF_OK;
+    };
+    // host copies of the (scaled) diagonal / gradient pieces
+    std::vector<double> g(N), scale(N, 1.0), diagH(N), hfh(sF), diagonal(N), gradient(N), gn(N), step(N), delta(N), lm(N), y(N), tP(P), tF(sF), v(N);
+    bool scaling_ready = false;
+    double gradient_max_norm = 0, x_cost = 0;
+    auto fetch_diag_grad = [&]() -> int {            // diag(Hpp) / h_f and g_p / g_f from the device
+        // only the diagonal of Hpp is needed: strided copy
+        HIPCHECK(h, hipMemcpy2DAsync(diagH.data(), 8, c->Hpp.p, (sP + 1) * 8, 8, P, hipMemcpyDeviceToHost, h->stream));
+        if (F) { HIPCHECK(h, hipMemcpyAsync(&diagH[P], c->hf.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHECK(h, hipMemcpyAsync(&g[P], c->gf.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); }
+        HIPCHECK(h, hipMemcpyAsync(&g[0], c->gp.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        for (int f = 0; f < F; f++) if (in->feature_const[f]) { diagH[P + f] = 0.0; g[P + f] = 0.0; }
+        return VILF_OK;
+    };
+    // x^T H x with the (scaled) blocks on the device: returns v_p^T Hpp v_p + 2 sum_f v_f (W_f . v_p) + sum_f h_f v_f^2 and keeps Hpp v_p / W v_p
+    auto quad = [&](const std::vector<double> &vv, double &q) -> int {
+        const double one = 1.0, zero = 0.0;
+        HIPCHECK(h, hipMemcpyAsync(c->vec.p, vv.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+        RB(rocblas_dgemv(c->blas, rocblas_operation_none, P, P, &one, c->Hpp.as<double>(), P, c->vec.as<double>(), 1, &zero, c->tmpP.as<double>(), 1));
+        if (F) RB(rocblas_dgemv(c->blas, rocblas_operation_transpose, P, F, &one, c->W.as<double>(), P, c->vec.as<double>(), 1, &zero, c->tmpF.as<double>(), 1));
+        HIPCHECK(h, hipMemcpyAsync(tP.data(), c->tmpP.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
+        if (F) HIPCHECK(h, hipMemcpyAsync(tF.data(), c->tmpF.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        q = 0;
+        for (int i = 0; i < P; i++) q += vv[i] * tP[i];
+        for (int f = 0; f < F; f++) if (!in->feature_const[f]) q += vv[P + f] * (2.0 * tF[f] + hfh[f] * vv[P + f]);
+        return VILF_OK;
+    };
+    auto eval_grad_jac = [&]() -> int {
+        int rc = evaluate(x, true, x_cost);
+        if (rc != VILF_OK) return rc;
+        if ((rc = fetch_diag_grad()) != VILF_OK) return rc;           // unscaled
+        if (!scaling_ready) { for (int i = 0; i < N; i++) scale[i] = 1.0 / (1.0 + std::sqrt(diagH[i])); scaling_ready = true; }
+        // gradient_max_norm = || x - Plus(x, -g) ||_inf with the unscaled gradient
+        std::vector<double> ng(N), proj;
+        for (int i = 0; i < N; i++) ng[i] = -g[i];
+        plus(x, ng, proj);
+        gradient_max_norm = 0;
+        for (size_t i = 0; i < x.size(); i++) gradient_max_norm = std::max(gradient_max_norm, std::fabs(x[i] - proj[i]));
+        // Jacobi scaling of the blocks on the device and of the host copies
+        HIPCHECK(h, hipMemcpyAsync(c->vec.p, scale.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+        const size_t tot = sP * sP + (size_t)F * sP + F + P;
+        hipLaunchKernelGGL(lw_scale, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->vec.as<double>(), c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>());
+        for (int i = 0; i < N; i++) { g[i] *= scale[i]; diagH[i] *= scale[i] * scale[i]; }
+        for (int f = 0; f < F; f++) hfh[f] = diagH[P + f];
+        return VILF_OK;
+    };
+    // ---- the linear solve: (H' + lm^2) y = g'
+    auto linear_solve = [&](bool &ok) -> int {
+        const double one = 1.0, mone = -1.0;
+        ok = false;
+        for (int f = 0; f < F; f++) if (!in->feature_const[f] && !(hfh[f] + lm[P + f] * lm[P + f] > 0.0)) return VILF_OK;
+        HIPCHECK(h, hipMemcpyAsync(c->vec.p, lm.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+        const size_t tot = sP * sP + (size_t)F * sP + F;
+        hipLaunchKernelGGL(lw_schur_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gf.as<double>(), c->vec.as<double>(),
+                           c->fconst.as<unsigned char>(), c->S.as<double>(), c->Wn.as<double>(), c->den.as<double>(), c->tmpF.as<double>());
+        HIPCHECK(h, hipMemcpyAsync(c->rhs.p, c->gp.p, sP * 8, hipMemcpyDeviceToDevice, h->stream));
+        if (F) {
+            // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P == column-major P x F), rhs -= Wn^T (g_f / sqrt(den))
+            RB(rocblas_dsyrk(c->blas, rocblas_fill_lower, rocblas_operation_none, P, F, &mone, c->Wn.as<double>(), P, &one, c->S.as<double>(), P));
+            RB(rocblas_dgemv(c->blas, rocblas_operation_none, P, F, &mone, c->Wn.as<double>(), P, c->tmpF.as<double>(), 1, &one, c->rhs.as<double>(), 1));
+        }
+        rocblas_int *dinfo = c->info.as<rocblas_int>();
+        RB(rocsolver_dpotrf(c->blas, rocblas_fill_lower, P, c->S.as<double>(), P, dinfo));
+        int info = 0;
+        HIPCHECK(h, hipMemcpyAsync(&info, dinfo, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
+        RB(rocsolver_dpotrs(c->blas, rocblas_fill_lower, P, 1, c->S.as<double>(), P, c->rhs.as<double>(), P));
+        if (F) {
+            const double zero = 0.0;
+            RB(rocblas_dgemv(c->blas, rocblas_operation_transpose, P, F, &one, c->W.as<double>(), P, c->rhs.as<double>(), 1, &zero, c->tmpF.as<double>(), 1));
+            hipLaunchKernelGGL(lw_feature_back, dim3((F + 255) / 256), dim3(256), 0, h->stream, F, c->gf.as<double>(), c->tmpF.as<double>(), c->den.as<double>(), c->vec.as<double>());
+            HIPCHECK(h, hipMemcpyAsync(&y[P], c->vec.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHECK(h, hipMemcpyAsync(&y[0], c->rhs.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        for (int f = 0; f < F; f++) if (in->feature_const[f]) y[P + f] = 0.0;
+        for (double a : y) if (!std::isfinite(a)) return VILF_OK;
+        ok = true;
+        return VILF_OK;
+    };
+
+    // ---- trust-region loop (trust_region_minimizer.cc) with the traditional dogleg strategy (dogleg_strategy.cc)
+    const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+    double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_step_norm = 0;
+    bool reuse = false;
+    int iteration = 0, consecutive_invalid = 0, num_successful = 0, num_linear_solves = 0, termination = VILF_TERM_NO_CONVERGENCE;
+    auto vdotN = [&](const std::vector<double> &a, const std::vector<double> &b) { double s = 0; for (int i = 0; i < N; i++) s += a[i] * b[i]; return s; };
+    auto traditional = [&]() {
+        const double gradient_norm = std::sqrt(vdotN(gradient, gradient)), gn_norm = std::sqrt(vdotN(gn, gn));
+        if (gn_norm <= radius) { for (int i = 0; i < N; i++) step[i] = gn[i] / diagonal[i]; dogleg_step_norm = gn_norm; return; }
+        if (gradient_norm * alpha >= radius) { for (int i = 0; i < N; i++) step[i] = -(radius / gradient_norm) * gradient[i] / diagonal[i]; dogleg_step_norm = radius; return; }
+        const double b_dot_a = -alpha * vdotN(gradient, gn), a_sq = std::pow(alpha * gradient_norm, 2.0), bma = a_sq - 2 * b_dot_a + std::pow(gn_norm, 2);
+        const double cc = b_dot_a - a_sq, dd = std::sqrt(cc * cc + bma * (std::pow(radius, 2.0) - a_sq));
+        const double beta = (cc <= 0) ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
+        double nn = 0;
+        for (int i = 0; i < N; i++) { step[i] = (-alpha * (1.0 - beta)) * gradient[i] + beta * gn[i]; nn += step[i] * step[i]; }
+        dogleg_step_norm = std::sqrt(nn);
+        for (int i = 0; i < N; i++) step[i] /= diagonal[i];
+    };
+    int rc = eval_grad_jac();
+    if (rc != VILF_OK) return rc;
+    const double initial_cost = x_cost;
+    double x_norm = xnorm(x);
+    const int max_it = h->opts.max_num_iterations;
+    while (true) {
+        if (iteration >= max_it) { termination = VILF_TERM_NO_CONVERGENCE; break; }
+        if (gradient_max_norm <= gradient_tolerance) { termination = VILF_TERM_CONVERGENCE_GRADIENT; break; }
+        if (radius <= 1e-32) { termination = VILF_TERM_FAILURE; break; }
+        iteration++;
+        bool valid = true;
+        if (reuse) traditional();
+        else {
+            reuse = true;
+            for (int i = 0; i < N; i++) diagonal[i] = std::sqrt(std::min(std::max(diagH[i], min_lm_diagonal), max_lm_diagonal));
+            for (int i = 0; i < N; i++) gradient[i] = g[i] / diagonal[i];
+            for (int i = 0; i < N; i++) v[i] = gradient[i] / diagonal[i];
+            double Jg2;
+            if ((rc = quad(v, Jg2)) != VILF_OK) return rc;
+            alpha = vdotN(gradient, gradient) / Jg2;
+            bool ok = false;
+            while (mu < 1.0) {
+                for (int i = 0; i < N; i++) lm[i] = diagonal[i] * std::sqrt(mu);
+                num_linear_solves++;
+                if ((rc = linear_solve(ok)) != VILF_OK) return rc;
+                if (ok) break;
+                mu *= 10.0;
+            }
+            if (!ok) valid = false;
+            else { for (int i = 0; i < N; i++) gn[i] = y[i] * -diagonal[i]; traditional(); }
+        }
+        double model_cost_change = 0;
+        if (valid) {
+            double sHs;
+            if ((rc = quad(step, sHs)) != VILF_OK) return rc;
+            model_cost_change = -(vdotN(g, step) + 0.5 * sHs);
+            if (model_cost_change <= 0.0) valid = false;
+        }
+        if (!valid) {
+            consecutive_invalid++;
+            mu *= 10.0; reuse = false;                                   // step_is_invalid
+            if (consecutive_invalid >= 5) { termination = VILF_TERM_FAILURE; break; }
+            continue;
+        }
+        consecutive_invalid = 0;
+        for (int i = 0; i < N; i++) delta[i] = step[i] * scale[i];
+        plus(x, delta, cand);
+        double cand_cost;
+        if ((rc = evaluate(cand, false, cand_cost)) != VILF_OK) return rc;
+        double sn = 0;
+        for (int i = 0; i < 16 * NF; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
+        for (int f = 0; f < F; f++) if (!in->feature_const[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
+        if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = VILF_TERM_CONVERGENCE_PARAMETER; break; }
+        const double cost_change = x_cost - cand_cost;
+        if (std::fabs(cost_change) <= function_tolerance * x_cost) { termination = VILF_TERM_CONVERGENCE_FUNCTION; break; }
+        const double rd = cost_change / model_cost_change;
+        if (rd > min_relative_decrease) {
+            x = cand; x_norm = xnorm(x);
+            if ((rc = eval_grad_jac()) != VILF_OK) return rc;
+            num_successful++;
+            if (rd < 0.25) radius *= 0.5;                                // step_accepted
+            if (rd > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
+            mu = std::max(1e-8, 2.0 * mu / 10.0);
+            reuse = false;
+        } else { radius *= 0.5; reuse = true; }                          // step_rejected
+    }
+    // ---- outputs + double2vector (estimator.cpp:549-638)
+    if (out->para_pose) std::memcpy(out->para_pose, &x[0], 7 * NF * 8);
+    if (out->para_speed_bias) std::memcpy(out->para_speed_bias, &x[7 * NF], 9 * NF * 8);
+    if (out->para_feature) for (int f = 0; f < F; f++) out->para_feature[f] = x[16 * NF + f];
+    double R00[9], y0[3], y00[3], rot_diff[9];
+    h_q2R(&x[3], R00);
+    h_R2ypr(R0b, y0); h_R2ypr(R00, y00);
+    const double yd[3] = {y0[0] - y00[0], 0, 0};
+    h_ypr2R(yd, rot_diff);
+    if (std::fabs(std::fabs(y0[1]) - 90) < 1.0 || std::fabs(std::fabs(y00[1]) - 90) < 1.0)
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += R0b[3 * i + k] * R00[3 * j + k]; rot_diff[3 * i + j] = s; }
+    for (int i = 0; i < NF; i++) {
+        double Ri[9];
+        h_q2R(&x[7 * i + 3], Ri);
+        const double dp[3] = {x[7 * i] - x[0], x[7 * i + 1] - x[1], x[7 * i + 2] - x[2]};
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) { double s = 0; for (int k = 0; k < 3; k++) s += rot_diff[3 * a + k] * Ri[3 * k + b]; out->Rs[9 * i + 3 * a + b] = s; }
+            double sp = P0b[a], sv = 0;
+            for (int k = 0; k < 3; k++) { sp += rot_diff[3 * a + k] * dp[k]; sv += rot_diff[3 * a + k] * x[7 * NF + 9 * i + k]; }
+            out->Ps[3 * i + a] = sp; out->Vs[3 * i + a] = sv;
+            out->Bas[3 * i + a] = x[7 * NF + 9 * i + 3 + a]; out->Bgs[3 * i + a] = x[7 * NF + 9 * i + 6 + a];
+        }
+    }
+    for (int k = 0; k < 3; k++) out->tic[k] = in->para_ex_pose[k];
+    h_q2R(in->para_ex_pose + 3, out->ric);
+    out->td = in->para_td;
+    out->summary.num_iterations = iteration; out->summary.num_successful_steps = num_successful; out->summary.num_linear_solves = num_linear_solves;
+    out->summary.termination = termination; out->summary.initial_cost = initial_cost; out->summary.final_cost = x_cost; out->summary.final_radius = radius;
+    out->summary.usec_solve = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
+    return termination == VILF_TERM_FAILURE ? VILF_SOLVER_ABNORMAL : VILF_OK;
+}
