@@ -440,9 +440,12 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             int a = 0; while ((a + 1) * (a + 2) / 2 <= blk) a++;
             const int bb = blk - a * (a + 1) / 2;
             double s = 0;
-            if (a == bb) {
-                for (int i = 0; i < a; i++) s += PD(pair_index(i, a), e);
-                for (int j = a + 1; j < VB_NF; j++) s += PD(pair_index(a, j), 72 + e);
+            if (a == bb) {        // the 10 pairs of frame a: all loads first (a loop of dependent load -> add trips would wait for every load in turn), same order of additions
+                double v[VB_NF - 1];
+#pragma unroll
+                for (int k = 0; k < VB_NF - 1; k++) v[k] = (k < a) ? PD(pair_index(min(k, a - 1), a), e) : PD(pair_index(a, k + 1), 72 + e);
+#pragma unroll
+                for (int k = 0; k < VB_NF - 1; k++) s += v[k];
             } else s = PD(pair_index(bb, a), 36 + e);
             Hpp[t] = s;
         }
@@ -456,9 +459,17 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             if (f_const[f]) { hf[f] = 0; gf[f] = 0; continue; }
             const int n = f_nobs[f] - 1, f0 = f_fac0[f];
             double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int t = 0; t < n; t++) {
+            for (int t0 = 0; t0 < n; t0 += 4) {           // four factor records per trip in flight, added in factor order
+                double v[4][8];
 #pragma unroll
-                for (int c = 0; c < 8; c++) acc[c] += facw[(size_t)(f0 + t) * VB_FACW + c];
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) v[u][c] = facw[(size_t)(f0 + min(t0 + u, n - 1)) * VB_FACW + c];
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (t0 + u < n) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) acc[c] += v[u][c];
+                }
             }
             double *Wr = W + (size_t)f * VB_WLD;
 #pragma unroll
@@ -477,8 +488,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         const double *imug = b.imug + (size_t)w * 300, *lidg = b.lidg + (size_t)w * 120;
         double s = 0;
         if (l < 6) {
-            for (int i = 0; i < a; i++) s += PD(pair_index(i, a), 108 + l);
-            for (int j = a + 1; j < VB_NF; j++) s += PD(pair_index(a, j), 114 + l);
+            double v[VB_NF - 1];
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) v[k] = (k < a) ? PD(pair_index(min(k, a - 1), a), 108 + l) : PD(pair_index(a, k + 1), 114 + l);
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) s += v[k];
             if (a >= 1) s += lidg[12 * (a - 1) + 6 + l];
             if (a <= 9) s += lidg[12 * a + l];
         }
@@ -498,8 +512,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         const double *imuHg = b.imuH + (size_t)w * 9000, *lidHg = b.lidH + (size_t)w * 1440;
         double dg = 0;
         if (l < 6) {
-            for (int i = 0; i < a; i++) dg += PD(pair_index(i, a), 7 * l);
-            for (int j = a + 1; j < VB_NF; j++) dg += PD(pair_index(a, j), 72 + 7 * l);
+            double v[VB_NF - 1];
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) v[k] = (k < a) ? PD(pair_index(min(k, a - 1), a), 7 * l) : PD(pair_index(a, k + 1), 72 + 7 * l);
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) dg += v[k];
             if (a >= 1) dg += lidHg[144 * (a - 1) + 13 * (6 + l)];
             if (a <= 9) dg += lidHg[144 * a + 13 * l];
         }
