@@ -87,6 +87,75 @@ def _profile_order(path):
     return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
 
 
+def stress_main(args):
+    """BASELINE configs[4]: the 51-frame stress window through vilf_window_solve's general path; a step = one window solve per GPU (independent
+    windows per rank, no collective). Reports solver iterations/s and the fp64 MFMA roofline of the Schur SYRK (2 F P^2 flop per linear solve)."""
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
+    rehearse = os.environ.get("VILF_BENCH_REHEARSAL") == "1"
+    if rehearse:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    from vil_fusion_amd import synth
+    from vil_fusion_amd.estimator import BackendSolver
+    from vil_fusion_amd.lib import default_options
+    opts = default_options(); opts.window_size = 50
+    win, _, _ = synth.make_window(900 + rank, opts, synth.SynthConfig(n_frames=51, n_features=2500, with_prior=False))
+    solver = BackendSolver(opts, device=local_rank)
+    for _ in range(max(args.warmup, 1)):
+        res = solver.optimization(win)
+    solver.set_profiling(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter(); its = 0
+    for _ in range(args.steps):
+        res = solver.optimization(win); its += res.summary["num_iterations"]
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = solver.get_profile_large_window()
+    t = torch.tensor([dt, float(its)], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, its = float(tmax[0]), float(tsum[1])
+    if rank == 0:
+        P, F = 15 * 51, win.n_features
+        nfac = len(win.obs_point) - win.n_features
+        syrk = prof["lw_schur_syrk"]; flop = 2.0 * F * P * P
+        ach = flop * syrk["launches"] / max(syrk["ms"] * 1e-3, 1e-12) / 1e12 if syrk["launches"] else 0.0
+        out = {"metric": "sliding-window solve iters/sec (10 KF, ~5.5k factors) @1/2/4/8 GPU vs CPU", "value": its / dt, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "configs[4]: synthetic stress window, 51 frames (reduced system 765 x 765), one independent window per GPU and step", "frames": 51, "features": int(F),
+                          "visual_factors": int(nfac), "imu_factors": 50, "lidar_between_factors": 50, "max_iterations": int(opts.max_num_iterations), "parallelism": f"{world} x independent windows"},
+               "roofline": {"bound": "mfma", "kernel": "Schur reduce S -= Wn^T Wn (rocBLAS dsyrk, fp64 MFMA 16x16x4)", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
+                            "flop_per_launch": flop, "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
+                            "kernels_ms_per_solve": {k: v["ms"] / args.steps for k, v in prof.items()}},
+               "cpu_baseline": None}
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib
+            tc = time.perf_counter(); ref = oracle_lib.window_solve(opts, win, None); tc = time.perf_counter() - tc
+            out["cpu_baseline"] = {"value": ref.summary["num_iterations"] / tc, "unit": "iterations/s", "cores": 1, "kind": "port", "sample": "one stress window (%d iterations) through oracle/ (C++ -O3, one thread), %.2f s" % (ref.summary["num_iterations"], tc)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +169,10 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="run the LiDAR stage on its own handle / HIP stream / host thread, concurrently with the "
                     "window solve (like the reference's separate nodes); ~7 %% more frames/s, but per-kernel timings then include contention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stress", action="store_true", help="BASELINE configs[4] instead of the headline workload: one synthetic 51-frame / ~46 k-factor window per step and GPU")
     args = ap.parse_args()
+    if args.stress:
+        return stress_main(args)
 
     import numpy as np
     import torch

@@ -200,6 +200,8 @@ int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]);
 int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long launches_out[8]);
 /* same switch, marginalization kernels: 0 prepare (factor re-evaluation at the linearisation point), 1 Schur complement, 2 eigen + prior, 3 prior H/g */
 int vilf_get_profile_marginalize(vilf_handle *h, double ms_out[4], long launches_out[4]);
+/* the general (window_size != 10) path of vilf_window_solve: factor scatter (linearisations), Schur SYRK, Cholesky, unused */
+int vilf_get_profile_large_window(vilf_handle *h, double ms_out[4], long launches_out[4]);
 /* newest-frame pose per resident window: [stamp x y z qx qy qz qw] (8 doubles each) into a DEVICE buffer
  * (feeds the RCCL gather for global_fusion, poseGraphOptimization.cpp:116-121). */
 int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8);

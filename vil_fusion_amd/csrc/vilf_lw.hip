@@ -6,7 +6,8 @@
 //                                   corrector, J^T J / J^T r scattered with hardware fp64 atomics into the dense reduced blocks
 //                                   Hpp (P x P), W (F x P, one row per feature), h_f, g_f, g_p
 //   lw_scale, lw_schur_prep         Jacobi scaling; LM-regularised reduced system and the row-scaled W for the Schur product
-//   rocBLAS dsyrk / dgemv           S = Hpp' + mu D^2 - Wn^T Wn (the fp64 MFMA Schur reduce: 2 F P^2 = 2.9 GFLOP per solve), matrix-vector products
+//   lw_syrk_mfma                    S = Hpp' + mu D^2 - Wn^T Wn: the Schur reduce as a hand-written fp64 MFMA SYRK (2 F P^2 = 2.9 GFLOP per solve)
+//   rocBLAS dgemv                   matrix-vector products
 //   rocSOLVER dpotrf / dpotrs       dense Cholesky of the reduced system
 // and keeps the trust-region logic (Ceres 2.0 TrustRegionMinimizer + traditional dogleg + Jacobi scaling, the same restatement as
 // k_solve / k_step) on the host: per iteration only vectors of P + F doubles cross PCIe. No marginalization prior on this path.
@@ -26,12 +27,20 @@ extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, do
 struct LwCtx {
     rocblas_handle blas = nullptr;
     DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    double ms[4] = {0, 0, 0, 0};       // vilf_set_profiling: factor scatter, Schur SYRK, Cholesky (potrf + potrs), other device work
+    long launches[4] = {0, 0, 0, 0};
     void release() {
         DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den};
         for (DBuf *b : all) b->release();
         if (blas) { rocblas_destroy_handle(blas); blas = nullptr; }
     }
 };
+extern "C" int vilf_get_profile_large_window(vilf_handle *h, double ms_out[4], long launches_out[4]) {
+    if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 4; i++) { ms_out[i] = h->lw ? h->lw->ms[i] : 0.0; launches_out[i] = h->lw ? h->lw->launches[i] : 0; }
+    return VILF_OK;
+}
 void vilf_lw_release(vilf_handle *h) { if (h->lw) { h->lw->release(); delete h->lw; h->lw = nullptr; } }
 
 namespace {
@@ -153,6 +162,63 @@ __global__ void lw_feature_back(int F, const double *gf, const double *Wy, const
     if (f < F) yf[f] = (gf[f] - Wy[f]) / den[f];
 }
 
+// ---- the Schur reduce S -= Wn^T Wn as a hand-written fp64 MFMA SYRK ------------------------------------------------------------------
+// Wn is F x P row-major (one row per feature, already scaled by 1 / sqrt(h_f')). One workgroup per 64 x 64 output tile of the lower
+// triangle and per K split; four waves, each a 32 x 32 sub-tile = 2 x 2 v_mfma_f64_16x16x4_f64 accumulators; the two K x 64 panels of
+// Wn stream through LDS 16 feature rows at a time (coalesced 512-byte rows, padded row stride against bank conflicts). The K splits
+// (so that 78 tiles fill 256 CUs) and the mirrored tile are combined with hardware fp64 atomics on S, which already holds Hpp' + mu D^2.
+#define SY_KB 16
+#define SY_LD 65
+typedef double lw_double4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *Wn, double *S, int ksplit) {
+    __shared__ double sA[SY_KB * SY_LD], sB[SY_KB * SY_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
+    const int tj = blockIdx.x - ti * (ti + 1) / 2, i0 = 64 * ti, j0 = 64 * tj;
+    const int kchunk = ((F + ksplit - 1) / ksplit + SY_KB - 1) / SY_KB * SY_KB, kb = blockIdx.y * kchunk, ke = min(F, kb + kchunk);
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    lw_double4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = lw_double4{0, 0, 0, 0};
+    for (int k0 = kb; k0 < ke; k0 += SY_KB) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = tid + 256 * u, kk = e >> 6, cc = e & 63, k = k0 + kk;
+            const bool kin = k < ke;
+            sA[kk * SY_LD + cc] = (kin && i0 + cc < P) ? Wn[(size_t)k * P + i0 + cc] : 0.0;
+            sB[kk * SY_LD + cc] = (kin && j0 + cc < P) ? Wn[(size_t)k * P + j0 + cc] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < SY_KB / 4; s4++) {
+            double av[2], bv[2];
+            const int kr = (4 * s4 + (lane >> 4)) * SY_LD + (lane & 15);
+#pragma unroll
+            for (int a = 0; a < 2; a++) { av[a] = sA[kr + wi + 16 * a]; bv[a] = sB[kr + wj + 16 * a]; }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = i0 + wi + 16 * a + (lane >> 4) + 4 * q, col = j0 + wj + 16 * b + (lane & 15);
+                if (row < P && col < P) {
+                    unsafeAtomicAdd(S + (size_t)row * P + col, -acc[a][b][q]);
+                    if (ti != tj) unsafeAtomicAdd(S + (size_t)col * P + row, -acc[a][b][q]);
+                }
+            }
+}
+
 // ---- host-side manifold helpers (PoseLocalParameterization, utility.h) ------------------------------------------------------------
 struct HQ { double x, y, z, w; };
 inline HQ hq_mul(const HQ &a, const HQ &b) { return HQ{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z}; }
@@ -198,6 +264,10 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     if (!h->lw) h->lw = new LwCtx();
     LwCtx *c = h->lw;
     if (!c->blas) { if (rocblas_create_handle(&c->blas) != rocblas_status_success) { h->err = "rocblas_create_handle failed"; return VILF_ERR_DEVICE; } rocblas_set_stream(c->blas, h->stream); }
+    const bool prof = h->profiling != 0;
+    if (prof && !c->ev[0]) { hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); }
+    auto tic = [&]() { if (prof) hipEventRecord(c->ev[0], h->stream); };
+    auto toc = [&](int grp) { if (prof) { hipEventRecord(c->ev[1], h->stream); hipEventSynchronize(c->ev[1]); float t = 0; hipEventElapsedTime(&t, c->ev[0], c->ev[1]); c->ms[grp] += t; c->launches[grp] += 1; } };
     // ---- pack the factors
     std::vector<LwVis> vis;
     for (int f = 0; f < F; f++) {
@@ -279,10 +349,12 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             HIPCHECK(h, hipMemsetAsync(c->Hpp.p, 0, sP * sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->W.p, 0, sF * sP * 8, h->stream));
             HIPCHECK(h, hipMemsetAsync(c->hf.p, 0, sF * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gp.p, 0, sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gf.p, 0, sF * 8, h->stream));
         }
+        if (jac) tic();
         if (nvis) hipLaunchKernelGGL(lw_visual, dim3((nvis + 255) / 256), dim3(256), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->ex.as<double>(), NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
                                      c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
         hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
                            c->Hpp.as<double>(), c->gp.as<double>(), scal);
+        if (jac) toc(0);
         HIPCHECK(h, hipGetLastError());
         HIPCHECK(h, hipMemcpyAsync(&cost, scal, 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -346,16 +418,23 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         HIPCHECK(h, hipMemcpyAsync(c->rhs.p, c->gp.p, sP * 8, hipMemcpyDeviceToDevice, h->stream));
         if (F) {
             // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P == column-major P x F), rhs -= Wn^T (g_f / sqrt(den))
-            RB(rocblas_dsyrk(c->blas, rocblas_fill_lower, rocblas_operation_none, P, F, &mone, c->Wn.as<double>(), P, &one, c->S.as<double>(), P));
+            tic();
+            {
+                const int nt = (P + 63) / 64, ksplit = 4;
+                hipLaunchKernelGGL(lw_syrk_mfma, dim3(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, P, F, c->Wn.as<double>(), c->S.as<double>(), ksplit);
+            }
+            toc(1);
             RB(rocblas_dgemv(c->blas, rocblas_operation_none, P, F, &mone, c->Wn.as<double>(), P, c->tmpF.as<double>(), 1, &one, c->rhs.as<double>(), 1));
         }
         rocblas_int *dinfo = c->info.as<rocblas_int>();
+        tic();
         RB(rocsolver_dpotrf(c->blas, rocblas_fill_lower, P, c->S.as<double>(), P, dinfo));
         int info = 0;
         HIPCHECK(h, hipMemcpyAsync(&info, dinfo, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
         RB(rocsolver_dpotrs(c->blas, rocblas_fill_lower, P, 1, c->S.as<double>(), P, c->rhs.as<double>(), P));
+        toc(2);
         if (F) {
             const double zero = 0.0;
             RB(rocblas_dgemv(c->blas, rocblas_operation_transpose, P, F, &one, c->W.as<double>(), P, c->rhs.as<double>(), 1, &zero, c->tmpF.as<double>(), 1));

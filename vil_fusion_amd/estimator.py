@@ -110,6 +110,11 @@ class BackendSolver:
         self._check(self._L.vilf_get_profile_marginalize(self._h, ms, n), "vilf_get_profile_marginalize")
         return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(("k_marg_prepare", "k_marg_schur", "k_marg_finish", "k_prior_prep"))}
 
+    def get_profile_large_window(self):
+        ms = (C.c_double * 4)(); n = (C.c_long * 4)()
+        self._check(self._L.vilf_get_profile_large_window(self._h, ms, n), "vilf_get_profile_large_window")
+        return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(("lw_factor_scatter", "lw_schur_syrk", "lw_cholesky", "lw_other"))}
+
     def batch_marginalize(self, sync=True):
         self._check(self._L.vilf_batch_marginalize(self._h, 1 if sync else 0), "vilf_batch_marginalize")
 
