@@ -51,13 +51,23 @@ struct LwVis { double pi[3], pj[3]; int f, i, j, cst; };     // one ProjectionFa
 __device__ __forceinline__ void add(double *p, double v) { unsafeAtomicAdd(p, v); }
 
 // x layout: pose[NF][7] | sb[NF][9] | feat[F]
-__global__ void lw_visual(int n, const LwVis *vis, const double *x, const double *ex, int NF, int F, double sqrt_info, double cauchy_b, int jac,
-                          double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// The factors arrive sorted by frame pair (i, j). A workgroup takes LW_CH consecutive factors: every lane evaluates one and parks its
+// corrected 2 x 12 Jacobian and residual in LDS; then, per run of equal pairs inside the chunk (a handful), 156 lanes each own one entry of
+// the pair's 12 x 12 block / 12-vector, sum it over the run from LDS and issue ONE atomic per entry — instead of 156 atomics per factor on
+// the same few hundred addresses (the 51 diagonal pose blocks collect ~2 k factors each). The per-feature terms keep their per-factor atomics
+// (a feature's ~20 factors spread over many workgroups).
+#define LW_CH 128
+__global__ __launch_bounds__(LW_CH) void lw_visual(int n, const LwVis *vis, const double *x, const double *ex, int NF, int F, double sqrt_info, double cauchy_b, int jac,
+                                                     double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost) {
+    __shared__ double s_J[LW_CH][26];                 // 24 Jacobian entries (row 0: 12, row 1: 12), r0, r1
+    __shared__ int s_pair[LW_CH + 1];
+    const int tid = threadIdx.x, t = blockIdx.x * LW_CH + tid;
+    const int P = 15 * NF;
     double c = 0;
+    int pr = -1;
     if (t < n) {
         const LwVis v = vis[t];
-        const int P = 15 * NF;
+        pr = v.i * NF + v.j;
         const double *pi = x + 7 * v.i, *pj = x + 7 * v.j;
         double Ri[9], Rj[9], ric[9];
         q_toR(q_load(pi + 3), Ri); q_toR(q_load(pj + 3), Rj); q_toR(q_load(ex + 3), ric);
@@ -70,25 +80,50 @@ __global__ void lw_visual(int n, const LwVis *vis, const double *x, const double
         c = 0.5 * rho0;
         if (jac) {
             const int ci = 15 * v.i, cj = 15 * v.j;
-            double J[2][12];
-            for (int k = 0; k < 6; k++) { J[0][k] = sw * Ji[k]; J[1][k] = sw * Ji[6 + k]; J[0][6 + k] = sw * Jj[k]; J[1][6 + k] = sw * Jj[6 + k]; }
+            double J0[12], J1[12];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { J0[k] = sw * Ji[k]; J1[k] = sw * Ji[6 + k]; J0[6 + k] = sw * Jj[k]; J1[6 + k] = sw * Jj[6 + k]; }
             const double r0 = sw * r[0], r1 = sw * r[1];
-            for (int a = 0; a < 12; a++) {
-                const int ca = (a < 6 ? ci + a : cj + a - 6);
-                add(gp + ca, J[0][a] * r0 + J[1][a] * r1);
-                for (int b = 0; b < 12; b++) { const int cb = (b < 6 ? ci + b : cj + b - 6); add(Hpp + (size_t)ca * P + cb, J[0][a] * J[0][b] + J[1][a] * J[1][b]); }
-            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) { s_J[tid][k] = J0[k]; s_J[tid][12 + k] = J1[k]; }
+            s_J[tid][24] = r0; s_J[tid][25] = r1;
             if (!v.cst) {
                 const double f0 = sw * Jf[0], f1 = sw * Jf[1];
                 add(hf + v.f, f0 * f0 + f1 * f1);
                 add(gf + v.f, f0 * r0 + f1 * r1);
-                for (int a = 0; a < 12; a++) add(W + (size_t)v.f * P + (a < 6 ? ci + a : cj + a - 6), J[0][a] * f0 + J[1][a] * f1);
+#pragma unroll
+                for (int a = 0; a < 12; a++) add(W + (size_t)v.f * P + (a < 6 ? ci + a : cj + a - 6), J0[a] * f0 + J1[a] * f1);
             }
+        }
+    }
+    if (jac) {
+        s_pair[tid] = pr;
+        if (tid == 0) s_pair[LW_CH] = -2;
+        __syncthreads();
+        const int cnt = min(LW_CH, n - blockIdx.x * LW_CH);
+        for (int b0 = 0; b0 < cnt;) {                 // runs of equal pairs (uniform loop: every lane walks the same run boundaries)
+            const int pp = s_pair[b0];
+            int b1 = b0 + 1;
+            while (b1 < cnt && s_pair[b1] == pp) b1++;
+            const int fi = pp / NF, fj = pp - fi * NF, ci = 15 * fi, cj = 15 * fj;
+            for (int e = tid; e < 156; e += LW_CH) {
+                double sum = 0;
+                if (e < 144) {
+                    const int a = e / 12, b = e - 12 * a;
+                    for (int q = b0; q < b1; q++) sum += s_J[q][a] * s_J[q][b] + s_J[q][12 + a] * s_J[q][12 + b];
+                    add(Hpp + (size_t)(a < 6 ? ci + a : cj + a - 6) * P + (b < 6 ? ci + b : cj + b - 6), sum);
+                } else {
+                    const int a = e - 144;
+                    for (int q = b0; q < b1; q++) sum += s_J[q][a] * s_J[q][24] + s_J[q][12 + a] * s_J[q][25];
+                    add(gp + (a < 6 ? ci + a : cj + a - 6), sum);
+                }
+            }
+            b0 = b1;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0 && c != 0.0) add(cost, c);
+    if ((tid & 63) == 0 && c != 0.0) add(cost, c);
 }
 // IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair
 __global__ void lw_imu_lidar(int NF, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
@@ -280,6 +315,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             vis.push_back(v);
         }
     }
+    std::stable_sort(vis.begin(), vis.end(), [NF](const LwVis &a, const LwVis &b) { return a.i * NF + a.j < b.i * NF + b.j; });   // pair-sorted: lw_visual flushes one block per run of equal pairs
     const int nvis = (int)vis.size(), nimu = NF - 1;
     std::vector<double> imu((size_t)nimu * IMU_REC, 0.0), cov((size_t)nimu * 225), lid((size_t)nimu * 7, 0.0);
     for (int k = 0; k < nimu; k++) {
@@ -350,7 +386,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             HIPCHECK(h, hipMemsetAsync(c->hf.p, 0, sF * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gp.p, 0, sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gf.p, 0, sF * 8, h->stream));
         }
         if (jac) tic();
-        if (nvis) hipLaunchKernelGGL(lw_visual, dim3((nvis + 255) / 256), dim3(256), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->ex.as<double>(), NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
+        if (nvis) hipLaunchKernelGGL(lw_visual, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->ex.as<double>(), NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
                                      c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
         hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
                            c->Hpp.as<double>(), c->gp.as<double>(), scal);
