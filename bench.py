@@ -145,7 +145,7 @@ def stress_main(args):
                             "flop_per_launch": flop, "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
                             "kernels_ms_per_solve": {k: v["ms"] / args.steps for k, v in prof.items()}},
                "cpu_baseline": None}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
             tc = time.perf_counter(); ref = oracle_lib.window_solve(opts, win, None); tc = time.perf_counter() - tc
