@@ -395,3 +395,28 @@ def test_large_window_solve_matches_oracle(oracle, n_frames, n_features, tol):
     assert abs(got.summary["final_cost"] - ref.summary["final_cost"]) <= 1e-6 * ref.summary["final_cost"]
     assert np.abs(got.Ps - ref.Ps).max() < tol and np.abs(got.Rs - ref.Rs).max() < tol and np.abs(got.Vs - ref.Vs).max() < 10 * tol
     assert np.abs(1.0 / got.para_feature - 1.0 / ref.para_feature).max() < 1e-4
+
+
+def test_error_behaviour_of_the_newer_entry_points(solver, oracle, opts):
+    """loud failures instead of silent fall-backs: a pose graph without a complete odometry chain, an edge to a missing node, a non-positive
+    sigma; a window whose frame count does not match options.window_size; a batched call with a non-11-frame window"""
+    from vil_fusion_amd.estimator import posegraph_optimize
+    from vil_fusion_amd.lib import VilfError
+    from vil_fusion_amd import posegraph
+    truth, x0, edges = posegraph.make_synthetic_graph(1, 8)
+    ps = np.full(6, 1e-6)
+    with pytest.raises(VilfError, match="no odometry edge"):
+        posegraph_optimize(solver, x0, ps, edges[:3] + edges[4:])
+    bad = list(edges); i, j, q, t, sg, rb = bad[0]; bad[0] = (i, 99, q, t, sg, rb)
+    with pytest.raises(VilfError, match="out of range"):
+        posegraph_optimize(solver, x0, ps, bad)
+    bad = list(edges); bad[1] = (bad[1][0], bad[1][1], bad[1][2], bad[1][3], np.array([1e-3, 1e-3, 0.0, 1e-2, 1e-2, 1e-2]), 0)
+    with pytest.raises(VilfError, match="sigma"):
+        posegraph_optimize(solver, x0, ps, bad)
+    # 21-frame window handed to a handle configured for the reference's WINDOW_SIZE = 10
+    o21 = oracle.default_options(); o21.window_size = 20
+    win21, _, _ = synth.make_window(3, o21, synth.SynthConfig(n_frames=21, n_features=60, with_prior=False))
+    with pytest.raises(VilfError, match="window_size"):
+        solver.optimization(win21)
+    with pytest.raises(VilfError):
+        solver.batch_upload([win21], [None])
