@@ -381,17 +381,21 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
     float4 *s_tq = (cap * 2 >= 2 * SV_T * 16) ? reinterpret_cast<float4 *>(dst) : reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(s_cnt) + 8192);
     unsigned int *s_tk = reinterpret_cast<unsigned int *>(s_cnt);
     int carry = 0;
+    float4 qn[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) qn[u] = p[src[min(u * SV_T + tid, n - 1)]];
     for (int t0 = 0; t0 < n; t0 += 2 * SV_T) {
         int head[2], incl[2];
         unsigned int key[2];
         float4 q0[2];
         const int tile_n = min(2 * SV_T, n - t0);
 #pragma unroll
+        for (int u = 0; u < 2; u++) { q0[u] = qn[u]; qn[u] = p[src[min(t0 + 2 * SV_T + u * SV_T + tid, n - 1)]]; }     // the next tile's gathers are in flight during this tile
+#pragma unroll
         for (int u = 0; u < 2; u++) {
             const int j = t0 + u * SV_T + tid, jc = min(j, n - 1);
             const unsigned short idx = src[jc];
             key[u] = key_at(idx);
-            q0[u] = p[idx];
             head[u] = (j < n && (j == 0 || key_at(src[max(jc - 1, 0)]) != key[u])) ? 1 : 0;
             incl[u] = head[u];
 #pragma unroll
