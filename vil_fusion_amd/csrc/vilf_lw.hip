@@ -26,12 +26,12 @@ extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, do
 
 struct LwCtx {
     rocblas_handle blas = nullptr;
-    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den;
+    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den, jscr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     double ms[4] = {0, 0, 0, 0};       // vilf_set_profiling: factor scatter, Schur SYRK, Cholesky (potrf + potrs), other device work
     long launches[4] = {0, 0, 0, 0};
     void release() {
-        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den};
+        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr};
         for (DBuf *b : all) b->release();
         if (blas) { rocblas_destroy_handle(blas); blas = nullptr; }
     }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(int n, const LwVis *vis, cons
 }
 // IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair
 __global__ void lw_imu_lidar(int NF, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
-                             double *Hpp, double *gp, double *cost) {
+                             double *Hpp, double *gp, double *cost, double *jscr) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= NF - 1) return;
     const int P = 15 * NF, c0 = 15 * k;
@@ -145,14 +145,11 @@ __global__ void lw_imu_lidar(int NF, const double *x, const double *imu_rec, con
                 for (int a = 0; a < 15; a++) { double s = 0; for (int m = a; m < 15; m++) s += S[15 * a + m] * Jr[30 * m + col]; jw[a] = s; }
                 for (int a = 0; a < 15; a++) Jr[30 * a + col] = jw[a];   // rows a >= ... of this column are final: columns are processed left to right and
             }                                                            // S is applied to a whole column at once (reads rows m >= a of the raw column only)
-            for (int a = 0; a < 30; a++) {
-                double s = 0;
-                for (int m = 0; m < 15; m++) s += Jr[30 * m + a] * rw[m];
-                add(gp + c0 + a, s);
-                for (int b = 0; b < 30; b++) { double h = 0; for (int m = 0; m < 15; m++) h += Jr[30 * m + a] * Jr[30 * m + b]; add(Hpp + (size_t)(c0 + a) * P + c0 + b, h); }
-            }
+            double *jo = jscr + (size_t)k * 480;             // weighted Jacobian (15 x 30) and residual (15) for lw_imu_products
+            for (int e = 0; e < 450; e++) jo[e] = Jr[e];
+            for (int e = 0; e < 15; e++) jo[450 + e] = rw[e];
         }
-    }
+    } else if (jac) { double *jo = jscr + (size_t)k * 480; for (int e = 0; e < 465; e++) jo[e] = 0.0; }
     if (use_lidar) {
         double r[6], Ji[36], Jj[36];
         const double *lc = lid + 7 * (size_t)k;
@@ -175,6 +172,17 @@ __global__ void lw_imu_lidar(int NF, const double *x, const double *imu_rec, con
         }
     }
     add(cost, c);
+}
+// J^T [J r] of every IMU factor: one lane per (factor, row a, column b <= 30): 15-term dot products, one atomic each
+__global__ void lw_imu_products(int NF, const double *jscr, double *Hpp, double *gp) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, k = t / 930, e = t - 930 * k;
+    if (k >= NF - 1) return;
+    const int a = e / 31, b = e - 31 * a, P = 15 * NF, c0 = 15 * k;
+    const double *J = jscr + (size_t)k * 480;
+    double s = 0;
+    for (int m = 0; m < 15; m++) s += J[30 * m + a] * (b < 30 ? J[30 * m + b] : J[450 + m]);
+    if (s == 0.0) return;
+    if (b < 30) add(Hpp + (size_t)(c0 + a) * P + c0 + b, s); else add(gp + c0 + a, s);
 }
 // Jacobi scaling in place: Hpp(i, j) *= s_i s_j, W(f, c) *= s_f s_c, h_f *= s_f^2, g *= s. s = [P pose/speed-bias entries | F features]
 __global__ void lw_scale(int P, int F, const double *s, double *Hpp, double *W, double *hf, double *gp, double *gf) {
@@ -348,7 +356,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     if (!c->x.ensure((16 * (size_t)NF + sF) * 8) || !c->ex.ensure(7 * 8 + 64) || !c->vis.ensure(std::max<size_t>(nvis, 1) * sizeof(LwVis)) || !c->imu.ensure(imu.size() * 8) || !c->cov.ensure(cov.size() * 8) ||
         !c->lid.ensure(lid.size() * 8) || !c->Hpp.ensure(sP * sP * 8) || !c->W.ensure(sF * sP * 8) || !c->hf.ensure(sF * 8) || !c->gp.ensure(sP * 8) || !c->gf.ensure(sF * 8) || !c->S.ensure(sP * sP * 8) ||
         !c->Wn.ensure(sF * sP * 8) || !c->rhs.ensure(sP * 8) || !c->tmpP.ensure(sP * 8) || !c->tmpF.ensure(sF * 8) || !c->vec.ensure(2 * sN * 8) || !c->scal.ensure(256) || !c->info.ensure(64) ||
-        !c->fconst.ensure(sF) || !c->den.ensure(sF * 8)) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
+        !c->fconst.ensure(sF) || !c->den.ensure(sF * 8) || !c->jscr.ensure((size_t)nimu * 480 * 8)) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
     double geo[7 + 3 + 4];
     for (int k = 0; k < 4; k++) geo[k] = qil[k];
     for (int k = 0; k < 3; k++) geo[4 + k] = til[k];
@@ -389,7 +397,8 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         if (nvis) hipLaunchKernelGGL(lw_visual, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->ex.as<double>(), NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
                                      c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
         hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
-                           c->Hpp.as<double>(), c->gp.as<double>(), scal);
+                           c->Hpp.as<double>(), c->gp.as<double>(), scal, c->jscr.as<double>());
+        if (jac) hipLaunchKernelGGL(lw_imu_products, dim3((nimu * 930 + 255) / 256), dim3(256), 0, h->stream, NF, c->jscr.as<double>(), c->Hpp.as<double>(), c->gp.as<double>());
         if (jac) toc(0);
         HIPCHECK(h, hipGetLastError());
         HIPCHECK(h, hipMemcpyAsync(&cost, scal, 8, hipMemcpyDeviceToHost, h->stream));
