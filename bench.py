@@ -141,7 +141,7 @@ def stress_main(args):
                "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": "configs[4]: synthetic stress window, 51 frames (reduced system 765 x 765), one independent window per GPU and step", "frames": 51, "features": int(F),
                           "visual_factors": int(nfac), "imu_factors": 50, "lidar_between_factors": 50, "max_iterations": int(opts.max_num_iterations), "parallelism": f"{world} x independent windows"},
-               "roofline": {"bound": "mfma", "kernel": "Schur reduce S -= Wn^T Wn (rocBLAS dsyrk, fp64 MFMA 16x16x4)", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
+               "roofline": {"bound": "mfma", "kernel": "lw_syrk_mfma: Schur reduce S -= Wn^T Wn (hand-written fp64 MFMA 16x16x4 SYRK)", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6, "traffic": None,
                             "flop_per_launch": flop, "avg_launch_ms": syrk["ms"] / max(syrk["launches"], 1),
                             "kernels_ms_per_solve": {k: v["ms"] / args.steps for k, v in prof.items()}},
                "cpu_baseline": None}
