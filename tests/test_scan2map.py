@@ -254,3 +254,22 @@ def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
             assert np.array_equal(b.getMapCloud(i, 0), refs[i].get_map(0))
     assert got[0].map_surf_size > (8192 if n_scan > 20000 and leaf > 0.1 else 500)
     s.close()
+
+
+@pytest.mark.gpu
+def test_voxel_index_overflow_fails_loudly(oracle):
+    """a leaf so small that the scan's voxel index needs more than 32 bits (17 bits per axis here) must be reported, not silently mis-binned"""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
+    from vil_fusion_amd.lib import VilfError
+    o = oracle.default_options()
+    o.surf_leaf_size = 0.001
+    rng = np.random.default_rng(0)
+    cloud = lambda n, h: np.concatenate([rng.uniform(-h, h, (n, 3)), rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    s = BackendSolver(o)
+    b = Scan2MapBatch(s, 1, 64, 4096, 256, 20000)
+    b.localMapInited(0, cloud(5, 1.0), cloud(2000, 50.0), None, None)
+    b.set_scan(0, cloud(1, 1.0), cloud(3000, 60.0))
+    with pytest.raises(VilfError, match="voxel index"):
+        b.step()
+        b.results()
+    s.close()
