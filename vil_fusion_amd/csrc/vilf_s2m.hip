@@ -50,28 +50,16 @@ struct S2BRes {                       // per-stream result of one step (device)
 
 __device__ __forceinline__ int bits_of(long long v) { return v <= 0 ? 0 : 64 - __clzll(v); }
 // bits[0]: width of the largest leaf index (+1) over all streams; bits[1..3]: widths of the 1 m cell extents (inv == 1)
-// m_pre (optional): the first m_pre[s] points of stream s are expected to be in ascending leaf order already (the cropped old map);
-// bits[4] is raised if that does not hold for some stream or if its unsorted tail does not fit cap_tail -> the caller sorts everything.
-__global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits, const int *m_pre, int cap_tail) {
+__global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
     __shared__ float s[6][1024];
     const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
     const float4 *p = in.p + (size_t)sid * in.cap;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    const int m = m_pre ? m_pre[sid] : 0;
-    bool bad = m_pre && (m < 0 || m > n || n - m > cap_tail);
     for (int i = tid; i < n; i += blockDim.x) {
         const float4 q = p[i];
         mn[0] = fminf(mn[0], q.x); mn[1] = fminf(mn[1], q.y); mn[2] = fminf(mn[2], q.z);
         mx[0] = fmaxf(mx[0], q.x); mx[1] = fmaxf(mx[1], q.y); mx[2] = fmaxf(mx[2], q.z);
-        if (i > 0 && i < m) {              // leaf order is lexicographic in (z, y, x) leaf coordinates, whatever the min corner is
-            const float4 r = p[i - 1];
-            const float az = floorf(__fmul_rn(r.z, inv)), bz = floorf(__fmul_rn(q.z, inv));
-            const float ay = floorf(__fmul_rn(r.y, inv)), by = floorf(__fmul_rn(q.y, inv));
-            const float ax = floorf(__fmul_rn(r.x, inv)), bx = floorf(__fmul_rn(q.x, inv));
-            if (az > bz || (az == bz && (ay > by || (ay == by && ax > bx)))) bad = true;
-        }
     }
-    if (bad) atomicOr(bits + 4, 1);
     for (int k = 0; k < 3; k++) { s[k][tid] = mn[k]; s[3 + k][tid] = mx[k]; }
     __syncthreads();
     for (int st = blockDim.x / 2; st > 0; st >>= 1) {
@@ -179,53 +167,6 @@ __global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const KeyT *ke
     }
     if (t0 + S2B_VT >= n && tid == 0) out.n[sid] = carry + total;
 }
-// ---- map grids in steady state: the cropped old map is already in leaf order, only the appended points are not ------------
-// keys of the sorted prefix stay in place (index = position), the tail goes to a compact [S][cap_tail] array that is radix-sorted,
-// then ONE workgroup per stream merges the two runs (merge path, prefix first on equal keys = the stable order of a full sort).
-template <typename KeyT>
-__global__ void b_voxel_keys_split(CSet in, float inv, const MinMax *mm, const int *m_pre, KeyT *keys, KeyT *tkeys, int *tvals, int cap_tail, int vbits) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    const int n = in.n[sid], m = m_pre[sid];
-    const KeyT hi = (KeyT)((unsigned long long)sid << vbits);
-    if (i < n) {
-        const size_t g = (size_t)sid * in.cap + i;
-        const float4 q = in.p[g];
-        const MinMax *mmx = mm + sid;
-        const long long a = (long long)floorf(__fmul_rn(q.x, inv)) - mmx->minb[0], b = (long long)floorf(__fmul_rn(q.y, inv)) - mmx->minb[1], c = (long long)floorf(__fmul_rn(q.z, inv)) - mmx->minb[2];
-        const KeyT k = hi | (KeyT)(unsigned long long)(a + b * mmx->mul1 + c * mmx->mul2);
-        if (i < m) keys[g] = k;
-        else { tkeys[(size_t)sid * cap_tail + (i - m)] = k; tvals[(size_t)sid * cap_tail + (i - m)] = i; }
-    }
-    if (i < cap_tail && i >= n - m) { tkeys[(size_t)sid * cap_tail + i] = hi | (KeyT)((1ULL << vbits) - 1); tvals[(size_t)sid * cap_tail + i] = 0; }   // padding sorts last
-}
-// merge by ranking: the sorted tail B (a few thousand keys) is staged in LDS; every prefix element A[i] goes to i + #{B < A[i]},
-// every tail element B[j] to j + #{A <= B[j]} (prefix first on equal keys). Reads and writes stay coalesced.
-template <typename KeyT, bool B_IN_LDS>
-__global__ __launch_bounds__(S2B_VT) void b_voxel_merge(CSet in, const int *m_pre, const KeyT *keys_all, const KeyT *tkeys_all, const int *tvals_all, int cap_tail, KeyT *okeys_all, int *ovals_all) {
-    extern __shared__ unsigned long long s_raw[];
-    KeyT *s_B = reinterpret_cast<KeyT *>(s_raw);
-    const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid], m = m_pre[sid], nb = n - m;
-    const size_t base = (size_t)sid * in.cap;
-    const KeyT *A = keys_all + base, *Bg = tkeys_all + (size_t)sid * cap_tail;
-    const int *Bv = tvals_all + (size_t)sid * cap_tail;
-    KeyT *ok = okeys_all + base;
-    int *ov = ovals_all + base;
-    if (B_IN_LDS) { for (int j = tid; j < nb; j += S2B_VT) s_B[j] = Bg[j]; __syncthreads(); }
-    const KeyT *B = B_IN_LDS ? s_B : Bg;
-    for (int i = tid; i < m; i += S2B_VT) {
-        const KeyT k = A[i];
-        int lo = 0, hi = nb;                                   // #{B < k}
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (B[mid] < k) lo = mid + 1; else hi = mid; }
-        ok[i + lo] = k; ov[i + lo] = i;
-    }
-    for (int j = tid; j < nb; j += S2B_VT) {
-        const KeyT k = B[j];
-        int lo = 0, hi = m;                                    // #{A <= k}
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] <= k) lo = mid + 1; else hi = mid; }
-        ok[j + lo] = k; ov[j + lo] = Bv[j];
-    }
-}
-
 // Fused crop flags + scan + compaction (pcl::CropBox, order preserving): one workgroup per stream
 // m_out[s] = how many of the first n_old[s] points (the old map, before the append) survive the crop
 __global__ __launch_bounds__(S2B_VT) void b_crop_compact(CSet map, const double *pose_all, double half, CSet out, const int *n_old, int *m_out) {
@@ -1255,7 +1196,7 @@ struct S2B {
     int S = 0;
     int capScan[2] = {0, 0}, capMap[2] = {0, 0};
     DBuf scan[2], nScan[2], ds[2], nDs[2], map[2], mapAlt[2], nMap[2], tmpB, nTmp, sorted[2], bstart[2], bcnt;   // map: current local maps; mapAlt: where the next step writes its maps
-    DBuf tkeys, tkeys2, tvals, tvals2, nOld, mOld;      // steady-state map grids: the unsorted tails, old / surviving-old counts
+    DBuf nOld, mOld;                                     // map point counts before the append / surviving the crop (unsorted-map path)
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0, muT, tileHeads;
     int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
@@ -1272,7 +1213,7 @@ struct S2B {
     CSet cs_mapout(int w) { return CSet{mapAlt[w].as<float4>(), nMap[w].as<int>(), capMap[w]}; }
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &mapAlt[0], &mapAlt[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
-                       &bstart[0], &bstart[1], &bcnt, &tkeys, &tkeys2, &tvals, &tvals2, &nOld, &mOld, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
+                       &bstart[0], &bstart[1], &bcnt, &nOld, &mOld, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
                        &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads};
         for (DBuf *b : all) b->release();
     }
@@ -1319,8 +1260,6 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS32 * 8 + 8192));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS24 * 7 + 8192));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12));
-        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned int, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_voxel_merge<unsigned long long, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         c->h_res.assign(S, S2BRes{});
     }
@@ -1351,8 +1290,6 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         if (!c->tmpB.ensure((size_t)S * maxMap * 16)) return VILF_ERR_DEVICE;
         const size_t capq = (size_t)c->capScan[0] + c->capScan[1];
         if (!c->frec.ensure((size_t)S * capq * S2M_FREC * 8) || !c->fkind.ensure((size_t)S * capq * 4)) return VILF_ERR_DEVICE;
-        const size_t nt = (size_t)S * std::max(c->capScan[0], c->capScan[1]);
-        if (!c->tkeys.ensure(nt * 8) || !c->tkeys2.ensure(nt * 8) || !c->tvals.ensure(nt * 4) || !c->tvals2.ensure(nt * 4)) return VILF_ERR_DEVICE;
         if (n > c->work_n) {
             if (!c->keys.ensure(n * 8) || !c->keys2.ensure(n * 8) || !c->vals.ensure(n * 4) || !c->vals2.ensure(n * 4)) return VILF_ERR_DEVICE;
             size_t need = 0;
@@ -1368,25 +1305,14 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
 
 // pcl::VoxelGrid over every stream: in -> out (device counters)
 template <typename KeyT>
-static int s2b_voxel_typed(vilf_handle *h, S2B *c, CSet in, float inv, CSet out, int vbits, const int *m_pre, int cap_tail) {
+static int s2b_voxel_typed(vilf_handle *h, S2B *c, CSet in, float inv, CSet out, int vbits) {
     const int S = c->S, kbits = vbits + sbits_of(S);
     KeyT *k1 = c->keys.as<KeyT>(), *k2 = c->keys2.as<KeyT>();
     size_t tb = c->temp_bytes;
-    if (m_pre) {       // steady-state map grid: sort only the appended tail, merge it into the leaf-ordered prefix
-        KeyT *t1 = c->tkeys.as<KeyT>(), *t2 = c->tkeys2.as<KeyT>();
-        hipLaunchKernelGGL(b_voxel_keys_split<KeyT>, GRID2(std::max(in.cap, cap_tail), S), 0, h->stream, in, inv, c->mm.as<MinMax>(), m_pre, k1, t1, c->tvals.as<int>(), cap_tail, vbits);
-        PROF(0)
-        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, t1, t2, c->tvals.as<int>(), c->tvals2.as<int>(), (size_t)S * cap_tail, 0, kbits, h->stream));
-        PROF(1)
-        const size_t lds = (size_t)cap_tail * sizeof(KeyT);
-        if (lds <= 96 * 1024) hipLaunchKernelGGL((b_voxel_merge<KeyT, true>), dim3(S), dim3(S2B_VT), lds, h->stream, in, m_pre, k1, t2, c->tvals2.as<int>(), cap_tail, k2, c->vals2.as<int>());
-        else hipLaunchKernelGGL((b_voxel_merge<KeyT, false>), dim3(S), dim3(S2B_VT), 0, h->stream, in, m_pre, k1, t2, c->tvals2.as<int>(), cap_tail, k2, c->vals2.as<int>());
-    } else {
-        hipLaunchKernelGGL(b_voxel_keys<KeyT>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits);
-        PROF(0)
-        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
-        PROF(1)
-    }
+    hipLaunchKernelGGL(b_voxel_keys<KeyT>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits);
+    PROF(0)
+    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
+    PROF(1)
     const int ntiles = (in.cap + S2B_VT - 1) / S2B_VT;
     if (!c->tileHeads.ensure((size_t)S * ntiles * 4)) return VILF_ERR_DEVICE;
     hipLaunchKernelGGL(b_voxel_heads<KeyT>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, k2, c->tileHeads.as<int>(), ntiles);
@@ -1394,22 +1320,21 @@ static int s2b_voxel_typed(vilf_handle *h, S2B *c, CSet in, float inv, CSet out,
     PROF(0)
     return VILF_OK;
 }
-// pcl::VoxelGrid over every stream: in -> out (device counters). m_pre != NULL: the caller expects the first m_pre[s] points of
-// every stream to be in leaf order already and at most cap_tail points behind them (checked on the device; full sort otherwise)
-static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out, const int *m_pre = nullptr, int cap_tail = 0) {
+// pcl::VoxelGrid over every stream by ONE global sort: in -> out (device counters). The general path: scan clouds too large for the in-LDS
+// grid (b_scan_voxel) and local maps that are not voxel grids yet (b_map_update needs leaf order)
+static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
     const int S = c->S;
     const float inv = 1.0f / leaf;
     int hb[8];
     HIPCHECK(h, hipMemsetAsync(c->bits.p, 0, 32, h->stream));
-    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->bits.as<int>(), m_pre, cap_tail);
+    hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->bits.as<int>());
     HIPCHECK(h, hipMemcpyAsync(hb, c->bits.p, 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     const int vbits = std::max(hb[0], 1);
     if (vbits + sbits_of(S) > 63) { h->err = "scan2map: voxel index too wide (leaf size too small for the cloud extent)"; return VILF_ERR_UNSUPPORTED; }
     PROF(0)
-    if (hb[4]) m_pre = nullptr;
-    if (vbits + sbits_of(S) <= 32) return s2b_voxel_typed<unsigned int>(h, c, in, inv, out, vbits, m_pre, cap_tail);      // 32-bit keys: a third less sort traffic
-    return s2b_voxel_typed<unsigned long long>(h, c, in, inv, out, vbits, m_pre, cap_tail);
+    if (vbits + sbits_of(S) <= 32) return s2b_voxel_typed<unsigned int>(h, c, in, inv, out, vbits);      // 32-bit keys: a third less sort traffic
+    return s2b_voxel_typed<unsigned long long>(h, c, in, inv, out, vbits);
 }
 
 static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
