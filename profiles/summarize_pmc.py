@@ -16,7 +16,7 @@ GROUPS = {   # kernel-name prefix -> bench.py launch group
     "k_linearize": "k_linearize", "k_solve": "k_solve", "k_step": "k_step",
     "k_marg_prepare": "k_marg_prepare", "k_marg_schur": "k_marg_schur", "k_marg_finish": "k_marg_finish", "k_mf_": "k_marg_finish", "k_prior_prep": "k_prior_prep",
     "b_minmax": "s2m_voxel_grid", "b_voxel_keys": "s2m_voxel_grid", "void b_voxel_keys": "s2m_voxel_grid", "void b_voxel_reduce": "s2m_voxel_grid",
-    "void b_voxel_merge": "s2m_voxel_grid", "void b_voxel_keys_split": "s2m_voxel_grid", "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_voxel_grid",
+    "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_voxel_grid",
     "b_check_order": "s2m_voxel_grid", "void b_scan_voxel": "s2m_voxel_grid",
     "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
     "b_crop_compact": "s2m_submap", "b_transform_append": "s2m_submap", "b_bump": "s2m_submap",
