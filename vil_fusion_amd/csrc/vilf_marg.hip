@@ -451,13 +451,17 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                 for (int i = 0; i < md; i++) { double v = s_Y[i * XL + k]; for (int t = 0; t < i; t++) v -= s_S[i * md + t] * s_Y[t * XL + k]; s_Y[i * XL + k] = v / s_S[i * md + i]; }
             double tr = 0;
             for (int c = tid; c < md + mf; c += NT) {
-                double z[MG_MD];
+                double z[MG_MD];                                   // compile-time indices only (fully unrolled, guarded by md): the vector stays in registers
                 double sq = 0;
-                for (int i = 0; i < md; i++) {
-                    double v = (c < md) ? (i == c ? 1.0 : 0.0) : Wf[(size_t)(c - md) * MG_ND + i];
-                    for (int t = 0; t < i; t++) v -= s_S[i * md + t] * z[t];
-                    z[i] = v / s_S[i * md + i];
-                    sq += z[i] * z[i];
+#pragma unroll
+                for (int i = 0; i < MG_MD; i++) {
+                    if (i < md) {
+                        double v = (c < md) ? (i == c ? 1.0 : 0.0) : Wf[(size_t)(c - md) * MG_ND + i];
+#pragma unroll
+                        for (int t = 0; t < i; t++) v -= s_S[i * md + t] * z[t];
+                        z[i] = v / s_S[i * md + i];
+                        sq += z[i] * z[i];
+                    }
                 }
                 tr += (c < md) ? sq : s_ih[c - md] + sq * s_ih[c - md] * s_ih[c - md];
             }
