@@ -18,7 +18,8 @@
 
 extern "C" {
 __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec);
-__global__ void k_prior_prep(VbBatch b, double *prior_H, double *prior_g);
+__global__ void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsigned lds_bytes);
+#define VILF_PRIOR_PREP_LDS ((size_t)(MG_NK + 1) * (MG_NK + 1) * sizeof(double))     // the n x n prior Jacobian in LDS (n <= 96: 73.5 KB, two workgroups per CU)
 __global__ void k_linearize(VbBatch b, int iteration_zero);
 __global__ void k_solve(VbBatch b);
 __global__ void k_step(VbBatch b);
@@ -116,6 +117,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     h->marg_lds_finish = (size_t)(MG_NK + 2) * (MG_NK + 2) * sizeof(double);
     if (hipFuncSetAttribute((const void *)k_marg_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_schur) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_prior_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VILF_PRIOR_PREP_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * 64 * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
@@ -235,7 +237,7 @@ static int upload_priors(vilf_handle *h) {
             HIPCHECK(h, hipStreamSynchronize(h->stream));   // hd / x0 are stack buffers
         }
     }
-    hipLaunchKernelGGL(k_prior_prep, dim3(B), dim3(VB_NT), 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
+    hipLaunchKernelGGL(k_prior_prep, dim3(B), dim3(VB_NT), VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS);
     HIPCHECK(h, hipGetLastError());
     for (int w = 0; w < B; w++) h->prior_dirty[w] = 0;
     h->prior_slots_valid = std::max(h->prior_slots_valid, B);
@@ -691,7 +693,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, 1);
     hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, 1);
     if (prof) hipEventRecord(h->pev[3], h->stream);
-    hipLaunchKernelGGL(k_prior_prep, grid, block, 0, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>());
+    hipLaunchKernelGGL(k_prior_prep, grid, block, VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS);
     if (prof) hipEventRecord(h->pev[4], h->stream);
     HIPCHECK(h, hipGetLastError());
     if (prof) {

@@ -112,7 +112,7 @@ extern "C" __global__ __launch_bounds__(64) void k_imu_prep(int n, const double 
     if (row) { double *S = imu_rec + (size_t)id * IMU_REC + IMU_SQRT; for (int j = 0; j < 15; j++) S[15 * r + j] = (j >= r) ? sI[grp][j][r] : 0.0; }
 }
 
-extern "C" __global__ __launch_bounds__(NT) void k_prior_prep(VbBatch b, double *prior_H, double *prior_g) {
+extern "C" __global__ __launch_bounds__(NT) void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsigned lds_bytes) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
     if (!hdr[0]) return;
@@ -121,6 +121,25 @@ extern "C" __global__ __launch_bounds__(NT) void k_prior_prep(VbBatch b, double 
     const double *r = b.prior_r + (size_t)w * VB_PRIOR_LD;
     double *H = prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
     double *g = prior_g + (size_t)w * VB_PRIOR_LD;
+    // J (n x n) staged in LDS once: every entry of H = J^T J reads two of its columns (2 n reads per entry from L2 otherwise); same order of additions
+    extern __shared__ double s_J[];
+    const int ld = n | 1;
+    if ((size_t)n * ld * sizeof(double) <= lds_bytes) {
+        for (int e = tid; e < n * n; e += NT) { const int k = e / n, i = e - k * n; s_J[k * ld + i] = J[e]; }
+        __syncthreads();
+        for (int e = tid; e < n * n; e += NT) {
+            int i = e / n, j = e - i * n;
+            double s = 0;
+            for (int k = 0; k < n; k++) s += s_J[k * ld + i] * s_J[k * ld + j];
+            H[i * VB_PRIOR_LD + j] = s;
+        }
+        for (int i = tid; i < n; i += NT) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += s_J[k * ld + i] * r[k];
+            g[i] = s;
+        }
+        return;
+    }
     for (int e = tid; e < n * n; e += NT) {
         int i = e / n, j = e - i * n;
         double s = 0;
