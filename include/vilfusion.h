@@ -103,7 +103,12 @@ typedef struct vilf_lidar_constraint {
 /* One window ≙ the members optimization() reads (estimator.h:70-146). */
 typedef struct vilf_window_in {
     int n_frames;                         /* options.window_size + 1. 11 = the reference's WINDOW_SIZE: batched LDS kernels; any other size: the general
-                                             single-window path (vilf_window_solve only; no prior, no marginalization) — BASELINE configs[4] */
+                                             single-window path (vilf_window_solve only; no prior, no marginalization) — BASELINE configs[4].
+                                             options.estimate_extrinsic / estimate_td (para_ex_pose / para_td become variables; obs_velocity,
+                                             obs_cur_td, obs_row required for td): vilf_window_solve only, through the same general path, at any
+                                             window size; an 11-frame window keeps its prior and vilf_window_marginalize() (estimate_extrinsic;
+                                             with estimate_td the marginalization returns VILF_ERR_UNSUPPORTED). The batched calls return
+                                             VILF_ERR_UNSUPPORTED when either option is set. */
     const double *para_pose;              /* [n_frames][7] */
     const double *para_speed_bias;        /* [n_frames][9] */
     double para_ex_pose[7];
@@ -217,7 +222,8 @@ int vilf_prior_import(vilf_handle *h, int slot, const vilf_prior *prior);
 int vilf_eval_projection(vilf_handle *h, const double *const *parameters, const double pts_i[3],
                          const double pts_j[3], double *residuals, double **jacobians);   /* projection_factor.cpp:21 */
 /* ProjectionTdFactor (5 blocks: Pose_i, Pose_j, Ex_Pose, inverse depth, td); row_* = uv.y of the two observations, TR / ROW from the options.
- * Factor-level only: the device solve does not estimate td / the extrinsic (estimate_td, estimate_extrinsic -> VILF_ERR_UNSUPPORTED). */
+ * In the solve: options.estimate_td = 1 makes vilf_window_solve use this factor for every visual observation and td a variable
+ * (estimator.cpp:713-717, 765-777); see vilf_window_solve. */
 int vilf_eval_projection_td(vilf_handle *h, const double *const *parameters, const double pts_i[3], const double pts_j[3],
                             const double velocity_i[2], const double velocity_j[2], double td_i, double td_j, double row_i, double row_j,
                             double *residuals, double **jacobians);                          /* projection_td_factor.cpp:34 */

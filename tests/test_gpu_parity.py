@@ -420,3 +420,107 @@ def test_error_behaviour_of_the_newer_entry_points(solver, oracle, opts):
         solver.optimization(win21)
     with pytest.raises(VilfError):
         solver.batch_upload([win21], [None])
+
+
+def _with_td_inputs(win, seed, td_true=0.004):
+    """ProjectionTdFactor inputs for a synthetic window: pixel velocities on the normalised plane, zero per-observation td, image rows;
+    the observations are shifted as a camera running `td_true` seconds late would have seen them."""
+    rng = np.random.default_rng(seed)
+    vel = rng.normal(0.0, 0.4, (win.n_obs, 2))
+    pts = win.obs_point.copy()
+    pts[:, :2] += td_true * vel
+    return abi.Window(win.para_pose, win.para_speed_bias, win.para_ex_pose, win.para_feature, win.feature_const, win.feature_start_frame,
+                      win.feature_obs_offset, pts, win.imu, win.lidar, para_td=0.0, marginalization_flag=win.marginalization_flag,
+                      obs_velocity=vel, obs_cur_td=np.zeros(win.n_obs), obs_row=rng.uniform(0.0, 370.0, win.n_obs))
+
+
+def _perturbed_extrinsic(win, seed):
+    rng = np.random.default_rng(seed)
+    ex = win.para_ex_pose.copy()
+    ex[:3] += rng.normal(0.0, 0.01, 3)
+    ex[3:] = synth.q_mul(ex[3:], synth.q_exp(rng.normal(0.0, np.deg2rad(0.3), 3)))
+    win.para_ex_pose = ex / np.concatenate([np.ones(3), np.full(4, np.linalg.norm(ex[3:]))])
+    return win
+
+
+@pytest.mark.parametrize("n_frames,est_ex,est_td,with_prior", [(11, 1, 0, True), (11, 0, 1, False), (11, 1, 1, False), (6, 1, 1, False)])
+def test_extrinsic_and_td_estimation_match_oracle(oracle, n_frames, est_ex, est_td, with_prior):
+    """estimate_extrinsic / estimate_td (estimator.cpp:701-717, 765-777; off in the KITTI configuration): Ex_Pose and td as variables of the
+    window solve, ProjectionTdFactor instead of ProjectionFactor — through vilf_window_solve's general single-window path, with the
+    marginalization prior for an 11-frame window. Against the oracle's solve of the same problem."""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    o.window_size = n_frames - 1
+    o.estimate_extrinsic, o.estimate_td = est_ex, est_td
+    cfg = synth.SynthConfig(n_frames=n_frames, n_features=120, with_prior=with_prior)
+    win, prior, _ = synth.make_window(70 + n_frames + est_td, o, cfg)
+    if est_td:
+        win = _with_td_inputs(win, 5)
+    if est_ex:
+        win = _perturbed_extrinsic(win, 6)
+    s = BackendSolver(o)
+    s.set_prior(prior if with_prior else None)
+    got = s.optimization(win)
+    ref = oracle.window_solve(o, win, prior if with_prior else None)
+    s.close()
+    assert got.summary["num_iterations"] == ref.summary["num_iterations"] and got.summary["num_successful_steps"] == ref.summary["num_successful_steps"]
+    assert abs(got.summary["initial_cost"] - ref.summary["initial_cost"]) <= 1e-9 * ref.summary["initial_cost"]
+    assert abs(got.summary["final_cost"] - ref.summary["final_cost"]) <= 1e-6 * ref.summary["final_cost"]
+    assert np.abs(got.Ps - ref.Ps).max() < 1e-6 and np.abs(got.Rs - ref.Rs).max() < 1e-7 and np.abs(got.Vs - ref.Vs).max() < 1e-5
+    assert np.abs(got.tic - ref.tic).max() < 1e-6 and np.abs(got.ric - ref.ric).max() < 1e-7 and abs(got.td - ref.td) < 1e-7
+    if est_ex:
+        assert np.abs(got.tic - win.para_ex_pose[:3]).max() > 1e-5, "the extrinsic must have moved"
+    if est_td:
+        assert abs(got.td) > 1e-4, "td must have moved"
+
+
+def test_extrinsic_estimation_solve_marginalize_solve_chain(oracle):
+    """estimate_extrinsic = 1 over two frames: solve (general path) -> device marginalization (Ex_Pose is a kept block whose linearisation
+    point is the estimated extrinsic) -> next solve with that prior, Ex_Pose columns of the prior active."""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    o.estimate_extrinsic = 1
+    cfg = synth.SynthConfig(with_prior=True, n_features=100)      # the synthetic prior pins the (weakly observable) extrinsic
+    win, prior0, _ = synth.make_window(33, o, cfg)
+    win = _perturbed_extrinsic(win, 7)
+    s = BackendSolver(o)
+    s.set_prior(prior0)
+    got1 = s.optimization(win)
+    s.marginalize()
+    pg = s.get_prior()
+    ref1 = oracle.window_solve(o, win, prior0)
+    pr = oracle.window_marginalize(o, win, ref1, prior0)
+    assert pg.valid == pr.valid and pg.n == pr.n and pg.n_blocks == pr.n_blocks
+    Lg, bg, blg = _prior_products(pg)
+    Lr, br_, blr = _prior_products(pr)
+    assert [b["id"] for b in blg] == [b["id"] for b in blr]
+    assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5
+    win2, _, _ = synth.make_window(33, o, cfg)
+    win2.para_ex_pose = np.concatenate([got1.tic, synth.R_to_q(got1.ric)])
+    got2 = s.optimization(win2)
+    ref2 = oracle.window_solve(o, win2, pr)
+    s.set_prior(pr)                                   # the same solve from the ORACLE's prior: isolates the solve from the two eigen-solvers' 2e-5
+    got3 = s.optimization(win2)
+    s.close()
+    assert got2.summary["num_iterations"] == ref2.summary["num_iterations"] == got3.summary["num_iterations"]
+    assert abs(got2.summary["final_cost"] - ref2.summary["final_cost"]) <= 1e-5 * ref2.summary["final_cost"]
+    # the extrinsic is weakly observable over one window: the priors' 2e-5 relative difference shows as a few 1e-5 m along the window
+    assert np.abs(got2.Ps - ref2.Ps).max() < 1e-4 and np.abs(got2.Rs - ref2.Rs).max() < 1e-5 and np.abs(got2.tic - ref2.tic).max() < 1e-4
+    assert np.abs(got3.Ps - ref2.Ps).max() < 1e-6 and np.abs(got3.Rs - ref2.Rs).max() < 1e-7 and np.abs(got3.tic - ref2.tic).max() < 1e-6
+
+
+def test_flagged_solves_fail_loudly_where_unsupported(oracle):
+    from vil_fusion_amd.estimator import BackendSolver
+    from vil_fusion_amd.lib import VilfError
+    o = oracle.default_options()
+    o.estimate_td = 1
+    s = BackendSolver(o)
+    win, _, _ = synth.make_window(2, o, synth.SynthConfig(n_features=40, with_prior=False))
+    with pytest.raises(VilfError):                       # td factor constants missing
+        s.optimization(win)
+    s.optimization(_with_td_inputs(win, 1))
+    with pytest.raises(VilfError):                       # no ProjectionTdFactor in the device marginalization
+        s.marginalize()
+    with pytest.raises(VilfError):                       # batched kernels: Ex_Pose / td constant only
+        s.batch_upload([win]); s.batch_solve()
+    s.close()

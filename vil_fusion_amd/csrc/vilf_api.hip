@@ -102,7 +102,6 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return VILF_ERR_NO_GPU;
     if (device < 0 || device >= ndev) return VILF_ERR_INVALID_ARGUMENT;
     if (opts->window_size < 1 || opts->window_size > 4096) return VILF_ERR_UNSUPPORTED;   // 10 = the reference's compile-time WINDOW_SIZE (batched LDS kernels); other sizes: single-window general path (vilf_lw.hip)
-    if (opts->estimate_extrinsic || opts->estimate_td) return VILF_ERR_UNSUPPORTED;  // KITTI config: both 0
     vilf_handle *h = new vilf_handle();
     h->opts = *opts;
     h->device = device;
@@ -491,6 +490,7 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
 
 extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
+    if (h->opts.estimate_extrinsic || h->opts.estimate_td) { h->err = "estimate_extrinsic / estimate_td: single-window solve only (vilf_window_solve)"; return VILF_ERR_UNSUPPORTED; }
     HIPCHECK(h, hipSetDevice(h->device));
     bool dirty = false;
     for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true;
@@ -609,11 +609,13 @@ extern "C" int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_
     if (!h || !in || !out) return VILF_ERR_INVALID_ARGUMENT;
     if (in->n_frames != VB_NF) {          // not the reference's WINDOW_SIZE = 10: the general path (one window spread over the device, no prior)
         if (in->n_frames != h->opts.window_size + 1) { h->err = "n_frames must be options.window_size + 1"; return VILF_ERR_INVALID_ARGUMENT; }
-        return vilf_lw_window_solve(h, in, out);
+        return vilf_lw_window_solve(h, in, out, 0);
     }
     auto t0 = std::chrono::steady_clock::now();
     int rc = vilf_batch_upload(h, 1, in);
     if (rc != VILF_OK) return rc;
+    if (h->opts.estimate_extrinsic || h->opts.estimate_td)      // Ex_Pose / td as variables (estimator.cpp:701-717): the general single-window path, with the slot-0 prior
+        return vilf_lw_window_solve(h, in, out, 1);
     rc = vilf_batch_solve(h, 1);
     if (rc != VILF_OK) return rc;
     rc = vilf_batch_download(h, 0, 1, out);
@@ -642,6 +644,7 @@ extern "C" int vilf_prior_export(vilf_handle *h, int slot, vilf_prior *out) {
 
 extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
+    if (h->opts.estimate_td) { h->err = "estimate_td: the device marginalization has no ProjectionTdFactor / td block"; return VILF_ERR_UNSUPPORTED; }
     HIPCHECK(h, hipSetDevice(h->device));
     { bool dirty = false; for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true; if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; } }
     const size_t sB = h->B, sF = h->batch.Fmax, sC = h->batch.FACmax, M = h->mg_Mcap;

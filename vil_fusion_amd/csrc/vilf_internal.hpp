@@ -92,4 +92,4 @@ void vilf_s2m_release(vilf_handle *h);
 void vilf_feat_release(vilf_handle *h);
 void vilf_pg_release(vilf_handle *h);
 void vilf_lw_release(vilf_handle *h);
-int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out);   // window sizes other than 10 (vilf_lw.hip)
+int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot0);   // window sizes other than 10, estimate_extrinsic / estimate_td (vilf_lw.hip)

@@ -10,7 +10,11 @@
 //   rocBLAS dgemv                   matrix-vector products
 //   rocSOLVER dpotrf / dpotrs       dense Cholesky of the reduced system
 // and keeps the trust-region logic (Ceres 2.0 TrustRegionMinimizer + traditional dogleg + Jacobi scaling, the same restatement as
-// k_solve / k_step) on the host: per iteration only vectors of P + F doubles cross PCIe. No marginalization prior on this path.
+// k_solve / k_step) on the host: per iteration only vectors of P + F doubles cross PCIe.
+// The same path runs the solves the batched LDS kernels do not cover at ANY window size: estimate_extrinsic (Ex_Pose a variable: six more
+// columns after the frame blocks) and estimate_td (ProjectionTdFactor, one more column) — estimator.cpp:701-717,765-777. For an 11-frame
+// window it then also applies the slot-0 marginalization prior resident on the device (lw_prior) and writes the solved state back into the
+// batch buffers, so that vilf_window_marginalize() continues from it. Other window sizes have no prior (no device marginalization).
 // Summation order of the atomics is not fixed: results are reproducible to rounding (~1e-12 relative), not bit for bit.
 #include <hip/hip_runtime.h>
 #include <rocsolver/rocsolver.h>
@@ -26,12 +30,12 @@ extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, do
 
 struct LwCtx {
     rocblas_handle blas = nullptr;
-    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den, jscr;
+    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den, jscr, tdrec, pri;
     hipEvent_t ev[2] = {nullptr, nullptr};
     double ms[4] = {0, 0, 0, 0};       // vilf_set_profiling: factor scatter, Schur SYRK, Cholesky (potrf + potrs), other device work
     long launches[4] = {0, 0, 0, 0};
     void release() {
-        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr};
+        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr, &tdrec, &pri};
         for (DBuf *b : all) b->release();
         if (blas) { rocblas_destroy_handle(blas); blas = nullptr; }
     }
@@ -125,12 +129,112 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(int n, const LwVis *vis, cons
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((tid & 63) == 0 && c != 0.0) add(cost, c);
 }
+
+// The same chunked scatter with Ex_Pose and / or td as variables (estimate_extrinsic / estimate_td): 19 Jacobian columns per factor row
+// [pose_i 6 | pose_j 6 | Ex 6 | td 1]; a column whose block is constant maps to -1 and is skipped. x = pose | sb | feat | ex[7] | td.
+struct LwTd { double vi[2], vj[2], tdi, tdj, rowi_c, rowj_c; };     // ProjectionTdFactor constants (projection_td_factor.cpp:6-21)
+__device__ __forceinline__ int lw_col(int a, int ci, int cj, int cEx, int cTd) { return a < 6 ? ci + a : (a < 12 ? cj + a - 6 : (a < 18 ? (cEx < 0 ? -1 : cEx + a - 12) : cTd)); }
+__global__ __launch_bounds__(LW_CH) void lw_visual_ext(int n, const LwVis *vis, const LwTd *tdr, const double *x, int NF, int F, int P, int cEx, int cTd, double tr_over_row,
+                                                         double sqrt_info, double cauchy_b, int jac, double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost) {
+    __shared__ double s_J[LW_CH][41];                 // row 0: 19, row 1: 19, r0, r1 (+ 1 pad)
+    __shared__ int s_pair[LW_CH + 1];
+    const int tid = threadIdx.x, t = blockIdx.x * LW_CH + tid;
+    const double *ex = x + 16 * (size_t)NF + F;
+    double c = 0;
+    int pr = -1;
+    if (t < n) {
+        const LwVis v = vis[t];
+        pr = v.i * NF + v.j;
+        const double *pi = x + 7 * v.i, *pj = x + 7 * v.j;
+        double Ri[9], Rj[9], ric[9];
+        q_toR(q_load(pi + 3), Ri); q_toR(q_load(pj + 3), Rj); q_toR(q_load(ex + 3), ric);
+        double r[2], Ji[12], Jj[12], Jf[2], Jex[12], Jtd[2] = {0.0, 0.0};
+        const double inv_dep = x[16 * NF + v.f];
+        if (cTd >= 0) {
+            const LwTd q = tdr[t];
+            if (jac) projection_td_eval<true>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, q.vi, q.vj, ex[7], q.tdi, q.tdj, q.rowi_c, q.rowj_c, tr_over_row, inv_dep, sqrt_info, r, Ji, Jj, Jf, Jex, Jtd);
+            else projection_td_eval<false>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, q.vi, q.vj, ex[7], q.tdi, q.tdj, q.rowi_c, q.rowj_c, tr_over_row, inv_dep, sqrt_info, r, Ji, Jj, Jf, Jex, Jtd);
+        } else {
+            if (jac) projection_eval<true>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, inv_dep, sqrt_info, r, Ji, Jj, Jf, Jex);
+            else projection_eval<false>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, inv_dep, sqrt_info, r, Ji, Jj, Jf, Jex);
+        }
+        double rho0, sw;
+        cauchy(r[0] * r[0] + r[1] * r[1], cauchy_b, rho0, sw);
+        c = 0.5 * rho0;
+        if (jac) {
+            const int ci = 15 * v.i, cj = 15 * v.j;
+            double J0[19], J1[19];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                J0[k] = sw * Ji[k]; J1[k] = sw * Ji[6 + k]; J0[6 + k] = sw * Jj[k]; J1[6 + k] = sw * Jj[6 + k];
+                J0[12 + k] = cEx < 0 ? 0.0 : sw * Jex[k]; J1[12 + k] = cEx < 0 ? 0.0 : sw * Jex[6 + k];
+            }
+            J0[18] = cTd < 0 ? 0.0 : sw * Jtd[0]; J1[18] = cTd < 0 ? 0.0 : sw * Jtd[1];
+            const double r0 = sw * r[0], r1 = sw * r[1];
+#pragma unroll
+            for (int k = 0; k < 19; k++) { s_J[tid][k] = J0[k]; s_J[tid][19 + k] = J1[k]; }
+            s_J[tid][38] = r0; s_J[tid][39] = r1;
+            if (!v.cst) {
+                const double f0 = sw * Jf[0], f1 = sw * Jf[1];
+                add(hf + v.f, f0 * f0 + f1 * f1);
+                add(gf + v.f, f0 * r0 + f1 * r1);
+#pragma unroll
+                for (int a = 0; a < 19; a++) { const int col = lw_col(a, ci, cj, cEx, cTd); if (col >= 0) add(W + (size_t)v.f * P + col, J0[a] * f0 + J1[a] * f1); }
+            }
+        }
+    }
+    if (jac) {
+        s_pair[tid] = pr;
+        if (tid == 0) s_pair[LW_CH] = -2;
+        __syncthreads();
+        const int cnt = min(LW_CH, n - blockIdx.x * LW_CH);
+        for (int b0 = 0; b0 < cnt;) {
+            const int pp = s_pair[b0];
+            int b1 = b0 + 1;
+            while (b1 < cnt && s_pair[b1] == pp) b1++;
+            const int fi = pp / NF, fj = pp - fi * NF, ci = 15 * fi, cj = 15 * fj;
+            for (int e = tid; e < 380; e += LW_CH) {
+                double sum = 0;
+                if (e < 361) {
+                    const int a = e / 19, b = e - 19 * a, ca = lw_col(a, ci, cj, cEx, cTd), cb = lw_col(b, ci, cj, cEx, cTd);
+                    if (ca < 0 || cb < 0) continue;
+                    for (int q = b0; q < b1; q++) sum += s_J[q][a] * s_J[q][b] + s_J[q][19 + a] * s_J[q][19 + b];
+                    add(Hpp + (size_t)ca * P + cb, sum);
+                } else {
+                    const int a = e - 361, ca = lw_col(a, ci, cj, cEx, cTd);
+                    if (ca < 0) continue;
+                    for (int q = b0; q < b1; q++) sum += s_J[q][a] * s_J[q][38] + s_J[q][19 + a] * s_J[q][39];
+                    add(gp + ca, sum);
+                }
+            }
+            b0 = b1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((tid & 63) == 0 && c != 0.0) add(cost, c);
+}
+// MarginalizationFactor (marginalization_factor.cpp:333-381) of an 11-frame window: r = r0 + J0 dx with dx from the host (n <= 96 entries),
+// J0^T J0 from k_prior_prep; pcol maps a prior column to its column of the reduced system (-1: block constant in this solve)
+__global__ __launch_bounds__(256) void lw_prior(int n, const double *J, const double *r0, const double *H0, const double *dx, const int *pcol, int P, int jac,
+                                                double *Hpp, double *gp, double *cost) {
+    __shared__ double s_r[VB_PRIOR_LD], s_dx[VB_PRIOR_LD];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) s_dx[i] = dx[i];
+    __syncthreads();
+    for (int k = tid; k < n; k += 256) { double s = r0[k]; for (int i = 0; i < n; i++) s += J[(size_t)k * n + i] * s_dx[i]; s_r[k] = s; }
+    __syncthreads();
+    if (tid == 0) { double c = 0; for (int k = 0; k < n; k++) c += 0.5 * s_r[k] * s_r[k]; add(cost, c); }
+    if (!jac) return;
+    for (int i = tid; i < n; i += 256) { if (pcol[i] < 0) continue; double s = 0; for (int k = 0; k < n; k++) s += J[(size_t)k * n + i] * s_r[k]; add(gp + pcol[i], s); }
+    for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e - i * n; if (pcol[i] >= 0 && pcol[j] >= 0) add(Hpp + (size_t)pcol[i] * P + pcol[j], H0[(size_t)i * VB_PRIOR_LD + j]); }
+}
 // IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair
-__global__ void lw_imu_lidar(int NF, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
+__global__ void lw_imu_lidar(int NF, int P, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
                              double *Hpp, double *gp, double *cost, double *jscr) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= NF - 1) return;
-    const int P = 15 * NF, c0 = 15 * k;
+    const int c0 = 15 * k;
     const double *pi = x + 7 * k, *pj = x + 7 * (k + 1), *sbi = x + 7 * NF + 9 * k, *sbj = sbi + 9;
     double c = 0;
     const double *rec = imu_rec + (size_t)k * IMU_REC;
@@ -174,10 +278,10 @@ __global__ void lw_imu_lidar(int NF, const double *x, const double *imu_rec, con
     add(cost, c);
 }
 // J^T [J r] of every IMU factor: one lane per (factor, row a, column b <= 30): 15-term dot products, one atomic each
-__global__ void lw_imu_products(int NF, const double *jscr, double *Hpp, double *gp) {
+__global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, double *gp) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, k = t / 930, e = t - 930 * k;
     if (k >= NF - 1) return;
-    const int a = e / 31, b = e - 31 * a, P = 15 * NF, c0 = 15 * k;
+    const int a = e / 31, b = e - 31 * a, c0 = 15 * k;
     const double *J = jscr + (size_t)k * 480;
     double s = 0;
     for (int m = 0; m < 15; m++) s += J[30 * m + a] * (b < 30 ? J[30 * m + b] : J[450 + m]);
@@ -297,12 +401,19 @@ inline void h_ypr2R(const double *ypr, double *R) {
 
 #define RB(call) do { if ((call) != rocblas_status_success) { h->err = "rocBLAS / rocSOLVER call failed (large-window solve)"; return VILF_ERR_DEVICE; } } while (0)
 
-int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out) {
+// batch_slot0 != 0: the window is also resident as slot 0 of the 11-frame batch (vilf_batch_upload ran): use that slot's prior and write
+// the solved state back into the batch buffers (the marginalization reads them)
+int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot0) {
     const auto t_start = std::chrono::steady_clock::now();
-    const int NF = in->n_frames, F = in->n_features, P = 15 * NF, N = P + F;
+    const bool est_ex = h->opts.estimate_extrinsic != 0, est_td = h->opts.estimate_td != 0;
+    const int NF = in->n_frames, F = in->n_features;
+    const int cEx = est_ex ? 15 * NF : -1, cTd = est_td ? 15 * NF + (est_ex ? 6 : 0) : -1;      // columns of Ex_Pose / td after the frame blocks
+    const int P = 15 * NF + (est_ex ? 6 : 0) + (est_td ? 1 : 0), N = P + F;
+    const size_t xo = 16 * (size_t)NF + F;                                                        // x = pose | sb | feat | ex[7] | td
     if (NF < 2 || F < 0 || !in->para_pose || !in->para_speed_bias || !in->imu || (F && (!in->para_feature || !in->feature_const || !in->feature_start_frame || !in->feature_obs_offset || !in->obs_point)))
         return VILF_ERR_INVALID_ARGUMENT;
-    if (h->opts.estimate_extrinsic || h->opts.estimate_td) { h->err = "estimate_extrinsic / estimate_td are not supported by the device solve"; return VILF_ERR_UNSUPPORTED; }
+    if (est_td && F && (!in->obs_velocity || !in->obs_cur_td || !in->obs_row)) { h->err = "estimate_td needs obs_velocity / obs_cur_td / obs_row"; return VILF_ERR_INVALID_ARGUMENT; }
+    if (batch_slot0 && (NF != VB_NF || !h->resident)) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipSetDevice(h->device));
     if (!h->lw) h->lw = new LwCtx();
     LwCtx *c = h->lw;
@@ -313,6 +424,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     auto toc = [&](int grp) { if (prof) { hipEventRecord(c->ev[1], h->stream); hipEventSynchronize(c->ev[1]); float t = 0; hipEventElapsedTime(&t, c->ev[0], c->ev[1]); c->ms[grp] += t; c->launches[grp] += 1; } };
     // ---- pack the factors
     std::vector<LwVis> vis;
+    std::vector<int> vis_obs;                         // (first, this) observation index of every factor: the td constants follow the pair sort
     for (int f = 0; f < F; f++) {
         const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
         if (s < 0 || s + (o1 - o0) > NF) { h->err = "feature track leaves the window"; return VILF_ERR_INVALID_ARGUMENT; }
@@ -321,10 +433,28 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             for (int k = 0; k < 3; k++) { v.pi[k] = in->obs_point[3 * (size_t)o0 + k]; v.pj[k] = in->obs_point[3 * (size_t)t + k]; }
             v.f = f; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
             vis.push_back(v);
+            vis_obs.push_back(o0); vis_obs.push_back(t);
         }
     }
-    std::stable_sort(vis.begin(), vis.end(), [NF](const LwVis &a, const LwVis &b) { return a.i * NF + a.j < b.i * NF + b.j; });   // pair-sorted: lw_visual flushes one block per run of equal pairs
     const int nvis = (int)vis.size(), nimu = NF - 1;
+    {   // pair-sorted: lw_visual flushes one block per run of equal pairs
+        std::vector<int> ord(nvis);
+        for (int k = 0; k < nvis; k++) ord[k] = k;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return vis[a].i * NF + vis[a].j < vis[b].i * NF + vis[b].j; });
+        std::vector<LwVis> sv(nvis); std::vector<int> so(2 * (size_t)nvis);
+        for (int k = 0; k < nvis; k++) { sv[k] = vis[ord[k]]; so[2 * k] = vis_obs[2 * ord[k]]; so[2 * k + 1] = vis_obs[2 * ord[k] + 1]; }
+        vis.swap(sv); vis_obs.swap(so);
+    }
+    std::vector<LwTd> tdrec;
+    if (est_td) {                                     // projection_td_factor.cpp:6-21
+        tdrec.resize(std::max(nvis, 1));
+        for (int k = 0; k < nvis; k++) {
+            const int oi = vis_obs[2 * k], oj = vis_obs[2 * k + 1];
+            LwTd &q = tdrec[k];
+            q.vi[0] = in->obs_velocity[2 * (size_t)oi]; q.vi[1] = in->obs_velocity[2 * (size_t)oi + 1]; q.vj[0] = in->obs_velocity[2 * (size_t)oj]; q.vj[1] = in->obs_velocity[2 * (size_t)oj + 1];
+            q.tdi = in->obs_cur_td[oi]; q.tdj = in->obs_cur_td[oj]; q.rowi_c = in->obs_row[oi] - h->opts.ROW / 2; q.rowj_c = in->obs_row[oj] - h->opts.ROW / 2;
+        }
+    }
     std::vector<double> imu((size_t)nimu * IMU_REC, 0.0), cov((size_t)nimu * 225), lid((size_t)nimu * 7, 0.0);
     for (int k = 0; k < nimu; k++) {
         const vilf_imu_preint &p = in->imu[k + 1];
@@ -353,7 +483,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     }
     // ---- device buffers
     const size_t sP = P, sF = std::max(F, 1), sN = N;
-    if (!c->x.ensure((16 * (size_t)NF + sF) * 8) || !c->ex.ensure(7 * 8 + 64) || !c->vis.ensure(std::max<size_t>(nvis, 1) * sizeof(LwVis)) || !c->imu.ensure(imu.size() * 8) || !c->cov.ensure(cov.size() * 8) ||
+    if (!c->x.ensure((16 * (size_t)NF + sF + 8) * 8) || !c->tdrec.ensure(std::max<size_t>(tdrec.size(), 1) * sizeof(LwTd)) || !c->pri.ensure(2 * VB_PRIOR_LD * 8) || !c->ex.ensure(7 * 8 + 64) || !c->vis.ensure(std::max<size_t>(nvis, 1) * sizeof(LwVis)) || !c->imu.ensure(imu.size() * 8) || !c->cov.ensure(cov.size() * 8) ||
         !c->lid.ensure(lid.size() * 8) || !c->Hpp.ensure(sP * sP * 8) || !c->W.ensure(sF * sP * 8) || !c->hf.ensure(sF * 8) || !c->gp.ensure(sP * 8) || !c->gf.ensure(sF * 8) || !c->S.ensure(sP * sP * 8) ||
         !c->Wn.ensure(sF * sP * 8) || !c->rhs.ensure(sP * 8) || !c->tmpP.ensure(sP * 8) || !c->tmpF.ensure(sF * 8) || !c->vec.ensure(2 * sN * 8) || !c->scal.ensure(256) || !c->info.ensure(64) ||
         !c->fconst.ensure(sF) || !c->den.ensure(sF * 8) || !c->jscr.ensure((size_t)nimu * 480 * 8)) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
@@ -364,6 +494,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     HIPCHECK(h, hipMemcpyAsync(c->ex.p, in->para_ex_pose, 56, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(c->scal.as<double>() + 1, geo, 10 * 8, hipMemcpyHostToDevice, h->stream));        // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
     if (nvis) HIPCHECK(h, hipMemcpyAsync(c->vis.p, vis.data(), (size_t)nvis * sizeof(LwVis), hipMemcpyHostToDevice, h->stream));
+    if (est_td && nvis) HIPCHECK(h, hipMemcpyAsync(c->tdrec.p, tdrec.data(), (size_t)nvis * sizeof(LwTd), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(c->imu.p, imu.data(), imu.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(c->cov.p, cov.data(), cov.size() * 8, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(c->lid.p, lid.data(), lid.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -373,18 +504,63 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = 1.0 / (h->opts.cauchy_a * h->opts.cauchy_a);
 
     // ---- host state: x = pose | sb | feat
-    std::vector<double> x(16 * (size_t)NF + F), cand(x.size());
+    std::vector<double> x(xo + 8), cand(x.size());
     std::memcpy(&x[0], in->para_pose, 7 * NF * 8); std::memcpy(&x[7 * NF], in->para_speed_bias, 9 * NF * 8);
     for (int f = 0; f < F; f++) x[16 * NF + f] = in->para_feature[f];
+    std::memcpy(&x[xo], in->para_ex_pose, 56); x[xo + 7] = in->para_td;
+    // ---- the slot-0 prior of the 11-frame batch (marginalization_factor.cpp:333-381): block table on the host, J0 / r0 / J0^T J0 stay on the device
+    int pn = 0, pnb = 0, phdr[VB_PRIOR_HDR];
+    std::vector<double> px0(24 * 9), pdx(VB_PRIOR_LD, 0.0);
+    std::vector<int> pcol(VB_PRIOR_LD, -1);
+    if (batch_slot0) {
+        HIPCHECK(h, hipMemcpyAsync(phdr, h->d[D_PHDR].p, sizeof(phdr), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(px0.data(), h->d[D_PX0].p, px0.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        if (phdr[0]) {
+            pn = phdr[1]; pnb = phdr[2];
+            for (int bk = 0; bk < pnb; bk++) {
+                const int id = phdr[3 + bk], idx = phdr[51 + bk];
+                if (id < NF) for (int k = 0; k < 6; k++) pcol[idx + k] = 15 * id + k;
+                else if (id < 2 * NF) for (int k = 0; k < 9; k++) pcol[idx + k] = 15 * (id - NF) + 6 + k;
+                else if (id == 2 * NF && est_ex) for (int k = 0; k < 6; k++) pcol[idx + k] = cEx + k;
+            }
+            HIPCHECK(h, hipMemcpyAsync(c->pri.as<char>() + VB_PRIOR_LD * 8, pcol.data(), VB_PRIOR_LD * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        }
+    }
+    auto prior_dx = [&](const std::vector<double> &xx) {                 // marginalization_factor.cpp:345-363
+        auto pose_dx = [&](const double *xb, const double *x0, double *d) {
+            for (int k = 0; k < 3; k++) d[k] = xb[k] - x0[k];
+            const double n0 = x0[3] * x0[3] + x0[4] * x0[4] + x0[5] * x0[5] + x0[6] * x0[6];
+            const HQ qi{-x0[3] / n0, -x0[4] / n0, -x0[5] / n0, x0[6] / n0}, dq = hq_mul(qi, HQ{xb[3], xb[4], xb[5], xb[6]});
+            const double sgn = dq.w >= 0 ? 2.0 : -2.0;
+            d[3] = sgn * dq.x; d[4] = sgn * dq.y; d[5] = sgn * dq.z;
+        };
+        for (int bk = 0; bk < pnb; bk++) {
+            const int id = phdr[3 + bk], idx = phdr[51 + bk];
+            const double *x0 = &px0[9 * bk];
+            if (id < NF) pose_dx(&xx[7 * id], x0, &pdx[idx]);
+            else if (id < 2 * NF) for (int k = 0; k < 9; k++) pdx[idx + k] = xx[7 * NF + 9 * (id - NF) + k] - x0[k];
+            else if (id == 2 * NF) pose_dx(&xx[xo], x0, &pdx[idx]);
+        }
+    };
     double R0b[9], P0b[3];
     if (in->gauge_R0) std::memcpy(R0b, in->gauge_R0, 72); else h_q2R(&x[3], R0b);
     if (in->gauge_P0) std::memcpy(P0b, in->gauge_P0, 24); else std::memcpy(P0b, &x[0], 24);
-    auto xnorm = [&](const std::vector<double> &v) { double s = 0; for (int i = 0; i < 16 * NF; i++) s += v[i] * v[i]; for (int f = 0; f < F; f++) if (!in->feature_const[f]) s += v[16 * NF + f] * v[16 * NF + f]; return std::sqrt(s); };
+    auto xnorm = [&](const std::vector<double> &v) {
+        double s = 0;
+        for (int i = 0; i < 16 * NF; i++) s += v[i] * v[i];
+        for (int f = 0; f < F; f++) if (!in->feature_const[f]) s += v[16 * NF + f] * v[16 * NF + f];
+        if (est_ex) for (int k = 0; k < 7; k++) s += v[xo + k] * v[xo + k];
+        if (est_td) s += v[xo + 7] * v[xo + 7];
+        return std::sqrt(s);
+    };
     // tangent vector d[N] = [15 per frame: pose 6, speed-bias 9 | F] applied to the state
     auto plus = [&](const std::vector<double> &xx, const std::vector<double> &d, std::vector<double> &o) {
         o = xx;
         for (int i = 0; i < NF; i++) { h_pose_plus(&xx[7 * i], &d[15 * i], &o[7 * i]); for (int k = 0; k < 9; k++) o[7 * NF + 9 * i + k] = xx[7 * NF + 9 * i + k] + d[15 * i + 6 + k]; }
         for (int f = 0; f < F; f++) o[16 * NF + f] = xx[16 * NF + f] + (in->feature_const[f] ? 0.0 : d[P + f]);
+        if (est_ex) h_pose_plus(&xx[xo], &d[cEx], &o[xo]);
+        if (est_td) o[xo + 7] = xx[xo + 7] + d[cTd];
     };
     auto evaluate = [&](const std::vector<double> &xx, bool jac, double &cost) -> int {
         HIPCHECK(h, hipMemcpyAsync(c->x.p, xx.data(), xx.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -394,11 +570,21 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             HIPCHECK(h, hipMemsetAsync(c->hf.p, 0, sF * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gp.p, 0, sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gf.p, 0, sF * 8, h->stream));
         }
         if (jac) tic();
-        if (nvis) hipLaunchKernelGGL(lw_visual, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->ex.as<double>(), NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
-                                     c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
-        hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
+        if (nvis && (est_ex || est_td))
+            hipLaunchKernelGGL(lw_visual_ext, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->tdrec.as<LwTd>(), c->x.as<double>(), NF, F, P, cEx, cTd,
+                               h->opts.TR / h->opts.ROW, sqrt_info, cauchy_b, jac ? 1 : 0, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
+        else if (nvis)
+            hipLaunchKernelGGL(lw_visual, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->x.as<double>() + xo, NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
+                               c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
+        if (pn) {
+            prior_dx(xx);
+            HIPCHECK(h, hipMemcpyAsync(c->pri.p, pdx.data(), VB_PRIOR_LD * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(lw_prior, dim3(1), dim3(256), 0, h->stream, pn, h->d[D_PJ].as<double>(), h->d[D_PR].as<double>(), h->d[D_PH].as<double>(), c->pri.as<double>(),
+                               (const int *)(c->pri.as<char>() + VB_PRIOR_LD * 8), P, jac ? 1 : 0, c->Hpp.as<double>(), c->gp.as<double>(), scal);
+        }
+        hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, P, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
                            c->Hpp.as<double>(), c->gp.as<double>(), scal, c->jscr.as<double>());
-        if (jac) hipLaunchKernelGGL(lw_imu_products, dim3((nimu * 930 + 255) / 256), dim3(256), 0, h->stream, NF, c->jscr.as<double>(), c->Hpp.as<double>(), c->gp.as<double>());
+        if (jac) hipLaunchKernelGGL(lw_imu_products, dim3((nimu * 930 + 255) / 256), dim3(256), 0, h->stream, NF, P, c->jscr.as<double>(), c->Hpp.as<double>(), c->gp.as<double>());
         if (jac) toc(0);
         HIPCHECK(h, hipGetLastError());
         HIPCHECK(h, hipMemcpyAsync(&cost, scal, 8, hipMemcpyDeviceToHost, h->stream));
@@ -564,6 +750,8 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         double sn = 0;
         for (int i = 0; i < 16 * NF; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
         for (int f = 0; f < F; f++) if (!in->feature_const[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
+        if (est_ex) for (int k = 0; k < 7; k++) sn += (x[xo + k] - cand[xo + k]) * (x[xo + k] - cand[xo + k]);
+        if (est_td) sn += (x[xo + 7] - cand[xo + 7]) * (x[xo + 7] - cand[xo + 7]);
         if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = VILF_TERM_CONVERGENCE_PARAMETER; break; }
         const double cost_change = x_cost - cand_cost;
         if (std::fabs(cost_change) <= function_tolerance * x_cost) { termination = VILF_TERM_CONVERGENCE_FUNCTION; break; }
@@ -601,9 +789,22 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             out->Bas[3 * i + a] = x[7 * NF + 9 * i + 3 + a]; out->Bgs[3 * i + a] = x[7 * NF + 9 * i + 6 + a];
         }
     }
-    for (int k = 0; k < 3; k++) out->tic[k] = in->para_ex_pose[k];
-    h_q2R(in->para_ex_pose + 3, out->ric);
-    out->td = in->para_td;
+    for (int k = 0; k < 3; k++) out->tic[k] = x[xo + k];                 // double2vector :607-617: tic / ric / td from para_Ex_Pose / para_Td
+    h_q2R(&x[xo + 3], out->ric);
+    out->td = est_td ? x[xo + 7] : in->para_td;
+    if (batch_slot0) {                                                  // the marginalization of this window reads the batch buffers of slot 0
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_POSE].p, &x[0], 77 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_SB].p, &x[77], 99 * 8, hipMemcpyHostToDevice, h->stream));
+        if (F) HIPCHECK(h, hipMemcpyAsync(h->d[D_FEAT].p, &x[16 * NF], (size_t)F * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_EX].p, &x[xo], 56, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OPS].p, out->Ps, 33 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_ORS].p, out->Rs, 99 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OVS].p, out->Vs, 33 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBAS].p, out->Bas, 33 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBGS].p, out->Bgs, 33 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        std::memcpy(&h->h_ex[0], &x[xo], 56); h->h_td[0] = out->td;
+    }
     out->summary.num_iterations = iteration; out->summary.num_successful_steps = num_successful; out->summary.num_linear_solves = num_linear_solves;
     out->summary.termination = termination; out->summary.initial_cost = initial_cost; out->summary.final_cost = x_cost; out->summary.final_radius = radius;
     out->summary.usec_solve = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
