@@ -667,6 +667,7 @@ __device__ __forceinline__ int bucket_of(int ix, int iy) { return ((ix & 255) <<
 #define S2B_IT 1024
 #define S2B_HW(w) ((w) + ((w) >> 5))     // LDS word index with one pad word per 32: a thread's 32 consecutive words and its neighbours' stay on different banks
 #define S2B_HWORDS (S2B_NB / 2 + S2B_NB / 64)
+#define S2B_FL 4
 __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all, int *start_all, float4 *sorted_all, int *err) {
     extern __shared__ unsigned int s_hist[];          // [S2B_HWORDS] two 16-bit counters per word (padded), then s_base[1024]
     __shared__ int s_w[S2B_IT / 64], s_total, s_big;
@@ -682,12 +683,12 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     if (tid == 0) s_big = 0;
     __syncthreads();
     bool over = false;
-    for (int i0 = tid; i0 < n; i0 += 4 * S2B_IT) {    // four points per lane in flight
-        float4 q[4];
+    for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {    // S2B_FL points per lane in flight
+        float4 q[S2B_FL];
 #pragma unroll
-        for (int u = 0; u < 4; u++) q[u] = p[min(i0 + u * S2B_IT, n - 1)];
+        for (int u = 0; u < S2B_FL; u++) q[u] = p[min(i0 + u * S2B_IT, n - 1)];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < S2B_FL; u++) {
             const int i = i0 + u * S2B_IT;
             if (i >= n) continue;
             const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
@@ -729,12 +730,12 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     const bool big = s_big != 0;
     __threadfence_block();
     __syncthreads();
-    for (int i0 = tid; i0 < n; i0 += 4 * S2B_IT) {
-        float4 q[4]; unsigned short r4[4];
+    for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {
+        float4 q[S2B_FL]; unsigned short r4[S2B_FL];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int ic = min(i0 + u * S2B_IT, n - 1); q[u] = p[ic]; r4[u] = rk[ic]; }
+        for (int u = 0; u < S2B_FL; u++) { const int ic = min(i0 + u * S2B_IT, n - 1); q[u] = p[ic]; r4[u] = rk[ic]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < S2B_FL; u++) {
             const int i = i0 + u * S2B_IT;
             if (i >= n) continue;
             const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
