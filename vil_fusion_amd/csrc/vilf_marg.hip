@@ -579,13 +579,15 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
         }
         __syncthreads();
         const double h = s_sc[1];
-        if (tid < i) {                       // e = A_sub d with the symmetric matrix read from its lower triangle; V(:, i) keeps the reflector
-            const int j = tid;
+        {                                    // e = A_sub d with the symmetric matrix read from its lower triangle; V(:, i) keeps the reflector.
+            // Row j's dot product is split over `parts` adjacent lanes (interleaved k) and combined by shuffles: the dependent chain is i / parts long
+            const int lg = (4 * i <= NT) ? 2 : ((2 * i <= NT) ? 1 : 0), parts = 1 << lg;
+            const int j = tid >> lg, part = tid & (parts - 1);
             double gq = 0;
-            for (int k = 0; k <= j; k++) gq += VV(j, k) * d[k];
-            for (int k = j + 1; k < i; k++) gq += VV(k, j) * d[k];
-            e[j] = gq / h;
-            VV(j, i) = d[j];
+            if (j < i) for (int k = part; k < i; k += parts) gq += (k <= j ? VV(j, k) : VV(k, j)) * d[k];
+            if (lg >= 1) gq += __shfl_xor(gq, 1, 64);
+            if (lg >= 2) gq += __shfl_xor(gq, 2, 64);
+            if (j < i && part == 0) { e[j] = gq / h; VV(j, i) = d[j]; }
         }
         __syncthreads();
         if (tid < 64) { double a = 0; for (int k = tid; k < i; k += 64) a += e[k] * d[k]; a = mg_wave_sum(a); if (tid == 0) s_sc[2] = a / (h + h); }
@@ -593,7 +595,17 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
         const double hh = s_sc[2];
         if (tid < i) e[tid] -= hh * d[tid];
         __syncthreads();
-        for (int t = tid; t < i * i; t += NT) { const int k = t / i, j = t - k * i; if (j <= k) VV(k, j) -= (d[j] * e[k] + e[j] * d[k]); }
+        {   // rank-2 update of the lower triangle only: rows r and i-1-r together fill one row of an (i+1)-wide rectangle; the row index comes from a
+            // float reciprocal (exact for these sizes) instead of an integer division per element
+            const int w = i + 1, nr = (i + 1) >> 1;
+            const float invw = 1.0f / (float)w;
+            for (int t = tid; t < nr * w; t += NT) {
+                const int r = (int)(((float)t + 0.5f) * invw), c = t - r * w;
+                int k, j;
+                if (c <= r) { k = r; j = c; } else { k = i - 1 - r; j = c - (r + 1); if (k == r) continue; }
+                VV(k, j) -= (d[j] * e[k] + e[j] * d[k]);
+            }
+        }
         __syncthreads();
         if (tid < i) { d[tid] = VV(i - 1, tid); VV(i, tid) = 0.0; }
         if (tid == 0) d[i] = h;
@@ -606,11 +618,14 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
         if (h != 0.0) {
             if (tid <= i) d[tid] = VV(tid, i + 1) / h;
             __syncthreads();
-            if (tid <= i) {
-                const int j = tid;
+            {                                // column j of the accumulated transformation, split over `parts` adjacent lanes like the mat-vec above
+                const int lg = (4 * (i + 1) <= NT) ? 2 : ((2 * (i + 1) <= NT) ? 1 : 0), parts = 1 << lg;
+                const int j = tid >> lg, part = tid & (parts - 1);
                 double gq = 0;
-                for (int k = 0; k <= i; k++) gq += VV(k, i + 1) * VV(k, j);
-                for (int k = 0; k <= i; k++) VV(k, j) -= gq * d[k];
+                if (j <= i) for (int k = part; k <= i; k += parts) gq += VV(k, i + 1) * VV(k, j);
+                if (lg >= 1) gq += __shfl_xor(gq, 1, 64);
+                if (lg >= 2) gq += __shfl_xor(gq, 2, 64);
+                if (j <= i) for (int k = part; k <= i; k += parts) VV(k, j) -= gq * d[k];
             }
             __syncthreads();
         }
