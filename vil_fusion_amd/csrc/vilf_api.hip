@@ -31,6 +31,7 @@ __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_mf_ql(VbBatch b, VbMarg g, int force_overflow);
 __global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
+#define VILF_MFA_LDS_EXTRA (4 * 64 * 8 + QL_ICAP * 2)      // k_mf_apply behind V: two staged chunks of the rotation log (MFA_CH = 64) + the 16-bit QL iteration table
 __global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
 __global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
 __global__ void k_hook_lidar(const double *, const double *, const double *, const double *, const double *, double *);
@@ -118,7 +119,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
         hipFuncSetAttribute((const void *)k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_prior_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VILF_PRIOR_PREP_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_mf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_mf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->marg_lds_finish + VILF_MFA_LDS_EXTRA)) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * 64 * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
@@ -691,8 +692,8 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
     hipLaunchKernelGGL(k_mf_ql, dim3((h->B + 63) / 64), dim3(64), (size_t)2 * (MG_NK + 2) * 64 * sizeof(double), h->stream, h->batch, g,
                        std::getenv("VILF_MARG_FORCE_QL_FALLBACK") ? 1 : 0);        // test hook
-    hipLaunchKernelGGL(k_mf_apply, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
-    hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
+    hipLaunchKernelGGL(k_mf_apply, grid, block, (size_t)77 * 77 * sizeof(double) + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 0, 78);
+    hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 78, 1 << 30);
     hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, 1);
     hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, 1);
     if (prof) hipEventRecord(h->pev[3], h->stream);

@@ -849,6 +849,7 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
     for (int i = 0; i < n; i++) dg[i] = d[64 * i];                          // eigenvalues
     qi[0] = ni; qi[1] = nr; qi[2] = over ? 1 : 0;
 }
+#define MFA_CH 64            // rotations per staged chunk of k_mf_apply (two buffers of 1 KB)
 extern "C" __global__ __launch_bounds__(NT) void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *info = g.info + (size_t)w * MG_INFO;
@@ -864,30 +865,54 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_apply(VbBatch b, VbMarg g,
     for (int e = tid; e < n * N; e += NT) V[e] = Vg[e];
     if (tid < n) { s_lam[tid] = dg[tid]; s_br[tid] = br[tid]; }
     __syncthreads();
-    if (tid < n) {                                                          // row k through every logged rotation; rows are independent
-        const int k = tid, ld = N;
+    // Row k goes through every logged rotation; rows are independent, one lane each (waves 0-1). The rotation log streams through LDS in
+    // chunks of MFA_CH rotations, double-buffered: waves 2-3 fetch chunk c + 1 (one double per lane) while the row waves apply chunk c — the
+    // rows never wait on a global / scalar load (a 64-byte s_load per four rotations cost ~200 cycles per rotation before; holding the chunk
+    // in registers and broadcasting with v_readlane was measured slower than the LDS broadcast reads). The iteration table
+    // (l | m << 8 per QL sweep) sits in LDS as 16-bit entries.
+    {
+        double *s_logd = V + n * N;                                         // [2][2 * MFA_CH] (c, s) pairs; 8-byte reads (16-byte broadcast reads measured slower)
+        unsigned short *s_it = reinterpret_cast<unsigned short *>(s_logd + 4 * MFA_CH);   // [QL_ICAP]
         const double *lg = g.qlLog + (size_t)w * 2 * QL_RCAP;
         const int *itab = g.qlIt + (size_t)w * QL_ICAP;
-        const int ni = qi[0];
-        int pos = 0;
-        for (int it = 0; it < ni; it++) {
-            const int lm = itab[it], l = lm & 255, m = lm >> 8;
-            double hq = VV(k, m);
-            int i = m - 1;
-            for (; i - 3 >= l; i -= 4, pos += 4) {                          // four rotations per trip: their operands are independent loads, only hq chains
-                double2 cs[4]; double vi[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { cs[u] = *reinterpret_cast<const double2 *>(lg + 2 * (pos + u)); vi[u] = VV(k, i - u); }
-#pragma unroll
-                for (int u = 0; u < 4; u++) { VV(k, i - u + 1) = cs[u].y * vi[u] + cs[u].x * hq; hq = cs[u].x * vi[u] - cs[u].y * hq; }
+        const int ni = qi[0], R = qi[1], nch = (R + MFA_CH - 1) / MFA_CH;
+        for (int e = tid; e < ni; e += NT) s_it[e] = (unsigned short)itab[e];
+        if (tid >= 128 && nch > 0) s_logd[tid - 128] = lg[min(tid - 128, 2 * R - 1)];
+        __syncthreads();
+        if (tid >= 128) {                                                   // loader waves
+            for (int c = 0; c < nch; c++) {
+                if (c + 1 < nch) s_logd[((c + 1) & 1) * 2 * MFA_CH + tid - 128] = lg[min((c + 1) * 2 * MFA_CH + tid - 128, 2 * R - 1)];
+                __syncthreads();
             }
-            for (; i >= l; i--, pos++) {
-                const double c = lg[2 * pos], sn = lg[2 * pos + 1];
-                const double vi = VV(k, i);
-                VV(k, i + 1) = sn * vi + c * hq;
-                hq = c * vi - sn * hq;
+        } else {                                                            // row waves: control flow is uniform, only the LDS accesses are predicated
+            const int k = tid, ld = N;
+            const bool act = k < n;
+            int it = 0, i = -1, l = 0, p = 0;
+            double hq = 0.0;
+            for (int c = 0; c < nch; c++) {
+                const double *cs = s_logd + (c & 1) * 2 * MFA_CH - 2 * c * MFA_CH;      // cs[2 p], cs[2 p + 1] = (c, s) of rotation p
+                const int pend = min(R, (c + 1) * MFA_CH);
+                while (p < pend && (i >= l || it < ni)) {
+                    if (i < l) { const int lm = s_it[it++]; l = lm & 255; const int m = lm >> 8; if (act) hq = VV(k, m); i = m - 1; }
+                    int cnt = min(i - l + 1, pend - p);
+                    if (act) {
+                        for (; cnt >= 4; cnt -= 4, i -= 4, p += 4) {        // four rotations per trip: their operands are independent loads, only hq chains
+                            double cc[4], sn[4], vi[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) { cc[u] = cs[2 * (p + u)]; sn[u] = cs[2 * (p + u) + 1]; vi[u] = VV(k, i - u); }
+#pragma unroll
+                            for (int u = 0; u < 4; u++) { VV(k, i - u + 1) = sn[u] * vi[u] + cc[u] * hq; hq = cc[u] * vi[u] - sn[u] * hq; }
+                        }
+                        for (; cnt > 0; cnt--, i--, p++) {
+                            const double c1 = cs[2 * p], s1 = cs[2 * p + 1], vi = VV(k, i);
+                            VV(k, i + 1) = s1 * vi + c1 * hq;
+                            hq = c1 * vi - s1 * hq;
+                        }
+                        if (i < l) VV(k, l) = hq;
+                    } else { i -= cnt; p += cnt; }
+                }
+                __syncthreads();
             }
-            VV(k, l) = hq;
         }
     }
     __syncthreads();
