@@ -141,6 +141,9 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     for (auto &b : h->d) b.release();
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->pev) hipEventDestroy(e);           // profiling events (vilf_set_profiling)
+    for (hipEvent_t e : h->s2m_ev) hipEventDestroy(e);
+    h->pev.clear(); h->s2m_ev.clear();
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }

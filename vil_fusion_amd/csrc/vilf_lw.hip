@@ -38,6 +38,7 @@ struct LwCtx {
         DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr, &tdrec, &pri};
         for (DBuf *b : all) b->release();
         if (blas) { rocblas_destroy_handle(blas); blas = nullptr; }
+        for (hipEvent_t &e : ev) if (e) { hipEventDestroy(e); e = nullptr; }
     }
 };
 extern "C" int vilf_get_profile_large_window(vilf_handle *h, double ms_out[4], long launches_out[4]) {
