@@ -636,6 +636,7 @@ __device__ __forceinline__ double block_sum_s(double v, double *s_red) {
 // indices are compile-time, so operands are plain register picks. Loads are unconditional, coalesced (zero-padded 80-wide rows,
 // rows >= F are zero) and prefetched three k-steps ahead with no arithmetic on them until they are consumed. Group results are
 // subtracted in fixed group order (bit-reproducible).
+#define SOLVE_RED_OFF (66 * 256 + 6 * VB_NPAD)   // LDS layout of k_solve: 66 tiles, then g, diag, scale, y, invd, v (VB_NPAD each), then s_red
 template <int HALF>
 __device__ __forceinline__ void schur_mfma(const double *W, int F, const double *s_cf, const double *s_scale, double *s_T, double *s_y, int lane, int wave) {
     constexpr int TA[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4};
@@ -643,9 +644,10 @@ __device__ __forceinline__ void schur_mfma(const double *W, int F, const double 
     constexpr int NP = HALF ? 7 : 8, PB = HALF ? 8 : 0;
     const int c16 = lane & 15, grp = wave >> 1, g4 = lane >> 4;
     const int nsteps = ((F + 3) & ~3) / 4;
+    double *s_t = s_T + SOLVE_RED_OFF;            // s_red of k_solve (free between its block sums): row 67 of the reduce
     double sc5[5];
 #pragma unroll
-    for (int t5 = 0; t5 < 5; t5++) { const int col = 16 * t5 + c16; sc5[t5] = (col < VB_NPOSE) ? s_scale[col] : (col == VB_NPOSE ? 1.0 : 0.0); }
+    for (int t5 = 0; t5 < 5; t5++) { const int col = 16 * t5 + c16; sc5[t5] = (col < VB_NPOSE) ? s_scale[col] : (col <= VB_NPOSE + 1 ? 1.0 : 0.0); }       // 66: rhs, 67: the Cauchy-point column (see k_solve)
     double4_t acc[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) acc[i] = double4_t{0, 0, 0, 0};
@@ -682,14 +684,14 @@ __device__ __forceinline__ void schur_mfma(const double *W, int F, const double 
                 for (int q = 0; q < 4; q++) {
                     const int rl = g4 + 4 * q;                        // row inside the tile
                     if (ta < 4) tv[q] = T[TIX(rl, c16)];
-                    else tv[q] = (rl < 2) ? T[TIX(rl, c16)] : ((rl == 2) ? s_y[16 * tb + c16] : 0.0);   // tile row 4: rows 64, 65 | row 66 = rhs
+                    else tv[q] = (rl < 2) ? T[TIX(rl, c16)] : ((rl == 2) ? s_y[16 * tb + c16] : ((rl == 3) ? s_t[16 * tb + c16] : 0.0));   // tile row 4: rows 64, 65 | row 66 = rhs | row 67 = Cauchy column
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int rl = g4 + 4 * q, col = 16 * tb + c16;
                     const double nv = tv[q] - acc[i][q];
                     if (ta < 4) { if (col < VB_NPOSE) T[TIX(rl, c16)] = nv; }
-                    else if (col < VB_NPOSE) { if (rl < 2) T[TIX(rl, c16)] = nv; else if (rl == 2) s_y[col] = nv; }
+                    else if (col < VB_NPOSE) { if (rl < 2) T[TIX(rl, c16)] = nv; else if (rl == 2) s_y[col] = nv; else if (rl == 3) s_t[col] = nv; }
                 }
             }
         }
@@ -771,7 +773,8 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
     const double *Hpp = b.Hpp + (size_t)w * 66 * 36;
     const double *imuH = b.imuH + (size_t)w * 9000, *lidH = b.lidH + (size_t)w * 1440;
     const double *priorH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
-    const double *W = b.W + (size_t)w * FM * VB_WLD, *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+    double *W = b.W + (size_t)w * FM * VB_WLD;
+    const double *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
     const int *f_start = b.f_start + (size_t)w * FM, *f_nobs = b.f_nobs + (size_t)w * FM;
     double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
@@ -906,19 +909,24 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
         if (tries == 0) {
             // Cauchy point: alpha = ||gradient_||^2 / || J~ (gradient_ ./ diagonal_) ||^2
             // v^T H~ v = v_p^T H~_pp v_p (accumulated above) + 2 sum_f v_f (w~_f . v_p) + sum_f h~_f v_f^2
-            if (tid < 80) s_y[tid] = (tid < VB_NPOSE) ? s_scale[tid] * s_v[tid] : 0.0;     // s_y is free until the LM step
-            __syncthreads();
-            feature_dots(W, F, f_const, s_y, s_cf, tid);                                     // s_cf temporarily holds W_f . (S v)_p
-            __syncthreads();
+            // The cross term 2 sum_p v_p S_p sum_f s_f v_f W_f[p] rides through the MFMA Schur reduce below instead of a pass of its own over W:
+            // column 67 of U (padding of the 80-wide rows) is set to c_f x_f with c_f^2 x_f = s_f v_f, so (U^T U)[p][67] is exactly that inner sum.
 #pragma unroll
             for (int u = 0; u < 2; u++) {          // the per-feature scalars are re-read (this thread wrote them above): nothing stays live across the assembly
                 const int f = tid + u * SNT;
-                if (f < F && !f_const[f]) {
-                    const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f], hfv = hf[f], gfv = gf[f];
-                    const double vf = sf * gfv / (df * df);
-                    part += vf * (2.0 * sf * s_cf[f] + sf * sf * hfv * vf);
+                if (f < F) {
+                    double xf = 0.0;
+                    if (!f_const[f]) {
+                        const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f], hfv = hf[f], gfv = gf[f];
+                        const double vf = sf * gfv / (df * df);
+                        part += sf * sf * hfv * vf * vf;
+                        xf = vf * (sf * sf * hfv + mu * df * df) / sf;
+                    }
+                    W[(size_t)f * VB_WLD + VB_NPOSE + 1] = xf;
                 }
             }
+            __threadfence_block();                 // the MFMA loader of every wave of this workgroup reads column 67 back from global memory after the barriers below
+                                                   // (workgroup scope: one CU, one L1 — an agent-scope fence writes back / invalidates L2 and doubled the kernel time)
             G2 = block_sum_s(g2, s_red);
             Jg2 = block_sum_s(part, s_red);
         }
@@ -935,8 +943,17 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
         STAMP(1, 4);
         // ---- MFMA Schur reduce: H~_pp -= U^T U and rhs_p -= U^T t over the 5x5 pose tile block -------------------------
         for (int f = F + tid; f < ((F + 3) & ~3); f += SNT) s_cf[f] = 0.0;
+        if (tid < 80) s_red[tid] = 0.0;           // row 67 of the reduce: -(U^T U)[p][67] (s_red is free between the block sums)
         __syncthreads();
+        __threadfence_block();
         if (wave & 1) schur_mfma<1>(W, F, s_cf, s_scale, s_T, s_y, lane, wave); else schur_mfma<0>(W, F, s_cf, s_scale, s_T, s_y, lane, wave);
+        if (tries == 0) {                         // every wave adds the cross term itself (same order in every wave: uniform and identical)
+            double cr = ((lane < VB_NPOSE) ? s_v[lane] * s_red[lane] : 0.0) + ((lane + 64 < VB_NPOSE) ? s_v[lane + 64] * s_red[lane + 64] : 0.0);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
+            Jg2 -= 2.0 * cr;
+            __syncthreads();                      // s_red is reused by later block sums
+        }
         STAMP(1, 5);
         // ---- blocked Cholesky (lower), 11 tile steps: TRSM (row per thread) -> MFMA trailing update, POTRF by wave 0 ------------
         // The reduced rhs rides along as row 165 (first padding row) of the lower-triangular storage: after the factorisation
