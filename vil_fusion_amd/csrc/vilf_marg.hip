@@ -781,14 +781,16 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_tridiag(VbBatch b, VbMarg 
 // one lane per window; d / e live in LDS as [i][lane]
 extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, int force_overflow) {
     extern __shared__ double s_de[];
-    const int lane = threadIdx.x, w = blockIdx.x * 64 + lane;
-    if (w >= b.B) return;
+    // QL_LPW windows per wave: the recurrence is one serial chain per window and lanes in different sweeps diverge (the wave pays the longest
+    // sweep of its lanes every time), so fewer windows per wave on more CUs is faster than full waves on a quarter of the chip
+    const int lane = threadIdx.x, w = blockIdx.x * QL_LPW + lane;
+    if (lane >= QL_LPW || w >= b.B) return;
     const int *info = g.info + (size_t)w * MG_INFO;
     int *qi = g.qlInfo + (size_t)w * 4;
     qi[0] = 0; qi[1] = 0; qi[2] = 0;
     if (info[0] != 0) return;
     const int n = info[3];
-    double *d = s_de + lane, *e = s_de + (MG_NK + 2) * 64 + lane;          // element i at [64 * i]
+    double *d = s_de + lane, *e = s_de + (MG_NK + 2) * 64 + lane;          // element i at [64 * i] (row stride 64 for any QL_LPW)
     double *dg = g.qlD + (size_t)w * 2 * (MG_NK + 2);
     for (int i = 0; i < n; i++) { d[64 * i] = dg[i]; e[64 * i] = dg[MG_NK + 2 + i]; }
     double *lg = g.qlLog + (size_t)w * 2 * QL_RCAP;
@@ -800,7 +802,17 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
     for (int l = 0; l < n && !over; l++) {
         tst1 = fmax(tst1, fabs(d[64 * l]) + fabs(e[64 * l]));
         int m = l;
-        while (m < n) { if (fabs(e[64 * m]) <= eps * tst1) break; m++; }
+        while (m < n) {                              // first negligible sub-diagonal element at or after l, eight candidates per LDS round trip
+            double t8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t8[u] = e[64 * min(m + u, n - 1)];
+            int first = 8;
+#pragma unroll
+            for (int u = 7; u >= 0; u--) if (m + u < n && fabs(t8[u]) <= eps * tst1) first = u;
+            if (first < 8) { m += first; break; }
+            m += 8;
+        }
+        m = min(m, n);
         if (m > l) {
             int iter = 0;
             for (;;) {
@@ -814,7 +826,17 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
                 d[64 * (l + 1)] = e[64 * l] * (p + r);
                 const double dl1 = d[64 * (l + 1)];
                 double hq = gq - d[64 * l];
-                for (int i = l + 2; i < n; i++) d[64 * i] -= hq;
+                {   // the shift of the remaining diagonal, eight loads in flight (one dependent LDS round trip per element cost a third of the kernel)
+                    int i = l + 2;
+                    for (; i + 7 < n; i += 8) {
+                        double t8[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) t8[u] = d[64 * (i + u)];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) d[64 * (i + u)] = t8[u] - hq;
+                    }
+                    for (; i < n; i++) d[64 * i] -= hq;
+                }
                 f += hq;
                 p = d[64 * m];
                 double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
