@@ -584,7 +584,17 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
             const int lg = (4 * i <= NT) ? 2 : ((2 * i <= NT) ? 1 : 0), parts = 1 << lg;
             const int j = tid >> lg, part = tid & (parts - 1);
             double gq = 0;
-            if (j < i) for (int k = part; k < i; k += parts) gq += (k <= j ? VV(j, k) : VV(k, j)) * d[k];
+            if (j < i) {
+                int k = part;
+                for (; k + 3 * parts < i; k += 4 * parts) {             // four terms per trip, their loads issued together
+                    double a4[4], d4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int kk = k + u * parts; a4[u] = (kk <= j ? VV(j, kk) : VV(kk, j)); d4[u] = d[kk]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) gq += a4[u] * d4[u];
+                }
+                for (; k < i; k += parts) gq += (k <= j ? VV(j, k) : VV(k, j)) * d[k];
+            }
             if (lg >= 1) gq += __shfl_xor(gq, 1, 64);
             if (lg >= 2) gq += __shfl_xor(gq, 2, 64);
             if (j < i && part == 0) { e[j] = gq / h; VV(j, i) = d[j]; }
@@ -622,10 +632,30 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
                 const int lg = (4 * (i + 1) <= NT) ? 2 : ((2 * (i + 1) <= NT) ? 1 : 0), parts = 1 << lg;
                 const int j = tid >> lg, part = tid & (parts - 1);
                 double gq = 0;
-                if (j <= i) for (int k = part; k <= i; k += parts) gq += VV(k, i + 1) * VV(k, j);
+                if (j <= i) {
+                    int k = part;
+                    for (; k + 3 * parts <= i; k += 4 * parts) {
+                        double a4[4], b4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { a4[u] = VV(k + u * parts, i + 1); b4[u] = VV(k + u * parts, j); }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) gq += a4[u] * b4[u];
+                    }
+                    for (; k <= i; k += parts) gq += VV(k, i + 1) * VV(k, j);
+                }
                 if (lg >= 1) gq += __shfl_xor(gq, 1, 64);
                 if (lg >= 2) gq += __shfl_xor(gq, 2, 64);
-                if (j <= i) for (int k = part; k <= i; k += parts) VV(k, j) -= gq * d[k];
+                if (j <= i) {
+                    int k = part;
+                    for (; k + 3 * parts <= i; k += 4 * parts) {
+                        double v4[4], d4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { v4[u] = VV(k + u * parts, j); d4[u] = d[k + u * parts]; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) VV(k + u * parts, j) = v4[u] - gq * d4[u];
+                    }
+                    for (; k <= i; k += parts) VV(k, j) -= gq * d[k];
+                }
             }
             __syncthreads();
         }
