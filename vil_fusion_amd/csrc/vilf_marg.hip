@@ -91,7 +91,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
     const int *phdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
     const int mode = g.mflag[w];
     const int have_prior = phdr[0];
-    const int *f_start = b.f_start + (size_t)w * FM, *f_nobs = b.f_nobs + (size_t)w * FM, *f_obs0 = b.f_obs0 + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
+    const int *f_start = b.f_start + (size_t)w * FM, *f_nobs = b.f_nobs + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
     int *f0rank = g.f0rank + (size_t)w * FM;
     double *st_feat = g.st_feat + (size_t)w * FM;
 
@@ -254,16 +254,27 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
     __syncthreads();
     // ---- visual factors of the start-frame-0 features: thread per factor -> Mbuf (slot order) ---------------------------
     double *Mb = g.Mbuf + (size_t)w * MG_MROW * FC;
-    const double *obs = b.obs + (size_t)w * b.Omax * 3;
     if (mode == 0) {
-        const int nfac = b.n_fac[w];
-        const int *ps_feat = b.ps_feat + (size_t)w * FC, *ps_obs = b.ps_obs + (size_t)w * FC, *ps_slot = b.ps_slot + (size_t)w * FC;
-        for (int q = tid; q < nfac; q += NT) {
-            const int f = ps_feat[q];
-            if (f_start[f] != 0) continue;
-            const int oj = ps_obs[q], slot = ps_slot[q], o0 = f_obs0[f], fj = oj - o0;
+        // the factors of the start-frame-0 features are the pair-sorted segments of the pairs (0, j): walk only those (a scan over all factors
+        // paid a chain of three dependent gathers per factor to find them), everything a factor needs in its one 64-byte record
+        int ntot = 0;
+#pragma unroll
+        for (int jj = 0; jj < 10; jj++) ntot += s_poff[pair_index_c(0, jj + 1) + 1] - s_poff[pair_index_c(0, jj + 1)];
+        for (int t = tid; t < ntot; t += NT) {
+            int rem = t, q = -1;
+#pragma unroll
+            for (int jj = 0; jj < 10; jj++) {
+                const int a0 = s_poff[pair_index_c(0, jj + 1)], nseg = s_poff[pair_index_c(0, jj + 1) + 1] - a0;
+                if (q < 0) { if (rem < nseg) q = a0 + rem; else rem -= nseg; }
+            }
+            const double *rec = b.facrec + ((size_t)w * FC + q) * 8;
+            double pts_i[3], pts_j[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { pts_i[k] = rec[k]; pts_j[k] = rec[3 + k]; }
+            const long long ra = __double_as_longlong(rec[6]), rb = __double_as_longlong(rec[7]);
+            const int f = (int)(ra & 0xffffffffll), slot = (int)(ra >> 32), fj = (int)((rb >> 8) & 255);
             double r[2], Ji[12], Jj[12], Jf[2], Jex[12];
-            projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, obs + 3 * o0, obs + 3 * oj, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
+            projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             for (int k = 0; k < 12; k++) { Mb[(size_t)slot * MG_MROW + (k)] = sw * Ji[k]; Mb[(size_t)slot * MG_MROW + (12 + k)] = sw * Jj[k]; Mb[(size_t)slot * MG_MROW + (24 + k)] = sw * Jex[k]; }
