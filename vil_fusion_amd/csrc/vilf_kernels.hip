@@ -651,28 +651,40 @@ __device__ __forceinline__ void schur_mfma(const double *W, int F, const double 
     double4_t acc[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) acc[i] = double4_t{0, 0, 0, 0};
-    double r0[5], r1[5], r2[5], c0, c1, c2;
-#define SCHUR_LOAD(ST, R, C)                                                                 \
-    {                                                                                        \
-        const int st_ = min((ST), nsteps - 1);                                               \
-        const int f_ = 4 * st_ + g4;                                                         \
-        C = s_cf[f_];                                                                        \
-        const double *Wr_ = W + (size_t)f_ * VB_WLD + c16;                                   \
-        _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) R[t5] = Wr_[16 * t5];               \
+    // Three k-steps of W in flight per wave. The loads are inline asm with hand-placed s_waitcnt: written as plain C++ the compiler sinks every
+    // load to its use (it carries the ADDRESS across the trips instead of the data), and each trip then waits out a full global-load latency —
+    // the whole phase was that latency. Three fixed register sets (no rotation: a v_mov from a register whose load is still in flight would not
+    // be interlocked), vmcnt counts: a set is ready when at most the two younger sets (10 loads) are outstanding.
+    double ra[5], rb[5], rc[5];
+#define SCHUR_ISSUE(ST, R)                                                                                                         \
+    {                                                                                                                              \
+        const int st_ = min((ST), nsteps - 1);                                                                                     \
+        const double *Wr_ = W + (size_t)(4 * st_ + g4) * VB_WLD + c16;                                                            \
+        asm volatile("global_load_dwordx2 %0, %5, off\n\tglobal_load_dwordx2 %1, %5, off offset:128\n\t"                           \
+                     "global_load_dwordx2 %2, %5, off offset:256\n\tglobal_load_dwordx2 %3, %5, off offset:384\n\t"                \
+                     "global_load_dwordx2 %4, %5, off offset:512"                                                                  \
+                     : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]) : "v"(Wr_) : "memory");                      \
     }
-    SCHUR_LOAD(grp, r0, c0) SCHUR_LOAD(grp + 4, r1, c1)
-    for (int st = grp; st < nsteps; st += 4) {
-        SCHUR_LOAD(st + 8, r2, c2)
-        double u[5];
-#pragma unroll
-        for (int t5 = 0; t5 < 5; t5++) u[t5] = r0[t5] * c0 * sc5[t5];
-#pragma unroll
-        for (int i = 0; i < NP; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[TA[PB + i]], u[TB[PB + i]], acc[i], 0, 0, 0);
-#pragma unroll
-        for (int t5 = 0; t5 < 5; t5++) { r0[t5] = r1[t5]; r1[t5] = r2[t5]; }
-        c0 = c1; c1 = c2;
+#define SCHUR_WAIT(N, R) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]) : : "memory");
+#define SCHUR_STEP(ST, R)                                                                                                          \
+    {                                                                                                                              \
+        const double c_ = s_cf[4 * (ST) + g4];                                                                                     \
+        double u[5];                                                                                                               \
+        _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) u[t5] = R[t5] * c_ * sc5[t5];                                             \
+        _Pragma("unroll") for (int i = 0; i < NP; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[TA[PB + i]], u[TB[PB + i]], acc[i], 0, 0, 0); \
     }
-#undef SCHUR_LOAD
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // nothing of the compiler's own in flight: the counts below are exact
+    SCHUR_ISSUE(grp, ra) SCHUR_ISSUE(grp + 4, rb)
+    for (int st = grp; st < nsteps; st += 12) {
+        SCHUR_ISSUE(st + 8, rc) SCHUR_WAIT(10, ra) SCHUR_STEP(st, ra)
+        if (st + 4 < nsteps) { SCHUR_ISSUE(st + 12, ra) SCHUR_WAIT(10, rb) SCHUR_STEP(st + 4, rb) }
+        if (st + 8 < nsteps) { SCHUR_ISSUE(st + 16, rb) SCHUR_WAIT(10, rc) SCHUR_STEP(st + 8, rc) }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]),
+                                        "+v"(rc[0]), "+v"(rc[1]), "+v"(rc[2]), "+v"(rc[3]), "+v"(rc[4]) : : "memory");   // the clamped over-reads land before their registers are reused
+#undef SCHUR_ISSUE
+#undef SCHUR_WAIT
+#undef SCHUR_STEP
     for (int gsel = 0; gsel < 4; gsel++) {
         if (grp == gsel) {
 #pragma unroll
