@@ -712,39 +712,47 @@ __device__ __forceinline__ void schur_mfma(const double *W, int F, const double 
 }
 
 // dot(W~_f[0..65], vec) for every feature, 16 lanes per feature (4 features per wave per round), coalesced 80-wide rows;
-// result per feature is written to out[f] (only for non-constant features, others 0). vec lives in LDS (>= 80 entries, 66.. = 0).
-__device__ __forceinline__ void feature_dots(const double *W, int F, const uint8_t *f_const, const double *s_sv /*scale .* vec, 80 entries*/, double *out, int tid) {
+// result per feature is written to out[f] (the caller ignores the entries of constant features). vec lives in LDS (>= 80 entries, 66.. = 0).
+// Three rounds of rows in flight per wave, inline-asm loads with explicit vmcnt waits like the Schur reduce (plain loads are sunk to their uses
+// by the compiler and every round then waits out a global-load latency).
+__device__ __forceinline__ void feature_dots(const double *W, int F, const double *s_sv /*scale .* vec, 80 entries*/, double *out, int tid) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g = lane >> 4;
     double sv[5];
 #pragma unroll
     for (int t5 = 0; t5 < 5; t5++) sv[t5] = s_sv[16 * t5 + c16];
     const int Fk4 = (F + 3) & ~3;                       // rows F..Fk4-1 of W are zero (never written)
-    double wn[5];
-    {
-        const int f = min(4 * wave + g, Fk4 - 1);
-        const double *Wr = W + (size_t)f * VB_WLD + c16;
-#pragma unroll
-        for (int t5 = 0; t5 < 5; t5++) wn[t5] = Wr[16 * t5];
+    double ra[5], rb[5], rc[5];
+#define FD_ISSUE(F0, R)                                                                                                            \
+    {                                                                                                                              \
+        const double *Wr_ = W + (size_t)min((F0) + g, Fk4 - 1) * VB_WLD + c16;                                                    \
+        asm volatile("global_load_dwordx2 %0, %5, off\n\tglobal_load_dwordx2 %1, %5, off offset:128\n\t"                           \
+                     "global_load_dwordx2 %2, %5, off offset:256\n\tglobal_load_dwordx2 %3, %5, off offset:384\n\t"                \
+                     "global_load_dwordx2 %4, %5, off offset:512"                                                                  \
+                     : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]) : "v"(Wr_) : "memory");                      \
     }
-    for (int f0 = 4 * wave; f0 < F; f0 += 4 * SNW) {
-        const int f = f0 + g;
-        double wv[5];
-#pragma unroll
-        for (int t5 = 0; t5 < 5; t5++) wv[t5] = wn[t5];
-        {
-            const int fn = min(f0 + 4 * SNW + g, Fk4 - 1);
-            const double *Wr = W + (size_t)fn * VB_WLD + c16;
-#pragma unroll
-            for (int t5 = 0; t5 < 5; t5++) wn[t5] = Wr[16 * t5];
-        }
-        double acc = 0;
-#pragma unroll
-        for (int t5 = 0; t5 < 5; t5++) acc += wv[t5] * sv[t5];
-        if (!(f < F) || f_const[min(f, F - 1)]) acc = 0;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (c16 == 0 && f < F) out[f] = acc;
+#define FD_WAIT(N, R) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]) : : "memory");
+#define FD_STEP(F0, R)                                                                                                             \
+    {                                                                                                                              \
+        const int f = (F0) + g;                                                                                                    \
+        double acc = 0;                                                                                                            \
+        _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) acc += R[t5] * sv[t5];                                                    \
+        if (!(f < F)) acc = 0;                                                                                                     \
+        _Pragma("unroll") for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);                                           \
+        if (c16 == 0 && f < F) out[f] = acc;                                                                                       \
     }
+    constexpr int RS = 4 * SNW;                          // features per round of the workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FD_ISSUE(4 * wave, ra) FD_ISSUE(4 * wave + RS, rb)
+    for (int f0 = 4 * wave; f0 < F; f0 += 3 * RS) {
+        FD_ISSUE(f0 + 2 * RS, rc) FD_WAIT(10, ra) FD_STEP(f0, ra)
+        if (f0 + RS < F) { FD_ISSUE(f0 + 3 * RS, ra) FD_WAIT(10, rb) FD_STEP(f0 + RS, rb) }
+        if (f0 + 2 * RS < F) { FD_ISSUE(f0 + 4 * RS, rb) FD_WAIT(10, rc) FD_STEP(f0 + 2 * RS, rc) }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]),
+                                        "+v"(rc[0]), "+v"(rc[1]), "+v"(rc[2]), "+v"(rc[3]), "+v"(rc[4]) : : "memory");
+#undef FD_ISSUE
+#undef FD_WAIT
+#undef FD_STEP
 }
 
 extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
@@ -1099,7 +1107,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
     }
     if (tid < 80) s_v[tid] = (tid < VB_NPOSE) ? s_scale[tid] * s_y[tid] : 0.0;
     __syncthreads();
-    feature_dots(W, F, f_const, s_v, s_cf, tid);                                             // s_cf <- W_f . (S y)_p
+    feature_dots(W, F, s_v, s_cf, tid);                                                      // s_cf <- W_f . (S y)_p
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 2; u++) {
