@@ -536,7 +536,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         float4 q[MU_E];
         unsigned long long key[MU_E];
         int tb[MU_E], flag[MU_E], incl[MU_E];
-        unsigned hm = 0, fm = 0, tmm = 0, cm = 0;                    // per-element bit masks: head, first of its run, tail has the leaf, needs mu_rare
+        unsigned hm = 0, fm = 0, cm = 0;                             // per-element bit masks: head, first of its run, needs mu_rare
 #pragma unroll
         for (int u = 0; u < MU_E; u++) { q[u] = qn[u]; qn[u] = p[min(t0 + MU_TILE + u * MU_T + tid, nOld - 1)]; }
 #pragma unroll
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             for (int u = 0; u < MU_E; u++) {
                 const bool valid = t0 + u * MU_T + tid < nOld;
                 const bool tm = valid && lo[u] < ntv && (T[lo[u]] >> IDXB) == key[u];
-                if (tm) { tmm |= 1u << u; cm |= 1u << u; }
+                if (tm) cm |= 1u << u;
                 tb[u] = thp(lo[u]);                                  // tail leaves before this key
                 s_te[u * MU_T + tid] = tb[u] + (tm ? 1 : 0);         // ... up to and including it
                 const bool head = (hm >> u) & 1;
