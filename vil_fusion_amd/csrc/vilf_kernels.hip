@@ -618,13 +618,18 @@ __device__ __forceinline__ void tile_add(double *s_T, int r, int c, double v) {
 
 #define SNT 512
 #define SNW (SNT / 64)
+// wave butterflies, then the eight wave sums added in wave order by every thread: three barriers instead of eleven (k_solve owns its CU:
+// nothing hides a barrier chain), fixed summation order
 __device__ __forceinline__ double block_sum_s(double v, double *s_red) {
     const int tid = threadIdx.x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     __syncthreads();
-    s_red[tid] = v;
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
-    for (int s = SNT / 2; s > 0; s >>= 1) { if (tid < s) s_red[tid] += s_red[tid + s]; __syncthreads(); }
-    const double r = s_red[0];
+    double r = 0;
+#pragma unroll
+    for (int k = 0; k < SNW; k++) r += s_red[k];
     __syncthreads();
     return r;
 }
