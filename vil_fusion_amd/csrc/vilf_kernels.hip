@@ -616,6 +616,10 @@ __device__ __forceinline__ void tile_add(double *s_T, int r, int c, double v) {
     if (tr >= tc) s_T[tile_index(tr, tc) * 256 + TIX(r & 15, c & 15)] += v;
 }
 
+// LDS accumulate without the read-modify-write round trip: inside one barrier-separated assembly phase every tile entry receives at most one
+// addend, so the hardware ds_add_f64 gives the same sum as `+=` — but several of them are in flight per thread instead of one dependent
+// read -> add -> write chain per element (the compiler must order plain `+=` on possibly aliasing offsets)
+__device__ __forceinline__ void lds_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define SNT 512
 #define SNW (SNT / 64)
 // wave butterflies, then the eight wave sums added in wave order by every thread: three barriers instead of eleven (k_solve owns its CU:
@@ -874,8 +878,8 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
                     const int r = (o[u].x >> 15) & 255, c = (o[u].x >> 23) & 255;
                     const double val = v[u] * s_scale[r] * s_scale[c];
                     const int off = (o[u].x & 0x7fff) - 1;
-                    if (off >= 0) s_T[off] += val;
-                    if (o[u].y > 0) s_T[o[u].y - 1] += val;                                   // diagonal tiles hold both triangles
+                    if (off >= 0) lds_add(&s_T[off], val);
+                    if (o[u].y > 0) lds_add(&s_T[o[u].y - 1], val);                                   // diagonal tiles hold both triangles
                     part += (((r / 6) != (c / 6)) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
                 }
             }
@@ -896,7 +900,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
                     const int r = (o[u] >> 15) & 255, c = (o[u] >> 23) & 255;
                     const double val = v[u] * s_scale[r] * s_scale[c];
                     const int off = (o[u] & 0x7fff) - 1;
-                    if (off >= 0) s_T[off] += val;
+                    if (off >= 0) lds_add(&s_T[off], val);
                     part += s_v[r] * val * s_v[c];
                 }
             }
@@ -907,7 +911,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
                 const int r = (o0 >> 15) & 255, c = (o0 >> 23) & 255;
                 const double val = lidH[src] * s_scale[r] * s_scale[c];
                 const int off = (o0 & 0x7fff) - 1;
-                if (off >= 0) s_T[off] += val;
+                if (off >= 0) lds_add(&s_T[off], val);
                 part += s_v[r] * val * s_v[c];
             }
             __syncthreads();
@@ -925,7 +929,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
                 const int r = rr[u], c = cc[u];
                 if (t0 + u * SNT >= pn * pn || r < 0 || c < 0) continue;
                 const double val = v[u] * s_scale[r] * s_scale[c];
-                if ((r >> 4) >= (c >> 4)) s_T[tile_index(r >> 4, c >> 4) * 256 + TIX(r & 15, c & 15)] += val;
+                if ((r >> 4) >= (c >> 4)) lds_add(&s_T[tile_index(r >> 4, c >> 4) * 256 + TIX(r & 15, c & 15)], val);
                 part += s_v[r] * val * s_v[c];
             }
         }
