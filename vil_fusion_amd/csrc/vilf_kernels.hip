@@ -784,14 +784,17 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
 
     // ---- iteration begin: FinalizeIterationAndCheckIfMinimizerCanContinue() of the previous iteration -------------
     if (tid == 0) {
+        // the five state words in one round trip (read one after the other behind the short-circuit tests they were five dependent global loads)
+        const int done = st->done, iteration = st->iteration, reuse = st->reuse;
+        const double gmn = st->gradient_max_norm, radius = st->radius;
         int go = 1;
-        if (st->done) go = 0;
-        else if (st->iteration >= b.max_iterations) { st->done = 1; st->termination = 0; go = 0; }
-        else if (st->gradient_max_norm <= b.gradient_tolerance) { st->done = 1; st->termination = 3; go = 0; }
-        else if (st->radius <= b.min_radius) { st->done = 1; st->termination = 4; go = 0; }
-        if (go) st->iteration += 1;
+        if (done) go = 0;
+        else if (iteration >= b.max_iterations) { st->done = 1; st->termination = 0; go = 0; }
+        else if (gmn <= b.gradient_tolerance) { st->done = 1; st->termination = 3; go = 0; }
+        else if (radius <= b.min_radius) { st->done = 1; st->termination = 4; go = 0; }
+        if (go) st->iteration = iteration + 1;
         s_flag[0] = go;
-        s_flag[1] = go ? st->reuse : 1;
+        s_flag[1] = go ? reuse : 1;
     }
     __syncthreads();
     if (!s_flag[0] || s_flag[1]) return;     // done, or the previous Gauss-Newton step is re-used (rejected step)
