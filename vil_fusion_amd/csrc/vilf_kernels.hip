@@ -575,6 +575,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 // ------------------------------------------------------------------------------------------------------------------
 // k_solve helpers
 
+// LDS accumulate without the read-modify-write round trip: inside one barrier-separated assembly phase every tile entry receives at most one
+// addend, so the hardware ds_add_f64 gives the same sum as `+=` — but several of them are in flight per thread instead of one dependent
+// read -> add -> write chain per element (the compiler must order plain `+=` on possibly aliasing offsets)
+__device__ __forceinline__ void lds_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 // 16x16 lower Cholesky of the diagonal tile by ONE wave. Lane r (< 16; the other lanes mirror lane r & 15) holds row r in 16
 // registers. Left-looking column sweep: for column j the pivot row L[j][0..j-1] is broadcast through SGPRs (v_readlane with a
 // compile-time lane), so there is no LDS / ds_bpermute round trip on the pivot chain; the update terms of column j+1 that do not
@@ -616,10 +621,6 @@ __device__ __forceinline__ void tile_add(double *s_T, int r, int c, double v) {
     if (tr >= tc) s_T[tile_index(tr, tc) * 256 + TIX(r & 15, c & 15)] += v;
 }
 
-// LDS accumulate without the read-modify-write round trip: inside one barrier-separated assembly phase every tile entry receives at most one
-// addend, so the hardware ds_add_f64 gives the same sum as `+=` — but several of them are in flight per thread instead of one dependent
-// read -> add -> write chain per element (the compiler must order plain `+=` on possibly aliasing offsets)
-__device__ __forceinline__ void lds_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #define SNT 512
 #define SNW (SNT / 64)
 // wave butterflies, then the eight wave sums added in wave order by every thread: three barriers instead of eleven (k_solve owns its CU:
@@ -697,22 +698,16 @@ __device__ __forceinline__ void schur_mfma(const double *W, int F, const double 
     for (int gsel = 0; gsel < 4; gsel++) {
         if (grp == gsel) {
 #pragma unroll
-            for (int i = 0; i < NP; i++) {       // one tile at a time: 4 LDS reads in flight, subtract, write back (keeps the epilogue's register need at one tile)
+            for (int i = 0; i < NP; i++) {       // subtract this group's partial with LDS fp64 atomics: no read-back latency; the groups take turns, so the order of the four subtractions is fixed
                 const int ta = TA[PB + i], tb = TB[PB + i];
                 double *T = s_T + tile_index(ta, tb) * 256;
-                double tv[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const int rl = g4 + 4 * q;                        // row inside the tile
-                    if (ta < 4) tv[q] = T[TIX(rl, c16)];
-                    else tv[q] = (rl < 2) ? T[TIX(rl, c16)] : ((rl == 2) ? s_y[16 * tb + c16] : ((rl == 3) ? s_t[16 * tb + c16] : 0.0));   // tile row 4: rows 64, 65 | row 66 = rhs | row 67 = Cauchy column
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int rl = g4 + 4 * q, col = 16 * tb + c16;
-                    const double nv = tv[q] - acc[i][q];
-                    if (ta < 4) { if (col < VB_NPOSE) T[TIX(rl, c16)] = nv; }
-                    else if (col < VB_NPOSE) { if (rl < 2) T[TIX(rl, c16)] = nv; else if (rl == 2) s_y[col] = nv; else if (rl == 3) s_t[col] = nv; }
+                    const int rl = g4 + 4 * q, col = 16 * tb + c16;   // row inside the tile; tile row 4: rows 64, 65 | row 66 = rhs | row 67 = Cauchy column
+                    if (col >= VB_NPOSE) continue;
+                    if (ta < 4 || rl < 2) lds_add(&T[TIX(rl, c16)], -acc[i][q]);
+                    else if (rl == 2) lds_add(&s_y[col], -acc[i][q]);
+                    else if (rl == 3) lds_add(&s_t[col], -acc[i][q]);
                 }
             }
         }
