@@ -148,6 +148,13 @@ VD void ypr2R(const double *ypr, double *R) {
 // Cauchy(a): rho0 = b log(1+s/b), rho1 = 1/(1+s/b); rho2 < 0 always => the Corrector reduces to sqrt(rho1) scaling
 // (marginalization_factor.cpp:45-49 / ceres corrector.cc).
 // 1/sqrt(x) in fp64: v_rsq_f64 seed (~2^-23 relative) + two Newton steps
+// the same from ONE third-order step (e = 1 - x y^2; y (1 + e/2 + 3 e^2/8)): seed error 2^-23 cubed is below fp64 resolution and the dependent
+// chain is four operations instead of eight — for the pivot chain of the tile Cholesky, where nothing else hides it
+VD double rsqrt_h3(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-x * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
+}
 VD double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     double e = fma(-x * y, y, 1.0);

@@ -597,7 +597,7 @@ __device__ bool potrf_tile_wave(double *T, double *s_invd, int lane) {
     for (int j = 0; j < 16; j++) {
         const double djj = readlane_f64(v[j], j);
         if (!(djj > 0.0)) ok = false;
-        const double inv = rsqrt_nr(djj);                       // long dependent chain: independent work below hides it
+        const double inv = rsqrt_h3(djj);                       // the pivot chain: one third-order step after the v_rsq_f64 seed
         // L[r][j] for r >= j; rows r < j keep junk in v[j] (upper triangle, never read)
         const double lrj = v[j] * inv;
         v[j] = lrj;
