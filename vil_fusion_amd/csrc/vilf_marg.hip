@@ -890,7 +890,7 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
                     gq = c * ei;
                     hq = c * p;
                     const double rr = p * p + ei * ei;
-                    const double inv = rr > 0.0 ? rsqrt_nr(rr) : 0.0;
+                    const double inv = rr > 0.0 ? rsqrt_h3(rr) : 0.0;
                     r = rr * inv;
                     e[64 * (i + 1)] = s * r;
                     s = ei * inv;
