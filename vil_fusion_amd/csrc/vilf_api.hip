@@ -120,7 +120,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
         hipFuncSetAttribute((const void *)k_prior_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VILF_PRIOR_PREP_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->marg_lds_finish + VILF_MFA_LDS_EXTRA)) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * 64 * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
+        hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * QL_LPW * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
         delete h; return VILF_ERR_DEVICE;
@@ -693,7 +693,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     // prior output per workgroup); k_marg_finish (everything in one workgroup) only takes windows whose rotation log overflowed
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
-    hipLaunchKernelGGL(k_mf_ql, dim3((h->B + QL_LPW - 1) / QL_LPW), dim3(64), (size_t)2 * (MG_NK + 2) * 64 * sizeof(double), h->stream, h->batch, g,
+    hipLaunchKernelGGL(k_mf_ql, dim3((h->B + QL_LPW - 1) / QL_LPW), dim3(64), (size_t)2 * (MG_NK + 2) * QL_LPW * sizeof(double), h->stream, h->batch, g,
                        std::getenv("VILF_MARG_FORCE_QL_FALLBACK") ? 1 : 0);        // test hook
     hipLaunchKernelGGL(k_mf_apply, grid, block, (size_t)77 * 77 * sizeof(double) + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 0, 78);
     hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 78, 1 << 30);

@@ -831,9 +831,9 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
     qi[0] = 0; qi[1] = 0; qi[2] = 0;
     if (info[0] != 0) return;
     const int n = info[3];
-    double *d = s_de + lane, *e = s_de + (MG_NK + 2) * 64 + lane;          // element i at [64 * i] (row stride 64 for any QL_LPW)
+    double *d = s_de + lane, *e = s_de + (MG_NK + 2) * QL_LPW + lane;      // element i at [QL_LPW * i]: 6 KB of LDS per wave, several waves per CU
     double *dg = g.qlD + (size_t)w * 2 * (MG_NK + 2);
-    for (int i = 0; i < n; i++) { d[64 * i] = dg[i]; e[64 * i] = dg[MG_NK + 2 + i]; }
+    for (int i = 0; i < n; i++) { d[QL_LPW * i] = dg[i]; e[QL_LPW * i] = dg[MG_NK + 2 + i]; }
     double *lg = g.qlLog + (size_t)w * 2 * QL_RCAP;
     int *itab = g.qlIt + (size_t)w * QL_ICAP;
     int ni = 0, nr = 0;
@@ -841,12 +841,12 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
     double f = 0.0, tst1 = 0.0;
     const double eps = 2.220446049250313e-16;
     for (int l = 0; l < n && !over; l++) {
-        tst1 = fmax(tst1, fabs(d[64 * l]) + fabs(e[64 * l]));
+        tst1 = fmax(tst1, fabs(d[QL_LPW * l]) + fabs(e[QL_LPW * l]));
         int m = l;
         while (m < n) {                              // first negligible sub-diagonal element at or after l, eight candidates per LDS round trip
             double t8[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) t8[u] = e[64 * min(m + u, n - 1)];
+            for (int u = 0; u < 8; u++) t8[u] = e[QL_LPW * min(m + u, n - 1)];
             int first = 8;
 #pragma unroll
             for (int u = 7; u >= 0; u--) if (m + u < n && fabs(t8[u]) <= eps * tst1) first = u;
@@ -859,57 +859,57 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
             for (;;) {
                 if (ni >= QL_ICAP || nr + (m - l) > QL_RCAP) { over = true; break; }
                 iter++;
-                double gq = d[64 * l];
-                double p = (d[64 * (l + 1)] - gq) / (2.0 * e[64 * l]);
+                double gq = d[QL_LPW * l];
+                double p = (d[QL_LPW * (l + 1)] - gq) / (2.0 * e[QL_LPW * l]);
                 double r = hypot(p, 1.0);
                 if (p < 0) r = -r;
-                d[64 * l] = e[64 * l] / (p + r);
-                d[64 * (l + 1)] = e[64 * l] * (p + r);
-                const double dl1 = d[64 * (l + 1)];
-                double hq = gq - d[64 * l];
+                d[QL_LPW * l] = e[QL_LPW * l] / (p + r);
+                d[QL_LPW * (l + 1)] = e[QL_LPW * l] * (p + r);
+                const double dl1 = d[QL_LPW * (l + 1)];
+                double hq = gq - d[QL_LPW * l];
                 {   // the shift of the remaining diagonal, eight loads in flight (one dependent LDS round trip per element cost a third of the kernel)
                     int i = l + 2;
                     for (; i + 7 < n; i += 8) {
                         double t8[8];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) t8[u] = d[64 * (i + u)];
+                        for (int u = 0; u < 8; u++) t8[u] = d[QL_LPW * (i + u)];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) d[64 * (i + u)] = t8[u] - hq;
+                        for (int u = 0; u < 8; u++) d[QL_LPW * (i + u)] = t8[u] - hq;
                     }
-                    for (; i < n; i++) d[64 * i] -= hq;
+                    for (; i < n; i++) d[QL_LPW * i] -= hq;
                 }
                 f += hq;
-                p = d[64 * m];
+                p = d[QL_LPW * m];
                 double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
-                const double el1 = e[64 * (l + 1)];
-                double ei = e[64 * (m - 1)], di = d[64 * (m - 1)];           // operands of the next step are fetched one step ahead: the LDS
+                const double el1 = e[QL_LPW * (l + 1)];
+                double ei = e[QL_LPW * (m - 1)], di = d[QL_LPW * (m - 1)];           // operands of the next step are fetched one step ahead: the LDS
                 for (int i = m - 1; i >= l; i--) {                            // latency stays off the dependent chain p -> rr -> inv -> c -> p
                     const int ip = max(i - 1, l);
-                    const double ei_n = e[64 * ip], di_n = d[64 * ip];
+                    const double ei_n = e[QL_LPW * ip], di_n = d[QL_LPW * ip];
                     c3 = c2; c2 = c; s2 = s;
                     gq = c * ei;
                     hq = c * p;
                     const double rr = p * p + ei * ei;
                     const double inv = rr > 0.0 ? rsqrt_h3(rr) : 0.0;
                     r = rr * inv;
-                    e[64 * (i + 1)] = s * r;
+                    e[QL_LPW * (i + 1)] = s * r;
                     s = ei * inv;
                     c = p * inv;
                     p = c * di - s * gq;
-                    d[64 * (i + 1)] = hq + s * (c * gq + s * di);
+                    d[QL_LPW * (i + 1)] = hq + s * (c * gq + s * di);
                     *reinterpret_cast<double2 *>(lg + 2 * nr) = make_double2(c, s); nr++;   // rotation of columns (i, i + 1), logged in application order
                     ei = ei_n; di = di_n;
                 }
-                p = -s * s2 * c3 * el1 * e[64 * l] / dl1;
-                e[64 * l] = s * p;
-                d[64 * l] = c * p;
+                p = -s * s2 * c3 * el1 * e[QL_LPW * l] / dl1;
+                e[QL_LPW * l] = s * p;
+                d[QL_LPW * l] = c * p;
                 itab[ni++] = l | (m << 8);
-                if (!(fabs(e[64 * l]) > eps * tst1 && iter < 64)) break;
+                if (!(fabs(e[QL_LPW * l]) > eps * tst1 && iter < 64)) break;
             }
         }
-        if (!over) { d[64 * l] += f; e[64 * l] = 0.0; }
+        if (!over) { d[QL_LPW * l] += f; e[QL_LPW * l] = 0.0; }
     }
-    for (int i = 0; i < n; i++) dg[i] = d[64 * i];                          // eigenvalues
+    for (int i = 0; i < n; i++) dg[i] = d[QL_LPW * i];                          // eigenvalues
     qi[0] = ni; qi[1] = nr; qi[2] = over ? 1 : 0;
 }
 #define MFA_CH 64            // rotations per staged chunk of k_mf_apply (two buffers of 1 KB)
