@@ -58,7 +58,7 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
 #define MG_PAIRM 400        // per pair (0,j): 19x19 (+19 rhs) products, stored 20x20
 #define QL_RCAP 12288        // rotations logged per window by k_mf_ql (typical: ~5 k for n = 75)
 #define QL_ICAP 768          // QL iterations logged per window
-#define QL_LPW 8            // windows per wave of k_mf_ql
+#define QL_LPW 16           // windows per wave of k_mf_ql (8: faster at 2048 windows, slower at 4096)
 #define MG_GCH 48           // factor rows staged per chunk in the pair gather of k_marg_prepare (15 KB of LDS)
 #define MG_MLDS 136         // largest Amm held in LDS by the Jacobi eigen-solver
 #define MG_INFO 128         // per window: [0] status [1] md [2] mf [3] n [4] m [5] nblocks [6] M(padded) [8..31] shifted ids [32..55] sizes
