@@ -62,7 +62,10 @@ typedef struct vilf_handle vilf_handle;
 typedef struct vilf_options {
     int window_size;          /* WINDOW_SIZE = 10 */
     int max_num_iterations;   /* NUM_ITERATIONS = 8 (kitti_config.yaml:74) */
-    double max_solver_time;   /* SOLVER_TIME seconds; <= 0 disables the wall-clock limit (parity runs) */
+    double max_solver_time;   /* SOLVER_TIME seconds (estimator.cpp:847-850); <= 0 disables the wall-clock limit (parity runs). When > 0 the
+                               * solve tests the host clock at the top of every iteration, as Ceres does; windows whose marginalization_flag is
+                               * VILF_MARGIN_OLD get 4/5 of it (the factor the reference applies). A stopped window reports VILF_TERM_NO_CONVERGENCE
+                               * and keeps its last accepted state. The batched solve then waits for the stream once per iteration. */
     double focal_length;      /* FOCAL_LENGTH = 460; sqrt_info = focal/1.5 * I2 (estimator.cpp:17) */
     double cauchy_a;          /* CauchyLoss(1.0) (estimator.cpp:694) */
     double G[3];              /* global G (parameters.cpp:14,77) */

@@ -33,7 +33,7 @@ def test_projection_factor_hook(solver, oracle, opts):
         r, J = solver.eval_projection([Pi, Pj, ex, lam], pi, pj)
         r0, J0 = oracle.eval_factor("projection", opts, [Pi, Pj, ex, lam], pi, pj, sizes=[7, 7, 7, 1], nres=2)
         assert np.allclose(r, r0, rtol=1e-11, atol=1e-10)
-        for k in (0, 1, 3):
+        for k in (0, 1, 2, 3):            # Pose_i, Pose_j, Ex_Pose (projection_factor.cpp:97-104), inverse depth
             assert np.allclose(J[k], J0[k], rtol=1e-10, atol=1e-9 * max(1, np.abs(J0[k]).max()))
 
 

@@ -22,6 +22,7 @@ __global__ void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsign
 #define VILF_PRIOR_PREP_LDS ((size_t)(MG_NK + 1) * (MG_NK + 1) * sizeof(double))     // the n x n prior Jacobian in LDS (n <= 96: 73.5 KB, two workgroups per CU)
 __global__ void k_linearize(VbBatch b, int iteration_zero);
 __global__ void k_solve(VbBatch b);
+__global__ void k_solve_sb(VbBatch b);
 __global__ void k_step(VbBatch b);
 __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
@@ -33,6 +34,8 @@ __global__ void k_mf_ql(VbBatch b, VbMarg g, int force_overflow);
 __global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
 #define VILF_MFA_LDS_EXTRA (4 * 64 * 8 + QL_ICAP * 2)      // k_mf_apply behind V: two staged chunks of the rotation log (MFA_CH = 64) + the 16-bit QL iteration table
 __global__ void k_hook_projection(const double *, const double *, const double *, double, const double *, const double *, double, double *);
+__global__ void k_hook_projection_td(const double *in, double *out);
+__global__ void k_time_limit(VbBatch b, const int *mflag, int only_margin_old);
 __global__ void k_hook_imu(const double *, const double *, const double *, const double *, const double *, const double *, double *, double *);
 __global__ void k_hook_lidar(const double *, const double *, const double *, const double *, const double *, double *);
 __global__ void k_hook_edge(const double *, const double *, const double *, const double *, double *);
@@ -112,6 +115,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + 512 + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
     h->lin_lds = (size_t)VB_LIN_LDS_DOUBLES * sizeof(double);
+    h->solve_sb_lds = (size_t)SB_LDS_DOUBLES * sizeof(double);
     static_assert(VB_LIN_LDS_DOUBLES >= 10 * 512, "IMU staging area");
     h->marg_lds_schur = (size_t)MG_MLDS * MG_MLDS * sizeof(double);
     h->marg_lds_finish = (size_t)(MG_NK + 2) * (MG_NK + 2) * sizeof(double);
@@ -122,7 +126,8 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
         hipFuncSetAttribute((const void *)k_mf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->marg_lds_finish + VILF_MFA_LDS_EXTRA)) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * QL_LPW * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess) {
+        hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_sb_lds) != hipSuccess) {
         delete h; return VILF_ERR_DEVICE;
     }
     std::memset(&h->batch, 0, sizeof(h->batch));
@@ -197,6 +202,7 @@ static int upload_priors(vilf_handle *h) {
         const vilf_prior &p = h->priors[w];
         h->prior_dev_newer[w] = 0;
         if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > 2 * VB_NF) { h->err = "prior touches Td / feature blocks: unsupported"; return VILF_ERR_UNSUPPORTED; }
+        if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > VB_NF && p.block_id[i] < 2 * VB_NF) h->solve_dense_fallback = true;
     }
     auto fill = [&](const vilf_prior &p, int *hd, double *x0) {
         std::memset(hd, 0, VB_PRIOR_HDR * sizeof(int)); std::memset(x0, 0, 24 * 9 * sizeof(double));
@@ -266,8 +272,12 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             h->err = "null input array"; return VILF_ERR_INVALID_ARGUMENT;
         }
         if (h->opts.use_lidar_const && !in.lidar) { h->err = "lidar constraints missing (use_lidar_const = 1)"; return VILF_ERR_INVALID_ARGUMENT; }
+        // the observation CSR must be exactly [0 .. n_obs): the packer indexes obs_point / the factor arrays through it
+        if (in.n_obs < 0 || (in.n_features && (in.feature_obs_offset[0] != 0 || in.feature_obs_offset[in.n_features] != in.n_obs)) || (!in.n_features && in.n_obs != 0)) {
+            h->err = "feature_obs_offset must start at 0 and end at n_obs"; return VILF_ERR_INVALID_ARGUMENT;
+        }
         for (int f = 0; f < in.n_features; f++) {
-            const int s = in.feature_start_frame[f], n = in.feature_obs_offset[f + 1] - in.feature_obs_offset[f];
+            const int s = in.feature_start_frame[f], n = in.feature_obs_offset[f + 1] - in.feature_obs_offset[f];     // n >= 2 also makes the offsets increasing
             if (s < 0 || n < 2 || s + n > VB_NF) { h->err = "feature track outside the window"; return VILF_ERR_INVALID_ARGUMENT; }
         }
         Fmax = std::max(Fmax, in.n_features); Omax = std::max(Omax, in.n_obs); FACmax = std::max(FACmax, in.n_obs - in.n_features);
@@ -300,7 +310,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
         {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_DIAGH, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
         {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
-        {D_OBGS, sB * 33 * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8}, {D_FACREC, sB * sC * 64}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
+        {D_OBGS, sB * 33 * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8}, {D_FACREC, sB * sC * 64}, {D_CF, sB * sF * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed"; return VILF_ERR_DEVICE; }
 
@@ -427,6 +437,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.prior_H = h->d[D_PH].as<double>(); b.prior_g = h->d[D_PG].as<double>();
     b.facw = h->d[D_FACW].as<double>(); b.Hpp = h->d[D_HPP].as<double>(); b.W = h->d[D_W].as<double>(); b.hf = h->d[D_HF].as<double>(); b.gf = h->d[D_GF].as<double>();
     b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>(); b.diagH = h->d[D_DIAGH].as<double>(); b.pairD = h->d[D_PAIRD].as<double>();
+    b.cf = h->d[D_CF].as<double>();
     b.scale = h->d[D_SCALE].as<double>(); b.diag = h->d[D_DIAG].as<double>(); b.grad = h->d[D_GRAD].as<double>(); b.gn = h->d[D_GN].as<double>();
     b.st = h->d[D_ST].as<VbState>();
     b.out_Ps = h->d[D_OPS].as<double>(); b.out_Rs = h->d[D_ORS].as<double>(); b.out_Vs = h->d[D_OVS].as<double>();
@@ -457,6 +468,56 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         HIPCHECK(h, hipMemcpy(h->d[D_LUTL].p, ll.data(), ll.size() * 4, hipMemcpyHostToDevice));
         HIPCHECK(h, hipMemcpy(h->d[D_LUTV].p, lv.data(), lv.size() * 4, hipMemcpyHostToDevice));
         h->batch.lut_imu = h->d[D_LUTI].as<int>(); h->batch.lut_lid = h->d[D_LUTL].as<int>(); h->batch.lut_vis = h->d[D_LUTV].as<int>();
+    }
+    {   // gather tables of k_solve_sb (same for every window): destination entry of the LDS system -> source elements of Hpp / imuH / lidH.
+        // meta = LDS offset (14 bits) | permuted row index << 14 | permuted column index << 22; a source of -1 is absent.
+        auto meta = [](int dst, int r, int c) { return dst | (r << 14) | (c << 22); };
+        auto prow = [](int r) { return r * (r + 1) / 2; };
+        std::vector<int> la, lb, lc;
+        for (int r = 0; r < VB_NPOSE; r++) for (int c = 0; c <= r; c++) {           // pose-pose: H(6A+la, 6Bf+lb), A >= Bf
+            const int A = r / 6, l1 = r % 6, Bf = c / 6, l2 = c % 6;
+            int imu0 = -1, imu1 = -1, lid0 = -1, lid1 = -1;
+            if (A == Bf) {
+                if (A >= 1) { imu0 = 900 * (A - 1) + 30 * (15 + l1) + 15 + l2; lid0 = 144 * (A - 1) + 12 * (6 + l1) + 6 + l2; }
+                if (A <= 9) { imu1 = 900 * A + 30 * l1 + l2; lid1 = 144 * A + 12 * l1 + l2; }
+            } else if (A == Bf + 1) { imu0 = 900 * Bf + 30 * (15 + l1) + l2; lid0 = 144 * Bf + 12 * (6 + l1) + l2; }
+            const int e[8] = {meta(SB_OFF_P + prow(r) + c, r, c), 36 * (A * (A + 1) / 2 + Bf) + 6 * l1 + l2, imu0, imu1, lid0, lid1, 0, 0};
+            la.insert(la.end(), e, e + 8);
+        }
+        for (int i = 0; i < 9; i++) for (int c = 0; c <= VB_NPOSE + i; c++) {      // SpeedBias[0] rows of the dense block: IMU factor 0 (rows 6 + i) + prior
+            const int r = VB_NPOSE + i;
+            int src = -1;
+            if (c < VB_NPOSE) { const int Bf = c / 6, l2 = c % 6; if (Bf <= 1) src = 30 * (6 + i) + (Bf == 0 ? l2 : 15 + l2); }
+            else src = 30 * (6 + i) + 6 + (c - VB_NPOSE);
+            lb.push_back(meta(SB_OFF_P + prow(r) + c, r, c)); lb.push_back(src);
+        }
+        for (int a = 1; a <= SB_NCH; a++) {                                         // chain: SpeedBias[a]; IMU factor a-1 holds it as rows 21.., factor a as rows 6..
+            const int ra = VB_NPOSE + 9 * a;
+            for (int i = 0; i < 9; i++) for (int j = 0; j <= i; j++) {              // D_a (lower)
+                const int e[4] = {meta(SB_OFF_D + 81 * (a - 1) + 9 * i + j, ra + i, ra + j), 900 * (a - 1) + 30 * (21 + i) + 21 + j, a <= 9 ? 900 * a + 30 * (6 + i) + 6 + j : -1, 0};
+                lc.insert(lc.end(), e, e + 4);
+            }
+            if (a <= 9) for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) {   // E_a = H(SpeedBias[a+1], SpeedBias[a])
+                const int e[4] = {meta(SB_OFF_E + 81 * (a - 1) + 9 * i + j, ra + 9 + i, ra + j), 900 * a + 30 * (21 + i) + 6 + j, -1, 0};
+                lc.insert(lc.end(), e, e + 4);
+            }
+            for (int i = 0; i < 9; i++) {                                           // band_a: [Pose a-1 | Pose a | Pose a+1 | SpeedBias[0] (a = 1)]
+                const int dst = SB_OFF_BAND + (9 * (a - 1) + i) * SB_BLD;
+                for (int m = 0; m < 6; m++) {
+                    const int e0[4] = {meta(dst + m, ra + i, 6 * (a - 1) + m), 900 * (a - 1) + 30 * (21 + i) + m, -1, 0};
+                    const int e1[4] = {meta(dst + 6 + m, ra + i, 6 * a + m), 900 * (a - 1) + 30 * (21 + i) + 15 + m, a <= 9 ? 900 * a + 30 * (6 + i) + m : -1, 0};
+                    lc.insert(lc.end(), e0, e0 + 4); lc.insert(lc.end(), e1, e1 + 4);
+                    if (a <= 9) { const int e2[4] = {meta(dst + 12 + m, ra + i, 6 * (a + 1) + m), 900 * a + 30 * (6 + i) + 15 + m, -1, 0}; lc.insert(lc.end(), e2, e2 + 4); }
+                }
+                if (a == 1) for (int j = 0; j < 9; j++) { const int e3[4] = {meta(dst + 18 + j, ra + i, VB_NPOSE + j), 30 * (21 + i) + 6 + j, -1, 0}; lc.insert(lc.end(), e3, e3 + 4); }
+            }
+        }
+        if (!h->d[D_LUTSBA].ensure(la.size() * 4) || !h->d[D_LUTSBB].ensure(lb.size() * 4) || !h->d[D_LUTSBC].ensure(lc.size() * 4)) return VILF_ERR_DEVICE;
+        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBA].p, la.data(), la.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBB].p, lb.data(), lb.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBC].p, lc.data(), lc.size() * 4, hipMemcpyHostToDevice));
+        h->batch.lut_sba = h->d[D_LUTSBA].as<int>(); h->batch.lut_sbb = h->d[D_LUTSBB].as<int>(); h->batch.lut_sbc = h->d[D_LUTSBC].as<int>();
+        h->batch.n_sba = (int)la.size() / 8; h->batch.n_sbb = (int)lb.size() / 2; h->batch.n_sbc = (int)lc.size() / 4;
     }
     const int nimu = B * 10;
     hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
@@ -500,6 +561,9 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true;
     if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; }
     const dim3 grid(h->B), block(VB_NT);
+    // k_solve_sb eliminates SpeedBias[1..10] as a block-tridiagonal chain: valid while the priors hold no speed-bias block but SpeedBias[0] (all the
+    // reference ever produces, estimator.cpp:960-971); VILF_SOLVE_DENSE=1 forces the dense-Cholesky kernel (tests compare the two)
+    const bool dense = h->solve_dense_fallback || std::getenv("VILF_SOLVE_DENSE") != nullptr;
     const int nlaunch = 3 * h->opts.max_num_iterations + 3;
     const bool prof = h->profiling != 0;
     if (prof && (int)h->pev.size() < nlaunch + 1) { while ((int)h->pev.size() < nlaunch + 1) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); } }
@@ -511,9 +575,22 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
     mark(0);
     hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 1);
+    // options.max_solver_time (estimator.cpp:847-850: SOLVER_TIME, x 4/5 when the oldest frame is marginalized): Ceres tests the wall clock at the top of
+    // every iteration. The iterations of a batch run in lockstep, so the host waits for the stream before each one (only when the limit is on) and
+    // stops the windows whose limit has passed (termination NO_CONVERGENCE, like Ceres' "maximum solver time reached").
+    const double tlim = h->opts.max_solver_time;
+    const auto t_begin = std::chrono::steady_clock::now();
+    bool stopped_old = false;
     for (int it = 0; it < h->opts.max_num_iterations; it++) {
+        if (tlim > 0) {
+            HIPCHECK(h, hipStreamSynchronize(h->stream));
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+            if (el >= tlim) { hipLaunchKernelGGL(k_time_limit, grid, dim3(64), 0, h->stream, h->batch, h->d[D_MFLAG].as<int>(), 0); break; }
+            if (el >= tlim * 4.0 / 5.0 && !stopped_old) { hipLaunchKernelGGL(k_time_limit, grid, dim3(64), 0, h->stream, h->batch, h->d[D_MFLAG].as<int>(), 1); stopped_old = true; }
+        }
         mark(1);
-        hipLaunchKernelGGL(k_solve, grid, dim3(512), h->solve_lds, h->stream, h->batch);
+        if (dense) hipLaunchKernelGGL(k_solve, grid, dim3(512), h->solve_lds, h->stream, h->batch);
+        else hipLaunchKernelGGL(k_solve_sb, grid, dim3(256), h->solve_sb_lds, h->stream, h->batch);
         mark(2);
         hipLaunchKernelGGL(k_step, grid, block, 0, h->stream, h->batch);
         mark(0);
@@ -631,6 +708,12 @@ extern "C" int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_
 extern "C" int vilf_prior_import(vilf_handle *h, int slot, const vilf_prior *prior) {
     if (!h || slot < 0 || !prior) return VILF_ERR_INVALID_ARGUMENT;
     if (prior->valid && (prior->n <= 0 || prior->n > VILF_PRIOR_MAX_DIM || prior->n_blocks <= 0 || prior->n_blocks > VILF_PRIOR_MAX_BLOCKS)) return VILF_ERR_INVALID_ARGUMENT;
+    if (prior->valid) {          // block table: global sizes 7 (pose), 9 (speed-bias) or 1 (td), local columns inside [0, n) — the kernels index LDS vectors with it
+        for (int i = 0; i < prior->n_blocks; i++) {
+            const int gs = prior->block_size[i], ls = gs == 7 ? 6 : gs, idx = prior->block_idx[i];
+            if ((gs != 7 && gs != 9 && gs != 1) || prior->block_id[i] < 0 || idx < 0 || idx + ls > prior->n) { h->err = "prior block table out of range"; return VILF_ERR_INVALID_ARGUMENT; }
+        }
+    }
     if ((int)h->priors.size() <= slot) { vilf_prior z; std::memset(&z, 0, sizeof(z)); h->priors.resize(slot + 1, z); h->prior_dirty.resize(slot + 1, 1); }
     h->priors[slot] = *prior;
     h->prior_dirty[slot] = 1;
@@ -746,7 +829,7 @@ static int hook_buf(vilf_handle *h, size_t doubles) { return h->d[D_HOOK].ensure
 
 extern "C" int vilf_eval_projection(vilf_handle *h, const double *const *p, const double pts_i[3], const double pts_j[3], double *residuals, double **jac) {
     if (!h || !p || !residuals) return VILF_ERR_INVALID_ARGUMENT;
-    if (hook_buf(h, 128) != VILF_OK) return VILF_ERR_DEVICE;
+    if (hook_buf(h, 256) != VILF_OK) return VILF_ERR_DEVICE;
     double in[32];
     std::memcpy(in, p[0], 56); std::memcpy(in + 7, p[1], 56); std::memcpy(in + 14, p[2], 56);
     std::memcpy(in + 21, pts_i, 24); std::memcpy(in + 24, pts_j, 24);
@@ -760,13 +843,23 @@ extern "C" int vilf_eval_projection(vilf_handle *h, const double *const *p, cons
     if (jac) {
         for (int blk = 0; blk < 2; blk++)
             if (jac[blk]) for (int r = 0; r < 2; r++) { for (int c = 0; c < 6; c++) jac[blk][7 * r + c] = out[2 + 12 * blk + 6 * r + c]; jac[blk][7 * r + 6] = 0; }
-        if (jac[2]) return VILF_ERR_UNSUPPORTED;    // extrinsic jacobian: estimate_extrinsic = 1 is not built on the device
+        if (jac[2]) {                               // Ex_Pose block (projection_factor.cpp:97-104): the device routine of the general path (ProjectionTdFactor with td = td_i = td_j, zero velocity
+                                                    // = ProjectionFactor); its residual and other blocks are the same function of the same inputs
+            double in2[40] = {0};
+            std::memcpy(in2, in, 27 * 8);
+            in2[31] = p[3][0]; in2[37] = 0.0; in2[38] = h->opts.focal_length / 1.5;
+            HIPCHECK(h, hipMemcpyAsync(d + 64, in2, sizeof(in2), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_hook_projection_td, dim3(1), dim3(64), 0, h->stream, d + 64, d + 64 + 40);
+            double out2[42];
+            HIPCHECK(h, hipMemcpyAsync(out2, d + 64 + 40, sizeof(out2), hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipStreamSynchronize(h->stream));
+            for (int r = 0; r < 2; r++) { for (int c = 0; c < 6; c++) jac[2][7 * r + c] = out2[26 + 6 * r + c]; jac[2][7 * r + 6] = 0; }
+        }
         if (jac[3]) { jac[3][0] = out[26]; jac[3][1] = out[27]; }
     }
     return VILF_OK;
 }
 
-extern "C" __global__ void k_hook_projection_td(const double *in, double *out);
 extern "C" int vilf_eval_projection_td(vilf_handle *h, const double *const *p, const double pts_i[3], const double pts_j[3], const double vel_i[2], const double vel_j[2],
                                        double td_i, double td_j, double row_i, double row_j, double *residuals, double **jac) {
     if (!h || !p || !residuals || !pts_i || !pts_j || !vel_i || !vel_j) return VILF_ERR_INVALID_ARGUMENT;

@@ -35,6 +35,30 @@
 #define VB_PRIOR_HDR 80     // valid, n, nblocks, ids[24], sizes[24], idx[24]
 #define VB_PRIOR_LD 160
 
+// ---- k_solve_sb: speed-bias-first elimination (vilf_kernels.hip) -------------------------------------------------------
+// After the feature Schur complement the speed-bias part of the reduced system is block tridiagonal (an IMU factor couples consecutive frames only,
+// estimator.cpp:742-749; the prior holds SpeedBias[0] alone). SpeedBias[1..10] ("chain" blocks) are eliminated first, newest frame first; the poses and
+// SpeedBias[0] (which the prior couples to every pose) form the dense block: 66 + 9 = 75 variables, row 75 = right-hand side, row 76 = Cauchy-point row.
+#define SB_ND 75            // dense variables (permuted indices 0..74: poses, SpeedBias[0])
+#define SB_NR 76            // rows of the packed lower-triangular dense system (SB_ND + the right-hand side row)
+#define SB_NCH 10           // chain blocks: SpeedBias[1..10]
+#define SB_BLD 28           // band row stride: [pose a-1 | pose a | pose a+1 | SpeedBias[0] (a = 1 only) | rhs]
+#define SB_YLD 80           // row stride of the Y_a buffer (12 rows: 9 + 3 zero rows = 3 MFMA k-steps)
+#define SB_OFF_P 0
+#define SB_OFF_D (SB_OFF_P + SB_NR * (SB_NR + 1) / 2)            // 2926
+#define SB_OFF_E (SB_OFF_D + SB_NCH * 81)                         // 3736
+#define SB_OFF_BAND (SB_OFF_E + (SB_NCH - 1) * 81)                // 4465
+#define SB_OFF_Y (SB_OFF_BAND + SB_NCH * 9 * SB_BLD)              // 6985
+#define SB_OFF_VEC (SB_OFF_Y + 12 * SB_YLD)                       // 7945: g~, diagonal_, scale, y, v (168 each)
+#define SB_VLD 168
+#define SB_OFF_T (SB_OFF_VEC + 5 * SB_VLD)                        // Cauchy-point row (80)
+#define SB_OFF_LINV (SB_OFF_T + 80)                               // 1 / L_ii of the chain blocks (96)
+#define SB_OFF_INVD (SB_OFF_LINV + 96)                            // 1 / L_jj of the dense block (80)
+#define SB_OFF_COL (SB_OFF_INVD + 80)                             // current column of the dense factorisation, double-buffered (2 x 80)
+#define SB_OFF_U (SB_OFF_COL + 160)                               // chain right-hand side / forward solution (96)
+#define SB_OFF_RED (SB_OFF_U + 96)                                // block-sum scratch (16)
+#define SB_LDS_DOUBLES (SB_OFF_RED + 16)
+
 struct VbState {            // per-window trust-region state (ceres TrustRegionMinimizer + DoglegStrategy members)
     double x_cost, cand_cost, initial_cost;
     double radius, mu, alpha, dogleg_step_norm;
@@ -112,6 +136,9 @@ struct VbBatch {
                             // coalesced 64-byte record instead of five dependent gathers
     const double *imu, *lidar;
     const int *lut_imu, *lut_lid, *lut_vis;   // static scatter tables: source element -> LDS tile offset (or -1)
+    const int *lut_sba, *lut_sbb, *lut_sbc;   // k_solve_sb gather tables (destination entry -> source elements): pose-pose [n][8], SpeedBias[0] rows [n][2], chain [n][4]
+    int n_sba, n_sbb, n_sbc;
+    double *cf;             // [B][Fmax] per-feature Schur coefficient s_f / sqrt(h~_f'), then W_f . (S y)_p (k_solve_sb)
     const int *prior_hdr;
     const double *prior_x0, *prior_J, *prior_r, *prior_H, *prior_g;
     // workspace

@@ -1139,6 +1139,672 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// k_solve_sb — the same linear solve as k_solve (DoglegStrategy::ComputeStep on the Jacobi-scaled DENSE_SCHUR system), with the
+// speed-bias part eliminated FIRST. One 256-thread workgroup per window, 74 KB of LDS => two workgroups per CU.
+//
+//   H~ = [ dense (poses + SpeedBias[0], 75) | chain (SpeedBias[1..10], 10 x 9) ]: the chain part is block tridiagonal, its coupling to the dense part a
+//   band (SpeedBias[a] <-> Pose[a-1], Pose[a], Pose[a+1]; SpeedBias[1] <-> SpeedBias[0]). Phases:
+//   P1  gather assembly: one thread per DESTINATION entry sums its <= 6 source elements in a fixed order (host-built tables lut_sb*), scales, adds the LM
+//       term and stores — no atomics, no zero fill, one barrier; v^T H~ v of the Cauchy point rides along.
+//   P2  waves 0..2: MFMA Schur reduce of the inverse depths, U^T U in registers (5 of the 15 lower 16x16 tiles of the 80-wide dense block per wave)
+//       wave 3   : block-tridiagonal Cholesky of the chain, newest block first: L_a = chol(D_a), B_a = L_a^-1 E_(a-1), D_(a-1) -= B_a^T B_a
+//   P3  for a = 10..1: wave 3 forms Y_a = L_a^-1 (band_a - B_(a+1)^T Y_(a+1)) (two columns per lane, rhs as column 75); waves 0..2 add Y_a^T Y_a to the
+//       SAME accumulators (3 MFMA k-steps per tile)
+//   P4  dense -= accumulators (rows 0..74), rhs row 75, Cauchy row 76
+//   P5  Cholesky of the 75 + 1 dense rows: 4 x 4 register blocks, one thread per block of the lower triangle, ONE barrier per column (the column is
+//       broadcast through LDS, every thread recomputes the pivot's reciprocal square root) — no tile TRSM / POTRF chain
+//   P6  wave 0: back substitution of the dense block, then the chain forward / backward sweeps; waves 1..3: W_f . (S y)_p of every feature meanwhile
+//   P7  feature back-substitution, Gauss-Newton step, dogleg scalars (as k_solve)
+// Same arithmetic as a Cholesky of the whole system under another elimination order: results equal k_solve's to rounding.
+#define SBT 256
+#define SBW (SBT / 64)
+__device__ __forceinline__ double block_sum_sb(double v, double *s_red) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int k = 0; k < SBW; k++) r += s_red[k];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int sb_prow(int r) { return r * (r + 1) / 2; }
+
+// waves 0..2: U^T U of the feature rows into acc[5]. Every wave streams ALL rows (no K split: nothing to combine afterwards); tile lists are compile-time.
+//   dense columns 0..65 = W columns 0..65 (poses); 66..74 (SpeedBias[0]) = 0; 75 (rhs) = W column 66 (g_f); 76 (Cauchy row) = W column 67
+template <int WV> struct SbTiles;
+template <> struct SbTiles<0> { static constexpr int TA[5] = {0, 1, 1, 2, 2}, TB[5] = {0, 0, 1, 0, 1}; };
+template <> struct SbTiles<1> { static constexpr int TA[5] = {2, 3, 3, 4, 4}, TB[5] = {2, 2, 3, 2, 3}; };
+template <> struct SbTiles<2> { static constexpr int TA[5] = {3, 3, 4, 4, 4}, TB[5] = {0, 1, 0, 1, 4}; };
+template <int WV>
+__device__ __forceinline__ void sb_feature_reduce(const double *W, const double *cf, int F, const double *s_scale, double4_t (&acc)[5], int lane) {
+    constexpr const int *TA = SbTiles<WV>::TA, *TB = SbTiles<WV>::TB;
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int nsteps = ((F + 3) & ~3) / 4;
+    if (nsteps == 0) return;
+    double sc5[5];
+#pragma unroll
+    for (int t5 = 0; t5 < 4; t5++) sc5[t5] = s_scale[16 * t5 + c16];
+    sc5[4] = (c16 < 2) ? s_scale[64 + c16] : ((c16 == 11 || c16 == 12) ? 1.0 : 0.0);
+    const int col4 = (c16 < 2) ? 64 + c16 : (c16 == 11 ? VB_NPOSE : (c16 == 12 ? VB_NPOSE + 1 : VB_NPOSE + 2));   // W column 68 is never written: zero
+    double ra[5], rb[5], rc[5], ca, cb, cc;
+#define SBF_ISSUE(ST, R, C)                                                                                                        \
+    {                                                                                                                              \
+        const int row_ = 4 * min((ST), nsteps - 1) + g4;                                                                           \
+        const double *p0_ = W + (size_t)row_ * VB_WLD + c16, *p4_ = W + (size_t)row_ * VB_WLD + col4, *pc_ = cf + row_;             \
+        asm volatile("global_load_dwordx2 %0, %6, off\n\tglobal_load_dwordx2 %1, %6, off offset:128\n\t"                           \
+                     "global_load_dwordx2 %2, %6, off offset:256\n\tglobal_load_dwordx2 %3, %6, off offset:384\n\t"                \
+                     "global_load_dwordx2 %4, %7, off\n\tglobal_load_dwordx2 %5, %8, off"                                          \
+                     : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]), "=&v"(C) : "v"(p0_), "v"(p4_), "v"(pc_) : "memory"); \
+    }
+#define SBF_WAIT(N, R, C) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(C) : : "memory");
+#define SBF_STEP(R, C)                                                                                                             \
+    {                                                                                                                              \
+        double u[5];                                                                                                               \
+        _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) u[t5] = R[t5] * C * sc5[t5];                                              \
+        _Pragma("unroll") for (int i = 0; i < 5; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[TA[i]], u[TB[i]], acc[i], 0, 0, 0); \
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SBF_ISSUE(0, ra, ca) SBF_ISSUE(1, rb, cb)
+    for (int st = 0; st < nsteps; st += 3) {
+        SBF_ISSUE(st + 2, rc, cc) SBF_WAIT(12, ra, ca) SBF_STEP(ra, ca)
+        if (st + 1 < nsteps) { SBF_ISSUE(st + 3, ra, ca) SBF_WAIT(12, rb, cb) SBF_STEP(rb, cb) }
+        if (st + 2 < nsteps) { SBF_ISSUE(st + 4, rb, cb) SBF_WAIT(12, rc, cc) SBF_STEP(rc, cc) }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]),
+                                        "+v"(rc[0]), "+v"(rc[1]), "+v"(rc[2]), "+v"(rc[3]), "+v"(rc[4]), "+v"(ca), "+v"(cb), "+v"(cc) : : "memory");
+#undef SBF_ISSUE
+#undef SBF_WAIT
+#undef SBF_STEP
+}
+// waves 0..2: the 12 x 80 Y buffer (three k-steps) as MFMA operands, and the accumulation
+__device__ __forceinline__ void sb_y_load(const double *s_Y, double (&yo)[3][5], int lane) {
+    const int c16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+        for (int t5 = 0; t5 < 5; t5++) yo[ks][t5] = s_Y[(4 * ks + g4) * SB_YLD + 16 * t5 + c16];
+}
+template <int WV>
+__device__ __forceinline__ void sb_y_mfma(const double (&yo)[3][5], double4_t (&acc)[5]) {
+    constexpr const int *TA = SbTiles<WV>::TA, *TB = SbTiles<WV>::TB;
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+        for (int i = 0; i < 5; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[ks][TA[i]], yo[ks][TB[i]], acc[i], 0, 0, 0);
+}
+// dense -= acc (rows <= 74, lower triangle), rhs row 75, Cauchy row 76 -> s_t. Every entry is owned by exactly one lane of one wave.
+template <int WV>
+__device__ __forceinline__ void sb_acc_store(const double4_t (&acc)[5], double *s_P, double *s_t, int lane) {
+    constexpr const int *TA = SbTiles<WV>::TA, *TB = SbTiles<WV>::TB;
+    const int c16 = lane & 15, g4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 16 * TA[i] + g4 + 4 * q, c = 16 * TB[i] + c16;
+            if (r < SB_NR && c <= r && c < SB_ND) s_P[sb_prow(r) + c] -= acc[i][q];
+            else if (r == SB_NR && c < SB_ND) s_t[c] = -acc[i][q];
+        }
+}
+
+// wave 3: 9 x 9 lower Cholesky by lanes 0..8 (lane r = row r in registers, pivots broadcast through SGPRs), result written back, 1 / L_ii to linv
+__device__ __forceinline__ bool sb_potrf9(double *Dp, double *linv, int lane) {
+    const int r = min(lane, 8);
+    double v[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) v[c] = Dp[9 * r + c];
+    bool ok = true;
+    double myinv = 1.0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const double djj = readlane_f64(v[j], j);
+        if (!(djj > 0.0)) ok = false;
+        const double inv = rsqrt_h3(djj);
+        const double lrj = v[j] * inv;
+        v[j] = lrj;
+        if (r == j) myinv = inv;
+#pragma unroll
+        for (int c = j + 1; c < 9; c++) v[c] -= lrj * readlane_f64(lrj, c);
+    }
+    if (lane < 9) {
+#pragma unroll
+        for (int c = 0; c < 9; c++) if (c <= r) Dp[9 * r + c] = v[c];
+        linv[r] = myinv;
+    }
+    return ok;
+}
+
+extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    VbState *st = b.st + w;
+    extern __shared__ double s_dyn[];
+    double *s_P = s_dyn + SB_OFF_P, *s_D = s_dyn + SB_OFF_D, *s_E = s_dyn + SB_OFF_E, *s_band = s_dyn + SB_OFF_BAND, *s_Y = s_dyn + SB_OFF_Y;
+    double *s_g = s_dyn + SB_OFF_VEC, *s_diag = s_g + SB_VLD, *s_scale = s_diag + SB_VLD, *s_y = s_scale + SB_VLD, *s_v = s_y + SB_VLD;
+    double *s_t = s_dyn + SB_OFF_T, *s_linv = s_dyn + SB_OFF_LINV, *s_invd = s_dyn + SB_OFF_INVD, *s_col = s_dyn + SB_OFF_COL, *s_u = s_dyn + SB_OFF_U;
+    double *s_red = s_dyn + SB_OFF_RED;
+    __shared__ int s_pcp[VB_P];        // permuted reduced index -> prior column (-1: not in the prior)
+    __shared__ int s_flag[4];
+
+    if (tid == 0) {     // FinalizeIterationAndCheckIfMinimizerCanContinue() of the previous iteration (as k_solve)
+        const int done = st->done, iteration = st->iteration, reuse = st->reuse;
+        const double gmn = st->gradient_max_norm, radius = st->radius;
+        int go = 1;
+        if (done) go = 0;
+        else if (iteration >= b.max_iterations) { st->done = 1; st->termination = 0; go = 0; }
+        else if (gmn <= b.gradient_tolerance) { st->done = 1; st->termination = 3; go = 0; }
+        else if (radius <= b.min_radius) { st->done = 1; st->termination = 4; go = 0; }
+        if (go) st->iteration = iteration + 1;
+        s_flag[0] = go;
+        s_flag[1] = go ? reuse : 1;
+    }
+    __syncthreads();
+    if (!s_flag[0] || s_flag[1]) return;
+
+    STAMP(1, 0);
+    const int F = b.n_feat[w];
+    const size_t FM = b.Fmax;
+    const double *Hpp = b.Hpp + (size_t)w * 66 * 36;
+    const double *imuH = b.imuH + (size_t)w * 9000, *lidH = b.lidH + (size_t)w * 1440;
+    const double *priorH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
+    double *W = b.W + (size_t)w * FM * VB_WLD;
+    double *cf = b.cf + (size_t)w * FM;
+    const double *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+    const uint8_t *f_const = b.f_const + (size_t)w * FM;
+    double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
+    double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
+    const double *g_in = b.g + (size_t)w * VB_P;
+    const int *phdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    const bool has_prior = phdr[0] != 0;
+
+    // ---- set-up: prior column map, zero fill (padding entries stay zero for the whole launch), scaling vectors --------------------------------
+    for (int i = tid; i < SB_LDS_DOUBLES; i += SBT) s_dyn[i] = 0.0;
+    if (tid < VB_P) s_pcp[tid] = -1;
+    __syncthreads();
+    if (has_prior && tid < phdr[2]) {
+        const int id = phdr[3 + tid], idx = phdr[51 + tid];
+        if (id < VB_NF) { for (int k = 0; k < 6; k++) s_pcp[6 * id + k] = idx + k; }
+        else if (id == VB_NF) { for (int k = 0; k < 9; k++) s_pcp[VB_NPOSE + k] = idx + k; }     // SpeedBias[0]; other speed-bias blocks: k_solve (host-selected)
+    }
+    const int scaling_ready = st->scaling_ready;
+    double mu = st->mu;
+    int tries = 0;
+    bool solved = false;
+    double Jg2 = 0, G2 = 0, g2 = 0;
+    if (tid < VB_P) {
+        int a, l; unperm(tid, a, l);
+        const double dh = b.diagH[(size_t)w * VB_P + 15 * a + l];
+        double sc;
+        if (scaling_ready) sc = scale_g[tid]; else { sc = 1.0 / (1.0 + sqrt(dh)); scale_g[tid] = sc; }
+        const double d = sqrt(fmin(fmax(sc * sc * dh, b.min_lm_diagonal), b.max_lm_diagonal));
+        const double gs = g_in[15 * a + l] * sc;
+        diag_g[tid] = d;
+        const double gr = gs / d;
+        grad_g[tid] = gr;
+        g2 = gr * gr;
+        s_scale[tid] = sc; s_diag[tid] = d; s_g[tid] = gs; s_v[tid] = gr / d;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int f = tid + u * SBT;
+        if (f < F && !f_const[f]) {
+            const double hfv = hf[f], gfv = gf[f];
+            double sf;
+            if (scaling_ready) sf = scale_g[VB_P + f]; else { sf = 1.0 / (1.0 + sqrt(hfv)); scale_g[VB_P + f] = sf; }
+            const double d = sqrt(fmin(fmax(sf * sf * hfv, b.min_lm_diagonal), b.max_lm_diagonal));
+            diag_g[VB_P + f] = d;
+            const double gr = sf * gfv / d;
+            grad_g[VB_P + f] = gr;
+            g2 += gr * gr;
+        }
+    }
+    __syncthreads();
+    // thread -> 4 x 4 block of the dense lower triangle (19 block rows, 190 blocks)
+    int blk_i = 0;
+    while ((blk_i + 1) * (blk_i + 2) / 2 <= tid) blk_i++;
+    const int blk_j = tid - blk_i * (blk_i + 1) / 2;
+    const bool blk_on = tid < 19 * 20 / 2;
+
+    STAMP(1, 1);
+    for (;;) {
+        // lane-derived predicates and addresses of the phases below are loop invariant; hoisted out of this (rarely repeated) loop they would pin ~100 registers
+        int ln = lane, bi = blk_i, bjm = blk_j;
+        asm volatile("" : "+v"(ln), "+v"(bi), "+v"(bjm));
+        // ---- P1: gather assembly ----------------------------------------------------------------------------------------------------------------
+        double part = 0;
+        {
+            const int4 *la = (const int4 *)b.lut_sba;
+            for (int e0 = tid; e0 < b.n_sba; e0 += 3 * SBT) {               // pose-pose: visual + IMU (<= 2) + LiDAR (<= 2) + prior, three entries in flight
+                int4 m0[3], m1[3]; double sv[3][6];
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int e = min(e0 + u * SBT, b.n_sba - 1); m0[u] = la[2 * e]; m1[u] = la[2 * e + 1]; }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int r = (m0[u].x >> 14) & 255, c = (m0[u].x >> 22) & 255;
+                    const int pr = s_pcp[r], pc = s_pcp[c];
+                    sv[u][0] = Hpp[m0[u].y];
+                    sv[u][1] = imuH[max(m0[u].z, 0)]; sv[u][2] = imuH[max(m0[u].w, 0)];
+                    sv[u][3] = lidH[max(m1[u].x, 0)]; sv[u][4] = lidH[max(m1[u].y, 0)];
+                    sv[u][5] = priorH[(size_t)max(pr, 0) * VB_PRIOR_LD + max(pc, 0)];
+                    if (m0[u].z < 0) sv[u][1] = 0.0;
+                    if (m0[u].w < 0) sv[u][2] = 0.0;
+                    if (m1[u].x < 0) sv[u][3] = 0.0;
+                    if (m1[u].y < 0) sv[u][4] = 0.0;
+                    if (pr < 0 || pc < 0) sv[u][5] = 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if (e0 + u * SBT >= b.n_sba) continue;
+                    const int r = (m0[u].x >> 14) & 255, c = (m0[u].x >> 22) & 255;
+                    const double val = (((((sv[u][0] + sv[u][1]) + sv[u][2]) + sv[u][3]) + sv[u][4]) + sv[u][5]) * s_scale[r] * s_scale[c];
+                    part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
+                    s_dyn[m0[u].x & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                }
+            }
+            const int2 *lb = (const int2 *)b.lut_sbb;
+            for (int e0 = tid; e0 < b.n_sbb; e0 += 3 * SBT) {               // SpeedBias[0] rows of the dense block: IMU factor 0 + prior
+                int2 m[3]; double sv[3][2];
+#pragma unroll
+                for (int u = 0; u < 3; u++) m[u] = lb[min(e0 + u * SBT, b.n_sbb - 1)];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int r = (m[u].x >> 14) & 255, c = (m[u].x >> 22) & 255;
+                    const int pr = s_pcp[r], pc = s_pcp[c];
+                    sv[u][0] = imuH[max(m[u].y, 0)];
+                    sv[u][1] = priorH[(size_t)max(pr, 0) * VB_PRIOR_LD + max(pc, 0)];
+                    if (m[u].y < 0) sv[u][0] = 0.0;
+                    if (pr < 0 || pc < 0) sv[u][1] = 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if (e0 + u * SBT >= b.n_sbb) continue;
+                    const int r = (m[u].x >> 14) & 255, c = (m[u].x >> 22) & 255;
+                    const double val = (sv[u][0] + sv[u][1]) * s_scale[r] * s_scale[c];
+                    part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
+                    s_dyn[m[u].x & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                }
+            }
+            const int4 *lc = (const int4 *)b.lut_sbc;
+            for (int e0 = tid; e0 < b.n_sbc; e0 += 4 * SBT) {               // chain: diagonal blocks D_a, sub-diagonal blocks E_a, band
+                int4 m[4]; double sv[4][2];
+#pragma unroll
+                for (int u = 0; u < 4; u++) m[u] = lc[min(e0 + u * SBT, b.n_sbc - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { sv[u][0] = imuH[m[u].y]; sv[u][1] = imuH[max(m[u].z, 0)]; if (m[u].z < 0) sv[u][1] = 0.0; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (e0 + u * SBT >= b.n_sbc) continue;
+                    const int r = (m[u].x >> 14) & 255, c = (m[u].x >> 22) & 255;
+                    const double val = (sv[u][0] + sv[u][1]) * s_scale[r] * s_scale[c];
+                    part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
+                    s_dyn[m[u].x & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                }
+            }
+        }
+        STAMP(1, 2);
+        // right-hand sides: dense row 75, band column 27
+        if (tid < SB_ND) s_P[sb_prow(SB_ND) + tid] = s_g[tid];
+        if (tid >= 96 && tid < 96 + 9 * SB_NCH) { const int q = tid - 96, a1 = q / 9, i = q - 9 * a1; s_band[(9 * a1 + i) * SB_BLD + 27] = s_g[VB_NPOSE + 9 + q]; }
+        // per-feature: Cauchy-point terms (first try), Schur coefficient
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int f = tid + u * SBT;
+            if (f < ((F + 3) & ~3)) {
+                double c = 0.0, xf = 0.0;
+                if (f < F && !f_const[f]) {
+                    const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f], hfv = hf[f], gfv = gf[f];
+                    const double hp = sf * sf * hfv + mu * df * df;
+                    c = sf * rsqrt_nr(hp);
+                    if (tries == 0) {
+                        const double vf = sf * gfv / (df * df);
+                        part += sf * sf * hfv * vf * vf;
+                        xf = vf * hp / sf;              // column 67 of U: c_f x_f with c_f^2 x_f = s_f v_f  =>  (U^T U)[p][76] = sum_f s_f v_f W~_f[p]
+                    }
+                }
+                cf[f] = c;
+                if (tries == 0 && f < F) W[(size_t)f * VB_WLD + VB_NPOSE + 1] = xf;
+            }
+        }
+        __threadfence_block();
+        if (tries == 0) { G2 = block_sum_sb(g2, s_red); Jg2 = block_sum_sb(part, s_red); }
+        if (tid == 0) s_flag[2] = 1;
+        __syncthreads();
+        __threadfence_block();
+
+        STAMP(1, 3);
+        // ---- P2: feature Schur reduce (waves 0..2)  ||  block-tridiagonal Cholesky of the chain (wave 3) -------------------------------------------
+        double4_t acc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) acc[i] = double4_t{0, 0, 0, 0};
+        if (wave == 0) sb_feature_reduce<0>(W, cf, F, s_scale, acc, ln);
+        else if (wave == 1) sb_feature_reduce<1>(W, cf, F, s_scale, acc, ln);
+        else if (wave == 2) sb_feature_reduce<2>(W, cf, F, s_scale, acc, ln);
+        else {
+            bool ok = true;
+#pragma unroll 1
+            for (int a = SB_NCH; a >= 1; a--) {
+                double *Da = s_D + 81 * (a - 1);
+                ok = sb_potrf9(Da, s_linv + 9 * (a - 1), ln) && ok;
+                if (a == 1) break;
+                // B_a = L_a^-1 E_(a-1): lane c owns column c
+                double *Ea = s_E + 81 * (a - 2);
+                const int c = min(ln, 8);
+                double x[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    double s = Ea[9 * i + c];
+#pragma unroll
+                    for (int j = 0; j < i; j++) s -= Da[9 * i + j] * x[j];
+                    x[i] = s * s_linv[9 * (a - 1) + i];
+                }
+                if (ln < 9) {
+#pragma unroll
+                    for (int i = 0; i < 9; i++) Ea[9 * i + c] = x[i];
+                }
+                // D_(a-1) -= B_a^T B_a (lower triangle): lane -> (r, cc), r >= cc
+                if (ln < 45) {
+                    int r = 0; while ((r + 1) * (r + 2) / 2 <= ln) r++;
+                    const int cc = ln - r * (r + 1) / 2;
+                    double s = 0;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) s += Ea[9 * i + r] * Ea[9 * i + cc];
+                    s_D[81 * (a - 2) + 9 * r + cc] -= s;
+                }
+            }
+            if (!ok && ln == 0) s_flag[2] = 0;
+        }
+#ifdef VILF_STAMPS
+        if (b.dbg && blockIdx.x == 0 && (tid & 63) == 0) b.dbg[32 + 16 + (tid >> 6)] = __builtin_readcyclecounter();
+#endif
+        __syncthreads();
+
+        STAMP(1, 4);
+        // ---- P3: Y_a = L_a^-1 (band_a - B_(a+1)^T Y_(a+1)), accumulate Y_a^T Y_a ------------------------------------------------------------------
+        {
+            double yp0[9], yp1[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) { yp0[i] = 0.0; yp1[i] = 0.0; }
+            const int c0 = min(ln, 37), c1 = c0 + 38;          // wave 3, lanes 0..37: dense columns c0 and c0 + 38 (column 75 = rhs)
+#pragma unroll 1
+            for (int a = SB_NCH; a >= 1; a--) {
+                if (wave == 3) {
+                    const double *Ba = s_band + 9 * (a - 1) * SB_BLD, *La = s_D + 81 * (a - 1), *Bn = s_E + 81 * (a - 1) /* B_(a+1): rows s_(a+1), cols s_a */;
+                    // band position of a dense column (-1: structurally zero)
+                    int p0 = c0 - 6 * (a - 1); if (p0 < 0 || p0 >= 18 || c0 >= VB_NPOSE) p0 = -1;
+                    int p1 = c1 - 6 * (a - 1); if (p1 < 0 || p1 >= 18 || c1 >= VB_NPOSE) p1 = -1;
+                    if (a == 1 && c1 >= VB_NPOSE && c1 < SB_ND) p1 = 18 + (c1 - VB_NPOSE);
+                    if (c1 == SB_ND) p1 = 27;
+                    double t0[9], t1[9];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        const double v0 = Ba[i * SB_BLD + max(p0, 0)], v1 = Ba[i * SB_BLD + max(p1, 0)];
+                        t0[i] = (p0 >= 0) ? v0 : 0.0; t1[i] = (p1 >= 0) ? v1 : 0.0;
+                    }
+                    if (a < SB_NCH) {
+#pragma unroll
+                        for (int j = 0; j < 9; j++)
+#pragma unroll
+                            for (int i = 0; i < 9; i++) { const double bji = Bn[9 * j + i]; t0[i] -= bji * yp0[j]; t1[i] -= bji * yp1[j]; }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        double s0 = t0[i], s1 = t1[i];
+#pragma unroll
+                        for (int j = 0; j < i; j++) { const double lij = La[9 * i + j]; s0 -= lij * yp0[j]; s1 -= lij * yp1[j]; }
+                        const double li = s_linv[9 * (a - 1) + i];
+                        yp0[i] = s0 * li; yp1[i] = s1 * li;       // yp* now hold Y_a (rows < i already replaced: the substitution reads exactly those)
+                    }
+                    if (ln < 38) {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) { s_Y[i * SB_YLD + c0] = yp0[i]; s_Y[i * SB_YLD + c1] = yp1[i]; }
+                    }
+                }
+                __syncthreads();
+                double yo[3][5];
+                if (wave < 3) sb_y_load(s_Y, yo, ln);
+                __syncthreads();
+                if (wave == 0) sb_y_mfma<0>(yo, acc); else if (wave == 1) sb_y_mfma<1>(yo, acc); else if (wave == 2) sb_y_mfma<2>(yo, acc);
+            }
+        }
+        STAMP(1, 5);
+        // ---- P4: dense -= U^T U + Y^T Y ---------------------------------------------------------------------------------------------------------
+        if (wave == 0) sb_acc_store<0>(acc, s_P, s_t, ln); else if (wave == 1) sb_acc_store<1>(acc, s_P, s_t, ln); else if (wave == 2) sb_acc_store<2>(acc, s_P, s_t, ln);
+        __syncthreads();
+        if (tries == 0) {                             // cross term of the Cauchy point: 2 sum_p v_p S_p sum_f s_f v_f W_f[p]  (s_t = -that inner sum, scaled)
+            double cr = ((lane < VB_NPOSE) ? s_v[lane] * s_t[lane] : 0.0) + ((lane + 64 < VB_NPOSE) ? s_v[lane + 64] * s_t[lane + 64] : 0.0);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
+            Jg2 -= 2.0 * cr;
+        }
+        STAMP(1, 6);
+        // ---- P5: Cholesky of the dense block, rhs as row 75 (L[75][0..74] = L^-1 rhs) ---------------------------------------------------------------
+        {
+            double a4[4][4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) {
+                    const int r = 4 * bi + ii, c = 4 * bjm + kk;
+                    a4[ii][kk] = (blk_on && c <= r) ? s_P[sb_prow(min(r, SB_NR - 1)) + min(c, SB_NR - 1)] : 0.0;
+                }
+#pragma unroll 1
+            for (int bj = 0; bj < 19; bj++) {
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int j = 4 * bj + jj;
+                    if (j >= SB_ND) break;
+                    double *col = s_col + 80 * (j & 1);
+                    if (blk_on && bjm == bj) {
+#pragma unroll
+                        for (int ii = 0; ii < 4; ii++) col[4 * bi + ii] = a4[ii][jj];
+                    }
+                    __syncthreads();
+                    if (blk_on && bjm >= bj) {
+                        const double piv = col[j];
+                        if (!(piv > 0.0)) s_flag[2] = 0;
+                        const double d = rsqrt_h3(piv);
+                        double li[4], lk[4];
+#pragma unroll
+                        for (int ii = 0; ii < 4; ii++) { li[ii] = col[4 * bi + ii] * d; lk[ii] = col[4 * bjm + ii] * d; }
+                        if (bjm == bj) {
+#pragma unroll
+                            for (int ii = 0; ii < 4; ii++) {
+                                a4[ii][jj] = li[ii];
+#pragma unroll
+                                for (int kk = jj + 1; kk < 4; kk++) a4[ii][kk] -= li[ii] * lk[kk];
+                            }
+                            if (bi == bj) s_invd[j] = d;
+                        } else {
+#pragma unroll
+                            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                                for (int kk = 0; kk < 4; kk++) a4[ii][kk] -= li[ii] * lk[kk];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (blk_on) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        const int r = 4 * bi + ii, c = 4 * bjm + kk;
+                        if (c <= r && c < SB_ND) s_P[sb_prow(r) + c] = a4[ii][kk];
+                    }
+            }
+            __syncthreads();
+        }
+        STAMP(1, 7);
+        tries++;
+        if (s_flag[2]) { solved = true; break; }
+        mu *= 10.0;                                 // dogleg_strategy.cc: mu_ *= mu_increase_factor_
+        if (!(mu < 1.0)) break;                     // max_mu_
+        __syncthreads();
+    }
+    if (!solved) {
+        if (tid == 0) { st->solve_failed = 1; st->mu = mu; st->num_linear_solves += tries; st->scaling_ready = 1; st->grad_sqnorm = G2; st->Jg2 = Jg2; }
+        return;
+    }
+    // ---- P6: wave 0 — back substitution L^T y = z of the dense block (z = row 75 of L); each lane owns entries lane and lane + 64 --------------------
+    if (wave == 0) {
+        const double *zrow = s_P + sb_prow(SB_ND);
+        double z0 = zrow[lane], z1 = (lane + 64 < SB_ND) ? zrow[lane + 64] : 0.0;
+#pragma unroll 1
+        for (int j = SB_ND - 1; j >= 64; j--) {
+            const double yj = readlane_f64(z1, j - 64) * s_invd[j];
+            const double *Lj = s_P + sb_prow(j);
+            const double l0 = Lj[lane], l1 = Lj[min(lane + 64, j)];
+            z0 -= l0 * yj;
+            if (lane + 64 < j) z1 -= l1 * yj;
+            if (lane + 64 == j) z1 = yj;
+        }
+#pragma unroll 2
+        for (int j = 63; j >= 0; j--) {
+            const double yj = readlane_f64(z0, j) * s_invd[j];
+            const double l0 = s_P[sb_prow(j) + min(lane, j)];
+            if (lane < j) z0 -= l0 * yj;
+            if (lane == j) z0 = yj;
+        }
+        s_y[lane] = z0;
+        if (lane + 64 < SB_ND) s_y[lane + 64] = z1;
+    }
+    __syncthreads();
+    STAMP(1, 8);
+    // chain right-hand side r_a = g~_a - band_a y_dense (90 threads); (S y)_p for the feature back-substitution
+    if (tid < 9 * SB_NCH) {
+        const int a1 = tid / 9, i = tid - 9 * a1, a = a1 + 1;
+        const double *Ba = s_band + (9 * a1 + i) * SB_BLD;
+        double s = s_g[VB_NPOSE + 9 + tid];
+#pragma unroll
+        for (int p = 0; p < 18; p++) { const int c = 6 * (a - 1) + p; if (c < VB_NPOSE) s -= Ba[p] * s_y[c]; }
+        if (a == 1) {
+#pragma unroll
+            for (int p = 0; p < 9; p++) s -= Ba[18 + p] * s_y[VB_NPOSE + p];
+        }
+        s_u[tid] = s;
+    }
+    if (tid >= 128 && tid < 128 + 80) { const int c = tid - 128; s_v[c] = (c < VB_NPOSE) ? s_scale[c] * s_y[c] : 0.0; }
+    __syncthreads();
+    if (wave == 0) {
+        // forward (a = 10..1): u_a = L_a^-1 (r_a - B_(a+1)^T u_(a+1)); backward (a = 1..10): x_a = L_a^-T (u_a - B_a x_(a-1)); lanes 0..8 = rows
+        const int i9 = min(lane, 8);
+        double un = 0.0;
+#pragma unroll 1
+        for (int a = SB_NCH; a >= 1; a--) {
+            const double *La = s_D + 81 * (a - 1), *Bn = s_E + 81 * (a - 1);
+            double t = s_u[9 * (a - 1) + i9];
+            if (a < SB_NCH) {
+#pragma unroll
+                for (int j = 0; j < 9; j++) t -= Bn[9 * j + i9] * readlane_f64(un, j);
+            }
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                const double xj = readlane_f64(t, j) * s_linv[9 * (a - 1) + j];
+                if (i9 > j) t -= La[9 * i9 + j] * xj;
+                if (i9 == j) t = xj;
+            }
+            un = t;
+            if (lane < 9) s_u[9 * (a - 1) + i9] = t;
+        }
+        double xp = 0.0;
+#pragma unroll 1
+        for (int a = 1; a <= SB_NCH; a++) {
+            const double *La = s_D + 81 * (a - 1), *Bm = s_E + 81 * max(a - 2, 0);      // B_a: rows s_a, cols s_(a-1)
+            double t = s_u[9 * (a - 1) + i9];
+            if (a > 1) {
+#pragma unroll
+                for (int j = 0; j < 9; j++) t -= Bm[9 * i9 + j] * readlane_f64(xp, j);
+            }
+#pragma unroll
+            for (int j = 8; j >= 0; j--) {
+                const double xj = readlane_f64(t, j) * s_linv[9 * (a - 1) + j];
+                if (i9 < j) t -= La[9 * j + i9] * xj;
+                if (i9 == j) t = xj;
+            }
+            xp = t;
+            if (lane < 9) s_y[VB_NPOSE + 9 * a + i9] = t;
+        }
+#ifdef VILF_STAMPS
+        if (b.dbg && blockIdx.x == 0 && tid == 0) b.dbg[32 + 9] = __builtin_readcyclecounter();
+#endif
+    } else if (F > 0) {
+        // waves 1..3: W~_f[0..65] . (S y)_p for every feature, 16 lanes per feature, three rounds of rows in flight (as feature_dots of k_solve)
+        const int c16 = lane & 15, g = lane >> 4, w3 = wave - 1;
+        double sv[5];
+#pragma unroll
+        for (int t5 = 0; t5 < 5; t5++) sv[t5] = s_v[16 * t5 + c16];
+        const int Fk4 = (F + 3) & ~3;
+        double ra[5], rb[5], rc[5];
+#define FD_ISSUE(F0, R)                                                                                                            \
+        {                                                                                                                          \
+            const double *Wr_ = W + (size_t)min((F0) + g, Fk4 - 1) * VB_WLD + c16;                                                \
+            asm volatile("global_load_dwordx2 %0, %5, off\n\tglobal_load_dwordx2 %1, %5, off offset:128\n\t"                       \
+                         "global_load_dwordx2 %2, %5, off offset:256\n\tglobal_load_dwordx2 %3, %5, off offset:384\n\t"            \
+                         "global_load_dwordx2 %4, %5, off offset:512"                                                              \
+                         : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]) : "v"(Wr_) : "memory");                  \
+        }
+#define FD_WAIT(N, R) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]) : : "memory");
+#define FD_STEP(F0, R)                                                                                                             \
+        {                                                                                                                          \
+            const int f = (F0) + g;                                                                                                \
+            double dacc = 0;                                                                                                       \
+            _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) dacc += R[t5] * sv[t5];                                               \
+            if (!(f < F)) dacc = 0;                                                                                                \
+            _Pragma("unroll") for (int o = 8; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o, 64);                                     \
+            if (c16 == 0 && f < F) cf[f] = dacc;                                                                                   \
+        }
+        constexpr int RS = 4 * 3;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FD_ISSUE(4 * w3, ra) FD_ISSUE(4 * w3 + RS, rb)
+        for (int f0 = 4 * w3; f0 < F; f0 += 3 * RS) {
+            FD_ISSUE(f0 + 2 * RS, rc) FD_WAIT(10, ra) FD_STEP(f0, ra)
+            if (f0 + RS < F) { FD_ISSUE(f0 + 3 * RS, ra) FD_WAIT(10, rb) FD_STEP(f0 + RS, rb) }
+            if (f0 + 2 * RS < F) { FD_ISSUE(f0 + 4 * RS, rb) FD_WAIT(10, rc) FD_STEP(f0 + 2 * RS, rc) }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]),
+                                            "+v"(rc[0]), "+v"(rc[1]), "+v"(rc[2]), "+v"(rc[3]), "+v"(rc[4]) : : "memory");
+#undef FD_ISSUE
+#undef FD_WAIT
+#undef FD_STEP
+        __threadfence_block();
+    }
+    __syncthreads();
+    STAMP(1, 10);
+    // ---- P7: Gauss-Newton step = -diagonal_ .* y, feature back-substitution, reductions ---------------------------------------------------------
+    double gy = 0, gn2 = 0;
+    if (tid < VB_P) {
+        const double y = s_y[tid], d = s_diag[tid];
+        gn_g[tid] = -d * y;
+        gy += s_g[tid] * y;
+        gn2 += d * d * y * y;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int f = tid + u * SBT;
+        if (f >= F || f_const[f]) continue;
+        const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
+        const double hp = sf * sf * hf[f] + mu * df * df;
+        const double gt = sf * gf[f];
+        const double y = (gt - sf * cf[f]) / hp;
+        gn_g[VB_P + f] = -df * y;
+        gy += gt * y;
+        gn2 += df * df * y * y;
+    }
+    gy = block_sum_sb(gy, s_red);
+    gn2 = block_sum_sb(gn2, s_red);
+    STAMP(1, 11);
+    if (tid == 0) {
+        st->grad_sqnorm = G2; st->Jg2 = Jg2; st->alpha = G2 / Jg2;
+        st->gy = gy; st->gn_sqnorm = gn2; st->mu = mu; st->mu_used = mu;
+        st->num_linear_solves += tries; st->solve_failed = 0; st->reuse = 1; st->scaling_ready = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // k_step
 extern "C" __global__ __launch_bounds__(NT) void k_step(VbBatch b) {
     const int w = blockIdx.x, tid = threadIdx.x;
@@ -1338,6 +2004,16 @@ extern "C" __global__ void k_finalize(VbBatch b) {
         b.out_Bas[((size_t)w * VB_NF + tid) * 3 + k] = sb[9 * tid + 3 + k];
         b.out_Bgs[((size_t)w * VB_NF + tid) * 3 + k] = sb[9 * tid + 6 + k];
     }
+}
+
+// options.max_solver_time reached (host clock, vilf_batch_solve): the windows still iterating stop as Ceres does at the top of an iteration —
+// termination NO_CONVERGENCE, state = last accepted point. only_margin_old: the 4/5 limit of the windows that marginalize the oldest frame (estimator.cpp:847-850)
+extern "C" __global__ void k_time_limit(VbBatch b, const int *mflag, int only_margin_old) {
+    const int w = blockIdx.x;
+    if (threadIdx.x) return;
+    if (only_margin_old && mflag[w] != 0) return;
+    VbState *st = b.st + w;
+    if (!st->done) { st->done = 1; st->termination = 0; }
 }
 
 // reset of the per-window solver state (≙ TrustRegionMinimizer::Init + DoglegStrategy ctor) and state rewind

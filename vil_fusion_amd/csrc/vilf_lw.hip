@@ -413,6 +413,8 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     const size_t xo = 16 * (size_t)NF + F;                                                        // x = pose | sb | feat | ex[7] | td
     if (NF < 2 || F < 0 || !in->para_pose || !in->para_speed_bias || !in->imu || (F && (!in->para_feature || !in->feature_const || !in->feature_start_frame || !in->feature_obs_offset || !in->obs_point)))
         return VILF_ERR_INVALID_ARGUMENT;
+    if (in->n_obs < 0 || (F && (in->feature_obs_offset[0] != 0 || in->feature_obs_offset[F] != in->n_obs)) || (!F && in->n_obs != 0)) { h->err = "feature_obs_offset must start at 0 and end at n_obs"; return VILF_ERR_INVALID_ARGUMENT; }
+    for (int f = 0; f < F; f++) if (in->feature_obs_offset[f + 1] - in->feature_obs_offset[f] < 2) { h->err = "feature with fewer than two observations"; return VILF_ERR_INVALID_ARGUMENT; }
     if (est_td && F && (!in->obs_velocity || !in->obs_cur_td || !in->obs_row)) { h->err = "estimate_td needs obs_velocity / obs_cur_td / obs_row"; return VILF_ERR_INVALID_ARGUMENT; }
     if (batch_slot0 && (NF != VB_NF || !h->resident)) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipSetDevice(h->device));
@@ -502,7 +504,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     if (F) HIPCHECK(h, hipMemcpyAsync(c->fconst.p, in->feature_const, F, hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, c->cov.as<double>(), c->tmpP.as<double>(), c->imu.as<double>());
     double *scal = c->scal.as<double>();
-    const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = 1.0 / (h->opts.cauchy_a * h->opts.cauchy_a);
+    const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = h->opts.cauchy_a * h->opts.cauchy_a;      // rho(s) = b log(1 + s / b), b = a^2 (ceres CauchyLoss; same as the batched path)
 
     // ---- host state: x = pose | sb | feat
     std::vector<double> x(xo + 8), cand(x.size());
@@ -704,7 +706,9 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     const double initial_cost = x_cost;
     double x_norm = xnorm(x);
     const int max_it = h->opts.max_num_iterations;
+    const double tlim = h->opts.max_solver_time > 0 ? h->opts.max_solver_time * (in->marginalization_flag == VILF_MARGIN_OLD ? 4.0 / 5.0 : 1.0) : -1.0;   // estimator.cpp:847-850
     while (true) {
+        if (tlim > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= tlim) { termination = VILF_TERM_NO_CONVERGENCE; break; }
         if (iteration >= max_it) { termination = VILF_TERM_NO_CONVERGENCE; break; }
         if (gradient_max_norm <= gradient_tolerance) { termination = VILF_TERM_CONVERGENCE_GRADIENT; break; }
         if (radius <= 1e-32) { termination = VILF_TERM_FAILURE; break; }

@@ -145,7 +145,7 @@ class BackendSolver:
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
         return arrs, (abi.c_double_p * len(arrs))(*[abi.dptr(a) for a in arrs])
 
-    def eval_projection(self, params, pts_i, pts_j, want_ex_jacobian=False):
+    def eval_projection(self, params, pts_i, pts_j, want_ex_jacobian=True):
         arrs, p = self._params(params)
         r = np.zeros(2)
         jacs = [np.zeros((2, 7)), np.zeros((2, 7)), np.zeros((2, 7)), np.zeros((2, 1))]
