@@ -214,6 +214,21 @@ int vilf_get_profile_large_window(vilf_handle *h, double ms_out[4], long launche
  * (feeds the RCCL gather for global_fusion, poseGraphOptimization.cpp:116-121). */
 int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8);
 
+/* ---- multi-GPU: the pose gather over RCCL (SURVEY.md §8(b),(e)) --------------------------- */
+/* Independent windows / sequence segments shard over the GPUs of a node, one process and one vilf_handle per GPU, no intra-solve
+ * communication. The only exchange is an all-gather of the newest-frame pose rows above — what global_fusion subscribes to as
+ * nav_msgs/Odometry (src/global_fusion/poseGraphOptimization.cpp:116-121: position, quaternion, stamp). The communicator is RCCL
+ * (ncclCommInitRank / ncclAllGather over xGMI); the launcher distributes rank 0's id (MPI, a file, a ROS parameter ...). */
+#define VILF_COMM_ID_BYTES 128
+typedef struct vilf_comm vilf_comm;
+int vilf_comm_unique_id(unsigned char id[VILF_COMM_ID_BYTES]);                       /* rank 0: ncclGetUniqueId */
+int vilf_comm_create(const unsigned char id[VILF_COMM_ID_BYTES], int world_size, int rank, int device, vilf_comm **out);
+int vilf_comm_destroy(vilf_comm *comm);
+/* local_dev8: n_local rows of 8 doubles on this rank's device; out_dev8: world_size * n_local rows, rank-major (= the global unit order
+ * under contiguous sharding). Enqueued on hip_stream (NULL: default stream); the caller synchronises. Every rank passes the same n_local. */
+int vilf_gather_poses(vilf_comm *comm, void *hip_stream, const double *local_dev8, int n_local, double *out_dev8);
+const char *vilf_comm_last_error(void);
+
 /* ---- prior import / export (tests, snapshots) ------------------------------------------ */
 int vilf_prior_export(vilf_handle *h, int slot, vilf_prior *out);
 int vilf_prior_import(vilf_handle *h, int slot, const vilf_prior *prior);

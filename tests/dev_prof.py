@@ -24,9 +24,9 @@ if os.environ.get("VILF_DEBUG_STAMPS"):
             print(name, "phase cycles:", np.diff(v), "total", v[-1] - v[0])
 if os.environ.get("VILF_DEBUG_STAMPS") and not os.environ.get("VILF_SOLVE_DENSE"):
     v = a[1]
-    names = ["prologue", "setup", "P1 gather", "P1 rhs/features+sums", "P2 reduce||chain", "P3 Y+syrk", "P4 store", "P5 dense chol", "P6 dense backsub", "P6 chain (wave0)", "P6 wait dots", "P7"]
+    names = ["prologue", "setup", "P1 gather(w0)", "P2 reduce||chain", "P2b acc store+sums", "P3 Y chain+syrk", "P4 store", "P5 dense chol", "P6 dense backsub", "P6 chain (wave0)", "P6 wait dots+x", "P7"]
     print("k_solve_sb stamps (cycles, delta):", [(names[i], int(v[i] - v[i - 1])) for i in range(1, 12) if v[i] and v[i - 1]])
-    print("  P2 per-wave finish rel. to P2 start:", [int(v[16 + q] - v[3]) for q in range(4)])
+    print("  P1+P2 per-wave finish rel. to loop start:", [int(v[16 + q] - v[1]) for q in range(4)])
 if os.environ.get("VILF_DEBUG_STAMPS"):
     print("linearize chunk-loop (wave 0): eval", a[2][16], "sync1", a[2][17], "mfma", a[2][18], "sync2", a[2][19])
 if os.environ.get("VILF_DEBUG_STAMPS"):

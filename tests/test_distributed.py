@@ -81,3 +81,63 @@ def test_gathered_poses_feed_the_pose_graph(tmp_path):
     before = np.array([pg._qt(n["pose"]) for n in pg.nodes])
     after = pg.update()
     assert np.abs(after[:, 4:] - before[:, 4:]).max() < 1e-8        # an odometry chain without loop edges is its own optimum
+
+
+# ---- BASELINE configs[3] on the GPU: sharded windows through the HIP path + pose gather ------------------------------------------------------
+def _gpu_worker(rank, world, port, n_units, out_dir):
+    """one process per shard (both on cuda:0 of the one-GPU test box; on a node every rank takes its own GPU): solve the shard's windows through
+    the C ABI, newest-frame poses on the device, gather. The collective is gloo here — RCCL refuses two ranks on one device — and RCCL itself on a
+    single-rank communicator below."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from vil_fusion_amd import synth
+    from vil_fusion_amd.estimator import BackendSolver
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    solver = BackendSolver(device=0)
+    opts = solver.options
+    lo, hi = vdist.shard_range(n_units, rank, world)
+    made = [synth.make_window(100 + u, opts, synth.SynthConfig(n_features=30)) for u in range(lo, hi)]
+    solver.batch_upload([m[0] for m in made], [m[1] for m in made])
+    solver.batch_solve()
+    poses = torch.zeros((hi - lo, 8), dtype=torch.float64, device="cuda")
+    solver.newest_poses_to_device(np.arange(lo, hi, dtype=np.float64), poses.data_ptr())
+    torch.cuda.synchronize()
+    allp = vdist.gather_poses(poses.cpu(), n_units=n_units)
+    np.save(os.path.join(out_dir, f"gpu_gather_{rank}.npy"), allp.numpy())
+    if rank == 0:        # the C-ABI collective on a one-rank RCCL communicator: same rows out as in
+        g = vdist.RcclPoseGather(1, 0, device=0)
+        out = torch.zeros_like(poses)
+        g.gather(poses.data_ptr(), hi - lo, out.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(out, poses)
+        g.close()
+    solver.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_shards_hip_path_pose_gather_feeds_pose_graph(tmp_path):
+    """configs[3] stand-in (KITTI-08 is not available): independent window units in two shards, every shard solved by its own process through the HIP
+    path, poses gathered in global unit order and equal to the oracle's per-window poses; the gathered table drives the global pose graph."""
+    import torch.multiprocessing as mp
+    import oracle_lib
+    from vil_fusion_amd import synth, posegraph
+    n_units = 5
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, n_units, str(tmp_path)), nprocs=2, join=True)       # fresh children: the parent has not touched the GPU here
+    a = np.load(tmp_path / "gpu_gather_0.npy"); b = np.load(tmp_path / "gpu_gather_1.npy")
+    assert a.shape == (n_units, 8) and np.array_equal(a, b)
+    assert np.array_equal(a[:, 0], np.arange(n_units, dtype=np.float64))
+    opts = oracle_lib.default_options()
+    for u in range(n_units):
+        win, prior, _ = synth.make_window(100 + u, opts, synth.SynthConfig(n_features=30))
+        ref = oracle_lib.window_solve(opts, win, prior)
+        assert np.abs(a[u, 1:4] - ref.Ps[-1]).max() < 1e-7
+        q = synth.R_to_q(ref.Rs[-1])
+        assert min(np.abs(a[u, 4:8] - q).max(), np.abs(a[u, 4:8] + q).max()) < 1e-8
+    pg = posegraph.PoseGraph(backend=lambda x, ps, e: oracle_lib.posegraph_optimize(x, ps, e)[0])
+    keys = [pg.add_odometry(r[0], np.concatenate([r[4:8], r[1:4]])) for r in a]
+    assert keys[0] and len(pg.edges) == len(pg.nodes) - 1

@@ -524,3 +524,112 @@ def test_flagged_solves_fail_loudly_where_unsupported(oracle):
     with pytest.raises(VilfError):                       # batched kernels: Ex_Pose / td constant only
         s.batch_upload([win]); s.batch_solve()
     s.close()
+
+
+# ---- round 2: speed-bias-first solve kernel, boundary behaviour --------------------------------------------------------------------------------
+def test_speed_bias_first_kernel_equals_dense_kernel_and_oracle(solver, oracle, opts, monkeypatch):
+    """k_solve_sb (block-tridiagonal speed-bias chain eliminated first) against k_solve (Cholesky of the whole 165 x 165 system, VILF_SOLVE_DENSE=1) and the
+    oracle: the same iterations / accepted steps / linear solves in every window, states equal to rounding; windows with and without a prior, with constant
+    features only, with a rejected step."""
+    cfgs = [synth.SynthConfig(n_features=230), synth.SynthConfig(n_features=90, with_prior=False), synth.SynthConfig(const_fraction=1.0, n_features=40),
+            synth.SynthConfig(n_features=150, state_noise=(0.5, np.deg2rad(5.0), 0.5)), synth.SynthConfig(n_features=3, const_fraction=0.0)]
+    made = [synth.make_window(300 + i, opts, c) for i, c in enumerate(cfgs)]
+    wins, priors = [m[0] for m in made], [m[1] for m in made]
+
+    def run():
+        solver.batch_upload(wins, priors); solver.batch_solve()
+        return solver.batch_download(), solver.batch_summaries()
+    monkeypatch.delenv("VILF_SOLVE_DENSE", raising=False)
+    r_sb, s_sb = run()
+    monkeypatch.setenv("VILF_SOLVE_DENSE", "1")
+    r_de, s_de = run()
+    monkeypatch.delenv("VILF_SOLVE_DENSE")
+    for i in range(len(wins)):
+        a, b = s_sb[i], s_de[i]
+        assert (a.num_iterations, a.num_successful_steps, a.num_linear_solves, a.termination) == (b.num_iterations, b.num_successful_steps, b.num_linear_solves, b.termination)
+        assert np.abs(r_sb[i].Ps - r_de[i].Ps).max() < 1e-8 and np.abs(r_sb[i].Vs - r_de[i].Vs).max() < 1e-7
+        _compare(r_sb[i], oracle.window_solve(opts, wins[i], priors[i]), tol_p=1e-6, tol_r=1e-7, tol_cost=1e-6)
+
+
+def test_prior_with_other_speed_bias_blocks_takes_the_dense_kernel(oracle, opts):
+    """the chain elimination assumes SpeedBias[0] is the only speed-bias block of the prior (all the reference ever produces); an imported prior that also holds
+    SpeedBias[3] must still be solved correctly — the handle switches to the dense kernel"""
+    from vil_fusion_amd.estimator import BackendSolver
+    win, prior, _ = synth.make_window(41, opts, synth.SynthConfig(n_features=80))
+    rng = np.random.default_rng(3)
+    n = 6 * 3 + 9 * 2
+    p = abi.Prior()
+    p.valid = 1; p.n = n; p.m = 0; p.n_blocks = 5
+    ids, sizes = [2, 4, 7, 11, 14], [7, 7, 7, 9, 9]         # three poses, SpeedBias[0], SpeedBias[3]
+    idx = 0
+    for k, (bid, sz) in enumerate(zip(ids, sizes)):
+        p.block_id[k] = bid; p.block_size[k] = sz; p.block_idx[k] = idx
+        x0 = win.para_pose[bid] if bid < 11 else win.para_speed_bias[bid - 11]
+        for q in range(sz):
+            p.block_x0[k][q] = x0[q]
+        idx += 6 if sz == 7 else sz
+    J = rng.normal(0, 3.0, (n, n)); r = rng.normal(0, 0.1, n)
+    for i in range(n):
+        p.linearized_residuals[i] = r[i]
+        for j in range(n):
+            p.linearized_jacobians[i * n + j] = J[i, j]
+    s = BackendSolver(opts)
+    s.set_prior(p)
+    got = s.optimization(win)
+    _compare(got, oracle.window_solve(opts, win, p), tol_p=1e-6, tol_r=1e-7, tol_cost=1e-6)
+    s.close()
+
+
+def test_max_solver_time_is_honoured(oracle):
+    """options.max_solver_time (estimator.cpp:847-850): a limit that has already passed stops the solve at the top of the first iteration (state = initial state,
+    NO_CONVERGENCE, like Ceres); a generous limit changes nothing"""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    win, prior, _ = synth.make_window(5, o, synth.SynthConfig(n_features=60))
+    o.max_solver_time = 1e-9
+    s = BackendSolver(o); s.set_prior(prior)
+    got = s.optimization(win)
+    assert got.summary["num_iterations"] == 0 and got.summary["termination"] == 0    # VILF_TERM_NO_CONVERGENCE
+    assert np.allclose(got.para_pose, win.para_pose, atol=0, rtol=0)
+    s.close()
+    o.max_solver_time = 100.0
+    s = BackendSolver(o); s.set_prior(prior)
+    got = s.optimization(win)
+    o.max_solver_time = -1.0
+    _compare(got, oracle.window_solve(o, win, prior))
+    s.close()
+
+
+def test_cauchy_scale_other_than_one_on_both_paths(oracle):
+    """CauchyLoss(a), a != 1 (the reference uses 1.0, estimator.cpp:694): b = a^2 in rho(s) = b log(1 + s / b) on the batched AND the general path"""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    o.cauchy_a = 0.5
+    win, prior, _ = synth.make_window(6, o, synth.SynthConfig(n_features=60))
+    s = BackendSolver(o); s.set_prior(prior)
+    _compare(s.optimization(win), oracle.window_solve(o, win, prior))
+    s.close()
+    o6 = oracle.default_options(); o6.cauchy_a = 0.5; o6.window_size = 5
+    win6, _, _ = synth.make_window(7, o6, synth.SynthConfig(n_frames=6, n_features=50, with_prior=False))
+    s = BackendSolver(o6)
+    _compare(s.optimization(win6), oracle.window_solve(o6, win6, None), tol_p=1e-6, tol_r=1e-7, tol_cost=1e-6)
+    s.close()
+
+
+def test_malformed_inputs_are_rejected(solver, opts):
+    """the ABI never aborts: an observation CSR that does not cover [0, n_obs) and a prior block table outside [0, n) return INVALID_ARGUMENT"""
+    from vil_fusion_amd.lib import VilfError
+    win, prior, _ = synth.make_window(8, opts, synth.SynthConfig(n_features=20))
+    bad = copy.deepcopy(win)
+    bad.feature_obs_offset = bad.feature_obs_offset.copy(); bad.feature_obs_offset[-1] += 3
+    with pytest.raises(VilfError):
+        solver.batch_upload([bad], [None])
+    bad = copy.deepcopy(win)
+    bad.feature_obs_offset = bad.feature_obs_offset.copy(); bad.feature_obs_offset[0] = 1
+    with pytest.raises(VilfError):
+        solver.batch_upload([bad], [None])
+    p = copy.deepcopy(prior)
+    p.block_idx[p.n_blocks - 1] = p.n - 2
+    with pytest.raises(VilfError):
+        solver.set_prior(p)
+    solver.set_prior(None)

@@ -60,3 +60,34 @@ print("max rel err", np.abs(y - y_ref).max() / np.abs(y_ref).max())
 # staircase structure of Y
 nz = [np.nonzero(np.abs(Y[a][:, :NP]).max(0) > 1e-14)[0].min() for a in range(11)]
 print("first nonzero pose column of Y_a:", nz)
+
+# ---- product form (k_solve_sb v2): chain blocks a = 1..10 only (SpeedBias[0] belongs to the dense part), M_a = L_a^-1, N_a = M_a B_(a+1)^T ----
+ND = 75
+Hd = H[:ND, :ND]; Hcd = H[ND:, :ND]; Hcc = H[ND:, ND:]
+Dc = [Hcc[9 * k:9 * k + 9, 9 * k:9 * k + 9].copy() for k in range(10)]          # index k = a - 1
+Ec = [Hcc[9 * (k + 1):9 * (k + 1) + 9, 9 * k:9 * k + 9].copy() for k in range(9)]
+Lc = [None] * 10; Bc = [None] * 10
+for k in range(9, -1, -1):
+    Lc[k] = np.linalg.cholesky(Dc[k])
+    if k > 0:
+        Bc[k] = np.linalg.solve(Lc[k], Ec[k - 1]); Dc[k - 1] -= Bc[k].T @ Bc[k]
+M = [np.linalg.inv(l) for l in Lc]
+N = [M[k] @ Bc[k + 1].T for k in range(9)]                                      # N_a, a = k + 1 = 1..9
+R = np.hstack([Hcd, g[ND:, None]])
+Y = [None] * 10
+for k in range(9, -1, -1):
+    Y[k] = M[k] @ R[9 * k:9 * k + 9] - (N[k] @ Y[k + 1] if k < 9 else 0)
+Yall = np.vstack(Y)
+S = Hd - Yall[:, :ND].T @ Yall[:, :ND]; rhs = g[:ND] - Yall[:, :ND].T @ Yall[:, ND]
+yd = np.linalg.solve(S, rhs)
+r = g[ND:] - Hcd @ yd
+c = [M[k] @ r[9 * k:9 * k + 9] for k in range(10)]
+u = [None] * 10
+for k in range(9, -1, -1):
+    u[k] = c[k] - (N[k] @ u[k + 1] if k < 9 else 0)
+wv = [None] * 10; wv[0] = u[0]
+for k in range(9):
+    wv[k + 1] = u[k + 1] - N[k].T @ wv[k]
+x = [M[k].T @ wv[k] for k in range(10)]
+y2 = np.r_[yd, np.concatenate(x)]
+print("product form: max rel err", np.abs(y2 - y_ref).max() / np.abs(y_ref).max())

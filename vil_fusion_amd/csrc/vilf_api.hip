@@ -473,7 +473,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         // meta = LDS offset (14 bits) | permuted row index << 14 | permuted column index << 22; a source of -1 is absent.
         auto meta = [](int dst, int r, int c) { return dst | (r << 14) | (c << 22); };
         auto prow = [](int r) { return r * (r + 1) / 2; };
-        std::vector<int> la, lb, lc;
+        std::vector<int> la, lb, lc, ld;
         for (int r = 0; r < VB_NPOSE; r++) for (int c = 0; c <= r; c++) {           // pose-pose: H(6A+la, 6Bf+lb), A >= Bf
             const int A = r / 6, l1 = r % 6, Bf = c / 6, l2 = c % 6;
             int imu0 = -1, imu1 = -1, lid0 = -1, lid1 = -1;
@@ -495,14 +495,14 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             const int ra = VB_NPOSE + 9 * a;
             for (int i = 0; i < 9; i++) for (int j = 0; j <= i; j++) {              // D_a (lower)
                 const int e[4] = {meta(SB_OFF_D + 81 * (a - 1) + 9 * i + j, ra + i, ra + j), 900 * (a - 1) + 30 * (21 + i) + 21 + j, a <= 9 ? 900 * a + 30 * (6 + i) + 6 + j : -1, 0};
-                lc.insert(lc.end(), e, e + 4);
+                ld.insert(ld.end(), e, e + 4);
             }
             if (a <= 9) for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) {   // E_a = H(SpeedBias[a+1], SpeedBias[a])
                 const int e[4] = {meta(SB_OFF_E + 81 * (a - 1) + 9 * i + j, ra + 9 + i, ra + j), 900 * a + 30 * (21 + i) + 6 + j, -1, 0};
-                lc.insert(lc.end(), e, e + 4);
+                ld.insert(ld.end(), e, e + 4);
             }
             for (int i = 0; i < 9; i++) {                                           // band_a: [Pose a-1 | Pose a | Pose a+1 | SpeedBias[0] (a = 1)]
-                const int dst = SB_OFF_BAND + (9 * (a - 1) + i) * SB_BLD;
+                const int dst = SB_OFF_BAND + SB_BOFF(a) + i * SB_BSTR(a);
                 for (int m = 0; m < 6; m++) {
                     const int e0[4] = {meta(dst + m, ra + i, 6 * (a - 1) + m), 900 * (a - 1) + 30 * (21 + i) + m, -1, 0};
                     const int e1[4] = {meta(dst + 6 + m, ra + i, 6 * a + m), 900 * (a - 1) + 30 * (21 + i) + 15 + m, a <= 9 ? 900 * a + 30 * (6 + i) + m : -1, 0};
@@ -512,12 +512,13 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
                 if (a == 1) for (int j = 0; j < 9; j++) { const int e3[4] = {meta(dst + 18 + j, ra + i, VB_NPOSE + j), 30 * (21 + i) + 6 + j, -1, 0}; lc.insert(lc.end(), e3, e3 + 4); }
             }
         }
-        if (!h->d[D_LUTSBA].ensure(la.size() * 4) || !h->d[D_LUTSBB].ensure(lb.size() * 4) || !h->d[D_LUTSBC].ensure(lc.size() * 4)) return VILF_ERR_DEVICE;
+        if (!h->d[D_LUTSBA].ensure(la.size() * 4) || !h->d[D_LUTSBB].ensure(lb.size() * 4) || !h->d[D_LUTSBC].ensure(lc.size() * 4) || !h->d[D_LUTSBD].ensure(ld.size() * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemcpy(h->d[D_LUTSBA].p, la.data(), la.size() * 4, hipMemcpyHostToDevice));
         HIPCHECK(h, hipMemcpy(h->d[D_LUTSBB].p, lb.data(), lb.size() * 4, hipMemcpyHostToDevice));
         HIPCHECK(h, hipMemcpy(h->d[D_LUTSBC].p, lc.data(), lc.size() * 4, hipMemcpyHostToDevice));
-        h->batch.lut_sba = h->d[D_LUTSBA].as<int>(); h->batch.lut_sbb = h->d[D_LUTSBB].as<int>(); h->batch.lut_sbc = h->d[D_LUTSBC].as<int>();
-        h->batch.n_sba = (int)la.size() / 8; h->batch.n_sbb = (int)lb.size() / 2; h->batch.n_sbc = (int)lc.size() / 4;
+        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBD].p, ld.data(), ld.size() * 4, hipMemcpyHostToDevice));
+        h->batch.lut_sba = h->d[D_LUTSBA].as<int>(); h->batch.lut_sbb = h->d[D_LUTSBB].as<int>(); h->batch.lut_sbc = h->d[D_LUTSBC].as<int>(); h->batch.lut_sbd = h->d[D_LUTSBD].as<int>();
+        h->batch.n_sba = (int)la.size() / 8; h->batch.n_sbb = (int)lb.size() / 2; h->batch.n_sbc = (int)lc.size() / 4; h->batch.n_sbd = (int)ld.size() / 4;
     }
     const int nimu = B * 10;
     hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
@@ -805,24 +806,6 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     return VILF_OK;
 }
 extern "C" int vilf_window_marginalize(vilf_handle *h) { return vilf_batch_marginalize(h, 1); }
-
-extern "C" int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8) {
-    if (!h || !h->resident || !device_out8) return VILF_ERR_INVALID_ARGUMENT;
-    // [stamp x y z qx qy qz qw] per window from the gauge-fixed newest frame (host assembled; tiny)
-    const int B = h->B;
-    std::vector<double> Ps((size_t)B * 33), Rs((size_t)B * 99), out((size_t)B * 8);
-    HIPCHECK(h, hipMemcpyAsync(Ps.data(), h->batch.out_Ps, Ps.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(Rs.data(), h->batch.out_Rs, Rs.size() * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
-    for (int w = 0; w < B; w++) {
-        out[(size_t)w * 8] = stamps_host ? stamps_host[w] : (double)w;
-        for (int k = 0; k < 3; k++) out[(size_t)w * 8 + 1 + k] = Ps[(size_t)w * 33 + 30 + k];
-        quat_from_R(&Rs[(size_t)w * 99 + 90], &out[(size_t)w * 8 + 4]);
-    }
-    HIPCHECK(h, hipMemcpyAsync(device_out8, out.data(), out.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
-    return VILF_OK;
-}
 
 // ---- Ceres-layout hooks --------------------------------------------------------------------------------------
 static int hook_buf(vilf_handle *h, size_t doubles) { return h->d[D_HOOK].ensure(doubles * 8) ? VILF_OK : VILF_ERR_DEVICE; }

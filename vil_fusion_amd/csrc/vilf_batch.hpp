@@ -42,21 +42,23 @@
 #define SB_ND 75            // dense variables (permuted indices 0..74: poses, SpeedBias[0])
 #define SB_NR 76            // rows of the packed lower-triangular dense system (SB_ND + the right-hand side row)
 #define SB_NCH 10           // chain blocks: SpeedBias[1..10]
-#define SB_BLD 28           // band row stride: [pose a-1 | pose a | pose a+1 | SpeedBias[0] (a = 1 only) | rhs]
-#define SB_YLD 80           // row stride of the Y_a buffer (12 rows: 9 + 3 zero rows = 3 MFMA k-steps)
+// band_a = H~(SpeedBias[a], dense): [Pose a-1 | Pose a | Pose a+1 | rhs] (stride 20, rhs at 18); a = 1 also holds SpeedBias[0]: [.. | SpeedBias[0] | rhs] (stride 28, rhs at 27)
+#define SB_BSTR(a) ((a) == 1 ? 28 : 20)
+#define SB_BRHS(a) ((a) == 1 ? 27 : 18)
+#define SB_BOFF(a) ((a) == 1 ? 0 : 252 + 180 * ((a) - 2))
 #define SB_OFF_P 0
-#define SB_OFF_D (SB_OFF_P + SB_NR * (SB_NR + 1) / 2)            // 2926
-#define SB_OFF_E (SB_OFF_D + SB_NCH * 81)                         // 3736
-#define SB_OFF_BAND (SB_OFF_E + (SB_NCH - 1) * 81)                // 4465
-#define SB_OFF_Y (SB_OFF_BAND + SB_NCH * 9 * SB_BLD)              // 6985
-#define SB_OFF_VEC (SB_OFF_Y + 12 * SB_YLD)                       // 7945: g~, diagonal_, scale, y, v (168 each)
+#define SB_OFF_D (SB_OFF_P + SB_NR * (SB_NR + 1) / 2)            // 2926: D_a -> L_a -> M_a = L_a^-1 (lower, 9 x 9 each)
+#define SB_OFF_E (SB_OFF_D + SB_NCH * 81)                         // 3736: E_a -> B_(a+1) -> N_a
+#define SB_OFF_BAND (SB_OFF_E + (SB_NCH - 1) * 81)                // 4465: band_a -> M_a band_a
+#define SB_OFF_VEC (SB_OFF_BAND + 252 + 180 * (SB_NCH - 1))       // 6337: g~, diagonal_, scale, y, v (168 each)
 #define SB_VLD 168
 #define SB_OFF_T (SB_OFF_VEC + 5 * SB_VLD)                        // Cauchy-point row (80)
 #define SB_OFF_LINV (SB_OFF_T + 80)                               // 1 / L_ii of the chain blocks (96)
-#define SB_OFF_INVD (SB_OFF_LINV + 96)                            // 1 / L_jj of the dense block (80)
-#define SB_OFF_COL (SB_OFF_INVD + 80)                             // current column of the dense factorisation, double-buffered (2 x 80)
-#define SB_OFF_U (SB_OFF_COL + 160)                               // chain right-hand side / forward solution (96)
-#define SB_OFF_RED (SB_OFF_U + 96)                                // block-sum scratch (16)
+#define SB_OFF_DINV (SB_OFF_LINV + 96)                            // inverses of the 4 x 4 diagonal blocks of the dense factor (19 x 16)
+#define SB_OFF_PAN (SB_OFF_DINV + 19 * 16)                        // current 4-column panel of the dense factorisation, double-buffered (2 x 76 x 4)
+#define SB_OFF_U (SB_OFF_PAN + 2 * 304)                           // chain: forward solution (96)
+#define SB_OFF_W (SB_OFF_U + 96)                                  // chain: M r -> backward vectors (96)
+#define SB_OFF_RED (SB_OFF_W + 96)                                // block-sum scratch (16)
 #define SB_LDS_DOUBLES (SB_OFF_RED + 16)
 
 struct VbState {            // per-window trust-region state (ceres TrustRegionMinimizer + DoglegStrategy members)
@@ -136,8 +138,8 @@ struct VbBatch {
                             // coalesced 64-byte record instead of five dependent gathers
     const double *imu, *lidar;
     const int *lut_imu, *lut_lid, *lut_vis;   // static scatter tables: source element -> LDS tile offset (or -1)
-    const int *lut_sba, *lut_sbb, *lut_sbc;   // k_solve_sb gather tables (destination entry -> source elements): pose-pose [n][8], SpeedBias[0] rows [n][2], chain [n][4]
-    int n_sba, n_sbb, n_sbc;
+    const int *lut_sba, *lut_sbb, *lut_sbc, *lut_sbd;   // k_solve_sb gather tables (destination entry -> source elements): pose-pose [n][8], SpeedBias[0] rows [n][2], band [n][4], chain blocks D / E [n][4]
+    int n_sba, n_sbb, n_sbc, n_sbd;
     double *cf;             // [B][Fmax] per-feature Schur coefficient s_f / sqrt(h~_f'), then W_f . (S y)_p (k_solve_sb)
     const int *prior_hdr;
     const double *prior_x0, *prior_J, *prior_r, *prior_H, *prior_g;

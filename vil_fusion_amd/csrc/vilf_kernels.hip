@@ -1140,22 +1140,35 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_solve_sb — the same linear solve as k_solve (DoglegStrategy::ComputeStep on the Jacobi-scaled DENSE_SCHUR system), with the
-// speed-bias part eliminated FIRST. One 256-thread workgroup per window, 74 KB of LDS => two workgroups per CU.
+// speed-bias part eliminated FIRST. One 256-thread workgroup per window, 78 KB of LDS => two workgroups per CU.
 //
 //   H~ = [ dense (poses + SpeedBias[0], 75) | chain (SpeedBias[1..10], 10 x 9) ]: the chain part is block tridiagonal, its coupling to the dense part a
-//   band (SpeedBias[a] <-> Pose[a-1], Pose[a], Pose[a+1]; SpeedBias[1] <-> SpeedBias[0]). Phases:
-//   P1  gather assembly: one thread per DESTINATION entry sums its <= 6 source elements in a fixed order (host-built tables lut_sb*), scales, adds the LM
-//       term and stores — no atomics, no zero fill, one barrier; v^T H~ v of the Cauchy point rides along.
-//   P2  waves 0..2: MFMA Schur reduce of the inverse depths, U^T U in registers (5 of the 15 lower 16x16 tiles of the 80-wide dense block per wave)
-//       wave 3   : block-tridiagonal Cholesky of the chain, newest block first: L_a = chol(D_a), B_a = L_a^-1 E_(a-1), D_(a-1) -= B_a^T B_a
-//   P3  for a = 10..1: wave 3 forms Y_a = L_a^-1 (band_a - B_(a+1)^T Y_(a+1)) (two columns per lane, rhs as column 75); waves 0..2 add Y_a^T Y_a to the
-//       SAME accumulators (3 MFMA k-steps per tile)
-//   P4  dense -= accumulators (rows 0..74), rhs row 75, Cauchy row 76
-//   P5  Cholesky of the 75 + 1 dense rows: 4 x 4 register blocks, one thread per block of the lower triangle, ONE barrier per column (the column is
-//       broadcast through LDS, every thread recomputes the pivot's reciprocal square root) — no tile TRSM / POTRF chain
-//   P6  wave 0: back substitution of the dense block, then the chain forward / backward sweeps; waves 1..3: W_f . (S y)_p of every feature meanwhile
-//   P7  feature back-substitution, Gauss-Newton step, dogleg scalars (as k_solve)
+//   band (SpeedBias[a] <-> Pose[a-1], Pose[a], Pose[a+1]; SpeedBias[1] <-> SpeedBias[0]). A single window is latency-bound, so the phases are cut to
+//   keep every dependent chain short and to run the two long ones side by side:
+//   P1/P2  wave 3   : gathers the chain blocks D_a, E_a, then the block-tridiagonal Cholesky, newest block first:
+//                     L_a = chol(D_a), B_a = L_a^-1 E_(a-1), D_(a-1) -= B_a^T B_a                      (the longest dependent chain of the kernel)
+//          waves 0-2: gather assembly of the dense block and the band — one thread per DESTINATION entry sums its <= 6 source elements in a fixed order
+//                     (host-built tables lut_sb*), scales, adds the LM term and stores: no atomics, no zero fill; v^T H~ v of the Cauchy point rides along —
+//                     then the MFMA Schur reduce of the inverse depths, K split over the three waves (15 lower 16x16 tiles of the 80-wide dense block each)
+//   P2b    the three partial U^T U are subtracted in wave order; M_a = L_a^-1 and N_a = M_a B_(a+1)^T replace L_a / B_(a+1): every later use of the chain is
+//          a product, not a substitution
+//   P3     for a = 10..1: Y_a = M_a band_a - N_a Y_(a+1): wave 3 forms M_a band_a (VALU, 28 columns), waves 0-2 N_a Y_(a+1) on the MFMA (Y_(a+1) is already
+//          in their operand registers), then Y_a^T Y_a into 5 tile accumulators per wave (rhs as column 75)
+//   P4     dense -= Y^T Y
+//   P5     Cholesky of the 75 + 1 dense rows: 4 x 4 register blocks, one thread per block of the lower triangle, ONE barrier per 4-column panel (the panel
+//          is broadcast through LDS; every thread factors the 4 x 4 diagonal block itself and solves its own row / column strips)
+//   P6     wave 0: block back substitution of the dense part, then the chain: u_a = M_a r_a - N_a u_(a+1), w_(a+1) = u_(a+1) - N_a^T w_a, x_a = M_a^T w_a;
+//          waves 1-3: W_f . (S y)_p of every feature meanwhile
+//   P7     feature back-substitution, Gauss-Newton step, dogleg scalars (as k_solve)
 // Same arithmetic as a Cholesky of the whole system under another elimination order: results equal k_solve's to rounding.
+typedef unsigned int uint2_t __attribute__((ext_vector_type(2)));
+// raw buffer load of one double: ONE address register per load (32-bit byte offset against an SGPR descriptor) instead of a 64-bit pair, and an offset past the
+// end of the buffer returns zero — an absent source needs no clamped address and no select. elem < 0 means absent (offset far past num_records, no 32-bit wrap).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sb_rsrc(const double *p, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00027000); }
+__device__ __forceinline__ double sb_bload(__amdgpu_buffer_rsrc_t r, int elem) {
+    const uint2_t v = __builtin_amdgcn_raw_buffer_load_b64(r, elem < 0 ? 0x7ffffff0u : 8u * (unsigned)elem, 0, 0);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
 #define SBT 256
 #define SBW (SBT / 64)
 __device__ __forceinline__ double block_sum_sb(double v, double *s_red) {
@@ -1172,25 +1185,37 @@ __device__ __forceinline__ double block_sum_sb(double v, double *s_red) {
     return r;
 }
 __device__ __forceinline__ int sb_prow(int r) { return r * (r + 1) / 2; }
+// band position of dense column c in step a (-1: structurally zero)
+__device__ __forceinline__ int sb_band_pos(int a, int c) {
+    if (c < VB_NPOSE) { const int p = c - 6 * (a - 1); return (p >= 0 && p < 18) ? p : -1; }
+    if (c < SB_ND) return (a == 1) ? 18 + (c - VB_NPOSE) : -1;
+    return (c == SB_ND) ? SB_BRHS(a) : -1;
+}
 
-// waves 0..2: U^T U of the feature rows into acc[5]. Every wave streams ALL rows (no K split: nothing to combine afterwards); tile lists are compile-time.
+// the 15 lower 16 x 16 tiles of the 80-wide dense block. Function-local constant tables: a static data member would be a device global, which the host may
+// re-initialise (externally_initialized) — its loads are not folded after unrolling and every MFMA operand became a chain of selects.
+__device__ __forceinline__ constexpr int sb_t15_a(int i) { constexpr int T[15] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4}; return T[i]; }
+__device__ __forceinline__ constexpr int sb_t15_b(int i) { constexpr int T[15] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4}; return T[i]; }
+// P3: every wave owns <= 4 of those tiles and the 3 column tiles CT they touch; tile i = (CT[PA[i]], CT[PB[i]]):
+//   wave 0: (0,0) (1,0) (1,1) (2,0)   wave 1: (2,1) (2,2) (3,1) (3,2)   wave 2: (3,0) (3,3) (4,0) (4,3)   wave 3: (4,1) (4,2) (4,4)
+__device__ __forceinline__ constexpr int sb_y_ntl(int wv) { return wv == 3 ? 3 : 4; }
+__device__ __forceinline__ constexpr int sb_y_ct(int wv, int k) { constexpr int T[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 3, 4}, {1, 2, 4}}; return T[wv][k]; }
+__device__ __forceinline__ constexpr int sb_y_pa(int wv, int i) { constexpr int T[4][4] = {{0, 1, 1, 2}, {1, 1, 2, 2}, {1, 1, 2, 2}, {2, 2, 2, 2}}; return T[wv][i]; }
+__device__ __forceinline__ constexpr int sb_y_pb(int wv, int i) { constexpr int T[4][4] = {{0, 0, 1, 0}, {0, 1, 0, 1}, {0, 1, 0, 1}, {0, 1, 2, 2}}; return T[wv][i]; }
+
+// waves 0..2: U^T U of the feature rows, K split: wave wv takes the k-steps wv, wv + 3, ...
 //   dense columns 0..65 = W columns 0..65 (poses); 66..74 (SpeedBias[0]) = 0; 75 (rhs) = W column 66 (g_f); 76 (Cauchy row) = W column 67
-template <int WV> struct SbTiles;
-template <> struct SbTiles<0> { static constexpr int TA[5] = {0, 1, 1, 2, 2}, TB[5] = {0, 0, 1, 0, 1}; };
-template <> struct SbTiles<1> { static constexpr int TA[5] = {2, 3, 3, 4, 4}, TB[5] = {2, 2, 3, 2, 3}; };
-template <> struct SbTiles<2> { static constexpr int TA[5] = {3, 3, 4, 4, 4}, TB[5] = {0, 1, 0, 1, 4}; };
-template <int WV>
-__device__ __forceinline__ void sb_feature_reduce(const double *W, const double *cf, int F, const double *s_scale, double4_t (&acc)[5], int lane) {
-    constexpr const int *TA = SbTiles<WV>::TA, *TB = SbTiles<WV>::TB;
+__device__ __forceinline__ void sb_feature_reduce(const double *W, const double *cf, int F, int wv, const double *s_scale, double4_t (&acc)[15], int lane) {
     const int c16 = lane & 15, g4 = lane >> 4;
     const int nsteps = ((F + 3) & ~3) / 4;
-    if (nsteps == 0) return;
+    if (wv >= nsteps) return;
     double sc5[5];
 #pragma unroll
     for (int t5 = 0; t5 < 4; t5++) sc5[t5] = s_scale[16 * t5 + c16];
     sc5[4] = (c16 < 2) ? s_scale[64 + c16] : ((c16 == 11 || c16 == 12) ? 1.0 : 0.0);
     const int col4 = (c16 < 2) ? 64 + c16 : (c16 == 11 ? VB_NPOSE : (c16 == 12 ? VB_NPOSE + 1 : VB_NPOSE + 2));   // W column 68 is never written: zero
-    double ra[5], rb[5], rc[5], ca, cb, cc;
+    // five k-steps of W in flight per wave (a global round trip is ~3 us here; the wave alone on its SIMD has nothing else to cover it)
+    double r0[5], r1[5], r2[5], r3[5], r4[5], c0, c1, c2, c3, c4;
 #define SBF_ISSUE(ST, R, C)                                                                                                        \
     {                                                                                                                              \
         const int row_ = 4 * min((ST), nsteps - 1) + g4;                                                                           \
@@ -1205,50 +1230,81 @@ __device__ __forceinline__ void sb_feature_reduce(const double *W, const double 
     {                                                                                                                              \
         double u[5];                                                                                                               \
         _Pragma("unroll") for (int t5 = 0; t5 < 5; t5++) u[t5] = R[t5] * C * sc5[t5];                                              \
-        _Pragma("unroll") for (int i = 0; i < 5; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[TA[i]], u[TB[i]], acc[i], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 15; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[sb_t15_a(i)], u[sb_t15_b(i)], acc[i], 0, 0, 0); \
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    SBF_ISSUE(0, ra, ca) SBF_ISSUE(1, rb, cb)
-    for (int st = 0; st < nsteps; st += 3) {
-        SBF_ISSUE(st + 2, rc, cc) SBF_WAIT(12, ra, ca) SBF_STEP(ra, ca)
-        if (st + 1 < nsteps) { SBF_ISSUE(st + 3, ra, ca) SBF_WAIT(12, rb, cb) SBF_STEP(rb, cb) }
-        if (st + 2 < nsteps) { SBF_ISSUE(st + 4, rb, cb) SBF_WAIT(12, rc, cc) SBF_STEP(rc, cc) }
+    SBF_ISSUE(wv, r0, c0) SBF_ISSUE(wv + 3, r1, c1) SBF_ISSUE(wv + 6, r2, c2) SBF_ISSUE(wv + 9, r3, c3)
+    for (int st = wv; st < nsteps; st += 15) {
+        SBF_ISSUE(st + 12, r4, c4) SBF_WAIT(24, r0, c0) SBF_STEP(r0, c0)
+        if (st + 3 < nsteps) { SBF_ISSUE(st + 15, r0, c0) SBF_WAIT(24, r1, c1) SBF_STEP(r1, c1) }
+        if (st + 6 < nsteps) { SBF_ISSUE(st + 18, r1, c1) SBF_WAIT(24, r2, c2) SBF_STEP(r2, c2) }
+        if (st + 9 < nsteps) { SBF_ISSUE(st + 21, r2, c2) SBF_WAIT(24, r3, c3) SBF_STEP(r3, c3) }
+        if (st + 12 < nsteps) { SBF_ISSUE(st + 24, r3, c3) SBF_WAIT(24, r4, c4) SBF_STEP(r4, c4) }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]),
-                                        "+v"(rc[0]), "+v"(rc[1]), "+v"(rc[2]), "+v"(rc[3]), "+v"(rc[4]), "+v"(ca), "+v"(cb), "+v"(cc) : : "memory");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0[0]), "+v"(r0[1]), "+v"(r0[2]), "+v"(r0[3]), "+v"(r0[4]), "+v"(r1[0]), "+v"(r1[1]), "+v"(r1[2]), "+v"(r1[3]), "+v"(r1[4]),
+                                        "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r3[0]), "+v"(r3[1]), "+v"(r3[2]), "+v"(r3[3]), "+v"(r3[4]),
+                                        "+v"(r4[0]), "+v"(r4[1]), "+v"(r4[2]), "+v"(r4[3]), "+v"(r4[4]), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3), "+v"(c4) : : "memory");
 #undef SBF_ISSUE
 #undef SBF_WAIT
 #undef SBF_STEP
 }
-// waves 0..2: the 12 x 80 Y buffer (three k-steps) as MFMA operands, and the accumulation
-__device__ __forceinline__ void sb_y_load(const double *s_Y, double (&yo)[3][5], int lane) {
+// dense -= acc (rows <= 74, lower triangle), rhs row 75, Cauchy row 76 -> s_t. LDS fp64 atomics: 60 independent adds in flight instead of 60 dependent
+// read-subtract-write round trips; inside one barrier-separated turn every entry receives exactly one addend (one lane of one wave owns it): deterministic.
+__device__ __forceinline__ void sb_acc_sub(double *s_P, double *s_t, int TA, int TB, const double4_t &a, int lane, bool cauchy) {
     const int c16 = lane & 15, g4 = lane >> 4;
 #pragma unroll
-    for (int ks = 0; ks < 3; ks++)
-#pragma unroll
-        for (int t5 = 0; t5 < 5; t5++) yo[ks][t5] = s_Y[(4 * ks + g4) * SB_YLD + 16 * t5 + c16];
+    for (int q = 0; q < 4; q++) {
+        const int r = 16 * TA + g4 + 4 * q, c = 16 * TB + c16;
+        if (r < SB_NR && c <= r && c < SB_ND) lds_add(&s_P[sb_prow(r) + c], -a[q]);
+        else if (cauchy && r == SB_NR && c < SB_ND) lds_add(&s_t[c], -a[q]);
+    }
 }
+// P3, one wave: Y_a = M_a band_a - N_a Y_(a+1) for a = 10..1 on the wave's three column tiles, entirely in registers — the MFMA output layout of
+// T = N_a Y_(a+1) (lane (g4, c16), element q: row g4 + 4 q) IS the B-operand layout of the next product (k-step q: row 4 q + g4), so the recurrence needs
+// no exchange and no barrier; Y_a^T Y_a of the wave's tiles accumulates alongside. M_a band_a and N_a are read-only in LDS.
 template <int WV>
-__device__ __forceinline__ void sb_y_mfma(const double (&yo)[3][5], double4_t (&acc)[5]) {
-    constexpr const int *TA = SbTiles<WV>::TA, *TB = SbTiles<WV>::TB;
-#pragma unroll
-    for (int ks = 0; ks < 3; ks++)
-#pragma unroll
-        for (int i = 0; i < 5; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[ks][TA[i]], yo[ks][TB[i]], acc[i], 0, 0, 0);
-}
-// dense -= acc (rows <= 74, lower triangle), rhs row 75, Cauchy row 76 -> s_t. Every entry is owned by exactly one lane of one wave.
-template <int WV>
-__device__ __forceinline__ void sb_acc_store(const double4_t (&acc)[5], double *s_P, double *s_t, int lane) {
-    constexpr const int *TA = SbTiles<WV>::TA, *TB = SbTiles<WV>::TB;
+__device__ __forceinline__ void sb_y_chain(const double *s_band, const double *s_E, double4_t (&acc)[4], int lane) {
     const int c16 = lane & 15, g4 = lane >> 4;
+    double4_t t[3];
 #pragma unroll
-    for (int i = 0; i < 5; i++)
+    for (int ct = 0; ct < 3; ct++) t[ct] = double4_t{0, 0, 0, 0};
+#pragma unroll 1
+    for (int a = SB_NCH; a >= 1; a--) {
+        const double *Ba = s_band + SB_BOFF(a);
+        const int str = SB_BSTR(a);
+        double yo[3][3];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = 16 * TA[i] + g4 + 4 * q, c = 16 * TB[i] + c16;
-            if (r < SB_NR && c <= r && c < SB_ND) s_P[sb_prow(r) + c] -= acc[i][q];
-            else if (r == SB_NR && c < SB_ND) s_t[c] = -acc[i][q];
+        for (int ct = 0; ct < 3; ct++) {
+            const int p = sb_band_pos(a, 16 * sb_y_ct(WV, ct) + c16);
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) {
+                const int r = 4 * ks + g4;
+                const double v = Ba[min(r, 8) * str + max(p, 0)];
+                yo[ks][ct] = ((r < 9 && p >= 0) ? v : 0.0) - t[ct][ks];
+            }
         }
+        if (a > 1) {                                   // T of the next step first: the chain waits for it, the tile products below do not
+            const double *Na = s_E + 81 * (a - 2);     // N_(a-1)
+            double av[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++) { const int k = 4 * ks + g4; const double v = Na[9 * min(c16, 8) + min(k, 8)]; av[ks] = (c16 < 9 && k < 9) ? v : 0.0; }
+#pragma unroll
+            for (int ct = 0; ct < 3; ct++) t[ct] = double4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+                for (int ct = 0; ct < 3; ct++) t[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ks], yo[ks][ct], t[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ks++)
+#pragma unroll
+            for (int i = 0; i < sb_y_ntl(WV); i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(yo[ks][sb_y_pa(WV, i)], yo[ks][sb_y_pb(WV, i)], acc[i], 0, 0, 0);
+    }
+}
+template <int WV>
+__device__ __forceinline__ void sb_y_store(const double4_t (&acc)[4], double *s_P, double *s_t, int lane) {
+#pragma unroll
+    for (int i = 0; i < sb_y_ntl(WV); i++) sb_acc_sub(s_P, s_t, sb_y_ct(WV, sb_y_pa(WV, i)), sb_y_ct(WV, sb_y_pb(WV, i)), acc[i], lane, false);
 }
 
 // wave 3: 9 x 9 lower Cholesky by lanes 0..8 (lane r = row r in registers, pivots broadcast through SGPRs), result written back, 1 / L_ii to linv
@@ -1277,14 +1333,14 @@ __device__ __forceinline__ bool sb_potrf9(double *Dp, double *linv, int lane) {
     }
     return ok;
 }
-
+// one gather entry of the chain / band tables: (meta, src0, src1, -) -> scaled value + LM term, Cauchy-point contribution
 extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     VbState *st = b.st + w;
     extern __shared__ double s_dyn[];
-    double *s_P = s_dyn + SB_OFF_P, *s_D = s_dyn + SB_OFF_D, *s_E = s_dyn + SB_OFF_E, *s_band = s_dyn + SB_OFF_BAND, *s_Y = s_dyn + SB_OFF_Y;
+    double *s_P = s_dyn + SB_OFF_P, *s_D = s_dyn + SB_OFF_D, *s_E = s_dyn + SB_OFF_E, *s_band = s_dyn + SB_OFF_BAND;
     double *s_g = s_dyn + SB_OFF_VEC, *s_diag = s_g + SB_VLD, *s_scale = s_diag + SB_VLD, *s_y = s_scale + SB_VLD, *s_v = s_y + SB_VLD;
-    double *s_t = s_dyn + SB_OFF_T, *s_linv = s_dyn + SB_OFF_LINV, *s_invd = s_dyn + SB_OFF_INVD, *s_col = s_dyn + SB_OFF_COL, *s_u = s_dyn + SB_OFF_U;
+    double *s_t = s_dyn + SB_OFF_T, *s_linv = s_dyn + SB_OFF_LINV, *s_dinv = s_dyn + SB_OFF_DINV, *s_pan = s_dyn + SB_OFF_PAN, *s_u = s_dyn + SB_OFF_U, *s_w = s_dyn + SB_OFF_W;
     double *s_red = s_dyn + SB_OFF_RED;
     __shared__ int s_pcp[VB_P];        // permuted reduced index -> prior column (-1: not in the prior)
     __shared__ int s_flag[4];
@@ -1319,10 +1375,15 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     const double *g_in = b.g + (size_t)w * VB_P;
     const int *phdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
     const bool has_prior = phdr[0] != 0;
+    const __amdgpu_buffer_rsrc_t rHpp = sb_rsrc(Hpp, 66 * 36 * 8), rImu = sb_rsrc(imuH, 9000 * 8), rLid = sb_rsrc(lidH, 1440 * 8), rPri = sb_rsrc(priorH, VB_PRIOR_LD * VB_PRIOR_LD * 8);
 
     // ---- set-up: prior column map, zero fill (padding entries stay zero for the whole launch), scaling vectors --------------------------------
-    for (int i = tid; i < SB_LDS_DOUBLES; i += SBT) s_dyn[i] = 0.0;
+    for (int i = tid; i < SB_NCH * 81; i += SBT) s_D[i] = 0.0;              // upper triangles of D_a (read by the row-wise factorisation), band padding, Cauchy row
+    for (int i = tid; i < 252 + 180 * (SB_NCH - 1); i += SBT) s_band[i] = 0.0;
+    if (tid < 80) s_t[tid] = 0.0;
+    if (tid == 0) s_P[sb_prow(SB_ND) + SB_ND] = 0.0;
     if (tid < VB_P) s_pcp[tid] = -1;
+    if (tid == 0) s_flag[3] = 0;
     __syncthreads();
     if (has_prior && tid < phdr[2]) {
         const int id = phdr[3 + tid], idx = phdr[51 + tid];
@@ -1347,20 +1408,18 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         g2 = gr * gr;
         s_scale[tid] = sc; s_diag[tid] = d; s_g[tid] = gs; s_v[tid] = gr / d;
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int f = tid + u * SBT;
-        if (f < F && !f_const[f]) {
-            const double hfv = hf[f], gfv = gf[f];
-            double sf;
-            if (scaling_ready) sf = scale_g[VB_P + f]; else { sf = 1.0 / (1.0 + sqrt(hfv)); scale_g[VB_P + f] = sf; }
-            const double d = sqrt(fmin(fmax(sf * sf * hfv, b.min_lm_diagonal), b.max_lm_diagonal));
-            diag_g[VB_P + f] = d;
-            const double gr = sf * gfv / d;
-            grad_g[VB_P + f] = gr;
-            g2 += gr * gr;
-        }
+    for (int f = tid; f < F; f += SBT) {
+        if (f_const[f]) continue;
+        const double hfv = hf[f], gfv = gf[f];
+        double sf;
+        if (scaling_ready) sf = scale_g[VB_P + f]; else { sf = 1.0 / (1.0 + sqrt(hfv)); scale_g[VB_P + f] = sf; }
+        const double d = sqrt(fmin(fmax(sf * sf * hfv, b.min_lm_diagonal), b.max_lm_diagonal));
+        diag_g[VB_P + f] = d;
+        const double gr = sf * gfv / d;
+        grad_g[VB_P + f] = gr;
+        g2 += gr * gr;
     }
+    __threadfence_block();
     __syncthreads();
     // thread -> 4 x 4 block of the dense lower triangle (19 block rows, 190 blocks)
     int blk_i = 0;
@@ -1371,118 +1430,40 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     STAMP(1, 1);
     for (;;) {
         // lane-derived predicates and addresses of the phases below are loop invariant; hoisted out of this (rarely repeated) loop they would pin ~100 registers
-        int ln = lane, bi = blk_i, bjm = blk_j;
-        asm volatile("" : "+v"(ln), "+v"(bi), "+v"(bjm));
-        // ---- P1: gather assembly ----------------------------------------------------------------------------------------------------------------
+        int ln = lane, bi = blk_i, bjm = blk_j, td = tid;
+        asm volatile("" : "+v"(ln), "+v"(bi), "+v"(bjm), "+v"(td));
         double part = 0;
-        {
-            const int4 *la = (const int4 *)b.lut_sba;
-            for (int e0 = tid; e0 < b.n_sba; e0 += 3 * SBT) {               // pose-pose: visual + IMU (<= 2) + LiDAR (<= 2) + prior, three entries in flight
-                int4 m0[3], m1[3]; double sv[3][6];
+        if (td == 0) s_flag[2] = 1;
+        // ---- P1 / P2 --------------------------------------------------------------------------------------------------------------------------------
+        if (wave == 3) {
+            // chain blocks D_a (lower) and E_a straight from the IMU blocks: every destination entry decodes its own source indices (no table: a table read
+            // would be one more dependent global round trip, ~3 us each here), all loads of the lane in flight at once
+            {
+                double sv[25][2]; int meta[25];
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const int e = min(e0 + u * SBT, b.n_sba - 1); m0[u] = la[2 * e]; m1[u] = la[2 * e + 1]; }
-#pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int r = (m0[u].x >> 14) & 255, c = (m0[u].x >> 22) & 255;
-                    const int pr = s_pcp[r], pc = s_pcp[c];
-                    sv[u][0] = Hpp[m0[u].y];
-                    sv[u][1] = imuH[max(m0[u].z, 0)]; sv[u][2] = imuH[max(m0[u].w, 0)];
-                    sv[u][3] = lidH[max(m1[u].x, 0)]; sv[u][4] = lidH[max(m1[u].y, 0)];
-                    sv[u][5] = priorH[(size_t)max(pr, 0) * VB_PRIOR_LD + max(pc, 0)];
-                    if (m0[u].z < 0) sv[u][1] = 0.0;
-                    if (m0[u].w < 0) sv[u][2] = 0.0;
-                    if (m1[u].x < 0) sv[u][3] = 0.0;
-                    if (m1[u].y < 0) sv[u][4] = 0.0;
-                    if (pr < 0 || pc < 0) sv[u][5] = 0.0;
+                for (int u = 0; u < 13; u++) {          // D_a[i][j], j <= i: IMU factor a-1 rows 21.. (+ factor a rows 6..)
+                    const int q = min(ln + 64 * u, 809), a1 = q / 81, rem = q - 81 * a1, i = rem / 9, j = rem - 9 * i;
+                    const bool on = ln + 64 * u < 810 && j <= i;
+                    sv[u][0] = sb_bload(rImu, 900 * a1 + 30 * (21 + i) + 21 + j);
+                    sv[u][1] = sb_bload(rImu, a1 + 1 <= 9 ? 900 * (a1 + 1) + 30 * (6 + i) + 6 + j : -1);
+                    meta[u] = on ? ((SB_OFF_D + q) | ((VB_NPOSE + 9 + 9 * a1 + i) << 14) | ((VB_NPOSE + 9 + 9 * a1 + j) << 22)) : -1;
                 }
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    if (e0 + u * SBT >= b.n_sba) continue;
-                    const int r = (m0[u].x >> 14) & 255, c = (m0[u].x >> 22) & 255;
-                    const double val = (((((sv[u][0] + sv[u][1]) + sv[u][2]) + sv[u][3]) + sv[u][4]) + sv[u][5]) * s_scale[r] * s_scale[c];
-                    part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
-                    s_dyn[m0[u].x & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
-                }
-            }
-            const int2 *lb = (const int2 *)b.lut_sbb;
-            for (int e0 = tid; e0 < b.n_sbb; e0 += 3 * SBT) {               // SpeedBias[0] rows of the dense block: IMU factor 0 + prior
-                int2 m[3]; double sv[3][2];
-#pragma unroll
-                for (int u = 0; u < 3; u++) m[u] = lb[min(e0 + u * SBT, b.n_sbb - 1)];
-#pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int r = (m[u].x >> 14) & 255, c = (m[u].x >> 22) & 255;
-                    const int pr = s_pcp[r], pc = s_pcp[c];
-                    sv[u][0] = imuH[max(m[u].y, 0)];
-                    sv[u][1] = priorH[(size_t)max(pr, 0) * VB_PRIOR_LD + max(pc, 0)];
-                    if (m[u].y < 0) sv[u][0] = 0.0;
-                    if (pr < 0 || pc < 0) sv[u][1] = 0.0;
+                for (int u = 0; u < 12; u++) {          // E_a[i][j] = H(SpeedBias[a+1], SpeedBias[a]): IMU factor a, rows 21.., columns 6..
+                    const int q = min(ln + 64 * u, 728), a1 = q / 81, rem = q - 81 * a1, i = rem / 9, j = rem - 9 * i;
+                    sv[13 + u][0] = sb_bload(rImu, 900 * (a1 + 1) + 30 * (21 + i) + 6 + j);
+                    sv[13 + u][1] = 0.0;
+                    meta[13 + u] = (ln + 64 * u < 729) ? ((SB_OFF_E + q) | ((VB_NPOSE + 18 + 9 * a1 + i) << 14) | ((VB_NPOSE + 9 + 9 * a1 + j) << 22)) : -1;
                 }
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    if (e0 + u * SBT >= b.n_sbb) continue;
-                    const int r = (m[u].x >> 14) & 255, c = (m[u].x >> 22) & 255;
+                for (int u = 0; u < 25; u++) {
+                    if (meta[u] < 0) continue;
+                    const int r = (meta[u] >> 14) & 255, c = (meta[u] >> 22) & 255;
                     const double val = (sv[u][0] + sv[u][1]) * s_scale[r] * s_scale[c];
                     part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
-                    s_dyn[m[u].x & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                    s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
                 }
             }
-            const int4 *lc = (const int4 *)b.lut_sbc;
-            for (int e0 = tid; e0 < b.n_sbc; e0 += 4 * SBT) {               // chain: diagonal blocks D_a, sub-diagonal blocks E_a, band
-                int4 m[4]; double sv[4][2];
-#pragma unroll
-                for (int u = 0; u < 4; u++) m[u] = lc[min(e0 + u * SBT, b.n_sbc - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { sv[u][0] = imuH[m[u].y]; sv[u][1] = imuH[max(m[u].z, 0)]; if (m[u].z < 0) sv[u][1] = 0.0; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (e0 + u * SBT >= b.n_sbc) continue;
-                    const int r = (m[u].x >> 14) & 255, c = (m[u].x >> 22) & 255;
-                    const double val = (sv[u][0] + sv[u][1]) * s_scale[r] * s_scale[c];
-                    part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
-                    s_dyn[m[u].x & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
-                }
-            }
-        }
-        STAMP(1, 2);
-        // right-hand sides: dense row 75, band column 27
-        if (tid < SB_ND) s_P[sb_prow(SB_ND) + tid] = s_g[tid];
-        if (tid >= 96 && tid < 96 + 9 * SB_NCH) { const int q = tid - 96, a1 = q / 9, i = q - 9 * a1; s_band[(9 * a1 + i) * SB_BLD + 27] = s_g[VB_NPOSE + 9 + q]; }
-        // per-feature: Cauchy-point terms (first try), Schur coefficient
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int f = tid + u * SBT;
-            if (f < ((F + 3) & ~3)) {
-                double c = 0.0, xf = 0.0;
-                if (f < F && !f_const[f]) {
-                    const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f], hfv = hf[f], gfv = gf[f];
-                    const double hp = sf * sf * hfv + mu * df * df;
-                    c = sf * rsqrt_nr(hp);
-                    if (tries == 0) {
-                        const double vf = sf * gfv / (df * df);
-                        part += sf * sf * hfv * vf * vf;
-                        xf = vf * hp / sf;              // column 67 of U: c_f x_f with c_f^2 x_f = s_f v_f  =>  (U^T U)[p][76] = sum_f s_f v_f W~_f[p]
-                    }
-                }
-                cf[f] = c;
-                if (tries == 0 && f < F) W[(size_t)f * VB_WLD + VB_NPOSE + 1] = xf;
-            }
-        }
-        __threadfence_block();
-        if (tries == 0) { G2 = block_sum_sb(g2, s_red); Jg2 = block_sum_sb(part, s_red); }
-        if (tid == 0) s_flag[2] = 1;
-        __syncthreads();
-        __threadfence_block();
-
-        STAMP(1, 3);
-        // ---- P2: feature Schur reduce (waves 0..2)  ||  block-tridiagonal Cholesky of the chain (wave 3) -------------------------------------------
-        double4_t acc[5];
-#pragma unroll
-        for (int i = 0; i < 5; i++) acc[i] = double4_t{0, 0, 0, 0};
-        if (wave == 0) sb_feature_reduce<0>(W, cf, F, s_scale, acc, ln);
-        else if (wave == 1) sb_feature_reduce<1>(W, cf, F, s_scale, acc, ln);
-        else if (wave == 2) sb_feature_reduce<2>(W, cf, F, s_scale, acc, ln);
-        else {
             bool ok = true;
 #pragma unroll 1
             for (int a = SB_NCH; a >= 1; a--) {
@@ -1515,72 +1496,216 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                 }
             }
             if (!ok && ln == 0) s_flag[2] = 0;
+            // ---- wave 3's slack (waves 0..2 are still reducing): M_a = L_a^-1 over L_a, band_a <- M_a band_a, N_a = M_a B_(a+1)^T over B_(a+1). One wave: LDS accesses
+            // are in program order, every pass reads all it needs before it writes ----
+            {
+                double mx[2][9];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {           // column c of M_a: L x = e_c (90 columns: lanes, lanes + 64)
+                    const int t = min(ln + 64 * u, 9 * SB_NCH - 1), a1 = t / 9, c = t - 9 * a1;
+                    const double *La = s_D + 81 * a1, *li = s_linv + 9 * a1;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                        for (int j = 0; j < i; j++) sacc -= La[9 * i + j] * mx[u][j];
+                        mx[u][i] = (i >= c) ? sacc * li[i] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int t = ln + 64 * u, a1 = t / 9, c = t - 9 * a1;
+                    if (t < 9 * SB_NCH) {
+#pragma unroll
+                        for (int i = 0; i < 9; i++) if (i >= c) s_D[81 * a1 + 9 * i + c] = mx[u][i];
+                    }
+                }
+                // the band is assembled by waves 0..2 (long done by now, but not ordered with this wave by a barrier): wait for their three arrivals
+                if (ln == 0) while (__hip_atomic_load(&s_flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 3) __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll 1
+                for (int t = ln; t < 28 + 19 * (SB_NCH - 1); t += 64) {   // band_a <- M_a band_a in place, one lane per column (the later uses of the band are all products with M_a)
+                    const int a = (t < 28) ? 1 : 2 + (t - 28) / 19, p = (t < 28) ? t : (t - 28) % 19;
+                    double *Bc = s_band + SB_BOFF(a) + p;
+                    const int str = SB_BSTR(a);
+                    const double *Ma = s_D + 81 * (a - 1);
+                    double bc[9], o[9];
+#pragma unroll
+                    for (int kk = 0; kk < 9; kk++) bc[kk] = Bc[kk * str];
+#pragma unroll
+                    for (int i = 0; i < 9; i++) {
+                        double sacc = 0;
+#pragma unroll
+                        for (int kk = 0; kk <= i; kk++) sacc += Ma[9 * i + kk] * bc[kk];
+                        o[i] = sacc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 9; i++) Bc[i * str] = o[i];
+                }
+#pragma unroll 1
+                for (int a1 = 0; a1 < SB_NCH - 1; a1++) {                 // N_a[i][j] = sum_(k <= i) M_a[i][k] B_(a+1)[j][k], a = a1 + 1; the slot's 81 entries are read before any is written
+                    double nv[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int e = min(ln + 64 * u, 80), i = e / 9, j = e - 9 * i;
+                        const double *Ma = s_D + 81 * a1 + 9 * i, *Bn = s_E + 81 * a1 + 9 * j;
+                        double sacc = 0;
+#pragma unroll
+                        for (int kk = 0; kk < 9; kk++) sacc += ((kk <= i) ? Ma[kk] : 0.0) * Bn[kk];
+                        nv[u] = sacc;
+                    }
+                    s_E[81 * a1 + ln] = nv[0];
+                    if (ln + 64 < 81) s_E[81 * a1 + ln + 64] = nv[1];
+                }
+            }
+        } else {
+            // dense block and band: gather assembly by the 192 threads of waves 0..2. One thread per DESTINATION entry; the entry decodes its source indices itself
+            // (no table: a table read would be one more dependent global round trip, ~3 us each here) and every load of the thread is in flight at once.
+            {
+                constexpr int KN = 4, KF = 9, KT = KN + KF;
+                double sn[KN][6], sf[KF][2];
+                int meta[KT];
+#pragma unroll
+                for (int u = 0; u < KN; u++) {           // pose blocks on / next to the diagonal (21 blocks): visual + IMU (<= 2) + LiDAR (<= 2) + prior
+                    const int q = min(td + 192 * u, 755), nb = q / 36, e = q - 36 * nb, l1 = e / 6, l2 = e - 6 * l1;
+                    const bool dg = nb < 11;
+                    const int A = dg ? nb : nb - 10, Bf = dg ? nb : nb - 11, r = 6 * A + l1, c = 6 * Bf + l2;
+                    const int i0 = dg ? 900 * (A - 1) + 30 * (15 + l1) + 15 + l2 : 900 * Bf + 30 * (15 + l1) + l2, i1i = 900 * A + 30 * l1 + l2;
+                    const int j0 = dg ? 144 * (A - 1) + 12 * (6 + l1) + 6 + l2 : 144 * Bf + 12 * (6 + l1) + l2, j1 = 144 * A + 12 * l1 + l2;
+                    const bool h0 = !dg || A >= 1, h1 = dg && A <= 9;
+                    const int pr = s_pcp[r], pc = s_pcp[c];
+                    sn[u][0] = sb_bload(rHpp, 36 * (A * (A + 1) / 2 + Bf) + e);
+                    sn[u][1] = sb_bload(rImu, h0 ? i0 : -1); sn[u][2] = sb_bload(rImu, h1 ? i1i : -1); sn[u][3] = sb_bload(rLid, h0 ? j0 : -1); sn[u][4] = sb_bload(rLid, h1 ? j1 : -1);
+                    sn[u][5] = sb_bload(rPri, (pr >= 0 && pc >= 0) ? pr * VB_PRIOR_LD + pc : -1);
+                    meta[u] = (td + 192 * u < 756 && c <= r) ? ((SB_OFF_P + sb_prow(r) + c) | (r << 14) | (c << 22)) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < KF; u++) {           // the other 45 pose blocks: visual + prior
+                    const int q = min(td + 192 * u, 1619), fb = q / 36, e = q - 36 * fb, l1 = e / 6, l2 = e - 6 * l1;
+                    int A2 = (int)((sqrtf(8.0f * (float)fb + 1.0f) - 1.0f) * 0.5f);
+                    if (A2 * (A2 + 1) / 2 > fb) A2--;
+                    if ((A2 + 1) * (A2 + 2) / 2 <= fb) A2++;
+                    const int Bf = fb - A2 * (A2 + 1) / 2, A = A2 + 2, r = 6 * A + l1, c = 6 * Bf + l2;
+                    const int pr = s_pcp[r], pc = s_pcp[c];
+                    sf[u][0] = sb_bload(rHpp, 36 * (A * (A + 1) / 2 + Bf) + e);
+                    sf[u][1] = sb_bload(rPri, (pr >= 0 && pc >= 0) ? pr * VB_PRIOR_LD + pc : -1);
+                    meta[KN + u] = (td + 192 * u < 1620) ? ((SB_OFF_P + sb_prow(r) + c) | (r << 14) | (c << 22)) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < KT; u++) {
+                    if (meta[u] < 0) continue;
+                    const int r = (meta[u] >> 14) & 255, c = (meta[u] >> 22) & 255;
+                    double raw;
+                    if (u < KN) raw = ((((sn[u][0] + sn[u][1]) + sn[u][2]) + sn[u][3]) + sn[u][4]) + sn[u][5];
+                    else raw = sf[u - KN][0] + sf[u - KN][1];
+                    const double val = raw * s_scale[r] * s_scale[c];
+                    part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
+                    s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);          // the second round's address arithmetic stays behind the first round (register pressure)
+            {
+                constexpr int KS = 4, KB2 = 13, KT = KS + KB2;
+                double ss[KS][2], sb3[KB2][2];
+                int meta[KT];
+#pragma unroll
+                for (int u = 0; u < KS; u++) {           // SpeedBias[0] rows of the dense block: IMU factor 0 (rows 6 + i) + prior
+                    const int q = min(td + 192 * u, 674), i = q / 75, c = q - 75 * i, r = VB_NPOSE + i, Bf = c / 6, l2 = c - 6 * Bf;
+                    const int src = (c < VB_NPOSE) ? 30 * (6 + i) + (Bf == 0 ? l2 : 15 + l2) : 30 * (6 + i) + 6 + (c - VB_NPOSE);
+                    const bool hs = c >= VB_NPOSE || Bf <= 1;
+                    const int pr = s_pcp[r], pc = s_pcp[min(c, VB_P - 1)];
+                    ss[u][0] = sb_bload(rImu, hs ? src : -1);
+                    ss[u][1] = sb_bload(rPri, (pr >= 0 && pc >= 0) ? pr * VB_PRIOR_LD + pc : -1);
+                    meta[u] = (td + 192 * u < 675 && c <= r) ? ((SB_OFF_P + sb_prow(r) + c) | (r << 14) | (c << 22)) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < KB2; u++) {          // band_a[i][pos]: SpeedBias[a] x (Pose a-1 | Pose a | Pose a+1 | SpeedBias[0] for a = 1)
+                    const int q = min(td + 192 * u, 2429), a1 = q / 243, rem = q - 243 * a1, i = rem / 27, pos = rem - 27 * i, a = a1 + 1;
+                    const int seg = pos / 6, m = pos - 6 * seg;            // seg 0: Pose a-1, 1: Pose a, 2: Pose a+1, 3..4: SpeedBias[0]
+                    const bool on = td + 192 * u < 2430 && (seg < 2 || (seg == 2 && a <= 9) || (seg >= 3 && a == 1));
+                    int s0, s1 = -1, c165;
+                    if (seg == 0) { s0 = 900 * a1 + 30 * (21 + i) + m; c165 = 6 * a1 + m; }
+                    else if (seg == 1) { s0 = 900 * a1 + 30 * (21 + i) + 15 + m; s1 = (a <= 9) ? 900 * a + 30 * (6 + i) + m : -1; c165 = 6 * a + m; }
+                    else if (seg == 2) { s0 = 900 * min(a, 9) + 30 * (6 + i) + 15 + m; c165 = 6 * (a + 1) + m; }
+                    else { s0 = 30 * (21 + i) + 6 + (pos - 18); c165 = VB_NPOSE + (pos - 18); }
+                    sb3[u][0] = sb_bload(rImu, on ? s0 : -1);
+                    sb3[u][1] = sb_bload(rImu, s1);
+                    meta[KS + u] = on ? ((SB_OFF_BAND + SB_BOFF(a) + i * SB_BSTR(a) + pos) | ((VB_NPOSE + 9 * a + i) << 14) | (c165 << 22)) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < KT; u++) {
+                    if (meta[u] < 0) continue;
+                    const int r = (meta[u] >> 14) & 255, c = (meta[u] >> 22) & 255;
+                    const double raw = (u < KS) ? ss[u < KS ? u : 0][0] + ss[u < KS ? u : 0][1] : sb3[u >= KS ? u - KS : 0][0] + sb3[u >= KS ? u - KS : 0][1];
+                    const double val = raw * s_scale[r] * s_scale[c];
+                    part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
+                    s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                }
+            }
+            // right-hand sides: dense row 75, band rhs column
+            if (td < SB_ND) s_P[sb_prow(SB_ND) + td] = s_g[td];
+            if (td >= 96 && td < 96 + 9 * SB_NCH) { const int q = td - 96, a = q / 9 + 1, i = q - 9 * (a - 1); s_band[SB_BOFF(a) + i * SB_BSTR(a) + SB_BRHS(a)] = s_g[VB_NPOSE + 9 + q]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // band and dense block of this wave are in LDS: wave 3 may take the band
+            if (ln == 0) __hip_atomic_fetch_add(&s_flag[3], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // per-feature Schur coefficient and (first try) the Cauchy-point terms. Every wave writes ALL features (identical values): each wave then reads
+            // back what it wrote itself — no cross-wave synchronisation while wave 3 runs the chain
+            for (int f = ln; f < ((F + 3) & ~3); f += 64) {
+                double c = 0.0, xf = 0.0;
+                if (f < F && !f_const[f]) {
+                    const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f], hfv = hf[f], gfv = gf[f];
+                    const double hp = sf * sf * hfv + mu * df * df;
+                    c = sf * rsqrt_nr(hp);
+                    if (tries == 0) {
+                        const double vf = sf * gfv / (df * df);
+                        if (wave == 0) part += sf * sf * hfv * vf * vf;
+                        xf = vf * hp / sf;              // column 67 of W: c_f x_f with c_f^2 x_f = s_f v_f  =>  (U^T U)[p][76] = sum_f s_f v_f W~_f[p]
+                    }
+                }
+                cf[f] = c;
+                if (tries == 0 && f < F) W[(size_t)f * VB_WLD + VB_NPOSE + 1] = xf;
+            }
+            __threadfence_block();
         }
+        STAMP(1, 2);
+        double4_t acc15[15];
+#pragma unroll
+        for (int i = 0; i < 15; i++) acc15[i] = double4_t{0, 0, 0, 0};
+        if (wave < 3) sb_feature_reduce(W, cf, F, wave, s_scale, acc15, ln);
 #ifdef VILF_STAMPS
         if (b.dbg && blockIdx.x == 0 && (tid & 63) == 0) b.dbg[32 + 16 + (tid >> 6)] = __builtin_readcyclecounter();
 #endif
         __syncthreads();
-
-        STAMP(1, 4);
-        // ---- P3: Y_a = L_a^-1 (band_a - B_(a+1)^T Y_(a+1)), accumulate Y_a^T Y_a ------------------------------------------------------------------
-        {
-            double yp0[9], yp1[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) { yp0[i] = 0.0; yp1[i] = 0.0; }
-            const int c0 = min(ln, 37), c1 = c0 + 38;          // wave 3, lanes 0..37: dense columns c0 and c0 + 38 (column 75 = rhs)
+        STAMP(1, 3);
+        // ---- P2b: dense -= U^T U, the three K partials in wave order (fixed order of the additions) ----------------------------------------------------
 #pragma unroll 1
-            for (int a = SB_NCH; a >= 1; a--) {
-                if (wave == 3) {
-                    const double *Ba = s_band + 9 * (a - 1) * SB_BLD, *La = s_D + 81 * (a - 1), *Bn = s_E + 81 * (a - 1) /* B_(a+1): rows s_(a+1), cols s_a */;
-                    // band position of a dense column (-1: structurally zero)
-                    int p0 = c0 - 6 * (a - 1); if (p0 < 0 || p0 >= 18 || c0 >= VB_NPOSE) p0 = -1;
-                    int p1 = c1 - 6 * (a - 1); if (p1 < 0 || p1 >= 18 || c1 >= VB_NPOSE) p1 = -1;
-                    if (a == 1 && c1 >= VB_NPOSE && c1 < SB_ND) p1 = 18 + (c1 - VB_NPOSE);
-                    if (c1 == SB_ND) p1 = 27;
-                    double t0[9], t1[9];
+        for (int turn = 0; turn < 3; turn++) {
+            if (wave == turn) {
 #pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        const double v0 = Ba[i * SB_BLD + max(p0, 0)], v1 = Ba[i * SB_BLD + max(p1, 0)];
-                        t0[i] = (p0 >= 0) ? v0 : 0.0; t1[i] = (p1 >= 0) ? v1 : 0.0;
-                    }
-                    if (a < SB_NCH) {
-#pragma unroll
-                        for (int j = 0; j < 9; j++)
-#pragma unroll
-                            for (int i = 0; i < 9; i++) { const double bji = Bn[9 * j + i]; t0[i] -= bji * yp0[j]; t1[i] -= bji * yp1[j]; }
-                    }
-#pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        double s0 = t0[i], s1 = t1[i];
-#pragma unroll
-                        for (int j = 0; j < i; j++) { const double lij = La[9 * i + j]; s0 -= lij * yp0[j]; s1 -= lij * yp1[j]; }
-                        const double li = s_linv[9 * (a - 1) + i];
-                        yp0[i] = s0 * li; yp1[i] = s1 * li;       // yp* now hold Y_a (rows < i already replaced: the substitution reads exactly those)
-                    }
-                    if (ln < 38) {
-#pragma unroll
-                        for (int i = 0; i < 9; i++) { s_Y[i * SB_YLD + c0] = yp0[i]; s_Y[i * SB_YLD + c1] = yp1[i]; }
-                    }
-                }
-                __syncthreads();
-                double yo[3][5];
-                if (wave < 3) sb_y_load(s_Y, yo, ln);
-                __syncthreads();
-                if (wave == 0) sb_y_mfma<0>(yo, acc); else if (wave == 1) sb_y_mfma<1>(yo, acc); else if (wave == 2) sb_y_mfma<2>(yo, acc);
+                for (int i = 0; i < 15; i++) sb_acc_sub(s_P, s_t, sb_t15_a(i), sb_t15_b(i), acc15[i], ln, true);
             }
+            __syncthreads();
         }
-        STAMP(1, 5);
-        // ---- P4: dense -= U^T U + Y^T Y ---------------------------------------------------------------------------------------------------------
-        if (wave == 0) sb_acc_store<0>(acc, s_P, s_t, ln); else if (wave == 1) sb_acc_store<1>(acc, s_P, s_t, ln); else if (wave == 2) sb_acc_store<2>(acc, s_P, s_t, ln);
-        __syncthreads();
+        if (tries == 0) { G2 = block_sum_sb(g2, s_red); Jg2 = block_sum_sb(part, s_red); }
         if (tries == 0) {                             // cross term of the Cauchy point: 2 sum_p v_p S_p sum_f s_f v_f W_f[p]  (s_t = -that inner sum, scaled)
-            double cr = ((lane < VB_NPOSE) ? s_v[lane] * s_t[lane] : 0.0) + ((lane + 64 < VB_NPOSE) ? s_v[lane + 64] * s_t[lane + 64] : 0.0);
+            double cr = ((ln < VB_NPOSE) ? s_v[ln] * s_t[ln] : 0.0) + ((ln + 64 < VB_NPOSE) ? s_v[ln + 64] * s_t[ln + 64] : 0.0);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
             Jg2 -= 2.0 * cr;
         }
+        STAMP(1, 4);
+        // ---- P3: Y_a = M_a band_a - N_a Y_(a+1) and Y_a^T Y_a, every wave on its own column tiles (registers only, no barrier) ----------------------------
+        double4_t acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = double4_t{0, 0, 0, 0};
+        if (wave == 0) sb_y_chain<0>(s_band, s_E, acc, ln); else if (wave == 1) sb_y_chain<1>(s_band, s_E, acc, ln);
+        else if (wave == 2) sb_y_chain<2>(s_band, s_E, acc, ln); else sb_y_chain<3>(s_band, s_E, acc, ln);
+        STAMP(1, 5);
+        // ---- P4: dense -= Y^T Y -------------------------------------------------------------------------------------------------------------------
+        if (wave == 0) sb_y_store<0>(acc, s_P, s_t, ln); else if (wave == 1) sb_y_store<1>(acc, s_P, s_t, ln);
+        else if (wave == 2) sb_y_store<2>(acc, s_P, s_t, ln); else sb_y_store<3>(acc, s_P, s_t, ln);
+        __syncthreads();
         STAMP(1, 6);
-        // ---- P5: Cholesky of the dense block, rhs as row 75 (L[75][0..74] = L^-1 rhs) ---------------------------------------------------------------
+        // ---- P5: Cholesky of the dense block, rhs as row 75 (L[75][0..74] = L^-1 rhs), one 4-column panel per barrier -----------------------------------
         {
             double a4[4][4];
 #pragma unroll
@@ -1592,41 +1717,58 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                 }
 #pragma unroll 1
             for (int bj = 0; bj < 19; bj++) {
+                double *pb = s_pan + 304 * (bj & 1);
+                if (blk_on && bjm == bj) {
 #pragma unroll
-                for (int jj = 0; jj < 4; jj++) {
-                    const int j = 4 * bj + jj;
-                    if (j >= SB_ND) break;
-                    double *col = s_col + 80 * (j & 1);
-                    if (blk_on && bjm == bj) {
+                    for (int ii = 0; ii < 4; ii++)
 #pragma unroll
-                        for (int ii = 0; ii < 4; ii++) col[4 * bi + ii] = a4[ii][jj];
-                    }
-                    __syncthreads();
-                    if (blk_on && bjm >= bj) {
-                        const double piv = col[j];
-                        if (!(piv > 0.0)) s_flag[2] = 0;
-                        const double d = rsqrt_h3(piv);
-                        double li[4], lk[4];
+                        for (int kk = 0; kk < 4; kk++) pb[(4 * bi + ii) * 4 + kk] = a4[ii][kk];
+                }
+                __syncthreads();
+                if (blk_on && bjm >= bj) {
+                    const double *dg = pb + 16 * bj;
+                    const double d00 = dg[0], d10 = dg[4], d11 = dg[5], d20 = dg[8], d21 = dg[9], d22 = dg[10], d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
+                    const double i0 = rsqrt_h3(d00), l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+                    const double t11 = d11 - l10 * l10, i1 = rsqrt_h3(t11), l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+                    const double t22 = d22 - l20 * l20 - l21 * l21, i2 = rsqrt_h3(t22), l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+                    const double t33 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+                    const bool last = 4 * bj + 3 >= SB_ND;            // panel 18: column 75 is the right-hand side row's own diagonal — not a pivot
+                    const double i3 = last ? 0.0 : rsqrt_h3(t33);
+                    if (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || (!last && !(t33 > 0.0))) s_flag[2] = 0;
+                    if (bi == bj) {                    // the diagonal block itself: L, and its inverse for the back substitution
+                        a4[0][0] = d00 * i0; a4[1][0] = l10; a4[2][0] = l20; a4[3][0] = l30;
+                        a4[1][1] = t11 * i1; a4[2][1] = l21; a4[3][1] = l31;
+                        a4[2][2] = t22 * i2; a4[3][2] = l32; a4[3][3] = t33 * i3;
+                        const double m10 = -l10 * i0 * i1, m21 = -l21 * i1 * i2, m32 = -l32 * i2 * i3;
+                        const double m20 = -(l20 * i0 + l21 * m10) * i2, m31 = -(l31 * i1 + l32 * m21) * i3;
+                        const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
+                        double *dv = s_dinv + 16 * bj;
+                        dv[0] = i0; dv[4] = m10; dv[5] = i1; dv[8] = m20; dv[9] = m21; dv[10] = i2; dv[12] = m30; dv[13] = m31; dv[14] = m32; dv[15] = i3;
+                    } else {
+                        double lr[4][4];
 #pragma unroll
-                        for (int ii = 0; ii < 4; ii++) { li[ii] = col[4 * bi + ii] * d; lk[ii] = col[4 * bjm + ii] * d; }
+                        for (int ii = 0; ii < 4; ii++) {
+                            const double *rp = pb + (4 * bi + ii) * 4;
+                            const double x0 = rp[0] * i0, x1 = (rp[1] - x0 * l10) * i1, x2 = (rp[2] - x0 * l20 - x1 * l21) * i2, x3 = (rp[3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+                            lr[ii][0] = x0; lr[ii][1] = x1; lr[ii][2] = x2; lr[ii][3] = x3;
+                        }
                         if (bjm == bj) {
-#pragma unroll
-                            for (int ii = 0; ii < 4; ii++) {
-                                a4[ii][jj] = li[ii];
-#pragma unroll
-                                for (int kk = jj + 1; kk < 4; kk++) a4[ii][kk] -= li[ii] * lk[kk];
-                            }
-                            if (bi == bj) s_invd[j] = d;
-                        } else {
 #pragma unroll
                             for (int ii = 0; ii < 4; ii++)
 #pragma unroll
-                                for (int kk = 0; kk < 4; kk++) a4[ii][kk] -= li[ii] * lk[kk];
+                                for (int kk = 0; kk < 4; kk++) a4[ii][kk] = lr[ii][kk];
+                        } else {
+#pragma unroll
+                            for (int kk = 0; kk < 4; kk++) {
+                                const double *cp = pb + (4 * bjm + kk) * 4;
+                                const double x0 = cp[0] * i0, x1 = (cp[1] - x0 * l10) * i1, x2 = (cp[2] - x0 * l20 - x1 * l21) * i2, x3 = (cp[3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+#pragma unroll
+                                for (int ii = 0; ii < 4; ii++) a4[ii][kk] -= lr[ii][0] * x0 + lr[ii][1] * x1 + lr[ii][2] * x2 + lr[ii][3] * x3;
+                            }
                         }
                     }
                 }
             }
-            __syncthreads();
             if (blk_on) {
 #pragma unroll
                 for (int ii = 0; ii < 4; ii++)
@@ -1643,90 +1785,101 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         if (s_flag[2]) { solved = true; break; }
         mu *= 10.0;                                 // dogleg_strategy.cc: mu_ *= mu_increase_factor_
         if (!(mu < 1.0)) break;                     // max_mu_
+        if (tid == 0) s_flag[3] = 0;
         __syncthreads();
     }
     if (!solved) {
         if (tid == 0) { st->solve_failed = 1; st->mu = mu; st->num_linear_solves += tries; st->scaling_ready = 1; st->grad_sqnorm = G2; st->Jg2 = Jg2; }
         return;
     }
-    // ---- P6: wave 0 — back substitution L^T y = z of the dense block (z = row 75 of L); each lane owns entries lane and lane + 64 --------------------
+    // ---- P6: wave 0 — block back substitution L^T y = z of the dense part (z = row 75 of L); each lane owns entries lane and lane + 64 -----------------
     if (wave == 0) {
         const double *zrow = s_P + sb_prow(SB_ND);
         double z0 = zrow[lane], z1 = (lane + 64 < SB_ND) ? zrow[lane + 64] : 0.0;
+        // the factor rows and the inverse diagonal block of the NEXT block are fetched before the current block's dependent chain runs
+        double dvn[10], l0n[4], l1n[4];
+        auto fetch = [&](int bj) {
+            const double *d = s_dinv + 16 * bj;
+            dvn[0] = d[0]; dvn[1] = d[4]; dvn[2] = d[5]; dvn[3] = d[8]; dvn[4] = d[9]; dvn[5] = d[10]; dvn[6] = d[12]; dvn[7] = d[13]; dvn[8] = d[14]; dvn[9] = d[15];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) { const int r = 4 * bj + kk; const double *Lr = s_P + sb_prow(r); l0n[kk] = Lr[min(lane, r)]; l1n[kk] = Lr[min(lane + 64, r)]; }
+        };
+        fetch(18);
 #pragma unroll 1
-        for (int j = SB_ND - 1; j >= 64; j--) {
-            const double yj = readlane_f64(z1, j - 64) * s_invd[j];
-            const double *Lj = s_P + sb_prow(j);
-            const double l0 = Lj[lane], l1 = Lj[min(lane + 64, j)];
-            z0 -= l0 * yj;
-            if (lane + 64 < j) z1 -= l1 * yj;
-            if (lane + 64 == j) z1 = yj;
-        }
-#pragma unroll 2
-        for (int j = 63; j >= 0; j--) {
-            const double yj = readlane_f64(z0, j) * s_invd[j];
-            const double l0 = s_P[sb_prow(j) + min(lane, j)];
-            if (lane < j) z0 -= l0 * yj;
-            if (lane == j) z0 = yj;
+        for (int bj = 18; bj >= 0; bj--) {
+            const int r0 = 4 * bj;
+            double dv[10], l0[4], l1[4];
+#pragma unroll
+            for (int q = 0; q < 10; q++) dv[q] = dvn[q];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) { l0[kk] = l0n[kk]; l1[kk] = l1n[kk]; }
+            if (bj > 0) fetch(bj - 1);
+            double zb[4], yb[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int r = r0 + kk;
+                const double a = readlane_f64(z0, r & 63), c = readlane_f64(z1, r & 63);
+                zb[kk] = (r >= 64) ? c : a;
+            }
+            // y_blk = Ld^-T z_blk (dv = Ld^-1, lower; row / column 3 of block 18 are zero: row 75 is not a variable)
+            yb[0] = dv[0] * zb[0] + dv[1] * zb[1] + dv[3] * zb[2] + dv[6] * zb[3];
+            yb[1] = dv[2] * zb[1] + dv[4] * zb[2] + dv[7] * zb[3];
+            yb[2] = dv[5] * zb[2] + dv[8] * zb[3];
+            yb[3] = dv[9] * zb[3];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const int r = r0 + kk;
+                if (lane < r0) z0 -= l0[kk] * yb[kk];
+                if (lane + 64 < r0) z1 -= l1[kk] * yb[kk];
+                if (lane == r) z0 = yb[kk];
+                if (lane + 64 == r) z1 = yb[kk];
+            }
         }
         s_y[lane] = z0;
         if (lane + 64 < SB_ND) s_y[lane + 64] = z1;
     }
     __syncthreads();
     STAMP(1, 8);
-    // chain right-hand side r_a = g~_a - band_a y_dense (90 threads); (S y)_p for the feature back-substitution
+    // chain: c_a = M_a (g~_a - band_a y_dense) from the products M_a band_a (90 threads); (S y)_p for the feature back-substitution
     if (tid < 9 * SB_NCH) {
-        const int a1 = tid / 9, i = tid - 9 * a1, a = a1 + 1;
-        const double *Ba = s_band + (9 * a1 + i) * SB_BLD;
-        double s = s_g[VB_NPOSE + 9 + tid];
+        const int a = tid / 9 + 1, i = tid - 9 * (a - 1);
+        const double *Ba = s_band + SB_BOFF(a) + i * SB_BSTR(a);
+        double sacc = Ba[SB_BRHS(a)];
 #pragma unroll
-        for (int p = 0; p < 18; p++) { const int c = 6 * (a - 1) + p; if (c < VB_NPOSE) s -= Ba[p] * s_y[c]; }
+        for (int p = 0; p < 18; p++) { const int c = 6 * (a - 1) + p; if (c < VB_NPOSE) sacc -= Ba[p] * s_y[c]; }
         if (a == 1) {
 #pragma unroll
-            for (int p = 0; p < 9; p++) s -= Ba[18 + p] * s_y[VB_NPOSE + p];
+            for (int p = 0; p < 9; p++) sacc -= Ba[18 + p] * s_y[VB_NPOSE + p];
         }
-        s_u[tid] = s;
+        s_w[tid] = sacc;
     }
     if (tid >= 128 && tid < 128 + 80) { const int c = tid - 128; s_v[c] = (c < VB_NPOSE) ? s_scale[c] * s_y[c] : 0.0; }
     __syncthreads();
     if (wave == 0) {
-        // forward (a = 10..1): u_a = L_a^-1 (r_a - B_(a+1)^T u_(a+1)); backward (a = 1..10): x_a = L_a^-T (u_a - B_a x_(a-1)); lanes 0..8 = rows
+        // forward u_a = c_a - N_a u_(a+1) (a = 10..1), backward w_1 = u_1, w_(a+1) = u_(a+1) - N_a^T w_a; lanes 0..8 = rows
         const int i9 = min(lane, 8);
         double un = 0.0;
 #pragma unroll 1
         for (int a = SB_NCH; a >= 1; a--) {
-            const double *La = s_D + 81 * (a - 1), *Bn = s_E + 81 * (a - 1);
-            double t = s_u[9 * (a - 1) + i9];
+            double t = s_w[9 * (a - 1) + i9];
             if (a < SB_NCH) {
+                const double *Na = s_E + 81 * (a - 1) + 9 * i9;
 #pragma unroll
-                for (int j = 0; j < 9; j++) t -= Bn[9 * j + i9] * readlane_f64(un, j);
-            }
-#pragma unroll
-            for (int j = 0; j < 9; j++) {
-                const double xj = readlane_f64(t, j) * s_linv[9 * (a - 1) + j];
-                if (i9 > j) t -= La[9 * i9 + j] * xj;
-                if (i9 == j) t = xj;
+                for (int j = 0; j < 9; j++) t -= Na[j] * readlane_f64(un, j);
             }
             un = t;
             if (lane < 9) s_u[9 * (a - 1) + i9] = t;
         }
-        double xp = 0.0;
+        double wp = un;                 // w_1 = u_1
+        if (lane < 9) s_w[i9] = wp;
 #pragma unroll 1
-        for (int a = 1; a <= SB_NCH; a++) {
-            const double *La = s_D + 81 * (a - 1), *Bm = s_E + 81 * max(a - 2, 0);      // B_a: rows s_a, cols s_(a-1)
-            double t = s_u[9 * (a - 1) + i9];
-            if (a > 1) {
+        for (int a = 1; a < SB_NCH; a++) {
+            const double *Na = s_E + 81 * (a - 1);
+            double t = s_u[9 * a + i9];
 #pragma unroll
-                for (int j = 0; j < 9; j++) t -= Bm[9 * i9 + j] * readlane_f64(xp, j);
-            }
-#pragma unroll
-            for (int j = 8; j >= 0; j--) {
-                const double xj = readlane_f64(t, j) * s_linv[9 * (a - 1) + j];
-                if (i9 < j) t -= La[9 * j + i9] * xj;
-                if (i9 == j) t = xj;
-            }
-            xp = t;
-            if (lane < 9) s_y[VB_NPOSE + 9 * a + i9] = t;
+            for (int j = 0; j < 9; j++) t -= Na[9 * j + i9] * readlane_f64(wp, j);
+            wp = t;
+            if (lane < 9) s_w[9 * a + i9] = t;
         }
 #ifdef VILF_STAMPS
         if (b.dbg && blockIdx.x == 0 && tid == 0) b.dbg[32 + 9] = __builtin_readcyclecounter();
@@ -1773,6 +1926,14 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         __threadfence_block();
     }
     __syncthreads();
+    if (tid < 9 * SB_NCH) {      // x_a = M_a^T w_a
+        const int a1 = tid / 9, i = tid - 9 * a1;
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) s += ((k >= i) ? s_D[81 * a1 + 9 * k + i] : 0.0) * s_w[9 * a1 + k];
+        s_y[VB_NPOSE + 9 + tid] = s;
+    }
+    __syncthreads();
     STAMP(1, 10);
     // ---- P7: Gauss-Newton step = -diagonal_ .* y, feature back-substitution, reductions ---------------------------------------------------------
     double gy = 0, gn2 = 0;
@@ -1782,10 +1943,8 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         gy += s_g[tid] * y;
         gn2 += d * d * y * y;
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int f = tid + u * SBT;
-        if (f >= F || f_const[f]) continue;
+    for (int f = tid; f < F; f += SBT) {
+        if (f_const[f]) continue;
         const double sf = scale_g[VB_P + f], df = diag_g[VB_P + f];
         const double hp = sf * sf * hf[f] + mu * df * df;
         const double gt = sf * gf[f];

@@ -48,3 +48,46 @@ def newest_poses_rows(results, stamps):
         rows[i, 1:4] = r.Ps[-1]
         rows[i, 4:8] = R_to_q(r.Rs[-1])
     return rows
+
+
+class RcclPoseGather:
+    """ctypes mirror of the C-ABI collective (include/vilfusion.h: vilf_comm_* / vilf_gather_poses): what a C++ / ROS estimator process per GPU calls instead
+    of torch.distributed. rank 0 creates the id (ncclGetUniqueId) and the launcher hands it to the other ranks (here: any byte channel)."""
+
+    def __init__(self, world_size, rank, device=0, unique_id=None):
+        import ctypes as C
+        from . import lib as vlib
+        self._L = vlib.lib()
+        self._L.vilf_comm_last_error.restype = C.c_char_p
+        self._L.vilf_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        self._L.vilf_comm_destroy.argtypes = [C.c_void_p]
+        self._L.vilf_gather_poses.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        if unique_id is None:
+            unique_id = self.unique_id()
+        self.world_size, self.rank = world_size, rank
+        self._c = C.c_void_p()
+        rc = self._L.vilf_comm_create(bytes(unique_id), world_size, rank, device, C.byref(self._c))
+        if rc != 0:
+            raise RuntimeError(f"vilf_comm_create: {rc}: {self._L.vilf_comm_last_error().decode()}")
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import lib as vlib
+        L = vlib.lib()
+        buf = (C.c_ubyte * 128)()
+        L.vilf_comm_last_error.restype = C.c_char_p
+        rc = L.vilf_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"vilf_comm_unique_id: {rc}: {L.vilf_comm_last_error().decode()}")
+        return bytes(buf)
+
+    def gather(self, local_dev_ptr, n_local, out_dev_ptr, stream=None):
+        rc = self._L.vilf_gather_poses(self._c, stream, local_dev_ptr, n_local, out_dev_ptr)
+        if rc != 0:
+            raise RuntimeError(f"vilf_gather_poses: {rc}: {self._L.vilf_comm_last_error().decode()}")
+
+    def close(self):
+        if self._c:
+            self._L.vilf_comm_destroy(self._c)
+            self._c = None
