@@ -1248,16 +1248,28 @@ __device__ __forceinline__ void sb_feature_reduce(const double *W, const double 
 #undef SBF_WAIT
 #undef SBF_STEP
 }
-// dense -= acc (rows <= 74, lower triangle), rhs row 75, Cauchy row 76 -> s_t. LDS fp64 atomics: 60 independent adds in flight instead of 60 dependent
-// read-subtract-write round trips; inside one barrier-separated turn every entry receives exactly one addend (one lane of one wave owns it): deterministic.
-__device__ __forceinline__ void sb_acc_sub(double *s_P, double *s_t, int TA, int TB, const double4_t &a, int lane, bool cauchy) {
+// dense -= acc (rows <= 74, lower triangle), rhs row 75, Cauchy row 76 -> s_t, NTL tiles at a time: all reads, then the subtractions, then all writes — the entries of
+// one call are distinct (one lane of one wave owns each), so nothing orders the loads behind the stores; written as `x -= a` per entry the compiler must assume aliasing
+// and serialises the LDS round trips, and ds_add_f64 costs about as much per wave. An entry outside the stored triangle reads / writes a dump slot of its own.
+template <int NTL, int PA, int PB>       // tile i = ((PA >> 4 i) & 15, (PB >> 4 i) & 15)
+__device__ __forceinline__ void sb_acc_sub(double *s_P, double *s_t, const double4_t *a, int lane, bool cauchy, double *s_dump) {
     const int c16 = lane & 15, g4 = lane >> 4;
+    double v[NTL][4]; int off[NTL][4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int r = 16 * TA + g4 + 4 * q, c = 16 * TB + c16;
-        if (r < SB_NR && c <= r && c < SB_ND) lds_add(&s_P[sb_prow(r) + c], -a[q]);
-        else if (cauchy && r == SB_NR && c < SB_ND) lds_add(&s_t[c], -a[q]);
-    }
+    for (int i = 0; i < NTL; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 16 * ((PA >> (4 * i)) & 15) + g4 + 4 * q, c = 16 * ((PB >> (4 * i)) & 15) + c16;
+            int o = (int)(s_dump - s_P) + lane;                                          // not stored: a private dump slot (never read back as data)
+            if (r < SB_NR && c <= r && c < SB_ND) o = sb_prow(r) + c;
+            else if (cauchy && r == SB_NR && c < SB_ND) o = (int)(s_t - s_P) + c;
+            off[i][q] = o;
+            v[i][q] = s_P[o];
+        }
+#pragma unroll
+    for (int i = 0; i < NTL; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) s_P[off[i][q]] = v[i][q] - a[i][q];
 }
 // P3, one wave: Y_a = M_a band_a - N_a Y_(a+1) for a = 10..1 on the wave's three column tiles, entirely in registers — the MFMA output layout of
 // T = N_a Y_(a+1) (lane (g4, c16), element q: row g4 + 4 q) IS the B-operand layout of the next product (k-step q: row 4 q + g4), so the recurrence needs
@@ -1302,9 +1314,10 @@ __device__ __forceinline__ void sb_y_chain(const double *s_band, const double *s
     }
 }
 template <int WV>
-__device__ __forceinline__ void sb_y_store(const double4_t (&acc)[4], double *s_P, double *s_t, int lane) {
-#pragma unroll
-    for (int i = 0; i < sb_y_ntl(WV); i++) sb_acc_sub(s_P, s_t, sb_y_ct(WV, sb_y_pa(WV, i)), sb_y_ct(WV, sb_y_pb(WV, i)), acc[i], lane, false);
+__device__ __forceinline__ void sb_y_store(const double4_t (&acc)[4], double *s_P, double *s_t, int lane, double *s_dump) {
+    constexpr int PA = sb_y_ct(WV, sb_y_pa(WV, 0)) | (sb_y_ct(WV, sb_y_pa(WV, 1)) << 4) | (sb_y_ct(WV, sb_y_pa(WV, 2)) << 8) | (sb_y_ct(WV, sb_y_pa(WV, 3)) << 12);
+    constexpr int PB = sb_y_ct(WV, sb_y_pb(WV, 0)) | (sb_y_ct(WV, sb_y_pb(WV, 1)) << 4) | (sb_y_ct(WV, sb_y_pb(WV, 2)) << 8) | (sb_y_ct(WV, sb_y_pb(WV, 3)) << 12);
+    sb_acc_sub<sb_y_ntl(WV), PA, PB>(s_P, s_t, &acc[0], lane, false, s_dump);
 }
 
 // wave 3: 9 x 9 lower Cholesky by lanes 0..8 (lane r = row r in registers, pivots broadcast through SGPRs), result written back, 1 / L_ii to linv
@@ -1383,7 +1396,6 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     if (tid < 80) s_t[tid] = 0.0;
     if (tid == 0) s_P[sb_prow(SB_ND) + SB_ND] = 0.0;
     if (tid < VB_P) s_pcp[tid] = -1;
-    if (tid == 0) s_flag[3] = 0;
     __syncthreads();
     if (has_prior && tid < phdr[2]) {
         const int id = phdr[3 + tid], idx = phdr[51 + tid];
@@ -1496,68 +1508,6 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                 }
             }
             if (!ok && ln == 0) s_flag[2] = 0;
-            // ---- wave 3's slack (waves 0..2 are still reducing): M_a = L_a^-1 over L_a, band_a <- M_a band_a, N_a = M_a B_(a+1)^T over B_(a+1). One wave: LDS accesses
-            // are in program order, every pass reads all it needs before it writes ----
-            {
-                double mx[2][9];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {           // column c of M_a: L x = e_c (90 columns: lanes, lanes + 64)
-                    const int t = min(ln + 64 * u, 9 * SB_NCH - 1), a1 = t / 9, c = t - 9 * a1;
-                    const double *La = s_D + 81 * a1, *li = s_linv + 9 * a1;
-#pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        double sacc = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-                        for (int j = 0; j < i; j++) sacc -= La[9 * i + j] * mx[u][j];
-                        mx[u][i] = (i >= c) ? sacc * li[i] : 0.0;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int t = ln + 64 * u, a1 = t / 9, c = t - 9 * a1;
-                    if (t < 9 * SB_NCH) {
-#pragma unroll
-                        for (int i = 0; i < 9; i++) if (i >= c) s_D[81 * a1 + 9 * i + c] = mx[u][i];
-                    }
-                }
-                // the band is assembled by waves 0..2 (long done by now, but not ordered with this wave by a barrier): wait for their three arrivals
-                if (ln == 0) while (__hip_atomic_load(&s_flag[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 3) __builtin_amdgcn_s_sleep(2);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll 1
-                for (int t = ln; t < 28 + 19 * (SB_NCH - 1); t += 64) {   // band_a <- M_a band_a in place, one lane per column (the later uses of the band are all products with M_a)
-                    const int a = (t < 28) ? 1 : 2 + (t - 28) / 19, p = (t < 28) ? t : (t - 28) % 19;
-                    double *Bc = s_band + SB_BOFF(a) + p;
-                    const int str = SB_BSTR(a);
-                    const double *Ma = s_D + 81 * (a - 1);
-                    double bc[9], o[9];
-#pragma unroll
-                    for (int kk = 0; kk < 9; kk++) bc[kk] = Bc[kk * str];
-#pragma unroll
-                    for (int i = 0; i < 9; i++) {
-                        double sacc = 0;
-#pragma unroll
-                        for (int kk = 0; kk <= i; kk++) sacc += Ma[9 * i + kk] * bc[kk];
-                        o[i] = sacc;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 9; i++) Bc[i * str] = o[i];
-                }
-#pragma unroll 1
-                for (int a1 = 0; a1 < SB_NCH - 1; a1++) {                 // N_a[i][j] = sum_(k <= i) M_a[i][k] B_(a+1)[j][k], a = a1 + 1; the slot's 81 entries are read before any is written
-                    double nv[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int e = min(ln + 64 * u, 80), i = e / 9, j = e - 9 * i;
-                        const double *Ma = s_D + 81 * a1 + 9 * i, *Bn = s_E + 81 * a1 + 9 * j;
-                        double sacc = 0;
-#pragma unroll
-                        for (int kk = 0; kk < 9; kk++) sacc += ((kk <= i) ? Ma[kk] : 0.0) * Bn[kk];
-                        nv[u] = sacc;
-                    }
-                    s_E[81 * a1 + ln] = nv[0];
-                    if (ln + 64 < 81) s_E[81 * a1 + ln + 64] = nv[1];
-                }
-            }
         } else {
             // dense block and band: gather assembly by the 192 threads of waves 0..2. One thread per DESTINATION entry; the entry decodes its source indices itself
             // (no table: a table read would be one more dependent global round trip, ~3 us each here) and every load of the thread is in flight at once.
@@ -1645,8 +1595,6 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
             // right-hand sides: dense row 75, band rhs column
             if (td < SB_ND) s_P[sb_prow(SB_ND) + td] = s_g[td];
             if (td >= 96 && td < 96 + 9 * SB_NCH) { const int q = td - 96, a = q / 9 + 1, i = q - 9 * (a - 1); s_band[SB_BOFF(a) + i * SB_BSTR(a) + SB_BRHS(a)] = s_g[VB_NPOSE + 9 + q]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // band and dense block of this wave are in LDS: wave 3 may take the band
-            if (ln == 0) __hip_atomic_fetch_add(&s_flag[3], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             // per-feature Schur coefficient and (first try) the Cauchy-point terms. Every wave writes ALL features (identical values): each wave then reads
             // back what it wrote itself — no cross-wave synchronisation while wave 3 runs the chain
             for (int f = ln; f < ((F + 3) & ~3); f += 64) {
@@ -1679,13 +1627,74 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         // ---- P2b: dense -= U^T U, the three K partials in wave order (fixed order of the additions) ----------------------------------------------------
 #pragma unroll 1
         for (int turn = 0; turn < 3; turn++) {
-            if (wave == turn) {
-#pragma unroll
-                for (int i = 0; i < 15; i++) sb_acc_sub(s_P, s_t, sb_t15_a(i), sb_t15_b(i), acc15[i], ln, true);
+            if (wave == turn) {          // tile order of sb_t15_a / sb_t15_b, three tiles per round
+                sb_acc_sub<3, 0x110, 0x100>(s_P, s_t, &acc15[0], ln, true, s_pan);      // (0,0) (1,0) (1,1)
+                __builtin_amdgcn_sched_barrier(0);
+                sb_acc_sub<3, 0x222, 0x210>(s_P, s_t, &acc15[3], ln, true, s_pan);      // (2,0) (2,1) (2,2)
+                __builtin_amdgcn_sched_barrier(0);
+                sb_acc_sub<3, 0x333, 0x210>(s_P, s_t, &acc15[6], ln, true, s_pan);      // (3,0) (3,1) (3,2)
+                __builtin_amdgcn_sched_barrier(0);
+                sb_acc_sub<3, 0x443, 0x103>(s_P, s_t, &acc15[9], ln, true, s_pan);      // (3,3) (4,0) (4,1)
+                __builtin_amdgcn_sched_barrier(0);
+                sb_acc_sub<3, 0x444, 0x432>(s_P, s_t, &acc15[12], ln, true, s_pan);     // (4,2) (4,3) (4,4)
             }
             __syncthreads();
         }
-        if (tries == 0) { G2 = block_sum_sb(g2, s_red); Jg2 = block_sum_sb(part, s_red); }
+        // M_a = L_a^-1 over L_a, band_a <- M_a band_a, N_a = M_a B_(a+1)^T over B_(a+1): every later use of the chain is a product
+        {
+            double mx[9];
+            {                                        // column c of M_a: L x = e_c (threads >= 90 repeat column 89: the values stay in registers across the barrier)
+                const int tt = min(td, 9 * SB_NCH - 1), a1 = tt / 9, c = tt - 9 * a1;
+                const double *La = s_D + 81 * a1, *li = s_linv + 9 * a1;
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    double sacc = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int j = 0; j < i; j++) sacc -= La[9 * i + j] * mx[j];
+                    mx[i] = (i >= c) ? sacc * li[i] : 0.0;
+                }
+            }
+            __syncthreads();
+            if (td < 9 * SB_NCH) {
+                const int a1 = td / 9, c = td - 9 * a1;
+#pragma unroll
+                for (int i = 0; i < 9; i++) if (i >= c) s_D[81 * a1 + 9 * i + c] = mx[i];
+            }
+            __syncthreads();
+            if (td < 28 + 19 * (SB_NCH - 1)) {       // band_a <- M_a band_a in place, one thread per column
+                const int a = (td < 28) ? 1 : 2 + (td - 28) / 19, p = (td < 28) ? td : (td - 28) % 19;
+                double *Bc = s_band + SB_BOFF(a) + p;
+                const int str = SB_BSTR(a);
+                const double *Ma = s_D + 81 * (a - 1);
+                double bc[9], o[9];
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) bc[kk] = Bc[kk * str];
+#pragma unroll
+                for (int i = 0; i < 9; i++) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int kk = 0; kk <= i; kk++) sacc += Ma[9 * i + kk] * bc[kk];
+                    o[i] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < 9; i++) Bc[i * str] = o[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            double nv[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++) {            // N_a[i][j] = sum_(k <= i) M_a[i][k] B_(a+1)[j][k], a = 1..9
+                const int e = min(td + u * SBT, 81 * (SB_NCH - 1) - 1), a1 = e / 81, ij = e - 81 * a1, i = ij / 9, j = ij - 9 * i;
+                const double *Ma = s_D + 81 * a1 + 9 * i, *Bn = s_E + 81 * a1 + 9 * j;
+                double sacc = 0;
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) sacc += ((kk <= i) ? Ma[kk] : 0.0) * Bn[kk];
+                nv[u] = sacc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 3; u++) { const int e = td + u * SBT; if (e < 81 * (SB_NCH - 1)) s_E[e] = nv[u]; }
+        }
+        if (tries == 0) { G2 = block_sum_sb(g2, s_red); Jg2 = block_sum_sb(part, s_red); } else __syncthreads();
         if (tries == 0) {                             // cross term of the Cauchy point: 2 sum_p v_p S_p sum_f s_f v_f W_f[p]  (s_t = -that inner sum, scaled)
             double cr = ((ln < VB_NPOSE) ? s_v[ln] * s_t[ln] : 0.0) + ((ln + 64 < VB_NPOSE) ? s_v[ln + 64] * s_t[ln + 64] : 0.0);
 #pragma unroll
@@ -1701,8 +1710,8 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         else if (wave == 2) sb_y_chain<2>(s_band, s_E, acc, ln); else sb_y_chain<3>(s_band, s_E, acc, ln);
         STAMP(1, 5);
         // ---- P4: dense -= Y^T Y -------------------------------------------------------------------------------------------------------------------
-        if (wave == 0) sb_y_store<0>(acc, s_P, s_t, ln); else if (wave == 1) sb_y_store<1>(acc, s_P, s_t, ln);
-        else if (wave == 2) sb_y_store<2>(acc, s_P, s_t, ln); else sb_y_store<3>(acc, s_P, s_t, ln);
+        if (wave == 0) sb_y_store<0>(acc, s_P, s_t, ln, s_pan); else if (wave == 1) sb_y_store<1>(acc, s_P, s_t, ln, s_pan + 64);
+        else if (wave == 2) sb_y_store<2>(acc, s_P, s_t, ln, s_pan + 128); else sb_y_store<3>(acc, s_P, s_t, ln, s_pan + 192);
         __syncthreads();
         STAMP(1, 6);
         // ---- P5: Cholesky of the dense block, rhs as row 75 (L[75][0..74] = L^-1 rhs), one 4-column panel per barrier -----------------------------------
@@ -1785,8 +1794,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         if (s_flag[2]) { solved = true; break; }
         mu *= 10.0;                                 // dogleg_strategy.cc: mu_ *= mu_increase_factor_
         if (!(mu < 1.0)) break;                     // max_mu_
-        if (tid == 0) s_flag[3] = 0;
-        __syncthreads();
+            __syncthreads();
     }
     if (!solved) {
         if (tid == 0) { st->solve_failed = 1; st->mu = mu; st->num_linear_solves += tries; st->scaling_ready = 1; st->grad_sqnorm = G2; st->Jg2 = Jg2; }
