@@ -1184,6 +1184,18 @@ __device__ __forceinline__ double block_sum_sb(double v, double *s_red) {
     __syncthreads();
     return r;
 }
+__device__ __forceinline__ void block_sum2_sb(double v0, double v1, double *s_red, double &r0, double &r1) {      // two sums in one pass (same order of additions as block_sum_sb)
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); }
+    __syncthreads();
+    if ((tid & 63) == 0) { s_red[tid >> 6] = v0; s_red[8 + (tid >> 6)] = v1; }
+    __syncthreads();
+    r0 = 0; r1 = 0;
+#pragma unroll
+    for (int k = 0; k < SBW; k++) { r0 += s_red[k]; r1 += s_red[8 + k]; }
+    __syncthreads();
+}
 __device__ __forceinline__ int sb_prow(int r) { return r * (r + 1) / 2; }
 // band position of dense column c in step a (-1: structurally zero)
 __device__ __forceinline__ int sb_band_pos(int a, int c) {
@@ -1553,7 +1565,6 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);          // the second round's address arithmetic stays behind the first round (register pressure)
             {
                 constexpr int KS = 4, KB2 = 13, KT = KS + KB2;
                 double ss[KS][2], sb3[KB2][2];
@@ -1694,7 +1705,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
 #pragma unroll
             for (int u = 0; u < 3; u++) { const int e = td + u * SBT; if (e < 81 * (SB_NCH - 1)) s_E[e] = nv[u]; }
         }
-        if (tries == 0) { G2 = block_sum_sb(g2, s_red); Jg2 = block_sum_sb(part, s_red); } else __syncthreads();
+        if (tries == 0) block_sum2_sb(g2, part, s_red, G2, Jg2); else __syncthreads();
         if (tries == 0) {                             // cross term of the Cauchy point: 2 sum_p v_p S_p sum_f s_f v_f W_f[p]  (s_t = -that inner sum, scaled)
             double cr = ((ln < VB_NPOSE) ? s_v[ln] * s_t[ln] : 0.0) + ((ln + 64 < VB_NPOSE) ? s_v[ln + 64] * s_t[ln + 64] : 0.0);
 #pragma unroll
@@ -1814,21 +1825,17 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         };
         fetch(18);
 #pragma unroll 1
-        for (int bj = 18; bj >= 0; bj--) {
+        for (int bj = 18; bj >= 16; bj--) {           // rows 64..75: the second register of lanes 0..10 holds them
             const int r0 = 4 * bj;
             double dv[10], l0[4], l1[4];
 #pragma unroll
             for (int q = 0; q < 10; q++) dv[q] = dvn[q];
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) { l0[kk] = l0n[kk]; l1[kk] = l1n[kk]; }
-            if (bj > 0) fetch(bj - 1);
+            fetch(bj - 1);
             double zb[4], yb[4];
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int r = r0 + kk;
-                const double a = readlane_f64(z0, r & 63), c = readlane_f64(z1, r & 63);
-                zb[kk] = (r >= 64) ? c : a;
-            }
+            for (int kk = 0; kk < 4; kk++) zb[kk] = readlane_f64(z1, r0 + kk - 64);
             // y_blk = Ld^-T z_blk (dv = Ld^-1, lower; row / column 3 of block 18 are zero: row 75 is not a variable)
             yb[0] = dv[0] * zb[0] + dv[1] * zb[1] + dv[3] * zb[2] + dv[6] * zb[3];
             yb[1] = dv[2] * zb[1] + dv[4] * zb[2] + dv[7] * zb[3];
@@ -1836,12 +1843,36 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
             yb[3] = dv[9] * zb[3];
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                const int r = r0 + kk;
-                if (lane < r0) z0 -= l0[kk] * yb[kk];
+                z0 -= l0[kk] * yb[kk];
                 if (lane + 64 < r0) z1 -= l1[kk] * yb[kk];
-                if (lane == r) z0 = yb[kk];
-                if (lane + 64 == r) z1 = yb[kk];
+                if (lane + 64 == r0 + kk) z1 = yb[kk];
             }
+        }
+#pragma unroll 1
+        for (int bj = 15; bj >= 0; bj--) {            // rows 0..63: one register, one row of the factor per lane
+            const int r0 = 4 * bj;
+            double dv[10], l0[4];
+#pragma unroll
+            for (int q = 0; q < 10; q++) dv[q] = dvn[q];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) l0[kk] = l0n[kk];
+            if (bj > 0) {
+                const double *d = s_dinv + 16 * (bj - 1);
+                dvn[0] = d[0]; dvn[1] = d[4]; dvn[2] = d[5]; dvn[3] = d[8]; dvn[4] = d[9]; dvn[5] = d[10]; dvn[6] = d[12]; dvn[7] = d[13]; dvn[8] = d[14]; dvn[9] = d[15];
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) { const int r = r0 - 4 + kk; l0n[kk] = s_P[sb_prow(r) + min(lane, r)]; }
+            }
+            double zb[4], yb[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) zb[kk] = readlane_f64(z0, r0 + kk);
+            yb[0] = dv[0] * zb[0] + dv[1] * zb[1] + dv[3] * zb[2] + dv[6] * zb[3];
+            yb[1] = dv[2] * zb[1] + dv[4] * zb[2] + dv[7] * zb[3];
+            yb[2] = dv[5] * zb[2] + dv[8] * zb[3];
+            yb[3] = dv[9] * zb[3];
+            double upd = l0[0] * yb[0] + l0[1] * yb[1] + l0[2] * yb[2] + l0[3] * yb[3];
+            const int kme = lane - r0;
+            const double mine = (kme == 0) ? yb[0] : (kme == 1) ? yb[1] : (kme == 2) ? yb[2] : yb[3];
+            z0 = (lane < r0) ? z0 - upd : ((kme >= 0 && kme < 4) ? mine : z0);
         }
         s_y[lane] = z0;
         if (lane + 64 < SB_ND) s_y[lane + 64] = z1;
@@ -1961,8 +1992,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         gy += gt * y;
         gn2 += df * df * y * y;
     }
-    gy = block_sum_sb(gy, s_red);
-    gn2 = block_sum_sb(gn2, s_red);
+    block_sum2_sb(gy, gn2, s_red, gy, gn2);
     STAMP(1, 11);
     if (tid == 0) {
         st->grad_sqnorm = G2; st->Jg2 = Jg2; st->alpha = G2 / Jg2;
