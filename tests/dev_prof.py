@@ -24,8 +24,9 @@ if os.environ.get("VILF_DEBUG_STAMPS"):
             print(name, "phase cycles:", np.diff(v), "total", v[-1] - v[0])
 if os.environ.get("VILF_DEBUG_STAMPS") and not os.environ.get("VILF_SOLVE_DENSE"):
     v = a[1]
-    names = ["prologue", "setup", "P1 gather(w0)", "P2 reduce||chain", "P2b acc store+sums", "P3 Y chain+syrk", "P4 store", "P5 dense chol", "P6 dense backsub", "P6 chain (wave0)", "P6 wait dots+x", "P7"]
-    print("k_solve_sb stamps (cycles, delta):", [(names[i], int(v[i] - v[i - 1])) for i in range(1, 12) if v[i] and v[i - 1]])
+    names = ["prologue", "setup", "P1 gather(w0)", "P2 reduce||chain", "P2b acc store+sums", "P3 Y chain+syrk", "-", "P4+P5 dense chol (MFMA)", "P6 dense backsub", "P6 chain (wave0)", "P6 wait dots+x", "P7"]
+    print("k_solve_sb stamps (cycles, delta):", [(names[i], int(v[i] - v[max(j for j in range(i) if v[j])])) for i in range(1, 12) if v[i]])
+    print("  P1 detail (w0): decode+issue A", int(v[20]-v[1]), "process A", int(v[21]-v[20]), "decode+issue B", int(v[22]-v[21]), "process B", int(v[23]-v[22]), "rhs+cf", int(v[24]-v[23]), "| P2b: turns", int(v[26]-v[3]), "M/BP/N", int(v[27]-v[26]), "sums+cross", int(v[4]-v[27]))
     print("  P1+P2 per-wave finish rel. to loop start:", [int(v[16 + q] - v[1]) for q in range(4)])
 if os.environ.get("VILF_DEBUG_STAMPS"):
     print("linearize chunk-loop (wave 0): eval", a[2][16], "sync1", a[2][17], "mfma", a[2][18], "sync2", a[2][19])

@@ -55,8 +55,8 @@
 #define SB_OFF_T (SB_OFF_VEC + 5 * SB_VLD)                        // Cauchy-point row (80)
 #define SB_OFF_LINV (SB_OFF_T + 80)                               // 1 / L_ii of the chain blocks (96)
 #define SB_OFF_DINV (SB_OFF_LINV + 96)                            // inverses of the 4 x 4 diagonal blocks of the dense factor (19 x 16)
-#define SB_OFF_PAN (SB_OFF_DINV + 19 * 16)                        // current 4-column panel of the dense factorisation, double-buffered (2 x 76 x 4)
-#define SB_OFF_U (SB_OFF_PAN + 2 * 304)                           // chain: forward solution (96)
+#define SB_OFF_PAN (SB_OFF_DINV + 19 * 16)                        // dense factorisation: current 4-column panel [76][4], then the factor rows of the panel as MFMA operands [80][4]
+#define SB_OFF_U (SB_OFF_PAN + 2 * 304 + 16)                      // chain: forward solution (96)
 #define SB_OFF_W (SB_OFF_U + 96)                                  // chain: M r -> backward vectors (96)
 #define SB_OFF_RED (SB_OFF_W + 96)                                // block-sum scratch (16)
 #define SB_LDS_DOUBLES (SB_OFF_RED + 16)

@@ -1553,6 +1553,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     sf[u][1] = sb_bload(rPri, (pr >= 0 && pc >= 0) ? pr * VB_PRIOR_LD + pc : -1);
                     meta[KN + u] = (td + 192 * u < 1620) ? ((SB_OFF_P + sb_prow(r) + c) | (r << 14) | (c << 22)) : -1;
                 }
+                STAMP(1, 20);
 #pragma unroll
                 for (int u = 0; u < KT; u++) {
                     if (meta[u] < 0) continue;
@@ -1565,6 +1566,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
                 }
             }
+            STAMP(1, 21);
             {
                 constexpr int KS = 4, KB2 = 13, KT = KS + KB2;
                 double ss[KS][2], sb3[KB2][2];
@@ -1593,6 +1595,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     sb3[u][1] = sb_bload(rImu, s1);
                     meta[KS + u] = on ? ((SB_OFF_BAND + SB_BOFF(a) + i * SB_BSTR(a) + pos) | ((VB_NPOSE + 9 * a + i) << 14) | (c165 << 22)) : -1;
                 }
+                STAMP(1, 22);
 #pragma unroll
                 for (int u = 0; u < KT; u++) {
                     if (meta[u] < 0) continue;
@@ -1603,6 +1606,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
                 }
             }
+            STAMP(1, 23);
             // right-hand sides: dense row 75, band rhs column
             if (td < SB_ND) s_P[sb_prow(SB_ND) + td] = s_g[td];
             if (td >= 96 && td < 96 + 9 * SB_NCH) { const int q = td - 96, a = q / 9 + 1, i = q - 9 * (a - 1); s_band[SB_BOFF(a) + i * SB_BSTR(a) + SB_BRHS(a)] = s_g[VB_NPOSE + 9 + q]; }
@@ -1626,6 +1630,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
             __threadfence_block();
         }
         STAMP(1, 2);
+        STAMP(1, 24);
         double4_t acc15[15];
 #pragma unroll
         for (int i = 0; i < 15; i++) acc15[i] = double4_t{0, 0, 0, 0};
@@ -1651,6 +1656,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
             }
             __syncthreads();
         }
+        STAMP(1, 26);
         // M_a = L_a^-1 over L_a, band_a <- M_a band_a, N_a = M_a B_(a+1)^T over B_(a+1): every later use of the chain is a product
         {
             double mx[9];
@@ -1705,6 +1711,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
 #pragma unroll
             for (int u = 0; u < 3; u++) { const int e = td + u * SBT; if (e < 81 * (SB_NCH - 1)) s_E[e] = nv[u]; }
         }
+        STAMP(1, 27);
         if (tries == 0) block_sum2_sb(g2, part, s_red, G2, Jg2); else __syncthreads();
         if (tries == 0) {                             // cross term of the Cauchy point: 2 sum_p v_p S_p sum_f s_f v_f W_f[p]  (s_t = -that inner sum, scaled)
             double cr = ((ln < VB_NPOSE) ? s_v[ln] * s_t[ln] : 0.0) + ((ln + 64 < VB_NPOSE) ? s_v[ln + 64] * s_t[ln + 64] : 0.0);
@@ -1720,82 +1727,82 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         if (wave == 0) sb_y_chain<0>(s_band, s_E, acc, ln); else if (wave == 1) sb_y_chain<1>(s_band, s_E, acc, ln);
         else if (wave == 2) sb_y_chain<2>(s_band, s_E, acc, ln); else sb_y_chain<3>(s_band, s_E, acc, ln);
         STAMP(1, 5);
-        // ---- P4: dense -= Y^T Y -------------------------------------------------------------------------------------------------------------------
-        if (wave == 0) sb_y_store<0>(acc, s_P, s_t, ln, s_pan); else if (wave == 1) sb_y_store<1>(acc, s_P, s_t, ln, s_pan + 64);
-        else if (wave == 2) sb_y_store<2>(acc, s_P, s_t, ln, s_pan + 128); else sb_y_store<3>(acc, s_P, s_t, ln, s_pan + 192);
-        __syncthreads();
-        STAMP(1, 6);
-        // ---- P5: Cholesky of the dense block, rhs as row 75 (L[75][0..74] = L^-1 rhs), one 4-column panel per barrier -----------------------------------
+        // ---- P4 / P5: Cholesky of the dense block with the trailing matrix in MFMA accumulator registers ---------------------------------------------------
+        // Every wave keeps its <= 4 tiles (dense - U^T U from LDS, minus its Y^T Y accumulators) in registers. Per 4-column panel: the lanes holding the
+        // panel's columns write them to LDS; one thread per ROW factors the 4 x 4 diagonal block itself and solves its own row strip (the factor row goes to
+        // the packed matrix for the back substitution and to the operand buffer); the rank-4 trailing update is ONE MFMA per tile. Right-hand side = row 75.
         {
-            double a4[4][4];
+            int tTA[4], tTB[4];
 #pragma unroll
-            for (int ii = 0; ii < 4; ii++)
+            for (int i = 0; i < 4; i++) {
+                const int wv = wave;
+                tTA[i] = (wv == 0) ? sb_y_ct(0, sb_y_pa(0, i)) : (wv == 1) ? sb_y_ct(1, sb_y_pa(1, i)) : (wv == 2) ? sb_y_ct(2, sb_y_pa(2, i)) : sb_y_ct(3, sb_y_pa(3, i));
+                tTB[i] = (wv == 0) ? sb_y_ct(0, sb_y_pb(0, i)) : (wv == 1) ? sb_y_ct(1, sb_y_pb(1, i)) : (wv == 2) ? sb_y_ct(2, sb_y_pb(2, i)) : sb_y_ct(3, sb_y_pb(3, i));
+            }
+            const int ntl = (wave == 3) ? 3 : 4;
+            const int c16 = ln & 15, g4 = ln >> 4;
+            double4_t T[4];
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) {
-                    const int r = 4 * bi + ii, c = 4 * bjm + kk;
-                    a4[ii][kk] = (blk_on && c <= r) ? s_P[sb_prow(min(r, SB_NR - 1)) + min(c, SB_NR - 1)] : 0.0;
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = 16 * tTA[i] + g4 + 4 * q, c = 16 * tTB[i] + c16;
+                    const double v = s_P[sb_prow(min(r, SB_NR - 1)) + min(c, min(r, SB_NR - 1))];
+                    T[i][q] = ((r < SB_NR && c <= r) ? v : 0.0) - acc[i][q];
                 }
+            double *s_lp = s_pan + 304;               // operand buffer of the current panel's factor rows [80][4] (rows 76..79 zero)
+            if (td < 16) s_lp[304 + td] = 0.0;
+            __syncthreads();                          // every tile is in registers: the packed matrix may be overwritten by the factor
 #pragma unroll 1
             for (int bj = 0; bj < 19; bj++) {
-                double *pb = s_pan + 304 * (bj & 1);
-                if (blk_on && bjm == bj) {
+                const int j0 = 4 * bj, tc = bj >> 2, sp = bj & 3;
+                // 1. the panel's columns, rows >= j0, to LDS
+                if ((c16 >> 2) == sp) {
 #pragma unroll
-                    for (int ii = 0; ii < 4; ii++)
+                    for (int i = 0; i < 4; i++)
+                        if (i < ntl && tTB[i] == tc) {
 #pragma unroll
-                        for (int kk = 0; kk < 4; kk++) pb[(4 * bi + ii) * 4 + kk] = a4[ii][kk];
+                            for (int q = 0; q < 4; q++) { const int r = 16 * tTA[i] + g4 + 4 * q; if (r >= j0 && r < SB_NR) s_pan[4 * r + (c16 & 3)] = T[i][q]; }
+                        }
                 }
                 __syncthreads();
-                if (blk_on && bjm >= bj) {
-                    const double *dg = pb + 16 * bj;
+                // 2. one thread per row: Cholesky of the diagonal block, the row's strip of the factor
+                if (td >= j0 && td < SB_NR) {
+                    const double *dg = s_pan + 4 * j0, *rp = s_pan + 4 * td;
                     const double d00 = dg[0], d10 = dg[4], d11 = dg[5], d20 = dg[8], d21 = dg[9], d22 = dg[10], d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
+                    const double r0v = rp[0], r1v = rp[1], r2v = rp[2], r3v = rp[3];
                     const double i0 = rsqrt_h3(d00), l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
                     const double t11 = d11 - l10 * l10, i1 = rsqrt_h3(t11), l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
                     const double t22 = d22 - l20 * l20 - l21 * l21, i2 = rsqrt_h3(t22), l32 = (d32 - l30 * l20 - l31 * l21) * i2;
                     const double t33 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
-                    const bool last = 4 * bj + 3 >= SB_ND;            // panel 18: column 75 is the right-hand side row's own diagonal — not a pivot
+                    const bool last = j0 + 3 >= SB_ND;                // panel 18: column 75 is the right-hand side row's own diagonal — not a pivot
                     const double i3 = last ? 0.0 : rsqrt_h3(t33);
-                    if (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || (!last && !(t33 > 0.0))) s_flag[2] = 0;
-                    if (bi == bj) {                    // the diagonal block itself: L, and its inverse for the back substitution
-                        a4[0][0] = d00 * i0; a4[1][0] = l10; a4[2][0] = l20; a4[3][0] = l30;
-                        a4[1][1] = t11 * i1; a4[2][1] = l21; a4[3][1] = l31;
-                        a4[2][2] = t22 * i2; a4[3][2] = l32; a4[3][3] = t33 * i3;
+                    const double x0 = r0v * i0, x1 = (r1v - x0 * l10) * i1, x2 = (r2v - x0 * l20 - x1 * l21) * i2, x3 = (r3v - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+                    const int k = td - j0;                            // rows of the diagonal block keep their lower part only
+                    double *Lr = s_P + sb_prow(td) + j0;
+                    Lr[0] = x0;
+                    if (k >= 1) Lr[1] = x1;
+                    if (k >= 2) Lr[2] = x2;
+                    if (k >= 3 && j0 + 3 < SB_ND) Lr[3] = x3;
+                    double *lp = s_lp + 4 * td;
+                    lp[0] = x0; lp[1] = (k >= 1) ? x1 : 0.0; lp[2] = (k >= 2) ? x2 : 0.0; lp[3] = (k >= 3) ? x3 : 0.0;
+                    if (k == 0) {
+                        if (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || (!last && !(t33 > 0.0))) s_flag[2] = 0;
                         const double m10 = -l10 * i0 * i1, m21 = -l21 * i1 * i2, m32 = -l32 * i2 * i3;
                         const double m20 = -(l20 * i0 + l21 * m10) * i2, m31 = -(l31 * i1 + l32 * m21) * i3;
                         const double m30 = -(l30 * i0 + l31 * m10 + l32 * m20) * i3;
                         double *dv = s_dinv + 16 * bj;
                         dv[0] = i0; dv[4] = m10; dv[5] = i1; dv[8] = m20; dv[9] = m21; dv[10] = i2; dv[12] = m30; dv[13] = m31; dv[14] = m32; dv[15] = i3;
-                    } else {
-                        double lr[4][4];
-#pragma unroll
-                        for (int ii = 0; ii < 4; ii++) {
-                            const double *rp = pb + (4 * bi + ii) * 4;
-                            const double x0 = rp[0] * i0, x1 = (rp[1] - x0 * l10) * i1, x2 = (rp[2] - x0 * l20 - x1 * l21) * i2, x3 = (rp[3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
-                            lr[ii][0] = x0; lr[ii][1] = x1; lr[ii][2] = x2; lr[ii][3] = x3;
-                        }
-                        if (bjm == bj) {
-#pragma unroll
-                            for (int ii = 0; ii < 4; ii++)
-#pragma unroll
-                                for (int kk = 0; kk < 4; kk++) a4[ii][kk] = lr[ii][kk];
-                        } else {
-#pragma unroll
-                            for (int kk = 0; kk < 4; kk++) {
-                                const double *cp = pb + (4 * bjm + kk) * 4;
-                                const double x0 = cp[0] * i0, x1 = (cp[1] - x0 * l10) * i1, x2 = (cp[2] - x0 * l20 - x1 * l21) * i2, x3 = (cp[3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
-#pragma unroll
-                                for (int ii = 0; ii < 4; ii++) a4[ii][kk] -= lr[ii][0] * x0 + lr[ii][1] * x1 + lr[ii][2] * x2 + lr[ii][3] * x3;
-                            }
-                        }
                     }
                 }
-            }
-            if (blk_on) {
+                __syncthreads();
+                // 3. rank-4 update of the tiles that reach beyond the panel: T -= L_panel(rows of the tile) L_panel(columns of the tile)^T, one MFMA each.
+                //    Rows above the panel's end still hold older strips in the operand buffer: they only touch entries that are never read again.
 #pragma unroll
-                for (int ii = 0; ii < 4; ii++)
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-                        const int r = 4 * bi + ii, c = 4 * bjm + kk;
-                        if (c <= r && c < SB_ND) s_P[sb_prow(r) + c] = a4[ii][kk];
+                for (int i = 0; i < 4; i++)
+                    if (i < ntl && 16 * tTB[i] + 15 >= j0 + 4) {
+                        const double av = -s_lp[4 * min(16 * tTA[i] + c16, 79) + g4], bv = s_lp[4 * min(16 * tTB[i] + c16, 79) + g4];
+                        T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T[i], 0, 0, 0);
                     }
             }
             __syncthreads();
