@@ -201,7 +201,7 @@ static int upload_priors(vilf_handle *h) {
     for (int w : dirty) {
         const vilf_prior &p = h->priors[w];
         h->prior_dev_newer[w] = 0;
-        if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > 2 * VB_NF) { h->err = "prior touches Td / feature blocks: unsupported"; return VILF_ERR_UNSUPPORTED; }
+        if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > 2 * VB_NF + (h->opts.estimate_td ? 1 : 0)) { h->err = "prior touches feature blocks (or Td without estimate_td): unsupported"; return VILF_ERR_UNSUPPORTED; }
         if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > VB_NF && p.block_id[i] < 2 * VB_NF) h->solve_dense_fallback = true;
     }
     auto fill = [&](const vilf_prior &p, int *hd, double *x0) {
@@ -272,6 +272,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             h->err = "null input array"; return VILF_ERR_INVALID_ARGUMENT;
         }
         if (h->opts.use_lidar_const && !in.lidar) { h->err = "lidar constraints missing (use_lidar_const = 1)"; return VILF_ERR_INVALID_ARGUMENT; }
+        if (h->opts.estimate_td && in.n_features && (!in.obs_velocity || !in.obs_cur_td || !in.obs_row)) { h->err = "estimate_td needs obs_velocity / obs_cur_td / obs_row"; return VILF_ERR_INVALID_ARGUMENT; }
         // the observation CSR must be exactly [0 .. n_obs): the packer indexes obs_point / the factor arrays through it
         if (in.n_obs < 0 || (in.n_features && (in.feature_obs_offset[0] != 0 || in.feature_obs_offset[in.n_features] != in.n_obs)) || (!in.n_features && in.n_obs != 0)) {
             h->err = "feature_obs_offset must start at 0 and end at n_obs"; return VILF_ERR_INVALID_ARGUMENT;
@@ -310,7 +311,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
         {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_DIAGH, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
         {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
-        {D_OBGS, sB * 33 * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8}, {D_FACREC, sB * sC * 64}, {D_CF, sB * sF * 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
+        {D_OBGS, sB * 33 * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8}, {D_FACREC, sB * sC * 64}, {D_CF, sB * sF * 8}, {D_TD, sB * 8},
+        {D_OBSV, h->opts.estimate_td ? sB * sO * 16 : 8}, {D_OBSTD, h->opts.estimate_td ? sB * sO * 8 : 8}, {D_OBSROW, h->opts.estimate_td ? sB * sO * 8 : 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed"; return VILF_ERR_DEVICE; }
 
@@ -322,6 +324,10 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     std::vector<double> pose(sB * 77), sb(sB * 99), feat(sB * sF, 1.0), ex(sB * 7), gR0(sB * 9), gP0(sB * 3), obs(sB * sO * 3, 0.0), imu(sB * 10 * IMU_REC, 0.0),
         lidar(sB * 10 * 7, 0.0), cov(sB * 10 * 225, 0.0), facrec(sB * sC * 8, 0.0);
     h->h_nfeat.assign(B, 0); h->h_ex.assign(sB * 7, 0.0); h->h_td.assign(B, 0.0);
+    const bool est_any = h->opts.estimate_extrinsic || h->opts.estimate_td, est_td = h->opts.estimate_td != 0;
+    std::vector<double> obsv(est_td ? sB * sO * 2 : 0, 0.0), obstd(est_td ? sB * sO : 0, 0.0), obsrow(est_td ? sB * sO : 0, 0.0);
+    h->own.clear();
+    if (est_any) h->own.resize(B);
     lap("host vectors");
     auto pack_one = [&](int w) {        // every window writes its own slices only: packed by several host threads below
         const vilf_window_in &in = wins[w];
@@ -335,6 +341,31 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         if (in.gauge_R0) std::memcpy(&gR0[(size_t)w * 9], in.gauge_R0, 72); else quat_to_R(in.para_pose + 3, &gR0[(size_t)w * 9]);
         if (in.gauge_P0) std::memcpy(&gP0[(size_t)w * 3], in.gauge_P0, 24); else std::memcpy(&gP0[(size_t)w * 3], in.para_pose, 24);
         std::memcpy(&obs[(size_t)w * sO * 3], in.obs_point, (size_t)in.n_obs * 24);
+        if (est_td && in.n_obs) {
+            std::memcpy(&obsv[(size_t)w * sO * 2], in.obs_velocity, (size_t)in.n_obs * 16);
+            std::memcpy(&obstd[(size_t)w * sO], in.obs_cur_td, (size_t)in.n_obs * 8);
+            std::memcpy(&obsrow[(size_t)w * sO], in.obs_row, (size_t)in.n_obs * 8);
+        }
+        if (est_any) {                  // the batched solve of these options runs the general path per slot: keep the inputs
+            OwnedWindow &o = h->own[w];
+            o.in = in;
+            o.pose.assign(in.para_pose, in.para_pose + 77); o.sb.assign(in.para_speed_bias, in.para_speed_bias + 99);
+            o.feat.assign(in.para_feature, in.para_feature + F); o.fconst.assign(in.feature_const, in.feature_const + F);
+            o.fstart.assign(in.feature_start_frame, in.feature_start_frame + F); o.foff.assign(in.feature_obs_offset, in.feature_obs_offset + F + 1);
+            o.obs.assign(in.obs_point, in.obs_point + 3 * (size_t)in.n_obs);
+            if (in.obs_velocity) o.vel.assign(in.obs_velocity, in.obs_velocity + 2 * (size_t)in.n_obs);
+            if (in.obs_cur_td) o.ctd.assign(in.obs_cur_td, in.obs_cur_td + in.n_obs);
+            if (in.obs_row) o.row.assign(in.obs_row, in.obs_row + in.n_obs);
+            o.imu.assign(in.imu, in.imu + VB_NF);
+            if (in.lidar) o.lidar.assign(in.lidar, in.lidar + VB_NF);
+            if (in.gauge_R0) o.gR0.assign(in.gauge_R0, in.gauge_R0 + 9);
+            if (in.gauge_P0) o.gP0.assign(in.gauge_P0, in.gauge_P0 + 3);
+            o.in.para_pose = o.pose.data(); o.in.para_speed_bias = o.sb.data(); o.in.para_feature = o.feat.data(); o.in.feature_const = o.fconst.data();
+            o.in.feature_start_frame = o.fstart.data(); o.in.feature_obs_offset = o.foff.data(); o.in.obs_point = o.obs.data();
+            o.in.obs_velocity = o.vel.empty() ? nullptr : o.vel.data(); o.in.obs_cur_td = o.ctd.empty() ? nullptr : o.ctd.data(); o.in.obs_row = o.row.empty() ? nullptr : o.row.data();
+            o.in.imu = o.imu.data(); o.in.lidar = o.lidar.empty() ? nullptr : o.lidar.data();
+            o.in.gauge_R0 = o.gR0.empty() ? nullptr : o.gR0.data(); o.in.gauge_P0 = o.gP0.empty() ? nullptr : o.gP0.data();
+        }
         int fac = 0;
         std::vector<int> pcount(VB_NPAIR + 1, 0);
         for (int f = 0; f < F; f++) {
@@ -404,6 +435,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, up(D_IMU, imu.data(), sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar.data(), sB * 10 * 7 * 8));
     HIPCHECK(h, up(D_COV, cov.data(), sB * 10 * 225 * 8));
     HIPCHECK(h, up(D_MFLAG, h->h_mflag.data(), sB * 4));
+    HIPCHECK(h, up(D_TD, h->h_td.data(), sB * 8));
+    if (est_td) { HIPCHECK(h, up(D_OBSV, obsv.data(), sB * sO * 16)); HIPCHECK(h, up(D_OBSTD, obstd.data(), sB * sO * 8)); HIPCHECK(h, up(D_OBSROW, obsrow.data(), sB * sO * 8)); }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     lap("H2D copies + sync");
 
@@ -430,6 +463,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.ex = h->d[D_EX].as<double>(); b.gauge_R0 = h->d[D_GR0].as<double>(); b.gauge_P0 = h->d[D_GP0].as<double>();
     b.f_start = h->d[D_FSTART].as<int>(); b.f_nobs = h->d[D_FNOBS].as<int>(); b.f_obs0 = h->d[D_FOBS0].as<int>(); b.f_fac0 = h->d[D_FFAC0].as<int>();
     b.f_const = h->d[D_FCONST].as<uint8_t>(); b.obs = h->d[D_OBS].as<double>();
+    b.obs_vel = h->d[D_OBSV].as<double>(); b.obs_ctd = h->d[D_OBSTD].as<double>(); b.obs_row = h->d[D_OBSROW].as<double>(); b.td = h->d[D_TD].as<double>();
+    b.est_td = o.estimate_td ? 1 : 0; b.tr_over_row = o.TR / o.ROW; b.row_half = o.ROW / 2;
     b.ps_feat = h->d[D_PSFEAT].as<int>(); b.ps_obs = h->d[D_PSOBS].as<int>(); b.ps_slot = h->d[D_PSSLOT].as<int>();
     b.pair_off = h->d[D_PAIROFF].as<int>(); b.facrec = h->d[D_FACREC].as<double>();
     b.imu = h->d[D_IMU].as<double>(); b.lidar = h->d[D_LIDAR].as<double>();
@@ -556,8 +591,34 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
 
 extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
-    if (h->opts.estimate_extrinsic || h->opts.estimate_td) { h->err = "estimate_extrinsic / estimate_td: single-window solve only (vilf_window_solve)"; return VILF_ERR_UNSUPPORTED; }
     HIPCHECK(h, hipSetDevice(h->device));
+    if (h->opts.estimate_extrinsic || h->opts.estimate_td) {
+        // Ex_Pose / td as variables (estimator.cpp:701-717; both off in the KITTI configuration): every slot through the general single-window path
+        // (vilf_lw.hip: ProjectionTdFactor / Ex_Pose Jacobians, the slot's device-resident prior), one after the other. State, gauge-fixed outputs and the
+        // summary are written back to the slot, so download / summaries / marginalization continue as after the batched kernels.
+        if ((int)h->own.size() != h->B) { h->err = "batch inputs not retained"; return VILF_ERR_INVALID_ARGUMENT; }
+        bool dirty0 = false;
+        for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty0 = true;
+        if (dirty0) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; }
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<double> bufP(77), bufS(99), bufF(h->batch.Fmax + 4), Ps(33), Rs(99), Vs(33), Bas(33), Bgs(33);
+        for (int w = 0; w < h->B; w++) {
+            vilf_window_out out;
+            std::memset(&out, 0, sizeof(out));
+            out.para_pose = bufP.data(); out.para_speed_bias = bufS.data(); out.para_feature = bufF.data();
+            out.Ps = Ps.data(); out.Rs = Rs.data(); out.Vs = Vs.data(); out.Bas = Bas.data(); out.Bgs = Bgs.data();
+            const int rc = vilf_lw_window_solve(h, &h->own[w].in, &out, w + 1);
+            if (rc < 0) return rc;
+            VbState st;
+            std::memset(&st, 0, sizeof(st));
+            st.iteration = out.summary.num_iterations; st.num_successful = out.summary.num_successful_steps; st.num_linear_solves = out.summary.num_linear_solves;
+            st.termination = out.summary.termination; st.initial_cost = out.summary.initial_cost; st.x_cost = out.summary.final_cost; st.radius = out.summary.final_radius; st.done = 1;
+            HIPCHECK(h, hipMemcpy(h->batch.st + w, &st, sizeof(st), hipMemcpyHostToDevice));
+        }
+        h->last_solve_usec = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        (void)sync;
+        return VILF_OK;
+    }
     bool dirty = false;
     for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true;
     if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; }
@@ -681,7 +742,7 @@ extern "C" int vilf_batch_download(vilf_handle *h, int first, int n, vilf_window
         const double *exw = &h->h_ex[(size_t)(first + i) * 7];
         for (int k = 0; k < 3; k++) o.tic[k] = exw[k];
         quat_to_R(exw + 3, o.ric);
-        o.td = h->h_td[first + i];
+        o.td = h->h_td[first + i];                      // kept current by the general path (estimate_td)
         o.summary = sums[i];
     }
     return VILF_OK;
@@ -697,7 +758,7 @@ extern "C" int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_
     int rc = vilf_batch_upload(h, 1, in);
     if (rc != VILF_OK) return rc;
     if (h->opts.estimate_extrinsic || h->opts.estimate_td)      // Ex_Pose / td as variables (estimator.cpp:701-717): the general single-window path, with the slot-0 prior
-        return vilf_lw_window_solve(h, in, out, 1);
+        return vilf_lw_window_solve(h, in, out, 1);      // slot 0
     rc = vilf_batch_solve(h, 1);
     if (rc != VILF_OK) return rc;
     rc = vilf_batch_download(h, 0, 1, out);
@@ -732,7 +793,6 @@ extern "C" int vilf_prior_export(vilf_handle *h, int slot, vilf_prior *out) {
 
 extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
-    if (h->opts.estimate_td) { h->err = "estimate_td: the device marginalization has no ProjectionTdFactor / td block"; return VILF_ERR_UNSUPPORTED; }
     HIPCHECK(h, hipSetDevice(h->device));
     { bool dirty = false; for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true; if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; } }
     const size_t sB = h->B, sF = h->batch.Fmax, sC = h->batch.FACmax, M = h->mg_Mcap;

@@ -80,8 +80,8 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
 #define MG_MD 21            // dropped non-feature variables: Pose[0] 6 + Pose[1] 6 (USE_LIDAR_CONST, estimator.cpp:891) + SpeedBias[0] 9
 #define MG_NK 96            // kept (prior) dimension capacity; the reference's prior never exceeds 75 + td
 #define MG_ND (MG_MD + MG_NK)
-#define MG_MROW 40          // per visual factor: J_P0[12] J_Pj[12] J_Ex[12] J_f[2] r[2]
-#define MG_PAIRM 400        // per pair (0,j): 19x19 (+19 rhs) products, stored 20x20
+#define MG_MROW 42          // per visual factor: J_P0[12] J_Pj[12] J_Ex[12] J_f[2] r[2] J_td[2] (the last two only with estimate_td)
+#define MG_PAIRM 400        // per pair (0,j): [J0 Jj Jex Jtd r]^T [..] upper triangle (20 columns: td = 18, r = 19), stored 20x20
 #define QL_RCAP 12288        // rotations logged per window by k_mf_ql (typical: ~5 k for n = 75)
 #define QL_ICAP 768          // QL iterations logged per window
 #define QL_LPW 16           // windows per wave of k_mf_ql (8: faster at 2048 windows, slower at 4096)
@@ -96,7 +96,7 @@ struct VbMarg {
     const int *mflag;       // [B] marginalization_flag
     int *info;              // [B][MG_INFO]
     int *f0rank;            // [B][Fmax] rank among the start-frame-0 features, or -1
-    double *st_pose, *st_sb, *st_feat, *st_ex;   // linearization point = vector2double() of the post-gauge state
+    double *st_pose, *st_sb, *st_feat, *st_ex;   // linearization point = vector2double() of the post-gauge state (para_Td: VbBatch::td)
     double *Mbuf;           // [B][FACmax][MG_MROW]   (one 40-double record per visual factor, feature-major slot order)
     double *Hd, *gd;        // [B][MG_ND*MG_ND], [B][MG_ND]    dense-variable normal equations
     double *Wf;             // [B][Fmax][MG_ND]  arrow rows of the start-0 features (indexed by rank)
@@ -132,6 +132,9 @@ struct VbBatch {
     const int *f_start, *f_nobs, *f_obs0, *f_fac0;
     const uint8_t *f_const;
     const double *obs;
+    const double *obs_vel, *obs_ctd, *obs_row;   // estimate_td only: [B][Omax][2] pixel velocity, [B][Omax] td at capture, [B][Omax] image row (ProjectionTdFactor, projection_td_factor.cpp:6-21)
+    double *td;             // [B] para_Td
+    int est_td; double tr_over_row, row_half;
     const int *ps_feat, *ps_obs, *ps_slot;
     const int *pair_off;
     const double *facrec;   // [B][FACmax][8]: per pair-sorted factor {pts_i[3], pts_j[3], (feature | slot << 32), (frame_i | frame_j << 8 | const << 16)} — one

@@ -28,7 +28,7 @@ enum {
     D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_FACW, D_HPP, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G, D_DIAGH,
     D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV,
     D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR, D_QLV, D_QLD, D_QLLOG, D_QLIT, D_QLINFO,
-    D_PAIRD, D_FACREC, D_CF, D_STAMPS, D_LUTSBA, D_LUTSBB, D_LUTSBC, D_LUTSBD, D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0,      // priors as uploaded (restored by vilf_batch_rewind after a marginalization)
+    D_PAIRD, D_FACREC, D_CF, D_STAMPS, D_OBSV, D_OBSTD, D_OBSROW, D_TD, D_LUTSBA, D_LUTSBB, D_LUTSBC, D_LUTSBD, D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0,      // priors as uploaded (restored by vilf_batch_rewind after a marginalization)
     D_COUNT
 };
 
@@ -36,6 +36,16 @@ struct S2B;
 struct FeatCtx;
 struct PgCtx;
 struct LwCtx;
+
+// deep copy of a window snapshot (estimate_extrinsic / estimate_td: the batched entry points run the general single-window solve per slot and need the inputs again)
+struct OwnedWindow {
+    vilf_window_in in;
+    std::vector<double> pose, sb, feat, obs, vel, ctd, row, gR0, gP0;
+    std::vector<uint8_t> fconst;
+    std::vector<int32_t> fstart, foff;
+    std::vector<vilf_imu_preint> imu;
+    std::vector<vilf_lidar_constraint> lidar;
+};
 
 struct vilf_handle {
     vilf_options opts;
@@ -59,6 +69,7 @@ struct vilf_handle {
     size_t marg_lds_schur = 0, marg_lds_finish = 0;
     std::vector<int> h_nfeat, h_nframes;
     std::vector<double> h_ex, h_td;
+    std::vector<OwnedWindow> own;            // only with estimate_extrinsic / estimate_td
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int profiling = 0;                       // per-kernel HIP-event timing of the solve launches
     std::vector<hipEvent_t> pev;
@@ -93,4 +104,4 @@ void vilf_s2m_release(vilf_handle *h);
 void vilf_feat_release(vilf_handle *h);
 void vilf_pg_release(vilf_handle *h);
 void vilf_lw_release(vilf_handle *h);
-int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot0);   // window sizes other than 10, estimate_extrinsic / estimate_td (vilf_lw.hip)
+int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot1);   // batch_slot1 = resident slot + 1 (0: not resident)   // window sizes other than 10, estimate_extrinsic / estimate_td (vilf_lw.hip)

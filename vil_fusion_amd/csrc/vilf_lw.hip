@@ -404,7 +404,9 @@ inline void h_ypr2R(const double *ypr, double *R) {
 
 // batch_slot0 != 0: the window is also resident as slot 0 of the 11-frame batch (vilf_batch_upload ran): use that slot's prior and write
 // the solved state back into the batch buffers (the marginalization reads them)
-int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot0) {
+int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot1) {
+    const int batch_slot0 = batch_slot1 != 0;          // resident in the 11-frame batch
+    const size_t slot = batch_slot1 ? (size_t)(batch_slot1 - 1) : 0;
     const auto t_start = std::chrono::steady_clock::now();
     const bool est_ex = h->opts.estimate_extrinsic != 0, est_td = h->opts.estimate_td != 0;
     const int NF = in->n_frames, F = in->n_features;
@@ -416,7 +418,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     if (in->n_obs < 0 || (F && (in->feature_obs_offset[0] != 0 || in->feature_obs_offset[F] != in->n_obs)) || (!F && in->n_obs != 0)) { h->err = "feature_obs_offset must start at 0 and end at n_obs"; return VILF_ERR_INVALID_ARGUMENT; }
     for (int f = 0; f < F; f++) if (in->feature_obs_offset[f + 1] - in->feature_obs_offset[f] < 2) { h->err = "feature with fewer than two observations"; return VILF_ERR_INVALID_ARGUMENT; }
     if (est_td && F && (!in->obs_velocity || !in->obs_cur_td || !in->obs_row)) { h->err = "estimate_td needs obs_velocity / obs_cur_td / obs_row"; return VILF_ERR_INVALID_ARGUMENT; }
-    if (batch_slot0 && (NF != VB_NF || !h->resident)) return VILF_ERR_INVALID_ARGUMENT;
+    if (batch_slot0 && (NF != VB_NF || !h->resident || (int)slot >= h->B)) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipSetDevice(h->device));
     if (!h->lw) h->lw = new LwCtx();
     LwCtx *c = h->lw;
@@ -516,8 +518,8 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     std::vector<double> px0(24 * 9), pdx(VB_PRIOR_LD, 0.0);
     std::vector<int> pcol(VB_PRIOR_LD, -1);
     if (batch_slot0) {
-        HIPCHECK(h, hipMemcpyAsync(phdr, h->d[D_PHDR].p, sizeof(phdr), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(px0.data(), h->d[D_PX0].p, px0.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(phdr, h->d[D_PHDR].as<int>() + slot * VB_PRIOR_HDR, sizeof(phdr), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(px0.data(), h->d[D_PX0].as<double>() + slot * 24 * 9, px0.size() * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         if (phdr[0]) {
             pn = phdr[1]; pnb = phdr[2];
@@ -526,6 +528,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
                 if (id < NF) for (int k = 0; k < 6; k++) pcol[idx + k] = 15 * id + k;
                 else if (id < 2 * NF) for (int k = 0; k < 9; k++) pcol[idx + k] = 15 * (id - NF) + 6 + k;
                 else if (id == 2 * NF && est_ex) for (int k = 0; k < 6; k++) pcol[idx + k] = cEx + k;
+                else if (id == 2 * NF + 1 && est_td) pcol[idx] = cTd;                       // para_Td, kept by the marginalization (estimator.cpp:930-935,968-969)
             }
             HIPCHECK(h, hipMemcpyAsync(c->pri.as<char>() + VB_PRIOR_LD * 8, pcol.data(), VB_PRIOR_LD * sizeof(int), hipMemcpyHostToDevice, h->stream));
         }
@@ -544,6 +547,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             if (id < NF) pose_dx(&xx[7 * id], x0, &pdx[idx]);
             else if (id < 2 * NF) for (int k = 0; k < 9; k++) pdx[idx + k] = xx[7 * NF + 9 * (id - NF) + k] - x0[k];
             else if (id == 2 * NF) pose_dx(&xx[xo], x0, &pdx[idx]);
+            else if (id == 2 * NF + 1) pdx[idx] = xx[xo + 7] - x0[0];
         }
     };
     double R0b[9], P0b[3];
@@ -582,7 +586,8 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         if (pn) {
             prior_dx(xx);
             HIPCHECK(h, hipMemcpyAsync(c->pri.p, pdx.data(), VB_PRIOR_LD * 8, hipMemcpyHostToDevice, h->stream));
-            hipLaunchKernelGGL(lw_prior, dim3(1), dim3(256), 0, h->stream, pn, h->d[D_PJ].as<double>(), h->d[D_PR].as<double>(), h->d[D_PH].as<double>(), c->pri.as<double>(),
+            hipLaunchKernelGGL(lw_prior, dim3(1), dim3(256), 0, h->stream, pn, h->d[D_PJ].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, h->d[D_PR].as<double>() + slot * VB_PRIOR_LD,
+                               h->d[D_PH].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, c->pri.as<double>(),
                                (const int *)(c->pri.as<char>() + VB_PRIOR_LD * 8), P, jac ? 1 : 0, c->Hpp.as<double>(), c->gp.as<double>(), scal);
         }
         hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, P, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
@@ -797,18 +802,20 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     for (int k = 0; k < 3; k++) out->tic[k] = x[xo + k];                 // double2vector :607-617: tic / ric / td from para_Ex_Pose / para_Td
     h_q2R(&x[xo + 3], out->ric);
     out->td = est_td ? x[xo + 7] : in->para_td;
-    if (batch_slot0) {                                                  // the marginalization of this window reads the batch buffers of slot 0
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_POSE].p, &x[0], 77 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_SB].p, &x[77], 99 * 8, hipMemcpyHostToDevice, h->stream));
-        if (F) HIPCHECK(h, hipMemcpyAsync(h->d[D_FEAT].p, &x[16 * NF], (size_t)F * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_EX].p, &x[xo], 56, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OPS].p, out->Ps, 33 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_ORS].p, out->Rs, 99 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OVS].p, out->Vs, 33 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBAS].p, out->Bas, 33 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBGS].p, out->Bgs, 33 * 8, hipMemcpyHostToDevice, h->stream));
+    if (batch_slot0) {                                                  // the marginalization of this window reads the batch buffers of its slot
+        const size_t sF2 = h->batch.Fmax;
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_POSE].as<double>() + slot * 77, &x[0], 77 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_SB].as<double>() + slot * 99, &x[77], 99 * 8, hipMemcpyHostToDevice, h->stream));
+        if (F) HIPCHECK(h, hipMemcpyAsync(h->d[D_FEAT].as<double>() + slot * sF2, &x[16 * NF], (size_t)F * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_EX].as<double>() + slot * 7, &x[xo], 56, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_TD].as<double>() + slot, &out->td, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OPS].as<double>() + slot * 33, out->Ps, 33 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_ORS].as<double>() + slot * 99, out->Rs, 99 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OVS].as<double>() + slot * 33, out->Vs, 33 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBAS].as<double>() + slot * 33, out->Bas, 33 * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBGS].as<double>() + slot * 33, out->Bgs, 33 * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
-        std::memcpy(&h->h_ex[0], &x[xo], 56); h->h_td[0] = out->td;
+        std::memcpy(&h->h_ex[slot * 7], &x[xo], 56); h->h_td[slot] = out->td;
     }
     out->summary.num_iterations = iteration; out->summary.num_successful_steps = num_successful; out->summary.num_linear_solves = num_linear_solves;
     out->summary.termination = termination; out->summary.initial_cost = initial_cost; out->summary.final_cost = x_cost; out->summary.final_radius = radius;

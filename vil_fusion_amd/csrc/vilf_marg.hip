@@ -84,7 +84,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
     const int w = blockIdx.x, tid = threadIdx.x;
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ex[7], s_ric[9], s_dx[VB_PRIOR_LD], s_J[15 * 32], s_r[16], s_lJ[72], s_lr[8];
     __shared__ double s_pm[10 * MG_PAIRM];
-    __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_pmap[VB_PRIOR_LD], s_hdr[8], s_poff[VB_NPAIR + 1];
+    __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_poff[VB_NPAIR + 1];
+    __shared__ double s_td;
     int *info = g.info + (size_t)w * MG_INFO;
     const int F = b.n_feat[w];
     const size_t FM = b.Fmax, FC = b.FACmax;
@@ -103,6 +104,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
         for (int k = 0; k < 9; k++) s_R[9 * tid + k] = R[k];
         for (int k = 0; k < 3; k++) { s_sb[9 * tid + k] = b.out_Vs[((size_t)w * VB_NF + tid) * 3 + k]; s_sb[9 * tid + 3 + k] = b.out_Bas[((size_t)w * VB_NF + tid) * 3 + k]; s_sb[9 * tid + 6 + k] = b.out_Bgs[((size_t)w * VB_NF + tid) * 3 + k]; }
     }
+    if (tid == 33) s_td = b.td[w];
     if (tid == 32) {
         const double *ex = b.ex + (size_t)w * 7;
         q_toR(q_load(ex + 3), s_ric);
@@ -161,24 +163,26 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             mf = s_mf;                                                                   // features observed from frame 0 (:921-950)
             for (int j = 1; j < s_maxobs && j < VB_NF; j++) present[j] = true;
             if (mf > 0) present[2 * VB_NF] = true;
+            if (mf > 0 && b.est_td) present[2 * VB_NF + 1] = true;                      // para_Td of the ProjectionTdFactors (estimator.cpp:930-935)
         } else {             // MARGIN_SECOND_NEW: only the prior, drop Pose[WINDOW_SIZE-1] (:986-1003)
             if (!have_prior || !present[VB_NF - 2]) status = 2;                          // nothing to do: prior stays as it is
             drop[VB_NF - 2] = true;
         }
         int off = 0;
         for (int a = 0; a < VB_NF; a++) s_off_pose[a] = -1;
-        s_off_sb[0] = s_off_sb[1] = -1; s_off_ex = -1;
+        s_off_sb[0] = s_off_sb[1] = -1; s_off_ex = -1; s_off_td = -1;
         for (int id = 0; id < 2 * VB_NF + 1 && status == 0; id++) if (present[id] && drop[id]) {
             if (id < VB_NF) { s_off_pose[id] = off; off += 6; } else if (id < 2 * VB_NF) { if (id - VB_NF < 2) s_off_sb[id - VB_NF] = off; else status = 3; off += 9; }
         }
         md = off;
-        for (int id = 0; id < 2 * VB_NF + 1 && status == 0; id++) if (present[id] && !drop[id]) {
+        for (int id = 0; id < 2 * VB_NF + 2 && status == 0; id++) if (present[id] && !drop[id]) {
             int size = 7, loc = 6, sid;
             if (id < VB_NF) { s_off_pose[id] = off; }
             else if (id < 2 * VB_NF) { if (id - VB_NF < 2) s_off_sb[id - VB_NF] = off; else status = 3; size = 9; loc = 9; }
-            else s_off_ex = off;
+            else if (id == 2 * VB_NF) s_off_ex = off;
+            else { s_off_td = off; size = 1; loc = 1; }
             // address shift (estimator.cpp:960-971 MARGIN_OLD: frame i -> i-1; :1016-1037 SECOND_NEW: frame WINDOW_SIZE -> WINDOW_SIZE-1)
-            if (id == 2 * VB_NF) sid = id;
+            if (id >= 2 * VB_NF) sid = id;
             else if (mode == 0) sid = id - 1;
             else { const int fr = id < VB_NF ? id : id - VB_NF; sid = (fr == VB_NF - 1) ? id - 1 : id; }
             if (nb >= 24) { status = 3; break; }
@@ -205,8 +209,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
     if (have_prior && tid < phdr[2]) {
         const int id = phdr[3 + tid], size = phdr[27 + tid], idx = phdr[51 + tid];
         const double *x0 = b.prior_x0 + ((size_t)w * 24 + tid) * 9;
-        const double *x = id < VB_NF ? s_pose + 7 * id : (id < 2 * VB_NF ? s_sb + 9 * (id - VB_NF) : s_ex);
-        const int doff = id < VB_NF ? s_off_pose[id] : (id < 2 * VB_NF ? s_off_sb[id - VB_NF] : s_off_ex);
+        const double *x = id < VB_NF ? s_pose + 7 * id : (id < 2 * VB_NF ? s_sb + 9 * (id - VB_NF) : (id == 2 * VB_NF ? s_ex : &s_td));
+        const int doff = id < VB_NF ? s_off_pose[id] : (id < 2 * VB_NF ? s_off_sb[id - VB_NF] : (id == 2 * VB_NF ? s_off_ex : s_off_td));
         if (size == 7) {
             for (int k = 0; k < 3; k++) s_dx[idx + k] = x[k] - x0[k];
             Q dq = q_mul(q_inv(q_load(x0 + 3)), q_load(x + 3));
@@ -273,27 +277,34 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             for (int k = 0; k < 3; k++) { pts_i[k] = rec[k]; pts_j[k] = rec[3 + k]; }
             const long long ra = __double_as_longlong(rec[6]), rb = __double_as_longlong(rec[7]);
             const int f = (int)(ra & 0xffffffffll), slot = (int)(ra >> 32), fj = (int)((rb >> 8) & 255);
-            double r[2], Ji[12], Jj[12], Jf[2], Jex[12];
+            double r[2], Ji[12], Jj[12], Jf[2], Jex[12], Jtd[2] = {0.0, 0.0};
+            if (b.est_td) {         // ProjectionTdFactor (estimator.cpp:930-935): the observations shifted by the pixel velocity over td (+ rolling-shutter row time)
+                const int oj = b.ps_obs[(size_t)w * FC + q], oi = b.f_obs0[(size_t)w * FM + f];
+                const double *vi = b.obs_vel + ((size_t)w * b.Omax + oi) * 2, *vj = b.obs_vel + ((size_t)w * b.Omax + oj) * 2;
+                projection_td_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, vi, vj, s_td, b.obs_ctd[(size_t)w * b.Omax + oi], b.obs_ctd[(size_t)w * b.Omax + oj],
+                                         b.obs_row[(size_t)w * b.Omax + oi] - b.row_half, b.obs_row[(size_t)w * b.Omax + oj] - b.row_half, b.tr_over_row, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex, Jtd);
+            } else
             projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             for (int k = 0; k < 12; k++) { Mb[(size_t)slot * MG_MROW + (k)] = sw * Ji[k]; Mb[(size_t)slot * MG_MROW + (12 + k)] = sw * Jj[k]; Mb[(size_t)slot * MG_MROW + (24 + k)] = sw * Jex[k]; }
             Mb[(size_t)slot * MG_MROW + (36)] = sw * Jf[0]; Mb[(size_t)slot * MG_MROW + (37)] = sw * Jf[1];
             Mb[(size_t)slot * MG_MROW + (38)] = sw * r[0]; Mb[(size_t)slot * MG_MROW + (39)] = sw * r[1];
+            Mb[(size_t)slot * MG_MROW + (40)] = sw * Jtd[0]; Mb[(size_t)slot * MG_MROW + (41)] = sw * Jtd[1];
         }
     }
     __syncthreads();
-    // ---- per pair (0, j): [J0 Jj Jex r]^T [J0 Jj Jex r] (19 x 19, upper triangle) over the pair's factors. The factor rows of a pair
+    // ---- per pair (0, j): [J0 Jj Jex Jtd r]^T [J0 Jj Jex Jtd r] (20 x 20, upper triangle; the td column is zero without estimate_td) over the pair's factors. The factor rows of a pair
     // are staged through LDS in chunks (one coalesced 320-byte row per factor) and every entry is one thread's running sum over the
     // factors in pair order — the same summation order as a per-entry gather from global memory, without its dependent loads.
     if (mode == 0) {
         __shared__ double s_rows[MG_GCH * MG_MROW];
         const int *ps_slot = b.ps_slot + (size_t)w * FC;
         int u = 0, v = 0;
-        if (tid < 190) { int e = tid; while (e >= 19 - u) { e -= 19 - u; u++; } v = u + e; }      // upper-triangle entry tid -> (u <= v)
-        // column u of X: 0..5 J0, 6..11 Jj, 12..17 Jex, 18 r  -> Mbuf component rows (row0, row1)
-        const int cu0 = (u < 18) ? (12 * (u / 6) + (u % 6)) : 38, cu1 = (u < 18) ? cu0 + 6 : 39;
-        const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : 38, cv1 = (v < 18) ? cv0 + 6 : 39;
+        if (tid < 210) { int e = tid; while (e >= 20 - u) { e -= 20 - u; u++; } v = u + e; }      // upper-triangle entry tid -> (u <= v)
+        // column u of X: 0..5 J0, 6..11 Jj, 12..17 Jex, 18 Jtd, 19 r  -> Mbuf component rows (row0, row1)
+        const int cu0 = (u < 18) ? (12 * (u / 6) + (u % 6)) : (u == 18 ? 40 : 38), cu1 = (u < 18) ? cu0 + 6 : cu0 + 1;
+        const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : (v == 18 ? 40 : 38), cv1 = (v < 18) ? cv0 + 6 : cv0 + 1;
         for (int jj = 0; jj < 10; jj++) {
             const int p = pair_index_c(0, jj + 1), q0 = s_poff[p], q1 = s_poff[p + 1];
             double sum = 0;
@@ -301,10 +312,10 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
                 const int nr = min(MG_GCH, q1 - c0);
                 for (int idx = tid; idx < nr * MG_MROW; idx += NT) { const int r = idx / MG_MROW, comp = idx - MG_MROW * r; s_rows[idx] = Mb[(size_t)ps_slot[c0 + r] * MG_MROW + comp]; }
                 __syncthreads();
-                if (tid < 190) for (int r = 0; r < nr; r++) { const double *row = s_rows + r * MG_MROW; sum += row[cu0] * row[cv0] + row[cu1] * row[cv1]; }
+                if (tid < 210) for (int r = 0; r < nr; r++) { const double *row = s_rows + r * MG_MROW; sum += row[cu0] * row[cv0] + row[cu1] * row[cv1]; }
                 __syncthreads();
             }
-            if (tid < 190) s_pm[jj * MG_PAIRM + 20 * u + v] = sum;
+            if (tid < 210) s_pm[jj * MG_PAIRM + 20 * u + v] = sum;
         }
     }
     __syncthreads();
@@ -355,7 +366,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
     __syncthreads();
     if (mode == 0) {
         // visual dense blocks: P0 x P0, P0 x Pj, P0 x Ex, Pj x Pj, Pj x Ex, Ex x Ex (+ rhs), summed over j in fixed order
-        const int o0 = s_off_pose[0], oex = s_off_ex;
+        const int o0 = s_off_pose[0], oex = s_off_ex, otd = s_off_td;
         for (int e = tid; e < nd * (nd + 1); e += NT) {
             const int du = e / (nd + 1), dv = e - (nd + 1) * du;      // dv == nd: rhs
             double s = 0;
@@ -363,8 +374,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             for (int jj = 0; jj < 10; jj++) {
                 const int oj = s_off_pose[jj + 1];
                 if (s_poff[pair_index_c(0, jj + 1) + 1] == s_poff[pair_index_c(0, jj + 1)]) continue;
-                auto xcol = [&](int d) -> int { if (d >= o0 && d < o0 + 6) return d - o0; if (oj >= 0 && d >= oj && d < oj + 6) return 6 + d - oj; if (oex >= 0 && d >= oex && d < oex + 6) return 12 + d - oex; return -1; };
-                const int u = xcol(du), v = (dv == nd) ? 18 : xcol(dv);
+                auto xcol = [&](int d) -> int { if (d >= o0 && d < o0 + 6) return d - o0; if (oj >= 0 && d >= oj && d < oj + 6) return 6 + d - oj; if (oex >= 0 && d >= oex && d < oex + 6) return 12 + d - oex; if (otd >= 0 && d == otd) return 18; return -1; };
+                const int u = xcol(du), v = (dv == nd) ? 19 : xcol(dv);
                 if (u < 0 || v < 0) continue;
                 s += (u <= v) ? s_pm[jj * MG_PAIRM + 20 * u + v] : s_pm[jj * MG_PAIRM + 20 * v + u];
                 any = true;
@@ -379,13 +390,14 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             if (rk < 0) continue;
             double *Wr = Wf + (size_t)rk * MG_ND;
             for (int k = 0; k < nd; k++) Wr[k] = 0.0;
-            double h = 0, gg = 0, w0[6] = {0, 0, 0, 0, 0, 0}, wex[6] = {0, 0, 0, 0, 0, 0};
+            double h = 0, gg = 0, w0[6] = {0, 0, 0, 0, 0, 0}, wex[6] = {0, 0, 0, 0, 0, 0}, wtd = 0;
             const int nf = f_nobs[f] - 1, f0 = f_fac0[f];
             for (int t = 0; t < nf; t++) {
                 const int slot = f0 + t;
                 const double jf0 = Mb[(size_t)slot * MG_MROW + (36)], jf1 = Mb[(size_t)slot * MG_MROW + (37)];
                 h += jf0 * jf0 + jf1 * jf1;
                 gg += jf0 * Mb[(size_t)slot * MG_MROW + (38)] + jf1 * Mb[(size_t)slot * MG_MROW + (39)];
+                wtd += jf0 * Mb[(size_t)slot * MG_MROW + (40)] + jf1 * Mb[(size_t)slot * MG_MROW + (41)];
                 const int oj = s_off_pose[1 + t];
                 for (int c = 0; c < 6; c++) {
                     w0[c] += Mb[(size_t)slot * MG_MROW + (c)] * jf0 + Mb[(size_t)slot * MG_MROW + (6 + c)] * jf1;
@@ -394,6 +406,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
                 }
             }
             for (int c = 0; c < 6; c++) { Wr[o0 + c] = w0[c]; Wr[oex + c] = wex[c]; }
+            if (otd >= 0) Wr[otd] = wtd;
             hfm[rk] = h; gfm[rk] = gg;
         }
     }
@@ -789,7 +802,7 @@ __device__ void mf_tail(const VbBatch &b, const VbMarg &g, int w, const double *
         hdr[3 + tid] = tid < nb ? info[8 + tid] : 0; hdr[27 + tid] = tid < nb ? info[32 + tid] : 0; hdr[51 + tid] = tid < nb ? info[56 + tid] : 0;
         if (tid < nb) {
             const int id = info[80 + tid];
-            const double *x = id < VB_NF ? g.st_pose + (size_t)w * 77 + 7 * id : (id < 2 * VB_NF ? g.st_sb + (size_t)w * 99 + 9 * (id - VB_NF) : g.st_ex + (size_t)w * 7);
+            const double *x = id < VB_NF ? g.st_pose + (size_t)w * 77 + 7 * id : (id < 2 * VB_NF ? g.st_sb + (size_t)w * 99 + 9 * (id - VB_NF) : (id == 2 * VB_NF ? g.st_ex + (size_t)w * 7 : b.td + w));
             double *x0 = g.prior_x0_out + ((size_t)w * 24 + tid) * 9;
             const int size = info[32 + tid];
             for (int k = 0; k < 9; k++) x0[k] = k < size ? x[k] : 0.0;
