@@ -176,6 +176,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="run the LiDAR stage on its own handle / HIP stream / host thread, concurrently with the "
                     "window solve (like the reference's separate nodes); ~7 %% more frames/s, but per-kernel timings then include contention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ragged-windows", type=int, default=1024, help="distinct windows of the ragged-batch line (features U(120, 320), mixed prior / no prior, mixed marginalization flags), tiled to --windows; 0 skips it")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[4] instead of the headline workload: one synthetic 51-frame / ~46 k-factor window per step and GPU")
     args = ap.parse_args()
     if args.stress:
@@ -303,6 +304,43 @@ def main():
     else:
         dt_max, its_total = dt, float(its_local)
 
+    # ---- ragged-batch line: the headline replicates 64 windows of one shape; here every window differs (feature count, prior, marginalization flag).
+    # Solve + marginalization only (the LiDAR streams are the same), after the timed region, reported beside the headline — never as `value`.
+    ragged = None
+    if args.ragged_windows > 0 and world == 1:
+        rng = np.random.default_rng(4242)
+        nr = min(args.ragged_windows, B)
+        rw, rp = [], []
+        for i in range(nr):
+            c = synth.SynthConfig(n_features=int(rng.integers(120, 321)), with_prior=bool(rng.random() < 0.8),
+                                  marginalization_flag=(0 if rng.random() < 0.7 else 1))      # VILF_MARGIN_OLD / VILF_MARGIN_SECOND_NEW
+            wnd, pr, _ = synth.make_window(500000 + i, opts, c)
+            rw.append(wnd); rp.append(pr)
+        rsolver = BackendSolver(device=local_rank)
+        rsolver.batch_upload([rw[i % nr] for i in range(B)], [rp[i % nr] for i in range(B)])
+
+        def rstep():
+            rsolver.batch_rewind(); rsolver.batch_solve(sync=True)
+            if not args.no_marginalize:
+                rsolver.batch_marginalize(sync=True)
+        rstep()
+        torch.cuda.synchronize(); tr0 = time.perf_counter(); rits = 0
+        for _ in range(3):
+            rstep(); rits += sum(s_.num_iterations for s_ in rsolver.batch_summaries())
+        torch.cuda.synchronize(); trd = time.perf_counter() - tr0
+        # the same three steps of the regular (64 distinct) batch without the LiDAR stage, for a like-for-like ratio
+        tq0 = time.perf_counter(); qits = 0
+        for _ in range(3):
+            solver.batch_rewind(); solver.batch_solve(sync=True)
+            if not args.no_marginalize:
+                solver.batch_marginalize(sync=True)
+            qits += sum(s_.num_iterations for s_ in solver.batch_summaries())
+        torch.cuda.synchronize(); tqd = time.perf_counter() - tq0
+        ragged = {"value": rits / trd, "unit": "iterations/s", "what": "window solve" + ("" if args.no_marginalize else " + marginalization") + ", no LiDAR stage",
+                  "distinct_windows": nr, "features": "U(120, 320)", "prior_fraction": 0.8, "margin_old_fraction": 0.7, "mean_iterations": rits / (3.0 * B),
+                  "ms_per_step": trd / 3 * 1e3, "regular_batch_same_stages": {"value": qits / tqd, "ms_per_step": tqd / 3 * 1e3}}
+        rsolver.close()
+
     if rank == 0:
         abytes = float(np.mean([algorithmic_bytes_per_iteration(w, p) for w, p in zip(wins[:args.distinct], priors[:args.distinct])]))
         # algorithmic bytes per STEP (all B frames) per kernel / launch group; for the window kernels
@@ -336,21 +374,25 @@ def main():
                 traffic = pmc["groups"][dom]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
-        # the dense reduce (k_solve: MFMA Schur reduce + blocked Cholesky) against the fp64 MFMA roofline: flop count per dispatch from the
-        # committed PMC pass (SQ_INSTS_VALU_MFMA_F64 x 2048 flop, same 2048-window / 230-feature configuration), time from this run
+        # the dense reduce (k_solve_sb) against the fp64 MFMA roofline, counted analytically per window-iteration (no PMC file: a counter pass of an older kernel
+        # version must not be combined with current timings). "algorithmic" = SURVEY §8(d): P^3/3 + 2 P^2 + 2 sum_f (6 k_f)^2; "issued" = the v_mfma_f64_16x16x4_f64
+        # instructions the kernel executes (2048 flop each: 80-wide padded feature reduce, Y recurrence + Y^T Y, rank-4 panel updates of the dense Cholesky).
         mfma = None
         try:
-            import glob
-            pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")), key=_profile_order)[-1]))
-            if cfg.n_features == 230:      # per-window flop count is independent of the batch size: scale the 2048-window PMC figure
-                mfma = {}
-                for kk in ("k_solve", "k_linearize"):
-                    fl = pm["kernels"][kk]["mfma_flop_per_dispatch"] * (B / 2048.0)
-                    ms = prof[kk]["ms"] / max(prof[kk]["launches"], 1)
-                    mfma[kk] = {"bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / 78.6,
-                                "mfma_flop_per_launch": fl, "avg_launch_ms": ms, "pmc_MfmaUtil_percent": pm["kernels"][kk]["MfmaUtil_percent"]}
+            F_mean = float(np.mean([w.n_features for w in wins[:args.distinct]]))
+            nsteps = (int(F_mean) + 3) // 4
+            issued = 15 * nsteps + 10 * (9 * 4 + 3 * 15) - 9 * 4 + sum(sum(1 for (ta, tb) in [(a_, b_) for a_ in range(5) for b_ in range(a_ + 1)] if 16 * tb + 15 >= 4 * bj + 4) for bj in range(19))
+            kf = [np.diff(w.feature_obs_offset)[np.asarray(w.feature_const) == 0] for w in wins[:args.distinct]]
+            alg_flop = float(np.mean([165.0 ** 3 / 3 + 2 * 165.0 ** 2 + 2 * float(np.sum((6.0 * k) ** 2)) for k in kf]))
+            ms = prof["k_solve"]["ms"] / max(prof["k_solve"]["launches"], 1)
+            mfma = {"k_solve": {"bound": "mfma", "peak": 78.6, "unit": "TFLOP/s", "avg_launch_ms": ms, "mfma_instructions_per_window": issued,
+                                "issued_flop_per_launch": issued * 2048.0 * B, "achieved_issued": issued * 2048.0 * B / (ms * 1e-3) / 1e12, "frac_issued": issued * 2048.0 * B / (ms * 1e-3) / 1e12 / 78.6,
+                                "algorithmic_flop_per_launch": alg_flop * B, "achieved": alg_flop * B / (ms * 1e-3) / 1e12, "frac": alg_flop * B / (ms * 1e-3) / 1e12 / 78.6,
+                                "source": "analytic instruction count of the current kernel (see DESIGN.md); PMC cross-check in profiles/ when taken at this version"}}
         except Exception:
             mfma = None
+        it_ms = sum(prof[k]["ms"] for k in ("k_linearize", "k_solve", "k_step")) / max(prof["k_solve"]["launches"], 1)
+        whole_it = abytes * B / (it_ms * 1e-3) / 1e9
         out = {
             "metric": "sliding-window solve iters/sec (10 KF, ~5.5k factors) @1/2/4/8 GPU vs CPU",
             "value": its_total / dt_max, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -367,12 +409,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": lps[dom], "algorithmic_bytes_per_launch": alg[dom] / max(lps[dom], 1e-9),
                          "algorithmic_bytes_per_window_iteration": abytes,
+                         "whole_iteration": {"ms": it_ms, "achieved": whole_it, "frac": whole_it / 8000.0, "what": "388 KB x windows over k_linearize + k_solve + k_step of one iteration"},
                          "kernels_ms": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
                          "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                          "kernels_achieved_GBps": {k: alg[k] / (prof[k]["ms"] / args.steps) / 1e6 for k in alg if prof[k]["launches"] > 0 and prof[k]["ms"] > 0}},
         }
         if mfma is not None:
             out["roofline_mfma"] = mfma
+        if ragged is not None:
+            out["ragged_batch"] = ragged
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))

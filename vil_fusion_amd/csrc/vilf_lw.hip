@@ -17,7 +17,6 @@
 // batch buffers, so that vilf_window_marginalize() continues from it. Other window sizes have no prior (no device marginalization).
 // Summation order of the atomics is not fixed: results are reproducible to rounding (~1e-12 relative), not bit for bit.
 #include <hip/hip_runtime.h>
-#include <rocsolver/rocsolver.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -29,7 +28,6 @@
 extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec);
 
 struct LwCtx {
-    rocblas_handle blas = nullptr;
     DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den, jscr, tdrec, pri;
     hipEvent_t ev[2] = {nullptr, nullptr};
     double ms[4] = {0, 0, 0, 0};       // vilf_set_profiling: factor scatter, Schur SYRK, Cholesky (potrf + potrs), other device work
@@ -37,7 +35,6 @@ struct LwCtx {
     void release() {
         DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr, &tdrec, &pri};
         for (DBuf *b : all) b->release();
-        if (blas) { rocblas_destroy_handle(blas); blas = nullptr; }
         for (hipEvent_t &e : ev) if (e) { hipEventDestroy(e); e = nullptr; }
     }
 };
@@ -367,6 +364,178 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *
             }
 }
 
+// ---- dense Cholesky of the reduced system (P x P, fp64) with the right-hand side as row P: S = L L^T, L[P][0..P-1] = L^-1 rhs -----------------------
+// Right-looking over 64-column blocks, TWO launches per block column and no vendor library:
+//   lw_chol_panel   a workgroup = the 64 x 64 diagonal block + 192 rows of the panel below it, all as MFMA tiles in registers (the scheme of k_solve_sb's dense
+//                   factorisation): 4-column panels, one thread per slab row, rank-4 updates one v_mfma_f64_16x16x4_f64 per tile. Every workgroup factors the
+//                   diagonal block itself — the rows below cannot start before it is known, so that costs no time and saves a launch per block column.
+//   lw_chol_update  A22 -= L21 L21^T on the lower 64 x 64 tiles (one workgroup per tile, the two 64 x 64 panels through LDS, MFMA), rhs row included.
+//   lw_chol_back    L^T y = z by one workgroup (z = row P of the factor).
+#define CH_NB 64
+#define CH_LD 65
+#define CH_BELOW 192          // rows of the panel below the diagonal block per workgroup (256 rows with the block's own 64)
+// One workgroup = a 256 x 64 slab: the 64 rows of the diagonal block + 192 rows below it, as 16 x 4 MFMA tiles in registers (wave w owns the tile rows
+// w, w + 4, w + 8, w + 12). Per 4-column panel: lanes holding the panel's columns -> LDS; thread r (one per slab row) factors the 4 x 4 diagonal block itself
+// and solves its row's strip (the strip goes straight to S and to the operand buffer); rank-4 update of every tile right of the panel, one MFMA each.
+__global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, int *info) {
+    __shared__ double s_pan[256 * 4], s_lp[256 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g4 = lane >> 4;
+    const int nb = min(CH_NB, P - j0), P1 = P + 1;                 // the last block is padded with an identity
+    const int below0 = j0 + nb + CH_BELOW * (int)blockIdx.x;       // first global row of this workgroup's rows below the block
+    auto grow = [&](int lr) { return lr < CH_NB ? j0 + lr : below0 + (lr - CH_NB); };      // slab row -> row of S (rows 64.. of the slab are below the block)
+    auto live = [&](int lr) { return lr < CH_NB ? lr < nb : below0 + (lr - CH_NB) < P1; };
+    lw_double4 T[4][4];                                            // [m][tile column]: tile row wave + 4 m
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int tcl = 0; tcl < 4; tcl++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int lr = 16 * (wave + 4 * m) + g4 + 4 * q, c = 16 * tcl + c16;
+                double v = 0.0;
+                if (lr < CH_NB) { if (lr == c && lr >= nb) v = 1.0; else if (lr < nb && c <= lr) v = S[(size_t)(j0 + lr) * P + j0 + c]; }
+                else if (live(lr) && c < nb) v = S[(size_t)grow(lr) * P + j0 + c];
+                T[m][tcl][q] = v;
+            }
+    const bool mine = live(tid) && (tid >= CH_NB || blockIdx.x == 0);         // the block's own rows are written by workgroup 0 only
+    double *Srow = S + (size_t)grow(tid) * P + j0;
+#pragma unroll 1
+    for (int bj = 0; bj < 16; bj++) {
+        const int p0 = 4 * bj, tc = bj >> 2, sp = bj & 3;
+        if ((c16 >> 2) == sp) {
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int tcl = 0; tcl < 4; tcl++)
+                    if (tcl == tc) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { const int lr = 16 * (wave + 4 * m) + g4 + 4 * q; if (lr >= p0) s_pan[4 * lr + (c16 & 3)] = T[m][tcl][q]; }
+                    }
+        }
+        __syncthreads();
+        if (tid >= p0) {
+            const double *dg = s_pan + 4 * p0, *rp = s_pan + 4 * tid;
+            const double d00 = dg[0], d10 = dg[4], d11 = dg[5], d20 = dg[8], d21 = dg[9], d22 = dg[10], d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
+            const double i0 = rsqrt_h3(d00), l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+            const double t11 = d11 - l10 * l10, i1 = rsqrt_h3(t11), l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+            const double t22 = d22 - l20 * l20 - l21 * l21, i2 = rsqrt_h3(t22), l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+            const double t33 = d33 - l30 * l30 - l31 * l31 - l32 * l32, i3 = rsqrt_h3(t33);
+            const double x0 = rp[0] * i0, x1 = (rp[1] - x0 * l10) * i1, x2 = (rp[2] - x0 * l20 - x1 * l21) * i2, x3 = (rp[3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+            const int k = tid - p0;                                // rows of the diagonal 4 x 4 block keep their lower part
+            double *lp = s_lp + 4 * tid;
+            lp[0] = x0; lp[1] = (k >= 1) ? x1 : 0.0; lp[2] = (k >= 2) ? x2 : 0.0; lp[3] = (k >= 3) ? x3 : 0.0;
+            if (mine) {
+                if (p0 < nb) Srow[p0] = x0;
+                if (k >= 1 && p0 + 1 < nb) Srow[p0 + 1] = x1;
+                if (k >= 2 && p0 + 2 < nb) Srow[p0 + 2] = x2;
+                if (k >= 3 && p0 + 3 < nb) Srow[p0 + 3] = x3;
+            }
+            if (k == 0 && blockIdx.x == 0 && (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || !(t33 > 0.0))) *info = 1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int tcl = 0; tcl < 4; tcl++)
+                if (16 * tcl + 15 >= p0 + 4 && (m > 0 || tcl <= wave)) {          // right of the panel; the block's own tile rows: lower tiles only
+                    const double av = -s_lp[4 * (16 * (wave + 4 * m) + c16) + g4], bv = s_lp[4 * (16 * tcl + c16) + g4];
+                    T[m][tcl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T[m][tcl], 0, 0, 0);
+                }
+    }
+}
+// A22 -= L21 L21^T, lower 64 x 64 tiles of the rows / columns j1 .. P (row P = rhs). grid.x = nt (nt + 1) / 2
+__global__ __launch_bounds__(256) void lw_chol_update(int P, double *S, int j0, int nb) {
+    __shared__ double sA[CH_NB * CH_LD], sB[CH_NB * CH_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P1 = P + 1, j1 = j0 + nb;
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
+    const int tj = blockIdx.x - ti * (ti + 1) / 2, r0 = j1 + 64 * ti, c0 = j1 + 64 * tj;
+    // panels: element (row i, k) of L21 -> s[k][i] (k-major for the MFMA operand reads); the global read is coalesced along k
+    for (int e = tid; e < 64 * CH_NB; e += 256) {
+        const int i = e >> 6, k = e & 63;
+        sA[k * CH_LD + i] = (r0 + i < P1 && k < nb) ? S[(size_t)(r0 + i) * P + j0 + k] : 0.0;
+        sB[k * CH_LD + i] = (c0 + i < P1 && k < nb) ? S[(size_t)(c0 + i) * P + j0 + k] : 0.0;
+    }
+    __syncthreads();
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    lw_double4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = lw_double4{0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < CH_NB / 4; s4++) {
+        double av[2], bv[2];
+        const int kr = (4 * s4 + (lane >> 4)) * CH_LD + (lane & 15);
+#pragma unroll
+        for (int a = 0; a < 2; a++) { av[a] = sA[kr + wi + 16 * a]; bv[a] = sB[kr + wj + 16 * a]; }
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = r0 + wi + 16 * a + (lane >> 4) + 4 * q, col = c0 + wj + 16 * b + (lane & 15);
+                if (row < P1 && col < P && col <= row) S[(size_t)row * P + col] -= acc[a][b][q];
+            }
+}
+// L^T y = z, z = row P of the factor; one workgroup, columns right to left in 64-blocks: the block's triangle by one wave (lane = row of the block, pivots
+// broadcast through LDS), then every earlier entry subtracts its part — thread per entry, the block's 64 columns of L read along a row (coalesced)
+__global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, double *y) {
+    extern __shared__ double s_y[];                // P entries
+    __shared__ double s_blk[CH_NB], s_tri[CH_NB * CH_LD];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < P; i += 1024) s_y[i] = S[(size_t)P * P + i];
+    __syncthreads();
+    const int nblk = (P + CH_NB - 1) / CH_NB;
+    for (int bk = nblk - 1; bk >= 0; bk--) {
+        const int j0 = CH_NB * bk, nb = min(CH_NB, P - j0);
+        for (int e = tid; e < nb * CH_NB; e += 1024) { const int r = e >> 6, c = e & 63; s_tri[r * CH_LD + c] = (c < nb) ? S[(size_t)(j0 + r) * P + j0 + c] : 0.0; }
+        __syncthreads();
+        if (tid < 64) {                            // y_blk = L_bb^-T z_blk
+            double z = (tid < nb) ? s_y[j0 + tid] : 0.0;
+            for (int j = nb - 1; j >= 0; j--) {
+                const double yj = __shfl(z, j, 64) / s_tri[j * CH_LD + j];
+                if (tid < j) z -= s_tri[j * CH_LD + tid] * yj;
+                if (tid == j) z = yj;
+            }
+            if (tid < nb) { s_y[j0 + tid] = z; s_blk[tid] = z; }
+        }
+        __syncthreads();
+        for (int i = tid; i < j0; i += 1024) {     // z_i -= sum_r L[j0 + r][i] y[j0 + r]
+            double s = 0;
+            for (int r = 0; r < nb; r++) s += S[(size_t)(j0 + r) * P + i] * s_blk[r];
+            s_y[i] -= s;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < P; i += 1024) y[i] = s_y[i];
+}
+// row-wise dots y[r] = A[r][0..C) . x (one 64-lane wave per row, A row-major) and column sums y[c] += alpha sum_r A[r][c] x[r] (thread per column)
+__global__ __launch_bounds__(256) void lw_rowdot(int R, int C, const double *A, const double *x, double *y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const double *a = A + (size_t)row * C;
+    double s = 0;
+    for (int c = lane; c < C; c += 64) s += a[c] * x[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) y[row] = s;
+}
+__global__ __launch_bounds__(256) void lw_colsum(int R, int C, const double *A, const double *x, double alpha, double *y, int rsplit) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int rchunk = (R + rsplit - 1) / rsplit, ra = blockIdx.y * rchunk, rb = min(R, ra + rchunk);
+    double s = 0;
+    for (int r = ra; r < rb; r++) s += A[(size_t)r * C + c] * x[r];
+    unsafeAtomicAdd(y + c, alpha * s);
+}
+
 // ---- host-side manifold helpers (PoseLocalParameterization, utility.h) ------------------------------------------------------------
 struct HQ { double x, y, z, w; };
 inline HQ hq_mul(const HQ &a, const HQ &b) { return HQ{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z}; }
@@ -400,7 +569,6 @@ inline void h_ypr2R(const double *ypr, double *R) {
 }
 }  // namespace
 
-#define RB(call) do { if ((call) != rocblas_status_success) { h->err = "rocBLAS / rocSOLVER call failed (large-window solve)"; return VILF_ERR_DEVICE; } } while (0)
 
 // batch_slot0 != 0: the window is also resident as slot 0 of the 11-frame batch (vilf_batch_upload ran): use that slot's prior and write
 // the solved state back into the batch buffers (the marginalization reads them)
@@ -422,7 +590,6 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     HIPCHECK(h, hipSetDevice(h->device));
     if (!h->lw) h->lw = new LwCtx();
     LwCtx *c = h->lw;
-    if (!c->blas) { if (rocblas_create_handle(&c->blas) != rocblas_status_success) { h->err = "rocblas_create_handle failed"; return VILF_ERR_DEVICE; } rocblas_set_stream(c->blas, h->stream); }
     const bool prof = h->profiling != 0;
     if (prof && !c->ev[0]) { hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); }
     auto tic = [&]() { if (prof) hipEventRecord(c->ev[0], h->stream); };
@@ -489,7 +656,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     // ---- device buffers
     const size_t sP = P, sF = std::max(F, 1), sN = N;
     if (!c->x.ensure((16 * (size_t)NF + sF + 8) * 8) || !c->tdrec.ensure(std::max<size_t>(tdrec.size(), 1) * sizeof(LwTd)) || !c->pri.ensure(2 * VB_PRIOR_LD * 8) || !c->ex.ensure(7 * 8 + 64) || !c->vis.ensure(std::max<size_t>(nvis, 1) * sizeof(LwVis)) || !c->imu.ensure(imu.size() * 8) || !c->cov.ensure(cov.size() * 8) ||
-        !c->lid.ensure(lid.size() * 8) || !c->Hpp.ensure(sP * sP * 8) || !c->W.ensure(sF * sP * 8) || !c->hf.ensure(sF * 8) || !c->gp.ensure(sP * 8) || !c->gf.ensure(sF * 8) || !c->S.ensure(sP * sP * 8) ||
+        !c->lid.ensure(lid.size() * 8) || !c->Hpp.ensure(sP * sP * 8) || !c->W.ensure(sF * sP * 8) || !c->hf.ensure(sF * 8) || !c->gp.ensure(sP * 8) || !c->gf.ensure(sF * 8) || !c->S.ensure((sP + 1) * sP * 8) ||
         !c->Wn.ensure(sF * sP * 8) || !c->rhs.ensure(sP * 8) || !c->tmpP.ensure(sP * 8) || !c->tmpF.ensure(sF * 8) || !c->vec.ensure(2 * sN * 8) || !c->scal.ensure(256) || !c->info.ensure(64) ||
         !c->fconst.ensure(sF) || !c->den.ensure(sF * 8) || !c->jscr.ensure((size_t)nimu * 480 * 8)) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
     double geo[7 + 3 + 4];
@@ -614,10 +781,9 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     };
     // x^T H x with the (scaled) blocks on the device: returns v_p^T Hpp v_p + 2 sum_f v_f (W_f . v_p) + sum_f h_f v_f^2 and keeps Hpp v_p / W v_p
     auto quad = [&](const std::vector<double> &vv, double &q) -> int {
-        const double one = 1.0, zero = 0.0;
         HIPCHECK(h, hipMemcpyAsync(c->vec.p, vv.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
-        RB(rocblas_dgemv(c->blas, rocblas_operation_none, P, P, &one, c->Hpp.as<double>(), P, c->vec.as<double>(), 1, &zero, c->tmpP.as<double>(), 1));
-        if (F) RB(rocblas_dgemv(c->blas, rocblas_operation_transpose, P, F, &one, c->W.as<double>(), P, c->vec.as<double>(), 1, &zero, c->tmpF.as<double>(), 1));
+        hipLaunchKernelGGL(lw_rowdot, dim3((P + 3) / 4), dim3(256), 0, h->stream, P, P, c->Hpp.as<double>(), c->vec.as<double>(), c->tmpP.as<double>());          // Hpp v_p
+        if (F) hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->vec.as<double>(), c->tmpF.as<double>());    // W_f . v_p
         HIPCHECK(h, hipMemcpyAsync(tP.data(), c->tmpP.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
         if (F) HIPCHECK(h, hipMemcpyAsync(tF.data(), c->tmpF.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -647,36 +813,40 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     };
     // ---- the linear solve: (H' + lm^2) y = g'
     auto linear_solve = [&](bool &ok) -> int {
-        const double one = 1.0, mone = -1.0;
         ok = false;
         for (int f = 0; f < F; f++) if (!in->feature_const[f] && !(hfh[f] + lm[P + f] * lm[P + f] > 0.0)) return VILF_OK;
         HIPCHECK(h, hipMemcpyAsync(c->vec.p, lm.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
         const size_t tot = sP * sP + (size_t)F * sP + F;
         hipLaunchKernelGGL(lw_schur_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gf.as<double>(), c->vec.as<double>(),
                            c->fconst.as<unsigned char>(), c->S.as<double>(), c->Wn.as<double>(), c->den.as<double>(), c->tmpF.as<double>());
-        HIPCHECK(h, hipMemcpyAsync(c->rhs.p, c->gp.p, sP * 8, hipMemcpyDeviceToDevice, h->stream));
+        double *rhs_row = c->S.as<double>() + sP * sP;                    // the right-hand side rides as row P of S: after the factorisation it holds L^-1 rhs
+        HIPCHECK(h, hipMemcpyAsync(rhs_row, c->gp.p, sP * 8, hipMemcpyDeviceToDevice, h->stream));
         if (F) {
-            // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P == column-major P x F), rhs -= Wn^T (g_f / sqrt(den))
+            // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P), rhs -= Wn^T (g_f / sqrt(den))
             tic();
             {
                 const int nt = (P + 63) / 64, ksplit = 4;
                 hipLaunchKernelGGL(lw_syrk_mfma, dim3(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, P, F, c->Wn.as<double>(), c->S.as<double>(), ksplit);
             }
             toc(1);
-            RB(rocblas_dgemv(c->blas, rocblas_operation_none, P, F, &mone, c->Wn.as<double>(), P, c->tmpF.as<double>(), 1, &one, c->rhs.as<double>(), 1));
+            hipLaunchKernelGGL(lw_colsum, dim3((P + 255) / 256, 16), dim3(256), 0, h->stream, F, P, c->Wn.as<double>(), c->tmpF.as<double>(), -1.0, rhs_row, 16);
         }
-        rocblas_int *dinfo = c->info.as<rocblas_int>();
+        int *dinfo = c->info.as<int>();
         tic();
-        RB(rocsolver_dpotrf(c->blas, rocblas_fill_lower, P, c->S.as<double>(), P, dinfo));
+        HIPCHECK(h, hipMemsetAsync(dinfo, 0, 4, h->stream));
+        for (int j0 = 0; j0 < P; j0 += CH_NB) {                          // blocked Cholesky, two launches per 64-column block
+            const int nb = std::min(CH_NB, P - j0), below = P + 1 - (j0 + nb);
+            hipLaunchKernelGGL(lw_chol_panel, dim3(std::max(1, (below + CH_BELOW - 1) / CH_BELOW)), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, dinfo);
+            if (j0 + nb < P) { const int nt = (below + 63) / 64; hipLaunchKernelGGL(lw_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, nb); }
+        }
+        hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), sP * 8, h->stream, P, c->S.as<double>(), c->rhs.as<double>());
         int info = 0;
         HIPCHECK(h, hipMemcpyAsync(&info, dinfo, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
-        if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
-        RB(rocsolver_dpotrs(c->blas, rocblas_fill_lower, P, 1, c->S.as<double>(), P, c->rhs.as<double>(), P));
         toc(2);
+        if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
         if (F) {
-            const double zero = 0.0;
-            RB(rocblas_dgemv(c->blas, rocblas_operation_transpose, P, F, &one, c->W.as<double>(), P, c->rhs.as<double>(), 1, &zero, c->tmpF.as<double>(), 1));
+            hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->rhs.as<double>(), c->tmpF.as<double>());       // W_f . y_p
             hipLaunchKernelGGL(lw_feature_back, dim3((F + 255) / 256), dim3(256), 0, h->stream, F, c->gf.as<double>(), c->tmpF.as<double>(), c->den.as<double>(), c->vec.as<double>());
             HIPCHECK(h, hipMemcpyAsync(&y[P], c->vec.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
         }
