@@ -595,28 +595,28 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     auto tic = [&]() { if (prof) hipEventRecord(c->ev[0], h->stream); };
     auto toc = [&](int grp) { if (prof) { hipEventRecord(c->ev[1], h->stream); hipEventSynchronize(c->ev[1]); float t = 0; hipEventElapsedTime(&t, c->ev[0], c->ev[1]); c->ms[grp] += t; c->launches[grp] += 1; } };
     // ---- pack the factors
-    std::vector<LwVis> vis;
-    std::vector<int> vis_obs;                         // (first, this) observation index of every factor: the td constants follow the pair sort
+    // pair-sorted (lw_visual flushes one block per run of equal pairs): counting sort over the NF^2 pair keys, stable in feature order
+    const int nfac_in = std::max(0, in->n_obs - F);
+    std::vector<LwVis> vis(std::max(nfac_in, 1));
+    std::vector<int> vis_obs(2 * (size_t)std::max(nfac_in, 1));    // (first, this) observation index of every factor: the td constants follow the pair sort
+    std::vector<int> pair_cnt((size_t)NF * NF + 1, 0);
     for (int f = 0; f < F; f++) {
         const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
         if (s < 0 || s + (o1 - o0) > NF) { h->err = "feature track leaves the window"; return VILF_ERR_INVALID_ARGUMENT; }
+        for (int t = o0 + 1; t < o1; t++) pair_cnt[(size_t)s * NF + s + (t - o0) + 1]++;
+    }
+    for (size_t k = 1; k < pair_cnt.size(); k++) pair_cnt[k] += pair_cnt[k - 1];
+    for (int f = 0; f < F; f++) {
+        const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
         for (int t = o0 + 1; t < o1; t++) {
-            LwVis v;
-            for (int k = 0; k < 3; k++) { v.pi[k] = in->obs_point[3 * (size_t)o0 + k]; v.pj[k] = in->obs_point[3 * (size_t)t + k]; }
+            const int k = pair_cnt[(size_t)s * NF + s + (t - o0)]++;
+            LwVis &v = vis[k];
+            for (int q = 0; q < 3; q++) { v.pi[q] = in->obs_point[3 * (size_t)o0 + q]; v.pj[q] = in->obs_point[3 * (size_t)t + q]; }
             v.f = f; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
-            vis.push_back(v);
-            vis_obs.push_back(o0); vis_obs.push_back(t);
+            vis_obs[2 * (size_t)k] = o0; vis_obs[2 * (size_t)k + 1] = t;
         }
     }
-    const int nvis = (int)vis.size(), nimu = NF - 1;
-    {   // pair-sorted: lw_visual flushes one block per run of equal pairs
-        std::vector<int> ord(nvis);
-        for (int k = 0; k < nvis; k++) ord[k] = k;
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return vis[a].i * NF + vis[a].j < vis[b].i * NF + vis[b].j; });
-        std::vector<LwVis> sv(nvis); std::vector<int> so(2 * (size_t)nvis);
-        for (int k = 0; k < nvis; k++) { sv[k] = vis[ord[k]]; so[2 * k] = vis_obs[2 * ord[k]]; so[2 * k + 1] = vis_obs[2 * ord[k] + 1]; }
-        vis.swap(sv); vis_obs.swap(so);
-    }
+    const int nvis = nfac_in, nimu = NF - 1;
     std::vector<LwTd> tdrec;
     if (est_td) {                                     // projection_td_factor.cpp:6-21
         tdrec.resize(std::max(nvis, 1));
@@ -763,7 +763,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         if (jac) toc(0);
         HIPCHECK(h, hipGetLastError());
         HIPCHECK(h, hipMemcpyAsync(&cost, scal, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        if (!jac) HIPCHECK(h, hipStreamSynchronize(h->stream));         // with the Jacobians: fetch_diag_grad follows and waits once for both
         return VILF_OK;
     };
     // host copies of the (scaled) diagonal / gradient pieces
@@ -840,11 +840,9 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             if (j0 + nb < P) { const int nt = (below + 63) / 64; hipLaunchKernelGGL(lw_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, nb); }
         }
         hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), sP * 8, h->stream, P, c->S.as<double>(), c->rhs.as<double>());
-        int info = 0;
-        HIPCHECK(h, hipMemcpyAsync(&info, dinfo, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipStreamSynchronize(h->stream));
         toc(2);
-        if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
+        int info = 0;
+        HIPCHECK(h, hipMemcpyAsync(&info, dinfo, 4, hipMemcpyDeviceToHost, h->stream));      // read with the solution below: one wait per linear solve
         if (F) {
             hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->rhs.as<double>(), c->tmpF.as<double>());       // W_f . y_p
             hipLaunchKernelGGL(lw_feature_back, dim3((F + 255) / 256), dim3(256), 0, h->stream, F, c->gf.as<double>(), c->tmpF.as<double>(), c->den.as<double>(), c->vec.as<double>());
@@ -852,6 +850,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         }
         HIPCHECK(h, hipMemcpyAsync(&y[0], c->rhs.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
+        if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
         for (int f = 0; f < F; f++) if (in->feature_const[f]) y[P + f] = 0.0;
         for (double a : y) if (!std::isfinite(a)) return VILF_OK;
         ok = true;
