@@ -349,6 +349,32 @@ def main():
                   "ms_per_step": trd / 3 * 1e3, "regular_batch_same_stages": {"value": qits / tqd, "ms_per_step": tqd / 3 * 1e3}}
         rsolver.close()
 
+    # ---- PCIe-inclusive figure: host buffers in (vilf_batch_upload: pack on the host threads + H2D from pinned staging) -> solve -> host buffers out
+    # (vilf_batch_download_states), 2048 windows through ONE handle, priors resident (they are produced on the device in the running system). Never `value`.
+    pcie = None
+    if world == 1:
+        from vil_fusion_amd import abi as vabi
+        nb = min(2048, B)
+        psolver = BackendSolver(device=local_rank)
+        psolver.batch_upload(wins[:nb], priors[:nb])
+        parr = (vabi.WindowIn * nb)()
+        for i in range(nb):
+            parr[i] = wins[i].as_struct()
+        pout = psolver.batch_download_states()
+        best = None
+        for _ in range(4):
+            tp0 = time.perf_counter()
+            psolver._check(psolver._L.vilf_batch_upload(psolver._h, nb, parr), "vilf_batch_upload")
+            tp1 = time.perf_counter(); psolver.batch_solve(sync=True); tp2 = time.perf_counter()
+            psolver.batch_download_states(out=pout); tp3 = time.perf_counter()
+            pits = sum(x.num_iterations for x in pout["summaries"])
+            cur = {"value": pits / (tp3 - tp0), "unit": "iterations/s", "windows": nb, "upload_ms": 1e3 * (tp1 - tp0), "solve_ms": 1e3 * (tp2 - tp1), "download_ms": 1e3 * (tp3 - tp2),
+                   "what": "window solve only, one handle: vilf_batch_upload (pack + H2D) + vilf_batch_solve + vilf_batch_download_states"}
+            if best is None or cur["value"] > best["value"]:
+                best = cur
+        pcie = best
+        psolver.close()
+
     if rank == 0:
         abytes = float(np.mean([algorithmic_bytes_per_iteration(w, p) for w, p in zip(wins[:args.distinct], priors[:args.distinct])]))
         # algorithmic bytes per STEP (all B frames) per kernel / launch group; for the window kernels
@@ -426,6 +452,8 @@ def main():
             out["roofline_mfma"] = mfma
         if ragged is not None:
             out["ragged_batch"] = ragged
+        if pcie is not None:
+            out["pcie_inclusive"] = pcie
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))

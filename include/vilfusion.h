@@ -199,6 +199,9 @@ int vilf_batch_rewind(vilf_handle *h);
 int vilf_batch_marginalize(vilf_handle *h, int sync);
 int vilf_batch_download(vilf_handle *h, int first, int n_windows, vilf_window_out *outs);
 int vilf_batch_summaries(vilf_handle *h, int first, int n_windows, vilf_summary *sums);
+/* the estimator's outputs only (double2vector(): Ps [n][33], Rs [n][99] row-major, Vs, Bas, Bgs [n][33]) and the summaries into contiguous caller arrays;
+ * any pointer may be NULL. The per-frame caller's download: the parameter arrays stay on the device for the marginalization. */
+int vilf_batch_download_states(vilf_handle *h, int first, int n_windows, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, vilf_summary *sums);
 int vilf_synchronize(vilf_handle *h);
 /* per-kernel timing by HIP events on the handle's stream (kind 0 linearize, 1 reduce+solve, 2 step, 3 other); needs sync solves */
 int vilf_set_profiling(vilf_handle *h, int on);

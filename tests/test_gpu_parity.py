@@ -676,3 +676,16 @@ def test_malformed_inputs_are_rejected(solver, opts):
     with pytest.raises(VilfError):
         solver.set_prior(p)
     solver.set_prior(None)
+
+
+def test_state_download_equals_the_full_download(solver, opts):
+    """vilf_batch_download_states (Ps / Rs / Vs / Bas / Bgs + summaries into contiguous arrays, the per-frame download) against vilf_batch_download"""
+    wins, priors = synth.make_batch(9, 7, opts, synth.SynthConfig(n_features=60), distinct=7)
+    solver.batch_upload(wins, priors); solver.batch_solve()
+    full = solver.batch_download()
+    st = solver.batch_download_states(first=2, n=4)
+    for i in range(4):
+        r = full[2 + i]
+        assert np.array_equal(st["Ps"][i], r.Ps) and np.array_equal(st["Rs"][i], r.Rs) and np.array_equal(st["Vs"][i], r.Vs)
+        assert np.array_equal(st["Bas"][i], r.Bas) and np.array_equal(st["Bgs"][i], r.Bgs)
+        assert st["summaries"][i].num_iterations == r.summary["num_iterations"] and st["summaries"][i].final_cost == r.summary["final_cost"]

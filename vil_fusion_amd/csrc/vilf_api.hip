@@ -45,6 +45,9 @@ __global__ void k_hook_plus(const double *, const double *, int, double *);
 
 namespace {
 
+// typed spans out of one (pinned) staging allocation, 64-byte aligned
+struct Carve { char *base; size_t off = 0; template <typename T> T *take(size_t n) { off = (off + 63) & ~(size_t)63; T *r = reinterpret_cast<T *>(base + off); off += n * sizeof(T); return r; } };
+
 void quat_from_R(const double *m, double *q /*xyzw*/) {   // Eigen Quaterniond(Matrix3d)
     double t = m[0] + m[4] + m[8];
     if (t > 0) {
@@ -144,6 +147,7 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     vilf_pg_release(h);
     vilf_lw_release(h);
     for (auto &b : h->d) b.release();
+    h->pin_up.release(); h->pin_down.release();
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->pev) hipEventDestroy(e);           // profiling events (vilf_set_profiling)
@@ -318,14 +322,24 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
 
     lap("validate + device buffers");
     // ---- pack on the host ---------------------------------------------------------------------------------------
-    std::vector<int> nfeat(B), nfac(B), fstart(sB * sF, 0), fnobs(sB * sF, 2), fobs0(sB * sF, 0), ffac0(sB * sF, 0), facfeat(sB * sC, 0), facobs(sB * sC, 0),
-        pairoff(sB * (VB_NPAIR + 1), 0), psfeat(sB * sC, 0), psobs(sB * sC, 0), psslot(sB * sC, 0);
-    std::vector<uint8_t> fconst(sB * sF, 1);
-    std::vector<double> pose(sB * 77), sb(sB * 99), feat(sB * sF, 1.0), ex(sB * 7), gR0(sB * 9), gP0(sB * 3), obs(sB * sO * 3, 0.0), imu(sB * 10 * IMU_REC, 0.0),
-        lidar(sB * 10 * 7, 0.0), cov(sB * 10 * 225, 0.0), facrec(sB * sC * 8, 0.0);
+    // persistent PINNED staging carved into typed spans: allocating and zero-filling ~250 MB of std::vectors per call was half of the upload time, and copies
+    // from pageable memory are neither fast nor asynchronous. Every slice a kernel reads is rewritten by pack_one; padding is never read.
+    const bool est_td0 = h->opts.estimate_td != 0;
+    int *nfeat, *nfac, *fstart, *fnobs, *fobs0, *ffac0, *facfeat, *facobs, *pairoff, *psfeat, *psobs, *psslot;
+    uint8_t *fconst;
+    double *pose, *sb, *feat, *ex, *gR0, *gP0, *imu, *lidar, *cov, *facrec, *obsv = nullptr, *obstd = nullptr, *obsrow = nullptr;
+    auto carve_all = [&](Carve &cv) {          // the same sequence sizes the allocation (base = 0) and hands out the spans
+        nfeat = cv.take<int>(sB); nfac = cv.take<int>(sB); fstart = cv.take<int>(sB * sF); fnobs = cv.take<int>(sB * sF); fobs0 = cv.take<int>(sB * sF); ffac0 = cv.take<int>(sB * sF);
+        facfeat = cv.take<int>(sB * sC); facobs = cv.take<int>(sB * sC); pairoff = cv.take<int>(sB * (VB_NPAIR + 1)); psfeat = cv.take<int>(sB * sC); psobs = cv.take<int>(sB * sC); psslot = cv.take<int>(sB * sC);
+        fconst = cv.take<uint8_t>(sB * sF);
+        pose = cv.take<double>(sB * 77); sb = cv.take<double>(sB * 99); feat = cv.take<double>(sB * sF); ex = cv.take<double>(sB * 7); gR0 = cv.take<double>(sB * 9); gP0 = cv.take<double>(sB * 3);
+        imu = cv.take<double>(sB * 10 * IMU_REC); lidar = cv.take<double>(sB * 10 * 7); cov = cv.take<double>(sB * 10 * 225); facrec = cv.take<double>(sB * sC * 8);
+        if (est_td0) { obsv = cv.take<double>(sB * sO * 2); obstd = cv.take<double>(sB * sO); obsrow = cv.take<double>(sB * sO); }
+    };
+    { Carve sz{nullptr}; carve_all(sz); if (!h->pin_up.ensure(sz.off + 64)) { h->err = "hipHostMalloc failed (upload staging)"; return VILF_ERR_DEVICE; } }
+    { Carve cv{static_cast<char *>(h->pin_up.p)}; carve_all(cv); }
     h->h_nfeat.assign(B, 0); h->h_ex.assign(sB * 7, 0.0); h->h_td.assign(B, 0.0);
-    const bool est_any = h->opts.estimate_extrinsic || h->opts.estimate_td, est_td = h->opts.estimate_td != 0;
-    std::vector<double> obsv(est_td ? sB * sO * 2 : 0, 0.0), obstd(est_td ? sB * sO : 0, 0.0), obsrow(est_td ? sB * sO : 0, 0.0);
+    const bool est_any = h->opts.estimate_extrinsic || h->opts.estimate_td, est_td = est_td0;
     h->own.clear();
     if (est_any) h->own.resize(B);
     lap("host vectors");
@@ -340,7 +354,6 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         h->h_td[w] = in.para_td;
         if (in.gauge_R0) std::memcpy(&gR0[(size_t)w * 9], in.gauge_R0, 72); else quat_to_R(in.para_pose + 3, &gR0[(size_t)w * 9]);
         if (in.gauge_P0) std::memcpy(&gP0[(size_t)w * 3], in.gauge_P0, 24); else std::memcpy(&gP0[(size_t)w * 3], in.para_pose, 24);
-        std::memcpy(&obs[(size_t)w * sO * 3], in.obs_point, (size_t)in.n_obs * 24);
         if (est_td && in.n_obs) {
             std::memcpy(&obsv[(size_t)w * sO * 2], in.obs_velocity, (size_t)in.n_obs * 16);
             std::memcpy(&obstd[(size_t)w * sO], in.obs_cur_td, (size_t)in.n_obs * 8);
@@ -382,6 +395,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         }
         nfac[w] = fac;
         int *po = &pairoff[(size_t)w * (VB_NPAIR + 1)];
+        po[0] = 0;
         for (int p = 0; p < VB_NPAIR; p++) po[p + 1] = po[p] + pcount[p + 1];
         std::vector<int> cur(po, po + VB_NPAIR);
         for (int q = 0; q < fac; q++) {
@@ -407,7 +421,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             rec[287] = (p.sum_dt > 10.0) ? 0.0 : 1.0;                           // estimator.cpp:745
             std::memcpy(&cov[((size_t)w * 10 + k) * 225], p.covariance, 225 * 8);
             if (in.lidar) { const vilf_lidar_constraint &c = in.lidar[k + 1]; double *l = &lidar[((size_t)w * 10 + k) * 7]; for (int i = 0; i < 4; i++) l[i] = c.q[i]; for (int i = 0; i < 3; i++) l[4 + i] = c.t[i]; }
-            else lidar[((size_t)w * 10 + k) * 7 + 3] = 1.0;
+            else { double *l = &lidar[((size_t)w * 10 + k) * 7]; for (int i = 0; i < 7; i++) l[i] = (i == 3) ? 1.0 : 0.0; }
         }
     };
     {
@@ -421,22 +435,22 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     }
     lap("pack (threads)");
     auto up = [&](int id, const void *src, size_t bytes) { return hipMemcpyAsync(h->d[id].p, src, bytes, hipMemcpyHostToDevice, h->stream); };
-    HIPCHECK(h, up(D_NFEAT, nfeat.data(), sB * 4)); HIPCHECK(h, up(D_NFAC, nfac.data(), sB * 4));
-    HIPCHECK(h, up(D_POSE, pose.data(), sB * 77 * 8)); HIPCHECK(h, up(D_POSE0, pose.data(), sB * 77 * 8));
-    HIPCHECK(h, up(D_SB, sb.data(), sB * 99 * 8)); HIPCHECK(h, up(D_SB0, sb.data(), sB * 99 * 8));
-    HIPCHECK(h, up(D_FEAT, feat.data(), sB * sF * 8)); HIPCHECK(h, up(D_FEAT0, feat.data(), sB * sF * 8));
-    HIPCHECK(h, up(D_EX, ex.data(), sB * 7 * 8)); HIPCHECK(h, up(D_GR0, gR0.data(), sB * 9 * 8)); HIPCHECK(h, up(D_GP0, gP0.data(), sB * 3 * 8));
-    HIPCHECK(h, up(D_FSTART, fstart.data(), sB * sF * 4)); HIPCHECK(h, up(D_FNOBS, fnobs.data(), sB * sF * 4));
-    HIPCHECK(h, up(D_FOBS0, fobs0.data(), sB * sF * 4)); HIPCHECK(h, up(D_FFAC0, ffac0.data(), sB * sF * 4));
-    HIPCHECK(h, up(D_FCONST, fconst.data(), sB * sF)); HIPCHECK(h, up(D_OBS, obs.data(), sB * sO * 3 * 8));
-    HIPCHECK(h, up(D_PSFEAT, psfeat.data(), sB * sC * 4)); HIPCHECK(h, up(D_PSOBS, psobs.data(), sB * sC * 4)); HIPCHECK(h, up(D_PSSLOT, psslot.data(), sB * sC * 4));
-    HIPCHECK(h, up(D_PAIROFF, pairoff.data(), sB * (VB_NPAIR + 1) * 4));
-    HIPCHECK(h, up(D_FACREC, facrec.data(), sB * sC * 64));
-    HIPCHECK(h, up(D_IMU, imu.data(), sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar.data(), sB * 10 * 7 * 8));
-    HIPCHECK(h, up(D_COV, cov.data(), sB * 10 * 225 * 8));
+    HIPCHECK(h, up(D_NFEAT, nfeat, sB * 4)); HIPCHECK(h, up(D_NFAC, nfac, sB * 4));
+    HIPCHECK(h, up(D_POSE, pose, sB * 77 * 8)); HIPCHECK(h, up(D_POSE0, pose, sB * 77 * 8));
+    HIPCHECK(h, up(D_SB, sb, sB * 99 * 8)); HIPCHECK(h, up(D_SB0, sb, sB * 99 * 8));
+    HIPCHECK(h, up(D_FEAT, feat, sB * sF * 8)); HIPCHECK(h, up(D_FEAT0, feat, sB * sF * 8));
+    HIPCHECK(h, up(D_EX, ex, sB * 7 * 8)); HIPCHECK(h, up(D_GR0, gR0, sB * 9 * 8)); HIPCHECK(h, up(D_GP0, gP0, sB * 3 * 8));
+    HIPCHECK(h, up(D_FSTART, fstart, sB * sF * 4)); HIPCHECK(h, up(D_FNOBS, fnobs, sB * sF * 4));
+    HIPCHECK(h, up(D_FFAC0, ffac0, sB * sF * 4)); HIPCHECK(h, up(D_FCONST, fconst, sB * sF));
+    HIPCHECK(h, up(D_PSSLOT, psslot, sB * sC * 4));                                   // (obs points and the factor -> feature / observation maps travel inside facrec; the
+    if (est_td) { HIPCHECK(h, up(D_FOBS0, fobs0, sB * sF * 4)); HIPCHECK(h, up(D_PSOBS, psobs, sB * sC * 4)); }   //  observation indices are only needed by the td factors)
+    HIPCHECK(h, up(D_PAIROFF, pairoff, sB * (VB_NPAIR + 1) * 4));
+    HIPCHECK(h, up(D_FACREC, facrec, sB * sC * 64));
+    HIPCHECK(h, up(D_IMU, imu, sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar, sB * 10 * 7 * 8));
+    HIPCHECK(h, up(D_COV, cov, sB * 10 * 225 * 8));
     HIPCHECK(h, up(D_MFLAG, h->h_mflag.data(), sB * 4));
     HIPCHECK(h, up(D_TD, h->h_td.data(), sB * 8));
-    if (est_td) { HIPCHECK(h, up(D_OBSV, obsv.data(), sB * sO * 16)); HIPCHECK(h, up(D_OBSTD, obstd.data(), sB * sO * 8)); HIPCHECK(h, up(D_OBSROW, obsrow.data(), sB * sO * 8)); }
+    if (est_td) { HIPCHECK(h, up(D_OBSV, obsv, sB * sO * 16)); HIPCHECK(h, up(D_OBSTD, obstd, sB * sO * 8)); HIPCHECK(h, up(D_OBSROW, obsrow, sB * sO * 8)); }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     lap("H2D copies + sync");
 
@@ -481,7 +495,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     if (getenv("VILF_DEBUG_STAMPS")) { if (!h->d[D_DBG].ensure(3 * 32 * 8)) return VILF_ERR_DEVICE; hipMemset(h->d[D_DBG].p, 0, 3 * 32 * 8); b.dbg = h->d[D_DBG].as<long long>(); }
 
     HIPCHECK(h, hipMemsetAsync(h->d[D_W].p, 0, sB * sF * VB_WLD * 8, h->stream));   // W rows are zero outside the rewritten ranges
-    {   // static scatter tables of the tile assembly (same for every window): source element -> LDS offset, -1 = not stored
+    if (!h->luts_ready) {   // static scatter tables of the tile assembly (same for every window): source element -> LDS offset, -1 = not stored
         auto perm = [](int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); };
         // packed entry: bits 0..14 = LDS offset + 1 (0: element not stored, upper block triangle), bits 15..22 = row, bits 23..30 = column
         auto off1 = [](int r, int c) { const int tr = r >> 4, tc = c >> 4; if (tr < tc) return 0; return (tr * (tr + 1) / 2 + tc) * 256 + 16 * (r & 15) + ((c & 15) ^ (r & 15)) + 1; };
@@ -502,59 +516,9 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         HIPCHECK(h, hipMemcpy(h->d[D_LUTI].p, li.data(), li.size() * 4, hipMemcpyHostToDevice));
         HIPCHECK(h, hipMemcpy(h->d[D_LUTL].p, ll.data(), ll.size() * 4, hipMemcpyHostToDevice));
         HIPCHECK(h, hipMemcpy(h->d[D_LUTV].p, lv.data(), lv.size() * 4, hipMemcpyHostToDevice));
-        h->batch.lut_imu = h->d[D_LUTI].as<int>(); h->batch.lut_lid = h->d[D_LUTL].as<int>(); h->batch.lut_vis = h->d[D_LUTV].as<int>();
+        h->luts_ready = true;
     }
-    {   // gather tables of k_solve_sb (same for every window): destination entry of the LDS system -> source elements of Hpp / imuH / lidH.
-        // meta = LDS offset (14 bits) | permuted row index << 14 | permuted column index << 22; a source of -1 is absent.
-        auto meta = [](int dst, int r, int c) { return dst | (r << 14) | (c << 22); };
-        auto prow = [](int r) { return r * (r + 1) / 2; };
-        std::vector<int> la, lb, lc, ld;
-        for (int r = 0; r < VB_NPOSE; r++) for (int c = 0; c <= r; c++) {           // pose-pose: H(6A+la, 6Bf+lb), A >= Bf
-            const int A = r / 6, l1 = r % 6, Bf = c / 6, l2 = c % 6;
-            int imu0 = -1, imu1 = -1, lid0 = -1, lid1 = -1;
-            if (A == Bf) {
-                if (A >= 1) { imu0 = 900 * (A - 1) + 30 * (15 + l1) + 15 + l2; lid0 = 144 * (A - 1) + 12 * (6 + l1) + 6 + l2; }
-                if (A <= 9) { imu1 = 900 * A + 30 * l1 + l2; lid1 = 144 * A + 12 * l1 + l2; }
-            } else if (A == Bf + 1) { imu0 = 900 * Bf + 30 * (15 + l1) + l2; lid0 = 144 * Bf + 12 * (6 + l1) + l2; }
-            const int e[8] = {meta(SB_OFF_P + prow(r) + c, r, c), 36 * (A * (A + 1) / 2 + Bf) + 6 * l1 + l2, imu0, imu1, lid0, lid1, 0, 0};
-            la.insert(la.end(), e, e + 8);
-        }
-        for (int i = 0; i < 9; i++) for (int c = 0; c <= VB_NPOSE + i; c++) {      // SpeedBias[0] rows of the dense block: IMU factor 0 (rows 6 + i) + prior
-            const int r = VB_NPOSE + i;
-            int src = -1;
-            if (c < VB_NPOSE) { const int Bf = c / 6, l2 = c % 6; if (Bf <= 1) src = 30 * (6 + i) + (Bf == 0 ? l2 : 15 + l2); }
-            else src = 30 * (6 + i) + 6 + (c - VB_NPOSE);
-            lb.push_back(meta(SB_OFF_P + prow(r) + c, r, c)); lb.push_back(src);
-        }
-        for (int a = 1; a <= SB_NCH; a++) {                                         // chain: SpeedBias[a]; IMU factor a-1 holds it as rows 21.., factor a as rows 6..
-            const int ra = VB_NPOSE + 9 * a;
-            for (int i = 0; i < 9; i++) for (int j = 0; j <= i; j++) {              // D_a (lower)
-                const int e[4] = {meta(SB_OFF_D + 81 * (a - 1) + 9 * i + j, ra + i, ra + j), 900 * (a - 1) + 30 * (21 + i) + 21 + j, a <= 9 ? 900 * a + 30 * (6 + i) + 6 + j : -1, 0};
-                ld.insert(ld.end(), e, e + 4);
-            }
-            if (a <= 9) for (int i = 0; i < 9; i++) for (int j = 0; j < 9; j++) {   // E_a = H(SpeedBias[a+1], SpeedBias[a])
-                const int e[4] = {meta(SB_OFF_E + 81 * (a - 1) + 9 * i + j, ra + 9 + i, ra + j), 900 * a + 30 * (21 + i) + 6 + j, -1, 0};
-                ld.insert(ld.end(), e, e + 4);
-            }
-            for (int i = 0; i < 9; i++) {                                           // band_a: [Pose a-1 | Pose a | Pose a+1 | SpeedBias[0] (a = 1)]
-                const int dst = SB_OFF_BAND + SB_BOFF(a) + i * SB_BSTR(a);
-                for (int m = 0; m < 6; m++) {
-                    const int e0[4] = {meta(dst + m, ra + i, 6 * (a - 1) + m), 900 * (a - 1) + 30 * (21 + i) + m, -1, 0};
-                    const int e1[4] = {meta(dst + 6 + m, ra + i, 6 * a + m), 900 * (a - 1) + 30 * (21 + i) + 15 + m, a <= 9 ? 900 * a + 30 * (6 + i) + m : -1, 0};
-                    lc.insert(lc.end(), e0, e0 + 4); lc.insert(lc.end(), e1, e1 + 4);
-                    if (a <= 9) { const int e2[4] = {meta(dst + 12 + m, ra + i, 6 * (a + 1) + m), 900 * a + 30 * (6 + i) + 15 + m, -1, 0}; lc.insert(lc.end(), e2, e2 + 4); }
-                }
-                if (a == 1) for (int j = 0; j < 9; j++) { const int e3[4] = {meta(dst + 18 + j, ra + i, VB_NPOSE + j), 30 * (21 + i) + 6 + j, -1, 0}; lc.insert(lc.end(), e3, e3 + 4); }
-            }
-        }
-        if (!h->d[D_LUTSBA].ensure(la.size() * 4) || !h->d[D_LUTSBB].ensure(lb.size() * 4) || !h->d[D_LUTSBC].ensure(lc.size() * 4) || !h->d[D_LUTSBD].ensure(ld.size() * 4)) return VILF_ERR_DEVICE;
-        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBA].p, la.data(), la.size() * 4, hipMemcpyHostToDevice));
-        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBB].p, lb.data(), lb.size() * 4, hipMemcpyHostToDevice));
-        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBC].p, lc.data(), lc.size() * 4, hipMemcpyHostToDevice));
-        HIPCHECK(h, hipMemcpy(h->d[D_LUTSBD].p, ld.data(), ld.size() * 4, hipMemcpyHostToDevice));
-        h->batch.lut_sba = h->d[D_LUTSBA].as<int>(); h->batch.lut_sbb = h->d[D_LUTSBB].as<int>(); h->batch.lut_sbc = h->d[D_LUTSBC].as<int>(); h->batch.lut_sbd = h->d[D_LUTSBD].as<int>();
-        h->batch.n_sba = (int)la.size() / 8; h->batch.n_sbb = (int)lb.size() / 2; h->batch.n_sbc = (int)lc.size() / 4; h->batch.n_sbd = (int)ld.size() / 4;
-    }
+    h->batch.lut_imu = h->d[D_LUTI].as<int>(); h->batch.lut_lid = h->d[D_LUTL].as<int>(); h->batch.lut_vis = h->d[D_LUTV].as<int>();
     const int nimu = B * 10;
     hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
     HIPCHECK(h, hipGetLastError());
@@ -744,6 +708,38 @@ extern "C" int vilf_batch_download(vilf_handle *h, int first, int n, vilf_window
         quat_to_R(exw + 3, o.ric);
         o.td = h->h_td[first + i];                      // kept current by the general path (estimate_td)
         o.summary = sums[i];
+    }
+    return VILF_OK;
+}
+
+// The estimator's outputs only (double2vector(): Ps / Rs / Vs / Bas / Bgs, estimator.cpp:549-638) plus the summaries, into caller-owned contiguous arrays
+// [n][33] / [n][99] / ...: five device-to-host copies through pinned staging and one wait — what a per-frame caller needs back; the parameter arrays
+// (para_Pose, para_Feature ...) stay on the device for the marginalization. Any pointer may be NULL.
+extern "C" int vilf_batch_download_states(vilf_handle *h, int first, int n, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, vilf_summary *sums) {
+    if (!h || !h->resident || first < 0 || n < 0 || first + n > h->B) return VILF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return VILF_OK;
+    const size_t sn = n, per = 33 + 99 + 33 + 33 + 33;
+    if (!h->pin_down.ensure(sn * per * 8 + sn * sizeof(VbState) + 256)) { h->err = "hipHostMalloc failed (download staging)"; return VILF_ERR_DEVICE; }
+    double *st = static_cast<double *>(h->pin_down.p);
+    double *pP = st, *pR = pP + sn * 33, *pV = pR + sn * 99, *pA = pV + sn * 33, *pG = pA + sn * 33;
+    VbState *pS = reinterpret_cast<VbState *>(pG + sn * 33);
+    auto dn = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream); };
+    if (Ps) HIPCHECK(h, dn(pP, h->batch.out_Ps + (size_t)first * 33, sn * 33 * 8));
+    if (Rs) HIPCHECK(h, dn(pR, h->batch.out_Rs + (size_t)first * 99, sn * 99 * 8));
+    if (Vs) HIPCHECK(h, dn(pV, h->batch.out_Vs + (size_t)first * 33, sn * 33 * 8));
+    if (Bas) HIPCHECK(h, dn(pA, h->batch.out_Bas + (size_t)first * 33, sn * 33 * 8));
+    if (Bgs) HIPCHECK(h, dn(pG, h->batch.out_Bgs + (size_t)first * 33, sn * 33 * 8));
+    if (sums) HIPCHECK(h, dn(pS, h->batch.st + first, sn * sizeof(VbState)));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (Ps) std::memcpy(Ps, pP, sn * 33 * 8);
+    if (Rs) std::memcpy(Rs, pR, sn * 99 * 8);
+    if (Vs) std::memcpy(Vs, pV, sn * 33 * 8);
+    if (Bas) std::memcpy(Bas, pA, sn * 33 * 8);
+    if (Bgs) std::memcpy(Bgs, pG, sn * 33 * 8);
+    if (sums) for (int i = 0; i < n; i++) {
+        sums[i].num_iterations = pS[i].iteration; sums[i].num_successful_steps = pS[i].num_successful; sums[i].num_linear_solves = pS[i].num_linear_solves;
+        sums[i].termination = pS[i].termination; sums[i].initial_cost = pS[i].initial_cost; sums[i].final_cost = pS[i].x_cost; sums[i].final_radius = pS[i].radius;
+        sums[i].usec_solve = h->last_solve_usec;
     }
     return VILF_OK;
 }

@@ -141,8 +141,6 @@ struct VbBatch {
                             // coalesced 64-byte record instead of five dependent gathers
     const double *imu, *lidar;
     const int *lut_imu, *lut_lid, *lut_vis;   // static scatter tables: source element -> LDS tile offset (or -1)
-    const int *lut_sba, *lut_sbb, *lut_sbc, *lut_sbd;   // k_solve_sb gather tables (destination entry -> source elements): pose-pose [n][8], SpeedBias[0] rows [n][2], band [n][4], chain blocks D / E [n][4]
-    int n_sba, n_sbb, n_sbc, n_sbd;
     double *cf;             // [B][Fmax] per-feature Schur coefficient s_f / sqrt(h~_f'), then W_f . (S y)_p (k_solve_sb)
     const int *prior_hdr;
     const double *prior_x0, *prior_J, *prior_r, *prior_H, *prior_g;

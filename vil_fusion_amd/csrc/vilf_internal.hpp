@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <string>
 #include <vector>
+#include <cstring>
 #include "../../include/vilfusion.h"
 #include "vilf_batch.hpp"
 
@@ -28,8 +29,24 @@ enum {
     D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_FACW, D_HPP, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G, D_DIAGH,
     D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV,
     D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR, D_QLV, D_QLD, D_QLLOG, D_QLIT, D_QLINFO,
-    D_PAIRD, D_FACREC, D_CF, D_STAMPS, D_OBSV, D_OBSTD, D_OBSROW, D_TD, D_LUTSBA, D_LUTSBB, D_LUTSBC, D_LUTSBD, D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0,      // priors as uploaded (restored by vilf_batch_rewind after a marginalization)
+    D_PAIRD, D_FACREC, D_CF, D_STAMPS, D_OBSV, D_OBSTD, D_OBSROW, D_TD, D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0,      // priors as uploaded (restored by vilf_batch_rewind after a marginalization)
     D_COUNT
+};
+
+// pinned host staging kept across calls (vilf_batch_upload / download): no allocation, no zero fill, truly asynchronous copies
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (bytes <= cap) return true;
+        if (p) hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 8 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return false;
+        std::memset(p, 0, want);
+        cap = want;
+        return true;
+    }
+    void release() { if (p) hipHostFree(p); p = nullptr; cap = 0; }
 };
 
 struct S2B;
@@ -70,6 +87,8 @@ struct vilf_handle {
     std::vector<int> h_nfeat, h_nframes;
     std::vector<double> h_ex, h_td;
     std::vector<OwnedWindow> own;            // only with estimate_extrinsic / estimate_td
+    PinBuf pin_up, pin_down;                 // host staging of the batched upload / download
+    bool luts_ready = false;                 // static scatter / gather tables uploaded
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int profiling = 0;                       // per-kernel HIP-event timing of the solve launches
     std::vector<hipEvent_t> pev;

@@ -136,6 +136,16 @@ class BackendSolver:
             r.finish()
         return results
 
+    def batch_download_states(self, first=0, n=None, out=None):
+        """Ps / Rs / Vs / Bas / Bgs + summaries of n windows into contiguous numpy arrays (re-used when `out` is given): the per-frame download"""
+        n = self._n - first if n is None else n
+        if out is None:
+            out = dict(Ps=np.empty((n, 11, 3)), Rs=np.empty((n, 11, 3, 3)), Vs=np.empty((n, 11, 3)), Bas=np.empty((n, 11, 3)), Bgs=np.empty((n, 11, 3)), summaries=(abi.Summary * n)())
+        self._L.vilf_batch_download_states.argtypes = [C.c_void_p, C.c_int, C.c_int, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.POINTER(abi.Summary)]
+        self._check(self._L.vilf_batch_download_states(self._h, first, n, abi.dptr(out["Ps"]), abi.dptr(out["Rs"]), abi.dptr(out["Vs"]), abi.dptr(out["Bas"]), abi.dptr(out["Bgs"]), out["summaries"]),
+                    "vilf_batch_download_states")
+        return out
+
     def newest_poses_to_device(self, stamps, device_ptr):
         st = np.ascontiguousarray(stamps, dtype=np.float64)
         self._check(self._L.vilf_batch_newest_poses_device(self._h, abi.dptr(st), C.c_void_p(device_ptr)), "vilf_batch_newest_poses_device")
