@@ -45,6 +45,24 @@ __global__ void k_hook_plus(const double *, const double *, int, double *);
 
 namespace {
 
+// Frame pairs -> the four wave classes of k_linearize (longest-processing-time: pairs by falling factor count onto the lightest class, ties by pair index:
+// deterministic), start of every pair inside its class list, and the number of factor slots (whole chunks) the window needs.
+int class_plan(const vilf_window_in &in, int *cls, int *cstart, int *ccount) {
+    int pcount[VB_NPAIR] = {0};
+    for (int f = 0; f < in.n_features; f++) {
+        const int s = in.feature_start_frame[f], n = in.feature_obs_offset[f + 1] - in.feature_obs_offset[f];
+        for (int k = 1; k < n; k++) { const int j = s + k; pcount[j * (j - 1) / 2 + s]++; }
+    }
+    int order[VB_NPAIR], load[4] = {0, 0, 0, 0};
+    for (int p = 0; p < VB_NPAIR; p++) order[p] = p;
+    std::stable_sort(order, order + VB_NPAIR, [&](int a, int b) { return pcount[a] > pcount[b]; });
+    for (int k = 0; k < VB_NPAIR; k++) { const int p = order[k]; int best = 0; for (int c = 1; c < 4; c++) if (load[c] < load[best]) best = c; cls[p] = best; load[best] += pcount[p]; }
+    int pos[4] = {0, 0, 0, 0};
+    for (int p = 0; p < VB_NPAIR; p++) { cstart[p] = pos[cls[p]]; ccount[p] = pcount[p]; pos[cls[p]] += pcount[p]; }
+    const int longest = std::max(std::max(pos[0], pos[1]), std::max(pos[2], pos[3]));
+    return VB_CHUNK * std::max(1, (longest + VB_CLS - 1) / VB_CLS);
+}
+
 // typed spans out of one (pinned) staging allocation, 64-byte aligned
 struct Carve { char *base; size_t off = 0; template <typename T> T *take(size_t n) { off = (off + 63) & ~(size_t)63; T *r = reinterpret_cast<T *>(base + off); off += n * sizeof(T); return r; } };
 
@@ -285,7 +303,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             const int s = in.feature_start_frame[f], n = in.feature_obs_offset[f + 1] - in.feature_obs_offset[f];     // n >= 2 also makes the offsets increasing
             if (s < 0 || n < 2 || s + n > VB_NF) { h->err = "feature track outside the window"; return VILF_ERR_INVALID_ARGUMENT; }
         }
-        Fmax = std::max(Fmax, in.n_features); Omax = std::max(Omax, in.n_obs); FACmax = std::max(FACmax, in.n_obs - in.n_features);
+        { int c1[VB_NPAIR], c2[VB_NPAIR], c3[VB_NPAIR]; FACmax = std::max(FACmax, class_plan(in, c1, c2, c3)); }
+        Fmax = std::max(Fmax, in.n_features); Omax = std::max(Omax, in.n_obs);
     }
     Fmax = (Fmax + 3) & ~3; FACmax = (FACmax + 63) & ~63;
     h->B = B;
@@ -309,7 +328,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_NFEAT, sB * 4}, {D_NFAC, sB * 4}, {D_POSE, sB * 77 * 8}, {D_SB, sB * 99 * 8}, {D_FEAT, sB * sF * 8}, {D_CPOSE, sB * 77 * 8}, {D_CSB, sB * 99 * 8},
         {D_CFEAT, sB * sF * 8}, {D_POSE0, sB * 77 * 8}, {D_SB0, sB * 99 * 8}, {D_FEAT0, sB * sF * 8}, {D_EX, sB * 7 * 8}, {D_GR0, sB * 9 * 8}, {D_GP0, sB * 3 * 8},
         {D_FSTART, sB * sF * 4}, {D_FNOBS, sB * sF * 4}, {D_FOBS0, sB * sF * 4}, {D_FFAC0, sB * sF * 4}, {D_FCONST, sB * sF}, {D_OBS, sB * sO * 3 * 8},
-        {D_PSFEAT, sB * sC * 4}, {D_PSOBS, sB * sC * 4}, {D_PSSLOT, sB * sC * 4}, {D_PAIROFF, sB * (VB_NPAIR + 1) * 4}, {D_IMU, sB * 10 * IMU_REC * 8},
+        {D_PSFEAT, sB * sC * 4}, {D_PSOBS, sB * sC * 4}, {D_PSSLOT, sB * sC * 4}, {D_PAIROFF, sB * VB_PTAB * 4}, {D_IMU, sB * 10 * IMU_REC * 8},
         {D_LIDAR, sB * 10 * 7 * 8}, {D_PHDR, sB * VB_PRIOR_HDR * 4}, {D_PX0, sB * 24 * 9 * 8}, {D_PJ, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PR, sB * VB_PRIOR_LD * 8},
         {D_PH, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PG, sB * VB_PRIOR_LD * 8}, {D_FACW, sB * VB_FACW * sC * 8}, {D_HPP, sB * 66 * 36 * 8},
         {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
@@ -330,7 +349,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     double *pose, *sb, *feat, *ex, *gR0, *gP0, *imu, *lidar, *cov, *facrec, *obsv = nullptr, *obstd = nullptr, *obsrow = nullptr;
     auto carve_all = [&](Carve &cv) {          // the same sequence sizes the allocation (base = 0) and hands out the spans
         nfeat = cv.take<int>(sB); nfac = cv.take<int>(sB); fstart = cv.take<int>(sB * sF); fnobs = cv.take<int>(sB * sF); fobs0 = cv.take<int>(sB * sF); ffac0 = cv.take<int>(sB * sF);
-        facfeat = cv.take<int>(sB * sC); facobs = cv.take<int>(sB * sC); pairoff = cv.take<int>(sB * (VB_NPAIR + 1)); psfeat = cv.take<int>(sB * sC); psobs = cv.take<int>(sB * sC); psslot = cv.take<int>(sB * sC);
+        facfeat = cv.take<int>(sB * sC); facobs = cv.take<int>(sB * sC); pairoff = cv.take<int>(sB * VB_PTAB); psfeat = cv.take<int>(sB * sC); psobs = cv.take<int>(sB * sC); psslot = cv.take<int>(sB * sC);
         fconst = cv.take<uint8_t>(sB * sF);
         pose = cv.take<double>(sB * 77); sb = cv.take<double>(sB * 99); feat = cv.take<double>(sB * sF); ex = cv.take<double>(sB * 7); gR0 = cv.take<double>(sB * 9); gP0 = cv.take<double>(sB * 3);
         imu = cv.take<double>(sB * 10 * IMU_REC); lidar = cv.take<double>(sB * 10 * 7); cov = cv.take<double>(sB * 10 * 225); facrec = cv.take<double>(sB * sC * 8);
@@ -380,28 +399,27 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             o.in.gauge_R0 = o.gR0.empty() ? nullptr : o.gR0.data(); o.in.gauge_P0 = o.gP0.empty() ? nullptr : o.gP0.data();
         }
         int fac = 0;
-        std::vector<int> pcount(VB_NPAIR + 1, 0);
         for (int f = 0; f < F; f++) {
             const int o0 = in.feature_obs_offset[f], o1 = in.feature_obs_offset[f + 1], s = in.feature_start_frame[f];
             feat[(size_t)w * sF + f] = in.para_feature[f];
             fconst[(size_t)w * sF + f] = in.feature_const[f] ? 1 : 0;
             fstart[(size_t)w * sF + f] = s; fnobs[(size_t)w * sF + f] = o1 - o0; fobs0[(size_t)w * sF + f] = o0; ffac0[(size_t)w * sF + f] = fac;
-            for (int t = o0 + 1; t < o1; t++) {
-                facfeat[(size_t)w * sC + fac] = f; facobs[(size_t)w * sC + fac] = t;
-                const int j = s + (t - o0);
-                pcount[j * (j - 1) / 2 + s + 1]++;
-                fac++;
-            }
+            for (int t = o0 + 1; t < o1; t++) { facfeat[(size_t)w * sC + fac] = f; facobs[(size_t)w * sC + fac] = t; fac++; }
         }
-        nfac[w] = fac;
-        int *po = &pairoff[(size_t)w * (VB_NPAIR + 1)];
-        po[0] = 0;
-        for (int p = 0; p < VB_NPAIR; p++) po[p + 1] = po[p] + pcount[p + 1];
-        std::vector<int> cur(po, po + VB_NPAIR);
+        int cls[VB_NPAIR], cstart[VB_NPAIR], ccount[VB_NPAIR], cur[VB_NPAIR];
+        const int nslot = class_plan(in, cls, cstart, ccount);
+        nfac[w] = nslot;                                   // the kernels sweep slots; unused ones carry a null record
+        int *po = &pairoff[(size_t)w * VB_PTAB];
+        for (int p = 0; p < VB_NPAIR; p++) { po[2 * p] = cstart[p]; po[2 * p + 1] = ccount[p] | (cls[p] << 24); cur[p] = cstart[p]; }
+        po[2 * VB_NPAIR] = 0; po[2 * VB_NPAIR + 1] = 0;
+        {   // null records first (flag bit 17), then the factors at their slots
+            const unsigned long long nul = 1ULL << 17;
+            for (int g = 0; g < nslot; g++) { double *rec = &facrec[((size_t)w * sC + g) * 8]; for (int k = 0; k < 7; k++) rec[k] = 0.0; std::memcpy(&rec[7], &nul, 8); psslot[(size_t)w * sC + g] = 0; psobs[(size_t)w * sC + g] = 0; }
+        }
         for (int q = 0; q < fac; q++) {
             const int f = facfeat[(size_t)w * sC + q], t = facobs[(size_t)w * sC + q];
-            const int s = in.feature_start_frame[f], j = s + (t - in.feature_obs_offset[f]);
-            const int pos = cur[j * (j - 1) / 2 + s]++;
+            const int s = in.feature_start_frame[f], j = s + (t - in.feature_obs_offset[f]), p = j * (j - 1) / 2 + s;
+            const int pos = VB_SLOT(cls[p], cur[p]); cur[p]++;
             psfeat[(size_t)w * sC + pos] = f; psobs[(size_t)w * sC + pos] = t; psslot[(size_t)w * sC + pos] = q;
             double *rec = &facrec[((size_t)w * sC + pos) * 8];
             const double *pi = in.obs_point + 3 * (size_t)in.feature_obs_offset[f], *pj = in.obs_point + 3 * (size_t)t;
@@ -444,7 +462,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, up(D_FFAC0, ffac0, sB * sF * 4)); HIPCHECK(h, up(D_FCONST, fconst, sB * sF));
     HIPCHECK(h, up(D_PSSLOT, psslot, sB * sC * 4));                                   // (obs points and the factor -> feature / observation maps travel inside facrec; the
     if (est_td) { HIPCHECK(h, up(D_FOBS0, fobs0, sB * sF * 4)); HIPCHECK(h, up(D_PSOBS, psobs, sB * sC * 4)); }   //  observation indices are only needed by the td factors)
-    HIPCHECK(h, up(D_PAIROFF, pairoff, sB * (VB_NPAIR + 1) * 4));
+    HIPCHECK(h, up(D_PAIROFF, pairoff, sB * VB_PTAB * 4));
     HIPCHECK(h, up(D_FACREC, facrec, sB * sC * 64));
     HIPCHECK(h, up(D_IMU, imu, sB * 10 * IMU_REC * 8)); HIPCHECK(h, up(D_LIDAR, lidar, sB * 10 * 7 * 8));
     HIPCHECK(h, up(D_COV, cov, sB * 10 * 225 * 8));

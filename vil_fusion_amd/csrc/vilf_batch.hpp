@@ -4,9 +4,10 @@
 //   state      pose[B][11*7]  sb[B][11*9]  feat[B][Fmax]          (+ *_init copies for rewind, cand_* trial point)
 //   features   f_start/f_nobs/f_obs0/f_fac0/f_const [B][Fmax]     (CSR over observations, feature_manager order)
 //   obs        obs[B][Omax][3]                                     (feature_per_frame[k].point)
-//   factors    ps_feat/ps_obs/ps_slot [B][FACmax]                  (one per (feature, later observation), SORTED BY FRAME PAIR
-//                                                                   (i<j); ps_slot = index in feature-major order)
-//   pairs      pair_off[B][56]                                     (CSR over the pair-sorted factor list)
+//   factors    facrec / ps_obs / ps_slot [B][FACmax]               (one slot per (feature, later observation); the factors of a frame pair (i<j) are contiguous inside
+//                                                                   the list of the pair's wave class, the four class lists interleaved 56 slots at a time (VB_SLOT);
+//                                                                   unused slots carry a null record; ps_slot = index in feature-major order)
+//   pairs      pair_off[B][VB_PTAB]                                (per pair: start inside its class list, factor count, class)
 //   imu        imu[B][10][288]  (delta_*, bias jacobians, 15x15 sqrt_info precomputed once: imu_factor.h:64)
 //   lidar      lidar[B][10][7]
 //   prior      hdr[B][80] x0[B][24][9] J[B][160*160] r[B][160] H=J^T J [B][160*160] g=J^T r [B][160]
@@ -26,9 +27,13 @@
 #define VB_FACW 8           // per-factor Schur partials
 #define VB_WLD 80           // row stride of W: 66 pose columns, column 66 = g_f, 67..79 zero (5 MFMA column tiles)
 #define VB_XLD 13           // LDS row stride (doubles) of the factor chunk [Jj(6) Ji(6) r]; the MFMA operand load masks columns 13..15
-#define VB_CHUNK 224        // factors per LDS chunk (one per thread, threads 224..255 sit the evaluation out): 448 rows x 13 doubles = 46.6 KB
+#define VB_CLS 56           // factor slots per wave class in a chunk: the 55 frame pairs are dealt to the 4 waves of k_linearize by factor count (LPT), and every chunk
+                            // holds 56 slots of each class — each wave finds an equal share of MFMA rows in every chunk instead of one wave owning the chunk's big pair
+#define VB_CHUNK (4 * VB_CLS) // factor slots per LDS chunk (one per thread, threads 224..255 sit the evaluation out): 448 rows x 13 doubles = 46.6 KB
                             // -> k_linearize needs < 80 KB of LDS and two workgroups share a CU
 #define VB_LIN_LDS_DOUBLES (2 * VB_CHUNK * VB_XLD + 8)   // >= 10 * 512 (the IMU staging area that precedes the chunk loop)
+#define VB_PTAB (2 * VB_NPAIR + 2)   // per-window pair table: [2 p] = start of pair p inside its class list, [2 p + 1] = factor count | class << 24
+#define VB_SLOT(cls, x) (VB_CHUNK * ((x) / VB_CLS) + VB_CLS * (cls) + ((x) % VB_CLS))     // class-local position -> slot of the chunk-interleaved factor arrays
 #define VB_NT 256           // threads per window workgroup
 #define VB_NTILE 11         // 16x16 tiles per dimension (176 padded)
 #define VB_NPAD 176

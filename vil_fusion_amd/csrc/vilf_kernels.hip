@@ -220,7 +220,7 @@ __device__ double prior_cost_partial(const VbBatch &b, int w, const double *s_dx
 
 // pairD element of pair p, zero when the pair has no factor (unconditional load + select: a conditional load would serialise on
 // vmcnt(0); untouched slots hold garbage that never becomes an arithmetic input)
-__device__ __forceinline__ double pd_get(const double *pd, const int *s_poff, int p, int e) { const double v = pd[p * VB_PAIRD + e]; return (s_poff[p + 1] > s_poff[p]) ? v : 0.0; }
+__device__ __forceinline__ double pd_get(const double *pd, const int *s_pcn, int p, int e) { const double v = pd[p * VB_PAIRD + e]; return (s_pcn[p] > 0) ? v : 0.0; }
 
 __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the 16x16 X^T X tile -> slot in pairD (or -1)
     if (row < 6) {
@@ -249,7 +249,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     __shared__ double s_lidJ[10 * 72], s_lidr[64], s_grad[176];
     __shared__ double s_pt[VB_NPAIR * PT_LD];
     __shared__ double s_dx[VB_PRIOR_LD];
-    __shared__ int s_pcol[VB_P], s_poff[VB_NPAIR + 1];
+    __shared__ int s_pcol[VB_P], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_wl[4][VB_NPAIR + 1];     // pair table: start inside the class list, factor count; per wave the pairs of its class ([55] = how many)
     __shared__ double s_red[NT];
 
     STAMP(0, 0);
@@ -261,7 +261,15 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 
     if (tid < 77) s_pose[tid] = pose_g[tid];
     if (tid < 99) s_sb[tid] = sb_g[tid];
-    if (tid <= VB_NPAIR) s_poff[tid] = b.pair_off[(size_t)w * (VB_NPAIR + 1) + tid];
+    {   // pair table; every wave compacts the pairs of its own class (ballot + prefix count, pair order kept)
+        const int *pt = b.pair_off + (size_t)w * VB_PTAB;
+        const int pp = min(lane, VB_NPAIR - 1), v1 = pt[2 * pp + 1];
+        if (wave == 0 && lane < VB_NPAIR) { s_pst[lane] = pt[2 * lane]; s_pcn[lane] = v1 & 0xffffff; }
+        const bool mine = lane < VB_NPAIR && (v1 >> 24) == wave && (v1 & 0xffffff) > 0;
+        const unsigned long long m = __ballot(mine);
+        if (mine) s_wl[wave][__popcll(m & ((1ULL << lane) - 1ULL))] = lane;
+        if (lane == 0) s_wl[wave][VB_NPAIR] = __popcll(m);
+    }
     for (int i = tid; i < 10 * 512; i += NT) s_U[i] = 0.0;
     __syncthreads();
     if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
@@ -369,17 +377,18 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     int pe[4];
 #pragma unroll
     for (int q4 = 0; q4 < 4; q4++) pe[q4] = pair_elem((lane >> 4) + 4 * q4, lane & 15);   // C-tile register -> pairD slot (fixed per lane)
+    double4_t cacc = {0, 0, 0, 0}, cacc1 = {0, 0, 0, 0};            // the open pair of this wave's class list across chunk boundaries
     for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
         t_a = TICK();
         const int q = c0 + tid;
         double *x0 = s_X + (2 * min(tid, VB_CHUNK - 1)) * VB_XLD, *x1 = x0 + VB_XLD;
+        // one coalesced 64-byte record per factor slot (points, feature, slot, frames, const flag, null flag); only the inverse depth is a gather
+        const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)min(q, nfac - 1) * 8);
+        const double4_t ra = rp[0], rb = rp[1];
+        const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
         if (tid >= VB_CHUNK) {
-        } else if (q < nfac) {
-            // one coalesced 64-byte record per factor (points, feature, slot, frames, const flag); only the inverse depth is a gather
-            const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)q * 8);
-            const double4_t ra = rp[0], rb = rp[1];
+        } else if (q < nfac && !((ib >> 17) & 1)) {
             const double pts_i[3] = {ra[0], ra[1], ra[2]}, pts_j[3] = {ra[3], rb[0], rb[1]};
-            const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
             const int f = (int)(ia & 0xffffffffu), slot = (int)(ia >> 32), fi = (int)(ib & 0xff), fj = (int)((ib >> 8) & 0xff);
             const bool fc = ((ib >> 16) & 1) != 0;
             double r[2], Ji[12], Jj[12], Jf[2];
@@ -408,12 +417,14 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         { long long t_b = TICK(); t_eval += t_b - t_a; t_a = t_b; }
         __syncthreads();
         { long long t_b = TICK(); t_sync1 += t_b - t_a; t_a = t_b; }
-        const int cend = min(c0 + VB_CHUNK, nfac);
-        for (int p = wave; p < VB_NPAIR; p += 4) {
-            const int lo = __builtin_amdgcn_readfirstlane(max(s_poff[p], c0)), hi = __builtin_amdgcn_readfirstlane(min(s_poff[p + 1], cend));
+        const int x0c = VB_CLS * (c0 / VB_CHUNK);                              // this chunk holds the class-local positions [x0c, x0c + VB_CLS) of every class
+        for (int k = 0; k < s_wl[wave][VB_NPAIR]; k++) {                       // the pairs of this wave's class: every wave has ~ a quarter of the chunk's rows
+            const int p = __builtin_amdgcn_readfirstlane(s_wl[wave][k]);
+            const int pst = __builtin_amdgcn_readfirstlane(s_pst[p]), lo = max(pst, x0c), hi = min(pst + __builtin_amdgcn_readfirstlane(s_pcn[p]), x0c + VB_CLS);
             if (lo >= hi) continue;
-            const int r_hi = 2 * (hi - c0);
-            double4_t acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            const int r_lo = 2 * (VB_CLS * wave + lo - x0c), r_hi = 2 * (VB_CLS * wave + hi - x0c);
+            // a pair that began in an earlier chunk continues in the registers it was left in (a class list is walked in order: one open pair per wave at most)
+            double4_t acc = (pst < x0c) ? cacc : double4_t{0, 0, 0, 0}, acc1 = (pst < x0c) ? cacc1 : double4_t{0, 0, 0, 0};
             auto ld4 = [&](int r0, double *a) {         // unconditional LDS reads (clamped row), masked afterwards: no exec-masked loads
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -423,8 +434,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
                 }
             };
             double a[4], an[4];
-            ld4(2 * (lo - c0), a);
-            for (int r0 = 2 * (lo - c0); r0 < r_hi; r0 += 16) {
+            ld4(r_lo, a);
+            for (int r0 = r_lo; r0 < r_hi; r0 += 16) {
                 ld4(r0 + 16, an);                         // prefetch the next 16 rows while the 4 MFMAs below execute
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], acc1, 0, 0, 0);
@@ -433,15 +444,13 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #pragma unroll
                 for (int u = 0; u < 4; u++) a[u] = an[u];
             }
-            // pairD lives in global memory (L2): the first chunk of a pair writes, later chunks of the same pair (same wave) add
-            const bool first = __builtin_amdgcn_readfirstlane(s_poff[p]) >= c0;      // wave-uniform: most pairs live in one chunk and never read back
-            double old4[4] = {0.0, 0.0, 0.0, 0.0};
-            if (!first) {
+            // the pair's products go to pairD (global memory, L2) ONCE, when its last factor has been seen: a pair running on into the next chunk stays in
+            // registers — reading the partial sums back cost a dependent global round trip per pair and chunk (the largest part of this loop)
+            if (pst + __builtin_amdgcn_readfirstlane(s_pcn[p]) > x0c + VB_CLS) { cacc = acc; cacc1 = acc1; }
+            else {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) old4[q4] = pd[p * VB_PAIRD + max(pe[q4], 0)];
+                for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = acc[q4] + acc1[q4];
             }
-#pragma unroll
-            for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = old4[q4] + (acc[q4] + acc1[q4]);
         }
         { long long t_b = TICK(); t_mfma += t_b - t_a; t_a = t_b; }
         __syncthreads();
@@ -451,7 +460,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     STAMP(0, 5);
     // ---- visual pose-pose blocks (frame-block lower triangle) -> Hpp[66][36] ------------------------------------------
     // a pair without factors was never written: it reads as zero
-#define PD(p, e) pd_get(pd, s_poff, (p), (e))
+#define PD(p, e) pd_get(pd, s_pcn, (p), (e))
     {
         double *Hpp = b.Hpp + (size_t)w * 66 * 36;
         for (int t = tid; t < 66 * 36; t += NT) {
@@ -2115,6 +2124,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_step(VbBatch b) {
             const double4_t ra = rp[0], rb = rp[1];
             const double pts_i[3] = {ra[0], ra[1], ra[2]}, pts_j[3] = {ra[3], rb[0], rb[1]};
             const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
+            if ((ib >> 17) & 1) continue;                     // unused slot of the chunk-interleaved layout
             const int f = (int)(ia & 0xffffffffu), fi = (int)(ib & 0xff), fj = (int)((ib >> 8) & 0xff);
             double r[2];
             projection_eval_pair<false>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, pts_i, pts_j, cfeat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);

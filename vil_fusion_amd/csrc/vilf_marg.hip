@@ -84,7 +84,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
     const int w = blockIdx.x, tid = threadIdx.x;
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ex[7], s_ric[9], s_dx[VB_PRIOR_LD], s_J[15 * 32], s_r[16], s_lJ[72], s_lr[8];
     __shared__ double s_pm[10 * MG_PAIRM];
-    __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_poff[VB_NPAIR + 1];
+    __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_pcl[VB_NPAIR];     // pair table: start inside the class list, factor count, class
     __shared__ double s_td;
     int *info = g.info + (size_t)w * MG_INFO;
     const int F = b.n_feat[w];
@@ -115,7 +115,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
         const double est = 1.0 / b.feat[(size_t)w * FM + f];
         st_feat[f] = est > 0 ? 1.0 / est : 1.0 / g.init_depth;
     }
-    if (tid <= VB_NPAIR) s_poff[tid] = b.pair_off[(size_t)w * (VB_NPAIR + 1) + tid];
+    if (tid < VB_NPAIR) { const int *pt = b.pair_off + (size_t)w * VB_PTAB; const int v1 = pt[2 * tid + 1]; s_pst[tid] = pt[2 * tid]; s_pcn[tid] = v1 & 0xffffff; s_pcl[tid] = v1 >> 24; }
     __syncthreads();
     if (tid < 77) g.st_pose[(size_t)w * 77 + tid] = s_pose[tid];
     if (tid < 99) g.st_sb[(size_t)w * 99 + tid] = s_sb[tid];
@@ -263,13 +263,13 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
         // paid a chain of three dependent gathers per factor to find them), everything a factor needs in its one 64-byte record
         int ntot = 0;
 #pragma unroll
-        for (int jj = 0; jj < 10; jj++) ntot += s_poff[pair_index_c(0, jj + 1) + 1] - s_poff[pair_index_c(0, jj + 1)];
+        for (int jj = 0; jj < 10; jj++) ntot += s_pcn[pair_index_c(0, jj + 1)];
         for (int t = tid; t < ntot; t += NT) {
             int rem = t, q = -1;
 #pragma unroll
             for (int jj = 0; jj < 10; jj++) {
-                const int a0 = s_poff[pair_index_c(0, jj + 1)], nseg = s_poff[pair_index_c(0, jj + 1) + 1] - a0;
-                if (q < 0) { if (rem < nseg) q = a0 + rem; else rem -= nseg; }
+                const int pj = pair_index_c(0, jj + 1), nseg = s_pcn[pj];
+                if (q < 0) { if (rem < nseg) q = VB_SLOT(s_pcl[pj], s_pst[pj] + rem); else rem -= nseg; }
             }
             const double *rec = b.facrec + ((size_t)w * FC + q) * 8;
             double pts_i[3], pts_j[3];
@@ -306,11 +306,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
         const int cu0 = (u < 18) ? (12 * (u / 6) + (u % 6)) : (u == 18 ? 40 : 38), cu1 = (u < 18) ? cu0 + 6 : cu0 + 1;
         const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : (v == 18 ? 40 : 38), cv1 = (v < 18) ? cv0 + 6 : cv0 + 1;
         for (int jj = 0; jj < 10; jj++) {
-            const int p = pair_index_c(0, jj + 1), q0 = s_poff[p], q1 = s_poff[p + 1];
+            const int p = pair_index_c(0, jj + 1), q0 = s_pst[p], q1 = q0 + s_pcn[p], pcl = s_pcl[p];
             double sum = 0;
             for (int c0 = q0; c0 < q1; c0 += MG_GCH) {
                 const int nr = min(MG_GCH, q1 - c0);
-                for (int idx = tid; idx < nr * MG_MROW; idx += NT) { const int r = idx / MG_MROW, comp = idx - MG_MROW * r; s_rows[idx] = Mb[(size_t)ps_slot[c0 + r] * MG_MROW + comp]; }
+                for (int idx = tid; idx < nr * MG_MROW; idx += NT) { const int r = idx / MG_MROW, comp = idx - MG_MROW * r; s_rows[idx] = Mb[(size_t)ps_slot[VB_SLOT(pcl, c0 + r)] * MG_MROW + comp]; }
                 __syncthreads();
                 if (tid < 210) for (int r = 0; r < nr; r++) { const double *row = s_rows + r * MG_MROW; sum += row[cu0] * row[cv0] + row[cu1] * row[cv1]; }
                 __syncthreads();
@@ -373,7 +373,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             bool any = false;
             for (int jj = 0; jj < 10; jj++) {
                 const int oj = s_off_pose[jj + 1];
-                if (s_poff[pair_index_c(0, jj + 1) + 1] == s_poff[pair_index_c(0, jj + 1)]) continue;
+                if (s_pcn[pair_index_c(0, jj + 1)] == 0) continue;
                 auto xcol = [&](int d) -> int { if (d >= o0 && d < o0 + 6) return d - o0; if (oj >= 0 && d >= oj && d < oj + 6) return 6 + d - oj; if (oex >= 0 && d >= oex && d < oex + 6) return 12 + d - oex; if (otd >= 0 && d == otd) return 18; return -1; };
                 const int u = xcol(du), v = (dv == nd) ? 19 : xcol(dv);
                 if (u < 0 || v < 0) continue;
