@@ -746,6 +746,7 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
         }
     }
 }
+#define KNN_FL 8            // candidates in flight per lane and round
 // exact 5-NN within the 3 x 3 bucket block: pos[] = positions in the bucket-sorted array, ordered by (squared distance, original index)
 __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, float qy, float qz, int pos[5], float d2[5]) {
     int oid[5];
@@ -770,12 +771,12 @@ __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, flo
 #pragma unroll
     for (int sp = 0; sp < 9; sp++) {
         if (sp >= nspan) break;
-        for (int j0 = st[sp]; j0 < en[sp]; j0 += 4) {
-            float4 m4[4];
+        for (int j0 = st[sp]; j0 < en[sp]; j0 += KNN_FL) {
+            float4 m4[KNN_FL];
 #pragma unroll
-            for (int u = 0; u < 4; u++) m4[u] = sorted[min(j0 + u, en[sp] - 1)];
+            for (int u = 0; u < KNN_FL; u++) m4[u] = sorted[min(j0 + u, en[sp] - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < KNN_FL; u++) {
                 if (j0 + u >= en[sp]) break;
                 const float4 m = m4[u];
                 const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
