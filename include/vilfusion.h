@@ -108,10 +108,10 @@ typedef struct vilf_window_in {
     int n_frames;                         /* options.window_size + 1. 11 = the reference's WINDOW_SIZE: batched LDS kernels; any other size: the general
                                              single-window path (vilf_window_solve only; no prior, no marginalization) — BASELINE configs[4].
                                              options.estimate_extrinsic / estimate_td (para_ex_pose / para_td become variables; obs_velocity,
-                                             obs_cur_td, obs_row required for td): vilf_window_solve only, through the same general path, at any
-                                             window size; an 11-frame window keeps its prior and vilf_window_marginalize() (estimate_extrinsic;
-                                             with estimate_td the marginalization returns VILF_ERR_UNSUPPORTED). The batched calls return
-                                             VILF_ERR_UNSUPPORTED when either option is set. */
+                                             obs_cur_td, obs_row required for td): solved through the same general path at any window size, by
+                                             vilf_window_solve and, window by window, by vilf_batch_solve; an 11-frame window keeps its device
+                                             prior, and vilf_window_marginalize() / vilf_batch_marginalize() carry Ex_Pose and Td as kept blocks
+                                             of it (ProjectionTdFactor rows when estimate_td is set). */
     const double *para_pose;              /* [n_frames][7] */
     const double *para_speed_bias;        /* [n_frames][9] */
     double para_ex_pose[7];

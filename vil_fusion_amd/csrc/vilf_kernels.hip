@@ -1157,15 +1157,17 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
 //   P1/P2  wave 3   : gathers the chain blocks D_a, E_a, then the block-tridiagonal Cholesky, newest block first:
 //                     L_a = chol(D_a), B_a = L_a^-1 E_(a-1), D_(a-1) -= B_a^T B_a                      (the longest dependent chain of the kernel)
 //          waves 0-2: gather assembly of the dense block and the band — one thread per DESTINATION entry sums its <= 6 source elements in a fixed order
-//                     (host-built tables lut_sb*), scales, adds the LM term and stores: no atomics, no zero fill; v^T H~ v of the Cauchy point rides along —
+//                     (the source index of every entry is arithmetic in the thread id; raw buffer loads, out of range = 0), scales, adds the LM term and stores: no atomics, no zero fill; v^T H~ v of the Cauchy point rides along —
 //                     then the MFMA Schur reduce of the inverse depths, K split over the three waves (15 lower 16x16 tiles of the 80-wide dense block each)
-//   P2b    the three partial U^T U are subtracted in wave order; M_a = L_a^-1 and N_a = M_a B_(a+1)^T replace L_a / B_(a+1): every later use of the chain is
-//          a product, not a substitution
-//   P3     for a = 10..1: Y_a = M_a band_a - N_a Y_(a+1): wave 3 forms M_a band_a (VALU, 28 columns), waves 0-2 N_a Y_(a+1) on the MFMA (Y_(a+1) is already
-//          in their operand registers), then Y_a^T Y_a into 5 tile accumulators per wave (rhs as column 75)
-//   P4     dense -= Y^T Y
-//   P5     Cholesky of the 75 + 1 dense rows: 4 x 4 register blocks, one thread per block of the lower triangle, ONE barrier per 4-column panel (the panel
-//          is broadcast through LDS; every thread factors the 4 x 4 diagonal block itself and solves its own row / column strips)
+//   P2b    the three partial U^T U are subtracted in wave order (fixed summation order); M_a = L_a^-1 and N_a = M_a B_(a+1)^T replace L_a / B_(a+1): every
+//          later use of the chain is a product, not a substitution
+//   P3     for a = 10..1: Y_a = M_a band_a - N_a Y_(a+1), all four waves, each owning a 16-column strip of the 76 band columns: the D layout of the fp64
+//          16x16x4 MFMA (element q <-> row (lane>>4)+4q, column lane&15) IS the B-operand layout of the next product, so Y_(a+1) never leaves the
+//          registers and the recurrence needs no barrier; Y_a^T Y_a accumulates into the wave's tiles of the dense block (rhs as row 75, Cauchy row 76)
+//   P4     dense -= Y^T Y (batched read-subtract-write of the wave's tiles)
+//   P5     Cholesky of the 75 + 2 dense rows with the trailing matrix resident in MFMA accumulator tiles: per 4-column panel the panel is extracted
+//          to LDS, one thread per row factors the 4 x 4 diagonal block redundantly and solves its own strip, and the rank-4 update is ONE MFMA per
+//          tile; the inverted diagonal blocks are kept for P6
 //   P6     wave 0: block back substitution of the dense part, then the chain: u_a = M_a r_a - N_a u_(a+1), w_(a+1) = u_(a+1) - N_a^T w_a, x_a = M_a^T w_a;
 //          waves 1-3: W_f . (S y)_p of every feature meanwhile
 //   P7     feature back-substitution, Gauss-Newton step, dogleg scalars (as k_solve)

@@ -7,8 +7,10 @@
 //                                   Hpp (P x P), W (F x P, one row per feature), h_f, g_f, g_p
 //   lw_scale, lw_schur_prep         Jacobi scaling; LM-regularised reduced system and the row-scaled W for the Schur product
 //   lw_syrk_mfma                    S = Hpp' + mu D^2 - Wn^T Wn: the Schur reduce as a hand-written fp64 MFMA SYRK (2 F P^2 = 2.9 GFLOP per solve)
-//   rocBLAS dgemv                   matrix-vector products
-//   rocSOLVER dpotrf / dpotrs       dense Cholesky of the reduced system
+//   lw_rowdot / lw_colsum           matrix-vector products (W v per feature row, W^T v per column)
+//   lw_chol_panel / lw_chol_update  own blocked Cholesky of the reduced system: a 64-column panel factored by one workgroup (diagonal block in
+//                                   LDS, the slab below as 16 x 4 fp64 MFMA tiles), then the trailing SYRK update as MFMA tiles over the grid;
+//   lw_chol_back                    forward / back substitution with the triangle staged through LDS. No rocSOLVER / rocBLAS on this path.
 // and keeps the trust-region logic (Ceres 2.0 TrustRegionMinimizer + traditional dogleg + Jacobi scaling, the same restatement as
 // k_solve / k_step) on the host: per iteration only vectors of P + F doubles cross PCIe.
 // The same path runs the solves the batched LDS kernels do not cover at ANY window size: estimate_extrinsic (Ex_Pose a variable: six more
