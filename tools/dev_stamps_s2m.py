@@ -1,0 +1,21 @@
+# phase stamps of the scan-to-map kernels (diagnostic build: tools/dev_stamps_s2m.sh). One mid-grid workgroup of each launch, cycles.
+import sys, json, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np
+import bench
+sys.argv = [sys.argv[0], "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ragged-windows", "0", "--no-marginalize"]
+bench.main()
+from vil_fusion_amd import lib
+L = lib.lib()
+buf = (C.c_longlong * 256)()
+L.vilf_debug_stamps_s2m.argtypes = [C.POINTER(C.c_longlong)]
+L.vilf_debug_stamps_s2m(buf)
+a = np.array(buf[:]).reshape(8, 32)
+names = {0: ("scan_voxel<24> (surf cloud)", ["bbox", "keys", "radix sort", "heads+centroids"]), 1: ("scan_voxel<32> (edge cloud)", ["bbox", "keys", "radix sort", "heads+centroids"]),
+         2: ("bucket_index surf", ["zero", "count pass", "wait", "scan", "scatter pass", "wait"]), 3: ("bucket_index edge", ["zero", "count pass", "wait", "scan", "scatter pass", "wait"]),
+         4: ("map_update surf", ["tail sort", "sweep", "queued", "beyond"]), 5: ("map_update edge", ["tail sort", "sweep", "queued", "beyond"])}
+for k, (nm, ph) in names.items():
+    v = a[k]
+    st = [int(x) for x in v[:len(ph) + 1]]
+    if st[0] == 0: continue
+    print(nm, "n", int(v[30]), "aux", int(v[31]), int(v[29]), int(v[28]), "total", st[-1] - st[0], {p: st[i + 1] - st[i] for i, p in enumerate(ph)})

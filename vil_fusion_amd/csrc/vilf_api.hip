@@ -27,6 +27,7 @@ __global__ void k_step(VbBatch b);
 __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
 __global__ void k_marg_prepare(VbBatch b, VbMarg g);
+__global__ void k_marg_prepare_td(VbBatch b, VbMarg g);
 __global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
 __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged);
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
@@ -841,7 +842,8 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     const bool prof = h->profiling != 0 && sync;
     if (prof) while (h->pev.size() < 5) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
     if (prof) hipEventRecord(h->pev[0], h->stream);
-    hipLaunchKernelGGL(k_marg_prepare, grid, block, 0, h->stream, h->batch, g);
+    if (h->batch.est_td) hipLaunchKernelGGL(k_marg_prepare_td, grid, block, 0, h->stream, h->batch, g);
+    else hipLaunchKernelGGL(k_marg_prepare, grid, block, 0, h->stream, h->batch, g);
     if (prof) hipEventRecord(h->pev[1], h->stream);
     hipLaunchKernelGGL(k_marg_schur, grid, block, (size_t)(MG_MD * MG_MD + MG_MD * (MG_NK + 1) + 1000 + VB_NT) * sizeof(double), h->stream, h->batch, g,
                        std::getenv("VILF_MARG_FORCE_EXACT") ? 2 : 0);      // test hook: exercise the Jacobi path on well-conditioned windows too

@@ -80,7 +80,9 @@ __device__ int jacobi_eig(double *A, int M, int ld, double *V, double *rotlog, d
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMarg g) {
+// TD = estimate_td: the ProjectionTdFactor evaluation costs 100+ VGPRs more than ProjectionFactor; compiled apart so that the KITTI case keeps two workgroups per CU.
+template <bool TD>
+__device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg &g) {
     const int w = blockIdx.x, tid = threadIdx.x;
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ex[7], s_ric[9], s_dx[VB_PRIOR_LD], s_J[15 * 32], s_r[16], s_lJ[72], s_lr[8];
     __shared__ double s_pm[10 * MG_PAIRM];
@@ -163,7 +165,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             mf = s_mf;                                                                   // features observed from frame 0 (:921-950)
             for (int j = 1; j < s_maxobs && j < VB_NF; j++) present[j] = true;
             if (mf > 0) present[2 * VB_NF] = true;
-            if (mf > 0 && b.est_td) present[2 * VB_NF + 1] = true;                      // para_Td of the ProjectionTdFactors (estimator.cpp:930-935)
+            if (mf > 0 && TD) present[2 * VB_NF + 1] = true;                      // para_Td of the ProjectionTdFactors (estimator.cpp:930-935)
         } else {             // MARGIN_SECOND_NEW: only the prior, drop Pose[WINDOW_SIZE-1] (:986-1003)
             if (!have_prior || !present[VB_NF - 2]) status = 2;                          // nothing to do: prior stays as it is
             drop[VB_NF - 2] = true;
@@ -278,7 +280,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
             const long long ra = __double_as_longlong(rec[6]), rb = __double_as_longlong(rec[7]);
             const int f = (int)(ra & 0xffffffffll), slot = (int)(ra >> 32), fj = (int)((rb >> 8) & 255);
             double r[2], Ji[12], Jj[12], Jf[2], Jex[12], Jtd[2] = {0.0, 0.0};
-            if (b.est_td) {         // ProjectionTdFactor (estimator.cpp:930-935): the observations shifted by the pixel velocity over td (+ rolling-shutter row time)
+            if (TD) {         // ProjectionTdFactor (estimator.cpp:930-935): the observations shifted by the pixel velocity over td (+ rolling-shutter row time)
                 const int oj = b.ps_obs[(size_t)w * FC + q], oi = b.f_obs0[(size_t)w * FM + f];
                 const double *vi = b.obs_vel + ((size_t)w * b.Omax + oi) * 2, *vj = b.obs_vel + ((size_t)w * b.Omax + oj) * 2;
                 projection_td_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, vi, vj, s_td, b.obs_ctd[(size_t)w * b.Omax + oi], b.obs_ctd[(size_t)w * b.Omax + oj],
@@ -416,6 +418,9 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare(VbBatch b, VbMar
 #define MG_LDS_DOUBLES (MG_MLDS * MG_MLDS)
 // launched twice: exact == 0 runs the arrow fast path in ~30 KB of LDS (five workgroups per CU) and flags the windows whose guard
 // fails (info[7] = 1); exact == 1 runs the Jacobi path, with the full-size LDS allocation, for the flagged windows only.
+extern "C" __global__ __launch_bounds__(NT, 2) void k_marg_prepare(VbBatch b, VbMarg g) { marg_prepare_body<false>(b, g); }
+extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare_td(VbBatch b, VbMarg g) { marg_prepare_body<true>(b, g); }
+
 extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg g, int exact) {
     const int w = blockIdx.x, tid = threadIdx.x;
     int *info = g.info + (size_t)w * MG_INFO;

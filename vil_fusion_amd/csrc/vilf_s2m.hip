@@ -25,6 +25,17 @@
 #include "vilf_internal.hpp"
 #include "vilf_device.hpp"
 
+// In-kernel phase stamps: diagnostic build only (make HIPFLAGS+=-DVILF_STAMPS); workgroup S2M_STAMP_WG of a launch writes them, and only when
+// its stream is a big one (the short launches of a size class would overwrite the interesting ones otherwise).
+#ifdef VILF_STAMPS
+__device__ long long s2m_dbg[8 * 32];
+#define S2M_STAMP_WG 1500
+#define S2M_STAMP(kid, i, cond) do { if (blockIdx.x == S2M_STAMP_WG && threadIdx.x == 0 && (cond)) s2m_dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int vilf_debug_stamps_s2m(long long *out256) { return hipMemcpyFromSymbol(out256, HIP_SYMBOL(s2m_dbg), sizeof(long long) * 8 * 32) == hipSuccess ? 0 : -1; }
+#else
+#define S2M_STAMP(kid, i, cond) do { } while (0)
+#endif
+
 using namespace vd;
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
     const float4 *p = in.p + (size_t)sid * in.cap;
     float4 *o = out.p + (size_t)sid * out.cap;
     if (n <= 0) { if (tid == 0) out.n[sid] = 0; return; }
+    S2M_STAMP(K24 ? 0 : 1, 0, true);
     // ---- A. bounding box
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = tid; i < n; i += SV_T) {
@@ -264,6 +276,7 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
         if (shift == 16) return s_hi[idx];
         return (int)(key_of(p[idx]) >> 24);
     };
+    S2M_STAMP(K24 ? 0 : 1, 1, true);
     // ---- B. keys, index array = identity
     for (int i = tid; i < n; i += SV_T) {
         const unsigned int k = key_of(p[i]);
@@ -271,6 +284,7 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
         s_a[i] = (unsigned short)i;
     }
     __syncthreads();
+    S2M_STAMP(K24 ? 0 : 1, 2, true);
     // ---- C. stable LSD radix sort of the indices by key, 8 bits per pass
     unsigned short *src = s_a, *dst = s_b;
     const int seg = (n + 15) >> 4, lo = wave * seg, hi = min(n, lo + seg);
@@ -316,12 +330,16 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
         __syncthreads();
         unsigned short *t = src; src = dst; dst = t;
     }
+    S2M_STAMP(K24 ? 0 : 1, 3, true);
     // ---- D. run heads, output ranks (two sorted positions per lane and tile), centroids in index order. The tile's points and keys are staged
     // in LDS (the index buffer the sort no longer needs, the counter array): a leaf with dozens of points — dense near-range ground — is then
     // summed from LDS by its head lane instead of through a chain of dependent global gathers that the whole workgroup would wait for.
     float4 *s_tq = (cap * 2 >= 2 * SV_T * 16) ? reinterpret_cast<float4 *>(dst) : reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(s_cnt) + 8192);
     unsigned int *s_tk = reinterpret_cast<unsigned int *>(s_cnt);
-    int carry = 0;
+    __shared__ float s_open_f[2][4];
+    __shared__ int s_open_i[2][4];                 // valid, points so far, leaf key, output slot
+    if (tid == 0) s_open_i[0][0] = 0;
+    int carry = 0, par = 0;
     float4 qn[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) qn[u] = p[src[min(u * SV_T + tid, n - 1)]];
@@ -345,7 +363,33 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
 #pragma unroll
         for (int u = 0; u < 2; u++) { s_tq[u * SV_T + tid] = q0[u]; s_tk[u * SV_T + tid] = key[u]; }
         if (lane == 63) { s_w2[0][wave] = incl[0]; s_w2[1][wave] = incl[1]; }
+        if (tid == 0) s_open_i[par ^ 1][0] = 0;
         __syncthreads();
+        // the leaf left open by the previous tile (its run reached the tile end): thread 0 — element 0 cannot be a head then — adds this tile's leading points of the
+        // same leaf in index order and closes it, or hands it on when the whole tile belongs to it. No dependent global gathers: the continuation is read from LDS.
+        if (tid == 0 && s_open_i[par][0]) {
+            float cx = s_open_f[par][0], cy = s_open_f[par][1], cz = s_open_f[par][2], ci = s_open_f[par][3];
+            int len = s_open_i[par][1], m0 = 0;
+            const unsigned int okey = (unsigned int)s_open_i[par][2];
+            for (bool more = true; more;) {
+                unsigned int kk[8]; float4 qq[8];
+#pragma unroll
+                for (int v = 0; v < 8; v++) { const int ix = min(m0 + v, tile_n - 1); kk[v] = s_tk[ix]; qq[v] = s_tq[ix]; }
+                int m = 0;
+#pragma unroll
+                for (int v = 0; v < 8; v++) if (m == v && m0 + v < tile_n && kk[v] == okey) { cx = __fadd_rn(cx, qq[v].x); cy = __fadd_rn(cy, qq[v].y); cz = __fadd_rn(cz, qq[v].z); ci = __fadd_rn(ci, qq[v].w); m++; }
+                m0 += m;
+                more = m == 8;
+            }
+            len += m0;
+            if (m0 == tile_n && t0 + tile_n < n) {
+                s_open_f[par ^ 1][0] = cx; s_open_f[par ^ 1][1] = cy; s_open_f[par ^ 1][2] = cz; s_open_f[par ^ 1][3] = ci;
+                s_open_i[par ^ 1][1] = len; s_open_i[par ^ 1][2] = (int)okey; s_open_i[par ^ 1][3] = s_open_i[par][3]; s_open_i[par ^ 1][0] = 1;
+            } else {
+                const float nn = (float)len;
+                o[s_open_i[par][3]] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+            }
+        }
         int base = carry;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -356,17 +400,38 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
                 const int e = u * SV_T + tid, j = t0 + e;
                 float cx = __fadd_rn(0.0f, q0[u].x), cy = __fadd_rn(0.0f, q0[u].y), cz = __fadd_rn(0.0f, q0[u].z), ci = __fadd_rn(0.0f, q0[u].w);
                 int len = 1;
-                while (e + len < tile_n && s_tk[e + len] == key[u]) { const float4 q = s_tq[e + len]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); len++; }
-                if (e + len == tile_n)          // the leaf continues past the tile: the rest comes from global memory
-                    while (j + len < n && key_at(src[j + len]) == key[u]) { const float4 q = p[src[j + len]]; cx = __fadd_rn(cx, q.x); cy = __fadd_rn(cy, q.y); cz = __fadd_rn(cz, q.z); ci = __fadd_rn(ci, q.w); len++; }
-                const float nn = (float)len;
-                o[base + off + incl[u] - 1] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+                // the sum is a serial chain in index order (as pcl accumulates it); eight keys and points are read at once so that a leaf of a hundred near-range
+                // points costs eight additions per LDS round trip instead of one
+                for (bool more = true; more;) {
+                    const int b0 = e + len;
+                    unsigned int kk[8]; float4 qq[8];
+#pragma unroll
+                    for (int v = 0; v < 8; v++) { const int ix = min(b0 + v, tile_n - 1); kk[v] = s_tk[ix]; qq[v] = s_tq[ix]; }
+                    int m = 0;
+#pragma unroll
+                    for (int v = 0; v < 8; v++) if (m == v && b0 + v < tile_n && kk[v] == key[u]) { cx = __fadd_rn(cx, qq[v].x); cy = __fadd_rn(cy, qq[v].y); cz = __fadd_rn(cz, qq[v].z); ci = __fadd_rn(ci, qq[v].w); m++; }
+                    len += m;
+                    more = m == 8;
+                }
+                const int slot = base + off + incl[u] - 1;
+                if (e + len == tile_n && j + len < n) {      // the run reaches the tile end and points remain: the leaf may continue in the next tile -> left open
+                    s_open_f[par ^ 1][0] = cx; s_open_f[par ^ 1][1] = cy; s_open_f[par ^ 1][2] = cz; s_open_f[par ^ 1][3] = ci;
+                    s_open_i[par ^ 1][1] = len; s_open_i[par ^ 1][2] = (int)key[u]; s_open_i[par ^ 1][3] = slot; s_open_i[par ^ 1][0] = 1;
+                } else {
+                    const float nn = (float)len;
+                    o[slot] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
+                }
             }
             base += tot;
         }
+        par ^= 1;
         carry = base;
         __syncthreads();                         // the staging arrays and s_w2 are rewritten by the next tile
     }
+    S2M_STAMP(K24 ? 0 : 1, 4, true);
+#ifdef VILF_STAMPS
+    if (blockIdx.x == S2M_STAMP_WG && tid == 0) { s2m_dbg[(K24 ? 0 : 1) * 32 + 30] = n; s2m_dbg[(K24 ? 0 : 1) * 32 + 31] = vbits; }
+#endif
     if (tid == 0) out.n[sid] = carry;
 }
 
@@ -467,6 +532,8 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     box.mnx = (float)(pose[4] - half); box.mny = (float)(pose[5] - half); box.mnz = (float)(pose[6] - half);
     box.mxx = (float)(pose[4] + half); box.mxy = (float)(pose[5] + half); box.mxz = (float)(pose[6] + half);
     int bad = 0;
+    const int skid = nOld > 45000 ? 4 : 5;
+    S2M_STAMP(skid, 0, true);
 
     // ---- A. tail: crop, key, sort, points in sorted order, distinct-leaf prefix
     int P2 = 2;
@@ -517,6 +584,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     auto lower = [&](unsigned long long k) { int lo = 0, hi = ntv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T[mid] >> IDXB) < k) lo = mid + 1; else hi = mid; } return lo; };
     auto thp = [&](int j) { return j < ntv ? (int)(T[j] & LOW) : THtot; };
 
+    S2M_STAMP(skid, 1, true);
     // ---- B. sweep over the old map. Per tile: keys (+ survivor bit 63) go through LDS, so the neighbours i - 1 / i + 1 cost no global
     // load; the next tile's points are requested before this tile is processed. The common case — an old leaf that survives, alone in
     // its leaf, no tail point in it, no tail leaf between it and its predecessor — is handled inline; everything else is flagged and
@@ -525,20 +593,21 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     int *s_te = reinterpret_cast<int *>(s_key + MU_TILE);
     int *gq = gq_all + (size_t)sid * gq_stride;      // queue of uncommon points in global memory (3 ints each: index | head bit 30, H, M): room for every old point
     __shared__ int s_qn;
+    __shared__ unsigned long long s_nk;
     if (tid == 0) s_qn = 0;
     constexpr unsigned long long SVB = 1ULL << 63;
     int carryH = 0, carryM = 0, carryTE = 0;
     unsigned long long carryK = 0;
-    float4 qn[MU_E];
+    float4 qn[MU_E], qn2[MU_E];                                     // two tiles of points in flight: one tile ahead leaves the sweep waiting a memory round trip per tile
 #pragma unroll
-    for (int u = 0; u < MU_E; u++) qn[u] = p[min(u * MU_T + tid, max(nOld - 1, 0))];
+    for (int u = 0; u < MU_E; u++) { qn[u] = p[min(u * MU_T + tid, max(nOld - 1, 0))]; qn2[u] = p[min(MU_TILE + u * MU_T + tid, max(nOld - 1, 0))]; }
     for (int t0 = 0; t0 < nOld; t0 += MU_TILE) {
         float4 q[MU_E];
         unsigned long long key[MU_E];
         int tb[MU_E], flag[MU_E], incl[MU_E];
         unsigned hm = 0, fm = 0, cm = 0;                             // per-element bit masks: head, first of its run, needs mu_rare
 #pragma unroll
-        for (int u = 0; u < MU_E; u++) { q[u] = qn[u]; qn[u] = p[min(t0 + MU_TILE + u * MU_T + tid, nOld - 1)]; }
+        for (int u = 0; u < MU_E; u++) { q[u] = qn[u]; qn[u] = qn2[u]; qn2[u] = p[min(t0 + 2 * MU_TILE + u * MU_T + tid, nOld - 1)]; }
 #pragma unroll
         for (int u = 0; u < MU_E; u++) {
             const int i = t0 + u * MU_T + tid;
@@ -548,6 +617,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             s_key[u * MU_T + tid] = valid ? (key[u] | (sv ? SVB : 0ULL)) : ~0ULL;
             if (sv) hm |= 1u << u;
         }
+        if (tid == 0) { unsigned long long kx; mu_leaf<AXB>(qn[0], inv, kx); s_nk = kx; }
         __syncthreads();
         const unsigned long long lastK = s_key[MU_TILE - 1];
 #pragma unroll
@@ -556,7 +626,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             const bool valid = i < nOld, hasp = i > 0, hasn = i + 1 < nOld;
             const unsigned long long wp = e > 0 ? s_key[e - 1] : carryK;
             unsigned long long wn = e + 1 < MU_TILE ? s_key[e + 1] : 0ULL;
-            if (e + 1 == MU_TILE && hasn) { unsigned long long kx; const float4 r = p[i + 1]; mu_leaf<AXB>(r, inv, kx); wn = kx; }
+            if (e + 1 == MU_TILE && hasn) wn = s_nk;                  // the next tile's first key: from the point thread 0 already holds (a global load here made the tile's last wave wait out every prefetch in flight)
             const unsigned long long kp = wp & ~SVB, kn = wn & ~SVB;
             if (valid && hasp && kp > key[u]) bad |= S2B_ERR_ORDER;
             if (valid && (!hasp || kp != key[u])) fm |= 1u << u;
@@ -618,12 +688,14 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         carryTE = nextTE; carryK = lastK;
         __syncthreads();                                             // s_key / s_te / s_w are rewritten by the next tile
     }
+    S2M_STAMP(skid, 2, true);
     __syncthreads();
     {   // the queued points, one per lane: their dependent global loads run in parallel here instead of stalling a tile of the sweep
         const int qn = s_qn;
         for (int k = tid; k < qn; k += MU_T) mu_rare<AXB, IDXB>(gq[3 * k] & 0x3fffffff, gq[3 * k + 1], gq[3 * k + 2], (gq[3 * k] >> 30) & 1, nOld, p, o, ts, T, ntv, THtot, inv, box);
     }
     __syncthreads();
+    S2M_STAMP(skid, 3, true);
     // ---- tail leaves beyond the last old key (all of them when there is no old map)
     int jlast = 0;
     if (nOld > 0) { unsigned long long kl; mu_leaf<AXB>(p[nOld - 1], inv, kl); jlast = lower(kl + 1); }
@@ -634,6 +706,10 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         while (e < ntv && (T[e] >> IDXB) == lf) e++;
         o[carryH + thp(jj) - carryM] = mu_centroid(ts, jj, e);
     }
+    S2M_STAMP(skid, 4, true);
+#ifdef VILF_STAMPS
+    if (blockIdx.x == S2M_STAMP_WG && tid == 0) { s2m_dbg[skid * 32 + 30] = nOld; s2m_dbg[skid * 32 + 29] = nt; s2m_dbg[skid * 32 + 28] = s_qn; }
+#endif
     if (tid == 0) out.n[sid] = carryH + THtot - carryM;
     if (bad) atomicOr(err + sid, bad);
 }
@@ -652,7 +728,7 @@ __global__ void b_check_order(CSet map, float inv, int axb, int *flag) {
 }
 
 // ---- radix-hashed voxel neighbour index -----------------------------------------------------------------------------------
-// A map point hashes to a bucket by the low 8 bits of its 1 m cell coordinates in x and y: bucket = (ix & 255) << 8 | (iy & 255)
+// A map point hashes to a bucket by the low 8 bits of its 1 m cell coordinates in x and y: bucket = (iy & 255) << 8 | (ix & 255)
 // (a 16-bit radix digit; cells 256 m apart alias, z is not part of the key). The index is a single-pass counting (radix) sort of
 // the stream's points by that digit (count -> exclusive scan -> scatter), done by one workgroup per stream in LDS. A query scans the 3 x 3 buckets around its
 // own cell; every map point within 1 m lies in one of them (aliased far points are rejected by their true distance), so the
@@ -660,7 +736,10 @@ __global__ void b_check_order(CSet map, float inv, int axb, int *flag) {
 // The order inside a bucket is irrelevant: candidates are ranked by (squared distance, original map index).
 #define S2B_NB 65536
 #define S2B_NBS (S2B_NB + 4)      // row stride of start[] (keeps int4 accesses aligned)
-__device__ __forceinline__ int bucket_of(int ix, int iy) { return ((ix & 255) << 8) | (iy & 255); }    // y-minor: neighbouring points of a voxel row (x fastest) hit counters in different cache lines
+// x-minor: the map is in leaf order (z | y | x, x fastest), so consecutive input points of a voxel row fall into the same or the next bucket and their
+// scattered 16-byte stores land next to each other — the lines of the bucket-sorted copy fill up in L2 instead of leaving it as partial writes
+// (y-minor, which spares the LDS counters a few same-address atomics, spent 2/3 of the kernel in the scatter pass).
+__device__ __forceinline__ int bucket_of(int ix, int iy) { return ((iy & 255) << 8) | (ix & 255); }
 // ONE workgroup per stream builds the whole index: 16-bit bucket counters packed two per LDS word (128 KB), LDS atomics return
 // the arrival rank of a point inside its bucket, the workgroup scans the 65536 counts itself and scatters the points to
 // start[bucket] + rank. No global atomics, no separate scan / memset launches.
@@ -679,10 +758,13 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     unsigned short *rk = reinterpret_cast<unsigned short *>(bkt_all) + base;      // arrival rank of every point inside its bucket
     int *start = start_all + (size_t)sid * S2B_NBS;
     float4 *sorted = sorted_all + base;
+    const int skid = n > 45000 ? 2 : 3;
+    S2M_STAMP(skid, 0, true);
     for (int i = tid; i < S2B_HWORDS; i += S2B_IT) s_hist[i] = 0;
     if (tid == 0) s_big = 0;
     __syncthreads();
     bool over = false;
+    S2M_STAMP(skid, 1, true);
     for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {    // S2B_FL points per lane in flight
         float4 q[S2B_FL];
 #pragma unroll
@@ -700,7 +782,9 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
         }
     }
     if (over) atomicOr(err + sid, S2B_ERR_EXTENT);
+    S2M_STAMP(skid, 2, true);
     __syncthreads();
+    S2M_STAMP(skid, 3, true);
     // exclusive scan: thread t owns buckets [64 t, 64 t + 64) = words [32 t, 32 t + 32) (padded position 33 t + k)
     int local = 0;
     for (int k = 0; k < 32; k++) { const unsigned int w = s_hist[33 * tid + k]; local += (int)(w & 0xffffu) + (int)(w >> 16); }
@@ -730,6 +814,7 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     const bool big = s_big != 0;
     __threadfence_block();
     __syncthreads();
+    S2M_STAMP(skid, 4, true);
     for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {
         float4 q[S2B_FL]; unsigned short r4[S2B_FL];
 #pragma unroll
@@ -745,6 +830,12 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
             if (pos < map.cap) sorted[pos] = q[u];
         }
     }
+    S2M_STAMP(skid, 5, true);
+    __syncthreads();
+    S2M_STAMP(skid, 6, true);
+#ifdef VILF_STAMPS
+    if (blockIdx.x == S2M_STAMP_WG && tid == 0) s2m_dbg[skid * 32 + 30] = n;
+#endif
 }
 #define KNN_FL 8            // candidates in flight per lane and round
 // exact 5-NN within the 3 x 3 bucket block: pos[] = positions in the bucket-sorted array, ordered by (squared distance, original index)
@@ -753,8 +844,8 @@ __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, flo
 #pragma unroll
     for (int k = 0; k < 5; k++) { pos[k] = -1; oid[k] = 0x7fffffff; d2[k] = 3.0e38f; }
     const int cx = (int)floorf(qx), cy = (int)floorf(qy);
-    const int yl = (cy - 1) & 255, ym = cy & 255;
-    const bool one_span = yl < ym && ym < 255;           // the three y-buckets of a column are adjacent unless the digit wraps
+    const int xl = (cx - 1) & 255, xm = cx & 255;
+    const bool one_span = xl < xm && xm < 255;           // the three x-buckets of a row are adjacent unless the digit wraps
     // all span bounds first (independent loads), then the candidates four at a time (clamped, unconditional loads): the lane keeps
     // several loads in flight instead of one dependent load per candidate
     int st[9], en[9];
@@ -762,9 +853,9 @@ __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, flo
 #pragma unroll
     for (int sp = 0; sp < 9; sp++) {
         if (sp < nspan) {
-            const int dx = one_span ? sp - 1 : sp / 3 - 1, part = one_span ? 0 : sp % 3;
-            const int row = ((cx + dx) & 255) << 8;
-            const int b0 = one_span ? (row | yl) : (row | ((cy - 1 + part) & 255)), b1 = one_span ? b0 + 2 : b0;
+            const int dy = one_span ? sp - 1 : sp / 3 - 1, part = one_span ? 0 : sp % 3;
+            const int row = ((cy + dy) & 255) << 8;
+            const int b0 = one_span ? (row | xl) : (row | ((cx - 1 + part) & 255)), b1 = one_span ? b0 + 2 : b0;
             st[sp] = start[b0]; en[sp] = start[b1 + 1];
         } else { st[sp] = 0; en[sp] = 0; }
     }
