@@ -19,3 +19,4 @@ for k, (nm, ph) in names.items():
     st = [int(x) for x in v[:len(ph) + 1]]
     if st[0] == 0: continue
     print(nm, "n", int(v[30]), "aux", int(v[31]), int(v[29]), int(v[28]), "total", st[-1] - st[0], {p: st[i + 1] - st[i] for i, p in enumerate(ph)})
+    if v[16:24].any(): print("   tile-loop sums (thread 0):", [int(x) for x in v[16:24]])

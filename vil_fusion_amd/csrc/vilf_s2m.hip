@@ -32,8 +32,14 @@ __device__ long long s2m_dbg[8 * 32];
 #define S2M_STAMP_WG 1500
 #define S2M_STAMP(kid, i, cond) do { if (blockIdx.x == S2M_STAMP_WG && threadIdx.x == 0 && (cond)) s2m_dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int vilf_debug_stamps_s2m(long long *out256) { return hipMemcpyFromSymbol(out256, HIP_SYMBOL(s2m_dbg), sizeof(long long) * 8 * 32) == hipSuccess ? 0 : -1; }
+#define S2M_ACC_DECL long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long acc_last = __builtin_readcyclecounter();
+#define S2M_ACC(i) do { const long long now_ = __builtin_readcyclecounter(); acc_t[i] += now_ - acc_last; acc_last = now_; } while (0)
+#define S2M_ACC_OUT(kid) do { if (blockIdx.x == S2M_STAMP_WG && threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) s2m_dbg[(kid) * 32 + 16 + i_] = acc_t[i_]; } while (0)
 #else
 #define S2M_STAMP(kid, i, cond) do { } while (0)
+#define S2M_ACC_DECL
+#define S2M_ACC(i) do { } while (0)
+#define S2M_ACC_OUT(kid) do { } while (0)
 #endif
 
 using namespace vd;
@@ -213,6 +219,38 @@ __global__ __launch_bounds__(S2B_VT) void b_crop_compact(CSet map, const double 
 #define SV_MAXPTS32 19200              // 32-bit keys: 8 bytes of LDS per point
 #define SV_MAXPTS24 22000              // 24 stored key bits: 7 bytes per point (a wider key's top byte is recomputed from the point when needed)
 __device__ __forceinline__ int sv_bits(int v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }     // bits for values 0 .. v-1
+// c += s_tq[b], s_tq[b + 1], ... (cnt points, in this order: the serial float chain pcl's accumulation defines). The next eight points are already on their way from
+// LDS while eight are added, so a leaf of a few hundred near-range points costs a few cycles per point instead of an LDS round trip.
+#define SV_ADD4(X) _Pragma("unroll") for (int v = 0; v < 4; v++) { cx = __fadd_rn(cx, X[v].x); cy = __fadd_rn(cy, X[v].y); cz = __fadd_rn(cz, X[v].z); ci = __fadd_rn(ci, X[v].w); }
+#define SV_LD4(X, i) _Pragma("unroll") for (int v = 0; v < 4; v++) X[v] = q[4 * (i) + v];
+__device__ __forceinline__ void sv_run_sum(const float4 *s_tq, int b, int cnt, int tile_n, float &cx, float &cy, float &cz, float &ci) {
+    const int nfull = cnt >> 2;
+    if (nfull > 0) {            // full batches of four: no predication on the add chain, two batches in flight (three register sets taking turns)
+        const float4 *q = s_tq + b;
+        float4 S0[4], S1[4], S2[4];
+        SV_LD4(S0, 0)
+        if (nfull > 1) { SV_LD4(S1, 1) }
+        for (int i = 0;;) {
+            if (i + 2 < nfull) { SV_LD4(S2, i + 2) }
+            SV_ADD4(S0)
+            if (++i >= nfull) break;
+            if (i + 2 < nfull) { SV_LD4(S0, i + 2) }
+            SV_ADD4(S1)
+            if (++i >= nfull) break;
+            if (i + 2 < nfull) { SV_LD4(S1, i + 2) }
+            SV_ADD4(S2)
+            if (++i >= nfull) break;
+        }
+    }
+    const int k = nfull << 2;
+    if (k < cnt) {              // the last 1..3 points
+        float4 R[3];
+#pragma unroll
+        for (int v = 0; v < 3; v++) R[v] = s_tq[min(b + k + v, tile_n - 1)];
+#pragma unroll
+        for (int v = 0; v < 3; v++) if (k + v < cnt) { cx = __fadd_rn(cx, R[v].x); cy = __fadd_rn(cy, R[v].y); cz = __fadd_rn(cz, R[v].z); ci = __fadd_rn(ci, R[v].w); }
+    }
+}
 template <bool K24>
 __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet out, int cap, int *err) {
     extern __shared__ unsigned int sv_lds[];
@@ -335,17 +373,19 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
     // in LDS (the index buffer the sort no longer needs, the counter array): a leaf with dozens of points — dense near-range ground — is then
     // summed from LDS by its head lane instead of through a chain of dependent global gathers that the whole workgroup would wait for.
     float4 *s_tq = (cap * 2 >= 2 * SV_T * 16) ? reinterpret_cast<float4 *>(dst) : reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(s_cnt) + 8192);
-    unsigned int *s_tk = reinterpret_cast<unsigned int *>(s_cnt);
     __shared__ float s_open_f[2][4];
-    __shared__ int s_open_i[2][4];                 // valid, points so far, leaf key, output slot
+    __shared__ int s_open_i[2][4], s_fh[32];       // open leaf: valid, points so far, -, output slot; first head position of every 64-element strip of the tile
     if (tid == 0) s_open_i[0][0] = 0;
     int carry = 0, par = 0;
     float4 qn[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) qn[u] = p[src[min(u * SV_T + tid, n - 1)]];
+    S2M_ACC_DECL
     for (int t0 = 0; t0 < n; t0 += 2 * SV_T) {
+        S2M_ACC(0);
         int head[2], incl[2];
         unsigned int key[2];
+        unsigned long long hb[2];
         float4 q0[2];
         const int tile_n = min(2 * SV_T, n - t0);
 #pragma unroll
@@ -356,35 +396,31 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
             const unsigned short idx = src[jc];
             key[u] = key_at(idx);
             head[u] = (j < n && (j == 0 || key_at(src[max(jc - 1, 0)]) != key[u])) ? 1 : 0;
-            incl[u] = head[u];
-#pragma unroll
-            for (int of = 1; of < 64; of <<= 1) { const int v = __shfl_up(incl[u], of, 64); if (lane >= of) incl[u] += v; }
+            hb[u] = __ballot(head[u]);                                          // the heads of this 64-element strip: ranks and run ends come from the mask
+            incl[u] = __popcll(hb[u] & ((2ULL << lane) - 1ULL));
         }
 #pragma unroll
-        for (int u = 0; u < 2; u++) { s_tq[u * SV_T + tid] = q0[u]; s_tk[u * SV_T + tid] = key[u]; }
-        if (lane == 63) { s_w2[0][wave] = incl[0]; s_w2[1][wave] = incl[1]; }
+        for (int u = 0; u < 2; u++) s_tq[u * SV_T + tid] = q0[u];
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) { s_w2[u][wave] = __popcll(hb[u]); s_fh[u * 16 + wave] = hb[u] ? (u * 16 + wave) * 64 + __ffsll((long long)hb[u]) - 1 : 0x7fffffff; }
+        }
         if (tid == 0) s_open_i[par ^ 1][0] = 0;
+        S2M_ACC(1);
         __syncthreads();
-        // the leaf left open by the previous tile (its run reached the tile end): thread 0 — element 0 cannot be a head then — adds this tile's leading points of the
-        // same leaf in index order and closes it, or hands it on when the whole tile belongs to it. No dependent global gathers: the continuation is read from LDS.
+        S2M_ACC(2);
+        // the leaf left open by the previous tile (its run reached the tile end): thread 0 adds this tile's leading points of the same leaf — everything before the
+        // tile's first head — in index order and closes it, or hands it on when the whole tile belongs to it. No dependent global gathers, no key compares.
         if (tid == 0 && s_open_i[par][0]) {
             float cx = s_open_f[par][0], cy = s_open_f[par][1], cz = s_open_f[par][2], ci = s_open_f[par][3];
-            int len = s_open_i[par][1], m0 = 0;
-            const unsigned int okey = (unsigned int)s_open_i[par][2];
-            for (bool more = true; more;) {
-                unsigned int kk[8]; float4 qq[8];
-#pragma unroll
-                for (int v = 0; v < 8; v++) { const int ix = min(m0 + v, tile_n - 1); kk[v] = s_tk[ix]; qq[v] = s_tq[ix]; }
-                int m = 0;
-#pragma unroll
-                for (int v = 0; v < 8; v++) if (m == v && m0 + v < tile_n && kk[v] == okey) { cx = __fadd_rn(cx, qq[v].x); cy = __fadd_rn(cy, qq[v].y); cz = __fadd_rn(cz, qq[v].z); ci = __fadd_rn(ci, qq[v].w); m++; }
-                m0 += m;
-                more = m == 8;
-            }
-            len += m0;
+            int m0 = 0x7fffffff;
+            for (int k = 0; k < 32 && m0 == 0x7fffffff; k++) m0 = s_fh[k];
+            m0 = min(m0, tile_n);
+            sv_run_sum(s_tq, 0, m0, tile_n, cx, cy, cz, ci);
+            const int len = s_open_i[par][1] + m0;
             if (m0 == tile_n && t0 + tile_n < n) {
                 s_open_f[par ^ 1][0] = cx; s_open_f[par ^ 1][1] = cy; s_open_f[par ^ 1][2] = cz; s_open_f[par ^ 1][3] = ci;
-                s_open_i[par ^ 1][1] = len; s_open_i[par ^ 1][2] = (int)okey; s_open_i[par ^ 1][3] = s_open_i[par][3]; s_open_i[par ^ 1][0] = 1;
+                s_open_i[par ^ 1][1] = len; s_open_i[par ^ 1][3] = s_open_i[par][3]; s_open_i[par ^ 1][0] = 1;
             } else {
                 const float nn = (float)len;
                 o[s_open_i[par][3]] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
@@ -397,26 +433,18 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
 #pragma unroll
             for (int k = 0; k < 16; k++) { const int x = s_w2[u][k]; if (k < wave) off += x; tot += x; }
             if (head[u]) {
-                const int e = u * SV_T + tid, j = t0 + e;
+                const int e = u * SV_T + tid, j = t0 + e, strip = u * 16 + wave;
+                // the run ends at the next head: in this strip (mask), else the first head of a later strip, else the tile end
+                const unsigned long long rest = lane < 63 ? hb[u] & ~((2ULL << lane) - 1ULL) : 0ULL;
+                int re = rest ? strip * 64 + __ffsll((long long)rest) - 1 : 0x7fffffff;
+                for (int k = strip + 1; k < 32 && re == 0x7fffffff; k++) re = s_fh[k];
+                const int len = min(re, tile_n) - e;
                 float cx = __fadd_rn(0.0f, q0[u].x), cy = __fadd_rn(0.0f, q0[u].y), cz = __fadd_rn(0.0f, q0[u].z), ci = __fadd_rn(0.0f, q0[u].w);
-                int len = 1;
-                // the sum is a serial chain in index order (as pcl accumulates it); eight keys and points are read at once so that a leaf of a hundred near-range
-                // points costs eight additions per LDS round trip instead of one
-                for (bool more = true; more;) {
-                    const int b0 = e + len;
-                    unsigned int kk[8]; float4 qq[8];
-#pragma unroll
-                    for (int v = 0; v < 8; v++) { const int ix = min(b0 + v, tile_n - 1); kk[v] = s_tk[ix]; qq[v] = s_tq[ix]; }
-                    int m = 0;
-#pragma unroll
-                    for (int v = 0; v < 8; v++) if (m == v && b0 + v < tile_n && kk[v] == key[u]) { cx = __fadd_rn(cx, qq[v].x); cy = __fadd_rn(cy, qq[v].y); cz = __fadd_rn(cz, qq[v].z); ci = __fadd_rn(ci, qq[v].w); m++; }
-                    len += m;
-                    more = m == 8;
-                }
+                sv_run_sum(s_tq, e + 1, len - 1, tile_n, cx, cy, cz, ci);
                 const int slot = base + off + incl[u] - 1;
                 if (e + len == tile_n && j + len < n) {      // the run reaches the tile end and points remain: the leaf may continue in the next tile -> left open
                     s_open_f[par ^ 1][0] = cx; s_open_f[par ^ 1][1] = cy; s_open_f[par ^ 1][2] = cz; s_open_f[par ^ 1][3] = ci;
-                    s_open_i[par ^ 1][1] = len; s_open_i[par ^ 1][2] = (int)key[u]; s_open_i[par ^ 1][3] = slot; s_open_i[par ^ 1][0] = 1;
+                    s_open_i[par ^ 1][1] = len; s_open_i[par ^ 1][3] = slot; s_open_i[par ^ 1][0] = 1;
                 } else {
                     const float nn = (float)len;
                     o[slot] = make_float4(cx / nn, cy / nn, cz / nn, ci / nn);
@@ -426,8 +454,11 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
         }
         par ^= 1;
         carry = base;
-        __syncthreads();                         // the staging arrays and s_w2 are rewritten by the next tile
+        S2M_ACC(3);
+        __syncthreads();                         // the staging array, s_w2 and s_fh are rewritten by the next tile
+        S2M_ACC(4);
     }
+    S2M_ACC_OUT(K24 ? 0 : 1);
     S2M_STAMP(K24 ? 0 : 1, 4, true);
 #ifdef VILF_STAMPS
     if (blockIdx.x == S2M_STAMP_WG && tid == 0) { s2m_dbg[(K24 ? 0 : 1) * 32 + 30] = n; s2m_dbg[(K24 ? 0 : 1) * 32 + 31] = vbits; }
@@ -532,7 +563,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     box.mnx = (float)(pose[4] - half); box.mny = (float)(pose[5] - half); box.mnz = (float)(pose[6] - half);
     box.mxx = (float)(pose[4] + half); box.mxy = (float)(pose[5] + half); box.mxz = (float)(pose[6] + half);
     int bad = 0;
-    const int skid = nOld > 45000 ? 4 : 5;
+    [[maybe_unused]] const int skid = nOld > 45000 ? 4 : 5;
     S2M_STAMP(skid, 0, true);
 
     // ---- A. tail: crop, key, sort, points in sorted order, distinct-leaf prefix
@@ -601,7 +632,9 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     float4 qn[MU_E], qn2[MU_E];                                     // two tiles of points in flight: one tile ahead leaves the sweep waiting a memory round trip per tile
 #pragma unroll
     for (int u = 0; u < MU_E; u++) { qn[u] = p[min(u * MU_T + tid, max(nOld - 1, 0))]; qn2[u] = p[min(MU_TILE + u * MU_T + tid, max(nOld - 1, 0))]; }
+    S2M_ACC_DECL
     for (int t0 = 0; t0 < nOld; t0 += MU_TILE) {
+        S2M_ACC(0);
         float4 q[MU_E];
         unsigned long long key[MU_E];
         int tb[MU_E], flag[MU_E], incl[MU_E];
@@ -618,7 +651,9 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             if (sv) hm |= 1u << u;
         }
         if (tid == 0) { unsigned long long kx; mu_leaf<AXB>(qn[0], inv, kx); s_nk = kx; }
+        S2M_ACC(1);
         __syncthreads();
+        S2M_ACC(2);
         const unsigned long long lastK = s_key[MU_TILE - 1];
 #pragma unroll
         for (int u = 0; u < MU_E; u++) {
@@ -637,14 +672,23 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
                 if (!mine) hm &= ~(1u << u);
             }
         }
-        {   // the searches of a lane advance together (independent LDS reads in flight)
-            int lo[MU_E], hi[MU_E];
+        S2M_ACC(3);
+        {   // lower bound of every old key in the sorted tail. The tail array is padded with ~0 to the power of two P2, so the search is the branch-free halving
+            // form: one LDS read, one 64-bit compare and one conditional add per step and chain (the sweep is bound by VALU issue — sixteen waves share four
+            // SIMDs — and the textbook lo / hi / mid form cost four times the instructions)
+            int lo[MU_E];
+            unsigned long long kk[MU_E];
 #pragma unroll
-            for (int u = 0; u < MU_E; u++) { lo[u] = 0; hi[u] = ntv; }
-            for (int span = ntv; span > 0; span >>= 1) {
+            for (int u = 0; u < MU_E; u++) { lo[u] = 0; kk[u] = key[u] << IDXB; }
+            for (int half = P2 >> 1; half > 0; half >>= 1) {
+                unsigned long long tv[MU_E];
 #pragma unroll
-                for (int u = 0; u < MU_E; u++) if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if ((T[mid] >> IDXB) < key[u]) lo[u] = mid + 1; else hi[u] = mid; }
+                for (int u = 0; u < MU_E; u++) tv[u] = T[lo[u] + half - 1];
+#pragma unroll
+                for (int u = 0; u < MU_E; u++) lo[u] += tv[u] < kk[u] ? half : 0;
             }
+#pragma unroll
+            for (int u = 0; u < MU_E; u++) lo[u] += T[lo[u]] < kk[u] ? 1 : 0;
 #pragma unroll
             for (int u = 0; u < MU_E; u++) {
                 const bool valid = t0 + u * MU_T + tid < nOld;
@@ -657,16 +701,17 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             }
         }
 #pragma unroll
-        for (int u = 0; u < MU_E; u++) {
-            incl[u] = flag[u];
-#pragma unroll
-            for (int of = 1; of < 64; of <<= 1) { const int v = __shfl_up(incl[u], of, 64); if (lane >= of) incl[u] += v; }
+        for (int u = 0; u < MU_E; u++) {           // inclusive wave scan of the two packed counts from two ballots
+            const unsigned long long below = (2ULL << lane) - 1ULL;
+            incl[u] = __popcll(__ballot(flag[u] & 1) & below) | (__popcll(__ballot(flag[u] >> 16) & below) << 16);
         }
         if (lane == 63) {
 #pragma unroll
             for (int u = 0; u < MU_E; u++) s_w[u][wave] = incl[u];
         }
+        S2M_ACC(4);
         __syncthreads();
+        S2M_ACC(5);
         int base = 0;
 #pragma unroll
         for (int u = 0; u < MU_E; u++) {
@@ -686,8 +731,11 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         const int nextTE = s_te[MU_TILE - 1];
         carryH += base & 0xffff; carryM += base >> 16;
         carryTE = nextTE; carryK = lastK;
+        S2M_ACC(6);
         __syncthreads();                                             // s_key / s_te / s_w are rewritten by the next tile
+        S2M_ACC(7);
     }
+    S2M_ACC_OUT(skid);
     S2M_STAMP(skid, 2, true);
     __syncthreads();
     {   // the queued points, one per lane: their dependent global loads run in parallel here instead of stalling a tile of the sweep
@@ -758,7 +806,7 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     unsigned short *rk = reinterpret_cast<unsigned short *>(bkt_all) + base;      // arrival rank of every point inside its bucket
     int *start = start_all + (size_t)sid * S2B_NBS;
     float4 *sorted = sorted_all + base;
-    const int skid = n > 45000 ? 2 : 3;
+    [[maybe_unused]] const int skid = n > 45000 ? 2 : 3;
     S2M_STAMP(skid, 0, true);
     for (int i = tid; i < S2B_HWORDS; i += S2B_IT) s_hist[i] = 0;
     if (tid == 0) s_big = 0;
