@@ -20,3 +20,5 @@ for k, (nm, ph) in names.items():
     if st[0] == 0: continue
     print(nm, "n", int(v[30]), "aux", int(v[31]), int(v[29]), int(v[28]), "total", st[-1] - st[0], {p: st[i + 1] - st[i] for i, p in enumerate(ph)})
     if v[16:24].any(): print("   tile-loop sums (thread 0):", [int(x) for x in v[16:24]])
+for k, nm in ((6, "associate edge"), (7, "associate surf")):
+    print(nm, "queries", int(a[k][30]), "wave 0 of block 2: knn cycles", int(a[k][0]), "fit + store", int(a[k][1]))

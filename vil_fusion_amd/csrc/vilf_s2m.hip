@@ -813,20 +813,27 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     __syncthreads();
     bool over = false;
     S2M_STAMP(skid, 1, true);
-    for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {    // S2B_FL points per lane in flight
-        float4 q[S2B_FL];
+    {   // S2B_FL points per lane and round, the next round's loads in flight while this round's LDS atomics run (a round that issues its loads only after the last one's
+        // atomics pays the memory latency once per round: 15 rounds of a 59 k-point map)
+        float2 cur[S2B_FL], nxt[S2B_FL];
 #pragma unroll
-        for (int u = 0; u < S2B_FL; u++) q[u] = p[min(i0 + u * S2B_IT, n - 1)];
+        for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(tid + u * S2B_IT, max(n - 1, 0)); cur[u] = make_float2(pp->x, pp->y); }
+        for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {
 #pragma unroll
-        for (int u = 0; u < S2B_FL; u++) {
-            const int i = i0 + u * S2B_IT;
-            if (i >= n) continue;
-            const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
-            const int sh = 16 * (b & 1);
-            const unsigned int old = atomicAdd(&s_hist[S2B_HW(b >> 1)], 1u << sh);
-            const unsigned int rank = (old >> sh) & 0xffffu;
-            if (rank == 0xffffu) over = true;          // the 65536th point of a bucket would carry into its neighbour
-            rk[i] = (unsigned short)rank;
+            for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(i0 + (S2B_FL + u) * S2B_IT, n - 1); nxt[u] = make_float2(pp->x, pp->y); }
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) {
+                const int i = i0 + u * S2B_IT;
+                if (i >= n) continue;
+                const int b = bucket_of((int)floorf(cur[u].x), (int)floorf(cur[u].y));
+                const int sh = 16 * (b & 1);
+                const unsigned int old = atomicAdd(&s_hist[S2B_HW(b >> 1)], 1u << sh);
+                const unsigned int rank = (old >> sh) & 0xffffu;
+                if (rank == 0xffffu) over = true;          // the 65536th point of a bucket would carry into its neighbour
+                rk[i] = (unsigned short)rank;
+            }
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) cur[u] = nxt[u];
         }
     }
     if (over) atomicOr(err + sid, S2B_ERR_EXTENT);
@@ -863,19 +870,25 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     __threadfence_block();
     __syncthreads();
     S2M_STAMP(skid, 4, true);
-    for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {
-        float4 q[S2B_FL]; unsigned short r4[S2B_FL];
+    {
+        float4 q[S2B_FL], qn[S2B_FL]; unsigned short r4[S2B_FL], rn[S2B_FL];
 #pragma unroll
-        for (int u = 0; u < S2B_FL; u++) { const int ic = min(i0 + u * S2B_IT, n - 1); q[u] = p[ic]; r4[u] = rk[ic]; }
+        for (int u = 0; u < S2B_FL; u++) { const int ic = min(tid + u * S2B_IT, max(n - 1, 0)); q[u] = p[ic]; r4[u] = rk[ic]; }
+        for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {
 #pragma unroll
-        for (int u = 0; u < S2B_FL; u++) {
-            const int i = i0 + u * S2B_IT;
-            if (i >= n) continue;
-            const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
-            const int st = big ? start[b] : s_base[b >> 6] + (int)((s_hist[S2B_HW(b >> 1)] >> (16 * (b & 1))) & 0xffffu);
-            const int pos = st + (int)r4[u];
-            q[u].w = __int_as_float(i);                // original map index (tie-break like a linear scan)
-            if (pos < map.cap) sorted[pos] = q[u];
+            for (int u = 0; u < S2B_FL; u++) { const int ic = min(i0 + (S2B_FL + u) * S2B_IT, n - 1); qn[u] = p[ic]; rn[u] = rk[ic]; }
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) {
+                const int i = i0 + u * S2B_IT;
+                if (i >= n) continue;
+                const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
+                const int st = big ? start[b] : s_base[b >> 6] + (int)((s_hist[S2B_HW(b >> 1)] >> (16 * (b & 1))) & 0xffffu);
+                const int pos = st + (int)r4[u];
+                q[u].w = __int_as_float(i);                // original map index (tie-break like a linear scan)
+                if (pos < map.cap) sorted[pos] = q[u];
+            }
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) { q[u] = qn[u]; r4[u] = rn[u]; }
         }
     }
     S2M_STAMP(skid, 5, true);
@@ -907,9 +920,39 @@ __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, flo
             st[sp] = start[b0]; en[sp] = start[b1 + 1];
         } else { st[sp] = 0; en[sp] = 0; }
     }
+    // one candidate: sorted insertion with compile-time indices only (the five best stay in registers)
+#define KNN_TRY(M, POS) { const float4 m = (M); const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz; \
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)); const int oi = __float_as_int(m.w); \
+        if (d < d2[4] || (d == d2[4] && oi < oid[4])) { bool lt[5]; const int ps_ = (POS); \
+            _Pragma("unroll") for (int k = 0; k < 5; k++) lt[k] = d < d2[k] || (d == d2[k] && oi < oid[k]); \
+            _Pragma("unroll") for (int k = 4; k >= 1; k--) { d2[k] = lt[k - 1] ? d2[k - 1] : (lt[k] ? d : d2[k]); oid[k] = lt[k - 1] ? oid[k - 1] : (lt[k] ? oi : oid[k]); pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? ps_ : pos[k]); } \
+            if (lt[0]) { d2[0] = d; oid[0] = oi; pos[0] = ps_; } } }
+    if (one_span) {
+        // the usual case: three spans, walked as ONE sequence (virtual index t -> position t + offset of its span) so that a batch never ends at a span boundary,
+        // with the next batch's loads issued before this batch is ranked: the walk is bound by the latency of these gathers, not by the arithmetic
+        const int n0 = en[0] - st[0], n01 = n0 + en[1] - st[1], ntot = n01 + en[2] - st[2];
+        const int o0 = st[0], o1 = st[1] - n0, o2 = st[2] - n01;
+        if (ntot > 0) {
+            float4 cur[KNN_FL], nxt[KNN_FL];
 #pragma unroll
-    for (int sp = 0; sp < 9; sp++) {
-        if (sp >= nspan) break;
+            for (int u = 0; u < KNN_FL; u++) { const int t = min(u, ntot - 1); cur[u] = sorted[t + (t < n0 ? o0 : (t < n01 ? o1 : o2))]; }
+            for (int t0 = 0; t0 < ntot; t0 += KNN_FL) {
+#pragma unroll
+                for (int u = 0; u < KNN_FL; u++) { const int t = min(t0 + KNN_FL + u, ntot - 1); nxt[u] = sorted[t + (t < n0 ? o0 : (t < n01 ? o1 : o2))]; }
+#pragma unroll
+                for (int u = 0; u < KNN_FL; u++) {
+                    const int t = t0 + u;
+                    if (t >= ntot) break;
+                    KNN_TRY(cur[u], t + (t < n0 ? o0 : (t < n01 ? o1 : o2)))
+                }
+#pragma unroll
+                for (int u = 0; u < KNN_FL; u++) cur[u] = nxt[u];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int sp = 0; sp < 9; sp++) {          // a digit wraps inside the 3 x 3 block: nine single-bucket spans
         for (int j0 = st[sp]; j0 < en[sp]; j0 += KNN_FL) {
             float4 m4[KNN_FL];
 #pragma unroll
@@ -917,25 +960,11 @@ __device__ void knn5_cells(const float4 *sorted, const int *start, float qx, flo
 #pragma unroll
             for (int u = 0; u < KNN_FL; u++) {
                 if (j0 + u >= en[sp]) break;
-                const float4 m = m4[u];
-                const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
-                const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
-                const int oi = __float_as_int(m.w);
-                if (d < d2[4] || (d == d2[4] && oi < oid[4])) {       // sorted insertion with compile-time indices only (the five best stay in registers)
-                    bool lt[5];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) lt[k] = d < d2[k] || (d == d2[k] && oi < oid[k]);
-#pragma unroll
-                    for (int k = 4; k >= 1; k--) {
-                        d2[k] = lt[k - 1] ? d2[k - 1] : (lt[k] ? d : d2[k]);
-                        oid[k] = lt[k - 1] ? oid[k - 1] : (lt[k] ? oi : oid[k]);
-                        pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? j0 + u : pos[k]);
-                    }
-                    if (lt[0]) { d2[0] = d; oid[0] = oi; pos[0] = j0 + u; }
-                }
+                KNN_TRY(m4[u], j0 + u)
             }
         }
     }
+#undef KNN_TRY
 }
 
 // 3x3 symmetric eigen-decomposition by cyclic Jacobi: eigenvalues ascending, V columns. Every array index is a compile-time constant
@@ -1053,8 +1082,16 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
     int kind = 0;
     double rec[S2M_FREC] = {cp[0], cp[1], cp[2], 0, 0, 0, 0, 0, 0, 0};
     int idx[5]; float d2[5];
+#ifdef VILF_STAMPS
+    const bool st_ = blockIdx.y == S2M_STAMP_WG && blockIdx.x == 2 && threadIdx.x == 0;
+    const long long st0_ = __builtin_readcyclecounter();
+    long long st1_ = st0_;
+#endif
     if (nmap >= 5) {
         knn5_cells(sorted, start, qx, qy, qz, idx, d2);
+#ifdef VILF_STAMPS
+        st1_ = __builtin_readcyclecounter();
+#endif
         if (d2[4] < 1.0f) {
             double nb[5][3];
             for (int t = 0; t < 5; t++) { const float4 m = sorted[idx[t]]; nb[t][0] = m.x; nb[t][1] = m.y; nb[t][2] = m.z; }
@@ -1085,6 +1122,9 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
     }
     fkind_all[(size_t)sid * capq + slot] = kind;
     for (int k = 0; k < S2M_FREC; k++) frec[k] = rec[k];
+#ifdef VILF_STAMPS
+    if (st_) { const int kid = 6 + is_surf; s2m_dbg[kid * 32 + 0] = st1_ - st0_; s2m_dbg[kid * 32 + 1] = __builtin_readcyclecounter() - st1_; s2m_dbg[kid * 32 + 30] = ds.n[sid]; }
+#endif
 }
 
 // ---- the persistent LM solve -------------------------------------------------------------------------------------------
