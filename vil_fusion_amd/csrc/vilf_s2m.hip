@@ -1150,40 +1150,66 @@ __device__ double s2m_block_sum(double v, double *s_red) {
 }
 // cost (and, JAC: gradient g[6], hessian H[21] lower-packed) at pose x over all valid factors
 template <bool JAC>
-__device__ void s2m_evaluate(const double *x, const double *frec, const int *fkind, int nfac, double huber_a, double *s_red, double *s_out /*28*/) {
+__device__ void s2m_evaluate(const double *x, const double *frec, const int *fkind, int n_edge, int nfac, double huber_a, double *s_red, double *s_out /*28*/) {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0;
-    for (int i = threadIdx.x; i < nfac; i += S2M_NT) {
-        const int kind = fkind[i];
-        if (!kind) continue;
-        const double *rec = frec + (size_t)i * S2M_FREC;
-        // the two factor kinds are separate code paths with compile-time row counts: r / J keep static indices (registers, no scratch)
-        double r[3] = {0, 0, 0}, J[18];
-        if (kind == 1) edge_eval<JAC>(x, rec, rec + 3, rec + 6, r, J);
-        else surf_eval<JAC>(x, rec, rec + 3, rec[6], r, J);
-        double s = 0;
+    // one factor row: Huber-corrected J^T J (lower-packed), J^T r
+#define S2M_ROW(Jrow, rk_) { const double rk = sw * (rk_); double jr[6]; \
+        _Pragma("unroll") for (int c = 0; c < 6; c++) { jr[c] = sw * (Jrow)[c]; acc[21 + c] += jr[c] * rk; } \
+        int e = 0; _Pragma("unroll") for (int a = 0; a < 6; a++) _Pragma("unroll") for (int b2 = 0; b2 <= a; b2++) acc[e++] += jr[a] * jr[b2]; }
+    // The lane walks its factors i = tid, tid + 256, ... as before; the records [0, n_edge) hold the edge queries (kind 0 or 1), the rest the plane queries (kind 0 or
+    // 2), so the walk is two loops with one code path each. A record is requested together with its kind, not after the kind test (that made every factor two
+    // dependent memory round trips — eighteen factors per lane and sweep, most of the solve); the plane loop, lighter in registers, also keeps the next record in flight.
+    int i = threadIdx.x;
+    for (; i < n_edge; i += S2M_NT) {
+        const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)i * S2M_FREC);
+        double2 rr[5];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { if (k > 0 && kind != 1) break; s += r[k] * r[k]; }
+        for (int k = 0; k < 5; k++) rr[k] = rp[k];
+        const int kind = fkind[i];
+        double rec[S2M_FREC];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { rec[2 * k] = rr[k].x; rec[2 * k + 1] = rr[k].y; }
+        if (kind != 1) continue;
+        double r[3], J[18];
+        edge_eval<JAC>(x, rec, rec + 3, rec + 6, r, J);
         double rho0, sw;
-        huber(s, huber_a, rho0, sw);
+        huber(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], huber_a, rho0, sw);
         acc[27] += 0.5 * rho0;
         if (JAC) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (k > 0 && kind != 1) break;
-                const double rk = sw * r[k];
-                double jr[6];
-#pragma unroll
-                for (int c = 0; c < 6; c++) { jr[c] = sw * J[6 * k + c]; acc[21 + c] += jr[c] * rk; }
-                int e = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int b2 = 0; b2 <= a; b2++) acc[e++] += jr[a] * jr[b2];
-            }
+            for (int k = 0; k < 3; k++) S2M_ROW(J + 6 * k, r[k])
         }
     }
+    if (i < nfac) {
+        int kind_n = fkind[i];
+        double2 rn[4];
+        {
+            const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)i * S2M_FREC);
+#pragma unroll
+            for (int k = 0; k < 4; k++) rn[k] = rp[k];
+        }
+        for (; i < nfac; i += S2M_NT) {
+            const int kind = kind_n;
+            const double rec[8] = {rn[0].x, rn[0].y, rn[1].x, rn[1].y, rn[2].x, rn[2].y, rn[3].x, rn[3].y};
+            {
+                const int ic = min(i + S2M_NT, nfac - 1);
+                kind_n = fkind[ic];
+                const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)ic * S2M_FREC);
+#pragma unroll
+                for (int k = 0; k < 4; k++) rn[k] = rp[k];
+            }
+            if (kind != 2) continue;
+            double r[1], J[6];
+            surf_eval<JAC>(x, rec, rec + 3, rec[6], r, J);
+            double rho0, sw;
+            huber(r[0] * r[0], huber_a, rho0, sw);
+            acc[27] += 0.5 * rho0;
+            if (JAC) S2M_ROW(J, r[0])
+        }
+    }
+#undef S2M_ROW
     // 28 sums at once: wave butterflies, per-wave partials to LDS, thread k adds the partials of sum k in wave order
     __syncthreads();
 #pragma unroll
@@ -1211,7 +1237,7 @@ __global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const dou
     const int tne = (int)(s2m_block_sum((double)ne, s_red) + 0.5), tns = (int)(s2m_block_sum((double)ns, s_red) + 0.5);
     if (tne + tns == 0) { if (tid == 0) { out->cost[pass] = 0; out->its[pass] = 0; out->nfe[pass] = 0; out->nfs[pass] = 0; } return; }
     __syncthreads();
-    s2m_evaluate<true>(s_x, frec, fkind, nfac, huber_a, s_red, s_ev);
+    s2m_evaluate<true>(s_x, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_ev);
     // thread-0 scalars of the trust-region loop (trust_region_minimizer.cc + levenberg_marquardt_strategy.cc)
     double x_cost = s_ev[27], radius = 1e4, decrease_factor = 2.0, x_norm = 0, mcc = 0;
     bool reuse_diagonal = false;
@@ -1281,7 +1307,7 @@ __global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const dou
         if (!valid) continue;
         // cost AND linearisation at the candidate in one sweep over the factor records: an accepted step (the usual case) then needs no
         // second sweep; a rejected one leaves s_ev (the linearisation at x) untouched
-        s2m_evaluate<true>(s_c, frec, fkind, nfac, huber_a, s_red, s_cand);
+        s2m_evaluate<true>(s_c, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_cand);
         if (tid == 0) {
             const double cand = s_cand[27];
             double sn = 0;
