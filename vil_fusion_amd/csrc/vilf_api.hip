@@ -28,6 +28,7 @@ __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
 __global__ void k_marg_prepare(VbBatch b, VbMarg g);
 __global__ void k_marg_prepare_td(VbBatch b, VbMarg g);
+__global__ void k_prior_keep(VbBatch b, VbMarg g);
 __global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
 __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged);
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
@@ -42,6 +43,13 @@ __global__ void k_hook_lidar(const double *, const double *, const double *, con
 __global__ void k_hook_edge(const double *, const double *, const double *, const double *, double *);
 __global__ void k_hook_surf(const double *, const double *, const double *, double, double *);
 __global__ void k_hook_plus(const double *, const double *, int, double *);
+}
+
+// the batch descriptor's view of the live prior set (the two sets swap: vilf_batch_marginalize / vilf_batch_rewind)
+static void bind_prior_pointers(vilf_handle *h) {
+    VbBatch &b = h->batch;
+    b.prior_hdr = h->d[D_PHDR].as<int>(); b.prior_x0 = h->d[D_PX0].as<double>(); b.prior_J = h->d[D_PJ].as<double>(); b.prior_r = h->d[D_PR].as<double>();
+    b.prior_H = h->d[D_PH].as<double>(); b.prior_g = h->d[D_PG].as<double>();
 }
 
 namespace {
@@ -501,8 +509,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.ps_feat = h->d[D_PSFEAT].as<int>(); b.ps_obs = h->d[D_PSOBS].as<int>(); b.ps_slot = h->d[D_PSSLOT].as<int>();
     b.pair_off = h->d[D_PAIROFF].as<int>(); b.facrec = h->d[D_FACREC].as<double>();
     b.imu = h->d[D_IMU].as<double>(); b.lidar = h->d[D_LIDAR].as<double>();
-    b.prior_hdr = h->d[D_PHDR].as<int>(); b.prior_x0 = h->d[D_PX0].as<double>(); b.prior_J = h->d[D_PJ].as<double>(); b.prior_r = h->d[D_PR].as<double>();
-    b.prior_H = h->d[D_PH].as<double>(); b.prior_g = h->d[D_PG].as<double>();
+    bind_prior_pointers(h);
     b.facw = h->d[D_FACW].as<double>(); b.Hpp = h->d[D_HPP].as<double>(); b.W = h->d[D_W].as<double>(); b.hf = h->d[D_HF].as<double>(); b.gf = h->d[D_GF].as<double>();
     b.imuH = h->d[D_IMUH].as<double>(); b.imug = h->d[D_IMUG].as<double>(); b.lidH = h->d[D_LIDH].as<double>(); b.lidg = h->d[D_LIDG].as<double>(); b.g = h->d[D_G].as<double>(); b.diagH = h->d[D_DIAGH].as<double>(); b.pairD = h->d[D_PAIRD].as<double>();
     b.cf = h->d[D_CF].as<double>();
@@ -560,11 +567,10 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_reset, dim3(h->B), dim3(VB_NT), 0, h->stream, h->batch, 1);
     HIPCHECK(h, hipGetLastError());
-    if (h->prior_restore_needed && h->prior_backup_valid) {          // a marginalization replaced the priors: restore them as uploaded
-        const size_t sB = h->B;
+    if (h->prior_restore_needed && h->prior_backup_valid) {          // a marginalization replaced the priors: the set as uploaded becomes the live one again (swap, no copy)
         const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
-        const size_t bytes[6] = {sB * VB_PRIOR_HDR * 4, sB * 24 * 9 * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8};
-        for (int k = 0; k < 6; k++) HIPCHECK(h, hipMemcpyAsync(h->d[live[k]].p, h->d[bak[k]].p, bytes[k], hipMemcpyDeviceToDevice, h->stream));
+        for (int k = 0; k < 6; k++) std::swap(h->d[live[k]], h->d[bak[k]]);
+        bind_prior_pointers(h);
         // the device now holds the authoritative priors; the host mirror may have seen the marginalized ones through an export
         for (int w = 0; w < h->B; w++) { h->prior_dev_newer[w] = 1; h->prior_dirty[w] = 0; }
         h->prior_restore_needed = false;
@@ -828,16 +834,15 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     g.hfm = h->d[D_MHF].as<double>(); g.gfm = h->d[D_MGF].as<double>(); g.Amm = h->d[D_MAMM].as<double>(); g.X = h->d[D_MX].as<double>();
     g.rot = h->d[D_MROT].as<double>(); g.lam = h->d[D_MLAM].as<double>(); g.Ar = h->d[D_MAR].as<double>(); g.br = h->d[D_MBR].as<double>();
     g.qlV = h->d[D_QLV].as<double>(); g.qlD = h->d[D_QLD].as<double>(); g.qlLog = h->d[D_QLLOG].as<double>(); g.qlIt = h->d[D_QLIT].as<int>(); g.qlInfo = h->d[D_QLINFO].as<int>();
-    g.prior_hdr_out = h->d[D_PHDR].as<int>(); g.prior_x0_out = h->d[D_PX0].as<double>(); g.prior_J_out = h->d[D_PJ].as<double>(); g.prior_r_out = h->d[D_PR].as<double>();
-    if (!h->prior_backup_valid) {      // keep the priors as uploaded: vilf_batch_rewind re-arms them after this call overwrites them
-        const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
-        const size_t bytes[6] = {sB * VB_PRIOR_HDR * 4, sB * 24 * 9 * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8};
-        for (int k = 0; k < 6; k++) {
-            if (!h->d[bak[k]].ensure(bytes[k])) { h->err = "hipMalloc failed (prior backup)"; return VILF_ERR_DEVICE; }
-            HIPCHECK(h, hipMemcpyAsync(h->d[bak[k]].p, h->d[live[k]].p, bytes[k], hipMemcpyDeviceToDevice, h->stream));
-        }
-        h->prior_backup_valid = true;
-    }
+    // Two sets of prior buffers. When the live set is still the one the windows were uploaded / rewound with, the new priors go to the other set and the sets swap
+    // afterwards: the uploaded priors stay intact for vilf_batch_rewind at no cost (this used to be a 1.7 GB device copy per marginalization and another per rewind).
+    // A second marginalization without a rewind in between writes in place, as before, so that the snapshot survives.
+    const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
+    const size_t pbytes[6] = {sB * VB_PRIOR_HDR * 4, sB * 24 * 9 * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8, sB * VB_PRIOR_LD * 8};
+    const bool to_other_set = !h->prior_restore_needed;
+    if (to_other_set) for (int k = 0; k < 6; k++) if (!h->d[bak[k]].ensure(pbytes[k])) { h->err = "hipMalloc failed (second prior set)"; return VILF_ERR_DEVICE; }
+    const int *oset = to_other_set ? bak : live;
+    g.prior_hdr_out = h->d[oset[0]].as<int>(); g.prior_x0_out = h->d[oset[1]].as<double>(); g.prior_J_out = h->d[oset[2]].as<double>(); g.prior_r_out = h->d[oset[3]].as<double>();
     const dim3 grid(h->B), block(VB_NT);
     const bool prof = h->profiling != 0 && sync;
     if (prof) while (h->pev.size() < 5) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
@@ -859,6 +864,12 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 78, 1 << 30);
     hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, 1);
     hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, 1);
+    if (to_other_set) {
+        hipLaunchKernelGGL(k_prior_keep, grid, block, 0, h->stream, h->batch, g);
+        for (int k = 0; k < 6; k++) std::swap(h->d[live[k]], h->d[bak[k]]);
+        bind_prior_pointers(h);
+        h->prior_backup_valid = true;           // the other set now holds the priors as uploaded
+    }
     if (prof) hipEventRecord(h->pev[3], h->stream);
     hipLaunchKernelGGL(k_prior_prep, grid, block, VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS);
     if (prof) hipEventRecord(h->pev[4], h->stream);

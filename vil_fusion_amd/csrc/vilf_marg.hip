@@ -1023,3 +1023,15 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg
 }
 
 #undef VV
+
+// The new prior is written to a second set of buffers (the set that was read stays intact: a rewind to it is a pointer swap, no copy). A window whose prior this call
+// leaves as it is (SECOND_NEW without Pose[WINDOW_SIZE - 1] in it, estimator.cpp:982-983, or an unsupported block table) carries it over here.
+extern "C" __global__ __launch_bounds__(NT) void k_prior_keep(VbBatch b, VbMarg g) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (g.info[(size_t)w * MG_INFO] == 0) return;
+    for (int i = tid; i < VB_PRIOR_HDR; i += NT) g.prior_hdr_out[(size_t)w * VB_PRIOR_HDR + i] = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + i];
+    for (int i = tid; i < 24 * 9; i += NT) g.prior_x0_out[(size_t)w * 24 * 9 + i] = b.prior_x0[(size_t)w * 24 * 9 + i];
+    for (int i = tid; i < VB_PRIOR_LD; i += NT) g.prior_r_out[(size_t)w * VB_PRIOR_LD + i] = b.prior_r[(size_t)w * VB_PRIOR_LD + i];
+    for (int i = tid; i < VB_PRIOR_LD * VB_PRIOR_LD; i += NT) g.prior_J_out[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + i] = b.prior_J[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + i];
+}
+
