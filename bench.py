@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="run the LiDAR stage on its own handle / HIP stream / host thread, concurrently with the "
                     "window solve (like the reference's separate nodes); ~7 %% more frames/s, but per-kernel timings then include contention")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (profile runs: its 2048-window solves would mix into the per-kernel averages)")
     ap.add_argument("--ragged-windows", type=int, default=1024, help="distinct windows of the ragged-batch line (features U(120, 320), mixed prior / no prior, mixed marginalization flags), tiled to --windows; 0 skips it")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[4] instead of the headline workload: one synthetic 51-frame / ~46 k-factor window per step and GPU")
     args = ap.parse_args()
@@ -352,7 +353,7 @@ def main():
     # ---- PCIe-inclusive figure: host buffers in (vilf_batch_upload: pack on the host threads + H2D from pinned staging) -> solve -> host buffers out
     # (vilf_batch_download_states), 2048 windows through ONE handle, priors resident (they are produced on the device in the running system). Never `value`.
     pcie = None
-    if world == 1:
+    if world == 1 and not args.no_pcie:
         from vil_fusion_amd import abi as vabi
         nb = min(2048, B)
         psolver = BackendSolver(device=local_rank)
@@ -422,7 +423,22 @@ def main():
             mfma = {"k_solve": {"bound": "mfma", "peak": 78.6, "unit": "TFLOP/s", "avg_launch_ms": ms, "mfma_instructions_per_window": issued,
                                 "issued_flop_per_launch": issued * 2048.0 * B, "achieved_issued": issued * 2048.0 * B / (ms * 1e-3) / 1e12, "frac_issued": issued * 2048.0 * B / (ms * 1e-3) / 1e12 / 78.6,
                                 "algorithmic_flop_per_launch": alg_flop * B, "achieved": alg_flop * B / (ms * 1e-3) / 1e12, "frac": alg_flop * B / (ms * 1e-3) / 1e12 / 78.6,
-                                "source": "analytic instruction count of the current kernel (see DESIGN.md); PMC cross-check in profiles/ when taken at this version"}}
+                                "source": "analytic instruction count of the current kernel (see DESIGN.md)"}}
+            # PMC cross-check (profiles/r*_pmc_mfma.json, a separate rocprofv3 --pmc pass of the solve-only bench): used only when it was taken at this batch size AND
+            # its per-window MFMA count of k_solve_sb agrees with the count above (= the same kernel version); anything else is refused as stale and said so
+            try:
+                import glob
+                cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")), key=_profile_order)
+                pm = json.load(open(cand[-1]))
+                ke = pm["kernels"].get("k_solve_sb")
+                if ke is None or pm.get("config", {}).get("frames_per_gpu") != B:
+                    mfma["k_solve"]["pmc"] = "refused: " + os.path.basename(cand[-1]) + " was taken on another kernel / batch size"
+                elif abs(ke["mfma_instructions_per_window"] - issued) > 0.03 * issued:
+                    mfma["k_solve"]["pmc"] = "refused: " + os.path.basename(cand[-1]) + f" counts {ke['mfma_instructions_per_window']:.0f} MFMA instructions per window, the current kernel issues {issued}"
+                else:
+                    mfma["k_solve"]["pmc"] = {"file": os.path.basename(cand[-1]), "mfma_instructions_per_window": ke["mfma_instructions_per_window"], "MfmaUtil_percent": ke.get("MfmaUtil_percent")}
+            except Exception:
+                mfma["k_solve"]["pmc"] = None
         except Exception:
             mfma = None
         it_ms = sum(prof[k]["ms"] for k in ("k_linearize", "k_solve", "k_step")) / max(prof["k_solve"]["launches"], 1)

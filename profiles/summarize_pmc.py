@@ -40,7 +40,12 @@ def main():
     for cname, path in (("FETCH_SIZE", fetch_csv), ("WRITE_SIZE", write_csv)):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] == cname:
-                per_kernel[r["Kernel_Name"].split("(")[0][:80]][cname].append(float(r["Counter_Value"]))
+                kn = r["Kernel_Name"].split("(")[0][:80]
+                # the back-end kernels run one workgroup per window: only their dispatches over the full batch count (the bench's PCIe-inclusive leg and the ragged
+                # line solve other batch sizes with the same kernels, outside the timed steps)
+                if kn in ("k_linearize", "k_solve", "k_solve_sb", "k_step") and int(r["Grid_Size"]) != frames * int(r["Workgroup_Size"]):
+                    continue
+                per_kernel[kn][cname].append(float(r["Counter_Value"]))
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py --steps S --warmup W --no-cpu-baseline (two passes)",
            "note": __doc__.split("Counter unit:")[1].strip(), "steps_in_run": steps, "config": {"frames_per_gpu": frames, "workload_tag": tag}, "kernels": {}, "groups": {}}
     rows = []
