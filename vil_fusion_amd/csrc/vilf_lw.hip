@@ -229,53 +229,52 @@ __global__ __launch_bounds__(256) void lw_prior(int n, const double *J, const do
     for (int i = tid; i < n; i += 256) { if (pcol[i] < 0) continue; double s = 0; for (int k = 0; k < n; k++) s += J[(size_t)k * n + i] * s_r[k]; add(gp + pcol[i], s); }
     for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e - i * n; if (pcol[i] >= 0 && pcol[j] >= 0) add(Hpp + (size_t)pcol[i] * P + pcol[j], H0[(size_t)i * VB_PRIOR_LD + j]); }
 }
-// IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair
-__global__ void lw_imu_lidar(int NF, int P, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
-                             double *Hpp, double *gp, double *cost, double *jscr) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+// IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair: ONE workgroup per frame pair. Lane 0 of wave
+// 0 evaluates the raw IMU residual / Jacobian into LDS, lane 0 of wave 1 the LiDAR factor; the products with sqrt_info (15 x 15 upper triangular times 15 x 31) and
+// the LiDAR J^T [J r] entries are then one lane per entry. (A lane per factor kept its 15 x 30 Jacobian in a dynamically indexed local array = scratch memory, and
+// walked the 7 k multiply-adds of S J alone: 127 us per launch, 17 launches per solve.)
+__global__ __launch_bounds__(128) void lw_imu_lidar(int NF, int P, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
+                                                    double *Hpp, double *gp, double *cost, double *jscr) {
+    const int k = blockIdx.x, tid = threadIdx.x;
     if (k >= NF - 1) return;
+    __shared__ double s_r[16], s_J[15 * 30], s_rw[16], s_lr[8], s_lJi[36], s_lJj[36];
     const int c0 = 15 * k;
     const double *pi = x + 7 * k, *pj = x + 7 * (k + 1), *sbi = x + 7 * NF + 9 * k, *sbj = sbi + 9;
-    double c = 0;
     const double *rec = imu_rec + (size_t)k * IMU_REC;
-    if (rec[287] != 0.0) {
-        double r[15], Jr[15 * 30], rw[15];
-        if (jac) imu_raw_eval<true, 30, true>(pi, sbi, pj, sbj, rec, G, r, Jr); else imu_raw_eval<false, 30, true>(pi, sbi, pj, sbj, rec, G, r, Jr);
-        const double *S = rec + IMU_SQRT;                      // upper-triangular sqrt_info (15 x 15, row-major)
-        for (int a = 0; a < 15; a++) { double s = 0; for (int m = a; m < 15; m++) s += S[15 * a + m] * r[m]; rw[a] = s; c += 0.5 * s * s; }
-        if (jac) {
-            for (int col = 0; col < 30; col++) {               // Jw(:, col) = S Jraw(:, col); then the column's products with all earlier-or-equal columns
-                double jw[15];
-                for (int a = 0; a < 15; a++) { double s = 0; for (int m = a; m < 15; m++) s += S[15 * a + m] * Jr[30 * m + col]; jw[a] = s; }
-                for (int a = 0; a < 15; a++) Jr[30 * a + col] = jw[a];   // rows a >= ... of this column are final: columns are processed left to right and
-            }                                                            // S is applied to a whole column at once (reads rows m >= a of the raw column only)
-            double *jo = jscr + (size_t)k * 480;             // weighted Jacobian (15 x 30) and residual (15) for lw_imu_products
-            for (int e = 0; e < 450; e++) jo[e] = Jr[e];
-            for (int e = 0; e < 15; e++) jo[450 + e] = rw[e];
-        }
-    } else if (jac) { double *jo = jscr + (size_t)k * 480; for (int e = 0; e < 465; e++) jo[e] = 0.0; }
-    if (use_lidar) {
-        double r[6], Ji[36], Jj[36];
+    const bool has_imu = rec[287] != 0.0;
+    if (tid == 0 && has_imu) { if (jac) imu_raw_eval<true, 30, true>(pi, sbi, pj, sbj, rec, G, s_r, s_J); else imu_raw_eval<false, 30, true>(pi, sbi, pj, sbj, rec, G, s_r, s_J); }
+    if (tid == 64 && use_lidar) {
         const double *lc = lid + 7 * (size_t)k;
-        if (jac) lidar_between_eval<true>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, r, Ji, Jj); else lidar_between_eval<false>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, r, Ji, Jj);
-        for (int a = 0; a < 6; a++) c += 0.5 * r[a] * r[a];
-        if (jac) {
-            const int ci = c0, cj = c0 + 15;
-            for (int a = 0; a < 12; a++) {
-                const double *Ja = a < 6 ? Ji : Jj; const int aa = a < 6 ? a : a - 6, ca = a < 6 ? ci + a : cj + a - 6;
-                double s = 0;
-                for (int m = 0; m < 6; m++) s += Ja[6 * m + aa] * r[m];
-                add(gp + ca, s);
-                for (int b = 0; b < 12; b++) {
-                    const double *Jb = b < 6 ? Ji : Jj; const int bb = b < 6 ? b : b - 6, cb = b < 6 ? ci + b : cj + b - 6;
-                    double hh = 0;
-                    for (int m = 0; m < 6; m++) hh += Ja[6 * m + aa] * Jb[6 * m + bb];
-                    add(Hpp + (size_t)ca * P + cb, hh);
-                }
-            }
-        }
+        if (jac) lidar_between_eval<true>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr, s_lJi, s_lJj); else lidar_between_eval<false>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr, s_lJi, s_lJj);
     }
-    add(cost, c);
+    __syncthreads();
+    double *jo = jscr + (size_t)k * 480;                     // weighted Jacobian (15 x 30) and residual (15) for lw_imu_products
+    if (has_imu) {
+        const double *S = rec + IMU_SQRT;                    // upper-triangular sqrt_info (15 x 15, row-major)
+        for (int e = tid; e < (jac ? 465 : 15); e += 128) {
+            const int a = jac ? e / 31 : e, col = jac ? e - 31 * a : 30;
+            double sum = 0;
+            for (int m = a; m < 15; m++) sum += S[15 * a + m] * (col < 30 ? s_J[30 * m + col] : s_r[m]);
+            if (col < 30) jo[30 * a + col] = sum; else { s_rw[a] = sum; if (jac) jo[450 + a] = sum; }
+        }
+    } else if (jac) for (int e = tid; e < 465; e += 128) jo[e] = 0.0;
+    if (use_lidar && jac)
+        for (int e = tid; e < 12 * 13; e += 128) {           // LiDAR between-factor: J^T [J r] (unweighted Jacobian, weighted residual: the reference's quirk)
+            const int a = e / 13, b = e - 13 * a;
+            const double *Ja = a < 6 ? s_lJi : s_lJj; const int aa = a < 6 ? a : a - 6, ca = a < 6 ? c0 + a : c0 + 15 + a - 6;
+            double hh = 0;
+            if (b < 12) { const double *Jb = b < 6 ? s_lJi : s_lJj; const int bb = b < 6 ? b : b - 6, cb = b < 6 ? c0 + b : c0 + 15 + b - 6;
+                for (int m = 0; m < 6; m++) hh += Ja[6 * m + aa] * Jb[6 * m + bb];
+                add(Hpp + (size_t)ca * P + cb, hh);
+            } else { for (int m = 0; m < 6; m++) hh += Ja[6 * m + aa] * s_lr[m]; add(gp + ca, hh); }
+        }
+    __syncthreads();
+    if (tid == 0) {
+        double c = 0;
+        if (has_imu) for (int a = 0; a < 15; a++) c += 0.5 * s_rw[a] * s_rw[a];
+        if (use_lidar) for (int a = 0; a < 6; a++) c += 0.5 * s_lr[a] * s_lr[a];
+        add(cost, c);
+    }
 }
 // J^T [J r] of every IMU factor: one lane per (factor, row a, column b <= 30): 15-term dot products, one atomic each
 __global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, double *gp) {
@@ -486,33 +485,50 @@ __global__ __launch_bounds__(256) void lw_chol_update(int P, double *S, int j0, 
                 if (row < P1 && col < P && col <= row) S[(size_t)row * P + col] -= acc[a][b][q];
             }
 }
-// L^T y = z, z = row P of the factor; one workgroup, columns right to left in 64-blocks: the block's triangle by one wave (lane = row of the block, pivots
-// broadcast through LDS), then every earlier entry subtracts its part — thread per entry, the block's 64 columns of L read along a row (coalesced)
+// L^T y = z, z = row P of the factor; one workgroup, columns right to left in 64-blocks. Per block: wave 0 solves the block's triangle — lane = row, the 64 steps
+// fully unrolled so that the pivot row's value travels by v_readlane (a shuffle per step through LDS and a division per step were most of the 215 us this kernel
+// took), reciprocal diagonal computed once per block — while the other waves already stage the NEXT block's triangle in the second LDS buffer; then every earlier
+// entry subtracts its part, thread per entry, the block's 64 rows of L read along a row (coalesced, eight loads in flight).
+__device__ __forceinline__ double lw_readlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, double *y) {
     extern __shared__ double s_y[];                // P entries
     __shared__ double s_blk[CH_NB], s_tri[CH_NB * CH_LD];
     const int tid = threadIdx.x;
     for (int i = tid; i < P; i += 1024) s_y[i] = S[(size_t)P * P + i];
-    __syncthreads();
     const int nblk = (P + CH_NB - 1) / CH_NB;
+    // element e of a block's triangle; rows / columns past the matrix end: identity (the unrolled solve walks all 64)
+    auto tri_at = [&](int bk, int e) { const int j0 = CH_NB * bk, nb = min(CH_NB, P - j0), r = e >> 6, c = e & 63; return (r < nb && c < nb) ? S[(size_t)(j0 + r) * P + j0 + c] : (r == c ? 1.0 : 0.0); };
+    for (int e = tid; e < CH_NB * CH_NB; e += 1024) s_tri[(e >> 6) * CH_LD + (e & 63)] = tri_at(nblk - 1, e);
+    __syncthreads();
+    constexpr int NST = 1024 - 64, NPER = (CH_NB * CH_NB + NST - 1) / NST;
     for (int bk = nblk - 1; bk >= 0; bk--) {
         const int j0 = CH_NB * bk, nb = min(CH_NB, P - j0);
-        for (int e = tid; e < nb * CH_NB; e += 1024) { const int r = e >> 6, c = e & 63; s_tri[r * CH_LD + c] = (c < nb) ? S[(size_t)(j0 + r) * P + j0 + c] : 0.0; }
-        __syncthreads();
+        double nx[NPER];
         if (tid < 64) {                            // y_blk = L_bb^-T z_blk
             double z = (tid < nb) ? s_y[j0 + tid] : 0.0;
-            for (int j = nb - 1; j >= 0; j--) {
-                const double yj = __shfl(z, j, 64) / s_tri[j * CH_LD + j];
-                if (tid < j) z -= s_tri[j * CH_LD + tid] * yj;
-                if (tid == j) z = yj;
+            const double dinv = 1.0 / s_tri[tid * CH_LD + tid];
+#pragma unroll
+            for (int j = CH_NB - 1; j >= 0; j--) {
+                const double yj = lw_readlane(z, j) * lw_readlane(dinv, j);
+                z = (tid == j) ? yj : ((tid < j) ? z - s_tri[j * CH_LD + tid] * yj : z);
             }
             if (tid < nb) { s_y[j0 + tid] = z; s_blk[tid] = z; }
+        } else if (bk > 0) {                       // meanwhile: the next block's triangle on its way (registers; into LDS once this block's solve is done)
+#pragma unroll
+            for (int u = 0; u < NPER; u++) { const int e = tid - 64 + u * NST; nx[u] = e < CH_NB * CH_NB ? tri_at(bk - 1, e) : 0.0; }
         }
         __syncthreads();
+        if (tid >= 64 && bk > 0) {
+#pragma unroll
+            for (int u = 0; u < NPER; u++) { const int e = tid - 64 + u * NST; if (e < CH_NB * CH_NB) s_tri[(e >> 6) * CH_LD + (e & 63)] = nx[u]; }
+        }
         for (int i = tid; i < j0; i += 1024) {     // z_i -= sum_r L[j0 + r][i] y[j0 + r]
-            double s = 0;
-            for (int r = 0; r < nb; r++) s += S[(size_t)(j0 + r) * P + i] * s_blk[r];
-            s_y[i] -= s;
+            double sum = 0;
+#pragma unroll 8
+            for (int r = 0; r < nb; r++) sum += S[(size_t)(j0 + r) * P + i] * s_blk[r];
+            s_y[i] -= sum;
         }
         __syncthreads();
     }
@@ -759,7 +775,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
                                h->d[D_PH].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, c->pri.as<double>(),
                                (const int *)(c->pri.as<char>() + VB_PRIOR_LD * 8), P, jac ? 1 : 0, c->Hpp.as<double>(), c->gp.as<double>(), scal);
         }
-        hipLaunchKernelGGL(lw_imu_lidar, dim3((nimu + 63) / 64), dim3(64), 0, h->stream, NF, P, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
+        hipLaunchKernelGGL(lw_imu_lidar, dim3(nimu), dim3(128), 0, h->stream, NF, P, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
                            c->Hpp.as<double>(), c->gp.as<double>(), scal, c->jscr.as<double>());
         if (jac) hipLaunchKernelGGL(lw_imu_products, dim3((nimu * 930 + 255) / 256), dim3(256), 0, h->stream, NF, P, c->jscr.as<double>(), c->Hpp.as<double>(), c->gp.as<double>());
         if (jac) toc(0);
