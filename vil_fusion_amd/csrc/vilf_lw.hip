@@ -276,6 +276,20 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(int NF, int P, const double 
         add(cost, c);
     }
 }
+// zero the accumulation targets of one linearisation (Hpp, W, h_f, g_p, g_f) and the cost: four entries per thread
+__global__ __launch_bounds__(256) void lw_clear(double *a0, size_t n0, double *a1, size_t n1, double *a2, size_t n2, double *a3, size_t n3, double *a4, size_t n4, double *cost) {
+    const size_t t0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        size_t t = t0 + u;
+        if (t < n0) { a0[t] = 0.0; continue; } t -= n0;
+        if (t < n1) { a1[t] = 0.0; continue; } t -= n1;
+        if (t < n2) { a2[t] = 0.0; continue; } t -= n2;
+        if (t < n3) { a3[t] = 0.0; continue; } t -= n3;
+        if (t < n4) { a4[t] = 0.0; continue; } t -= n4;
+        if (t == 0) cost[0] = 0.0;
+    }
+}
 // J^T [J r] of every IMU factor: one lane per (factor, row a, column b <= 30): 15-term dot products, one atomic each
 __global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, double *gp) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, k = t / 930, e = t - 930 * k;
@@ -509,12 +523,17 @@ __global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, dou
         if (tid < 64) {                            // y_blk = L_bb^-T z_blk
             double z = (tid < nb) ? s_y[j0 + tid] : 0.0;
             const double dinv = 1.0 / s_tri[tid * CH_LD + tid];
+#pragma unroll 1
+            for (int jc = CH_NB - 16; jc >= 0; jc -= 16) {          // 16 steps at a time: their 16 LDS reads are hoisted in front of the chain, not all 64
 #pragma unroll
-            for (int j = CH_NB - 1; j >= 0; j--) {
-                const double yj = lw_readlane(z, j) * lw_readlane(dinv, j);
-                z = (tid == j) ? yj : ((tid < j) ? z - s_tri[j * CH_LD + tid] * yj : z);
+                for (int k = 15; k >= 0; k--) {
+                    const int j = jc + k;
+                    const double yj = lw_readlane(z, j) * lw_readlane(dinv, j);
+                    z = (tid == j) ? yj : ((tid < j) ? z - s_tri[j * CH_LD + tid] * yj : z);
+                }
             }
-            if (tid < nb) { s_y[j0 + tid] = z; s_blk[tid] = z; }
+            if (tid < nb) s_y[j0 + tid] = z;
+            s_blk[tid] = (tid < nb) ? z : 0.0;
         } else if (bk > 0) {                       // meanwhile: the next block's triangle on its way (registers; into LDS once this block's solve is done)
 #pragma unroll
             for (int u = 0; u < NPER; u++) { const int e = tid - 64 + u * NST; nx[u] = e < CH_NB * CH_NB ? tri_at(bk - 1, e) : 0.0; }
@@ -525,9 +544,16 @@ __global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, dou
             for (int u = 0; u < NPER; u++) { const int e = tid - 64 + u * NST; if (e < CH_NB * CH_NB) s_tri[(e >> 6) * CH_LD + (e & 63)] = nx[u]; }
         }
         for (int i = tid; i < j0; i += 1024) {     // z_i -= sum_r L[j0 + r][i] y[j0 + r]
+            const double *col = S + (size_t)j0 * P + i;
             double sum = 0;
-#pragma unroll 8
-            for (int r = 0; r < nb; r++) sum += S[(size_t)(j0 + r) * P + i] * s_blk[r];
+#pragma unroll 1
+            for (int h = 0; h < CH_NB; h += 16) {  // 16 loads of the lane in flight at a time (rows past the block: clamped, their y is zero)
+                double lv[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) lv[r] = col[(size_t)min(h + r, nb - 1) * P];
+#pragma unroll
+                for (int r = 0; r < 16; r++) sum += lv[r] * s_blk[h + r];
+            }
             s_y[i] -= sum;
         }
         __syncthreads();
@@ -756,11 +782,12 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
     };
     auto evaluate = [&](const std::vector<double> &xx, bool jac, double &cost) -> int {
         HIPCHECK(h, hipMemcpyAsync(c->x.p, xx.data(), xx.size() * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemsetAsync(scal, 0, 8, h->stream));
-        if (jac) {
-            HIPCHECK(h, hipMemsetAsync(c->Hpp.p, 0, sP * sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->W.p, 0, sF * sP * 8, h->stream));
-            HIPCHECK(h, hipMemsetAsync(c->hf.p, 0, sF * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gp.p, 0, sP * 8, h->stream)); HIPCHECK(h, hipMemsetAsync(c->gf.p, 0, sF * 8, h->stream));
-        }
+        if (jac) {      // one launch clears the cost and the five accumulation targets (six fill launches per linearisation were 0.4 ms of a solve)
+            const size_t n5[5] = {sP * sP, sF * sP, sF, sP, sF};
+            const size_t tot = n5[0] + n5[1] + n5[2] + n5[3] + n5[4] + 1;
+            hipLaunchKernelGGL(lw_clear, dim3((unsigned)((tot + 1023) / 1024)), dim3(256), 0, h->stream, c->Hpp.as<double>(), n5[0], c->W.as<double>(), n5[1], c->hf.as<double>(), n5[2],
+                               c->gp.as<double>(), n5[3], c->gf.as<double>(), n5[4], scal);
+        } else HIPCHECK(h, hipMemsetAsync(scal, 0, 8, h->stream));
         if (jac) tic();
         if (nvis && (est_ex || est_td))
             hipLaunchKernelGGL(lw_visual_ext, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->tdrec.as<LwTd>(), c->x.as<double>(), NF, F, P, cEx, cTd,
