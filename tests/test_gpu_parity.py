@@ -257,6 +257,24 @@ def test_marginalization_exact_path(solver, oracle, opts, monkeypatch, n_feature
     assert not np.array_equal(res["fast"][0], res["exact"][0]), "the hook did not switch paths (two different algorithms cannot agree bit for bit)"
 
 
+def test_marginalization_exact_path_workspace_pool(solver, opts, monkeypatch):
+    """The exact path's workspace (rotation log, Amm, X) is a pool of slots shared by the flagged windows, taken in rounds when the pool is smaller than the batch
+    (VILF_MARG_POOL forces that on a small batch): the priors must not depend on the pool size."""
+    wins, priors = synth.make_batch(31, 7, opts, distinct=7)
+    monkeypatch.setenv("VILF_MARG_FORCE_EXACT", "1")
+    out = {}
+    for pool in ("7", "3", "1"):
+        monkeypatch.setenv("VILF_MARG_POOL", pool)
+        solver.batch_upload(wins, priors)
+        solver.batch_solve()
+        solver.batch_marginalize()
+        out[pool] = [_prior_products(solver.get_prior(slot=k)) for k in range(7)]
+    monkeypatch.delenv("VILF_MARG_POOL"); monkeypatch.delenv("VILF_MARG_FORCE_EXACT")
+    for pool in ("3", "1"):
+        for k in range(7):
+            assert np.array_equal(out[pool][k][0], out["7"][k][0]) and np.array_equal(out[pool][k][1], out["7"][k][1]), (pool, k)
+
+
 def test_projection_td_factor_hook(solver, oracle, opts):
     """ProjectionTdFactor on the device (factor level; the device solve itself does not estimate td) vs the oracle, all five blocks."""
     import test_oracle_factors as tof

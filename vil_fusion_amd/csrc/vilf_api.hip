@@ -817,12 +817,17 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     HIPCHECK(h, hipSetDevice(h->device));
     { bool dirty = false; for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty = true; if (dirty) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; } }
     const size_t sB = h->B, sF = h->batch.Fmax, sC = h->batch.FACmax, M = h->mg_Mcap;
+    // the exact (Jacobi) fallback's workspace — rotation log, Amm, X, eigenvalues — is a pool of slots, not one per window: the log alone is 24 (M - 1) M doubles
+    // (20 MB at 300 dropped features). The pool is as large as 8 GB allow; flagged windows beyond it are taken by further launches of the exact pass.
+    const size_t slot_bytes = (MG_SWEEPS * (M - 1) * M + (M > MG_MLDS ? M * M : 0) + M * (MG_NK + 1) + M) * 8;
+    size_t sPool = std::max<size_t>(1, std::min<size_t>(sB, ((size_t)8 << 30) / std::max<size_t>(slot_bytes, 1)));
+    if (const char *e = std::getenv("VILF_MARG_POOL")) sPool = std::max<size_t>(1, std::min<size_t>(sB, (size_t)std::atoi(e)));      // test hook: several rounds on a small batch
     struct Req { int id; size_t bytes; };
     const Req reqs[] = {
         {D_MINFO, sB * MG_INFO * 4}, {D_MF0, sB * sF * 4}, {D_MSTP, sB * 77 * 8}, {D_MSTS, sB * 99 * 8}, {D_MSTF, sB * sF * 8}, {D_MSTE, sB * 7 * 8},
         {D_MBUF, sB * MG_MROW * sC * 8}, {D_MHD, sB * MG_ND * MG_ND * 8}, {D_MGD, sB * MG_ND * 8}, {D_MWF, sB * sF * MG_ND * 8}, {D_MHF, sB * sF * 8},
-        {D_MGF, sB * sF * 8}, {D_MAMM, (M > MG_MLDS ? sB * M * M * 8 : 8)}, {D_MX, sB * M * (MG_NK + 1) * 8}, {D_MROT, sB * MG_SWEEPS * (M - 1) * M * 8},
-        {D_MLAM, sB * M * 8}, {D_MAR, sB * MG_NK * MG_NK * 8}, {D_MBR, sB * MG_NK * 8},
+        {D_MGF, sB * sF * 8}, {D_MAMM, (M > MG_MLDS ? sPool * M * M * 8 : 8)}, {D_MX, sPool * M * (MG_NK + 1) * 8}, {D_MROT, sPool * MG_SWEEPS * (M - 1) * M * 8},
+        {D_MLAM, sPool * M * 8}, {D_MAR, sB * MG_NK * MG_NK * 8}, {D_MBR, sB * MG_NK * 8},
         {D_QLV, sB * MG_NK * (MG_NK + 1) * 8}, {D_QLD, sB * 2 * (MG_NK + 2) * 8}, {D_QLLOG, sB * 2 * QL_RCAP * 8}, {D_QLIT, sB * QL_ICAP * 4}, {D_QLINFO, sB * 4 * 4},
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed (marginalization workspace)"; return VILF_ERR_DEVICE; }
@@ -852,7 +857,12 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     if (prof) hipEventRecord(h->pev[1], h->stream);
     hipLaunchKernelGGL(k_marg_schur, grid, block, (size_t)(MG_MD * MG_MD + MG_MD * (MG_NK + 1) + 1000 + VB_NT) * sizeof(double), h->stream, h->batch, g,
                        std::getenv("VILF_MARG_FORCE_EXACT") ? 2 : 0);      // test hook: exercise the Jacobi path on well-conditioned windows too
-    hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g, 1);
+    g.pool = (int)sPool;
+    for (int r = 0; r < (int)((sB + sPool - 1) / sPool); r++) {      // one launch unless the pool is smaller than the batch (large Mcap)
+        g.pool_round = r;
+        hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g, 1);
+    }
+    g.pool_round = 0;
     if (prof) hipEventRecord(h->pev[2], h->stream);
     // eigen-solver of the kept block in three launches (tred2 per workgroup, the QL recurrence of every window one lane each, rotation replay +
     // prior output per workgroup); k_marg_finish (everything in one workgroup) only takes windows whose rotation log overflowed

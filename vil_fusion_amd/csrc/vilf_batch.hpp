@@ -106,9 +106,11 @@ struct VbMarg {
     double *Hd, *gd;        // [B][MG_ND*MG_ND], [B][MG_ND]    dense-variable normal equations
     double *Wf;             // [B][Fmax][MG_ND]  arrow rows of the start-0 features (indexed by rank)
     double *hfm, *gfm;      // [B][Fmax]
-    double *Amm;            // [B][Mcap*Mcap]    only used when m > MG_MLDS
+    double *Amm;            // [pool][Mcap*Mcap]    only used when m > MG_MLDS
     double *X;              // [B][Mcap][MG_NK+1]
-    double *rot;            // [B][MG_SWEEPS][Mcap-1][Mcap]   (c,s) log of the Jacobi rotations
+    double *rot;            // [pool][MG_SWEEPS][Mcap-1][Mcap]   (c,s) log of the Jacobi rotations
+    int pool, pool_round;   // Amm / X / rot / lam are a pool of `pool` slots for the windows of the exact (Jacobi) path: launch `pool_round` takes the flagged windows of rank
+                            // [pool_round * pool, (pool_round + 1) * pool) (a slot per window would be 20 MB per window at 300 dropped features)
     double *lam;            // [B][Mcap]
     double *Ar, *br;        // [B][MG_NK*MG_NK], [B][MG_NK]
     double *qlV, *qlD, *qlLog;   // eigen-solver split: [B][MG_NK*(MG_NK+1)] tridiagonalising transform, [B][2*(MG_NK+2)] d / e, [B][2*QL_RCAP] (c, s) rotations

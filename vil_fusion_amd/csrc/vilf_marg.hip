@@ -430,13 +430,27 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
     extern __shared__ double s_dyn[];
     __shared__ double s_cs[2 * 512];
     __shared__ int s_flag;
+    // the exact path's workspace is a pool: this window's rank among the flagged ones decides the launch that takes it and its slot there
+    int slot = w;
+    if (exact) {
+        __shared__ int s_rank;
+        if (tid == 0) s_rank = 0;
+        __syncthreads();
+        int cnt = 0;
+        for (int v = tid; v < w; v += NT) { const int *iv = g.info + (size_t)v * MG_INFO; cnt += (iv[0] == 0 && iv[7] == 1) ? 1 : 0; }
+        if (cnt) atomicAdd(&s_rank, cnt);
+        __syncthreads();
+        const int rank = s_rank;
+        if (rank / g.pool != g.pool_round) return;
+        slot = rank % g.pool;
+    }
     const int md = info[1], mf = info[2], n = info[3], m = info[4], M = info[6], H = M / 2;
     const size_t FM = b.Fmax;
     const double *Hd = g.Hd + (size_t)w * MG_ND * MG_ND, *gd = g.gd + (size_t)w * MG_ND;
     const double *Wf = g.Wf + (size_t)w * FM * MG_ND, *hfm = g.hfm + (size_t)w * FM, *gfm = g.gfm + (size_t)w * FM;
-    double *A = (M <= MG_MLDS) ? s_dyn : g.Amm + (size_t)w * g.Mcap * g.Mcap;
+    double *A = (M <= MG_MLDS) ? s_dyn : g.Amm + (size_t)slot * g.Mcap * g.Mcap;
     const int XL = n + 1;
-    double *Xg = g.X + (size_t)w * g.Mcap * (MG_NK + 1);
+    double *Xg = g.X + (size_t)slot * g.Mcap * (MG_NK + 1);
     // ---- arrow fast path -------------------------------------------------------------------------------------------------
     // Amm = [[Hdd, Wd^T], [Wd, D]] with D = diag(h_f): when Amm is positive definite with every eigenvalue above the reference's
     // threshold (1e-8, marginalization_factor.cpp:270) the pseudo-inverse IS the inverse and X^T Amm^-1 X follows from eliminating
@@ -536,9 +550,9 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
         Xg[e] = v;
     }
     __syncthreads();
-    double *rot = g.rot + (size_t)w * MG_SWEEPS * (size_t)(g.Mcap - 1) * g.Mcap;
+    double *rot = g.rot + (size_t)slot * MG_SWEEPS * (size_t)(g.Mcap - 1) * g.Mcap;
     const int sweeps = jacobi_eig<false>(A, M, M, nullptr, rot, s_cs, &s_flag);
-    double *lam = g.lam + (size_t)w * g.Mcap;
+    double *lam = g.lam + (size_t)slot * g.Mcap;
     for (int i = tid; i < M; i += NT) lam[i] = A[i * M + i];
     __syncthreads();
     // replay the rotations on X (X' = V^T X); X lives in LDS when it fits
