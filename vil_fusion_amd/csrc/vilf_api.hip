@@ -855,7 +855,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     if (h->batch.est_td) hipLaunchKernelGGL(k_marg_prepare_td, grid, block, 0, h->stream, h->batch, g);
     else hipLaunchKernelGGL(k_marg_prepare, grid, block, 0, h->stream, h->batch, g);
     if (prof) hipEventRecord(h->pev[1], h->stream);
-    hipLaunchKernelGGL(k_marg_schur, grid, block, (size_t)(MG_MD * MG_MD + MG_MD * (MG_NK + 1) + 1000 + VB_NT) * sizeof(double), h->stream, h->batch, g,
+    hipLaunchKernelGGL(k_marg_schur, grid, block, (size_t)(MG_MD * MG_MD + MG_MD * (MG_NK + 1) + 1000 + VB_NT + MG_FCH * MG_RWP) * sizeof(double), h->stream, h->batch, g,
                        std::getenv("VILF_MARG_FORCE_EXACT") ? 2 : 0);      // test hook: exercise the Jacobi path on well-conditioned windows too
     g.pool = (int)sPool;
     for (int r = 0; r < (int)((sB + sPool - 1) / sPool); r++) {      // one launch unless the pool is smaller than the batch (large Mcap)

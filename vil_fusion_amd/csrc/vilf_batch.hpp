@@ -82,6 +82,8 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
 };
 
 // ---- marginalization workspace (vilf_marg.hip) ---------------------------------------------------------------------
+#define MG_RWP 113          // staged row length: 7 tiles of 16 columns (+ 1: odd stride, no bank conflicts between the four k of an operand read)
+#define MG_FCH 16           // arrow rows staged per chunk in the fast path of k_marg_schur (16 x 118 doubles of LDS)
 #define MG_MD 21            // dropped non-feature variables: Pose[0] 6 + Pose[1] 6 (USE_LIDAR_CONST, estimator.cpp:891) + SpeedBias[0] 9
 #define MG_NK 96            // kept (prior) dimension capacity; the reference's prior never exceeds 75 + td
 #define MG_ND (MG_MD + MG_NK)

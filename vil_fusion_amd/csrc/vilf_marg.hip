@@ -421,6 +421,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
 extern "C" __global__ __launch_bounds__(NT, 2) void k_marg_prepare(VbBatch b, VbMarg g) { marg_prepare_body<false>(b, g); }
 extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare_td(VbBatch b, VbMarg g) { marg_prepare_body<true>(b, g); }
 
+typedef double mg_double4 __attribute__((ext_vector_type(4)));
 extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg g, int exact) {
     const int w = blockIdx.x, tid = threadIdx.x;
     int *info = g.info + (size_t)w * MG_INFO;
@@ -460,23 +461,53 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
     if (!exact) {
         double *s_S = s_dyn, *s_Y = s_S + MG_MD * MG_MD, *s_ih = s_Y + MG_MD * (MG_NK + 1), *s_red = s_ih + VILF_MAX_FEATURES_DEV;   // [md][md], [md][XL], [mf], [NT]
         __shared__ int s_ok;
-        if (tid == 0) s_ok = (md > 0 && md <= MG_MD && mf <= VILF_MAX_FEATURES_DEV) ? 1 : 0;
+        if (tid == 0) s_ok = (md > 0 && md <= MG_MD && mf <= VILF_MAX_FEATURES_DEV && md + n + 1 <= 16 * 7) ? 1 : 0;      // C = 7 x 7 tiles (the reference's prior: n <= 76)
         __syncthreads();
         for (int f = tid; f < mf; f += NT) { const double h = hfm[f]; if (!(h > 0.0)) s_ok = 0; s_ih[f] = 1.0 / h; }
         __syncthreads();
+        // Every product of the fast path with the arrow rows is a block of ONE symmetric matrix C = R^T diag(1 / h_f) R, R = [W_f (md + n columns) | g_f]: the md x md block
+        // of S, the md x (n + 1) block of Y and the feature part of Arr and b_r. C (<= 112 x 112, 28 lower 16 x 16 tiles, seven per wave) is accumulated by
+        // v_mfma_f64_16x16x4_f64 over the features, the rows staged through LDS 16 at a time. (Three scalar loops used to read every row from global memory once per
+        // ENTRY of their result: 2.5 ms per step.) Tile t of wave w is the (ti, tj) of index 7 w + t in row-major lower-triangle order.
+        mg_double4 T[7];
+        int tti[7], ttj[7];
+#pragma unroll
+        for (int t = 0; t < 7; t++) {
+            const int q = 7 * (tid >> 6) + t;
+            int ti = 0;
+            while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
+            tti[t] = ti; ttj[t] = q - ti * (ti + 1) / 2;
+            T[t] = mg_double4{0.0, 0.0, 0.0, 0.0};
+        }
+        const int RW = md + n + 1, lane = tid & 63, l16 = lane & 15, l4 = lane >> 4;
+        double *s_w = s_red + NT;                                   // [MG_FCH][MG_RWP]
         if (s_ok) {
-            for (int e = tid; e < md * md; e += NT) {
-                const int i = e / md, j = e - md * i;
-                double v = 0.5 * (Hd[i * MG_ND + j] + Hd[j * MG_ND + i]);
-                for (int f = 0; f < mf; f++) v -= Wf[(size_t)f * MG_ND + i] * Wf[(size_t)f * MG_ND + j] * s_ih[f];
-                s_S[e] = v;
+            for (int f0 = 0; f0 < mf; f0 += MG_FCH) {
+                __syncthreads();
+                for (int e = tid; e < MG_FCH * MG_RWP; e += NT) {
+                    const int f = e / MG_RWP, c = e - MG_RWP * f;
+                    s_w[e] = (f0 + f < mf && c < RW) ? ((c < RW - 1) ? Wf[(size_t)(f0 + f) * MG_ND + c] : gfm[f0 + f]) : 0.0;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int ks = 0; ks < MG_FCH / 4; ks++) {
+                    const int k = 4 * ks + l4;
+                    const double ihk = (f0 + k < mf) ? s_ih[f0 + k] : 0.0;
+                    const double *row = s_w + k * MG_RWP;
+#pragma unroll
+                    for (int t = 0; t < 7; t++) T[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(row[16 * tti[t] + l16], row[16 * ttj[t] + l16] * ihk, T[t], 0, 0, 0);
+                }
             }
-            for (int e = tid; e < md * XL; e += NT) {
-                const int i = e / XL, k = e - XL * i;
-                double v = (k < n) ? Hd[i * MG_ND + md + k] : gd[i];
-                for (int f = 0; f < mf; f++) v -= Wf[(size_t)f * MG_ND + i] * ((k < n) ? Wf[(size_t)f * MG_ND + md + k] : gfm[f]) * s_ih[f];
-                s_Y[e] = v;
-            }
+            __syncthreads();
+            // S = 0.5 (Hdd + Hdd^T) - C_dd and Y = [Hdr | g_d] - C_d,(r | rhs) to LDS; the rest of C stays in the tiles for Arr below. Element q of a tile: row l4 + 4 q, column l16.
+#pragma unroll
+            for (int t = 0; t < 7; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int r = 16 * tti[t] + l4 + 4 * q, c = 16 * ttj[t] + l16, lo = min(r, c), hi = max(r, c);
+                    if (hi < md) { const double v = 0.5 * (Hd[lo * MG_ND + hi] + Hd[hi * MG_ND + lo]) - T[t][q]; s_S[r * md + c] = v; s_S[c * md + r] = v; }
+                    else if (lo < md && hi < RW) { const int k = hi - md; s_Y[lo * XL + k] = ((k < n) ? Hd[lo * MG_ND + md + k] : gd[lo]) - T[t][q]; }
+                }
             __syncthreads();
             for (int j = 0; j < md; j++) {                      // in-place lower Cholesky of S (md <= 21)
                 if (tid == 0) { const double d = s_S[j * md + j]; if (!(d > 0.0)) s_ok = 0; s_S[j * md + j] = sqrt(d > 0.0 ? d : 1.0); }
@@ -516,14 +547,27 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
         }
         if (s_ok) {
             double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
-            for (int e = tid; e < n * XL; e += NT) {
-                const int i = e / XL, j = e - XL * i;
-                double sacc = 0;
-                for (int f = 0; f < mf; f++) sacc += Wf[(size_t)f * MG_ND + md + i] * ((j < n) ? Wf[(size_t)f * MG_ND + md + j] : gfm[f]) * s_ih[f];
-                for (int t = 0; t < md; t++) sacc += s_Y[t * XL + i] * s_Y[t * XL + j];
-                if (j < n) Ar[i * MG_NK + j] = Hd[(md + i) * MG_ND + md + j] - sacc;
-                else br[i] = gd[md + i] - sacc;
+            // Arr - (feature part, in the tiles) - Z^T Z: the second product by MFMA too (K = md, rows of Z = L^-1 Y from LDS, shifted by md against the tile grid)
+#pragma unroll
+            for (int ks = 0; ks < (MG_MD + 3) / 4; ks++) {
+                const int k = 4 * ks + l4;
+#pragma unroll
+                for (int t = 0; t < 7; t++) {
+                    const int ca = 16 * tti[t] + l16 - md, cb = 16 * ttj[t] + l16 - md;
+                    const double za = (k < md && ca >= 0 && ca < XL) ? s_Y[k * XL + ca] : 0.0, zb = (k < md && cb >= 0 && cb < XL) ? s_Y[k * XL + cb] : 0.0;
+                    T[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, zb, T[t], 0, 0, 0);
+                }
             }
+#pragma unroll
+            for (int t = 0; t < 7; t++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = 16 * tti[t] + l4 + 4 * q - md, j = 16 * ttj[t] + l16 - md;       // C index -> kept index (n = the right-hand side column / row)
+                    if (i < 0 || j < 0 || i > n || j > n) continue;
+                    const double sacc = T[t][q];
+                    if (i < n) { if (j < n) Ar[i * MG_NK + j] = Hd[(md + i) * MG_ND + md + j] - sacc; else br[i] = gd[md + i] - sacc; }
+                    if (tti[t] != ttj[t] && j < n) { if (i < n) Ar[j * MG_NK + i] = Hd[(md + j) * MG_ND + md + i] - sacc; else br[j] = gd[md + j] - sacc; }
+                }
             if (tid == 0) info[7] = 0;
             return;
         }
