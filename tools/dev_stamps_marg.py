@@ -1,0 +1,16 @@
+# phase stamps of k_marg_prepare (diagnostic build: tools/dev_stamps_marg.sh). One mid-grid workgroup, cycles between consecutive stamps.
+import sys, ctypes as C
+sys.path.insert(0, '.')
+import numpy as np
+import bench
+sys.argv = [sys.argv[0], "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--ragged-windows", "0", "--no-lidar-stage", "--no-pcie"]
+bench.main()
+from vil_fusion_amd import lib
+L = lib.lib()
+buf = (C.c_longlong * 128)()
+L.vilf_debug_stamps_marg.argtypes = [C.POINTER(C.c_longlong)]
+L.vilf_debug_stamps_marg(buf)
+a = np.array(buf[:]).reshape(4, 32)
+v = a[0]
+idx = [i for i in range(32) if v[i]]
+print("k_marg_prepare stamps:", [(idx[k + 1], int(v[idx[k + 1]] - v[idx[k]])) for k in range(len(idx) - 1)], "total", int(v[idx[-1]] - v[idx[0]]))

@@ -29,6 +29,16 @@ __device__ __forceinline__ void rr_pair(int round, int k, int M, int &p, int &q)
 
 // Parallel two-sided cyclic Jacobi on a symmetric M x M matrix (M even, row stride ld). WITH_V: accumulate V <- V J.
 // rotlog (optional): (c, s) of every pair of every round, [sweep][round][M/2][2]. Returns the number of sweeps run.
+// In-kernel phase stamps: diagnostic build only (make HIPFLAGS+=-DVILF_STAMPS); workgroup MG_STAMP_WG writes them.
+#ifdef VILF_STAMPS
+__device__ long long mg_dbg[4 * 32];
+#define MG_STAMP_WG 1500
+#define MG_STAMP(kid, i) do { if (blockIdx.x == MG_STAMP_WG && threadIdx.x == 0) mg_dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
+extern "C" int vilf_debug_stamps_marg(long long *out128) { return hipMemcpyFromSymbol(out128, HIP_SYMBOL(mg_dbg), sizeof(long long) * 4 * 32) == hipSuccess ? 0 : -1; }
+#else
+#define MG_STAMP(kid, i) do { } while (0)
+#endif
+
 template <bool WITH_V>
 __device__ int jacobi_eig(double *A, int M, int ld, double *V, double *rotlog, double *s_cs, int *s_flag) {
     const int tid = threadIdx.x, H = M / 2;
@@ -84,6 +94,7 @@ __device__ int jacobi_eig(double *A, int M, int ld, double *V, double *rotlog, d
 template <bool TD>
 __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg &g) {
     const int w = blockIdx.x, tid = threadIdx.x;
+    MG_STAMP(0, 0);
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ex[7], s_ric[9], s_dx[VB_PRIOR_LD], s_J[15 * 32], s_r[16], s_lJ[72], s_lr[8];
     __shared__ double s_pm[10 * MG_PAIRM];
     __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_pcl[VB_NPAIR];     // pair table: start inside the class list, factor count, class
@@ -119,6 +130,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     }
     if (tid < VB_NPAIR) { const int *pt = b.pair_off + (size_t)w * VB_PTAB; const int v1 = pt[2 * tid + 1]; s_pst[tid] = pt[2 * tid]; s_pcn[tid] = v1 & 0xffffff; s_pcl[tid] = v1 >> 24; }
     __syncthreads();
+    MG_STAMP(0, 1);
     if (tid < 77) g.st_pose[(size_t)w * 77 + tid] = s_pose[tid];
     if (tid < 99) g.st_sb[(size_t)w * 99 + tid] = s_sb[tid];
     if (tid < 7) g.st_ex[(size_t)w * 7 + tid] = s_ex[tid];
@@ -127,6 +139,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     __shared__ int s_fw[NT / 64], s_mf, s_maxobs;
     if (tid == 0) { s_mf = 0; s_maxobs = 0; }
     __syncthreads();
+    MG_STAMP(0, 2);
     if (mode == 0) {
         for (int f0 = 0; f0 < F; f0 += NT) {
             const int f = f0 + tid;
@@ -140,12 +153,15 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             if ((tid & 63) == 63) s_fw[tid >> 6] = incl;
             if ((tid & 63) == 0 && mx > 0) atomicMax(&s_maxobs, mx);
             __syncthreads();
+    MG_STAMP(0, 3);
             int off = s_mf;
             for (int k = 0; k < (tid >> 6); k++) off += s_fw[k];
             if (f < F) f0rank[f] = flag ? off + incl - 1 : -1;
             __syncthreads();
+    MG_STAMP(0, 4);
             if (tid == 0) { int t = 0; for (int k = 0; k < NT / 64; k++) t += s_fw[k]; s_mf += t; }
             __syncthreads();
+    MG_STAMP(0, 5);
         }
     } else for (int f = tid; f < F; f += NT) f0rank[f] = -1;
     // ---- variable tables (thread 0): dense variables = dropped non-feature blocks, then kept blocks ascending in id ------
@@ -200,6 +216,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         s_hdr[0] = status; s_hdr[1] = md; s_hdr[2] = mf; s_hdr[3] = n;
     }
     __syncthreads();
+    MG_STAMP(0, 6);
     if (s_hdr[0] != 0) return;
     const int md = s_hdr[1], n = s_hdr[3], nd = md + n;
     double *Hd = g.Hd + (size_t)w * MG_ND * MG_ND, *gd = g.gd + (size_t)w * MG_ND;
@@ -208,6 +225,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     // ---- prior factor: dx (marginalization_factor.cpp:345-363) and column map -------------------------------------------
     if (tid < VB_PRIOR_LD) { s_dx[tid] = 0.0; s_pmap[tid] = -1; }
     __syncthreads();
+    MG_STAMP(0, 7);
     if (have_prior && tid < phdr[2]) {
         const int id = phdr[3 + tid], size = phdr[27 + tid], idx = phdr[51 + tid];
         const double *x0 = b.prior_x0 + ((size_t)w * 24 + tid) * 9;
@@ -227,6 +245,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     if (tid < 16) s_r[tid] = 0.0;
     if (tid < 8) s_lr[tid] = 0.0;
     __syncthreads();
+    MG_STAMP(0, 8);
     if (mode == 0) {
         if (tid == 0) {
             const double *rec = b.imu + ((size_t)w * 10) * IMU_REC;
@@ -244,6 +263,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         }
     }
     __syncthreads();
+    MG_STAMP(0, 9);
     // sqrt_info multiplication of the IMU block (31 columns incl. the residual), in registers then back
     {
         const double *S = b.imu + ((size_t)w * 10) * IMU_REC + IMU_SQRT;
@@ -254,10 +274,12 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             if (e < 15 * 31) { const int row = e / 31, col = e - 31 * row; double s = 0; for (int m2 = row; m2 < 15; m2++) s += S[15 * row + m2] * s_J[32 * m2 + col]; acc[t] = s; }
         }
         __syncthreads();
+    MG_STAMP(0, 10);
         if (e0 < 15 * 31) s_J[32 * (e0 / 31) + (e0 % 31)] = acc[0];
         if (e1 < 15 * 31) s_J[32 * (e1 / 31) + (e1 % 31)] = acc[1];
     }
     __syncthreads();
+    MG_STAMP(0, 11);
     // ---- visual factors of the start-frame-0 features: thread per factor -> Mbuf (slot order) ---------------------------
     double *Mb = g.Mbuf + (size_t)w * MG_MROW * FC;
     if (mode == 0) {
@@ -296,6 +318,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         }
     }
     __syncthreads();
+    MG_STAMP(0, 12);
     // ---- per pair (0, j): [J0 Jj Jex Jtd r]^T [J0 Jj Jex Jtd r] (20 x 20, upper triangle; the td column is zero without estimate_td) over the pair's factors. The factor rows of a pair
     // are staged through LDS in chunks (one coalesced 320-byte row per factor) and every entry is one thread's running sum over the
     // factors in pair order — the same summation order as a per-entry gather from global memory, without its dependent loads.
@@ -314,13 +337,16 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
                 const int nr = min(MG_GCH, q1 - c0);
                 for (int idx = tid; idx < nr * MG_MROW; idx += NT) { const int r = idx / MG_MROW, comp = idx - MG_MROW * r; s_rows[idx] = Mb[(size_t)ps_slot[VB_SLOT(pcl, c0 + r)] * MG_MROW + comp]; }
                 __syncthreads();
+    MG_STAMP(0, 13);
                 if (tid < 210) for (int r = 0; r < nr; r++) { const double *row = s_rows + r * MG_MROW; sum += row[cu0] * row[cv0] + row[cu1] * row[cv1]; }
                 __syncthreads();
+    MG_STAMP(0, 14);
             }
             if (tid < 210) s_pm[jj * MG_PAIRM + 20 * u + v] = sum;
         }
     }
     __syncthreads();
+    MG_STAMP(0, 15);
     // ---- dense-variable normal equations: owner-computes over the (nd x nd) entries ---------------------------------------
     {
         const int opose0 = s_off_pose[0], opose1 = s_off_pose[1], osb0 = s_off_sb[0], osb1 = s_off_sb[1], oex = s_off_ex;
@@ -336,6 +362,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             else gd[du] += s;
         }
         __syncthreads();
+    MG_STAMP(0, 16);
         for (int e = tid; e < 13 * 12; e += NT) {     // LiDAR between-factor (unweighted jacobian, weighted residual: reference quirk)
             const int u = e / 13, v = e - 13 * u;
             double s = 0;
@@ -347,6 +374,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         (void)oex;
     }
     __syncthreads();
+    MG_STAMP(0, 17);
     // every pass above/below writes each address at most once and passes are separated by barriers: the summation order per
     // address is fixed (IMU, LiDAR, prior, visual) => bit-reproducible.
     if (have_prior) {
@@ -366,25 +394,34 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         }
     }
     __syncthreads();
+    MG_STAMP(0, 18);
     if (mode == 0) {
         // visual dense blocks: P0 x P0, P0 x Pj, P0 x Ex, Pj x Pj, Pj x Ex, Ex x Ex (+ rhs), summed over j in fixed order
         const int o0 = s_off_pose[0], oex = s_off_ex, otd = s_off_td;
-        for (int e = tid; e < nd * (nd + 1); e += NT) {
-            const int du = e / (nd + 1), dv = e - (nd + 1) * du;      // dv == nd: rhs
-            double s = 0;
-            bool any = false;
-            for (int jj = 0; jj < 10; jj++) {
-                const int oj = s_off_pose[jj + 1];
-                if (s_pcn[pair_index_c(0, jj + 1)] == 0) continue;
-                auto xcol = [&](int d) -> int { if (d >= o0 && d < o0 + 6) return d - o0; if (oj >= 0 && d >= oj && d < oj + 6) return 6 + d - oj; if (oex >= 0 && d >= oex && d < oex + 6) return 12 + d - oex; if (otd >= 0 && d == otd) return 18; return -1; };
-                const int u = xcol(du), v = (dv == nd) ? 19 : xcol(dv);
-                if (u < 0 || v < 0) continue;
-                s += (u <= v) ? s_pm[jj * MG_PAIRM + 20 * u + v] : s_pm[jj * MG_PAIRM + 20 * v + u];
-                any = true;
+        // one thread per entry (u, v) of the pairs' 19 x 20 blocks [J0 Jj Jex Jtd | r] (v == 19: right-hand side): its target in Hd / gd is fixed unless u or v lies in the
+        // Pj block, where it moves with the pair. (Walking the nd x (nd + 1) targets instead and searching, per target and pair, for the block column that maps
+        // to it was 150 k cycles of integer work per window.) Same sums in the same order: pairs ascending, one += per target.
+        for (int e = tid; e < 19 * 20; e += NT) {
+            const int u = e / 20, v = e - 20 * u;
+            const int ub = u < 6 ? o0 + u : (u < 12 ? -2 : (u < 18 ? (oex >= 0 ? oex + u - 12 : -1) : otd));          // -2: moves with the pair, -1: absent
+            const int vb = v == 19 ? -3 : (v < 6 ? o0 + v : (v < 12 ? -2 : (v < 18 ? (oex >= 0 ? oex + v - 12 : -1) : otd)));    // -3: rhs
+            if (ub == -1 || vb == -1) continue;
+            const int pe = (u <= v) ? 20 * u + v : 20 * v + u;
+            if (ub != -2 && vb != -2) {
+                double sum = 0; bool any = false;
+                for (int jj = 0; jj < 10; jj++) if (s_pcn[pair_index_c(0, jj + 1)] != 0) { sum += s_pm[jj * MG_PAIRM + pe]; any = true; }
+                if (any) { if (vb == -3) gd[ub] += sum; else Hd[ub * MG_ND + vb] += sum; }
+            } else {
+                for (int jj = 0; jj < 10; jj++) {
+                    const int oj = s_off_pose[jj + 1];
+                    if (s_pcn[pair_index_c(0, jj + 1)] == 0 || oj < 0) continue;
+                    const int du = ub == -2 ? oj + u - 6 : ub, dv = vb == -2 ? oj + v - 6 : vb;
+                    double sum = 0; sum += s_pm[jj * MG_PAIRM + pe];
+                    if (vb == -3) gd[du] += sum; else Hd[du * MG_ND + dv] += sum;
+                }
             }
-            if (!any) continue;
-            if (dv == nd) gd[du] += s; else Hd[du * MG_ND + dv] += s;
         }
+        MG_STAMP(0, 20);
         // per-feature arrow rows
         double *Wf = g.Wf + (size_t)w * FM * MG_ND, *hfm = g.hfm + (size_t)w * FM, *gfm = g.gfm + (size_t)w * FM;
         for (int f = tid; f < F; f += NT) {
@@ -412,6 +449,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             hfm[rk] = h; gfm[rk] = gg;
         }
     }
+    MG_STAMP(0, 21);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
