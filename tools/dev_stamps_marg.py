@@ -14,3 +14,4 @@ a = np.array(buf[:]).reshape(4, 32)
 v = a[0]
 idx = [i for i in range(32) if v[i]]
 print("k_marg_prepare stamps:", [(idx[k + 1], int(v[idx[k + 1]] - v[idx[k]])) for k in range(len(idx) - 1)], "total", int(v[idx[-1]] - v[idx[0]]))
+print("pair-loop sums (thread 0): top, stage, barrier, mfma, barrier:", [int(x) for x in a[0][24:30]])

@@ -35,8 +35,14 @@ __device__ long long mg_dbg[4 * 32];
 #define MG_STAMP_WG 1500
 #define MG_STAMP(kid, i) do { if (blockIdx.x == MG_STAMP_WG && threadIdx.x == 0) mg_dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 extern "C" int vilf_debug_stamps_marg(long long *out128) { return hipMemcpyFromSymbol(out128, HIP_SYMBOL(mg_dbg), sizeof(long long) * 4 * 32) == hipSuccess ? 0 : -1; }
+#define MG_ACC_DECL long long macc[6] = {0, 0, 0, 0, 0, 0}; long long macc_last = __builtin_readcyclecounter();
+#define MG_ACC(i) do { const long long now_ = __builtin_readcyclecounter(); macc[i] += now_ - macc_last; macc_last = now_; } while (0)
+#define MG_ACC_OUT(kid) do { if (blockIdx.x == MG_STAMP_WG && threadIdx.x == 0) for (int i_ = 0; i_ < 6; i_++) mg_dbg[(kid) * 32 + 24 + i_] = macc[i_]; } while (0)
 #else
 #define MG_STAMP(kid, i) do { } while (0)
+#define MG_ACC_DECL
+#define MG_ACC(i) do { } while (0)
+#define MG_ACC_OUT(kid) do { } while (0)
 #endif
 
 template <bool WITH_V>
@@ -90,6 +96,7 @@ __device__ int jacobi_eig(double *A, int M, int ld, double *V, double *rotlog, d
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+typedef double mgp_double4 __attribute__((ext_vector_type(4)));
 // TD = estimate_td: the ProjectionTdFactor evaluation costs 100+ VGPRs more than ProjectionFactor; compiled apart so that the KITTI case keeps two workgroups per CU.
 template <bool TD>
 __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg &g) {
@@ -99,6 +106,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     __shared__ double s_pm[10 * MG_PAIRM];
     __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_pcl[VB_NPAIR];     // pair table: start inside the class list, factor count, class
     __shared__ double s_td;
+    __shared__ int s_slots[MG_SLOTS], s_pend[10];                 // Mbuf row of the t-th start-frame-0 factor (evaluation order = pair order); cumulative factor count per pair
     int *info = g.info + (size_t)w * MG_INFO;
     const int F = b.n_feat[w];
     const size_t FM = b.Fmax, FC = b.FACmax;
@@ -167,33 +175,32 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     // ---- variable tables (thread 0): dense variables = dropped non-feature blocks, then kept blocks ascending in id ------
     if (tid == 0) {
         int status = 0, md = 0, mf = 0, n = 0, nb = 0;
-        bool present[2 * VB_NF + 2];
-        for (int i = 0; i < 2 * VB_NF + 2; i++) present[i] = false;
-        bool drop[2 * VB_NF + 2];
-        for (int i = 0; i < 2 * VB_NF + 2; i++) drop[i] = false;
-        if (have_prior) for (int i = 0; i < phdr[2]; i++) present[phdr[3 + i]] = true;
+        unsigned present = 0, drop = 0;          // bit per block id (dynamically indexed bool arrays lived in scratch memory: this serial section took 70 k cycles)
+#define MG_SET(m, i) ((m) |= 1u << (i))
+#define MG_HAS(m, i) (((m) >> (i)) & 1u)
+        if (have_prior) for (int i = 0; i < phdr[2]; i++) MG_SET(present, phdr[3 + i]);
         if (mode == 0) {     // MARGIN_OLD
-            present[0] = present[1] = true; drop[0] = true;
-            present[VB_NF] = true; drop[VB_NF] = true;
-            if (b.use_lidar) drop[1] = true;                                           // estimator.cpp:886-895 drop_set {0,1}
+            MG_SET(present, 0); MG_SET(present, 1); MG_SET(drop, 0);
+            MG_SET(present, VB_NF); MG_SET(drop, VB_NF);
+            if (b.use_lidar) MG_SET(drop, 1);                                           // estimator.cpp:886-895 drop_set {0,1}
             const double *rec = b.imu + ((size_t)w * 10) * IMU_REC;
-            if (rec[0] < 10.0) present[VB_NF + 1] = true;                                // :896-905
+            if (rec[0] < 10.0) MG_SET(present, VB_NF + 1);                                // :896-905
             mf = s_mf;                                                                   // features observed from frame 0 (:921-950)
-            for (int j = 1; j < s_maxobs && j < VB_NF; j++) present[j] = true;
-            if (mf > 0) present[2 * VB_NF] = true;
-            if (mf > 0 && TD) present[2 * VB_NF + 1] = true;                      // para_Td of the ProjectionTdFactors (estimator.cpp:930-935)
+            for (int j = 1; j < s_maxobs && j < VB_NF; j++) MG_SET(present, j);
+            if (mf > 0) MG_SET(present, 2 * VB_NF);
+            if (mf > 0 && TD) MG_SET(present, 2 * VB_NF + 1);                      // para_Td of the ProjectionTdFactors (estimator.cpp:930-935)
         } else {             // MARGIN_SECOND_NEW: only the prior, drop Pose[WINDOW_SIZE-1] (:986-1003)
-            if (!have_prior || !present[VB_NF - 2]) status = 2;                          // nothing to do: prior stays as it is
-            drop[VB_NF - 2] = true;
+            if (!have_prior || !MG_HAS(present, VB_NF - 2)) status = 2;                          // nothing to do: prior stays as it is
+            MG_SET(drop, VB_NF - 2);
         }
         int off = 0;
         for (int a = 0; a < VB_NF; a++) s_off_pose[a] = -1;
         s_off_sb[0] = s_off_sb[1] = -1; s_off_ex = -1; s_off_td = -1;
-        for (int id = 0; id < 2 * VB_NF + 1 && status == 0; id++) if (present[id] && drop[id]) {
+        for (int id = 0; id < 2 * VB_NF + 1 && status == 0; id++) if (MG_HAS(present, id) && MG_HAS(drop, id)) {
             if (id < VB_NF) { s_off_pose[id] = off; off += 6; } else if (id < 2 * VB_NF) { if (id - VB_NF < 2) s_off_sb[id - VB_NF] = off; else status = 3; off += 9; }
         }
         md = off;
-        for (int id = 0; id < 2 * VB_NF + 2 && status == 0; id++) if (present[id] && !drop[id]) {
+        for (int id = 0; id < 2 * VB_NF + 2 && status == 0; id++) if (MG_HAS(present, id) && !MG_HAS(drop, id)) {
             int size = 7, loc = 6, sid;
             if (id < VB_NF) { s_off_pose[id] = off; }
             else if (id < 2 * VB_NF) { if (id - VB_NF < 2) s_off_sb[id - VB_NF] = off; else status = 3; size = 9; loc = 9; }
@@ -301,6 +308,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             for (int k = 0; k < 3; k++) { pts_i[k] = rec[k]; pts_j[k] = rec[3 + k]; }
             const long long ra = __double_as_longlong(rec[6]), rb = __double_as_longlong(rec[7]);
             const int f = (int)(ra & 0xffffffffll), slot = (int)(ra >> 32), fj = (int)((rb >> 8) & 255);
+            if (t < MG_SLOTS) s_slots[t] = slot;
             double r[2], Ji[12], Jj[12], Jf[2], Jex[12], Jtd[2] = {0.0, 0.0};
             if (TD) {         // ProjectionTdFactor (estimator.cpp:930-935): the observations shifted by the pixel velocity over td (+ rolling-shutter row time)
                 const int oj = b.ps_obs[(size_t)w * FC + q], oi = b.f_obs0[(size_t)w * FM + f];
@@ -325,25 +333,82 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     if (mode == 0) {
         __shared__ double s_rows[MG_GCH * MG_MROW];
         const int *ps_slot = b.ps_slot + (size_t)w * FC;
-        int u = 0, v = 0;
-        if (tid < 210) { int e = tid; while (e >= 20 - u) { e -= 20 - u; u++; } v = u + e; }      // upper-triangle entry tid -> (u <= v)
-        // column u of X: 0..5 J0, 6..11 Jj, 12..17 Jex, 18 Jtd, 19 r  -> Mbuf component rows (row0, row1)
-        const int cu0 = (u < 18) ? (12 * (u / 6) + (u % 6)) : (u == 18 ? 40 : 38), cu1 = (u < 18) ? cu0 + 6 : cu0 + 1;
-        const int cv0 = (v < 18) ? (12 * (v / 6) + (v % 6)) : (v == 18 ? 40 : 38), cv1 = (v < 18) ? cv0 + 6 : cv0 + 1;
-        for (int jj = 0; jj < 10; jj++) {
-            const int p = pair_index_c(0, jj + 1), q0 = s_pst[p], q1 = q0 + s_pcn[p], pcl = s_pcl[p];
-            double sum = 0;
-            for (int c0 = q0; c0 < q1; c0 += MG_GCH) {
-                const int nr = min(MG_GCH, q1 - c0);
-                for (int idx = tid; idx < nr * MG_MROW; idx += NT) { const int r = idx / MG_MROW, comp = idx - MG_MROW * r; s_rows[idx] = Mb[(size_t)ps_slot[VB_SLOT(pcl, c0 + r)] * MG_MROW + comp]; }
-                __syncthreads();
-    MG_STAMP(0, 13);
-                if (tid < 210) for (int r = 0; r < nr; r++) { const double *row = s_rows + r * MG_MROW; sum += row[cu0] * row[cv0] + row[cu1] * row[cv1]; }
-                __syncthreads();
-    MG_STAMP(0, 14);
+        // the factor rows in evaluation order (pair after pair), MG_GCH at a time through LDS — a chunk spans several pairs, so the whole walk is a handful of memory
+        // round trips (one chunk per pair, its row indices fetched first, was ten times two dependent ones); a thread's running sum is flushed where a pair ends
+        if (tid < 10) { int c = 0; for (int k = 0; k <= tid; k++) c += s_pcn[pair_index_c(0, k + 1)]; s_pend[tid] = c; }
+        __syncthreads();
+        const int ntot = s_pend[9];
+        // X^T X per pair on the MFMA: X = the pair's factor rows as 2 n x 20 ([J0 Jj Jex Jtd r], two residual rows per factor), 20 -> 32 columns = the lower tiles (0,0),
+        // (1,0), (1,1), one per wave; a k-step is four X rows = two factors read from the staged chunk. (A thread per entry summing over the rows spent 250 k cycles per
+        // window in LDS reads.) The accumulators live across chunks and are flushed where a pair ends.
+        const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15, l4 = lane >> 4;
+        const int ti = wave == 0 ? 0 : 1, tj = wave == 2 ? 1 : 0, sub = l4 & 1;
+        auto comp_of = [&](int c) -> int { return c < 18 ? 12 * (c / 6) + (c % 6) + 6 * sub : (c == 18 ? 40 + sub : (c == 19 ? 38 + sub : -1)); };      // X column -> Mbuf row component
+        const int compA = comp_of(16 * ti + l16), compB = comp_of(16 * tj + l16);
+        mgp_double4 T = {0.0, 0.0, 0.0, 0.0};
+        int jj = 0;
+        auto flush = [&]() {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int uu = 16 * ti + l4 + 4 * q, vv = 16 * tj + l16; if (uu < 20 && vv <= uu) s_pm[jj * MG_PAIRM + 20 * vv + uu] = T[q]; }
+            T = mgp_double4{0.0, 0.0, 0.0, 0.0};
+            jj++;
+        };
+        MG_ACC_DECL
+        for (int t0 = 0; t0 < ntot; t0 += MG_GCH) {
+            const int nr = min(MG_GCH, ntot - t0);
+            MG_ACC(0);
+            {   // all of the thread's loads of the chunk in flight at once (a plain loop waited for every load before issuing the next: sixteen memory round trips per chunk):
+                // first the row indices (LDS), then the loads, then the stores
+                constexpr int NLD = (MG_GCH * MG_MROW + NT - 1) / NT;
+                int off[NLD];
+                double vals[NLD];
+                if (t0 + nr <= MG_SLOTS) {
+#pragma unroll
+                    for (int k = 0; k < NLD; k++) { const int idx = min(tid + NT * k, nr * MG_MROW - 1), r = idx / MG_MROW; off[k] = s_slots[t0 + r] * MG_MROW + (idx - MG_MROW * r); }
+                } else {
+#pragma unroll 1
+                    for (int k = 0; k < NLD; k++) {
+                        const int idx = min(tid + NT * k, nr * MG_MROW - 1), r = idx / MG_MROW;
+                        int rem = t0 + r, q = 0;
+                        for (int kk = 0; kk < 10; kk++) { const int pj = pair_index_c(0, kk + 1), nseg = s_pcn[pj]; if (rem >= 0) { if (rem < nseg) { q = VB_SLOT(s_pcl[pj], s_pst[pj] + rem); rem = -1; } else rem -= nseg; } }
+                        const int o = ps_slot[q] * MG_MROW + (idx - MG_MROW * r);
+#pragma unroll
+                        for (int k2 = 0; k2 < NLD; k2++) if (k2 == k) off[k2] = o;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NLD; k++) vals[k] = Mb[(size_t)off[k]];
+#pragma unroll
+                for (int k = 0; k < NLD; k++) { const int idx = tid + NT * k; if (idx < nr * MG_MROW) s_rows[idx] = vals[k]; }
             }
-            if (tid < 210) s_pm[jj * MG_PAIRM + 20 * u + v] = sum;
+            MG_ACC(1);
+            __syncthreads();
+            MG_ACC(2);
+            if (wave < 3) {
+                int r = 0;
+                while (r < nr) {
+                    while (jj < 10 && t0 + r >= s_pend[jj]) flush();                   // pairs that ended (or are empty) before this row
+                    const int rend = min(nr, s_pend[jj] - t0);                        // this pair's rows inside the chunk: [r, rend)
+                    for (int fr0 = r; fr0 < rend; fr0 += 8) {                        // four k-steps (eight factors) per trip: their eight LDS reads first, then the MFMAs
+                        double av[4], bv[4];
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; k4++) {
+                            const int fr = fr0 + 2 * k4 + (l4 >> 1), frc = min(fr, rend - 1);
+                            const double a_ = s_rows[frc * MG_MROW + max(compA, 0)], b_ = s_rows[frc * MG_MROW + max(compB, 0)];
+                            av[k4] = (fr < rend && compA >= 0) ? a_ : 0.0; bv[k4] = (fr < rend && compB >= 0) ? b_ : 0.0;
+                        }
+#pragma unroll
+                        for (int k4 = 0; k4 < 4; k4++) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4], bv[k4], T, 0, 0, 0);
+                    }
+                    r = rend;
+                }
+            }
+            MG_ACC(3);
+            __syncthreads();
+            MG_ACC(4);
         }
+        MG_ACC_OUT(0);
+        if (wave < 3) while (jj < 10) flush();
     }
     __syncthreads();
     MG_STAMP(0, 15);
@@ -389,7 +454,8 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             const int di = s_pmap[i];
             if (di < 0) continue;
             double s = pg[i];
-            for (int k = 0; k < pn; k++) s += pH[i * VB_PRIOR_LD + k] * s_dx[k];
+#pragma unroll 8
+            for (int k = 0; k < pn; k++) s += pH[k * VB_PRIOR_LD + i] * s_dx[k];       // H0 = J0^T J0 is symmetric entry by entry: column i read along rows = coalesced across the threads
             gd[di] += s;
         }
     }
