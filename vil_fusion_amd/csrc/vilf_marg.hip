@@ -106,6 +106,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     __shared__ double s_pm[10 * MG_PAIRM];
     __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_pcl[VB_NPAIR];     // pair table: start inside the class list, factor count, class
     __shared__ double s_td;
+    __shared__ double s_rows[MG_GCH * MG_MROW];                  // factor rows of the pair products; afterwards the rank -> feature table of the arrow rows
     __shared__ int s_slots[MG_SLOTS], s_pend[10];                 // Mbuf row of the t-th start-frame-0 factor (evaluation order = pair order); cumulative factor count per pair
     int *info = g.info + (size_t)w * MG_INFO;
     const int F = b.n_feat[w];
@@ -227,7 +228,6 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     if (s_hdr[0] != 0) return;
     const int md = s_hdr[1], n = s_hdr[3], nd = md + n;
     double *Hd = g.Hd + (size_t)w * MG_ND * MG_ND, *gd = g.gd + (size_t)w * MG_ND;
-    for (int i = tid; i < MG_ND * MG_ND; i += NT) Hd[i] = 0.0;
     for (int i = tid; i < MG_ND; i += NT) gd[i] = 0.0;
     // ---- prior factor: dx (marginalization_factor.cpp:345-363) and column map -------------------------------------------
     if (tid < VB_PRIOR_LD) { s_dx[tid] = 0.0; s_pmap[tid] = -1; }
@@ -253,6 +253,11 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     if (tid < 8) s_lr[tid] = 0.0;
     __syncthreads();
     MG_STAMP(0, 8);
+    // dense index -> prior column (for the fill of Hd below)
+    __shared__ int s_pinv[MG_ND];
+    if (tid < MG_ND) s_pinv[tid] = -1;
+    __syncthreads();
+    if (have_prior && tid < phdr[1] && s_pmap[tid] >= 0) s_pinv[s_pmap[tid]] = tid;
     if (mode == 0) {
         if (tid == 0) {
             const double *rec = b.imu + ((size_t)w * 10) * IMU_REC;
@@ -271,6 +276,24 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     }
     __syncthreads();
     MG_STAMP(0, 9);
+    // Hd starts as the prior's H0 = J0^T J0 scattered to the dense order (zero elsewhere): one pass of stores with the loads of eighteen entries in flight, instead of a zero
+    // fill and a later read-modify-write pass over the prior's entries. Order of the additions per address: prior, IMU, LiDAR, visual.
+    {
+        const double *__restrict__ pH0 = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
+        double *__restrict__ Hd0 = Hd;
+        for (int e0 = tid; e0 < MG_ND * MG_ND; e0 += 18 * NT) {
+            double v6[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                const int e = min(e0 + k * NT, MG_ND * MG_ND - 1), di = e / MG_ND, dj = e - MG_ND * di;
+                const int pi = s_pinv[di], pj = s_pinv[dj];
+                v6[k] = (pi >= 0 && pj >= 0) ? pH0[pi * VB_PRIOR_LD + pj] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 18; k++) { const int e = e0 + k * NT; if (e < MG_ND * MG_ND) Hd0[e] = v6[k]; }
+        }
+    }
+    __syncthreads();
     // sqrt_info multiplication of the IMU block (31 columns incl. the residual), in registers then back
     {
         const double *S = b.imu + ((size_t)w * 10) * IMU_REC + IMU_SQRT;
@@ -331,7 +354,6 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     // are staged through LDS in chunks (one coalesced 320-byte row per factor) and every entry is one thread's running sum over the
     // factors in pair order — the same summation order as a per-entry gather from global memory, without its dependent loads.
     if (mode == 0) {
-        __shared__ double s_rows[MG_GCH * MG_MROW];
         const int *ps_slot = b.ps_slot + (size_t)w * FC;
         // the factor rows in evaluation order (pair after pair), MG_GCH at a time through LDS — a chunk spans several pairs, so the whole walk is a handful of memory
         // round trips (one chunk per pair, its row indices fetched first, was ten times two dependent ones); a thread's running sum is flushed where a pair ends
@@ -445,11 +467,6 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     if (have_prior) {
         const int pn = phdr[1];
         const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *pg = b.prior_g + (size_t)w * VB_PRIOR_LD;
-        for (int e = tid; e < pn * pn; e += NT) {
-            const int i = e / pn, j = e - pn * i;
-            const int di = s_pmap[i], dj = s_pmap[j];
-            if (di >= 0 && dj >= 0) Hd[di * MG_ND + dj] += pH[i * VB_PRIOR_LD + j];
-        }
         for (int i = tid; i < pn; i += NT) {
             const int di = s_pmap[i];
             if (di < 0) continue;
@@ -488,13 +505,57 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             }
         }
         MG_STAMP(0, 20);
-        // per-feature arrow rows
+        // per-feature arrow rows: h_f, g_f and the P0 / Ex / td entries are sums over the feature's factors (one thread per (feature, entry), the loads of all its <= 10
+        // factors in flight at once); the Pj entries come from one factor each (one thread per (feature, factor, column)). A thread per feature walking its factors
+        // with some twenty dependent loads each was 75 k cycles. Same sums in the same order.
         double *Wf = g.Wf + (size_t)w * FM * MG_ND, *hfm = g.hfm + (size_t)w * FM, *gfm = g.gfm + (size_t)w * FM;
+        const int mfw = s_hdr[2];
+        int *s_frk = reinterpret_cast<int *>(s_rows);                       // rank -> feature (capacity 2 * MG_GCH * MG_MROW ints)
+        constexpr int FRK_CAP = 2 * MG_GCH * MG_MROW;
+        __syncthreads();
+        for (int f = tid; f < F; f += NT) { const int rk = f0rank[f]; if (rk >= 0 && rk < FRK_CAP) s_frk[rk] = f; }
+        for (int e = tid; e < mfw * nd; e += NT) { const int rk = e / nd; Wf[(size_t)rk * MG_ND + (e - nd * rk)] = 0.0; }
+        __syncthreads();
+        if (mfw <= FRK_CAP) {
+            const double *__restrict__ Mr = Mb;
+            for (int e = tid; e < mfw * 15; e += NT) {
+                const int rk = e / 15, c = e - 15 * rk, f = s_frk[rk], nf = f_nobs[f] - 1, f0 = f_fac0[f];
+                const int ca = c == 0 ? 36 : (c == 1 ? 38 : (c == 2 ? 40 : (c < 9 ? c - 3 : 24 + c - 9))), cb = c < 3 ? ca + 1 : ca + 6;
+                double a4[10][4];
+#pragma unroll
+                for (int t = 0; t < 10; t++) {
+                    const double *row = Mr + (size_t)(f0 + min(t, max(nf - 1, 0))) * MG_MROW;
+                    a4[t][0] = row[36]; a4[t][1] = row[37]; a4[t][2] = row[ca]; a4[t][3] = row[cb];
+                }
+                double sum = 0;
+#pragma unroll
+                for (int t = 0; t < 10; t++) if (t < nf) sum += a4[t][2] * a4[t][0] + a4[t][3] * a4[t][1];
+                for (int t = 10; t < nf; t++) { const double *row = Mr + (size_t)(f0 + t) * MG_MROW; sum += row[ca] * row[36] + row[cb] * row[37]; }
+                double *Wr = Wf + (size_t)rk * MG_ND;
+                if (c == 0) hfm[rk] = sum; else if (c == 1) gfm[rk] = sum; else if (c == 2) { if (otd >= 0) Wr[otd] = sum; } else if (c < 9) Wr[o0 + c - 3] = sum; else Wr[oex + c - 9] = sum;
+            }
+            for (int e0 = tid; e0 < mfw * 60; e0 += 4 * NT) {                // (feature, factor t < 10, column c < 6), four entries' loads in flight
+                double a4[4][4]; int dst[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = min(e0 + k * NT, mfw * 60 - 1), rk = e / 60, rem = e - 60 * rk, t = rem / 6, c = rem - 6 * t, f = s_frk[rk], nf = f_nobs[f] - 1, f0 = f_fac0[f];
+                    const double *row = Mr + (size_t)(f0 + min(t, max(nf - 1, 0))) * MG_MROW;
+                    a4[k][0] = row[36]; a4[k][1] = row[37]; a4[k][2] = row[12 + c]; a4[k][3] = row[18 + c];
+                    dst[k] = (e0 + k * NT < mfw * 60 && t < nf) ? rk * MG_ND + s_off_pose[1 + t] + c : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (dst[k] >= 0) Wf[dst[k]] = a4[k][2] * a4[k][0] + a4[k][3] * a4[k][1];
+            }
+            for (int f = tid; f < F; f += NT) {                               // factors beyond the tenth of a feature (longer windows than the reference's)
+                const int rk = f0rank[f]; if (rk < 0) continue;
+                const int nf = f_nobs[f] - 1, f0 = f_fac0[f];
+                for (int t = 10; t < nf; t++) { const double *row = Mr + (size_t)(f0 + t) * MG_MROW; for (int c = 0; c < 6; c++) Wf[(size_t)rk * MG_ND + s_off_pose[1 + t] + c] = row[12 + c] * row[36] + row[18 + c] * row[37]; }
+            }
+        } else
         for (int f = tid; f < F; f += NT) {
             const int rk = f0rank[f];
             if (rk < 0) continue;
             double *Wr = Wf + (size_t)rk * MG_ND;
-            for (int k = 0; k < nd; k++) Wr[k] = 0.0;
             double h = 0, gg = 0, w0[6] = {0, 0, 0, 0, 0, 0}, wex[6] = {0, 0, 0, 0, 0, 0}, wtd = 0;
             const int nf = f_nobs[f] - 1, f0 = f_fac0[f];
             for (int t = 0; t < nf; t++) {
