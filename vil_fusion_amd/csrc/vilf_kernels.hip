@@ -378,6 +378,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #pragma unroll
     for (int q4 = 0; q4 < 4; q4++) pe[q4] = pair_elem((lane >> 4) + 4 * q4, lane & 15);   // C-tile register -> pairD slot (fixed per lane)
     double4_t cacc = {0, 0, 0, 0}, cacc1 = {0, 0, 0, 0};            // the open pair of this wave's class list across chunk boundaries
+    int kcur = 0;
+    const int nk = __builtin_amdgcn_readfirstlane(s_wl[wave][VB_NPAIR]);
     for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
         t_a = TICK();
         const int q = c0 + tid;
@@ -418,9 +420,13 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         __syncthreads();
         { long long t_b = TICK(); t_sync1 += t_b - t_a; t_a = t_b; }
         const int x0c = VB_CLS * (c0 / VB_CHUNK);                              // this chunk holds the class-local positions [x0c, x0c + VB_CLS) of every class
-        for (int k = 0; k < s_wl[wave][VB_NPAIR]; k++) {                       // the pairs of this wave's class: every wave has ~ a quarter of the chunk's rows
-            const int p = __builtin_amdgcn_readfirstlane(s_wl[wave][k]);
-            const int pst = __builtin_amdgcn_readfirstlane(s_pst[p]), lo = max(pst, x0c), hi = min(pst + __builtin_amdgcn_readfirstlane(s_pcn[p]), x0c + VB_CLS);
+        // the pairs of this wave's class, in class-list order = ascending position: a cursor carried across the chunks stops at the first pair that starts in a later
+        // chunk (walking the whole list in every chunk and skipping cost three dependent LDS reads per pair and chunk: half of this phase)
+        for (; kcur < nk; kcur++) {
+            const int p = __builtin_amdgcn_readfirstlane(s_wl[wave][kcur]);
+            const int pst = __builtin_amdgcn_readfirstlane(s_pst[p]), pcn_ = __builtin_amdgcn_readfirstlane(s_pcn[p]);
+            if (pst >= x0c + VB_CLS) break;
+            const int lo = max(pst, x0c), hi = min(pst + pcn_, x0c + VB_CLS);
             if (lo >= hi) continue;
             const int r_lo = 2 * (VB_CLS * wave + lo - x0c), r_hi = 2 * (VB_CLS * wave + hi - x0c);
             // a pair that began in an earlier chunk continues in the registers it was left in (a class list is walked in order: one open pair per wave at most)
@@ -446,7 +452,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             }
             // the pair's products go to pairD (global memory, L2) ONCE, when its last factor has been seen: a pair running on into the next chunk stays in
             // registers — reading the partial sums back cost a dependent global round trip per pair and chunk (the largest part of this loop)
-            if (pst + __builtin_amdgcn_readfirstlane(s_pcn[p]) > x0c + VB_CLS) { cacc = acc; cacc1 = acc1; }
+            if (pst + pcn_ > x0c + VB_CLS) { cacc = acc; cacc1 = acc1; break; }          // continues in the next chunk: the cursor stays on it
             else {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = acc[q4] + acc1[q4];
@@ -463,19 +469,29 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
 #define PD(p, e) pd_get(pd, s_pcn, (p), (e))
     {
         double *Hpp = b.Hpp + (size_t)w * 66 * 36;
-        for (int t = tid; t < 66 * 36; t += NT) {
-            const int blk = t / 36, e = t - 36 * blk;
-            int a = 0; while ((a + 1) * (a + 2) / 2 <= blk) a++;
-            const int bb = blk - a * (a + 1) / 2;
-            double s = 0;
-            if (a == bb) {        // the 10 pairs of frame a: all loads first (a loop of dependent load -> add trips would wait for every load in turn), same order of additions
-                double v[VB_NF - 1];
+        // off-diagonal frame blocks (a > bb): one load each, eight entries of a thread in flight; then the diagonal blocks: the ten pairs of a frame, all loads first
+        // (a loop of dependent load -> add trips would wait for every load in turn), same order of additions
+        for (int t0 = tid; t0 < 55 * 36; t0 += 8 * NT) {
+            double v[8]; int dst[8];
 #pragma unroll
-                for (int k = 0; k < VB_NF - 1; k++) v[k] = (k < a) ? PD(pair_index(min(k, a - 1), a), e) : PD(pair_index(a, k + 1), 72 + e);
+            for (int k = 0; k < 8; k++) {
+                const int t = min(t0 + k * NT, 55 * 36 - 1), ob = t / 36, e = t - 36 * ob;       // ob-th off-diagonal block = pair (bb, a), bb < a, in pair_index order
+                int a = 1; while (a * (a + 1) / 2 <= ob) a++;
+                const int bb = ob - a * (a - 1) / 2;
+                v[k] = PD(pair_index(bb, a), 36 + e);
+                dst[k] = (t0 + k * NT < 55 * 36) ? 36 * (a * (a + 1) / 2 + bb) + e : -1;
+            }
 #pragma unroll
-                for (int k = 0; k < VB_NF - 1; k++) s += v[k];
-            } else s = PD(pair_index(bb, a), 36 + e);
-            Hpp[t] = s;
+            for (int k = 0; k < 8; k++) if (dst[k] >= 0) Hpp[dst[k]] = v[k];
+        }
+        for (int t = tid; t < VB_NF * 36; t += NT) {
+            const int a = t / 36, e = t - 36 * a;
+            double v[VB_NF - 1], s = 0;
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) v[k] = (k < a) ? PD(pair_index(min(k, a - 1), a), e) : PD(pair_index(a, k + 1), 72 + e);
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) s += v[k];
+            Hpp[36 * (a * (a + 1) / 2 + a) + e] = s;
         }
     }
     STAMP(0, 6);
@@ -531,6 +547,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             const int n = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + 1];
             const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
             double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
+#pragma unroll 8
             for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];
             s += t;
         }
