@@ -551,9 +551,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];
             s += t;
         }
-        gout[tid] = s;
-        s_grad[tid] = s;
-        // diagonal of J^T J for this reduced variable
+        // diagonal of J^T J for this reduced variable (its loads are issued before the gradient is stored: a store in between would fence them off)
         const double *imuHg = b.imuH + (size_t)w * 9000, *lidHg = b.lidH + (size_t)w * 1440;
         double dg = 0;
         if (l < 6) {
@@ -568,6 +566,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         if (a >= 1) dg += imuHg[900 * (a - 1) + 31 * (15 + l)];
         if (a <= 9) dg += imuHg[900 * a + 31 * l];
         if (pc >= 0) dg += b.prior_H[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * (VB_PRIOR_LD + 1)];
+        gout[tid] = s;
+        s_grad[tid] = s;
         b.diagH[(size_t)w * VB_P + tid] = dg;
     }
     __syncthreads();
