@@ -15,3 +15,4 @@ v = a[0]
 idx = [i for i in range(32) if v[i]]
 print("k_marg_prepare stamps:", [(idx[k + 1], int(v[idx[k + 1]] - v[idx[k]])) for k in range(len(idx) - 1)], "total", int(v[idx[-1]] - v[idx[0]]))
 print("pair-loop sums (thread 0): top, stage, barrier, mfma, barrier:", [int(x) for x in a[0][24:30]])
+print("tred2 Householder loop sums (thread 0): phaseA, barrier waits, matvec, phaseB, rank2, tail:", [int(x) for x in a[1][24:30]])

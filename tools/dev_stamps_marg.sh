@@ -3,4 +3,4 @@ cd vil_fusion_amd/csrc
 rm -f vilf_marg.o
 make HIPFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-fast-math -ffp-contract=on -mllvm -amdgpu-mfma-vgpr-form=1 -DVILF_STAMPS -Wno-unused-function -Wno-unused-value -Wno-unused-result" > /tmp/make.log 2>&1 || { tail -5 /tmp/make.log; exit 1; }
 cd ../..
-python tools/dev_stamps_marg.py 2>&1 | tail -3
+python tools/dev_stamps_marg.py 2>&1 | tail -4

@@ -13,6 +13,35 @@
 
 #define VD __device__ __forceinline__
 
+// Sum over the 64 lanes of a wave, the total in every lane, as a fixed binary tree: lane pairs, quads, half rows, rows (DPP: quad_perm, row_half_mirror, row_mirror),
+// then the four row sums as (r0 + r1) + (r2 + r3) through v_readlane. At every stage all lanes of a group hold the same group sum, so every lane ends with the same
+// bits. ~150 cycles instead of ~800 for a butterfly of six ds_bpermute round trips (three of these per Householder step of the marginalization, 28 per evaluation
+// of the scan-to-map LM solve ...). ALL 64 lanes must be active.
+template <int CTRL>
+VD double vilf_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+VD double vilf_wave_sum64(double v) {
+    v += vilf_dpp_f64<0xB1>(v);        // quad_perm [1 0 3 2]: lane ^ 1
+    v += vilf_dpp_f64<0x4E>(v);        // quad_perm [2 3 0 1]: lane ^ 2
+    v += vilf_dpp_f64<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half row
+    v += vilf_dpp_f64<0x140>(v);       // row_mirror: the other half of the 16-lane row
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+VD double vilf_wave_max64(double v) {           // the same tree with fmax
+    v = fmax(v, vilf_dpp_f64<0xB1>(v)); v = fmax(v, vilf_dpp_f64<0x4E>(v)); v = fmax(v, vilf_dpp_f64<0x141>(v)); v = fmax(v, vilf_dpp_f64<0x140>(v));
+    const double r0 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 0), __builtin_amdgcn_readlane(__double2loint(v), 0));
+    const double r1 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 16), __builtin_amdgcn_readlane(__double2loint(v), 16));
+    const double r2 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 32), __builtin_amdgcn_readlane(__double2loint(v), 32));
+    const double r3 = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 48), __builtin_amdgcn_readlane(__double2loint(v), 48));
+    return fmax(fmax(r0, r1), fmax(r2, r3));
+}
+
 namespace vd {
 
 struct Q { double x, y, z, w; };

@@ -42,29 +42,29 @@ __device__ __forceinline__ int tile_index(int ta, int tb) { return ta * (ta + 1)
 #define TIX(r, c) (16 * (r) + ((c) ^ (r)))
 
 // block-wide sum / max with a fixed reduction tree (deterministic)
+// block reductions of the 256-thread kernels: the fixed tree of vilf_wave_sum64 inside each wave, then the four wave results in wave order by every thread — three
+// barriers (the shared-memory halving tree they replace had ten per call)
 __device__ __forceinline__ double block_sum(double v, double *s_red) {
     const int tid = threadIdx.x;
+    v = vilf_wave_sum64(v);
     __syncthreads();
-    s_red[tid] = v;
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) s_red[tid] += s_red[tid + s];
-        __syncthreads();
-    }
-    double r = s_red[0];
+    double r = 0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) r += s_red[k];
     __syncthreads();
     return r;
 }
 __device__ __forceinline__ double block_max(double v, double *s_red) {
     const int tid = threadIdx.x;
+    v = vilf_wave_max64(v);
     __syncthreads();
-    s_red[tid] = v;
+    if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
-    for (int s = NT / 2; s > 0; s >>= 1) {
-        if (tid < s) s_red[tid] = fmax(s_red[tid], s_red[tid + s]);
-        __syncthreads();
-    }
     double r = s_red[0];
+#pragma unroll
+    for (int k = 1; k < NT / 64; k++) r = fmax(r, s_red[k]);
     __syncthreads();
     return r;
 }
@@ -653,8 +653,7 @@ __device__ __forceinline__ void tile_add(double *s_T, int r, int c, double v) {
 // nothing hides a barrier chain), fixed summation order
 __device__ __forceinline__ double block_sum_s(double v, double *s_red) {
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = vilf_wave_sum64(v);
     __syncthreads();
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
@@ -1002,8 +1001,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
         if (wave & 1) schur_mfma<1>(W, F, s_cf, s_scale, s_T, s_y, lane, wave); else schur_mfma<0>(W, F, s_cf, s_scale, s_T, s_y, lane, wave);
         if (tries == 0) {                         // every wave adds the cross term itself (same order in every wave: uniform and identical)
             double cr = ((lane < VB_NPOSE) ? s_v[lane] * s_red[lane] : 0.0) + ((lane + 64 < VB_NPOSE) ? s_v[lane + 64] * s_red[lane + 64] : 0.0);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
+            cr = vilf_wave_sum64(cr);
             Jg2 -= 2.0 * cr;
             __syncthreads();                      // s_red is reused by later block sums
         }
@@ -1201,8 +1199,7 @@ __device__ __forceinline__ double sb_bload(__amdgpu_buffer_rsrc_t r, int elem) {
 #define SBW (SBT / 64)
 __device__ __forceinline__ double block_sum_sb(double v, double *s_red) {
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = vilf_wave_sum64(v);
     __syncthreads();
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
     __syncthreads();
@@ -1214,8 +1211,7 @@ __device__ __forceinline__ double block_sum_sb(double v, double *s_red) {
 }
 __device__ __forceinline__ void block_sum2_sb(double v0, double v1, double *s_red, double &r0, double &r1) {      // two sums in one pass (same order of additions as block_sum_sb)
     const int tid = threadIdx.x;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o, 64); v1 += __shfl_xor(v1, o, 64); }
+    v0 = vilf_wave_sum64(v0); v1 = vilf_wave_sum64(v1);
     __syncthreads();
     if ((tid & 63) == 0) { s_red[tid >> 6] = v0; s_red[8 + (tid >> 6)] = v1; }
     __syncthreads();
@@ -1743,8 +1739,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         if (tries == 0) block_sum2_sb(g2, part, s_red, G2, Jg2); else __syncthreads();
         if (tries == 0) {                             // cross term of the Cauchy point: 2 sum_p v_p S_p sum_f s_f v_f W_f[p]  (s_t = -that inner sum, scaled)
             double cr = ((ln < VB_NPOSE) ? s_v[ln] * s_t[ln] : 0.0) + ((ln + 64 < VB_NPOSE) ? s_v[ln + 64] * s_t[ln + 64] : 0.0);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cr += __shfl_xor(cr, o, 64);
+            cr = vilf_wave_sum64(cr);
             Jg2 -= 2.0 * cr;
         }
         STAMP(1, 4);

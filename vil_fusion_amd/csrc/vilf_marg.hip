@@ -799,37 +799,45 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
 // (ascending-k dot products), the three length-i reductions of a tred2 step by wave 0, the scalar QL recurrence by thread 0 and
 // the rotations of one QL iteration applied to all rows of V in parallel. On exit V(:, j) is eigenvector j of eigenvalue d[j]
 // (unsorted). d, e: LDS arrays of n doubles; s_cs: 2 n doubles; s_sc: 4 doubles; s_ctl: 2 ints.
-__device__ __forceinline__ double mg_wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double mg_wave_sum(double v) { return vilf_wave_sum64(v); }       // every caller has its whole wave active
 #define VV(r, c) V[(r) * ld + (c)]
 // Householder tridiagonalisation with accumulated transformations (EISPACK tred2): d = diagonal, e[0 .. n-2] = sub-diagonal, V = Q
 __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, double *s_sc) {
+    // Per Householder step the work falls into two wide phases (the mat-vec and the rank-2 update, all threads) and two narrow ones (the three length-i reductions with
+    // the element-wise passes between them): the narrow ones run inside wave 0 — lane-strided, ordered by wave-level syncs — while the other waves wait at ONE barrier,
+    // so a step is four workgroup barriers (it used to be nine: every reduction and every element-wise pass was its own barrier phase). A one-wave-per-window form
+    // (no barriers at all) was measured 1.5 x SLOWER: one wave cannot keep enough LDS requests in flight, and the 46 KB matrix allows three windows per CU either way.
     const int tid = threadIdx.x;
-    if (tid < n) d[tid] = VV(n - 1, tid);
-    __syncthreads();
+#define W0SYNC __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier()
+    if (tid < 64) for (int k = tid; k < n; k += 64) d[k] = VV(n - 1, k);
+    MG_ACC_DECL
     for (int i = n - 1; i > 0; i--) {
-        if (tid < 64) { double a = 0; for (int k = tid; k < i; k += 64) a += fabs(d[k]); a = mg_wave_sum(a); if (tid == 0) s_sc[0] = a; }
+        // ---- narrow phase A (wave 0): scale, scaled d, h, e[i], d[i-1] (d was loaded by this wave at the end of the previous step)
+        if (tid < 64) {
+            W0SYNC;
+            double a = 0;
+            for (int k = tid; k < i; k += 64) a += fabs(d[k]);
+            const double scale = mg_wave_sum(a);
+            if (scale == 0.0) {
+                if (tid == 0) { e[i] = d[i - 1]; s_sc[0] = 0.0; }
+            } else {
+                a = 0;
+                for (int k = tid; k < i; k += 64) { const double t = d[k] / scale; d[k] = t; a += t * t; }
+                a = mg_wave_sum(a);
+                W0SYNC;
+                if (tid == 0) { double h = a; const double f = d[i - 1]; double gq = sqrt(h); if (f > 0) gq = -gq; e[i] = scale * gq; h = h - f * gq; d[i - 1] = f - gq; s_sc[1] = h; s_sc[0] = scale; }
+            }
+        }
+        MG_ACC(0);
         __syncthreads();
+        MG_ACC(1);
         const double scale = s_sc[0];
         if (scale == 0.0) {
-            if (tid == 0) e[i] = d[i - 1];
+            if (tid < i) { VV(i, tid) = 0.0; VV(tid, i) = 0.0; }
             __syncthreads();
-            if (tid < i) { d[tid] = VV(i - 1, tid); VV(i, tid) = 0.0; VV(tid, i) = 0.0; }
-            if (tid == 0) d[i] = 0.0;
-            __syncthreads();
+            if (tid < 64) { for (int k = tid; k < i; k += 64) d[k] = VV(i - 1, k); if (tid == 0) d[i] = 0.0; }
             continue;
         }
-        if (tid < i) d[tid] /= scale;
-        __syncthreads();
-        if (tid < 64) {
-            double a = 0; for (int k = tid; k < i; k += 64) a += d[k] * d[k];
-            a = mg_wave_sum(a);
-            if (tid == 0) { double h = a; const double f = d[i - 1]; double gq = sqrt(h); if (f > 0) gq = -gq; e[i] = scale * gq; h = h - f * gq; d[i - 1] = f - gq; s_sc[1] = h; }
-        }
-        __syncthreads();
         const double h = s_sc[1];
         {                                    // e = A_sub d with the symmetric matrix read from its lower triangle; V(:, i) keeps the reflector.
             // Row j's dot product is split over `parts` adjacent lanes (interleaved k) and combined by shuffles: the dependent chain is i / parts long
@@ -851,12 +859,19 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
             if (lg >= 2) gq += __shfl_xor(gq, 2, 64);
             if (j < i && part == 0) { e[j] = gq / h; VV(j, i) = d[j]; }
         }
+        MG_ACC(2);
         __syncthreads();
-        if (tid < 64) { double a = 0; for (int k = tid; k < i; k += 64) a += e[k] * d[k]; a = mg_wave_sum(a); if (tid == 0) s_sc[2] = a / (h + h); }
+        MG_ACC(1);
+        // ---- narrow phase B (wave 0): hh and e -= hh d
+        if (tid < 64) {
+            double a = 0;
+            for (int k = tid; k < i; k += 64) a += e[k] * d[k];
+            const double hh = mg_wave_sum(a) / (h + h);
+            for (int k = tid; k < i; k += 64) e[k] -= hh * d[k];
+        }
+        MG_ACC(3);
         __syncthreads();
-        const double hh = s_sc[2];
-        if (tid < i) e[tid] -= hh * d[tid];
-        __syncthreads();
+        MG_ACC(1);
         {   // rank-2 update of the lower triangle only: rows r and i-1-r together fill one row of an (i+1)-wide rectangle; the row index comes from a
             // float reciprocal (exact for these sizes) instead of an integer division per element
             const int w = i + 1, nr = (i + 1) >> 1;
@@ -868,11 +883,17 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
                 VV(k, j) -= (d[j] * e[k] + e[j] * d[k]);
             }
         }
+        MG_ACC(4);
         __syncthreads();
-        if (tid < i) { d[tid] = VV(i - 1, tid); VV(i, tid) = 0.0; }
-        if (tid == 0) d[i] = h;
-        __syncthreads();
+        MG_ACC(1);
+        // the next step's d = row i - 1 (wave 0, which is the one that reads it next); row i of V is cleared by everyone
+        if (tid < 64) { for (int k = tid; k < i; k += 64) d[k] = VV(i - 1, k); if (tid == 0) d[i] = h; }
+        if (tid < i) VV(i, tid) = 0.0;
     }
+    __syncthreads();
+#undef W0SYNC
+    MG_ACC(5);
+    MG_ACC_OUT(1);
     for (int i = 0; i < n - 1; i++) {        // accumulate the transformations
         if (tid == 0) { VV(n - 1, i) = VV(i, i); VV(i, i) = 1.0; }
         const double h = d[i + 1];
@@ -918,6 +939,7 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
     __syncthreads();
     if (tid == 0) { VV(n - 1, n - 1) = 1.0; for (int i = 1; i < n; i++) e[i - 1] = e[i]; e[n - 1] = 0.0; }
     __syncthreads();
+    MG_STAMP(1, 10);
 }
 // implicit QL on the tridiagonal matrix, rotations applied to the rows of V (EISPACK tql2), one workgroup
 __device__ void tql2_part(double *V, int n, int ld, double *d, double *e, double *s_cs, int *s_ctl) {

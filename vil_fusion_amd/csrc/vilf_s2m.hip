@@ -1152,11 +1152,7 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
 #define S2M_NT 256
 #define S2M_NW (S2M_NT / 64)
 // block sum with a fixed order: butterfly inside each wave, then the per-wave partials in wave order (two barriers)
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return vilf_wave_sum64(v); }       // callers: all lanes active
 __device__ double s2m_block_sum(double v, double *s_red) {
     const int tid = threadIdx.x;
     v = wave_sum(v);
