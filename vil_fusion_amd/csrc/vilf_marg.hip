@@ -846,7 +846,14 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
             double gq = 0;
             if (j < i) {
                 int k = part;
-                for (; k + 3 * parts < i; k += 4 * parts) {             // four terms per trip, their loads issued together
+                for (; k + 7 * parts < i; k += 8 * parts) {             // eight terms per trip, their loads issued together
+                    double a4[8], d4[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { const int kk = k + u * parts; a4[u] = (kk <= j ? VV(j, kk) : VV(kk, j)); d4[u] = d[kk]; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) gq += a4[u] * d4[u];
+                }
+                for (; k + 3 * parts < i; k += 4 * parts) {
                     double a4[4], d4[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) { const int kk = k + u * parts; a4[u] = (kk <= j ? VV(j, kk) : VV(kk, j)); d4[u] = d[kk]; }
@@ -855,8 +862,8 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
                 }
                 for (; k < i; k += parts) gq += (k <= j ? VV(j, k) : VV(k, j)) * d[k];
             }
-            if (lg >= 1) gq += __shfl_xor(gq, 1, 64);
-            if (lg >= 2) gq += __shfl_xor(gq, 2, 64);
+            if (lg >= 1) gq += vilf_dpp_f64<0xB1>(gq);      // lane ^ 1 by DPP (every lane takes part)
+            if (lg >= 2) gq += vilf_dpp_f64<0x4E>(gq);      // lane ^ 2
             if (j < i && part == 0) { e[j] = gq / h; VV(j, i) = d[j]; }
         }
         MG_ACC(2);
@@ -873,7 +880,9 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
         __syncthreads();
         MG_ACC(1);
         {   // rank-2 update of the lower triangle only: rows r and i-1-r together fill one row of an (i+1)-wide rectangle; the row index comes from a
-            // float reciprocal (exact for these sizes) instead of an integer division per element
+            // float reciprocal (exact for these sizes) instead of an integer division per element. (The kernel is bound by LDS throughput — three windows share a
+            // CU's LDS pipe — so what counts is the number of wave-level LDS instructions: a row-per-wave form with d[j], e[j] in registers issues more of them,
+            // half its lanes idle, and was 1.7 x slower.)
             const int w = i + 1, nr = (i + 1) >> 1;
             const float invw = 1.0f / (float)w;
             for (int t = tid; t < nr * w; t += NT) {
@@ -916,8 +925,8 @@ __device__ void tred2_part(double *V, int n, int ld, double *d, double *e, doubl
                     }
                     for (; k <= i; k += parts) gq += VV(k, i + 1) * VV(k, j);
                 }
-                if (lg >= 1) gq += __shfl_xor(gq, 1, 64);
-                if (lg >= 2) gq += __shfl_xor(gq, 2, 64);
+                if (lg >= 1) gq += vilf_dpp_f64<0xB1>(gq);      // lane ^ 1 by DPP (every lane takes part)
+                if (lg >= 2) gq += vilf_dpp_f64<0x4E>(gq);      // lane ^ 2
                 if (j <= i) {
                     int k = part;
                     for (; k + 3 * parts <= i; k += 4 * parts) {
