@@ -23,7 +23,6 @@ __global__ void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsign
 __global__ void k_linearize(VbBatch b, int iteration_zero);
 __global__ void k_solve(VbBatch b);
 __global__ void k_solve_sb(VbBatch b);
-__global__ void k_step(VbBatch b);
 __global__ void k_finalize(VbBatch b);
 __global__ void k_reset(VbBatch b, int rewind_state);
 __global__ void k_marg_prepare(VbBatch b, VbMarg g);
@@ -339,11 +338,11 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         {D_FSTART, sB * sF * 4}, {D_FNOBS, sB * sF * 4}, {D_FOBS0, sB * sF * 4}, {D_FFAC0, sB * sF * 4}, {D_FCONST, sB * sF}, {D_OBS, sB * sO * 3 * 8},
         {D_PSFEAT, sB * sC * 4}, {D_PSOBS, sB * sC * 4}, {D_PSSLOT, sB * sC * 4}, {D_PAIROFF, sB * VB_PTAB * 4}, {D_IMU, sB * 10 * IMU_REC * 8},
         {D_LIDAR, sB * 10 * 7 * 8}, {D_PHDR, sB * VB_PRIOR_HDR * 4}, {D_PX0, sB * 24 * 9 * 8}, {D_PJ, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PR, sB * VB_PRIOR_LD * 8},
-        {D_PH, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PG, sB * VB_PRIOR_LD * 8}, {D_FACW, sB * VB_FACW * sC * 8}, {D_HPP, sB * 66 * 36 * 8},
-        {D_W, sB * sF * VB_WLD * 8}, {D_HF, sB * sF * 8}, {D_GF, sB * sF * 8}, {D_IMUH, sB * 9000 * 8}, {D_IMUG, sB * 300 * 8}, {D_LIDH, sB * 1440 * 8},
-        {D_LIDG, sB * 120 * 8}, {D_G, sB * VB_P * 8}, {D_DIAGH, sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
+        {D_PH, sB * VB_PRIOR_LD * VB_PRIOR_LD * 8}, {D_PG, sB * VB_PRIOR_LD * 8}, {D_FACW, sB * VB_FACW * sC * 8}, {D_HPP, 2 * sB * 66 * 36 * 8},      // 2 x: the two linearisation workspaces (VbState::ws)
+        {D_W, 2 * sB * sF * VB_WLD * 8}, {D_HF, 2 * sB * sF * 8}, {D_GF, 2 * sB * sF * 8}, {D_IMUH, 2 * sB * 9000 * 8}, {D_IMUG, 2 * sB * 300 * 8}, {D_LIDH, 2 * sB * 1440 * 8},
+        {D_LIDG, 2 * sB * 120 * 8}, {D_G, 2 * sB * VB_P * 8}, {D_DIAGH, 2 * sB * VB_P * 8}, {D_SCALE, sB * (VB_P + sF) * 8}, {D_DIAG, sB * (VB_P + sF) * 8}, {D_GRAD, sB * (VB_P + sF) * 8},
         {D_GN, sB * (VB_P + sF) * 8}, {D_ST, sB * sizeof(VbState)}, {D_OPS, sB * 33 * 8}, {D_ORS, sB * 99 * 8}, {D_OVS, sB * 33 * 8}, {D_OBAS, sB * 33 * 8},
-        {D_OBGS, sB * 33 * 8}, {D_PAIRD, sB * VB_NPAIR * VB_PAIRD * 8}, {D_FACREC, sB * sC * 64}, {D_CF, sB * sF * 8}, {D_TD, sB * 8},
+        {D_OBGS, sB * 33 * 8}, {D_PAIRD, 2 * sB * VB_NPAIR * VB_PAIRD * 8}, {D_FACREC, sB * sC * 64}, {D_CF, sB * sF * 8}, {D_TD, sB * 8},
         {D_OBSV, h->opts.estimate_td ? sB * sO * 16 : 8}, {D_OBSTD, h->opts.estimate_td ? sB * sO * 8 : 8}, {D_OBSROW, h->opts.estimate_td ? sB * sO * 8 : 8}, {D_COV, sB * 10 * 225 * 8}, {D_WORK, sB * 10 * 450 * 8}, {D_MFLAG, sB * 4},
     };
     for (const Req &r : reqs) if (!h->d[r.id].ensure(r.bytes)) { h->err = "hipMalloc failed"; return VILF_ERR_DEVICE; }
@@ -520,7 +519,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.dbg = nullptr;
     if (getenv("VILF_DEBUG_STAMPS")) { if (!h->d[D_DBG].ensure(3 * 32 * 8)) return VILF_ERR_DEVICE; hipMemset(h->d[D_DBG].p, 0, 3 * 32 * 8); b.dbg = h->d[D_DBG].as<long long>(); }
 
-    HIPCHECK(h, hipMemsetAsync(h->d[D_W].p, 0, sB * sF * VB_WLD * 8, h->stream));   // W rows are zero outside the rewritten ranges
+    HIPCHECK(h, hipMemsetAsync(h->d[D_W].p, 0, 2 * sB * sF * VB_WLD * 8, h->stream));   // W rows are zero outside the rewritten ranges
     if (!h->luts_ready) {   // static scatter tables of the tile assembly (same for every window): source element -> LDS offset, -1 = not stored
         auto perm = [](int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); };
         // packed entry: bits 0..14 = LDS offset + 1 (0: element not stored, upper block triangle), bits 15..22 = row, bits 23..30 = column
@@ -642,9 +641,7 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
         mark(1);
         if (dense) hipLaunchKernelGGL(k_solve, grid, dim3(512), h->solve_lds, h->stream, h->batch);
         else hipLaunchKernelGGL(k_solve_sb, grid, dim3(256), h->solve_sb_lds, h->stream, h->batch);
-        mark(2);
-        hipLaunchKernelGGL(k_step, grid, block, 0, h->stream, h->batch);
-        mark(0);
+        mark(0);                                   // the trust-region step is part of k_linearize (kind 2 = the former k_step: no launches)
         hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 0);
     }
     mark(3);

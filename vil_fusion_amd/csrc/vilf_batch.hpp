@@ -78,7 +78,8 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
     double model_cost_change, relative_decrease;
     int iteration, num_successful, num_linear_solves, num_consecutive_invalid;
     int termination, done, reuse, need_linearize, solve_failed, scaling_ready, started;
-    int pad_;
+    int ws;                 // which of the two linearisation workspaces (W, Hpp, imuH, pairD, g ...) belongs to the current state x: k_linearize writes the OTHER one at the
+                            // candidate and flips this when the step is accepted
 };
 
 // ---- marginalization workspace (vilf_marg.hip) ---------------------------------------------------------------------

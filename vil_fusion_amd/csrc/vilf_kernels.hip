@@ -239,12 +239,17 @@ __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the
 extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) {
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     VbState *st = b.st + w;
-    if (!iteration_zero) { if (st->done || !st->need_linearize) return; }
+    if (!iteration_zero && st->done) return;
+    // Two linearisation workspaces per window. Iteration zero fills set 0 at the initial state. Later launches ARE the trust-region step (what k_step was): they form
+    // the dogleg step from the last solve, linearise at the CANDIDATE into the set that does not belong to x — the candidate's cost falls out of the same pass over
+    // the factors, so there is no separate cost-only pass — and flip st->ws when the step is accepted; a rejected step leaves x, its cost and its set untouched.
+    const int wset = iteration_zero ? 0 : (st->ws ^ 1);
+    const size_t ww = (size_t)wset * b.B + w;                               // window index inside the written set
 
     extern __shared__ double s_dyn[];
     double *s_X = s_dyn;
     double *s_U = s_dyn;                      // the IMU staging area (10 x 512) shares the region with the factor chunk that follows it
-    double *pd = b.pairD + (size_t)w * VB_NPAIR * VB_PAIRD;
+    double *pd = b.pairD + ww * VB_NPAIR * VB_PAIRD;
     __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3];
     __shared__ double s_lidJ[10 * 72], s_lidr[64], s_grad[176];
     __shared__ double s_pt[VB_NPAIR * PT_LD];
@@ -255,12 +260,87 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     STAMP(0, 0);
     const int F = b.n_feat[w], nfac = b.n_fac[w];
     const size_t FM = b.Fmax, FC = b.FACmax;
-    const double *pose_g = b.pose + (size_t)w * 77, *sb_g = b.sb + (size_t)w * 99;
-    const double *feat = b.feat + (size_t)w * FM;
+    double *pose_g = b.pose + (size_t)w * 77, *sb_g = b.sb + (size_t)w * 99;
+    double *feat_x = b.feat + (size_t)w * FM, *cfeat = b.cand_feat + (size_t)w * FM;
+    const double *feat = iteration_zero ? feat_x : cfeat;                    // the point of this linearisation
     const double *ex = b.ex + (size_t)w * 7;
+    const uint8_t *f_const0 = b.f_const + (size_t)w * FM;
 
     if (tid < 77) s_pose[tid] = pose_g[tid];
     if (tid < 99) s_sb[tid] = sb_g[tid];
+    double stepsq = 0;
+    if (!iteration_zero) {
+        // ---- DoglegStrategy::ComputeTraditionalDoglegStep + model cost change (thread 0), then the candidate x (+) delta -----------------------------
+        int *s_flagi = reinterpret_cast<int *>(s_red);                       // [0] valid step; the coefficients follow as doubles
+        if (tid == 0) {
+            int valid = 1;
+            double ca = 0, cb = 0;
+            if (st->solve_failed) valid = 0;
+            else {
+                const double radius = st->radius, alpha = st->alpha;
+                const double gradient_norm = sqrt(st->grad_sqnorm), gn_norm = sqrt(st->gn_sqnorm);
+                double norm;
+                if (gn_norm <= radius) { ca = 0; cb = 1; norm = gn_norm; }
+                else if (gradient_norm * alpha >= radius) { ca = -(radius / gradient_norm); cb = 0; norm = radius; }
+                else {
+                    const double b_dot_a = alpha * st->gy;                  // -alpha * gradient_ . gauss_newton_step_
+                    const double a_sq = (alpha * gradient_norm) * (alpha * gradient_norm);
+                    const double bma = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
+                    const double c = b_dot_a - a_sq;
+                    const double d = sqrt(c * c + bma * (radius * radius - a_sq));
+                    const double beta = (c <= 0) ? (d - c) / bma : (radius * radius - a_sq) / (d + c);
+                    ca = -alpha * (1.0 - beta); cb = beta;
+                    norm = sqrt(ca * ca * st->grad_sqnorm - 2 * ca * cb * st->gy + cb * cb * st->gn_sqnorm);
+                }
+                st->dogleg_step_norm = norm;
+                // step = ca * v - cb * y ; model_cost_change = -step.g~ - 0.5 step^T H~ step, with (H~ + mu D^2) y = g~
+                const double mu = st->mu_used, G2 = st->grad_sqnorm;
+                const double sg = ca * G2 - cb * st->gy;
+                const double vHy = G2 - mu * st->gy;
+                const double yHy = st->gy - mu * st->gn_sqnorm;
+                const double sHs = ca * ca * st->Jg2 - 2 * ca * cb * vHy + cb * cb * yHy;
+                const double mcc = -sg - 0.5 * sHs;
+                st->model_cost_change = mcc;
+                if (!(mcc > 0.0)) valid = 0;
+            }
+            if (!valid) {   // HandleInvalidStep + DoglegStrategy::StepIsInvalid
+                st->num_consecutive_invalid += 1;
+                st->mu *= 10.0;
+                st->reuse = 0;
+                st->solve_failed = 0;
+                if (st->num_consecutive_invalid >= 5) { st->done = 1; st->termination = 4; }
+            } else st->num_consecutive_invalid = 0;
+            s_flagi[0] = valid;
+            s_red[1] = ca; s_red[2] = cb;
+        }
+        __syncthreads();
+        if (!s_flagi[0]) return;
+        const double ca = s_red[1], cb = s_red[2];
+        const double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
+        const double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
+        // delta = (ca * gradient_ + cb * gauss_newton_step_) ./ diagonal_ .* jacobian_scaling   (s_grad is free until the gradient phase)
+        if (tid < VB_P) {
+            int a, l; unperm(tid, a, l);
+            s_grad[15 * a + l] = (ca * grad_g[tid] + cb * gn_g[tid]) / diag_g[tid] * scale_g[tid];
+        }
+        __syncthreads();
+        if (tid < VB_NF) {
+            double xp[7];
+            pose_plus(s_pose + 7 * tid, s_grad + 15 * tid, xp);
+            for (int k = 0; k < 7; k++) { const double d = s_pose[7 * tid + k] - xp[k]; stepsq += d * d; s_pose[7 * tid + k] = xp[k]; }
+            for (int k = 0; k < 9; k++) { const double d = s_grad[15 * tid + 6 + k]; stepsq += d * d; s_sb[9 * tid + k] += d; }
+        }
+        for (int f = tid; f < F; f += NT) {
+            double v = feat_x[f];
+            if (!f_const0[f]) {
+                const double d = (ca * grad_g[VB_P + f] + cb * gn_g[VB_P + f]) / diag_g[VB_P + f] * scale_g[VB_P + f];
+                stepsq += d * d;
+                v += d;
+            }
+            cfeat[f] = v;
+        }
+        __threadfence_block();                                               // cfeat is read back by other threads of this workgroup below (after the next barrier)
+    }
     {   // pair table; every wave compacts the pairs of its own class (ballot + prefix count, pair order kept)
         const int *pt = b.pair_off + (size_t)w * VB_PTAB;
         const int pp = min(lane, VB_NPAIR - 1), v1 = pt[2 * pp + 1];
@@ -330,7 +410,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     STAMP(0, 3);
     // ---- IMU: [J r]^T [J r] on MFMA -> imuH (30x30), imug (30), cost; LiDAR blocks on the VALU ------------------------
     {
-        double *imuH = b.imuH + (size_t)w * 9000, *imug = b.imug + (size_t)w * 300;
+        double *imuH = b.imuH + ww * 9000, *imug = b.imug + ww * 300;
         for (int task = wave; task < 30; task += 4) {
             const int k = task / 3, tt = task - 3 * k;
             const int ti = (tt == 0) ? 0 : 1, tj = (tt == 2) ? 1 : 0;
@@ -349,7 +429,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
                 if (p == 30 && c == 30) cost_local += 0.5 * acc[q];
             }
         }
-        double *lidH = b.lidH + (size_t)w * 1440, *lidg = b.lidg + (size_t)w * 120;
+        double *lidH = b.lidH + ww * 1440, *lidg = b.lidg + ww * 120;
         for (int idx = tid; idx < 1440; idx += NT) {
             const int k = idx / 144, e = idx - 144 * k, p = e / 12, q = e - 12 * p;
             double s = 0;
@@ -372,7 +452,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
     const double *facrec = b.facrec + (size_t)w * FC * 8;
     double *facw = b.facw + (size_t)w * VB_FACW * FC;
-    double *W = b.W + (size_t)w * FM * VB_WLD;
+    double *W = b.W + ww * FM * VB_WLD;
     long long t_eval = 0, t_sync1 = 0, t_mfma = 0, t_sync2 = 0, t_a = 0;
     int pe[4];
 #pragma unroll
@@ -468,7 +548,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     // a pair without factors was never written: it reads as zero
 #define PD(p, e) pd_get(pd, s_pcn, (p), (e))
     {
-        double *Hpp = b.Hpp + (size_t)w * 66 * 36;
+        double *Hpp = b.Hpp + ww * 66 * 36;
         // off-diagonal frame blocks (a > bb): one load each, eight entries of a thread in flight; then the diagonal blocks: the ten pairs of a frame, all loads first
         // (a loop of dependent load -> add trips would wait for every load in turn), same order of additions
         for (int t0 = tid; t0 < 55 * 36; t0 += 8 * NT) {
@@ -498,7 +578,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     // ---- per-feature Schur vectors: H_ff, g_f, anchor block of the H_pf row -------------------------------------------
     {
         const int *f_nobs = b.f_nobs + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
-        double *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+        double *hf = b.hf + ww * FM, *gf = b.gf + ww * FM;
         for (int f = tid; f < F; f += NT) {
             if (f_const[f]) { hf[f] = 0; gf[f] = 0; continue; }
             const int n = f_nobs[f] - 1, f0 = f_fac0[f];
@@ -526,10 +606,10 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     STAMP(0, 7);
     // ---- gradient g = J^T r over the reduced camera/IMU block (frame-major order) ---------------------------------
     double gmax = 0, xsq = 0;
-    double *gout = b.g + (size_t)w * VB_P;
+    double *gout = b.g + ww * VB_P;
     if (tid < VB_P) {
         const int a = tid / 15, l = tid - 15 * a;
-        const double *imug = b.imug + (size_t)w * 300, *lidg = b.lidg + (size_t)w * 120;
+        const double *imug = b.imug + ww * 300, *lidg = b.lidg + ww * 120;
         double s = 0;
         if (l < 6) {
             double v[VB_NF - 1];
@@ -552,7 +632,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
             s += t;
         }
         // diagonal of J^T J for this reduced variable (its loads are issued before the gradient is stored: a store in between would fence them off)
-        const double *imuHg = b.imuH + (size_t)w * 9000, *lidHg = b.lidH + (size_t)w * 1440;
+        const double *imuHg = b.imuH + ww * 9000, *lidHg = b.lidH + ww * 1440;
         double dg = 0;
         if (l < 6) {
             double v[VB_NF - 1];
@@ -568,7 +648,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         if (pc >= 0) dg += b.prior_H[(size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * (VB_PRIOR_LD + 1)];
         gout[tid] = s;
         s_grad[tid] = s;
-        b.diagH[(size_t)w * VB_P + tid] = dg;
+        b.diagH[ww * VB_P + tid] = dg;
     }
     __syncthreads();
     // gradient_max_norm = || x - Plus(x, -g) ||_inf (trust_region_minimizer.cc), x_norm = ||x||
@@ -580,20 +660,52 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         for (int k = 0; k < 9; k++) { gmax = fmax(gmax, fabs(gp[6 + k])); xsq += s_sb[9 * tid + k] * s_sb[9 * tid + k]; }
     }
     {
-        const double *gf = b.gf + (size_t)w * FM;
+        const double *gf = b.gf + ww * FM;
         for (int f = tid; f < F; f += NT) if (!f_const[f]) { gmax = fmax(gmax, fabs(gf[f])); xsq += feat[f] * feat[f]; }
     }
     STAMP(0, 8);
     const double cost = block_sum(cost_local, s_red);
     const double gm = block_max(gmax, s_red);
     const double xs = block_sum(xsq, s_red);
+    if (iteration_zero) {
+        if (tid == 0) { st->x_cost = cost; st->gradient_max_norm = gm; st->x_norm = sqrt(xs); st->need_linearize = 0; st->reuse = 0; st->initial_cost = cost; st->ws = 0; }
+        STAMP(0, 9);
+        return;
+    }
+    // ---- accept / reject (trust_region_minimizer.cc): `cost` is the cost at the candidate ---------------------------------------------------------------
+    const double step_norm = sqrt(block_sum(stepsq, s_red));
+    int *s_acc = reinterpret_cast<int *>(s_red);
     if (tid == 0) {
-        st->x_cost = cost;
-        st->gradient_max_norm = gm;
-        st->x_norm = sqrt(xs);
-        st->need_linearize = 0;
-        st->reuse = 0;
-        if (iteration_zero) { st->initial_cost = cost; }
+        int accept = 0;
+        st->cand_cost = cost;
+        const double x_cost = st->x_cost;
+        if (step_norm <= b.parameter_tolerance * (st->x_norm + b.parameter_tolerance)) { st->done = 1; st->termination = 2; }
+        else if (fabs(x_cost - cost) <= b.function_tolerance * x_cost) { st->done = 1; st->termination = 1; }
+        else {
+            const double rd = (x_cost - cost) / st->model_cost_change;
+            st->relative_decrease = rd;
+            if (rd > b.min_relative_decrease) {
+                accept = 1;
+                // DoglegStrategy::StepAccepted; x, its cost, its norms and its workspace become the candidate's
+                if (rd < 0.25) st->radius *= 0.5;
+                if (rd > 0.75) st->radius = fmax(st->radius, 3.0 * st->dogleg_step_norm);
+                st->mu = fmax(1e-8, 2.0 * st->mu / 10.0);
+                st->reuse = 0;
+                st->num_successful += 1;
+                st->x_cost = cost; st->gradient_max_norm = gm; st->x_norm = sqrt(xs);
+                st->ws = wset;
+            } else {
+                st->radius *= 0.5;     // StepRejected: the next solve re-uses the factorisation of x's workspace
+                st->reuse = 1;
+            }
+        }
+        s_acc[0] = accept;
+    }
+    __syncthreads();
+    if (s_acc[0]) {
+        if (tid < 77) pose_g[tid] = s_pose[tid];
+        if (tid < 99) sb_g[tid] = s_sb[tid];
+        for (int f = tid; f < F; f += NT) feat_x[f] = cfeat[f];
     }
     STAMP(0, 9);
 }
@@ -822,16 +934,17 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
     STAMP(1, 0);
     const int F = b.n_feat[w];
     const size_t FM = b.Fmax;
-    const double *Hpp = b.Hpp + (size_t)w * 66 * 36;
-    const double *imuH = b.imuH + (size_t)w * 9000, *lidH = b.lidH + (size_t)w * 1440;
+    const size_t ww = (size_t)st->ws * b.B + w;                             // the workspace that belongs to the current state x (k_linearize)
+    const double *Hpp = b.Hpp + ww * 66 * 36;
+    const double *imuH = b.imuH + ww * 9000, *lidH = b.lidH + ww * 1440;
     const double *priorH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
-    double *W = b.W + (size_t)w * FM * VB_WLD;
-    const double *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+    double *W = b.W + ww * FM * VB_WLD;
+    const double *hf = b.hf + ww * FM, *gf = b.gf + ww * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
     const int *f_start = b.f_start + (size_t)w * FM, *f_nobs = b.f_nobs + (size_t)w * FM;
     double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
     double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
-    const double *g_in = b.g + (size_t)w * VB_P;
+    const double *g_in = b.g + ww * VB_P;
     const int *phdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
     const int pn = phdr[0] ? phdr[1] : 0;
 
@@ -851,7 +964,7 @@ extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
         double sc = 1.0, d = 1.0, gs = 0.0, vv = 0.0;
         if (tid < VB_P) {
             int a, l; unperm(tid, a, l);
-            const double dh = b.diagH[(size_t)w * VB_P + 15 * a + l];
+            const double dh = b.diagH[ww * VB_P + 15 * a + l];
             if (scaling_ready) sc = scale_g[tid]; else { sc = 1.0 / (1.0 + sqrt(dh)); scale_g[tid] = sc; }
             d = sqrt(fmin(fmax(sc * sc * dh, b.min_lm_diagonal), b.max_lm_diagonal));
             gs = g_in[15 * a + l] * sc;
@@ -1412,16 +1525,17 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     STAMP(1, 0);
     const int F = b.n_feat[w];
     const size_t FM = b.Fmax;
-    const double *Hpp = b.Hpp + (size_t)w * 66 * 36;
-    const double *imuH = b.imuH + (size_t)w * 9000, *lidH = b.lidH + (size_t)w * 1440;
+    const size_t ww = (size_t)st->ws * b.B + w;                             // the workspace that belongs to the current state x (k_linearize)
+    const double *Hpp = b.Hpp + ww * 66 * 36;
+    const double *imuH = b.imuH + ww * 9000, *lidH = b.lidH + ww * 1440;
     const double *priorH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
-    double *W = b.W + (size_t)w * FM * VB_WLD;
+    double *W = b.W + ww * FM * VB_WLD;
     double *cf = b.cf + (size_t)w * FM;
-    const double *hf = b.hf + (size_t)w * FM, *gf = b.gf + (size_t)w * FM;
+    const double *hf = b.hf + ww * FM, *gf = b.gf + ww * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
     double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
     double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
-    const double *g_in = b.g + (size_t)w * VB_P;
+    const double *g_in = b.g + ww * VB_P;
     const int *phdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
     const bool has_prior = phdr[0] != 0;
     const __amdgpu_buffer_rsrc_t rHpp = sb_rsrc(Hpp, 66 * 36 * 8), rImu = sb_rsrc(imuH, 9000 * 8), rLid = sb_rsrc(lidH, 1440 * 8), rPri = sb_rsrc(priorH, VB_PRIOR_LD * VB_PRIOR_LD * 8);
@@ -1445,7 +1559,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     double Jg2 = 0, G2 = 0, g2 = 0;
     if (tid < VB_P) {
         int a, l; unperm(tid, a, l);
-        const double dh = b.diagH[(size_t)w * VB_P + 15 * a + l];
+        const double dh = b.diagH[ww * VB_P + 15 * a + l];
         double sc;
         if (scaling_ready) sc = scale_g[tid]; else { sc = 1.0 / (1.0 + sqrt(dh)); scale_g[tid] = sc; }
         const double d = sqrt(fmin(fmax(sc * sc * dh, b.min_lm_diagonal), b.max_lm_diagonal));
@@ -2033,175 +2147,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_step
-extern "C" __global__ __launch_bounds__(NT) void k_step(VbBatch b) {
-    const int w = blockIdx.x, tid = threadIdx.x;
-    VbState *st = b.st + w;
-    if (st->done) return;
-    __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3], s_step[VB_P];
-    __shared__ double s_red[NT], s_dx[VB_PRIOR_LD], s_coef[4], s_pt[VB_NPAIR * PT_LD];
-    __shared__ int s_pcol[VB_P], s_flag[2];
-    const int F = b.n_feat[w], nfac = b.n_fac[w];
-    const size_t FM = b.Fmax, FC = b.FACmax;
-    double *pose_g = b.pose + (size_t)w * 77, *sb_g = b.sb + (size_t)w * 99, *feat = b.feat + (size_t)w * FM;
-    double *cpose = b.cand_pose + (size_t)w * 77, *csb = b.cand_sb + (size_t)w * 99, *cfeat = b.cand_feat + (size_t)w * FM;
-    const uint8_t *f_const = b.f_const + (size_t)w * FM;
-    const double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
-    const double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
-
-    // ---- DoglegStrategy::ComputeTraditionalDoglegStep + model cost change (thread 0) --------------------------------
-    if (tid == 0) {
-        int valid = 1;
-        double ca = 0, cb = 0;
-        if (st->solve_failed) valid = 0;
-        else {
-            const double radius = st->radius, alpha = st->alpha;
-            const double gradient_norm = sqrt(st->grad_sqnorm), gn_norm = sqrt(st->gn_sqnorm);
-            double norm;
-            if (gn_norm <= radius) { ca = 0; cb = 1; norm = gn_norm; }
-            else if (gradient_norm * alpha >= radius) { ca = -(radius / gradient_norm); cb = 0; norm = radius; }
-            else {
-                const double b_dot_a = alpha * st->gy;                  // -alpha * gradient_ . gauss_newton_step_
-                const double a_sq = (alpha * gradient_norm) * (alpha * gradient_norm);
-                const double bma = a_sq - 2 * b_dot_a + gn_norm * gn_norm;
-                const double c = b_dot_a - a_sq;
-                const double d = sqrt(c * c + bma * (radius * radius - a_sq));
-                const double beta = (c <= 0) ? (d - c) / bma : (radius * radius - a_sq) / (d + c);
-                ca = -alpha * (1.0 - beta); cb = beta;
-                norm = sqrt(ca * ca * st->grad_sqnorm - 2 * ca * cb * st->gy + cb * cb * st->gn_sqnorm);
-            }
-            st->dogleg_step_norm = norm;
-            // step = ca * v - cb * y ; model_cost_change = -step.g~ - 0.5 step^T H~ step, with (H~ + mu D^2) y = g~
-            const double mu = st->mu_used, G2 = st->grad_sqnorm;
-            const double sg = ca * G2 - cb * st->gy;
-            const double vHy = G2 - mu * st->gy;
-            const double yHy = st->gy - mu * st->gn_sqnorm;
-            const double sHs = ca * ca * st->Jg2 - 2 * ca * cb * vHy + cb * cb * yHy;
-            const double mcc = -sg - 0.5 * sHs;
-            st->model_cost_change = mcc;
-            if (!(mcc > 0.0)) valid = 0;
-        }
-        if (!valid) {   // HandleInvalidStep + DoglegStrategy::StepIsInvalid
-            st->num_consecutive_invalid += 1;
-            st->mu *= 10.0;
-            st->reuse = 0;
-            st->solve_failed = 0;
-            if (st->num_consecutive_invalid >= 5) { st->done = 1; st->termination = 4; }
-        } else st->num_consecutive_invalid = 0;
-        s_flag[0] = valid;
-        s_coef[0] = ca; s_coef[1] = cb;
-    }
-    if (tid < 77) s_pose[tid] = pose_g[tid];
-    if (tid < 99) s_sb[tid] = sb_g[tid];
-    __syncthreads();
-    if (!s_flag[0]) return;
-    const double ca = s_coef[0], cb = s_coef[1];
-    // delta = (ca * gradient_ + cb * gauss_newton_step_) ./ diagonal_ .* jacobian_scaling
-    if (tid < VB_P) {
-        int a, l; unperm(tid, a, l);
-        s_step[15 * a + l] = (ca * grad_g[tid] + cb * gn_g[tid]) / diag_g[tid] * scale_g[tid];
-    }
-    __syncthreads();
-    double stepsq = 0;
-    if (tid < VB_NF) {
-        double xp[7];
-        pose_plus(s_pose + 7 * tid, s_step + 15 * tid, xp);
-        for (int k = 0; k < 7; k++) { const double d = s_pose[7 * tid + k] - xp[k]; stepsq += d * d; cpose[7 * tid + k] = xp[k]; s_pose[7 * tid + k] = xp[k]; }
-        for (int k = 0; k < 9; k++) { const double d = s_step[15 * tid + 6 + k]; stepsq += d * d; const double v = s_sb[9 * tid + k] + d; csb[9 * tid + k] = v; s_sb[9 * tid + k] = v; }
-    }
-    for (int f = tid; f < F; f += NT) {
-        double v = feat[f];
-        if (!f_const[f]) {
-            const double d = (ca * grad_g[VB_P + f] + cb * gn_g[VB_P + f]) / diag_g[VB_P + f] * scale_g[VB_P + f];
-            stepsq += d * d;
-            v += d;
-        }
-        cfeat[f] = v;
-    }
-    __syncthreads();
-    // ---- cost at the candidate (residual-only evaluation of every factor) --------------------------------------------
-    const double *ex = b.ex + (size_t)w * 7;
-    if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
-    if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
-    prior_setup(b, w, s_pose, s_sb, s_pcol, s_dx, tid);
-    if (tid >= 128 && tid < 128 + VB_NPAIR) {
-        const int p = tid - 128;
-        int j = 1; while (j * (j + 1) / 2 <= p) j++;
-        const int i = p - j * (j - 1) / 2;
-        pair_table(s_pose + 7 * i, s_R + 9 * i, s_pose + 7 * j, s_R + 9 * j, s_ric, s_tic, s_pt + PT_LD * p);
-    }
-    __syncthreads();
-    double cost_local = 0;
-    {
-        const double *facrec = b.facrec + (size_t)w * FC * 8;
-        for (int fac = tid; fac < nfac; fac += NT) {
-            const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)fac * 8);
-            const double4_t ra = rp[0], rb = rp[1];
-            const double pts_i[3] = {ra[0], ra[1], ra[2]}, pts_j[3] = {ra[3], rb[0], rb[1]};
-            const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
-            if ((ib >> 17) & 1) continue;                     // unused slot of the chunk-interleaved layout
-            const int f = (int)(ia & 0xffffffffu), fi = (int)(ib & 0xff), fj = (int)((ib >> 8) & 0xff);
-            double r[2];
-            projection_eval_pair<false>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, pts_i, pts_j, cfeat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);
-            double rho0, sw;
-            cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
-            cost_local += 0.5 * rho0;
-        }
-    }
-    if (tid < 10) {
-        const double *rec = b.imu + ((size_t)w * 10 + tid) * IMU_REC;
-        if (rec[287] != 0.0) {
-            double r[15];
-            imu_raw_eval<false>(s_pose + 7 * tid, s_sb + 9 * tid, s_pose + 7 * (tid + 1), s_sb + 9 * (tid + 1), rec, b.G, r, nullptr);
-            double acc = 0;
-            for (int i = 0; i < 15; i++) { double s = 0; for (int m = i; m < 15; m++) s += rec[IMU_SQRT + 15 * i + m] * r[m]; acc += s * s; }
-            cost_local += 0.5 * acc;
-        }
-    }
-    if (tid >= 64 && tid < 74 && b.use_lidar) {
-        const int k = tid - 64;
-        const double *lc = b.lidar + ((size_t)w * 10 + k) * 7;
-        double r[6];
-        lidar_between_eval<false>(s_pose + 7 * k, s_pose + 7 * (k + 1), q_load(b.qil), b.til, q_load(lc), lc + 4, r, nullptr, nullptr);
-        double acc = 0;
-        for (int m = 0; m < 6; m++) acc += r[m] * r[m];
-        cost_local += 0.5 * acc;
-    }
-    cost_local += prior_cost_partial(b, w, s_dx, tid);
-    const double cand_cost = block_sum(cost_local, s_red);
-    const double step_norm = sqrt(block_sum(stepsq, s_red));
-    // ---- accept / reject (trust_region_minimizer.cc) ------------------------------------------------------------------
-    if (tid == 0) {
-        int accept = 0;
-        st->cand_cost = cand_cost;
-        const double x_cost = st->x_cost;
-        if (step_norm <= b.parameter_tolerance * (st->x_norm + b.parameter_tolerance)) { st->done = 1; st->termination = 2; }
-        else if (fabs(x_cost - cand_cost) <= b.function_tolerance * x_cost) { st->done = 1; st->termination = 1; }
-        else {
-            const double rd = (x_cost - cand_cost) / st->model_cost_change;
-            st->relative_decrease = rd;
-            if (rd > b.min_relative_decrease) {
-                accept = 1;
-                // DoglegStrategy::StepAccepted
-                if (rd < 0.25) st->radius *= 0.5;
-                if (rd > 0.75) st->radius = fmax(st->radius, 3.0 * st->dogleg_step_norm);
-                st->mu = fmax(1e-8, 2.0 * st->mu / 10.0);
-                st->reuse = 0;
-                st->need_linearize = 1;
-                st->num_successful += 1;
-            } else {
-                st->radius *= 0.5;     // StepRejected
-                st->reuse = 1;
-            }
-        }
-        s_flag[1] = accept;
-    }
-    __syncthreads();
-    if (s_flag[1]) {
-        if (tid < 77) pose_g[tid] = s_pose[tid];
-        if (tid < 99) sb_g[tid] = s_sb[tid];
-        for (int f = tid; f < F; f += NT) feat[f] = cfeat[f];
-    }
-}
+// (the trust-region step — dogleg step, candidate, cost, accept / reject — is the prologue and the epilogue of k_linearize)
 
 // ------------------------------------------------------------------------------------------------------------------
 // double2vector(): yaw / position gauge fix of the whole window (estimator.cpp:549-596)
@@ -2259,7 +2205,7 @@ extern "C" __global__ void k_reset(VbBatch b, int rewind_state) {
         s.x_norm = 0; s.gradient_max_norm = 1e300; s.grad_sqnorm = 0; s.Jg2 = 0; s.gy = 0; s.gn_sqnorm = 0; s.mu_used = 1e-8;
         s.model_cost_change = 0; s.relative_decrease = 0;
         s.iteration = 0; s.num_successful = 0; s.num_linear_solves = 0; s.num_consecutive_invalid = 0;
-        s.termination = 0; s.done = 0; s.reuse = 0; s.need_linearize = 1; s.solve_failed = 0; s.scaling_ready = 0; s.started = 1; s.pad_ = 0;
+        s.termination = 0; s.done = 0; s.reuse = 0; s.need_linearize = 1; s.solve_failed = 0; s.scaling_ready = 0; s.started = 1; s.ws = 0;
         b.st[w] = s;
     }
 }
