@@ -8,7 +8,8 @@
 //   k_solve        assemble the 165x165 reduced system as 16x16 fp64 tiles in LDS, Jacobi scaling, dogleg diagonal,
 //                  Cauchy point, MFMA Schur reduce (-= W~^T W~), MFMA blocked Cholesky, Gauss-Newton step
 //                  (≙ DoglegStrategy::ComputeStep + DENSE_SCHUR, Ceres 2.0)
-//   k_step         dogleg interpolation, Plus(), trial cost, accept / reject, radius update
+//   (k_step)       dogleg interpolation, Plus(), trial cost, accept / reject, radius update: since round 2 the prologue / epilogue of k_linearize, which linearises at
+//                  the candidate into the second workspace and flips VbState::ws on acceptance
 //                  (≙ TrustRegionMinimizer loop body)
 //   k_finalize     double2vector() gauge fix (estimator.cpp:549-596)
 //
@@ -2146,7 +2147,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// k_step
+// k_step (folded into k_linearize)
 // (the trust-region step — dogleg step, candidate, cost, accept / reject — is the prologue and the epilogue of k_linearize)
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@
 //                                   LDS, the slab below as 16 x 4 fp64 MFMA tiles), then the trailing SYRK update as MFMA tiles over the grid;
 //   lw_chol_back                    forward / back substitution with the triangle staged through LDS. No rocSOLVER / rocBLAS on this path.
 // and keeps the trust-region logic (Ceres 2.0 TrustRegionMinimizer + traditional dogleg + Jacobi scaling, the same restatement as
-// k_solve / k_step) on the host: per iteration only vectors of P + F doubles cross PCIe.
+// k_solve / k_linearize's step) on the host: per iteration only vectors of P + F doubles cross PCIe.
 // The same path runs the solves the batched LDS kernels do not cover at ANY window size: estimate_extrinsic (Ex_Pose a variable: six more
 // columns after the frame blocks) and estimate_td (ProjectionTdFactor, one more column) — estimator.cpp:701-717,765-777. For an 11-frame
 // window it then also applies the slot-0 marginalization prior resident on the device (lw_prior) and writes the solved state back into the
