@@ -1588,7 +1588,6 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     int blk_i = 0;
     while ((blk_i + 1) * (blk_i + 2) / 2 <= tid) blk_i++;
     const int blk_j = tid - blk_i * (blk_i + 1) / 2;
-    const bool blk_on = tid < 19 * 20 / 2;
 
     STAMP(1, 1);
     for (;;) {
