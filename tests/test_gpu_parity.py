@@ -118,7 +118,7 @@ def test_window_solve_matches_oracle(solver, oracle, seed, with_prior, use_lidar
 
 
 def test_edge_cases(solver, oracle, opts):
-    # all features constant (no Schur block), very few features, and a window with a rejected step
+    # all features constant (no Schur block), very few features, and a strongly perturbed window (rejected steps: test_rejected_steps_match_oracle)
     for cfg in (synth.SynthConfig(const_fraction=1.0, n_features=40), synth.SynthConfig(n_features=3, const_fraction=0.0),
                 synth.SynthConfig(n_features=150, state_noise=(0.5, np.deg2rad(5.0), 0.5))):
         win, prior, _ = synth.make_window(9, opts, cfg)
@@ -126,6 +126,32 @@ def test_edge_cases(solver, oracle, opts):
         got = solver.optimization(win)
         ref = oracle.window_solve(opts, win, prior)
         _compare(got, ref, tol_p=1e-6, tol_r=1e-7, tol_cost=1e-6)
+
+
+def test_rejected_steps_match_oracle(solver, oracle, opts):
+    """Windows whose trust-region loop REJECTS steps (found with the oracle: strongly perturbed states): 6 or 7 successful steps out of 8 iterations, with and without a
+    re-used Gauss-Newton step. The device takes the step inside k_linearize, which linearises at the candidate into the second workspace and keeps x, its cost and its
+    workspace when the step is rejected — this is the path these windows exercise. Same iteration / accepted-step / linear-solve counts and the same state as the oracle,
+    one window at a time and as a batch."""
+    cases = [(1.5, 15.0, 409), (3.0, 25.0, 405), (3.0, 25.0, 408), (3.0, 25.0, 431), (3.0, 25.0, 400)]
+    made = [synth.make_window(seed, opts, synth.SynthConfig(n_features=60, state_noise=(nz, np.deg2rad(deg), nz))) for nz, deg, seed in cases]
+    refs = [oracle.window_solve(opts, w, p) for w, p, _ in made]
+    assert any(r.summary["num_successful_steps"] < r.summary["num_iterations"] for r in refs), "the cases were picked for their rejected steps"
+    assert any(r.summary["num_linear_solves"] < r.summary["num_iterations"] for r in refs), "... and for a re-used Gauss-Newton step"
+    for (w, p, _), ref in zip(made, refs):
+        solver.set_prior(p)
+        got = solver.optimization(w)
+        for k in ("num_iterations", "num_successful_steps", "num_linear_solves"):
+            assert got.summary[k] == ref.summary[k], k
+        assert abs(got.summary["final_cost"] - ref.summary["final_cost"]) <= 1e-4 * ref.summary["final_cost"]
+        # states (these windows are far from convergence and hold near-zero / negative inverse depths: the inverse depths themselves are compared, not the depths)
+        assert np.abs(got.Ps - ref.Ps).max() < 1e-4 and np.abs(got.Rs - ref.Rs).max() < 1e-5 and np.abs(got.Vs - ref.Vs).max() < 1e-3      # costs of 1e8..1e9 after 8 iterations: rounding differences are amplified
+        assert np.abs(got.para_feature - ref.para_feature).max() < 1e-4             # ill-conditioned by construction (costs ~ 1e9, near-singular steps): the counts above are the point
+    solver.batch_upload([m[0] for m in made], [m[1] for m in made])
+    solver.batch_solve()
+    for got, sm, ref in zip(solver.batch_download(), solver.batch_summaries(), refs):
+        assert (sm.num_iterations, sm.num_successful_steps, sm.num_linear_solves) == (ref.summary["num_iterations"], ref.summary["num_successful_steps"], ref.summary["num_linear_solves"])
+        assert np.abs(got.Ps - ref.Ps).max() < 1e-4
 
 
 def test_batch_matches_single_and_rewind_is_deterministic(solver, oracle, opts):
@@ -591,7 +617,7 @@ def test_td_estimation_solve_marginalize_solve_chain_single_and_batched(oracle, 
 def test_speed_bias_first_kernel_equals_dense_kernel_and_oracle(solver, oracle, opts, monkeypatch):
     """k_solve_sb (block-tridiagonal speed-bias chain eliminated first) against k_solve (Cholesky of the whole 165 x 165 system, VILF_SOLVE_DENSE=1) and the
     oracle: the same iterations / accepted steps / linear solves in every window, states equal to rounding; windows with and without a prior, with constant
-    features only, with a rejected step."""
+    features only, strongly perturbed."""
     cfgs = [synth.SynthConfig(n_features=230), synth.SynthConfig(n_features=90, with_prior=False), synth.SynthConfig(const_fraction=1.0, n_features=40),
             synth.SynthConfig(n_features=150, state_noise=(0.5, np.deg2rad(5.0), 0.5)), synth.SynthConfig(n_features=3, const_fraction=0.0)]
     made = [synth.make_window(300 + i, opts, c) for i, c in enumerate(cfgs)]
