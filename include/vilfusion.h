@@ -203,7 +203,7 @@ int vilf_batch_summaries(vilf_handle *h, int first, int n_windows, vilf_summary 
  * any pointer may be NULL. The per-frame caller's download: the parameter arrays stay on the device for the marginalization. */
 int vilf_batch_download_states(vilf_handle *h, int first, int n_windows, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, vilf_summary *sums);
 int vilf_synchronize(vilf_handle *h);
-/* per-kernel timing by HIP events on the handle's stream (kind 0 linearize incl. the trust-region step, 1 reduce+solve, 2 unused (the former step kernel), 3 other); needs sync solves */
+/* per-kernel timing by HIP events on the handle's stream (kind 0 linearize incl. the trust-region step, 1 reduce+solve, 2 the step-only launch that ends a solve, 3 other); needs sync solves */
 int vilf_set_profiling(vilf_handle *h, int on);
 int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]);
 /* same switch, scan-to-map launches by group: 0 voxel grid, 1 radix sort, 2 neighbour index, 3 associate (5-NN + fits),

@@ -13,7 +13,7 @@ import json
 import sys
 
 GROUPS = {   # kernel-name prefix -> bench.py launch group
-    "k_linearize": "k_linearize", "k_solve": "k_solve", "k_step": "k_step",
+    "k_linearize_last": "k_step", "k_linearize": "k_linearize", "k_solve": "k_solve", "k_step": "k_step",      # k_linearize_last = the step-only launch that ends a solve
     "k_marg_prepare": "k_marg_prepare", "k_marg_schur": "k_marg_schur", "k_marg_finish": "k_marg_finish", "k_mf_": "k_marg_finish", "k_prior_prep": "k_prior_prep",
     "b_minmax": "s2m_voxel_grid", "b_voxel_keys": "s2m_voxel_grid", "void b_voxel_keys": "s2m_voxel_grid", "void b_voxel_reduce": "s2m_voxel_grid",
     "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_voxel_grid",
@@ -21,7 +21,7 @@ GROUPS = {   # kernel-name prefix -> bench.py launch group
     "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
     "b_crop_compact": "s2m_submap", "b_transform_append": "s2m_submap", "b_bump": "s2m_submap",
 }
-LAUNCHES_PER_STEP = {"k_linearize": 9, "k_solve": 8, "k_step": 8, "k_marg_prepare": 1, "k_marg_schur": 1, "k_marg_finish": 1, "k_prior_prep": 1,
+LAUNCHES_PER_STEP = {"k_linearize": 8, "k_solve": 8, "k_step": 1, "k_marg_prepare": 1, "k_marg_schur": 1, "k_marg_finish": 1, "k_prior_prep": 1,
                      "s2m_voxel_grid": 4, "s2m_radix_sort": 1, "s2m_neighbour_index": 2, "s2m_associate": 4, "s2m_lm_solve": 2, "s2m_submap": 2}
 
 
@@ -43,7 +43,7 @@ def main():
                 kn = r["Kernel_Name"].split("(")[0][:80]
                 # the back-end kernels run one workgroup per window: only their dispatches over the full batch count (the bench's PCIe-inclusive leg and the ragged
                 # line solve other batch sizes with the same kernels, outside the timed steps)
-                if kn in ("k_linearize", "k_solve", "k_solve_sb", "k_step") and int(r["Grid_Size"]) != frames * int(r["Workgroup_Size"]):
+                if kn in ("k_linearize", "k_linearize_last", "k_solve", "k_solve_sb", "k_step") and int(r["Grid_Size"]) != frames * int(r["Workgroup_Size"]):
                     continue
                 per_kernel[kn][cname].append(float(r["Counter_Value"]))
     out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE --output-format csv -- python3 bench.py --steps S --warmup W --no-cpu-baseline (two passes)",

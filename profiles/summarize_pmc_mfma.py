@@ -19,7 +19,7 @@ def main():
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"].split("(")[0]
         # one workgroup per window: only the dispatches over the full batch count (the bench's PCIe-inclusive leg solves a smaller batch with the same kernels)
-        if k in ("k_linearize", "k_solve", "k_solve_sb", "k_step") and int(r["Grid_Size"]) == frames * int(r["Workgroup_Size"]):
+        if k in ("k_linearize", "k_linearize_last", "k_solve", "k_solve_sb", "k_step") and int(r["Grid_Size"]) == frames * int(r["Workgroup_Size"]):
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"source": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE "
                      "--output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-lidar-stage --no-marginalize --ragged-windows 0 (tools/gpu_round.sh)",

@@ -237,7 +237,10 @@ __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the
     return -1;
 }
 
-extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) {
+// JAC = false: the launch after the LAST solve of the iteration budget. Its linearisation would never be used (Ceres tests max_num_iterations before the gradient),
+// so it only takes the step: candidate, cost of every factor (residuals only), accept / reject — a ninth of the linearisations of a solve.
+template <bool JAC>
+__device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_zero) {
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     VbState *st = b.st + w;
     if (!iteration_zero && st->done) return;
@@ -351,7 +354,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         if (mine) s_wl[wave][__popcll(m & ((1ULL << lane) - 1ULL))] = lane;
         if (lane == 0) s_wl[wave][VB_NPAIR] = __popcll(m);
     }
-    for (int i = tid; i < 10 * 512; i += NT) s_U[i] = 0.0;
+    if (JAC) for (int i = tid; i < 10 * 512; i += NT) s_U[i] = 0.0;
     __syncthreads();
     if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
     if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
@@ -371,26 +374,35 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         const double *rec = b.imu + ((size_t)w * 10 + k) * IMU_REC;
         if (rec[287] != 0.0) {
             double r[15];
-            imu_raw_eval<true, 32, false>(s_pose + 7 * k, s_sb + 9 * k, s_pose + 7 * (k + 1), s_sb + 9 * (k + 1), rec, b.G, r, s_U + 512 * k);
-            for (int m = 0; m < 15; m++) s_U[512 * k + 32 * m + 30] = r[m];
+            if (JAC) {
+                imu_raw_eval<true, 32, false>(s_pose + 7 * k, s_sb + 9 * k, s_pose + 7 * (k + 1), s_sb + 9 * (k + 1), rec, b.G, r, s_U + 512 * k);
+                for (int m = 0; m < 15; m++) s_U[512 * k + 32 * m + 30] = r[m];
+            } else {
+                imu_raw_eval<false>(s_pose + 7 * k, s_sb + 9 * k, s_pose + 7 * (k + 1), s_sb + 9 * (k + 1), rec, b.G, r, nullptr);
+                double acc = 0;
+                for (int i = 0; i < 15; i++) { double sq = 0; for (int m = i; m < 15; m++) sq += rec[IMU_SQRT + 15 * i + m] * r[m]; acc += sq * sq; }
+                cost_local += 0.5 * acc;
+            }
         }
     }
     if (tid >= 64 && tid < 74) {
         const int k = tid - 64;
         if (b.use_lidar) {
             const double *lc = b.lidar + ((size_t)w * 10 + k) * 7;
-            double Ji[36], Jj[36];
-            lidar_between_eval<true>(s_pose + 7 * k, s_pose + 7 * (k + 1), q_load(b.qil), b.til, q_load(lc), lc + 4, s_lidr + 6 * k, Ji, Jj);
-            for (int rr = 0; rr < 6; rr++) for (int c = 0; c < 6; c++) { s_lidJ[72 * k + 12 * rr + c] = Ji[6 * rr + c]; s_lidJ[72 * k + 12 * rr + 6 + c] = Jj[6 * rr + c]; }
+            if (JAC) {
+                double Ji[36], Jj[36];
+                lidar_between_eval<true>(s_pose + 7 * k, s_pose + 7 * (k + 1), q_load(b.qil), b.til, q_load(lc), lc + 4, s_lidr + 6 * k, Ji, Jj);
+                for (int rr = 0; rr < 6; rr++) for (int c = 0; c < 6; c++) { s_lidJ[72 * k + 12 * rr + c] = Ji[6 * rr + c]; s_lidJ[72 * k + 12 * rr + 6 + c] = Jj[6 * rr + c]; }
+            } else lidar_between_eval<false>(s_pose + 7 * k, s_pose + 7 * (k + 1), q_load(b.qil), b.til, q_load(lc), lc + 4, s_lidr + 6 * k, nullptr, nullptr);
         } else {
-            for (int e = 0; e < 72; e++) s_lidJ[72 * k + e] = 0;
+            if (JAC) for (int e = 0; e < 72; e++) s_lidJ[72 * k + e] = 0;
             for (int e = 0; e < 6; e++) s_lidr[6 * k + e] = 0;
         }
     }
     __syncthreads();
     STAMP(0, 2);
     // ---- IMU: X = sqrt_info * [Jraw | r] on MFMA, in place (imu_factor.h:64,93,126,145,160) -------------------------
-    for (int task = wave; task < 20; task += 4) {
+    if (JAC) for (int task = wave; task < 20; task += 4) {
         const int k = task >> 1, ct = task & 1;
         double *Xk = s_U + 512 * k;
         const double *S = b.imu + ((size_t)w * 10 + k) * IMU_REC + IMU_SQRT;
@@ -410,7 +422,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     __syncthreads();
     STAMP(0, 3);
     // ---- IMU: [J r]^T [J r] on MFMA -> imuH (30x30), imug (30), cost; LiDAR blocks on the VALU ------------------------
-    {
+    if (JAC) {
         double *imuH = b.imuH + ww * 9000, *imug = b.imug + ww * 300;
         for (int task = wave; task < 30; task += 4) {
             const int k = task / 3, tt = task - 3 * k;
@@ -461,6 +473,22 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     double4_t cacc = {0, 0, 0, 0}, cacc1 = {0, 0, 0, 0};            // the open pair of this wave's class list across chunk boundaries
     int kcur = 0;
     const int nk = __builtin_amdgcn_readfirstlane(s_wl[wave][VB_NPAIR]);
+    if (!JAC) {
+        // residuals only: one lane per factor slot, no rows, no products
+        for (int fac = tid; fac < nfac; fac += NT) {
+            const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)fac * 8);
+            const double4_t ra = rp[0], rb = rp[1];
+            const double pts_i[3] = {ra[0], ra[1], ra[2]}, pts_j[3] = {ra[3], rb[0], rb[1]};
+            const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
+            if ((ib >> 17) & 1) continue;                     // unused slot of the chunk-interleaved layout
+            const int f = (int)(ia & 0xffffffffu), fi = (int)(ib & 0xff), fj = (int)((ib >> 8) & 0xff);
+            double r[2];
+            projection_eval_pair<false>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, pts_i, pts_j, feat[f], b.sqrt_info, r, nullptr, nullptr, nullptr);
+            double rho0, sw;
+            cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
+            cost_local += 0.5 * rho0;
+        }
+    } else
     for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
         t_a = TICK();
         const int q = c0 + tid;
@@ -544,6 +572,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         { long long t_b = TICK(); t_sync2 += t_b - t_a; t_a = t_b; }
     }
     if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
+    double gmax = 0, xsq = 0;
+    if (JAC) {
     STAMP(0, 5);
     // ---- visual pose-pose blocks (frame-block lower triangle) -> Hpp[66][36] ------------------------------------------
     // a pair without factors was never written: it reads as zero
@@ -606,7 +636,6 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     __syncthreads();
     STAMP(0, 7);
     // ---- gradient g = J^T r over the reduced camera/IMU block (frame-major order) ---------------------------------
-    double gmax = 0, xsq = 0;
     double *gout = b.g + ww * VB_P;
     if (tid < VB_P) {
         const int a = tid / 15, l = tid - 15 * a;
@@ -664,6 +693,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
         const double *gf = b.gf + ww * FM;
         for (int f = tid; f < F; f += NT) if (!f_const[f]) { gmax = fmax(gmax, fabs(gf[f])); xsq += feat[f] * feat[f]; }
     }
+    }
     STAMP(0, 8);
     const double cost = block_sum(cost_local, s_red);
     const double gm = block_max(gmax, s_red);
@@ -693,8 +723,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
                 st->mu = fmax(1e-8, 2.0 * st->mu / 10.0);
                 st->reuse = 0;
                 st->num_successful += 1;
-                st->x_cost = cost; st->gradient_max_norm = gm; st->x_norm = sqrt(xs);
-                st->ws = wset;
+                st->x_cost = cost;
+                if (JAC) { st->gradient_max_norm = gm; st->x_norm = sqrt(xs); st->ws = wset; }      // the cost-only launch wrote no workspace (and nothing reads one after it)
             } else {
                 st->radius *= 0.5;     // StepRejected: the next solve re-uses the factorisation of x's workspace
                 st->reuse = 1;
@@ -710,6 +740,8 @@ extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iter
     }
     STAMP(0, 9);
 }
+extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) { linearize_body<true>(b, iteration_zero); }
+extern "C" __global__ __launch_bounds__(NT) void k_linearize_last(VbBatch b) { linearize_body<false>(b, 0); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_solve helpers
