@@ -476,7 +476,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": lps[dom], "algorithmic_bytes_per_launch": alg[dom] / max(lps[dom], 1e-9),
                          "algorithmic_bytes_per_window_iteration": abytes,
-                         "whole_iteration": {"ms": it_ms, "achieved": whole_it, "frac": whole_it / 8000.0, "what": "388 KB x windows over k_linearize + k_solve + k_step of one iteration"},
+                         "whole_iteration": {"ms": it_ms, "achieved": whole_it, "frac": whole_it / 8000.0, "what": "388 KB x windows over the launches of one iteration (k_solve_sb + k_linearize; k_step = the step-only launch that ends a solve, spread over the iterations)"},
                          "kernels_ms": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
                          "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                          "kernels_achieved_GBps": {k: alg[k] / (prof[k]["ms"] / args.steps) / 1e6 for k in alg if prof[k]["launches"] > 0 and prof[k]["ms"] > 0}},
