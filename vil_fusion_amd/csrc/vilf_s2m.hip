@@ -1314,16 +1314,18 @@ __global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const dou
                     se3_plus(s_x, d, s_c);
                 }
             }
-            s_ctl[0] = go; s_ctl[1] = valid;
+            s_ctl[0] = go; s_ctl[1] = valid; s_ctl[2] = (iteration >= max_it) ? 1 : 0;
         }
         __syncthreads();
-        const int go = s_ctl[0], valid = s_ctl[1];
+        const int go = s_ctl[0], valid = s_ctl[1], last = s_ctl[2];
         __syncthreads();
         if (!go) break;
         if (!valid) continue;
         // cost AND linearisation at the candidate in one sweep over the factor records: an accepted step (the usual case) then needs no
         // second sweep; a rejected one leaves s_ev (the linearisation at x) untouched
-        s2m_evaluate<true>(s_c, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_cand);
+        // ... except at the last iteration of the budget: nothing would use that linearisation, the cost alone decides the step
+        if (last) s2m_evaluate<false>(s_c, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_cand);
+        else s2m_evaluate<true>(s_c, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_cand);
         if (tid == 0) {
             const double cand = s_cand[27];
             double sn = 0;
