@@ -982,7 +982,8 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         const double rd = cost_change / model_cost_change;
         if (rd > min_relative_decrease) {
             x = cand; x_norm = xnorm(x);
-            if ((rc = eval_grad_jac()) != VILF_OK) return rc;
+            if (iteration < max_it) { if ((rc = eval_grad_jac()) != VILF_OK) return rc; }
+            else x_cost = cand_cost;                                     // the budget is spent: nothing would use the linearisation at the accepted point
             num_successful++;
             if (rd < 0.25) radius *= 0.5;                                // step_accepted
             if (rd > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
