@@ -410,7 +410,7 @@ def main():
                 "s2m_neighbour_index": B * nm * 16 * 2,                  # both maps: read points, write them cell-sorted
                 "s2m_radix_sort": B * ns * 12 * 2,                       # only when a scan cloud exceeds the in-LDS grid (22 k points): ONE pass over (key, index)
                 "s2m_voxel_grid": B * (nm + ns + nq) * 16 * 2,           # 4 grids: read points, write centroids
-                "s2m_lm_solve": B * nq * 84.0 * 2 * 4,                   # factor records (80 B + kind), 2 passes x ~4 evaluations
+                "s2m_lm_solve": B * nq * 64.0 * 2 * 5,                   # factor records (one 64-byte sector each), 2 passes x 5 evaluations
                 "s2m_submap": B * nq * 16 * 2})                         # transform + append of the registered scan (crop and grid are in s2m_voxel_grid)
         workload_tag = ("lidar+" if lid is not None else "") + "solve" + ("" if args.no_marginalize else "+marginalize")
         dom = max(alg, key=lambda k: prof[k]["ms"])

@@ -1081,8 +1081,11 @@ __device__ __forceinline__ void qr_solve_5x3(const double *Ain, const double *bi
     }
 }
 
-// factor record: cp[3] then edge: pa[3] pb[3] / surf: n[3] d  -> 10 doubles; kind (0 invalid, 1 edge, 2 surf) separately
-#define S2M_FREC 10
+// factor record, ONE aligned 64-byte sector per query: doubles 0..5 = edge: pa[3] pb[3] / surf: n[3] d 0 0; double 6 = the bits of the floats cp.x | cp.y << 32; double 7 = cp.z |
+// kind << 32 (kind 0 invalid, 1 edge, 2 surf; the scan point cp IS a float). The LM solve re-reads every record five times per pass and is bound by that traffic: the
+// former 80-byte records (+ a separate kind array) straddled two sectors each.
+#define S2M_FREC 8
+__device__ __forceinline__ double s2m_pack2(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
 // one thread per query point of one stream. Edge queries write records [0, n_ds_edge), surf queries [n_ds_edge, n_ds_edge + n_ds_surf).
 __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const double *pose_all, CSet map, const float4 *sorted_all, const int *start_all,
                             const S2BRes *res, double *frec_all, int *fkind_all, int capq) {
@@ -1100,7 +1103,7 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
     q_rot(q_load(pose), cp, pw);
     const float qx = (float)(pw[0] + pose[4]), qy = (float)(pw[1] + pose[5]), qz = (float)(pw[2] + pose[6]);
     int kind = 0;
-    double rec[S2M_FREC] = {cp[0], cp[1], cp[2], 0, 0, 0, 0, 0, 0, 0};
+    double rec[S2M_FREC] = {0, 0, 0, 0, 0, 0, 0, 0};
     int idx[5]; float d2[5];
 #ifdef VILF_STAMPS
     const bool st_ = blockIdx.y == S2M_STAMP_WG && blockIdx.x == 2 && threadIdx.x == 0;
@@ -1125,7 +1128,7 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
                 eig3(cov, w, V);
                 if (w[2] > 3 * w[1]) {
                     kind = 1;
-                    for (int a = 0; a < 3; a++) { rec[3 + a] = 0.1 * V[3 * a + 2] + c[a]; rec[6 + a] = -0.1 * V[3 * a + 2] + c[a]; }
+                    for (int a = 0; a < 3; a++) { rec[a] = 0.1 * V[3 * a + 2] + c[a]; rec[3 + a] = -0.1 * V[3 * a + 2] + c[a]; }
                 }
             } else {
                 double A[15], B[5] = {-1, -1, -1, -1, -1}, nn[3];
@@ -1136,12 +1139,15 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
                 nn[0] /= nrm; nn[1] /= nrm; nn[2] /= nrm;
                 bool ok = true;
                 for (int j = 0; j < 5; j++) if (fabs(nn[0] * nb[j][0] + nn[1] * nb[j][1] + nn[2] * nb[j][2] + d) > 0.2) ok = false;
-                if (ok) { kind = 2; rec[3] = nn[0]; rec[4] = nn[1]; rec[5] = nn[2]; rec[6] = d; }
+                if (ok) { kind = 2; rec[0] = nn[0]; rec[1] = nn[1]; rec[2] = nn[2]; rec[3] = d; }
             }
         }
     }
-    fkind_all[(size_t)sid * capq + slot] = kind;
-    for (int k = 0; k < S2M_FREC; k++) frec[k] = rec[k];
+    fkind_all[(size_t)sid * capq + slot] = kind;                 // the solve counts its factors from this array; the sweeps read the kind out of the record
+    rec[6] = s2m_pack2(__float_as_uint(p.x), __float_as_uint(p.y)); rec[7] = s2m_pack2(__float_as_uint(p.z), (unsigned)kind);
+    double2 *fo = reinterpret_cast<double2 *>(frec);
+#pragma unroll
+    for (int k = 0; k < 4; k++) fo[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
 #ifdef VILF_STAMPS
     if (st_) { const int kid = 6 + is_surf; s2m_dbg[kid * 32 + 0] = st1_ - st0_; s2m_dbg[kid * 32 + 1] = __builtin_readcyclecounter() - st1_; s2m_dbg[kid * 32 + 30] = ds.n[sid]; }
 #endif
@@ -1177,19 +1183,21 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
     // The lane walks its factors i = tid, tid + 256, ... as before; the records [0, n_edge) hold the edge queries (kind 0 or 1), the rest the plane queries (kind 0 or
     // 2), so the walk is two loops with one code path each. A record is requested together with its kind, not after the kind test (that made every factor two
     // dependent memory round trips — eighteen factors per lane and sweep, most of the solve); the plane loop, lighter in registers, also keeps the next record in flight.
+    // unpack: the scan point (three floats) and the kind from doubles 6, 7
+#define S2M_UNPACK(R6, R7, CP, KIND) { const unsigned long long a_ = (unsigned long long)__double_as_longlong(R6), b_ = (unsigned long long)__double_as_longlong(R7); \
+        CP[0] = (double)__uint_as_float((unsigned)a_); CP[1] = (double)__uint_as_float((unsigned)(a_ >> 32)); CP[2] = (double)__uint_as_float((unsigned)b_); KIND = (int)(b_ >> 32); }
     int i = threadIdx.x;
     for (; i < n_edge; i += S2M_NT) {
         const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)i * S2M_FREC);
-        double2 rr[5];
+        double2 rr[4];
 #pragma unroll
-        for (int k = 0; k < 5; k++) rr[k] = rp[k];
-        const int kind = fkind[i];
-        double rec[S2M_FREC];
-#pragma unroll
-        for (int k = 0; k < 5; k++) { rec[2 * k] = rr[k].x; rec[2 * k + 1] = rr[k].y; }
+        for (int k = 0; k < 4; k++) rr[k] = rp[k];
+        double cp[3]; int kind;
+        S2M_UNPACK(rr[3].x, rr[3].y, cp, kind)
         if (kind != 1) continue;
+        const double pa[3] = {rr[0].x, rr[0].y, rr[1].x}, pb[3] = {rr[1].y, rr[2].x, rr[2].y};
         double r[3], J[18];
-        edge_eval<JAC>(x, rec, rec + 3, rec + 6, r, J);
+        edge_eval<JAC>(x, cp, pa, pb, r, J);
         double rho0, sw;
         huber(r[0] * r[0] + r[1] * r[1] + r[2] * r[2], huber_a, rho0, sw);
         acc[27] += 0.5 * rho0;
@@ -1199,7 +1207,6 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
         }
     }
     if (i < nfac) {
-        int kind_n = fkind[i];
         double2 rn[4];
         {
             const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)i * S2M_FREC);
@@ -1207,24 +1214,25 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
             for (int k = 0; k < 4; k++) rn[k] = rp[k];
         }
         for (; i < nfac; i += S2M_NT) {
-            const int kind = kind_n;
-            const double rec[8] = {rn[0].x, rn[0].y, rn[1].x, rn[1].y, rn[2].x, rn[2].y, rn[3].x, rn[3].y};
+            const double nv[3] = {rn[0].x, rn[0].y, rn[1].x}, dd = rn[1].y;
+            double cp[3]; int kind;
+            S2M_UNPACK(rn[3].x, rn[3].y, cp, kind)
             {
                 const int ic = min(i + S2M_NT, nfac - 1);
-                kind_n = fkind[ic];
                 const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)ic * S2M_FREC);
 #pragma unroll
                 for (int k = 0; k < 4; k++) rn[k] = rp[k];
             }
             if (kind != 2) continue;
             double r[1], J[6];
-            surf_eval<JAC>(x, rec, rec + 3, rec[6], r, J);
+            surf_eval<JAC>(x, cp, nv, dd, r, J);
             double rho0, sw;
             huber(r[0] * r[0], huber_a, rho0, sw);
             acc[27] += 0.5 * rho0;
             if (JAC) S2M_ROW(J, r[0])
         }
     }
+#undef S2M_UNPACK
 #undef S2M_ROW
     // 28 sums at once: wave butterflies, per-wave partials to LDS, thread k adds the partials of sum k in wave order
     __syncthreads();
