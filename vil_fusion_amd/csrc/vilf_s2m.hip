@@ -1156,6 +1156,7 @@ __global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const do
 // ---- the persistent LM solve -------------------------------------------------------------------------------------------
 
 #define S2M_NT 256
+#define S2M_LCAP 16384         // valid-factor slots listed in LDS by b_solve (32 KB); more valid factors than this: every slot is visited
 #define S2M_NW (S2M_NT / 64)
 // block sum with a fixed order: butterfly inside each wave, then the per-wave partials in wave order (two barriers)
 __device__ __forceinline__ double wave_sum(double v) { return vilf_wave_sum64(v); }       // callers: all lanes active
@@ -1172,7 +1173,9 @@ __device__ double s2m_block_sum(double v, double *s_red) {
 }
 // cost (and, JAC: gradient g[6], hessian H[21] lower-packed) at pose x over all valid factors
 template <bool JAC>
-__device__ void s2m_evaluate(const double *x, const double *frec, const int *fkind, int n_edge, int nfac, double huber_a, double *s_red, double *s_out /*28*/) {
+// list != nullptr: the slots of the VALID factors (edge factors first, then plane factors, ascending), n_edge / nfac counting list entries; nullptr: every query slot is
+// visited and the kind in the record decides
+__device__ void s2m_evaluate(const double *x, const double *frec, const unsigned short *list, int n_edge, int nfac, double huber_a, double *s_red, double *s_out /*28*/) {
     double acc[28];
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0;
@@ -1188,7 +1191,7 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
         CP[0] = (double)__uint_as_float((unsigned)a_); CP[1] = (double)__uint_as_float((unsigned)(a_ >> 32)); CP[2] = (double)__uint_as_float((unsigned)b_); KIND = (int)(b_ >> 32); }
     int i = threadIdx.x;
     for (; i < n_edge; i += S2M_NT) {
-        const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)i * S2M_FREC);
+        const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)(list ? (int)list[i] : i) * S2M_FREC);
         double2 rr[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) rr[k] = rp[k];
@@ -1209,7 +1212,7 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
     if (i < nfac) {
         double2 rn[4];
         {
-            const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)i * S2M_FREC);
+            const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)(list ? (int)list[i] : i) * S2M_FREC);
 #pragma unroll
             for (int k = 0; k < 4; k++) rn[k] = rp[k];
         }
@@ -1219,7 +1222,7 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const int *fki
             S2M_UNPACK(rn[3].x, rn[3].y, cp, kind)
             {
                 const int ic = min(i + S2M_NT, nfac - 1);
-                const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)ic * S2M_FREC);
+                const double2 *rp = reinterpret_cast<const double2 *>(frec + (size_t)(list ? (int)list[ic] : ic) * S2M_FREC);
 #pragma unroll
                 for (int k = 0; k < 4; k++) rn[k] = rp[k];
             }
@@ -1256,12 +1259,34 @@ __global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const dou
     __shared__ int s_ctl[4];
     const int tid = threadIdx.x, nfac = n_edge_q + n_surf_q;
     if (tid < 7) s_x[tid] = pose_in[tid];
+    // The valid factors' slots as a compact list in LDS (about a third of the queries have no valid factor; the five sweeps of a pass are bound by the traffic of the
+    // records): every thread counts the edge / plane factors of its contiguous slice of the slots, a block scan gives the offsets, a second walk over the slice fills
+    // the list — edge factors first, both parts ascending. Falls back to visiting every slot when the list would not fit.
+    __shared__ unsigned short s_list[S2M_LCAP];
+    __shared__ int s_scan[S2M_NW];
+    const int per = (nfac + S2M_NT - 1) / S2M_NT, a0 = min(nfac, tid * per), a1 = min(nfac, a0 + per);
     int ne = 0, ns = 0;
-    for (int i = tid; i < nfac; i += S2M_NT) { const int k = fkind[i]; if (k == 1) ne++; else if (k == 2) ns++; }
-    const int tne = (int)(s2m_block_sum((double)ne, s_red) + 0.5), tns = (int)(s2m_block_sum((double)ns, s_red) + 0.5);
-    if (tne + tns == 0) { if (tid == 0) { out->cost[pass] = 0; out->its[pass] = 0; out->nfe[pass] = 0; out->nfs[pass] = 0; } return; }
+    for (int i = a0; i < a1; i++) { const int k = fkind[i]; if (k == 1) ne++; else if (k == 2) ns++; }
+    int incl = ne | (ns << 16);                                   // two packed counts (<= 65535 each: slots are 16-bit)
+    const int mine = incl, lane_ = tid & 63, wave_ = tid >> 6;
+#pragma unroll
+    for (int of = 1; of < 64; of <<= 1) { const int u = __shfl_up(incl, of, 64); if (lane_ >= of) incl += u; }
+    if (lane_ == 63) s_scan[wave_] = incl;
     __syncthreads();
-    s2m_evaluate<true>(s_x, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_ev);
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < S2M_NW; k++) { if (k < wave_) off += s_scan[k]; tot += s_scan[k]; }
+    const int tne = tot & 0xffff, tns = tot >> 16, excl = off + incl - mine;
+    if (tne + tns == 0) { if (tid == 0) { out->cost[pass] = 0; out->its[pass] = 0; out->nfe[pass] = 0; out->nfs[pass] = 0; } return; }
+    const bool use_list = tne + tns <= S2M_LCAP && nfac <= 65535;
+    if (use_list) {
+        int pe = excl & 0xffff, ps = tne + (excl >> 16);
+        for (int i = a0; i < a1; i++) { const int k = fkind[i]; if (k == 1) s_list[pe++] = (unsigned short)i; else if (k == 2) s_list[ps++] = (unsigned short)i; }
+    }
+    const unsigned short *list = use_list ? s_list : nullptr;
+    const int ev_ne = use_list ? tne : min(n_edge_q, nfac), ev_n = use_list ? tne + tns : nfac;
+    __syncthreads();
+    s2m_evaluate<true>(s_x, frec, list, ev_ne, ev_n, huber_a, s_red, s_ev);
     // thread-0 scalars of the trust-region loop (trust_region_minimizer.cc + levenberg_marquardt_strategy.cc)
     double x_cost = s_ev[27], radius = 1e4, decrease_factor = 2.0, x_norm = 0, mcc = 0;
     bool reuse_diagonal = false;
@@ -1332,8 +1357,8 @@ __global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const dou
         // cost AND linearisation at the candidate in one sweep over the factor records: an accepted step (the usual case) then needs no
         // second sweep; a rejected one leaves s_ev (the linearisation at x) untouched
         // ... except at the last iteration of the budget: nothing would use that linearisation, the cost alone decides the step
-        if (last) s2m_evaluate<false>(s_c, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_cand);
-        else s2m_evaluate<true>(s_c, frec, fkind, min(n_edge_q, nfac), nfac, huber_a, s_red, s_cand);
+        if (last) s2m_evaluate<false>(s_c, frec, list, ev_ne, ev_n, huber_a, s_red, s_cand);
+        else s2m_evaluate<true>(s_c, frec, list, ev_ne, ev_n, huber_a, s_red, s_cand);
         if (tid == 0) {
             const double cand = s_cand[27];
             double sn = 0;
