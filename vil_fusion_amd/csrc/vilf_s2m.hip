@@ -815,6 +815,7 @@ __device__ __forceinline__ int bucket_of(int ix, int iy) { return ((iy & 255) <<
 #define S2B_HW(w) ((w) + ((w) >> 5))     // LDS word index with one pad word per 32: a thread's 32 consecutive words and its neighbours' stay on different banks
 #define S2B_HWORDS (S2B_NB / 2 + S2B_NB / 64)
 #define S2B_FL 4
+#define S2B_MAXR 28          // rounds (of S2B_FL x 1024 points) whose ranks b_bucket_index keeps in registers
 __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all, int *start_all, float4 *sorted_all, int *err) {
     extern __shared__ unsigned int s_hist[];          // [S2B_HWORDS] two 16-bit counters per word (padded), then s_base[1024]
     __shared__ int s_w[S2B_IT / 64], s_total, s_big;
@@ -833,6 +834,37 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     __syncthreads();
     bool over = false;
     S2M_STAMP(skid, 1, true);
+    // The arrival rank of a point inside its bucket (count pass) is what the scatter pass needs again: a lane meets the same points in both passes, so the ranks stay in
+    // its registers, two 16-bit ranks per register, the rounds fully unrolled (up to S2B_MAXR rounds = 114 k points; larger maps keep them in global memory as before:
+    // 4 bytes of HBM traffic per point, in a kernel that is bound by that traffic).
+    unsigned int rreg[2 * S2B_MAXR];
+    const bool regrk = n <= S2B_MAXR * S2B_FL * S2B_IT;
+    if (regrk) {
+        float2 cur[S2B_FL], nxt[S2B_FL];
+#pragma unroll
+        for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(tid + u * S2B_IT, max(n - 1, 0)); cur[u] = make_float2(pp->x, pp->y); }
+#pragma unroll
+        for (int r = 0; r < S2B_MAXR; r++) {
+            const int i0 = tid + r * S2B_FL * S2B_IT;
+            rreg[2 * r] = 0; rreg[2 * r + 1] = 0;
+            if (i0 >= n) break;
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(i0 + (S2B_FL + u) * S2B_IT, n - 1); nxt[u] = make_float2(pp->x, pp->y); }
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) {
+                const int i = i0 + u * S2B_IT;
+                if (i >= n) continue;
+                const int b = bucket_of((int)floorf(cur[u].x), (int)floorf(cur[u].y));
+                const int sh = 16 * (b & 1);
+                const unsigned int old = atomicAdd(&s_hist[S2B_HW(b >> 1)], 1u << sh);
+                const unsigned int rank = (old >> sh) & 0xffffu;
+                if (rank == 0xffffu) over = true;          // the 65536th point of a bucket would carry into its neighbour
+                rreg[2 * r + (u >> 1)] |= rank << (16 * (u & 1));
+            }
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) cur[u] = nxt[u];
+        }
+    } else
     {   // S2B_FL points per lane and round, the next round's loads in flight while this round's LDS atomics run (a round that issues its loads only after the last one's
         // atomics pays the memory latency once per round: 15 rounds of a 59 k-point map)
         float2 cur[S2B_FL], nxt[S2B_FL];
@@ -890,6 +922,32 @@ __global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all,
     __threadfence_block();
     __syncthreads();
     S2M_STAMP(skid, 4, true);
+    if (regrk) {
+        const float4 *__restrict__ pr = p;
+        float4 *__restrict__ so = sorted;
+        float4 q[S2B_FL], qn[S2B_FL];
+#pragma unroll
+        for (int u = 0; u < S2B_FL; u++) q[u] = pr[min(tid + u * S2B_IT, max(n - 1, 0))];
+#pragma unroll
+        for (int r = 0; r < S2B_MAXR; r++) {
+            const int i0 = tid + r * S2B_FL * S2B_IT;
+            if (i0 >= n) break;
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) qn[u] = pr[min(i0 + (S2B_FL + u) * S2B_IT, n - 1)];
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) {
+                const int i = i0 + u * S2B_IT;
+                if (i >= n) continue;
+                const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
+                const int st = big ? start[b] : s_base[b >> 6] + (int)((s_hist[S2B_HW(b >> 1)] >> (16 * (b & 1))) & 0xffffu);
+                const int pos = st + (int)((rreg[2 * r + (u >> 1)] >> (16 * (u & 1))) & 0xffffu);
+                q[u].w = __int_as_float(i);                // original map index (tie-break like a linear scan)
+                if (pos < map.cap) so[pos] = q[u];
+            }
+#pragma unroll
+            for (int u = 0; u < S2B_FL; u++) q[u] = qn[u];
+        }
+    } else
     {
         float4 q[S2B_FL], qn[S2B_FL]; unsigned short r4[S2B_FL], rn[S2B_FL];
 #pragma unroll
