@@ -508,8 +508,8 @@ __device__ __forceinline__ float4 mu_centroid(const float4 *ts, int a, int e) {
 // previous old key and this one, a tail run in this leaf, or a leaf that holds several old points. Such points are queued during the
 // sweep and handled afterwards, one per lane, from global memory — their dependent loads never sit on the sweep's critical path.
 template <int AXB, int IDXB>
-__device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, int nOld, const float4 *p, float4 *o, const float4 *ts, const unsigned long long *T, int ntv, int THtot,
-                                        float inv, const MuBox &box) {
+__device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool between, int jlo, int nOld, const float4 *p, float4 *o, const float4 *ts, const unsigned long long *T,
+                                        int ntv, int THtot, float inv, const MuBox &box) {
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
     auto lower = [&](unsigned long long k) { int lo = 0, hi = ntv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T[mid] >> IDXB) < k) lo = mid + 1; else hi = mid; } return lo; };
     auto thp = [&](int j) { return j < ntv ? (int)(T[j] & LOW) : THtot; };
@@ -517,11 +517,11 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, int nOld
     unsigned long long key, kp;
     mu_leaf<AXB>(q, inv, key); mu_leaf<AXB>(qp, inv, kp);
     const bool sv = mu_inside(q, box), hasp = i > 0, first = !hasp || kp != key;
-    const int jlo = lower(key);
-    int jup = jlo;
+    int jup = jlo;                                           // jlo = lower(key): found by the sweep, handed over through the queue
     while (jup < ntv && (T[jup] >> IDXB) == key) jup++;
     const bool tm = jup > jlo;
     if (first) {
+        if (between)                                         // (the sweep saw tail leaves between the two old keys: only then is the search worth its dependent LDS reads)
         for (int jj = hasp ? lower(kp + 1) : 0; jj < jlo;) {
             const unsigned long long lf = T[jj] >> IDXB;
             int f = jj + 1;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     // done by mu_rare() from LDS state (kept out of the unrolled body: registers).
     unsigned long long *s_key = s_T + (BIG ? 0 : lds_cap);
     int *s_te = reinterpret_cast<int *>(s_key + MU_TILE);
-    int *gq = gq_all + (size_t)sid * gq_stride;      // queue of uncommon points in global memory (3 ints each: index | head bit 30, H, M): room for every old point
+    int *gq = gq_all + (size_t)sid * gq_stride;      // queue of uncommon points in global memory (4 ints each: index | head bit 30 | between bit 29, H, M, lower bound in the tail): room for every old point
     __shared__ int s_qn;
     __shared__ unsigned long long s_nk;
     if (tid == 0) s_qn = 0;
@@ -693,10 +693,10 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             }
         }
         S2M_ACC(3);
+        int lo[MU_E];
         {   // lower bound of every old key in the sorted tail. The tail array is padded with ~0 to the power of two P2, so the search is the branch-free halving
             // form: one LDS read, one 64-bit compare and one conditional add per step and chain (the sweep is bound by VALU issue — sixteen waves share four
             // SIMDs — and the textbook lo / hi / mid form cost four times the instructions)
-            int lo[MU_E];
             unsigned long long kk[MU_E];
 #pragma unroll
             for (int u = 0; u < MU_E; u++) { lo[u] = 0; kk[u] = key[u] << IDXB; }
@@ -742,9 +742,13 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             base += tot;
             const int e = u * MU_T + tid;
             const int te_prev = e > 0 ? s_te[e - 1] : carryTE;
-            if (((fm >> u) & 1) && tb[u] > te_prev) cm |= 1u << u;   // tail leaves strictly between the previous old key and this one
+            const bool btw = ((fm >> u) & 1) && tb[u] > te_prev;     // tail leaves strictly between the previous old key and this one
+            if (btw) cm |= 1u << u;
             const int H = carryH + (ex & 0xffff), M = carryM + (ex >> 16);
-            if ((cm >> u) & 1) { const int k = atomicAdd(&s_qn, 1); gq[3 * k] = (t0 + e) | (((hm >> u) & 1) << 30); gq[3 * k + 1] = H; gq[3 * k + 2] = M; }
+            if ((cm >> u) & 1) {
+                const int k = atomicAdd(&s_qn, 1);
+                reinterpret_cast<int4 *>(gq)[k] = make_int4((t0 + e) | (((hm >> u) & 1) << 30) | (btw ? (1 << 29) : 0), H, M, lo[u]);
+            }
             else if ((hm >> u) & 1)                                  // the common case: the old point is its leaf's centroid, sum from +0 as the reference does
                 o[H + tb[u] - M] = make_float4(__fadd_rn(0.0f, q[u].x), __fadd_rn(0.0f, q[u].y), __fadd_rn(0.0f, q[u].z), __fadd_rn(0.0f, q[u].w));
         }
@@ -760,7 +764,10 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     __syncthreads();
     {   // the queued points, one per lane: their dependent global loads run in parallel here instead of stalling a tile of the sweep
         const int qn = s_qn;
-        for (int k = tid; k < qn; k += MU_T) mu_rare<AXB, IDXB>(gq[3 * k] & 0x3fffffff, gq[3 * k + 1], gq[3 * k + 2], (gq[3 * k] >> 30) & 1, nOld, p, o, ts, T, ntv, THtot, inv, box);
+        for (int k = tid; k < qn; k += MU_T) {
+            const int4 e = reinterpret_cast<const int4 *>(gq)[k];
+            mu_rare<AXB, IDXB>(e.x & 0x1fffffff, e.y, e.z, (e.x >> 30) & 1, (e.x >> 29) & 1, e.w, nOld, p, o, ts, T, ntv, THtot, inv, box);
+        }
     }
     __syncthreads();
     S2M_STAMP(skid, 3, true);
