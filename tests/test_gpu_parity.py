@@ -441,6 +441,40 @@ def test_large_window_solve_matches_oracle(oracle, n_frames, n_features, tol):
     assert np.abs(1.0 / got.para_feature - 1.0 / ref.para_feature).max() < 1e-4
 
 
+@pytest.mark.parametrize("noise,deg,seed", [(1.5, 15.0, 500), (3.0, 25.0, 502), (3.0, 25.0, 503)])
+def test_large_window_device_trust_region_loop(oracle, monkeypatch, noise, deg, seed):
+    """The general single-window path keeps its trust-region loop on the device (lw_tr_*: every iteration enqueued at once, skip flags instead of host decisions).
+    13-frame windows picked with the oracle for REJECTED steps and re-used Gauss-Newton steps: same iteration / accepted-step / linear-solve counts as the oracle; the
+    host loop (VILF_LW_HOST_LOOP, also the path a failed factorisation falls back to: VILF_LW_FORCE_FALLBACK) gives the same counts and the same state."""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    o.window_size = 12
+    win, _, _ = synth.make_window(seed, o, synth.SynthConfig(n_frames=13, n_features=60, with_prior=False, state_noise=(noise, np.deg2rad(deg), noise)))
+    ref = oracle.window_solve(o, win, None)
+    assert ref.summary["num_successful_steps"] < ref.summary["num_iterations"], "the case was picked for its rejected steps"
+    def run():
+        s = BackendSolver(o)
+        try:
+            return s.optimization(win)
+        finally:
+            s.close()
+    dev = run()
+    monkeypatch.setenv("VILF_LW_HOST_LOOP", "1")
+    host = run()
+    monkeypatch.delenv("VILF_LW_HOST_LOOP")
+    monkeypatch.setenv("VILF_LW_FORCE_FALLBACK", "1")
+    fb = run()
+    for got in (dev, host, fb):
+        for k in ("num_iterations", "num_successful_steps", "num_linear_solves", "termination"):
+            assert got.summary[k] == ref.summary[k], k
+        assert abs(got.summary["initial_cost"] - ref.summary["initial_cost"]) <= 1e-9 * ref.summary["initial_cost"]
+        assert abs(got.summary["final_cost"] - ref.summary["final_cost"]) <= 1e-4 * ref.summary["final_cost"]
+        assert np.abs(got.Ps - ref.Ps).max() < 1e-4 and np.abs(got.Rs - ref.Rs).max() < 1e-5 and np.abs(got.Vs - ref.Vs).max() < 1e-3
+    # (the factor lanes add with fp64 atomics: two runs of the same loop differ in the last bits, amplified by these ill-conditioned windows)
+    for other in (host, fb):
+        assert np.abs(dev.Ps - other.Ps).max() < 1e-5 and abs(dev.summary["final_radius"] - other.summary["final_radius"]) <= 1e-6 * other.summary["final_radius"]
+
+
 def test_error_behaviour_of_the_newer_entry_points(solver, oracle, opts):
     """loud failures instead of silent fall-backs: a pose graph without a complete odometry chain, an edge to a missing node, a non-positive
     sigma; a window whose frame count does not match options.window_size; a batched call with a non-11-frame window"""

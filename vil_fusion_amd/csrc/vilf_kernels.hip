@@ -31,6 +31,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 #define STAMP(kid, i) do { } while (0)
 #define TICK() 0LL
 #endif
+#define LSTAMP(i) do { if (JAC) STAMP(0, i); } while (0)      // the step-only launch shares the body: it must not overwrite the stamps of the linearisation
 __device__ __forceinline__ int pair_index(int i, int j) { return j * (j - 1) / 2 + i; }  // i < j
 // tangent index (frame a, local l in [0,15)) -> P-first permuted index: poses 0..65, speed-bias 66..164
 __device__ __forceinline__ int perm_index(int a, int l) { return l < 6 ? 6 * a + l : 66 + 9 * a + (l - 6); }
@@ -261,7 +262,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     __shared__ int s_pcol[VB_P], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_wl[4][VB_NPAIR + 1];     // pair table: start inside the class list, factor count; per wave the pairs of its class ([55] = how many)
     __shared__ double s_red[NT];
 
-    STAMP(0, 0);
+    LSTAMP(0);
     const int F = b.n_feat[w], nfac = b.n_fac[w];
     const size_t FM = b.Fmax, FC = b.FACmax;
     double *pose_g = b.pose + (size_t)w * 77, *sb_g = b.sb + (size_t)w * 99;
@@ -365,7 +366,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         const int i = p - j * (j - 1) / 2;
         pair_table(s_pose + 7 * i, s_R + 9 * i, s_pose + 7 * j, s_R + 9 * j, s_ric, s_tic, s_pt + PT_LD * p);
     }
-    STAMP(0, 1);
+    LSTAMP(1);
 
     double cost_local = 0;
     // ---- IMU raw (wave 3, lanes 0..9) and LiDAR between-factors (wave 1, lanes 0..9) ------------------------------
@@ -400,7 +401,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         }
     }
     __syncthreads();
-    STAMP(0, 2);
+    LSTAMP(2);
     // ---- IMU: X = sqrt_info * [Jraw | r] on MFMA, in place (imu_factor.h:64,93,126,145,160) -------------------------
     if (JAC) for (int task = wave; task < 20; task += 4) {
         const int k = task >> 1, ct = task & 1;
@@ -420,7 +421,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         for (int q = 0; q < 4; q++) Xk[32 * ((lane >> 4) + 4 * q) + 16 * ct + (lane & 15)] = acc[q];
     }
     __syncthreads();
-    STAMP(0, 3);
+    LSTAMP(3);
     // ---- IMU: [J r]^T [J r] on MFMA -> imuH (30x30), imug (30), cost; LiDAR blocks on the VALU ------------------------
     if (JAC) {
         double *imuH = b.imuH + ww * 9000, *imug = b.imug + ww * 300;
@@ -459,7 +460,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     if (tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
     cost_local += prior_cost_partial(b, w, s_dx, tid);
     __syncthreads();                                                       // the IMU staging area is dead: the region becomes s_X
-    STAMP(0, 4);
+    LSTAMP(4);
     // ---- visual factors: chunks of 256 pair-sorted factors -> LDS rows -> MFMA X^T X per pair ------------------------
     const int *f_start = b.f_start + (size_t)w * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
@@ -574,7 +575,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
     double gmax = 0, xsq = 0;
     if (JAC) {
-    STAMP(0, 5);
+    LSTAMP(5);
     // ---- visual pose-pose blocks (frame-block lower triangle) -> Hpp[66][36] ------------------------------------------
     // a pair without factors was never written: it reads as zero
 #define PD(p, e) pd_get(pd, s_pcn, (p), (e))
@@ -605,7 +606,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             Hpp[36 * (a * (a + 1) / 2 + a) + e] = s;
         }
     }
-    STAMP(0, 6);
+    LSTAMP(6);
     // ---- per-feature Schur vectors: H_ff, g_f, anchor block of the H_pf row -------------------------------------------
     {
         const int *f_nobs = b.f_nobs + (size_t)w * FM, *f_fac0 = b.f_fac0 + (size_t)w * FM;
@@ -634,7 +635,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         }
     }
     __syncthreads();
-    STAMP(0, 7);
+    LSTAMP(7);
     // ---- gradient g = J^T r over the reduced camera/IMU block (frame-major order) ---------------------------------
     double *gout = b.g + ww * VB_P;
     if (tid < VB_P) {
@@ -655,10 +656,11 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         const int pc = s_pcol[tid];
         if (pc >= 0) {
             const int n = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + 1];
-            const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
             double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
+            const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
 #pragma unroll 8
-            for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];
+            for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];     // (tried: 16 entries in flight — same time; column pc of the symmetric H0, coalesced — 17 % slower. Without this product the
+                                                                   //  phase still takes two thirds of its time: under load it waits on the memory system's queues, not on this row)
             s += t;
         }
         // diagonal of J^T J for this reduced variable (its loads are issued before the gradient is stored: a store in between would fence them off)
@@ -694,13 +696,13 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         for (int f = tid; f < F; f += NT) if (!f_const[f]) { gmax = fmax(gmax, fabs(gf[f])); xsq += feat[f] * feat[f]; }
     }
     }
-    STAMP(0, 8);
+    LSTAMP(8);
     const double cost = block_sum(cost_local, s_red);
     const double gm = block_max(gmax, s_red);
     const double xs = block_sum(xsq, s_red);
     if (iteration_zero) {
         if (tid == 0) { st->x_cost = cost; st->gradient_max_norm = gm; st->x_norm = sqrt(xs); st->need_linearize = 0; st->reuse = 0; st->initial_cost = cost; st->ws = 0; }
-        STAMP(0, 9);
+        LSTAMP(9);
         return;
     }
     // ---- accept / reject (trust_region_minimizer.cc): `cost` is the cost at the candidate ---------------------------------------------------------------
@@ -738,7 +740,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         if (tid < 99) sb_g[tid] = s_sb[tid];
         for (int f = tid; f < F; f += NT) feat_x[f] = cfeat[f];
     }
-    STAMP(0, 9);
+    LSTAMP(9);
 }
 extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) { linearize_body<true>(b, iteration_zero); }
 extern "C" __global__ __launch_bounds__(NT) void k_linearize_last(VbBatch b) { linearize_body<false>(b, 0); }

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -30,12 +31,12 @@
 extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec);
 
 struct LwCtx {
-    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den, jscr, tdrec, pri;
+    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den, jscr, tdrec, pri, dv, ctl;
     hipEvent_t ev[2] = {nullptr, nullptr};
     double ms[4] = {0, 0, 0, 0};       // vilf_set_profiling: factor scatter, Schur SYRK, Cholesky (potrf + potrs), other device work
     long launches[4] = {0, 0, 0, 0};
     void release() {
-        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr, &tdrec, &pri};
+        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr, &tdrec, &pri, &dv, &ctl};
         for (DBuf *b : all) b->release();
         for (hipEvent_t &e : ev) if (e) { hipEventDestroy(e); e = nullptr; }
     }
@@ -62,7 +63,8 @@ __device__ __forceinline__ void add(double *p, double v) { unsafeAtomicAdd(p, v)
 // (a feature's ~20 factors spread over many workgroups).
 #define LW_CH 128
 __global__ __launch_bounds__(LW_CH) void lw_visual(int n, const LwVis *vis, const double *x, const double *ex, int NF, int F, double sqrt_info, double cauchy_b, int jac,
-                                                     double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost) {
+                                                     double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     __shared__ double s_J[LW_CH][26];                 // 24 Jacobian entries (row 0: 12, row 1: 12), r0, r1
     __shared__ int s_pair[LW_CH + 1];
     const int tid = threadIdx.x, t = blockIdx.x * LW_CH + tid;
@@ -135,7 +137,8 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(int n, const LwVis *vis, cons
 struct LwTd { double vi[2], vj[2], tdi, tdj, rowi_c, rowj_c; };     // ProjectionTdFactor constants (projection_td_factor.cpp:6-21)
 __device__ __forceinline__ int lw_col(int a, int ci, int cj, int cEx, int cTd) { return a < 6 ? ci + a : (a < 12 ? cj + a - 6 : (a < 18 ? (cEx < 0 ? -1 : cEx + a - 12) : cTd)); }
 __global__ __launch_bounds__(LW_CH) void lw_visual_ext(int n, const LwVis *vis, const LwTd *tdr, const double *x, int NF, int F, int P, int cEx, int cTd, double tr_over_row,
-                                                         double sqrt_info, double cauchy_b, int jac, double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost) {
+                                                         double sqrt_info, double cauchy_b, int jac, double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     __shared__ double s_J[LW_CH][41];                 // row 0: 19, row 1: 19, r0, r1 (+ 1 pad)
     __shared__ int s_pair[LW_CH + 1];
     const int tid = threadIdx.x, t = blockIdx.x * LW_CH + tid;
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(int n, const LwVis *vis, 
 // MarginalizationFactor (marginalization_factor.cpp:333-381) of an 11-frame window: r = r0 + J0 dx with dx from the host (n <= 96 entries),
 // J0^T J0 from k_prior_prep; pcol maps a prior column to its column of the reduced system (-1: block constant in this solve)
 __global__ __launch_bounds__(256) void lw_prior(int n, const double *J, const double *r0, const double *H0, const double *dx, const int *pcol, int P, int jac,
-                                                double *Hpp, double *gp, double *cost) {
+                                                double *Hpp, double *gp, double *cost, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     __shared__ double s_r[VB_PRIOR_LD], s_dx[VB_PRIOR_LD];
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += 256) s_dx[i] = dx[i];
@@ -234,7 +238,8 @@ __global__ __launch_bounds__(256) void lw_prior(int n, const double *J, const do
 // the LiDAR J^T [J r] entries are then one lane per entry. (A lane per factor kept its 15 x 30 Jacobian in a dynamically indexed local array = scratch memory, and
 // walked the 7 k multiply-adds of S J alone: 127 us per launch, 17 launches per solve.)
 __global__ __launch_bounds__(128) void lw_imu_lidar(int NF, int P, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
-                                                    double *Hpp, double *gp, double *cost, double *jscr) {
+                                                    double *Hpp, double *gp, double *cost, double *jscr, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const int k = blockIdx.x, tid = threadIdx.x;
     if (k >= NF - 1) return;
     __shared__ double s_r[16], s_J[15 * 30], s_rw[16], s_lr[8], s_lJi[36], s_lJj[36];
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(int NF, int P, const double 
     }
 }
 // zero the accumulation targets of one linearisation (Hpp, W, h_f, g_p, g_f) and the cost: four entries per thread
-__global__ __launch_bounds__(256) void lw_clear(double *a0, size_t n0, double *a1, size_t n1, double *a2, size_t n2, double *a3, size_t n3, double *a4, size_t n4, double *cost) {
+__global__ __launch_bounds__(256) void lw_clear(double *a0, size_t n0, double *a1, size_t n1, double *a2, size_t n2, double *a3, size_t n3, double *a4, size_t n4, double *cost, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const size_t t0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -291,7 +297,8 @@ __global__ __launch_bounds__(256) void lw_clear(double *a0, size_t n0, double *a
     }
 }
 // J^T [J r] of every IMU factor: one lane per (factor, row a, column b <= 30): 15-term dot products, one atomic each
-__global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, double *gp) {
+__global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, double *gp, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const int t = blockIdx.x * blockDim.x + threadIdx.x, k = t / 930, e = t - 930 * k;
     if (k >= NF - 1) return;
     const int a = e / 31, b = e - 31 * a, c0 = 15 * k;
@@ -302,7 +309,8 @@ __global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, 
     if (b < 30) add(Hpp + (size_t)(c0 + a) * P + c0 + b, s); else add(gp + c0 + a, s);
 }
 // Jacobi scaling in place: Hpp(i, j) *= s_i s_j, W(f, c) *= s_f s_c, h_f *= s_f^2, g *= s. s = [P pose/speed-bias entries | F features]
-__global__ void lw_scale(int P, int F, const double *s, double *Hpp, double *W, double *hf, double *gp, double *gf) {
+__global__ void lw_scale(int P, int F, const double *s, double *Hpp, double *W, double *hf, double *gp, double *gf, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
     if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); Hpp[t] *= s[i] * s[j]; }
     else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P), c = (int)(u % P); W[u] *= s[P + f] * s[c]; }
@@ -311,13 +319,15 @@ __global__ void lw_scale(int P, int F, const double *s, double *Hpp, double *W, 
 }
 // S = Hpp + diag(lm_p^2); den_f = h_f + lm_f^2 (1 for constant features: their rows of W are zero); Wn = W / sqrt(den); tmpF = g_f / sqrt(den)
 __global__ void lw_schur_prep(int P, int F, const double *Hpp, const double *W, const double *hf, const double *gf, const double *lm, const unsigned char *fconst,
-                              double *S, double *Wn, double *den, double *tmpF) {
+                              double *S, double *Wn, double *den, double *tmpF, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
     if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); S[t] = Hpp[t] + (i == j ? lm[i] * lm[i] : 0.0); }
     else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; Wn[u] = W[u] / sqrt(d); }
     else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; den[f] = d; tmpF[f] = gf[f] / sqrt(d); }
 }
-__global__ void lw_feature_back(int F, const double *gf, const double *Wy, const double *den, double *yf) {
+__global__ void lw_feature_back(int F, const double *gf, const double *Wy, const double *den, double *yf, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f < F) yf[f] = (gf[f] - Wy[f]) / den[f];
 }
@@ -330,7 +340,8 @@ __global__ void lw_feature_back(int F, const double *gf, const double *Wy, const
 #define SY_KB 16
 #define SY_LD 65
 typedef double lw_double4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *Wn, double *S, int ksplit) {
+__global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *Wn, double *S, int ksplit, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     __shared__ double sA[SY_KB * SY_LD], sB[SY_KB * SY_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ti = 0;
@@ -392,7 +403,8 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *
 // One workgroup = a 256 x 64 slab: the 64 rows of the diagonal block + 192 rows below it, as 16 x 4 MFMA tiles in registers (wave w owns the tile rows
 // w, w + 4, w + 8, w + 12). Per 4-column panel: lanes holding the panel's columns -> LDS; thread r (one per slab row) factors the 4 x 4 diagonal block itself
 // and solves its row's strip (the strip goes straight to S and to the operand buffer); rank-4 update of every tile right of the panel, one MFMA each.
-__global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, int *info) {
+__global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, int *info, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     __shared__ double s_pan[256 * 4], s_lp[256 * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g4 = lane >> 4;
     const int nb = min(CH_NB, P - j0), P1 = P + 1;                 // the last block is padded with an identity
@@ -459,7 +471,8 @@ __global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, i
     }
 }
 // A22 -= L21 L21^T, lower 64 x 64 tiles of the rows / columns j1 .. P (row P = rhs). grid.x = nt (nt + 1) / 2
-__global__ __launch_bounds__(256) void lw_chol_update(int P, double *S, int j0, int nb) {
+__global__ __launch_bounds__(256) void lw_chol_update(int P, double *S, int j0, int nb, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     __shared__ double sA[CH_NB * CH_LD], sB[CH_NB * CH_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P1 = P + 1, j1 = j0 + nb;
     int ti = 0;
@@ -506,7 +519,8 @@ __global__ __launch_bounds__(256) void lw_chol_update(int P, double *S, int j0, 
 __device__ __forceinline__ double lw_readlane(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, double *y) {
+__global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, double *y, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     extern __shared__ double s_y[];                // P entries
     __shared__ double s_blk[CH_NB], s_tri[CH_NB * CH_LD];
     const int tid = threadIdx.x;
@@ -561,7 +575,8 @@ __global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, dou
     for (int i = tid; i < P; i += 1024) y[i] = s_y[i];
 }
 // row-wise dots y[r] = A[r][0..C) . x (one 64-lane wave per row, A row-major) and column sums y[c] += alpha sum_r A[r][c] x[r] (thread per column)
-__global__ __launch_bounds__(256) void lw_rowdot(int R, int C, const double *A, const double *x, double *y) {
+__global__ __launch_bounds__(256) void lw_rowdot(int R, int C, const double *A, const double *x, double *y, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= R) return;
     const double *a = A + (size_t)row * C;
@@ -571,7 +586,8 @@ __global__ __launch_bounds__(256) void lw_rowdot(int R, int C, const double *A, 
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) y[row] = s;
 }
-__global__ __launch_bounds__(256) void lw_colsum(int R, int C, const double *A, const double *x, double alpha, double *y, int rsplit) {
+__global__ __launch_bounds__(256) void lw_colsum(int R, int C, const double *A, const double *x, double alpha, double *y, int rsplit, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int rchunk = (R + rsplit - 1) / rsplit, ra = blockIdx.y * rchunk, rb = min(R, ra + rchunk);
@@ -613,6 +629,298 @@ inline void h_ypr2R(const double *ypr, double *R) {
 }
 }  // namespace
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The trust-region loop on the device (trust_region_minimizer.cc + dogleg_strategy.cc, traditional dogleg, Jacobi scaling — the logic of the host
+// loop further down, restated once more): the scalars of the minimizer live in LwCtl, the N-vectors in device buffers, and five single-workgroup
+// kernels carry the decisions between the factor / Schur / Cholesky launches. The host enqueues max_num_iterations iterations without reading
+// anything back; every launch of an iteration looks at the skip flags (a finished solve, a rejected step that reuses the linear solve, an invalid
+// step that needs no evaluation) and returns at once when its part is not needed. What the device loop does not do: raise mu and factor again after a
+// failed Cholesky (the number of launches is not known when they are enqueued) — it sets `fallback` and the host loop redoes the solve.
+struct LwCtl {
+    double radius, mu, alpha, step_norm, x_cost, cand_cost, x_norm, gmax, model_change, initial_cost, gg;
+    int iteration, reuse, done, termination, num_successful, num_linear_solves, consecutive_invalid, fallback;
+    int skip_solve, skip_quad, skip_eval, skip_jac, scaling_ready, pad_;
+};
+struct LwTr {
+    LwCtl *ctl;
+    int NF, F, P, N, cEx, cTd, xo, est_ex, est_td, max_it;
+    double *x, *cand;                                              // state: pose | sb | feat | ex[7] | td
+    double *g, *diagH, *scale, *diagonal, *gradient, *gn, *step;   // N each
+    double *vec, *yf;                                              // N: the vector handed to lw_rowdot / lw_schur_prep; F: the feature part of the linear solve
+    double *tmpP, *tmpF, *rhs;
+    const unsigned char *fconst;
+    const double *Hpp, *hf, *gp, *gf;
+    double *scal;
+    const int *info;
+    int pn, pnb;
+    const int *phdr;
+    const double *px0;
+    double *pdx;
+};
+namespace {
+using namespace vd;
+#define TR_T 1024
+__device__ __forceinline__ double tr_sum(double v, double *s_red) {       // all TR_T threads; result to every thread
+    v = vilf_wave_sum64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < TR_T / 64; k++) t += s_red[k];
+    return t;
+}
+__device__ __forceinline__ double tr_max(double v, double *s_red) {
+    v = vilf_wave_max64(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < TR_T / 64; k++) t = fmax(t, s_red[k]);
+    return t;
+}
+__device__ __forceinline__ void tr_finish(LwCtl *c, int term) { c->termination = term; c->done = 1; c->skip_solve = c->skip_quad = c->skip_eval = c->skip_jac = 1; }
+// o = Plus(xx, d): tangent d[N] = [15 per frame: pose 6, speed-bias 9 | ex 6 | td | F]
+__device__ void tr_plus(const LwTr &a, const double *xx, const double *d, double sgn, double *o) {
+    const int tid = threadIdx.x, NF = a.NF;
+    for (int i = tid; i < NF; i += TR_T) {
+        double dd[6];
+        for (int k = 0; k < 6; k++) dd[k] = sgn * d[15 * i + k];
+        pose_plus(xx + 7 * i, dd, o + 7 * i);
+        for (int k = 0; k < 9; k++) o[7 * NF + 9 * i + k] = xx[7 * NF + 9 * i + k] + sgn * d[15 * i + 6 + k];
+    }
+    for (int f = tid; f < a.F; f += TR_T) o[16 * NF + f] = xx[16 * NF + f] + (a.fconst[f] ? 0.0 : sgn * d[a.P + f]);
+    if (tid == 0) {
+        if (a.est_ex) { double dd[6]; for (int k = 0; k < 6; k++) dd[k] = sgn * d[a.cEx + k]; pose_plus(xx + a.xo, dd, o + a.xo); }
+        else for (int k = 0; k < 7; k++) o[a.xo + k] = xx[a.xo + k];
+        o[a.xo + 7] = a.est_td ? xx[a.xo + 7] + sgn * d[a.cTd] : xx[a.xo + 7];
+    }
+}
+// sum over the entries Ceres counts in ||x||: every frame block, the free features, Ex_Pose / td when they are estimated. fn(i) = the term of entry i
+template <class Fn>
+__device__ __forceinline__ double tr_state_sum(const LwTr &a, Fn fn, double *s_red) {
+    double s = 0;
+    for (int i = threadIdx.x; i < 16 * a.NF; i += TR_T) s += fn(i);
+    for (int f = threadIdx.x; f < a.F; f += TR_T) if (!a.fconst[f]) s += fn(16 * a.NF + f);
+    if (threadIdx.x == 0) {
+        if (a.est_ex) for (int k = 0; k < 7; k++) s += fn(a.xo + k);
+        if (a.est_td) s += fn(a.xo + 7);
+    }
+    return tr_sum(s, s_red);
+}
+// marginalization_factor.cpp:345-363: dx of the prior's blocks at the state xx
+__device__ void tr_prior_dx(const LwTr &a, const double *xx) {
+    const int bk = threadIdx.x;
+    if (bk >= a.pnb) return;
+    const int id = a.phdr[3 + bk], idx = a.phdr[51 + bk], NF = a.NF;
+    const double *x0 = a.px0 + 9 * bk;
+    auto pose_dx = [&](const double *xb, double *d) {
+        for (int k = 0; k < 3; k++) d[k] = xb[k] - x0[k];
+        const Q dq = q_mul(q_inv(q_load(x0 + 3)), q_load(xb + 3));
+        const double sg = dq.w >= 0 ? 2.0 : -2.0;
+        d[3] = sg * dq.x; d[4] = sg * dq.y; d[5] = sg * dq.z;
+    };
+    if (id < NF) pose_dx(xx + 7 * id, a.pdx + idx);
+    else if (id < 2 * NF) for (int k = 0; k < 9; k++) a.pdx[idx + k] = xx[7 * NF + 9 * (id - NF) + k] - x0[k];
+    else if (id == 2 * NF) pose_dx(xx + a.xo, a.pdx + idx);
+    else if (id == 2 * NF + 1) a.pdx[idx] = xx[a.xo + 7] - x0[0];
+}
+__global__ __launch_bounds__(TR_T) void lw_tr_init(LwTr a) {
+    __shared__ double s_red[TR_T / 64];
+    LwCtl *c = a.ctl;
+    for (int i = threadIdx.x; i < VB_PRIOR_LD; i += TR_T) a.pdx[i] = 0.0;
+    __syncthreads();
+    if (a.pn) tr_prior_dx(a, a.x);
+    const double *x = a.x;
+    const double xs = tr_state_sum(a, [&](int i) { return x[i] * x[i]; }, s_red);
+    if (threadIdx.x == 0) {
+        c->radius = 1e4; c->mu = 1e-8; c->alpha = 0; c->step_norm = 0; c->x_cost = 0; c->cand_cost = 0; c->x_norm = sqrt(xs); c->gmax = 0; c->model_change = 0; c->initial_cost = 0; c->gg = 0;
+        c->iteration = 0; c->reuse = 0; c->done = 0; c->termination = VILF_TERM_NO_CONVERGENCE; c->num_successful = 0; c->num_linear_solves = 0; c->consecutive_invalid = 0; c->fallback = 0;
+        c->skip_solve = 1; c->skip_quad = 1; c->skip_eval = 1; c->skip_jac = 0; c->scaling_ready = 0; c->pad_ = 0;
+    }
+}
+// after a linearisation at x (eval_grad_jac of the host loop): cost, diagonal / gradient pieces, the Jacobi scaling (fixed by the first linearisation),
+// gradient_max_norm = || x - Plus(x, -g) ||_inf with the unscaled gradient; lw_scale follows with a.scale
+__global__ __launch_bounds__(TR_T) void lw_tr_post(LwTr a, int first) {
+    __shared__ double s_red[TR_T / 64];
+    LwCtl *c = a.ctl;
+    if (c->skip_jac) return;
+    const int tid = threadIdx.x, P = a.P, N = a.N;
+    for (int i = tid; i < N; i += TR_T) {
+        double d, gg;
+        if (i < P) { d = a.Hpp[(size_t)i * (P + 1)]; gg = a.gp[i]; }
+        else { const int f = i - P; const bool cst = a.fconst[f]; d = cst ? 0.0 : a.hf[f]; gg = cst ? 0.0 : a.gf[f]; }
+        a.diagH[i] = d; a.g[i] = gg;
+    }
+    __syncthreads();
+    if (!c->scaling_ready) for (int i = tid; i < N; i += TR_T) a.scale[i] = 1.0 / (1.0 + sqrt(a.diagH[i]));
+    tr_plus(a, a.x, a.g, -1.0, a.cand);                 // cand is free between a decision and the next step
+    __syncthreads();
+    double m = 0;
+    for (int i = tid; i < a.xo + 8; i += TR_T) m = fmax(m, fabs(a.x[i] - a.cand[i]));
+    m = tr_max(m, s_red);
+    for (int i = tid; i < N; i += TR_T) { const double sc = a.scale[i]; a.g[i] *= sc; a.diagH[i] *= sc * sc; }
+    if (tid == 0) { c->gmax = m; c->x_cost = a.scal[0]; if (first) c->initial_cost = a.scal[0]; c->scaling_ready = 1; }
+}
+// top of an iteration (the tests of trust_region_minimizer.cc before a step) and, unless the last linear solve is reused, the vectors the dogleg needs
+__global__ __launch_bounds__(TR_T) void lw_tr_begin(LwTr a) {
+    __shared__ double s_red[TR_T / 64];
+    LwCtl *c = a.ctl;
+    if (c->done) return;
+    const int tid = threadIdx.x, N = a.N;
+    const bool stop_it = c->iteration >= a.max_it, stop_g = c->gmax <= 1e-10, stop_r = c->radius <= 1e-32;
+    const int reuse = c->reuse;
+    __syncthreads();
+    if (stop_it || stop_g || stop_r) { if (tid == 0) tr_finish(c, stop_it ? VILF_TERM_NO_CONVERGENCE : stop_g ? VILF_TERM_CONVERGENCE_GRADIENT : VILF_TERM_FAILURE); return; }
+    double gg = 0;
+    if (!reuse) for (int i = tid; i < N; i += TR_T) {
+        const double dg = sqrt(fmin(fmax(a.diagH[i], 1e-6), 1e32)), gr = a.g[i] / dg;
+        a.diagonal[i] = dg; a.gradient[i] = gr; a.vec[i] = gr / dg;
+        gg += gr * gr;
+    }
+    gg = tr_sum(gg, s_red);
+    if (tid == 0) {
+        c->iteration++;
+        c->skip_solve = reuse; c->skip_quad = 0; c->skip_eval = 0; c->skip_jac = 1;
+        if (!reuse) { c->gg = gg; c->reuse = 1; }
+    }
+}
+// alpha = |gradient|^2 / |J gradient|^2 (Cauchy point) from the products lw_rowdot left in tmpP / tmpF; the LM diagonal of this solve goes to vec
+__global__ __launch_bounds__(TR_T) void lw_tr_alpha(LwTr a) {
+    __shared__ double s_red[TR_T / 64];
+    LwCtl *c = a.ctl;
+    if (c->skip_solve) return;
+    const int tid = threadIdx.x, P = a.P, N = a.N;
+    double q = 0;
+    for (int i = tid; i < N; i += TR_T) {
+        const double v = a.vec[i];
+        if (i < P) q += v * a.tmpP[i];
+        else if (!a.fconst[i - P]) q += v * (2.0 * a.tmpF[i - P] + a.diagH[i] * v);
+    }
+    q = tr_sum(q, s_red);
+    const double smu = sqrt(c->mu);
+    double bad = 0;
+    for (int i = tid; i < N; i += TR_T) {
+        const double l = a.diagonal[i] * smu;
+        a.vec[i] = l;
+        if (i >= P && !a.fconst[i - P] && !(a.diagH[i] + l * l > 0.0)) bad = 1;
+    }
+    bad = tr_max(bad, s_red);
+    if (tid == 0) {
+        c->alpha = c->gg / q; c->num_linear_solves++;
+        if (bad > 0) { tr_finish(c, VILF_TERM_FAILURE); c->fallback = 1; }
+    }
+}
+// the Gauss-Newton step from the linear solve (or the one kept from the last solve) and the traditional dogleg step for the current radius; step -> vec
+__global__ __launch_bounds__(TR_T) void lw_tr_step(LwTr a) {
+    __shared__ double s_red[TR_T / 64];
+    LwCtl *c = a.ctl;
+    if (c->done) return;
+    const int tid = threadIdx.x, P = a.P, N = a.N;
+    if (!c->skip_solve) {
+        double bad = (*a.info != 0) ? 1.0 : 0.0;
+        for (int i = tid; i < N; i += TR_T) {
+            const double y = i < P ? a.rhs[i] : (a.fconst[i - P] ? 0.0 : a.yf[i - P]);
+            if (!isfinite(y)) bad = 1;
+            a.gn[i] = y * -a.diagonal[i];
+        }
+        bad = tr_max(bad, s_red);
+        if (bad > 0) { if (tid == 0) { tr_finish(c, VILF_TERM_FAILURE); c->fallback = 1; } return; }     // a failed factorisation: mu is raised by the host loop
+    }
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int i = tid; i < N; i += TR_T) { const double gr = a.gradient[i], n = a.gn[i]; s0 += gr * gr; s1 += n * n; s2 += gr * n; }
+    s0 = tr_sum(s0, s_red); s1 = tr_sum(s1, s_red); s2 = tr_sum(s2, s_red);
+    const double gradient_norm = sqrt(s0), gn_norm = sqrt(s1), radius = c->radius, alpha = c->alpha;
+    double nrm;
+    if (gn_norm <= radius) { for (int i = tid; i < N; i += TR_T) a.step[i] = a.gn[i] / a.diagonal[i]; nrm = gn_norm; }
+    else if (gradient_norm * alpha >= radius) { for (int i = tid; i < N; i += TR_T) a.step[i] = -(radius / gradient_norm) * a.gradient[i] / a.diagonal[i]; nrm = radius; }
+    else {
+        const double b_dot_a = -alpha * s2, a_sq = pow(alpha * gradient_norm, 2.0), bma = a_sq - 2 * b_dot_a + pow(gn_norm, 2.0);
+        const double cc = b_dot_a - a_sq, dd = sqrt(cc * cc + bma * (pow(radius, 2.0) - a_sq));
+        const double beta = (cc <= 0) ? (dd - cc) / bma : (radius * radius - a_sq) / (dd + cc);
+        double nn = 0;
+        for (int i = tid; i < N; i += TR_T) { const double st = (-alpha * (1.0 - beta)) * a.gradient[i] + beta * a.gn[i]; a.step[i] = st; nn += st * st; }
+        nn = tr_sum(nn, s_red);
+        nrm = sqrt(nn);
+        for (int i = tid; i < N; i += TR_T) a.step[i] /= a.diagonal[i];
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += TR_T) a.vec[i] = a.step[i];
+    if (tid == 0) c->step_norm = nrm;
+}
+// model_cost_change from step^T H step (lw_rowdot products), the candidate Plus(x, step * scale), its prior dx, the parameter-tolerance test
+__global__ __launch_bounds__(TR_T) void lw_tr_model(LwTr a) {
+    __shared__ double s_red[TR_T / 64];
+    LwCtl *c = a.ctl;
+    if (c->done) return;
+    const int tid = threadIdx.x, P = a.P, N = a.N;
+    double q = 0, gs = 0;
+    for (int i = tid; i < N; i += TR_T) {
+        const double v = a.step[i];
+        gs += a.g[i] * v;
+        if (i < P) q += v * a.tmpP[i];
+        else if (!a.fconst[i - P]) q += v * (2.0 * a.tmpF[i - P] + a.diagH[i] * v);
+    }
+    q = tr_sum(q, s_red); gs = tr_sum(gs, s_red);
+    const double model = -(gs + 0.5 * q);
+    if (!(model > 0.0)) {                                       // step_is_invalid: mu up, solve again next iteration
+        if (tid == 0) {
+            c->consecutive_invalid++; c->mu *= 10.0; c->reuse = 0; c->skip_eval = 1; c->skip_jac = 1;
+            if (c->consecutive_invalid >= 5) tr_finish(c, VILF_TERM_FAILURE);
+        }
+        return;
+    }
+    // delta = step * scale in place of vec (no launch reads vec before the next lw_tr_begin / lw_tr_step rewrites it)
+    for (int i = tid; i < N; i += TR_T) a.vec[i] = a.step[i] * a.scale[i];
+    __syncthreads();
+    tr_plus(a, a.x, a.vec, 1.0, a.cand);
+    __syncthreads();
+    if (a.pn) tr_prior_dx(a, a.cand);
+    const double *x = a.x, *cd = a.cand;
+    const double sn = tr_state_sum(a, [&](int i) { const double d = x[i] - cd[i]; return d * d; }, s_red);
+    if (tid == 0) {
+        c->consecutive_invalid = 0; c->model_change = model;
+        if (sqrt(sn) <= 1e-8 * (c->x_norm + 1e-8)) tr_finish(c, VILF_TERM_CONVERGENCE_PARAMETER);
+    }
+}
+// the cost at the candidate is in scal[0]: function tolerance, relative decrease, accept / reject, radius and mu updates
+__global__ __launch_bounds__(TR_T) void lw_tr_decide(LwTr a) {
+    __shared__ double s_red[TR_T / 64];
+    __shared__ int s_acc;
+    LwCtl *c = a.ctl;
+    if (c->done || c->skip_eval) return;
+    const int tid = threadIdx.x;
+    __syncthreads();                                            // every wave has read the flags before thread 0 may change them
+    if (tid == 0) {
+        const double cand_cost = a.scal[0], cost_change = c->x_cost - cand_cost;
+        int acc = 0;
+        c->cand_cost = cand_cost;
+        if (fabs(cost_change) <= 1e-6 * c->x_cost) tr_finish(c, VILF_TERM_CONVERGENCE_FUNCTION);
+        else {
+            const double rd = cost_change / c->model_change;
+            if (rd > 1e-3) {
+                acc = 1;
+                if (c->iteration < a.max_it) c->skip_jac = 0; else c->x_cost = cand_cost;      // the budget is spent: nothing would use the linearisation at the accepted point
+                c->num_successful++;
+                if (rd < 0.25) c->radius *= 0.5;
+                if (rd > 0.75) c->radius = fmax(c->radius, 3.0 * c->step_norm);
+                c->mu = fmax(1e-8, 2.0 * c->mu / 10.0);
+                c->reuse = 0;
+            } else { c->radius *= 0.5; c->reuse = 1; }
+        }
+        s_acc = acc;
+    }
+    __syncthreads();
+    if (!s_acc) return;
+    for (int i = tid; i < a.xo + 8; i += TR_T) a.x[i] = a.cand[i];
+    __syncthreads();
+    const double *x = a.x;
+    const double xs = tr_state_sum(a, [&](int i) { return x[i] * x[i]; }, s_red);
+    if (tid == 0) c->x_norm = sqrt(xs);
+}
+}  // namespace
 
 // batch_slot0 != 0: the window is also resident as slot 0 of the 11-frame batch (vilf_batch_upload ran): use that slot's prior and write
 // the solved state back into the batch buffers (the marginalization reads them)
@@ -780,33 +1088,40 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         if (est_ex) h_pose_plus(&xx[xo], &d[cEx], &o[xo]);
         if (est_td) o[xo + 7] = xx[xo + 7] + d[cTd];
     };
-    auto evaluate = [&](const std::vector<double> &xx, bool jac, double &cost) -> int {
-        HIPCHECK(h, hipMemcpyAsync(c->x.p, xx.data(), xx.size() * 8, hipMemcpyHostToDevice, h->stream));
+    // the launches of one evaluation at the device state xdev (prior dx already in c->pri); skip: flag of the device trust-region loop (nullptr = always run)
+    auto enq_evaluate = [&](const double *xdev, bool jac, const int *skip) -> int {
         if (jac) {      // one launch clears the cost and the five accumulation targets (six fill launches per linearisation were 0.4 ms of a solve)
             const size_t n5[5] = {sP * sP, sF * sP, sF, sP, sF};
             const size_t tot = n5[0] + n5[1] + n5[2] + n5[3] + n5[4] + 1;
             hipLaunchKernelGGL(lw_clear, dim3((unsigned)((tot + 1023) / 1024)), dim3(256), 0, h->stream, c->Hpp.as<double>(), n5[0], c->W.as<double>(), n5[1], c->hf.as<double>(), n5[2],
-                               c->gp.as<double>(), n5[3], c->gf.as<double>(), n5[4], scal);
+                               c->gp.as<double>(), n5[3], c->gf.as<double>(), n5[4], scal, skip);
         } else HIPCHECK(h, hipMemsetAsync(scal, 0, 8, h->stream));
         if (jac) tic();
         if (nvis && (est_ex || est_td))
-            hipLaunchKernelGGL(lw_visual_ext, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->tdrec.as<LwTd>(), c->x.as<double>(), NF, F, P, cEx, cTd,
-                               h->opts.TR / h->opts.ROW, sqrt_info, cauchy_b, jac ? 1 : 0, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
+            hipLaunchKernelGGL(lw_visual_ext, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->tdrec.as<LwTd>(), xdev, NF, F, P, cEx, cTd,
+                               h->opts.TR / h->opts.ROW, sqrt_info, cauchy_b, jac ? 1 : 0, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal, skip);
         else if (nvis)
-            hipLaunchKernelGGL(lw_visual, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->x.as<double>(), c->x.as<double>() + xo, NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
-                               c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal);
+            hipLaunchKernelGGL(lw_visual, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), xdev, xdev + xo, NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
+                               c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal, skip);
+        if (pn)
+            hipLaunchKernelGGL(lw_prior, dim3(1), dim3(256), 0, h->stream, pn, h->d[D_PJ].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, h->d[D_PR].as<double>() + slot * VB_PRIOR_LD,
+                               h->d[D_PH].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, c->pri.as<double>(),
+                               (const int *)(c->pri.as<char>() + VB_PRIOR_LD * 8), P, jac ? 1 : 0, c->Hpp.as<double>(), c->gp.as<double>(), scal, skip);
+        hipLaunchKernelGGL(lw_imu_lidar, dim3(nimu), dim3(128), 0, h->stream, NF, P, xdev, c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
+                           c->Hpp.as<double>(), c->gp.as<double>(), scal, c->jscr.as<double>(), skip);
+        if (jac) hipLaunchKernelGGL(lw_imu_products, dim3((nimu * 930 + 255) / 256), dim3(256), 0, h->stream, NF, P, c->jscr.as<double>(), c->Hpp.as<double>(), c->gp.as<double>(), skip);
+        if (jac) toc(0);
+        HIPCHECK(h, hipGetLastError());
+        return VILF_OK;
+    };
+    auto evaluate = [&](const std::vector<double> &xx, bool jac, double &cost) -> int {
+        HIPCHECK(h, hipMemcpyAsync(c->x.p, xx.data(), xx.size() * 8, hipMemcpyHostToDevice, h->stream));
         if (pn) {
             prior_dx(xx);
             HIPCHECK(h, hipMemcpyAsync(c->pri.p, pdx.data(), VB_PRIOR_LD * 8, hipMemcpyHostToDevice, h->stream));
-            hipLaunchKernelGGL(lw_prior, dim3(1), dim3(256), 0, h->stream, pn, h->d[D_PJ].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, h->d[D_PR].as<double>() + slot * VB_PRIOR_LD,
-                               h->d[D_PH].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, c->pri.as<double>(),
-                               (const int *)(c->pri.as<char>() + VB_PRIOR_LD * 8), P, jac ? 1 : 0, c->Hpp.as<double>(), c->gp.as<double>(), scal);
         }
-        hipLaunchKernelGGL(lw_imu_lidar, dim3(nimu), dim3(128), 0, h->stream, NF, P, c->x.as<double>(), c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
-                           c->Hpp.as<double>(), c->gp.as<double>(), scal, c->jscr.as<double>());
-        if (jac) hipLaunchKernelGGL(lw_imu_products, dim3((nimu * 930 + 255) / 256), dim3(256), 0, h->stream, NF, P, c->jscr.as<double>(), c->Hpp.as<double>(), c->gp.as<double>());
-        if (jac) toc(0);
-        HIPCHECK(h, hipGetLastError());
+        const int rc = enq_evaluate(c->x.as<double>(), jac, nullptr);
+        if (rc != VILF_OK) return rc;
         HIPCHECK(h, hipMemcpyAsync(&cost, scal, 8, hipMemcpyDeviceToHost, h->stream));
         if (!jac) HIPCHECK(h, hipStreamSynchronize(h->stream));         // with the Jacobians: fetch_diag_grad follows and waits once for both
         return VILF_OK;
@@ -825,10 +1140,13 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         return VILF_OK;
     };
     // x^T H x with the (scaled) blocks on the device: returns v_p^T Hpp v_p + 2 sum_f v_f (W_f . v_p) + sum_f h_f v_f^2 and keeps Hpp v_p / W v_p
+    auto enq_quad = [&](const int *skip) {                                // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in c->vec
+        hipLaunchKernelGGL(lw_rowdot, dim3((P + 3) / 4), dim3(256), 0, h->stream, P, P, c->Hpp.as<double>(), c->vec.as<double>(), c->tmpP.as<double>(), skip);
+        if (F) hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->vec.as<double>(), c->tmpF.as<double>(), skip);
+    };
     auto quad = [&](const std::vector<double> &vv, double &q) -> int {
         HIPCHECK(h, hipMemcpyAsync(c->vec.p, vv.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(lw_rowdot, dim3((P + 3) / 4), dim3(256), 0, h->stream, P, P, c->Hpp.as<double>(), c->vec.as<double>(), c->tmpP.as<double>());          // Hpp v_p
-        if (F) hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->vec.as<double>(), c->tmpF.as<double>());    // W_f . v_p
+        enq_quad(nullptr);
         HIPCHECK(h, hipMemcpyAsync(tP.data(), c->tmpP.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
         if (F) HIPCHECK(h, hipMemcpyAsync(tF.data(), c->tmpF.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -851,19 +1169,16 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         // Jacobi scaling of the blocks on the device and of the host copies
         HIPCHECK(h, hipMemcpyAsync(c->vec.p, scale.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
         const size_t tot = sP * sP + (size_t)F * sP + F + P;
-        hipLaunchKernelGGL(lw_scale, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->vec.as<double>(), c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>());
+        hipLaunchKernelGGL(lw_scale, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->vec.as<double>(), c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), (const int *)nullptr);
         for (int i = 0; i < N; i++) { g[i] *= scale[i]; diagH[i] *= scale[i] * scale[i]; }
         for (int f = 0; f < F; f++) hfh[f] = diagH[P + f];
         return VILF_OK;
     };
-    // ---- the linear solve: (H' + lm^2) y = g'
-    auto linear_solve = [&](bool &ok) -> int {
-        ok = false;
-        for (int f = 0; f < F; f++) if (!in->feature_const[f] && !(hfh[f] + lm[P + f] * lm[P + f] > 0.0)) return VILF_OK;
-        HIPCHECK(h, hipMemcpyAsync(c->vec.p, lm.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+    // the launches of one linear solve (H' + lm^2) y = g' with lm in c->vec: y_p -> c->rhs, y_f -> yf_out, the Cholesky's status -> c->info
+    auto enq_linear_solve = [&](double *yf_out, const int *skip) -> int {
         const size_t tot = sP * sP + (size_t)F * sP + F;
         hipLaunchKernelGGL(lw_schur_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gf.as<double>(), c->vec.as<double>(),
-                           c->fconst.as<unsigned char>(), c->S.as<double>(), c->Wn.as<double>(), c->den.as<double>(), c->tmpF.as<double>());
+                           c->fconst.as<unsigned char>(), c->S.as<double>(), c->Wn.as<double>(), c->den.as<double>(), c->tmpF.as<double>(), skip);
         double *rhs_row = c->S.as<double>() + sP * sP;                    // the right-hand side rides as row P of S: after the factorisation it holds L^-1 rhs
         HIPCHECK(h, hipMemcpyAsync(rhs_row, c->gp.p, sP * 8, hipMemcpyDeviceToDevice, h->stream));
         if (F) {
@@ -871,28 +1186,38 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             tic();
             {
                 const int nt = (P + 63) / 64, ksplit = 4;
-                hipLaunchKernelGGL(lw_syrk_mfma, dim3(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, P, F, c->Wn.as<double>(), c->S.as<double>(), ksplit);
+                hipLaunchKernelGGL(lw_syrk_mfma, dim3(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, P, F, c->Wn.as<double>(), c->S.as<double>(), ksplit, skip);
             }
             toc(1);
-            hipLaunchKernelGGL(lw_colsum, dim3((P + 255) / 256, 16), dim3(256), 0, h->stream, F, P, c->Wn.as<double>(), c->tmpF.as<double>(), -1.0, rhs_row, 16);
+            hipLaunchKernelGGL(lw_colsum, dim3((P + 255) / 256, 16), dim3(256), 0, h->stream, F, P, c->Wn.as<double>(), c->tmpF.as<double>(), -1.0, rhs_row, 16, skip);
         }
         int *dinfo = c->info.as<int>();
         tic();
         HIPCHECK(h, hipMemsetAsync(dinfo, 0, 4, h->stream));
         for (int j0 = 0; j0 < P; j0 += CH_NB) {                          // blocked Cholesky, two launches per 64-column block
             const int nb = std::min(CH_NB, P - j0), below = P + 1 - (j0 + nb);
-            hipLaunchKernelGGL(lw_chol_panel, dim3(std::max(1, (below + CH_BELOW - 1) / CH_BELOW)), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, dinfo);
-            if (j0 + nb < P) { const int nt = (below + 63) / 64; hipLaunchKernelGGL(lw_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, nb); }
+            hipLaunchKernelGGL(lw_chol_panel, dim3(std::max(1, (below + CH_BELOW - 1) / CH_BELOW)), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, dinfo, skip);
+            if (j0 + nb < P) { const int nt = (below + 63) / 64; hipLaunchKernelGGL(lw_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, nb, skip); }
         }
-        hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), sP * 8, h->stream, P, c->S.as<double>(), c->rhs.as<double>());
+        hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), sP * 8, h->stream, P, c->S.as<double>(), c->rhs.as<double>(), skip);
         toc(2);
-        int info = 0;
-        HIPCHECK(h, hipMemcpyAsync(&info, dinfo, 4, hipMemcpyDeviceToHost, h->stream));      // read with the solution below: one wait per linear solve
         if (F) {
-            hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->rhs.as<double>(), c->tmpF.as<double>());       // W_f . y_p
-            hipLaunchKernelGGL(lw_feature_back, dim3((F + 255) / 256), dim3(256), 0, h->stream, F, c->gf.as<double>(), c->tmpF.as<double>(), c->den.as<double>(), c->vec.as<double>());
-            HIPCHECK(h, hipMemcpyAsync(&y[P], c->vec.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
+            hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->rhs.as<double>(), c->tmpF.as<double>(), skip);       // W_f . y_p
+            hipLaunchKernelGGL(lw_feature_back, dim3((F + 255) / 256), dim3(256), 0, h->stream, F, c->gf.as<double>(), c->tmpF.as<double>(), c->den.as<double>(), yf_out, skip);
         }
+        HIPCHECK(h, hipGetLastError());
+        return VILF_OK;
+    };
+    // ---- the linear solve: (H' + lm^2) y = g'
+    auto linear_solve = [&](bool &ok) -> int {
+        ok = false;
+        for (int f = 0; f < F; f++) if (!in->feature_const[f] && !(hfh[f] + lm[P + f] * lm[P + f] > 0.0)) return VILF_OK;
+        HIPCHECK(h, hipMemcpyAsync(c->vec.p, lm.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+        int rc2 = enq_linear_solve(c->vec.as<double>(), nullptr);
+        if (rc2 != VILF_OK) return rc2;
+        int info = 0;
+        HIPCHECK(h, hipMemcpyAsync(&info, c->info.p, 4, hipMemcpyDeviceToHost, h->stream));      // read with the solution below: one wait per linear solve
+        if (F) HIPCHECK(h, hipMemcpyAsync(&y[P], c->vec.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipMemcpyAsync(&y[0], c->rhs.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
@@ -920,76 +1245,139 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         dogleg_step_norm = std::sqrt(nn);
         for (int i = 0; i < N; i++) step[i] /= diagonal[i];
     };
-    int rc = eval_grad_jac();
-    if (rc != VILF_OK) return rc;
-    const double initial_cost = x_cost;
-    double x_norm = xnorm(x);
+    int rc = VILF_OK;
+    double initial_cost = 0;
     const int max_it = h->opts.max_num_iterations;
     const double tlim = h->opts.max_solver_time > 0 ? h->opts.max_solver_time * (in->marginalization_flag == VILF_MARGIN_OLD ? 4.0 / 5.0 : 1.0) : -1.0;   // estimator.cpp:847-850
-    while (true) {
-        if (tlim > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= tlim) { termination = VILF_TERM_NO_CONVERGENCE; break; }
-        if (iteration >= max_it) { termination = VILF_TERM_NO_CONVERGENCE; break; }
-        if (gradient_max_norm <= gradient_tolerance) { termination = VILF_TERM_CONVERGENCE_GRADIENT; break; }
-        if (radius <= 1e-32) { termination = VILF_TERM_FAILURE; break; }
-        iteration++;
-        bool valid = true;
-        if (reuse) traditional();
-        else {
-            reuse = true;
-            for (int i = 0; i < N; i++) diagonal[i] = std::sqrt(std::min(std::max(diagH[i], min_lm_diagonal), max_lm_diagonal));
-            for (int i = 0; i < N; i++) gradient[i] = g[i] / diagonal[i];
-            for (int i = 0; i < N; i++) v[i] = gradient[i] / diagonal[i];
-            double Jg2;
-            if ((rc = quad(v, Jg2)) != VILF_OK) return rc;
-            alpha = vdotN(gradient, gradient) / Jg2;
-            bool ok = false;
-            while (mu < 1.0) {
-                for (int i = 0; i < N; i++) lm[i] = diagonal[i] * std::sqrt(mu);
-                num_linear_solves++;
-                if ((rc = linear_solve(ok)) != VILF_OK) return rc;
-                if (ok) break;
-                mu *= 10.0;
+    // ---- the loop on the device: every iteration's launches are enqueued at once, nothing is read back until the end. Not with a wall-clock limit
+    // (Ceres tests the clock at the top of every iteration: the host loop below does) and not when a factorisation fails (it sets `fallback`).
+    bool ran_device = false;
+    if (tlim <= 0 && !std::getenv("VILF_LW_HOST_LOOP")) {
+        const size_t xs = xo + 8;
+        if (!c->dv.ensure((xs + 7 * sN) * 8) || !c->ctl.ensure(sizeof(LwCtl))) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
+        LwTr a;
+        a.ctl = c->ctl.as<LwCtl>();
+        a.NF = NF; a.F = F; a.P = P; a.N = N; a.cEx = cEx; a.cTd = cTd; a.xo = (int)xo; a.est_ex = est_ex ? 1 : 0; a.est_td = est_td ? 1 : 0; a.max_it = max_it;
+        a.x = c->x.as<double>(); a.cand = c->dv.as<double>();
+        double *vecs = c->dv.as<double>() + xs;
+        a.g = vecs; a.diagH = vecs + sN; a.scale = vecs + 2 * sN; a.diagonal = vecs + 3 * sN; a.gradient = vecs + 4 * sN; a.gn = vecs + 5 * sN; a.step = vecs + 6 * sN;
+        a.vec = c->vec.as<double>(); a.yf = c->vec.as<double>() + sN;
+        a.tmpP = c->tmpP.as<double>(); a.tmpF = c->tmpF.as<double>(); a.rhs = c->rhs.as<double>();
+        a.fconst = c->fconst.as<unsigned char>();
+        a.Hpp = c->Hpp.as<double>(); a.hf = c->hf.as<double>(); a.gp = c->gp.as<double>(); a.gf = c->gf.as<double>();
+        a.scal = scal; a.info = c->info.as<int>();
+        a.pn = pn; a.pnb = pnb;
+        a.phdr = batch_slot0 ? h->d[D_PHDR].as<int>() + slot * VB_PRIOR_HDR : nullptr;
+        a.px0 = batch_slot0 ? h->d[D_PX0].as<double>() + slot * 24 * 9 : nullptr;
+        a.pdx = c->pri.as<double>();
+        const LwCtl *dctl = a.ctl;
+        HIPCHECK(h, hipMemcpyAsync(c->x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(lw_tr_init, dim3(1), dim3(TR_T), 0, h->stream, a);
+        const size_t tot_scale = sP * sP + (size_t)F * sP + F + P;
+        auto enq_linearize = [&](int first) -> int {                       // eval_grad_jac of the host loop
+            const int r2 = enq_evaluate(a.x, true, &dctl->skip_jac);
+            if (r2 != VILF_OK) return r2;
+            hipLaunchKernelGGL(lw_tr_post, dim3(1), dim3(TR_T), 0, h->stream, a, first);
+            hipLaunchKernelGGL(lw_scale, dim3((unsigned)((tot_scale + 255) / 256)), dim3(256), 0, h->stream, P, F, a.scale, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), &dctl->skip_jac);
+            return VILF_OK;
+        };
+        if ((rc = enq_linearize(1)) != VILF_OK) return rc;
+        for (int it = 0; it < max_it; it++) {
+            hipLaunchKernelGGL(lw_tr_begin, dim3(1), dim3(TR_T), 0, h->stream, a);
+            enq_quad(&dctl->skip_solve);
+            hipLaunchKernelGGL(lw_tr_alpha, dim3(1), dim3(TR_T), 0, h->stream, a);
+            if ((rc = enq_linear_solve(a.yf, &dctl->skip_solve)) != VILF_OK) return rc;
+            hipLaunchKernelGGL(lw_tr_step, dim3(1), dim3(TR_T), 0, h->stream, a);
+            enq_quad(&dctl->skip_quad);
+            hipLaunchKernelGGL(lw_tr_model, dim3(1), dim3(TR_T), 0, h->stream, a);
+            if ((rc = enq_evaluate(a.cand, false, &dctl->skip_eval)) != VILF_OK) return rc;
+            hipLaunchKernelGGL(lw_tr_decide, dim3(1), dim3(TR_T), 0, h->stream, a);
+            if (it + 1 < max_it && (rc = enq_linearize(0)) != VILF_OK) return rc;
+        }
+        LwCtl hc;
+        HIPCHECK(h, hipGetLastError());
+        HIPCHECK(h, hipMemcpyAsync(&hc, a.ctl, sizeof(LwCtl), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(cand.data(), c->x.p, x.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        if (std::getenv("VILF_LW_FORCE_FALLBACK")) hc.fallback = 1;          // test hook: take the path of a failed factorisation (the host loop redoes the solve from the initial state)
+        if (std::getenv("VILF_LW_TRACE")) std::fprintf(stderr, "[vilf lw] device loop: fallback %d iterations %d successful %d solves %d termination %d cost %.9g -> %.9g\n", hc.fallback, hc.iteration, hc.num_successful, hc.num_linear_solves, hc.termination, hc.initial_cost, hc.x_cost);
+        if (!hc.fallback) {
+            ran_device = true;
+            x = cand;
+            iteration = hc.iteration; num_successful = hc.num_successful; num_linear_solves = hc.num_linear_solves; termination = hc.termination;
+            initial_cost = hc.initial_cost; x_cost = hc.x_cost; radius = hc.radius;
+        }
+    }
+    if (!ran_device) {
+        rc = eval_grad_jac();
+        if (rc != VILF_OK) return rc;
+        initial_cost = x_cost;
+        double x_norm = xnorm(x);
+        while (true) {
+            if (tlim > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= tlim) { termination = VILF_TERM_NO_CONVERGENCE; break; }
+            if (iteration >= max_it) { termination = VILF_TERM_NO_CONVERGENCE; break; }
+            if (gradient_max_norm <= gradient_tolerance) { termination = VILF_TERM_CONVERGENCE_GRADIENT; break; }
+            if (radius <= 1e-32) { termination = VILF_TERM_FAILURE; break; }
+            iteration++;
+            bool valid = true;
+            if (reuse) traditional();
+            else {
+                reuse = true;
+                for (int i = 0; i < N; i++) diagonal[i] = std::sqrt(std::min(std::max(diagH[i], min_lm_diagonal), max_lm_diagonal));
+                for (int i = 0; i < N; i++) gradient[i] = g[i] / diagonal[i];
+                for (int i = 0; i < N; i++) v[i] = gradient[i] / diagonal[i];
+                double Jg2;
+                if ((rc = quad(v, Jg2)) != VILF_OK) return rc;
+                alpha = vdotN(gradient, gradient) / Jg2;
+                bool ok = false;
+                while (mu < 1.0) {
+                    for (int i = 0; i < N; i++) lm[i] = diagonal[i] * std::sqrt(mu);
+                    num_linear_solves++;
+                    if ((rc = linear_solve(ok)) != VILF_OK) return rc;
+                    if (ok) break;
+                    mu *= 10.0;
+                }
+                if (!ok) valid = false;
+                else { for (int i = 0; i < N; i++) gn[i] = y[i] * -diagonal[i]; traditional(); }
             }
-            if (!ok) valid = false;
-            else { for (int i = 0; i < N; i++) gn[i] = y[i] * -diagonal[i]; traditional(); }
+            double model_cost_change = 0;
+            if (valid) {
+                double sHs;
+                if ((rc = quad(step, sHs)) != VILF_OK) return rc;
+                model_cost_change = -(vdotN(g, step) + 0.5 * sHs);
+                if (model_cost_change <= 0.0) valid = false;
+            }
+            if (!valid) {
+                consecutive_invalid++;
+                mu *= 10.0; reuse = false;                                   // step_is_invalid
+                if (consecutive_invalid >= 5) { termination = VILF_TERM_FAILURE; break; }
+                continue;
+            }
+            consecutive_invalid = 0;
+            for (int i = 0; i < N; i++) delta[i] = step[i] * scale[i];
+            plus(x, delta, cand);
+            double cand_cost;
+            if ((rc = evaluate(cand, false, cand_cost)) != VILF_OK) return rc;
+            double sn = 0;
+            for (int i = 0; i < 16 * NF; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
+            for (int f = 0; f < F; f++) if (!in->feature_const[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
+            if (est_ex) for (int k = 0; k < 7; k++) sn += (x[xo + k] - cand[xo + k]) * (x[xo + k] - cand[xo + k]);
+            if (est_td) sn += (x[xo + 7] - cand[xo + 7]) * (x[xo + 7] - cand[xo + 7]);
+            if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = VILF_TERM_CONVERGENCE_PARAMETER; break; }
+            const double cost_change = x_cost - cand_cost;
+            if (std::fabs(cost_change) <= function_tolerance * x_cost) { termination = VILF_TERM_CONVERGENCE_FUNCTION; break; }
+            const double rd = cost_change / model_cost_change;
+            if (rd > min_relative_decrease) {
+                x = cand; x_norm = xnorm(x);
+                if (iteration < max_it) { if ((rc = eval_grad_jac()) != VILF_OK) return rc; }
+                else x_cost = cand_cost;                                     // the budget is spent: nothing would use the linearisation at the accepted point
+                num_successful++;
+                if (rd < 0.25) radius *= 0.5;                                // step_accepted
+                if (rd > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
+                mu = std::max(1e-8, 2.0 * mu / 10.0);
+                reuse = false;
+            } else { radius *= 0.5; reuse = true; }                          // step_rejected
         }
-        double model_cost_change = 0;
-        if (valid) {
-            double sHs;
-            if ((rc = quad(step, sHs)) != VILF_OK) return rc;
-            model_cost_change = -(vdotN(g, step) + 0.5 * sHs);
-            if (model_cost_change <= 0.0) valid = false;
-        }
-        if (!valid) {
-            consecutive_invalid++;
-            mu *= 10.0; reuse = false;                                   // step_is_invalid
-            if (consecutive_invalid >= 5) { termination = VILF_TERM_FAILURE; break; }
-            continue;
-        }
-        consecutive_invalid = 0;
-        for (int i = 0; i < N; i++) delta[i] = step[i] * scale[i];
-        plus(x, delta, cand);
-        double cand_cost;
-        if ((rc = evaluate(cand, false, cand_cost)) != VILF_OK) return rc;
-        double sn = 0;
-        for (int i = 0; i < 16 * NF; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
-        for (int f = 0; f < F; f++) if (!in->feature_const[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
-        if (est_ex) for (int k = 0; k < 7; k++) sn += (x[xo + k] - cand[xo + k]) * (x[xo + k] - cand[xo + k]);
-        if (est_td) sn += (x[xo + 7] - cand[xo + 7]) * (x[xo + 7] - cand[xo + 7]);
-        if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = VILF_TERM_CONVERGENCE_PARAMETER; break; }
-        const double cost_change = x_cost - cand_cost;
-        if (std::fabs(cost_change) <= function_tolerance * x_cost) { termination = VILF_TERM_CONVERGENCE_FUNCTION; break; }
-        const double rd = cost_change / model_cost_change;
-        if (rd > min_relative_decrease) {
-            x = cand; x_norm = xnorm(x);
-            if (iteration < max_it) { if ((rc = eval_grad_jac()) != VILF_OK) return rc; }
-            else x_cost = cand_cost;                                     // the budget is spent: nothing would use the linearisation at the accepted point
-            num_successful++;
-            if (rd < 0.25) radius *= 0.5;                                // step_accepted
-            if (rd > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
-            mu = std::max(1e-8, 2.0 * mu / 10.0);
-            reuse = false;
-        } else { radius *= 0.5; reuse = true; }                          // step_rejected
     }
     // ---- outputs + double2vector (estimator.cpp:549-638)
     if (out->para_pose) std::memcpy(out->para_pose, &x[0], 7 * NF * 8);
