@@ -421,8 +421,8 @@ def test_marginalization_eigen_solver_fallback(solver, oracle, opts, monkeypatch
 @pytest.mark.parametrize("n_frames,n_features,tol", [(21, 400, 1e-7), (51, 2500, 1e-6)])
 def test_large_window_solve_matches_oracle(oracle, n_frames, n_features, tol):
     """BASELINE configs[4]: the synthetic 51-frame / ~50 k-factor stress window (reduced system 765 x 765) — and a 21-frame one — through
-    vilf_window_solve's general path (one window spread over the device: factor lanes with fp64 atomics, rocBLAS SYRK Schur reduce,
-    rocSOLVER Cholesky, trust-region logic on the host) against the oracle. The atomics' summation order is free: tolerances, not bits."""
+    vilf_window_solve's general path (one window spread over the device: factor lanes with fp64 atomics, MFMA SYRK Schur reduce,
+    the path's own blocked Cholesky, trust-region loop on the device) against the oracle. The atomics' summation order is free: tolerances, not bits."""
     from vil_fusion_amd.estimator import BackendSolver
     o = oracle.default_options()
     o.window_size = n_frames - 1
