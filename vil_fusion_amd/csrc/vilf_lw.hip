@@ -8,11 +8,12 @@
 //   lw_scale, lw_schur_prep         Jacobi scaling; LM-regularised reduced system and the row-scaled W for the Schur product
 //   lw_syrk_mfma                    S = Hpp' + mu D^2 - Wn^T Wn: the Schur reduce as a hand-written fp64 MFMA SYRK (2 F P^2 = 2.9 GFLOP per solve)
 //   lw_rowdot / lw_colsum           matrix-vector products (W v per feature row, W^T v per column)
-//   lw_chol_panel / lw_chol_update  own blocked Cholesky of the reduced system: a 64-column panel factored by one workgroup (diagonal block in
-//                                   LDS, the slab below as 16 x 4 fp64 MFMA tiles), then the trailing SYRK update as MFMA tiles over the grid;
-//   lw_chol_back                    forward / back substitution with the triangle staged through LDS. No rocSOLVER / rocBLAS on this path.
-// and keeps the trust-region logic (Ceres 2.0 TrustRegionMinimizer + traditional dogleg + Jacobi scaling, the same restatement as
-// k_solve / k_linearize's step) on the host: per iteration only vectors of P + F doubles cross PCIe.
+//   lw_chol_panel / lw_chol_step    own blocked Cholesky of the reduced system, one launch per 64-column block: the panel workgroups (diagonal block + the slab
+//                                   below as 16 x 4 fp64 MFMA tiles in registers) beside workgroups that apply the previous column's trailing update;
+//   lw_chol_back                    back substitution with the triangle staged through LDS. No rocSOLVER / rocBLAS on this path.
+//   lw_tr_*                         the trust-region loop (Ceres 2.0 TrustRegionMinimizer + traditional dogleg + Jacobi scaling, the same restatement as
+//                                   k_solve / k_linearize's step) on the device: all iterations enqueued at once, one read-back per solve. The host loop
+//                                   further down is the path of a wall-clock limit and the fallback of a failed factorisation.
 // The same path runs the solves the batched LDS kernels do not cover at ANY window size: estimate_extrinsic (Ex_Pose a variable: six more
 // columns after the frame blocks) and estimate_td (ProjectionTdFactor, one more column) — estimator.cpp:701-717,765-777. For an 11-frame
 // window it then also applies the slot-0 marginalization prior resident on the device (lw_prior) and writes the solved state back into the
@@ -391,11 +392,14 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *
 }
 
 // ---- dense Cholesky of the reduced system (P x P, fp64) with the right-hand side as row P: S = L L^T, L[P][0..P-1] = L^-1 rhs -----------------------
-// Right-looking over 64-column blocks, TWO launches per block column and no vendor library:
-//   lw_chol_panel   a workgroup = the 64 x 64 diagonal block + 192 rows of the panel below it, all as MFMA tiles in registers (the scheme of k_solve_sb's dense
-//                   factorisation): 4-column panels, one thread per slab row, rank-4 updates one v_mfma_f64_16x16x4_f64 per tile. Every workgroup factors the
-//                   diagonal block itself — the rows below cannot start before it is known, so that costs no time and saves a launch per block column.
-//   lw_chol_update  A22 -= L21 L21^T on the lower 64 x 64 tiles (one workgroup per tile, the two 64 x 64 panels through LDS, MFMA), rhs row included.
+// Right-looking over 64-column blocks, ONE launch per block column and no vendor library:
+//   lw_chol_panel   (block column 0) a workgroup = the 64 x 64 diagonal block + 192 rows of the panel below it, all as MFMA tiles in registers (the scheme of
+//                   k_solve_sb's dense factorisation): 4-column panels, one thread per slab row, rank-4 updates one v_mfma_f64_16x16x4_f64 per tile. Every workgroup
+//                   factors the diagonal block itself — the rows below cannot start before it is known, so that costs no time and saves a launch per block column.
+//   lw_chol_step    (block columns 1 ..) the same panel workgroups, which first take the previous column's update of THEIR block column into their registers
+//                   (T -= L21 L21^T, operands through LDS), beside workgroups that apply the previous column's update to the 64 x 64 tiles further right (the two
+//                   panels through LDS, MFMA), rhs row included. Two launches per block column (panel, then the whole trailing update) were 0.63 ms per
+//                   factorisation, this is 0.55.
 //   lw_chol_back    L^T y = z by one workgroup (z = row P of the factor).
 #define CH_NB 64
 #define CH_LD 65
@@ -403,12 +407,13 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *
 // One workgroup = a 256 x 64 slab: the 64 rows of the diagonal block + 192 rows below it, as 16 x 4 MFMA tiles in registers (wave w owns the tile rows
 // w, w + 4, w + 8, w + 12). Per 4-column panel: lanes holding the panel's columns -> LDS; thread r (one per slab row) factors the 4 x 4 diagonal block itself
 // and solves its row's strip (the strip goes straight to S and to the operand buffer); rank-4 update of every tile right of the panel, one MFMA each.
-__global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, int *info, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
-    __shared__ double s_pan[256 * 4], s_lp[256 * 4];
+// PRE: the update of the previous block column (jp = j0 - 64) has not been applied to this block column yet — the slab takes it itself, in registers, before it
+// factors (lw_chol_step: the rest of that update runs beside it in the same launch)
+template <bool PRE>
+__device__ __forceinline__ void lw_chol_panel_body(int P, double *S, int j0, int *info, int wg, double *s_pan, double *s_lp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g4 = lane >> 4;
     const int nb = min(CH_NB, P - j0), P1 = P + 1;                 // the last block is padded with an identity
-    const int below0 = j0 + nb + CH_BELOW * (int)blockIdx.x;       // first global row of this workgroup's rows below the block
+    const int below0 = j0 + nb + CH_BELOW * wg;                    // first global row of this workgroup's rows below the block
     auto grow = [&](int lr) { return lr < CH_NB ? j0 + lr : below0 + (lr - CH_NB); };      // slab row -> row of S (rows 64.. of the slab are below the block)
     auto live = [&](int lr) { return lr < CH_NB ? lr < nb : below0 + (lr - CH_NB) < P1; };
     lw_double4 T[4][4];                                            // [m][tile column]: tile row wave + 4 m
@@ -418,13 +423,61 @@ __global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, i
         for (int tcl = 0; tcl < 4; tcl++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
+                // straight-line: every entry loads (a dead one from the block's first entry) and is selected afterwards — 64 loads in flight instead of a branch each
                 const int lr = 16 * (wave + 4 * m) + g4 + 4 * q, c = 16 * tcl + c16;
-                double v = 0.0;
-                if (lr < CH_NB) { if (lr == c && lr >= nb) v = 1.0; else if (lr < nb && c <= lr) v = S[(size_t)(j0 + lr) * P + j0 + c]; }
-                else if (live(lr) && c < nb) v = S[(size_t)grow(lr) * P + j0 + c];
-                T[m][tcl][q] = v;
+                const bool ld = lr < CH_NB ? (lr < nb && c <= lr) : (live(lr) && c < nb);
+                const double v = S[ld ? (size_t)grow(lr) * P + j0 + c : (size_t)j0 * P + j0];
+                T[m][tcl][q] = ld ? v : ((lr < CH_NB && lr == c && lr >= nb) ? 1.0 : 0.0);
             }
-    const bool mine = live(tid) && (tid >= CH_NB || blockIdx.x == 0);         // the block's own rows are written by workgroup 0 only
+    if (PRE) {
+        // T -= L[slab rows][jp .. jp + 63] L[block rows][jp .. jp + 63]^T. The two operands go through LDS in four K-quarters of 16, read from S along k (a wave
+        // instruction covers four rows x 128 contiguous bytes; MFMA operands fetched straight from S touch sixteen rows per instruction and took 18 us instead of 4).
+        // The staging area is the panel's s_pan / s_lp region and what follows it (the caller's buffer holds 16 x 257 + 16 x 65 doubles).
+        const int jp = j0 - CH_NB;
+        double *sA = s_pan, *sB = s_pan + 16 * 257;
+        // straight-line loads (a dead row reads a live one and is zeroed on the way to LDS: a branch per load kept them from being issued together), the next
+        // quarter's loads are in flight while this quarter's MFMAs run
+        const double *pa[16], *pb[4];
+        unsigned alive = 0;
+#pragma unroll
+        for (int u = 0; u < 16; u++) { const int e = tid + 256 * u, row = e >> 4; const bool lv = live(row); alive |= (lv ? 1u : 0u) << u; pa[u] = S + (size_t)(lv ? grow(row) : j0) * P + jp + (e & 15); }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int e = tid + 256 * u, c = e >> 4; const bool lv = c < nb; alive |= (lv ? 1u : 0u) << (16 + u); pb[u] = S + (size_t)(j0 + (lv ? c : 0)) * P + jp + (e & 15); }
+        double va[16], vb[4];
+#pragma unroll
+        for (int u = 0; u < 16; u++) va[u] = pa[u][0];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vb[u] = pb[u][0];
+#pragma unroll 1
+        for (int kq = 0; kq < 4; kq++) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int e = tid + 256 * u; sA[(e & 15) * 257 + (e >> 4)] = ((alive >> u) & 1) ? -va[u] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int e = tid + 256 * u; sB[(e & 15) * 65 + (e >> 4)] = ((alive >> (16 + u)) & 1) ? vb[u] : 0.0; }
+            if (kq < 3) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) va[u] = pa[u][16 * (kq + 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) vb[u] = pb[u][16 * (kq + 1)];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                double av[4], bv[4];
+                const int k = 4 * s4 + g4;
+#pragma unroll
+                for (int t = 0; t < 4; t++) { av[t] = sA[k * 257 + 16 * (wave + 4 * t) + c16]; bv[t] = sB[k * 65 + 16 * t + c16]; }
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int tcl = 0; tcl < 4; tcl++)
+                        if (m > 0 || tcl <= wave) T[m][tcl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[tcl], T[m][tcl], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                           // the staging area becomes s_pan / s_lp
+    }
+    const bool mine = live(tid) && (tid >= CH_NB || wg == 0);                 // the block's own rows are written by workgroup 0 only
     double *Srow = S + (size_t)grow(tid) * P + j0;
 #pragma unroll 1
     for (int bj = 0; bj < 16; bj++) {
@@ -457,7 +510,7 @@ __global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, i
                 if (k >= 2 && p0 + 2 < nb) Srow[p0 + 2] = x2;
                 if (k >= 3 && p0 + 3 < nb) Srow[p0 + 3] = x3;
             }
-            if (k == 0 && blockIdx.x == 0 && (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || !(t33 > 0.0))) *info = 1;
+            if (k == 0 && wg == 0 && (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || !(t33 > 0.0))) *info = 1;
         }
         __syncthreads();
 #pragma unroll
@@ -470,14 +523,20 @@ __global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, i
                 }
     }
 }
-// A22 -= L21 L21^T, lower 64 x 64 tiles of the rows / columns j1 .. P (row P = rhs). grid.x = nt (nt + 1) / 2
-__global__ __launch_bounds__(256) void lw_chol_update(int P, double *S, int j0, int nb, const int *skip) {
+__global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, int *info, const int *skip) {
     if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
-    __shared__ double sA[CH_NB * CH_LD], sB[CH_NB * CH_LD];
+    __shared__ double s_pan[256 * 4], s_lp[256 * 4];
+    lw_chol_panel_body<false>(P, S, j0, info, (int)blockIdx.x, s_pan, s_lp);
+}
+// A22 -= L21 L21^T, lower 64 x 64 tiles of the rows / columns j1 .. P (row P = rhs). Tile u of the lower triangle, shifted by `shift` tile rows / columns
+// (shift 1 = lw_chol_step: the tiles right of the next block column; that column itself is the panel workgroups')
+__device__ __forceinline__ void lw_chol_update_body(int P, double *S, int j0, int nb, int u, int shift, double *sA, double *sB) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, P1 = P + 1, j1 = j0 + nb;
     int ti = 0;
-    while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
-    const int tj = blockIdx.x - ti * (ti + 1) / 2, r0 = j1 + 64 * ti, c0 = j1 + 64 * tj;
+    while ((ti + 1) * (ti + 2) / 2 <= u) ti++;
+    const int tj = u - ti * (ti + 1) / 2 + shift;
+    ti += shift;
+    const int r0 = j1 + 64 * ti, c0 = j1 + 64 * tj;
     // panels: element (row i, k) of L21 -> s[k][i] (k-major for the MFMA operand reads); the global read is coalesced along k
     for (int e = tid; e < 64 * CH_NB; e += 256) {
         const int i = e >> 6, k = e & 63;
@@ -511,6 +570,15 @@ __global__ __launch_bounds__(256) void lw_chol_update(int P, double *S, int j0, 
                 const int row = r0 + wi + 16 * a + (lane >> 4) + 4 * q, col = c0 + wj + 16 * b + (lane & 15);
                 if (row < P1 && col < P && col <= row) S[(size_t)row * P + col] -= acc[a][b][q];
             }
+}
+// One launch per block column j0 >= 64: the first npanel workgroups factor block column j0 (taking the update of column j0 - 64 into their registers first),
+// the others apply the update of column j0 - 64 to the tiles right of block column j0. The two sets write disjoint parts of S and both only read column j0 - 64:
+// the panel no longer waits for a whole trailing update, and a block column costs one launch instead of two.
+__global__ __launch_bounds__(256) void lw_chol_step(int P, double *S, int j0, int npanel, int *info, const int *skip) {
+    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+    __shared__ double s_buf[2 * CH_NB * CH_LD];
+    if ((int)blockIdx.x < npanel) lw_chol_panel_body<true>(P, S, j0, info, (int)blockIdx.x, s_buf, s_buf + 256 * 4);
+    else lw_chol_update_body(P, S, j0 - CH_NB, CH_NB, (int)blockIdx.x - npanel, 1, s_buf, s_buf + CH_NB * CH_LD);
 }
 // L^T y = z, z = row P of the factor; one workgroup, columns right to left in 64-blocks. Per block: wave 0 solves the block's triangle — lane = row, the 64 steps
 // fully unrolled so that the pivot row's value travels by v_readlane (a shuffle per step through LDS and a division per step were most of the 215 us this kernel
@@ -1194,10 +1262,13 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         int *dinfo = c->info.as<int>();
         tic();
         HIPCHECK(h, hipMemsetAsync(dinfo, 0, 4, h->stream));
-        for (int j0 = 0; j0 < P; j0 += CH_NB) {                          // blocked Cholesky, two launches per 64-column block
-            const int nb = std::min(CH_NB, P - j0), below = P + 1 - (j0 + nb);
-            hipLaunchKernelGGL(lw_chol_panel, dim3(std::max(1, (below + CH_BELOW - 1) / CH_BELOW)), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, dinfo, skip);
-            if (j0 + nb < P) { const int nt = (below + 63) / 64; hipLaunchKernelGGL(lw_chol_update, dim3(nt * (nt + 1) / 2), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, nb, skip); }
+        for (int j0 = 0; j0 < P; j0 += CH_NB) {                          // blocked Cholesky, one launch per 64-column block (panel of this column + the rest of the previous column's update)
+            const int nb = std::min(CH_NB, P - j0), below = P + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
+            if (j0 == 0) hipLaunchKernelGGL(lw_chol_panel, dim3(npanel), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, dinfo, skip);
+            else {
+                const int nt = (P + 1 - j0 + 63) / 64;                   // tiles of the rows / columns j0 .. P; column 0 of them is the panel's
+                hipLaunchKernelGGL(lw_chol_step, dim3(npanel + nt * (nt - 1) / 2), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, npanel, dinfo, skip);
+            }
         }
         hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), sP * 8, h->stream, P, c->S.as<double>(), c->rhs.as<double>(), skip);
         toc(2);
