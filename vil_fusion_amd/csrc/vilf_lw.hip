@@ -660,6 +660,7 @@ __global__ __launch_bounds__(256) void lw_colsum(int R, int C, const double *A, 
     if (c >= C) return;
     const int rchunk = (R + rsplit - 1) / rsplit, ra = blockIdx.y * rchunk, rb = min(R, ra + rchunk);
     double s = 0;
+#pragma unroll 8
     for (int r = ra; r < rb; r++) s += A[(size_t)r * C + c] * x[r];
     unsafeAtomicAdd(y + c, alpha * s);
 }
@@ -1257,7 +1258,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
                 hipLaunchKernelGGL(lw_syrk_mfma, dim3(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, P, F, c->Wn.as<double>(), c->S.as<double>(), ksplit, skip);
             }
             toc(1);
-            hipLaunchKernelGGL(lw_colsum, dim3((P + 255) / 256, 16), dim3(256), 0, h->stream, F, P, c->Wn.as<double>(), c->tmpF.as<double>(), -1.0, rhs_row, 16, skip);
+            hipLaunchKernelGGL(lw_colsum, dim3((P + 255) / 256, 128), dim3(256), 0, h->stream, F, P, c->Wn.as<double>(), c->tmpF.as<double>(), -1.0, rhs_row, 128, skip);    // 128 row chunks: 16 left most CUs idle (42 us for 15 MB)
         }
         int *dinfo = c->info.as<int>();
         tic();
