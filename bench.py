@@ -264,13 +264,21 @@ def main():
             th = threading.Thread(target=lidar_stage)   # ctypes releases the GIL: both stages enqueue and run concurrently
             th.start()
         elif s2m is not None:
-            lidar_stage()                               # the LiDAR stage to completion, then the window solve: nothing overlaps, the per-kernel times are clean
+            # the LiDAR stage, then the window solve: nothing overlaps on the device (the per-kernel times are clean), but the host does not wait in between —
+            # the solver's stream takes a device-side dependency on the LiDAR stage's stream (vilf_wait_for) and the whole frame is enqueued at once
+            s2m.rewind()
+            s2m.step(sync=False)
+            if lidar_handle is not solver:
+                solver.wait_for(lidar_handle)
         solver.batch_rewind()                           # state AND priors back to the uploaded snapshot
-        solver.batch_solve(sync=True)
+        solver.batch_solve(sync=False)
         if not args.no_marginalize:
-            solver.batch_marginalize(sync=True)         # estimator.cpp:863-1046: the new priors stay on the device
+            solver.batch_marginalize(sync=False)        # estimator.cpp:863-1046: the new priors stay on the device
         if th is not None:
             th.join()
+        solver.synchronize()                            # end of the frame: the one host wait (the LiDAR stage finished before the solve started)
+        if s2m is not None and lidar_handle is not solver:
+            lidar_handle.synchronize()                  # (already idle: reads its pending profile spans, so its event pool is reused)
         if world > 1:
             solver.newest_poses_to_device(stamps, poses.data_ptr())
             vdist.gather_poses(poses.cpu() if rehearse else poses)   # RCCL all_gather: 64 B per solved window (rank 0 feeds global_fusion)

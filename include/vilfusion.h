@@ -203,7 +203,13 @@ int vilf_batch_summaries(vilf_handle *h, int first, int n_windows, vilf_summary 
  * any pointer may be NULL. The per-frame caller's download: the parameter arrays stay on the device for the marginalization. */
 int vilf_batch_download_states(vilf_handle *h, int first, int n_windows, double *Ps, double *Rs, double *Vs, double *Bas, double *Bgs, vilf_summary *sums);
 int vilf_synchronize(vilf_handle *h);
-/* per-kernel timing by HIP events on the handle's stream (kind 0 linearize incl. the trust-region step, 1 reduce+solve, 2 the step-only launch that ends a solve, 3 other); needs sync solves */
+/* Work enqueued on h's stream after this call starts once everything enqueued on other's stream so far has finished — a dependency on the device
+ * (hipEventRecord + hipStreamWaitEvent), the host does not wait. The reference runs the LiDAR node and the estimator node side by side and hands
+ * lidarConstraints across (feature_tracker_node.cpp:384,524 -> estimator.cpp:689-860); with one handle per stage this orders a frame's two stages
+ * without a host round trip between them. Both handles must be on the same device. */
+int vilf_wait_for(vilf_handle *h, vilf_handle *other);
+/* per-kernel timing by HIP events on the handle's stream (kind 0 linearize incl. the trust-region step, 1 reduce+solve, 2 the step-only launch that ends a solve, 3 other).
+ * With sync == 0 calls the spans stay pending and are read by the next call that waits for the stream (a sync call, vilf_batch_summaries, vilf_get_profile*). */
 int vilf_set_profiling(vilf_handle *h, int on);
 int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]);
 /* same switch, scan-to-map launches by group: 0 voxel grid, 1 radix sort, 2 neighbour index, 3 associate (5-NN + fits),

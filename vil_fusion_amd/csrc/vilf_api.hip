@@ -179,10 +179,43 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->pev) hipEventDestroy(e);           // profiling events (vilf_set_profiling)
-    for (hipEvent_t e : h->s2m_ev) hipEventDestroy(e);
-    h->pev.clear(); h->s2m_ev.clear();
+    for (hipEvent_t e : h->prof_used) hipEventDestroy(e);
+    for (hipEvent_t e : h->prof_free) hipEventDestroy(e);
+    if (h->wait_ev) hipEventDestroy(h->wait_ev);
+    h->pev.clear(); h->s2m_ev.clear(); h->prof_used.clear(); h->prof_free.clear(); h->prof_pending.clear();
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
+}
+
+// ---- deferred profile spans (see vilf_handle::prof_pending)
+hipEvent_t vilf_prof_event(vilf_handle *h) {
+    hipEvent_t e = nullptr;
+    if (!h->prof_free.empty()) { e = h->prof_free.back(); h->prof_free.pop_back(); } else hipEventCreate(&e);
+    h->prof_used.push_back(e);
+    hipEventRecord(e, h->stream);
+    return e;
+}
+void vilf_prof_span(vilf_handle *h, hipEvent_t a, hipEvent_t b, double *ms, long *cnt) { h->prof_pending.push_back(vilf_handle::ProfSpan{a, b, ms, cnt}); }
+int vilf_prof_flush(vilf_handle *h) {
+    if (h->prof_used.empty()) return VILF_OK;
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (const vilf_handle::ProfSpan &p : h->prof_pending) { float t = 0; hipEventElapsedTime(&t, p.a, p.b); *p.ms += t; *p.cnt += 1; }
+    h->prof_pending.clear();
+    for (hipEvent_t e : h->prof_used) h->prof_free.push_back(e);
+    h->prof_used.clear();
+    return VILF_OK;
+}
+// The work enqueued on h's stream from now on starts after everything enqueued on other's stream so far has finished: a dependency on the device, the host
+// does not wait. (The LiDAR stage and the window solve of a frame run on two handles: this orders them without a host round trip between them.)
+extern "C" int vilf_wait_for(vilf_handle *h, vilf_handle *other) {
+    if (!h || !other) return VILF_ERR_INVALID_ARGUMENT;
+    if (h->device != other->device) { h->err = "vilf_wait_for: the handles are on different devices"; return VILF_ERR_INVALID_ARGUMENT; }
+    if (h == other || h->stream == other->stream) return VILF_OK;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (!h->wait_ev) HIPCHECK(h, hipEventCreateWithFlags(&h->wait_ev, hipEventDisableTiming));
+    HIPCHECK(h, hipEventRecord(h->wait_ev, other->stream));
+    HIPCHECK(h, hipStreamWaitEvent(h->stream, h->wait_ev, 0));
+    return VILF_OK;
 }
 
 extern "C" const char *vilf_last_error(const vilf_handle *h) { return h ? h->err.c_str() : "null handle"; }
@@ -198,6 +231,7 @@ extern "C" int vilf_reset(vilf_handle *h) {
 extern "C" int vilf_synchronize(vilf_handle *h) {
     if (!h) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }      // pending profile spans: the stream is idle, reading them costs nothing
     return VILF_OK;
 }
 
@@ -616,12 +650,12 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     // k_solve_sb eliminates SpeedBias[1..10] as a block-tridiagonal chain: valid while the priors hold no speed-bias block but SpeedBias[0] (all the
     // reference ever produces, estimator.cpp:960-971); VILF_SOLVE_DENSE=1 forces the dense-Cholesky kernel (tests compare the two)
     const bool dense = h->solve_dense_fallback || std::getenv("VILF_SOLVE_DENSE") != nullptr;
-    const int nlaunch = 3 * h->opts.max_num_iterations + 3;
     const bool prof = h->profiling != 0;
-    if (prof && (int)h->pev.size() < nlaunch + 1) { while ((int)h->pev.size() < nlaunch + 1) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); } }
+    if (prof && h->prof_used.size() > 4096) { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }      // asynchronous calls without a reader: bound the pool
     std::vector<int> kinds;
     int ne = 0;
-    auto mark = [&](int kind) { if (prof) { hipEventRecord(h->pev[ne++], h->stream); kinds.push_back(kind); } };
+    std::vector<hipEvent_t> pev;
+    auto mark = [&](int kind) { if (prof) { pev.push_back(vilf_prof_event(h)); ne++; kinds.push_back(kind); } };
     hipEventRecord(h->ev0, h->stream);
     mark(3);
     hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
@@ -650,7 +684,10 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     }
     mark(3);
     hipLaunchKernelGGL(k_finalize, grid, dim3(64), 0, h->stream, h->batch);
-    if (prof) hipEventRecord(h->pev[ne++], h->stream);
+    if (prof) {
+        pev.push_back(vilf_prof_event(h)); ne++;
+        for (size_t i = 0; i < kinds.size(); i++) vilf_prof_span(h, pev[i], pev[i + 1], &h->kernel_ms[kinds[i]], &h->kernel_launches[kinds[i]]);
+    }
     hipEventRecord(h->ev1, h->stream);
     HIPCHECK(h, hipGetLastError());
     if (sync) {
@@ -658,14 +695,15 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
         float ms = 0;
         hipEventElapsedTime(&ms, h->ev0, h->ev1);
         h->last_solve_usec = ms * 1000.0;
-        if (prof) for (size_t i = 0; i < kinds.size(); i++) { float t = 0; hipEventElapsedTime(&t, h->pev[i], h->pev[i + 1]); h->kernel_ms[kinds[i]] += t; h->kernel_launches[kinds[i]] += 1; }
-    } else if (prof) { h->err = "profiling needs sync != 0"; return VILF_ERR_INVALID_ARGUMENT; }
+        if (prof) { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
+    }                                           // sync == 0 with profiling on: the spans stay pending (read by the next call that waits for the stream)
     return VILF_OK;
 }
 
 // per-kernel timing with HIP events on the handle's stream (bench.py roofline). kind: 0 linearize, 1 solve, 2 step, 3 other
 extern "C" int vilf_set_profiling(vilf_handle *h, int on) {
     if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
     h->profiling = on;
     for (int i = 0; i < 4; i++) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
     for (int i = 0; i < 8; i++) { h->s2m_ms[i] = 0; h->s2m_launches[i] = 0; }
@@ -674,12 +712,14 @@ extern "C" int vilf_set_profiling(vilf_handle *h, int on) {
 }
 extern "C" int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]) {
     if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
+    { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
     for (int i = 0; i < 4; i++) { ms_out[i] = h->kernel_ms[i]; launches_out[i] = h->kernel_launches[i]; }
     return VILF_OK;
 }
 
 extern "C" int vilf_get_profile_marginalize(vilf_handle *h, double ms_out[4], long launches_out[4]) {
     if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
+    { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
     for (int i = 0; i < 4; i++) { ms_out[i] = h->marg_ms[i]; launches_out[i] = h->marg_launches[i]; }
     return VILF_OK;
 }
@@ -689,6 +729,7 @@ extern "C" int vilf_batch_summaries(vilf_handle *h, int first, int n, vilf_summa
     std::vector<VbState> st(n);
     HIPCHECK(h, hipMemcpyAsync(st.data(), h->batch.st + first, sizeof(VbState) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }     // the stream is idle: pending profile spans cost nothing to read now
     for (int i = 0; i < n; i++) {
         sums[i].num_iterations = st[i].iteration;
         sums[i].num_successful_steps = st[i].num_successful;
@@ -850,12 +891,12 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     const int *oset = to_other_set ? bak : live;
     g.prior_hdr_out = h->d[oset[0]].as<int>(); g.prior_x0_out = h->d[oset[1]].as<double>(); g.prior_J_out = h->d[oset[2]].as<double>(); g.prior_r_out = h->d[oset[3]].as<double>();
     const dim3 grid(h->B), block(VB_NT);
-    const bool prof = h->profiling != 0 && sync;
-    if (prof) while (h->pev.size() < 5) { hipEvent_t e; hipEventCreate(&e); h->pev.push_back(e); }
-    if (prof) hipEventRecord(h->pev[0], h->stream);
+    const bool prof = h->profiling != 0;
+    hipEvent_t mev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (prof) mev[0] = vilf_prof_event(h);
     if (h->batch.est_td) hipLaunchKernelGGL(k_marg_prepare_td, grid, block, 0, h->stream, h->batch, g);
     else hipLaunchKernelGGL(k_marg_prepare, grid, block, 0, h->stream, h->batch, g);
-    if (prof) hipEventRecord(h->pev[1], h->stream);
+    if (prof) mev[1] = vilf_prof_event(h);
     hipLaunchKernelGGL(k_marg_schur, grid, block, (size_t)(MG_MD * MG_MD + MG_MD * (MG_NK + 1) + 1000 + VB_NT + MG_FCH * MG_RWP) * sizeof(double), h->stream, h->batch, g,
                        std::getenv("VILF_MARG_FORCE_EXACT") ? 2 : 0);      // test hook: exercise the Jacobi path on well-conditioned windows too
     g.pool = (int)sPool;
@@ -864,7 +905,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
         hipLaunchKernelGGL(k_marg_schur, grid, block, h->marg_lds_schur, h->stream, h->batch, g, 1);
     }
     g.pool_round = 0;
-    if (prof) hipEventRecord(h->pev[2], h->stream);
+    if (prof) mev[2] = vilf_prof_event(h);
     // eigen-solver of the kept block in three launches (tred2 per workgroup, the QL recurrence of every window one lane each, rotation replay +
     // prior output per workgroup); k_marg_finish (everything in one workgroup) only takes windows whose rotation log overflowed
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
@@ -881,13 +922,13 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
         bind_prior_pointers(h);
         h->prior_backup_valid = true;           // the other set now holds the priors as uploaded
     }
-    if (prof) hipEventRecord(h->pev[3], h->stream);
+    if (prof) mev[3] = vilf_prof_event(h);
     hipLaunchKernelGGL(k_prior_prep, grid, block, VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS);
-    if (prof) hipEventRecord(h->pev[4], h->stream);
+    if (prof) mev[4] = vilf_prof_event(h);
     HIPCHECK(h, hipGetLastError());
     if (prof) {
-        HIPCHECK(h, hipStreamSynchronize(h->stream));
-        for (int k = 0; k < 4; k++) { float t = 0; hipEventElapsedTime(&t, h->pev[k], h->pev[k + 1]); h->marg_ms[k] += t; h->marg_launches[k] += 1; }
+        for (int k = 0; k < 4; k++) vilf_prof_span(h, mev[k], mev[k + 1], &h->marg_ms[k], &h->marg_launches[k]);
+        if (sync) { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
     }
     for (int w = 0; w < h->B; w++) { h->prior_dev_newer[w] = 1; h->prior_dirty[w] = 0; }
     h->prior_restore_needed = true;

@@ -92,6 +92,12 @@ struct vilf_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int profiling = 0;                       // per-kernel HIP-event timing of the solve launches
     std::vector<hipEvent_t> pev;
+    // deferred profile spans: an asynchronous call (sync == 0) records its events and leaves them here; they are read at the next point that waits for the
+    // stream anyway (a synchronous call, vilf_batch_summaries, vilf_get_profile*) — per-kernel times without a host round trip between the stages of a frame
+    struct ProfSpan { hipEvent_t a, b; double *ms; long *cnt; };
+    std::vector<ProfSpan> prof_pending;
+    std::vector<hipEvent_t> prof_used, prof_free;
+    hipEvent_t wait_ev = nullptr;            // vilf_wait_for
     double kernel_ms[4] = {0, 0, 0, 0};      // linearize, solve, step, other (accumulated since last reset)
     long kernel_launches[4] = {0, 0, 0, 0};
     std::vector<hipEvent_t> s2m_ev;         // scan-to-map profiling (same switch): group of launches -> ms
@@ -119,6 +125,9 @@ struct vilf_handle {
     } while (0)
 
 
+hipEvent_t vilf_prof_event(vilf_handle *h);                                 // an event recorded on the handle's stream now (from the pool)
+void vilf_prof_span(vilf_handle *h, hipEvent_t a, hipEvent_t b, double *ms, long *cnt);   // elapsed(a, b) is added to *ms at the next flush
+int vilf_prof_flush(vilf_handle *h);                                        // waits for the stream, reads every pending span
 void vilf_s2m_release(vilf_handle *h);
 void vilf_feat_release(vilf_handle *h);
 void vilf_pg_release(vilf_handle *h);

@@ -1549,10 +1549,10 @@ void vilf_s2m_release(vilf_handle *h) {
 // profiling (vilf_set_profiling): HIP events between groups of launches on the handle's stream.
 // group 0 voxel grid, 1 radix sort (rocPRIM), 2 neighbour index (cell keys, hash build), 3 associate (5-NN + fits), 4 LM solve,
 // 5 sub-map (append, crop, compact), 6 other
-static void s2m_prof_mark(vilf_handle *h, int group) {
-    const size_t k = h->s2m_groups.size();
-    if (h->s2m_ev.size() <= k) { hipEvent_t e; hipEventCreate(&e); h->s2m_ev.push_back(e); }
-    hipEventRecord(h->s2m_ev[k], h->stream);
+static void s2m_prof_mark(vilf_handle *h, int group) {       // the launches since the previous mark belong to `group`
+    hipEvent_t e = vilf_prof_event(h);
+    if (!h->s2m_groups.empty()) vilf_prof_span(h, h->s2m_ev.back(), e, &h->s2m_ms[group], &h->s2m_launches[group]);
+    h->s2m_ev.push_back(e);
     h->s2m_groups.push_back(group);
 }
 #define PROF(g) if (h->profiling) s2m_prof_mark(h, (g));
@@ -1693,7 +1693,7 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     double *d_pose = c->pose.as<double>();
     S2BRes *d_res = c->res.as<S2BRes>();
     int *d_err = c->err.as<int>();
-    h->s2m_groups.clear();
+    h->s2m_groups.clear(); h->s2m_ev.clear();
     PROF(6)
     hipLaunchKernelGGL(b_predict, GRIDS(S), 0, h->stream, d_pose, S);
     PROF(6)
@@ -1765,15 +1765,8 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
     PROF(6)
     HIPCHECK(h, hipGetLastError());
-    if (h->profiling) {
-        HIPCHECK(h, hipStreamSynchronize(h->stream));
-        for (size_t i = 1; i < h->s2m_groups.size(); i++) {
-            float t = 0;
-            hipEventElapsedTime(&t, h->s2m_ev[i - 1], h->s2m_ev[i]);
-            h->s2m_ms[h->s2m_groups[i]] += t; h->s2m_launches[h->s2m_groups[i]] += 1;
-        }
-    }
-    return VILF_OK;
+    if (h->profiling && h->prof_used.size() > 4096) return vilf_prof_flush(h);      // asynchronous steps without a reader: bound the pool
+    return VILF_OK;                                                                 // the spans are read by the next call that waits for the stream
 }
 
 static void s2b_fill_result(const S2BRes &r, vilf_scan2map_result *res) {
@@ -1926,11 +1919,12 @@ extern "C" int vilf_scan2map_batch_step(vilf_handle *h, int sync) {
     S2B_CHECK(h, 0)
     int rc = s2b_step(h, c);
     if (rc != VILF_OK) return rc;
-    if (sync) HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (sync) { HIPCHECK(h, hipStreamSynchronize(h->stream)); if ((rc = vilf_prof_flush(h)) != VILF_OK) return rc; }
     return VILF_OK;
 }
 extern "C" int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long launches_out[8]) {
     if (!h || !ms_out || !launches_out) return VILF_ERR_INVALID_ARGUMENT;
+    { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
     for (int i = 0; i < 8; i++) { ms_out[i] = h->s2m_ms[i]; launches_out[i] = h->s2m_launches[i]; }
     return VILF_OK;
 }

@@ -89,6 +89,10 @@ class BackendSolver:
     def synchronize(self):
         self._check(self._L.vilf_synchronize(self._h), "vilf_synchronize")
 
+    def wait_for(self, other):
+        """work enqueued on this handle from now on starts after everything enqueued on `other` so far has finished (device-side dependency, no host wait)"""
+        self._check(self._L.vilf_wait_for(self._h, other._h), "vilf_wait_for")
+
     def set_profiling(self, on=True):
         self._check(self._L.vilf_set_profiling(self._h, 1 if on else 0), "vilf_set_profiling")
 
