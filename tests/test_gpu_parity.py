@@ -475,6 +475,50 @@ def test_large_window_device_trust_region_loop(oracle, monkeypatch, noise, deg, 
         assert np.abs(dev.Ps - other.Ps).max() < 1e-5 and abs(dev.summary["final_radius"] - other.summary["final_radius"]) <= 1e-6 * other.summary["final_radius"]
 
 
+def test_frame_without_host_round_trips_between_its_stages(oracle, opts):
+    """One handle per stage, as INTEGRATION.md wires them: the LiDAR stage is enqueued asynchronously on its handle, the solver's stream takes a device-side dependency
+    on it (vilf_wait_for), solve + marginalization are enqueued asynchronously too and the host waits once. Profiling stays on: the per-kernel spans of asynchronous calls
+    are read by the next call that waits for the stream. Same results as the synchronous calls, and every profiled group has its launches."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
+    me, ms, scans, pl = synth.make_lidar_bench_case(7000)
+    wins, priors = synth.make_batch(41, 6, opts, synth.SynthConfig(n_features=80), distinct=6)
+    def run(asynchronous):
+        solver, lidar = BackendSolver(opts), BackendSolver(opts)
+        try:
+            b = Scan2MapBatch(lidar, 2, len(scans[0][0]) + 64, len(scans[0][1]) + 64, len(me) + len(scans[0][0]) + 64, len(ms) + len(scans[0][1]) + 64)
+            for i in range(2):
+                b.localMapInited(i, me, ms, None, pl)
+                b.set_scan(i, *scans[0])
+            solver.batch_upload(wins, priors)
+            solver.set_profiling(True); lidar.set_profiling(True)
+            for _ in range(2):                                   # twice: the second frame reuses the event pool
+                b.snapshot() if _ == 0 else b.rewind()
+                b.step(sync=not asynchronous)
+                if asynchronous:
+                    solver.wait_for(lidar)
+                solver.batch_rewind()
+                solver.batch_solve(sync=not asynchronous)
+                solver.batch_marginalize(sync=not asynchronous)
+                solver.synchronize(); lidar.synchronize()
+            prof = (solver.get_profile(), solver.get_profile_marginalize(), lidar.get_profile_scan2map())
+            poses = [np.array(r.pose_qt[:]) for r in b.results()]
+            return solver.batch_download(), [solver.get_prior(i) for i in range(6)], poses, prof
+        finally:
+            solver.close(); lidar.close()
+    res_s, pri_s, pose_s, prof_s = run(False)
+    res_a, pri_a, pose_a, prof_a = run(True)
+    for a, b_ in zip(res_a, res_s):
+        assert np.array_equal(a.Ps, b_.Ps) and np.array_equal(a.para_feature, b_.para_feature)
+    for a, b_ in zip(pri_a, pri_s):
+        assert np.array_equal(_prior_products(a)[0], _prior_products(b_)[0])
+    for a, b_ in zip(pose_a, pose_s):
+        assert np.array_equal(a, b_)
+    for pa, ps in zip(prof_a, prof_s):
+        assert {k: v["launches"] for k, v in pa.items()} == {k: v["launches"] for k, v in ps.items()}
+        assert all(v["ms"] > 0 for v in pa.values() if v["launches"] > 0)
+    assert prof_a[0]["k_linearize"]["launches"] > 0 and prof_a[1]["k_marg_prepare"]["launches"] == 2 and prof_a[2]["s2m_associate"]["launches"] > 0
+
+
 def test_error_behaviour_of_the_newer_entry_points(solver, oracle, opts):
     """loud failures instead of silent fall-backs: a pose graph without a complete odometry chain, an edge to a missing node, a non-positive
     sigma; a window whose frame count does not match options.window_size; a batched call with a non-11-frame window"""
