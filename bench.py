@@ -296,9 +296,27 @@ def main():
     barrier()
     t0 = time.perf_counter()
     its_local = 0
-    for _ in range(args.steps):
-        step()
-        its_local += sum(s.num_iterations for s in solver.batch_summaries())
+    # Back-to-back mode: frame k + 1's LiDAR stage is enqueued (behind a device-side dependency on frame k's marginalization) BEFORE the host reads frame k's
+    # summaries, so the device does not idle while the host counts iterations. Exactly `steps` LiDAR stages and `steps` back-end stages run inside the timed region.
+    pipelined = s2m is not None and not args.overlap and lidar_handle is not solver
+    if pipelined:
+        s2m.rewind(); s2m.step(sync=False)
+    for k in range(args.steps):
+        if pipelined:
+            solver.wait_for(lidar_handle)
+            solver.batch_rewind()
+            solver.batch_solve(sync=False)
+            if not args.no_marginalize:
+                solver.batch_marginalize(sync=False)
+            if k + 1 < args.steps:
+                lidar_handle.wait_for(solver)
+                s2m.rewind(); s2m.step(sync=False)
+            if world > 1:
+                solver.newest_poses_to_device(stamps, poses.data_ptr())
+                vdist.gather_poses(poses.cpu() if rehearse else poses)
+        else:
+            step()
+        its_local += sum(s.num_iterations for s in solver.batch_summaries())     # waits for the solver's stream (frame k done)
     barrier()
     dt = time.perf_counter() - t0
     prof = solver.get_profile()

@@ -704,6 +704,8 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
 extern "C" int vilf_set_profiling(vilf_handle *h, int on) {
     if (!h) return VILF_ERR_INVALID_ARGUMENT;
     { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
+    // hipEventCreate is slow enough to starve the stream when it happens between launches (measured: 1.9 ms per frame for ~50 events): the pool is filled here
+    if (on) { HIPCHECK(h, hipSetDevice(h->device)); while (h->prof_free.size() < 1024) { hipEvent_t e; HIPCHECK(h, hipEventCreate(&e)); h->prof_free.push_back(e); } }
     h->profiling = on;
     for (int i = 0; i < 4; i++) { h->kernel_ms[i] = 0; h->kernel_launches[i] = 0; }
     for (int i = 0; i < 8; i++) { h->s2m_ms[i] = 0; h->s2m_launches[i] = 0; }
