@@ -178,11 +178,10 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     h->pin_up.release(); h->pin_down.release();
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
-    for (hipEvent_t e : h->pev) hipEventDestroy(e);           // profiling events (vilf_set_profiling)
     for (hipEvent_t e : h->prof_used) hipEventDestroy(e);
     for (hipEvent_t e : h->prof_free) hipEventDestroy(e);
     if (h->wait_ev) hipEventDestroy(h->wait_ev);
-    h->pev.clear(); h->s2m_ev.clear(); h->prof_used.clear(); h->prof_free.clear(); h->prof_pending.clear();
+    h->s2m_ev.clear(); h->prof_used.clear(); h->prof_free.clear(); h->prof_pending.clear();
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }

@@ -91,7 +91,6 @@ struct vilf_handle {
     bool luts_ready = false;                 // static scatter / gather tables uploaded
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int profiling = 0;                       // per-kernel HIP-event timing of the solve launches
-    std::vector<hipEvent_t> pev;
     // deferred profile spans: an asynchronous call (sync == 0) records its events and leaves them here; they are read at the next point that waits for the
     // stream anyway (a synchronous call, vilf_batch_summaries, vilf_get_profile*) — per-kernel times without a host round trip between the stages of a frame
     struct ProfSpan { hipEvent_t a, b; double *ms; long *cnt; };
