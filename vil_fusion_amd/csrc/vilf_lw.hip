@@ -338,7 +338,7 @@ __global__ void lw_feature_back(int F, const double *gf, const double *Wy, const
 // triangle and per K split; four waves, each a 32 x 32 sub-tile = 2 x 2 v_mfma_f64_16x16x4_f64 accumulators; the two K x 64 panels of
 // Wn stream through LDS 16 feature rows at a time (coalesced 512-byte rows, padded row stride against bank conflicts). The K splits
 // (so that 78 tiles fill 256 CUs) and the mirrored tile are combined with hardware fp64 atomics on S, which already holds Hpp' + mu D^2.
-#define SY_KB 16
+#define SY_KB 32
 #define SY_LD 65
 typedef double lw_double4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *Wn, double *S, int ksplit, const int *skip) {
@@ -355,15 +355,30 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = lw_double4{0, 0, 0, 0};
-    for (int k0 = kb; k0 < ke; k0 += SY_KB) {
+    // The next K-step's panel entries are requested before this step's MFMAs (the loop used to wait a memory round trip per 16 rows of Wn: 130 us for a product
+    // the MFMA pipe does in 20), with straight-line loads: an entry outside the matrix reads a valid address and is zeroed on the way to LDS.
+    double ra[SY_KB / 4], rb[SY_KB / 4];
+    auto gload = [&](int k0) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < SY_KB / 4; u++) {
             const int e = tid + 256 * u, kk = e >> 6, cc = e & 63, k = k0 + kk;
             const bool kin = k < ke;
-            sA[kk * SY_LD + cc] = (kin && i0 + cc < P) ? Wn[(size_t)k * P + i0 + cc] : 0.0;
-            sB[kk * SY_LD + cc] = (kin && j0 + cc < P) ? Wn[(size_t)k * P + j0 + cc] : 0.0;
+            const size_t rowoff = (size_t)(kin ? k : kb) * P;
+            const double va = Wn[rowoff + min(i0 + cc, P - 1)], vb = Wn[rowoff + min(j0 + cc, P - 1)];
+            ra[u] = (kin && i0 + cc < P) ? va : 0.0;
+            rb[u] = (kin && j0 + cc < P) ? vb : 0.0;
+        }
+    };
+    if (kb < ke) gload(kb);
+    for (int k0 = kb; k0 < ke; k0 += SY_KB) {
+#pragma unroll
+        for (int u = 0; u < SY_KB / 4; u++) {
+            const int e = tid + 256 * u, kk = e >> 6, cc = e & 63;
+            sA[kk * SY_LD + cc] = ra[u];
+            sB[kk * SY_LD + cc] = rb[u];
         }
         __syncthreads();
+        if (k0 + SY_KB < ke) gload(k0 + SY_KB);
 #pragma unroll
         for (int s4 = 0; s4 < SY_KB / 4; s4++) {
             double av[2], bv[2];
