@@ -259,7 +259,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     __shared__ double s_lidJ[10 * 72], s_lidr[64], s_grad[176];
     __shared__ double s_pt[VB_NPAIR * PT_LD];
     __shared__ double s_dx[VB_PRIOR_LD];
-    __shared__ int s_pcol[VB_P], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_wl[4][VB_NPAIR + 1];     // pair table: start inside the class list, factor count; per wave the pairs of its class ([55] = how many)
+    __shared__ int s_pcol[VB_P], s_pst[VB_NPAIR], s_pcn[VB_NPAIR];     // pair table: start inside the class list, factor count
     __shared__ double s_red[NT];
 
     LSTAMP(0);
@@ -346,14 +346,17 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         }
         __threadfence_block();                                               // cfeat is read back by other threads of this workgroup below (after the next barrier)
     }
-    {   // pair table; every wave compacts the pairs of its own class (ballot + prefix count, pair order kept)
+    // pair table: lane p of every wave keeps pair p's start inside its class list and its factor count in registers, and the wave the set of its own class's pairs
+    // as a bit mask — the chunk loop walks the mask and fetches a pair's entry with v_readlane (three dependent LDS reads per pair and chunk before)
+    unsigned long long cls_mask;
+    int my_pst, my_pcn;
+    {
         const int *pt = b.pair_off + (size_t)w * VB_PTAB;
         const int pp = min(lane, VB_NPAIR - 1), v1 = pt[2 * pp + 1];
-        if (wave == 0 && lane < VB_NPAIR) { s_pst[lane] = pt[2 * lane]; s_pcn[lane] = v1 & 0xffffff; }
-        const bool mine = lane < VB_NPAIR && (v1 >> 24) == wave && (v1 & 0xffffff) > 0;
-        const unsigned long long m = __ballot(mine);
-        if (mine) s_wl[wave][__popcll(m & ((1ULL << lane) - 1ULL))] = lane;
-        if (lane == 0) s_wl[wave][VB_NPAIR] = __popcll(m);
+        my_pst = pt[2 * pp]; my_pcn = v1 & 0xffffff;
+        if (wave == 0 && lane < VB_NPAIR) { s_pst[lane] = my_pst; s_pcn[lane] = my_pcn; }
+        const bool mine = lane < VB_NPAIR && (v1 >> 24) == wave && my_pcn > 0;
+        cls_mask = __ballot(mine);
     }
     if (JAC) for (int i = tid; i < 10 * 512; i += NT) s_U[i] = 0.0;
     __syncthreads();
@@ -472,8 +475,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
 #pragma unroll
     for (int q4 = 0; q4 < 4; q4++) pe[q4] = pair_elem((lane >> 4) + 4 * q4, lane & 15);   // C-tile register -> pairD slot (fixed per lane)
     double4_t cacc = {0, 0, 0, 0}, cacc1 = {0, 0, 0, 0};            // the open pair of this wave's class list across chunk boundaries
-    int kcur = 0;
-    const int nk = __builtin_amdgcn_readfirstlane(s_wl[wave][VB_NPAIR]);
+    unsigned long long mrem = cls_mask;                              // the pairs of this wave's class not finished yet, ascending = class-list order
     if (!JAC) {
         // residuals only: one lane per factor slot, no rows, no products
         for (int fac = tid; fac < nfac; fac += NT) {
@@ -532,12 +534,12 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         const int x0c = VB_CLS * (c0 / VB_CHUNK);                              // this chunk holds the class-local positions [x0c, x0c + VB_CLS) of every class
         // the pairs of this wave's class, in class-list order = ascending position: a cursor carried across the chunks stops at the first pair that starts in a later
         // chunk (walking the whole list in every chunk and skipping cost three dependent LDS reads per pair and chunk: half of this phase)
-        for (; kcur < nk; kcur++) {
-            const int p = __builtin_amdgcn_readfirstlane(s_wl[wave][kcur]);
-            const int pst = __builtin_amdgcn_readfirstlane(s_pst[p]), pcn_ = __builtin_amdgcn_readfirstlane(s_pcn[p]);
+        while (mrem) {
+            const int p = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mrem));
+            const int pst = __builtin_amdgcn_readlane(my_pst, p), pcn_ = __builtin_amdgcn_readlane(my_pcn, p);
             if (pst >= x0c + VB_CLS) break;
             const int lo = max(pst, x0c), hi = min(pst + pcn_, x0c + VB_CLS);
-            if (lo >= hi) continue;
+            if (lo >= hi) { mrem &= mrem - 1; continue; }
             const int r_lo = 2 * (VB_CLS * wave + lo - x0c), r_hi = 2 * (VB_CLS * wave + hi - x0c);
             // a pair that began in an earlier chunk continues in the registers it was left in (a class list is walked in order: one open pair per wave at most)
             double4_t acc = (pst < x0c) ? cacc : double4_t{0, 0, 0, 0}, acc1 = (pst < x0c) ? cacc1 : double4_t{0, 0, 0, 0};
@@ -566,13 +568,14 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             else {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = acc[q4] + acc1[q4];
+                mrem &= mrem - 1;
             }
         }
         { long long t_b = TICK(); t_mfma += t_b - t_a; t_a = t_b; }
         __syncthreads();
         { long long t_b = TICK(); t_sync2 += t_b - t_a; t_a = t_b; }
     }
-    if (b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
+    if (JAC && b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
     double gmax = 0, xsq = 0;
     if (JAC) {
     LSTAMP(5);
