@@ -1006,6 +1006,24 @@ __global__ __launch_bounds__(TR_T) void lw_tr_decide(LwTr a) {
 }
 }  // namespace
 
+// The blocked Cholesky of this file as a service to the other translation units (the pose graph's loop-closure block): S is (n + 1) x n, row-major, rows 0 .. n - 1 the
+// symmetric positive-definite matrix (lower triangle read, overwritten by L), row n the right-hand side; y (n) receives the solution. *info (device, zeroed by the caller)
+// is set to 1 when a pivot is not positive. Everything is enqueued on the handle's stream.
+int vilf_lw_chol_solve(vilf_handle *h, int n, double *S, double *y, int *info) {
+    if (n < 1 || (size_t)n * 8 > 48 * 1024) { h->err = "vilf_lw_chol_solve: dimension outside the supported range"; return VILF_ERR_UNSUPPORTED; }
+    for (int j0 = 0; j0 < n; j0 += CH_NB) {
+        const int nb = std::min(CH_NB, n - j0), below = n + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
+        if (j0 == 0) hipLaunchKernelGGL(lw_chol_panel, dim3(npanel), dim3(256), 0, h->stream, n, S, j0, info, (const int *)nullptr);
+        else {
+            const int nt = (n + 1 - j0 + 63) / 64;
+            hipLaunchKernelGGL(lw_chol_step, dim3(npanel + nt * (nt - 1) / 2), dim3(256), 0, h->stream, n, S, j0, npanel, info, (const int *)nullptr);
+        }
+    }
+    hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), (size_t)n * 8, h->stream, n, S, y, (const int *)nullptr);
+    HIPCHECK(h, hipGetLastError());
+    return VILF_OK;
+}
+
 // batch_slot0 != 0: the window is also resident as slot 0 of the 11-frame batch (vilf_batch_upload ran): use that slot's prior and write
 // the solved state back into the batch buffers (the marginalization reads them)
 int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot1) {

@@ -8,12 +8,11 @@
 //   pg_chain_factor  block Cholesky of the block-tridiagonal chain matrix (prior + odometry), one wave walking the K key frames
 //   pg_chain_solve   T^-1 applied to 1 + 6 L right-hand sides at once (the gradient and the 6 Jacobian rows of every loop edge), one
 //                    thread per column, columns interleaved so a wave's loads coalesce; the chain factors are broadcast loads
-//   pg_capacitance   the loop edges as a low-rank (6 L) update: C = I + U^T T^-1 U; dense Cholesky solve of C by rocSOLVER (potrf / potrs)
+//   pg_capacitance   the loop edges as a low-rank (6 L) update: C = I + U^T T^-1 U; dense Cholesky solve of C by the blocked MFMA Cholesky of vilf_lw.hip (vilf_lw_chol_solve)
 //   pg_update        delta = z - Y C^-1 U^T z, retract p <- p * Expmap(delta), max |delta|
 // The normal equations of a pose graph are block tridiagonal plus a few loop edges: the chain is factorised in O(K), the loops go
 // through the Woodbury identity — no general sparse solver, no fill-in, no iteration count that grows with the chain length.
 #include <hip/hip_runtime.h>
-#include <rocsolver/rocsolver.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -22,12 +21,10 @@
 #include "vilf_device.hpp"
 
 struct PgCtx {
-    rocblas_handle blas = nullptr;
     DBuf x, prior, edges, rec, adj_off, adj_item, loop_ij, D, E, C, F, g, Y, Cm, rhs, scal, info;
     void release() {
         DBuf *all[] = {&x, &prior, &edges, &rec, &adj_off, &adj_item, &loop_ij, &D, &E, &C, &F, &g, &Y, &Cm, &rhs, &scal, &info};
         for (DBuf *b : all) b->release();
-        if (blas) { rocblas_destroy_handle(blas); blas = nullptr; }
     }
 };
 void vilf_pg_release(vilf_handle *h) { if (h->pg) { h->pg->release(); delete h->pg; h->pg = nullptr; } }
@@ -338,11 +335,7 @@ extern "C" int vilf_posegraph_optimize(vilf_handle *h, int K, double *poses_qt, 
     if (!c->x.ensure(sK * 56) || !c->prior.ensure(7 * 8 + 6 * 8) || !c->edges.ensure(ed.size() * sizeof(PgEdgeDev)) || !c->rec.ensure((size_t)nF * PG_REC * 8) ||
         !c->adj_off.ensure((sK + 1) * 4) || !c->adj_item.ensure(std::max<size_t>(adj_item.size(), 1) * 4) || !c->loop_ij.ensure(std::max<size_t>(loop_ij.size(), 1) * 4) ||
         !c->D.ensure(sK * 288) || !c->E.ensure(sK * 288) || !c->C.ensure(sK * 288) || !c->F.ensure(sK * 288) || !c->g.ensure(sK * 48) || !c->Y.ensure(sK * 6 * NC * 8) ||
-        !c->Cm.ensure(std::max<size_t>((size_t)NL * NL, 1) * 8) || !c->rhs.ensure(std::max(NL, 1) * 8) || !c->scal.ensure(64) || !c->info.ensure(64)) { h->err = "hipMalloc failed (pose graph)"; return VILF_ERR_DEVICE; }
-    if (L > 0 && !c->blas) {
-        if (rocblas_create_handle(&c->blas) != rocblas_status_success) { h->err = "rocblas_create_handle failed"; return VILF_ERR_DEVICE; }
-        rocblas_set_stream(c->blas, h->stream);
-    }
+        !c->Cm.ensure(std::max<size_t>((size_t)(NL + 1) * NL, 1) * 8) || !c->rhs.ensure(std::max(NL, 1) * 8) || !c->scal.ensure(64) || !c->info.ensure(64)) { h->err = "hipMalloc failed (pose graph)"; return VILF_ERR_DEVICE; }
     double pr[13];
     std::memcpy(pr, poses_qt, 56); std::memcpy(pr + 7, prior_sigma, 48);
     HIPCHECK(h, hipMemcpyAsync(c->x.p, poses_qt, sK * 56, hipMemcpyHostToDevice, h->stream));
@@ -373,10 +366,10 @@ extern "C" int vilf_posegraph_optimize(vilf_handle *h, int K, double *poses_qt, 
         hipLaunchKernelGGL(pg_chain_solve, dim3((NC + 63) / 64), dim3(64), 0, h->stream, K, NC, c->C.as<double>(), c->F.as<double>(), Y);
         if (L > 0) {
             const size_t ne = (size_t)NL * (NL + 1);
-            hipLaunchKernelGGL(pg_capacitance, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, L, NC, d_lij, d_lf, rec, Y, c->Cm.as<double>(), c->rhs.as<double>());
-            rocblas_int *dinfo = c->info.as<rocblas_int>() + 4;
-            if (rocsolver_dpotrf(c->blas, rocblas_fill_lower, NL, c->Cm.as<double>(), NL, dinfo) != rocblas_status_success ||
-                rocsolver_dpotrs(c->blas, rocblas_fill_lower, NL, 1, c->Cm.as<double>(), NL, c->rhs.as<double>(), NL) != rocblas_status_success) { h->err = "rocsolver potrf / potrs failed"; return VILF_ERR_DEVICE; }
+            // the capacitance matrix (symmetric entry by entry) with its right-hand side as row NL, solved by the blocked Cholesky of vilf_lw.hip (no vendor solver)
+            hipLaunchKernelGGL(pg_capacitance, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, L, NC, d_lij, d_lf, rec, Y, c->Cm.as<double>(), c->Cm.as<double>() + (size_t)NL * NL);
+            const int rcs = vilf_lw_chol_solve(h, NL, c->Cm.as<double>(), c->rhs.as<double>(), c->info.as<int>() + 4);
+            if (rcs != VILF_OK) return rcs;
         }
         hipLaunchKernelGGL(pg_update, dim3((K + 63) / 64), dim3(64), 0, h->stream, K, NC, NL, Y, c->rhs.as<double>(), x, scal);
         HIPCHECK(h, hipGetLastError());
