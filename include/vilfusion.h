@@ -217,6 +217,12 @@ int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]);
 int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long launches_out[8]);
 /* same switch, marginalization kernels: 0 prepare (factor re-evaluation at the linearisation point), 1 Schur complement, 2 eigen + prior, 3 prior H/g */
 int vilf_get_profile_marginalize(vilf_handle *h, double ms_out[4], long launches_out[4]);
+/* Which form the last vilf_batch_marginalize() / vilf_window_marginalize() took per window. marginalization_factor.cpp:267-291 eigen-decomposes the dropped
+ * block Amm and the kept block with a 1e-8 truncation; where that truncation provably removes nothing (positive Cholesky pivots and trace(A^-1) < 1e8, i.e.
+ * lambda_min > 1e-8) the library uses Cholesky factors instead — same J0^T J0, J0^T r0, |r0|^2 — and falls back to the eigen-decompositions otherwise.
+ * counts[0] windows that produced a new prior; [1] of those: Amm by the arrow Cholesky; [2] of those: kept block by Cholesky (J0 = L^T, r0 = L^-1 b);
+ * [3] windows whose prior was left as it was. */
+int vilf_batch_marginalize_stats(vilf_handle *h, int counts[4]);
 /* the general (window_size != 10) path of vilf_window_solve: factor scatter (linearisations), Schur SYRK, Cholesky, unused */
 int vilf_get_profile_large_window(vilf_handle *h, double ms_out[4], long launches_out[4]);
 /* newest-frame pose per resident window: [stamp x y z qx qy qz qw] (8 doubles each) into a DEVICE buffer

@@ -406,7 +406,9 @@ def test_marginalization_eigen_solver_fallback(solver, oracle, opts, monkeypatch
     """the eigen-solver runs in three launches with a bounded rotation log; a window whose log overflows is redone by the
     single-workgroup kernel. Force that path (VILF_MARG_FORCE_QL_FALLBACK) and compare both with the oracle and with the split path."""
     wins, priors = synth.make_batch(77, 6, opts, synth.SynthConfig(n_features=120), distinct=6)
+    monkeypatch.setenv("VILF_MARG_NO_CHOL", "1")            # these well-conditioned windows would take the Cholesky form of the kept block otherwise
     solver.batch_upload(wins, priors); solver.batch_solve(); solver.batch_marginalize()
+    assert solver.marginalize_stats()["kept_cholesky"] == 0
     split = [_prior_products(solver.get_prior(i)) for i in range(6)]
     monkeypatch.setenv("VILF_MARG_FORCE_QL_FALLBACK", "1")
     solver.batch_upload(wins, priors); solver.batch_solve(); solver.batch_marginalize()
@@ -416,6 +418,44 @@ def test_marginalization_eigen_solver_fallback(solver, oracle, opts, monkeypatch
         Lr, br_, _ = _prior_products(pr)
         assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5
         assert np.abs(Lg - split[i][0]).max() / np.abs(Lr).max() < 1e-9        # same arithmetic in both paths up to FMA contraction of the replay
+
+
+def test_marginalization_kept_block_cholesky_form_and_its_guard(solver, oracle, opts, monkeypatch):
+    """marginalize() ends in an eigen-decomposition of the kept block with a 1e-8 truncation (marginalization_factor.cpp:283-291). Where nothing is truncated
+    (positive pivots and trace(A^-1) < 1e8 => lambda_min > 1e-8) the library writes J0 = L^T, r0 = L^-1 b from a Cholesky factorisation instead: same J0^T J0,
+    J0^T r0 and |r0|^2, which is all the next solve / marginalization sees of a prior. Both forms against the oracle and against each other, the path counters, and
+    the guard: windows without a prior leave the gauge (yaw + position) unobserved, their kept block is singular, and they must take the eigen-solver."""
+    wins, priors = synth.make_batch(91, 6, opts, synth.SynthConfig(n_features=120), distinct=6)
+    free, _ = synth.make_batch(92, 2, opts, synth.SynthConfig(n_features=120, with_prior=False), distinct=2)
+    wins = wins + free; priors = priors + [None, None]
+    out = {}
+    for tag in ("chol", "eig"):
+        if tag == "eig":
+            monkeypatch.setenv("VILF_MARG_NO_CHOL", "1")
+        solver.batch_upload(wins, priors); solver.batch_solve(); solver.batch_marginalize()
+        st = solver.marginalize_stats()
+        assert st["new_prior"] == 8 and st["kept_cholesky"] == (6 if tag == "chol" else 0), st
+        out[tag] = [solver.get_prior(i) for i in range(8)]
+    monkeypatch.delenv("VILF_MARG_NO_CHOL")
+    for i in range(8):
+        pr = oracle.window_marginalize(opts, wins[i], oracle.window_solve(opts, wins[i], priors[i]), priors[i])
+        Lr, br_, blr = _prior_products(pr)
+        J0r, r0r, _ = abi.prior_to_numpy(pr)
+        for tag in ("chol", "eig"):
+            pg = out[tag][i]
+            Lg, bg, blg = _prior_products(pg)
+            assert pg.n == pr.n and [b["id"] for b in blg] == [b["id"] for b in blr] and [b["idx"] for b in blg] == [b["idx"] for b in blr]
+            for a, b in zip(blg, blr):
+                assert np.allclose(a["x0"], b["x0"], atol=1e-9)
+            assert np.abs(Lg - Lr).max() / np.abs(Lr).max() < 2e-5 and np.abs(bg - br_).max() / np.abs(br_).max() < 2e-5, (tag, i)
+        if i < 6:
+            J0, r0, _ = abi.prior_to_numpy(out["chol"][i])
+            assert np.allclose(J0, np.triu(J0)) and (np.diag(J0) > 0).all(), "J0 = L^T is upper triangular"
+            assert abs(r0 @ r0 - r0r @ r0r) <= 1e-6 * (r0r @ r0r), "|r0|^2 = b^T A^-1 b in both forms"
+            Lc, bc, _ = _prior_products(out["chol"][i]); Le, be, _ = _prior_products(out["eig"][i])
+            assert np.abs(Lc - Le).max() / np.abs(Le).max() < 2e-5 and np.abs(bc - be).max() / np.abs(be).max() < 2e-5
+        else:
+            assert bytes(out["chol"][i]) == bytes(out["eig"][i]), "a window that fails the guard goes through the same eigen-solver in both runs"
 
 
 @pytest.mark.parametrize("n_frames,n_features,tol", [(21, 400, 1e-7), (51, 2500, 1e-6)])

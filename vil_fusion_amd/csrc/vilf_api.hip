@@ -32,6 +32,7 @@ __global__ void k_prior_keep(VbBatch b, VbMarg g);
 __global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
 __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged);
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
+__global__ void k_mf_chol(VbBatch b, VbMarg g, int n_lo, int n_hi, int disable);
 __global__ void k_mf_ql(VbBatch b, VbMarg g, int force_overflow);
 __global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
 #define VILF_MFA_LDS_EXTRA (4 * 64 * 8 + QL_ICAP * 2)      // k_mf_apply behind V: two staged chunks of the rotation log (MFA_CH = 64) + the 16-bit QL iteration table
@@ -153,6 +154,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
         hipFuncSetAttribute((const void *)k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_prior_prep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)VILF_PRIOR_PREP_LDS) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_mf_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->marg_lds_finish) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(h->marg_lds_finish + VILF_MFA_LDS_EXTRA)) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * QL_LPW * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
@@ -907,8 +909,15 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     }
     g.pool_round = 0;
     if (prof) mev[2] = vilf_prof_event(h);
+    // kept block: the Cholesky form of the new prior where the reference's 1e-8 truncation provably removes nothing (k_mf_chol; it marks the windows it has
+    // finished, the launches below skip those), otherwise the
     // eigen-solver of the kept block in three launches (tred2 per workgroup, the QL recurrence of every window one lane each, rotation replay +
     // prior output per workgroup); k_marg_finish (everything in one workgroup) only takes windows whose rotation log overflowed
+    {
+        const int no_chol = std::getenv("VILF_MARG_NO_CHOL") ? 1 : 0;         // test hook: the eigen-solver for every window
+        hipLaunchKernelGGL(k_mf_chol, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, no_chol);
+        hipLaunchKernelGGL(k_mf_chol, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, no_chol);
+    }
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
     hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
     hipLaunchKernelGGL(k_mf_ql, dim3((h->B + QL_LPW - 1) / QL_LPW), dim3(64), (size_t)2 * (MG_NK + 2) * QL_LPW * sizeof(double), h->stream, h->batch, g,
@@ -946,6 +955,27 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     return VILF_OK;
 }
 extern "C" int vilf_window_marginalize(vilf_handle *h) { return vilf_batch_marginalize(h, 1); }
+
+// which path every window of the last vilf_batch_marginalize took: counts[0] windows that produced a new prior; [1] of those, dropped block Amm by the arrow
+// Cholesky (the rest: Jacobi eigen-decomposition with the 1e-8 pseudo-inverse); [2] kept block by Cholesky (J0 = L^T; the rest: tred2 / tql2 eigen-solver);
+// [3] windows whose prior was left unchanged (SECOND_NEW without Pose[WINDOW_SIZE - 1] in it) or unsupported
+extern "C" int vilf_batch_marginalize_stats(vilf_handle *h, int counts[4]) {
+    if (!h || !counts || !h->resident || !h->marg.info || !h->marg.qlInfo) return VILF_ERR_INVALID_ARGUMENT;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const size_t sB = h->B;
+    std::vector<int> info(sB * MG_INFO), qi(sB * 4);
+    HIPCHECK(h, hipMemcpyAsync(info.data(), h->marg.info, info.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(qi.data(), h->marg.qlInfo, qi.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    counts[0] = counts[1] = counts[2] = counts[3] = 0;
+    for (size_t w = 0; w < sB; w++) {
+        if (info[w * MG_INFO] != 0) { counts[3]++; continue; }
+        counts[0]++;
+        if (info[w * MG_INFO + 7] == 0) counts[1]++;
+        if (qi[w * 4 + 3] == 1) counts[2]++;
+    }
+    return VILF_OK;
+}
 
 // ---- Ceres-layout hooks --------------------------------------------------------------------------------------
 static int hook_buf(vilf_handle *h, size_t doubles) { return h->d[D_HOOK].ensure(doubles * 8) ? VILF_OK : VILF_ERR_DEVICE; }

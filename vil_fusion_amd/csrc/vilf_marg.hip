@@ -1030,6 +1030,22 @@ __device__ void tred2_tql2(double *V, int n, int ld, double *d, double *e, doubl
     tql2_part(V, n, ld, d, e, s_cs, s_ctl);
 }
 
+// block table with the address shift + x0 = parameter_block_data (getParameterBlocks, :299-319) of the new prior of window w
+__device__ void mf_table(const VbBatch &b, const VbMarg &g, int w, int n, int nb, const int *info) {
+    const int tid = threadIdx.x;
+    int *hdr = g.prior_hdr_out + (size_t)w * VB_PRIOR_HDR;
+    if (tid == 0) { hdr[0] = 1; hdr[1] = n; hdr[2] = nb; hdr[75] = info[4]; }     // [75] = m (marginalized dimension, informative)
+    if (tid < 24) {
+        hdr[3 + tid] = tid < nb ? info[8 + tid] : 0; hdr[27 + tid] = tid < nb ? info[32 + tid] : 0; hdr[51 + tid] = tid < nb ? info[56 + tid] : 0;
+        if (tid < nb) {
+            const int id = info[80 + tid];
+            const double *x = id < VB_NF ? g.st_pose + (size_t)w * 77 + 7 * id : (id < 2 * VB_NF ? g.st_sb + (size_t)w * 99 + 9 * (id - VB_NF) : (id == 2 * VB_NF ? g.st_ex + (size_t)w * 7 : b.td + w));
+            double *x0 = g.prior_x0_out + ((size_t)w * 24 + tid) * 9;
+            const int size = info[32 + tid];
+            for (int k = 0; k < 9; k++) x0[k] = k < size ? x[k] : 0.0;
+        }
+    }
+}
 // launched twice: windows with n_lo <= n < n_hi only. The usual kept dimension (n <= 77) needs < 48 KB of LDS for its n x n matrix,
 // so three workgroups share a CU; the rare larger priors go through the second launch with the full-size allocation.
 // eigenvalues in s_lam, eigenvectors in the columns of V -> the new prior: J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b, block table, x0
@@ -1054,19 +1070,82 @@ __device__ void mf_tail(const VbBatch &b, const VbMarg &g, int w, const double *
         for (int k = 0; k < n; k++) s += V[k * N + tid] * s_br[k];
         ro[s_rank[tid]] = sqrt(Sinv) * s;
     }
-    // block table with the address shift + x0 = parameter_block_data (getParameterBlocks, :299-319)
-    int *hdr = g.prior_hdr_out + (size_t)w * VB_PRIOR_HDR;
-    if (tid == 0) { hdr[0] = 1; hdr[1] = n; hdr[2] = nb; hdr[75] = info[4]; }     // [75] = m (marginalized dimension, informative)
-    if (tid < 24) {
-        hdr[3 + tid] = tid < nb ? info[8 + tid] : 0; hdr[27 + tid] = tid < nb ? info[32 + tid] : 0; hdr[51 + tid] = tid < nb ? info[56 + tid] : 0;
-        if (tid < nb) {
-            const int id = info[80 + tid];
-            const double *x = id < VB_NF ? g.st_pose + (size_t)w * 77 + 7 * id : (id < 2 * VB_NF ? g.st_sb + (size_t)w * 99 + 9 * (id - VB_NF) : (id == 2 * VB_NF ? g.st_ex + (size_t)w * 7 : b.td + w));
-            double *x0 = g.prior_x0_out + ((size_t)w * 24 + tid) * 9;
-            const int size = info[32 + tid];
-            for (int k = 0; k < 9; k++) x0[k] = k < size ? x[k] : 0.0;
+    mf_table(b, g, w, n, nb, info);
+}
+
+// ---- kept block without an eigen-decomposition ------------------------------------------------------------------------------------
+// marginalize() ends with A = V S V^T, J0 = sqrt(S) V^T, r0 = S^-1/2 V^T b, eigenvalues below 1e-8 truncated (marginalization_factor.cpp:283-291).
+// Everything downstream of the prior — MarginalizationFactor::Evaluate's r0 + J0 dx inside a least-squares cost (:333-381), the next marginalization's
+// J^T J / J^T r — sees (J0, r0) only through J0^T J0, J0^T r0 and |r0|^2, which are invariant under an orthogonal transform of the rows. When NO eigenvalue is
+// truncated, J0^T J0 = A and J0^T r0 = b, so the Cholesky factor serves as well: A = L L^T, J0 = L^T, r0 = L^-1 b (|r0|^2 = b^T A^-1 b in both forms).
+// Guard: every pivot positive and trace(A^-1) = |L^-1|_F^2 < 1e8, which bounds the largest eigenvalue of A^-1, i.e. lambda_min(A) > 1e-8: the reference would
+// truncate nothing. A window that fails the guard (the gauge-deficient priors of a window chain that started without a prior: four eigenvalues at rounding level)
+// is left to the eigen-solver launches below (qlInfo[3] = 0).
+// One workgroup per window, everything in one n x N LDS array: the lower triangle becomes L column by column (right-looking); the strict upper triangle holds
+// X = L^-1 transposed (X[i][c] at V[c][i]), built by the fan-out form of the forward substitution IN THE SAME column loop: once column j of L is final, row j of X is
+// final too (X[j][c] /= L[j][j], X[j][j] = 1 / L[j][j]) and every later row takes X[i][c] -= L[i][j] X[j][c] (c <= j) beside the trailing update
+// A[i][c] -= L[i][j] L[c][j] (j < c <= i). Two barriers per column, no storage besides the matrix itself; the diagonal of L lives in s_dg (V[j][j] keeps the pivot).
+extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, int n_lo, int n_hi, int disable) {
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int *info = g.info + (size_t)w * MG_INFO;
+    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
+    int *qi = g.qlInfo + (size_t)w * 4;
+    if (disable) { if (tid == 0) qi[3] = 0; return; }          // test hook: every window through the eigen-solver
+    extern __shared__ double s_dyn[];
+    __shared__ double s_dg[MG_NK + 2], s_br[MG_NK + 2], s_red[NT / 64];
+    __shared__ int s_ok;
+    const int n = info[3], nb = info[5], N = n | 1;
+    double *V = s_dyn;
+    const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
+    for (int e = tid; e < n * n; e += NT) { const int i = e / n, j = e - n * i; V[i * N + j] = (j <= i) ? 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]) : 0.0; }
+    if (tid < n) s_br[tid] = br[tid];
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    const int tr = tid >> 2, tc = tid & 3;                       // rows j + 1 + tr (+ 64); every fourth element of a row's run
+    for (int j = 0; j < n; j++) {
+        // phase 1: column j of L and row j of X. Every thread takes the pivot from LDS itself (no broadcast phase).
+        const double d = V[j * N + j];
+        const double l = sqrt(d > 0.0 ? d : 1.0), linv = 1.0 / l;
+        if (tid < n) {
+            if (tid != j) V[tid * N + j] /= l;                   // tid > j: L[tid][j]; tid < j: X[j][tid] (stored transposed)
+            else { s_dg[j] = l; if (!(d > 0.0)) s_ok = 0; }
         }
+        __syncthreads();
+        if (!s_ok) break;                                        // uniform: written before the barrier, read by every thread after it
+        // phase 2: rows i > j; nothing here writes column j, which both loops read
+        for (int i = j + 1 + tr; i < n; i += 64) {
+            const double lij = V[i * N + j];
+            for (int c = tc; c < j; c += 4) V[c * N + i] -= lij * V[c * N + j];              // X[i][c] -= L[i][j] X[j][c]
+            for (int c = j + 1 + tc; c <= i; c += 4) V[i * N + c] -= lij * V[c * N + j];     // A[i][c] -= L[i][j] L[c][j]
+            if (tc == 0) V[j * N + i] -= lij * linv;                                          // X[i][j] -= L[i][j] X[j][j]
+        }
+        __syncthreads();
     }
+    if (!s_ok) { if (tid == 0) qi[3] = 0; return; }
+    // trace(A^-1) = |X|_F^2
+    double sq = 0.0;
+    for (int e = tid; e < n * n; e += NT) { const int c = e / n, i = e - n * c; if (i > c) { const double x = V[c * N + i]; sq += x * x; } }
+    if (tid < n) { const double x = 1.0 / s_dg[tid]; sq += x * x; }
+    sq = mg_wave_sum(sq);
+    if ((tid & 63) == 0) s_red[tid >> 6] = sq;
+    __syncthreads();
+    double trc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) trc += s_red[k];
+    if (!(trc < 1e8)) { if (tid == 0) qi[3] = 0; return; }
+    // the new prior: linearized_jacobians = L^T (leading dimension n), linearized_residuals = L^-1 b
+    double *Jo = g.prior_J_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *ro = g.prior_r_out + (size_t)w * VB_PRIOR_LD;
+    for (int e = tid; e < n * n; e += NT) {
+        const int i = e / n, k = e - n * i;
+        Jo[e] = k > i ? V[k * N + i] : (k == i ? s_dg[i] : 0.0);
+    }
+    if (tid < n) {
+        double s = s_br[tid] / s_dg[tid];
+        for (int c = 0; c < tid; c++) s += V[c * N + tid] * s_br[c];
+        ro[tid] = s;
+    }
+    mf_table(b, g, w, n, nb, info);
+    if (tid == 0) qi[3] = 1;
 }
 
 // ---- the eigen-solver split in three launches --------------------------------------------------------------------------------------
@@ -1078,7 +1157,7 @@ __device__ void mf_tail(const VbBatch &b, const VbMarg &g, int w, const double *
 extern "C" __global__ __launch_bounds__(NT) void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *info = g.info + (size_t)w * MG_INFO;
-    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
+    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi || g.qlInfo[(size_t)w * 4 + 3]) return;
     extern __shared__ double s_dyn[];
     __shared__ double s_lam[MG_NK + 2], s_e[MG_NK + 2], s_sc[4];
     const int n = info[3], N = n | 1;
@@ -1101,7 +1180,7 @@ extern "C" __global__ __launch_bounds__(64) void k_mf_ql(VbBatch b, VbMarg g, in
     const int *info = g.info + (size_t)w * MG_INFO;
     int *qi = g.qlInfo + (size_t)w * 4;
     qi[0] = 0; qi[1] = 0; qi[2] = 0;
-    if (info[0] != 0) return;
+    if (info[0] != 0 || qi[3]) return;
     const int n = info[3];
     double *d = s_de + lane, *e = s_de + (MG_NK + 2) * QL_LPW + lane;      // element i at [QL_LPW * i]: 6 KB of LDS per wave, several waves per CU
     double *dg = g.qlD + (size_t)w * 2 * (MG_NK + 2);
@@ -1190,7 +1269,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_apply(VbBatch b, VbMarg g,
     const int *info = g.info + (size_t)w * MG_INFO;
     if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
     const int *qi = g.qlInfo + (size_t)w * 4;
-    if (qi[2]) return;                                                      // log overflow: k_marg_finish redoes this window
+    if (qi[2] || qi[3]) return;                                             // log overflow: k_marg_finish redoes this window; [3]: k_mf_chol has written this prior
     extern __shared__ double s_dyn[];
     __shared__ double s_lam[MG_NK + 2], s_br[MG_NK + 2];
     __shared__ int s_rank[MG_NK + 2];
@@ -1258,7 +1337,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_finish(VbBatch b, VbMarg
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *info = g.info + (size_t)w * MG_INFO;
     if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
-    if (only_flagged && !g.qlInfo[(size_t)w * 4 + 2]) return;
+    if (g.qlInfo[(size_t)w * 4 + 3] || (only_flagged && !g.qlInfo[(size_t)w * 4 + 2])) return;
     extern __shared__ double s_dyn[];
     __shared__ double s_cs[2 * (MG_NK + 2)], s_lam[MG_NK + 2], s_e[MG_NK + 2], s_br[MG_NK + 2], s_sc[4];
     __shared__ int s_rank[MG_NK + 2], s_ctl[2];

@@ -119,6 +119,12 @@ class BackendSolver:
         self._check(self._L.vilf_get_profile_large_window(self._h, ms, n), "vilf_get_profile_large_window")
         return {k: dict(ms=ms[i], launches=n[i]) for i, k in enumerate(("lw_factor_scatter", "lw_schur_syrk", "lw_cholesky", "lw_other"))}
 
+    def marginalize_stats(self):
+        """paths of the last marginalization: windows with a new prior, of those Amm by Cholesky, of those the kept block by Cholesky, windows left unchanged"""
+        c = (C.c_int * 4)()
+        self._check(self._L.vilf_batch_marginalize_stats(self._h, c), "vilf_batch_marginalize_stats")
+        return dict(new_prior=c[0], amm_cholesky=c[1], kept_cholesky=c[2], unchanged=c[3])
+
     def batch_marginalize(self, sync=True):
         self._check(self._L.vilf_batch_marginalize(self._h, 1 if sync else 0), "vilf_batch_marginalize")
 
