@@ -244,10 +244,12 @@ def main():
         lidar_cases = [(warm.getMapCloud(k, 0), warm.getMapCloud(k, 1), raw[k][2][1], np.array(wres[k].pose_qt[:]), raw[k]) for k in range(D)]
         s2m = Scan2MapBatch(lidar_handle, B, max(len(c[2][0]) for c in lidar_cases) + 64, max(len(c[2][1]) for c in lidar_cases) + 64,
                             max(len(c[0]) + len(c[2][0]) for c in lidar_cases) + 64, max(len(c[1]) + len(c[2][1]) for c in lidar_cases) + 64)
-        for i in range(B):
-            me, ms, (se, ss), pose1, _ = lidar_cases[i % D]
+        for i in range(min(B, D)):
+            me, ms, (se, ss), pose1, _ = lidar_cases[i]
             s2m.localMapInited(i, me, ms, pose1, ident)    # globalOdom = pose after frame 1, globalOdom_last = pose 0
             s2m.set_scan(i, se, ss)
+        for i in range(D, B):
+            s2m.copy_stream(i % D, i)                      # replicas of the distinct streams, copied on the device
         s2m.snapshot()
     poses = torch.zeros((B, 8), dtype=torch.float64, device="cuda")
     stamps = np.arange(B, dtype=np.float64)

@@ -346,6 +346,8 @@ int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float *edge_xyzi,
                              const double *pose_qt, const double *pose_last_qt);
 /* the scan the next vilf_scan2map_batch_step consumes for this stream (stays resident in HBM until replaced) */
 int vilf_scan2map_batch_set_scan(vilf_handle *h, int stream, const float *edge_xyzi, int n_edge, const float *surf_xyzi, int n_surf);
+/* stream dst := stream src (local maps, poses, resident scan) by device copies: replicas of a few distinct streams without one upload per stream */
+int vilf_scan2map_batch_copy_stream(vilf_handle *h, int src, int dst);
 int vilf_scan2map_batch_step(vilf_handle *h, int sync);                 /* optimation_processing (:235) for every stream */
 int vilf_scan2map_batch_snapshot(vilf_handle *h);                       /* remember maps + poses ... */
 int vilf_scan2map_batch_rewind(vilf_handle *h);                         /* ... and restore them (bench loop: repeated identical steps) */

@@ -273,3 +273,44 @@ def test_voxel_index_overflow_fails_loudly(oracle):
         b.step()
         b.results()
     s.close()
+
+
+@pytest.mark.gpu
+def test_local_map_orders_uploads_and_stream_copies(oracle, opts):
+    """The device keeps a local map in cell-major leaf order (its own neighbour index); the outside sees pcl::VoxelGrid's order. (i) a raw cloud handed to
+    localMapInited comes back from getMapCloud as given; (ii) a map that getMapCloud handed out (a voxel grid in PCL order) can be uploaded again — it is stored in
+    cell-major order, comes back unchanged, and the next steps of that stream equal the steps of the stream it was taken from, bit for bit, and the oracle;
+    (iii) a stream copied on the device is a replica; (iv) every maintained map is in ascending PCL leaf order with one point per leaf."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
+    scans, _ = synth.make_lidar_sequence(31, 6, rings=32, azimuths=900)
+    s = BackendSolver(opts)
+    b = Scan2MapBatch(s, 3, 2048, 8192, 8192, 32768)
+    b.localMapInited(0, *scans[0])
+    for which in (0, 1):
+        assert np.array_equal(b.getMapCloud(0, which), scans[0][which]), "a raw cloud is not re-ordered"
+    ref = oracle.OracleS2M(opts); ref.init(*scans[0])
+    poses = []
+    for f in (1, 2):
+        b.set_scan(0, *scans[f]); b.step(); ref.step(*scans[f])
+        poses.append(np.array(b.results(0, 1)[0].pose_qt[:]))
+    maps = [b.getMapCloud(0, which) for which in (0, 1)]
+    for which, leaf in ((0, np.float32(opts.edge_leaf_size)), (1, np.float32(opts.surf_leaf_size))):
+        assert np.array_equal(maps[which], ref.get_map(which))
+        ijk = np.floor(maps[which][:, :3] * (np.float32(1.0) / leaf)).astype(np.int64)
+        assert np.all(np.diff(ijk[:, 2] * (1 << 42) + ijk[:, 1] * (1 << 21) + ijk[:, 0]) > 0), "ascending PCL leaf order, one point per leaf"
+    b.localMapInited(1, maps[0], maps[1], poses[1], poses[0])     # globalOdom = the pose after frame 2, globalOdom_last = after frame 1
+    b.copy_stream(0, 2)
+    for which in (0, 1):
+        assert np.array_equal(b.getMapCloud(1, which), maps[which]) and np.array_equal(b.getMapCloud(2, which), maps[which])
+    for f in (3, 4, 5):
+        for i in range(3):
+            b.set_scan(i, *scans[f])
+        b.step()
+        got = b.results(); o = ref.step(*scans[f])
+        assert bytes(got[0]) == bytes(got[2]), "a device copy of a stream is a replica"
+        assert bytes(got[0]) == bytes(got[1]), "an uploaded voxel grid behaves like the map it was downloaded from"
+        assert list(got[0].n_edge_factors) == list(o.n_edge_factors) and list(got[0].n_surf_factors) == list(o.n_surf_factors) and list(got[0].iterations) == list(o.iterations)
+        assert np.abs(np.array(got[0].pose_qt[:]) - np.array(o.pose_qt[:])).max() < 1e-9
+    for which in (0, 1):
+        assert np.array_equal(b.getMapCloud(2, which), ref.get_map(which)) and np.array_equal(b.getMapCloud(1, which), ref.get_map(which))
+    s.close()

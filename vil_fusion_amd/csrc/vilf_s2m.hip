@@ -21,6 +21,9 @@
 #include <cstring>
 #include <string.h>
 #include <cmath>
+#include <climits>
+#include <algorithm>
+#include <utility>
 #include <rocprim/rocprim.hpp>
 #include "vilf_internal.hpp"
 #include "vilf_device.hpp"
@@ -52,7 +55,7 @@ using namespace vd;
 // Sorts are ONE rocPRIM radix sort over all segments with the stream id in the high key bits; padding entries carry the largest
 // key of their stream and stay at the end of their own segment.
 struct CSet { float4 *p; int *n; int cap; };
-struct MinMax { float mn[3], mx[3]; int minb[3]; int pad_; long long mul1, mul2; };
+struct MinMax { float mn[3], mx[3]; int minb[3]; int pad_; long long mul1, mul2; int divb[3]; int pad2_; };
 struct S2BRes {                       // per-stream result of one step (device)
     double pose[7], prev[7];
     double cost[2];
@@ -66,7 +69,7 @@ struct S2BRes {                       // per-stream result of one step (device)
 #define S2B_ERR_VOXEL 4
 
 __device__ __forceinline__ int bits_of(long long v) { return v <= 0 ? 0 : 64 - __clzll(v); }
-// bits[0]: width of the largest leaf index (+1) over all streams; bits[1..3]: widths of the 1 m cell extents (inv == 1)
+// bits[0]: width of the largest leaf index (+1) over all streams; bits[1..3]: widths of the per-axis leaf extents; bits[4..6]: the largest per-axis leaf extents
 __global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
     __shared__ float s[6][1024];
     const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
@@ -90,16 +93,19 @@ __global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
             out->mn[k] = s[k][0]; out->mx[k] = s[3 + k][0];
             out->minb[k] = (int)floorf(__fmul_rn(s[k][0], inv));
             divb[k] = (int)floorf(__fmul_rn(s[3 + k][0], inv)) - out->minb[k] + 1;
+            out->divb[k] = divb[k];
         }
         out->mul1 = divb[0]; out->mul2 = (long long)divb[0] * divb[1];
         if (n > 0) {
             atomicMax(bits, bits_of((long long)divb[0] * divb[1] * divb[2]));
-            for (int k = 0; k < 3; k++) atomicMax(bits + 1 + k, bits_of(divb[k]));
+            for (int k = 0; k < 3; k++) { atomicMax(bits + 1 + k, bits_of(divb[k])); atomicMax(bits + 4 + k, divb[k]); }     // [4..6]: the largest leaf extents (cell-major keys, cell size of an unordered map)
         }
     }
 }
+// cs < 0: pcl::VoxelGrid's leaf index x + y dx + z dx dy relative to the cloud's min corner; cs >= 0: the cell-major order of the local maps (mu_leaf: cy | cx | z |
+// y_low | x_low with cells of 2^cs x 2^cs leaf columns on the ABSOLUTE leaf grid), made narrow the same way: cell coordinates relative to the cloud's first cell
 template <typename KeyT>
-__global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, KeyT *keys, int *vals, int *err, int vbits) {
+__global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, KeyT *keys, int *vals, int *err, int vbits, int cs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
     if (i >= in.cap) return;
     const size_t g = (size_t)sid * in.cap + i;
@@ -108,7 +114,14 @@ __global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, KeyT *keys, i
         const float4 q = in.p[g];
         const MinMax *m = mm + sid;
         const long long a = (long long)floorf(__fmul_rn(q.x, inv)) - m->minb[0], b = (long long)floorf(__fmul_rn(q.y, inv)) - m->minb[1], c = (long long)floorf(__fmul_rn(q.z, inv)) - m->minb[2];
-        k = (unsigned long long)(a + b * m->mul1 + c * m->mul2);
+        if (cs < 0) k = (unsigned long long)(a + b * m->mul1 + c * m->mul2);
+        else {
+            const long long ixa = a + m->minb[0], iya = b + m->minb[1], lm = (1LL << cs) - 1;
+            const long long cminx = (long long)m->minb[0] >> cs, cminy = (long long)m->minb[1] >> cs;
+            const long long ncx = (((long long)m->minb[0] + m->divb[0] - 1) >> cs) - cminx + 1;
+            const long long cell = ((iya >> cs) - cminy) * ncx + ((ixa >> cs) - cminx);
+            k = (unsigned long long)((((cell * m->divb[2] + c) << cs | (iya & lm)) << cs) | (ixa & lm));
+        }
     }
     keys[g] = (KeyT)(((unsigned long long)sid << vbits) | k);
     vals[g] = i;
@@ -485,14 +498,22 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
 #define MU_TILE (MU_T * MU_E)
 #define MU_LDS_TAIL 8192
 #define S2B_ERR_ORDER 8
+// The local maps are kept in CELL-MAJOR leaf order: the absolute leaf coordinates (ix, iy, iz), AXB bits each, are packed as
+//     cy | cx | iz | iy_low | ix_low        with cx = ix >> cs, cy = iy >> cs (a cell = 2^cs x 2^cs leaf columns, all z), *_low = the cs low bits
+// — a permutation of the bits of pcl::VoxelGrid's index order z | y | x. Points of one leaf share a key under both orders, so the voxel grid (merge runs of equal
+// keys, old points first, then the new ones in scan order) is the same computation; what the permutation buys is that every cell's points are contiguous, and
+// the cells of a row (cy) follow each other in x: the map IS its own neighbour index, a directory of cell starts (b_dir_build) is all the 5-NN needs, and the
+// per-frame re-sort of the whole map into a bucket-sorted copy is gone. PCL's order is what the outside sees: vilf_scan2map_get_map sorts the copy it hands out
+// (s2b_get_map), and the 5-NN breaks exact distance ties by the PCL key (b_associate_ties).
 template <int AXB>
-__device__ __forceinline__ bool mu_leaf(const float4 q, float inv, unsigned long long &k) {
+__device__ __forceinline__ bool mu_leaf(const float4 q, float inv, int cs, unsigned long long &k) {
     const float fx = floorf(__fmul_rn(q.x, inv)), fy = floorf(__fmul_rn(q.y, inv)), fz = floorf(__fmul_rn(q.z, inv));
     const float lim = (float)(1 << (AXB - 1));
     const bool ok = fx >= -lim && fx < lim - 1.0f && fy >= -lim && fy < lim - 1.0f && fz >= -lim && fz < lim - 1.0f;   // false for NaN
     const int off = 1 << (AXB - 1);
     const unsigned long long ix = (unsigned long long)((int)fx + off), iy = (unsigned long long)((int)fy + off), iz = (unsigned long long)((int)fz + off);
-    k = ok ? ((iz << (2 * AXB)) | (iy << AXB) | ix) : 0ULL;
+    const unsigned long long lm = (1ULL << cs) - 1ULL;
+    k = ok ? (((iy >> cs) << (2 * AXB + cs)) | ((ix >> cs) << (AXB + 2 * cs)) | (iz << (2 * cs)) | ((iy & lm) << cs) | (ix & lm)) : 0ULL;
     return ok;
 }
 struct MuBox { float mnx, mny, mnz, mxx, mxy, mxz; };
@@ -509,13 +530,13 @@ __device__ __forceinline__ float4 mu_centroid(const float4 *ts, int a, int e) {
 // sweep and handled afterwards, one per lane, from global memory — their dependent loads never sit on the sweep's critical path.
 template <int AXB, int IDXB>
 __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool between, int jlo, int nOld, const float4 *p, float4 *o, const float4 *ts, const unsigned long long *T,
-                                        int ntv, int THtot, float inv, const MuBox &box) {
+                                        int ntv, int THtot, float inv, int cs, const MuBox &box) {
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
     auto lower = [&](unsigned long long k) { int lo = 0, hi = ntv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T[mid] >> IDXB) < k) lo = mid + 1; else hi = mid; } return lo; };
     auto thp = [&](int j) { return j < ntv ? (int)(T[j] & LOW) : THtot; };
     const float4 q = p[i], qp = p[max(i - 1, 0)];
     unsigned long long key, kp;
-    mu_leaf<AXB>(q, inv, key); mu_leaf<AXB>(qp, inv, kp);
+    mu_leaf<AXB>(q, inv, cs, key); mu_leaf<AXB>(qp, inv, cs, kp);
     const bool sv = mu_inside(q, box), hasp = i > 0, first = !hasp || kp != key;
     int jup = jlo;                                           // jlo = lower(key): found by the sweep, handed over through the queue
     while (jup < ntv && (T[jup] >> IDXB) == key) jup++;
@@ -531,21 +552,21 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool bet
         }
         if (tm && !sv) {                                     // the tail has this leaf; the old run may have no survivor at all -> a new leaf
             bool any = false;
-            for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, kr); if (kr != key) break; if (mu_inside(r, box)) { any = true; break; } }
+            for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, cs, kr); if (kr != key) break; if (mu_inside(r, box)) { any = true; break; } }
             if (!any) o[H + thp(jlo) - M] = mu_centroid(ts, jlo, jup);
         }
     }
     if (head) {
         float4 s = make_float4(__fadd_rn(0.0f, q.x), __fadd_rn(0.0f, q.y), __fadd_rn(0.0f, q.z), __fadd_rn(0.0f, q.w));
         int cnt = 1;
-        for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, kr); if (kr != key) break; if (mu_inside(r, box)) { mu_acc(s, r); cnt++; } }
+        for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, cs, kr); if (kr != key) break; if (mu_inside(r, box)) { mu_acc(s, r); cnt++; } }
         for (int jj = jlo; jj < jup; jj++) { mu_acc(s, ts[jj]); cnt++; }
         const float nn = (float)cnt;
         o[H + thp(jlo) - M] = make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn);
     }
 }
 template <bool BIG>
-__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, CSet out, float4 *ts_all, int ts_stride,
+__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, int cs, CSet out, float4 *ts_all, int ts_stride,
                                                        unsigned long long *gT_all, int gT_stride, int lds_lo, int lds_cap, int *gq_all, size_t gq_stride, int *err) {
     constexpr int AXB = BIG ? 16 : 17, IDXB = BIG ? 16 : 13;
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
@@ -575,7 +596,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         if (j < nt) {
             const float4 q = p[nOld + j];
             unsigned long long k;
-            if (mu_inside(q, box)) { if (mu_leaf<AXB>(q, inv, k)) { w = (k << IDXB) | (unsigned long long)j; myvalid++; } else bad |= S2B_ERR_VOXEL; }
+            if (mu_inside(q, box)) { if (mu_leaf<AXB>(q, inv, cs, k)) { w = (k << IDXB) | (unsigned long long)j; myvalid++; } else bad |= S2B_ERR_VOXEL; }
         }
         T[j] = w;
     }
@@ -665,12 +686,12 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         for (int u = 0; u < MU_E; u++) {
             const int i = t0 + u * MU_T + tid;
             const bool valid = i < nOld;
-            if (!mu_leaf<AXB>(q[u], inv, key[u]) && valid) bad |= S2B_ERR_VOXEL;
+            if (!mu_leaf<AXB>(q[u], inv, cs, key[u]) && valid) bad |= S2B_ERR_VOXEL;
             const bool sv = valid && mu_inside(q[u], box);
             s_key[u * MU_T + tid] = valid ? (key[u] | (sv ? SVB : 0ULL)) : ~0ULL;
             if (sv) hm |= 1u << u;
         }
-        if (tid == 0) { unsigned long long kx; mu_leaf<AXB>(qn[0], inv, kx); s_nk = kx; }
+        if (tid == 0) { unsigned long long kx; mu_leaf<AXB>(qn[0], inv, cs, kx); s_nk = kx; }
         S2M_ACC(1);
         __syncthreads();
         S2M_ACC(2);
@@ -688,7 +709,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             if (valid && hasn && kn == key[u]) cm |= 1u << u;       // the leaf continues: summed by mu_rare
             if (((hm >> u) & 1) && hasp && kp == key[u]) {          // an earlier survivor of the same leaf owns it (rare: rounding put two centroids in one leaf)
                 bool mine = !(wp & SVB);
-                if (mine) for (int b = i - 2; b >= 0; b--) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, kr); if (kr != key[u]) break; if (mu_inside(r, box)) { mine = false; break; } }
+                if (mine) for (int b = i - 2; b >= 0; b--) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, cs, kr); if (kr != key[u]) break; if (mu_inside(r, box)) { mine = false; break; } }
                 if (!mine) hm &= ~(1u << u);
             }
         }
@@ -766,14 +787,14 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         const int qn = s_qn;
         for (int k = tid; k < qn; k += MU_T) {
             const int4 e = reinterpret_cast<const int4 *>(gq)[k];
-            mu_rare<AXB, IDXB>(e.x & 0x1fffffff, e.y, e.z, (e.x >> 30) & 1, (e.x >> 29) & 1, e.w, nOld, p, o, ts, T, ntv, THtot, inv, box);
+            mu_rare<AXB, IDXB>(e.x & 0x1fffffff, e.y, e.z, (e.x >> 30) & 1, (e.x >> 29) & 1, e.w, nOld, p, o, ts, T, ntv, THtot, inv, cs, box);
         }
     }
     __syncthreads();
     S2M_STAMP(skid, 3, true);
     // ---- tail leaves beyond the last old key (all of them when there is no old map)
     int jlast = 0;
-    if (nOld > 0) { unsigned long long kl; mu_leaf<AXB>(p[nOld - 1], inv, kl); jlast = lower(kl + 1); }
+    if (nOld > 0) { unsigned long long kl; mu_leaf<AXB>(p[nOld - 1], inv, cs, kl); jlast = lower(kl + 1); }
     for (int jj = jlast + tid; jj < ntv; jj += MU_T) {
         const unsigned long long lf = T[jj] >> IDXB;
         if (jj > jlast && (T[jj - 1] >> IDXB) == lf) continue;
@@ -789,267 +810,164 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     if (bad) atomicOr(err + sid, bad);
 }
 // the old maps of every stream are in non-decreasing leaf order with leaf coordinates inside the AXB-bit range? flag[0] |= 1 if not
-__global__ void b_check_order(CSet map, float inv, int axb, int *flag) {
+__global__ void b_check_order(CSet map, float inv, int cs, int axb, int *flag) {
     const int sid = blockIdx.y, n = map.n[sid];
     const float4 *p = map.p + (size_t)sid * map.cap;
     bool bad = false;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         unsigned long long k, kp = 0;
-        const bool ok = axb == 16 ? mu_leaf<16>(p[i], inv, k) : mu_leaf<17>(p[i], inv, k);
-        if (i > 0) { if (axb == 16) mu_leaf<16>(p[i - 1], inv, kp); else mu_leaf<17>(p[i - 1], inv, kp); }
+        const bool ok = axb == 16 ? mu_leaf<16>(p[i], inv, cs, k) : mu_leaf<17>(p[i], inv, cs, k);
+        if (i > 0) { if (axb == 16) mu_leaf<16>(p[i - 1], inv, cs, kp); else mu_leaf<17>(p[i - 1], inv, cs, kp); }
         if (!ok || kp > k) bad = true;
     }
     if (bad) atomicOr(flag, 1);
 }
 
 // ---- radix-hashed voxel neighbour index -----------------------------------------------------------------------------------
-// A map point hashes to a bucket by the low 8 bits of its 1 m cell coordinates in x and y: bucket = (iy & 255) << 8 | (ix & 255)
-// (a 16-bit radix digit; cells 256 m apart alias, z is not part of the key). The index is a single-pass counting (radix) sort of
-// the stream's points by that digit (count -> exclusive scan -> scatter), done by one workgroup per stream in LDS. A query scans the 3 x 3 buckets around its
-// own cell; every map point within 1 m lies in one of them (aliased far points are rejected by their true distance), so the
-// 5-NN is exact whenever the 5th squared distance is < 1 — the only case the reference uses (EstimationMapping.hpp:129,189).
-// The order inside a bucket is irrelevant: candidates are ranked by (squared distance, original map index).
-#define S2B_NB 65536
-#define S2B_NBS (S2B_NB + 4)      // row stride of start[] (keeps int4 accesses aligned)
-// x-minor: the map is in leaf order (z | y | x, x fastest), so consecutive input points of a voxel row fall into the same or the next bucket and their
-// scattered 16-byte stores land next to each other — the lines of the bucket-sorted copy fill up in L2 instead of leaving it as partial writes
-// (y-minor, which spares the LDS counters a few same-address atomics, spent 2/3 of the kernel in the scatter pass).
-__device__ __forceinline__ int bucket_of(int ix, int iy) { return ((iy & 255) << 8) | (ix & 255); }
-// ONE workgroup per stream builds the whole index: 16-bit bucket counters packed two per LDS word (128 KB), LDS atomics return
-// the arrival rank of a point inside its bucket, the workgroup scans the 65536 counts itself and scatters the points to
-// start[bucket] + rank. No global atomics, no separate scan / memset launches.
-#define S2B_IT 1024
-#define S2B_HW(w) ((w) + ((w) >> 5))     // LDS word index with one pad word per 32: a thread's 32 consecutive words and its neighbours' stay on different banks
-#define S2B_HWORDS (S2B_NB / 2 + S2B_NB / 64)
-#define S2B_FL 4
-#define S2B_MAXR 28          // rounds (of S2B_FL x 1024 points) whose ranks b_bucket_index keeps in registers
-__global__ __launch_bounds__(S2B_IT) void b_bucket_index(CSet map, int *bkt_all, int *start_all, float4 *sorted_all, int *err) {
-    extern __shared__ unsigned int s_hist[];          // [S2B_HWORDS] two 16-bit counters per word (padded), then s_base[1024]
-    __shared__ int s_w[S2B_IT / 64], s_total, s_big;
-    int *s_base = reinterpret_cast<int *>(s_hist + S2B_HWORDS);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
-    const int n = map.n[sid];
-    const size_t base = (size_t)sid * map.cap;
-    const float4 *p = map.p + base;
-    unsigned short *rk = reinterpret_cast<unsigned short *>(bkt_all) + base;      // arrival rank of every point inside its bucket
-    int *start = start_all + (size_t)sid * S2B_NBS;
-    float4 *sorted = sorted_all + base;
-    [[maybe_unused]] const int skid = n > 45000 ? 2 : 3;
-    S2M_STAMP(skid, 0, true);
-    for (int i = tid; i < S2B_HWORDS; i += S2B_IT) s_hist[i] = 0;
-    if (tid == 0) s_big = 0;
-    __syncthreads();
-    bool over = false;
-    S2M_STAMP(skid, 1, true);
-    // The arrival rank of a point inside its bucket (count pass) is what the scatter pass needs again: a lane meets the same points in both passes, so the ranks stay in
-    // its registers, two 16-bit ranks per register, the rounds fully unrolled (up to S2B_MAXR rounds = 114 k points; larger maps keep them in global memory as before:
-    // 4 bytes of HBM traffic per point, in a kernel that is bound by that traffic).
-    unsigned int rreg[2 * S2B_MAXR];
-    const bool regrk = n <= S2B_MAXR * S2B_FL * S2B_IT;
-    if (regrk) {
-        float2 cur[S2B_FL], nxt[S2B_FL];
-#pragma unroll
-        for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(tid + u * S2B_IT, max(n - 1, 0)); cur[u] = make_float2(pp->x, pp->y); }
-#pragma unroll
-        for (int r = 0; r < S2B_MAXR; r++) {
-            const int i0 = tid + r * S2B_FL * S2B_IT;
-            rreg[2 * r] = 0; rreg[2 * r + 1] = 0;
-            if (i0 >= n) break;
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(i0 + (S2B_FL + u) * S2B_IT, n - 1); nxt[u] = make_float2(pp->x, pp->y); }
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) {
-                const int i = i0 + u * S2B_IT;
-                if (i >= n) continue;
-                const int b = bucket_of((int)floorf(cur[u].x), (int)floorf(cur[u].y));
-                const int sh = 16 * (b & 1);
-                const unsigned int old = atomicAdd(&s_hist[S2B_HW(b >> 1)], 1u << sh);
-                const unsigned int rank = (old >> sh) & 0xffffu;
-                if (rank == 0xffffu) over = true;          // the 65536th point of a bucket would carry into its neighbour
-                rreg[2 * r + (u >> 1)] |= rank << (16 * (u & 1));
-            }
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) cur[u] = nxt[u];
-        }
-    } else
-    {   // S2B_FL points per lane and round, the next round's loads in flight while this round's LDS atomics run (a round that issues its loads only after the last one's
-        // atomics pays the memory latency once per round: 15 rounds of a 59 k-point map)
-        float2 cur[S2B_FL], nxt[S2B_FL];
-#pragma unroll
-        for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(tid + u * S2B_IT, max(n - 1, 0)); cur[u] = make_float2(pp->x, pp->y); }
-        for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) { const float4 *pp = p + min(i0 + (S2B_FL + u) * S2B_IT, n - 1); nxt[u] = make_float2(pp->x, pp->y); }
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) {
-                const int i = i0 + u * S2B_IT;
-                if (i >= n) continue;
-                const int b = bucket_of((int)floorf(cur[u].x), (int)floorf(cur[u].y));
-                const int sh = 16 * (b & 1);
-                const unsigned int old = atomicAdd(&s_hist[S2B_HW(b >> 1)], 1u << sh);
-                const unsigned int rank = (old >> sh) & 0xffffu;
-                if (rank == 0xffffu) over = true;          // the 65536th point of a bucket would carry into its neighbour
-                rk[i] = (unsigned short)rank;
-            }
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) cur[u] = nxt[u];
-        }
-    }
-    if (over) atomicOr(err + sid, S2B_ERR_EXTENT);
-    S2M_STAMP(skid, 2, true);
-    __syncthreads();
-    S2M_STAMP(skid, 3, true);
-    // exclusive scan: thread t owns buckets [64 t, 64 t + 64) = words [32 t, 32 t + 32) (padded position 33 t + k)
-    int local = 0;
-    for (int k = 0; k < 32; k++) { const unsigned int w = s_hist[33 * tid + k]; local += (int)(w & 0xffffu) + (int)(w >> 16); }
-    int incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
-    if (lane == 63) s_w[wave] = incl;
-    if (local > 0xffff) s_big = 1;                    // a 64-bucket group beyond 16 bits: the scatter pass reads the 32-bit starts from global memory
-    __syncthreads();
-    int off = incl - local;
-    for (int k = 0; k < wave; k++) off += s_w[k];
-    if (tid == S2B_IT - 1) s_total = off + local;
-    s_base[tid] = off;
-    int run = 0;                                       // the counters become exclusive prefixes inside the thread's group (16 bits each)
-    for (int k = 0; k < 32; k += 2) {
-        const unsigned int w0 = s_hist[33 * tid + k], w1 = s_hist[33 * tid + k + 1];
-        const int c0 = (int)(w0 & 0xffffu), c1 = (int)(w0 >> 16), c2 = (int)(w1 & 0xffffu), c3 = (int)(w1 >> 16);
-        int4 o4;
-        o4.x = off + run; o4.y = o4.x + c0; o4.z = o4.y + c1; o4.w = o4.z + c2;
-        *reinterpret_cast<int4 *>(start + 64 * tid + 2 * k) = o4;
-        s_hist[33 * tid + k] = (unsigned int)(run & 0xffff) | ((unsigned int)((run + c0) & 0xffff) << 16);
-        s_hist[33 * tid + k + 1] = (unsigned int)((run + c0 + c1) & 0xffff) | ((unsigned int)((run + c0 + c1 + c2) & 0xffff) << 16);
-        run += c0 + c1 + c2 + c3;
-    }
-    __syncthreads();
-    if (tid == 0) start[S2B_NB] = s_total;
-    const bool big = s_big != 0;
-    __threadfence_block();
-    __syncthreads();
-    S2M_STAMP(skid, 4, true);
-    if (regrk) {
-        const float4 *__restrict__ pr = p;
-        float4 *__restrict__ so = sorted;
-        float4 q[S2B_FL], qn[S2B_FL];
-#pragma unroll
-        for (int u = 0; u < S2B_FL; u++) q[u] = pr[min(tid + u * S2B_IT, max(n - 1, 0))];
-#pragma unroll
-        for (int r = 0; r < S2B_MAXR; r++) {
-            const int i0 = tid + r * S2B_FL * S2B_IT;
-            if (i0 >= n) break;
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) qn[u] = pr[min(i0 + (S2B_FL + u) * S2B_IT, n - 1)];
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) {
-                const int i = i0 + u * S2B_IT;
-                if (i >= n) continue;
-                const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
-                const int st = big ? start[b] : s_base[b >> 6] + (int)((s_hist[S2B_HW(b >> 1)] >> (16 * (b & 1))) & 0xffffu);
-                const int pos = st + (int)((rreg[2 * r + (u >> 1)] >> (16 * (u & 1))) & 0xffffu);
-                q[u].w = __int_as_float(i);                // original map index (tie-break like a linear scan)
-                if (pos < map.cap) so[pos] = q[u];
-            }
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) q[u] = qn[u];
-        }
-    } else
-    {
-        float4 q[S2B_FL], qn[S2B_FL]; unsigned short r4[S2B_FL], rn[S2B_FL];
-#pragma unroll
-        for (int u = 0; u < S2B_FL; u++) { const int ic = min(tid + u * S2B_IT, max(n - 1, 0)); q[u] = p[ic]; r4[u] = rk[ic]; }
-        for (int i0 = tid; i0 < n; i0 += S2B_FL * S2B_IT) {
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) { const int ic = min(i0 + (S2B_FL + u) * S2B_IT, n - 1); qn[u] = p[ic]; rn[u] = rk[ic]; }
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) {
-                const int i = i0 + u * S2B_IT;
-                if (i >= n) continue;
-                const int b = bucket_of((int)floorf(q[u].x), (int)floorf(q[u].y));
-                const int st = big ? start[b] : s_base[b >> 6] + (int)((s_hist[S2B_HW(b >> 1)] >> (16 * (b & 1))) & 0xffffu);
-                const int pos = st + (int)r4[u];
-                q[u].w = __int_as_float(i);                // original map index (tie-break like a linear scan)
-                if (pos < map.cap) sorted[pos] = q[u];
-            }
-#pragma unroll
-            for (int u = 0; u < S2B_FL; u++) { q[u] = qn[u]; r4[u] = rn[u]; }
-        }
-    }
-    S2M_STAMP(skid, 5, true);
-    __syncthreads();
-    S2M_STAMP(skid, 6, true);
-#ifdef VILF_STAMPS
-    if (blockIdx.x == S2M_STAMP_WG && tid == 0) s2m_dbg[skid * 32 + 30] = n;
-#endif
+// pcl::KdTreeFLANN::nearestKSearch(k = 5) (EstimationMapping.hpp:128,185) is replaced by a search over the cells of the cell-major map order (mu_leaf): a cell is
+// 2^cs x 2^cs leaf columns (0.8 m x 0.8 m for both maps of the KITTI configuration), all z; its points are one contiguous run of the map, and the cells of a row
+// follow each other in x. The DIRECTORY hashes a cell to a slot by the low 9 bits of its coordinates — slot = (cy & 511) << 9 | (cx & 511) — and holds the
+// position of the first map point whose cell is >= that cell in the map's order (a lower bound, also for empty cells next to occupied ones), tagged with the
+// step's epoch in the top byte. A query visits the rows cy of [qy - 1, qy + 1] and reads, per row, the two slots of cells cx_lo and cx_hi + 1: the points in
+// between are ONE span of the map. Every map point within 1 m of the query lies in such a span, so the 5-NN is exact whenever the 5th squared distance is
+// < 1 — the only case the reference uses (EstimationMapping.hpp:129,189). Slots the current step did not write carry an old tag: the span is empty.
+// b_dir_build writes the directory from the map in one pass (a thread per point; a point whose cell differs from its predecessor's fills the slots of the cells
+// in between, and S2B_DMARGIN cells before the first / after the last cell of a row, so that a span that touches an occupied cell always finds both its
+// ends). No sort, no copy of the map, no pass over the table. Maps wider than 512 - 2 S2B_DMARGIN cells would alias: the host picks cs so that the crop box
+// fits (s2b_cell_shift), and for a map that is not a voxel grid yet (as initialised) from the cloud's extent.
+#define S2B_DB 9
+#define S2B_NB (1 << (2 * S2B_DB))
+#define S2B_NBS (S2B_NB + 4)
+#define S2B_DMARGIN 8
+#define S2B_LOFF 65536
+#define S2B_QR 1.001f        // search radius in metres: the reference's gate is 1 (squared distance < 1); the margin covers the rounding of q -+ 1 and of the squared distance
+__device__ __forceinline__ int cm_leaf(float v, float inv) { return (int)floorf(__fmul_rn(v, inv)) + S2B_LOFF; }
+__device__ __forceinline__ int dir_slot(int cy, int cx) { return ((cy & 511) << S2B_DB) | (cx & 511); }
+// pts: the map in cell-major order (or the cell-major-sorted copy of a map that is not a voxel grid yet), n points per stream
+__global__ void b_dir_build(const float4 *pts_all, const int *n_all, int cap, float inv, int cs, unsigned tag, unsigned *dir_all) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y, n = min(n_all[sid], cap);
+    if (i >= n) return;
+    const float4 *p = pts_all + (size_t)sid * cap;
+    unsigned *T = dir_all + (size_t)sid * S2B_NBS;
+    const float4 q = p[i], qp = p[max(i - 1, 0)];
+    const int cx = cm_leaf(q.x, inv) >> cs, cy = cm_leaf(q.y, inv) >> cs, cxp = cm_leaf(qp.x, inv) >> cs, cyp = cm_leaf(qp.y, inv) >> cs;
+    if (i == n - 1) for (int c = cx + 1; c <= cx + S2B_DMARGIN; c++) T[dir_slot(cy, c)] = tag | (unsigned)n;
+    const bool first = i == 0, newrow = first || cy != cyp;
+    if (!newrow && cx == cxp) return;
+    const unsigned v = tag | (unsigned)i;
+    for (int c = newrow ? cx - S2B_DMARGIN : max(cxp + 1, cx - 511); c <= cx; c++) T[dir_slot(cy, c)] = v;
+    if (newrow && !first) for (int c = cxp + 1; c <= cxp + S2B_DMARGIN; c++) T[dir_slot(cyp, c)] = v;
+}
+// the cell-major-sorted copy of a map that is not a voxel grid yet: point vals[g] of the stream to position g, its index in w (ties of the 5-NN go by it)
+__global__ void b_gather_sorted(CSet in, const int *vals_all, float4 *sorted_all) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= min(in.n[sid], in.cap)) return;
+    const size_t base = (size_t)sid * in.cap;
+    const int v = vals_all[base + i];
+    float4 q = in.p[base + v];
+    q.w = __int_as_float(v);
+    sorted_all[base + i] = q;
 }
 #define KNN_FL 8            // candidates in flight per lane and round
-// exact 5-NN within the 3 x 3 bucket block: pos[] = positions in the bucket-sorted array, ordered by (squared distance, original index)
-__device__ void knn5_cells(const float4 *sorted, const int *start, float qx, float qy, float qz, int pos[5], float d2[5]) {
-    int oid[5];
+#define KNN_ROWS 4          // rows of cells walked as one sequence (cells of >= 2/3 m: at most four rows)
+struct KnnSpans { int nrow, cylo, cxlo, cxhi1; };
+__device__ __forceinline__ KnnSpans knn_rows(float qx, float qy, float inv, int cs) {
+    KnnSpans r;
+    r.cylo = cm_leaf(qy - S2B_QR, inv) >> cs; r.nrow = (cm_leaf(qy + S2B_QR, inv) >> cs) - r.cylo + 1;
+    r.cxlo = cm_leaf(qx - S2B_QR, inv) >> cs; r.cxhi1 = (cm_leaf(qx + S2B_QR, inv) >> cs) + 1;
+    return r;
+}
+// the span of row cy: [st, en) or an empty one when either slot was not written by this step / is inconsistent
+__device__ __forceinline__ void knn_span(const unsigned *T, unsigned tag, int n, int cy, int cxlo, int cxhi1, int &st, int &en) {
+    const unsigned a = T[dir_slot(cy, cxlo)], b = T[dir_slot(cy, cxhi1)];
+    const int sa = (int)(a & 0xffffffu), sb = (int)(b & 0xffffffu);
+    const bool ok = (a & 0xff000000u) == tag && (b & 0xff000000u) == tag && sa <= sb && sb <= n;
+    st = ok ? sa : 0; en = ok ? sb : 0;
+}
+// exact 5-NN within the rows of cells around the query: pos[] = positions in the cell-major array, ordered by squared distance; candidates at exactly equal distances are
+// ordered by position here and reported through `tie` — b_associate_ties then redoes the query with the reference order (rare)
+__device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag, int n, float inv, int cs, float qx, float qy, float qz, int pos[5], float d2[5], bool &tie) {
 #pragma unroll
-    for (int k = 0; k < 5; k++) { pos[k] = -1; oid[k] = 0x7fffffff; d2[k] = 3.0e38f; }
-    const int cx = (int)floorf(qx), cy = (int)floorf(qy);
-    const int xl = (cx - 1) & 255, xm = cx & 255;
-    const bool one_span = xl < xm && xm < 255;           // the three x-buckets of a row are adjacent unless the digit wraps
-    // all span bounds first (independent loads), then the candidates four at a time (clamped, unconditional loads): the lane keeps
+    for (int k = 0; k < 5; k++) { pos[k] = -1; d2[k] = 3.0e38f; }
+    tie = false;
+    const KnnSpans R = knn_rows(qx, qy, inv, cs);
+    // all span bounds first (independent loads), then the candidates eight at a time (clamped, unconditional loads): the lane keeps
     // several loads in flight instead of one dependent load per candidate
-    int st[9], en[9];
-    const int nspan = one_span ? 3 : 9;
+    int st[KNN_ROWS], en[KNN_ROWS];
 #pragma unroll
-    for (int sp = 0; sp < 9; sp++) {
-        if (sp < nspan) {
-            const int dy = one_span ? sp - 1 : sp / 3 - 1, part = one_span ? 0 : sp % 3;
-            const int row = ((cy + dy) & 255) << 8;
-            const int b0 = one_span ? (row | xl) : (row | ((cx - 1 + part) & 255)), b1 = one_span ? b0 + 2 : b0;
-            st[sp] = start[b0]; en[sp] = start[b1 + 1];
-        } else { st[sp] = 0; en[sp] = 0; }
-    }
+    for (int r = 0; r < KNN_ROWS; r++) { if (r < R.nrow) knn_span(T, tag, n, R.cylo + r, R.cxlo, R.cxhi1, st[r], en[r]); else { st[r] = 0; en[r] = 0; } }
     // one candidate: sorted insertion with compile-time indices only (the five best stay in registers)
 #define KNN_TRY(M, POS) { const float4 m = (M); const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz; \
-        const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)); const int oi = __float_as_int(m.w); \
-        if (d < d2[4] || (d == d2[4] && oi < oid[4])) { bool lt[5]; const int ps_ = (POS); \
-            _Pragma("unroll") for (int k = 0; k < 5; k++) lt[k] = d < d2[k] || (d == d2[k] && oi < oid[k]); \
-            _Pragma("unroll") for (int k = 4; k >= 1; k--) { d2[k] = lt[k - 1] ? d2[k - 1] : (lt[k] ? d : d2[k]); oid[k] = lt[k - 1] ? oid[k - 1] : (lt[k] ? oi : oid[k]); pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? ps_ : pos[k]); } \
-            if (lt[0]) { d2[0] = d; oid[0] = oi; pos[0] = ps_; } } }
-    if (one_span) {
-        // the usual case: three spans, walked as ONE sequence (virtual index t -> position t + offset of its span) so that a batch never ends at a span boundary,
+        const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)); \
+        if (d <= d2[4]) { bool lt[5]; const int ps_ = (POS); \
+            _Pragma("unroll") for (int k = 0; k < 5; k++) { lt[k] = d < d2[k]; tie = tie || d == d2[k]; } \
+            _Pragma("unroll") for (int k = 4; k >= 1; k--) { d2[k] = lt[k - 1] ? d2[k - 1] : (lt[k] ? d : d2[k]); pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? ps_ : pos[k]); } \
+            if (lt[0]) { d2[0] = d; pos[0] = ps_; } } }
+    {
+        // the rows' spans are walked as ONE sequence (virtual index t -> position t + offset of its span) so that a batch never ends at a span boundary,
         // with the next batch's loads issued before this batch is ranked: the walk is bound by the latency of these gathers, not by the arithmetic
-        const int n0 = en[0] - st[0], n01 = n0 + en[1] - st[1], ntot = n01 + en[2] - st[2];
-        const int o0 = st[0], o1 = st[1] - n0, o2 = st[2] - n01;
+        const int n0 = en[0] - st[0], n01 = n0 + en[1] - st[1], n012 = n01 + en[2] - st[2], ntot = n012 + en[3] - st[3];
+        const int o0 = st[0], o1 = st[1] - n0, o2 = st[2] - n01, o3 = st[3] - n012;
+#define KNN_AT(t) ((t) + ((t) < n0 ? o0 : ((t) < n01 ? o1 : ((t) < n012 ? o2 : o3))))
         if (ntot > 0) {
             float4 cur[KNN_FL], nxt[KNN_FL];
 #pragma unroll
-            for (int u = 0; u < KNN_FL; u++) { const int t = min(u, ntot - 1); cur[u] = sorted[t + (t < n0 ? o0 : (t < n01 ? o1 : o2))]; }
+            for (int u = 0; u < KNN_FL; u++) { const int t = min(u, ntot - 1); cur[u] = sorted[KNN_AT(t)]; }
             for (int t0 = 0; t0 < ntot; t0 += KNN_FL) {
 #pragma unroll
-                for (int u = 0; u < KNN_FL; u++) { const int t = min(t0 + KNN_FL + u, ntot - 1); nxt[u] = sorted[t + (t < n0 ? o0 : (t < n01 ? o1 : o2))]; }
+                for (int u = 0; u < KNN_FL; u++) { const int t = min(t0 + KNN_FL + u, ntot - 1); nxt[u] = sorted[KNN_AT(t)]; }
 #pragma unroll
                 for (int u = 0; u < KNN_FL; u++) {
                     const int t = t0 + u;
                     if (t >= ntot) break;
-                    KNN_TRY(cur[u], t + (t < n0 ? o0 : (t < n01 ? o1 : o2)))
+                    KNN_TRY(cur[u], KNN_AT(t))
                 }
 #pragma unroll
                 for (int u = 0; u < KNN_FL; u++) cur[u] = nxt[u];
             }
         }
-        return;
+#undef KNN_AT
     }
-#pragma unroll
-    for (int sp = 0; sp < 9; sp++) {          // a digit wraps inside the 3 x 3 block: nine single-bucket spans
-        for (int j0 = st[sp]; j0 < en[sp]; j0 += KNN_FL) {
+    for (int r = KNN_ROWS; r < R.nrow; r++) {          // cells smaller than 2/3 m: the further rows one by one
+        int s0, e0;
+        knn_span(T, tag, n, R.cylo + r, R.cxlo, R.cxhi1, s0, e0);
+        for (int j0 = s0; j0 < e0; j0 += KNN_FL) {
             float4 m4[KNN_FL];
 #pragma unroll
-            for (int u = 0; u < KNN_FL; u++) m4[u] = sorted[min(j0 + u, en[sp] - 1)];
+            for (int u = 0; u < KNN_FL; u++) m4[u] = sorted[min(j0 + u, e0 - 1)];
 #pragma unroll
             for (int u = 0; u < KNN_FL; u++) {
-                if (j0 + u >= en[sp]) break;
+                if (j0 + u >= e0) break;
                 KNN_TRY(m4[u], j0 + u)
             }
         }
     }
 #undef KNN_TRY
+}
+// The same search with the reference's order of equal distances: ascending map index in PCL's order (a linear scan keeps the first of equals) — for the cell-major map
+// that is the PCL leaf key z | y | x of the candidate, then its position (points of one leaf keep their relative order); for the sorted copy of a map that is not a
+// voxel grid yet the original index travels in w. Only queries that met a tie come here (b_associate_ties): plain loops, no attempt at speed.
+__device__ void knn5_cells_exact(const float4 *sorted, const unsigned *T, unsigned tag, int n, float inv, int cs, bool w_is_index, float qx, float qy, float qz, int pos[5], float d2[5]) {
+    unsigned long long ky[5];
+    for (int k = 0; k < 5; k++) { pos[k] = -1; d2[k] = 3.0e38f; ky[k] = ~0ULL; }
+    const KnnSpans R = knn_rows(qx, qy, inv, cs);
+    for (int r = 0; r < R.nrow; r++) {
+        int s0, e0;
+        knn_span(T, tag, n, R.cylo + r, R.cxlo, R.cxhi1, s0, e0);
+        for (int j = s0; j < e0; j++) {
+            const float4 m = sorted[j];
+            const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+            const unsigned long long key = w_is_index ? (unsigned long long)(unsigned)__float_as_int(m.w)
+                                                      : (((unsigned long long)(unsigned)cm_leaf(m.z, inv) << 40) | ((unsigned long long)(unsigned)cm_leaf(m.y, inv) << 20) | (unsigned long long)(unsigned)cm_leaf(m.x, inv));
+            int at = 5;
+            for (int k = 4; k >= 0; k--) if (d < d2[k] || (d == d2[k] && (key < ky[k] || (key == ky[k] && j < pos[k])))) at = k;
+            if (at < 5) {
+                for (int k = 4; k > at; k--) { d2[k] = d2[k - 1]; ky[k] = ky[k - 1]; pos[k] = pos[k - 1]; }
+                d2[at] = d; ky[at] = key; pos[at] = j;
+            }
+        }
+    }
 }
 
 // 3x3 symmetric eigen-decomposition by cyclic Jacobi: eigenvalues ascending, V columns. Every array index is a compile-time constant
@@ -1151,70 +1069,91 @@ __device__ __forceinline__ void qr_solve_5x3(const double *Ain, const double *bi
 // former 80-byte records (+ a separate kind array) straddled two sectors each.
 #define S2M_FREC 8
 __device__ __forceinline__ double s2m_pack2(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)); }
-// one thread per query point of one stream. Edge queries write records [0, n_ds_edge), surf queries [n_ds_edge, n_ds_edge + n_ds_surf).
-__global__ void b_associate(CSet ds, int is_surf, const int *n_ds_edge, const double *pose_all, CSet map, const float4 *sorted_all, const int *start_all,
-                            const S2BRes *res, double *frec_all, int *fkind_all, int capq) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= ds.n[sid] || !res[sid].do_opt) return;
-    const double *pose = pose_all + 24 * sid;
-    const float4 *sorted = sorted_all + (size_t)sid * map.cap;
-    const int *start = start_all + (size_t)sid * S2B_NBS;
-    const int nmap = map.n[sid];
-    const int slot = is_surf ? n_ds_edge[sid] + i : i;
-    double *frec = frec_all + ((size_t)sid * capq + slot) * S2M_FREC;
-    const float4 p = ds.p[(size_t)sid * ds.cap + i];
-    const double cp[3] = {p.x, p.y, p.z};
-    double pw[3];
-    q_rot(q_load(pose), cp, pw);
-    const float qx = (float)(pw[0] + pose[4]), qy = (float)(pw[1] + pose[5]), qz = (float)(pw[2] + pose[6]);
+// the line / plane fit of one query from its five neighbours (EdgeCostFactor :143-157, SurfCostFactor :198-213) and its 64-byte factor record
+__device__ __forceinline__ void assoc_fit_write(const float4 *sorted, const int idx[5], bool gate, int is_surf, const float4 p, double *frec, int *fkind_slot) {
     int kind = 0;
     double rec[S2M_FREC] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int idx[5]; float d2[5];
-#ifdef VILF_STAMPS
-    const bool st_ = blockIdx.y == S2M_STAMP_WG && blockIdx.x == 2 && threadIdx.x == 0;
-    const long long st0_ = __builtin_readcyclecounter();
-    long long st1_ = st0_;
-#endif
-    if (nmap >= 5) {
-        knn5_cells(sorted, start, qx, qy, qz, idx, d2);
-#ifdef VILF_STAMPS
-        st1_ = __builtin_readcyclecounter();
-#endif
-        if (d2[4] < 1.0f) {
-            double nb[5][3];
-            for (int t = 0; t < 5; t++) { const float4 m = sorted[idx[t]]; nb[t][0] = m.x; nb[t][1] = m.y; nb[t][2] = m.z; }
-            if (!is_surf) {
-                double c[3] = {0, 0, 0};
-                for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) c[a] += nb[j][a];
-                for (int a = 0; a < 3; a++) c[a] /= 5.0;
-                double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-                for (int j = 0; j < 5; j++) { const double d[3] = {nb[j][0] - c[0], nb[j][1] - c[1], nb[j][2] - c[2]}; for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) cov[3 * a + b2] += d[a] * d[b2]; }
-                double w[3], V[9];
-                eig3(cov, w, V);
-                if (w[2] > 3 * w[1]) {
-                    kind = 1;
-                    for (int a = 0; a < 3; a++) { rec[a] = 0.1 * V[3 * a + 2] + c[a]; rec[3 + a] = -0.1 * V[3 * a + 2] + c[a]; }
-                }
-            } else {
-                double A[15], B[5] = {-1, -1, -1, -1, -1}, nn[3];
-                for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) A[3 * j + a] = nb[j][a];
-                qr_solve_5x3(A, B, nn);
-                const double nrm = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
-                const double d = 1.0 / nrm;
-                nn[0] /= nrm; nn[1] /= nrm; nn[2] /= nrm;
-                bool ok = true;
-                for (int j = 0; j < 5; j++) if (fabs(nn[0] * nb[j][0] + nn[1] * nb[j][1] + nn[2] * nb[j][2] + d) > 0.2) ok = false;
-                if (ok) { kind = 2; rec[0] = nn[0]; rec[1] = nn[1]; rec[2] = nn[2]; rec[3] = d; }
+    if (gate) {
+        double nb[5][3];
+        for (int t = 0; t < 5; t++) { const float4 m = sorted[idx[t]]; nb[t][0] = m.x; nb[t][1] = m.y; nb[t][2] = m.z; }
+        if (!is_surf) {
+            double c[3] = {0, 0, 0};
+            for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) c[a] += nb[j][a];
+            for (int a = 0; a < 3; a++) c[a] /= 5.0;
+            double cov[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < 5; j++) { const double d[3] = {nb[j][0] - c[0], nb[j][1] - c[1], nb[j][2] - c[2]}; for (int a = 0; a < 3; a++) for (int b2 = 0; b2 < 3; b2++) cov[3 * a + b2] += d[a] * d[b2]; }
+            double w[3], V[9];
+            eig3(cov, w, V);
+            if (w[2] > 3 * w[1]) {
+                kind = 1;
+                for (int a = 0; a < 3; a++) { rec[a] = 0.1 * V[3 * a + 2] + c[a]; rec[3 + a] = -0.1 * V[3 * a + 2] + c[a]; }
             }
+        } else {
+            double A[15], B[5] = {-1, -1, -1, -1, -1}, nn[3];
+            for (int j = 0; j < 5; j++) for (int a = 0; a < 3; a++) A[3 * j + a] = nb[j][a];
+            qr_solve_5x3(A, B, nn);
+            const double nrm = sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+            const double d = 1.0 / nrm;
+            nn[0] /= nrm; nn[1] /= nrm; nn[2] /= nrm;
+            bool ok = true;
+            for (int j = 0; j < 5; j++) if (fabs(nn[0] * nb[j][0] + nn[1] * nb[j][1] + nn[2] * nb[j][2] + d) > 0.2) ok = false;
+            if (ok) { kind = 2; rec[0] = nn[0]; rec[1] = nn[1]; rec[2] = nn[2]; rec[3] = d; }
         }
     }
-    fkind_all[(size_t)sid * capq + slot] = kind;                 // the solve counts its factors from this array; the sweeps read the kind out of the record
+    *fkind_slot = kind;                                          // the solve counts its factors from this array; the sweeps read the kind out of the record
     rec[6] = s2m_pack2(__float_as_uint(p.x), __float_as_uint(p.y)); rec[7] = s2m_pack2(__float_as_uint(p.z), (unsigned)kind);
     double2 *fo = reinterpret_cast<double2 *>(frec);
 #pragma unroll
     for (int k = 0; k < 4; k++) fo[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+}
+struct AssocArgs {
+    CSet ds; int is_surf; const int *n_ds_edge; const double *pose_all;
+    const float4 *sorted_all; const int *n_map; int cap_map;      // the cell-major array the search runs on (the map itself, or the sorted copy of an unordered map)
+    const unsigned *dir_all; unsigned tag; float inv; int cs; int w_is_index;
+    const S2BRes *res; double *frec_all; int *fkind_all; int capq; int *tie_count;
+};
+#define S2M_KIND_TIE 3      // fkind of a query whose 5-NN met exactly equal distances: b_associate_ties redoes it in the reference's order (b_solve skips kinds other than 1, 2)
+// one thread per query point of one stream. Edge queries write records [0, n_ds_edge), surf queries [n_ds_edge, n_ds_edge + n_ds_surf).
+// ONE launch serves both query sets: blocks [0, nblk_edge) take the edge cloud against the edge map (arguments ae), the others the surf cloud (as).
+template <bool TIES>
+__global__ void b_associate(AssocArgs ae, AssocArgs as, int nblk_edge) {
+    const bool second = (int)blockIdx.x >= nblk_edge;
+    const AssocArgs &a = second ? as : ae;
+    const int i = ((int)blockIdx.x - (second ? nblk_edge : 0)) * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= a.ds.n[sid] || !a.res[sid].do_opt) return;
+    const int slot = a.is_surf ? a.n_ds_edge[sid] + i : i;
+    int *fk = a.fkind_all + (size_t)sid * a.capq + slot;
+    if (TIES && *fk != S2M_KIND_TIE) return;
+    const double *pose = a.pose_all + 24 * sid;
+    const float4 *sorted = a.sorted_all + (size_t)sid * a.cap_map;
+    const unsigned *T = a.dir_all + (size_t)sid * S2B_NBS;
+    const int nmap = min(a.n_map[sid], a.cap_map);
+    double *frec = a.frec_all + ((size_t)sid * a.capq + slot) * S2M_FREC;
+    const float4 p = a.ds.p[(size_t)sid * a.ds.cap + i];
+    const double cp[3] = {p.x, p.y, p.z};
+    double pw[3];
+    q_rot(q_load(pose), cp, pw);
+    const float qx = (float)(pw[0] + pose[4]), qy = (float)(pw[1] + pose[5]), qz = (float)(pw[2] + pose[6]);
+    int idx[5] = {-1, -1, -1, -1, -1}; float d2[5] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
 #ifdef VILF_STAMPS
-    if (st_) { const int kid = 6 + is_surf; s2m_dbg[kid * 32 + 0] = st1_ - st0_; s2m_dbg[kid * 32 + 1] = __builtin_readcyclecounter() - st1_; s2m_dbg[kid * 32 + 30] = ds.n[sid]; }
+    const bool st_ = blockIdx.y == S2M_STAMP_WG && (blockIdx.x == 2 || (int)blockIdx.x == nblk_edge + 2) && threadIdx.x == 0;
+    const long long st0_ = __builtin_readcyclecounter();
+    long long st1_ = st0_;
+#endif
+    if (nmap >= 5) {
+        if (TIES) knn5_cells_exact(sorted, T, a.tag, nmap, a.inv, a.cs, a.w_is_index != 0, qx, qy, qz, idx, d2);
+        else {
+            bool tie;
+            knn5_cells(sorted, T, a.tag, nmap, a.inv, a.cs, qx, qy, qz, idx, d2, tie);
+            if (tie) { *fk = S2M_KIND_TIE; atomicAdd(a.tie_count + sid, 1); return; }
+        }
+    }
+#ifdef VILF_STAMPS
+    st1_ = __builtin_readcyclecounter();
+#endif
+    assoc_fit_write(sorted, idx, nmap >= 5 && d2[4] < 1.0f, a.is_surf, p, frec, fk);
+#ifdef VILF_STAMPS
+    if (st_) { const int kid = 6 + a.is_surf; s2m_dbg[kid * 32 + 0] = st1_ - st0_; s2m_dbg[kid * 32 + 1] = __builtin_readcyclecounter() - st1_; s2m_dbg[kid * 32 + 30] = a.ds.n[sid]; }
 #endif
 }
 
@@ -1522,7 +1461,13 @@ struct S2B {
     DBuf nOld, mOld;                                     // map point counts before the append / surviving the crop (unsorted-map path)
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0, muT, tileHeads;
-    int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
+    int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending (cell-major) leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
+    int cs_cfg[2] = {0, 0};            // cell shift of the maps' cell-major order (s2b_cell_shift of the leaf size and the crop box)
+    int cs_idx[2] = {0, 0};            // ... of this step's neighbour directory (larger for an unordered map whose extent needs it)
+    bool idx_copy[2] = {false, false}; // this step's search runs on the cell-major-sorted COPY of an unordered map (w = original index) instead of the map itself
+    unsigned epoch = 0;                // directory entries carry (epoch % 255 + 1) << 24: a slot this step did not write reads as empty
+    // how many leading points of a stream's map are in cell-major order and therefore handed out in PCL order by get_map (INT_MAX: all of it — the state after a step)
+    std::vector<int> h_cmn[2], snap_cmn[2];
     bool has_snapshot = false, scan_dirty = true;
     bool snap_live = false;            // the snapshot's maps still live in a map / mapAlt buffer (rewind = pointer swap, no copy)
     void *snap_ptr[2] = {nullptr, nullptr};
@@ -1560,6 +1505,12 @@ static void s2m_prof_mark(vilf_handle *h, int group) {       // the launches sin
 #define GRIDS(S) dim3(((S) + 63) / 64), dim3(64)
 
 static int sbits_of(int S) { int b = 0; while ((1 << b) < S) b++; return b; }
+// the cells of a local map: 2^cs leaves wide, at least half a metre (at most six rows of cells per query), and the crop box plus the directory's margins within its 512 slots per axis
+static int s2b_cell_shift(float leaf, double half) {
+    int cs = 0;
+    while (cs < 15 && ((double)leaf * (1 << cs) < 0.5 || 2.0 * half / ((double)leaf * (1 << cs)) + 2.0 + 2 * S2B_DMARGIN > (double)(1 << S2B_DB))) cs++;
+    return cs;
+}
 
 // (Re)size the context. Map contents, counters and poses survive a capacity growth; a change of S starts from scratch.
 static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS, int capMapE, int capMapS) {
@@ -1567,9 +1518,13 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
     if (S != c->S) {
         c->release();
         c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false; c->order_state[0] = c->order_state[1] = 0;
-        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64) || !c->nOld.ensure((size_t)S * 4) || !c->mOld.ensure((size_t)S * 4)) return VILF_ERR_DEVICE;
+        if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64) || !c->nOld.ensure((size_t)S * 4) || !c->mOld.ensure((size_t)S * 4) || !c->bcnt.ensure((size_t)S * 4)) return VILF_ERR_DEVICE;
+        HIPCHECK(h, hipMemsetAsync(c->bcnt.p, 0, (size_t)S * 4, h->stream));
         for (int w = 0; w < 2; w++) {
             if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->bstart[w].ensure((size_t)S * S2B_NBS * 4)) return VILF_ERR_DEVICE;
+            HIPCHECK(h, hipMemsetAsync(c->bstart[w].p, 0, (size_t)S * S2B_NBS * 4, h->stream));      // tag 0: no slot is valid yet
+            c->h_cmn[w].assign(S, 0);
+            c->cs_cfg[w] = s2b_cell_shift((float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), h->opts.s2m_crop_half);
             HIPCHECK(h, hipMemsetAsync(c->nScan[w].p, 0, (size_t)S * 4, h->stream));
             HIPCHECK(h, hipMemsetAsync(c->nDs[w].p, 0, (size_t)S * 4, h->stream));
             HIPCHECK(h, hipMemsetAsync(c->nMap[w].p, 0, (size_t)S * 4, h->stream));
@@ -1579,7 +1534,6 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         for (int s = 0; s < S; s++) { ident[24 * s + 3] = 1.0; ident[24 * s + 11] = 1.0; ident[24 * s + 19] = 1.0; }
         HIPCHECK(h, hipMemcpyAsync(c->pose.p, ident.data(), ident.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
-        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_bucket_index), hipFuncAttributeMaxDynamicSharedMemorySize, S2B_HWORDS * 4 + S2B_IT * 4));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS32 * 8 + 8192));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS24 * 7 + 8192));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12));
@@ -1595,6 +1549,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         }
         if (wantMap[w] > c->capMap[w]) {
             const int oc = c->capMap[w], nc = oc ? std::max(wantMap[w], 2 * oc) : wantMap[w];
+            if (nc >= (1 << 24)) { h->err = "scan2map: local-map capacity beyond 2^24 points per stream (directory positions are 24 bits)"; return VILF_ERR_UNSUPPORTED; }
             DBuf nb;
             if (!nb.ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
             if (oc) {
@@ -1626,26 +1581,9 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
     return VILF_OK;
 }
 
-// pcl::VoxelGrid over every stream: in -> out (device counters)
-template <typename KeyT>
-static int s2b_voxel_typed(vilf_handle *h, S2B *c, CSet in, float inv, CSet out, int vbits) {
-    const int S = c->S, kbits = vbits + sbits_of(S);
-    KeyT *k1 = c->keys.as<KeyT>(), *k2 = c->keys2.as<KeyT>();
-    size_t tb = c->temp_bytes;
-    hipLaunchKernelGGL(b_voxel_keys<KeyT>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits);
-    PROF(0)
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
-    PROF(1)
-    const int ntiles = (in.cap + S2B_VT - 1) / S2B_VT;
-    if (!c->tileHeads.ensure((size_t)S * ntiles * 4)) return VILF_ERR_DEVICE;
-    hipLaunchKernelGGL(b_voxel_heads<KeyT>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, k2, c->tileHeads.as<int>(), ntiles);
-    hipLaunchKernelGGL(b_voxel_reduce<KeyT>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, k2, c->vals2.as<int>(), out, c->tileHeads.as<int>(), ntiles);
-    PROF(0)
-    return VILF_OK;
-}
-// pcl::VoxelGrid over every stream by ONE global sort: in -> out (device counters). The general path: scan clouds too large for the in-LDS
-// grid (b_scan_voxel) and local maps that are not voxel grids yet (b_map_update needs leaf order)
-static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
+// keys (PCL leaf index, or the maps' cell-major order when cs >= 0) of every stream's cloud + ONE stable radix sort over all streams: (sorted keys, point indices) land in
+// keys2 / vals2. Host round trip: the key width (and, for *cs_fit, the cloud extents) come back from the device. Returns the key type used through *wide.
+static int s2b_sort_keys(vilf_handle *h, S2B *c, CSet in, float leaf, int cs, int *cs_fit, bool *wide) {
     const int S = c->S;
     const float inv = 1.0f / leaf;
     int hb[8];
@@ -1653,16 +1591,69 @@ static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out) {
     hipLaunchKernelGGL(b_minmax, dim3(S), dim3(1024), 0, h->stream, in, inv, c->mm.as<MinMax>(), c->bits.as<int>());
     HIPCHECK(h, hipMemcpyAsync(hb, c->bits.p, 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
-    const int vbits = std::max(hb[0], 1);
+    int vbits = std::max(hb[0], 1);
+    if (cs_fit) {             // an unordered map's cells: at least the configured size, and large enough for the cloud's extent to fit the directory without aliasing
+        while (cs < 15 && ((std::max(hb[4], hb[5]) >> cs) + 2 + 2 * S2B_DMARGIN > (1 << S2B_DB))) cs++;
+        *cs_fit = cs;
+    }
+    if (cs >= 0) {            // bound of the cell-major key over all streams (every factor maximised on its own)
+        const long long bound = ((long long)((hb[5] >> cs) + 2) * ((hb[4] >> cs) + 2) * std::max(hb[6], 1)) << (2 * cs);
+        vbits = 1; while (vbits < 62 && (1LL << vbits) < bound) vbits++;
+    }
     if (vbits + sbits_of(S) > 63) { h->err = "scan2map: voxel index too wide (leaf size too small for the cloud extent)"; return VILF_ERR_UNSUPPORTED; }
     PROF(0)
-    if (vbits + sbits_of(S) <= 32) return s2b_voxel_typed<unsigned int>(h, c, in, inv, out, vbits);      // 32-bit keys: a third less sort traffic
-    return s2b_voxel_typed<unsigned long long>(h, c, in, inv, out, vbits);
+    const int kbits = vbits + sbits_of(S);
+    size_t tb = c->temp_bytes;
+    *wide = kbits > 32;                                           // 32-bit keys: a third less sort traffic
+    if (!*wide) {
+        unsigned int *k1 = c->keys.as<unsigned int>(), *k2 = c->keys2.as<unsigned int>();
+        hipLaunchKernelGGL(b_voxel_keys<unsigned int>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits, cs);
+        PROF(0)
+        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
+    } else {
+        unsigned long long *k1 = c->keys.as<unsigned long long>(), *k2 = c->keys2.as<unsigned long long>();
+        hipLaunchKernelGGL(b_voxel_keys<unsigned long long>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits, cs);
+        PROF(0)
+        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
+    }
+    PROF(1)
+    return VILF_OK;
+}
+// pcl::VoxelGrid over every stream by ONE global sort: in -> out (device counters), leaves in PCL order (cs < 0: scan clouds too large for the in-LDS grid, b_scan_voxel)
+// or in the maps' cell-major order (cs >= 0: local maps that are not voxel grids yet — b_map_update needs that order)
+static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out, int cs) {
+    bool wide;
+    int rc = s2b_sort_keys(h, c, in, leaf, cs, nullptr, &wide);
+    if (rc != VILF_OK) return rc;
+    const int S = c->S, ntiles = (in.cap + S2B_VT - 1) / S2B_VT;
+    if (!c->tileHeads.ensure((size_t)S * ntiles * 4)) return VILF_ERR_DEVICE;
+    if (!wide) {
+        hipLaunchKernelGGL(b_voxel_heads<unsigned int>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, c->keys2.as<unsigned int>(), c->tileHeads.as<int>(), ntiles);
+        hipLaunchKernelGGL(b_voxel_reduce<unsigned int>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, c->keys2.as<unsigned int>(), c->vals2.as<int>(), out, c->tileHeads.as<int>(), ntiles);
+    } else {
+        hipLaunchKernelGGL(b_voxel_heads<unsigned long long>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, c->keys2.as<unsigned long long>(), c->tileHeads.as<int>(), ntiles);
+        hipLaunchKernelGGL(b_voxel_reduce<unsigned long long>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, c->keys2.as<unsigned long long>(), c->vals2.as<int>(), out, c->tileHeads.as<int>(), ntiles);
+    }
+    PROF(0)
+    return VILF_OK;
 }
 
+// The neighbour directory of local map w for this step. A map in cell-major order (every step leaves it so) is searched in place: one pass writes the directory. A map
+// that is not a voxel grid yet (as initialised) is first copied in cell-major order (global sort; the original index travels in w and breaks distance ties).
 static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
     CSet map = c->cs_map(w);
-    hipLaunchKernelGGL(b_bucket_index, dim3(c->S), dim3(S2B_IT), (size_t)S2B_HWORDS * 4 + S2B_IT * 4, h->stream, map, c->vals.as<int>(), c->bstart[w].as<int>(), c->sorted[w].as<float4>(), c->err.as<int>());
+    const float leaf = (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
+    const unsigned tag = (c->epoch % 255u + 1u) << 24;
+    const float4 *arr = map.p;
+    c->cs_idx[w] = c->cs_cfg[w]; c->idx_copy[w] = false;
+    if (c->order_state[w] != 1) {
+        bool wide;
+        int rc = s2b_sort_keys(h, c, map, leaf, c->cs_cfg[w], &c->cs_idx[w], &wide);
+        if (rc != VILF_OK) return rc;
+        hipLaunchKernelGGL(b_gather_sorted, GRID2(map.cap, c->S), 0, h->stream, map, c->vals2.as<int>(), c->sorted[w].as<float4>());
+        arr = c->sorted[w].as<float4>(); c->idx_copy[w] = true;
+    }
+    hipLaunchKernelGGL(b_dir_build, GRID2(map.cap, c->S), 0, h->stream, arr, map.n, map.cap, 1.0f / leaf, c->cs_idx[w], tag, c->bstart[w].as<unsigned>());
     PROF(2)
     return VILF_OK;
 }
@@ -1675,7 +1666,7 @@ static int s2b_resolve_order(vilf_handle *h, S2B *c, int w) {
     const float leaf = (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
     int flag = 0;
     HIPCHECK(h, hipMemsetAsync(c->bits.p, 0, 4, h->stream));
-    hipLaunchKernelGGL(b_check_order, dim3(64, c->S), dim3(256), 0, h->stream, c->cs_map(w), 1.0f / leaf, c->capScan[w] > mu_lds_cap(c->capScan[w]) ? 16 : 17, c->bits.as<int>());
+    hipLaunchKernelGGL(b_check_order, dim3(64, c->S), dim3(256), 0, h->stream, c->cs_map(w), 1.0f / leaf, c->cs_cfg[w], c->capScan[w] > mu_lds_cap(c->capScan[w]) ? 16 : 17, c->bits.as<int>());
     HIPCHECK(h, hipMemcpyAsync(&flag, c->bits.p, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     c->order_state[w] = flag ? 2 : 1;
@@ -1705,16 +1696,28 @@ static int s2b_step(vilf_handle *h, S2B *c) {
             if (cap <= SV_MAXPTS32) hipLaunchKernelGGL(b_scan_voxel<false>, dim3(S), dim3(SV_T), (size_t)cap * 8 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
             else hipLaunchKernelGGL(b_scan_voxel<true>, dim3(S), dim3(SV_T), (size_t)cap * 7 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
             PROF(0)
-        } else if ((rc = s2b_voxel(h, c, c->cs_scan(w), leaf[w], c->cs_ds(w))) != VILF_OK) return rc;
+        } else if ((rc = s2b_voxel(h, c, c->cs_scan(w), leaf[w], c->cs_ds(w), -1)) != VILF_OK) return rc;
     }
     hipLaunchKernelGGL(b_gate, GRIDS(S), 0, h->stream, c->nMap[0].as<int>(), c->nMap[1].as<int>(), c->nDs[0].as<int>(), c->nDs[1].as<int>(), d_res, d_err, S);
     PROF(6)
-    for (int w = 0; w < 2; w++) if ((rc = s2b_build_index(h, c, w)) != VILF_OK) return rc;
+    c->epoch++;
+    for (int w = 0; w < 2; w++) {
+        if ((rc = s2b_resolve_order(h, c, w)) != VILF_OK) return rc;
+        if ((rc = s2b_build_index(h, c, w)) != VILF_OK) return rc;
+    }
     const int capq = c->capScan[0] + c->capScan[1];
+    AssocArgs aa[2];
+    for (int w = 0; w < 2; w++) {
+        AssocArgs &a = aa[w];
+        a.ds = c->cs_ds(w); a.is_surf = w; a.n_ds_edge = c->nDs[0].as<int>(); a.pose_all = d_pose;
+        a.sorted_all = c->idx_copy[w] ? c->sorted[w].as<float4>() : c->map[w].as<float4>(); a.n_map = c->nMap[w].as<int>(); a.cap_map = c->capMap[w];
+        a.dir_all = c->bstart[w].as<unsigned>(); a.tag = (c->epoch % 255u + 1u) << 24; a.inv = 1.0f / leaf[w]; a.cs = c->cs_idx[w]; a.w_is_index = c->idx_copy[w] ? 1 : 0;
+        a.res = d_res; a.frec_all = c->frec.as<double>(); a.fkind_all = c->fkind.as<int>(); a.capq = capq; a.tie_count = c->bcnt.as<int>();
+    }
+    const int nblk_e = (c->capScan[0] + 255) / 256, nblk_s = (c->capScan[1] + 255) / 256;
     for (int pass = 0; pass < h->opts.s2m_outer_iterations && pass < 2; pass++) {
-        for (int w = 0; w < 2; w++)
-            hipLaunchKernelGGL(b_associate, GRID2(c->capScan[w], S), 0, h->stream, c->cs_ds(w), w, c->nDs[0].as<int>(), d_pose, c->cs_map(w), c->sorted[w].as<float4>(), c->bstart[w].as<int>(),
-                               d_res, c->frec.as<double>(), c->fkind.as<int>(), capq);
+        hipLaunchKernelGGL(b_associate<false>, dim3(nblk_e + nblk_s, S), dim3(256), 0, h->stream, aa[0], aa[1], nblk_e);
+        hipLaunchKernelGGL(b_associate<true>, dim3(nblk_e + nblk_s, S), dim3(256), 0, h->stream, aa[0], aa[1], nblk_e);      // queries that met exactly equal distances (rare), in the reference's order
         PROF(3)
         hipLaunchKernelGGL(b_solve, dim3(S), dim3(S2M_NT), 0, h->stream, d_pose, c->frec.as<double>(), c->fkind.as<int>(), capq, c->nDs[0].as<int>(), c->nDs[1].as<int>(), h->opts.huber_a,
                            h->opts.s2m_max_iterations, pass, d_res);
@@ -1722,7 +1725,6 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     }
     for (int w = 0; w < 2; w++) {     // createSubMap: append registered points, crop, voxel grid
         CSet map = c->cs_map(w), dsw = c->cs_ds(w), tmp = c->cs_tmp(w);
-        if ((rc = s2b_resolve_order(h, c, w)) != VILF_OK) return rc;
         hipLaunchKernelGGL(b_transform_append, GRID2(dsw.cap, S), 0, h->stream, dsw, d_pose, map, d_err);
         hipLaunchKernelGGL(b_bump, GRIDS(S), 0, h->stream, map, dsw, c->nOld.as<int>(), S);
         PROF(5)
@@ -1742,24 +1744,25 @@ static int s2b_step(vilf_handle *h, S2B *c) {
             const int lds_cap = mu_lds_cap(c->capScan[w]), lds_half = std::min(lds_cap, MU_LDS_TAIL / 2);
             int *gq = c->sorted[w].as<int>();
             const size_t gq_stride = (size_t)c->capMap[w] * 4;
-            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_half * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_half * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w),
                                c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, -1, lds_half, gq, gq_stride, d_err);
             if (lds_cap > lds_half)
-                hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+                hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w),
                                    c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, lds_half, lds_cap, gq, gq_stride, d_err);
             if (c->capScan[w] > lds_cap) {
                 int p2 = 2; while (p2 < c->capScan[w]) p2 <<= 1;
                 if (!c->muT.ensure((size_t)S * p2 * 8)) return VILF_ERR_DEVICE;
-                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_mapout(w),
+                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w),
                                    c->tmpB.as<float4>(), c->capScan[w], c->muT.as<unsigned long long>(), p2, 0, lds_cap, gq, gq_stride, d_err);
             }
             PROF(0)
         } else {                       // a map that is not a voxel grid yet (as initialised): crop copy + full sort
             hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp, c->nOld.as<int>(), c->mOld.as<int>());
             PROF(5)
-            if ((rc = s2b_voxel(h, c, tmp, leaf[w], c->cs_mapout(w))) != VILF_OK) return rc;
+            if ((rc = s2b_voxel(h, c, tmp, leaf[w], c->cs_mapout(w), c->cs_cfg[w])) != VILF_OK) return rc;
         }
         c->order_state[w] = 1;
+        std::fill(c->h_cmn[w].begin(), c->h_cmn[w].end(), INT_MAX);
     }
     for (int w = 0; w < 2; w++) std::swap(c->map[w], c->mapAlt[w]);
     hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
@@ -1801,6 +1804,49 @@ static int s2b_set_cloud(vilf_handle *h, S2B *c, DBuf &buf, int cap, int sid, in
     return VILF_OK;
 }
 
+// ---- the maps' two orders on the host ---------------------------------------------------------------------------------------------
+// Leaf coordinates as the device computes them: single-precision product, floor.
+static inline long long h_leaf(float v, float inv) { return (long long)std::floor(v * inv); }
+static inline unsigned long long h_pcl_key(const float *q, float inv) {       // z | y | x (21 bits each): pcl::VoxelGrid's order for any min corner
+    return ((unsigned long long)((h_leaf(q[2], inv) + (1 << 20)) & 0x1fffff) << 42) | ((unsigned long long)((h_leaf(q[1], inv) + (1 << 20)) & 0x1fffff) << 21) | (unsigned long long)((h_leaf(q[0], inv) + (1 << 20)) & 0x1fffff);
+}
+// A cloud that IS a voxel grid in PCL's order (strictly ascending leaf index: one point per leaf — e.g. a map that vilf_scan2map_get_map handed out) is uploaded in the
+// maps' cell-major order, so that the first step finds an ordered map (b_check_order) and takes the fused update. This changes nothing observable: no two points share a
+// leaf, the 5-NN breaks distance ties by the PCL key, and get_map hands the points back in PCL order. Anything else (a raw scan) is uploaded as it is.
+static bool s2b_host_cell_major(const float *xyzi, int n, float leaf, int cs, std::vector<float> &out) {
+    if (n <= 0) return false;
+    const float inv = 1.0f / leaf;
+    std::vector<std::pair<unsigned long long, int>> kc(n);
+    unsigned long long prev = 0;
+    const unsigned long long lm = (1ULL << cs) - 1ULL;
+    for (int i = 0; i < n; i++) {
+        const float *q = xyzi + 4 * (size_t)i;
+        if (!std::isfinite(q[0]) || !std::isfinite(q[1]) || !std::isfinite(q[2])) return false;
+        const long long lx = h_leaf(q[0], inv), ly = h_leaf(q[1], inv), lz = h_leaf(q[2], inv);
+        if (lx < -32768 || lx >= 32767 || ly < -32768 || ly >= 32767 || lz < -32768 || lz >= 32767) return false;      // the narrower of the two ranges of b_map_update
+        const unsigned long long kp = h_pcl_key(q, inv);
+        if (i > 0 && kp <= prev) return false;
+        prev = kp;
+        const unsigned long long ix = (unsigned long long)(lx + 65536), iy = (unsigned long long)(ly + 65536), iz = (unsigned long long)(lz + 65536);
+        kc[i] = {((iy >> cs) << (34 + cs)) | ((ix >> cs) << (17 + 2 * cs)) | (iz << (2 * cs)) | ((iy & lm) << cs) | (ix & lm), i};
+    }
+    std::sort(kc.begin(), kc.end());
+    out.resize((size_t)n * 4);
+    for (int i = 0; i < n; i++) std::memcpy(&out[4 * (size_t)i], xyzi + 4 * (size_t)kc[i].second, 16);
+    return true;
+}
+// the first m points of a downloaded map are in cell-major order: into PCL order (points of one leaf keep their relative order)
+static void s2b_host_pcl_order(float *xyzi, int m, float leaf) {
+    if (m < 2) return;
+    const float inv = 1.0f / leaf;
+    std::vector<std::pair<unsigned long long, int>> kp(m);
+    for (int i = 0; i < m; i++) kp[i] = {h_pcl_key(xyzi + 4 * (size_t)i, inv), i};
+    std::sort(kp.begin(), kp.end());                       // (key, position): stable by construction
+    std::vector<float> tmp((size_t)m * 4);
+    for (int i = 0; i < m; i++) std::memcpy(&tmp[4 * (size_t)i], xyzi + 4 * (size_t)kp[i].second, 16);
+    std::memcpy(xyzi, tmp.data(), (size_t)m * 16);
+}
+
 // ---- single-stream ABI (S = 1, capacities grow on demand) ---------------------------------------------------------------
 static S2B *single(vilf_handle *h) { if (!h->s2m) h->s2m = new S2B(); return h->s2m; }
 
@@ -1812,8 +1858,13 @@ extern "C" int vilf_scan2map_init(vilf_handle *h, const float *e, int ne, const 
     int rc = s2b_reserve(h, c, 1, ne, ns, oe + ne, os + ns);
     if (rc != VILF_OK) return rc;
     const float *src[2] = {e, s}; const int nn[2] = {ne, ns};                       // localMapInited (:105): map += cloud
+    std::vector<float> cm[2];
     for (int w = 0; w < 2; w++) {
-        if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], 0, c->h_nMap[w][0], src[w], nn[w])) != VILF_OK) return rc;
+        const int old_n = c->h_nMap[w][0];
+        const int keep = c->order_state[w] == 1 ? old_n : std::min(c->h_cmn[w][0], old_n);      // what was in cell-major order stays so; the appended cloud is raw ...
+        const bool conv = old_n == 0 && s2b_host_cell_major(src[w], nn[w], (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), c->cs_cfg[w], cm[w]);   // ... unless it is a whole voxel grid
+        if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], 0, old_n, conv ? cm[w].data() : src[w], nn[w])) != VILF_OK) return rc;
+        c->h_cmn[w][0] = conv ? nn[w] : keep;
         c->h_nMap[w][0] += nn[w]; c->order_state[w] = 0;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->h_nMap[w].data(), 4, hipMemcpyHostToDevice, h->stream));
     }
@@ -1837,7 +1888,20 @@ static int s2b_get_map(vilf_handle *h, S2B *c, int sid, int which, float *out, i
     if (c->S) HIPCHECK(h, hipMemcpy(&n, c->nMap[which].as<int>() + sid, 4, hipMemcpyDeviceToHost));
     *n_out = n;
     const int k = std::min(cap, n);
-    if (k > 0 && out) HIPCHECK(h, hipMemcpy(out, c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)k * 16, hipMemcpyDeviceToHost));
+    if (k > 0 && out) {
+        // the map lives in cell-major order on the device (mu_leaf); what the caller sees is pcl::VoxelGrid's order, as the reference's map has it
+        const int m = std::min(c->order_state[which] == 1 ? n : c->h_cmn[which][sid], n);
+        const float leaf = (float)(which == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
+        if (m <= k) {
+            HIPCHECK(h, hipMemcpy(out, c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)k * 16, hipMemcpyDeviceToHost));
+            s2b_host_pcl_order(out, m, leaf);
+        } else {                                            // a truncated read: order the whole prefix first, then hand out its first k points
+            std::vector<float> all((size_t)n * 4);
+            HIPCHECK(h, hipMemcpy(all.data(), c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)n * 16, hipMemcpyDeviceToHost));
+            s2b_host_pcl_order(all.data(), m, leaf);
+            std::memcpy(out, all.data(), (size_t)k * 16);
+        }
+    }
     return VILF_OK;
 }
 extern "C" int vilf_scan2map_get_map(vilf_handle *h, int which, float *out, int cap, int *n_out) {
@@ -1889,8 +1953,12 @@ extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float 
     if (ne < 0 || ns < 0 || ne > c->capMap[0] || ns > c->capMap[1] || (ne && !e) || (ns && !s)) return VILF_ERR_INVALID_ARGUMENT;
     const float *src[2] = {e, s}; const int nn[2] = {ne, ns};
     int rc;
+    std::vector<float> cm[2];
     for (int w = 0; w < 2; w++) {                                                   // the stream's local map := cloud
-        if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], stream, 0, src[w], nn[w])) != VILF_OK) return rc;
+        if (c->order_state[w] == 1) std::fill(c->h_cmn[w].begin(), c->h_cmn[w].end(), INT_MAX);   // the other streams' maps stay in cell-major order
+        const bool conv = s2b_host_cell_major(src[w], nn[w], (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), c->cs_cfg[w], cm[w]);
+        if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], stream, 0, conv ? cm[w].data() : src[w], nn[w])) != VILF_OK) return rc;
+        c->h_cmn[w][stream] = conv ? nn[w] : 0;
         c->h_nMap[w][stream] = nn[w]; c->order_state[w] = 0;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + stream, &c->h_nMap[w][stream], 4, hipMemcpyHostToDevice, h->stream));
     }
@@ -1900,6 +1968,21 @@ extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float 
     if (pose_last_qt) for (int k = 0; k < 7; k++) p[8 + k] = pose_last_qt[k];
     HIPCHECK(h, hipMemcpyAsync(c->pose.as<double>() + 24 * (size_t)stream, p, sizeof(p), hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    return VILF_OK;
+}
+// stream dst := stream src (local maps, poses, resident scan), copied on the device: a batch of replicas of a few distinct streams without one upload per stream
+extern "C" int vilf_scan2map_batch_copy_stream(vilf_handle *h, int src, int dst) {
+    S2B_CHECK(h, src)
+    if (dst < 0 || dst >= c->S) return VILF_ERR_INVALID_ARGUMENT;
+    if (src == dst) return VILF_OK;
+    for (int w = 0; w < 2; w++) {
+        HIPCHECK(h, hipMemcpyAsync(c->map[w].as<float4>() + (size_t)dst * c->capMap[w], c->map[w].as<float4>() + (size_t)src * c->capMap[w], (size_t)c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(c->scan[w].as<float4>() + (size_t)dst * c->capScan[w], c->scan[w].as<float4>() + (size_t)src * c->capScan[w], (size_t)c->capScan[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + dst, c->nMap[w].as<int>() + src, 4, hipMemcpyDeviceToDevice, h->stream));
+        c->h_nMap[w][dst] = c->h_nMap[w][src]; c->h_nScan[w][dst] = c->h_nScan[w][src]; c->h_cmn[w][dst] = c->h_cmn[w][src];
+    }
+    HIPCHECK(h, hipMemcpyAsync(c->pose.as<double>() + 24 * (size_t)dst, c->pose.as<double>() + 24 * (size_t)src, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
+    c->scan_dirty = true;
     return VILF_OK;
 }
 extern "C" int vilf_scan2map_batch_set_scan(vilf_handle *h, int stream, const float *e, int ne, const float *s, int ns) {
@@ -1933,7 +2016,7 @@ extern "C" int vilf_scan2map_batch_snapshot(vilf_handle *h) {
     for (int w = 0; w < 2; w++) {                 // the maps are not copied: a step never overwrites its input maps (see s2b_step)
         int rc = s2b_resolve_order(h, c, w);
         if (rc != VILF_OK) return rc;
-        c->snap_order[w] = c->order_state[w];
+        c->snap_order[w] = c->order_state[w]; c->snap_cmn[w] = c->h_cmn[w];
         if (!c->nMap0[w].ensure((size_t)c->S * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemcpyAsync(c->nMap0[w].p, c->nMap[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
         c->snap_ptr[w] = c->map[w].p;
@@ -1951,7 +2034,7 @@ extern "C" int vilf_scan2map_batch_rewind(vilf_handle *h) {
         if (c->snap_live) { if (c->map[w].p != c->snap_ptr[w]) std::swap(c->map[w], c->mapAlt[w]); }
         else HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->nMap0[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
-        c->order_state[w] = c->snap_order[w];
+        c->order_state[w] = c->snap_order[w]; c->h_cmn[w] = c->snap_cmn[w];
     }
     HIPCHECK(h, hipMemcpyAsync(c->pose.p, c->pose0.p, (size_t)c->S * 24 * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)c->S * 4, h->stream));

@@ -368,6 +368,10 @@ class Scan2MapBatch:
     def rewind(self):
         self.s._check(self._L.vilf_scan2map_batch_rewind(self.s._h), "vilf_scan2map_batch_rewind")
 
+    def copy_stream(self, src, dst):
+        """stream dst := stream src (maps, poses, resident scan), on the device"""
+        self.s._check(self._L.vilf_scan2map_batch_copy_stream(self.s._h, src, dst), "vilf_scan2map_batch_copy_stream")
+
     def results(self, first=0, n=None):
         n = self.n - first if n is None else n
         arr = (abi.Scan2MapResult * n)()

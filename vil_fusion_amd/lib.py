@@ -17,7 +17,7 @@ EXPORTED = [
     "vilf_eval_lidar_between", "vilf_eval_projection_td", "vilf_eval_prior", "vilf_eval_edge", "vilf_eval_surf", "vilf_pose_plus", "vilf_se3_plus",
     "vilf_imu_preintegrate", "vilf_imu_preintegrate_batch", "vilf_visual_imu_alignment", "vilf_posegraph_optimize", "vilf_scan2map_init", "vilf_scan2map_step", "vilf_scan2map_get_map", "vilf_scan2map_set_pose",
     "vilf_scan2map_batch_create", "vilf_scan2map_batch_init", "vilf_scan2map_batch_set_scan", "vilf_scan2map_batch_step", "vilf_scan2map_batch_snapshot",
-    "vilf_scan2map_batch_rewind", "vilf_scan2map_batch_results", "vilf_scan2map_batch_get_map", "vilf_get_profile_scan2map", "vilf_get_profile_marginalize", "vilf_batch_marginalize_stats", "vilf_get_profile_large_window", "vilf_lidar_extract_features", "vilf_feature_depth",
+    "vilf_scan2map_batch_rewind", "vilf_scan2map_batch_copy_stream", "vilf_scan2map_batch_results", "vilf_scan2map_batch_get_map", "vilf_get_profile_scan2map", "vilf_get_profile_marginalize", "vilf_batch_marginalize_stats", "vilf_get_profile_large_window", "vilf_lidar_extract_features", "vilf_feature_depth",
     "vilf_comm_unique_id", "vilf_comm_create", "vilf_comm_destroy", "vilf_gather_poses", "vilf_comm_last_error",
 ]
 
@@ -90,6 +90,7 @@ def lib():
     L.vilf_batch_marginalize_stats.argtypes = [vp, C.POINTER(C.c_int)]
     L.vilf_get_profile_large_window.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.vilf_scan2map_batch_rewind.argtypes = [vp]
+    L.vilf_scan2map_batch_copy_stream.argtypes = [vp, C.c_int, C.c_int]
     L.vilf_scan2map_batch_results.argtypes = [vp, C.c_int, C.c_int, C.POINTER(abi.Scan2MapResult)]
     L.vilf_scan2map_batch_get_map.argtypes = [vp, C.c_int, C.c_int, fpp, C.c_int, C.POINTER(C.c_int)]
     _lib = L
