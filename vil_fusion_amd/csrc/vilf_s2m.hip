@@ -516,6 +516,14 @@ __device__ __forceinline__ bool mu_leaf(const float4 q, float inv, int cs, unsig
     k = ok ? (((iy >> cs) << (2 * AXB + cs)) | ((ix >> cs) << (AXB + 2 * cs)) | (iz << (2 * cs)) | ((iy & lm) << cs) | (ix & lm)) : 0ULL;
     return ok;
 }
+// the directory slot (dir_slot: nine low bits of the cell's row and column) of a cell-major key — what b_dir_build needs of an output point. The sweep writes it next to
+// every point it emits (cid), so that the directory of the NEXT step is built from 4 bytes per point instead of the points themselves.
+template <int AXB>
+__device__ __forceinline__ unsigned mu_cid(unsigned long long k, int cs) {
+    const int adj = (65536 - (1 << (AXB - 1))) >> cs;              // the directory counts cells from leaf offset 65536 (cm_leaf), the key from 2^(AXB-1)
+    const int cy = (int)(k >> (2 * AXB + cs)) + adj, cx = (int)((k >> (AXB + 2 * cs)) & ((1ULL << (AXB - cs)) - 1ULL)) + adj;
+    return (unsigned)(((cy & 511) << 9) | (cx & 511));
+}
 struct MuBox { float mnx, mny, mnz, mxx, mxy, mxz; };
 __device__ __forceinline__ bool mu_inside(const float4 q, const MuBox &b) { return !(q.x < b.mnx || q.y < b.mny || q.z < b.mnz || q.x > b.mxx || q.y > b.mxy || q.z > b.mxz); }
 __device__ __forceinline__ void mu_acc(float4 &s, const float4 q) { s.x = __fadd_rn(s.x, q.x); s.y = __fadd_rn(s.y, q.y); s.z = __fadd_rn(s.z, q.z); s.w = __fadd_rn(s.w, q.w); }
@@ -529,7 +537,7 @@ __device__ __forceinline__ float4 mu_centroid(const float4 *ts, int a, int e) {
 // previous old key and this one, a tail run in this leaf, or a leaf that holds several old points. Such points are queued during the
 // sweep and handled afterwards, one per lane, from global memory — their dependent loads never sit on the sweep's critical path.
 template <int AXB, int IDXB>
-__device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool between, int jlo, int nOld, const float4 *p, float4 *o, const float4 *ts, const unsigned long long *T,
+__device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool between, int jlo, int nOld, const float4 *p, float4 *o, unsigned *cid, const float4 *ts, const unsigned long long *T,
                                         int ntv, int THtot, float inv, int cs, const MuBox &box) {
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
     auto lower = [&](unsigned long long k) { int lo = 0, hi = ntv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T[mid] >> IDXB) < k) lo = mid + 1; else hi = mid; } return lo; };
@@ -547,13 +555,13 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool bet
             const unsigned long long lf = T[jj] >> IDXB;
             int f = jj + 1;
             while (f < jlo && (T[f] >> IDXB) == lf) f++;
-            o[H + thp(jj) - M] = mu_centroid(ts, jj, f);
+            o[H + thp(jj) - M] = mu_centroid(ts, jj, f); cid[H + thp(jj) - M] = mu_cid<AXB>(lf, cs);
             jj = f;
         }
         if (tm && !sv) {                                     // the tail has this leaf; the old run may have no survivor at all -> a new leaf
             bool any = false;
             for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, cs, kr); if (kr != key) break; if (mu_inside(r, box)) { any = true; break; } }
-            if (!any) o[H + thp(jlo) - M] = mu_centroid(ts, jlo, jup);
+            if (!any) { o[H + thp(jlo) - M] = mu_centroid(ts, jlo, jup); cid[H + thp(jlo) - M] = mu_cid<AXB>(key, cs); }
         }
     }
     if (head) {
@@ -562,11 +570,11 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool bet
         for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, cs, kr); if (kr != key) break; if (mu_inside(r, box)) { mu_acc(s, r); cnt++; } }
         for (int jj = jlo; jj < jup; jj++) { mu_acc(s, ts[jj]); cnt++; }
         const float nn = (float)cnt;
-        o[H + thp(jlo) - M] = make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn);
+        o[H + thp(jlo) - M] = make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn); cid[H + thp(jlo) - M] = mu_cid<AXB>(key, cs);
     }
 }
 template <bool BIG>
-__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, int cs, CSet out, float4 *ts_all, int ts_stride,
+__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, int cs, CSet out, unsigned *cid_all, float4 *ts_all, int ts_stride,
                                                        unsigned long long *gT_all, int gT_stride, int lds_lo, int lds_cap, int *gq_all, size_t gq_stride, int *err) {
     constexpr int AXB = BIG ? 16 : 17, IDXB = BIG ? 16 : 13;
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
@@ -578,6 +586,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     unsigned long long *T = BIG ? gT_all + (size_t)sid * gT_stride : s_T;
     const float4 *p = map.p + (size_t)sid * map.cap;
     float4 *o = out.p + (size_t)sid * out.cap;
+    unsigned *cid = cid_all + (size_t)sid * out.cap;
     float4 *ts = ts_all + (size_t)sid * ts_stride;
     const double *pose = pose_all + 24 * sid;
     MuBox box;
@@ -770,8 +779,10 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
                 const int k = atomicAdd(&s_qn, 1);
                 reinterpret_cast<int4 *>(gq)[k] = make_int4((t0 + e) | (((hm >> u) & 1) << 30) | (btw ? (1 << 29) : 0), H, M, lo[u]);
             }
-            else if ((hm >> u) & 1)                                  // the common case: the old point is its leaf's centroid, sum from +0 as the reference does
+            else if ((hm >> u) & 1) {                                // the common case: the old point is its leaf's centroid, sum from +0 as the reference does
                 o[H + tb[u] - M] = make_float4(__fadd_rn(0.0f, q[u].x), __fadd_rn(0.0f, q[u].y), __fadd_rn(0.0f, q[u].z), __fadd_rn(0.0f, q[u].w));
+                cid[H + tb[u] - M] = mu_cid<AXB>(key[u], cs);
+            }
         }
         const int nextTE = s_te[MU_TILE - 1];
         carryH += base & 0xffff; carryM += base >> 16;
@@ -787,7 +798,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         const int qn = s_qn;
         for (int k = tid; k < qn; k += MU_T) {
             const int4 e = reinterpret_cast<const int4 *>(gq)[k];
-            mu_rare<AXB, IDXB>(e.x & 0x1fffffff, e.y, e.z, (e.x >> 30) & 1, (e.x >> 29) & 1, e.w, nOld, p, o, ts, T, ntv, THtot, inv, cs, box);
+            mu_rare<AXB, IDXB>(e.x & 0x1fffffff, e.y, e.z, (e.x >> 30) & 1, (e.x >> 29) & 1, e.w, nOld, p, o, cid, ts, T, ntv, THtot, inv, cs, box);
         }
     }
     __syncthreads();
@@ -800,7 +811,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         if (jj > jlast && (T[jj - 1] >> IDXB) == lf) continue;
         int e = jj + 1;
         while (e < ntv && (T[e] >> IDXB) == lf) e++;
-        o[carryH + thp(jj) - carryM] = mu_centroid(ts, jj, e);
+        o[carryH + thp(jj) - carryM] = mu_centroid(ts, jj, e); cid[carryH + thp(jj) - carryM] = mu_cid<AXB>(lf, cs);
     }
     S2M_STAMP(skid, 4, true);
 #ifdef VILF_STAMPS
@@ -843,20 +854,58 @@ __global__ void b_check_order(CSet map, float inv, int cs, int axb, int *flag) {
 #define S2B_QR 1.001f        // search radius in metres: the reference's gate is 1 (squared distance < 1); the margin covers the rounding of q -+ 1 and of the squared distance
 __device__ __forceinline__ int cm_leaf(float v, float inv) { return (int)floorf(__fmul_rn(v, inv)) + S2B_LOFF; }
 __device__ __forceinline__ int dir_slot(int cy, int cx) { return ((cy & 511) << S2B_DB) | (cx & 511); }
-// pts: the map in cell-major order (or the cell-major-sorted copy of a map that is not a voxel grid yet), n points per stream
-__global__ void b_dir_build(const float4 *pts_all, const int *n_all, int cap, float inv, int cs, unsigned tag, unsigned *dir_all) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y, n = min(n_all[sid], cap);
-    if (i >= n) return;
-    const float4 *p = pts_all + (size_t)sid * cap;
-    unsigned *T = dir_all + (size_t)sid * S2B_NBS;
-    const float4 q = p[i], qp = p[max(i - 1, 0)];
-    const int cx = cm_leaf(q.x, inv) >> cs, cy = cm_leaf(q.y, inv) >> cs, cxp = cm_leaf(qp.x, inv) >> cs, cyp = cm_leaf(qp.y, inv) >> cs;
+// One point of the cell-major array: (cy, cx) its cell's row / column modulo 512, (cyp, cxp) its predecessor's. Differences are taken modulo 512 too: a map spans fewer cells.
+__device__ __forceinline__ void dir_point(unsigned *T, unsigned tag, int i, int n, int cy, int cx, int cyp, int cxp) {
     if (i == n - 1) for (int c = cx + 1; c <= cx + S2B_DMARGIN; c++) T[dir_slot(cy, c)] = tag | (unsigned)n;
     const bool first = i == 0, newrow = first || cy != cyp;
     if (!newrow && cx == cxp) return;
     const unsigned v = tag | (unsigned)i;
-    for (int c = newrow ? cx - S2B_DMARGIN : max(cxp + 1, cx - 511); c <= cx; c++) T[dir_slot(cy, c)] = v;
+    const int gap = newrow ? S2B_DMARGIN : ((cx - cxp) & 511) - 1;            // cells to fill before this one
+    for (int c = cx - gap; c <= cx; c++) T[dir_slot(cy, c)] = v;
     if (newrow && !first) for (int c = cxp + 1; c <= cxp + S2B_DMARGIN; c++) T[dir_slot(cyp, c)] = v;
+}
+#define DIR_PT 8            // points per thread: every load of a thread is issued before the first is used (one load in flight per lane left the kernel waiting on memory latency),
+                            // and a block covers 2048 points — the grid is sized for the capacity, most of its blocks exit at once
+// pts: the map in cell-major order (or the cell-major-sorted copy of a map that is not a voxel grid yet), n points per stream
+__global__ void b_dir_build(const float4 *pts_all, const int *n_all, int cap, float inv, int cs, unsigned tag, unsigned *dir_all) {
+    const int sid = blockIdx.y, n = min(n_all[sid], cap), i0 = blockIdx.x * DIR_PT * blockDim.x + threadIdx.x;
+    if (i0 >= n) return;
+    const float4 *p = pts_all + (size_t)sid * cap;
+    unsigned *T = dir_all + (size_t)sid * S2B_NBS;
+    float2 q[DIR_PT], qp[DIR_PT];
+#pragma unroll
+    for (int u = 0; u < DIR_PT; u++) {
+        const int ic = min(i0 + u * (int)blockDim.x, n - 1);
+        const float4 *a = p + ic, *b = p + max(ic - 1, 0);
+        q[u] = make_float2(a->x, a->y); qp[u] = make_float2(b->x, b->y);
+    }
+#pragma unroll
+    for (int u = 0; u < DIR_PT; u++) {
+        const int i = i0 + u * (int)blockDim.x;
+        if (i < n) dir_point(T, tag, i, n, (cm_leaf(q[u].y, inv) >> cs) & 511, (cm_leaf(q[u].x, inv) >> cs) & 511, (cm_leaf(qp[u].y, inv) >> cs) & 511, (cm_leaf(qp[u].x, inv) >> cs) & 511);
+    }
+}
+// the same from the slots the map update wrote beside the points (cid): 4 bytes per point instead of 16
+__global__ void b_dir_build_cid(const unsigned *cid_all, const int *n_all, int cap, unsigned tag, unsigned *dir_all) {
+    const int sid = blockIdx.y, n = min(n_all[sid], cap), i0 = blockIdx.x * DIR_PT * blockDim.x + threadIdx.x;
+    if (i0 >= n) return;
+    const unsigned *cid = cid_all + (size_t)sid * cap;
+    unsigned *T = dir_all + (size_t)sid * S2B_NBS;
+    unsigned a[DIR_PT], ap[DIR_PT];
+#pragma unroll
+    for (int u = 0; u < DIR_PT; u++) { const int ic = min(i0 + u * (int)blockDim.x, n - 1); a[u] = cid[ic]; ap[u] = cid[max(ic - 1, 0)]; }
+#pragma unroll
+    for (int u = 0; u < DIR_PT; u++) {
+        const int i = i0 + u * (int)blockDim.x;
+        if (i < n) dir_point(T, tag, i, n, (int)(a[u] >> 9), (int)(a[u] & 511), (int)(ap[u] >> 9), (int)(ap[u] & 511));
+    }
+}
+// cid of a map that did not come out of b_map_update (uploaded, or voxelised by the global sort)
+__global__ void b_make_cid(const float4 *pts_all, const int *n_all, int cap, float inv, int cs, unsigned *cid_all) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= min(n_all[sid], cap)) return;
+    const float4 q = pts_all[(size_t)sid * cap + i];
+    cid_all[(size_t)sid * cap + i] = (unsigned)dir_slot(cm_leaf(q.y, inv) >> cs, cm_leaf(q.x, inv) >> cs);
 }
 // the cell-major-sorted copy of a map that is not a voxel grid yet: point vals[g] of the stream to position g, its index in w (ties of the 5-NN go by it)
 __global__ void b_gather_sorted(CSet in, const int *vals_all, float4 *sorted_all) {
@@ -1114,16 +1163,11 @@ struct AssocArgs {
 };
 #define S2M_KIND_TIE 3      // fkind of a query whose 5-NN met exactly equal distances: b_associate_ties redoes it in the reference's order (b_solve skips kinds other than 1, 2)
 // one thread per query point of one stream. Edge queries write records [0, n_ds_edge), surf queries [n_ds_edge, n_ds_edge + n_ds_surf).
-// ONE launch serves both query sets: blocks [0, nblk_edge) take the edge cloud against the edge map (arguments ae), the others the surf cloud (as).
+// one query i of the cloud described by a. TIES: the exact redo of a query that met equal distances
 template <bool TIES>
-__global__ void b_associate(AssocArgs ae, AssocArgs as, int nblk_edge) {
-    const bool second = (int)blockIdx.x >= nblk_edge;
-    const AssocArgs &a = second ? as : ae;
-    const int i = ((int)blockIdx.x - (second ? nblk_edge : 0)) * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= a.ds.n[sid] || !a.res[sid].do_opt) return;
+__device__ __forceinline__ void assoc_one(const AssocArgs &a, int i, int sid, bool stamp) {
     const int slot = a.is_surf ? a.n_ds_edge[sid] + i : i;
     int *fk = a.fkind_all + (size_t)sid * a.capq + slot;
-    if (TIES && *fk != S2M_KIND_TIE) return;
     const double *pose = a.pose_all + 24 * sid;
     const float4 *sorted = a.sorted_all + (size_t)sid * a.cap_map;
     const unsigned *T = a.dir_all + (size_t)sid * S2B_NBS;
@@ -1136,7 +1180,6 @@ __global__ void b_associate(AssocArgs ae, AssocArgs as, int nblk_edge) {
     const float qx = (float)(pw[0] + pose[4]), qy = (float)(pw[1] + pose[5]), qz = (float)(pw[2] + pose[6]);
     int idx[5] = {-1, -1, -1, -1, -1}; float d2[5] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
 #ifdef VILF_STAMPS
-    const bool st_ = blockIdx.y == S2M_STAMP_WG && (blockIdx.x == 2 || (int)blockIdx.x == nblk_edge + 2) && threadIdx.x == 0;
     const long long st0_ = __builtin_readcyclecounter();
     long long st1_ = st0_;
 #endif
@@ -1153,8 +1196,34 @@ __global__ void b_associate(AssocArgs ae, AssocArgs as, int nblk_edge) {
 #endif
     assoc_fit_write(sorted, idx, nmap >= 5 && d2[4] < 1.0f, a.is_surf, p, frec, fk);
 #ifdef VILF_STAMPS
-    if (st_) { const int kid = 6 + a.is_surf; s2m_dbg[kid * 32 + 0] = st1_ - st0_; s2m_dbg[kid * 32 + 1] = __builtin_readcyclecounter() - st1_; s2m_dbg[kid * 32 + 30] = a.ds.n[sid]; }
+    if (stamp) { const int kid = 6 + a.is_surf; s2m_dbg[kid * 32 + 0] = st1_ - st0_; s2m_dbg[kid * 32 + 1] = __builtin_readcyclecounter() - st1_; s2m_dbg[kid * 32 + 30] = a.ds.n[sid]; }
 #endif
+    (void)stamp;
+}
+// ONE launch serves both query sets: blocks [0, nblk_edge) take the edge cloud against the edge map (arguments ae), the others the surf cloud (as).
+__global__ void b_associate(AssocArgs ae, AssocArgs as, int nblk_edge) {
+    const bool second = (int)blockIdx.x >= nblk_edge;
+    const AssocArgs &a = second ? as : ae;
+    const int i = ((int)blockIdx.x - (second ? nblk_edge : 0)) * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    if (i >= a.ds.n[sid] || !a.res[sid].do_opt) return;
+    bool stamp = false;
+#ifdef VILF_STAMPS
+    stamp = blockIdx.y == S2M_STAMP_WG && (blockIdx.x == 2 || (int)blockIdx.x == nblk_edge + 2) && threadIdx.x == 0;
+#endif
+    assoc_one<false>(a, i, sid, stamp);
+}
+// the queries that met exactly equal distances, redone in the reference's order: one block per stream, which leaves at once unless its stream counted a tie
+__global__ void b_associate_ties(AssocArgs ae, AssocArgs as) {
+    const int sid = blockIdx.x;
+    if (ae.tie_count[sid] == 0) return;
+    const int ne = ae.ds.n[sid], nq = ne + as.ds.n[sid];
+    const int *fkind = ae.fkind_all + (size_t)sid * ae.capq;
+    for (int slot = threadIdx.x; slot < nq; slot += blockDim.x) {
+        if (fkind[slot] != S2M_KIND_TIE) continue;
+        if (slot < ne) assoc_one<true>(ae, slot, sid, false); else assoc_one<true>(as, slot - ne, sid, false);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ae.tie_count[sid] = 0;
 }
 
 // ---- the persistent LM solve -------------------------------------------------------------------------------------------
@@ -1461,6 +1530,8 @@ struct S2B {
     DBuf nOld, mOld;                                     // map point counts before the append / surviving the crop (unsorted-map path)
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0, muT, tileHeads;
+    DBuf cid[2], cidAlt[2], cid0[2];   // directory slot of every map point (b_map_update writes it beside the point): cid pairs with map, cidAlt with mapAlt, cid0 with map0
+    bool cid_ok[2] = {false, false}, snap_cid_ok[2] = {false, false};   // cid[w] describes map[w] for every stream
     int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending (cell-major) leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
     int cs_cfg[2] = {0, 0};            // cell shift of the maps' cell-major order (s2b_cell_shift of the leaf size and the crop box)
     int cs_idx[2] = {0, 0};            // ... of this step's neighbour directory (larger for an unordered map whose extent needs it)
@@ -1482,7 +1553,7 @@ struct S2B {
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &mapAlt[0], &mapAlt[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
                        &bstart[0], &bstart[1], &bcnt, &nOld, &mOld, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
-                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads};
+                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads, &cid[0], &cid[1], &cidAlt[0], &cidAlt[1], &cid0[0], &cid0[1]};
         for (DBuf *b : all) b->release();
     }
 };
@@ -1560,6 +1631,8 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
             c->map[w] = nb;
             c->capMap[w] = nc; grew = true; c->has_snapshot = false; c->snap_live = false;
             if (!c->sorted[w].ensure((size_t)S * nc * 16) || !c->mapAlt[w].ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
+            if (!c->cid[w].ensure((size_t)S * nc * 4) || !c->cidAlt[w].ensure((size_t)S * nc * 4)) return VILF_ERR_DEVICE;
+            c->cid_ok[w] = false;
         }
     }
     if (grew) {
@@ -1653,7 +1726,9 @@ static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
         hipLaunchKernelGGL(b_gather_sorted, GRID2(map.cap, c->S), 0, h->stream, map, c->vals2.as<int>(), c->sorted[w].as<float4>());
         arr = c->sorted[w].as<float4>(); c->idx_copy[w] = true;
     }
-    hipLaunchKernelGGL(b_dir_build, GRID2(map.cap, c->S), 0, h->stream, arr, map.n, map.cap, 1.0f / leaf, c->cs_idx[w], tag, c->bstart[w].as<unsigned>());
+    const dim3 dgrid((map.cap + 256 * DIR_PT - 1) / (256 * DIR_PT), c->S);
+    if (!c->idx_copy[w] && c->cid_ok[w]) hipLaunchKernelGGL(b_dir_build_cid, dgrid, dim3(256), 0, h->stream, c->cid[w].as<unsigned>(), map.n, map.cap, tag, c->bstart[w].as<unsigned>());
+    else hipLaunchKernelGGL(b_dir_build, dgrid, dim3(256), 0, h->stream, arr, map.n, map.cap, 1.0f / leaf, c->cs_idx[w], tag, c->bstart[w].as<unsigned>());
     PROF(2)
     return VILF_OK;
 }
@@ -1716,8 +1791,8 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     }
     const int nblk_e = (c->capScan[0] + 255) / 256, nblk_s = (c->capScan[1] + 255) / 256;
     for (int pass = 0; pass < h->opts.s2m_outer_iterations && pass < 2; pass++) {
-        hipLaunchKernelGGL(b_associate<false>, dim3(nblk_e + nblk_s, S), dim3(256), 0, h->stream, aa[0], aa[1], nblk_e);
-        hipLaunchKernelGGL(b_associate<true>, dim3(nblk_e + nblk_s, S), dim3(256), 0, h->stream, aa[0], aa[1], nblk_e);      // queries that met exactly equal distances (rare), in the reference's order
+        hipLaunchKernelGGL(b_associate, dim3(nblk_e + nblk_s, S), dim3(256), 0, h->stream, aa[0], aa[1], nblk_e);
+        hipLaunchKernelGGL(b_associate_ties, dim3(S), dim3(256), 0, h->stream, aa[0], aa[1]);      // queries that met exactly equal distances (rare), in the reference's order
         PROF(3)
         hipLaunchKernelGGL(b_solve, dim3(S), dim3(S2M_NT), 0, h->stream, d_pose, c->frec.as<double>(), c->fkind.as<int>(), capq, c->nDs[0].as<int>(), c->nDs[1].as<int>(), h->opts.huber_a,
                            h->opts.s2m_max_iterations, pass, d_res);
@@ -1732,9 +1807,10 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         // restored by swapping back). If that other buffer is where a live snapshot sits, save the snapshot first.
         if (c->has_snapshot && c->snap_live && c->mapAlt[w].p == c->snap_ptr[w]) {
             for (int v = 0; v < 2; v++) {
-                if (!c->map0[v].ensure((size_t)S * c->capMap[v] * 16)) return VILF_ERR_DEVICE;
-                void *src = (c->map[v].p == c->snap_ptr[v]) ? c->map[v].p : c->mapAlt[v].p;
-                HIPCHECK(h, hipMemcpyAsync(c->map0[v].p, src, (size_t)S * c->capMap[v] * 16, hipMemcpyDeviceToDevice, h->stream));
+                if (!c->map0[v].ensure((size_t)S * c->capMap[v] * 16) || !c->cid0[v].ensure((size_t)S * c->capMap[v] * 4)) return VILF_ERR_DEVICE;
+                const bool cur = c->map[v].p == c->snap_ptr[v];
+                HIPCHECK(h, hipMemcpyAsync(c->map0[v].p, cur ? c->map[v].p : c->mapAlt[v].p, (size_t)S * c->capMap[v] * 16, hipMemcpyDeviceToDevice, h->stream));
+                if (c->snap_cid_ok[v]) HIPCHECK(h, hipMemcpyAsync(c->cid0[v].p, cur ? c->cid[v].p : c->cidAlt[v].p, (size_t)S * c->capMap[v] * 4, hipMemcpyDeviceToDevice, h->stream));
             }
             c->snap_live = false;
         }
@@ -1744,19 +1820,21 @@ static int s2b_step(vilf_handle *h, S2B *c) {
             const int lds_cap = mu_lds_cap(c->capScan[w]), lds_half = std::min(lds_cap, MU_LDS_TAIL / 2);
             int *gq = c->sorted[w].as<int>();
             const size_t gq_stride = (size_t)c->capMap[w] * 4;
-            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_half * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w),
+            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_half * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->cidAlt[w].as<unsigned>(),
                                c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, -1, lds_half, gq, gq_stride, d_err);
             if (lds_cap > lds_half)
-                hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w),
+                hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->cidAlt[w].as<unsigned>(),
                                    c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, lds_half, lds_cap, gq, gq_stride, d_err);
             if (c->capScan[w] > lds_cap) {
                 int p2 = 2; while (p2 < c->capScan[w]) p2 <<= 1;
                 if (!c->muT.ensure((size_t)S * p2 * 8)) return VILF_ERR_DEVICE;
-                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w),
+                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->cidAlt[w].as<unsigned>(),
                                    c->tmpB.as<float4>(), c->capScan[w], c->muT.as<unsigned long long>(), p2, 0, lds_cap, gq, gq_stride, d_err);
             }
             PROF(0)
+            c->cid_ok[w] = true;       // (of the map the swap below makes current)
         } else {                       // a map that is not a voxel grid yet (as initialised): crop copy + full sort
+            c->cid_ok[w] = false;
             hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp, c->nOld.as<int>(), c->mOld.as<int>());
             PROF(5)
             if ((rc = s2b_voxel(h, c, tmp, leaf[w], c->cs_mapout(w), c->cs_cfg[w])) != VILF_OK) return rc;
@@ -1764,7 +1842,7 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         c->order_state[w] = 1;
         std::fill(c->h_cmn[w].begin(), c->h_cmn[w].end(), INT_MAX);
     }
-    for (int w = 0; w < 2; w++) std::swap(c->map[w], c->mapAlt[w]);
+    for (int w = 0; w < 2; w++) { std::swap(c->map[w], c->mapAlt[w]); std::swap(c->cid[w], c->cidAlt[w]); }
     hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
     PROF(6)
     HIPCHECK(h, hipGetLastError());
@@ -1865,7 +1943,7 @@ extern "C" int vilf_scan2map_init(vilf_handle *h, const float *e, int ne, const 
         const bool conv = old_n == 0 && s2b_host_cell_major(src[w], nn[w], (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), c->cs_cfg[w], cm[w]);   // ... unless it is a whole voxel grid
         if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], 0, old_n, conv ? cm[w].data() : src[w], nn[w])) != VILF_OK) return rc;
         c->h_cmn[w][0] = conv ? nn[w] : keep;
-        c->h_nMap[w][0] += nn[w]; c->order_state[w] = 0;
+        c->h_nMap[w][0] += nn[w]; c->order_state[w] = 0; c->cid_ok[w] = false;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->h_nMap[w].data(), 4, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -1959,7 +2037,7 @@ extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float 
         const bool conv = s2b_host_cell_major(src[w], nn[w], (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), c->cs_cfg[w], cm[w]);
         if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], stream, 0, conv ? cm[w].data() : src[w], nn[w])) != VILF_OK) return rc;
         c->h_cmn[w][stream] = conv ? nn[w] : 0;
-        c->h_nMap[w][stream] = nn[w]; c->order_state[w] = 0;
+        c->h_nMap[w][stream] = nn[w]; c->order_state[w] = 0; c->cid_ok[w] = false;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + stream, &c->h_nMap[w][stream], 4, hipMemcpyHostToDevice, h->stream));
     }
     double p[24] = {0};
@@ -1979,6 +2057,7 @@ extern "C" int vilf_scan2map_batch_copy_stream(vilf_handle *h, int src, int dst)
         HIPCHECK(h, hipMemcpyAsync(c->map[w].as<float4>() + (size_t)dst * c->capMap[w], c->map[w].as<float4>() + (size_t)src * c->capMap[w], (size_t)c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHECK(h, hipMemcpyAsync(c->scan[w].as<float4>() + (size_t)dst * c->capScan[w], c->scan[w].as<float4>() + (size_t)src * c->capScan[w], (size_t)c->capScan[w] * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + dst, c->nMap[w].as<int>() + src, 4, hipMemcpyDeviceToDevice, h->stream));
+        if (c->cid_ok[w]) HIPCHECK(h, hipMemcpyAsync(c->cid[w].as<unsigned>() + (size_t)dst * c->capMap[w], c->cid[w].as<unsigned>() + (size_t)src * c->capMap[w], (size_t)c->capMap[w] * 4, hipMemcpyDeviceToDevice, h->stream));
         c->h_nMap[w][dst] = c->h_nMap[w][src]; c->h_nScan[w][dst] = c->h_nScan[w][src]; c->h_cmn[w][dst] = c->h_cmn[w][src];
     }
     HIPCHECK(h, hipMemcpyAsync(c->pose.as<double>() + 24 * (size_t)dst, c->pose.as<double>() + 24 * (size_t)src, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -2017,6 +2096,12 @@ extern "C" int vilf_scan2map_batch_snapshot(vilf_handle *h) {
         int rc = s2b_resolve_order(h, c, w);
         if (rc != VILF_OK) return rc;
         c->snap_order[w] = c->order_state[w]; c->snap_cmn[w] = c->h_cmn[w];
+        if (c->order_state[w] == 1 && !c->cid_ok[w]) {          // the snapshot carries the maps' directory slots, as a map that came out of a step does
+            const float leaf = (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
+            hipLaunchKernelGGL(b_make_cid, GRID2(c->capMap[w], c->S), 0, h->stream, c->map[w].as<float4>(), c->nMap[w].as<int>(), c->capMap[w], 1.0f / leaf, c->cs_cfg[w], c->cid[w].as<unsigned>());
+            c->cid_ok[w] = true;
+        }
+        c->snap_cid_ok[w] = c->cid_ok[w];
         if (!c->nMap0[w].ensure((size_t)c->S * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemcpyAsync(c->nMap0[w].p, c->nMap[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
         c->snap_ptr[w] = c->map[w].p;
@@ -2031,8 +2116,12 @@ extern "C" int vilf_scan2map_batch_rewind(vilf_handle *h) {
     S2B_CHECK(h, 0)
     if (!c->has_snapshot) { h->err = "scan2map_batch_rewind: no snapshot"; return VILF_ERR_INVALID_ARGUMENT; }
     for (int w = 0; w < 2; w++) {
-        if (c->snap_live) { if (c->map[w].p != c->snap_ptr[w]) std::swap(c->map[w], c->mapAlt[w]); }
-        else HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+        if (c->snap_live) { if (c->map[w].p != c->snap_ptr[w]) { std::swap(c->map[w], c->mapAlt[w]); std::swap(c->cid[w], c->cidAlt[w]); } }
+        else {
+            HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
+            if (c->snap_cid_ok[w]) HIPCHECK(h, hipMemcpyAsync(c->cid[w].p, c->cid0[w].p, (size_t)c->S * c->capMap[w] * 4, hipMemcpyDeviceToDevice, h->stream));
+        }
+        c->cid_ok[w] = c->snap_cid_ok[w];
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->nMap0[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
         c->order_state[w] = c->snap_order[w]; c->h_cmn[w] = c->snap_cmn[w];
     }
