@@ -87,6 +87,34 @@ def cpu_baseline(opts_unused, wins, priors, lidar_cases, marginalize, seconds_ta
                 value_4_threads=its4 / dt4)
 
 
+def lidar_search_statistics(cases, opts):
+    """What the 5-NN of the LiDAR stage touches, counted on the host from the steady-state maps: cells are 0.8 m x 0.8 m (two edge leaves, one surf leaf), a query visits the
+    rows / columns of cells that [q - 1.001, q + 1.001] m covers. The raw scan points, moved by the pose after the warm-up frame, stand in for the down-sampled queries.
+    Returns averages per query (weighted by the edge / surf query counts of the scene) and the occupied cells per frame (both maps)."""
+    import numpy as np
+    from vil_fusion_amd import synth
+    tot_c = tot_r = tot_q = 0.0; cells = []
+    for me, ms, (se, ss), pose, _ in cases:
+        R = synth.q_to_R(np.asarray(pose[:4])); t = np.asarray(pose[4:])
+        ncell = 0
+        for m, sc, leaf in ((me, se, float(opts.edge_leaf_size)), (ms, ss, float(opts.surf_leaf_size))):
+            k = 1
+            while leaf * k < 0.5:
+                k *= 2
+            c = leaf * k
+            ij = np.floor(np.asarray(m)[:, :2] / c).astype(np.int64)
+            lo = ij.min(0) - 4; ext = ij.max(0) - lo + 5
+            grid = np.zeros((ext[1] + 1, ext[0] + 1)); np.add.at(grid, (ij[:, 1] - lo[1] + 1, ij[:, 0] - lo[0] + 1), 1.0)
+            ncell += int((grid > 0).sum())
+            sat = grid.cumsum(0).cumsum(1)
+            q = (np.asarray(sc)[::7, :3] @ R.T + t)[:, :2]
+            a = np.clip(np.floor((q - 1.001) / c).astype(np.int64) - lo, 0, ext - 1); b_ = np.clip(np.floor((q + 1.001) / c).astype(np.int64) - lo, 0, ext - 1)
+            cnt = sat[b_[:, 1] + 1, b_[:, 0] + 1] - sat[a[:, 1], b_[:, 0] + 1] - sat[b_[:, 1] + 1, a[:, 0]] + sat[a[:, 1], a[:, 0]]
+            tot_c += float(cnt.sum()); tot_r += float((b_[:, 1] - a[:, 1] + 1).sum()); tot_q += len(q)
+        cells.append(ncell)
+    return dict(candidates_per_query=tot_c / max(tot_q, 1), rows_per_query=tot_r / max(tot_q, 1), map_cells=float(np.mean(cells)))
+
+
 def _profile_order(path):
     """profiles/rNN_vMM_*: round, then version, numerically (r01_v10 after r01_v9)"""
     import re
@@ -178,7 +206,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--windows", type=int, default=4096, help="frames (window snapshot + LiDAR stream) resident per GPU")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic windows (tiled to --windows)")
-    ap.add_argument("--distinct-lidar", type=int, default=4, help="distinct synthetic LiDAR scenes (tiled to --windows)")
+    ap.add_argument("--distinct-lidar", type=int, default=64, help="distinct synthetic LiDAR scenes (tiled to --windows; generated on the host cores before the GPU is touched)")
+    ap.add_argument("--converging-windows", type=int, default=32, help="distinct windows of the converging-batch line (half of them start at their own fixed point and stop by tolerance); 0 skips it")
     ap.add_argument("--no-lidar-stage", action="store_true", help="configs[1]-style run: back-end window solve only")
     ap.add_argument("--no-marginalize", action="store_true", help="leave lines 863-1046 of Estimator::optimization() (marginalization) out of the frame")
     ap.add_argument("--overlap", action="store_true", help="run the LiDAR stage on its own handle / HIP stream / host thread, concurrently with the "
@@ -192,10 +221,21 @@ def main():
         return stress_main(args)
 
     import numpy as np
-    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    raw_lidar = []
+    if not args.no_lidar_stage:                    # the distinct synthetic scenes (ray casting in numpy, ~6 s each): on the host cores, in child processes forked BEFORE
+        from vil_fusion_amd import synth as _synth  # anything initialises the GPU
+        seeds = [7000 + 31 * rank + k for k in range(args.distinct_lidar)]
+        nproc = max(1, min(len(seeds), (os.cpu_count() or 1) // max(1, min(world, 8))))
+        try:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(nproc) as pool:
+                raw_lidar = pool.map(_synth.make_lidar_bench_case, seeds)
+        except Exception:
+            raw_lidar = [_synth.make_lidar_bench_case(sd) for sd in seeds]
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the solve path has no CPU fallback")
     # VILF_BENCH_REHEARSAL=1: every rank on cuda:0 with gloo collectives — rehearses the N > 1 code path on a one-GPU box (never a measurement)
@@ -225,7 +265,7 @@ def main():
     solver.batch_upload(wins, priors)              # inputs resident in HBM before the timed region
     lidar_cases, s2m = [], None
     if not args.no_lidar_stage:                    # one LiDAR stream per frame, resident in HBM
-        raw = [synth.make_lidar_bench_case(7000 + 31 * rank + k) for k in range(args.distinct_lidar)]
+        raw = raw_lidar
         # --overlap: the LiDAR stage gets its own handle = its own HIP stream and host thread, like the reference's separate
         # feature-tracker node (feature_tracker_node.cpp:384,524); default: both stages back to back on one stream
         lidar_handle = BackendSolver(device=local_rank)            # its own handle = its own HIP stream, always; whether the two stages run back to back or concurrently is step()'s choice
@@ -253,6 +293,26 @@ def main():
         s2m.snapshot()
     poses = torch.zeros((B, 8), dtype=torch.float64, device="cuda")
     stamps = np.arange(B, dtype=np.float64)
+    # N > 1: the newest-frame poses go through the library's own collective (vilf_comm_create / vilf_gather_poses = ncclCommInitRank / ncclAllGather over RCCL — what a
+    # C++ / ROS estimator process per GPU would call), enqueued on the solver's stream behind the kernel that writes the rows. torch.distributed only
+    # hands rank 0's communicator id to the other ranks and provides the barrier / the max-over-ranks of the timing. The one-GPU rehearsal keeps gloo (two ranks may not
+    # share a device in one RCCL communicator).
+    gather = None
+    gathered = None
+    if world > 1 and not rehearse:
+        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(vdist.RcclPoseGather.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        gather = vdist.RcclPoseGather(world, rank, device=local_rank, unique_id=bytes(idt.cpu().numpy().tobytes()))
+        gathered = torch.zeros((world * B, 8), dtype=torch.float64, device="cuda")
+
+    def gather_step():
+        solver.newest_poses_to_device(stamps, poses.data_ptr())              # a kernel on the solver's stream, no host wait
+        if gather is not None:
+            gather.gather(poses.data_ptr(), B, gathered.data_ptr(), stream=stream)
+        else:
+            vdist.gather_poses(poses.cpu() if rehearse else poses)
 
     import threading
 
@@ -282,8 +342,7 @@ def main():
         if s2m is not None and lidar_handle is not solver:
             lidar_handle.synchronize()                  # (already idle: reads its pending profile spans, so its event pool is reused)
         if world > 1:
-            solver.newest_poses_to_device(stamps, poses.data_ptr())
-            vdist.gather_poses(poses.cpu() if rehearse else poses)   # RCCL all_gather: 64 B per solved window (rank 0 feeds global_fusion)
+            gather_step()                               # RCCL all_gather: 64 B per solved window (rank 0 feeds global_fusion)
 
     def barrier():
         if world > 1:
@@ -314,8 +373,7 @@ def main():
                 lidar_handle.wait_for(solver)
                 s2m.rewind(); s2m.step(sync=False)
             if world > 1:
-                solver.newest_poses_to_device(stamps, poses.data_ptr())
-                vdist.gather_poses(poses.cpu() if rehearse else poses)
+                gather_step()
         else:
             step()
         its_local += sum(s.num_iterations for s in solver.batch_summaries())     # waits for the solver's stream (frame k done)
@@ -333,6 +391,7 @@ def main():
                    lm_iterations=float(np.mean([r.iterations[0] + r.iterations[1] for r in rs])),
                    map_points=float(np.mean([len(c[0]) + len(c[1]) for c in lidar_cases])), scan_points=float(np.mean([len(c[2][0]) + len(c[2][1]) for c in lidar_cases])),
                    map_edge_points=float(np.mean([len(c[0]) for c in lidar_cases])), map_surf_points=float(np.mean([len(c[1]) for c in lidar_cases])))
+        lid.update(lidar_search_statistics(lidar_cases[:8], opts))
     t = torch.tensor([dt, float(its_local)], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -395,6 +454,55 @@ def main():
                   "ms_per_step": trd / 3 * 1e3, "regular_batch_same_stages": {"value": qits / tqd, "ms_per_step": tqd / 3 * 1e3}}
         rsolver.close()
 
+    # ---- converging-batch line: with Ceres' default tolerances none of the synthetic windows stops before the iteration budget (the cost still falls by ~3e-4 per iteration
+    # after eight of them; function_tolerance is 1e-6). Here half of the distinct windows START at their own fixed point (pre-solved on the device with a budget of 1000
+    # iterations: FUNCTION_TOLERANCE after ~120) and stop in their first iteration, the other half are the regular windows. A finished window's workgroup leaves every
+    # later launch at once (VbState::done), so the step costs what the unfinished windows cost; the launches themselves are still enqueued (no host round trip inside a solve).
+    converging = None
+    if args.converging_windows > 1 and world == 1:
+        import copy
+        nc = min(args.converging_windows, args.distinct, B); half = nc // 2
+        o2 = type(opts).from_buffer_copy(opts); o2.max_num_iterations = 1000
+        pre = BackendSolver(o2, device=local_rank)
+        pre.batch_upload(wins[:half], priors[:half]); pre.batch_solve(sync=True)
+        pres = pre.batch_download(); psum = pre.batch_summaries(); pre.close()
+        cw = []
+        for i in range(nc):
+            if i < half:
+                w2 = copy.deepcopy(wins[i]); r_ = pres[i]
+                w2.para_pose = np.ascontiguousarray(np.asarray(r_.para_pose).reshape(-1, 7)); w2.para_speed_bias = np.ascontiguousarray(np.asarray(r_.para_speed_bias).reshape(-1, 9))
+                w2.para_feature = np.ascontiguousarray(r_.para_feature)
+                cw.append(w2)
+            else:
+                cw.append(wins[i])
+        order = [int(k) for k in np.random.default_rng(77).integers(0, nc, B)]      # which window sits in which slot is random, as in a real batch: a periodic arrangement of
+                                                                                    # short and long workgroups can fall on the same CUs launch after launch (tools/dev_converge.py)
+        csolver = BackendSolver(device=local_rank)
+        csolver.batch_upload([cw[k] for k in order], [priors[k] for k in order])
+
+        def cstep():
+            csolver.batch_rewind(); csolver.batch_solve(sync=True)
+            if not args.no_marginalize:
+                csolver.batch_marginalize(sync=True)
+        cstep()
+        torch.cuda.synchronize(); tc0 = time.perf_counter(); cits = 0; cterm = 0
+        for _ in range(3):
+            cstep(); sm = csolver.batch_summaries(); cits += sum(s_.num_iterations for s_ in sm); cterm += sum(1 for s_ in sm if s_.termination != 0)
+        torch.cuda.synchronize(); tcd = time.perf_counter() - tc0
+        tq0 = time.perf_counter(); qits = 0
+        for _ in range(3):
+            solver.batch_rewind(); solver.batch_solve(sync=True)
+            if not args.no_marginalize:
+                solver.batch_marginalize(sync=True)
+            qits += sum(s_.num_iterations for s_ in solver.batch_summaries())
+        torch.cuda.synchronize(); tqd = time.perf_counter() - tq0
+        converging = {"value": cits / tcd, "unit": "iterations/s", "windows_per_s": 3.0 * B / tcd, "ms_per_step": tcd / 3 * 1e3, "mean_iterations": cits / (3.0 * B),
+                      "stopped_by_tolerance_fraction": cterm / (3.0 * B), "distinct_windows": nc,
+                      "presolve_iterations": [int(s_.num_iterations) for s_ in psum][:8],
+                      "what": "window solve" + ("" if args.no_marginalize else " + marginalization") + ", no LiDAR stage; half of the windows start at their fixed point (FUNCTION_TOLERANCE in iteration 1), half are the regular 8-iteration windows",
+                      "regular_batch_same_stages": {"value": qits / tqd, "windows_per_s": 3.0 * B / tqd, "ms_per_step": tqd / 3 * 1e3, "mean_iterations": qits / (3.0 * B)}}
+        csolver.close()
+
     # ---- PCIe-inclusive figure: host buffers in (vilf_batch_upload: pack on the host threads + H2D from pinned staging) -> solve -> host buffers out
     # (vilf_batch_download_states), 2048 windows through ONE handle, priors resident (they are produced on the device in the running system). Never `value`.
     pcie = None
@@ -434,10 +542,12 @@ def main():
         if lid is not None:
             nm, ns, nq = lid["map_points"], lid["scan_points"], lid["queries"]
             alg.update({
-                "s2m_associate": B * 2 * nq * (12 + 27 * 2.0 * 16),      # 2 passes over all queries: point + 27 cells x c̄ = 2 pts x 16 B
-                "s2m_neighbour_index": B * nm * 16 * 2,                  # both maps: read points, write them cell-sorted
+                # 2 passes over all queries: the query point in (16 B), its factor record out (64 B), per row of cells two directory slots (8 B), and the candidates the
+                # rows' spans hold (16 B each; counted on the host from the maps: lid["candidates_per_query"]) — the bytes this design moves, not SURVEY's 27-cell estimate
+                "s2m_associate": B * 2 * nq * (16 + 64 + lid["rows_per_query"] * 8 + lid["candidates_per_query"] * 16),
+                "s2m_neighbour_index": B * (nm * 4 + lid["map_cells"] * 4),  # directory: one 4-byte slot id in per map point, one 4-byte slot out per occupied cell
                 "s2m_radix_sort": B * ns * 12 * 2,                       # only when a scan cloud exceeds the in-LDS grid (22 k points): ONE pass over (key, index)
-                "s2m_voxel_grid": B * (nm + ns + nq) * 16 * 2,           # 4 grids: read points, write centroids
+                "s2m_voxel_grid": B * ((nm + ns + nq) * 16 * 2 + nm * 4),    # 4 grids: read points, write centroids (+ the slot id beside every map point)
                 "s2m_lm_solve": B * nq * 64.0 * 2 * 5,                   # factor records (one 64-byte sector each), 2 passes x 5 evaluations
                 "s2m_submap": B * nq * 16 * 2})                         # transform + append of the registered scan (crop and grid are in s2m_voxel_grid)
         workload_tag = ("lidar+" if lid is not None else "") + "solve" + ("" if args.no_marginalize else "+marginalize")
@@ -515,11 +625,15 @@ def main():
             out["stages_overlapped"] = overlapped
         if ragged is not None:
             out["ragged_batch"] = ragged
+        if converging is not None:
+            out["converging_batch"] = converging
         if pcie is not None:
             out["pcie_inclusive"] = pcie
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))
+    if gather is not None:
+        gather.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -226,7 +226,9 @@ int vilf_batch_marginalize_stats(vilf_handle *h, int counts[4]);
 /* the general (window_size != 10) path of vilf_window_solve: factor scatter (linearisations), Schur SYRK, Cholesky, unused */
 int vilf_get_profile_large_window(vilf_handle *h, double ms_out[4], long launches_out[4]);
 /* newest-frame pose per resident window: [stamp x y z qx qy qz qw] (8 doubles each) into a DEVICE buffer
- * (feeds the RCCL gather for global_fusion, poseGraphOptimization.cpp:116-121). */
+ * (feeds the RCCL gather for global_fusion, poseGraphOptimization.cpp:116-121). Enqueued on the handle's stream; the call does NOT wait for it (stamps_host is
+ * copied to a pinned staging buffer of the handle before the call returns): order a consumer behind it by using the same stream (vilf_gather_poses takes one) or
+ * vilf_synchronize(). */
 int vilf_batch_newest_poses_device(vilf_handle *h, const double *stamps_host, void *device_out8);
 
 /* ---- multi-GPU: the pose gather over RCCL (SURVEY.md §8(b),(e)) --------------------------- */
@@ -312,6 +314,8 @@ typedef struct vilf_pg_edge {
     int robust;
     int pad_;
 } vilf_pg_edge;
+/* Limit: at most 2048 loop edges (edges between non-consecutive key frames): their 6 L x 6 L capacitance block is solved by the library's own dense Cholesky, whose
+ * back substitution keeps the solution in LDS. More loop edges: VILF_ERR_UNSUPPORTED, before any work is enqueued. */
 int vilf_posegraph_optimize(vilf_handle *h, int n_nodes, double *poses_qt /*[n][7] in/out*/, const double prior_sigma[6], int n_edges, const vilf_pg_edge *edges,
                             int max_iterations, double tol, int *iterations_out, double *final_cost);
 

@@ -141,3 +141,65 @@ def test_two_shards_hip_path_pose_gather_feeds_pose_graph(tmp_path):
     pg = posegraph.PoseGraph(backend=lambda x, ps, e: oracle_lib.posegraph_optimize(x, ps, e)[0])
     keys = [pg.add_odometry(r[0], np.concatenate([r[4:8], r[1:4]])) for r in a]
     assert keys[0] and len(pg.edges) == len(pg.nodes) - 1
+
+
+def _rccl_worker(rank, world, id_path, n_units, out_dir):
+    """one process per GPU: own device, own communicator rank, the C-ABI collective (vilf_comm_create / vilf_gather_poses) on the solver's stream"""
+    import time
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
+    from vil_fusion_amd import synth
+    from vil_fusion_amd.estimator import BackendSolver
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    if rank == 0:                                   # rank 0 creates the communicator id; the launcher (here: a file) hands it to the other ranks
+        uid = vdist.RcclPoseGather.unique_id()
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(id_path + ".tmp", id_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(id_path):
+                break
+            time.sleep(0.1)
+        uid = open(id_path, "rb").read()
+    g = vdist.RcclPoseGather(world, rank, device=rank, unique_id=uid)
+    assert torch.cuda.current_device() == rank, "vilf_comm_create must leave the caller's device as it was"
+    stream = torch.cuda.current_stream().cuda_stream
+    solver = BackendSolver(device=rank, stream=stream)
+    opts = solver.options
+    per = n_units // world                          # equal shards: one ncclAllGather, no padding
+    lo, hi = rank * per, (rank + 1) * per
+    made = [synth.make_window(100 + u, opts, synth.SynthConfig(n_features=30)) for u in range(lo, hi)]
+    solver.batch_upload([m[0] for m in made], [m[1] for m in made])
+    solver.batch_solve(sync=False)
+    poses = torch.zeros((per, 8), dtype=torch.float64, device="cuda")
+    allp = torch.zeros((world * per, 8), dtype=torch.float64, device="cuda")
+    solver.newest_poses_to_device(np.arange(lo, hi, dtype=np.float64), poses.data_ptr())      # enqueued behind the solve, no host wait
+    g.gather(poses.data_ptr(), per, allp.data_ptr(), stream=stream)                          # same stream: ordered behind the kernel that writes the rows
+    solver.synchronize(); torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"rccl_gather_{rank}.npy"), allp.cpu().numpy())
+    g.close(); solver.close()
+
+
+@pytest.mark.gpu
+def test_two_gpu_rccl_pose_gather_through_the_c_abi(tmp_path):
+    """configs[3] on real links: two processes, two devices, one RCCL communicator created through the C ABI (vilf_comm_unique_id / vilf_comm_create) and the pose
+    gather as ONE ncclAllGather (vilf_gather_poses). Needs two visible GPUs — skipped on the one-GPU box this suite usually runs on; the children are spawned before
+    the parent touches a GPU (torch.cuda.device_count() does not initialise it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    import oracle_lib
+    from vil_fusion_amd import synth
+    n_units = 6
+    mp.spawn(_rccl_worker, args=(2, str(tmp_path / "rccl_id.bin"), n_units, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "rccl_gather_0.npy"); b = np.load(tmp_path / "rccl_gather_1.npy")
+    assert a.shape == (n_units, 8) and np.array_equal(a, b), "every rank holds the same table"
+    assert np.array_equal(a[:, 0], np.arange(n_units, dtype=np.float64)), "rank-major = global unit order"
+    opts = oracle_lib.default_options()
+    for u in range(n_units):
+        win, prior, _ = synth.make_window(100 + u, opts, synth.SynthConfig(n_features=30))
+        ref = oracle_lib.window_solve(opts, win, prior)
+        assert np.abs(a[u, 1:4] - ref.Ps[-1]).max() < 1e-7

@@ -119,3 +119,23 @@ def test_posegraph_matches_oracle(oracle, K, loops):
     assert it == it_ref
     assert np.abs(got[:, 4:] - ref[:, 4:]).max() < 1e-7 and posegraph.max_rotation_difference(got, ref) < 1e-9
     assert abs(cost - cost_ref) <= 1e-6 * max(cost_ref, 1e-9)
+
+
+@pytest.mark.gpu
+def test_posegraph_many_loop_edges_and_the_documented_limit(oracle):
+    """680 loop edges: the 4080 x 4080 loop-closure block needs more than 64 KB of LDS in the back substitution of the library's dense Cholesky (launch attribute set
+    by the library) — one Gauss-Newton iteration against the oracle; beyond the documented 2048 loop edges the call refuses before doing any work."""
+    from vil_fusion_amd.estimator import BackendSolver, posegraph_optimize
+    from vil_fusion_amd.lib import VilfError
+    K, L = 700, 680
+    truth, x0, edges = posegraph.make_synthetic_graph(5, K, loops=[(k, K - 5 - k) for k in range(L // 2)] + [(k, k + 7) for k in range(L - L // 2)], odom_noise=(0.002, 0.02), loop_noise=(0.0005, 0.005))
+    ref, it_ref, cost_ref = oracle.posegraph_optimize(x0, PRIOR_SIGMA, edges, max_iterations=1, tol=0.0)
+    s = BackendSolver()
+    got, it, cost = posegraph_optimize(s, x0, PRIOR_SIGMA, edges, max_iterations=1, tol=0.0)
+    assert it == it_ref == 1
+    assert np.abs(got[:, 4:] - ref[:, 4:]).max() < 1e-7 and posegraph.max_rotation_difference(got, ref) < 1e-9
+    K2 = 2200
+    truth, x0, edges = posegraph.make_synthetic_graph(6, K2, loops=[(k, k + 50) for k in range(2049)], odom_noise=(0.002, 0.02), loop_noise=(0.0005, 0.005))
+    with pytest.raises(VilfError, match="loop edges"):
+        posegraph_optimize(s, x0, PRIOR_SIGMA, edges, max_iterations=1, tol=0.0)
+    s.close()

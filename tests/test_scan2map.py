@@ -212,7 +212,7 @@ def test_scan2map_bench_size_parity_and_invariants(oracle, opts):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_scan,leaf", [(3000, 0.8), (24000, 0.25), (20500, 0.25), (20500, 0.02), (3000, 0.02)])
+@pytest.mark.parametrize("n_scan,leaf", [(3000, 0.8), (24000, 0.25), (22150, 0.25), (20500, 0.25), (20500, 0.02), (3000, 0.02)])
 def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
     """createSubMap (EstimationMapping.hpp:298-352) in isolation: with <= 10 edge points in the map the reference skips the optimisation
     (:250) and still updates the maps, so the pose is the constant-velocity prediction on both sides and the surf map sees: a crop box
@@ -221,7 +221,7 @@ def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
     (the fused update's global-memory variant). Maps must stay bit-identical to the oracle over 5 frames; the first frame also
     exercises the unsorted-map path. The scan sizes / leaf sizes also walk the scan voxel grid through its variants: 32-bit keys in LDS
     (3000 points; leaf 0.02 m: 30 key bits = 4 radix passes), the 24-bit layout (20500 points; leaf 0.02 m: top key byte recomputed from
-    the points), and the global-sort path (24000 points)."""
+    the points), the global-sort path (24000 points) and a batch whose streams split between the two (22150, 22050 and 21950 points: the in-LDS grid holds 22000)."""
     from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
     o = oracle.default_options()
     o.s2m_crop_half = 6.0

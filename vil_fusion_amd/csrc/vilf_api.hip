@@ -183,6 +183,8 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     for (hipEvent_t e : h->prof_used) hipEventDestroy(e);
     for (hipEvent_t e : h->prof_free) hipEventDestroy(e);
     if (h->wait_ev) hipEventDestroy(h->wait_ev);
+    if (h->stamp_ev) hipEventDestroy(h->stamp_ev);
+    if (h->stamp_pinned) (void)hipHostFree(h->stamp_pinned);
     h->s2m_ev.clear(); h->prof_used.clear(); h->prof_free.clear(); h->prof_pending.clear();
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include "vilf_internal.hpp"
 #include "vilf_device.hpp"
@@ -25,17 +26,19 @@ struct Rccl {
 };
 Rccl &rccl() {
     static Rccl r;
-    if (r.lib || !r.err.empty()) return r;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
-    if (!r.lib) { r.err = std::string("librccl not found: ") + dlerror(); return r; }
-    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
-    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
-    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-    r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
-    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
-    if (!r.ok) r.err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+    static std::once_flag once;
+    std::call_once(once, [] {                       // first callers from several threads: one of them fills the table, the others wait
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) { r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
+        if (!r.lib) { r.err = std::string("librccl not found: ") + dlerror(); return; }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+        if (!r.ok) r.err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+    });
     return r;
 }
 thread_local std::string g_comm_err;
@@ -68,12 +71,15 @@ extern "C" int vilf_comm_create(const unsigned char id[VILF_COMM_ID_BYTES], int 
     if (device < 0 || device >= ndev) return VILF_ERR_INVALID_ARGUMENT;
     Rccl &r = rccl();
     if (!r.ok) { g_comm_err = r.err; return VILF_ERR_DEVICE; }
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);                  // the caller's current device is restored: a library call must not change it
     if (hipSetDevice(device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return VILF_ERR_DEVICE; }
     rcclUniqueId_t u;
     std::memcpy(&u, id, sizeof(u));
     vilf_comm *c = new vilf_comm();
     c->world = world_size; c->rank = rank; c->device = device;
     const int rc = r.CommInitRank(&c->comm, world_size, u, rank);
+    if (prev_dev >= 0 && prev_dev != device) (void)hipSetDevice(prev_dev);
     if (rc != 0) { g_comm_err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"); delete c; return VILF_ERR_DEVICE; }
     *out = c;
     return VILF_OK;
@@ -94,8 +100,11 @@ extern "C" int vilf_gather_poses(vilf_comm *c, void *hip_stream, const double *l
     if (n_local == 0) return VILF_OK;
     Rccl &r = rccl();
     if (!r.ok) { g_comm_err = r.err; return VILF_ERR_DEVICE; }
-    if (hipSetDevice(c->device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return VILF_ERR_DEVICE; }
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
+    if (prev_dev != c->device && hipSetDevice(c->device) != hipSuccess) { g_comm_err = "hipSetDevice failed"; return VILF_ERR_DEVICE; }
     const int rc = r.AllGather(local_dev8, out_dev8, (size_t)n_local * 8, 8 /* ncclFloat64 (rccl.h:467) */, c->comm, (hipStream_t)hip_stream);
+    if (prev_dev >= 0 && prev_dev != c->device) (void)hipSetDevice(prev_dev);
     if (rc != 0) { g_comm_err = std::string("ncclAllGather: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"); return VILF_ERR_DEVICE; }
     return VILF_OK;
 }
@@ -117,12 +126,22 @@ extern "C" int vilf_batch_newest_poses_device(vilf_handle *h, const double *stam
     const int B = h->B;
     const double *stamps_dev = nullptr;
     if (stamps_host) {
+        // The caller's stamps go through a pinned staging buffer the handle owns, so the call returns without waiting for the stream (the gather path has no host
+        // wait). The buffer is re-used by the next call: only then — normally long after the copy has run — the event of the previous copy is waited for.
         if (!h->d[D_STAMPS].ensure((size_t)B * 8)) return VILF_ERR_DEVICE;
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_STAMPS].p, stamps_host, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        if (h->stamp_cap < (size_t)B * 8) {
+            if (h->stamp_pinned) { HIPCHECK(h, hipStreamSynchronize(h->stream)); (void)hipHostFree(h->stamp_pinned); h->stamp_pinned = nullptr; h->stamp_cap = 0; }
+            HIPCHECK(h, hipHostMalloc(&h->stamp_pinned, (size_t)B * 8, hipHostMallocDefault));
+            h->stamp_cap = (size_t)B * 8;
+        }
+        if (!h->stamp_ev) HIPCHECK(h, hipEventCreateWithFlags(&h->stamp_ev, hipEventDisableTiming));
+        else HIPCHECK(h, hipEventSynchronize(h->stamp_ev));
+        std::memcpy(h->stamp_pinned, stamps_host, (size_t)B * 8);
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_STAMPS].p, h->stamp_pinned, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipEventRecord(h->stamp_ev, h->stream));
         stamps_dev = h->d[D_STAMPS].as<double>();
     }
     hipLaunchKernelGGL(k_newest_poses, dim3((B + 127) / 128), dim3(128), 0, h->stream, B, h->batch.out_Ps, h->batch.out_Rs, stamps_dev, (double *)device_out8);
     HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipStreamSynchronize(h->stream));     // stamps_host may be a temporary of the caller
     return VILF_OK;
 }

@@ -97,6 +97,7 @@ struct vilf_handle {
     std::vector<ProfSpan> prof_pending;
     std::vector<hipEvent_t> prof_used, prof_free;
     hipEvent_t wait_ev = nullptr;            // vilf_wait_for
+    void *stamp_pinned = nullptr; size_t stamp_cap = 0; hipEvent_t stamp_ev = nullptr;   // vilf_batch_newest_poses_device: pinned staging of the caller's stamps
     double kernel_ms[4] = {0, 0, 0, 0};      // linearize, solve, step, other (accumulated since last reset)
     long kernel_launches[4] = {0, 0, 0, 0};
     std::vector<hipEvent_t> s2m_ev;         // scan-to-map profiling (same switch): group of launches -> ms
@@ -131,5 +132,6 @@ void vilf_s2m_release(vilf_handle *h);
 void vilf_feat_release(vilf_handle *h);
 void vilf_pg_release(vilf_handle *h);
 void vilf_lw_release(vilf_handle *h);
+int vilf_lw_chol_max_n();                                                      // largest n vilf_lw_chol_solve takes (its back substitution keeps the solution in LDS)
 int vilf_lw_chol_solve(vilf_handle *h, int n, double *S, double *y, int *info);   // blocked Cholesky solve on the handle's stream (vilf_lw.hip): S = [(n + 1) x n] row-major, row n = rhs
 int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot1);   // batch_slot1 = resident slot + 1 (0: not resident)   // window sizes other than 10, estimate_extrinsic / estimate_td (vilf_lw.hip)

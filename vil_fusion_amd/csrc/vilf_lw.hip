@@ -1009,8 +1009,15 @@ __global__ __launch_bounds__(TR_T) void lw_tr_decide(LwTr a) {
 // The blocked Cholesky of this file as a service to the other translation units (the pose graph's loop-closure block): S is (n + 1) x n, row-major, rows 0 .. n - 1 the
 // symmetric positive-definite matrix (lower triangle read, overwritten by L), row n the right-hand side; y (n) receives the solution. *info (device, zeroed by the caller)
 // is set to 1 when a pivot is not positive. Everything is enqueued on the handle's stream.
+// lw_chol_back keeps the solution vector in LDS (n doubles of dynamic LDS beside 33.8 KB of static staging): 12288 x 8 + 33.8 KB = 130 KB of the CU's 160 KB
+int vilf_lw_chol_max_n() { return 12288; }
 int vilf_lw_chol_solve(vilf_handle *h, int n, double *S, double *y, int *info) {
-    if (n < 1 || (size_t)n * 8 > 48 * 1024) { h->err = "vilf_lw_chol_solve: dimension outside the supported range"; return VILF_ERR_UNSUPPORTED; }
+    if (n < 1 || n > vilf_lw_chol_max_n()) { h->err = "vilf_lw_chol_solve: dimension outside the supported range (1 .. 12288)"; return VILF_ERR_UNSUPPORTED; }
+    static bool attr_set = false;                  // above 64 KB in all, a launch needs the attribute; set once, for the largest supported n
+    if (!attr_set) {
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(lw_chol_back), hipFuncAttributeMaxDynamicSharedMemorySize, vilf_lw_chol_max_n() * 8));
+        attr_set = true;
+    }
     for (int j0 = 0; j0 < n; j0 += CH_NB) {
         const int nb = std::min(CH_NB, n - j0), below = n + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
         if (j0 == 0) hipLaunchKernelGGL(lw_chol_panel, dim3(npanel), dim3(256), 0, h->stream, n, S, j0, info, (const int *)nullptr);

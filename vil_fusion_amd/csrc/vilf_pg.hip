@@ -328,6 +328,10 @@ extern "C" int vilf_posegraph_optimize(vilf_handle *h, int K, double *poses_qt, 
     }
     for (int k = 0; k + 1 < K; k++) if (!linked[k]) { h->err = "posegraph: key frames " + std::to_string(k) + " and " + std::to_string(k + 1) + " have no odometry edge"; return VILF_ERR_UNSUPPORTED; }
     const int L = (int)loop_f.size(), NL = 6 * L, NC = 1 + NL, nF = n_edges + 1;
+    if (NL > vilf_lw_chol_max_n()) {       // checked before anything is uploaded or enqueued: the loop-closure block (6 L x 6 L) goes through vilf_lw_chol_solve
+        h->err = "posegraph: " + std::to_string(L) + " loop edges; the dense loop-closure block supports " + std::to_string(vilf_lw_chol_max_n() / 6);
+        return VILF_ERR_UNSUPPORTED;
+    }
     std::vector<int> adj_off(K + 1, 0), adj_item;
     for (int k = 0; k < K; k++) { adj_off[k + 1] = adj_off[k] + (int)adj[k].size(); adj_item.insert(adj_item.end(), adj[k].begin(), adj[k].end()); }
     loop_ij.insert(loop_ij.end(), loop_f.begin(), loop_f.end());               // [2 L] endpoints, then [L] factor ids

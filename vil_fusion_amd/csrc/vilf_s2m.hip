@@ -54,7 +54,8 @@ using namespace vd;
 // step (voxel grids, index build, 2 x (associate + LM solve), sub-map maintenance) is enqueued without a host round trip.
 // Sorts are ONE rocPRIM radix sort over all segments with the stream id in the high key bits; padding entries carry the largest
 // key of their stream and stay at the end of their own segment.
-struct CSet { float4 *p; int *n; int cap; };
+struct CSet { float4 *p; int *n; int cap; const int *smap = nullptr; };      // smap (general voxel path only): grid row -> stream, for a sub-batch of streams
+__device__ __forceinline__ int cset_sid(const CSet &c, int ls) { return c.smap ? c.smap[ls] : ls; }
 struct MinMax { float mn[3], mx[3]; int minb[3]; int pad_; long long mul1, mul2; int divb[3]; int pad2_; };
 struct S2BRes {                       // per-stream result of one step (device)
     double pose[7], prev[7];
@@ -72,7 +73,7 @@ __device__ __forceinline__ int bits_of(long long v) { return v <= 0 ? 0 : 64 - _
 // bits[0]: width of the largest leaf index (+1) over all streams; bits[1..3]: widths of the per-axis leaf extents; bits[4..6]: the largest per-axis leaf extents
 __global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
     __shared__ float s[6][1024];
-    const int tid = threadIdx.x, sid = blockIdx.x, n = in.n[sid];
+    const int tid = threadIdx.x, ls = blockIdx.x, sid = cset_sid(in, ls), n = in.n[sid];
     const float4 *p = in.p + (size_t)sid * in.cap;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = tid; i < n; i += blockDim.x) {
@@ -87,7 +88,7 @@ __global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
         __syncthreads();
     }
     if (tid == 0) {
-        MinMax *out = mm + sid;
+        MinMax *out = mm + ls;
         int divb[3];
         for (int k = 0; k < 3; k++) {
             out->mn[k] = s[k][0]; out->mx[k] = s[3 + k][0];
@@ -106,13 +107,13 @@ __global__ void b_minmax(CSet in, float inv, MinMax *mm, int *bits) {
 // y_low | x_low with cells of 2^cs x 2^cs leaf columns on the ABSOLUTE leaf grid), made narrow the same way: cell coordinates relative to the cloud's first cell
 template <typename KeyT>
 __global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, KeyT *keys, int *vals, int *err, int vbits, int cs) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, ls = blockIdx.y, sid = cset_sid(in, ls);
     if (i >= in.cap) return;
-    const size_t g = (size_t)sid * in.cap + i;
+    const size_t g = (size_t)ls * in.cap + i;                   // keys / indices are laid out by grid row, the points by stream
     unsigned long long k = (1ULL << vbits) - 1;                 // padding: larger than every leaf index of the stream
     if (i < in.n[sid]) {
-        const float4 q = in.p[g];
-        const MinMax *m = mm + sid;
+        const float4 q = in.p[(size_t)sid * in.cap + i];
+        const MinMax *m = mm + ls;
         const long long a = (long long)floorf(__fmul_rn(q.x, inv)) - m->minb[0], b = (long long)floorf(__fmul_rn(q.y, inv)) - m->minb[1], c = (long long)floorf(__fmul_rn(q.z, inv)) - m->minb[2];
         if (cs < 0) k = (unsigned long long)(a + b * m->mul1 + c * m->mul2);
         else {
@@ -123,7 +124,7 @@ __global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, KeyT *keys, i
             k = (unsigned long long)((((cell * m->divb[2] + c) << cs | (iya & lm)) << cs) | (ixa & lm));
         }
     }
-    keys[g] = (KeyT)(((unsigned long long)sid << vbits) | k);
+    keys[g] = (KeyT)(((unsigned long long)ls << vbits) | k);
     vals[g] = i;
 }
 // Fused heads + scan + centroids: ONE workgroup per stream walks its sorted (leaf, index) pairs in tiles of 1024, ranks the run
@@ -149,29 +150,29 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int &total)
 template <typename KeyT>
 __global__ __launch_bounds__(S2B_VT) void b_voxel_heads(CSet in, const KeyT *keys_all, int *tile_heads, int ntiles) {
     __shared__ int s_w[16];
-    const int tid = threadIdx.x, sid = blockIdx.y, t = blockIdx.x, n = in.n[sid];
+    const int tid = threadIdx.x, ls = blockIdx.y, sid = cset_sid(in, ls), t = blockIdx.x, n = in.n[sid];
     const int i = t * S2B_VT + tid;
     int head = 0;
     if (t * S2B_VT < n) {
-        const KeyT *keys = keys_all + (size_t)sid * in.cap;
+        const KeyT *keys = keys_all + (size_t)ls * in.cap;
         const int ic = min(i, n - 1);
         const KeyT k = keys[ic], kprev = keys[max(ic - 1, 0)];
         head = (i < n && (i == 0 || kprev != k)) ? 1 : 0;
     }
     int total;
     block_excl_scan_1024(head, s_w, total);
-    if (tid == 0) tile_heads[(size_t)sid * ntiles + t] = total;
+    if (tid == 0) tile_heads[(size_t)ls * ntiles + t] = total;
 }
 template <typename KeyT>
 __global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const KeyT *keys_all, const int *vals_all, CSet out, const int *tile_heads, int ntiles) {
     __shared__ int s_w[16];
-    const int tid = threadIdx.x, sid = blockIdx.y, t = blockIdx.x, n = in.n[sid];
+    const int tid = threadIdx.x, ls = blockIdx.y, sid = cset_sid(in, ls), t = blockIdx.x, n = in.n[sid];
     const int t0 = t * S2B_VT;
     if (t0 >= n) { if (t == 0 && tid == 0) out.n[sid] = 0; return; }
-    const size_t base = (size_t)sid * in.cap;
+    const size_t base = (size_t)ls * in.cap;
     const KeyT *keys = keys_all + base;
     const int *vals = vals_all + base;
-    const float4 *p = in.p + base;
+    const float4 *p = in.p + (size_t)sid * in.cap;
     float4 *o = out.p + (size_t)sid * out.cap;
     const int i = t0 + tid, ic = min(i, n - 1);
     // everything a lane needs for its own element is requested up front (clamped, unconditional loads): the keys before and
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(S2B_VT) void b_voxel_reduce(CSet in, const KeyT *ke
     const float4 q0 = p[vals[ic]];
     int carry = 0;
     {
-        const int *th = tile_heads + (size_t)sid * ntiles;
+        const int *th = tile_heads + (size_t)ls * ntiles;
         for (int u = tid; u < t; u += S2B_VT) carry += th[u];
         if (t > 1) { int tot; block_excl_scan_1024(carry, s_w, tot); carry = tot; __syncthreads(); }   // t <= 1: only lane 0 holds a value ...
         else carry = t == 1 ? th[0] : 0;                                                                // ... which every lane can read itself
@@ -276,7 +277,8 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
     __shared__ float s_mm[6][16];
     __shared__ int s_w2[2][16], s_geo[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
-    const int n = min(in.n[sid], cap);
+    const int n = in.n[sid];
+    if (n > cap) return;                                   // a larger cloud: the global-sort path takes this stream (s2b_step)
     const float4 *p = in.p + (size_t)sid * in.cap;
     float4 *o = out.p + (size_t)sid * out.cap;
     if (n <= 0) { if (tid == 0) out.n[sid] = 0; return; }
@@ -1530,6 +1532,7 @@ struct S2B {
     DBuf nOld, mOld;                                     // map point counts before the append / surviving the crop (unsorted-map path)
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0, muT, tileHeads;
+    DBuf bigmap[2]; std::vector<int> h_big[2];   // streams whose scan cloud does not fit the in-LDS voxel grid (b_scan_voxel): the global-sort path takes them as a sub-batch
     DBuf cid[2], cidAlt[2], cid0[2];   // directory slot of every map point (b_map_update writes it beside the point): cid pairs with map, cidAlt with mapAlt, cid0 with map0
     bool cid_ok[2] = {false, false}, snap_cid_ok[2] = {false, false};   // cid[w] describes map[w] for every stream
     int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending (cell-major) leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
@@ -1553,7 +1556,7 @@ struct S2B {
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &mapAlt[0], &mapAlt[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
                        &bstart[0], &bstart[1], &bcnt, &nOld, &mOld, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
-                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads, &cid[0], &cid[1], &cidAlt[0], &cidAlt[1], &cid0[0], &cid0[1]};
+                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads, &cid[0], &cid[1], &cidAlt[0], &cidAlt[1], &cid0[0], &cid0[1], &bigmap[0], &bigmap[1]};
         for (DBuf *b : all) b->release();
     }
 };
@@ -1589,6 +1592,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
     if (S != c->S) {
         c->release();
         c->S = S; c->capScan[0] = c->capScan[1] = c->capMap[0] = c->capMap[1] = 0; c->work_n = 0; c->has_snapshot = false; c->order_state[0] = c->order_state[1] = 0;
+        c->h_big[0].clear(); c->h_big[1].clear();
         if (!c->pose.ensure((size_t)S * 24 * 8) || !c->res.ensure((size_t)S * sizeof(S2BRes)) || !c->err.ensure((size_t)S * 4) || !c->mm.ensure((size_t)S * sizeof(MinMax)) || !c->nTmp.ensure((size_t)S * 4) || !c->bits.ensure(64) || !c->nOld.ensure((size_t)S * 4) || !c->mOld.ensure((size_t)S * 4) || !c->bcnt.ensure((size_t)S * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemsetAsync(c->bcnt.p, 0, (size_t)S * 4, h->stream));
         for (int w = 0; w < 2; w++) {
@@ -1656,8 +1660,8 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
 
 // keys (PCL leaf index, or the maps' cell-major order when cs >= 0) of every stream's cloud + ONE stable radix sort over all streams: (sorted keys, point indices) land in
 // keys2 / vals2. Host round trip: the key width (and, for *cs_fit, the cloud extents) come back from the device. Returns the key type used through *wide.
-static int s2b_sort_keys(vilf_handle *h, S2B *c, CSet in, float leaf, int cs, int *cs_fit, bool *wide) {
-    const int S = c->S;
+static int s2b_sort_keys(vilf_handle *h, S2B *c, CSet in, float leaf, int cs, int *cs_fit, bool *wide, int nrows = -1) {
+    const int S = nrows < 0 ? c->S : nrows;
     const float inv = 1.0f / leaf;
     int hb[8];
     HIPCHECK(h, hipMemsetAsync(c->bits.p, 0, 32, h->stream));
@@ -1694,11 +1698,11 @@ static int s2b_sort_keys(vilf_handle *h, S2B *c, CSet in, float leaf, int cs, in
 }
 // pcl::VoxelGrid over every stream by ONE global sort: in -> out (device counters), leaves in PCL order (cs < 0: scan clouds too large for the in-LDS grid, b_scan_voxel)
 // or in the maps' cell-major order (cs >= 0: local maps that are not voxel grids yet — b_map_update needs that order)
-static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out, int cs) {
+static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out, int cs, int nrows = -1) {
     bool wide;
-    int rc = s2b_sort_keys(h, c, in, leaf, cs, nullptr, &wide);
+    int rc = s2b_sort_keys(h, c, in, leaf, cs, nullptr, &wide, nrows);
     if (rc != VILF_OK) return rc;
-    const int S = c->S, ntiles = (in.cap + S2B_VT - 1) / S2B_VT;
+    const int S = nrows < 0 ? c->S : nrows, ntiles = (in.cap + S2B_VT - 1) / S2B_VT;
     if (!c->tileHeads.ensure((size_t)S * ntiles * 4)) return VILF_ERR_DEVICE;
     if (!wide) {
         hipLaunchKernelGGL(b_voxel_heads<unsigned int>, dim3(ntiles, S), dim3(S2B_VT), 0, h->stream, in, c->keys2.as<unsigned int>(), c->tileHeads.as<int>(), ntiles);
@@ -1765,13 +1769,29 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     PROF(6)
     const float leaf[2] = {(float)h->opts.edge_leaf_size, (float)h->opts.surf_leaf_size};
     for (int w = 0; w < 2; w++) {
-        if (c->capScan[w] <= SV_MAXPTS24) {    // the cloud fits the LDS: one workgroup per stream does the whole grid, no host round trip
-            const int cap = (c->capScan[w] + 15) & ~15;
+        // the host knows every stream's scan size (vilf_scan2map_batch_set_scan): clouds that fit the LDS get the one-workgroup grid (its layout sized for the largest of them),
+        // the others — if any — go through the global-sort path as a sub-batch (grid row -> stream map), not the whole batch
+        int nmax = 0;
+        std::vector<int> big;
+        for (int i = 0; i < S; i++) { const int n = c->h_nScan[w][i]; if (n > SV_MAXPTS24) big.push_back(i); else nmax = std::max(nmax, n); }
+        if ((int)big.size() < S) {
+            const int cap = (std::max(nmax, 1) + 15) & ~15;
             const size_t stage = (cap * 2 >= 2 * SV_T * 16) ? 0 : (size_t)2 * SV_T * 16;      // small clouds: the tile staging area gets its own LDS
             if (cap <= SV_MAXPTS32) hipLaunchKernelGGL(b_scan_voxel<false>, dim3(S), dim3(SV_T), (size_t)cap * 8 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
             else hipLaunchKernelGGL(b_scan_voxel<true>, dim3(S), dim3(SV_T), (size_t)cap * 7 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
             PROF(0)
-        } else if ((rc = s2b_voxel(h, c, c->cs_scan(w), leaf[w], c->cs_ds(w), -1)) != VILF_OK) return rc;
+        }
+        if (!big.empty()) {
+            if (big != c->h_big[w]) {
+                if (!c->bigmap[w].ensure(big.size() * 4)) return VILF_ERR_DEVICE;
+                HIPCHECK(h, hipMemcpyAsync(c->bigmap[w].p, big.data(), big.size() * 4, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipStreamSynchronize(h->stream));          // `big` is a temporary
+                c->h_big[w] = big;
+            }
+            CSet in = c->cs_scan(w), out = c->cs_ds(w);
+            in.smap = out.smap = c->bigmap[w].as<int>();
+            if ((rc = s2b_voxel(h, c, in, leaf[w], out, -1, (int)big.size())) != VILF_OK) return rc;
+        }
     }
     hipLaunchKernelGGL(b_gate, GRIDS(S), 0, h->stream, c->nMap[0].as<int>(), c->nMap[1].as<int>(), c->nDs[0].as<int>(), c->nDs[1].as<int>(), d_res, d_err, S);
     PROF(6)
