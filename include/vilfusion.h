@@ -264,6 +264,10 @@ int vilf_eval_projection_td(vilf_handle *h, const double *const *parameters, con
                             double *residuals, double **jacobians);                          /* projection_td_factor.cpp:34 */
 int vilf_eval_imu(vilf_handle *h, const double *const *parameters, const vilf_imu_preint *pre,
                   double *residuals, double **jacobians);                                   /* imu_factor.h:19 */
+/* the two parts of that product on their own (test hook): residuals / jacobians BEFORE the multiplication by sqrt_info (imu_factor.h:60-62, 86-173 without the
+ * sqrt_info * ... lines), same layouts, and sqrt_info = LLT(covariance^-1).matrixL()^T (:64) as the device computes it once per upload; any output may be NULL. */
+int vilf_eval_imu_raw(vilf_handle *h, const double *const *parameters, const vilf_imu_preint *pre,
+                      double *residuals, double **jacobians, double *sqrt_info225);
 int vilf_eval_lidar_between(vilf_handle *h, const double *const *parameters,
                             const vilf_lidar_constraint *c, double *residuals, double **jacobians); /* lidar_factor.h:19 */
 int vilf_eval_prior(vilf_handle *h, const vilf_prior *prior, const double *const *parameters,

@@ -272,7 +272,8 @@ bool IMUFactor::Evaluate(double const *const *p, double *residuals, double **jac
     double r[15] = {rp.x, rp.y, rp.z, rq.x, rq.y, rq.z, rv.x, rv.y, rv.z, rba.x, rba.y, rba.z, rbg.x, rbg.y, rbg.z};
 
     double S[225];
-    sqrt_info(pre, S);
+    if (whiten) sqrt_info(pre, S);
+    else for (int i = 0; i < 225; i++) S[i] = (i % 16 == 0) ? 1.0 : 0.0;
     for (int i = 0; i < 15; i++) { double s = 0; for (int k = 0; k < 15; k++) s += S[i * 15 + k] * r[k]; residuals[i] = s; }
 
     if (jacobians) {

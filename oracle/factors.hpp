@@ -57,6 +57,7 @@ struct ProjectionTdFactor : CostFunction {
 struct IMUFactor : CostFunction {
     const vilf_imu_preint *pre;
     V3 G;
+    bool whiten = true;      // false (tests only): residual and Jacobians before the multiplication by sqrt_info — the part of imu_factor.h:60-178 that does not depend on how sqrt_info is computed
     IMUFactor(const vilf_imu_preint *p, V3 G_);
     bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const override;
     // sqrt_info = LLT(covariance^-1).matrixL().transpose()  (imu_factor.h:64)

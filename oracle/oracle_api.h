@@ -30,6 +30,8 @@ int vilo_eval_projection_td(const vilf_options *o, const double *const *paramete
                             const double vel_i[2], const double vel_j[2], double td_i, double td_j, double row_i, double row_j,
                             double *residuals, double **jacobians);
 int vilo_eval_imu(const vilf_options *o, const double *const *parameters, const vilf_imu_preint *pre, double *residuals, double **jacobians);
+/* the same before the multiplication by sqrt_info (residual [15], Jacobians in the same layout): compared on its own, tightly (tests) */
+int vilo_eval_imu_raw(const vilf_options *o, const double *const *parameters, const vilf_imu_preint *pre, double *residuals, double **jacobians);
 int vilo_eval_lidar_between(const vilf_options *o, const double *const *parameters, const vilf_lidar_constraint *c,
                             double *residuals, double **jacobians);
 int vilo_eval_prior(const vilf_prior *prior, const double *const *parameters, double *residuals, double **jacobians);

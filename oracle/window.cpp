@@ -457,6 +457,12 @@ extern "C" int vilo_eval_imu(const vilf_options *o, const double *const *p, cons
     f.Evaluate(p, r, J);
     return VILF_OK;
 }
+extern "C" int vilo_eval_imu_raw(const vilf_options *o, const double *const *p, const vilf_imu_preint *pre, double *r, double **J) {
+    IMUFactor f(pre, V3(o->G));
+    f.whiten = false;
+    f.Evaluate(p, r, J);
+    return VILF_OK;
+}
 extern "C" int vilo_eval_lidar_between(const vilf_options *o, const double *const *p, const vilf_lidar_constraint *c, double *r, double **J) {
     LidarFactor f(c, o);
     f.Evaluate(p, r, J);

@@ -1076,6 +1076,34 @@ extern "C" int vilf_eval_imu(vilf_handle *h, const double *const *p, const vilf_
     return VILF_OK;
 }
 
+// the parts of IMUFactor::Evaluate on their own: residual / Jacobians BEFORE the multiplication by sqrt_info (Ceres layout as above), and the 15 x 15 sqrt_info the device
+// computes once per upload (k_imu_prep) — the tests compare each tightly instead of only their ill-conditioned product
+extern "C" int vilf_eval_imu_raw(vilf_handle *h, const double *const *p, const vilf_imu_preint *pre, double *residuals, double **jac, double *sqrt_info_out) {
+    if (!h || !p || !pre || !residuals) return VILF_ERR_INVALID_ARGUMENT;
+    if (hook_buf(h, 4096) != VILF_OK) return VILF_ERR_DEVICE;
+    double *d = h->d[D_HOOK].as<double>();
+    std::vector<double> in(40 + IMU_REC + 225, 0.0);
+    std::memcpy(&in[0], p[0], 56); std::memcpy(&in[7], p[1], 72); std::memcpy(&in[16], p[2], 56); std::memcpy(&in[23], p[3], 72);
+    for (int i = 0; i < 3; i++) in[32 + i] = h->opts.G[i];
+    pack_imu_rec(pre, &in[40]);
+    std::memcpy(&in[40 + IMU_REC], pre->covariance, 225 * 8);
+    HIPCHECK(h, hipMemcpyAsync(d, in.data(), in.size() * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_imu_prep, dim3(1), dim3(64), 0, h->stream, 1, d + 40 + IMU_REC, d + 1024, d + 40);
+    hipLaunchKernelGGL(k_hook_imu, dim3(1), dim3(64), 0, h->stream, d, d + 7, d + 16, d + 23, d + 40, d + 32, d + 2048, d + 3072);
+    std::vector<double> raw(450 + 15), S(225);
+    HIPCHECK(h, hipMemcpyAsync(raw.data(), d + 3072, raw.size() * 8, hipMemcpyDeviceToHost, h->stream));       // scratch of k_hook_imu: J_raw [15 x 30], r_raw [15]
+    HIPCHECK(h, hipMemcpyAsync(S.data(), d + 40 + IMU_SQRT, 225 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 15; i++) residuals[i] = raw[450 + i];
+    if (jac) {
+        const int off[4] = {0, 6, 15, 21}, loc[4] = {6, 9, 6, 9}, glob[4] = {7, 9, 7, 9};
+        for (int blk = 0; blk < 4; blk++)
+            if (jac[blk]) for (int r = 0; r < 15; r++) { for (int c = 0; c < glob[blk]; c++) jac[blk][glob[blk] * r + c] = (c < loc[blk]) ? raw[30 * r + off[blk] + c] : 0.0; }
+    }
+    if (sqrt_info_out) std::memcpy(sqrt_info_out, S.data(), 225 * 8);
+    return VILF_OK;
+}
+
 extern "C" int vilf_eval_lidar_between(vilf_handle *h, const double *const *p, const vilf_lidar_constraint *c, double *residuals, double **jac) {
     if (!h || !p || !c || !residuals) return VILF_ERR_INVALID_ARGUMENT;
     if (hook_buf(h, 256) != VILF_OK) return VILF_ERR_DEVICE;

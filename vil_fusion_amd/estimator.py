@@ -183,6 +183,15 @@ class BackendSolver:
         self._check(self._L.vilf_eval_imu(self._h, p, C.byref(pre), abi.dptr(r), jp), "vilf_eval_imu")
         return r, jacs
 
+    def eval_imu_raw(self, params, pre):
+        """residual / jacobians before the multiplication by sqrt_info, and the device's sqrt_info [15, 15]"""
+        arrs, p = self._params(params)
+        r = np.zeros(15); S = np.zeros((15, 15))
+        jacs = [np.zeros((15, 7)), np.zeros((15, 9)), np.zeros((15, 7)), np.zeros((15, 9))]
+        jp = (abi.c_double_p * 4)(*[abi.dptr(j) for j in jacs])
+        self._check(self._L.vilf_eval_imu_raw(self._h, p, C.byref(pre), abi.dptr(r), jp, abi.dptr(S)), "vilf_eval_imu_raw")
+        return r, jacs, S
+
     def eval_lidar_between(self, params, c):
         arrs, p = self._params(params)
         r = np.zeros(6)

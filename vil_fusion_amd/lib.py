@@ -13,7 +13,7 @@ EXPORTED = [
     "vilf_default_options", "vilf_create", "vilf_destroy", "vilf_reset", "vilf_last_error", "vilf_version",
     "vilf_window_solve", "vilf_window_marginalize", "vilf_batch_upload", "vilf_batch_solve", "vilf_batch_rewind",
     "vilf_batch_marginalize", "vilf_batch_download", "vilf_batch_download_states", "vilf_batch_summaries", "vilf_synchronize", "vilf_wait_for", "vilf_set_profiling", "vilf_get_profile",
-    "vilf_batch_newest_poses_device", "vilf_prior_export", "vilf_prior_import", "vilf_eval_projection", "vilf_eval_imu",
+    "vilf_batch_newest_poses_device", "vilf_prior_export", "vilf_prior_import", "vilf_eval_projection", "vilf_eval_imu", "vilf_eval_imu_raw",
     "vilf_eval_lidar_between", "vilf_eval_projection_td", "vilf_eval_prior", "vilf_eval_edge", "vilf_eval_surf", "vilf_pose_plus", "vilf_se3_plus",
     "vilf_imu_preintegrate", "vilf_imu_preintegrate_batch", "vilf_visual_imu_alignment", "vilf_posegraph_optimize", "vilf_scan2map_init", "vilf_scan2map_step", "vilf_scan2map_get_map", "vilf_scan2map_set_pose",
     "vilf_scan2map_batch_create", "vilf_scan2map_batch_init", "vilf_scan2map_batch_set_scan", "vilf_scan2map_batch_step", "vilf_scan2map_batch_snapshot",
@@ -68,6 +68,7 @@ def lib():
     L.vilf_prior_import.argtypes = [vp, C.c_int, C.POINTER(abi.Prior)]
     L.vilf_eval_projection.argtypes = [vp, dpp, abi.c_double_p, abi.c_double_p, abi.c_double_p, dpp]
     L.vilf_eval_imu.argtypes = [vp, dpp, C.POINTER(abi.ImuPreint), abi.c_double_p, dpp]
+    L.vilf_eval_imu_raw.argtypes = [vp, dpp, C.POINTER(abi.ImuPreint), abi.c_double_p, dpp, abi.c_double_p]
     L.vilf_eval_lidar_between.argtypes = [vp, dpp, C.POINTER(abi.LidarConstraint), abi.c_double_p, dpp]
     L.vilf_eval_edge.argtypes = [vp, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p, abi.c_double_p]
     L.vilf_eval_surf.argtypes = [vp, abi.c_double_p, abi.c_double_p, abi.c_double_p, C.c_double, abi.c_double_p, abi.c_double_p]
