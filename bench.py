@@ -596,11 +596,13 @@ def main():
         # HBM traffic per launch of the dominant kernel from the committed PMC passes (separate rocprofv3 --pmc runs of this
         # same command; gfx950-corrected as MI355X_MICROARCH.md prescribes) — only when they were taken on this configuration
         traffic = None
+        traffic_raw = None
         try:
             import glob
             pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=_profile_order)[-1]))
             if pmc.get("config", {}).get("frames_per_gpu") == B and pmc["config"].get("workload_tag") == workload_tag:
                 traffic = pmc["groups"][dom]["hbm_bytes_per_launch_corrected"]
+                traffic_raw = pmc["groups"][dom].get("hbm_bytes_per_launch_raw")
         except Exception:
             traffic = None
         # the dense reduce (k_solve_sb) against the fp64 MFMA roofline, counted analytically per window-iteration (no PMC file: a counter pass of an older kernel
@@ -651,7 +653,8 @@ def main():
                        "features_per_window": float(np.mean([w.n_features for w in wins[:args.distinct]])), "max_iterations": int(opts.max_num_iterations),
                        "parallelism": f"{world} x independent window shards (no data-path collective; RCCL all_gather of 64 B poses)"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                         "traffic": traffic, "avg_launch_ms": avg_ms, "launches_per_step": lps[dom], "algorithmic_bytes_per_launch": alg[dom] / max(lps[dom], 1e-9),
+                         "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": "PMC FETCH_SIZE doubled (gfx950: wide coalesced reads are under-counted 2x) + WRITE_SIZE; `traffic_raw` without the doubling — this kernel reads mostly 8-byte operands, the truth lies between",
+                         "avg_launch_ms": avg_ms, "launches_per_step": lps[dom], "algorithmic_bytes_per_launch": alg[dom] / max(lps[dom], 1e-9),
                          "algorithmic_bytes_per_window_iteration": abytes,
                          "whole_iteration": {"ms": it_ms, "achieved": whole_it, "frac": whole_it / 8000.0, "what": "388 KB x windows over the launches of one iteration (k_solve_sb + k_linearize; k_step = the step-only launch that ends a solve, spread over the iterations)"},
                          "kernels_ms": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},

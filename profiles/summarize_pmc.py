@@ -4,9 +4,11 @@
 
     python profiles/summarize_pmc.py <fetch counter_collection.csv> <write counter_collection.csv> <steps incl. warm-up> <out prefix> [frames_per_gpu] [workload_tag]
 
-Counter unit: KB per dispatch. gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-counts wide coalesced reads by 2x,
-so corrected bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; raw = (FETCH_SIZE + WRITE_SIZE) * 1024. Groups are bench.py's launch
-groups (vilf_get_profile*): traffic per group launch = group bytes per step / group launches per step."""
+Counter unit: KB per dispatch. gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE reports exactly half the bytes of a WIDE COALESCED streaming read (16 B per
+lane), so corrected bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024; raw = (FETCH_SIZE + WRITE_SIZE) * 1024. The guide calibrates the factor for that access shape only:
+for the gather kernels (GATHER below: the 5-NN walk, the directory build, the LM solve's factor records, the window kernels' 8-byte operands) "corrected" is an UPPER
+bound and the truth lies between the two figures — both are written side by side. Groups are bench.py's launch groups (vilf_get_profile*): traffic per group launch =
+group bytes per step / group launches per step."""
 import collections
 import csv
 import json
@@ -18,11 +20,13 @@ GROUPS = {   # kernel-name prefix -> bench.py launch group
     "b_minmax": "s2m_voxel_grid", "b_voxel_keys": "s2m_voxel_grid", "void b_voxel_keys": "s2m_voxel_grid", "void b_voxel_reduce": "s2m_voxel_grid",
     "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_voxel_grid",
     "b_check_order": "s2m_voxel_grid", "void b_scan_voxel": "s2m_voxel_grid",
-    "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
+    "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_dir_build": "s2m_neighbour_index", "b_gather_sorted": "s2m_neighbour_index",
+    "b_make_cid": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
     "b_crop_compact": "s2m_submap", "b_transform_append": "s2m_submap", "b_bump": "s2m_submap",
 }
 LAUNCHES_PER_STEP = {"k_linearize": 8, "k_solve": 8, "k_step": 1, "k_marg_prepare": 1, "k_marg_schur": 1, "k_marg_finish": 1, "k_prior_prep": 1,
-                     "s2m_voxel_grid": 4, "s2m_radix_sort": 1, "s2m_neighbour_index": 2, "s2m_associate": 4, "s2m_lm_solve": 2, "s2m_submap": 2}
+                     "s2m_voxel_grid": 4, "s2m_radix_sort": 1, "s2m_neighbour_index": 2, "s2m_associate": 2, "s2m_lm_solve": 2, "s2m_submap": 2}
+GATHER = ("s2m_associate", "s2m_neighbour_index", "s2m_lm_solve", "k_linearize", "k_solve", "k_step", "k_marg_prepare", "k_marg_schur", "k_marg_finish", "k_prior_prep")
 
 
 def group_of(name):
@@ -59,11 +63,14 @@ def main():
             groups[g][0] += fs; groups[g][1] += ws
         if k.startswith(("k_", "b_", "void b_")):
             out["kernels"][k] = {"dispatches": len(f), "FETCH_SIZE_KB_mean": fs / max(len(f), 1), "WRITE_SIZE_KB_mean": ws / max(len(w), 1),
+                                 "hbm_bytes_per_launch_raw": (fs / max(len(f), 1) + ws / max(len(w), 1)) * 1024,
                                  "hbm_bytes_per_launch_corrected": (2 * fs / max(len(f), 1) + ws / max(len(w), 1)) * 1024}
     for g, (fs, ws) in groups.items():
         lps = LAUNCHES_PER_STEP.get(g, 1)
         out["groups"][g] = {"hbm_bytes_per_step_corrected": (2 * fs + ws) * 1024 / steps, "hbm_bytes_per_step_raw": (fs + ws) * 1024 / steps,
-                            "launches_per_step": lps, "hbm_bytes_per_launch_corrected": (2 * fs + ws) * 1024 / steps / lps}
+                            "launches_per_step": lps, "hbm_bytes_per_launch_corrected": (2 * fs + ws) * 1024 / steps / lps,
+                            "hbm_bytes_per_launch_raw": (fs + ws) * 1024 / steps / lps,
+                            "access": "gather / narrow: corrected is an upper bound" if g in GATHER else "wide coalesced streams: corrected applies"}
     json.dump(out, open(prefix + "_pmc_traffic.json", "w"), indent=1)
     with open(prefix + "_pmc_summary.csv", "w") as fh:
         fh.write("kernel,dispatches,mean_FETCH_SIZE_KB,mean_WRITE_SIZE_KB\n")
