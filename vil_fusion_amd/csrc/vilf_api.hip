@@ -184,6 +184,8 @@ extern "C" void vilf_destroy(vilf_handle *h) {
     for (hipEvent_t e : h->prof_free) hipEventDestroy(e);
     if (h->wait_ev) hipEventDestroy(h->wait_ev);
     if (h->stamp_ev) hipEventDestroy(h->stamp_ev);
+    if (h->split_ev) hipEventDestroy(h->split_ev);
+    for (hipStream_t st : h->split_streams) if (st) hipStreamDestroy(st);
     if (h->stamp_pinned) (void)hipHostFree(h->stamp_pinned);
     h->s2m_ev.clear(); h->prof_used.clear(); h->prof_free.clear(); h->prof_pending.clear();
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -523,7 +525,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     VbBatch &b = h->batch;
     std::memset(&b, 0, sizeof(b));
     const vilf_options &o = h->opts;
-    b.B = B; b.Fmax = Fmax; b.Omax = Omax; b.FACmax = FACmax;
+    b.B = B; b.w0 = 0; b.Fmax = Fmax; b.Omax = Omax; b.FACmax = FACmax;
     b.sqrt_info = o.focal_length / 1.5; b.cauchy_b = o.cauchy_a * o.cauchy_a;
     for (int i = 0; i < 3; i++) b.G[i] = o.G[i];
     {   // qil = Quaterniond(RIC*RCL), til = RIC*TCL + TIC (lidar_factor.h:28-29)
@@ -616,6 +618,7 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
     return VILF_OK;
 }
 
+static bool tlim_disabled(vilf_handle *h) { return !(h->opts.max_solver_time > 0); }
 extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, hipSetDevice(h->device));
@@ -660,6 +663,40 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     std::vector<hipEvent_t> pev;
     auto mark = [&](int kind) { if (prof) { pev.push_back(vilf_prof_event(h)); ne++; kinds.push_back(kind); } };
     hipEventRecord(h->ev0, h->stream);
+    h->batch.w0 = 0;
+    // Experiment (VILF_SOLVE_SPLIT=n): the batch as n parts on n streams, each part running its own chain of launches. The two kernels of an iteration then meet on the
+    // chip (one part's k_solve_sb beside another part's k_linearize) instead of the whole chip running one kernel at a time.
+    if (const char *es = std::getenv("VILF_SOLVE_SPLIT")) {
+        const int np = std::max(2, std::min(8, std::atoi(es)));
+        if (!dense && tlim_disabled(h) && h->B >= 2 * np) {
+            if ((int)h->split_streams.size() < np) { h->split_streams.resize(np, nullptr); for (auto &st : h->split_streams) if (!st) HIPCHECK(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); }
+            if (!h->split_ev) HIPCHECK(h, hipEventCreateWithFlags(&h->split_ev, hipEventDisableTiming));
+            HIPCHECK(h, hipEventRecord(h->split_ev, h->stream));
+            for (int p = 0; p < np; p++) {
+                hipStream_t st = h->split_streams[p];
+                HIPCHECK(h, hipStreamWaitEvent(st, h->split_ev, 0));
+                VbBatch bb = h->batch;
+                bb.w0 = (int)((long long)h->B * p / np);
+                const dim3 g2((unsigned)((long long)h->B * (p + 1) / np - bb.w0));
+                hipLaunchKernelGGL(k_reset, g2, block, 0, st, bb, 0);
+                hipLaunchKernelGGL(k_linearize, g2, block, h->lin_lds, st, bb, 1);
+                for (int it = 0; it < h->opts.max_num_iterations; it++) {
+                    hipLaunchKernelGGL(k_solve_sb, g2, dim3(256), h->solve_sb_lds, st, bb);
+                    if (it + 1 == h->opts.max_num_iterations) hipLaunchKernelGGL(k_linearize_last, g2, block, h->lin_lds, st, bb);
+                    else hipLaunchKernelGGL(k_linearize, g2, block, h->lin_lds, st, bb, 0);
+                }
+                hipLaunchKernelGGL(k_finalize, g2, dim3(64), 0, st, bb);
+            }
+            for (int p = 0; p < np; p++) {                       // join: the handle's stream continues after every part
+                HIPCHECK(h, hipEventRecord(h->split_ev, h->split_streams[p]));
+                HIPCHECK(h, hipStreamWaitEvent(h->stream, h->split_ev, 0));
+            }
+            hipEventRecord(h->ev1, h->stream);
+            HIPCHECK(h, hipGetLastError());
+            if (sync) { HIPCHECK(h, hipStreamSynchronize(h->stream)); float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->last_solve_usec = ms * 1000.0; }
+            return VILF_OK;
+        }
+    }
     mark(3);
     hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
     mark(0);

@@ -125,6 +125,7 @@ struct VbMarg {
 
 struct VbBatch {
     int B, Fmax, Omax, FACmax;
+    int w0;                 // first window of this launch (a batch may be enqueued in parts: window = blockIdx.x + w0)
     // options
     double sqrt_info, cauchy_b, G[3];
     double qil[4], til[3];  // RIC*RCL as quaternion (xyzw), RIC*TCL+TIC (lidar_factor.h:28-29)

@@ -96,6 +96,7 @@ struct vilf_handle {
     struct ProfSpan { hipEvent_t a, b; double *ms; long *cnt; };
     std::vector<ProfSpan> prof_pending;
     std::vector<hipEvent_t> prof_used, prof_free;
+    std::vector<hipStream_t> split_streams; hipEvent_t split_ev = nullptr;    // VILF_SOLVE_SPLIT experiment: the batch in parts on their own streams
     hipEvent_t wait_ev = nullptr;            // vilf_wait_for
     void *stamp_pinned = nullptr; size_t stamp_cap = 0; hipEvent_t stamp_ev = nullptr;   // vilf_batch_newest_poses_device: pinned staging of the caller's stamps
     double kernel_ms[4] = {0, 0, 0, 0};      // linearize, solve, step, other (accumulated since last reset)

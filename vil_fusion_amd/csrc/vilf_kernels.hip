@@ -242,7 +242,7 @@ __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the
 // so it only takes the step: candidate, cost of every factor (residuals only), accept / reject — a ninth of the linearisations of a solve.
 template <bool JAC>
 __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_zero) {
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int w = blockIdx.x + b.w0, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     VbState *st = b.st + w;
     if (!iteration_zero && st->done) return;
     // Two linearisation workspaces per window. Iteration zero fills set 0 at the initial state. Later launches ARE the trust-region step (what k_step was): they form
@@ -935,7 +935,7 @@ __device__ __forceinline__ void feature_dots(const double *W, int F, const doubl
 }
 
 extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int w = blockIdx.x + b.w0, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     VbState *st = b.st + w;
     extern __shared__ double s_dyn[];
     double *s_T = s_dyn;                      // 66 tiles * 256
@@ -1535,7 +1535,7 @@ __device__ __forceinline__ bool sb_potrf9(double *Dp, double *linv, int lane) {
 }
 // one gather entry of the chain / band tables: (meta, src0, src1, -) -> scaled value + LM term, Cauchy-point contribution
 extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = blockIdx.x + b.w0, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     VbState *st = b.st + w;
     extern __shared__ double s_dyn[];
     double *s_P = s_dyn + SB_OFF_P, *s_D = s_dyn + SB_OFF_D, *s_E = s_dyn + SB_OFF_E, *s_band = s_dyn + SB_OFF_BAND;
@@ -2189,7 +2189,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
 // ------------------------------------------------------------------------------------------------------------------
 // double2vector(): yaw / position gauge fix of the whole window (estimator.cpp:549-596)
 extern "C" __global__ void k_finalize(VbBatch b) {
-    const int w = blockIdx.x, tid = threadIdx.x;
+    const int w = blockIdx.x + b.w0, tid = threadIdx.x;
     if (tid >= VB_NF) return;
     const double *pose = b.pose + (size_t)w * 77, *sb = b.sb + (size_t)w * 99;
     const double *R0b = b.gauge_R0 + (size_t)w * 9, *P0b = b.gauge_P0 + (size_t)w * 3;
@@ -2220,7 +2220,7 @@ extern "C" __global__ void k_finalize(VbBatch b) {
 // options.max_solver_time reached (host clock, vilf_batch_solve): the windows still iterating stop as Ceres does at the top of an iteration —
 // termination NO_CONVERGENCE, state = last accepted point. only_margin_old: the 4/5 limit of the windows that marginalize the oldest frame (estimator.cpp:847-850)
 extern "C" __global__ void k_time_limit(VbBatch b, const int *mflag, int only_margin_old) {
-    const int w = blockIdx.x;
+    const int w = blockIdx.x + b.w0;
     if (threadIdx.x) return;
     if (only_margin_old && mflag[w] != 0) return;
     VbState *st = b.st + w;
@@ -2229,7 +2229,7 @@ extern "C" __global__ void k_time_limit(VbBatch b, const int *mflag, int only_ma
 
 // reset of the per-window solver state (≙ TrustRegionMinimizer::Init + DoglegStrategy ctor) and state rewind
 extern "C" __global__ void k_reset(VbBatch b, int rewind_state) {
-    const int w = blockIdx.x, tid = threadIdx.x;
+    const int w = blockIdx.x + b.w0, tid = threadIdx.x;
     if (rewind_state) {
         if (tid < 77) b.pose[(size_t)w * 77 + tid] = b.pose_init[(size_t)w * 77 + tid];
         if (tid < 99) b.sb[(size_t)w * 99 + tid] = b.sb_init[(size_t)w * 99 + tid];
