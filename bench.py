@@ -269,6 +269,8 @@ def main():
         seeds = [7000 + 31 * rank + k for k in range(args.distinct_lidar)]
         nproc = max(1, min(len(seeds), (os.cpu_count() or 1) // max(1, min(world, 8))))
         try:
+            if len(seeds) <= 4:                    # few scenes (profile runs: a counter-collecting profiler has initialised the GPU before python starts — no fork then)
+                raise RuntimeError("serial")
             import multiprocessing as mp
             with mp.get_context("fork").Pool(nproc) as pool:
                 raw_lidar = pool.map(_synth.make_lidar_bench_case, seeds)
