@@ -518,8 +518,33 @@ __device__ __forceinline__ bool mu_leaf(const float4 q, float inv, int cs, unsig
     k = ok ? (((iy >> cs) << (2 * AXB + cs)) | ((ix >> cs) << (AXB + 2 * cs)) | (iz << (2 * cs)) | ((iy & lm) << cs) | (ix & lm)) : 0ULL;
     return ok;
 }
-// the directory slot (dir_slot: nine low bits of the cell's row and column) of a cell-major key — what b_dir_build needs of an output point. The sweep writes it next to
-// every point it emits (cid), so that the directory of the NEXT step is built from 4 bytes per point instead of the points themselves.
+// ---- the neighbour directory's constants and slot arithmetic (the design: see "radix-hashed voxel neighbour index" below)
+#define S2B_DB 9
+#define S2B_NB (1 << (2 * S2B_DB))
+#define S2B_NBS (S2B_NB + 4)
+#define S2B_DMARGIN 8
+#define S2B_LOFF 65536
+#define S2B_QR 1.001f        // search radius in metres: the reference's gate is 1 (squared distance < 1); the margin covers the rounding of q -+ 1 and of the squared distance
+__device__ __forceinline__ int cm_leaf(float v, float inv) { return (int)floorf(__fmul_rn(v, inv)) + S2B_LOFF; }
+__device__ __forceinline__ int dir_slot(int cy, int cx) { return ((cy & 511) << S2B_DB) | (cx & 511); }
+// One point of the cell-major array: (cy, cx) its cell's row / column modulo 512, (cyp, cxp) its predecessor's. Differences are taken modulo 512 too: a map spans fewer cells.
+__device__ __forceinline__ void dir_point(unsigned *T, unsigned tag, int i, int n, int cy, int cx, int cyp, int cxp) {
+    if (i == n - 1) for (int c = cx + 1; c <= cx + S2B_DMARGIN; c++) T[dir_slot(cy, c)] = tag | (unsigned)n;
+    const bool first = i == 0, newrow = first || cy != cyp;
+    if (!newrow && cx == cxp) return;
+    const unsigned v = tag | (unsigned)i;
+    // a long run of empty cells inside a row is treated like a row break: S2B_DMARGIN cells behind the previous occupied cell and S2B_DMARGIN in front of this one are
+    // filled, the slots in between keep their old tag (a span can only end there if it holds no occupied cell — it then reads as empty, which it is)
+    const int gapfull = ((cx - cxp) & 511) - 1;
+    const bool brk = newrow || gapfull > 2 * S2B_DMARGIN;
+    const int gap = brk ? S2B_DMARGIN : gapfull;                              // cells to fill before this one
+    for (int c = cx - gap; c <= cx; c++) T[dir_slot(cy, c)] = v;
+    if (brk && !first) for (int c = cxp + 1; c <= cxp + S2B_DMARGIN; c++) T[dir_slot(cyp, c)] = v;
+}
+// the directory slot (dir_slot: nine low bits of the cell's row and column) of a cell-major key. b_map_update writes the directory of the map it emits — the index of
+// the NEXT step — itself: an emitted point whose predecessor in the output is known in the sweep (the usual case: the previous old point survives the crop and no new
+// leaf falls between the two) compares the two cells on the spot and, when they differ, fills the slots exactly as b_dir_build would (dir_point); every other emitted
+// point (first of the map, behind a cropped point, new leaves, merged leaves) goes on a short list that is resolved from the written map after the sweep.
 template <int AXB>
 __device__ __forceinline__ unsigned mu_cid(unsigned long long k, int cs) {
     const int adj = (65536 - (1 << (AXB - 1))) >> cs;              // the directory counts cells from leaf offset 65536 (cm_leaf), the key from 2^(AXB-1)
@@ -539,7 +564,7 @@ __device__ __forceinline__ float4 mu_centroid(const float4 *ts, int a, int e) {
 // previous old key and this one, a tail run in this leaf, or a leaf that holds several old points. Such points are queued during the
 // sweep and handled afterwards, one per lane, from global memory — their dependent loads never sit on the sweep's critical path.
 template <int AXB, int IDXB>
-__device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool between, int jlo, int nOld, const float4 *p, float4 *o, unsigned *cid, const float4 *ts, const unsigned long long *T,
+__device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool between, int jlo, int nOld, const float4 *p, float4 *o, int *fixq, int *s_fn, const float4 *ts, const unsigned long long *T,
                                         int ntv, int THtot, float inv, int cs, const MuBox &box) {
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
     auto lower = [&](unsigned long long k) { int lo = 0, hi = ntv; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((T[mid] >> IDXB) < k) lo = mid + 1; else hi = mid; } return lo; };
@@ -557,13 +582,13 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool bet
             const unsigned long long lf = T[jj] >> IDXB;
             int f = jj + 1;
             while (f < jlo && (T[f] >> IDXB) == lf) f++;
-            o[H + thp(jj) - M] = mu_centroid(ts, jj, f); cid[H + thp(jj) - M] = mu_cid<AXB>(lf, cs);
+            o[H + thp(jj) - M] = mu_centroid(ts, jj, f); fixq[atomicAdd(s_fn, 1)] = H + thp(jj) - M;
             jj = f;
         }
         if (tm && !sv) {                                     // the tail has this leaf; the old run may have no survivor at all -> a new leaf
             bool any = false;
             for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, cs, kr); if (kr != key) break; if (mu_inside(r, box)) { any = true; break; } }
-            if (!any) { o[H + thp(jlo) - M] = mu_centroid(ts, jlo, jup); cid[H + thp(jlo) - M] = mu_cid<AXB>(key, cs); }
+            if (!any) { o[H + thp(jlo) - M] = mu_centroid(ts, jlo, jup); fixq[atomicAdd(s_fn, 1)] = H + thp(jlo) - M; }
         }
     }
     if (head) {
@@ -572,11 +597,11 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool bet
         for (int b = i + 1; b < nOld; b++) { const float4 r = p[b]; unsigned long long kr; mu_leaf<AXB>(r, inv, cs, kr); if (kr != key) break; if (mu_inside(r, box)) { mu_acc(s, r); cnt++; } }
         for (int jj = jlo; jj < jup; jj++) { mu_acc(s, ts[jj]); cnt++; }
         const float nn = (float)cnt;
-        o[H + thp(jlo) - M] = make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn); cid[H + thp(jlo) - M] = mu_cid<AXB>(key, cs);
+        o[H + thp(jlo) - M] = make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn); fixq[atomicAdd(s_fn, 1)] = H + thp(jlo) - M;
     }
 }
 template <bool BIG>
-__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, int cs, CSet out, unsigned *cid_all, float4 *ts_all, int ts_stride,
+__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, int cs, CSet out, unsigned *dir_all, unsigned dtag, int *fix_all, float4 *ts_all, int ts_stride,
                                                        unsigned long long *gT_all, int gT_stride, int lds_lo, int lds_cap, int *gq_all, size_t gq_stride, int *err) {
     constexpr int AXB = BIG ? 16 : 17, IDXB = BIG ? 16 : 13;
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
@@ -588,7 +613,8 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     unsigned long long *T = BIG ? gT_all + (size_t)sid * gT_stride : s_T;
     const float4 *p = map.p + (size_t)sid * map.cap;
     float4 *o = out.p + (size_t)sid * out.cap;
-    unsigned *cid = cid_all + (size_t)sid * out.cap;
+    unsigned *Tdir = dir_all + (size_t)sid * S2B_NBS;          // the directory of the map this launch emits
+    int *fixq = fix_all + (size_t)sid * out.cap;               // positions of emitted points whose predecessor the sweep does not know
     float4 *ts = ts_all + (size_t)sid * ts_stride;
     const double *pose = pose_all + 24 * sid;
     MuBox box;
@@ -675,9 +701,9 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
     unsigned long long *s_key = s_T + (BIG ? 0 : lds_cap);
     int *s_te = reinterpret_cast<int *>(s_key + MU_TILE);
     int *gq = gq_all + (size_t)sid * gq_stride;      // queue of uncommon points in global memory (4 ints each: index | head bit 30 | between bit 29, H, M, lower bound in the tail): room for every old point
-    __shared__ int s_qn;
+    __shared__ int s_qn, s_fn;
     __shared__ unsigned long long s_nk;
-    if (tid == 0) s_qn = 0;
+    if (tid == 0) { s_qn = 0; s_fn = 0; }
     constexpr unsigned long long SVB = 1ULL << 63;
     int carryH = 0, carryM = 0, carryTE = 0;
     unsigned long long carryK = 0;
@@ -782,8 +808,17 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
                 reinterpret_cast<int4 *>(gq)[k] = make_int4((t0 + e) | (((hm >> u) & 1) << 30) | (btw ? (1 << 29) : 0), H, M, lo[u]);
             }
             else if ((hm >> u) & 1) {                                // the common case: the old point is its leaf's centroid, sum from +0 as the reference does
-                o[H + tb[u] - M] = make_float4(__fadd_rn(0.0f, q[u].x), __fadd_rn(0.0f, q[u].y), __fadd_rn(0.0f, q[u].z), __fadd_rn(0.0f, q[u].w));
-                cid[H + tb[u] - M] = mu_cid<AXB>(key[u], cs);
+                const int pos = H + tb[u] - M;
+                o[pos] = make_float4(__fadd_rn(0.0f, q[u].x), __fadd_rn(0.0f, q[u].y), __fadd_rn(0.0f, q[u].z), __fadd_rn(0.0f, q[u].w));
+                // directory: the previous old point survives (its leaf is in the output) and no new leaf lies between -> that leaf's output is this point's predecessor
+                const unsigned long long wp6 = e > 0 ? s_key[e - 1] : carryK;
+                // (only the two cheap cases are settled here — same cell: nothing to write; the next cell of the same row: one store. Gaps and row starts mean loops
+                // of stores, which a sixteen-wave workgroup between two barriers pays sixteen-fold: they go on the list with the rest.)
+                const unsigned cme = mu_cid<AXB>(key[u], cs), cpr = mu_cid<AXB>(wp6 & ~SVB, cs);
+                const bool known = t0 + e > 0 && (wp6 & SVB) && !btw;
+                if (known && cme == cpr) { }
+                else if (known && cme == cpr + 1u && (cme & 511u) != 0u) Tdir[cme] = dtag | (unsigned)pos;
+                else fixq[atomicAdd(&s_fn, 1)] = pos;
             }
         }
         const int nextTE = s_te[MU_TILE - 1];
@@ -800,7 +835,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         const int qn = s_qn;
         for (int k = tid; k < qn; k += MU_T) {
             const int4 e = reinterpret_cast<const int4 *>(gq)[k];
-            mu_rare<AXB, IDXB>(e.x & 0x1fffffff, e.y, e.z, (e.x >> 30) & 1, (e.x >> 29) & 1, e.w, nOld, p, o, cid, ts, T, ntv, THtot, inv, cs, box);
+            mu_rare<AXB, IDXB>(e.x & 0x1fffffff, e.y, e.z, (e.x >> 30) & 1, (e.x >> 29) & 1, e.w, nOld, p, o, fixq, &s_fn, ts, T, ntv, THtot, inv, cs, box);
         }
     }
     __syncthreads();
@@ -813,14 +848,28 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         if (jj > jlast && (T[jj - 1] >> IDXB) == lf) continue;
         int e = jj + 1;
         while (e < ntv && (T[e] >> IDXB) == lf) e++;
-        o[carryH + thp(jj) - carryM] = mu_centroid(ts, jj, e); cid[carryH + thp(jj) - carryM] = mu_cid<AXB>(lf, cs);
+        o[carryH + thp(jj) - carryM] = mu_centroid(ts, jj, e); fixq[atomicAdd(&s_fn, 1)] = carryH + thp(jj) - carryM;
     }
     S2M_STAMP(skid, 4, true);
 #ifdef VILF_STAMPS
     if (blockIdx.x == S2M_STAMP_WG && tid == 0) { s2m_dbg[skid * 32 + 30] = nOld; s2m_dbg[skid * 32 + 29] = nt; s2m_dbg[skid * 32 + 28] = s_qn; }
 #endif
-    if (tid == 0) out.n[sid] = carryH + THtot - carryM;
+    const int n_out = carryH + THtot - carryM;
+    if (tid == 0) out.n[sid] = n_out;
     if (bad) atomicOr(err + sid, bad);
+    // ---- the directory entries the sweep could not write: predecessor and own cell from the emitted map (this workgroup's own stores: visible after the barrier)
+    __threadfence_block();
+    __syncthreads();
+    for (int k = tid; k < s_fn; k += MU_T) {
+        const int pos = fixq[k];
+        const float4 a = o[pos], ap = o[max(pos - 1, 0)];
+        dir_point(Tdir, dtag, pos, n_out, (cm_leaf(a.y, inv) >> cs) & 511, (cm_leaf(a.x, inv) >> cs) & 511, (cm_leaf(ap.y, inv) >> cs) & 511, (cm_leaf(ap.x, inv) >> cs) & 511);
+    }
+    if (tid == 0 && n_out > 0) {                      // the margin behind the last point (its own thread may have resolved it in the sweep, where the count was not known yet)
+        const float4 a = o[n_out - 1];
+        const int cy = (cm_leaf(a.y, inv) >> cs) & 511, cx = (cm_leaf(a.x, inv) >> cs) & 511;
+        for (int c = cx + 1; c <= cx + S2B_DMARGIN; c++) Tdir[dir_slot(cy, c)] = dtag | (unsigned)n_out;
+    }
 }
 // the old maps of every stream are in non-decreasing leaf order with leaf coordinates inside the AXB-bit range? flag[0] |= 1 if not
 __global__ void b_check_order(CSet map, float inv, int cs, int axb, int *flag) {
@@ -848,26 +897,7 @@ __global__ void b_check_order(CSet map, float inv, int cs, int axb, int *flag) {
 // in between, and S2B_DMARGIN cells before the first / after the last cell of a row, so that a span that touches an occupied cell always finds both its
 // ends). No sort, no copy of the map, no pass over the table. Maps wider than 512 - 2 S2B_DMARGIN cells would alias: the host picks cs so that the crop box
 // fits (s2b_cell_shift), and for a map that is not a voxel grid yet (as initialised) from the cloud's extent.
-#define S2B_DB 9
-#define S2B_NB (1 << (2 * S2B_DB))
-#define S2B_NBS (S2B_NB + 4)
-#define S2B_DMARGIN 8
-#define S2B_LOFF 65536
-#define S2B_QR 1.001f        // search radius in metres: the reference's gate is 1 (squared distance < 1); the margin covers the rounding of q -+ 1 and of the squared distance
-__device__ __forceinline__ int cm_leaf(float v, float inv) { return (int)floorf(__fmul_rn(v, inv)) + S2B_LOFF; }
-__device__ __forceinline__ int dir_slot(int cy, int cx) { return ((cy & 511) << S2B_DB) | (cx & 511); }
-// One point of the cell-major array: (cy, cx) its cell's row / column modulo 512, (cyp, cxp) its predecessor's. Differences are taken modulo 512 too: a map spans fewer cells.
-__device__ __forceinline__ void dir_point(unsigned *T, unsigned tag, int i, int n, int cy, int cx, int cyp, int cxp) {
-    if (i == n - 1) for (int c = cx + 1; c <= cx + S2B_DMARGIN; c++) T[dir_slot(cy, c)] = tag | (unsigned)n;
-    const bool first = i == 0, newrow = first || cy != cyp;
-    if (!newrow && cx == cxp) return;
-    const unsigned v = tag | (unsigned)i;
-    const int gap = newrow ? S2B_DMARGIN : ((cx - cxp) & 511) - 1;            // cells to fill before this one
-    for (int c = cx - gap; c <= cx; c++) T[dir_slot(cy, c)] = v;
-    if (newrow && !first) for (int c = cxp + 1; c <= cxp + S2B_DMARGIN; c++) T[dir_slot(cyp, c)] = v;
-}
-#define DIR_PT 8            // points per thread: every load of a thread is issued before the first is used (one load in flight per lane left the kernel waiting on memory latency),
-                            // and a block covers 2048 points — the grid is sized for the capacity, most of its blocks exit at once
+#define DIR_PT 8            // points per thread: every load of a thread is issued before the first is used, and a block covers 2048 points (the grid is sized for the capacity)
 // pts: the map in cell-major order (or the cell-major-sorted copy of a map that is not a voxel grid yet), n points per stream
 __global__ void b_dir_build(const float4 *pts_all, const int *n_all, int cap, float inv, int cs, unsigned tag, unsigned *dir_all) {
     const int sid = blockIdx.y, n = min(n_all[sid], cap), i0 = blockIdx.x * DIR_PT * blockDim.x + threadIdx.x;
@@ -886,28 +916,6 @@ __global__ void b_dir_build(const float4 *pts_all, const int *n_all, int cap, fl
         const int i = i0 + u * (int)blockDim.x;
         if (i < n) dir_point(T, tag, i, n, (cm_leaf(q[u].y, inv) >> cs) & 511, (cm_leaf(q[u].x, inv) >> cs) & 511, (cm_leaf(qp[u].y, inv) >> cs) & 511, (cm_leaf(qp[u].x, inv) >> cs) & 511);
     }
-}
-// the same from the slots the map update wrote beside the points (cid): 4 bytes per point instead of 16
-__global__ void b_dir_build_cid(const unsigned *cid_all, const int *n_all, int cap, unsigned tag, unsigned *dir_all) {
-    const int sid = blockIdx.y, n = min(n_all[sid], cap), i0 = blockIdx.x * DIR_PT * blockDim.x + threadIdx.x;
-    if (i0 >= n) return;
-    const unsigned *cid = cid_all + (size_t)sid * cap;
-    unsigned *T = dir_all + (size_t)sid * S2B_NBS;
-    unsigned a[DIR_PT], ap[DIR_PT];
-#pragma unroll
-    for (int u = 0; u < DIR_PT; u++) { const int ic = min(i0 + u * (int)blockDim.x, n - 1); a[u] = cid[ic]; ap[u] = cid[max(ic - 1, 0)]; }
-#pragma unroll
-    for (int u = 0; u < DIR_PT; u++) {
-        const int i = i0 + u * (int)blockDim.x;
-        if (i < n) dir_point(T, tag, i, n, (int)(a[u] >> 9), (int)(a[u] & 511), (int)(ap[u] >> 9), (int)(ap[u] & 511));
-    }
-}
-// cid of a map that did not come out of b_map_update (uploaded, or voxelised by the global sort)
-__global__ void b_make_cid(const float4 *pts_all, const int *n_all, int cap, float inv, int cs, unsigned *cid_all) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x, sid = blockIdx.y;
-    if (i >= min(n_all[sid], cap)) return;
-    const float4 q = pts_all[(size_t)sid * cap + i];
-    cid_all[(size_t)sid * cap + i] = (unsigned)dir_slot(cm_leaf(q.y, inv) >> cs, cm_leaf(q.x, inv) >> cs);
 }
 // the cell-major-sorted copy of a map that is not a voxel grid yet: point vals[g] of the stream to position g, its index in w (ties of the 5-NN go by it)
 __global__ void b_gather_sorted(CSet in, const int *vals_all, float4 *sorted_all) {
@@ -1533,8 +1541,11 @@ struct S2B {
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0, muT, tileHeads;
     DBuf bigmap[2]; std::vector<int> h_big[2];   // streams whose scan cloud does not fit the in-LDS voxel grid (b_scan_voxel): the global-sort path takes them as a sub-batch
-    DBuf cid[2], cidAlt[2], cid0[2];   // directory slot of every map point (b_map_update writes it beside the point): cid pairs with map, cidAlt with mapAlt, cid0 with map0
-    bool cid_ok[2] = {false, false}, snap_cid_ok[2] = {false, false};   // cid[w] describes map[w] for every stream
+    // The neighbour directory travels with its map: bstart pairs with map, bstartAlt with mapAlt (the map update writes the directory of the map it emits), dir0 with map0.
+    DBuf bstartAlt[2], dir0[2], fixq[2];
+    bool dir_ok[2] = {false, false}, snap_dir_ok[2] = {false, false};      // bstart[w] is the directory of map[w] for every stream (tag dir_tag[w])
+    unsigned dir_tag[2] = {0, 0}, snap_dir_tag[2] = {0, 0};
+    unsigned next_tag() { epoch++; return (epoch % 255u + 1u) << 24; }
     int order_state[2] = {0, 0}, snap_order[2] = {0, 0};   // local maps in ascending (cell-major) leaf order? 0 unknown, 1 yes (every step leaves them so), 2 no (as initialised)
     int cs_cfg[2] = {0, 0};            // cell shift of the maps' cell-major order (s2b_cell_shift of the leaf size and the crop box)
     int cs_idx[2] = {0, 0};            // ... of this step's neighbour directory (larger for an unordered map whose extent needs it)
@@ -1556,7 +1567,7 @@ struct S2B {
     void release() {
         DBuf *all[] = {&scan[0], &scan[1], &nScan[0], &nScan[1], &ds[0], &ds[1], &nDs[0], &nDs[1], &map[0], &map[1], &mapAlt[0], &mapAlt[1], &nMap[0], &nMap[1], &tmpB, &nTmp, &sorted[0], &sorted[1],
                        &bstart[0], &bstart[1], &bcnt, &nOld, &mOld, &keys, &keys2, &vals, &vals2, &temp, &mm, &frec, &fkind, &pose, &res, &err, &bits,
-                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads, &cid[0], &cid[1], &cidAlt[0], &cidAlt[1], &cid0[0], &cid0[1], &bigmap[0], &bigmap[1]};
+                       &map0[0], &map0[1], &nMap0[0], &nMap0[1], &pose0, &muT, &tileHeads, &bstartAlt[0], &bstartAlt[1], &dir0[0], &dir0[1], &fixq[0], &fixq[1], &bigmap[0], &bigmap[1]};
         for (DBuf *b : all) b->release();
     }
 };
@@ -1597,7 +1608,10 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         HIPCHECK(h, hipMemsetAsync(c->bcnt.p, 0, (size_t)S * 4, h->stream));
         for (int w = 0; w < 2; w++) {
             if (!c->nScan[w].ensure((size_t)S * 4) || !c->nDs[w].ensure((size_t)S * 4) || !c->nMap[w].ensure((size_t)S * 4) || !c->bstart[w].ensure((size_t)S * S2B_NBS * 4)) return VILF_ERR_DEVICE;
+            if (!c->bstartAlt[w].ensure((size_t)S * S2B_NBS * 4)) return VILF_ERR_DEVICE;
             HIPCHECK(h, hipMemsetAsync(c->bstart[w].p, 0, (size_t)S * S2B_NBS * 4, h->stream));      // tag 0: no slot is valid yet
+            HIPCHECK(h, hipMemsetAsync(c->bstartAlt[w].p, 0, (size_t)S * S2B_NBS * 4, h->stream));
+            c->dir_ok[w] = false;
             c->h_cmn[w].assign(S, 0);
             c->cs_cfg[w] = s2b_cell_shift((float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), h->opts.s2m_crop_half);
             HIPCHECK(h, hipMemsetAsync(c->nScan[w].p, 0, (size_t)S * 4, h->stream));
@@ -1635,8 +1649,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
             c->map[w] = nb;
             c->capMap[w] = nc; grew = true; c->has_snapshot = false; c->snap_live = false;
             if (!c->sorted[w].ensure((size_t)S * nc * 16) || !c->mapAlt[w].ensure((size_t)S * nc * 16)) return VILF_ERR_DEVICE;
-            if (!c->cid[w].ensure((size_t)S * nc * 4) || !c->cidAlt[w].ensure((size_t)S * nc * 4)) return VILF_ERR_DEVICE;
-            c->cid_ok[w] = false;
+            if (!c->fixq[w].ensure((size_t)S * nc * 4)) return VILF_ERR_DEVICE;
         }
     }
     if (grew) {
@@ -1720,9 +1733,9 @@ static int s2b_voxel(vilf_handle *h, S2B *c, CSet in, float leaf, CSet out, int 
 static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
     CSet map = c->cs_map(w);
     const float leaf = (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
-    const unsigned tag = (c->epoch % 255u + 1u) << 24;
-    const float4 *arr = map.p;
     c->cs_idx[w] = c->cs_cfg[w]; c->idx_copy[w] = false;
+    if (c->order_state[w] == 1 && c->dir_ok[w]) return VILF_OK;        // the map update that emitted this map wrote its directory: nothing to do
+    const float4 *arr = map.p;
     if (c->order_state[w] != 1) {
         bool wide;
         int rc = s2b_sort_keys(h, c, map, leaf, c->cs_cfg[w], &c->cs_idx[w], &wide);
@@ -1730,9 +1743,10 @@ static int s2b_build_index(vilf_handle *h, S2B *c, int w) {
         hipLaunchKernelGGL(b_gather_sorted, GRID2(map.cap, c->S), 0, h->stream, map, c->vals2.as<int>(), c->sorted[w].as<float4>());
         arr = c->sorted[w].as<float4>(); c->idx_copy[w] = true;
     }
+    c->dir_tag[w] = c->next_tag();
     const dim3 dgrid((map.cap + 256 * DIR_PT - 1) / (256 * DIR_PT), c->S);
-    if (!c->idx_copy[w] && c->cid_ok[w]) hipLaunchKernelGGL(b_dir_build_cid, dgrid, dim3(256), 0, h->stream, c->cid[w].as<unsigned>(), map.n, map.cap, tag, c->bstart[w].as<unsigned>());
-    else hipLaunchKernelGGL(b_dir_build, dgrid, dim3(256), 0, h->stream, arr, map.n, map.cap, 1.0f / leaf, c->cs_idx[w], tag, c->bstart[w].as<unsigned>());
+    hipLaunchKernelGGL(b_dir_build, dgrid, dim3(256), 0, h->stream, arr, map.n, map.cap, 1.0f / leaf, c->cs_idx[w], c->dir_tag[w], c->bstart[w].as<unsigned>());
+    c->dir_ok[w] = !c->idx_copy[w];         // (a directory over the sorted copy of an unordered map serves this step only)
     PROF(2)
     return VILF_OK;
 }
@@ -1795,7 +1809,6 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     }
     hipLaunchKernelGGL(b_gate, GRIDS(S), 0, h->stream, c->nMap[0].as<int>(), c->nMap[1].as<int>(), c->nDs[0].as<int>(), c->nDs[1].as<int>(), d_res, d_err, S);
     PROF(6)
-    c->epoch++;
     for (int w = 0; w < 2; w++) {
         if ((rc = s2b_resolve_order(h, c, w)) != VILF_OK) return rc;
         if ((rc = s2b_build_index(h, c, w)) != VILF_OK) return rc;
@@ -1806,7 +1819,7 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         AssocArgs &a = aa[w];
         a.ds = c->cs_ds(w); a.is_surf = w; a.n_ds_edge = c->nDs[0].as<int>(); a.pose_all = d_pose;
         a.sorted_all = c->idx_copy[w] ? c->sorted[w].as<float4>() : c->map[w].as<float4>(); a.n_map = c->nMap[w].as<int>(); a.cap_map = c->capMap[w];
-        a.dir_all = c->bstart[w].as<unsigned>(); a.tag = (c->epoch % 255u + 1u) << 24; a.inv = 1.0f / leaf[w]; a.cs = c->cs_idx[w]; a.w_is_index = c->idx_copy[w] ? 1 : 0;
+        a.dir_all = c->bstart[w].as<unsigned>(); a.tag = c->dir_tag[w]; a.inv = 1.0f / leaf[w]; a.cs = c->cs_idx[w]; a.w_is_index = c->idx_copy[w] ? 1 : 0;
         a.res = d_res; a.frec_all = c->frec.as<double>(); a.fkind_all = c->fkind.as<int>(); a.capq = capq; a.tie_count = c->bcnt.as<int>();
     }
     const int nblk_e = (c->capScan[0] + 255) / 256, nblk_s = (c->capScan[1] + 255) / 256;
@@ -1818,6 +1831,8 @@ static int s2b_step(vilf_handle *h, S2B *c) {
                            h->opts.s2m_max_iterations, pass, d_res);
         PROF(4)
     }
+    bool new_dir_ok[2] = {false, false};
+    const unsigned new_tag[2] = {c->next_tag(), c->next_tag()};      // tags of the directories the map updates write (for the maps they emit)
     for (int w = 0; w < 2; w++) {     // createSubMap: append registered points, crop, voxel grid
         CSet map = c->cs_map(w), dsw = c->cs_ds(w), tmp = c->cs_tmp(w);
         hipLaunchKernelGGL(b_transform_append, GRID2(dsw.cap, S), 0, h->stream, dsw, d_pose, map, d_err);
@@ -1827,10 +1842,13 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         // restored by swapping back). If that other buffer is where a live snapshot sits, save the snapshot first.
         if (c->has_snapshot && c->snap_live && c->mapAlt[w].p == c->snap_ptr[w]) {
             for (int v = 0; v < 2; v++) {
-                if (!c->map0[v].ensure((size_t)S * c->capMap[v] * 16) || !c->cid0[v].ensure((size_t)S * c->capMap[v] * 4)) return VILF_ERR_DEVICE;
+                if (!c->map0[v].ensure((size_t)S * c->capMap[v] * 16)) return VILF_ERR_DEVICE;
                 const bool cur = c->map[v].p == c->snap_ptr[v];
                 HIPCHECK(h, hipMemcpyAsync(c->map0[v].p, cur ? c->map[v].p : c->mapAlt[v].p, (size_t)S * c->capMap[v] * 16, hipMemcpyDeviceToDevice, h->stream));
-                if (c->snap_cid_ok[v]) HIPCHECK(h, hipMemcpyAsync(c->cid0[v].p, cur ? c->cid[v].p : c->cidAlt[v].p, (size_t)S * c->capMap[v] * 4, hipMemcpyDeviceToDevice, h->stream));
+                if (c->snap_dir_ok[v]) {
+                    if (!c->dir0[v].ensure((size_t)S * S2B_NBS * 4)) return VILF_ERR_DEVICE;
+                    HIPCHECK(h, hipMemcpyAsync(c->dir0[v].p, cur ? c->bstart[v].p : c->bstartAlt[v].p, (size_t)S * S2B_NBS * 4, hipMemcpyDeviceToDevice, h->stream));
+                }
             }
             c->snap_live = false;
         }
@@ -1840,21 +1858,20 @@ static int s2b_step(vilf_handle *h, S2B *c) {
             const int lds_cap = mu_lds_cap(c->capScan[w]), lds_half = std::min(lds_cap, MU_LDS_TAIL / 2);
             int *gq = c->sorted[w].as<int>();
             const size_t gq_stride = (size_t)c->capMap[w] * 4;
-            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_half * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->cidAlt[w].as<unsigned>(),
+            hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_half * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->bstartAlt[w].as<unsigned>(), new_tag[w], c->fixq[w].as<int>(),
                                c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, -1, lds_half, gq, gq_stride, d_err);
             if (lds_cap > lds_half)
-                hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->cidAlt[w].as<unsigned>(),
+                hipLaunchKernelGGL(b_map_update<false>, dim3(S), dim3(MU_T), ((size_t)lds_cap * 8 + (size_t)MU_TILE * 12), h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->bstartAlt[w].as<unsigned>(), new_tag[w], c->fixq[w].as<int>(),
                                    c->tmpB.as<float4>(), c->capScan[w], (unsigned long long *)nullptr, 0, lds_half, lds_cap, gq, gq_stride, d_err);
             if (c->capScan[w] > lds_cap) {
                 int p2 = 2; while (p2 < c->capScan[w]) p2 <<= 1;
                 if (!c->muT.ensure((size_t)S * p2 * 8)) return VILF_ERR_DEVICE;
-                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->cidAlt[w].as<unsigned>(),
+                hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->bstartAlt[w].as<unsigned>(), new_tag[w], c->fixq[w].as<int>(),
                                    c->tmpB.as<float4>(), c->capScan[w], c->muT.as<unsigned long long>(), p2, 0, lds_cap, gq, gq_stride, d_err);
             }
             PROF(0)
-            c->cid_ok[w] = true;       // (of the map the swap below makes current)
+            new_dir_ok[w] = true;      // (of the map the swap below makes current)
         } else {                       // a map that is not a voxel grid yet (as initialised): crop copy + full sort
-            c->cid_ok[w] = false;
             hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp, c->nOld.as<int>(), c->mOld.as<int>());
             PROF(5)
             if ((rc = s2b_voxel(h, c, tmp, leaf[w], c->cs_mapout(w), c->cs_cfg[w])) != VILF_OK) return rc;
@@ -1862,7 +1879,10 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         c->order_state[w] = 1;
         std::fill(c->h_cmn[w].begin(), c->h_cmn[w].end(), INT_MAX);
     }
-    for (int w = 0; w < 2; w++) { std::swap(c->map[w], c->mapAlt[w]); std::swap(c->cid[w], c->cidAlt[w]); }
+    for (int w = 0; w < 2; w++) {
+        std::swap(c->map[w], c->mapAlt[w]); std::swap(c->bstart[w], c->bstartAlt[w]);
+        c->dir_ok[w] = new_dir_ok[w]; c->dir_tag[w] = new_tag[w];
+    }
     hipLaunchKernelGGL(b_finish, GRIDS(S), 0, h->stream, d_pose, c->nMap[0].as<int>(), c->nMap[1].as<int>(), d_err, d_res, S);
     PROF(6)
     HIPCHECK(h, hipGetLastError());
@@ -1963,7 +1983,7 @@ extern "C" int vilf_scan2map_init(vilf_handle *h, const float *e, int ne, const 
         const bool conv = old_n == 0 && s2b_host_cell_major(src[w], nn[w], (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), c->cs_cfg[w], cm[w]);   // ... unless it is a whole voxel grid
         if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], 0, old_n, conv ? cm[w].data() : src[w], nn[w])) != VILF_OK) return rc;
         c->h_cmn[w][0] = conv ? nn[w] : keep;
-        c->h_nMap[w][0] += nn[w]; c->order_state[w] = 0; c->cid_ok[w] = false;
+        c->h_nMap[w][0] += nn[w]; c->order_state[w] = 0; c->dir_ok[w] = false;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->h_nMap[w].data(), 4, hipMemcpyHostToDevice, h->stream));
     }
     HIPCHECK(h, hipStreamSynchronize(h->stream));
@@ -2057,7 +2077,7 @@ extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float 
         const bool conv = s2b_host_cell_major(src[w], nn[w], (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size), c->cs_cfg[w], cm[w]);
         if ((rc = s2b_set_cloud(h, c, c->map[w], c->capMap[w], stream, 0, conv ? cm[w].data() : src[w], nn[w])) != VILF_OK) return rc;
         c->h_cmn[w][stream] = conv ? nn[w] : 0;
-        c->h_nMap[w][stream] = nn[w]; c->order_state[w] = 0; c->cid_ok[w] = false;
+        c->h_nMap[w][stream] = nn[w]; c->order_state[w] = 0; c->dir_ok[w] = false;
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + stream, &c->h_nMap[w][stream], 4, hipMemcpyHostToDevice, h->stream));
     }
     double p[24] = {0};
@@ -2077,7 +2097,7 @@ extern "C" int vilf_scan2map_batch_copy_stream(vilf_handle *h, int src, int dst)
         HIPCHECK(h, hipMemcpyAsync(c->map[w].as<float4>() + (size_t)dst * c->capMap[w], c->map[w].as<float4>() + (size_t)src * c->capMap[w], (size_t)c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHECK(h, hipMemcpyAsync(c->scan[w].as<float4>() + (size_t)dst * c->capScan[w], c->scan[w].as<float4>() + (size_t)src * c->capScan[w], (size_t)c->capScan[w] * 16, hipMemcpyDeviceToDevice, h->stream));
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + dst, c->nMap[w].as<int>() + src, 4, hipMemcpyDeviceToDevice, h->stream));
-        if (c->cid_ok[w]) HIPCHECK(h, hipMemcpyAsync(c->cid[w].as<unsigned>() + (size_t)dst * c->capMap[w], c->cid[w].as<unsigned>() + (size_t)src * c->capMap[w], (size_t)c->capMap[w] * 4, hipMemcpyDeviceToDevice, h->stream));
+        if (c->dir_ok[w]) HIPCHECK(h, hipMemcpyAsync(c->bstart[w].as<unsigned>() + (size_t)dst * S2B_NBS, c->bstart[w].as<unsigned>() + (size_t)src * S2B_NBS, (size_t)S2B_NBS * 4, hipMemcpyDeviceToDevice, h->stream));
         c->h_nMap[w][dst] = c->h_nMap[w][src]; c->h_nScan[w][dst] = c->h_nScan[w][src]; c->h_cmn[w][dst] = c->h_cmn[w][src];
     }
     HIPCHECK(h, hipMemcpyAsync(c->pose.as<double>() + 24 * (size_t)dst, c->pose.as<double>() + 24 * (size_t)src, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -2116,12 +2136,14 @@ extern "C" int vilf_scan2map_batch_snapshot(vilf_handle *h) {
         int rc = s2b_resolve_order(h, c, w);
         if (rc != VILF_OK) return rc;
         c->snap_order[w] = c->order_state[w]; c->snap_cmn[w] = c->h_cmn[w];
-        if (c->order_state[w] == 1 && !c->cid_ok[w]) {          // the snapshot carries the maps' directory slots, as a map that came out of a step does
+        if (c->order_state[w] == 1 && !c->dir_ok[w]) {          // the snapshot carries the maps' directory, as a map that came out of a step does
             const float leaf = (float)(w == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
-            hipLaunchKernelGGL(b_make_cid, GRID2(c->capMap[w], c->S), 0, h->stream, c->map[w].as<float4>(), c->nMap[w].as<int>(), c->capMap[w], 1.0f / leaf, c->cs_cfg[w], c->cid[w].as<unsigned>());
-            c->cid_ok[w] = true;
+            c->dir_tag[w] = c->next_tag();
+            hipLaunchKernelGGL(b_dir_build, dim3((c->capMap[w] + 256 * DIR_PT - 1) / (256 * DIR_PT), c->S), dim3(256), 0, h->stream, c->map[w].as<float4>(), c->nMap[w].as<int>(), c->capMap[w], 1.0f / leaf,
+                               c->cs_cfg[w], c->dir_tag[w], c->bstart[w].as<unsigned>());
+            c->dir_ok[w] = true;
         }
-        c->snap_cid_ok[w] = c->cid_ok[w];
+        c->snap_dir_ok[w] = c->dir_ok[w]; c->snap_dir_tag[w] = c->dir_tag[w];
         if (!c->nMap0[w].ensure((size_t)c->S * 4)) return VILF_ERR_DEVICE;
         HIPCHECK(h, hipMemcpyAsync(c->nMap0[w].p, c->nMap[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
         c->snap_ptr[w] = c->map[w].p;
@@ -2136,12 +2158,12 @@ extern "C" int vilf_scan2map_batch_rewind(vilf_handle *h) {
     S2B_CHECK(h, 0)
     if (!c->has_snapshot) { h->err = "scan2map_batch_rewind: no snapshot"; return VILF_ERR_INVALID_ARGUMENT; }
     for (int w = 0; w < 2; w++) {
-        if (c->snap_live) { if (c->map[w].p != c->snap_ptr[w]) { std::swap(c->map[w], c->mapAlt[w]); std::swap(c->cid[w], c->cidAlt[w]); } }
+        if (c->snap_live) { if (c->map[w].p != c->snap_ptr[w]) { std::swap(c->map[w], c->mapAlt[w]); std::swap(c->bstart[w], c->bstartAlt[w]); } }
         else {
             HIPCHECK(h, hipMemcpyAsync(c->map[w].p, c->map0[w].p, (size_t)c->S * c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
-            if (c->snap_cid_ok[w]) HIPCHECK(h, hipMemcpyAsync(c->cid[w].p, c->cid0[w].p, (size_t)c->S * c->capMap[w] * 4, hipMemcpyDeviceToDevice, h->stream));
+            if (c->snap_dir_ok[w]) HIPCHECK(h, hipMemcpyAsync(c->bstart[w].p, c->dir0[w].p, (size_t)c->S * S2B_NBS * 4, hipMemcpyDeviceToDevice, h->stream));
         }
-        c->cid_ok[w] = c->snap_cid_ok[w];
+        c->dir_ok[w] = c->snap_dir_ok[w]; c->dir_tag[w] = c->snap_dir_tag[w];
         HIPCHECK(h, hipMemcpyAsync(c->nMap[w].p, c->nMap0[w].p, (size_t)c->S * 4, hipMemcpyDeviceToDevice, h->stream));
         c->order_state[w] = c->snap_order[w]; c->h_cmn[w] = c->snap_cmn[w];
     }
