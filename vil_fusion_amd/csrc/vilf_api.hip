@@ -18,7 +18,7 @@
 
 extern "C" {
 __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec);
-__global__ void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsigned lds_bytes);
+__global__ void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsigned lds_bytes, const int *done4);
 #define VILF_PRIOR_PREP_LDS ((size_t)(MG_NK + 1) * (MG_NK + 1) * sizeof(double))     // the n x n prior Jacobian in LDS (n <= 96: 73.5 KB, two workgroups per CU)
 __global__ void k_linearize(VbBatch b, int iteration_zero);
 __global__ void k_linearize_last(VbBatch b);
@@ -317,7 +317,7 @@ static int upload_priors(vilf_handle *h) {
             HIPCHECK(h, hipStreamSynchronize(h->stream));   // hd / x0 are stack buffers
         }
     }
-    hipLaunchKernelGGL(k_prior_prep, dim3(B), dim3(VB_NT), VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS);
+    hipLaunchKernelGGL(k_prior_prep, dim3(B), dim3(VB_NT), VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS, (const int *)nullptr);
     HIPCHECK(h, hipGetLastError());
     for (int w = 0; w < B; w++) h->prior_dirty[w] = 0;
     h->prior_slots_valid = std::max(h->prior_slots_valid, B);
@@ -932,6 +932,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     if (to_other_set) for (int k = 0; k < 6; k++) if (!h->d[bak[k]].ensure(pbytes[k])) { h->err = "hipMalloc failed (second prior set)"; return VILF_ERR_DEVICE; }
     const int *oset = to_other_set ? bak : live;
     g.prior_hdr_out = h->d[oset[0]].as<int>(); g.prior_x0_out = h->d[oset[1]].as<double>(); g.prior_J_out = h->d[oset[2]].as<double>(); g.prior_r_out = h->d[oset[3]].as<double>();
+    g.prior_H_out = h->d[oset[4]].as<double>(); g.prior_g_out = h->d[oset[5]].as<double>();
     const dim3 grid(h->B), block(VB_NT);
     const bool prof = h->profiling != 0;
     hipEvent_t mev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -972,7 +973,7 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
         h->prior_backup_valid = true;           // the other set now holds the priors as uploaded
     }
     if (prof) mev[3] = vilf_prof_event(h);
-    hipLaunchKernelGGL(k_prior_prep, grid, block, VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS);
+    hipLaunchKernelGGL(k_prior_prep, grid, block, VILF_PRIOR_PREP_LDS, h->stream, h->batch, h->d[D_PH].as<double>(), h->d[D_PG].as<double>(), (unsigned)VILF_PRIOR_PREP_LDS, (const int *)g.qlInfo);
     if (prof) mev[4] = vilf_prof_event(h);
     HIPCHECK(h, hipGetLastError());
     if (prof) {

@@ -121,6 +121,7 @@ struct VbMarg {
     int *qlIt, *qlInfo;     // [B][QL_ICAP] l | m << 8 per QL iteration, [B][4] iterations, rotations, overflow
     int *prior_hdr_out;     // = batch prior arrays (written by k_marg_finish)
     double *prior_x0_out, *prior_J_out, *prior_r_out;
+    double *prior_H_out, *prior_g_out;   // H0 = J0^T J0, g0 = J0^T r0 of the new prior: k_mf_chol writes them itself (they ARE A and b there); k_prior_prep fills the rest
 };
 
 struct VbBatch {

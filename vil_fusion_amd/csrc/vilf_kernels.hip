@@ -114,10 +114,11 @@ extern "C" __global__ __launch_bounds__(64) void k_imu_prep(int n, const double 
     if (row) { double *S = imu_rec + (size_t)id * IMU_REC + IMU_SQRT; for (int j = 0; j < 15; j++) S[15 * r + j] = (j >= r) ? sI[grp][j][r] : 0.0; }
 }
 
-extern "C" __global__ __launch_bounds__(NT) void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsigned lds_bytes) {
+// done4 (nullable): [B][4] flags of the marginalization; [4 w + 3] != 0: k_mf_chol has written this window's H0 / g0 already
+extern "C" __global__ __launch_bounds__(NT) void k_prior_prep(VbBatch b, double *prior_H, double *prior_g, unsigned lds_bytes, const int *done4) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
-    if (!hdr[0]) return;
+    if (!hdr[0] || (done4 && done4[4 * (size_t)w + 3])) return;
     const int n = hdr[1];
     const double *J = b.prior_J + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
     const double *r = b.prior_r + (size_t)w * VB_PRIOR_LD;

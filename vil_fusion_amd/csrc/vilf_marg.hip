@@ -1088,8 +1088,9 @@ __device__ void mf_tail(const VbBatch &b, const VbMarg &g, int w, const double *
 extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, int n_lo, int n_hi, int disable) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const int *info = g.info + (size_t)w * MG_INFO;
-    if (info[0] != 0 || info[3] < n_lo || info[3] >= n_hi) return;
     int *qi = g.qlInfo + (size_t)w * 4;
+    if (info[0] != 0) { if (tid == 0 && n_lo == 0) qi[3] = 0; return; }     // no new prior for this window: the flag must not keep an earlier call's value (k_prior_prep reads it)
+    if (info[3] < n_lo || info[3] >= n_hi) return;
     if (disable) { if (tid == 0) qi[3] = 0; return; }          // test hook: every window through the eigen-solver
     extern __shared__ double s_dyn[];
     __shared__ double s_dg[MG_NK + 2], s_br[MG_NK + 2], s_red[NT / 64];
@@ -1144,6 +1145,10 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, 
         for (int c = 0; c < tid; c++) s += V[c * N + tid] * s_br[c];
         ro[tid] = s;
     }
+    // H0 = J0^T J0 = L L^T = A and g0 = J0^T r0 = b: written from the kept block itself, k_prior_prep skips this window
+    double *Ho = g.prior_H_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *go = g.prior_g_out + (size_t)w * VB_PRIOR_LD;
+    for (int e = tid; e < n * n; e += NT) { const int i = e / n, j = e - n * i; Ho[i * VB_PRIOR_LD + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]); }
+    if (tid < n) go[tid] = s_br[tid];
     mf_table(b, g, w, n, nb, info);
     if (tid == 0) qi[3] = 1;
 }
