@@ -1113,11 +1113,24 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, 
         }
         __syncthreads();
         if (!s_ok) break;                                        // uniform: written before the barrier, read by every thread after it
-        // phase 2: rows i > j; nothing here writes column j, which both loops read
+        // phase 2: rows i > j; nothing here writes column j, which both loops read. Four elements per trip, every operand loaded before the first store: a loop of
+        // load - multiply - store trips on one LDS array is kept in program order by the compiler (possible aliasing) and pays the LDS latency per element
         for (int i = j + 1 + tr; i < n; i += 64) {
             const double lij = V[i * N + j];
-            for (int c = tc; c < j; c += 4) V[c * N + i] -= lij * V[c * N + j];              // X[i][c] -= L[i][j] X[j][c]
-            for (int c = j + 1 + tc; c <= i; c += 4) V[i * N + c] -= lij * V[c * N + j];     // A[i][c] -= L[i][j] L[c][j]
+            for (int c0 = tc; c0 < j; c0 += 16) {                                             // X[i][c] -= L[i][j] X[j][c]
+                double v[4], xj[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int c = min(c0 + 4 * u, j - 1); v[u] = V[c * N + i]; xj[u] = V[c * N + j]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (c0 + 4 * u < j) V[(c0 + 4 * u) * N + i] = v[u] - lij * xj[u];
+            }
+            for (int c0 = j + 1 + tc; c0 <= i; c0 += 16) {                                    // A[i][c] -= L[i][j] L[c][j]
+                double v[4], lc[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int c = min(c0 + 4 * u, i); v[u] = V[i * N + c]; lc[u] = V[c * N + j]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (c0 + 4 * u <= i) V[i * N + c0 + 4 * u] = v[u] - lij * lc[u];
+            }
             if (tc == 0) V[j * N + i] -= lij * linv;                                          // X[i][j] -= L[i][j] X[j][j]
         }
         __syncthreads();

@@ -2088,19 +2088,37 @@ extern "C" int vilf_scan2map_batch_init(vilf_handle *h, int stream, const float 
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     return VILF_OK;
 }
-// stream dst := stream src (local maps, poses, resident scan), copied on the device: a batch of replicas of a few distinct streams without one upload per stream
+// stream dst := stream src (local maps, poses, resident scan), copied on the device: a batch of replicas of a few distinct streams without one upload per stream.
+// One launch of the library's own copy kernel per call (thousands of runtime memcpy calls in a row were also what a counter-collecting profiler choked on).
+struct CopyJob { const void *src[8]; void *dst[8]; unsigned long long bytes[8]; int n; };
+__global__ void b_copy_regions(CopyJob job) {
+    const int r = blockIdx.y;
+    if (r >= job.n) return;
+    const size_t n4 = job.bytes[r] / 4;                           // every region is a whole number of 4-byte words; 16-byte aligned ones go by uint4
+    const bool wide = ((size_t)job.src[r] % 16 == 0) && ((size_t)job.dst[r] % 16 == 0) && n4 % 4 == 0;
+    if (wide) { const uint4 *s4 = static_cast<const uint4 *>(job.src[r]); uint4 *d4 = static_cast<uint4 *>(job.dst[r]); for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4 / 4; i += (size_t)gridDim.x * blockDim.x) d4[i] = s4[i]; }
+    else { const unsigned *s1 = static_cast<const unsigned *>(job.src[r]); unsigned *d1 = static_cast<unsigned *>(job.dst[r]); for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) d1[i] = s1[i]; }
+}
 extern "C" int vilf_scan2map_batch_copy_stream(vilf_handle *h, int src, int dst) {
     S2B_CHECK(h, src)
     if (dst < 0 || dst >= c->S) return VILF_ERR_INVALID_ARGUMENT;
     if (src == dst) return VILF_OK;
+    CopyJob job; job.n = 0;
+    auto add = [&](const void *s_, void *d_, size_t bytes) { job.src[job.n] = s_; job.dst[job.n] = d_; job.bytes[job.n] = bytes; job.n++; };
+    size_t largest = 0;
     for (int w = 0; w < 2; w++) {
-        HIPCHECK(h, hipMemcpyAsync(c->map[w].as<float4>() + (size_t)dst * c->capMap[w], c->map[w].as<float4>() + (size_t)src * c->capMap[w], (size_t)c->capMap[w] * 16, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(c->scan[w].as<float4>() + (size_t)dst * c->capScan[w], c->scan[w].as<float4>() + (size_t)src * c->capScan[w], (size_t)c->capScan[w] * 16, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(c->nMap[w].as<int>() + dst, c->nMap[w].as<int>() + src, 4, hipMemcpyDeviceToDevice, h->stream));
-        if (c->dir_ok[w]) HIPCHECK(h, hipMemcpyAsync(c->bstart[w].as<unsigned>() + (size_t)dst * S2B_NBS, c->bstart[w].as<unsigned>() + (size_t)src * S2B_NBS, (size_t)S2B_NBS * 4, hipMemcpyDeviceToDevice, h->stream));
+        add(c->map[w].as<float4>() + (size_t)src * c->capMap[w], c->map[w].as<float4>() + (size_t)dst * c->capMap[w], (size_t)c->capMap[w] * 16);
+        if (c->dir_ok[w]) add(c->bstart[w].as<unsigned>() + (size_t)src * S2B_NBS, c->bstart[w].as<unsigned>() + (size_t)dst * S2B_NBS, (size_t)S2B_NBS * 4);
+        add(c->nMap[w].as<int>() + src, c->nMap[w].as<int>() + dst, 4);
         c->h_nMap[w][dst] = c->h_nMap[w][src]; c->h_nScan[w][dst] = c->h_nScan[w][src]; c->h_cmn[w][dst] = c->h_cmn[w][src];
     }
-    HIPCHECK(h, hipMemcpyAsync(c->pose.as<double>() + 24 * (size_t)dst, c->pose.as<double>() + 24 * (size_t)src, 24 * 8, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(b_copy_regions, dim3(64, job.n), dim3(256), 0, h->stream, job);
+    job.n = 0;
+    for (int w = 0; w < 2; w++) add(c->scan[w].as<float4>() + (size_t)src * c->capScan[w], c->scan[w].as<float4>() + (size_t)dst * c->capScan[w], (size_t)c->capScan[w] * 16);
+    add(c->pose.as<double>() + 24 * (size_t)src, c->pose.as<double>() + 24 * (size_t)dst, 24 * 8);
+    hipLaunchKernelGGL(b_copy_regions, dim3(16, job.n), dim3(256), 0, h->stream, job);
+    (void)largest;
+    HIPCHECK(h, hipGetLastError());
     c->scan_dirty = true;
     return VILF_OK;
 }
