@@ -130,7 +130,8 @@ __global__ void b_voxel_keys(CSet in, float inv, const MinMax *mm, KeyT *keys, i
 // Fused heads + scan + centroids: ONE workgroup per stream walks its sorted (leaf, index) pairs in tiles of 1024, ranks the run
 // heads with a block scan and lets each head thread sum its run in sorted (= input) order — same float sums as pcl::VoxelGrid.
 #define S2B_VT 1024
-__device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int &total) {
+template <int NW>            // workgroup of NW waves
+__device__ __forceinline__ int block_excl_scan_nw(int v, int *s_w, int &total) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int incl = v;
 #pragma unroll
@@ -140,10 +141,11 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int &total)
     __syncthreads();
     int off = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { const int x = s_w[k]; if (k < wave) off += x; tot += x; }
+    for (int k = 0; k < NW; k++) { const int x = s_w[k]; if (k < wave) off += x; tot += x; }
     total = tot;
     return off + incl - v;
 }
+__device__ __forceinline__ int block_excl_scan_1024(int v, int *s_w, int &total) { return block_excl_scan_nw<16>(v, s_w, total); }
 // Two launches over (tile, stream): b_voxel_heads counts the run heads of every 1024-pair tile, b_voxel_reduce turns the counts of the
 // stream's earlier tiles into its output offset (a handful of ints) and then works on its tile alone — every tile of every stream is
 // an independent workgroup, instead of one workgroup walking a stream's tiles one after the other.
@@ -495,7 +497,10 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
 // HBM traffic: the map is read once and written once (the unfused path: crop copy, keys, merge, gather + write: ~3.5 x that).
 // Streams whose tail does not fit the LDS buffer are handled by the BIG instantiation (tail in global memory), launched only when the
 // scan capacity allows such tails; each instantiation skips the other's streams.
-#define MU_T 1024
+#ifndef MU_T
+#define MU_T 512             // two workgroups of eight waves per CU instead of one of sixteen: the sweep waits 40 % of its cycles at its three barriers per tile and another stream's
+                             // workgroup fills part of them. Same-box A/B of the voxel-grid group per 4096-frame step (tools/dev_ab_mut.sh): 1024 threads 9.01 ms, 512: 8.82, 256: 8.94
+#endif
 #define MU_E 2
 #define MU_TILE (MU_T * MU_E)
 #define MU_LDS_TAIL 8192
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
             __syncthreads();
         }
     int ntv;
-    { int tot; block_excl_scan_1024(myvalid, s_w[0], tot); ntv = tot; }
+    { int tot; block_excl_scan_nw<MU_T / 64>(myvalid, s_w[0], tot); ntv = tot; }
     for (int j = tid; j < ntv; j += MU_T) ts[j] = p[nOld + (int)(T[j] & LOW)];
     __syncthreads();
     int THtot = 0;
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         int cnt = 0;
         for (int j = j0; j < j0 + C && j < ntv; j++) cnt += (j == 0 || (T[j - 1] >> IDXB) != (T[j] >> IDXB)) ? 1 : 0;
         int tot;
-        int run = block_excl_scan_1024(cnt, s_w[1], tot);
+        int run = block_excl_scan_nw<MU_T / 64>(cnt, s_w[1], tot);
         THtot = tot;
         // flags are re-derived from the leaf bits, which the rewrite of the low bits does not touch
         unsigned long long prev = (j0 > 0 && j0 <= ntv) ? (T[j0 - 1] >> IDXB) : ~0ULL;
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old,
         for (int u = 0; u < MU_E; u++) {
             int off = 0, tot = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) { const int x = s_w[u][k]; if (k < wave) off += x; tot += x; }
+            for (int k = 0; k < MU_T / 64; k++) { const int x = s_w[u][k]; if (k < wave) off += x; tot += x; }
             const int ex = base + off + incl[u] - flag[u];
             base += tot;
             const int e = u * MU_T + tid;
