@@ -106,10 +106,11 @@ typedef struct vilf_lidar_constraint {
 /* One window ≙ the members optimization() reads (estimator.h:70-146). */
 typedef struct vilf_window_in {
     int n_frames;                         /* options.window_size + 1. 11 = the reference's WINDOW_SIZE: batched LDS kernels; any other size: the general
-                                             single-window path (vilf_window_solve only; no prior, no marginalization) — BASELINE configs[4].
+                                             path (vilf_window_solve, or several at once: vilf_window_solve_group; no prior, no marginalization) —
+                                             BASELINE configs[4].
                                              options.estimate_extrinsic / estimate_td (para_ex_pose / para_td become variables; obs_velocity,
                                              obs_cur_td, obs_row required for td): solved through the same general path at any window size, by
-                                             vilf_window_solve and, window by window, by vilf_batch_solve; an 11-frame window keeps its device
+                                             vilf_window_solve and by vilf_batch_solve (all slots side by side as one group); an 11-frame window keeps its device
                                              prior, and vilf_window_marginalize() / vilf_batch_marginalize() carry Ex_Pose and Td as kept blocks
                                              of it (ProjectionTdFactor rows when estimate_td is set). */
     const double *para_pose;              /* [n_frames][7] */
@@ -186,6 +187,11 @@ const char *vilf_version(void);
 /* ---- single-window drop-in (≙ Estimator::optimization()) ------------------------------- */
 /* estimator.cpp:689-860: build problem, Solve, double2vector. Uses/keeps the prior of slot 0. */
 int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out);
+/* n independent windows of sizes other than 11 frames (the general path), solved side by side in ONE chain of launches: a window's chain is ~36 small dependent
+ * launches per iteration, so a group fills the chip where a single window (or one handle / stream per window) cannot. in / out: arrays of n; every out[i] needs
+ * Ps / Rs / Vs / Bas / Bgs. Same results as n calls of vilf_window_solve (to the rounding of the atomics' summation order). 11-frame windows:
+ * VILF_ERR_UNSUPPORTED (use vilf_batch_*). Returns VILF_SOLVER_ABNORMAL if any window terminated abnormally (its summary tells). */
+int vilf_window_solve_group(vilf_handle *h, int n, const vilf_window_in *in, vilf_window_out *out);
 /* estimator.cpp:863-1046: marginalization of the just-solved window (slot 0); new prior stays on device. */
 int vilf_window_marginalize(vilf_handle *h);
 

@@ -512,6 +512,43 @@ def test_large_window_solve_matches_oracle(oracle, n_frames, n_features, tol):
     assert np.abs(1.0 / got.para_feature - 1.0 / ref.para_feature).max() < 1e-4
 
 
+def test_window_solve_group_matches_the_oracle_window_by_window(oracle, monkeypatch):
+    """vilf_window_solve_group: windows of DIFFERENT sizes (13 / 21 / 16 / 26 frames, one picked for its rejected steps, one without features' worth of slack) in one
+    chain of launches — every kernel finds its window in blockIdx.z, grids are sized for the largest, the blocked Cholesky runs as many block columns as the largest needs.
+    Each window against the oracle with the counts and tolerances of the single-window tests; then the same group with one window forced through the host-loop fallback."""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    cases = [(13, 60, 502, (3.0, np.deg2rad(25.0), 3.0)), (21, 400, 81, None), (16, 150, 82, None), (26, 700, 83, None), (13, 60, 500, (1.5, np.deg2rad(15.0), 1.5))]
+    wins, refs = [], []
+    for nf, nfeat, seed, noise in cases:
+        oo = oracle.default_options(); oo.window_size = nf - 1
+        cfg = synth.SynthConfig(n_frames=nf, n_features=nfeat, with_prior=False, **({"state_noise": noise} if noise else {}))
+        w, _, _ = synth.make_window(seed, oo, cfg)
+        wins.append(w); refs.append(oracle.window_solve(oo, w, None))
+    assert refs[0].summary["num_successful_steps"] < refs[0].summary["num_iterations"], "one window of the group has rejected steps"
+    o.window_size = 12                      # a group takes every window's own n_frames (vilf_window_solve insists on options.window_size + 1)
+    s = BackendSolver(o)
+    got = s.optimization_group(wins)
+    single = []
+    for w in wins:
+        oo = oracle.default_options(); oo.window_size = w.n_frames - 1
+        s1 = BackendSolver(oo); single.append(s1.optimization(w)); s1.close()
+    monkeypatch.setenv("VILF_LW_FORCE_FALLBACK", "1")
+    fb = s.optimization_group(wins[:2])
+    monkeypatch.delenv("VILF_LW_FORCE_FALLBACK")
+    s.close()
+    for k, (g, r) in enumerate(zip(got + fb, refs + refs[:2])):
+        for key in ("num_iterations", "num_successful_steps", "num_linear_solves", "termination"):
+            assert g.summary[key] == r.summary[key], (k, key)
+        loose = k in (0, 4, 5)              # the ill-conditioned 13-frame windows: tolerances of test_large_window_device_trust_region_loop
+        assert abs(g.summary["initial_cost"] - r.summary["initial_cost"]) <= 1e-9 * r.summary["initial_cost"]
+        assert abs(g.summary["final_cost"] - r.summary["final_cost"]) <= (1e-4 if loose else 1e-6) * r.summary["final_cost"]
+        tol = 1e-4 if loose else 1e-7
+        assert np.abs(g.Ps - r.Ps).max() < tol and np.abs(g.Rs - r.Rs).max() < tol and np.abs(g.Vs - r.Vs).max() < 10 * tol, k
+    for g, one in zip(got, single):         # a group of one is the same code: equal to the rounding of the atomics' order
+        assert g.summary["num_iterations"] == one.summary["num_iterations"] and np.abs(g.Ps - one.Ps).max() < 1e-5
+
+
 @pytest.mark.parametrize("noise,deg,seed", [(1.5, 15.0, 500), (3.0, 25.0, 502), (3.0, 25.0, 503)])
 def test_large_window_device_trust_region_loop(oracle, monkeypatch, noise, deg, seed):
     """The general single-window path keeps its trust-region loop on the device (lw_tr_*: every iteration enqueued at once, skip flags instead of host decisions).

@@ -631,20 +631,22 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
         for (int w = 0; w < h->B; w++) if (h->prior_dirty[w]) dirty0 = true;
         if (dirty0) { int rc = upload_priors(h); if (rc != VILF_OK) return rc; }
         const auto t0 = std::chrono::steady_clock::now();
-        std::vector<double> bufP(77), bufS(99), bufF(h->batch.Fmax + 4), Ps(33), Rs(99), Vs(33), Bas(33), Bgs(33);
-        for (int w = 0; w < h->B; w++) {
-            vilf_window_out out;
+        // all slots as ONE group: a single chain of launches solves them side by side (vilf_lw_group_solve), priors in and states / summaries back in bulk copies
+        const size_t B = h->B;
+        std::vector<double> bufP(B * 77), bufS(B * 99), bufF(B * (h->batch.Fmax + 4)), Ps(B * 33), Rs(B * 99), Vs(B * 33), Bas(B * 33), Bgs(B * 33);
+        std::vector<vilf_window_out> outv(B);
+        std::vector<const vilf_window_in *> inp(B);
+        std::vector<vilf_window_out *> outp(B);
+        std::vector<int> slot1(B);
+        for (size_t w = 0; w < B; w++) {
+            vilf_window_out &out = outv[w];
             std::memset(&out, 0, sizeof(out));
-            out.para_pose = bufP.data(); out.para_speed_bias = bufS.data(); out.para_feature = bufF.data();
-            out.Ps = Ps.data(); out.Rs = Rs.data(); out.Vs = Vs.data(); out.Bas = Bas.data(); out.Bgs = Bgs.data();
-            const int rc = vilf_lw_window_solve(h, &h->own[w].in, &out, w + 1);
-            if (rc < 0) return rc;
-            VbState st;
-            std::memset(&st, 0, sizeof(st));
-            st.iteration = out.summary.num_iterations; st.num_successful = out.summary.num_successful_steps; st.num_linear_solves = out.summary.num_linear_solves;
-            st.termination = out.summary.termination; st.initial_cost = out.summary.initial_cost; st.x_cost = out.summary.final_cost; st.radius = out.summary.final_radius; st.done = 1;
-            HIPCHECK(h, hipMemcpy(h->batch.st + w, &st, sizeof(st), hipMemcpyHostToDevice));
+            out.para_pose = &bufP[w * 77]; out.para_speed_bias = &bufS[w * 99]; out.para_feature = &bufF[w * (h->batch.Fmax + 4)];
+            out.Ps = &Ps[w * 33]; out.Rs = &Rs[w * 99]; out.Vs = &Vs[w * 33]; out.Bas = &Bas[w * 33]; out.Bgs = &Bgs[w * 33];
+            inp[w] = &h->own[w].in; outp[w] = &out; slot1[w] = (int)w + 1;
         }
+        const int rc = vilf_lw_group_solve(h, h->B, inp.data(), outp.data(), slot1.data());
+        if (rc < 0) return rc;
         h->last_solve_usec = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         (void)sync;
         return VILF_OK;
@@ -853,6 +855,19 @@ extern "C" int vilf_batch_download_states(vilf_handle *h, int first, int n, doub
     return VILF_OK;
 }
 
+// n independent windows of sizes other than the reference's WINDOW_SIZE + 1 = 11 frames, solved side by side in one chain of launches (vilf_lw.hip). 11-frame
+// windows belong to the vilf_batch_* entry points (LDS kernels, priors, marginalization).
+extern "C" int vilf_window_solve_group(vilf_handle *h, int n, const vilf_window_in *in, vilf_window_out *out) {
+    if (!h || n < 1 || !in || !out) return VILF_ERR_INVALID_ARGUMENT;
+    std::vector<const vilf_window_in *> inp(n);
+    std::vector<vilf_window_out *> outp(n);
+    for (int i = 0; i < n; i++) {
+        if (in[i].n_frames == VB_NF) { h->err = "vilf_window_solve_group: 11-frame windows go through vilf_batch_upload / vilf_batch_solve"; return VILF_ERR_UNSUPPORTED; }
+        if (!out[i].Ps || !out[i].Rs || !out[i].Vs || !out[i].Bas || !out[i].Bgs) return VILF_ERR_INVALID_ARGUMENT;
+        inp[i] = &in[i]; outp[i] = &out[i];
+    }
+    return vilf_lw_group_solve(h, n, inp.data(), outp.data(), nullptr);
+}
 extern "C" int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out) {
     if (!h || !in || !out) return VILF_ERR_INVALID_ARGUMENT;
     if (in->n_frames != VB_NF) {          // not the reference's WINDOW_SIZE = 10: the general path (one window spread over the device, no prior)

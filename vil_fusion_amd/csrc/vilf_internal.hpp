@@ -135,4 +135,5 @@ void vilf_pg_release(vilf_handle *h);
 void vilf_lw_release(vilf_handle *h);
 int vilf_lw_chol_max_n();                                                      // largest n vilf_lw_chol_solve takes (its back substitution keeps the solution in LDS)
 int vilf_lw_chol_solve(vilf_handle *h, int n, double *S, double *y, int *info);   // blocked Cholesky solve on the handle's stream (vilf_lw.hip): S = [(n + 1) x n] row-major, row n = rhs
+int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins, vilf_window_out *const *outs, const int *slot1);   // G windows in one chain of launches; slot1[g] = resident batch slot + 1 (0 / nullptr: not resident)
 int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot1);   // batch_slot1 = resident slot + 1 (0: not resident)   // window sizes other than 10, estimate_extrinsic / estimate_td (vilf_lw.hip)

@@ -19,6 +19,12 @@
 // window it then also applies the slot-0 marginalization prior resident on the device (lw_prior) and writes the solved state back into the
 // batch buffers, so that vilf_window_marginalize() continues from it. Other window sizes have no prior (no device marginalization).
 // Summation order of the atomics is not fixed: results are reproducible to rounding (~1e-12 relative), not bit for bit.
+// Groups: every kernel of this file takes an array of window descriptors (LwWin, one per window, resident on the device) and finds its window in blockIdx.z —
+// ONE chain of launches solves G independent windows side by side (vilf_window_solve_group; the estimate_td / estimate_extrinsic slots of vilf_batch_solve).
+// A window's chain is ~36 small dependent launches per iteration on a handful of workgroups, so a single window leaves most of the chip idle and G handles on G
+// streams do not help either (the runtime multiplexes its streams onto four hardware queues: 3.1 k iterations/s at eight streams, worse with more queues);
+// in one launch the G windows' workgroups simply fill more CUs. A single window is a group of one. All device memory of a group is one arena (DBuf): the
+// small inputs of all windows go up in one copy, states and minimizer scalars come back in one.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
@@ -26,19 +32,48 @@
 #include <cmath>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <atomic>
 #include "vilf_internal.hpp"
 #include "vilf_device.hpp"
 
 extern "C" __global__ void k_imu_prep(int n, const double *cov, double *work, double *imu_rec);
 
+struct LwVis { double pi[3], pj[3]; int f, i, j, cst; };     // one ProjectionFactor: feature, start frame, observing frame
+struct LwTd { double vi[2], vj[2], tdi, tdj, rowi_c, rowj_c; };     // ProjectionTdFactor constants (projection_td_factor.cpp:6-21)
+// The trust-region loop on the device (see lw_tr_* below): the scalars of the minimizer. skip_* = what the launches of the current iteration may leave out
+// (a finished solve, a rejected step that reuses the linear solve, an invalid step that needs no evaluation), in the order of the LW_SK_* selectors.
+struct LwCtl {
+    double radius, mu, alpha, step_norm, x_cost, cand_cost, x_norm, gmax, model_change, initial_cost, gg;
+    int iteration, reuse, done, termination, num_successful, num_linear_solves, consecutive_invalid, fallback;
+    int skip_solve, skip_quad, skip_eval, skip_jac, scaling_ready, pad_;
+};
+enum { LW_SK_NONE = -1, LW_SK_SOLVE = 0, LW_SK_QUAD = 1, LW_SK_EVAL = 2, LW_SK_JAC = 3 };
+// One window of a group: sizes, options and device pointers (into the group's arena; the prior's into the 11-frame batch buffers of the window's slot).
+// State x (and cand): pose[NF][7] | sb[NF][9] | feat[F] | ex[7] | td. Tangent / N-vectors: [15 per frame: pose 6, speed-bias 9 | ex 6 | td | F].
+struct LwWin {
+    int NF, F, P, N, nvis, nimu, cEx, cTd, xo, est_ex, est_td, use_lidar, pn, pnb, max_it, pad_;
+    double sqrt_info, cauchy_b, tr_over_row;
+    LwCtl *ctl;
+    double *x, *cand;
+    const LwVis *vis; const LwTd *tdr; const double *imu, *lid; const unsigned char *fconst;
+    double *Hpp, *W, *hf, *gp, *gf, *S, *Wn, *rhs, *tmpP, *tmpF, *vec, *yf, *scal, *den, *jscr;     // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
+    int *info;
+    double *g, *diagH, *scale, *diagonal, *gradient, *gn, *step;                                    // N each: the minimizer's vectors
+    const double *pJ, *pr0, *pH0, *px0; const int *phdr, *pcol; double *pdx;                       // marginalization prior of an 11-frame window (pn = 0: none)
+};
+__device__ __forceinline__ bool lw_skip(const LwWin &w, int sk) { return sk >= 0 && (&w.ctl->skip_solve)[sk] != 0; }
+
 struct LwCtx {
-    DBuf x, ex, vis, imu, cov, lid, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, scal, info, fconst, den, jscr, tdrec, pri, dv, ctl;
+    DBuf arena, desc;                  // the group's device memory; its LwWin array
+    char *stage = nullptr;             // host image of the arena's input region (pinned: the copy of a group's factors runs at the link's rate)
+    size_t stage_cap = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     double ms[4] = {0, 0, 0, 0};       // vilf_set_profiling: factor scatter, Schur SYRK, Cholesky (potrf + potrs), other device work
     long launches[4] = {0, 0, 0, 0};
     void release() {
-        DBuf *all[] = {&x, &ex, &vis, &imu, &cov, &lid, &Hpp, &W, &hf, &gp, &gf, &S, &Wn, &rhs, &tmpP, &tmpF, &vec, &scal, &info, &fconst, &den, &jscr, &tdrec, &pri, &dv, &ctl};
-        for (DBuf *b : all) b->release();
+        arena.release(); desc.release();
+        if (stage) { hipHostFree(stage); stage = nullptr; stage_cap = 0; }
         for (hipEvent_t &e : ev) if (e) { hipEventDestroy(e); e = nullptr; }
     }
 };
@@ -52,7 +87,6 @@ void vilf_lw_release(vilf_handle *h) { if (h->lw) { h->lw->release(); delete h->
 namespace {
 using namespace vd;
 
-struct LwVis { double pi[3], pj[3]; int f, i, j, cst; };     // one ProjectionFactor: feature, start frame, observing frame
 
 __device__ __forceinline__ void add(double *p, double v) { unsafeAtomicAdd(p, v); }
 
@@ -63,9 +97,15 @@ __device__ __forceinline__ void add(double *p, double v) { unsafeAtomicAdd(p, v)
 // the same few hundred addresses (the 51 diagonal pose blocks collect ~2 k factors each). The per-feature terms keep their per-factor atomics
 // (a feature's ~20 factors spread over many workgroups).
 #define LW_CH 128
-__global__ __launch_bounds__(LW_CH) void lw_visual(int n, const LwVis *vis, const double *x, const double *ex, int NF, int F, double sqrt_info, double cauchy_b, int jac,
-                                                     double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+__global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, int jac, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int n = w.nvis, NF = w.NF;
+    if ((int)blockIdx.x * LW_CH >= n) return;         // the grid is sized for the group's largest window
+    const double *x = which ? w.cand : w.x, *ex = x + w.xo;
+    const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b;
+    double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gp = w.gp, *gf = w.gf, *cost = w.scal;
+    const LwVis *vis = w.vis;
     __shared__ double s_J[LW_CH][26];                 // 24 Jacobian entries (row 0: 12, row 1: 12), r0, r1
     __shared__ int s_pair[LW_CH + 1];
     const int tid = threadIdx.x, t = blockIdx.x * LW_CH + tid;
@@ -135,11 +175,16 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(int n, const LwVis *vis, cons
 
 // The same chunked scatter with Ex_Pose and / or td as variables (estimate_extrinsic / estimate_td): 19 Jacobian columns per factor row
 // [pose_i 6 | pose_j 6 | Ex 6 | td 1]; a column whose block is constant maps to -1 and is skipped. x = pose | sb | feat | ex[7] | td.
-struct LwTd { double vi[2], vj[2], tdi, tdj, rowi_c, rowj_c; };     // ProjectionTdFactor constants (projection_td_factor.cpp:6-21)
 __device__ __forceinline__ int lw_col(int a, int ci, int cj, int cEx, int cTd) { return a < 6 ? ci + a : (a < 12 ? cj + a - 6 : (a < 18 ? (cEx < 0 ? -1 : cEx + a - 12) : cTd)); }
-__global__ __launch_bounds__(LW_CH) void lw_visual_ext(int n, const LwVis *vis, const LwTd *tdr, const double *x, int NF, int F, int P, int cEx, int cTd, double tr_over_row,
-                                                         double sqrt_info, double cauchy_b, int jac, double *Hpp, double *W, double *hf, double *gp, double *gf, double *cost, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+__global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int which, int jac, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int n = w.nvis, NF = w.NF, F = w.F, P = w.P, cEx = w.cEx, cTd = w.cTd;
+    if ((int)blockIdx.x * LW_CH >= n) return;
+    const double *x = which ? w.cand : w.x;
+    const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b, tr_over_row = w.tr_over_row;
+    double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gp = w.gp, *gf = w.gf, *cost = w.scal;
+    const LwVis *vis = w.vis; const LwTd *tdr = w.tdr;
     __shared__ double s_J[LW_CH][41];                 // row 0: 19, row 1: 19, r0, r1 (+ 1 pad)
     __shared__ int s_pair[LW_CH + 1];
     const int tid = threadIdx.x, t = blockIdx.x * LW_CH + tid;
@@ -218,11 +263,14 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(int n, const LwVis *vis, 
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((tid & 63) == 0 && c != 0.0) add(cost, c);
 }
-// MarginalizationFactor (marginalization_factor.cpp:333-381) of an 11-frame window: r = r0 + J0 dx with dx from the host (n <= 96 entries),
+// MarginalizationFactor (marginalization_factor.cpp:333-381) of an 11-frame window: r = r0 + J0 dx with dx from lw_tr_* / the host (n <= 96 entries),
 // J0^T J0 from k_prior_prep; pcol maps a prior column to its column of the reduced system (-1: block constant in this solve)
-__global__ __launch_bounds__(256) void lw_prior(int n, const double *J, const double *r0, const double *H0, const double *dx, const int *pcol, int P, int jac,
-                                                double *Hpp, double *gp, double *cost, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+__global__ __launch_bounds__(256) void lw_prior(const LwWin *ws, int jac, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk) || !w.pn) return;
+    const int n = w.pn, P = w.P;
+    const double *J = w.pJ, *r0 = w.pr0, *H0 = w.pH0, *dx = w.pdx; const int *pcol = w.pcol;
+    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
     __shared__ double s_r[VB_PRIOR_LD], s_dx[VB_PRIOR_LD];
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += 256) s_dx[i] = dx[i];
@@ -238,11 +286,13 @@ __global__ __launch_bounds__(256) void lw_prior(int n, const double *J, const do
 // 0 evaluates the raw IMU residual / Jacobian into LDS, lane 0 of wave 1 the LiDAR factor; the products with sqrt_info (15 x 15 upper triangular times 15 x 31) and
 // the LiDAR J^T [J r] entries are then one lane per entry. (A lane per factor kept its 15 x 30 Jacobian in a dynamically indexed local array = scratch memory, and
 // walked the 7 k multiply-adds of S J alone: 127 us per launch, 17 launches per solve.)
-__global__ __launch_bounds__(128) void lw_imu_lidar(int NF, int P, const double *x, const double *imu_rec, const double *lid, const double *G, const double *qil, const double *til, int use_lidar, int jac,
-                                                    double *Hpp, double *gp, double *cost, double *jscr, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
-    const int k = blockIdx.x, tid = threadIdx.x;
-    if (k >= NF - 1) return;
+__global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, int jac, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int k = blockIdx.x, tid = threadIdx.x, NF = w.NF, P = w.P, use_lidar = w.use_lidar;
+    if (k >= w.nimu) return;
+    const double *x = which ? w.cand : w.x, *imu_rec = w.imu, *lid = w.lid, *G = w.scal + 8, *qil = w.scal + 1, *til = w.scal + 5;
+    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal, *jscr = w.jscr;
     __shared__ double s_r[16], s_J[15 * 30], s_rw[16], s_lr[8], s_lJi[36], s_lJj[36];
     const int c0 = 15 * k;
     const double *pi = x + 7 * k, *pj = x + 7 * (k + 1), *sbi = x + 7 * NF + 9 * k, *sbj = sbi + 9;
@@ -283,9 +333,13 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(int NF, int P, const double 
     }
 }
 // zero the accumulation targets of one linearisation (Hpp, W, h_f, g_p, g_f) and the cost: four entries per thread
-__global__ __launch_bounds__(256) void lw_clear(double *a0, size_t n0, double *a1, size_t n1, double *a2, size_t n2, double *a3, size_t n3, double *a4, size_t n4, double *cost, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+__global__ __launch_bounds__(256) void lw_clear(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const size_t n0 = (size_t)w.P * w.P, n1 = (size_t)w.F * w.P, n2 = w.F, n3 = w.P, n4 = w.F;
+    double *a0 = w.Hpp, *a1 = w.W, *a2 = w.hf, *a3 = w.gp, *a4 = w.gf, *cost = w.scal;
     const size_t t0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (t0 > n0 + n1 + n2 + n3 + n4) return;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         size_t t = t0 + u;
@@ -298,10 +352,13 @@ __global__ __launch_bounds__(256) void lw_clear(double *a0, size_t n0, double *a
     }
 }
 // J^T [J r] of every IMU factor: one lane per (factor, row a, column b <= 30): 15-term dot products, one atomic each
-__global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, double *gp, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+__global__ void lw_imu_products(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int P = w.P;
+    const double *jscr = w.jscr; double *Hpp = w.Hpp, *gp = w.gp;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, k = t / 930, e = t - 930 * k;
-    if (k >= NF - 1) return;
+    if (k >= w.nimu) return;
     const int a = e / 31, b = e - 31 * a, c0 = 15 * k;
     const double *J = jscr + (size_t)k * 480;
     double s = 0;
@@ -309,28 +366,40 @@ __global__ void lw_imu_products(int NF, int P, const double *jscr, double *Hpp, 
     if (s == 0.0) return;
     if (b < 30) add(Hpp + (size_t)(c0 + a) * P + c0 + b, s); else add(gp + c0 + a, s);
 }
-// Jacobi scaling in place: Hpp(i, j) *= s_i s_j, W(f, c) *= s_f s_c, h_f *= s_f^2, g *= s. s = [P pose/speed-bias entries | F features]
-__global__ void lw_scale(int P, int F, const double *s, double *Hpp, double *W, double *hf, double *gp, double *gf, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+// Jacobi scaling in place: Hpp(i, j) *= s_i s_j, W(f, c) *= s_f s_c, h_f *= s_f^2, g *= s. s = [P pose/speed-bias entries | F features] (src 0: the minimizer's
+// scale vector, 1: vec — the host loop uploads it there)
+__global__ void lw_scale(const LwWin *ws, int src, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int P = w.P, F = w.F;
+    const double *s = src ? w.vec : w.scale;
+    double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gp = w.gp, *gf = w.gf;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
     if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); Hpp[t] *= s[i] * s[j]; }
     else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P), c = (int)(u % P); W[u] *= s[P + f] * s[c]; }
     else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); hf[f] *= s[P + f] * s[P + f]; gf[f] *= s[P + f]; }
     else if (t < nH + nW + F + P) { const int i = (int)(t - nH - nW - F); gp[i] *= s[i]; }
 }
-// S = Hpp + diag(lm_p^2); den_f = h_f + lm_f^2 (1 for constant features: their rows of W are zero); Wn = W / sqrt(den); tmpF = g_f / sqrt(den)
-__global__ void lw_schur_prep(int P, int F, const double *Hpp, const double *W, const double *hf, const double *gf, const double *lm, const unsigned char *fconst,
-                              double *S, double *Wn, double *den, double *tmpF, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+// S = Hpp + diag(lm_p^2); den_f = h_f + lm_f^2 (1 for constant features: their rows of W are zero); Wn = W / sqrt(den); tmpF = g_f / sqrt(den);
+// row P of S = g_p (the right-hand side rides through the factorisation as one more row); the factorisation's status word = 0. lm = vec.
+__global__ void lw_schur_prep(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int P = w.P, F = w.F;
+    const double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gf = w.gf, *lm = w.vec; const unsigned char *fconst = w.fconst;
+    double *S = w.S, *Wn = w.Wn, *den = w.den, *tmpF = w.tmpF;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
     if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); S[t] = Hpp[t] + (i == j ? lm[i] * lm[i] : 0.0); }
     else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; Wn[u] = W[u] / sqrt(d); }
     else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; den[f] = d; tmpF[f] = gf[f] / sqrt(d); }
+    else if (t < nH + nW + F + P) { const int i = (int)(t - nH - nW - F); S[nH + i] = w.gp[i]; }
+    else if (t == nH + nW + F + P) *w.info = 0;
 }
-__global__ void lw_feature_back(int F, const double *gf, const double *Wy, const double *den, double *yf, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+__global__ void lw_feature_back(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < F) yf[f] = (gf[f] - Wy[f]) / den[f];
+    if (f < w.F) w.yf[f] = (w.gf[f] - w.tmpF[f]) / w.den[f];
 }
 
 // ---- the Schur reduce S -= Wn^T Wn as a hand-written fp64 MFMA SYRK ------------------------------------------------------------------
@@ -341,12 +410,16 @@ __global__ void lw_feature_back(int F, const double *gf, const double *Wy, const
 #define SY_KB 32
 #define SY_LD 65
 typedef double lw_double4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void lw_syrk_mfma(int P, int F, const double *Wn, double *S, int ksplit, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+__global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int ksplit, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int P = w.P, F = w.F;
+    const double *Wn = w.Wn; double *S = w.S;
     __shared__ double sA[SY_KB * SY_LD], sB[SY_KB * SY_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
+    if (64 * ti >= P || F == 0) return;               // the grid is sized for the group's largest window
     const int tj = blockIdx.x - ti * (ti + 1) / 2, i0 = 64 * ti, j0 = 64 * tj;
     const int kchunk = ((F + ksplit - 1) / ksplit + SY_KB - 1) / SY_KB * SY_KB, kb = blockIdx.y * kchunk, ke = min(F, kb + kchunk);
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
@@ -538,10 +611,18 @@ __device__ __forceinline__ void lw_chol_panel_body(int P, double *S, int j0, int
                 }
     }
 }
-__global__ __launch_bounds__(256) void lw_chol_panel(int P, double *S, int j0, int *info, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+// block column 0. npanel = the slabs of 256 rows the block column needs (the grid is sized for the group's largest window)
+__device__ __forceinline__ int lw_chol_npanel(int P, int j0) { const int nb = min(CH_NB, P - j0), below = P + 1 - (j0 + nb); return max(1, (below + CH_BELOW - 1) / CH_BELOW); }
+__global__ __launch_bounds__(256) void lw_chol_panel(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    if ((int)blockIdx.x >= lw_chol_npanel(w.P, 0)) return;
     __shared__ double s_pan[256 * 4], s_lp[256 * 4];
-    lw_chol_panel_body<false>(P, S, j0, info, (int)blockIdx.x, s_pan, s_lp);
+    lw_chol_panel_body<false>(w.P, w.S, 0, w.info, (int)blockIdx.x, s_pan, s_lp);
+}
+__global__ __launch_bounds__(256) void lw_chol_panel_raw(int P, double *S, int *info) {
+    __shared__ double s_pan[256 * 4], s_lp[256 * 4];
+    lw_chol_panel_body<false>(P, S, 0, info, (int)blockIdx.x, s_pan, s_lp);
 }
 // A22 -= L21 L21^T, lower 64 x 64 tiles of the rows / columns j1 .. P (row P = rhs). Tile u of the lower triangle, shifted by `shift` tile rows / columns
 // (shift 1 = lw_chol_step: the tiles right of the next block column; that column itself is the panel workgroups')
@@ -589,11 +670,21 @@ __device__ __forceinline__ void lw_chol_update_body(int P, double *S, int j0, in
 // One launch per block column j0 >= 64: the first npanel workgroups factor block column j0 (taking the update of column j0 - 64 into their registers first),
 // the others apply the update of column j0 - 64 to the tiles right of block column j0. The two sets write disjoint parts of S and both only read column j0 - 64:
 // the panel no longer waits for a whole trailing update, and a block column costs one launch instead of two.
-__global__ __launch_bounds__(256) void lw_chol_step(int P, double *S, int j0, int npanel, int *info, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
-    __shared__ double s_buf[2 * CH_NB * CH_LD];
+__device__ __forceinline__ void lw_chol_step_body(int P, double *S, int j0, int *info, double *s_buf) {
+    const int npanel = lw_chol_npanel(P, j0), nt = (P + 1 - j0 + 63) / 64;     // tiles of the rows / columns j0 .. P; column 0 of them is the panel's
+    if ((int)blockIdx.x >= npanel + nt * (nt - 1) / 2) return;
     if ((int)blockIdx.x < npanel) lw_chol_panel_body<true>(P, S, j0, info, (int)blockIdx.x, s_buf, s_buf + 256 * 4);
     else lw_chol_update_body(P, S, j0 - CH_NB, CH_NB, (int)blockIdx.x - npanel, 1, s_buf, s_buf + CH_NB * CH_LD);
+}
+__global__ __launch_bounds__(256) void lw_chol_step(const LwWin *ws, int j0, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk) || j0 >= w.P) return;          // device trust-region loop: not needed; a smaller window of the group: already factored
+    __shared__ double s_buf[2 * CH_NB * CH_LD];
+    lw_chol_step_body(w.P, w.S, j0, w.info, s_buf);
+}
+__global__ __launch_bounds__(256) void lw_chol_step_raw(int P, double *S, int j0, int *info) {
+    __shared__ double s_buf[2 * CH_NB * CH_LD];
+    lw_chol_step_body(P, S, j0, info, s_buf);
 }
 // L^T y = z, z = row P of the factor; one workgroup, columns right to left in 64-blocks. Per block: wave 0 solves the block's triangle — lane = row, the 64 steps
 // fully unrolled so that the pivot row's value travels by v_readlane (a shuffle per step through LDS and a division per step were most of the 215 us this kernel
@@ -602,10 +693,7 @@ __global__ __launch_bounds__(256) void lw_chol_step(int P, double *S, int j0, in
 __device__ __forceinline__ double lw_readlane(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-__global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, double *y, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
-    extern __shared__ double s_y[];                // P entries
-    __shared__ double s_blk[CH_NB], s_tri[CH_NB * CH_LD];
+__device__ __forceinline__ void lw_chol_back_body(int P, const double *S, double *y, double *s_y, double *s_blk, double *s_tri) {
     const int tid = threadIdx.x;
     for (int i = tid; i < P; i += 1024) s_y[i] = S[(size_t)P * P + i];
     const int nblk = (P + CH_NB - 1) / CH_NB;
@@ -657,27 +745,47 @@ __global__ __launch_bounds__(1024) void lw_chol_back(int P, const double *S, dou
     }
     for (int i = tid; i < P; i += 1024) y[i] = s_y[i];
 }
-// row-wise dots y[r] = A[r][0..C) . x (one 64-lane wave per row, A row-major) and column sums y[c] += alpha sum_r A[r][c] x[r] (thread per column)
-__global__ __launch_bounds__(256) void lw_rowdot(int R, int C, const double *A, const double *x, double *y, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= R) return;
-    const double *a = A + (size_t)row * C;
+__global__ __launch_bounds__(1024) void lw_chol_back(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    extern __shared__ double s_y[];                   // P entries (of the group's largest window)
+    __shared__ double s_blk[CH_NB], s_tri[CH_NB * CH_LD];
+    lw_chol_back_body(w.P, w.S, w.rhs, s_y, s_blk, s_tri);
+}
+__global__ __launch_bounds__(1024) void lw_chol_back_raw(int P, const double *S, double *y) {
+    extern __shared__ double s_y[];
+    __shared__ double s_blk[CH_NB], s_tri[CH_NB * CH_LD];
+    lw_chol_back_body(P, S, y, s_y, s_blk, s_tri);
+}
+// row-wise dots y[r] = A[r][0..P) . v, one 64-lane wave per row. mode 0 (x^T H x pieces for the vector in vec): rows 0 .. P - 1: Hpp vec -> tmpP, rows P .. P + F - 1:
+// W_f . vec -> tmpF; mode 1 (back substitution of the features): W_f . rhs -> tmpF
+__global__ __launch_bounds__(256) void lw_rowdot(const LwWin *ws, int mode, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, C = w.P;
+    if (row >= (mode == 0 ? w.P + w.F : w.F)) return;
+    const bool hp = mode == 0 && row < w.P;
+    const int r = hp ? row : (mode == 0 ? row - w.P : row);
+    const double *a = (hp ? w.Hpp : w.W) + (size_t)r * C, *x = mode == 0 ? w.vec : w.rhs;
     double s = 0;
     for (int c = lane; c < C; c += 64) s += a[c] * x[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) y[row] = s;
+    if (lane == 0) (hp ? w.tmpP : w.tmpF)[r] = s;
 }
-__global__ __launch_bounds__(256) void lw_colsum(int R, int C, const double *A, const double *x, double alpha, double *y, int rsplit, const int *skip) {
-    if (skip && *skip) return;                        // device trust-region loop: this part of the iteration is not needed
+// rhs row of S -= Wn^T (g_f / sqrt(den)): column sums over row chunks (thread per column, blockIdx.y = chunk), combined with atomics
+__global__ __launch_bounds__(256) void lw_colsum(const LwWin *ws, int rsplit, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int R = w.F, C = w.P;
+    const double *A = w.Wn, *x = w.tmpF; double *y = w.S + (size_t)C * C;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int rchunk = (R + rsplit - 1) / rsplit, ra = blockIdx.y * rchunk, rb = min(R, ra + rchunk);
     double s = 0;
 #pragma unroll 8
     for (int r = ra; r < rb; r++) s += A[(size_t)r * C + c] * x[r];
-    unsafeAtomicAdd(y + c, alpha * s);
+    if (ra < rb) unsafeAtomicAdd(y + c, -s);
 }
 
 // ---- host-side manifold helpers (PoseLocalParameterization, utility.h) ------------------------------------------------------------
@@ -721,27 +829,6 @@ inline void h_ypr2R(const double *ypr, double *R) {
 // anything back; every launch of an iteration looks at the skip flags (a finished solve, a rejected step that reuses the linear solve, an invalid
 // step that needs no evaluation) and returns at once when its part is not needed. What the device loop does not do: raise mu and factor again after a
 // failed Cholesky (the number of launches is not known when they are enqueued) — it sets `fallback` and the host loop redoes the solve.
-struct LwCtl {
-    double radius, mu, alpha, step_norm, x_cost, cand_cost, x_norm, gmax, model_change, initial_cost, gg;
-    int iteration, reuse, done, termination, num_successful, num_linear_solves, consecutive_invalid, fallback;
-    int skip_solve, skip_quad, skip_eval, skip_jac, scaling_ready, pad_;
-};
-struct LwTr {
-    LwCtl *ctl;
-    int NF, F, P, N, cEx, cTd, xo, est_ex, est_td, max_it;
-    double *x, *cand;                                              // state: pose | sb | feat | ex[7] | td
-    double *g, *diagH, *scale, *diagonal, *gradient, *gn, *step;   // N each
-    double *vec, *yf;                                              // N: the vector handed to lw_rowdot / lw_schur_prep; F: the feature part of the linear solve
-    double *tmpP, *tmpF, *rhs;
-    const unsigned char *fconst;
-    const double *Hpp, *hf, *gp, *gf;
-    double *scal;
-    const int *info;
-    int pn, pnb;
-    const int *phdr;
-    const double *px0;
-    double *pdx;
-};
 namespace {
 using namespace vd;
 #define TR_T 1024
@@ -767,7 +854,7 @@ __device__ __forceinline__ double tr_max(double v, double *s_red) {
 }
 __device__ __forceinline__ void tr_finish(LwCtl *c, int term) { c->termination = term; c->done = 1; c->skip_solve = c->skip_quad = c->skip_eval = c->skip_jac = 1; }
 // o = Plus(xx, d): tangent d[N] = [15 per frame: pose 6, speed-bias 9 | ex 6 | td | F]
-__device__ void tr_plus(const LwTr &a, const double *xx, const double *d, double sgn, double *o) {
+__device__ void tr_plus(const LwWin &a, const double *xx, const double *d, double sgn, double *o) {
     const int tid = threadIdx.x, NF = a.NF;
     for (int i = tid; i < NF; i += TR_T) {
         double dd[6];
@@ -784,7 +871,7 @@ __device__ void tr_plus(const LwTr &a, const double *xx, const double *d, double
 }
 // sum over the entries Ceres counts in ||x||: every frame block, the free features, Ex_Pose / td when they are estimated. fn(i) = the term of entry i
 template <class Fn>
-__device__ __forceinline__ double tr_state_sum(const LwTr &a, Fn fn, double *s_red) {
+__device__ __forceinline__ double tr_state_sum(const LwWin &a, Fn fn, double *s_red) {
     double s = 0;
     for (int i = threadIdx.x; i < 16 * a.NF; i += TR_T) s += fn(i);
     for (int f = threadIdx.x; f < a.F; f += TR_T) if (!a.fconst[f]) s += fn(16 * a.NF + f);
@@ -795,7 +882,7 @@ __device__ __forceinline__ double tr_state_sum(const LwTr &a, Fn fn, double *s_r
     return tr_sum(s, s_red);
 }
 // marginalization_factor.cpp:345-363: dx of the prior's blocks at the state xx
-__device__ void tr_prior_dx(const LwTr &a, const double *xx) {
+__device__ void tr_prior_dx(const LwWin &a, const double *xx) {
     const int bk = threadIdx.x;
     if (bk >= a.pnb) return;
     const int id = a.phdr[3 + bk], idx = a.phdr[51 + bk], NF = a.NF;
@@ -811,7 +898,8 @@ __device__ void tr_prior_dx(const LwTr &a, const double *xx) {
     else if (id == 2 * NF) pose_dx(xx + a.xo, a.pdx + idx);
     else if (id == 2 * NF + 1) a.pdx[idx] = xx[a.xo + 7] - x0[0];
 }
-__global__ __launch_bounds__(TR_T) void lw_tr_init(LwTr a) {
+__global__ __launch_bounds__(TR_T) void lw_tr_init(const LwWin *ws) {
+    const LwWin &a = ws[blockIdx.z];
     __shared__ double s_red[TR_T / 64];
     LwCtl *c = a.ctl;
     for (int i = threadIdx.x; i < VB_PRIOR_LD; i += TR_T) a.pdx[i] = 0.0;
@@ -827,7 +915,8 @@ __global__ __launch_bounds__(TR_T) void lw_tr_init(LwTr a) {
 }
 // after a linearisation at x (eval_grad_jac of the host loop): cost, diagonal / gradient pieces, the Jacobi scaling (fixed by the first linearisation),
 // gradient_max_norm = || x - Plus(x, -g) ||_inf with the unscaled gradient; lw_scale follows with a.scale
-__global__ __launch_bounds__(TR_T) void lw_tr_post(LwTr a, int first) {
+__global__ __launch_bounds__(TR_T) void lw_tr_post(const LwWin *ws, int first) {
+    const LwWin &a = ws[blockIdx.z];
     __shared__ double s_red[TR_T / 64];
     LwCtl *c = a.ctl;
     if (c->skip_jac) return;
@@ -849,7 +938,8 @@ __global__ __launch_bounds__(TR_T) void lw_tr_post(LwTr a, int first) {
     if (tid == 0) { c->gmax = m; c->x_cost = a.scal[0]; if (first) c->initial_cost = a.scal[0]; c->scaling_ready = 1; }
 }
 // top of an iteration (the tests of trust_region_minimizer.cc before a step) and, unless the last linear solve is reused, the vectors the dogleg needs
-__global__ __launch_bounds__(TR_T) void lw_tr_begin(LwTr a) {
+__global__ __launch_bounds__(TR_T) void lw_tr_begin(const LwWin *ws) {
+    const LwWin &a = ws[blockIdx.z];
     __shared__ double s_red[TR_T / 64];
     LwCtl *c = a.ctl;
     if (c->done) return;
@@ -872,7 +962,8 @@ __global__ __launch_bounds__(TR_T) void lw_tr_begin(LwTr a) {
     }
 }
 // alpha = |gradient|^2 / |J gradient|^2 (Cauchy point) from the products lw_rowdot left in tmpP / tmpF; the LM diagonal of this solve goes to vec
-__global__ __launch_bounds__(TR_T) void lw_tr_alpha(LwTr a) {
+__global__ __launch_bounds__(TR_T) void lw_tr_alpha(const LwWin *ws) {
+    const LwWin &a = ws[blockIdx.z];
     __shared__ double s_red[TR_T / 64];
     LwCtl *c = a.ctl;
     if (c->skip_solve) return;
@@ -898,7 +989,8 @@ __global__ __launch_bounds__(TR_T) void lw_tr_alpha(LwTr a) {
     }
 }
 // the Gauss-Newton step from the linear solve (or the one kept from the last solve) and the traditional dogleg step for the current radius; step -> vec
-__global__ __launch_bounds__(TR_T) void lw_tr_step(LwTr a) {
+__global__ __launch_bounds__(TR_T) void lw_tr_step(const LwWin *ws) {
+    const LwWin &a = ws[blockIdx.z];
     __shared__ double s_red[TR_T / 64];
     LwCtl *c = a.ctl;
     if (c->done) return;
@@ -935,11 +1027,13 @@ __global__ __launch_bounds__(TR_T) void lw_tr_step(LwTr a) {
     if (tid == 0) c->step_norm = nrm;
 }
 // model_cost_change from step^T H step (lw_rowdot products), the candidate Plus(x, step * scale), its prior dx, the parameter-tolerance test
-__global__ __launch_bounds__(TR_T) void lw_tr_model(LwTr a) {
+__global__ __launch_bounds__(TR_T) void lw_tr_model(const LwWin *ws) {
+    const LwWin &a = ws[blockIdx.z];
     __shared__ double s_red[TR_T / 64];
     LwCtl *c = a.ctl;
     if (c->done) return;
     const int tid = threadIdx.x, P = a.P, N = a.N;
+    if (tid == 0) a.scal[0] = 0.0;                              // the cost at the candidate accumulates here (the evaluation that follows)
     double q = 0, gs = 0;
     for (int i = tid; i < N; i += TR_T) {
         const double v = a.step[i];
@@ -970,7 +1064,8 @@ __global__ __launch_bounds__(TR_T) void lw_tr_model(LwTr a) {
     }
 }
 // the cost at the candidate is in scal[0]: function tolerance, relative decrease, accept / reject, radius and mu updates
-__global__ __launch_bounds__(TR_T) void lw_tr_decide(LwTr a) {
+__global__ __launch_bounds__(TR_T) void lw_tr_decide(const LwWin *ws) {
+    const LwWin &a = ws[blockIdx.z];
     __shared__ double s_red[TR_T / 64];
     __shared__ int s_acc;
     LwCtl *c = a.ctl;
@@ -1011,156 +1106,130 @@ __global__ __launch_bounds__(TR_T) void lw_tr_decide(LwTr a) {
 // is set to 1 when a pivot is not positive. Everything is enqueued on the handle's stream.
 // lw_chol_back keeps the solution vector in LDS (n doubles of dynamic LDS beside 33.8 KB of static staging): 12288 x 8 + 33.8 KB = 130 KB of the CU's 160 KB
 int vilf_lw_chol_max_n() { return 12288; }
-int vilf_lw_chol_solve(vilf_handle *h, int n, double *S, double *y, int *info) {
-    if (n < 1 || n > vilf_lw_chol_max_n()) { h->err = "vilf_lw_chol_solve: dimension outside the supported range (1 .. 12288)"; return VILF_ERR_UNSUPPORTED; }
-    static bool attr_set = false;                  // above 64 KB in all, a launch needs the attribute; set once, for the largest supported n
+static int lw_chol_back_attr(vilf_handle *h) {     // above 64 KB in all, a launch needs the attribute; set once, for the largest supported n
+    static bool attr_set = false;
     if (!attr_set) {
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(lw_chol_back_raw), hipFuncAttributeMaxDynamicSharedMemorySize, vilf_lw_chol_max_n() * 8));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(lw_chol_back), hipFuncAttributeMaxDynamicSharedMemorySize, vilf_lw_chol_max_n() * 8));
         attr_set = true;
     }
+    return VILF_OK;
+}
+int vilf_lw_chol_solve(vilf_handle *h, int n, double *S, double *y, int *info) {
+    if (n < 1 || n > vilf_lw_chol_max_n()) { h->err = "vilf_lw_chol_solve: dimension outside the supported range (1 .. 12288)"; return VILF_ERR_UNSUPPORTED; }
+    const int rca = lw_chol_back_attr(h);
+    if (rca != VILF_OK) return rca;
     for (int j0 = 0; j0 < n; j0 += CH_NB) {
         const int nb = std::min(CH_NB, n - j0), below = n + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
-        if (j0 == 0) hipLaunchKernelGGL(lw_chol_panel, dim3(npanel), dim3(256), 0, h->stream, n, S, j0, info, (const int *)nullptr);
+        if (j0 == 0) hipLaunchKernelGGL(lw_chol_panel_raw, dim3(npanel), dim3(256), 0, h->stream, n, S, info);
         else {
             const int nt = (n + 1 - j0 + 63) / 64;
-            hipLaunchKernelGGL(lw_chol_step, dim3(npanel + nt * (nt - 1) / 2), dim3(256), 0, h->stream, n, S, j0, npanel, info, (const int *)nullptr);
+            hipLaunchKernelGGL(lw_chol_step_raw, dim3(npanel + nt * (nt - 1) / 2), dim3(256), 0, h->stream, n, S, j0, info);
         }
     }
-    hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), (size_t)n * 8, h->stream, n, S, y, (const int *)nullptr);
+    hipLaunchKernelGGL(lw_chol_back_raw, dim3(1), dim3(1024), (size_t)n * 8, h->stream, n, S, y);
     HIPCHECK(h, hipGetLastError());
     return VILF_OK;
 }
 
-// batch_slot0 != 0: the window is also resident as slot 0 of the 11-frame batch (vilf_batch_upload ran): use that slot's prior and write
-// the solved state back into the batch buffers (the marginalization reads them)
-int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot1) {
-    const int batch_slot0 = batch_slot1 != 0;          // resident in the 11-frame batch
-    const size_t slot = batch_slot1 ? (size_t)(batch_slot1 - 1) : 0;
-    const auto t_start = std::chrono::steady_clock::now();
-    const bool est_ex = h->opts.estimate_extrinsic != 0, est_td = h->opts.estimate_td != 0;
-    const int NF = in->n_frames, F = in->n_features;
-    const int cEx = est_ex ? 15 * NF : -1, cTd = est_td ? 15 * NF + (est_ex ? 6 : 0) : -1;      // columns of Ex_Pose / td after the frame blocks
-    const int P = 15 * NF + (est_ex ? 6 : 0) + (est_td ? 1 : 0), N = P + F;
-    const size_t xo = 16 * (size_t)NF + F;                                                        // x = pose | sb | feat | ex[7] | td
-    if (NF < 2 || F < 0 || !in->para_pose || !in->para_speed_bias || !in->imu || (F && (!in->para_feature || !in->feature_const || !in->feature_start_frame || !in->feature_obs_offset || !in->obs_point)))
-        return VILF_ERR_INVALID_ARGUMENT;
-    if (in->n_obs < 0 || (F && (in->feature_obs_offset[0] != 0 || in->feature_obs_offset[F] != in->n_obs)) || (!F && in->n_obs != 0)) { h->err = "feature_obs_offset must start at 0 and end at n_obs"; return VILF_ERR_INVALID_ARGUMENT; }
-    for (int f = 0; f < F; f++) if (in->feature_obs_offset[f + 1] - in->feature_obs_offset[f] < 2) { h->err = "feature with fewer than two observations"; return VILF_ERR_INVALID_ARGUMENT; }
-    if (est_td && F && (!in->obs_velocity || !in->obs_cur_td || !in->obs_row)) { h->err = "estimate_td needs obs_velocity / obs_cur_td / obs_row"; return VILF_ERR_INVALID_ARGUMENT; }
-    if (batch_slot0 && (NF != VB_NF || !h->resident || (int)slot >= h->B)) return VILF_ERR_INVALID_ARGUMENT;
-    HIPCHECK(h, hipSetDevice(h->device));
-    if (!h->lw) h->lw = new LwCtx();
-    LwCtx *c = h->lw;
-    const bool prof = h->profiling != 0;
-    if (prof && !c->ev[0]) { hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); }
-    auto tic = [&]() { if (prof) hipEventRecord(c->ev[0], h->stream); };
-    auto toc = [&](int grp) { if (prof) { hipEventRecord(c->ev[1], h->stream); hipEventSynchronize(c->ev[1]); float t = 0; hipEventElapsedTime(&t, c->ev[0], c->ev[1]); c->ms[grp] += t; c->launches[grp] += 1; } };
-    // ---- pack the factors
-    // pair-sorted (lw_visual flushes one block per run of equal pairs): counting sort over the NF^2 pair keys, stable in feature order
-    const int nfac_in = std::max(0, in->n_obs - F);
-    std::vector<LwVis> vis(std::max(nfac_in, 1));
-    std::vector<int> vis_obs(2 * (size_t)std::max(nfac_in, 1));    // (first, this) observation index of every factor: the td constants follow the pair sort
-    std::vector<int> pair_cnt((size_t)NF * NF + 1, 0);
-    for (int f = 0; f < F; f++) {
-        const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
-        if (s < 0 || s + (o1 - o0) > NF) { h->err = "feature track leaves the window"; return VILF_ERR_INVALID_ARGUMENT; }
-        for (int t = o0 + 1; t < o1; t++) pair_cnt[(size_t)s * NF + s + (t - o0) + 1]++;
-    }
-    for (size_t k = 1; k < pair_cnt.size(); k++) pair_cnt[k] += pair_cnt[k - 1];
-    for (int f = 0; f < F; f++) {
-        const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
-        for (int t = o0 + 1; t < o1; t++) {
-            const int k = pair_cnt[(size_t)s * NF + s + (t - o0)]++;
-            LwVis &v = vis[k];
-            for (int q = 0; q < 3; q++) { v.pi[q] = in->obs_point[3 * (size_t)o0 + q]; v.pj[q] = in->obs_point[3 * (size_t)t + q]; }
-            v.f = f; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
-            vis_obs[2 * (size_t)k] = o0; vis_obs[2 * (size_t)k + 1] = t;
-        }
-    }
-    const int nvis = nfac_in, nimu = NF - 1;
-    std::vector<LwTd> tdrec;
-    if (est_td) {                                     // projection_td_factor.cpp:6-21
-        tdrec.resize(std::max(nvis, 1));
-        for (int k = 0; k < nvis; k++) {
-            const int oi = vis_obs[2 * k], oj = vis_obs[2 * k + 1];
-            LwTd &q = tdrec[k];
-            q.vi[0] = in->obs_velocity[2 * (size_t)oi]; q.vi[1] = in->obs_velocity[2 * (size_t)oi + 1]; q.vj[0] = in->obs_velocity[2 * (size_t)oj]; q.vj[1] = in->obs_velocity[2 * (size_t)oj + 1];
-            q.tdi = in->obs_cur_td[oi]; q.tdj = in->obs_cur_td[oj]; q.rowi_c = in->obs_row[oi] - h->opts.ROW / 2; q.rowj_c = in->obs_row[oj] - h->opts.ROW / 2;
-        }
-    }
-    std::vector<double> imu((size_t)nimu * IMU_REC, 0.0), cov((size_t)nimu * 225), lid((size_t)nimu * 7, 0.0);
-    for (int k = 0; k < nimu; k++) {
-        const vilf_imu_preint &p = in->imu[k + 1];
-        double *rec = &imu[(size_t)k * IMU_REC];
-        rec[0] = p.sum_dt;
-        for (int i = 0; i < 3; i++) { rec[1 + i] = p.delta_p[i]; rec[8 + i] = p.delta_v[i]; rec[11 + i] = p.linearized_ba[i]; rec[14 + i] = p.linearized_bg[i]; }
-        for (int i = 0; i < 4; i++) rec[4 + i] = p.delta_q[i];
-        auto blk = [&](int off, int r0, int c0) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rec[off + 3 * i + j] = p.jacobian[(r0 + i) * 15 + c0 + j]; };
-        blk(17, 0, 9); blk(26, 0, 12); blk(35, 3, 12); blk(44, 6, 9); blk(53, 6, 12);
-        rec[287] = (p.sum_dt > 10.0) ? 0.0 : 1.0;
-        std::memcpy(&cov[(size_t)k * 225], p.covariance, 225 * 8);
-        if (in->lidar) { const vilf_lidar_constraint &l = in->lidar[k + 1]; for (int i = 0; i < 4; i++) lid[7 * k + i] = l.q[i]; for (int i = 0; i < 3; i++) lid[7 * k + 4 + i] = l.t[i]; }
-        else lid[7 * k + 3] = 1.0;
-    }
-    const bool use_lidar = h->opts.use_lidar_const && in->lidar;
-    // extrinsic-derived constants (lidar_factor.h:28-29): q_il = RIC RCL, t_il = RIC TCL + TIC
-    double Ril[9], qil[4], til[3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += h->opts.RIC[3 * i + k] * h->opts.RCL[3 * k + j]; Ril[3 * i + j] = s; }
-    for (int i = 0; i < 3; i++) { double s = h->opts.TIC[i]; for (int k = 0; k < 3; k++) s += h->opts.RIC[3 * i + k] * h->opts.TCL[k]; til[i] = s; }
-    {   // rotation matrix -> quaternion (Eigen's branch on the trace)
-        const double *m = Ril; const double tr = m[0] + m[4] + m[8];
-        double q[4];
-        if (tr > 0) { double t = std::sqrt(tr + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t; }
-        else { int i = 0; if (m[4] > m[0]) i = 1; if (m[8] > m[4 * i]) i = 2; const int j = (i + 1) % 3, k = (j + 1) % 3; double t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t; q[3] = (m[3 * k + j] - m[3 * j + k]) * t; q[j] = (m[3 * j + i] + m[3 * i + j]) * t; q[k] = (m[3 * k + i] + m[3 * i + k]) * t; }
-        for (int k = 0; k < 4; k++) qil[k] = q[k];
-    }
-    // ---- device buffers
-    const size_t sP = P, sF = std::max(F, 1), sN = N;
-    if (!c->x.ensure((16 * (size_t)NF + sF + 8) * 8) || !c->tdrec.ensure(std::max<size_t>(tdrec.size(), 1) * sizeof(LwTd)) || !c->pri.ensure(2 * VB_PRIOR_LD * 8) || !c->ex.ensure(7 * 8 + 64) || !c->vis.ensure(std::max<size_t>(nvis, 1) * sizeof(LwVis)) || !c->imu.ensure(imu.size() * 8) || !c->cov.ensure(cov.size() * 8) ||
-        !c->lid.ensure(lid.size() * 8) || !c->Hpp.ensure(sP * sP * 8) || !c->W.ensure(sF * sP * 8) || !c->hf.ensure(sF * 8) || !c->gp.ensure(sP * 8) || !c->gf.ensure(sF * 8) || !c->S.ensure((sP + 1) * sP * 8) ||
-        !c->Wn.ensure(sF * sP * 8) || !c->rhs.ensure(sP * 8) || !c->tmpP.ensure(sP * 8) || !c->tmpF.ensure(sF * 8) || !c->vec.ensure(2 * sN * 8) || !c->scal.ensure(256) || !c->info.ensure(64) ||
-        !c->fconst.ensure(sF) || !c->den.ensure(sF * 8) || !c->jscr.ensure((size_t)nimu * 480 * 8)) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
-    double geo[7 + 3 + 4];
-    for (int k = 0; k < 4; k++) geo[k] = qil[k];
-    for (int k = 0; k < 3; k++) geo[4 + k] = til[k];
-    for (int k = 0; k < 3; k++) geo[7 + k] = h->opts.G[k];
-    HIPCHECK(h, hipMemcpyAsync(c->ex.p, in->para_ex_pose, 56, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(c->scal.as<double>() + 1, geo, 10 * 8, hipMemcpyHostToDevice, h->stream));        // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
-    if (nvis) HIPCHECK(h, hipMemcpyAsync(c->vis.p, vis.data(), (size_t)nvis * sizeof(LwVis), hipMemcpyHostToDevice, h->stream));
-    if (est_td && nvis) HIPCHECK(h, hipMemcpyAsync(c->tdrec.p, tdrec.data(), (size_t)nvis * sizeof(LwTd), hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(c->imu.p, imu.data(), imu.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(c->cov.p, cov.data(), cov.size() * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHECK(h, hipMemcpyAsync(c->lid.p, lid.data(), lid.size() * 8, hipMemcpyHostToDevice, h->stream));
-    if (F) HIPCHECK(h, hipMemcpyAsync(c->fconst.p, in->feature_const, F, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, c->cov.as<double>(), c->tmpP.as<double>(), c->imu.as<double>());
-    double *scal = c->scal.as<double>();
-    const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = h->opts.cauchy_a * h->opts.cauchy_a;      // rho(s) = b log(1 + s / b), b = a^2 (ceres CauchyLoss; same as the batched path)
-
-    // ---- host state: x = pose | sb | feat
-    std::vector<double> x(xo + 8), cand(x.size());
-    std::memcpy(&x[0], in->para_pose, 7 * NF * 8); std::memcpy(&x[7 * NF], in->para_speed_bias, 9 * NF * 8);
-    for (int f = 0; f < F; f++) x[16 * NF + f] = in->para_feature[f];
-    std::memcpy(&x[xo], in->para_ex_pose, 56); x[xo + 7] = in->para_td;
-    // ---- the slot-0 prior of the 11-frame batch (marginalization_factor.cpp:333-381): block table on the host, J0 / r0 / J0^T J0 stay on the device
+namespace {
+// ---- one window of a group on the host -------------------------------------------------------------------------------------------
+struct LwHostWin {
+    const vilf_window_in *in = nullptr;
+    vilf_window_out *out = nullptr;
+    bool resident = false;             // also a slot of the 11-frame batch: its prior applies, the solved state goes back into the batch buffers
+    size_t slot = 0;
+    int NF = 0, F = 0, P = 0, N = 0, nvis = 0, nimu = 0, cEx = -1, cTd = -1;
+    size_t xo = 0;
+    bool use_lidar = false;
     int pn = 0, pnb = 0, phdr[VB_PRIOR_HDR];
-    std::vector<double> px0(24 * 9), pdx(VB_PRIOR_LD, 0.0);
-    std::vector<int> pcol(VB_PRIOR_LD, -1);
-    if (batch_slot0) {
-        HIPCHECK(h, hipMemcpyAsync(phdr, h->d[D_PHDR].as<int>() + slot * VB_PRIOR_HDR, sizeof(phdr), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(px0.data(), h->d[D_PX0].as<double>() + slot * 24 * 9, px0.size() * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipStreamSynchronize(h->stream));
-        if (phdr[0]) {
-            pn = phdr[1]; pnb = phdr[2];
-            for (int bk = 0; bk < pnb; bk++) {
-                const int id = phdr[3 + bk], idx = phdr[51 + bk];
-                if (id < NF) for (int k = 0; k < 6; k++) pcol[idx + k] = 15 * id + k;
-                else if (id < 2 * NF) for (int k = 0; k < 9; k++) pcol[idx + k] = 15 * (id - NF) + 6 + k;
-                else if (id == 2 * NF && est_ex) for (int k = 0; k < 6; k++) pcol[idx + k] = cEx + k;
-                else if (id == 2 * NF + 1 && est_td) pcol[idx] = cTd;                       // para_Td, kept by the marginalization (estimator.cpp:930-935,968-969)
+    double px0[24 * 9];
+    std::vector<double> x;             // the state: pose | sb | feat | ex[7] | td
+    LwWin dw;                          // the descriptor (device pointers)
+    size_t o_vis = 0, o_tdr = 0, o_fconst = 0, o_scal = 0, o_pcol = 0, o_lid = 0;       // offsets of the inputs in the staging image (imu / cov / x: group-wide runs)
+    // results of the device loop
+    LwCtl hc;
+};
+// launch shapes for a set of windows (the whole group, or one window for the host loop): every grid is sized for the largest window, the others' surplus
+// workgroups return at once
+struct LwDims {
+    int G = 0, maxP = 0, maxF = 0, maxNvis = 0, maxNimu = 0;
+    bool any_prior = false;
+    void take(const LwHostWin &w) {
+        G++; maxP = std::max(maxP, w.P); maxF = std::max(maxF, w.F); maxNvis = std::max(maxNvis, w.nvis); maxNimu = std::max(maxNimu, w.nimu);
+        any_prior = any_prior || w.pn != 0;
+    }
+};
+struct LwEnq {
+    vilf_handle *h; LwCtx *c; const LwWin *ws; LwDims d; bool ext, prof;
+    void tic() { if (prof) hipEventRecord(c->ev[0], h->stream); }
+    void toc(int grp) { if (prof) { hipEventRecord(c->ev[1], h->stream); hipEventSynchronize(c->ev[1]); float t = 0; hipEventElapsedTime(&t, c->ev[0], c->ev[1]); c->ms[grp] += t; c->launches[grp] += 1; } }
+    dim3 grid(size_t gx, unsigned gy = 1) const { return dim3((unsigned)std::max<size_t>(gx, 1), gy, (unsigned)d.G); }
+    // one evaluation at the device state x (which = 0) or cand (1), the prior's dx already in pdx. Cost only (jac = 0): the caller has zeroed scal[0]
+    void evaluate(int which, int jac, int sk) {
+        const size_t sP = d.maxP, sF = d.maxF;
+        if (jac) {      // one launch clears the cost and the five accumulation targets
+            const size_t tot = sP * sP + sF * sP + 2 * sF + sP + 1;
+            hipLaunchKernelGGL(lw_clear, grid((tot + 1023) / 1024), dim3(256), 0, h->stream, ws, sk);
+            tic();
+        }
+        if (d.maxNvis) {
+            if (ext) hipLaunchKernelGGL(lw_visual_ext, grid((d.maxNvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, ws, which, jac, sk);
+            else hipLaunchKernelGGL(lw_visual, grid((d.maxNvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, ws, which, jac, sk);
+        }
+        if (d.any_prior) hipLaunchKernelGGL(lw_prior, grid(1), dim3(256), 0, h->stream, ws, jac, sk);
+        hipLaunchKernelGGL(lw_imu_lidar, grid(d.maxNimu), dim3(128), 0, h->stream, ws, which, jac, sk);
+        if (jac) { hipLaunchKernelGGL(lw_imu_products, grid(((size_t)d.maxNimu * 930 + 255) / 256), dim3(256), 0, h->stream, ws, sk); toc(0); }
+    }
+    // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in vec
+    void quad(int sk) { hipLaunchKernelGGL(lw_rowdot, grid((d.maxP + d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, 0, sk); }
+    void scale(int src, int sk) {
+        const size_t sP = d.maxP, sF = d.maxF, tot = sP * sP + sF * sP + sF + sP;
+        hipLaunchKernelGGL(lw_scale, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, src, sk);
+    }
+    // one linear solve (H' + lm^2) y = g' with lm in vec: y_p -> rhs, y_f -> yf, the Cholesky's status -> info
+    void linear_solve(int sk) {
+        const size_t sP = d.maxP, sF = d.maxF, tot = sP * sP + sF * sP + sF + sP + 1;
+        hipLaunchKernelGGL(lw_schur_prep, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, sk);
+        if (d.maxF) {
+            // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P), rhs -= Wn^T (g_f / sqrt(den))
+            tic();
+            const int nt = (d.maxP + 63) / 64, ksplit = d.G >= 4 ? 1 : 4;      // K splits only while the tiles alone do not fill the chip
+            hipLaunchKernelGGL(lw_syrk_mfma, grid(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, ws, ksplit, sk);
+            toc(1);
+            const int rsplit = d.G >= 8 ? 16 : 128;
+            hipLaunchKernelGGL(lw_colsum, grid((d.maxP + 255) / 256, rsplit), dim3(256), 0, h->stream, ws, rsplit, sk);
+        }
+        tic();
+        for (int j0 = 0; j0 < d.maxP; j0 += CH_NB) {                     // blocked Cholesky, one launch per 64-column block (panel of this column + the rest of the previous column's update)
+            const int nb = std::min(CH_NB, d.maxP - j0), below = d.maxP + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
+            if (j0 == 0) hipLaunchKernelGGL(lw_chol_panel, grid(npanel), dim3(256), 0, h->stream, ws, sk);
+            else {
+                const int nt = (d.maxP + 1 - j0 + 63) / 64;
+                hipLaunchKernelGGL(lw_chol_step, grid(npanel + nt * (nt - 1) / 2), dim3(256), 0, h->stream, ws, j0, sk);
             }
-            HIPCHECK(h, hipMemcpyAsync(c->pri.as<char>() + VB_PRIOR_LD * 8, pcol.data(), VB_PRIOR_LD * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        }
+        hipLaunchKernelGGL(lw_chol_back, grid(1), dim3(1024), (size_t)d.maxP * 8, h->stream, ws, sk);
+        toc(2);
+        if (d.maxF) {
+            hipLaunchKernelGGL(lw_rowdot, grid((d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, 1, sk);       // W_f . y_p
+            hipLaunchKernelGGL(lw_feature_back, grid((d.maxF + 255) / 256), dim3(256), 0, h->stream, ws, sk);
         }
     }
+};
+
+// ---- the trust-region loop on the host (trust_region_minimizer.cc with the traditional dogleg strategy, dogleg_strategy.cc): the path of a wall-clock limit
+// (Ceres tests the clock at the top of every iteration) and the fallback of a failed factorisation in the device loop. One window; `dws` = its descriptor on the device.
+int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, double tlim, const std::chrono::steady_clock::time_point t_start, bool ext) {
+    const vilf_window_in *in = hw.in;
+    const LwWin &dw = hw.dw;
+    const int NF = hw.NF, F = hw.F, P = hw.P, N = hw.N, cEx = hw.cEx, cTd = hw.cTd, pn = hw.pn, pnb = hw.pnb;
+    const size_t xo = hw.xo, sP = P, sN = N;
+    const bool est_ex = cEx >= 0, est_td = cTd >= 0;
+    LwEnq q{h, c, dws, LwDims(), ext, h->profiling != 0};
+    q.d.take(hw);
+    std::vector<double> &x = hw.x;
+    std::vector<double> cand(x.size()), pdx(VB_PRIOR_LD, 0.0);
     auto prior_dx = [&](const std::vector<double> &xx) {                 // marginalization_factor.cpp:345-363
         auto pose_dx = [&](const double *xb, const double *x0, double *d) {
             for (int k = 0; k < 3; k++) d[k] = xb[k] - x0[k];
@@ -1170,17 +1239,14 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
             d[3] = sgn * dq.x; d[4] = sgn * dq.y; d[5] = sgn * dq.z;
         };
         for (int bk = 0; bk < pnb; bk++) {
-            const int id = phdr[3 + bk], idx = phdr[51 + bk];
-            const double *x0 = &px0[9 * bk];
+            const int id = hw.phdr[3 + bk], idx = hw.phdr[51 + bk];
+            const double *x0 = &hw.px0[9 * bk];
             if (id < NF) pose_dx(&xx[7 * id], x0, &pdx[idx]);
             else if (id < 2 * NF) for (int k = 0; k < 9; k++) pdx[idx + k] = xx[7 * NF + 9 * (id - NF) + k] - x0[k];
             else if (id == 2 * NF) pose_dx(&xx[xo], x0, &pdx[idx]);
             else if (id == 2 * NF + 1) pdx[idx] = xx[xo + 7] - x0[0];
         }
     };
-    double R0b[9], P0b[3];
-    if (in->gauge_R0) std::memcpy(R0b, in->gauge_R0, 72); else h_q2R(&x[3], R0b);
-    if (in->gauge_P0) std::memcpy(P0b, in->gauge_P0, 24); else std::memcpy(P0b, &x[0], 24);
     auto xnorm = [&](const std::vector<double> &v) {
         double s = 0;
         for (int i = 0; i < 16 * NF; i++) s += v[i] * v[i];
@@ -1189,7 +1255,7 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         if (est_td) s += v[xo + 7] * v[xo + 7];
         return std::sqrt(s);
     };
-    // tangent vector d[N] = [15 per frame: pose 6, speed-bias 9 | F] applied to the state
+    // tangent vector d[N] = [15 per frame: pose 6, speed-bias 9 | ex 6 | td | F] applied to the state
     auto plus = [&](const std::vector<double> &xx, const std::vector<double> &d, std::vector<double> &o) {
         o = xx;
         for (int i = 0; i < NF; i++) { h_pose_plus(&xx[7 * i], &d[15 * i], &o[7 * i]); for (int k = 0; k < 9; k++) o[7 * NF + 9 * i + k] = xx[7 * NF + 9 * i + k] + d[15 * i + 6 + k]; }
@@ -1197,71 +1263,42 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         if (est_ex) h_pose_plus(&xx[xo], &d[cEx], &o[xo]);
         if (est_td) o[xo + 7] = xx[xo + 7] + d[cTd];
     };
-    // the launches of one evaluation at the device state xdev (prior dx already in c->pri); skip: flag of the device trust-region loop (nullptr = always run)
-    auto enq_evaluate = [&](const double *xdev, bool jac, const int *skip) -> int {
-        if (jac) {      // one launch clears the cost and the five accumulation targets (six fill launches per linearisation were 0.4 ms of a solve)
-            const size_t n5[5] = {sP * sP, sF * sP, sF, sP, sF};
-            const size_t tot = n5[0] + n5[1] + n5[2] + n5[3] + n5[4] + 1;
-            hipLaunchKernelGGL(lw_clear, dim3((unsigned)((tot + 1023) / 1024)), dim3(256), 0, h->stream, c->Hpp.as<double>(), n5[0], c->W.as<double>(), n5[1], c->hf.as<double>(), n5[2],
-                               c->gp.as<double>(), n5[3], c->gf.as<double>(), n5[4], scal, skip);
-        } else HIPCHECK(h, hipMemsetAsync(scal, 0, 8, h->stream));
-        if (jac) tic();
-        if (nvis && (est_ex || est_td))
-            hipLaunchKernelGGL(lw_visual_ext, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), c->tdrec.as<LwTd>(), xdev, NF, F, P, cEx, cTd,
-                               h->opts.TR / h->opts.ROW, sqrt_info, cauchy_b, jac ? 1 : 0, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal, skip);
-        else if (nvis)
-            hipLaunchKernelGGL(lw_visual, dim3((nvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, nvis, c->vis.as<LwVis>(), xdev, xdev + xo, NF, F, sqrt_info, cauchy_b, jac ? 1 : 0,
-                               c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), scal, skip);
-        if (pn)
-            hipLaunchKernelGGL(lw_prior, dim3(1), dim3(256), 0, h->stream, pn, h->d[D_PJ].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, h->d[D_PR].as<double>() + slot * VB_PRIOR_LD,
-                               h->d[D_PH].as<double>() + slot * VB_PRIOR_LD * VB_PRIOR_LD, c->pri.as<double>(),
-                               (const int *)(c->pri.as<char>() + VB_PRIOR_LD * 8), P, jac ? 1 : 0, c->Hpp.as<double>(), c->gp.as<double>(), scal, skip);
-        hipLaunchKernelGGL(lw_imu_lidar, dim3(nimu), dim3(128), 0, h->stream, NF, P, xdev, c->imu.as<double>(), c->lid.as<double>(), scal + 8, scal + 1, scal + 5, use_lidar ? 1 : 0, jac ? 1 : 0,
-                           c->Hpp.as<double>(), c->gp.as<double>(), scal, c->jscr.as<double>(), skip);
-        if (jac) hipLaunchKernelGGL(lw_imu_products, dim3((nimu * 930 + 255) / 256), dim3(256), 0, h->stream, NF, P, c->jscr.as<double>(), c->Hpp.as<double>(), c->gp.as<double>(), skip);
-        if (jac) toc(0);
-        HIPCHECK(h, hipGetLastError());
-        return VILF_OK;
-    };
     auto evaluate = [&](const std::vector<double> &xx, bool jac, double &cost) -> int {
-        HIPCHECK(h, hipMemcpyAsync(c->x.p, xx.data(), xx.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(dw.x, xx.data(), xx.size() * 8, hipMemcpyHostToDevice, h->stream));
         if (pn) {
             prior_dx(xx);
-            HIPCHECK(h, hipMemcpyAsync(c->pri.p, pdx.data(), VB_PRIOR_LD * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(dw.pdx, pdx.data(), VB_PRIOR_LD * 8, hipMemcpyHostToDevice, h->stream));
         }
-        const int rc = enq_evaluate(c->x.as<double>(), jac, nullptr);
-        if (rc != VILF_OK) return rc;
-        HIPCHECK(h, hipMemcpyAsync(&cost, scal, 8, hipMemcpyDeviceToHost, h->stream));
+        if (!jac) HIPCHECK(h, hipMemsetAsync(dw.scal, 0, 8, h->stream));
+        q.evaluate(0, jac ? 1 : 0, LW_SK_NONE);
+        HIPCHECK(h, hipGetLastError());
+        HIPCHECK(h, hipMemcpyAsync(&cost, dw.scal, 8, hipMemcpyDeviceToHost, h->stream));
         if (!jac) HIPCHECK(h, hipStreamSynchronize(h->stream));         // with the Jacobians: fetch_diag_grad follows and waits once for both
         return VILF_OK;
     };
     // host copies of the (scaled) diagonal / gradient pieces
+    const size_t sF = std::max(F, 1);
     std::vector<double> g(N), scale(N, 1.0), diagH(N), hfh(sF), diagonal(N), gradient(N), gn(N), step(N), delta(N), lm(N), y(N), tP(P), tF(sF), v(N);
     bool scaling_ready = false;
     double gradient_max_norm = 0, x_cost = 0;
     auto fetch_diag_grad = [&]() -> int {            // diag(Hpp) / h_f and g_p / g_f from the device
-        // only the diagonal of Hpp is needed: strided copy
-        HIPCHECK(h, hipMemcpy2DAsync(diagH.data(), 8, c->Hpp.p, (sP + 1) * 8, 8, P, hipMemcpyDeviceToHost, h->stream));
-        if (F) { HIPCHECK(h, hipMemcpyAsync(&diagH[P], c->hf.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHECK(h, hipMemcpyAsync(&g[P], c->gf.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); }
-        HIPCHECK(h, hipMemcpyAsync(&g[0], c->gp.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpy2DAsync(diagH.data(), 8, dw.Hpp, (sP + 1) * 8, 8, P, hipMemcpyDeviceToHost, h->stream));     // only the diagonal of Hpp: strided copy
+        if (F) { HIPCHECK(h, hipMemcpyAsync(&diagH[P], dw.hf, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHECK(h, hipMemcpyAsync(&g[P], dw.gf, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); }
+        HIPCHECK(h, hipMemcpyAsync(&g[0], dw.gp, sP * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         for (int f = 0; f < F; f++) if (in->feature_const[f]) { diagH[P + f] = 0.0; g[P + f] = 0.0; }
         return VILF_OK;
     };
-    // x^T H x with the (scaled) blocks on the device: returns v_p^T Hpp v_p + 2 sum_f v_f (W_f . v_p) + sum_f h_f v_f^2 and keeps Hpp v_p / W v_p
-    auto enq_quad = [&](const int *skip) {                                // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in c->vec
-        hipLaunchKernelGGL(lw_rowdot, dim3((P + 3) / 4), dim3(256), 0, h->stream, P, P, c->Hpp.as<double>(), c->vec.as<double>(), c->tmpP.as<double>(), skip);
-        if (F) hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->vec.as<double>(), c->tmpF.as<double>(), skip);
-    };
-    auto quad = [&](const std::vector<double> &vv, double &q) -> int {
-        HIPCHECK(h, hipMemcpyAsync(c->vec.p, vv.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
-        enq_quad(nullptr);
-        HIPCHECK(h, hipMemcpyAsync(tP.data(), c->tmpP.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
-        if (F) HIPCHECK(h, hipMemcpyAsync(tF.data(), c->tmpF.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
+    // x^T H x with the (scaled) blocks on the device: v_p^T Hpp v_p + 2 sum_f v_f (W_f . v_p) + sum_f h_f v_f^2
+    auto quad = [&](const std::vector<double> &vv, double &qq) -> int {
+        HIPCHECK(h, hipMemcpyAsync(dw.vec, vv.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+        q.quad(LW_SK_NONE);
+        HIPCHECK(h, hipMemcpyAsync(tP.data(), dw.tmpP, sP * 8, hipMemcpyDeviceToHost, h->stream));
+        if (F) HIPCHECK(h, hipMemcpyAsync(tF.data(), dw.tmpF, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
-        q = 0;
-        for (int i = 0; i < P; i++) q += vv[i] * tP[i];
-        for (int f = 0; f < F; f++) if (!in->feature_const[f]) q += vv[P + f] * (2.0 * tF[f] + hfh[f] * vv[P + f]);
+        qq = 0;
+        for (int i = 0; i < P; i++) qq += vv[i] * tP[i];
+        for (int f = 0; f < F; f++) if (!in->feature_const[f]) qq += vv[P + f] * (2.0 * tF[f] + hfh[f] * vv[P + f]);
         return VILF_OK;
     };
     auto eval_grad_jac = [&]() -> int {
@@ -1276,61 +1313,23 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         gradient_max_norm = 0;
         for (size_t i = 0; i < x.size(); i++) gradient_max_norm = std::max(gradient_max_norm, std::fabs(x[i] - proj[i]));
         // Jacobi scaling of the blocks on the device and of the host copies
-        HIPCHECK(h, hipMemcpyAsync(c->vec.p, scale.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
-        const size_t tot = sP * sP + (size_t)F * sP + F + P;
-        hipLaunchKernelGGL(lw_scale, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->vec.as<double>(), c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), (const int *)nullptr);
+        HIPCHECK(h, hipMemcpyAsync(dw.vec, scale.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+        q.scale(1, LW_SK_NONE);
         for (int i = 0; i < N; i++) { g[i] *= scale[i]; diagH[i] *= scale[i] * scale[i]; }
         for (int f = 0; f < F; f++) hfh[f] = diagH[P + f];
-        return VILF_OK;
-    };
-    // the launches of one linear solve (H' + lm^2) y = g' with lm in c->vec: y_p -> c->rhs, y_f -> yf_out, the Cholesky's status -> c->info
-    auto enq_linear_solve = [&](double *yf_out, const int *skip) -> int {
-        const size_t tot = sP * sP + (size_t)F * sP + F;
-        hipLaunchKernelGGL(lw_schur_prep, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, P, F, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gf.as<double>(), c->vec.as<double>(),
-                           c->fconst.as<unsigned char>(), c->S.as<double>(), c->Wn.as<double>(), c->den.as<double>(), c->tmpF.as<double>(), skip);
-        double *rhs_row = c->S.as<double>() + sP * sP;                    // the right-hand side rides as row P of S: after the factorisation it holds L^-1 rhs
-        HIPCHECK(h, hipMemcpyAsync(rhs_row, c->gp.p, sP * 8, hipMemcpyDeviceToDevice, h->stream));
-        if (F) {
-            // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P), rhs -= Wn^T (g_f / sqrt(den))
-            tic();
-            {
-                const int nt = (P + 63) / 64, ksplit = 4;
-                hipLaunchKernelGGL(lw_syrk_mfma, dim3(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, P, F, c->Wn.as<double>(), c->S.as<double>(), ksplit, skip);
-            }
-            toc(1);
-            hipLaunchKernelGGL(lw_colsum, dim3((P + 255) / 256, 128), dim3(256), 0, h->stream, F, P, c->Wn.as<double>(), c->tmpF.as<double>(), -1.0, rhs_row, 128, skip);    // 128 row chunks: 16 left most CUs idle (42 us for 15 MB)
-        }
-        int *dinfo = c->info.as<int>();
-        tic();
-        HIPCHECK(h, hipMemsetAsync(dinfo, 0, 4, h->stream));
-        for (int j0 = 0; j0 < P; j0 += CH_NB) {                          // blocked Cholesky, one launch per 64-column block (panel of this column + the rest of the previous column's update)
-            const int nb = std::min(CH_NB, P - j0), below = P + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
-            if (j0 == 0) hipLaunchKernelGGL(lw_chol_panel, dim3(npanel), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, dinfo, skip);
-            else {
-                const int nt = (P + 1 - j0 + 63) / 64;                   // tiles of the rows / columns j0 .. P; column 0 of them is the panel's
-                hipLaunchKernelGGL(lw_chol_step, dim3(npanel + nt * (nt - 1) / 2), dim3(256), 0, h->stream, P, c->S.as<double>(), j0, npanel, dinfo, skip);
-            }
-        }
-        hipLaunchKernelGGL(lw_chol_back, dim3(1), dim3(1024), sP * 8, h->stream, P, c->S.as<double>(), c->rhs.as<double>(), skip);
-        toc(2);
-        if (F) {
-            hipLaunchKernelGGL(lw_rowdot, dim3((F + 3) / 4), dim3(256), 0, h->stream, F, P, c->W.as<double>(), c->rhs.as<double>(), c->tmpF.as<double>(), skip);       // W_f . y_p
-            hipLaunchKernelGGL(lw_feature_back, dim3((F + 255) / 256), dim3(256), 0, h->stream, F, c->gf.as<double>(), c->tmpF.as<double>(), c->den.as<double>(), yf_out, skip);
-        }
-        HIPCHECK(h, hipGetLastError());
         return VILF_OK;
     };
     // ---- the linear solve: (H' + lm^2) y = g'
     auto linear_solve = [&](bool &ok) -> int {
         ok = false;
         for (int f = 0; f < F; f++) if (!in->feature_const[f] && !(hfh[f] + lm[P + f] * lm[P + f] > 0.0)) return VILF_OK;
-        HIPCHECK(h, hipMemcpyAsync(c->vec.p, lm.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
-        int rc2 = enq_linear_solve(c->vec.as<double>(), nullptr);
-        if (rc2 != VILF_OK) return rc2;
+        HIPCHECK(h, hipMemcpyAsync(dw.vec, lm.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
+        q.linear_solve(LW_SK_NONE);
+        HIPCHECK(h, hipGetLastError());
         int info = 0;
-        HIPCHECK(h, hipMemcpyAsync(&info, c->info.p, 4, hipMemcpyDeviceToHost, h->stream));      // read with the solution below: one wait per linear solve
-        if (F) HIPCHECK(h, hipMemcpyAsync(&y[P], c->vec.p, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(&y[0], c->rhs.p, sP * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(&info, dw.info, 4, hipMemcpyDeviceToHost, h->stream));      // read with the solution below: one wait per linear solve
+        if (F) HIPCHECK(h, hipMemcpyAsync(&y[P], dw.yf, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(&y[0], dw.rhs, sP * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
         for (int f = 0; f < F; f++) if (in->feature_const[f]) y[P + f] = 0.0;
@@ -1338,8 +1337,6 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         ok = true;
         return VILF_OK;
     };
-
-    // ---- trust-region loop (trust_region_minimizer.cc) with the traditional dogleg strategy (dogleg_strategy.cc)
     const double min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32, min_relative_decrease = 1e-3, function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
     double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_step_norm = 0;
     bool reuse = false;
@@ -1357,183 +1354,460 @@ int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_o
         dogleg_step_norm = std::sqrt(nn);
         for (int i = 0; i < N; i++) step[i] /= diagonal[i];
     };
-    int rc = VILF_OK;
-    double initial_cost = 0;
     const int max_it = h->opts.max_num_iterations;
-    const double tlim = h->opts.max_solver_time > 0 ? h->opts.max_solver_time * (in->marginalization_flag == VILF_MARGIN_OLD ? 4.0 / 5.0 : 1.0) : -1.0;   // estimator.cpp:847-850
-    // ---- the loop on the device: every iteration's launches are enqueued at once, nothing is read back until the end. Not with a wall-clock limit
-    // (Ceres tests the clock at the top of every iteration: the host loop below does) and not when a factorisation fails (it sets `fallback`).
-    bool ran_device = false;
-    if (tlim <= 0 && !std::getenv("VILF_LW_HOST_LOOP")) {
-        const size_t xs = xo + 8;
-        if (!c->dv.ensure((xs + 7 * sN) * 8) || !c->ctl.ensure(sizeof(LwCtl))) { h->err = "hipMalloc failed (large-window solve)"; return VILF_ERR_DEVICE; }
-        LwTr a;
-        a.ctl = c->ctl.as<LwCtl>();
-        a.NF = NF; a.F = F; a.P = P; a.N = N; a.cEx = cEx; a.cTd = cTd; a.xo = (int)xo; a.est_ex = est_ex ? 1 : 0; a.est_td = est_td ? 1 : 0; a.max_it = max_it;
-        a.x = c->x.as<double>(); a.cand = c->dv.as<double>();
-        double *vecs = c->dv.as<double>() + xs;
-        a.g = vecs; a.diagH = vecs + sN; a.scale = vecs + 2 * sN; a.diagonal = vecs + 3 * sN; a.gradient = vecs + 4 * sN; a.gn = vecs + 5 * sN; a.step = vecs + 6 * sN;
-        a.vec = c->vec.as<double>(); a.yf = c->vec.as<double>() + sN;
-        a.tmpP = c->tmpP.as<double>(); a.tmpF = c->tmpF.as<double>(); a.rhs = c->rhs.as<double>();
-        a.fconst = c->fconst.as<unsigned char>();
-        a.Hpp = c->Hpp.as<double>(); a.hf = c->hf.as<double>(); a.gp = c->gp.as<double>(); a.gf = c->gf.as<double>();
-        a.scal = scal; a.info = c->info.as<int>();
-        a.pn = pn; a.pnb = pnb;
-        a.phdr = batch_slot0 ? h->d[D_PHDR].as<int>() + slot * VB_PRIOR_HDR : nullptr;
-        a.px0 = batch_slot0 ? h->d[D_PX0].as<double>() + slot * 24 * 9 : nullptr;
-        a.pdx = c->pri.as<double>();
-        const LwCtl *dctl = a.ctl;
-        HIPCHECK(h, hipMemcpyAsync(c->x.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
-        hipLaunchKernelGGL(lw_tr_init, dim3(1), dim3(TR_T), 0, h->stream, a);
-        const size_t tot_scale = sP * sP + (size_t)F * sP + F + P;
-        auto enq_linearize = [&](int first) -> int {                       // eval_grad_jac of the host loop
-            const int r2 = enq_evaluate(a.x, true, &dctl->skip_jac);
-            if (r2 != VILF_OK) return r2;
-            hipLaunchKernelGGL(lw_tr_post, dim3(1), dim3(TR_T), 0, h->stream, a, first);
-            hipLaunchKernelGGL(lw_scale, dim3((unsigned)((tot_scale + 255) / 256)), dim3(256), 0, h->stream, P, F, a.scale, c->Hpp.as<double>(), c->W.as<double>(), c->hf.as<double>(), c->gp.as<double>(), c->gf.as<double>(), &dctl->skip_jac);
-            return VILF_OK;
-        };
-        if ((rc = enq_linearize(1)) != VILF_OK) return rc;
-        for (int it = 0; it < max_it; it++) {
-            hipLaunchKernelGGL(lw_tr_begin, dim3(1), dim3(TR_T), 0, h->stream, a);
-            enq_quad(&dctl->skip_solve);
-            hipLaunchKernelGGL(lw_tr_alpha, dim3(1), dim3(TR_T), 0, h->stream, a);
-            if ((rc = enq_linear_solve(a.yf, &dctl->skip_solve)) != VILF_OK) return rc;
-            hipLaunchKernelGGL(lw_tr_step, dim3(1), dim3(TR_T), 0, h->stream, a);
-            enq_quad(&dctl->skip_quad);
-            hipLaunchKernelGGL(lw_tr_model, dim3(1), dim3(TR_T), 0, h->stream, a);
-            if ((rc = enq_evaluate(a.cand, false, &dctl->skip_eval)) != VILF_OK) return rc;
-            hipLaunchKernelGGL(lw_tr_decide, dim3(1), dim3(TR_T), 0, h->stream, a);
-            if (it + 1 < max_it && (rc = enq_linearize(0)) != VILF_OK) return rc;
+    int rc = eval_grad_jac();
+    if (rc != VILF_OK) return rc;
+    const double initial_cost = x_cost;
+    double x_norm = xnorm(x);
+    while (true) {
+        if (tlim > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= tlim) { termination = VILF_TERM_NO_CONVERGENCE; break; }
+        if (iteration >= max_it) { termination = VILF_TERM_NO_CONVERGENCE; break; }
+        if (gradient_max_norm <= gradient_tolerance) { termination = VILF_TERM_CONVERGENCE_GRADIENT; break; }
+        if (radius <= 1e-32) { termination = VILF_TERM_FAILURE; break; }
+        iteration++;
+        bool valid = true;
+        if (reuse) traditional();
+        else {
+            reuse = true;
+            for (int i = 0; i < N; i++) diagonal[i] = std::sqrt(std::min(std::max(diagH[i], min_lm_diagonal), max_lm_diagonal));
+            for (int i = 0; i < N; i++) gradient[i] = g[i] / diagonal[i];
+            for (int i = 0; i < N; i++) v[i] = gradient[i] / diagonal[i];
+            double Jg2;
+            if ((rc = quad(v, Jg2)) != VILF_OK) return rc;
+            alpha = vdotN(gradient, gradient) / Jg2;
+            bool ok = false;
+            while (mu < 1.0) {
+                for (int i = 0; i < N; i++) lm[i] = diagonal[i] * std::sqrt(mu);
+                num_linear_solves++;
+                if ((rc = linear_solve(ok)) != VILF_OK) return rc;
+                if (ok) break;
+                mu *= 10.0;
+            }
+            if (!ok) valid = false;
+            else { for (int i = 0; i < N; i++) gn[i] = y[i] * -diagonal[i]; traditional(); }
         }
-        LwCtl hc;
-        HIPCHECK(h, hipGetLastError());
-        HIPCHECK(h, hipMemcpyAsync(&hc, a.ctl, sizeof(LwCtl), hipMemcpyDeviceToHost, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(cand.data(), c->x.p, x.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        double model_cost_change = 0;
+        if (valid) {
+            double sHs;
+            if ((rc = quad(step, sHs)) != VILF_OK) return rc;
+            model_cost_change = -(vdotN(g, step) + 0.5 * sHs);
+            if (model_cost_change <= 0.0) valid = false;
+        }
+        if (!valid) {
+            consecutive_invalid++;
+            mu *= 10.0; reuse = false;                                   // step_is_invalid
+            if (consecutive_invalid >= 5) { termination = VILF_TERM_FAILURE; break; }
+            continue;
+        }
+        consecutive_invalid = 0;
+        for (int i = 0; i < N; i++) delta[i] = step[i] * scale[i];
+        plus(x, delta, cand);
+        double cand_cost;
+        if ((rc = evaluate(cand, false, cand_cost)) != VILF_OK) return rc;
+        double sn = 0;
+        for (int i = 0; i < 16 * NF; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
+        for (int f = 0; f < F; f++) if (!in->feature_const[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
+        if (est_ex) for (int k = 0; k < 7; k++) sn += (x[xo + k] - cand[xo + k]) * (x[xo + k] - cand[xo + k]);
+        if (est_td) sn += (x[xo + 7] - cand[xo + 7]) * (x[xo + 7] - cand[xo + 7]);
+        if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = VILF_TERM_CONVERGENCE_PARAMETER; break; }
+        const double cost_change = x_cost - cand_cost;
+        if (std::fabs(cost_change) <= function_tolerance * x_cost) { termination = VILF_TERM_CONVERGENCE_FUNCTION; break; }
+        const double rd = cost_change / model_cost_change;
+        if (rd > min_relative_decrease) {
+            x = cand; x_norm = xnorm(x);
+            if (iteration < max_it) { if ((rc = eval_grad_jac()) != VILF_OK) return rc; }
+            else x_cost = cand_cost;                                     // the budget is spent: nothing would use the linearisation at the accepted point
+            num_successful++;
+            if (rd < 0.25) radius *= 0.5;                                // step_accepted
+            if (rd > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
+            mu = std::max(1e-8, 2.0 * mu / 10.0);
+            reuse = false;
+        } else { radius *= 0.5; reuse = true; }                          // step_rejected
+    }
+    LwCtl &hc = hw.hc;
+    hc.iteration = iteration; hc.num_successful = num_successful; hc.num_linear_solves = num_linear_solves; hc.termination = termination;
+    hc.initial_cost = initial_cost; hc.x_cost = x_cost; hc.radius = radius; hc.fallback = 0;
+    return VILF_OK;
+}
+inline size_t lw_al(size_t b) { return (b + 255) & ~(size_t)255; }
+}  // namespace
+
+// G independent windows in one chain of launches. slot1[g] != 0: window g is also resident as slot slot1[g] - 1 of the 11-frame batch (vilf_batch_upload ran):
+// that slot's prior applies and the solved state is written back into the batch buffers (the marginalization reads them). slot1 = nullptr: none is.
+int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins, vilf_window_out *const *outs, const int *slot1) {
+    const auto t_start = std::chrono::steady_clock::now();
+    if (G < 1 || G > 65535) return VILF_ERR_INVALID_ARGUMENT;
+    const bool est_ex = h->opts.estimate_extrinsic != 0, est_td = h->opts.estimate_td != 0, ext = est_ex || est_td;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (!h->lw) h->lw = new LwCtx();
+    LwCtx *c = h->lw;
+    const bool prof = h->profiling != 0;
+    if (prof && !c->ev[0]) { hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); }
+    std::vector<LwHostWin> hws(G);
+    // ---- validation, sizes
+    bool any_slot = false, contig = slot1 != nullptr;       // contig: the group is a run of consecutive batch slots (vilf_batch_solve): priors in, states back in bulk copies
+    size_t tot_imu = 0, tot_x = 0;
+    for (int g = 0; g < G; g++) {
+        LwHostWin &w = hws[g];
+        const vilf_window_in *in = ins[g];
+        w.in = in; w.out = outs[g];
+        w.resident = slot1 && slot1[g] != 0; w.slot = w.resident ? (size_t)(slot1[g] - 1) : 0;
+        any_slot = any_slot || w.resident;
+        if (!w.resident || w.slot != hws[0].slot + (size_t)g) contig = false;
+        const int NF = in->n_frames, F = in->n_features;
+        if (NF < 2 || F < 0 || !in->para_pose || !in->para_speed_bias || !in->imu || (F && (!in->para_feature || !in->feature_const || !in->feature_start_frame || !in->feature_obs_offset || !in->obs_point)))
+            return VILF_ERR_INVALID_ARGUMENT;
+        if (in->n_obs < 0 || (F && (in->feature_obs_offset[0] != 0 || in->feature_obs_offset[F] != in->n_obs)) || (!F && in->n_obs != 0)) { h->err = "feature_obs_offset must start at 0 and end at n_obs"; return VILF_ERR_INVALID_ARGUMENT; }
+        for (int f = 0; f < F; f++) if (in->feature_obs_offset[f + 1] - in->feature_obs_offset[f] < 2) { h->err = "feature with fewer than two observations"; return VILF_ERR_INVALID_ARGUMENT; }
+        if (est_td && F && (!in->obs_velocity || !in->obs_cur_td || !in->obs_row)) { h->err = "estimate_td needs obs_velocity / obs_cur_td / obs_row"; return VILF_ERR_INVALID_ARGUMENT; }
+        if (w.resident && (NF != VB_NF || !h->resident || (int)w.slot >= h->B)) return VILF_ERR_INVALID_ARGUMENT;
+        for (int f = 0; f < F; f++) {
+            const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
+            if (s < 0 || s + (o1 - o0) > NF) { h->err = "feature track leaves the window"; return VILF_ERR_INVALID_ARGUMENT; }
+        }
+        w.NF = NF; w.F = F;
+        w.cEx = est_ex ? 15 * NF : -1; w.cTd = est_td ? 15 * NF + (est_ex ? 6 : 0) : -1;      // columns of Ex_Pose / td after the frame blocks
+        w.P = 15 * NF + (est_ex ? 6 : 0) + (est_td ? 1 : 0); w.N = w.P + F;
+        if (w.P > vilf_lw_chol_max_n()) { h->err = "window too large for the general path (reduced system above 12288 columns)"; return VILF_ERR_UNSUPPORTED; }
+        w.xo = 16 * (size_t)NF + F;
+        w.nvis = std::max(0, in->n_obs - F); w.nimu = NF - 1;
+        w.use_lidar = h->opts.use_lidar_const && in->lidar;
+        tot_imu += w.nimu; tot_x += w.xo + 8;
+    }
+    {
+        const int rca = lw_chol_back_attr(h);
+        if (rca != VILF_OK) return rca;
+    }
+    // ---- the priors of the resident windows (marginalization_factor.cpp:333-381): block tables to the host, J0 / r0 / J0^T J0 stay on the device
+    if (any_slot) {
+        std::vector<int> hdr_all; std::vector<double> x0_all;
+        if (contig) {
+            hdr_all.resize((size_t)G * VB_PRIOR_HDR); x0_all.resize((size_t)G * 24 * 9);
+            HIPCHECK(h, hipMemcpyAsync(hdr_all.data(), h->d[D_PHDR].as<int>() + hws[0].slot * VB_PRIOR_HDR, hdr_all.size() * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(x0_all.data(), h->d[D_PX0].as<double>() + hws[0].slot * 24 * 9, x0_all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        } else
+            for (LwHostWin &w : hws) if (w.resident) {
+                HIPCHECK(h, hipMemcpyAsync(w.phdr, h->d[D_PHDR].as<int>() + w.slot * VB_PRIOR_HDR, sizeof(w.phdr), hipMemcpyDeviceToHost, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(w.px0, h->d[D_PX0].as<double>() + w.slot * 24 * 9, sizeof(w.px0), hipMemcpyDeviceToHost, h->stream));
+            }
         HIPCHECK(h, hipStreamSynchronize(h->stream));
-        if (std::getenv("VILF_LW_FORCE_FALLBACK")) hc.fallback = 1;          // test hook: take the path of a failed factorisation (the host loop redoes the solve from the initial state)
-        if (std::getenv("VILF_LW_TRACE")) std::fprintf(stderr, "[vilf lw] device loop: fallback %d iterations %d successful %d solves %d termination %d cost %.9g -> %.9g\n", hc.fallback, hc.iteration, hc.num_successful, hc.num_linear_solves, hc.termination, hc.initial_cost, hc.x_cost);
-        if (!hc.fallback) {
-            ran_device = true;
-            x = cand;
-            iteration = hc.iteration; num_successful = hc.num_successful; num_linear_solves = hc.num_linear_solves; termination = hc.termination;
-            initial_cost = hc.initial_cost; x_cost = hc.x_cost; radius = hc.radius;
+        for (int g = 0; g < G; g++) {
+            LwHostWin &w = hws[g];
+            if (!w.resident) continue;
+            if (contig) { std::memcpy(w.phdr, &hdr_all[(size_t)g * VB_PRIOR_HDR], sizeof(w.phdr)); std::memcpy(w.px0, &x0_all[(size_t)g * 24 * 9], sizeof(w.px0)); }
+            if (w.phdr[0]) { w.pn = w.phdr[1]; w.pnb = w.phdr[2]; }
         }
     }
-    if (!ran_device) {
-        rc = eval_grad_jac();
-        if (rc != VILF_OK) return rc;
-        initial_cost = x_cost;
-        double x_norm = xnorm(x);
-        while (true) {
-            if (tlim > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() >= tlim) { termination = VILF_TERM_NO_CONVERGENCE; break; }
-            if (iteration >= max_it) { termination = VILF_TERM_NO_CONVERGENCE; break; }
-            if (gradient_max_norm <= gradient_tolerance) { termination = VILF_TERM_CONVERGENCE_GRADIENT; break; }
-            if (radius <= 1e-32) { termination = VILF_TERM_FAILURE; break; }
-            iteration++;
-            bool valid = true;
-            if (reuse) traditional();
-            else {
-                reuse = true;
-                for (int i = 0; i < N; i++) diagonal[i] = std::sqrt(std::min(std::max(diagH[i], min_lm_diagonal), max_lm_diagonal));
-                for (int i = 0; i < N; i++) gradient[i] = g[i] / diagonal[i];
-                for (int i = 0; i < N; i++) v[i] = gradient[i] / diagonal[i];
-                double Jg2;
-                if ((rc = quad(v, Jg2)) != VILF_OK) return rc;
-                alpha = vdotN(gradient, gradient) / Jg2;
-                bool ok = false;
-                while (mu < 1.0) {
-                    for (int i = 0; i < N; i++) lm[i] = diagonal[i] * std::sqrt(mu);
-                    num_linear_solves++;
-                    if ((rc = linear_solve(ok)) != VILF_OK) return rc;
-                    if (ok) break;
-                    mu *= 10.0;
-                }
-                if (!ok) valid = false;
-                else { for (int i = 0; i < N; i++) gn[i] = y[i] * -diagonal[i]; traditional(); }
-            }
-            double model_cost_change = 0;
-            if (valid) {
-                double sHs;
-                if ((rc = quad(step, sHs)) != VILF_OK) return rc;
-                model_cost_change = -(vdotN(g, step) + 0.5 * sHs);
-                if (model_cost_change <= 0.0) valid = false;
-            }
-            if (!valid) {
-                consecutive_invalid++;
-                mu *= 10.0; reuse = false;                                   // step_is_invalid
-                if (consecutive_invalid >= 5) { termination = VILF_TERM_FAILURE; break; }
-                continue;
-            }
-            consecutive_invalid = 0;
-            for (int i = 0; i < N; i++) delta[i] = step[i] * scale[i];
-            plus(x, delta, cand);
-            double cand_cost;
-            if ((rc = evaluate(cand, false, cand_cost)) != VILF_OK) return rc;
-            double sn = 0;
-            for (int i = 0; i < 16 * NF; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
-            for (int f = 0; f < F; f++) if (!in->feature_const[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
-            if (est_ex) for (int k = 0; k < 7; k++) sn += (x[xo + k] - cand[xo + k]) * (x[xo + k] - cand[xo + k]);
-            if (est_td) sn += (x[xo + 7] - cand[xo + 7]) * (x[xo + 7] - cand[xo + 7]);
-            if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = VILF_TERM_CONVERGENCE_PARAMETER; break; }
-            const double cost_change = x_cost - cand_cost;
-            if (std::fabs(cost_change) <= function_tolerance * x_cost) { termination = VILF_TERM_CONVERGENCE_FUNCTION; break; }
-            const double rd = cost_change / model_cost_change;
-            if (rd > min_relative_decrease) {
-                x = cand; x_norm = xnorm(x);
-                if (iteration < max_it) { if ((rc = eval_grad_jac()) != VILF_OK) return rc; }
-                else x_cost = cand_cost;                                     // the budget is spent: nothing would use the linearisation at the accepted point
-                num_successful++;
-                if (rd < 0.25) radius *= 0.5;                                // step_accepted
-                if (rd > 0.75) radius = std::max(radius, 3.0 * dogleg_step_norm);
-                mu = std::max(1e-8, 2.0 * mu / 10.0);
-                reuse = false;
-            } else { radius *= 0.5; reuse = true; }                          // step_rejected
+    // ---- arena layout. Inputs first (one host image, one copy): per window vis | tdr | lid | fconst | scal | pcol; then group-wide runs imu | cov | x (k_imu_prep
+    // takes the IMU factors of all windows in one launch; the states come back in one copy); then the minimizer scalars (one copy back) and the work areas.
+    size_t off = 0;
+    for (LwHostWin &w : hws) {
+        w.o_vis = off; off = lw_al(off + std::max(w.nvis, 1) * sizeof(LwVis));
+        w.o_tdr = off; off = lw_al(off + (est_td ? std::max(w.nvis, 1) : 1) * sizeof(LwTd));
+        w.o_lid = off; off = lw_al(off + (size_t)w.nimu * 7 * 8);
+        w.o_fconst = off; off = lw_al(off + std::max(w.F, 1));
+        w.o_scal = off; off = lw_al(off + 16 * 8);
+        w.o_pcol = off; off = lw_al(off + VB_PRIOR_LD * sizeof(int));
+    }
+    const size_t o_imu = off; off = lw_al(off + tot_imu * IMU_REC * 8);
+    const size_t o_cov = off; off = lw_al(off + tot_imu * 225 * 8);
+    const size_t o_x = off; off = lw_al(off + tot_x * 8);
+    const size_t n_input = off;
+    const size_t o_ctl = off; off = lw_al(off + (size_t)G * sizeof(LwCtl));
+    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, den, jscr, info, nvec, pdx; };
+    std::vector<WorkOff> wo(G);
+    for (int g = 0; g < G; g++) {
+        const LwHostWin &w = hws[g];
+        const size_t sP = w.P, sF = std::max(w.F, 1), sN = w.N;
+        WorkOff &o = wo[g];
+        auto take = [&](size_t bytes) { const size_t at = off; off = lw_al(off + bytes); return at; };
+        o.cand = take((w.xo + 8) * 8); o.Hpp = take(sP * sP * 8); o.W = take(sF * sP * 8); o.hf = take(sF * 8); o.gp = take(sP * 8); o.gf = take(sF * 8);
+        o.S = take((sP + 1) * sP * 8); o.Wn = take(sF * sP * 8); o.rhs = take(sP * 8); o.tmpP = take(sP * 8); o.tmpF = take(sF * 8); o.vec = take(2 * sN * 8);
+        o.den = take(sF * 8); o.jscr = take((size_t)w.nimu * 480 * 8); o.info = take(64); o.nvec = take(7 * sN * 8); o.pdx = take(VB_PRIOR_LD * 8);
+    }
+    if (!c->arena.ensure(off) || !c->desc.ensure((size_t)G * sizeof(LwWin))) { h->err = "hipMalloc failed (general-path solve)"; return VILF_ERR_DEVICE; }
+    if (c->stage_cap < n_input) {
+        if (c->stage) hipHostFree(c->stage);
+        c->stage = nullptr; c->stage_cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->stage), n_input + n_input / 8, hipHostMallocDefault) != hipSuccess) { h->err = "hipHostMalloc failed (general-path solve)"; return VILF_ERR_DEVICE; }
+        c->stage_cap = n_input + n_input / 8;
+    }
+    char *st = c->stage, *dev = c->arena.as<char>();
+    // ---- pack the factors
+    // extrinsic-derived constants (lidar_factor.h:28-29): q_il = RIC RCL, t_il = RIC TCL + TIC
+    double Ril[9], qil[4], til[3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += h->opts.RIC[3 * i + k] * h->opts.RCL[3 * k + j]; Ril[3 * i + j] = s; }
+    for (int i = 0; i < 3; i++) { double s = h->opts.TIC[i]; for (int k = 0; k < 3; k++) s += h->opts.RIC[3 * i + k] * h->opts.TCL[k]; til[i] = s; }
+    {   // rotation matrix -> quaternion (Eigen's branch on the trace)
+        const double *m = Ril; const double tr = m[0] + m[4] + m[8];
+        double q[4];
+        if (tr > 0) { double t = std::sqrt(tr + 1.0); q[3] = 0.5 * t; t = 0.5 / t; q[0] = (m[7] - m[5]) * t; q[1] = (m[2] - m[6]) * t; q[2] = (m[3] - m[1]) * t; }
+        else { int i = 0; if (m[4] > m[0]) i = 1; if (m[8] > m[4 * i]) i = 2; const int j = (i + 1) % 3, k = (j + 1) % 3; double t = std::sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0); q[i] = 0.5 * t; t = 0.5 / t; q[3] = (m[3 * k + j] - m[3 * j + k]) * t; q[j] = (m[3 * j + i] + m[3 * i + j]) * t; q[k] = (m[3 * k + i] + m[3 * i + k]) * t; }
+        for (int k = 0; k < 4; k++) qil[k] = q[k];
+    }
+    const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = h->opts.cauchy_a * h->opts.cauchy_a;      // rho(s) = b log(1 + s / b), b = a^2 (ceres CauchyLoss; same as the batched path)
+    std::vector<LwWin> dws(G);
+    std::vector<size_t> imu_at(G), x_at(G);
+    { size_t a = 0, b = 0; for (int g = 0; g < G; g++) { imu_at[g] = a; x_at[g] = b; a += hws[g].nimu; b += hws[g].xo + 8; } }
+    auto pack = [&](int g) {
+        std::vector<int> pair_cnt, vis_obs;
+        const size_t at_imu = imu_at[g], at_x = x_at[g];
+        LwHostWin &w = hws[g];
+        const vilf_window_in *in = w.in;
+        const int NF = w.NF, F = w.F, nvis = w.nvis, nimu = w.nimu;
+        // pair-sorted (lw_visual flushes one block per run of equal pairs): counting sort over the NF^2 pair keys, stable in feature order
+        LwVis *vis = reinterpret_cast<LwVis *>(st + w.o_vis);
+        vis_obs.assign(2 * (size_t)std::max(nvis, 1), 0);           // (first, this) observation index of every factor: the td constants follow the pair sort
+        pair_cnt.assign((size_t)NF * NF + 1, 0);
+        for (int f = 0; f < F; f++) {
+            const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
+            for (int t = o0 + 1; t < o1; t++) pair_cnt[(size_t)s * NF + s + (t - o0) + 1]++;
         }
+        for (size_t k = 1; k < pair_cnt.size(); k++) pair_cnt[k] += pair_cnt[k - 1];
+        for (int f = 0; f < F; f++) {
+            const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
+            for (int t = o0 + 1; t < o1; t++) {
+                const int k = pair_cnt[(size_t)s * NF + s + (t - o0)]++;
+                LwVis &v = vis[k];
+                for (int q = 0; q < 3; q++) { v.pi[q] = in->obs_point[3 * (size_t)o0 + q]; v.pj[q] = in->obs_point[3 * (size_t)t + q]; }
+                v.f = f; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
+                vis_obs[2 * (size_t)k] = o0; vis_obs[2 * (size_t)k + 1] = t;
+            }
+        }
+        if (est_td) {                                     // projection_td_factor.cpp:6-21
+            LwTd *tdrec = reinterpret_cast<LwTd *>(st + w.o_tdr);
+            for (int k = 0; k < nvis; k++) {
+                const int oi = vis_obs[2 * (size_t)k], oj = vis_obs[2 * (size_t)k + 1];
+                LwTd &q = tdrec[k];
+                q.vi[0] = in->obs_velocity[2 * (size_t)oi]; q.vi[1] = in->obs_velocity[2 * (size_t)oi + 1]; q.vj[0] = in->obs_velocity[2 * (size_t)oj]; q.vj[1] = in->obs_velocity[2 * (size_t)oj + 1];
+                q.tdi = in->obs_cur_td[oi]; q.tdj = in->obs_cur_td[oj]; q.rowi_c = in->obs_row[oi] - h->opts.ROW / 2; q.rowj_c = in->obs_row[oj] - h->opts.ROW / 2;
+            }
+        }
+        double *imu = reinterpret_cast<double *>(st + o_imu) + at_imu * IMU_REC, *cov = reinterpret_cast<double *>(st + o_cov) + at_imu * 225, *lid = reinterpret_cast<double *>(st + w.o_lid);
+        std::memset(imu, 0, (size_t)nimu * IMU_REC * 8); std::memset(lid, 0, (size_t)nimu * 7 * 8);
+        for (int k = 0; k < nimu; k++) {
+            const vilf_imu_preint &p = in->imu[k + 1];
+            double *rec = imu + (size_t)k * IMU_REC;
+            rec[0] = p.sum_dt;
+            for (int i = 0; i < 3; i++) { rec[1 + i] = p.delta_p[i]; rec[8 + i] = p.delta_v[i]; rec[11 + i] = p.linearized_ba[i]; rec[14 + i] = p.linearized_bg[i]; }
+            for (int i = 0; i < 4; i++) rec[4 + i] = p.delta_q[i];
+            auto blk = [&](int o2, int r0, int c0) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rec[o2 + 3 * i + j] = p.jacobian[(r0 + i) * 15 + c0 + j]; };
+            blk(17, 0, 9); blk(26, 0, 12); blk(35, 3, 12); blk(44, 6, 9); blk(53, 6, 12);
+            rec[287] = (p.sum_dt > 10.0) ? 0.0 : 1.0;
+            std::memcpy(cov + (size_t)k * 225, p.covariance, 225 * 8);
+            if (in->lidar) { const vilf_lidar_constraint &l = in->lidar[k + 1]; for (int i = 0; i < 4; i++) lid[7 * k + i] = l.q[i]; for (int i = 0; i < 3; i++) lid[7 * k + 4 + i] = l.t[i]; }
+            else lid[7 * k + 3] = 1.0;
+        }
+        if (F) std::memcpy(st + w.o_fconst, in->feature_const, F);
+        double *scal = reinterpret_cast<double *>(st + w.o_scal);
+        std::memset(scal, 0, 16 * 8);
+        for (int k = 0; k < 4; k++) scal[1 + k] = qil[k];
+        for (int k = 0; k < 3; k++) { scal[5 + k] = til[k]; scal[8 + k] = h->opts.G[k]; }
+        // the state: x = pose | sb | feat | ex[7] | td
+        w.x.resize(w.xo + 8);
+        std::memcpy(&w.x[0], in->para_pose, 7 * (size_t)NF * 8); std::memcpy(&w.x[7 * (size_t)NF], in->para_speed_bias, 9 * (size_t)NF * 8);
+        for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + f] = in->para_feature[f];
+        std::memcpy(&w.x[w.xo], in->para_ex_pose, 56); w.x[w.xo + 7] = in->para_td;
+        std::memcpy(reinterpret_cast<double *>(st + o_x) + at_x, w.x.data(), w.x.size() * 8);
+        int *pcol = reinterpret_cast<int *>(st + w.o_pcol);
+        for (int i = 0; i < VB_PRIOR_LD; i++) pcol[i] = -1;
+        for (int bk = 0; bk < w.pnb; bk++) {
+            const int id = w.phdr[3 + bk], idx = w.phdr[51 + bk];
+            if (id < NF) for (int k = 0; k < 6; k++) pcol[idx + k] = 15 * id + k;
+            else if (id < 2 * NF) for (int k = 0; k < 9; k++) pcol[idx + k] = 15 * (id - NF) + 6 + k;
+            else if (id == 2 * NF && est_ex) for (int k = 0; k < 6; k++) pcol[idx + k] = w.cEx + k;
+            else if (id == 2 * NF + 1 && est_td) pcol[idx] = w.cTd;                       // para_Td, kept by the marginalization (estimator.cpp:930-935,968-969)
+        }
+        // ---- the descriptor
+        LwWin &d = dws[g];
+        std::memset(&d, 0, sizeof(d));
+        const WorkOff &o = wo[g];
+        const size_t sN = w.N;
+        d.NF = NF; d.F = F; d.P = w.P; d.N = w.N; d.nvis = nvis; d.nimu = nimu; d.cEx = w.cEx; d.cTd = w.cTd; d.xo = (int)w.xo; d.est_ex = est_ex ? 1 : 0; d.est_td = est_td ? 1 : 0;
+        d.use_lidar = w.use_lidar ? 1 : 0; d.pn = w.pn; d.pnb = w.pnb; d.max_it = h->opts.max_num_iterations;
+        d.sqrt_info = sqrt_info; d.cauchy_b = cauchy_b; d.tr_over_row = h->opts.TR / h->opts.ROW;
+        d.ctl = reinterpret_cast<LwCtl *>(dev + o_ctl) + g;
+        d.x = reinterpret_cast<double *>(dev + o_x) + at_x; d.cand = reinterpret_cast<double *>(dev + o.cand);
+        d.vis = reinterpret_cast<const LwVis *>(dev + w.o_vis); d.tdr = reinterpret_cast<const LwTd *>(dev + w.o_tdr);
+        d.imu = reinterpret_cast<const double *>(dev + o_imu) + at_imu * IMU_REC; d.lid = reinterpret_cast<const double *>(dev + w.o_lid);
+        d.fconst = reinterpret_cast<const unsigned char *>(dev + w.o_fconst);
+        auto dp = [&](size_t at) { return reinterpret_cast<double *>(dev + at); };
+        d.Hpp = dp(o.Hpp); d.W = dp(o.W); d.hf = dp(o.hf); d.gp = dp(o.gp); d.gf = dp(o.gf); d.S = dp(o.S); d.Wn = dp(o.Wn); d.rhs = dp(o.rhs); d.tmpP = dp(o.tmpP); d.tmpF = dp(o.tmpF);
+        d.vec = dp(o.vec); d.yf = dp(o.vec) + sN; d.scal = dp(w.o_scal); d.den = dp(o.den); d.jscr = dp(o.jscr); d.info = reinterpret_cast<int *>(dev + o.info);
+        double *nv = dp(o.nvec);
+        d.g = nv; d.diagH = nv + sN; d.scale = nv + 2 * sN; d.diagonal = nv + 3 * sN; d.gradient = nv + 4 * sN; d.gn = nv + 5 * sN; d.step = nv + 6 * sN;
+        d.pcol = reinterpret_cast<const int *>(dev + w.o_pcol); d.pdx = dp(o.pdx);
+        if (w.resident) {
+            d.pJ = h->d[D_PJ].as<double>() + w.slot * VB_PRIOR_LD * VB_PRIOR_LD; d.pr0 = h->d[D_PR].as<double>() + w.slot * VB_PRIOR_LD; d.pH0 = h->d[D_PH].as<double>() + w.slot * VB_PRIOR_LD * VB_PRIOR_LD;
+            d.phdr = h->d[D_PHDR].as<int>() + w.slot * VB_PRIOR_HDR; d.px0 = h->d[D_PX0].as<double>() + w.slot * 24 * 9;
+        }
+        w.dw = d;
+    };
+    {   // a group's windows are packed by a few host threads (a stress window is ~3 MB of factor records)
+        const int nthr = (int)std::min<size_t>({(size_t)G, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+        size_t tot_vis = 0;
+        for (const LwHostWin &w : hws) tot_vis += w.nvis;
+        if (nthr <= 1 || tot_vis < 20000) for (int g = 0; g < G; g++) pack(g);
+        else {
+            std::atomic<int> next(0);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthr; t++) th.emplace_back([&]() { for (int g = next.fetch_add(1); g < G; g = next.fetch_add(1)) pack(g); });
+            for (std::thread &t : th) t.join();
+        }
+    }
+    HIPCHECK(h, hipMemcpyAsync(dev, st, n_input, hipMemcpyHostToDevice, h->stream));
+    HIPCHECK(h, hipMemcpyAsync(c->desc.p, dws.data(), (size_t)G * sizeof(LwWin), hipMemcpyHostToDevice, h->stream));
+    const LwWin *dws_dev = c->desc.as<LwWin>();
+    hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)((tot_imu + 3) / 4)), dim3(64), 0, h->stream, (int)tot_imu, reinterpret_cast<const double *>(dev + o_cov), (double *)nullptr, reinterpret_cast<double *>(dev + o_imu));
+
+    int rc = VILF_OK;
+    const int max_it = h->opts.max_num_iterations;
+    // ---- the loop on the device: every iteration's launches are enqueued at once, nothing is read back until the end. Not with a wall-clock limit
+    // (Ceres tests the clock at the top of every iteration: the host loop does) and not for a window whose factorisation fails (it sets `fallback`).
+    bool ran_device = false;
+    const bool tlim_on = h->opts.max_solver_time > 0;
+    if (!tlim_on && !std::getenv("VILF_LW_HOST_LOOP")) {
+        LwEnq q{h, c, dws_dev, LwDims(), ext, prof};
+        for (const LwHostWin &w : hws) q.d.take(w);
+        const dim3 one(1, 1, (unsigned)G);
+        hipLaunchKernelGGL(lw_tr_init, one, dim3(TR_T), 0, h->stream, dws_dev);
+        auto enq_linearize = [&](int first) {                              // eval_grad_jac of the host loop
+            q.evaluate(0, 1, LW_SK_JAC);
+            hipLaunchKernelGGL(lw_tr_post, one, dim3(TR_T), 0, h->stream, dws_dev, first);
+            q.scale(0, LW_SK_JAC);
+        };
+        enq_linearize(1);
+        for (int it = 0; it < max_it; it++) {
+            hipLaunchKernelGGL(lw_tr_begin, one, dim3(TR_T), 0, h->stream, dws_dev);
+            q.quad(LW_SK_SOLVE);
+            hipLaunchKernelGGL(lw_tr_alpha, one, dim3(TR_T), 0, h->stream, dws_dev);
+            q.linear_solve(LW_SK_SOLVE);
+            hipLaunchKernelGGL(lw_tr_step, one, dim3(TR_T), 0, h->stream, dws_dev);
+            q.quad(LW_SK_QUAD);
+            hipLaunchKernelGGL(lw_tr_model, one, dim3(TR_T), 0, h->stream, dws_dev);
+            q.evaluate(1, 0, LW_SK_EVAL);
+            hipLaunchKernelGGL(lw_tr_decide, one, dim3(TR_T), 0, h->stream, dws_dev);
+            if (it + 1 < max_it) enq_linearize(0);
+        }
+        HIPCHECK(h, hipGetLastError());
+        std::vector<LwCtl> hcs(G);
+        std::vector<double> xs(tot_x);
+        HIPCHECK(h, hipMemcpyAsync(hcs.data(), dev + o_ctl, (size_t)G * sizeof(LwCtl), hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(xs.data(), dev + o_x, tot_x * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        ran_device = true;
+        size_t at = 0;
+        for (int g = 0; g < G; g++) {
+            LwHostWin &w = hws[g];
+            w.hc = hcs[g];
+            if (std::getenv("VILF_LW_FORCE_FALLBACK")) w.hc.fallback = 1;      // test hook: take the path of a failed factorisation (the host loop redoes the solve from the initial state)
+            if (std::getenv("VILF_LW_TRACE")) std::fprintf(stderr, "[vilf lw] device loop, window %d: fallback %d iterations %d successful %d solves %d termination %d cost %.9g -> %.9g\n", g, w.hc.fallback, w.hc.iteration, w.hc.num_successful, w.hc.num_linear_solves, w.hc.termination, w.hc.initial_cost, w.hc.x_cost);
+            if (!w.hc.fallback) std::memcpy(w.x.data(), &xs[at], (w.xo + 8) * 8);
+            at += w.xo + 8;
+        }
+    }
+    const double tl0 = h->opts.max_solver_time;
+    for (int g = 0; g < G; g++) {
+        LwHostWin &w = hws[g];
+        if (ran_device && !w.hc.fallback) continue;
+        const double tlim = tl0 > 0 ? tl0 * (w.in->marginalization_flag == VILF_MARGIN_OLD ? 4.0 / 5.0 : 1.0) : -1.0;   // estimator.cpp:847-850
+        // a group under a wall-clock limit: every window's clock starts with its own solve (the reference runs one window per call)
+        if ((rc = lw_host_loop(h, c, w, dws_dev + g, tlim, G == 1 ? t_start : std::chrono::steady_clock::now(), ext)) != VILF_OK) return rc;
     }
     // ---- outputs + double2vector (estimator.cpp:549-638)
-    if (out->para_pose) std::memcpy(out->para_pose, &x[0], 7 * NF * 8);
-    if (out->para_speed_bias) std::memcpy(out->para_speed_bias, &x[7 * NF], 9 * NF * 8);
-    if (out->para_feature) for (int f = 0; f < F; f++) out->para_feature[f] = x[16 * NF + f];
-    double R00[9], y0[3], y00[3], rot_diff[9];
-    h_q2R(&x[3], R00);
-    h_R2ypr(R0b, y0); h_R2ypr(R00, y00);
-    const double yd[3] = {y0[0] - y00[0], 0, 0};
-    h_ypr2R(yd, rot_diff);
-    if (std::fabs(std::fabs(y0[1]) - 90) < 1.0 || std::fabs(std::fabs(y00[1]) - 90) < 1.0)
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += R0b[3 * i + k] * R00[3 * j + k]; rot_diff[3 * i + j] = s; }
-    for (int i = 0; i < NF; i++) {
-        double Ri[9];
-        h_q2R(&x[7 * i + 3], Ri);
-        const double dp[3] = {x[7 * i] - x[0], x[7 * i + 1] - x[1], x[7 * i + 2] - x[2]};
-        for (int a = 0; a < 3; a++) {
-            for (int b = 0; b < 3; b++) { double s = 0; for (int k = 0; k < 3; k++) s += rot_diff[3 * a + k] * Ri[3 * k + b]; out->Rs[9 * i + 3 * a + b] = s; }
-            double sp = P0b[a], sv = 0;
-            for (int k = 0; k < 3; k++) { sp += rot_diff[3 * a + k] * dp[k]; sv += rot_diff[3 * a + k] * x[7 * NF + 9 * i + k]; }
-            out->Ps[3 * i + a] = sp; out->Vs[3 * i + a] = sv;
-            out->Bas[3 * i + a] = x[7 * NF + 9 * i + 3 + a]; out->Bgs[3 * i + a] = x[7 * NF + 9 * i + 6 + a];
+    std::vector<double> b_pose, b_sb, b_feat, b_ex, b_td, b_ps, b_rs, b_vs, b_bas, b_bgs;
+    std::vector<VbState> b_st;
+    const size_t sF2 = any_slot ? (size_t)h->batch.Fmax : 0;
+    if (contig) { b_pose.resize((size_t)G * 77); b_sb.resize((size_t)G * 99); b_feat.assign((size_t)G * sF2, 0.0); b_ex.resize((size_t)G * 7); b_td.resize(G); b_ps.resize((size_t)G * 33); b_rs.resize((size_t)G * 99); b_vs.resize((size_t)G * 33); b_bas.resize((size_t)G * 33); b_bgs.resize((size_t)G * 33); }
+    bool abnormal = false;
+    for (int g = 0; g < G; g++) {
+        LwHostWin &w = hws[g];
+        const vilf_window_in *in = w.in; vilf_window_out *out = w.out;
+        const int NF = w.NF, F = w.F; const size_t xo = w.xo;
+        const std::vector<double> &x = w.x;
+        double R0b[9], P0b[3];
+        if (in->gauge_R0) std::memcpy(R0b, in->gauge_R0, 72); else { double q0[4] = {in->para_pose[3], in->para_pose[4], in->para_pose[5], in->para_pose[6]}; h_q2R(q0, R0b); }
+        if (in->gauge_P0) std::memcpy(P0b, in->gauge_P0, 24); else std::memcpy(P0b, in->para_pose, 24);
+        if (out->para_pose) std::memcpy(out->para_pose, &x[0], 7 * (size_t)NF * 8);
+        if (out->para_speed_bias) std::memcpy(out->para_speed_bias, &x[7 * (size_t)NF], 9 * (size_t)NF * 8);
+        if (out->para_feature) for (int f = 0; f < F; f++) out->para_feature[f] = x[16 * (size_t)NF + f];
+        double R00[9], y0[3], y00[3], rot_diff[9];
+        h_q2R(&x[3], R00);
+        h_R2ypr(R0b, y0); h_R2ypr(R00, y00);
+        const double yd[3] = {y0[0] - y00[0], 0, 0};
+        h_ypr2R(yd, rot_diff);
+        if (std::fabs(std::fabs(y0[1]) - 90) < 1.0 || std::fabs(std::fabs(y00[1]) - 90) < 1.0)
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += R0b[3 * i + k] * R00[3 * j + k]; rot_diff[3 * i + j] = s; }
+        for (int i = 0; i < NF; i++) {
+            double Ri[9];
+            h_q2R(&x[7 * i + 3], Ri);
+            const double dp[3] = {x[7 * i] - x[0], x[7 * i + 1] - x[1], x[7 * i + 2] - x[2]};
+            for (int a = 0; a < 3; a++) {
+                for (int b = 0; b < 3; b++) { double s = 0; for (int k = 0; k < 3; k++) s += rot_diff[3 * a + k] * Ri[3 * k + b]; out->Rs[9 * i + 3 * a + b] = s; }
+                double sp = P0b[a], sv = 0;
+                for (int k = 0; k < 3; k++) { sp += rot_diff[3 * a + k] * dp[k]; sv += rot_diff[3 * a + k] * x[7 * NF + 9 * i + k]; }
+                out->Ps[3 * i + a] = sp; out->Vs[3 * i + a] = sv;
+                out->Bas[3 * i + a] = x[7 * NF + 9 * i + 3 + a]; out->Bgs[3 * i + a] = x[7 * NF + 9 * i + 6 + a];
+            }
+        }
+        for (int k = 0; k < 3; k++) out->tic[k] = x[xo + k];                 // double2vector :607-617: tic / ric / td from para_Ex_Pose / para_Td
+        h_q2R(&x[xo + 3], out->ric);
+        out->td = est_td ? x[xo + 7] : in->para_td;
+        const LwCtl &hc = w.hc;
+        out->summary.num_iterations = hc.iteration; out->summary.num_successful_steps = hc.num_successful; out->summary.num_linear_solves = hc.num_linear_solves;
+        out->summary.termination = hc.termination; out->summary.initial_cost = hc.initial_cost; out->summary.final_cost = hc.x_cost; out->summary.final_radius = hc.radius;
+        if (hc.termination == VILF_TERM_FAILURE) abnormal = true;
+        if (w.resident) {                                                    // the marginalization of this window reads the batch buffers of its slot
+            const size_t s = w.slot;
+            VbState stt;
+            std::memset(&stt, 0, sizeof(stt));
+            stt.iteration = hc.iteration; stt.num_successful = hc.num_successful; stt.num_linear_solves = hc.num_linear_solves;
+            stt.termination = hc.termination; stt.initial_cost = hc.initial_cost; stt.x_cost = hc.x_cost; stt.radius = hc.radius; stt.done = 1;
+            if (contig) {
+                std::memcpy(&b_pose[(size_t)g * 77], &x[0], 77 * 8); std::memcpy(&b_sb[(size_t)g * 99], &x[77], 99 * 8);
+                for (int f = 0; f < F; f++) b_feat[(size_t)g * sF2 + f] = x[16 * (size_t)NF + f];
+                std::memcpy(&b_ex[(size_t)g * 7], &x[xo], 56); b_td[g] = out->td;
+                std::memcpy(&b_ps[(size_t)g * 33], out->Ps, 33 * 8); std::memcpy(&b_rs[(size_t)g * 99], out->Rs, 99 * 8); std::memcpy(&b_vs[(size_t)g * 33], out->Vs, 33 * 8);
+                std::memcpy(&b_bas[(size_t)g * 33], out->Bas, 33 * 8); std::memcpy(&b_bgs[(size_t)g * 33], out->Bgs, 33 * 8);
+                b_st.push_back(stt);
+            } else {
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_POSE].as<double>() + s * 77, &x[0], 77 * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_SB].as<double>() + s * 99, &x[77], 99 * 8, hipMemcpyHostToDevice, h->stream));
+                if (F) HIPCHECK(h, hipMemcpyAsync(h->d[D_FEAT].as<double>() + s * sF2, &x[16 * (size_t)NF], (size_t)F * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_EX].as<double>() + s * 7, &x[xo], 56, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_TD].as<double>() + s, &out->td, 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_OPS].as<double>() + s * 33, out->Ps, 33 * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_ORS].as<double>() + s * 99, out->Rs, 99 * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_OVS].as<double>() + s * 33, out->Vs, 33 * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_OBAS].as<double>() + s * 33, out->Bas, 33 * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->d[D_OBGS].as<double>() + s * 33, out->Bgs, 33 * 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(h->batch.st + s, &stt, sizeof(stt), hipMemcpyHostToDevice, h->stream));
+                HIPCHECK(h, hipStreamSynchronize(h->stream));              // the sources are locals of this iteration
+            }
+            std::memcpy(&h->h_ex[s * 7], &x[xo], 56); h->h_td[s] = out->td;
         }
     }
-    for (int k = 0; k < 3; k++) out->tic[k] = x[xo + k];                 // double2vector :607-617: tic / ric / td from para_Ex_Pose / para_Td
-    h_q2R(&x[xo + 3], out->ric);
-    out->td = est_td ? x[xo + 7] : in->para_td;
-    if (batch_slot0) {                                                  // the marginalization of this window reads the batch buffers of its slot
-        const size_t sF2 = h->batch.Fmax;
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_POSE].as<double>() + slot * 77, &x[0], 77 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_SB].as<double>() + slot * 99, &x[77], 99 * 8, hipMemcpyHostToDevice, h->stream));
-        if (F) HIPCHECK(h, hipMemcpyAsync(h->d[D_FEAT].as<double>() + slot * sF2, &x[16 * NF], (size_t)F * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_EX].as<double>() + slot * 7, &x[xo], 56, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_TD].as<double>() + slot, &out->td, 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OPS].as<double>() + slot * 33, out->Ps, 33 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_ORS].as<double>() + slot * 99, out->Rs, 99 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OVS].as<double>() + slot * 33, out->Vs, 33 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBAS].as<double>() + slot * 33, out->Bas, 33 * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBGS].as<double>() + slot * 33, out->Bgs, 33 * 8, hipMemcpyHostToDevice, h->stream));
+    if (contig) {
+        const size_t s0 = hws[0].slot;
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_POSE].as<double>() + s0 * 77, b_pose.data(), b_pose.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_SB].as<double>() + s0 * 99, b_sb.data(), b_sb.size() * 8, hipMemcpyHostToDevice, h->stream));
+        if (sF2) HIPCHECK(h, hipMemcpyAsync(h->d[D_FEAT].as<double>() + s0 * sF2, b_feat.data(), b_feat.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_EX].as<double>() + s0 * 7, b_ex.data(), b_ex.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_TD].as<double>() + s0, b_td.data(), b_td.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OPS].as<double>() + s0 * 33, b_ps.data(), b_ps.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_ORS].as<double>() + s0 * 99, b_rs.data(), b_rs.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OVS].as<double>() + s0 * 33, b_vs.data(), b_vs.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBAS].as<double>() + s0 * 33, b_bas.data(), b_bas.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_OBGS].as<double>() + s0 * 33, b_bgs.data(), b_bgs.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->batch.st + s0, b_st.data(), b_st.size() * sizeof(VbState), hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
-        std::memcpy(&h->h_ex[slot * 7], &x[xo], 56); h->h_td[slot] = out->td;
     }
-    out->summary.num_iterations = iteration; out->summary.num_successful_steps = num_successful; out->summary.num_linear_solves = num_linear_solves;
-    out->summary.termination = termination; out->summary.initial_cost = initial_cost; out->summary.final_cost = x_cost; out->summary.final_radius = radius;
-    out->summary.usec_solve = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
-    return termination == VILF_TERM_FAILURE ? VILF_SOLVER_ABNORMAL : VILF_OK;
+    const double usec = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
+    for (LwHostWin &w : hws) w.out->summary.usec_solve = usec;          // the group's wall time: its windows are solved side by side
+    return abnormal ? VILF_SOLVER_ABNORMAL : VILF_OK;
+}
+
+// batch_slot1 != 0: the window is also resident as slot batch_slot1 - 1 of the 11-frame batch
+int vilf_lw_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out, int batch_slot1) {
+    return vilf_lw_group_solve(h, 1, &in, &out, &batch_slot1);
 }

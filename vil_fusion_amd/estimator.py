@@ -59,6 +59,18 @@ class BackendSolver:
         self._check(self._L.vilf_window_solve(self._h, C.byref(s), C.byref(res.struct)), "vilf_window_solve")
         return res.finish()
 
+    def optimization_group(self, windows):
+        """several windows of sizes other than 11 frames (the general path) side by side in one chain of launches ≙ one optimization() each"""
+        n = len(windows)
+        res = [abi.WindowResult(w.n_frames, w.n_features) for w in windows]
+        ins = (abi.WindowIn * n)(); outs = (abi.WindowOut * n)()
+        for i, w in enumerate(windows):
+            ins[i] = w.as_struct(); outs[i] = res[i].struct
+        self._check(self._L.vilf_window_solve_group(self._h, n, ins, outs), "vilf_window_solve_group")
+        for i in range(n):
+            res[i].struct = outs[i]              # the summaries were written into the array's copies (the buffers they point to are the results' own)
+        return [r.finish() for r in res]
+
     def marginalize(self):
         self._check(self._L.vilf_window_marginalize(self._h), "vilf_window_marginalize")
 

@@ -11,7 +11,7 @@ _lib = None
 
 EXPORTED = [
     "vilf_default_options", "vilf_create", "vilf_destroy", "vilf_reset", "vilf_last_error", "vilf_version",
-    "vilf_window_solve", "vilf_window_marginalize", "vilf_batch_upload", "vilf_batch_solve", "vilf_batch_rewind",
+    "vilf_window_solve", "vilf_window_solve_group", "vilf_window_marginalize", "vilf_batch_upload", "vilf_batch_solve", "vilf_batch_rewind",
     "vilf_batch_marginalize", "vilf_batch_download", "vilf_batch_download_states", "vilf_batch_summaries", "vilf_synchronize", "vilf_wait_for", "vilf_set_profiling", "vilf_get_profile",
     "vilf_batch_newest_poses_device", "vilf_prior_export", "vilf_prior_import", "vilf_eval_projection", "vilf_eval_imu", "vilf_eval_imu_raw",
     "vilf_eval_lidar_between", "vilf_eval_projection_td", "vilf_eval_prior", "vilf_eval_edge", "vilf_eval_surf", "vilf_pose_plus", "vilf_se3_plus",
@@ -52,6 +52,7 @@ def lib():
     L.vilf_destroy.restype = None
     L.vilf_reset.argtypes = [vp]
     L.vilf_window_solve.argtypes = [vp, C.POINTER(abi.WindowIn), C.POINTER(abi.WindowOut)]
+    L.vilf_window_solve_group.argtypes = [vp, C.c_int, C.POINTER(abi.WindowIn), C.POINTER(abi.WindowOut)]
     L.vilf_window_marginalize.argtypes = [vp]
     L.vilf_batch_upload.argtypes = [vp, C.c_int, C.POINTER(abi.WindowIn)]
     L.vilf_batch_solve.argtypes = [vp, C.c_int]
