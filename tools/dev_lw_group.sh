@@ -1,6 +1,6 @@
-# the general path after the grouping rewrite: its parity tests, then the stress bench with the per-group device times
+# the general path: its parity tests (+ the pose graph, which uses the same Cholesky), then group timing with the per-group device times
 mkdir -p gpurun_out/lwg
-timeout -k 10 800 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "large_window or group or td_estimation or extrinsic or time_limit or max_solver" > gpurun_out/lwg/tests.txt 2>&1; echo "tests rc $?"; tail -5 gpurun_out/lwg/tests.txt
+timeout -k 10 800 python -m pytest tests/test_gpu_parity.py tests/test_pose_graph.py -x -q -m gpu -k "large_window or group or td_estimation or extrinsic or time_limit or max_solver or pose_graph or loop" > gpurun_out/lwg/tests.txt 2>&1; echo "tests rc $?"; tail -5 gpurun_out/lwg/tests.txt
 python - <<P
 import time, numpy as np, torch
 from vil_fusion_amd import synth

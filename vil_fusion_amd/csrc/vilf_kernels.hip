@@ -23,7 +23,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 
 #define NT VB_NT
 #define VILF_MAX_FEATURES_DEV 1000
-// In-kernel phase stamps are a diagnostic build only (make HIPFLAGS+=-DVILF_STAMPS): the production kernels carry no clock reads.
+// In-kernel phase stamps are a diagnostic build only (make DEFS=-DVILF_STAMPS): the production kernels carry no clock reads.
 #ifdef VILF_STAMPS
 #define STAMP(kid, i) do { if (b.dbg && blockIdx.x == 0 && threadIdx.x == 0) b.dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
 #define TICK() __builtin_readcyclecounter()

@@ -481,22 +481,36 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int ksplit,
 
 // ---- dense Cholesky of the reduced system (P x P, fp64) with the right-hand side as row P: S = L L^T, L[P][0..P-1] = L^-1 rhs -----------------------
 // Right-looking over 64-column blocks, ONE launch per block column and no vendor library:
-//   lw_chol_panel   (block column 0) a workgroup = the 64 x 64 diagonal block + 192 rows of the panel below it, all as MFMA tiles in registers (the scheme of
-//                   k_solve_sb's dense factorisation): 4-column panels, one thread per slab row, rank-4 updates one v_mfma_f64_16x16x4_f64 per tile. Every workgroup
-//                   factors the diagonal block itself — the rows below cannot start before it is known, so that costs no time and saves a launch per block column.
+//   lw_chol_panel   (block column 0) a workgroup = the 64 x 64 diagonal block + 64 rows of the panel below it, all as MFMA tiles in registers: four 16-column
+//                   sub-panels, each a one-wave factorisation of the diagonal 16 x 16 tile (lane = row, v_readlane) that also yields the tile's inverse, the rows
+//                   below by MFMA against that inverse, rank-16 updates by MFMA. Every workgroup factors the diagonal block itself — the rows below cannot start
+//                   before it is known, so that costs no time and saves a launch per block column.
 //   lw_chol_step    (block columns 1 ..) the same panel workgroups, which first take the previous column's update of THEIR block column into their registers
 //                   (T -= L21 L21^T, operands through LDS), beside workgroups that apply the previous column's update to the 64 x 64 tiles further right (the two
 //                   panels through LDS, MFMA), rhs row included. Two launches per block column (panel, then the whole trailing update) were 0.63 ms per
-//                   factorisation, this is 0.55.
+//                   765 x 765 factorisation; one launch with 256-row slabs and 4-column panels 0.55; 128-row slabs and 16-column sub-panels 0.39 (a step:
+//                   2.3 us load, 6.1 us the slab's own update, 4 x (2.6 us tile factorisation + 0.7 us MFMA strip and update); lw_chol_back 0.10).
 //   lw_chol_back    L^T y = z by one workgroup (z = row P of the factor).
 #define CH_NB 64
 #define CH_LD 65
-#define CH_BELOW 192          // rows of the panel below the diagonal block per workgroup (256 rows with the block's own 64)
-// One workgroup = a 256 x 64 slab: the 64 rows of the diagonal block + 192 rows below it, as 16 x 4 MFMA tiles in registers (wave w owns the tile rows
-// w, w + 4, w + 8, w + 12). Per 4-column panel: lanes holding the panel's columns -> LDS; thread r (one per slab row) factors the 4 x 4 diagonal block itself
-// and solves its row's strip (the strip goes straight to S and to the operand buffer); rank-4 update of every tile right of the panel, one MFMA each.
+#define CH_M 2                // tile rows per wave: a slab = 64 CH_M rows. fp64 MFMA is 64 cycles an instruction on this part and a slab's MFMAs all run on ONE CU:
+#define CH_ROWS (64 * CH_M)   // with 256-row slabs (CH_M = 4) the update a slab takes first was 11 us of a 33 us step, mostly MFMA issue
+#define CH_LDS (CH_ROWS * 17 + 2 * 64 * 17 + 2 * 16 * 17)     // the panel workgroup's LDS, doubles
+#define CH_BELOW (CH_ROWS - 64)          // rows of the panel below the diagonal block per workgroup (256 rows with the block's own 64)
+// One workgroup = a CH_ROWS x 64 slab: the 64 rows of the diagonal block + CH_BELOW rows below it, as 16 x 16 MFMA accumulator tiles in registers (wave w owns the
+// tile rows w, w + 4, ...).
 // PRE: the update of the previous block column (jp = j0 - 64) has not been applied to this block column yet — the slab takes it itself, in registers, before it
 // factors (lw_chol_step: the rest of that update runs beside it in the same launch)
+__device__ __forceinline__ double lw_readlane(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// phase stamps of one panel workgroup (diagnostic build only: make DEFS=-DVILF_LW_STAMPS): 100 MHz wall clock of workgroup 0 at block column 128
+#ifdef VILF_LW_STAMPS
+__device__ long long lw_dbg_stamps[64];
+#define LWSTAMP(i) do { if (wg == 0 && threadIdx.x == 0 && j0 == 128) lw_dbg_stamps[i] = wall_clock64(); } while (0)
+#else
+#define LWSTAMP(i) do { } while (0)
+#endif
 template <bool PRE>
 __device__ __forceinline__ void lw_chol_panel_body(int P, double *S, int j0, int *info, int wg, double *s_pan, double *s_lp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c16 = lane & 15, g4 = lane >> 4;
@@ -504,9 +518,10 @@ __device__ __forceinline__ void lw_chol_panel_body(int P, double *S, int j0, int
     const int below0 = j0 + nb + CH_BELOW * wg;                    // first global row of this workgroup's rows below the block
     auto grow = [&](int lr) { return lr < CH_NB ? j0 + lr : below0 + (lr - CH_NB); };      // slab row -> row of S (rows 64.. of the slab are below the block)
     auto live = [&](int lr) { return lr < CH_NB ? lr < nb : below0 + (lr - CH_NB) < P1; };
-    lw_double4 T[4][4];                                            // [m][tile column]: tile row wave + 4 m
+    LWSTAMP(0);
+    lw_double4 T[CH_M][4];                                            // [m][tile column]: tile row wave + 4 m
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+    for (int m = 0; m < CH_M; m++)
 #pragma unroll
         for (int tcl = 0; tcl < 4; tcl++)
 #pragma unroll
@@ -517,47 +532,49 @@ __device__ __forceinline__ void lw_chol_panel_body(int P, double *S, int j0, int
                 const double v = S[ld ? (size_t)grow(lr) * P + j0 + c : (size_t)j0 * P + j0];
                 T[m][tcl][q] = ld ? v : ((lr < CH_NB && lr == c && lr >= nb) ? 1.0 : 0.0);
             }
+    LWSTAMP(1);
     if (PRE) {
         // T -= L[slab rows][jp .. jp + 63] L[block rows][jp .. jp + 63]^T. The two operands go through LDS in four K-quarters of 16, read from S along k (a wave
         // instruction covers four rows x 128 contiguous bytes; MFMA operands fetched straight from S touch sixteen rows per instruction and took 18 us instead of 4).
         // The staging area is the panel's s_pan / s_lp region and what follows it (the caller's buffer holds 16 x 257 + 16 x 65 doubles).
         const int jp = j0 - CH_NB;
-        double *sA = s_pan, *sB = s_pan + 16 * 257;
+        double *sA = s_pan, *sB = s_pan + 16 * (CH_ROWS + 1);
         // straight-line loads (a dead row reads a live one and is zeroed on the way to LDS: a branch per load kept them from being issued together), the next
         // quarter's loads are in flight while this quarter's MFMAs run
-        const double *pa[16], *pb[4];
+        const double *pa[CH_ROWS / 16], *pb[4];
         unsigned alive = 0;
 #pragma unroll
-        for (int u = 0; u < 16; u++) { const int e = tid + 256 * u, row = e >> 4; const bool lv = live(row); alive |= (lv ? 1u : 0u) << u; pa[u] = S + (size_t)(lv ? grow(row) : j0) * P + jp + (e & 15); }
+        for (int u = 0; u < CH_ROWS / 16; u++) { const int e = tid + 256 * u, row = e >> 4; const bool lv = live(row); alive |= (lv ? 1u : 0u) << u; pa[u] = S + (size_t)(lv ? grow(row) : j0) * P + jp + (e & 15); }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int e = tid + 256 * u, c = e >> 4; const bool lv = c < nb; alive |= (lv ? 1u : 0u) << (16 + u); pb[u] = S + (size_t)(j0 + (lv ? c : 0)) * P + jp + (e & 15); }
-        double va[16], vb[4];
+        for (int u = 0; u < 4; u++) { const int e = tid + 256 * u, c = e >> 4; const bool lv = c < nb; alive |= (lv ? 1u : 0u) << (CH_ROWS / 16 + u); pb[u] = S + (size_t)(j0 + (lv ? c : 0)) * P + jp + (e & 15); }
+        // every quarter's loads are issued here, in one batch: a round trip to S (written by the previous launch on other CUs) is ~2.8 us, and a quarter's
+        // MFMAs hide nothing of it — four dependent round trips were 11 of a step's 33 us (80 values per lane: the register file of a one-wave-per-SIMD kernel holds them)
+        double va[4][CH_ROWS / 16], vb[4][4];
 #pragma unroll
-        for (int u = 0; u < 16; u++) va[u] = pa[u][0];
+        for (int kq = 0; kq < 4; kq++) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) vb[u] = pb[u][0];
-#pragma unroll 1
+            for (int u = 0; u < CH_ROWS / 16; u++) va[kq][u] = pa[u][16 * kq];
+#pragma unroll
+            for (int u = 0; u < 4; u++) vb[kq][u] = pb[u][16 * kq];
+        }
+#pragma unroll
         for (int kq = 0; kq < 4; kq++) {
             __syncthreads();
 #pragma unroll
-            for (int u = 0; u < 16; u++) { const int e = tid + 256 * u; sA[(e & 15) * 257 + (e >> 4)] = ((alive >> u) & 1) ? -va[u] : 0.0; }
+            for (int u = 0; u < CH_ROWS / 16; u++) { const int e = tid + 256 * u; sA[(e & 15) * (CH_ROWS + 1) + (e >> 4)] = ((alive >> u) & 1) ? -va[kq][u] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int e = tid + 256 * u; sB[(e & 15) * 65 + (e >> 4)] = ((alive >> (16 + u)) & 1) ? vb[u] : 0.0; }
-            if (kq < 3) {
-#pragma unroll
-                for (int u = 0; u < 16; u++) va[u] = pa[u][16 * (kq + 1)];
-#pragma unroll
-                for (int u = 0; u < 4; u++) vb[u] = pb[u][16 * (kq + 1)];
-            }
+            for (int u = 0; u < 4; u++) { const int e = tid + 256 * u; sB[(e & 15) * 65 + (e >> 4)] = ((alive >> (CH_ROWS / 16 + u)) & 1) ? vb[kq][u] : 0.0; }
             __syncthreads();
 #pragma unroll
             for (int s4 = 0; s4 < 4; s4++) {
-                double av[4], bv[4];
+                double av[CH_M], bv[4];
                 const int k = 4 * s4 + g4;
 #pragma unroll
-                for (int t = 0; t < 4; t++) { av[t] = sA[k * 257 + 16 * (wave + 4 * t) + c16]; bv[t] = sB[k * 65 + 16 * t + c16]; }
+                for (int t = 0; t < CH_M; t++) av[t] = sA[k * (CH_ROWS + 1) + 16 * (wave + 4 * t) + c16];
 #pragma unroll
-                for (int m = 0; m < 4; m++)
+                for (int t = 0; t < 4; t++) bv[t] = sB[k * 65 + 16 * t + c16];
+#pragma unroll
+                for (int m = 0; m < CH_M; m++)
 #pragma unroll
                     for (int tcl = 0; tcl < 4; tcl++)
                         if (m > 0 || tcl <= wave) T[m][tcl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bv[tcl], T[m][tcl], 0, 0, 0);
@@ -565,50 +582,94 @@ __device__ __forceinline__ void lw_chol_panel_body(int P, double *S, int j0, int
         }
         __syncthreads();                                           // the staging area becomes s_pan / s_lp
     }
-    const bool mine = live(tid) && (tid >= CH_NB || wg == 0);                 // the block's own rows are written by workgroup 0 only
-    double *Srow = S + (size_t)grow(tid) * P + j0;
-#pragma unroll 1
-    for (int bj = 0; bj < 16; bj++) {
-        const int p0 = 4 * bj, tc = bj >> 2, sp = bj & 3;
-        if ((c16 >> 2) == sp) {
+    // ---- the slab's 64 columns as four 16-column sub-panels, two barriers each (4-column panels with a thread per row were 32 barriers and 16 dependent 4 x 4
+    // factorisations per block column: 28 of a step's 38 us):
+    //   A  the wave that owns the diagonal 16 x 16 tile (tile row tc = wave tc) factors it ALONE, lane = row: the tile goes through LDS into row layout, the pivot
+    //      row's entries travel by v_readlane, nothing waits for a barrier. Lanes 16 .. 31 run the same elimination on the rows of an identity: they end as L^-T.
+    //      Meanwhile every wave parks its tiles of the sub-panel in LDS (rows it owns: no other wave touches them).
+    //   B  X = T L^-T for every tile row of the sub-panel, four MFMAs per tile (the triangular solve as a product with the explicit 16 x 16 inverse), X -> S, and
+    //      into LDS as the operand of
+    //   C  the rank-16 update of the tiles right of the sub-panel (own rows as A operand, the block's rows — double-buffered copy — as B operand).
+    LWSTAMP(2);
+    double *s_own = s_pan, *s_blk = s_pan + CH_ROWS * 17, *s_inv = s_blk + 2 * 64 * 17, *s_dg = s_inv + 16 * 17;      
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+    for (int tc = 0; tc < 4; tc++) {
 #pragma unroll
-                for (int tcl = 0; tcl < 4; tcl++)
-                    if (tcl == tc) {
+        for (int m = 0; m < CH_M; m++)
+            if (m > 0 || wave >= tc) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) { const int lr = 16 * (wave + 4 * m) + g4 + 4 * q; if (lr >= p0) s_pan[4 * lr + (c16 & 3)] = T[m][tcl][q]; }
-                    }
-        }
-        __syncthreads();
-        if (tid >= p0) {
-            const double *dg = s_pan + 4 * p0, *rp = s_pan + 4 * tid;
-            const double d00 = dg[0], d10 = dg[4], d11 = dg[5], d20 = dg[8], d21 = dg[9], d22 = dg[10], d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
-            const double i0 = rsqrt_h3(d00), l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
-            const double t11 = d11 - l10 * l10, i1 = rsqrt_h3(t11), l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
-            const double t22 = d22 - l20 * l20 - l21 * l21, i2 = rsqrt_h3(t22), l32 = (d32 - l30 * l20 - l31 * l21) * i2;
-            const double t33 = d33 - l30 * l30 - l31 * l31 - l32 * l32, i3 = rsqrt_h3(t33);
-            const double x0 = rp[0] * i0, x1 = (rp[1] - x0 * l10) * i1, x2 = (rp[2] - x0 * l20 - x1 * l21) * i2, x3 = (rp[3] - x0 * l30 - x1 * l31 - x2 * l32) * i3;
-            const int k = tid - p0;                                // rows of the diagonal 4 x 4 block keep their lower part
-            double *lp = s_lp + 4 * tid;
-            lp[0] = x0; lp[1] = (k >= 1) ? x1 : 0.0; lp[2] = (k >= 2) ? x2 : 0.0; lp[3] = (k >= 3) ? x3 : 0.0;
-            if (mine) {
-                if (p0 < nb) Srow[p0] = x0;
-                if (k >= 1 && p0 + 1 < nb) Srow[p0 + 1] = x1;
-                if (k >= 2 && p0 + 2 < nb) Srow[p0 + 2] = x2;
-                if (k >= 3 && p0 + 3 < nb) Srow[p0 + 3] = x3;
+                for (int q = 0; q < 4; q++) s_own[(16 * (wave + 4 * m) + g4 + 4 * q) * 17 + c16] = T[m][tc][q];
             }
-            if (k == 0 && wg == 0 && (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || !(t33 > 0.0))) *info = 1;
+        if (wave == tc) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) s_dg[(g4 + 4 * q) * 17 + c16] = T[0][tc][q];
+            __builtin_amdgcn_wave_barrier();
+            // lane = row: lanes 0 .. 15 the tile's rows, lanes 16 .. 31 the rows of an identity (they end as L^-T); column k: scale by 1 / sqrt(pivot), then
+            // [j] -= [k] l_jk with l_jk by v_readlane. (Tried: the same elimination with v_mov_b64_dpp row_newbcast instead of v_readlane, square-root free with a
+            // shorter pivot chain: 2.6 us per tile like this one, but 180 more registers — one workgroup per CU instead of two, which costs a group of 32 windows 2x.)
+            double bb[16];
+            const int r = lane & 15;
+#pragma unroll
+            for (int j = 0; j < 16; j++) { const double dv = s_dg[r * 17 + j]; bb[j] = lane < 16 ? (j <= r ? dv : 0.0) : ((lane < 32 && j == r) ? 1.0 : 0.0); }
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const double piv = lw_readlane(bb[k], k);
+                bad = bad || !(piv > 0.0);
+                bb[k] *= rsqrt_h3(piv);
+                double sv[16];
+#pragma unroll
+                for (int j = k + 1; j < 16; j++) sv[j] = lw_readlane(bb[k], j);
+#pragma unroll
+                for (int j = k + 1; j < 16; j++) bb[j] = fma(-bb[k], sv[j], bb[j]);
+            }
+            if (lane >= 16 && lane < 32) {
+#pragma unroll
+                for (int n = 0; n < 16; n++) s_inv[r * 17 + n] = bb[n];
+            }
+            if (bad && wg == 0 && lane == 0) *info = 1;
         }
+        LWSTAMP(3 + 4 * tc);
         __syncthreads();
+        LWSTAMP(4 + 4 * tc);
+        double bv[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++)
+        for (int s4 = 0; s4 < 4; s4++) bv[s4] = s_inv[(4 * s4 + g4) * 17 + c16];
 #pragma unroll
-            for (int tcl = 0; tcl < 4; tcl++)
-                if (16 * tcl + 15 >= p0 + 4 && (m > 0 || tcl <= wave)) {          // right of the panel; the block's own tile rows: lower tiles only
-                    const double av = -s_lp[4 * (16 * (wave + 4 * m) + c16) + g4], bv = s_lp[4 * (16 * tcl + c16) + g4];
-                    T[m][tcl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T[m][tcl], 0, 0, 0);
+        for (int m = 0; m < CH_M; m++)
+            if (m > 0 || wave >= tc) {
+                lw_double4 X = lw_double4{0, 0, 0, 0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) X = __builtin_amdgcn_mfma_f64_16x16x4f64(s_own[(16 * (wave + 4 * m) + c16) * 17 + 4 * s4 + g4], bv[s4], X, 0, 0, 0);
+                const bool dtile = m == 0 && wave == tc;               // the diagonal tile: X = L, its upper part is rounding noise
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int lr = 16 * (wave + 4 * m) + g4 + 4 * q, col = 16 * tc + c16;
+                    const double xv = (dtile && c16 > g4 + 4 * q) ? 0.0 : X[q];
+                    T[m][tc][q] = xv;
+                    s_own[lr * 17 + c16] = xv;
+                    if (m == 0) s_blk[(tc & 1) * 64 * 17 + lr * 17 + c16] = xv;
+                    if (live(lr) && (lr >= CH_NB || wg == 0) && col < nb && (!dtile || c16 <= g4 + 4 * q)) S[(size_t)grow(lr) * P + j0 + col] = xv;      // the block's own rows are written by workgroup 0 only
                 }
+            }
+        LWSTAMP(5 + 4 * tc);
+        if (tc < 3) {
+            __syncthreads();
+            LWSTAMP(6 + 4 * tc);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                double av[CH_M], bw[4];
+#pragma unroll
+                for (int m = 0; m < CH_M; m++) av[m] = -s_own[(16 * (wave + 4 * m) + c16) * 17 + 4 * s4 + g4];
+#pragma unroll
+                for (int tcl = 0; tcl < 4; tcl++) bw[tcl] = tcl > tc ? s_blk[(tc & 1) * 64 * 17 + (16 * tcl + c16) * 17 + 4 * s4 + g4] : 0.0;
+#pragma unroll
+                for (int m = 0; m < CH_M; m++)
+#pragma unroll
+                    for (int tcl = 0; tcl < 4; tcl++)
+                        if (tcl > tc && (m > 0 || tcl <= wave)) T[m][tcl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m], bw[tcl], T[m][tcl], 0, 0, 0);
+            }
+        }
     }
 }
 // block column 0. npanel = the slabs of 256 rows the block column needs (the grid is sized for the group's largest window)
@@ -617,12 +678,12 @@ __global__ __launch_bounds__(256) void lw_chol_panel(const LwWin *ws, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
     if ((int)blockIdx.x >= lw_chol_npanel(w.P, 0)) return;
-    __shared__ double s_pan[256 * 4], s_lp[256 * 4];
-    lw_chol_panel_body<false>(w.P, w.S, 0, w.info, (int)blockIdx.x, s_pan, s_lp);
+    __shared__ double s_pan[CH_LDS];
+    lw_chol_panel_body<false>(w.P, w.S, 0, w.info, (int)blockIdx.x, s_pan, nullptr);
 }
 __global__ __launch_bounds__(256) void lw_chol_panel_raw(int P, double *S, int *info) {
-    __shared__ double s_pan[256 * 4], s_lp[256 * 4];
-    lw_chol_panel_body<false>(P, S, 0, info, (int)blockIdx.x, s_pan, s_lp);
+    __shared__ double s_pan[CH_LDS];
+    lw_chol_panel_body<false>(P, S, 0, info, (int)blockIdx.x, s_pan, nullptr);
 }
 // A22 -= L21 L21^T, lower 64 x 64 tiles of the rows / columns j1 .. P (row P = rhs). Tile u of the lower triangle, shifted by `shift` tile rows / columns
 // (shift 1 = lw_chol_step: the tiles right of the next block column; that column itself is the panel workgroups')
@@ -673,7 +734,7 @@ __device__ __forceinline__ void lw_chol_update_body(int P, double *S, int j0, in
 __device__ __forceinline__ void lw_chol_step_body(int P, double *S, int j0, int *info, double *s_buf) {
     const int npanel = lw_chol_npanel(P, j0), nt = (P + 1 - j0 + 63) / 64;     // tiles of the rows / columns j0 .. P; column 0 of them is the panel's
     if ((int)blockIdx.x >= npanel + nt * (nt - 1) / 2) return;
-    if ((int)blockIdx.x < npanel) lw_chol_panel_body<true>(P, S, j0, info, (int)blockIdx.x, s_buf, s_buf + 256 * 4);
+    if ((int)blockIdx.x < npanel) lw_chol_panel_body<true>(P, S, j0, info, (int)blockIdx.x, s_buf, nullptr);
     else lw_chol_update_body(P, S, j0 - CH_NB, CH_NB, (int)blockIdx.x - npanel, 1, s_buf, s_buf + CH_NB * CH_LD);
 }
 __global__ __launch_bounds__(256) void lw_chol_step(const LwWin *ws, int j0, int sk) {
@@ -690,9 +751,6 @@ __global__ __launch_bounds__(256) void lw_chol_step_raw(int P, double *S, int j0
 // fully unrolled so that the pivot row's value travels by v_readlane (a shuffle per step through LDS and a division per step were most of the 215 us this kernel
 // took), reciprocal diagonal computed once per block — while the other waves already stage the NEXT block's triangle in the second LDS buffer; then every earlier
 // entry subtracts its part, thread per entry, the block's 64 rows of L read along a row (coalesced, eight loads in flight).
-__device__ __forceinline__ double lw_readlane(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-}
 __device__ __forceinline__ void lw_chol_back_body(int P, const double *S, double *y, double *s_y, double *s_blk, double *s_tri) {
     const int tid = threadIdx.x;
     for (int i = tid; i < P; i += 1024) s_y[i] = S[(size_t)P * P + i];
@@ -1105,6 +1163,9 @@ __global__ __launch_bounds__(TR_T) void lw_tr_decide(const LwWin *ws) {
 // symmetric positive-definite matrix (lower triangle read, overwritten by L), row n the right-hand side; y (n) receives the solution. *info (device, zeroed by the caller)
 // is set to 1 when a pivot is not positive. Everything is enqueued on the handle's stream.
 // lw_chol_back keeps the solution vector in LDS (n doubles of dynamic LDS beside 33.8 KB of static staging): 12288 x 8 + 33.8 KB = 130 KB of the CU's 160 KB
+#ifdef VILF_LW_STAMPS
+extern "C" int vilf_debug_lw_stamps(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(lw_dbg_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#endif
 int vilf_lw_chol_max_n() { return 12288; }
 static int lw_chol_back_attr(vilf_handle *h) {     // above 64 KB in all, a launch needs the attribute; set once, for the largest supported n
     static bool attr_set = false;

@@ -29,7 +29,7 @@ __device__ __forceinline__ void rr_pair(int round, int k, int M, int &p, int &q)
 
 // Parallel two-sided cyclic Jacobi on a symmetric M x M matrix (M even, row stride ld). WITH_V: accumulate V <- V J.
 // rotlog (optional): (c, s) of every pair of every round, [sweep][round][M/2][2]. Returns the number of sweeps run.
-// In-kernel phase stamps: diagnostic build only (make HIPFLAGS+=-DVILF_STAMPS); workgroup MG_STAMP_WG writes them.
+// In-kernel phase stamps: diagnostic build only (make DEFS=-DVILF_STAMPS); workgroup MG_STAMP_WG writes them.
 #ifdef VILF_STAMPS
 __device__ long long mg_dbg[4 * 32];
 #define MG_STAMP_WG 1500

@@ -28,7 +28,7 @@
 #include "vilf_internal.hpp"
 #include "vilf_device.hpp"
 
-// In-kernel phase stamps: diagnostic build only (make HIPFLAGS+=-DVILF_STAMPS); workgroup S2M_STAMP_WG of a launch writes them, and only when
+// In-kernel phase stamps: diagnostic build only (make DEFS=-DVILF_STAMPS); workgroup S2M_STAMP_WG of a launch writes them, and only when
 // its stream is a big one (the short launches of a size class would overwrite the interesting ones otherwise).
 #ifdef VILF_STAMPS
 __device__ long long s2m_dbg[8 * 32];
