@@ -57,7 +57,7 @@ struct LwWin {
     LwCtl *ctl;
     double *x, *cand;
     const LwVis *vis; const LwTd *tdr; const double *imu, *lid; const unsigned char *fconst;
-    double *Hpp, *W, *hf, *gp, *gf, *S, *Wn, *rhs, *tmpP, *tmpF, *vec, *yf, *scal, *den, *jscr;     // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
+    double *Hpp, *W, *hf, *gp, *gf, *S, *Wn, *rhs, *tmpP, *tmpF, *vec, *yf, *scal, *den;     // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
     int *info;
     double *g, *diagH, *scale, *diagonal, *gradient, *gn, *step;                                    // N each: the minimizer's vectors
     const double *pJ, *pr0, *pH0, *px0; const int *phdr, *pcol; double *pdx;                       // marginalization prior of an 11-frame window (pn = 0: none)
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, 
     const int k = blockIdx.x, tid = threadIdx.x, NF = w.NF, P = w.P, use_lidar = w.use_lidar;
     if (k >= w.nimu) return;
     const double *x = which ? w.cand : w.x, *imu_rec = w.imu, *lid = w.lid, *G = w.scal + 8, *qil = w.scal + 1, *til = w.scal + 5;
-    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal, *jscr = w.jscr;
-    __shared__ double s_r[16], s_J[15 * 30], s_rw[16], s_lr[8], s_lJi[36], s_lJj[36];
+    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
+    __shared__ double s_r[16], s_J[15 * 30], s_rw[16], s_lr[8], s_lJi[36], s_lJj[36], s_jo[480];
     const int c0 = 15 * k;
     const double *pi = x + 7 * k, *pj = x + 7 * (k + 1), *sbi = x + 7 * NF + 9 * k, *sbj = sbi + 9;
     const double *rec = imu_rec + (size_t)k * IMU_REC;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, 
         if (jac) lidar_between_eval<true>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr, s_lJi, s_lJj); else lidar_between_eval<false>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr, s_lJi, s_lJj);
     }
     __syncthreads();
-    double *jo = jscr + (size_t)k * 480;                     // weighted Jacobian (15 x 30) and residual (15) for lw_imu_products
+    double *jo = s_jo;                                       // weighted Jacobian (15 x 30) and residual (15)
     if (has_imu) {
         const double *S = rec + IMU_SQRT;                    // upper-triangular sqrt_info (15 x 15, row-major)
         for (int e = tid; e < (jac ? 465 : 15); e += 128) {
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, 
             for (int m = a; m < 15; m++) sum += S[15 * a + m] * (col < 30 ? s_J[30 * m + col] : s_r[m]);
             if (col < 30) jo[30 * a + col] = sum; else { s_rw[a] = sum; if (jac) jo[450 + a] = sum; }
         }
-    } else if (jac) for (int e = tid; e < 465; e += 128) jo[e] = 0.0;
+    }
     if (use_lidar && jac)
         for (int e = tid; e < 12 * 13; e += 128) {           // LiDAR between-factor: J^T [J r] (unweighted Jacobian, weighted residual: the reference's quirk)
             const int a = e / 13, b = e - 13 * a;
@@ -325,6 +325,14 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, 
             } else { for (int m = 0; m < 6; m++) hh += Ja[6 * m + aa] * s_lr[m]; add(gp + ca, hh); }
         }
     __syncthreads();
+    if (has_imu && jac)                                      // J^T [J r] of the IMU factor: one lane per (row a, column b <= 30), 15-term dot products, one atomic each
+        for (int e = tid; e < 930; e += 128) {               // (a launch of its own, reading the weighted Jacobian back from global memory, until round 3)
+            const int a = e / 31, b = e - 31 * a;
+            double sum = 0;
+            for (int m = 0; m < 15; m++) sum += jo[30 * m + a] * (b < 30 ? jo[30 * m + b] : jo[450 + m]);
+            if (sum == 0.0) continue;
+            if (b < 30) add(Hpp + (size_t)(c0 + a) * P + c0 + b, sum); else add(gp + c0 + a, sum);
+        }
     if (tid == 0) {
         double c = 0;
         if (has_imu) for (int a = 0; a < 15; a++) c += 0.5 * s_rw[a] * s_rw[a];
@@ -350,21 +358,6 @@ __global__ __launch_bounds__(256) void lw_clear(const LwWin *ws, int sk) {
         if (t < n4) { a4[t] = 0.0; continue; } t -= n4;
         if (t == 0) cost[0] = 0.0;
     }
-}
-// J^T [J r] of every IMU factor: one lane per (factor, row a, column b <= 30): 15-term dot products, one atomic each
-__global__ void lw_imu_products(const LwWin *ws, int sk) {
-    const LwWin &w = ws[blockIdx.z];
-    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int P = w.P;
-    const double *jscr = w.jscr; double *Hpp = w.Hpp, *gp = w.gp;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x, k = t / 930, e = t - 930 * k;
-    if (k >= w.nimu) return;
-    const int a = e / 31, b = e - 31 * a, c0 = 15 * k;
-    const double *J = jscr + (size_t)k * 480;
-    double s = 0;
-    for (int m = 0; m < 15; m++) s += J[30 * m + a] * (b < 30 ? J[30 * m + b] : J[450 + m]);
-    if (s == 0.0) return;
-    if (b < 30) add(Hpp + (size_t)(c0 + a) * P + c0 + b, s); else add(gp + c0 + a, s);
 }
 // Jacobi scaling in place: Hpp(i, j) *= s_i s_j, W(f, c) *= s_f s_c, h_f *= s_f^2, g *= s. s = [P pose/speed-bias entries | F features] (src 0: the minimizer's
 // scale vector, 1: vec — the host loop uploads it there)
@@ -394,12 +387,6 @@ __global__ void lw_schur_prep(const LwWin *ws, int sk) {
     else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; den[f] = d; tmpF[f] = gf[f] / sqrt(d); }
     else if (t < nH + nW + F + P) { const int i = (int)(t - nH - nW - F); S[nH + i] = w.gp[i]; }
     else if (t == nH + nW + F + P) *w.info = 0;
-}
-__global__ void lw_feature_back(const LwWin *ws, int sk) {
-    const LwWin &w = ws[blockIdx.z];
-    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f < w.F) w.yf[f] = (w.gf[f] - w.tmpF[f]) / w.den[f];
 }
 
 // ---- the Schur reduce S -= Wn^T Wn as a hand-written fp64 MFMA SYRK ------------------------------------------------------------------
@@ -816,7 +803,7 @@ __global__ __launch_bounds__(1024) void lw_chol_back_raw(int P, const double *S,
     lw_chol_back_body(P, S, y, s_y, s_blk, s_tri);
 }
 // row-wise dots y[r] = A[r][0..P) . v, one 64-lane wave per row. mode 0 (x^T H x pieces for the vector in vec): rows 0 .. P - 1: Hpp vec -> tmpP, rows P .. P + F - 1:
-// W_f . vec -> tmpF; mode 1 (back substitution of the features): W_f . rhs -> tmpF
+// W_f . vec -> tmpF; mode 1 (back substitution of the features): y_f = (g_f - W_f . rhs) / den_f
 __global__ __launch_bounds__(256) void lw_rowdot(const LwWin *ws, int mode, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
@@ -829,7 +816,10 @@ __global__ __launch_bounds__(256) void lw_rowdot(const LwWin *ws, int mode, int 
     for (int c = lane; c < C; c += 64) s += a[c] * x[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (lane == 0) (hp ? w.tmpP : w.tmpF)[r] = s;
+    if (lane == 0) {
+        if (mode == 0) (hp ? w.tmpP : w.tmpF)[r] = s;
+        else w.yf[r] = (w.gf[r] - s) / w.den[r];            // y_f = (g_f - W_f . y_p) / den_f
+    }
 }
 // rhs row of S -= Wn^T (g_f / sqrt(den)): column sums over row chunks (thread per column, blockIdx.y = chunk), combined with atomics
 __global__ __launch_bounds__(256) void lw_colsum(const LwWin *ws, int rsplit, int sk) {
@@ -1240,7 +1230,7 @@ struct LwEnq {
         }
         if (d.any_prior) hipLaunchKernelGGL(lw_prior, grid(1), dim3(256), 0, h->stream, ws, jac, sk);
         hipLaunchKernelGGL(lw_imu_lidar, grid(d.maxNimu), dim3(128), 0, h->stream, ws, which, jac, sk);
-        if (jac) { hipLaunchKernelGGL(lw_imu_products, grid(((size_t)d.maxNimu * 930 + 255) / 256), dim3(256), 0, h->stream, ws, sk); toc(0); }
+        if (jac) toc(0);
     }
     // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in vec
     void quad(int sk) { hipLaunchKernelGGL(lw_rowdot, grid((d.maxP + d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, 0, sk); }
@@ -1255,7 +1245,7 @@ struct LwEnq {
         if (d.maxF) {
             // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P), rhs -= Wn^T (g_f / sqrt(den))
             tic();
-            const int nt = (d.maxP + 63) / 64, ksplit = d.G >= 4 ? 1 : 4;      // K splits only while the tiles alone do not fill the chip
+            const int nt = (d.maxP + 63) / 64, ksplit = nt * (nt + 1) / 2 * d.G >= 1024 ? 1 : 4;      // K splits only while the tiles alone do not fill the chip
             hipLaunchKernelGGL(lw_syrk_mfma, grid(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, ws, ksplit, sk);
             toc(1);
             const int rsplit = d.G >= 8 ? 16 : 128;
@@ -1273,8 +1263,7 @@ struct LwEnq {
         hipLaunchKernelGGL(lw_chol_back, grid(1), dim3(1024), (size_t)d.maxP * 8, h->stream, ws, sk);
         toc(2);
         if (d.maxF) {
-            hipLaunchKernelGGL(lw_rowdot, grid((d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, 1, sk);       // W_f . y_p
-            hipLaunchKernelGGL(lw_feature_back, grid((d.maxF + 255) / 256), dim3(256), 0, h->stream, ws, sk);
+            hipLaunchKernelGGL(lw_rowdot, grid((d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, 1, sk);       // y_f = (g_f - W_f . y_p) / den_f
         }
     }
 };
@@ -1505,6 +1494,10 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
     const bool prof = h->profiling != 0;
     if (prof && !c->ev[0]) { hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); }
     std::vector<LwHostWin> hws(G);
+    const bool trace = std::getenv("VILF_LW_TRACE") != nullptr;
+    double t_ph[6] = {0, 0, 0, 0, 0, 0};              // VILF_LW_TRACE: host phases (validate + priors, pack, upload + enqueue, wait, outputs)
+    auto t_last = t_start;
+    auto lap = [&](int i) { if (trace) { const auto n = std::chrono::steady_clock::now(); t_ph[i] += std::chrono::duration<double, std::milli>(n - t_last).count(); t_last = n; } };
     // ---- validation, sizes
     bool any_slot = false, contig = slot1 != nullptr;       // contig: the group is a run of consecutive batch slots (vilf_batch_solve): priors in, states back in bulk copies
     size_t tot_imu = 0, tot_x = 0;
@@ -1559,6 +1552,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
             if (w.phdr[0]) { w.pn = w.phdr[1]; w.pnb = w.phdr[2]; }
         }
     }
+    lap(0);
     // ---- arena layout. Inputs first (one host image, one copy): per window vis | tdr | lid | fconst | scal | pcol; then group-wide runs imu | cov | x (k_imu_prep
     // takes the IMU factors of all windows in one launch; the states come back in one copy); then the minimizer scalars (one copy back) and the work areas.
     size_t off = 0;
@@ -1575,7 +1569,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
     const size_t o_x = off; off = lw_al(off + tot_x * 8);
     const size_t n_input = off;
     const size_t o_ctl = off; off = lw_al(off + (size_t)G * sizeof(LwCtl));
-    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, den, jscr, info, nvec, pdx; };
+    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, den, info, nvec, pdx; };
     std::vector<WorkOff> wo(G);
     for (int g = 0; g < G; g++) {
         const LwHostWin &w = hws[g];
@@ -1584,7 +1578,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         auto take = [&](size_t bytes) { const size_t at = off; off = lw_al(off + bytes); return at; };
         o.cand = take((w.xo + 8) * 8); o.Hpp = take(sP * sP * 8); o.W = take(sF * sP * 8); o.hf = take(sF * 8); o.gp = take(sP * 8); o.gf = take(sF * 8);
         o.S = take((sP + 1) * sP * 8); o.Wn = take(sF * sP * 8); o.rhs = take(sP * 8); o.tmpP = take(sP * 8); o.tmpF = take(sF * 8); o.vec = take(2 * sN * 8);
-        o.den = take(sF * 8); o.jscr = take((size_t)w.nimu * 480 * 8); o.info = take(64); o.nvec = take(7 * sN * 8); o.pdx = take(VB_PRIOR_LD * 8);
+        o.den = take(sF * 8); o.info = take(64); o.nvec = take(7 * sN * 8); o.pdx = take(VB_PRIOR_LD * 8);
     }
     if (!c->arena.ensure(off) || !c->desc.ensure((size_t)G * sizeof(LwWin))) { h->err = "hipMalloc failed (general-path solve)"; return VILF_ERR_DEVICE; }
     if (c->stage_cap < n_input) {
@@ -1694,7 +1688,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         d.fconst = reinterpret_cast<const unsigned char *>(dev + w.o_fconst);
         auto dp = [&](size_t at) { return reinterpret_cast<double *>(dev + at); };
         d.Hpp = dp(o.Hpp); d.W = dp(o.W); d.hf = dp(o.hf); d.gp = dp(o.gp); d.gf = dp(o.gf); d.S = dp(o.S); d.Wn = dp(o.Wn); d.rhs = dp(o.rhs); d.tmpP = dp(o.tmpP); d.tmpF = dp(o.tmpF);
-        d.vec = dp(o.vec); d.yf = dp(o.vec) + sN; d.scal = dp(w.o_scal); d.den = dp(o.den); d.jscr = dp(o.jscr); d.info = reinterpret_cast<int *>(dev + o.info);
+        d.vec = dp(o.vec); d.yf = dp(o.vec) + sN; d.scal = dp(w.o_scal); d.den = dp(o.den); d.info = reinterpret_cast<int *>(dev + o.info);
         double *nv = dp(o.nvec);
         d.g = nv; d.diagH = nv + sN; d.scale = nv + 2 * sN; d.diagonal = nv + 3 * sN; d.gradient = nv + 4 * sN; d.gn = nv + 5 * sN; d.step = nv + 6 * sN;
         d.pcol = reinterpret_cast<const int *>(dev + w.o_pcol); d.pdx = dp(o.pdx);
@@ -1716,6 +1710,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
             for (std::thread &t : th) t.join();
         }
     }
+    lap(1);
     HIPCHECK(h, hipMemcpyAsync(dev, st, n_input, hipMemcpyHostToDevice, h->stream));
     HIPCHECK(h, hipMemcpyAsync(c->desc.p, dws.data(), (size_t)G * sizeof(LwWin), hipMemcpyHostToDevice, h->stream));
     const LwWin *dws_dev = c->desc.as<LwWin>();
@@ -1753,9 +1748,11 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         HIPCHECK(h, hipGetLastError());
         std::vector<LwCtl> hcs(G);
         std::vector<double> xs(tot_x);
+        lap(2);
         HIPCHECK(h, hipMemcpyAsync(hcs.data(), dev + o_ctl, (size_t)G * sizeof(LwCtl), hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipMemcpyAsync(xs.data(), dev + o_x, tot_x * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
+        lap(3);
         ran_device = true;
         size_t at = 0;
         for (int g = 0; g < G; g++) {
@@ -1863,6 +1860,8 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         HIPCHECK(h, hipMemcpyAsync(h->batch.st + s0, b_st.data(), b_st.size() * sizeof(VbState), hipMemcpyHostToDevice, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
     }
+    lap(4);
+    if (trace) std::fprintf(stderr, "[vilf lw] group of %d: validate + priors %.3f ms, pack %.3f, upload + enqueue %.3f, wait %.3f, outputs %.3f\n", G, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4]);
     const double usec = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
     for (LwHostWin &w : hws) w.out->summary.usec_solve = usec;          // the group's wall time: its windows are solved side by side
     return abnormal ? VILF_SOLVER_ABNORMAL : VILF_OK;
