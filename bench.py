@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (profile runs: its 2048-window solves would mix into the per-kernel averages)")
     ap.add_argument("--ragged-windows", type=int, default=1024, help="distinct windows of the ragged-batch line (features U(120, 320), mixed prior / no prior, mixed marginalization flags), tiled to --windows; 0 skips it")
+    ap.add_argument("--td-windows", type=int, default=64, help="windows of the estimate_td batch line (general path as one group of launches vs the plain batch); 0 skips it")
     ap.add_argument("--stress-mode", default="group", choices=["group", "streams"], help="--stress: how the independent windows run side by side (one grouped chain of launches / one handle and stream each)")
     ap.add_argument("--stress-windows", default="1,8,32", help="--stress: numbers of independent stress windows solved side by side (one handle / stream / host thread each)")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[4] instead of the headline workload: one synthetic 51-frame / ~46 k-factor window per step and GPU")
@@ -353,13 +354,25 @@ def main():
     # share a device in one RCCL communicator).
     gather = None
     gathered = None
+    gather_note = None
     if world > 1 and not rehearse:
-        idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(vdist.RcclPoseGather.unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, src=0)
-        gather = vdist.RcclPoseGather(world, rank, device=local_rank, unique_id=bytes(idt.cpu().numpy().tobytes()))
-        gathered = torch.zeros((world * B, 8), dtype=torch.float64, device="cuda")
+        # every rank first checks, without any collective, that the library's own RCCL binding loads (vilf_comm_unique_id dlopens librccl); only when all do is the
+        # communicator created (a collective: a rank that failed before it would leave the others waiting). Otherwise torch.distributed carries the gather and says so.
+        ok = torch.ones(1, dtype=torch.int32, device="cuda")
+        try:
+            my_id = vdist.RcclPoseGather.unique_id()
+        except Exception as e:                                            # noqa: BLE001 — reported in the JSON line
+            ok.zero_(); gather_note = f"C-ABI RCCL binding unavailable on rank {rank}: {e}"
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(my_id), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            gather = vdist.RcclPoseGather(world, rank, device=local_rank, unique_id=bytes(idt.cpu().numpy().tobytes()))
+            gathered = torch.zeros((world * B, 8), dtype=torch.float64, device="cuda")
+        elif gather_note is None:
+            gather_note = "C-ABI RCCL binding unavailable on another rank"
 
     def gather_step():
         solver.newest_poses_to_device(stamps, poses.data_ptr())              # a kernel on the solver's stream, no host wait
@@ -583,6 +596,31 @@ def main():
         pcie = best
         psolver.close()
 
+    # ---- estimate_td batch (ProjectionTdFactor, td a variable: estimator.cpp:713-717,772-777; off in the KITTI configuration): such batches go through the general path,
+    # all slots as ONE group of launches (vilf_lw.hip), not through the LDS kernels. 64 windows, solve only, against the plain batch of the same windows.
+    td_batch = None
+    if world == 1 and args.td_windows > 0:
+        nb = args.td_windows
+        tdw = [synth.with_td_inputs(wins[i % args.distinct], 10 + i) for i in range(min(nb, 16))]
+        tdw = [tdw[i % len(tdw)] for i in range(nb)]
+        tdp = [priors[i % min(nb, 16) % args.distinct] for i in range(nb)]
+        tms = {}
+        for flag in (0, 1):
+            from vil_fusion_amd.lib import default_options as _defopts
+            o2 = _defopts(); o2.estimate_td = flag
+            ts = BackendSolver(o2, device=local_rank)
+            ts.batch_upload(tdw, tdp)
+            for _ in range(2):
+                ts.batch_rewind(); ts.batch_solve()
+            torch.cuda.synchronize(); tq0 = time.perf_counter()
+            for _ in range(5):
+                ts.batch_rewind(); ts.batch_solve()
+            torch.cuda.synchronize(); tms[flag] = (time.perf_counter() - tq0) / 5 * 1e3
+            tms[(flag, "it")] = sum(x.num_iterations for x in ts.batch_summaries())
+            ts.close()
+        td_batch = {"windows": nb, "plain_batch_ms": tms[0], "estimate_td_batch_ms": tms[1], "ratio": tms[1] / tms[0], "iterations": [tms[(0, "it")], tms[(1, "it")]],
+                    "what": "vilf_batch_solve of the same 64 windows (with priors): estimate_td = 0 (LDS kernels) vs estimate_td = 1 (general path, one group of launches; the slots ran one by one until round 3: ~80 ms)"}
+
     if rank == 0:
         abytes = float(np.mean([algorithmic_bytes_per_iteration(w, p) for w, p in zip(wins[:args.distinct], priors[:args.distinct])]))
         # algorithmic bytes per STEP (all B frames) per kernel / launch group; for the window kernels
@@ -666,7 +704,7 @@ def main():
                        "frames_per_gpu": B, "workload_tag": workload_tag, "lidar_stage": lid,
                        "windows_per_gpu": B, "distinct_windows": args.distinct, "visual_factors_per_window": float(np.mean([w.n_factors for w in wins[:args.distinct]])),
                        "features_per_window": float(np.mean([w.n_features for w in wins[:args.distinct]])), "max_iterations": int(opts.max_num_iterations),
-                       "parallelism": f"{world} x independent window shards (no data-path collective; RCCL all_gather of 64 B poses)"},
+                       "parallelism": f"{world} x independent window shards (no data-path collective; RCCL all_gather of 64 B poses" + (" through vilf_gather_poses" if gather is not None else (" through torch.distributed: " + gather_note if gather_note else "")) + ")"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": "PMC FETCH_SIZE doubled (gfx950: wide coalesced reads are under-counted 2x) + WRITE_SIZE; `traffic_raw` without the doubling — this kernel reads mostly 8-byte operands, the truth lies between",
                          "avg_launch_ms": avg_ms, "launches_per_step": lps[dom], "algorithmic_bytes_per_launch": alg[dom] / max(lps[dom], 1e-9),
@@ -686,6 +724,8 @@ def main():
             out["converging_batch"] = converging
         if pcie is not None:
             out["pcie_inclusive"] = pcie
+        if td_batch is not None:
+            out["estimate_td_batch"] = td_batch
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))

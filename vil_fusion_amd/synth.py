@@ -506,3 +506,16 @@ def make_lidar_sequence(seed, n_frames, speed=8.0, dt=0.1, yaw_rate=0.05, **kw):
         scans.append(scene.scan(R, t))
         poses.append((R, t))
     return scans, poses
+
+
+def with_td_inputs(win, seed, td_true=0.004):
+    """ProjectionTdFactor inputs (projection_td_factor.cpp:6-21) for a synthetic window: pixel velocities on the normalised plane, zero per-observation td, image
+    rows; the observations are shifted as a camera running `td_true` seconds late would have seen them."""
+    from . import abi
+    rng = np.random.default_rng(seed)
+    vel = rng.normal(0.0, 0.4, (win.n_obs, 2))
+    pts = win.obs_point.copy()
+    pts[:, :2] += td_true * vel
+    return abi.Window(win.para_pose, win.para_speed_bias, win.para_ex_pose, win.para_feature, win.feature_const, win.feature_start_frame,
+                      win.feature_obs_offset, pts, win.imu, win.lidar, para_td=0.0, marginalization_flag=win.marginalization_flag,
+                      obs_velocity=vel, obs_cur_td=np.zeros(win.n_obs), obs_row=rng.uniform(0.0, 370.0, win.n_obs))
