@@ -198,7 +198,11 @@ int vilf_window_marginalize(vilf_handle *h);
 /* ---- batched windows (independent window snapshots resident in HBM) -------------------- */
 /* Pack + upload n windows into slots 0..n-1 (inputs stay resident until the next upload). */
 int vilf_batch_upload(vilf_handle *h, int n_windows, const vilf_window_in *wins);
-/* Solve every resident window (all kernels enqueued on the handle's stream). sync!=0 waits. */
+/* Solve every resident window from its resident state (all kernels enqueued on the handle's stream). sync!=0 waits; with sync == 0 the usec_solve of the summaries
+ * is filled by the next call that waits for the stream (vilf_batch_summaries / vilf_batch_download_states). Returns VILF_OK also when single windows terminated
+ * abnormally: their summaries tell (termination = VILF_TERM_FAILURE). options.estimate_extrinsic / estimate_td: all slots run through the general path as ONE group
+ * of launches (vilf_window_solve_group's machinery, each slot with its device-resident prior); that path reads its results back, so the call is always synchronous.
+ * options.max_solver_time > 0: ONE host clock for the whole batch, started by this call (the windows of a batch run in lockstep), and a stream wait per iteration. */
 int vilf_batch_solve(vilf_handle *h, int sync);
 /* Re-arm the resident windows with their uploaded initial state (bench loop: repeated identical steps). */
 int vilf_batch_rewind(vilf_handle *h);

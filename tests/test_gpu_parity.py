@@ -664,6 +664,32 @@ def _with_td_inputs(win, seed, td_true=0.004):
                       obs_velocity=vel, obs_cur_td=np.zeros(win.n_obs), obs_row=rng.uniform(0.0, 370.0, win.n_obs))
 
 
+def test_estimate_td_batch_continues_from_the_resident_state_and_async_solve_time(oracle):
+    """Like the batched LDS kernels, the estimate_td slots (general path, one group of launches) solve from the RESIDENT state: a second vilf_batch_solve without a
+    rewind starts where the first ended (its initial cost = the first's final cost), a rewind restores the uploaded state. And: a solve enqueued with sync = 0
+    reports its own device time through the next call that waits for the stream (usec_solve was stale there)."""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options(); o.estimate_td = 1
+    cfg = synth.SynthConfig(with_prior=False, n_features=100)
+    wins = [_with_td_inputs(synth.make_window(70 + k, o, cfg)[0], 30 + k) for k in range(3)]
+    s = BackendSolver(o)
+    s.batch_upload(wins, None)
+    s.batch_solve(); s1 = s.batch_summaries()
+    s.batch_solve(); s2 = s.batch_summaries()
+    s.batch_rewind(); s.batch_solve(); s3 = s.batch_summaries()
+    s.close()
+    for a, b, c in zip(s1, s2, s3):
+        assert abs(b.initial_cost - a.final_cost) <= 1e-9 * a.final_cost and b.final_cost <= a.final_cost * (1 + 1e-12)
+        assert abs(c.initial_cost - a.initial_cost) <= 1e-12 * a.initial_cost and c.num_iterations == a.num_iterations
+    p = BackendSolver(oracle.default_options())
+    pw, pp = synth.make_batch(11, 4, oracle.default_options(), synth.SynthConfig(n_features=80), distinct=4)
+    p.batch_upload(pw, pp)
+    p.batch_solve(sync=True); t_sync = p.batch_summaries()[0].usec_solve
+    p.batch_rewind(); p.batch_solve(sync=False); t_async = p.batch_summaries()[0].usec_solve
+    p.close()
+    assert t_sync > 0 and t_async > 0 and 0.3 < t_async / t_sync < 3.0, (t_sync, t_async)
+
+
 def _perturbed_extrinsic(win, seed):
     rng = np.random.default_rng(seed)
     ex = win.para_ex_pose.copy()

@@ -607,6 +607,11 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(k_reset, dim3(h->B), dim3(VB_NT), 0, h->stream, h->batch, 1);
     HIPCHECK(h, hipGetLastError());
+    if ((h->opts.estimate_extrinsic || h->opts.estimate_td) && (int)h->own.size() == h->B) {      // Ex_Pose / td are variables then: their uploaded values are part of the state
+        for (int w = 0; w < h->B; w++) { std::memcpy(&h->h_ex[(size_t)w * 7], h->own[w].in.para_ex_pose, 56); h->h_td[w] = h->own[w].in.para_td; }
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_EX].p, h->h_ex.data(), (size_t)h->B * 56, hipMemcpyHostToDevice, h->stream));
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_TD].p, h->h_td.data(), (size_t)h->B * 8, hipMemcpyHostToDevice, h->stream));
+    }
     if (h->prior_restore_needed && h->prior_backup_valid) {          // a marginalization replaced the priors: the set as uploaded becomes the live one again (swap, no copy)
         const int live[6] = {D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG}, bak[6] = {D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0};
         for (int k = 0; k < 6; k++) std::swap(h->d[live[k]], h->d[bak[k]]);
@@ -618,6 +623,13 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
     return VILF_OK;
 }
 
+// usec_solve of an asynchronous solve: its two events are read once the stream has been waited for (summaries / download_states)
+static void solve_time_resolve(vilf_handle *h) {
+    if (!h->solve_time_pending) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->last_solve_usec = ms * 1000.0;
+    h->solve_time_pending = false;
+}
 static bool tlim_disabled(vilf_handle *h) { return !(h->opts.max_solver_time > 0); }
 extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     if (!h || !h->resident) return VILF_ERR_INVALID_ARGUMENT;
@@ -648,7 +660,8 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
         const int rc = vilf_lw_group_solve(h, h->B, inp.data(), outp.data(), slot1.data());
         if (rc < 0) return rc;
         h->last_solve_usec = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        (void)sync;
+        h->solve_time_pending = false;
+        (void)sync;                             // the general path reads its results back: always synchronous
         return VILF_OK;
     }
     bool dirty = false;
@@ -695,7 +708,8 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
             }
             hipEventRecord(h->ev1, h->stream);
             HIPCHECK(h, hipGetLastError());
-            if (sync) { HIPCHECK(h, hipStreamSynchronize(h->stream)); float ms = 0; hipEventElapsedTime(&ms, h->ev0, h->ev1); h->last_solve_usec = ms * 1000.0; }
+            h->solve_time_pending = true;
+            if (sync) { HIPCHECK(h, hipStreamSynchronize(h->stream)); solve_time_resolve(h); }
             return VILF_OK;
         }
     }
@@ -732,11 +746,10 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     }
     hipEventRecord(h->ev1, h->stream);
     HIPCHECK(h, hipGetLastError());
+    h->solve_time_pending = true;
     if (sync) {
         HIPCHECK(h, hipStreamSynchronize(h->stream));
-        float ms = 0;
-        hipEventElapsedTime(&ms, h->ev0, h->ev1);
-        h->last_solve_usec = ms * 1000.0;
+        solve_time_resolve(h);
         if (prof) { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
     }                                           // sync == 0 with profiling on: the spans stay pending (read by the next call that waits for the stream)
     return VILF_OK;
@@ -773,6 +786,7 @@ extern "C" int vilf_batch_summaries(vilf_handle *h, int first, int n, vilf_summa
     std::vector<VbState> st(n);
     HIPCHECK(h, hipMemcpyAsync(st.data(), h->batch.st + first, sizeof(VbState) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    solve_time_resolve(h);
     { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }     // the stream is idle: pending profile spans cost nothing to read now
     for (int i = 0; i < n; i++) {
         sums[i].num_iterations = st[i].iteration;
@@ -842,6 +856,7 @@ extern "C" int vilf_batch_download_states(vilf_handle *h, int first, int n, doub
     if (Bgs) HIPCHECK(h, dn(pG, h->batch.out_Bgs + (size_t)first * 33, sn * 33 * 8));
     if (sums) HIPCHECK(h, dn(pS, h->batch.st + first, sn * sizeof(VbState)));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    solve_time_resolve(h);
     if (Ps) std::memcpy(Ps, pP, sn * 33 * 8);
     if (Rs) std::memcpy(Rs, pR, sn * 99 * 8);
     if (Vs) std::memcpy(Vs, pV, sn * 33 * 8);

@@ -1532,17 +1532,34 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         const int rca = lw_chol_back_attr(h);
         if (rca != VILF_OK) return rca;
     }
-    // ---- the priors of the resident windows (marginalization_factor.cpp:333-381): block tables to the host, J0 / r0 / J0^T J0 stay on the device
+    // ---- the resident windows: their priors (marginalization_factor.cpp:333-381: block tables to the host, J0 / r0 / J0^T J0 stay on the device) and their CURRENT state
+    // in the batch buffers — like the batched kernels, a solve continues from the resident state (the uploaded one after an upload or a rewind, the solved one otherwise)
+    std::vector<double> r_pose, r_sb, r_feat, r_ex, r_td;
+    const size_t rF = any_slot ? (size_t)h->batch.Fmax : 0;
     if (any_slot) {
         std::vector<int> hdr_all; std::vector<double> x0_all;
+        r_pose.resize((size_t)G * 77); r_sb.resize((size_t)G * 99); r_feat.resize((size_t)G * std::max<size_t>(rF, 1)); r_ex.resize((size_t)G * 7); r_td.resize(G);
         if (contig) {
+            const size_t s0 = hws[0].slot;
             hdr_all.resize((size_t)G * VB_PRIOR_HDR); x0_all.resize((size_t)G * 24 * 9);
-            HIPCHECK(h, hipMemcpyAsync(hdr_all.data(), h->d[D_PHDR].as<int>() + hws[0].slot * VB_PRIOR_HDR, hdr_all.size() * 4, hipMemcpyDeviceToHost, h->stream));
-            HIPCHECK(h, hipMemcpyAsync(x0_all.data(), h->d[D_PX0].as<double>() + hws[0].slot * 24 * 9, x0_all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(hdr_all.data(), h->d[D_PHDR].as<int>() + s0 * VB_PRIOR_HDR, hdr_all.size() * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(x0_all.data(), h->d[D_PX0].as<double>() + s0 * 24 * 9, x0_all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(r_pose.data(), h->d[D_POSE].as<double>() + s0 * 77, r_pose.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(r_sb.data(), h->d[D_SB].as<double>() + s0 * 99, r_sb.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            if (rF) HIPCHECK(h, hipMemcpyAsync(r_feat.data(), h->d[D_FEAT].as<double>() + s0 * rF, (size_t)G * rF * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(r_ex.data(), h->d[D_EX].as<double>() + s0 * 7, r_ex.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHECK(h, hipMemcpyAsync(r_td.data(), h->d[D_TD].as<double>() + s0, r_td.size() * 8, hipMemcpyDeviceToHost, h->stream));
         } else
-            for (LwHostWin &w : hws) if (w.resident) {
+            for (int g = 0; g < G; g++) {
+                LwHostWin &w = hws[g];
+                if (!w.resident) continue;
                 HIPCHECK(h, hipMemcpyAsync(w.phdr, h->d[D_PHDR].as<int>() + w.slot * VB_PRIOR_HDR, sizeof(w.phdr), hipMemcpyDeviceToHost, h->stream));
                 HIPCHECK(h, hipMemcpyAsync(w.px0, h->d[D_PX0].as<double>() + w.slot * 24 * 9, sizeof(w.px0), hipMemcpyDeviceToHost, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(&r_pose[(size_t)g * 77], h->d[D_POSE].as<double>() + w.slot * 77, 77 * 8, hipMemcpyDeviceToHost, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(&r_sb[(size_t)g * 99], h->d[D_SB].as<double>() + w.slot * 99, 99 * 8, hipMemcpyDeviceToHost, h->stream));
+                if (rF) HIPCHECK(h, hipMemcpyAsync(&r_feat[(size_t)g * rF], h->d[D_FEAT].as<double>() + w.slot * rF, rF * 8, hipMemcpyDeviceToHost, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(&r_ex[(size_t)g * 7], h->d[D_EX].as<double>() + w.slot * 7, 56, hipMemcpyDeviceToHost, h->stream));
+                HIPCHECK(h, hipMemcpyAsync(&r_td[g], h->d[D_TD].as<double>() + w.slot, 8, hipMemcpyDeviceToHost, h->stream));
             }
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         for (int g = 0; g < G; g++) {
@@ -1660,9 +1677,15 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         for (int k = 0; k < 3; k++) { scal[5 + k] = til[k]; scal[8 + k] = h->opts.G[k]; }
         // the state: x = pose | sb | feat | ex[7] | td
         w.x.resize(w.xo + 8);
-        std::memcpy(&w.x[0], in->para_pose, 7 * (size_t)NF * 8); std::memcpy(&w.x[7 * (size_t)NF], in->para_speed_bias, 9 * (size_t)NF * 8);
-        for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + f] = in->para_feature[f];
-        std::memcpy(&w.x[w.xo], in->para_ex_pose, 56); w.x[w.xo + 7] = in->para_td;
+        if (w.resident) {                              // NF = 11: the slot's current state
+            std::memcpy(&w.x[0], &r_pose[(size_t)g * 77], 77 * 8); std::memcpy(&w.x[77], &r_sb[(size_t)g * 99], 99 * 8);
+            for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + f] = r_feat[(size_t)g * rF + f];
+            std::memcpy(&w.x[w.xo], &r_ex[(size_t)g * 7], 56); w.x[w.xo + 7] = r_td[g];
+        } else {
+            std::memcpy(&w.x[0], in->para_pose, 7 * (size_t)NF * 8); std::memcpy(&w.x[7 * (size_t)NF], in->para_speed_bias, 9 * (size_t)NF * 8);
+            for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + f] = in->para_feature[f];
+            std::memcpy(&w.x[w.xo], in->para_ex_pose, 56); w.x[w.xo + 7] = in->para_td;
+        }
         std::memcpy(reinterpret_cast<double *>(st + o_x) + at_x, w.x.data(), w.x.size() * 8);
         int *pcol = reinterpret_cast<int *>(st + w.o_pcol);
         for (int i = 0; i < VB_PRIOR_LD; i++) pcol[i] = -1;
