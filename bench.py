@@ -151,7 +151,7 @@ def stress_main(args):
     for _ in range(max(args.warmup, 1)):
         res = solver.optimization(win)
 
-    # ---- S independent stress windows at once. A single window's solve is a chain of ~36 small launches per iteration on a handful of workgroups (12 sequential panel
+    # ---- S independent stress windows at once. A single window's solve is a chain of ~32 small launches per iteration on a handful of workgroups (12 sequential panel
     # steps per factorisation), so the chip is filled by solving windows side by side. "group" (default): vilf_window_solve_group — ONE chain of launches, every kernel
     # finds its window in blockIdx.z. "streams": one handle (= HIP stream, workspace) and one host thread per window — the runtime multiplexes its streams onto four
     # hardware queues, so that tops out near 3 k iterations/s; kept for comparison. Aggregate iterations/s; no per-kernel profiling here.
@@ -639,7 +639,8 @@ def main():
                 "s2m_associate": B * 2 * nq * (16 + 64 + lid["rows_per_query"] * 8 + lid["candidates_per_query"] * 16),
                 "s2m_neighbour_index": B * (nm * 4 + lid["map_cells"] * 4),  # directory: one 4-byte slot id in per map point, one 4-byte slot out per occupied cell
                 "s2m_radix_sort": B * ns * 12 * 2,                       # only when a scan cloud exceeds the in-LDS grid (22 k points): ONE pass over (key, index)
-                "s2m_voxel_grid": B * ((nm + ns + nq) * 16 * 2 + nm * 4),    # 4 grids: read points, write centroids (+ the slot id beside every map point)
+                "s2m_voxel_grid": B * (ns + nq) * 16,                    # the two scan grids: raw scan points in, centroids out
+                "s2m_map_update": B * (nm * 32 + nq * 16),               # the two map updates: old map + registered scan in, new map out (+ 4 B per occupied cell: the directory)
                 "s2m_lm_solve": B * nq * 64.0 * 2 * 5,                   # factor records (one 64-byte sector each), 2 passes x 5 evaluations
                 "s2m_submap": B * nq * 16 * 2})                         # transform + append of the registered scan (crop and grid are in s2m_voxel_grid)
         workload_tag = ("lidar+" if lid is not None else "") + "solve" + ("" if args.no_marginalize else "+marginalize")

@@ -187,7 +187,7 @@ const char *vilf_version(void);
 /* ---- single-window drop-in (≙ Estimator::optimization()) ------------------------------- */
 /* estimator.cpp:689-860: build problem, Solve, double2vector. Uses/keeps the prior of slot 0. */
 int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out);
-/* n independent windows of sizes other than 11 frames (the general path), solved side by side in ONE chain of launches: a window's chain is ~36 small dependent
+/* n independent windows of sizes other than 11 frames (the general path), solved side by side in ONE chain of launches: a window's chain is ~32 small dependent
  * launches per iteration, so a group fills the chip where a single window (or one handle / stream per window) cannot. in / out: arrays of n; every out[i] needs
  * Ps / Rs / Vs / Bas / Bgs. Same results as n calls of vilf_window_solve (to the rounding of the atomics' summation order). 11-frame windows:
  * VILF_ERR_UNSUPPORTED (use vilf_batch_*). Returns VILF_SOLVER_ABNORMAL if any window terminated abnormally (its summary tells). */
@@ -222,8 +222,8 @@ int vilf_wait_for(vilf_handle *h, vilf_handle *other);
  * With sync == 0 calls the spans stay pending and are read by the next call that waits for the stream (a sync call, vilf_batch_summaries, vilf_get_profile*). */
 int vilf_set_profiling(vilf_handle *h, int on);
 int vilf_get_profile(vilf_handle *h, double ms_out[4], long launches_out[4]);
-/* same switch, scan-to-map launches by group: 0 voxel grid, 1 radix sort, 2 neighbour index, 3 associate (5-NN + fits),
- * 4 LM solve, 5 sub-map maintenance, 6 other, 7 unused */
+/* same switch, scan-to-map launches by group: 0 voxel grid of the scan clouds, 1 radix sort, 2 neighbour index, 3 associate (5-NN + fits),
+ * 4 LM solve, 5 sub-map maintenance, 6 other, 7 fused local-map update (crop + merge + voxel grid + directory) */
 int vilf_get_profile_scan2map(vilf_handle *h, double ms_out[8], long launches_out[8]);
 /* same switch, marginalization kernels: 0 prepare (factor re-evaluation at the linearisation point), 1 Schur complement, 2 eigen + prior, 3 prior H/g */
 int vilf_get_profile_marginalize(vilf_handle *h, double ms_out[4], long launches_out[4]);

@@ -18,14 +18,14 @@ GROUPS = {   # kernel-name prefix -> bench.py launch group
     "k_linearize_last": "k_step", "k_linearize": "k_linearize", "k_solve": "k_solve", "k_step": "k_step",      # k_linearize_last = the step-only launch that ends a solve
     "k_marg_prepare": "k_marg_prepare", "k_marg_schur": "k_marg_schur", "k_marg_finish": "k_marg_finish", "k_mf_": "k_marg_finish", "k_prior_prep": "k_prior_prep",
     "b_minmax": "s2m_voxel_grid", "b_voxel_keys": "s2m_voxel_grid", "void b_voxel_keys": "s2m_voxel_grid", "void b_voxel_reduce": "s2m_voxel_grid",
-    "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_voxel_grid",
+    "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_map_update",
     "b_check_order": "s2m_voxel_grid", "void b_scan_voxel": "s2m_voxel_grid",
     "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_dir_build": "s2m_neighbour_index", "b_gather_sorted": "s2m_neighbour_index",
     "b_make_cid": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
     "b_crop_compact": "s2m_submap", "b_transform_append": "s2m_submap", "b_bump": "s2m_submap",
 }
 LAUNCHES_PER_STEP = {"k_linearize": 8, "k_solve": 8, "k_step": 1, "k_marg_prepare": 1, "k_marg_schur": 1, "k_marg_finish": 1, "k_prior_prep": 1,
-                     "s2m_voxel_grid": 4, "s2m_radix_sort": 1, "s2m_neighbour_index": 2, "s2m_associate": 2, "s2m_lm_solve": 2, "s2m_submap": 2}
+                     "s2m_voxel_grid": 2, "s2m_map_update": 2, "s2m_radix_sort": 1, "s2m_neighbour_index": 2, "s2m_associate": 2, "s2m_lm_solve": 2, "s2m_submap": 2}
 GATHER = ("s2m_associate", "s2m_neighbour_index", "s2m_lm_solve", "k_linearize", "k_solve", "k_step", "k_marg_prepare", "k_marg_schur", "k_marg_finish", "k_prior_prep")
 
 

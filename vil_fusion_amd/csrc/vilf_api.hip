@@ -273,8 +273,12 @@ static int upload_priors(vilf_handle *h) {
         const vilf_prior &p = h->priors[w];
         h->prior_dev_newer[w] = 0;
         if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > 2 * VB_NF + (h->opts.estimate_td ? 1 : 0)) { h->err = "prior touches feature blocks (or Td without estimate_td): unsupported"; return VILF_ERR_UNSUPPORTED; }
-        if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > VB_NF && p.block_id[i] < 2 * VB_NF) h->solve_dense_fallback = true;
+        char dense_w = 0;
+        if (p.valid) for (int i = 0; i < p.n_blocks; i++) if (p.block_id[i] > VB_NF && p.block_id[i] < 2 * VB_NF) dense_w = 1;
+        if ((int)h->prior_dense.size() <= w) h->prior_dense.resize(w + 1, 0);
+        h->prior_dense_count += dense_w - h->prior_dense[w]; h->prior_dense[w] = dense_w;
     }
+    h->solve_dense_fallback = h->prior_dense_count > 0;      // recomputed with every upload: a later prior without such a block returns the handle to k_solve_sb
     auto fill = [&](const vilf_prior &p, int *hd, double *x0) {
         std::memset(hd, 0, VB_PRIOR_HDR * sizeof(int)); std::memset(x0, 0, 24 * 9 * sizeof(double));
         if (!p.valid) return;
@@ -618,6 +622,7 @@ extern "C" int vilf_batch_rewind(vilf_handle *h) {
         bind_prior_pointers(h);
         // the device now holds the authoritative priors; the host mirror may have seen the marginalized ones through an export
         for (int w = 0; w < h->B; w++) { h->prior_dev_newer[w] = 1; h->prior_dirty[w] = 0; }
+        // (the restored set is the uploaded one: prior_dense / solve_dense_fallback describe exactly it)
         h->prior_restore_needed = false;
     }
     return VILF_OK;
@@ -670,7 +675,8 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     const dim3 grid(h->B), block(VB_NT);
     // k_solve_sb eliminates SpeedBias[1..10] as a block-tridiagonal chain: valid while the priors hold no speed-bias block but SpeedBias[0] (all the
     // reference ever produces, estimator.cpp:960-971); VILF_SOLVE_DENSE=1 forces the dense-Cholesky kernel (tests compare the two)
-    const bool dense = h->solve_dense_fallback || std::getenv("VILF_SOLVE_DENSE") != nullptr;
+    // (solve_dense_fallback describes the priors as uploaded; after a device marginalization the live priors hold SpeedBias[0] only — prior_restore_needed — until a rewind)
+    const bool dense = (h->solve_dense_fallback && !h->prior_restore_needed) || std::getenv("VILF_SOLVE_DENSE") != nullptr;
     const bool prof = h->profiling != 0;
     if (prof && h->prof_used.size() > 4096) { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }      // asynchronous calls without a reader: bound the pool
     std::vector<int> kinds;

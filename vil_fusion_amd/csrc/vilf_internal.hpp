@@ -76,6 +76,8 @@ struct vilf_handle {
     bool resident = false;
     std::vector<vilf_prior> priors;          // per slot (host mirror)
     std::vector<char> prior_dirty;
+    std::vector<char> prior_dense;           // slot's live prior (imported from the host) holds a speed-bias block other than SpeedBias[0]
+    int prior_dense_count = 0;
     std::vector<char> prior_dev_newer;       // slot's prior was produced on the device (marginalize) and not yet mirrored
     std::vector<int> h_mflag;
     int prior_slots_valid = 0;               // the device prior arrays hold slots 0 .. prior_slots_valid-1 (survive a re-upload of the windows)

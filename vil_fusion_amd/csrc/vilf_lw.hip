@@ -21,7 +21,7 @@
 // Summation order of the atomics is not fixed: results are reproducible to rounding (~1e-12 relative), not bit for bit.
 // Groups: every kernel of this file takes an array of window descriptors (LwWin, one per window, resident on the device) and finds its window in blockIdx.z —
 // ONE chain of launches solves G independent windows side by side (vilf_window_solve_group; the estimate_td / estimate_extrinsic slots of vilf_batch_solve).
-// A window's chain is ~36 small dependent launches per iteration on a handful of workgroups, so a single window leaves most of the chip idle and G handles on G
+// A window's chain is ~32 small dependent launches per iteration on a handful of workgroups, so a single window leaves most of the chip idle and G handles on G
 // streams do not help either (the runtime multiplexes its streams onto four hardware queues: 3.1 k iterations/s at eight streams, worse with more queues);
 // in one launch the G windows' workgroups simply fill more CUs. A single window is a group of one. All device memory of a group is one arena (DBuf): the
 // small inputs of all windows go up in one copy, states and minimizer scalars come back in one.

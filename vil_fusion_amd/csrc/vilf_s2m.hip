@@ -1874,7 +1874,7 @@ static int s2b_step(vilf_handle *h, S2B *c) {
                 hipLaunchKernelGGL(b_map_update<true>, dim3(S), dim3(MU_T), (size_t)MU_TILE * 12, h->stream, map, c->nOld.as<int>(), d_pose, h->opts.s2m_crop_half, 1.0f / leaf[w], c->cs_cfg[w], c->cs_mapout(w), c->bstartAlt[w].as<unsigned>(), new_tag[w], c->fixq[w].as<int>(),
                                    c->tmpB.as<float4>(), c->capScan[w], c->muT.as<unsigned long long>(), p2, 0, lds_cap, gq, gq_stride, d_err);
             }
-            PROF(0)
+            PROF(7)
             new_dir_ok[w] = true;      // (of the map the swap below makes current)
         } else {                       // a map that is not a voxel grid yet (as initialised): crop copy + full sort
             hipLaunchKernelGGL(b_crop_compact, dim3(S), dim3(S2B_VT), 0, h->stream, map, d_pose, h->opts.s2m_crop_half, tmp, c->nOld.as<int>(), c->mOld.as<int>());

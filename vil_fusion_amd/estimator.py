@@ -114,7 +114,7 @@ class BackendSolver:
         names = ["k_linearize", "k_solve", "k_step", "other"]
         return {names[i]: dict(ms=ms[i], launches=n[i]) for i in range(4)}
 
-    S2M_GROUPS = ("s2m_voxel_grid", "s2m_radix_sort", "s2m_neighbour_index", "s2m_associate", "s2m_lm_solve", "s2m_submap", "s2m_other")
+    S2M_GROUPS = ("s2m_voxel_grid", "s2m_radix_sort", "s2m_neighbour_index", "s2m_associate", "s2m_lm_solve", "s2m_submap", "s2m_other", "s2m_map_update")
 
     def get_profile_scan2map(self):
         ms = (C.c_double * 8)(); n = (C.c_long * 8)()
