@@ -64,6 +64,8 @@ struct OwnedWindow {
     std::vector<vilf_lidar_constraint> lidar;
 };
 
+// class plan of one window's visual factors (class_plan, vilf_api.hip): computed by the upload's validation pass, used by its packer
+struct WindowPlan { int cls[VB_NPAIR], cstart[VB_NPAIR], ccount[VB_NPAIR], nslot; };
 struct vilf_handle {
     vilf_options opts;
     int device = 0;
@@ -109,6 +111,7 @@ struct vilf_handle {
     long marg_launches[4] = {0, 0, 0, 0};
     double s2m_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long s2m_launches[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<WindowPlan> plans;
     double last_solve_usec = 0;
     bool solve_time_pending = false;         // the last solve was enqueued with sync == 0: ev0 / ev1 are read by the next call that waits for the stream
     size_t solve_lds = 0, lin_lds = 0, solve_sb_lds = 0;
