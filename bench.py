@@ -81,7 +81,14 @@ def cpu_baseline(opts_unused, wins, priors, lidar_cases, marginalize, seconds_ta
         its4 = sum(ex.map(frame, range(n4)))
     dt4 = time.perf_counter() - t0
     what = ("scan-to-map step (1 m grid 5-NN) + " if lidar_cases else "") + "window solve" + (" + marginalization" if marginalize else "")
-    return dict(value=its / dt, unit="iterations/s", cores=cores, kind="port",
+    # one frame alone on one thread (the oracle has no threads inside a frame; Ceres in the reference uses 4 inside its solve): the latency reference
+    tl = time.perf_counter(); r1 = oracle_lib.window_solve(o, wins[0], priors[0]); tl1 = time.perf_counter()
+    oracle_lib.window_marginalize(o, wins[0], r1, priors[0]); tl2 = time.perf_counter()
+    lat = {"window_solve_ms": 1e3 * (tl1 - tl), "marginalize_ms": 1e3 * (tl2 - tl1)}
+    if prepared:
+        m, (se, ss) = prepared[0]
+        mc = m.clone(); tl3 = time.perf_counter(); mc.step(se, ss); lat["scan_to_map_frame_ms"] = 1e3 * (time.perf_counter() - tl3)
+    return dict(single_frame_latency_1_thread=lat, value=its / dt, unit="iterations/s", cores=cores, kind="port",
                 sample=f"{n} frames ({its} window iterations; per frame: {what}) of the same synthetic input by oracle/ "
                        f"(C++ -O3, one frame per thread, {cores} threads), {dt:.1f} s; at the reference's 4 threads: {n4} frames in {dt4:.1f} s",
                 value_4_threads=its4 / dt4)
@@ -265,6 +272,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg (profile runs: its 2048-window solves would mix into the per-kernel averages)")
     ap.add_argument("--ragged-windows", type=int, default=1024, help="distinct windows of the ragged-batch line (features U(120, 320), mixed prior / no prior, mixed marginalization flags), tiled to --windows; 0 skips it")
+    ap.add_argument("--no-latency", dest="latency", action="store_false", help="skip the single-frame latency line")
     ap.add_argument("--td-windows", type=int, default=64, help="windows of the estimate_td batch line (general path as one group of launches vs the plain batch); 0 skips it")
     ap.add_argument("--stress-mode", default="group", choices=["group", "streams"], help="--stress: how the independent windows run side by side (one grouped chain of launches / one handle and stream each)")
     ap.add_argument("--stress-windows", default="1,8,32", help="--stress: numbers of independent stress windows solved side by side (one handle / stream / host thread each)")
@@ -596,6 +604,35 @@ def main():
         pcie = best
         psolver.close()
 
+    # ---- single-frame latency: the reference's only mode is ONE window per frame (estimator_node.cpp:243-396) — through the single-window / single-stream entry
+    # points, host buffers in, host buffers out, median of 20 (one workgroup per kernel: a chain of dependent fp64 operations at 36 cycles each)
+    latency = None
+    if world == 1 and args.latency:
+        from vil_fusion_amd.estimator import Scan2Map
+        ls = BackendSolver(device=local_rank)
+        lw_, lp_ = wins[0], priors[0]
+
+        def med(fn, n=20):
+            ts = []
+            for _ in range(n):
+                t_ = time.perf_counter(); fn(); ts.append(time.perf_counter() - t_)
+            return 1e3 * float(np.median(ts))
+
+        def f_solve():
+            ls.set_prior(lp_); return ls.optimization(lw_)
+
+        def f_solve_marg():
+            ls.set_prior(lp_); ls.optimization(lw_); ls.marginalize()
+        f_solve()
+        latency = {"window_solve_ms": med(f_solve), "window_solve_device_usec": f_solve().summary["usec_solve"], "window_solve_marginalize_ms": med(f_solve_marg),
+                   "what": "vilf_window_solve (upload + <= 8 dogleg iterations + download) and + vilf_window_marginalize of ONE 11-frame window; vilf_scan2map_step of ONE LiDAR stream (steady-state local map)"}
+        if raw_lidar:
+            me_, ms_, scans_, pl_ = raw_lidar[0]
+            m1 = Scan2Map(ls); m1.localMapInited(me_, ms_)
+            m1.optimation_processing(*scans_[0])
+            t_ = time.perf_counter(); m1.optimation_processing(*scans_[1]); latency["scan_to_map_frame_ms"] = 1e3 * (time.perf_counter() - t_)
+        ls.close()
+
     # ---- estimate_td batch (ProjectionTdFactor, td a variable: estimator.cpp:713-717,772-777; off in the KITTI configuration): such batches go through the general path,
     # all slots as ONE group of launches (vilf_lw.hip), not through the LDS kernels. 64 windows, solve only, against the plain batch of the same windows.
     td_batch = None
@@ -727,6 +764,8 @@ def main():
             out["pcie_inclusive"] = pcie
         if td_batch is not None:
             out["estimate_td_batch"] = td_batch
+        if latency is not None:
+            out["single_frame_latency"] = latency
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))
