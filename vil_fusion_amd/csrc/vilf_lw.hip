@@ -34,6 +34,7 @@
 #include <vector>
 #include <thread>
 #include <atomic>
+#include <mutex>
 #include "vilf_internal.hpp"
 #include "vilf_device.hpp"
 
@@ -1157,13 +1158,15 @@ __global__ __launch_bounds__(TR_T) void lw_tr_decide(const LwWin *ws) {
 extern "C" int vilf_debug_lw_stamps(long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(lw_dbg_stamps), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
 #endif
 int vilf_lw_chol_max_n() { return 12288; }
-static int lw_chol_back_attr(vilf_handle *h) {     // above 64 KB in all, a launch needs the attribute; set once, for the largest supported n
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(lw_chol_back_raw), hipFuncAttributeMaxDynamicSharedMemorySize, vilf_lw_chol_max_n() * 8));
-        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(lw_chol_back), hipFuncAttributeMaxDynamicSharedMemorySize, vilf_lw_chol_max_n() * 8));
-        attr_set = true;
-    }
+static int lw_chol_back_attr(vilf_handle *h) {     // above 64 KB in all, a launch needs the attribute; set once per process (handles on several host threads may get here together), for the largest supported n
+    static std::once_flag once;
+    static hipError_t e1 = hipSuccess, e2 = hipSuccess;
+    std::call_once(once, []() {
+        e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_chol_back_raw), hipFuncAttributeMaxDynamicSharedMemorySize, vilf_lw_chol_max_n() * 8);
+        e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(lw_chol_back), hipFuncAttributeMaxDynamicSharedMemorySize, vilf_lw_chol_max_n() * 8);
+    });
+    HIPCHECK(h, e1);
+    HIPCHECK(h, e2);
     return VILF_OK;
 }
 int vilf_lw_chol_solve(vilf_handle *h, int n, double *S, double *y, int *info) {
