@@ -1829,7 +1829,8 @@ static int s2b_step(vilf_handle *h, S2B *c) {
     }
     const int nblk_e = (c->capScan[0] + 255) / 256, nblk_s = (c->capScan[1] + 255) / 256;
     for (int pass = 0; pass < h->opts.s2m_outer_iterations && pass < 2; pass++) {
-        hipLaunchKernelGGL(b_associate, dim3(nblk_e + nblk_s, S), dim3(256), 0, h->stream, aa[0], aa[1], nblk_e);
+        static const size_t assoc_lds_probe = std::getenv("VILF_ASSOC_LDS") ? (size_t)std::atoi(std::getenv("VILF_ASSOC_LDS")) : 0;     // occupancy experiment: unused dynamic LDS caps the workgroups per CU
+        hipLaunchKernelGGL(b_associate, dim3(nblk_e + nblk_s, S), dim3(256), assoc_lds_probe, h->stream, aa[0], aa[1], nblk_e);
         hipLaunchKernelGGL(b_associate_ties, dim3(S), dim3(256), 0, h->stream, aa[0], aa[1]);      // queries that met exactly equal distances (rare), in the reference's order
         PROF(3)
         hipLaunchKernelGGL(b_solve, dim3(S), dim3(S2M_NT), 0, h->stream, d_pose, c->frec.as<double>(), c->fkind.as<int>(), capq, c->nDs[0].as<int>(), c->nDs[1].as<int>(), h->opts.huber_a,
