@@ -742,7 +742,7 @@ def main():
                        "frames_per_gpu": B, "workload_tag": workload_tag, "lidar_stage": lid,
                        "windows_per_gpu": B, "distinct_windows": args.distinct, "visual_factors_per_window": float(np.mean([w.n_factors for w in wins[:args.distinct]])),
                        "features_per_window": float(np.mean([w.n_features for w in wins[:args.distinct]])), "max_iterations": int(opts.max_num_iterations),
-                       "parallelism": f"{world} x independent window shards (no data-path collective; RCCL all_gather of 64 B poses" + (" through vilf_gather_poses" if gather is not None else (" through torch.distributed: " + gather_note if gather_note else "")) + ")"},
+                       "parallelism": f"{world} x independent window shards (no data-path collective; " + ("one-GPU rehearsal: gloo all_gather of 64 B poses" if rehearse else "RCCL all_gather of 64 B poses" + (" through vilf_gather_poses" if gather is not None else (" through torch.distributed: " + gather_note if gather_note else ""))) + ")"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                          "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": "PMC FETCH_SIZE doubled (gfx950: wide coalesced reads are under-counted 2x) + WRITE_SIZE; `traffic_raw` without the doubling — this kernel reads mostly 8-byte operands, the truth lies between",
                          "avg_launch_ms": avg_ms, "launches_per_step": lps[dom], "algorithmic_bytes_per_launch": alg[dom] / max(lps[dom], 1e-9),
