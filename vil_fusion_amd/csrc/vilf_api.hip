@@ -148,6 +148,9 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + 512 + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
     h->lin_lds = (size_t)VB_LIN_LDS_DOUBLES * sizeof(double);
     h->solve_sb_lds = (size_t)SB_LDS_DOUBLES * sizeof(double);
+    // occupancy experiment (tools/dev_window_occ.sh): unused extra dynamic LDS leaves ONE workgroup per CU instead of two
+    if (const char *e = std::getenv("VILF_LIN_LDS_EXTRA")) h->lin_lds += (size_t)std::atoi(e);
+    if (const char *e = std::getenv("VILF_SB_LDS_EXTRA")) h->solve_sb_lds += (size_t)std::atoi(e);
     static_assert(VB_LIN_LDS_DOUBLES >= 10 * 512, "IMU staging area");
     h->marg_lds_schur = (size_t)MG_MLDS * MG_MLDS * sizeof(double);
     h->marg_lds_finish = (size_t)(MG_NK + 2) * (MG_NK + 2) * sizeof(double);
