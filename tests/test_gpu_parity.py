@@ -269,6 +269,11 @@ def test_replicas_and_reruns_are_bit_identical(solver, opts):
     solver.batch_rewind(); solver.batch_solve()
     P2 = np.stack([np.concatenate([r.Ps.ravel(), r.Vs.ravel(), r.Bas.ravel(), r.Bgs.ravel()]) for r in solver.batch_download()])
     assert np.array_equal(P2, base), "rewind after a marginalization must restore the uploaded priors"
+    # the upload of 512 windows packs on the host threads and copies in quarters; eight windows are packed by the calling thread: same bytes on the device, same results
+    solver.batch_upload(wins[:8], priors[:8])
+    solver.batch_solve()
+    P3 = np.stack([np.concatenate([r.Ps.ravel(), r.Vs.ravel(), r.Bas.ravel(), r.Bgs.ravel()]) for r in solver.batch_download()])
+    assert np.array_equal(P3, base[:8]), "threaded / chunked upload and serial upload differ"
 
 
 def test_prior_factor_hook(solver, oracle, opts):
