@@ -243,3 +243,94 @@ def posegraph_optimize(poses_qt, prior_sigma, edges, max_iterations=30, tol=1e-1
     rc = L.vilo_posegraph_optimize(len(x), abi.dptr(x), abi.dptr(ps), len(edges), arr, max_iterations, tol, C.byref(it), abi.dptr(cost))
     assert rc == 0, rc
     return x, it.value, cost[0]
+
+
+class SeqFrameOut(C.Structure):
+    _fields_ = [("status", C.c_int), ("marginalization_flag", C.c_int), ("solver_flag", C.c_int), ("frame_count", C.c_int),
+                ("n_features_window", C.c_int), ("last_track_num", C.c_int), ("stamp", C.c_double), ("P", C.c_double * 3), ("q_xyzw", C.c_double * 4),
+                ("summary", abi.Summary)]
+
+
+class OracleSequence:
+    """the C++ restatement of the estimator's per-frame host loop (oracle/sequence.cpp): feature manager, processIMU / processImage, failureDetection
+    reboot, slideWindow around the oracle's window solve + marginalization. Independent of vil_fusion_amd/sequence.py."""
+
+    def __init__(self, opts, noise=None):
+        from vil_fusion_amd import synth
+        L = lib()
+        L.vilo_seq_create.restype = C.c_void_p
+        L.vilo_seq_create.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.ImuNoise)]
+        L.vilo_seq_destroy.argtypes = [C.c_void_p]
+        L.vilo_seq_process_imu.argtypes = [C.c_void_p, C.c_double, abi.c_double_p, abi.c_double_p]
+        L.vilo_seq_process_odometry.argtypes = [C.c_void_p, abi.c_double_p, abi.c_double_p]
+        L.vilo_seq_process_image.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int), abi.c_double_p, abi.c_double_p, C.POINTER(SeqFrameOut)]
+        ip = C.POINTER(C.c_int)
+        L.vilo_seq_features.argtypes = [C.c_void_p, C.c_int, ip, ip, ip, ip, ip, abi.c_double_p]
+        L.vilo_seq_state.argtypes = [C.c_void_p] + [abi.c_double_p] * 5
+        L.vilo_seq_prior.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]
+        self.L = L
+        self.noise = noise if noise is not None else abi.ImuNoise(synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)
+        self.h = L.vilo_seq_create(C.byref(opts), C.byref(self.noise))
+        assert self.h
+        self.solver_flag = 0
+        self.trajectory, self.flags, self.summaries, self.events = [], [], [], []
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.vilo_seq_destroy(self.h); self.h = None
+
+    def process_imu(self, dt, acc, gyr):
+        a = np.ascontiguousarray(acc, dtype=np.float64); w = np.ascontiguousarray(gyr, dtype=np.float64)
+        self.L.vilo_seq_process_imu(self.h, float(dt), abi.dptr(a), abi.dptr(w))
+
+    def process_odometry(self, q, t):
+        q = np.ascontiguousarray(q, dtype=np.float64); t = np.ascontiguousarray(t, dtype=np.float64)
+        self.L.vilo_seq_process_odometry(self.h, abi.dptr(q), abi.dptr(t))
+
+    def process_image(self, image, stamp, init_state=None):
+        ids = np.ascontiguousarray(list(image.keys()), dtype=np.int32)
+        p8 = np.ascontiguousarray(np.array(list(image.values()), dtype=np.float64).reshape(-1, 8))
+        st = None
+        if init_state is not None:
+            P, R, V, ba, bg = init_state
+            st = np.ascontiguousarray(np.concatenate([np.ravel(P), np.ravel(R), np.ravel(V), np.ravel(ba), np.ravel(bg)]), dtype=np.float64)
+        out = SeqFrameOut()
+        rc = self.L.vilo_seq_process_image(self.h, float(stamp), len(ids), ids.ctypes.data_as(C.POINTER(C.c_int)), abi.dptr(p8), abi.dptr(st) if st is not None else None, C.byref(out))
+        assert rc == 0, rc
+        self.solver_flag = out.solver_flag
+        self.events.append(("fill", "solved", "reboot")[out.status])
+        if out.status == 1:
+            self.trajectory.append((out.stamp, np.array(out.P[:]), np.array(out.q_xyzw[:])))
+            self.flags.append(out.marginalization_flag)
+            self.summaries.append({k: getattr(out.summary, k) for k, _ in abi.Summary._fields_})
+        return out
+
+    def features(self):
+        """[(feature_id, start_frame, n_obs, solve_flag, lidar_depth_flag, estimated_depth)] in list order"""
+        cap = 4096
+        i = [np.zeros(cap, dtype=np.int32) for _ in range(5)]
+        d = np.zeros(cap)
+        ip = C.POINTER(C.c_int)
+        n = self.L.vilo_seq_features(self.h, cap, *[a.ctypes.data_as(ip) for a in i], abi.dptr(d))
+        assert n <= cap
+        return [(int(i[0][k]), int(i[1][k]), int(i[2][k]), int(i[3][k]), int(i[4][k]), float(d[k])) for k in range(n)]
+
+    def state(self):
+        Ps, Rs, Vs, Bas, Bgs = np.zeros((11, 3)), np.zeros((11, 3, 3)), np.zeros((11, 3)), np.zeros((11, 3)), np.zeros((11, 3))
+        self.L.vilo_seq_state(self.h, *[abi.dptr(a) for a in (Ps, Rs, Vs, Bas, Bgs)])
+        return Ps, Rs, Vs, Bas, Bgs
+
+    def run(self, seq, n_frames=None, on_frame=None):
+        """the driver loop of vil_fusion_amd.sequence.run_sequence (startup=None) over this object"""
+        n = len(seq["images"]) if n_frames is None else n_frames
+        self.process_imu(0.0, *seq["imu0"])
+        for k in range(n):
+            if k >= 1:
+                dt, acc, gyr = seq["imu"][k]
+                for a, w in zip(acc, gyr):
+                    self.process_imu(dt, a, w)
+                self.process_odometry(*seq["lidar"][k])
+            out = self.process_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if self.solver_flag == 0 else None)
+            if on_frame is not None:
+                on_frame(k, self, out)
+        return self

@@ -17,6 +17,9 @@ class OracleBackend:
         p = oracle_lib.window_marginalize(self.o, win, res, self.prior)
         self.prior = p if p.valid else None
 
+    def reset(self):
+        self.prior = None
+
 
 class HipBackend:
     def __init__(self, solver):
@@ -33,3 +36,6 @@ class HipBackend:
 
     def marginalize(self, win, res):
         self.s.marginalize()
+
+    def reset(self):
+        self.s.set_prior(None)

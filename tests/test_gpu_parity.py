@@ -951,3 +951,42 @@ def test_state_download_equals_the_full_download(solver, opts):
         assert np.array_equal(st["Ps"][i], r.Ps) and np.array_equal(st["Rs"][i], r.Rs) and np.array_equal(st["Vs"][i], r.Vs)
         assert np.array_equal(st["Bas"][i], r.Bas) and np.array_equal(st["Bgs"][i], r.Bgs)
         assert st["summaries"][i].num_iterations == r.summary["num_iterations"] and st["summaries"][i].final_cost == r.summary["final_cost"]
+
+
+def test_double2vector_euler_singular_branch_and_gauge_override(solver, oracle, opts):
+    """double2vector's two rarely taken branches (estimator.cpp:549-596), HIP (k_finalize) vs oracle:
+    (i) frame-0 pitch within 1 degree of +-90: rot_diff = Rs[0] * R(para_Pose[0])^T instead of the yaw-only rotation (:567-574) — a window from a
+        drive that climbs at 89.6 / -89.5 degrees; asserted that the oracle's own R2ypr sees the singular pitch before AND after the solve, and that
+        the result differs from what the yaw-only branch would give (so the branch was really taken);
+    (ii) vilf_window_in.gauge_R0 / gauge_P0 (the failure_occur override, :554-559): the window is re-gauged to a frame-0 pose that is NOT the
+        pre-solve one."""
+    from vil_fusion_amd import sequence
+    for seed, pitch in ((11, np.deg2rad(89.6)), (12, np.deg2rad(-89.5))):
+        win, prior, _ = synth.make_window(seed, opts, synth.SynthConfig(n_features=120, pitch_offset=pitch))
+        solver.set_prior(prior)
+        got = solver.optimization(win)
+        ref = oracle.window_solve(opts, win, prior)
+        p_before = sequence.R2ypr(synth.q_to_R(win.para_pose[0, 3:]))[1]
+        p_after = sequence.R2ypr(synth.q_to_R(ref.para_pose[0, 3:]))[1]
+        assert abs(abs(p_before) - 90) < 1.0 and abs(abs(p_after) - 90) < 1.0, (p_before, p_after)
+        # the singular branch: Rs[0] comes back EXACTLY as the pre-solve rotation (rot_diff * R(para_Pose[0]) = Rs[0]); the yaw-only branch would not do that
+        R0 = synth.q_to_R(win.para_pose[0, 3:])
+        assert np.abs(ref.Rs[0] - R0).max() < 1e-12 and np.abs(got.Rs[0] - R0).max() < 1e-12
+        y_only = sequence.ypr2R(np.array([sequence.R2ypr(R0)[0] - sequence.R2ypr(synth.q_to_R(ref.para_pose[0, 3:]))[0], 0, 0])) @ synth.q_to_R(ref.para_pose[0, 3:])
+        assert np.abs(y_only - R0).max() > 1e-6, "the yaw-only gauge fix would have left a roll / pitch change at frame 0: the branches differ on this window"
+        assert got.summary["num_iterations"] == ref.summary["num_iterations"] and got.summary["num_successful_steps"] == ref.summary["num_successful_steps"]
+        assert np.abs(got.Ps - ref.Ps).max() < 1e-7 and np.abs(got.Rs - ref.Rs).max() < 1e-8 and np.abs(got.Vs - ref.Vs).max() < 1e-7
+    # (ii) gauge override
+    rng = np.random.default_rng(5)
+    win, prior, _ = synth.make_window(13, opts, synth.SynthConfig(n_features=120))
+    Rg = synth.q_to_R(synth.q_mul(win.para_pose[0, 3:], synth.q_exp(np.array([0.0, 0.0, 0.4]))))          # a frame-0 attitude 0.4 rad of yaw away
+    Pg = win.para_pose[0, :3] + rng.normal(0, 3.0, 3)
+    plain_ref = oracle.window_solve(opts, win, prior)
+    win.gauge_R0, win.gauge_P0 = np.ascontiguousarray(Rg), np.ascontiguousarray(Pg)
+    solver.set_prior(prior)
+    got = solver.optimization(win)
+    ref = oracle.window_solve(opts, win, prior)
+    assert np.abs(ref.Ps[0] - Pg).max() < 1e-12 and np.abs(got.Ps[0] - Pg).max() < 1e-12                   # origin_P0 = last_P0
+    assert abs(sequence.R2ypr(got.Rs[0])[0] - sequence.R2ypr(Rg)[0]) < 1e-9                                # frame-0 yaw = last_R0's yaw
+    assert np.abs(ref.Ps - plain_ref.Ps).max() > 1.0, "the override moved the window"
+    assert np.abs(got.Ps - ref.Ps).max() < 1e-7 and np.abs(got.Rs - ref.Rs).max() < 1e-8 and np.abs(got.Vs - ref.Vs).max() < 1e-7

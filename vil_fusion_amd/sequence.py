@@ -6,9 +6,12 @@ A Python mirror of the reference's per-frame host logic, so whole multi-frame se
     FeatureManager            ≙ vins_estimator/feature_manager.cpp (addFeatureCheckParallax :45-109, getFeatureCount :28-43,
                                 setDepth :150-168, removeFailures :170-180, getDepthVector :194-216, triangulate :218-276,
                                 removeBackShiftDepth :292-349, removeBack :351-366, removeFront :368-388, compensatedParallax2 :390-423)
-    SlidingWindowEstimator    ≙ vins_estimator/estimator.cpp: processOdometry :90-101, processIMU :103-137, processImage :139-234
-                                (steady-state NON_LINEAR branch; the SfM initialisation :237-459 is out of scope — the window is
-                                bootstrapped from given states), solveOdometry :492-503, vector2double :505-547, slideWindow :1052-1186
+    SlidingWindowEstimator    ≙ vins_estimator/estimator.cpp: clearState :36-88, processOdometry :90-101, processIMU :103-137, processImage :139-234
+                                (NON_LINEAR branch incl. the failureDetection reboot :212-220; the SfM initialisation :237-459 is out of scope —
+                                the window is bootstrapped from given states), solveOdometry :492-503, vector2double :505-547,
+                                failureDetection :640-686, slideWindow :1052-1186
+    run_sequences_lockstep    several independent estimators (sequence segments) stepped frame by frame as ONE batch on the device
+                                (vilf_batch_upload / _solve / _marginalize per frame; every segment's prior stays in its slot)
     write_tum                 ≙ utility/visualization.cpp:159-172 (t x y z qx qy qz qw, time relative to the first frame)
 
 The back-end is pluggable: `backend.solve(window) -> WindowResult` and `backend.marginalize(window, result)`; see HipBackend /
@@ -203,30 +206,63 @@ def g2R(g):
 
 
 class Integration:
-    """≙ IntegrationBase: the sample buffers + linearisation biases; the pre-integrated row is computed on demand."""
+    """≙ IntegrationBase: the sample buffers + linearisation biases; the pre-integrated row is computed on demand by the library's host
+    routine (vilf_imu_preintegrate ≙ push_back / propagate / midPointIntegration, integration_base.h:30-158) and cached until a sample
+    or the biases change."""
+    noise = abi.ImuNoise(synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W)
 
     def __init__(self, acc_0, gyr_0, ba, bg):
         self.acc = [np.array(acc_0, dtype=np.float64)]; self.gyr = [np.array(gyr_0, dtype=np.float64)]
         self.dt = []
-        self.ba, self.bg = np.array(ba, dtype=np.float64), np.array(bg, dtype=np.float64)
+        self._ba, self._bg = np.array(ba, dtype=np.float64), np.array(bg, dtype=np.float64)
+        self._row = None
+
+    ba = property(lambda self: self._ba)
+    bg = property(lambda self: self._bg)
+
+    @ba.setter
+    def ba(self, v):
+        self._ba, self._row = np.array(v, dtype=np.float64), None
+
+    @bg.setter
+    def bg(self, v):
+        self._bg, self._row = np.array(v, dtype=np.float64), None
 
     def push_back(self, dt, acc, gyr):
         self.dt.append(float(dt)); self.acc.append(np.array(acc, dtype=np.float64)); self.gyr.append(np.array(gyr, dtype=np.float64))
+        self._row = None
 
     def row(self):
-        if not self.dt:
-            r = np.zeros(abi.IMU_DOUBLES); r[synth.IMU_OFF["delta_q"][0] + 3] = 1.0
-            return r
-        dt = self.dt[0]
-        assert np.allclose(self.dt, dt)
-        return synth.preintegrate(np.array(self.acc)[None], np.array(self.gyr)[None], dt, self.ba[None], self.bg[None])[0]
+        if self._row is None:
+            if not self.dt:
+                r = np.zeros(abi.IMU_DOUBLES); r[synth.IMU_OFF["delta_q"][0] + 3] = 1.0
+            else:
+                from .estimator import imu_preintegrate
+                pre = imu_preintegrate(self.noise, self.acc[0], self.gyr[0], self._ba, self._bg, np.array(self.dt), np.array(self.acc[1:]), np.array(self.gyr[1:]))
+                r = np.frombuffer(pre, dtype=np.float64).copy()
+            self._row = r
+        return self._row
 
 
 class SlidingWindowEstimator:
     """Steady-state (NON_LINEAR) Estimator loop. `backend.solve(window) -> abi.WindowResult`, `backend.marginalize(window, result)`."""
 
+    INITIAL, NON_LINEAR = 0, 1
+
     def __init__(self, opts, backend):
         self.o, self.backend = opts, backend
+        self.trajectory = []            # (stamp, P[3], q[4] xyzw) of the newest frame after every solved frame
+        self.flags = []
+        self.summaries = []
+        self.events = []                # per process_image call: "fill" | "solved" | "reboot"
+        self.n_reboots = 0
+        self.initial_ok, self.alignment = None, None
+        self.last_R = self.last_P = self.last_R0 = self.last_P0 = None
+        self.clear_state()
+
+    # estimator.cpp:36-88 (+ setParameter :24-34)
+    def clear_state(self):
+        opts = self.o
         n = WINDOW_SIZE + 1
         self.Ps = np.zeros((n, 3)); self.Vs = np.zeros((n, 3)); self.Rs = np.tile(np.eye(3), (n, 1, 1))
         self.Bas = np.zeros((n, 3)); self.Bgs = np.zeros((n, 3))
@@ -241,10 +277,8 @@ class SlidingWindowEstimator:
         self.first_imu = False
         self.acc_0 = np.zeros(3); self.gyr_0 = np.zeros(3)
         self.marginalization_flag = MARGIN_OLD
-        self.trajectory = []            # (stamp, P[3], q[4] xyzw) of the newest frame after every solved frame
-        self.flags = []
-        self.summaries = []
-        self.initial_ok, self.alignment = None, None
+        self.solver_flag = self.INITIAL
+        self.failure_occur = 0
 
     # estimator.cpp:90-101
     def process_odometry(self, q, t):
@@ -265,8 +299,8 @@ class SlidingWindowEstimator:
             un_acc_0 = self.Rs[j] @ (self.acc_0 - self.Bas[j]) - self.g
             un_gyr = 0.5 * (self.gyr_0 + gyr) - self.Bgs[j]
             th = un_gyr * dt
-            dq = np.array([th[0] / 2, th[1] / 2, th[2] / 2, 1.0])                  # Utility::deltaQ
-            self.Rs[j] = self.Rs[j] @ synth.q_to_R(dq / np.linalg.norm(dq))
+            dq = np.array([th[0] / 2, th[1] / 2, th[2] / 2, 1.0])                  # Utility::deltaQ: (1, theta / 2), NOT normalised; Eigen's
+            self.Rs[j] = self.Rs[j] @ synth.q_to_R(dq)                             # toRotationMatrix() does not normalise either (:127)
             un_acc = 0.5 * (un_acc_0 + self.Rs[j] @ (acc - self.Bas[j]) - self.g)
             self.Ps[j] = self.Ps[j] + dt * self.Vs[j] + 0.5 * dt * dt * un_acc
             self.Vs[j] = self.Vs[j] + dt * un_acc
@@ -275,7 +309,17 @@ class SlidingWindowEstimator:
     # estimator.cpp:139-234. `init_state` = (P, R, V, ba, bg) of this frame while the window is being filled (replaces the SfM start-up)
     def process_image(self, image, stamp, init_state=None, sfm_frames=None):
         """`sfm_frames` (only looked at when the window has just filled): the output of initialStructure's SfM + PnP stage (estimator.cpp:237-371),
-        a time-ordered list of dict(stamp, R = c0_R_bk, T = c0_T_ck up to scale, pre = that frame's Integration) -> visualInitialAlign runs first."""
+        a time-ordered list of dict(stamp, R = c0_R_bk, T = c0_T_ck up to scale, pre = that frame's Integration) -> visualInitialAlign runs first.
+        Returns the WindowResult of a solved frame, None while the window fills, "reboot" when failureDetection() fired."""
+        win = self.begin_image(image, stamp, init_state, sfm_frames)
+        if win is None:
+            return None
+        res = self.backend.solve(win)
+        self.backend.marginalize(win, res)
+        return self.end_image(res)
+
+    def begin_image(self, image, stamp, init_state=None, sfm_frames=None):
+        """processImage up to the solve: returns the window description (vector2double + the factor walk) or None when this frame only fills the window"""
         j = self.frame_count
         keyframe = self.f.add_feature_check_parallax(j, dict(sorted(image.items())), self.td)
         self.marginalization_flag = MARGIN_OLD if keyframe else MARGIN_SECOND_NEW
@@ -284,23 +328,57 @@ class SlidingWindowEstimator:
             self.Ps[j], self.Rs[j], self.Vs[j], self.Bas[j], self.Bgs[j] = [np.array(x, dtype=np.float64) for x in init_state]
             if self.pre[j] is not None:       # ≙ repropagate() with the start-up biases (initial_aligment.cpp / estimator.cpp:437-440)
                 self.pre[j].ba, self.pre[j].bg = self.Bas[j].copy(), self.Bgs[j].copy()
-        if j < WINDOW_SIZE:
-            self.frame_count += 1
-            return None
-        if sfm_frames is not None:
-            self.initial_ok = self.visual_initial_align(sfm_frames)
-            if not self.initial_ok:             # the reference slides the window and retries on the next frame (:201-216)
-                self.slide_window()
+        if self.solver_flag == self.INITIAL:
+            if j < WINDOW_SIZE:
+                self.frame_count += 1
+                self.events.append("fill")
                 return None
+            if sfm_frames is not None:
+                self.initial_ok = self.visual_initial_align(sfm_frames)
+                if not self.initial_ok:             # the reference slides the window and retries on the next frame (:201-216)
+                    self.slide_window()
+                    self.events.append("fill")
+                    return None
+            self._initial_frame = True              # initialStructure() succeeded (:188-206): no failureDetection on this frame
+            self.solver_flag = self.NON_LINEAR
+        else:
+            self._initial_frame = False
         # solveOdometry (:492-503)
         self.f.triangulate(self.Ps, self.Rs, self.tic, self.ric)
-        res = self.optimization()
+        return self.make_window()
+
+    def end_image(self, res):
+        """processImage after optimization(): double2vector's state, failureDetection -> reboot, slideWindow, removeFailures, the trajectory row"""
+        self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs = res.Ps.copy(), res.Rs.copy(), res.Vs.copy(), res.Bas.copy(), res.Bgs.copy()
+        self.f.set_depth(res.para_feature)
+        self.failure_occur = 0                      # consumed by double2vector (:554-559)
+        if not self._initial_frame and self.failure_detection():
+            self.failure_occur = 1                  # :212-220; clearState() resets it at once (:80), so the gauge override of double2vector is never
+            self.clear_state()                      # reached through this loop — the ABI keeps it (vilf_window_in.gauge_R0 / gauge_P0)
+            self.n_reboots += 1
+            if hasattr(self.backend, "reset"):
+                self.backend.reset()
+            self.events.append("reboot")
+            return "reboot"
+        self.summaries.append(res.summary)
         self.slide_window()
         self.f.remove_failures()
+        self.last_R, self.last_P = self.Rs[WINDOW_SIZE].copy(), self.Ps[WINDOW_SIZE].copy()
+        self.last_R0, self.last_P0 = self.Rs[0].copy(), self.Ps[0].copy()
         q = synth.R_to_q(self.Rs[WINDOW_SIZE])
         self.trajectory.append((self.stamps[WINDOW_SIZE], self.Ps[WINDOW_SIZE].copy(), q))
         self.flags.append(self.marginalization_flag)
+        self.events.append("solved")
         return res
+
+    # estimator.cpp:640-686 (the two commented-out returns — too few tracked features, a big rotation — stay out)
+    def failure_detection(self):
+        W = WINDOW_SIZE
+        if np.linalg.norm(self.Bas[W]) > 2.5 or np.linalg.norm(self.Bgs[W]) > 1.0:
+            return True
+        if np.linalg.norm(self.Ps[W] - self.last_P) > 5:
+            return True
+        return bool(abs(self.Ps[W][2] - self.last_P[2]) > 1)
 
     # estimator.cpp:383-459
     def visual_initial_align(self, frames):
@@ -381,17 +459,6 @@ class SlidingWindowEstimator:
         return abi.Window(para_pose, para_sb, ex, depth, const, starts, np.array(offs, dtype=np.int32), np.array(pts).reshape(-1, 3), imu,
                           lidar=lid, para_td=self.td, marginalization_flag=self.marginalization_flag)
 
-    # estimator.cpp:689-1050
-    def optimization(self):
-        win = self.make_window()
-        res = self.backend.solve(win)
-        # double2vector (:549-638) happened inside the back-end: take the gauge-fixed state
-        self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs = res.Ps.copy(), res.Rs.copy(), res.Vs.copy(), res.Bas.copy(), res.Bgs.copy()
-        self.f.set_depth(res.para_feature)
-        self.backend.marginalize(win, res)
-        self.summaries.append(res.summary)
-        return res
-
     # estimator.cpp:1052-1186
     def slide_window(self):
         W = WINDOW_SIZE
@@ -430,10 +497,11 @@ def write_tum(path, trajectory):
 # ---------------------------------------------------------------------------------------------------------------------
 # synthetic multi-frame sequence (same motion / camera / IMU model as synth.make_window, feature tracks with ids)
 def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, pixel_sigma=0.5 / 460.0, state_noise=(0.05, np.deg2rad(0.5), 0.05),
-                  imu_noise_scale=1.0, bias_scale=1.0, yaw_amplitude=None):
+                  imu_noise_scale=1.0, bias_scale=1.0, yaw_amplitude=None, mean_speed=None, speed_modulation=0.0):
     """Returns a dict: stamps[n], imu[k] = (dt, acc[S,3], gyr[S,3]) for the interval ending at frame k (k >= 1, first-ever sample in
     imu0), images[k] = {feature_id: 8-vector}, lidar[k] = (q, t) relative LiDAR pose k-1 -> k, truth P/R/V, and `init[k]` = noisy
-    (P, R, V, ba, bg) for the first WINDOW_SIZE + 1 frames (stands in for the reference's SfM initialisation)."""
+    (P, R, V, ba, bg) for every frame (stands in for the reference's SfM initialisation: the first WINDOW_SIZE + 1 frames, and the
+    frames after a failureDetection reboot)."""
     rng = np.random.default_rng(seed)
     RIC = np.array(opts.RIC[:]).reshape(3, 3); TIC = np.array(opts.TIC[:])
     RCL = np.array(opts.RCL[:]).reshape(3, 3); TCL = np.array(opts.TCL[:])
@@ -442,6 +510,9 @@ def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, p
     nt = (n_frames - 1) * S + 1
     t = np.arange(nt) * dt
     speed = rng.uniform(8.0, 12.0)
+    if mean_speed is not None:                # slow / stop-and-go drives: frames without enough parallax -> MARGIN_SECOND_NEW
+        speed = float(mean_speed)
+    As, ws = float(speed_modulation), 0.9     # speed(t) = speed (1 + As sin(ws t))
     Ay, wy, py = rng.uniform(0.05, 0.3), rng.uniform(0.3, 1.0), rng.uniform(0, 2 * np.pi)
     if yaw_amplitude is not None:
         Ay, wy = yaw_amplitude, 2.0
@@ -455,8 +526,9 @@ def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, p
         rol = Ar * np.sin(wr * tt + pr); drol = Ar * wr * np.cos(wr * tt + pr)
         R = synth.euler_R(yaw, pit, rol)
         w_b = np.stack([drol - dyaw * np.sin(pit), dpit * np.cos(rol) + dyaw * np.sin(rol) * np.cos(pit), -dpit * np.sin(rol) + dyaw * np.cos(rol) * np.cos(pit)], -1)
-        v = speed * R[..., :, 0]
-        a = speed * np.einsum('...ij,...j->...i', R, np.cross(w_b, np.array([1.0, 0, 0])))
+        sp = speed * (1.0 + As * np.sin(ws * tt)); dsp = speed * As * ws * np.cos(ws * tt)
+        v = sp[..., None] * R[..., :, 0]
+        a = dsp[..., None] * R[..., :, 0] + sp[..., None] * np.einsum('...ij,...j->...i', R, np.cross(w_b, np.array([1.0, 0, 0])))
         return R, w_b, v, a
 
     fine = 10
@@ -511,7 +583,7 @@ def make_sequence(seed, n_frames, opts, max_cnt=150, lidar_depth_fraction=0.4, p
     sp, sr, sv = state_noise
     ba_est = ba_true + rng.normal(0, 0.005, 3); bg_est = bg_true + rng.normal(0, 0.0005, 3)
     init = []
-    for k in range(min(n_frames, WINDOW_SIZE + 1)):
+    for k in range(n_frames):
         Rn = Rw[k] @ synth.q_to_R(synth.q_exp(rng.normal(0, sr, 3)))
         init.append((Pw[k] + rng.normal(0, sp, 3), Rn, Vw[k] + rng.normal(0, sv, 3), ba_est, bg_est))
     imu = [None] + [(dt, acc_m[(k - 1) * S + 1: k * S + 1], gyr_m[(k - 1) * S + 1: k * S + 1]) for k in range(1, n_frames)]
@@ -536,27 +608,112 @@ def make_sfm_frames(seq, opts, est, seed=0, scale=3.7, rot_noise=np.deg2rad(0.02
     return frames
 
 
+def drop_frames(seq, k0, n):
+    """A sensor gap: camera / LiDAR frames k0 .. k0 + n - 1 never arrive. The IMU keeps running (the samples of the dropped intervals join the
+    interval that ends at the next frame, as estimator_node.cpp:102-160 hands them over) and the LiDAR odometry of the next frame is relative to
+    the last frame that did arrive. A gap of more than 5 m of travel trips failureDetection()'s translation gate (estimator.cpp:665-669)."""
+    out = dict(seq)
+    keep = [k for k in range(len(seq["images"])) if not (k0 <= k < k0 + n)]
+    for key in ("stamps", "P", "R", "V"):
+        out[key] = seq[key][keep]
+    for key in ("images", "init"):
+        out[key] = [seq[key][k] for k in keep]
+    imu, lidar = list(seq["imu"]), list(seq["lidar"])
+    dt = imu[k0][0]
+    imu[k0 + n] = (dt, np.concatenate([imu[k][1] for k in range(k0, k0 + n + 1)]), np.concatenate([imu[k][2] for k in range(k0, k0 + n + 1)]))
+    q, t = np.array([0, 0, 0, 1.0]), np.zeros(3)
+    for k in range(k0, k0 + n + 1):               # T_(k0-1 -> k0+n) = T_(k0-1 -> k0) o ... o T_(k0+n-1 -> k0+n)
+        qk, tk = lidar[k]
+        q, t = synth.q_mul(q, qk), synth.q_to_R(q) @ tk + t
+    lidar[k0 + n] = (q / np.linalg.norm(q), t)
+    out["imu"] = [imu[k] for k in keep]; out["lidar"] = [lidar[k] for k in keep]
+    return out
+
+
+def _feed_measurements(est, seq, k):
+    if k >= 1:
+        dt, acc, gyr = seq["imu"][k]
+        for a, w in zip(acc, gyr):
+            est.process_imu(dt, a, w)
+        est.process_odometry(*seq["lidar"][k])
+
+
 def run_sequence(seq, opts, backend, n_frames=None, startup=None):
     """Feed a make_sequence() dict through SlidingWindowEstimator; returns the estimator (trajectory, flags, summaries).
-    startup=None: the first WINDOW_SIZE + 1 frames take seq["init"] (a state already initialised). startup=dict(make_sfm_frames kwargs): the
-    window fills from a zero state and visualInitialAlign (SfM stand-in + VisualIMUAlignment on the back-end) initialises it."""
+    startup=None: while the estimator is INITIAL (the first WINDOW_SIZE + 1 frames, and again after a failureDetection reboot) the frames take
+    seq["init"] (a state already initialised). startup=dict(make_sfm_frames kwargs): the window fills from a zero state and visualInitialAlign
+    (SfM stand-in + VisualIMUAlignment on the back-end) initialises it."""
     est = SlidingWindowEstimator(opts, backend)
     n = len(seq["images"]) if n_frames is None else n_frames
     est.process_imu(0.0, *seq["imu0"])                 # first sample: only latches acc_0 / gyr_0 (frame_count == 0)
     for k in range(n):
-        if k >= 1:
-            dt, acc, gyr = seq["imu"][k]
-            for a, w in zip(acc, gyr):
-                est.process_imu(dt, a, w)
-            est.process_odometry(*seq["lidar"][k])
+        _feed_measurements(est, seq, k)
         if startup is None:
-            est.process_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if k < len(seq["init"]) else None)
+            est.process_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if est.solver_flag == est.INITIAL else None)
         elif k == WINDOW_SIZE:
             est.stamps[k] = seq["stamps"][k]
             est.process_image(seq["images"][k], seq["stamps"][k], None, sfm_frames=make_sfm_frames(seq, opts, est, **startup))
         else:
             est.process_image(seq["images"][k], seq["stamps"][k], None)
     return est
+
+
+class _SlotBackend:
+    """what SlidingWindowEstimator needs from a back-end when the solve itself is driven from outside (run_sequences_lockstep)"""
+
+    def __init__(self, solver, slot):
+        self.s, self.slot, self.drop_prior = solver, slot, True
+
+    def reset(self):                                    # ≙ clearState(): last_marginalization_info = nullptr (estimator.cpp:72-77)
+        self.drop_prior = True
+
+
+def run_sequences_lockstep(seqs, opts, solver, n_frames=None, on_frame=None):
+    """len(seqs) independent sequence segments, one SlidingWindowEstimator each, stepped frame by frame as ONE device batch: per frame one
+    vilf_batch_upload of the segments' windows (slot i = segment i, so every segment's prior stays in its slot on the device), one
+    vilf_batch_solve, one vilf_batch_marginalize, one download. A segment that has no window to solve in a frame (its window is still
+    filling, at the start or after a failureDetection reboot) contributes its previous window as a placeholder whose result is dropped; its
+    slot's prior is cleared before its next real solve. Returns the estimators; `solver.lockstep_stats` counts the marginalization paths."""
+    S = len(seqs)
+    ests = [SlidingWindowEstimator(opts, _SlotBackend(solver, i)) for i in range(S)]
+    n = min(len(q["images"]) for q in seqs) if n_frames is None else n_frames
+    for est, seq in zip(ests, seqs):
+        est.process_imu(0.0, *seq["imu0"])
+    placeholder = [None] * S
+    stats = dict(frames=0, new_prior=0, amm_cholesky=0, kept_cholesky=0, unchanged=0)
+    for k in range(n):
+        wins = [None] * S
+        for i, (est, seq) in enumerate(zip(ests, seqs)):
+            _feed_measurements(est, seq, k)
+            wins[i] = est.begin_image(seq["images"][k], seq["stamps"][k], seq["init"][k] if est.solver_flag == est.INITIAL else None)
+        live = [i for i in range(S) if wins[i] is not None]
+        if not live:
+            continue
+        for i in live:
+            placeholder[i] = wins[i]
+            if ests[i].backend.drop_prior:
+                solver.set_prior(None, i)
+                ests[i].backend.drop_prior = False
+        fill = placeholder[live[0]]
+        batch = [wins[i] if wins[i] is not None else (placeholder[i] if placeholder[i] is not None else fill) for i in range(S)]
+        solver.batch_upload(batch)
+        solver.batch_solve(sync=False)
+        solver.batch_marginalize(sync=True)
+        results = solver.batch_download()
+        if len(live) == S:
+            st = solver.marginalize_stats()
+            stats["frames"] += 1
+            for key in ("new_prior", "amm_cholesky", "kept_cholesky", "unchanged"):
+                stats[key] += st[key]
+        for i in range(S):
+            if wins[i] is None:
+                ests[i].backend.drop_prior = True       # the placeholder's marginalization wrote a prior into this slot
+                continue
+            r = ests[i].end_image(results[i])
+            if on_frame is not None:
+                on_frame(i, k, ests[i], r)
+    solver.lockstep_stats = stats
+    return ests
 
 
 def make_alignment_case(seed, opts, n_frames=14, scale=3.7, rot_noise=np.deg2rad(0.05), pos_noise=0.01, **seq_kw):

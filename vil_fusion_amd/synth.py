@@ -165,8 +165,9 @@ def preintegrate(acc, gyr, dt, lin_ba, lin_bg, noise=(ACC_N, GYR_N, ACC_W, GYR_W
 class SynthConfig:
     def __init__(self, n_frames=11, n_features=190, const_fraction=0.4, use_lidar=True, with_prior=True,
                  imu_rate=100.0, frame_rate=10.0, pixel_sigma=0.5 / 460.0, marginalization_flag=MARGIN_OLD,
-                 state_noise=(0.05, np.deg2rad(0.5), 0.05), early_end_fraction=0.15):
+                 state_noise=(0.05, np.deg2rad(0.5), 0.05), early_end_fraction=0.15, pitch_offset=0.0):
         self.n_frames = n_frames
+        self.pitch_offset = pitch_offset      # radians added to the pitch profile (a climb; near +-pi/2: the Euler-singular branch of double2vector, estimator.cpp:567-574)
         self.n_features = n_features
         self.const_fraction = const_fraction
         self.use_lidar = use_lidar
@@ -201,7 +202,7 @@ def make_window(seed, opts, cfg=None):
 
     def angles(tt):
         yaw = yaw0 + Ay * np.sin(wy * tt + py); dyaw = Ay * wy * np.cos(wy * tt + py)
-        pit = Ap * np.sin(wp * tt + pp); dpit = Ap * wp * np.cos(wp * tt + pp)
+        pit = cfg.pitch_offset + Ap * np.sin(wp * tt + pp); dpit = Ap * wp * np.cos(wp * tt + pp)
         rol = Ar * np.sin(wr * tt + pr); drol = Ar * wr * np.cos(wr * tt + pr)
         return yaw, pit, rol, dyaw, dpit, drol
 
