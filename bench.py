@@ -129,6 +129,42 @@ def _profile_order(path):
     return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
 
 
+def stress_leg(local_rank, n_windows=8, steps=3):
+    """BASELINE configs[4] inside the default run, so that the driver times it: ONE group of `n_windows` independent 51-frame / ~46 k-factor windows
+    (vilf_window_solve_group), `steps` solves after one warm-up; aggregate iterations/s + the general path's launch groups. Never `value`."""
+    import torch
+    from vil_fusion_amd import synth
+    from vil_fusion_amd.estimator import BackendSolver
+    from vil_fusion_amd.lib import default_options
+    o = default_options(); o.window_size = 50
+    distinct = [synth.make_window(900 + 7 * k, o, synth.SynthConfig(n_frames=51, n_features=2500, with_prior=False))[0] for k in range(min(n_windows, 2))]
+    wl = [distinct[k % len(distinct)] for k in range(n_windows)]
+    s = BackendSolver(o, device=local_rank)
+    s.optimization_group(wl)                       # warm-up: arena allocated
+    s.set_profiling(True)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); its = 0
+    for _ in range(steps):
+        its += sum(r.summary["num_iterations"] for r in s.optimization_group(wl))
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    prof = s.get_profile_large_window()
+    s.close()
+    w = distinct[0]
+    P, F = 15 * 51, w.n_features
+    kf = np_diff_nonconst(w)
+    alg_schur = 2.0 * float((36.0 * kf * kf).sum())          # SURVEY 8(d): 2 sum_f (6 k_f)^2
+    lin_solves = max(prof["lw_cholesky"]["launches"], 1)
+    return {"value": its / dt, "unit": "iterations/s", "windows": n_windows, "steps": steps, "ms_per_group_solve": 1e3 * dt / steps, "iterations": its,
+            "frames": 51, "features": int(F), "visual_factors": int(len(w.obs_point) - F), "reduced_system": P,
+            "kernels_ms_per_group_solve": {k: v["ms"] / steps for k, v in prof.items()},
+            "schur_algorithmic_flop_per_window_iteration": alg_schur, "cholesky_flop_per_window_iteration": P ** 3 / 3.0 + 2.0 * P * P,
+            "what": "configs[4]: vilf_window_solve_group of %d independent 51-frame windows (host buffers in / out, pack + upload inside), general path (vilf_lw.hip)" % n_windows}
+
+
+def np_diff_nonconst(w):
+    import numpy as np
+    return np.diff(w.feature_obs_offset)[np.asarray(w.feature_const) == 0].astype(np.float64)
+
+
 def stress_main(args):
     """BASELINE configs[4]: the 51-frame stress window through vilf_window_solve's general path; a step = one window solve per GPU (independent
     windows per rank, no collective). Reports solver iterations/s and the fp64 MFMA roofline of the Schur SYRK (2 F P^2 flop per linear solve)."""
@@ -276,6 +312,7 @@ def main():
     ap.add_argument("--td-windows", type=int, default=64, help="windows of the estimate_td batch line (general path as one group of launches vs the plain batch); 0 skips it")
     ap.add_argument("--stress-mode", default="group", choices=["group", "streams"], help="--stress: how the independent windows run side by side (one grouped chain of launches / one handle and stream each)")
     ap.add_argument("--stress-windows", default="1,8,32", help="--stress: numbers of independent stress windows solved side by side (one handle / stream / host thread each)")
+    ap.add_argument("--no-stress-leg", dest="stress_leg", action="store_false", help="skip the compact configs[4] leg (one group of 8 stress windows, 3 solves) of the default run")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[4] instead of the headline workload: one synthetic 51-frame / ~46 k-factor window per step and GPU")
     args = ap.parse_args()
     if args.stress:
@@ -658,6 +695,11 @@ def main():
         td_batch = {"windows": nb, "plain_batch_ms": tms[0], "estimate_td_batch_ms": tms[1], "ratio": tms[1] / tms[0], "iterations": [tms[(0, "it")], tms[(1, "it")]],
                     "what": "vilf_batch_solve of the same 64 windows (with priors): estimate_td = 0 (LDS kernels) vs estimate_td = 1 (general path, one group of launches; the slots ran one by one until round 3: ~80 ms)"}
 
+    # ---- configs[4] in brief (the full sweep: --stress)
+    stress = None
+    if world == 1 and args.stress_leg:
+        stress = stress_leg(local_rank)
+
     if rank == 0:
         abytes = float(np.mean([algorithmic_bytes_per_iteration(w, p) for w, p in zip(wins[:args.distinct], priors[:args.distinct])]))
         # algorithmic bytes per STEP (all B frames) per kernel / launch group; for the window kernels
@@ -728,6 +770,19 @@ def main():
                 mfma["k_solve"]["pmc"] = None
         except Exception:
             mfma = None
+        # launch groups whose bytes are not HBM traffic of the timed launches (pricing them gave "bandwidths" above the 8 TB/s peak): the radix-sort group only runs for
+        # oversized scans (none in this workload: the launches counted are set-up), k_prior_prep skips every window whose prior is unchanged, and the LM solve re-reads
+        # its factor records from L2 (PMC: 3.96 GB per launch at the HBM interface against 5 x the record bytes priced)
+        not_priced = {"s2m_radix_sort": "not on the steady-state path (oversized scans only)", "k_prior_prep": "skips windows whose prior is unchanged: no fixed byte count per launch",
+                      "s2m_lm_solve": "factor records are re-read from L2 across the 5 evaluations: algorithmic bytes are not HBM bytes here"}
+        window_kernels = None
+        try:                                   # registers / spills / LDS of the two window kernels, from the code objects of the shipped library (tools/kernel_resources.py at build time)
+            kr = json.load(open(os.path.join(ROOT, "vil_fusion_amd", "csrc", "kernel_resources.json")))
+            dyn = {"k_linearize": 46.6e3, "k_solve_sb": 78.0e3}
+            window_kernels = {k: {"vgpr": kr[k]["vgpr"], "vgpr_spills": kr[k]["vgpr_spills"], "scratch_bytes_per_lane": kr[k]["scratch_bytes_per_lane"],
+                                  "static_lds_bytes": kr[k]["static_lds_bytes"], "waves_per_simd_by_registers": kr[k]["waves_per_simd_by_registers"]} for k in ("k_linearize", "k_solve_sb", "k_solve")}
+        except Exception:
+            window_kernels = None
         it_ms = sum(prof[k]["ms"] for k in ("k_linearize", "k_solve", "k_step")) / max(prof["k_solve"]["launches"], 1)
         whole_it = abytes * B / (it_ms * 1e-3) / 1e9
         out = {
@@ -750,7 +805,12 @@ def main():
                          "whole_iteration": {"ms": it_ms, "achieved": whole_it, "frac": whole_it / 8000.0, "what": "388 KB x windows over the launches of one iteration (k_solve_sb + k_linearize; k_step = the step-only launch that ends a solve, spread over the iterations)"},
                          "kernels_ms": {k: v["ms"] / max(v["launches"], 1) for k, v in prof.items()},
                          "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
-                         "kernels_achieved_GBps": {k: alg[k] / (prof[k]["ms"] / args.steps) / 1e6 for k in alg if prof[k]["launches"] > 0 and prof[k]["ms"] > 0}},
+                         "kernels_achieved_GBps": {k: alg[k] / (prof[k]["ms"] / args.steps) / 1e6 for k in alg
+                                                   if prof[k]["launches"] > 0 and prof[k]["ms"] > 0 and k not in not_priced},
+                         "kernels_not_priced": not_priced,
+                         "binding": "fp64 issue + dependent latency, not HBM: one iteration is ~9 MFLOP per 388 KB (23 flop/B against a machine balance of 9.8), every dependent fp64 "
+                                    "operation costs 36 cycles and the kernels run two waves per SIMD (DESIGN.md 3c); `bound: hbm` is SURVEY 8(d)'s convention for this row",
+                         "window_kernels": window_kernels},
         }
         if mfma is not None:
             out["roofline_mfma"] = mfma
@@ -766,6 +826,8 @@ def main():
             out["estimate_td_batch"] = td_batch
         if latency is not None:
             out["single_frame_latency"] = latency
+        if stress is not None:
+            out["stress"] = stress
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))

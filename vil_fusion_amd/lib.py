@@ -29,6 +29,10 @@ class VilfError(RuntimeError):
 def build(verbose=False):
     """hipcc --offload-arch=gfx950 build of the HIP library (cross-compiles without a GPU)."""
     subprocess.check_call(["make", "-C", CSRC, "-j4"] + ([] if verbose else ["-s"]))
+    res = os.path.join(CSRC, "kernel_resources.json")          # registers / spills / LDS per kernel from the code objects (bench.py quotes the window kernels)
+    tool = os.path.join(os.path.dirname(_HERE), "tools", "kernel_resources.py")
+    if os.path.exists(tool) and (not os.path.exists(res) or os.path.getmtime(res) < os.path.getmtime(SO_PATH)):
+        subprocess.run(["python3", tool, "__none__"], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return SO_PATH
 
 
