@@ -3,11 +3,16 @@
 // The 11-frame kernels keep a window's whole reduced system in one workgroup's LDS; a 765 x 765 system does not fit, so this path
 // spreads ONE window over the device instead:
 //   lw_visual / lw_imu / lw_lidar   one lane per factor: residual + Jacobians (the same device functions as the 11-frame kernels), Cauchy
-//                                   corrector, J^T J / J^T r scattered with hardware fp64 atomics into the dense reduced blocks
-//                                   Hpp (P x P), W (F x P, one row per feature), h_f, g_f, g_p
-//   lw_scale, lw_schur_prep         Jacobi scaling; LM-regularised reduced system and the row-scaled W for the Schur product
-//   lw_syrk_mfma                    S = Hpp' + mu D^2 - Wn^T Wn: the Schur reduce as a hand-written fp64 MFMA SYRK (2 F P^2 = 2.9 GFLOP per solve)
-//   lw_rowdot / lw_colsum           matrix-vector products (W v per feature row, W^T v per column)
+//                                   corrector, J^T J / J^T r scattered with hardware fp64 atomics into the reduced blocks
+//                                   Hpp (P x P), W (one row per feature over the POSE columns only: a visual factor touches two poses, the extrinsic, td and
+//                                   one inverse depth — never a SpeedBias block, estimator.cpp:750-794 — so W is F x PC with PC = 6 NF [+ 6 + 1], not F x P), h_f, g_f, g_p
+//   lw_scale                        Jacobi scaling
+//   lw_syrk_mfma                    the Schur reduce Wn^T Wn (Wn = W / sqrt(h_f + mu d_f^2), formed on the way into LDS) as a hand-written fp64 MFMA SYRK over the
+//                                   compact columns, features in start-frame order and K-chunks skipped by a tile whose columns the chunk's frame span does not reach
+//                                   (a feature seen in k frames fills a 6k x 6k block, SURVEY 8(d): 2 sum (6 k_f)^2 flop, not 2 F P^2); K-split partials in their own
+//                                   buffers; the right-hand side's W^T g_f / den rides along in the diagonal tiles
+//   lw_schur_prep                   S = Hpp' + mu D^2 - sum of the partials (fixed order: no atomics), rhs row
+//   lw_rowdot                       matrix-vector products (Hpp v, W v per feature row)
 //   lw_chol_panel / lw_chol_step    own blocked Cholesky of the reduced system, one launch per 64-column block: the panel workgroups (diagonal block + the slab
 //                                   below as 16 x 4 fp64 MFMA tiles in registers) beside workgroups that apply the previous column's trailing update;
 //   lw_chol_back                    back substitution with the triangle staged through LDS. No rocSOLVER / rocBLAS on this path.
@@ -54,16 +59,32 @@ enum { LW_SK_NONE = -1, LW_SK_SOLVE = 0, LW_SK_QUAD = 1, LW_SK_EVAL = 2, LW_SK_J
 // State x (and cand): pose[NF][7] | sb[NF][9] | feat[F] | ex[7] | td. Tangent / N-vectors: [15 per frame: pose 6, speed-bias 9 | ex 6 | td | F].
 struct LwWin {
     int NF, F, P, N, nvis, nimu, cEx, cTd, xo, est_ex, est_td, use_lidar, pn, pnb, max_it, pad_;
+    int PC, WS, nchunk, pad2_;                     // W: F rows of WS doubles, PC = 6 NF (+ 6 Ex)(+ 1 td) of them used: compact column c <-> column lw_fullcol(c) of the reduced system
+    const int *fvis, *fidx;                        // CSR over the features: the factors of feature f are vis[fidx[fvis[f] .. fvis[f + 1])] (vis itself is pair-sorted)
+    const int *kspan;                              // the device's feature order is by start frame (the host permutes on the way in and out); per K-chunk of SY_KB
+                                                   // features: first and last compact column any of them touches
+    double *rsd;                                   // 1 / sqrt(den_f) of the current linear solve
+    double *SC;                                    // [SY_KS][tiles][64 x 64] K-split partials of Wn^T Wn, + [SY_KS][SY_NT x 64] of Wn^T (g_f / sqrt(den))
     double sqrt_info, cauchy_b, tr_over_row;
     LwCtl *ctl;
     double *x, *cand;
     const LwVis *vis; const LwTd *tdr; const double *imu, *lid; const unsigned char *fconst;
-    double *Hpp, *W, *hf, *gp, *gf, *S, *Wn, *rhs, *tmpP, *tmpF, *vec, *yf, *scal, *den;     // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
+    double *Hpp, *W, *hf, *gp, *gf, *S, *rhs, *tmpP, *tmpF, *vec, *yf, *scal, *den;     // scal[0] = cost, [1..4] q_il, [5..7] t_il, [8..10] G
     int *info;
     double *g, *diagH, *scale, *diagonal, *gradient, *gn, *step;                                    // N each: the minimizer's vectors
     const double *pJ, *pr0, *pH0, *px0; const int *phdr, *pcol; double *pdx;                       // marginalization prior of an 11-frame window (pn = 0: none)
 };
 __device__ __forceinline__ bool lw_skip(const LwWin &w, int sk) { return sk >= 0 && (&w.ctl->skip_solve)[sk] != 0; }
+// compact column of W (pose columns frame-major, then Ex_Pose, then td) -> column of the reduced system, and back (-1: a SpeedBias column)
+__device__ __forceinline__ int lw_fullcol(const LwWin &w, int c) { const int np = 6 * w.NF; return c < np ? 15 * (c / 6) + c % 6 : (w.est_ex && c < np + 6 ? w.cEx + (c - np) : w.cTd); }
+__device__ __forceinline__ int lw_compcol(const LwWin &w, int i) {
+    const int np = 15 * w.NF;
+    if (i < np) { const int r = i % 15; return r < 6 ? 6 * (i / 15) + r : -1; }
+    if (w.est_ex && i >= w.cEx && i < w.cEx + 6) return 6 * w.NF + (i - w.cEx);
+    return (w.est_td && i == w.cTd) ? 6 * w.NF + (w.est_ex ? 6 : 0) : -1;
+}
+#define SY_KB 32
+#define SY_KS 4                                    // K splits of the Schur reduce (partials in their own buffers, summed in fixed order by lw_schur_prep)
 
 struct LwCtx {
     DBuf arena, desc;                  // the group's device memory; its LwWin array
@@ -105,7 +126,7 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, i
     if ((int)blockIdx.x * LW_CH >= n) return;         // the grid is sized for the group's largest window
     const double *x = which ? w.cand : w.x, *ex = x + w.xo;
     const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b;
-    double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gp = w.gp, *gf = w.gf, *cost = w.scal;
+    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
     const LwVis *vis = w.vis;
     __shared__ double s_J[LW_CH][26];                 // 24 Jacobian entries (row 0: 12, row 1: 12), r0, r1
     __shared__ int s_pair[LW_CH + 1];
@@ -127,21 +148,13 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, i
         cauchy(r[0] * r[0] + r[1] * r[1], cauchy_b, rho0, sw);
         c = 0.5 * rho0;
         if (jac) {
-            const int ci = 15 * v.i, cj = 15 * v.j;
             double J0[12], J1[12];
 #pragma unroll
             for (int k = 0; k < 6; k++) { J0[k] = sw * Ji[k]; J1[k] = sw * Ji[6 + k]; J0[6 + k] = sw * Jj[k]; J1[6 + k] = sw * Jj[6 + k]; }
             const double r0 = sw * r[0], r1 = sw * r[1];
 #pragma unroll
             for (int k = 0; k < 12; k++) { s_J[tid][k] = J0[k]; s_J[tid][12 + k] = J1[k]; }
-            s_J[tid][24] = r0; s_J[tid][25] = r1;
-            if (!v.cst) {
-                const double f0 = sw * Jf[0], f1 = sw * Jf[1];
-                add(hf + v.f, f0 * f0 + f1 * f1);
-                add(gf + v.f, f0 * r0 + f1 * r1);
-#pragma unroll
-                for (int a = 0; a < 12; a++) add(W + (size_t)v.f * P + (a < 6 ? ci + a : cj + a - 6), J0[a] * f0 + J1[a] * f1);
-            }
+            s_J[tid][24] = r0; s_J[tid][25] = r1;           // the feature's row of W, h_f, g_f: lw_feature_rows (feature-major, no atomics)
         }
     }
     if (jac) {
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int whic
     if ((int)blockIdx.x * LW_CH >= n) return;
     const double *x = which ? w.cand : w.x;
     const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b, tr_over_row = w.tr_over_row;
-    double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gp = w.gp, *gf = w.gf, *cost = w.scal;
+    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
     const LwVis *vis = w.vis; const LwTd *tdr = w.tdr;
     __shared__ double s_J[LW_CH][41];                 // row 0: 19, row 1: 19, r0, r1 (+ 1 pad)
     __shared__ int s_pair[LW_CH + 1];
@@ -212,7 +225,6 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int whic
         cauchy(r[0] * r[0] + r[1] * r[1], cauchy_b, rho0, sw);
         c = 0.5 * rho0;
         if (jac) {
-            const int ci = 15 * v.i, cj = 15 * v.j;
             double J0[19], J1[19];
 #pragma unroll
             for (int k = 0; k < 6; k++) {
@@ -223,14 +235,7 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int whic
             const double r0 = sw * r[0], r1 = sw * r[1];
 #pragma unroll
             for (int k = 0; k < 19; k++) { s_J[tid][k] = J0[k]; s_J[tid][19 + k] = J1[k]; }
-            s_J[tid][38] = r0; s_J[tid][39] = r1;
-            if (!v.cst) {
-                const double f0 = sw * Jf[0], f1 = sw * Jf[1];
-                add(hf + v.f, f0 * f0 + f1 * f1);
-                add(gf + v.f, f0 * r0 + f1 * r1);
-#pragma unroll
-                for (int a = 0; a < 19; a++) { const int col = lw_col(a, ci, cj, cEx, cTd); if (col >= 0) add(W + (size_t)v.f * P + col, J0[a] * f0 + J1[a] * f1); }
-            }
+            s_J[tid][38] = r0; s_J[tid][39] = r1;           // the feature's row of W, h_f, g_f: lw_feature_rows
         }
     }
     if (jac) {
@@ -263,6 +268,89 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int whic
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((tid & 63) == 0 && c != 0.0) add(cost, c);
+}
+// The per-feature terms of a linearisation — the feature's row of W (pose-feature blocks of J^T J over the compact columns), h_f, g_f — FEATURE-major and without
+// atomics: one wave per feature, a lane per factor of it (fidx lists them; blocks of 64 for longer tracks). A factor's pose_j block lands in columns of its own
+// (frame j observes the feature once), the pose_i block (every factor shares the start frame), the Ex_Pose / td blocks, h_f and g_f are wave sums in a fixed tree.
+// The row is composed in LDS (zeros elsewhere) and written out whole: nothing to clear beforehand, one coalesced row store, bit-reproducible. Until round 4 these
+// were 14 hardware atomics per factor from the pair-major kernel, 64 different rows per wave instruction: 0.6 of the 2.5 ms of an iteration of 32 stress windows.
+template <bool EXT>
+__global__ __launch_bounds__(256) void lw_feature_rows(const LwWin *ws, int which, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;
+    extern __shared__ double s_rows[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.x * 4 + wave, NF = w.NF, WS = w.WS, PC = w.PC;
+    if (f >= w.F) return;                             // whole waves leave: no workgroup barrier below
+    double *row = s_rows + (size_t)wave * WS;
+    for (int c = lane; c < WS; c += 64) row[c] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double hacc = 0, gacc = 0;
+    if (!w.fconst[f]) {
+        const double *x = which ? w.cand : w.x, *ex = x + w.xo;
+        const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b;
+        const int n0 = w.fvis[f], n1 = w.fvis[f + 1];
+        const double inv_dep = x[16 * NF + f];
+        double ric[9];
+        q_toR(q_load(ex + 3), ric);
+        double iacc[6] = {0, 0, 0, 0, 0, 0}, eacc[7] = {0, 0, 0, 0, 0, 0, 0};
+        int fi = 0;
+        for (int base = n0; base < n1; base += 64) {
+            const int t = base + lane;
+            const bool act = t < n1;
+            double wi_[6] = {0, 0, 0, 0, 0, 0}, we_[7] = {0, 0, 0, 0, 0, 0, 0}, hh = 0, gg = 0;
+            if (act) {
+                const int k = w.fidx[t];
+                const LwVis v = w.vis[k];
+                fi = v.i;
+                const double *pi = x + 7 * v.i, *pj = x + 7 * v.j;
+                double Ri[9], Rj[9];
+                q_toR(q_load(pi + 3), Ri); q_toR(q_load(pj + 3), Rj);
+                double r[2], Ji[12], Jj[12], Jf[2], Jex[12], Jtd[2] = {0.0, 0.0};
+                if (EXT) {
+                    if (w.cTd >= 0) { const LwTd q = w.tdr[k]; projection_td_eval<true>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, q.vi, q.vj, ex[7], q.tdi, q.tdj, q.rowi_c, q.rowj_c, w.tr_over_row, inv_dep, sqrt_info, r, Ji, Jj, Jf, Jex, Jtd); }
+                    else projection_eval<true>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, inv_dep, sqrt_info, r, Ji, Jj, Jf, Jex);
+                } else projection_eval<true>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, inv_dep, sqrt_info, r, Ji, Jj, Jf);
+                double rho0, sw;
+                cauchy(r[0] * r[0] + r[1] * r[1], cauchy_b, rho0, sw);
+                const double f0 = sw * sw * Jf[0], f1 = sw * sw * Jf[1];          // (sw J)^T (sw Jf): both factors of the product carry the corrector's sqrt(rho')
+                hh = f0 * Jf[0] + f1 * Jf[1];
+                gg = f0 * r[0] + f1 * r[1];
+#pragma unroll
+                for (int a = 0; a < 6; a++) { wi_[a] = Ji[a] * f0 + Ji[6 + a] * f1; row[6 * v.j + a] = Jj[a] * f0 + Jj[6 + a] * f1; }
+                if (EXT) {
+                    if (w.cEx >= 0) {
+#pragma unroll
+                        for (int a = 0; a < 6; a++) we_[a] = Jex[a] * f0 + Jex[6 + a] * f1;
+                    }
+                    if (w.cTd >= 0) we_[6] = Jtd[0] * f0 + Jtd[1] * f1;
+                }
+            }
+            hacc += vilf_wave_sum64(hh); gacc += vilf_wave_sum64(gg);
+#pragma unroll
+            for (int a = 0; a < 6; a++) iacc[a] += vilf_wave_sum64(wi_[a]);
+            if (EXT) {
+#pragma unroll
+                for (int a = 0; a < 7; a++) eacc[a] += vilf_wave_sum64(we_[a]);
+            }
+        }
+        fi = __builtin_amdgcn_readfirstlane(fi);      // the start frame: every factor of the feature has it (lane 0 of the last block is active)
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0 && n1 > n0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) row[6 * fi + a] = iacc[a];
+            if (EXT) {
+                if (w.cEx >= 0) {
+#pragma unroll
+                    for (int a = 0; a < 6; a++) row[6 * NF + a] = eacc[a];
+                }
+                if (w.cTd >= 0) row[PC - 1] = eacc[6];
+            }
+        }
+    }
+    if (lane == 0) { w.hf[f] = hacc; w.gf[f] = gacc; }
+    __builtin_amdgcn_wave_barrier();
+    double *dst = w.W + (size_t)f * WS;
+    for (int c = lane; c < WS; c += 64) dst[c] = row[c];
 }
 // MarginalizationFactor (marginalization_factor.cpp:333-381) of an 11-frame window: r = r0 + J0 dx with dx from lw_tr_* / the host (n <= 96 entries),
 // J0^T J0 from k_prior_prep; pcol maps a prior column to its column of the reduced system (-1: block constant in this solve)
@@ -341,22 +429,20 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, 
         add(cost, c);
     }
 }
-// zero the accumulation targets of one linearisation (Hpp, W, h_f, g_p, g_f) and the cost: four entries per thread
+// zero the accumulation targets of one linearisation that are summed into with atomics (Hpp, g_p) and the cost: four entries per thread. W, h_f and g_f are
+// written whole by lw_feature_rows.
 __global__ __launch_bounds__(256) void lw_clear(const LwWin *ws, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const size_t n0 = (size_t)w.P * w.P, n1 = (size_t)w.F * w.P, n2 = w.F, n3 = w.P, n4 = w.F;
-    double *a0 = w.Hpp, *a1 = w.W, *a2 = w.hf, *a3 = w.gp, *a4 = w.gf, *cost = w.scal;
+    const size_t n0 = (size_t)w.P * w.P, n3 = w.P;
+    double *a0 = w.Hpp, *a3 = w.gp, *cost = w.scal;
     const size_t t0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (t0 > n0 + n1 + n2 + n3 + n4) return;
+    if (t0 > n0 + n3) return;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         size_t t = t0 + u;
         if (t < n0) { a0[t] = 0.0; continue; } t -= n0;
-        if (t < n1) { a1[t] = 0.0; continue; } t -= n1;
-        if (t < n2) { a2[t] = 0.0; continue; } t -= n2;
         if (t < n3) { a3[t] = 0.0; continue; } t -= n3;
-        if (t < n4) { a4[t] = 0.0; continue; } t -= n4;
         if (t == 0) cost[0] = 0.0;
     }
 }
@@ -368,103 +454,167 @@ __global__ void lw_scale(const LwWin *ws, int src, int sk) {
     const int P = w.P, F = w.F;
     const double *s = src ? w.vec : w.scale;
     double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gp = w.gp, *gf = w.gf;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
+    const int WS = w.WS, PC = w.PC;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * WS;
     if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); Hpp[t] *= s[i] * s[j]; }
-    else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P), c = (int)(u % P); W[u] *= s[P + f] * s[c]; }
+    else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / WS), c = (int)(u % WS); if (c < PC) W[u] *= s[P + f] * s[lw_fullcol(w, c)]; }
     else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); hf[f] *= s[P + f] * s[P + f]; gf[f] *= s[P + f]; }
     else if (t < nH + nW + F + P) { const int i = (int)(t - nH - nW - F); gp[i] *= s[i]; }
 }
-// S = Hpp + diag(lm_p^2); den_f = h_f + lm_f^2 (1 for constant features: their rows of W are zero); Wn = W / sqrt(den); tmpF = g_f / sqrt(den);
-// row P of S = g_p (the right-hand side rides through the factorisation as one more row); the factorisation's status word = 0. lm = vec.
-__global__ void lw_schur_prep(const LwWin *ws, int sk) {
-    const LwWin &w = ws[blockIdx.z];
-    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int P = w.P, F = w.F;
-    const double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gf = w.gf, *lm = w.vec; const unsigned char *fconst = w.fconst;
-    double *S = w.S, *Wn = w.Wn, *den = w.den, *tmpF = w.tmpF;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * P;
-    if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); S[t] = Hpp[t] + (i == j ? lm[i] * lm[i] : 0.0); }
-    else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / P); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; Wn[u] = W[u] / sqrt(d); }
-    else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); const double d = fconst[f] ? 1.0 : hf[f] + lm[P + f] * lm[P + f]; den[f] = d; tmpF[f] = gf[f] / sqrt(d); }
-    else if (t < nH + nW + F + P) { const int i = (int)(t - nH - nW - F); S[nH + i] = w.gp[i]; }
-    else if (t == nH + nW + F + P) *w.info = 0;
-}
-
-// ---- the Schur reduce S -= Wn^T Wn as a hand-written fp64 MFMA SYRK ------------------------------------------------------------------
-// Wn is F x P row-major (one row per feature, already scaled by 1 / sqrt(h_f')). One workgroup per 64 x 64 output tile of the lower
-// triangle and per K split; four waves, each a 32 x 32 sub-tile = 2 x 2 v_mfma_f64_16x16x4_f64 accumulators; the two K x 64 panels of
-// Wn stream through LDS 16 feature rows at a time (coalesced 512-byte rows, padded row stride against bank conflicts). The K splits
-// (so that 78 tiles fill 256 CUs) and the mirrored tile are combined with hardware fp64 atomics on S, which already holds Hpp' + mu D^2.
-#define SY_KB 32
+// ---- the Schur reduce Wn^T Wn as a hand-written fp64 MFMA SYRK over the compact (pose-only) columns ----------------------------------------
+// W is F x WS row-major, one row per feature, PC columns used; Wn = W / sqrt(den_f) with den_f = h_f + lm_f^2 (1 for a constant feature: its row is zero) is formed
+// on the way into LDS and never stored. One workgroup per 64 x 64 tile of the lower triangle (in compact columns) and per K split; four waves, each a 32 x 32
+// sub-tile = 2 x 2 v_mfma_f64_16x16x4_f64 accumulators; the two K x 64 panels stream through LDS SY_KB feature rows at a time, the next chunk's loads in flight.
+// Structure: K runs over the features in START-FRAME order (forder), and a chunk of SY_KB of them touches the compact columns kspan[2 q] .. kspan[2 q + 1] only
+// (6 columns per frame of its features' spans) — a tile whose row or column range that interval misses skips the chunk. For the stress window (features seen in ~21
+// of 51 frames) a chunk meets ~7 of the 15 tiles; the dense F x 765 product of rounds 1-3 issued 37 x the flops of SURVEY 8(d)'s 2 sum (6 k_f)^2.
+// Output: every workgroup stores ITS partial tile (zeros when it met no chunk) to SC[split][tile]; diagonal-tile workgroups also accumulate the right-hand side's
+// Wn^T (g_f / sqrt(den_f)) for their 64 columns (the panel is in LDS anyway) into SC's tail. lw_schur_prep sums the SY_KS partials in fixed order: no atomics,
+// bit-reproducible.
 #define SY_LD 65
+#define SY_NT(PC) (((PC) + 63) / 64)
 typedef double lw_double4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int ksplit, int sk) {
+// den_f = h_f + lm_f^2 (1 for a constant feature: its row of W is zero), rsd_f = 1 / sqrt(den_f), tmpF_f = g_f / sqrt(den_f): once per linear solve
+__global__ __launch_bounds__(256) void lw_den(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= w.F) return;
+    const double lmf = w.vec[w.P + f], d = w.fconst[f] ? 1.0 : w.hf[f] + lmf * lmf, rs = 1.0 / sqrt(d);
+    w.den[f] = d; w.rsd[f] = rs; w.tmpF[f] = w.gf[f] * rs;
+}
+#define SY_LIST 1024
+__global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int P = w.P, F = w.F;
-    const double *Wn = w.Wn; double *S = w.S;
-    __shared__ double sA[SY_KB * SY_LD], sB[SY_KB * SY_LD];
+    const int PC = w.PC, WS = w.WS, F = w.F, nchunk = w.nchunk;
+    const double *W = w.W, *rsd = w.rsd, *gn = w.tmpF; const int *kspan = w.kspan;
+    __shared__ double sA[SY_KB * SY_LD], sB[SY_KB * SY_LD], sG[SY_KB];
+    __shared__ int s_list[SY_LIST], s_cnt[5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
-    if (64 * ti >= P || F == 0) return;               // the grid is sized for the group's largest window
-    const int tj = blockIdx.x - ti * (ti + 1) / 2, i0 = 64 * ti, j0 = 64 * tj;
-    const int kchunk = ((F + ksplit - 1) / ksplit + SY_KB - 1) / SY_KB * SY_KB, kb = blockIdx.y * kchunk, ke = min(F, kb + kchunk);
+    const int nt = SY_NT(PC);
+    if (ti >= nt || F == 0) return;                   // the grid is sized for the group's largest window
+    const int tj = blockIdx.x - ti * (ti + 1) / 2, i0 = 64 * ti, j0 = 64 * tj, ks = blockIdx.y;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const bool diag = ti == tj;
     lw_double4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++) acc[a][b] = lw_double4{0, 0, 0, 0};
-    // The next K-step's panel entries are requested before this step's MFMAs (the loop used to wait a memory round trip per 16 rows of Wn: 130 us for a product
-    // the MFMA pipe does in 20), with straight-line loads: an entry outside the matrix reads a valid address and is zeroed on the way to LDS.
-    double ra[SY_KB / 4], rb[SY_KB / 4];
-    auto gload = [&](int k0) {
+    double racc = 0;                                  // diagonal tiles, tid < 64: sum_f Wn(f, j0 + tid) g_f / sqrt(den_f)
+    double ra[SY_KB / 4], rb[SY_KB / 4], rg = 0;
+    auto gload = [&](int q) {                         // straight-line loads: an entry outside the matrix reads a valid address and is zeroed on the way to LDS
+        const int k0 = q * SY_KB;
 #pragma unroll
         for (int u = 0; u < SY_KB / 4; u++) {
             const int e = tid + 256 * u, kk = e >> 6, cc = e & 63, k = k0 + kk;
-            const bool kin = k < ke;
-            const size_t rowoff = (size_t)(kin ? k : kb) * P;
-            const double va = Wn[rowoff + min(i0 + cc, P - 1)], vb = Wn[rowoff + min(j0 + cc, P - 1)];
-            ra[u] = (kin && i0 + cc < P) ? va : 0.0;
-            rb[u] = (kin && j0 + cc < P) ? vb : 0.0;
+            const bool kin = k < F;
+            const int f = kin ? k : 0;
+            const double rs = rsd[f];
+            const size_t rowoff = (size_t)f * WS;
+            const double vb = W[rowoff + min(j0 + cc, PC - 1)];
+            rb[u] = (kin && j0 + cc < PC) ? vb * rs : 0.0;
+            if (!diag) { const double va = W[rowoff + min(i0 + cc, PC - 1)]; ra[u] = (kin && i0 + cc < PC) ? va * rs : 0.0; }
         }
+        if (diag && tid < SY_KB) { const int k = k0 + tid; rg = k < F ? gn[k] : 0.0; }
     };
-    if (kb < ke) gload(kb);
-    for (int k0 = kb; k0 < ke; k0 += SY_KB) {
-#pragma unroll
-        for (int u = 0; u < SY_KB / 4; u++) {
-            const int e = tid + 256 * u, kk = e >> 6, cc = e & 63;
-            sA[kk * SY_LD + cc] = ra[u];
-            sB[kk * SY_LD + cc] = rb[u];
+    // chunks of this K split: q = ks, ks + SY_KS, ... (interleaved: neighbouring chunks have neighbouring spans, so every split meets every tile about equally often).
+    // The ones whose span reaches both the tile's rows and its columns are listed in LDS first, in ascending order (ballot compaction: the summation order is fixed).
+    const int ncand = (nchunk - ks + SY_KS - 1) / SY_KS;
+    for (int base = 0; base < ncand; base += SY_LIST) {
+        int nl = 0;
+        for (int r0 = base; r0 < min(ncand, base + SY_LIST); r0 += 256) {
+            const int cnd = r0 + tid, q = ks + SY_KS * cnd;
+            bool rel = false;
+            if (cnd < ncand) { const int lo = kspan[2 * q], hi = kspan[2 * q + 1]; rel = lo < j0 + 64 && hi >= j0 && lo < i0 + 64 && hi >= i0; }
+            const unsigned long long m = __ballot(rel);
+            if (lane == 0) s_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = nl;
+            for (int v = 0; v < wave; v++) off += s_cnt[v];
+            if (rel) s_list[off + __popcll(m & ((1ull << lane) - 1ull))] = q;
+            nl += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            __syncthreads();
         }
-        __syncthreads();
-        if (k0 + SY_KB < ke) gload(k0 + SY_KB);
+        if (nl) gload(s_list[0]);
+        for (int it = 0; it < nl; it++) {
+            if (!diag) {
 #pragma unroll
-        for (int s4 = 0; s4 < SY_KB / 4; s4++) {
-            double av[2], bv[2];
-            const int kr = (4 * s4 + (lane >> 4)) * SY_LD + (lane & 15);
+                for (int u = 0; u < SY_KB / 4; u++) { const int e = tid + 256 * u; sA[(e >> 6) * SY_LD + (e & 63)] = ra[u]; }
+            }
 #pragma unroll
-            for (int a = 0; a < 2; a++) { av[a] = sA[kr + wi + 16 * a]; bv[a] = sB[kr + wj + 16 * a]; }
+            for (int u = 0; u < SY_KB / 4; u++) { const int e = tid + 256 * u; sB[(e >> 6) * SY_LD + (e & 63)] = rb[u]; }
+            if (diag && tid < SY_KB) sG[tid] = rg;
+            __syncthreads();
+            if (it + 1 < nl) gload(s_list[it + 1]);
+            const double *pA = diag ? sB : sA;
 #pragma unroll
-            for (int a = 0; a < 2; a++)
+            for (int s4 = 0; s4 < SY_KB / 4; s4++) {
+                double av[2], bv[2];
+                const int kr = (4 * s4 + (lane >> 4)) * SY_LD + (lane & 15);
 #pragma unroll
-                for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                for (int a = 0; a < 2; a++) { av[a] = pA[kr + wi + 16 * a]; bv[a] = sB[kr + wj + 16 * a]; }
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+            if (diag && tid < 64) {
+#pragma unroll 8
+                for (int kk = 0; kk < SY_KB; kk++) racc += sB[kk * SY_LD + tid] * sG[kk];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
+    const int ntile = nt * (nt + 1) / 2;
+    double *out = w.SC + ((size_t)ks * ntile + blockIdx.x) * 4096;
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
         for (int b = 0; b < 2; b++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int row = i0 + wi + 16 * a + (lane >> 4) + 4 * q, col = j0 + wj + 16 * b + (lane & 15);
-                if (row < P && col < P) {
-                    unsafeAtomicAdd(S + (size_t)row * P + col, -acc[a][b][q]);
-                    if (ti != tj) unsafeAtomicAdd(S + (size_t)col * P + row, -acc[a][b][q]);
-                }
-            }
+            for (int q4 = 0; q4 < 4; q4++) out[(wi + 16 * a + (lane >> 4) + 4 * q4) * 64 + wj + 16 * b + (lane & 15)] = acc[a][b][q4];
+    if (diag && tid < 64) w.SC[(size_t)SY_KS * ntile * 4096 + (size_t)ks * nt * 64 + j0 + tid] = racc;
+}
+// S = Hpp + diag(lm_p^2) - sum over the K splits of Wn^T Wn (the partial tiles of lw_syrk_mfma, summed in split order: no atomics); row P of S = g_p - Wn^T (g_f /
+// sqrt(den)) (the right-hand side rides through the factorisation as one more row); the factorisation's status word = 0.
+__global__ void lw_schur_prep(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    const int P = w.P, F = w.F, nt = SY_NT(w.PC), ntile = nt * (nt + 1) / 2;
+    const double *Hpp = w.Hpp, *lm = w.vec, *SC = w.SC;
+    double *S = w.S;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P;
+    if (t < nH) {
+        const int i = (int)(t / P), j = (int)(t % P);
+        double v = Hpp[t] + (i == j ? lm[i] * lm[i] : 0.0);
+        const int ci = lw_compcol(w, i), cj = lw_compcol(w, j);
+        if (F && ci >= 0 && cj >= 0) {
+            const int r = max(ci, cj), c = min(ci, cj), tr = r >> 6, tc = c >> 6;
+            const double *src = SC + ((size_t)(tr * (tr + 1) / 2 + tc)) * 4096 + (r & 63) * 64 + (c & 63);
+            double sub = 0;
+#pragma unroll
+            for (int k = 0; k < SY_KS; k++) sub += src[(size_t)k * ntile * 4096];
+            v -= sub;
+        }
+        S[t] = v;
+    }
+    else if (t < nH + P) {
+        const int i = (int)(t - nH);
+        double v = w.gp[i];
+        const int ci = lw_compcol(w, i);
+        if (F && ci >= 0) {
+            double sub = 0;
+#pragma unroll
+            for (int k = 0; k < SY_KS; k++) sub += SC[(size_t)SY_KS * ntile * 4096 + (size_t)k * nt * 64 + ci];
+            v -= sub;
+        }
+        S[nH + i] = v;
+    }
+    else if (t == nH + P) *w.info = 0;
 }
 
 // ---- dense Cholesky of the reduced system (P x P, fp64) with the right-hand side as row P: S = L L^T, L[P][0..P-1] = L^-1 rhs -----------------------
@@ -803,38 +953,25 @@ __global__ __launch_bounds__(1024) void lw_chol_back_raw(int P, const double *S,
     __shared__ double s_blk[CH_NB], s_tri[CH_NB * CH_LD];
     lw_chol_back_body(P, S, y, s_y, s_blk, s_tri);
 }
-// row-wise dots y[r] = A[r][0..P) . v, one 64-lane wave per row. mode 0 (x^T H x pieces for the vector in vec): rows 0 .. P - 1: Hpp vec -> tmpP, rows P .. P + F - 1:
-// W_f . vec -> tmpF; mode 1 (back substitution of the features): y_f = (g_f - W_f . rhs) / den_f
+// row-wise dots, one 64-lane wave per row. mode 0 (x^T H x pieces for the vector in vec): rows 0 .. P - 1: Hpp vec -> tmpP, rows P .. P + F - 1:
+// W_f . vec -> tmpF; mode 1 (back substitution of the features): y_f = (g_f - W_f . rhs) / den_f. W's rows run over the compact (pose) columns.
 __global__ __launch_bounds__(256) void lw_rowdot(const LwWin *ws, int mode, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, C = w.P;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= (mode == 0 ? w.P + w.F : w.F)) return;
     const bool hp = mode == 0 && row < w.P;
     const int r = hp ? row : (mode == 0 ? row - w.P : row);
-    const double *a = (hp ? w.Hpp : w.W) + (size_t)r * C, *x = mode == 0 ? w.vec : w.rhs;
+    const double *x = mode == 0 ? w.vec : w.rhs;
     double s = 0;
-    for (int c = lane; c < C; c += 64) s += a[c] * x[c];
+    if (hp) { const double *a = w.Hpp + (size_t)r * w.P; for (int c = lane; c < w.P; c += 64) s += a[c] * x[c]; }
+    else { const double *a = w.W + (size_t)r * w.WS; for (int c = lane; c < w.PC; c += 64) s += a[c] * x[lw_fullcol(w, c)]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) {
         if (mode == 0) (hp ? w.tmpP : w.tmpF)[r] = s;
         else w.yf[r] = (w.gf[r] - s) / w.den[r];            // y_f = (g_f - W_f . y_p) / den_f
     }
-}
-// rhs row of S -= Wn^T (g_f / sqrt(den)): column sums over row chunks (thread per column, blockIdx.y = chunk), combined with atomics
-__global__ __launch_bounds__(256) void lw_colsum(const LwWin *ws, int rsplit, int sk) {
-    const LwWin &w = ws[blockIdx.z];
-    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int R = w.F, C = w.P;
-    const double *A = w.Wn, *x = w.tmpF; double *y = w.S + (size_t)C * C;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const int rchunk = (R + rsplit - 1) / rsplit, ra = blockIdx.y * rchunk, rb = min(R, ra + rchunk);
-    double s = 0;
-#pragma unroll 8
-    for (int r = ra; r < rb; r++) s += A[(size_t)r * C + c] * x[r];
-    if (ra < rb) unsafeAtomicAdd(y + c, -s);
 }
 
 // ---- host-side manifold helpers (PoseLocalParameterization, utility.h) ------------------------------------------------------------
@@ -1193,24 +1330,27 @@ struct LwHostWin {
     vilf_window_out *out = nullptr;
     bool resident = false;             // also a slot of the 11-frame batch: its prior applies, the solved state goes back into the batch buffers
     size_t slot = 0;
-    int NF = 0, F = 0, P = 0, N = 0, nvis = 0, nimu = 0, cEx = -1, cTd = -1;
+    int NF = 0, F = 0, P = 0, N = 0, nvis = 0, nimu = 0, cEx = -1, cTd = -1, PC = 0, WS = 0, nchunk = 0;
     size_t xo = 0;
     bool use_lidar = false;
     int pn = 0, pnb = 0, phdr[VB_PRIOR_HDR];
     double px0[24 * 9];
-    std::vector<double> x;             // the state: pose | sb | feat | ex[7] | td
+    std::vector<double> x;             // the state: pose | sb | feat | ex[7] | td — feat in the DEVICE's feature order (by start frame) until the results are handed out
+    std::vector<int> fdev;             // host feature index -> device feature index
+    std::vector<unsigned char> fc;     // feature_const in device order
     LwWin dw;                          // the descriptor (device pointers)
-    size_t o_vis = 0, o_tdr = 0, o_fconst = 0, o_scal = 0, o_pcol = 0, o_lid = 0;       // offsets of the inputs in the staging image (imu / cov / x: group-wide runs)
+    size_t o_vis = 0, o_tdr = 0, o_fconst = 0, o_scal = 0, o_pcol = 0, o_lid = 0, o_kspan = 0, o_fvis = 0, o_fidx = 0;       // offsets of the inputs in the staging image (imu / cov / x: group-wide runs)
     // results of the device loop
     LwCtl hc;
 };
 // launch shapes for a set of windows (the whole group, or one window for the host loop): every grid is sized for the largest window, the others' surplus
 // workgroups return at once
 struct LwDims {
-    int G = 0, maxP = 0, maxF = 0, maxNvis = 0, maxNimu = 0;
+    int G = 0, maxP = 0, maxF = 0, maxNvis = 0, maxNimu = 0, maxPC = 0, maxWS = 0;
     bool any_prior = false;
     void take(const LwHostWin &w) {
         G++; maxP = std::max(maxP, w.P); maxF = std::max(maxF, w.F); maxNvis = std::max(maxNvis, w.nvis); maxNimu = std::max(maxNimu, w.nimu);
+        maxPC = std::max(maxPC, w.PC); maxWS = std::max(maxWS, w.WS);
         any_prior = any_prior || w.pn != 0;
     }
 };
@@ -1221,11 +1361,16 @@ struct LwEnq {
     dim3 grid(size_t gx, unsigned gy = 1) const { return dim3((unsigned)std::max<size_t>(gx, 1), gy, (unsigned)d.G); }
     // one evaluation at the device state x (which = 0) or cand (1), the prior's dx already in pdx. Cost only (jac = 0): the caller has zeroed scal[0]
     void evaluate(int which, int jac, int sk) {
-        const size_t sP = d.maxP, sF = d.maxF;
+        const size_t sP = d.maxP;
         if (jac) {      // one launch clears the cost and the five accumulation targets
-            const size_t tot = sP * sP + sF * sP + 2 * sF + sP + 1;
+            const size_t tot = sP * sP + sP + 1;
             hipLaunchKernelGGL(lw_clear, grid((tot + 1023) / 1024), dim3(256), 0, h->stream, ws, sk);
             tic();
+        }
+        if (d.maxNvis && jac) {                       // the rows of W, h_f, g_f: feature-major
+            const size_t lds = 4 * (size_t)d.maxWS * 8;
+            if (ext) hipLaunchKernelGGL(lw_feature_rows<true>, grid((d.maxF + 3) / 4), dim3(256), lds, h->stream, ws, which, sk);
+            else hipLaunchKernelGGL(lw_feature_rows<false>, grid((d.maxF + 3) / 4), dim3(256), lds, h->stream, ws, which, sk);
         }
         if (d.maxNvis) {
             if (ext) hipLaunchKernelGGL(lw_visual_ext, grid((d.maxNvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, ws, which, jac, sk);
@@ -1238,22 +1383,21 @@ struct LwEnq {
     // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in vec
     void quad(int sk) { hipLaunchKernelGGL(lw_rowdot, grid((d.maxP + d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, 0, sk); }
     void scale(int src, int sk) {
-        const size_t sP = d.maxP, sF = d.maxF, tot = sP * sP + sF * sP + sF + sP;
+        const size_t sP = d.maxP, sF = d.maxF, tot = sP * sP + sF * d.maxWS + sF + sP;
         hipLaunchKernelGGL(lw_scale, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, src, sk);
     }
     // one linear solve (H' + lm^2) y = g' with lm in vec: y_p -> rhs, y_f -> yf, the Cholesky's status -> info
     void linear_solve(int sk) {
-        const size_t sP = d.maxP, sF = d.maxF, tot = sP * sP + sF * sP + sF + sP + 1;
-        hipLaunchKernelGGL(lw_schur_prep, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, sk);
+        const size_t sP = d.maxP, tot = sP * sP + sP + 1;
         if (d.maxF) {
-            // the Schur reduce: S -= Wn^T Wn as one fp64 SYRK (row-major F x P), rhs -= Wn^T (g_f / sqrt(den))
+            hipLaunchKernelGGL(lw_den, grid((d.maxF + 255) / 256), dim3(256), 0, h->stream, ws, sk);
+            // the Schur reduce over the compact columns: K-split partial tiles of Wn^T Wn (+ Wn^T g_f / sqrt(den) in the diagonal tiles), summed by lw_schur_prep
             tic();
-            const int nt = (d.maxP + 63) / 64, ksplit = nt * (nt + 1) / 2 * d.G >= 1024 ? 1 : 4;      // K splits only while the tiles alone do not fill the chip
-            hipLaunchKernelGGL(lw_syrk_mfma, grid(nt * (nt + 1) / 2, ksplit), dim3(256), 0, h->stream, ws, ksplit, sk);
+            const int nt = (d.maxPC + 63) / 64;
+            hipLaunchKernelGGL(lw_syrk_mfma, grid(nt * (nt + 1) / 2, SY_KS), dim3(256), 0, h->stream, ws, sk);
             toc(1);
-            const int rsplit = d.G >= 8 ? 16 : 128;
-            hipLaunchKernelGGL(lw_colsum, grid((d.maxP + 255) / 256, rsplit), dim3(256), 0, h->stream, ws, rsplit, sk);
         }
+        hipLaunchKernelGGL(lw_schur_prep, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, sk);
         tic();
         for (int j0 = 0; j0 < d.maxP; j0 += CH_NB) {                     // blocked Cholesky, one launch per 64-column block (panel of this column + the rest of the previous column's update)
             const int nb = std::min(CH_NB, d.maxP - j0), below = d.maxP + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
@@ -1274,7 +1418,7 @@ struct LwEnq {
 // ---- the trust-region loop on the host (trust_region_minimizer.cc with the traditional dogleg strategy, dogleg_strategy.cc): the path of a wall-clock limit
 // (Ceres tests the clock at the top of every iteration) and the fallback of a failed factorisation in the device loop. One window; `dws` = its descriptor on the device.
 int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, double tlim, const std::chrono::steady_clock::time_point t_start, bool ext) {
-    const vilf_window_in *in = hw.in;
+    (void)hw.in;
     const LwWin &dw = hw.dw;
     const int NF = hw.NF, F = hw.F, P = hw.P, N = hw.N, cEx = hw.cEx, cTd = hw.cTd, pn = hw.pn, pnb = hw.pnb;
     const size_t xo = hw.xo, sP = P, sN = N;
@@ -1303,7 +1447,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
     auto xnorm = [&](const std::vector<double> &v) {
         double s = 0;
         for (int i = 0; i < 16 * NF; i++) s += v[i] * v[i];
-        for (int f = 0; f < F; f++) if (!in->feature_const[f]) s += v[16 * NF + f] * v[16 * NF + f];
+        for (int f = 0; f < F; f++) if (!hw.fc[f]) s += v[16 * NF + f] * v[16 * NF + f];
         if (est_ex) for (int k = 0; k < 7; k++) s += v[xo + k] * v[xo + k];
         if (est_td) s += v[xo + 7] * v[xo + 7];
         return std::sqrt(s);
@@ -1312,7 +1456,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
     auto plus = [&](const std::vector<double> &xx, const std::vector<double> &d, std::vector<double> &o) {
         o = xx;
         for (int i = 0; i < NF; i++) { h_pose_plus(&xx[7 * i], &d[15 * i], &o[7 * i]); for (int k = 0; k < 9; k++) o[7 * NF + 9 * i + k] = xx[7 * NF + 9 * i + k] + d[15 * i + 6 + k]; }
-        for (int f = 0; f < F; f++) o[16 * NF + f] = xx[16 * NF + f] + (in->feature_const[f] ? 0.0 : d[P + f]);
+        for (int f = 0; f < F; f++) o[16 * NF + f] = xx[16 * NF + f] + (hw.fc[f] ? 0.0 : d[P + f]);
         if (est_ex) h_pose_plus(&xx[xo], &d[cEx], &o[xo]);
         if (est_td) o[xo + 7] = xx[xo + 7] + d[cTd];
     };
@@ -1339,7 +1483,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
         if (F) { HIPCHECK(h, hipMemcpyAsync(&diagH[P], dw.hf, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); HIPCHECK(h, hipMemcpyAsync(&g[P], dw.gf, (size_t)F * 8, hipMemcpyDeviceToHost, h->stream)); }
         HIPCHECK(h, hipMemcpyAsync(&g[0], dw.gp, sP * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
-        for (int f = 0; f < F; f++) if (in->feature_const[f]) { diagH[P + f] = 0.0; g[P + f] = 0.0; }
+        for (int f = 0; f < F; f++) if (hw.fc[f]) { diagH[P + f] = 0.0; g[P + f] = 0.0; }
         return VILF_OK;
     };
     // x^T H x with the (scaled) blocks on the device: v_p^T Hpp v_p + 2 sum_f v_f (W_f . v_p) + sum_f h_f v_f^2
@@ -1351,7 +1495,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         qq = 0;
         for (int i = 0; i < P; i++) qq += vv[i] * tP[i];
-        for (int f = 0; f < F; f++) if (!in->feature_const[f]) qq += vv[P + f] * (2.0 * tF[f] + hfh[f] * vv[P + f]);
+        for (int f = 0; f < F; f++) if (!hw.fc[f]) qq += vv[P + f] * (2.0 * tF[f] + hfh[f] * vv[P + f]);
         return VILF_OK;
     };
     auto eval_grad_jac = [&]() -> int {
@@ -1375,7 +1519,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
     // ---- the linear solve: (H' + lm^2) y = g'
     auto linear_solve = [&](bool &ok) -> int {
         ok = false;
-        for (int f = 0; f < F; f++) if (!in->feature_const[f] && !(hfh[f] + lm[P + f] * lm[P + f] > 0.0)) return VILF_OK;
+        for (int f = 0; f < F; f++) if (!hw.fc[f] && !(hfh[f] + lm[P + f] * lm[P + f] > 0.0)) return VILF_OK;
         HIPCHECK(h, hipMemcpyAsync(dw.vec, lm.data(), sN * 8, hipMemcpyHostToDevice, h->stream));
         q.linear_solve(LW_SK_NONE);
         HIPCHECK(h, hipGetLastError());
@@ -1385,7 +1529,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
         HIPCHECK(h, hipMemcpyAsync(&y[0], dw.rhs, sP * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         if (info != 0) return VILF_OK;                                  // not positive definite: the caller raises mu
-        for (int f = 0; f < F; f++) if (in->feature_const[f]) y[P + f] = 0.0;
+        for (int f = 0; f < F; f++) if (hw.fc[f]) y[P + f] = 0.0;
         for (double a : y) if (!std::isfinite(a)) return VILF_OK;
         ok = true;
         return VILF_OK;
@@ -1459,7 +1603,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
         if ((rc = evaluate(cand, false, cand_cost)) != VILF_OK) return rc;
         double sn = 0;
         for (int i = 0; i < 16 * NF; i++) sn += (x[i] - cand[i]) * (x[i] - cand[i]);
-        for (int f = 0; f < F; f++) if (!in->feature_const[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
+        for (int f = 0; f < F; f++) if (!hw.fc[f]) sn += (x[16 * NF + f] - cand[16 * NF + f]) * (x[16 * NF + f] - cand[16 * NF + f]);
         if (est_ex) for (int k = 0; k < 7; k++) sn += (x[xo + k] - cand[xo + k]) * (x[xo + k] - cand[xo + k]);
         if (est_td) sn += (x[xo + 7] - cand[xo + 7]) * (x[xo + 7] - cand[xo + 7]);
         if (std::sqrt(sn) <= parameter_tolerance * (x_norm + parameter_tolerance)) { termination = VILF_TERM_CONVERGENCE_PARAMETER; break; }
@@ -1525,6 +1669,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         w.NF = NF; w.F = F;
         w.cEx = est_ex ? 15 * NF : -1; w.cTd = est_td ? 15 * NF + (est_ex ? 6 : 0) : -1;      // columns of Ex_Pose / td after the frame blocks
         w.P = 15 * NF + (est_ex ? 6 : 0) + (est_td ? 1 : 0); w.N = w.P + F;
+        w.PC = 6 * NF + (est_ex ? 6 : 0) + (est_td ? 1 : 0); w.WS = (w.PC + 7) / 8 * 8; w.nchunk = (F + SY_KB - 1) / SY_KB;      // W over the pose / Ex / td columns only, 64-byte rows
         if (w.P > vilf_lw_chol_max_n()) { h->err = "window too large for the general path (reduced system above 12288 columns)"; return VILF_ERR_UNSUPPORTED; }
         w.xo = 16 * (size_t)NF + F;
         w.nvis = std::max(0, in->n_obs - F); w.nimu = NF - 1;
@@ -1583,22 +1728,27 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         w.o_fconst = off; off = lw_al(off + std::max(w.F, 1));
         w.o_scal = off; off = lw_al(off + 16 * 8);
         w.o_pcol = off; off = lw_al(off + VB_PRIOR_LD * sizeof(int));
+        w.o_kspan = off; off = lw_al(off + (size_t)std::max(w.nchunk, 1) * 2 * sizeof(int));
+        w.o_fvis = off; off = lw_al(off + ((size_t)w.F + 1) * sizeof(int));
+        w.o_fidx = off; off = lw_al(off + (size_t)std::max(w.nvis, 1) * sizeof(int));
     }
     const size_t o_imu = off; off = lw_al(off + tot_imu * IMU_REC * 8);
     const size_t o_cov = off; off = lw_al(off + tot_imu * 225 * 8);
     const size_t o_x = off; off = lw_al(off + tot_x * 8);
     const size_t n_input = off;
     const size_t o_ctl = off; off = lw_al(off + (size_t)G * sizeof(LwCtl));
-    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, Wn, rhs, tmpP, tmpF, vec, den, info, nvec, pdx; };
+    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, SC, rhs, tmpP, tmpF, vec, den, rsd, info, nvec, pdx; };
     std::vector<WorkOff> wo(G);
     for (int g = 0; g < G; g++) {
         const LwHostWin &w = hws[g];
         const size_t sP = w.P, sF = std::max(w.F, 1), sN = w.N;
         WorkOff &o = wo[g];
         auto take = [&](size_t bytes) { const size_t at = off; off = lw_al(off + bytes); return at; };
-        o.cand = take((w.xo + 8) * 8); o.Hpp = take(sP * sP * 8); o.W = take(sF * sP * 8); o.hf = take(sF * 8); o.gp = take(sP * 8); o.gf = take(sF * 8);
-        o.S = take((sP + 1) * sP * 8); o.Wn = take(sF * sP * 8); o.rhs = take(sP * 8); o.tmpP = take(sP * 8); o.tmpF = take(sF * 8); o.vec = take(2 * sN * 8);
-        o.den = take(sF * 8); o.info = take(64); o.nvec = take(7 * sN * 8); o.pdx = take(VB_PRIOR_LD * 8);
+        o.cand = take((w.xo + 8) * 8); o.Hpp = take(sP * sP * 8); o.W = take(sF * (size_t)w.WS * 8); o.hf = take(sF * 8); o.gp = take(sP * 8); o.gf = take(sF * 8);
+        o.S = take((sP + 1) * sP * 8);
+        { const size_t nt = (w.PC + 63) / 64, ntile = nt * (nt + 1) / 2; o.SC = take((size_t)SY_KS * (ntile * 4096 + nt * 64) * 8); }
+        o.rhs = take(sP * 8); o.tmpP = take(sP * 8); o.tmpF = take(sF * 8); o.vec = take(2 * sN * 8);
+        o.den = take(sF * 8); o.rsd = take(sF * 8); o.info = take(64); o.nvec = take(7 * sN * 8); o.pdx = take(VB_PRIOR_LD * 8);
     }
     if (!c->arena.ensure(off) || !c->desc.ensure((size_t)G * sizeof(LwWin))) { h->err = "hipMalloc failed (general-path solve)"; return VILF_ERR_DEVICE; }
     if (c->stage_cap < n_input) {
@@ -1630,6 +1780,14 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         LwHostWin &w = hws[g];
         const vilf_window_in *in = w.in;
         const int NF = w.NF, F = w.F, nvis = w.nvis, nimu = w.nimu;
+        // the device's feature order: by start frame (counting sort, stable) — the Schur reduce runs K over the features and skips what a tile's columns cannot meet
+        w.fdev.assign(std::max(F, 1), 0); w.fc.assign(std::max(F, 1), 0);
+        {
+            std::vector<int> cnt((size_t)NF + 1, 0);
+            for (int f = 0; f < F; f++) cnt[in->feature_start_frame[f] + 1]++;
+            for (int k = 1; k <= NF; k++) cnt[k] += cnt[k - 1];
+            for (int f = 0; f < F; f++) { const int dvi = cnt[in->feature_start_frame[f]]++; w.fdev[f] = dvi; w.fc[dvi] = in->feature_const[f] ? 1 : 0; }
+        }
         // pair-sorted (lw_visual flushes one block per run of equal pairs): counting sort over the NF^2 pair keys, stable in feature order
         LwVis *vis = reinterpret_cast<LwVis *>(st + w.o_vis);
         vis_obs.assign(2 * (size_t)std::max(nvis, 1), 0);           // (first, this) observation index of every factor: the td constants follow the pair sort
@@ -1639,13 +1797,18 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
             for (int t = o0 + 1; t < o1; t++) pair_cnt[(size_t)s * NF + s + (t - o0) + 1]++;
         }
         for (size_t k = 1; k < pair_cnt.size(); k++) pair_cnt[k] += pair_cnt[k - 1];
+        int *fvis = reinterpret_cast<int *>(st + w.o_fvis), *fidx = reinterpret_cast<int *>(st + w.o_fidx);     // the feature-major view of the pair-sorted records
+        fvis[0] = 0;
+        for (int f = 0; f < F; f++) fvis[w.fdev[f] + 1] = std::max(0, in->feature_obs_offset[f + 1] - in->feature_obs_offset[f] - 1);
+        for (int f = 0; f < F; f++) fvis[f + 1] += fvis[f];
         for (int f = 0; f < F; f++) {
             const int o0 = in->feature_obs_offset[f], o1 = in->feature_obs_offset[f + 1], s = in->feature_start_frame[f];
             for (int t = o0 + 1; t < o1; t++) {
                 const int k = pair_cnt[(size_t)s * NF + s + (t - o0)]++;
+                fidx[fvis[w.fdev[f]] + (t - o0 - 1)] = k;
                 LwVis &v = vis[k];
                 for (int q = 0; q < 3; q++) { v.pi[q] = in->obs_point[3 * (size_t)o0 + q]; v.pj[q] = in->obs_point[3 * (size_t)t + q]; }
-                v.f = f; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
+                v.f = w.fdev[f]; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
                 vis_obs[2 * (size_t)k] = o0; vis_obs[2 * (size_t)k + 1] = t;
             }
         }
@@ -1673,7 +1836,18 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
             if (in->lidar) { const vilf_lidar_constraint &l = in->lidar[k + 1]; for (int i = 0; i < 4; i++) lid[7 * k + i] = l.q[i]; for (int i = 0; i < 3; i++) lid[7 * k + 4 + i] = l.t[i]; }
             else lid[7 * k + 3] = 1.0;
         }
-        if (F) std::memcpy(st + w.o_fconst, in->feature_const, F);
+        if (F) std::memcpy(st + w.o_fconst, w.fc.data(), F);
+        {   // per chunk of SY_KB features (device order) the compact columns their frame spans cover; with Ex_Pose / td as variables every row also reaches the last columns
+            int *kspan = reinterpret_cast<int *>(st + w.o_kspan);
+            for (int q = 0; q < w.nchunk; q++) { kspan[2 * q] = w.PC; kspan[2 * q + 1] = -1; }
+            for (int f = 0; f < F; f++) {
+                if (in->feature_const[f]) continue;                       // a constant depth: no row in W
+                const int s0 = in->feature_start_frame[f], nobs = in->feature_obs_offset[f + 1] - in->feature_obs_offset[f], q = w.fdev[f] / SY_KB;
+                if (nobs < 2) continue;
+                kspan[2 * q] = std::min(kspan[2 * q], 6 * s0);
+                kspan[2 * q + 1] = std::max(kspan[2 * q + 1], w.PC > 6 * NF ? w.PC - 1 : 6 * (s0 + nobs - 1) + 5);      // lo > hi: nothing in this chunk
+            }
+        }
         double *scal = reinterpret_cast<double *>(st + w.o_scal);
         std::memset(scal, 0, 16 * 8);
         for (int k = 0; k < 4; k++) scal[1 + k] = qil[k];
@@ -1682,11 +1856,11 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         w.x.resize(w.xo + 8);
         if (w.resident) {                              // NF = 11: the slot's current state
             std::memcpy(&w.x[0], &r_pose[(size_t)g * 77], 77 * 8); std::memcpy(&w.x[77], &r_sb[(size_t)g * 99], 99 * 8);
-            for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + f] = r_feat[(size_t)g * rF + f];
+            for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + w.fdev[f]] = r_feat[(size_t)g * rF + f];
             std::memcpy(&w.x[w.xo], &r_ex[(size_t)g * 7], 56); w.x[w.xo + 7] = r_td[g];
         } else {
             std::memcpy(&w.x[0], in->para_pose, 7 * (size_t)NF * 8); std::memcpy(&w.x[7 * (size_t)NF], in->para_speed_bias, 9 * (size_t)NF * 8);
-            for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + f] = in->para_feature[f];
+            for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + w.fdev[f]] = in->para_feature[f];
             std::memcpy(&w.x[w.xo], in->para_ex_pose, 56); w.x[w.xo + 7] = in->para_td;
         }
         std::memcpy(reinterpret_cast<double *>(st + o_x) + at_x, w.x.data(), w.x.size() * 8);
@@ -1706,6 +1880,9 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         const size_t sN = w.N;
         d.NF = NF; d.F = F; d.P = w.P; d.N = w.N; d.nvis = nvis; d.nimu = nimu; d.cEx = w.cEx; d.cTd = w.cTd; d.xo = (int)w.xo; d.est_ex = est_ex ? 1 : 0; d.est_td = est_td ? 1 : 0;
         d.use_lidar = w.use_lidar ? 1 : 0; d.pn = w.pn; d.pnb = w.pnb; d.max_it = h->opts.max_num_iterations;
+        d.PC = w.PC; d.WS = w.WS; d.nchunk = w.nchunk;
+        d.kspan = reinterpret_cast<const int *>(dev + w.o_kspan);
+        d.fvis = reinterpret_cast<const int *>(dev + w.o_fvis); d.fidx = reinterpret_cast<const int *>(dev + w.o_fidx);
         d.sqrt_info = sqrt_info; d.cauchy_b = cauchy_b; d.tr_over_row = h->opts.TR / h->opts.ROW;
         d.ctl = reinterpret_cast<LwCtl *>(dev + o_ctl) + g;
         d.x = reinterpret_cast<double *>(dev + o_x) + at_x; d.cand = reinterpret_cast<double *>(dev + o.cand);
@@ -1713,8 +1890,8 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         d.imu = reinterpret_cast<const double *>(dev + o_imu) + at_imu * IMU_REC; d.lid = reinterpret_cast<const double *>(dev + w.o_lid);
         d.fconst = reinterpret_cast<const unsigned char *>(dev + w.o_fconst);
         auto dp = [&](size_t at) { return reinterpret_cast<double *>(dev + at); };
-        d.Hpp = dp(o.Hpp); d.W = dp(o.W); d.hf = dp(o.hf); d.gp = dp(o.gp); d.gf = dp(o.gf); d.S = dp(o.S); d.Wn = dp(o.Wn); d.rhs = dp(o.rhs); d.tmpP = dp(o.tmpP); d.tmpF = dp(o.tmpF);
-        d.vec = dp(o.vec); d.yf = dp(o.vec) + sN; d.scal = dp(w.o_scal); d.den = dp(o.den); d.info = reinterpret_cast<int *>(dev + o.info);
+        d.Hpp = dp(o.Hpp); d.W = dp(o.W); d.hf = dp(o.hf); d.gp = dp(o.gp); d.gf = dp(o.gf); d.S = dp(o.S); d.SC = dp(o.SC); d.rhs = dp(o.rhs); d.tmpP = dp(o.tmpP); d.tmpF = dp(o.tmpF);
+        d.vec = dp(o.vec); d.yf = dp(o.vec) + sN; d.scal = dp(w.o_scal); d.den = dp(o.den); d.rsd = dp(o.rsd); d.info = reinterpret_cast<int *>(dev + o.info);
         double *nv = dp(o.nvec);
         d.g = nv; d.diagH = nv + sN; d.scale = nv + 2 * sN; d.diagonal = nv + 3 * sN; d.gradient = nv + 4 * sN; d.gn = nv + 5 * sN; d.step = nv + 6 * sN;
         d.pcol = reinterpret_cast<const int *>(dev + w.o_pcol); d.pdx = dp(o.pdx);
@@ -1808,6 +1985,10 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         LwHostWin &w = hws[g];
         const vilf_window_in *in = w.in; vilf_window_out *out = w.out;
         const int NF = w.NF, F = w.F; const size_t xo = w.xo;
+        {   // the inverse depths back into the caller's feature order
+            std::vector<double> tmp(w.x.begin() + 16 * (size_t)NF, w.x.begin() + 16 * (size_t)NF + F);
+            for (int f = 0; f < F; f++) w.x[16 * (size_t)NF + f] = tmp[w.fdev[f]];
+        }
         const std::vector<double> &x = w.x;
         double R0b[9], P0b[3];
         if (in->gauge_R0) std::memcpy(R0b, in->gauge_R0, 72); else { double q0[4] = {in->para_pose[3], in->para_pose[4], in->para_pose[5], in->para_pose[6]}; h_q2R(q0, R0b); }
