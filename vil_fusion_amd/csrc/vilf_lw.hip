@@ -59,7 +59,11 @@ enum { LW_SK_NONE = -1, LW_SK_SOLVE = 0, LW_SK_QUAD = 1, LW_SK_EVAL = 2, LW_SK_J
 // State x (and cand): pose[NF][7] | sb[NF][9] | feat[F] | ex[7] | td. Tangent / N-vectors: [15 per frame: pose 6, speed-bias 9 | ex 6 | td | F].
 struct LwWin {
     int NF, F, P, N, nvis, nimu, cEx, cTd, xo, est_ex, est_td, use_lidar, pn, pnb, max_it, pad_;
-    int PC, WS, nchunk, pad2_;                     // W: F rows of WS doubles, PC = 6 NF (+ 6 Ex)(+ 1 td) of them used: compact column c <-> column lw_fullcol(c) of the reduced system
+    int PC, WS, nchunk, nks;                       // W: F rows of WS doubles, PC = 6 NF (+ 6 Ex)(+ 1 td) of them used: compact column c <-> column lw_fullcol(c) of the reduced system
+    // pose-pose blocks of the visual factors without atomics: every run of equal frame pairs inside a chunk of lw_visual owns a SLOT of PS (12 x 12 + 12 sums, stride 160);
+    // lw_assemble adds the slots of a pair / of a frame's pairs in slot order. cslot: first slot of a chunk; prt: per pair {i, j, first slot, end slot}; froff / frlist:
+    // CSR per frame of (pair << 1 | 0: the frame is the pair's i, 1: its j)
+    double *PS; const int *cslot, *prt, *froff, *frlist; int npairs, pad3_;
     const int *fvis, *fidx;                        // CSR over the features: the factors of feature f are vis[fidx[fvis[f] .. fvis[f + 1])] (vis itself is pair-sorted)
     const int *kspan;                              // the device's feature order is by start frame (the host permutes on the way in and out); per K-chunk of SY_KB
                                                    // features: first and last compact column any of them touches
@@ -84,7 +88,8 @@ __device__ __forceinline__ int lw_compcol(const LwWin &w, int i) {
     return (w.est_td && i == w.cTd) ? 6 * w.NF + (w.est_ex ? 6 : 0) : -1;
 }
 #define SY_KB 32
-#define SY_KS 4                                    // K splits of the Schur reduce (partials in their own buffers, summed in fixed order by lw_schur_prep)
+#define SY_KS 16                                   // most K splits of the Schur reduce (partials in their own buffers, summed in fixed order by lw_schur_prep); a group uses
+                                                   // LwWin::nks of them: 4 when its windows' tiles fill the chip, up to 16 for a single window (60 workgroups of ~12 chunks otherwise)
 
 struct LwCtx {
     DBuf arena, desc;                  // the group's device memory; its LwWin array
@@ -115,10 +120,11 @@ __device__ __forceinline__ void add(double *p, double v) { unsafeAtomicAdd(p, v)
 // x layout: pose[NF][7] | sb[NF][9] | feat[F]
 // The factors arrive sorted by frame pair (i, j). A workgroup takes LW_CH consecutive factors: every lane evaluates one and parks its
 // corrected 2 x 12 Jacobian and residual in LDS; then, per run of equal pairs inside the chunk (a handful), 156 lanes each own one entry of
-// the pair's 12 x 12 block / 12-vector, sum it over the run from LDS and issue ONE atomic per entry — instead of 156 atomics per factor on
-// the same few hundred addresses (the 51 diagonal pose blocks collect ~2 k factors each). The per-feature terms keep their per-factor atomics
-// (a feature's ~20 factors spread over many workgroups).
+// the pair's 12 x 12 block / 12-vector, sum it over the run from LDS and store it to the run's own slot of PS (host-assigned: cslot); lw_assemble
+// then adds a pair's slots / the slots of a frame's pairs in slot order into Hpp and g_p — no atomics (until round 4: one atomic per entry and run, all
+// workgroups of a start frame colliding on its diagonal block: 0.3 of an iteration's 2.5 ms at 32 stress windows). The per-feature terms: lw_feature_rows.
 #define LW_CH 128
+typedef double lw_double4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, int jac, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
@@ -126,12 +132,13 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, i
     if ((int)blockIdx.x * LW_CH >= n) return;         // the grid is sized for the group's largest window
     const double *x = which ? w.cand : w.x, *ex = x + w.xo;
     const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b;
-    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
+    double *PS = w.PS, *cost = w.scal;
     const LwVis *vis = w.vis;
     __shared__ double s_J[LW_CH][26];                 // 24 Jacobian entries (row 0: 12, row 1: 12), r0, r1
+    __shared__ double s_red[4][64];
+    __shared__ unsigned long long s_bnd[2];
     __shared__ int s_pair[LW_CH + 1];
     const int tid = threadIdx.x, t = blockIdx.x * LW_CH + tid;
-    const int P = 15 * NF;
     double c = 0;
     int pr = -1;
     if (t < n) {
@@ -158,27 +165,48 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, i
         }
     }
     if (jac) {
+        // X = the run's rows [J0 | r0], [J1 | r1] (two per factor, 13 columns): X^T X on the matrix cores. v_mfma_f64_16x16x4_f64 takes four rows per instruction with ONE
+        // operand register serving as A and as B (lane l holds X[4 s + l / 16][l % 16]); the two waves take alternate K steps of a run, wave 1 hands its accumulators to
+        // wave 0 through LDS, wave 0 stores the run's slot. (Until round 4: a lane per entry summing over the run from LDS — 256 dependent LDS round trips per lane, 32 us
+        // of a workgroup's life.) The run boundaries come from two ballots instead of a serial walk over s_pair.
         s_pair[tid] = pr;
         if (tid == 0) s_pair[LW_CH] = -2;
         __syncthreads();
-        const int cnt = min(LW_CH, n - blockIdx.x * LW_CH);
-        for (int b0 = 0; b0 < cnt;) {                 // runs of equal pairs (uniform loop: every lane walks the same run boundaries)
-            const int pp = s_pair[b0];
-            int b1 = b0 + 1;
-            while (b1 < cnt && s_pair[b1] == pp) b1++;
-            const int fi = pp / NF, fj = pp - fi * NF, ci = 15 * fi, cj = 15 * fj;
-            for (int e = tid; e < 156; e += LW_CH) {
-                double sum = 0;
-                if (e < 144) {
-                    const int a = e / 12, b = e - 12 * a;
-                    for (int q = b0; q < b1; q++) sum += s_J[q][a] * s_J[q][b] + s_J[q][12 + a] * s_J[q][12 + b];
-                    add(Hpp + (size_t)(a < 6 ? ci + a : cj + a - 6) * P + (b < 6 ? ci + b : cj + b - 6), sum);
-                } else {
-                    const int a = e - 144;
-                    for (int q = b0; q < b1; q++) sum += s_J[q][a] * s_J[q][24] + s_J[q][12 + a] * s_J[q][25];
-                    add(gp + (a < 6 ? ci + a : cj + a - 6), sum);
+        const int cnt = min(LW_CH, n - blockIdx.x * LW_CH), slot0 = w.cslot[blockIdx.x];
+        const int lane = tid & 63, wave = tid >> 6, c16 = lane & 15, g4 = lane >> 4;
+        const unsigned long long bm = __ballot(tid < cnt && s_pair[tid] != s_pair[tid + 1]);      // bit t: a run ends at factor t of this wave's half
+        if (lane == 0) s_bnd[wave] = bm;
+        __syncthreads();
+        const unsigned long long m0 = s_bnd[0], m1 = s_bnd[1];
+        int run = 0;
+        for (int b0 = 0; b0 < cnt;) {                 // runs of equal pairs (uniform loop)
+            int b1;
+            { const unsigned long long lo = b0 < 64 ? (m0 >> b0) : 0ull; if (lo) b1 = b0 + __ffsll((long long)lo); else { const int s0 = b0 < 64 ? 0 : b0 - 64; b1 = 64 + s0 + __ffsll((long long)(m1 >> s0)); } }
+            lw_double4 acc = lw_double4{0, 0, 0, 0};
+            const int nst = (b1 - b0 + 1) >> 1;        // K steps of four rows = two factors
+            for (int st = wave; st < nst; st += 2) {
+                const int q = b0 + 2 * st + (g4 >> 1), hrow = g4 & 1;
+                double xv = 0.0;
+                if (q < b1 && c16 < 13) xv = s_J[q][c16 < 12 ? 12 * hrow + c16 : 24 + hrow];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xv, xv, acc, 0, 0, 0);
+            }
+            if (wave == 1) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) s_red[q4][lane] = acc[q4];
+            }
+            __syncthreads();
+            if (wave == 0) {
+                double *slot = PS + (size_t)(slot0 + run) * 160;       // this run's own slot: plain stores, lw_assemble adds the slots up in a fixed order
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const int row = g4 + 4 * q4;                        // entry (row, c16) of X^T X
+                    const double v = acc[q4] + s_red[q4][lane];
+                    if (row < 12 && c16 < 12) slot[12 * row + c16] = v;
+                    else if (row < 12 && c16 == 12) slot[144 + row] = v;
                 }
             }
+            __syncthreads();
+            run++;
             b0 = b1;
         }
     }
@@ -268,6 +296,61 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int whic
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if ((tid & 63) == 0 && c != 0.0) add(cost, c);
+}
+// Hpp's pose-pose blocks and g_p's pose parts of the visual factors from the slots of lw_visual, every entry by ONE thread in slot order (bit-reproducible, plain
+// stores into the cleared arrays; the IMU / LiDAR / prior kernels add on top afterwards). Workgroup b < NF: frame b's diagonal block = the i-i parts of the
+// pairs (b, *) and the j-j parts of the pairs (*, b), and g_p[15 b ..]; workgroup NF + p: pair p's off-diagonal block and its transpose.
+__global__ __launch_bounds__(256) void lw_assemble(const LwWin *ws, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;
+    const int NF = w.NF, P = w.P, tid = threadIdx.x, b = blockIdx.x;
+    const double *PS = w.PS; const int *prt = w.prt;
+    __shared__ double s_part[6][42];
+    __shared__ int s_sl[256];                          // the slots of this block's list (slot << 1 | kind), in list order
+    __shared__ int s_n;
+    if (b < NF) {
+        // a frame's list is a few dozen slots: six lanes per entry take every sixth slot (independent loads instead of one dependent chain of ~60: 58 us for a single
+        // window), the six partial sums are added in lane order — the same order every run
+        const int u0 = w.froff[b], u1 = w.froff[b + 1];
+        const int e = tid % 42, part = tid / 42, a = e < 36 ? e / 6 : e - 36, c = e < 36 ? e % 6 : 0;
+        double acc = 0;
+        int u = u0, sl = u0 < u1 ? prt[4 * (w.frlist[u0] >> 1) + 2] : 0;      // thread 0's cursor through the list (rounds of 256 slots: a frame of a large window can have more)
+        for (;;) {
+            if (tid == 0) {
+                int n = 0;
+                while (u < u1 && n < 256) {
+                    const int pk = w.frlist[u], p = pk >> 1, end = prt[4 * p + 3];
+                    while (sl < end && n < 256) s_sl[n++] = (sl++ << 1) | (pk & 1);
+                    if (sl >= end) { u++; if (u < u1) sl = prt[4 * (w.frlist[u] >> 1) + 2]; }
+                }
+                s_n = n;
+            }
+            __syncthreads();
+            const int n = s_n;
+            if (tid < 252)
+                for (int k = part; k < n; k += 6) {        // which of the six partial sums a slot joins depends only on its place in the list: the same every run
+                    const int sk2 = s_sl[k], kind = sk2 & 1, o = e < 36 ? (6 * kind + a) * 12 + 6 * kind + c : 144 + 6 * kind + a;
+                    acc += PS[(size_t)(sk2 >> 1) * 160 + o];
+                }
+            __syncthreads();
+            if (n < 256) break;
+        }
+        if (tid < 252) s_part[part][e] = acc;
+        __syncthreads();
+        if (tid < 42) {
+            const int a = tid < 36 ? tid / 6 : tid - 36, c = tid < 36 ? tid % 6 : 0;
+            const double acc = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) + (s_part[4][tid] + s_part[5][tid]);
+            if (tid < 36) w.Hpp[(size_t)(15 * b + a) * P + 15 * b + c] = acc; else w.gp[15 * b + a] = acc;
+        }
+    } else {
+        const int p = b - NF;
+        if (p >= w.npairs || tid >= 36) return;
+        const int a = tid / 6, c = tid % 6, i = prt[4 * p], j = prt[4 * p + 1];
+        double acc = 0;
+        for (int sl = prt[4 * p + 2]; sl < prt[4 * p + 3]; sl++) acc += PS[(size_t)sl * 160 + a * 12 + 6 + c];
+        w.Hpp[(size_t)(15 * i + a) * P + 15 * j + c] = acc;
+        w.Hpp[(size_t)(15 * j + c) * P + 15 * i + a] = acc;
+    }
 }
 // The per-feature terms of a linearisation — the feature's row of W (pose-feature blocks of J^T J over the compact columns), h_f, g_f — FEATURE-major and without
 // atomics: one wave per feature, a lane per factor of it (fidx lists them; blocks of 64 for longer tracks). A factor's pose_j block lands in columns of its own
@@ -473,7 +556,6 @@ __global__ void lw_scale(const LwWin *ws, int src, int sk) {
 // bit-reproducible.
 #define SY_LD 65
 #define SY_NT(PC) (((PC) + 63) / 64)
-typedef double lw_double4 __attribute__((ext_vector_type(4)));
 // den_f = h_f + lm_f^2 (1 for a constant feature: its row of W is zero), rsd_f = 1 / sqrt(den_f), tmpF_f = g_f / sqrt(den_f): once per linear solve
 __global__ __launch_bounds__(256) void lw_den(const LwWin *ws, int sk) {
     const LwWin &w = ws[blockIdx.z];
@@ -496,7 +578,7 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int sk) {
     while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ti++;
     const int nt = SY_NT(PC);
     if (ti >= nt || F == 0) return;                   // the grid is sized for the group's largest window
-    const int tj = blockIdx.x - ti * (ti + 1) / 2, i0 = 64 * ti, j0 = 64 * tj, ks = blockIdx.y;
+    const int tj = blockIdx.x - ti * (ti + 1) / 2, i0 = 64 * ti, j0 = 64 * tj, ks = blockIdx.y, nks = w.nks;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
     const bool diag = ti == tj;
     lw_double4 acc[2][2];
@@ -521,13 +603,13 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int sk) {
         }
         if (diag && tid < SY_KB) { const int k = k0 + tid; rg = k < F ? gn[k] : 0.0; }
     };
-    // chunks of this K split: q = ks, ks + SY_KS, ... (interleaved: neighbouring chunks have neighbouring spans, so every split meets every tile about equally often).
+    // chunks of this K split: q = ks, ks + nks, ... (interleaved: neighbouring chunks have neighbouring spans, so every split meets every tile about equally often).
     // The ones whose span reaches both the tile's rows and its columns are listed in LDS first, in ascending order (ballot compaction: the summation order is fixed).
-    const int ncand = (nchunk - ks + SY_KS - 1) / SY_KS;
+    const int ncand = (nchunk - ks + nks - 1) / nks;
     for (int base = 0; base < ncand; base += SY_LIST) {
         int nl = 0;
         for (int r0 = base; r0 < min(ncand, base + SY_LIST); r0 += 256) {
-            const int cnd = r0 + tid, q = ks + SY_KS * cnd;
+            const int cnd = r0 + tid, q = ks + nks * cnd;
             bool rel = false;
             if (cnd < ncand) { const int lo = kspan[2 * q], hi = kspan[2 * q + 1]; rel = lo < j0 + 64 && hi >= j0 && lo < i0 + 64 && hi >= i0; }
             const unsigned long long m = __ballot(rel);
@@ -577,14 +659,14 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int sk) {
         for (int b = 0; b < 2; b++)
 #pragma unroll
             for (int q4 = 0; q4 < 4; q4++) out[(wi + 16 * a + (lane >> 4) + 4 * q4) * 64 + wj + 16 * b + (lane & 15)] = acc[a][b][q4];
-    if (diag && tid < 64) w.SC[(size_t)SY_KS * ntile * 4096 + (size_t)ks * nt * 64 + j0 + tid] = racc;
+    if (diag && tid < 64) w.SC[(size_t)nks * ntile * 4096 + (size_t)ks * nt * 64 + j0 + tid] = racc;
 }
 // S = Hpp + diag(lm_p^2) - sum over the K splits of Wn^T Wn (the partial tiles of lw_syrk_mfma, summed in split order: no atomics); row P of S = g_p - Wn^T (g_f /
 // sqrt(den)) (the right-hand side rides through the factorisation as one more row); the factorisation's status word = 0.
 __global__ void lw_schur_prep(const LwWin *ws, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int P = w.P, F = w.F, nt = SY_NT(w.PC), ntile = nt * (nt + 1) / 2;
+    const int P = w.P, F = w.F, nt = SY_NT(w.PC), ntile = nt * (nt + 1) / 2, nks = w.nks;
     const double *Hpp = w.Hpp, *lm = w.vec, *SC = w.SC;
     double *S = w.S;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P;
@@ -596,8 +678,7 @@ __global__ void lw_schur_prep(const LwWin *ws, int sk) {
             const int r = max(ci, cj), c = min(ci, cj), tr = r >> 6, tc = c >> 6;
             const double *src = SC + ((size_t)(tr * (tr + 1) / 2 + tc)) * 4096 + (r & 63) * 64 + (c & 63);
             double sub = 0;
-#pragma unroll
-            for (int k = 0; k < SY_KS; k++) sub += src[(size_t)k * ntile * 4096];
+            for (int k = 0; k < nks; k++) sub += src[(size_t)k * ntile * 4096];
             v -= sub;
         }
         S[t] = v;
@@ -608,8 +689,7 @@ __global__ void lw_schur_prep(const LwWin *ws, int sk) {
         const int ci = lw_compcol(w, i);
         if (F && ci >= 0) {
             double sub = 0;
-#pragma unroll
-            for (int k = 0; k < SY_KS; k++) sub += SC[(size_t)SY_KS * ntile * 4096 + (size_t)k * nt * 64 + ci];
+            for (int k = 0; k < nks; k++) sub += SC[(size_t)nks * ntile * 4096 + (size_t)k * nt * 64 + ci];
             v -= sub;
         }
         S[nH + i] = v;
@@ -1330,7 +1410,7 @@ struct LwHostWin {
     vilf_window_out *out = nullptr;
     bool resident = false;             // also a slot of the 11-frame batch: its prior applies, the solved state goes back into the batch buffers
     size_t slot = 0;
-    int NF = 0, F = 0, P = 0, N = 0, nvis = 0, nimu = 0, cEx = -1, cTd = -1, PC = 0, WS = 0, nchunk = 0;
+    int NF = 0, F = 0, P = 0, N = 0, nvis = 0, nimu = 0, cEx = -1, cTd = -1, PC = 0, WS = 0, nchunk = 0, npairs_cap = 0, nslots_cap = 0, npairs = 0;
     size_t xo = 0;
     bool use_lidar = false;
     int pn = 0, pnb = 0, phdr[VB_PRIOR_HDR];
@@ -1339,18 +1419,19 @@ struct LwHostWin {
     std::vector<int> fdev;             // host feature index -> device feature index
     std::vector<unsigned char> fc;     // feature_const in device order
     LwWin dw;                          // the descriptor (device pointers)
-    size_t o_vis = 0, o_tdr = 0, o_fconst = 0, o_scal = 0, o_pcol = 0, o_lid = 0, o_kspan = 0, o_fvis = 0, o_fidx = 0;       // offsets of the inputs in the staging image (imu / cov / x: group-wide runs)
+    size_t o_vis = 0, o_tdr = 0, o_fconst = 0, o_scal = 0, o_pcol = 0, o_lid = 0, o_kspan = 0, o_fvis = 0, o_fidx = 0, o_cslot = 0, o_prt = 0, o_froff = 0, o_frlist = 0;       // offsets of the inputs in the staging image (imu / cov / x: group-wide runs)
     // results of the device loop
     LwCtl hc;
 };
 // launch shapes for a set of windows (the whole group, or one window for the host loop): every grid is sized for the largest window, the others' surplus
 // workgroups return at once
 struct LwDims {
-    int G = 0, maxP = 0, maxF = 0, maxNvis = 0, maxNimu = 0, maxPC = 0, maxWS = 0;
+    int G = 0, maxP = 0, maxF = 0, maxNvis = 0, maxNimu = 0, maxPC = 0, maxWS = 0, maxNF = 0, maxNpairs = 0, nks = 4;
     bool any_prior = false;
     void take(const LwHostWin &w) {
         G++; maxP = std::max(maxP, w.P); maxF = std::max(maxF, w.F); maxNvis = std::max(maxNvis, w.nvis); maxNimu = std::max(maxNimu, w.nimu);
-        maxPC = std::max(maxPC, w.PC); maxWS = std::max(maxWS, w.WS);
+        nks = w.dw.nks;
+        maxPC = std::max(maxPC, w.PC); maxWS = std::max(maxWS, w.WS); maxNF = std::max(maxNF, w.NF); maxNpairs = std::max(maxNpairs, w.npairs_cap);
         any_prior = any_prior || w.pn != 0;
     }
 };
@@ -1374,7 +1455,10 @@ struct LwEnq {
         }
         if (d.maxNvis) {
             if (ext) hipLaunchKernelGGL(lw_visual_ext, grid((d.maxNvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, ws, which, jac, sk);
-            else hipLaunchKernelGGL(lw_visual, grid((d.maxNvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, ws, which, jac, sk);
+            else {
+                hipLaunchKernelGGL(lw_visual, grid((d.maxNvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, ws, which, jac, sk);
+                if (jac) hipLaunchKernelGGL(lw_assemble, grid(d.maxNF + d.maxNpairs), dim3(256), 0, h->stream, ws, sk);
+            }
         }
         if (d.any_prior) hipLaunchKernelGGL(lw_prior, grid(1), dim3(256), 0, h->stream, ws, jac, sk);
         hipLaunchKernelGGL(lw_imu_lidar, grid(d.maxNimu), dim3(128), 0, h->stream, ws, which, jac, sk);
@@ -1394,7 +1478,7 @@ struct LwEnq {
             // the Schur reduce over the compact columns: K-split partial tiles of Wn^T Wn (+ Wn^T g_f / sqrt(den) in the diagonal tiles), summed by lw_schur_prep
             tic();
             const int nt = (d.maxPC + 63) / 64;
-            hipLaunchKernelGGL(lw_syrk_mfma, grid(nt * (nt + 1) / 2, SY_KS), dim3(256), 0, h->stream, ws, sk);
+            hipLaunchKernelGGL(lw_syrk_mfma, grid(nt * (nt + 1) / 2, d.nks), dim3(256), 0, h->stream, ws, sk);
             toc(1);
         }
         hipLaunchKernelGGL(lw_schur_prep, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, sk);
@@ -1673,6 +1757,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         if (w.P > vilf_lw_chol_max_n()) { h->err = "window too large for the general path (reduced system above 12288 columns)"; return VILF_ERR_UNSUPPORTED; }
         w.xo = 16 * (size_t)NF + F;
         w.nvis = std::max(0, in->n_obs - F); w.nimu = NF - 1;
+        w.npairs_cap = (int)std::min<long long>(w.nvis, (long long)NF * (NF - 1) / 2); w.nslots_cap = (w.nvis + LW_CH - 1) / LW_CH + w.npairs_cap;
         w.use_lidar = h->opts.use_lidar_const && in->lidar;
         tot_imu += w.nimu; tot_x += w.xo + 8;
     }
@@ -1731,13 +1816,17 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         w.o_kspan = off; off = lw_al(off + (size_t)std::max(w.nchunk, 1) * 2 * sizeof(int));
         w.o_fvis = off; off = lw_al(off + ((size_t)w.F + 1) * sizeof(int));
         w.o_fidx = off; off = lw_al(off + (size_t)std::max(w.nvis, 1) * sizeof(int));
+        w.o_cslot = off; off = lw_al(off + ((size_t)(w.nvis + LW_CH - 1) / LW_CH + 1) * sizeof(int));
+        w.o_prt = off; off = lw_al(off + (size_t)std::max(w.npairs_cap, 1) * 4 * sizeof(int));
+        w.o_froff = off; off = lw_al(off + ((size_t)w.NF + 1) * sizeof(int));
+        w.o_frlist = off; off = lw_al(off + (size_t)std::max(w.npairs_cap, 1) * 2 * sizeof(int));
     }
     const size_t o_imu = off; off = lw_al(off + tot_imu * IMU_REC * 8);
     const size_t o_cov = off; off = lw_al(off + tot_imu * 225 * 8);
     const size_t o_x = off; off = lw_al(off + tot_x * 8);
     const size_t n_input = off;
     const size_t o_ctl = off; off = lw_al(off + (size_t)G * sizeof(LwCtl));
-    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, SC, rhs, tmpP, tmpF, vec, den, rsd, info, nvec, pdx; };
+    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, SC, PS, rhs, tmpP, tmpF, vec, den, rsd, info, nvec, pdx; };
     std::vector<WorkOff> wo(G);
     for (int g = 0; g < G; g++) {
         const LwHostWin &w = hws[g];
@@ -1747,6 +1836,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         o.cand = take((w.xo + 8) * 8); o.Hpp = take(sP * sP * 8); o.W = take(sF * (size_t)w.WS * 8); o.hf = take(sF * 8); o.gp = take(sP * 8); o.gf = take(sF * 8);
         o.S = take((sP + 1) * sP * 8);
         { const size_t nt = (w.PC + 63) / 64, ntile = nt * (nt + 1) / 2; o.SC = take((size_t)SY_KS * (ntile * 4096 + nt * 64) * 8); }
+        o.PS = take((size_t)std::max(w.nslots_cap, 1) * 160 * 8);
         o.rhs = take(sP * 8); o.tmpP = take(sP * 8); o.tmpF = take(sF * 8); o.vec = take(2 * sN * 8);
         o.den = take(sF * 8); o.rsd = take(sF * 8); o.info = take(64); o.nvec = take(7 * sN * 8); o.pdx = take(VB_PRIOR_LD * 8);
     }
@@ -1772,6 +1862,8 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
     }
     const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = h->opts.cauchy_a * h->opts.cauchy_a;      // rho(s) = b log(1 + s / b), b = a^2 (ceres CauchyLoss; same as the batched path)
     std::vector<LwWin> dws(G);
+    int group_nks = 4;                                 // K splits of the Schur reduce: enough workgroups for the chip from a small group's few tiles
+    { int mpc = 1; for (const LwHostWin &w : hws) mpc = std::max(mpc, w.PC); const int nt = (mpc + 63) / 64, tiles = nt * (nt + 1) / 2; group_nks = std::min(SY_KS, std::max(4, (480 + tiles * G - 1) / (tiles * G))); }
     std::vector<size_t> imu_at(G), x_at(G);
     { size_t a = 0, b = 0; for (int g = 0; g < G; g++) { imu_at[g] = a; x_at[g] = b; a += hws[g].nimu; b += hws[g].xo + 8; } }
     auto pack = [&](int g) {
@@ -1811,6 +1903,23 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
                 v.f = w.fdev[f]; v.i = s; v.j = s + (t - o0); v.cst = in->feature_const[f] ? 1 : 0;
                 vis_obs[2 * (size_t)k] = o0; vis_obs[2 * (size_t)k + 1] = t;
             }
+        }
+        {   // slots of the pair-major kernel: a run of equal pairs inside a chunk of LW_CH factors owns one; pair table and the per-frame lists of lw_assemble
+            int *cslot = reinterpret_cast<int *>(st + w.o_cslot), *prt = reinterpret_cast<int *>(st + w.o_prt), *froff = reinterpret_cast<int *>(st + w.o_froff), *frlist = reinterpret_cast<int *>(st + w.o_frlist);
+            int nslot = 0, np = 0, last_key = -1;
+            for (int k = 0; k < nvis; k++) {
+                const int key = vis[k].i * NF + vis[k].j;
+                if (k % LW_CH == 0) cslot[k / LW_CH] = nslot;
+                if (key != last_key) { if (np) prt[4 * (np - 1) + 3] = nslot; prt[4 * np] = vis[k].i; prt[4 * np + 1] = vis[k].j; prt[4 * np + 2] = nslot; np++; last_key = key; nslot++; }
+                else if (k % LW_CH == 0) nslot++;
+            }
+            if (np) prt[4 * (np - 1) + 3] = nslot;
+            w.npairs = np;
+            std::vector<int> cnt((size_t)NF + 1, 0);
+            for (int q = 0; q < np; q++) { cnt[prt[4 * q] + 1]++; cnt[prt[4 * q + 1] + 1]++; }
+            for (int k = 1; k <= NF; k++) cnt[k] += cnt[k - 1];
+            for (int k = 0; k <= NF; k++) froff[k] = cnt[k];
+            for (int q = 0; q < np; q++) { frlist[cnt[prt[4 * q]]++] = q << 1; frlist[cnt[prt[4 * q + 1]]++] = (q << 1) | 1; }
         }
         if (est_td) {                                     // projection_td_factor.cpp:6-21
             LwTd *tdrec = reinterpret_cast<LwTd *>(st + w.o_tdr);
@@ -1880,9 +1989,11 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         const size_t sN = w.N;
         d.NF = NF; d.F = F; d.P = w.P; d.N = w.N; d.nvis = nvis; d.nimu = nimu; d.cEx = w.cEx; d.cTd = w.cTd; d.xo = (int)w.xo; d.est_ex = est_ex ? 1 : 0; d.est_td = est_td ? 1 : 0;
         d.use_lidar = w.use_lidar ? 1 : 0; d.pn = w.pn; d.pnb = w.pnb; d.max_it = h->opts.max_num_iterations;
-        d.PC = w.PC; d.WS = w.WS; d.nchunk = w.nchunk;
+        d.PC = w.PC; d.WS = w.WS; d.nchunk = w.nchunk; d.nks = group_nks;
         d.kspan = reinterpret_cast<const int *>(dev + w.o_kspan);
         d.fvis = reinterpret_cast<const int *>(dev + w.o_fvis); d.fidx = reinterpret_cast<const int *>(dev + w.o_fidx);
+        d.PS = reinterpret_cast<double *>(dev + o.PS); d.cslot = reinterpret_cast<const int *>(dev + w.o_cslot); d.prt = reinterpret_cast<const int *>(dev + w.o_prt);
+        d.froff = reinterpret_cast<const int *>(dev + w.o_froff); d.frlist = reinterpret_cast<const int *>(dev + w.o_frlist); d.npairs = w.npairs;
         d.sqrt_info = sqrt_info; d.cauchy_b = cauchy_b; d.tr_over_row = h->opts.TR / h->opts.ROW;
         d.ctl = reinterpret_cast<LwCtl *>(dev + o_ctl) + g;
         d.x = reinterpret_cast<double *>(dev + o_x) + at_x; d.cand = reinterpret_cast<double *>(dev + o.cand);
