@@ -64,6 +64,9 @@ struct LwWin {
     // lw_assemble adds the slots of a pair / of a frame's pairs in slot order. cslot: first slot of a chunk; prt: per pair {i, j, first slot, end slot}; froff / frlist:
     // CSR per frame of (pair << 1 | 0: the frame is the pair's i, 1: its j)
     double *PS; const int *cslot, *prt, *froff, *frlist; int npairs, pad3_;
+    // structure: Hpp(i, j) can be non-zero only for frames |f_i - f_j| <= bandf (feature track lengths; IMU / LiDAR factors join neighbours; NF when a prior or Ex_Pose /
+    // td columns couple everything), row f of W only in the compact columns fspan[2 f] .. fspan[2 f + 1] (its frames) and the Ex_Pose / td columns at the end
+    int bandf, pad4_; const int *fspan;
     const int *fvis, *fidx;                        // CSR over the features: the factors of feature f are vis[fidx[fvis[f] .. fvis[f + 1])] (vis itself is pair-sorted)
     const int *kspan;                              // the device's feature order is by start frame (the host permutes on the way in and out); per K-chunk of SY_KB
                                                    // features: first and last compact column any of them touches
@@ -86,6 +89,12 @@ __device__ __forceinline__ int lw_compcol(const LwWin &w, int i) {
     if (i < np) { const int r = i % 15; return r < 6 ? 6 * (i / 15) + r : -1; }
     if (w.est_ex && i >= w.cEx && i < w.cEx + 6) return 6 * w.NF + (i - w.cEx);
     return (w.est_td && i == w.cTd) ? 6 * w.NF + (w.est_ex ? 6 : 0) : -1;
+}
+__device__ __forceinline__ bool lw_inband(const LwWin &w, int i, int j) {
+    const int np = 15 * w.NF;
+    if (i >= np || j >= np) return true;
+    const int d = i / 15 - j / 15;
+    return d <= w.bandf && -d <= w.bandf;
 }
 #define SY_KB 32
 #define SY_KS 16                                   // most K splits of the Schur reduce (partials in their own buffers, summed in fixed order by lw_schur_prep); a group uses
@@ -514,35 +523,43 @@ __global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, 
 }
 // zero the accumulation targets of one linearisation that are summed into with atomics (Hpp, g_p) and the cost: four entries per thread. W, h_f and g_f are
 // written whole by lw_feature_rows.
-__global__ __launch_bounds__(256) void lw_clear(const LwWin *ws, int sk) {
+__global__ __launch_bounds__(256) void lw_clear(const LwWin *ws, int full, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const size_t n0 = (size_t)w.P * w.P, n3 = w.P;
-    double *a0 = w.Hpp, *a3 = w.gp, *cost = w.scal;
-    const size_t t0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (t0 > n0 + n3) return;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        size_t t = t0 + u;
-        if (t < n0) { a0[t] = 0.0; continue; } t -= n0;
-        if (t < n3) { a3[t] = 0.0; continue; } t -= n3;
-        if (t == 0) cost[0] = 0.0;
-    }
+    const int P = w.P, i = blockIdx.x, tid = threadIdx.x;
+    if (i > P) return;
+    if (i == P) { for (int c = tid; c < P; c += 256) w.gp[c] = 0.0; if (tid == 0) w.scal[0] = 0.0; return; }
+    // row i of Hpp: outside the band nothing is ever added — zero since the solve's first (full) clear
+    double *row = w.Hpp + (size_t)i * P;
+    const int np = 15 * w.NF, fr = i / 15;
+    const int c0 = (full || i >= np) ? 0 : 15 * max(0, fr - w.bandf), c1 = (full || i >= np) ? np : min(np, 15 * (fr + w.bandf + 1));
+    for (int c = c0 + tid; c < c1; c += 256) row[c] = 0.0;
+    for (int c = np + tid; c < P; c += 256) row[c] = 0.0;
 }
 // Jacobi scaling in place: Hpp(i, j) *= s_i s_j, W(f, c) *= s_f s_c, h_f *= s_f^2, g *= s. s = [P pose/speed-bias entries | F features] (src 0: the minimizer's
 // scale vector, 1: vec — the host loop uploads it there)
-__global__ void lw_scale(const LwWin *ws, int src, int sk) {
+__global__ __launch_bounds__(256) void lw_scale(const LwWin *ws, int src, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int P = w.P, F = w.F;
+    const int P = w.P, F = w.F, b = blockIdx.x, tid = threadIdx.x;
     const double *s = src ? w.vec : w.scale;
-    double *Hpp = w.Hpp, *W = w.W, *hf = w.hf, *gp = w.gp, *gf = w.gf;
-    const int WS = w.WS, PC = w.PC;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P, nW = (size_t)F * WS;
-    if (t < nH) { const int i = (int)(t / P), j = (int)(t % P); Hpp[t] *= s[i] * s[j]; }
-    else if (t < nH + nW) { const size_t u = t - nH; const int f = (int)(u / WS), c = (int)(u % WS); if (c < PC) W[u] *= s[P + f] * s[lw_fullcol(w, c)]; }
-    else if (t < nH + nW + F) { const int f = (int)(t - nH - nW); hf[f] *= s[P + f] * s[P + f]; gf[f] *= s[P + f]; }
-    else if (t < nH + nW + F + P) { const int i = (int)(t - nH - nW - F); gp[i] *= s[i]; }
+    if (b < P) {                                       // row b of Hpp: its band (zeros elsewhere), and g_p[b]
+        double *row = w.Hpp + (size_t)b * P;
+        const double si = s[b];
+        const int np = 15 * w.NF, fr = b / 15;
+        const int c0 = b >= np ? 0 : 15 * max(0, fr - w.bandf), c1 = b >= np ? np : min(np, 15 * (fr + w.bandf + 1));
+        for (int c = c0 + tid; c < c1; c += 256) row[c] *= si * s[c];
+        for (int c = np + tid; c < P; c += 256) row[c] *= si * s[c];
+        if (tid == 0) w.gp[b] *= si;
+        return;
+    }
+    const int f = (b - P) * 4 + (tid >> 6), lane = tid & 63;       // a wave per row of W: its span and the Ex_Pose / td columns; h_f, g_f
+    if (f >= F) return;
+    const double sf = s[P + f];
+    double *row = w.W + (size_t)f * w.WS;
+    for (int c = w.fspan[2 * f] + lane; c <= w.fspan[2 * f + 1]; c += 64) row[c] *= sf * s[lw_fullcol(w, c)];
+    for (int c = 6 * w.NF + lane; c < w.PC; c += 64) row[c] *= sf * s[lw_fullcol(w, c)];
+    if (lane == 0) { w.hf[f] *= sf * sf; w.gf[f] *= sf; }
 }
 // ---- the Schur reduce Wn^T Wn as a hand-written fp64 MFMA SYRK over the compact (pose-only) columns ----------------------------------------
 // W is F x WS row-major, one row per feature, PC columns used; Wn = W / sqrt(den_f) with den_f = h_f + lm_f^2 (1 for a constant feature: its row is zero) is formed
@@ -663,38 +680,39 @@ __global__ __launch_bounds__(256) void lw_syrk_mfma(const LwWin *ws, int sk) {
 }
 // S = Hpp + diag(lm_p^2) - sum over the K splits of Wn^T Wn (the partial tiles of lw_syrk_mfma, summed in split order: no atomics); row P of S = g_p - Wn^T (g_f /
 // sqrt(den)) (the right-hand side rides through the factorisation as one more row); the factorisation's status word = 0.
-__global__ void lw_schur_prep(const LwWin *ws, int sk) {
+__global__ __launch_bounds__(256) void lw_schur_prep(const LwWin *ws, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int P = w.P, F = w.F, nt = SY_NT(w.PC), ntile = nt * (nt + 1) / 2, nks = w.nks;
-    const double *Hpp = w.Hpp, *lm = w.vec, *SC = w.SC;
-    double *S = w.S;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nH = (size_t)P * P;
-    if (t < nH) {
-        const int i = (int)(t / P), j = (int)(t % P);
-        double v = Hpp[t] + (i == j ? lm[i] * lm[i] : 0.0);
-        const int ci = lw_compcol(w, i), cj = lw_compcol(w, j);
+    const int P = w.P, F = w.F, nt = SY_NT(w.PC), ntile = nt * (nt + 1) / 2, nks = w.nks, i = blockIdx.x, tid = threadIdx.x;
+    if (i > P) return;
+    const double *lm = w.vec, *SC = w.SC;
+    double *row = w.S + (size_t)i * P;
+    if (i == P) {                                      // the right-hand side's row
+        for (int c = tid; c < P; c += 256) {
+            double v = w.gp[c];
+            const int cc = lw_compcol(w, c);
+            if (F && cc >= 0) { double sub = 0; for (int k = 0; k < nks; k++) sub += SC[(size_t)nks * ntile * 4096 + (size_t)k * nt * 64 + cc]; v -= sub; }
+            row[c] = v;
+        }
+        if (tid == 0) *w.info = 0;
+        return;
+    }
+    const double *hrow = w.Hpp + (size_t)i * P;
+    const int np = 15 * w.NF, fr = i / 15, ci = lw_compcol(w, i);
+    const int c0 = i >= np ? 0 : 15 * max(0, fr - w.bandf), c1 = i >= np ? np : min(np, 15 * (fr + w.bandf + 1));
+    for (int c = tid; c < P; c += 256) {
+        if (c < np && (c < c0 || c >= c1)) { row[c] = 0.0; continue; }      // structurally zero: nothing to read
+        double v = hrow[c] + (i == c ? lm[i] * lm[i] : 0.0);
+        const int cj = lw_compcol(w, c);
         if (F && ci >= 0 && cj >= 0) {
-            const int r = max(ci, cj), c = min(ci, cj), tr = r >> 6, tc = c >> 6;
-            const double *src = SC + ((size_t)(tr * (tr + 1) / 2 + tc)) * 4096 + (r & 63) * 64 + (c & 63);
+            const int r = max(ci, cj), cm = min(ci, cj), tr = r >> 6, tc = cm >> 6;
+            const double *src = SC + ((size_t)(tr * (tr + 1) / 2 + tc)) * 4096 + (r & 63) * 64 + (cm & 63);
             double sub = 0;
             for (int k = 0; k < nks; k++) sub += src[(size_t)k * ntile * 4096];
             v -= sub;
         }
-        S[t] = v;
+        row[c] = v;
     }
-    else if (t < nH + P) {
-        const int i = (int)(t - nH);
-        double v = w.gp[i];
-        const int ci = lw_compcol(w, i);
-        if (F && ci >= 0) {
-            double sub = 0;
-            for (int k = 0; k < nks; k++) sub += SC[(size_t)nks * ntile * 4096 + (size_t)k * nt * 64 + ci];
-            v -= sub;
-        }
-        S[nH + i] = v;
-    }
-    else if (t == nH + P) *w.info = 0;
 }
 
 // ---- dense Cholesky of the reduced system (P x P, fp64) with the right-hand side as row P: S = L L^T, L[P][0..P-1] = L^-1 rhs -----------------------
@@ -1044,8 +1062,16 @@ __global__ __launch_bounds__(256) void lw_rowdot(const LwWin *ws, int mode, int 
     const int r = hp ? row : (mode == 0 ? row - w.P : row);
     const double *x = mode == 0 ? w.vec : w.rhs;
     double s = 0;
-    if (hp) { const double *a = w.Hpp + (size_t)r * w.P; for (int c = lane; c < w.P; c += 64) s += a[c] * x[c]; }
-    else { const double *a = w.W + (size_t)r * w.WS; for (int c = lane; c < w.PC; c += 64) s += a[c] * x[lw_fullcol(w, c)]; }
+    if (hp) {                                          // the band's columns (and the Ex_Pose / td columns behind the frames)
+        const double *a = w.Hpp + (size_t)r * w.P;
+        const int np = 15 * w.NF, fr = r / 15, c0 = r >= np ? 0 : 15 * max(0, fr - w.bandf), c1 = r >= np ? np : min(np, 15 * (fr + w.bandf + 1));
+        for (int c = c0 + lane; c < c1; c += 64) s += a[c] * x[c];
+        for (int c = np + lane; c < w.P; c += 64) s += a[c] * x[c];
+    } else {                                           // a row of W: its span and the Ex_Pose / td columns
+        const double *a = w.W + (size_t)r * w.WS;
+        for (int c = w.fspan[2 * r] + lane; c <= w.fspan[2 * r + 1]; c += 64) s += a[c] * x[lw_fullcol(w, c)];
+        for (int c = 6 * w.NF + lane; c < w.PC; c += 64) s += a[c] * x[lw_fullcol(w, c)];
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (lane == 0) {
@@ -1419,7 +1445,7 @@ struct LwHostWin {
     std::vector<int> fdev;             // host feature index -> device feature index
     std::vector<unsigned char> fc;     // feature_const in device order
     LwWin dw;                          // the descriptor (device pointers)
-    size_t o_vis = 0, o_tdr = 0, o_fconst = 0, o_scal = 0, o_pcol = 0, o_lid = 0, o_kspan = 0, o_fvis = 0, o_fidx = 0, o_cslot = 0, o_prt = 0, o_froff = 0, o_frlist = 0;       // offsets of the inputs in the staging image (imu / cov / x: group-wide runs)
+    size_t o_vis = 0, o_tdr = 0, o_fconst = 0, o_scal = 0, o_pcol = 0, o_lid = 0, o_kspan = 0, o_fvis = 0, o_fidx = 0, o_cslot = 0, o_prt = 0, o_froff = 0, o_frlist = 0, o_fspan = 0;       // offsets of the inputs in the staging image (imu / cov / x: group-wide runs)
     // results of the device loop
     LwCtl hc;
 };
@@ -1437,6 +1463,7 @@ struct LwDims {
 };
 struct LwEnq {
     vilf_handle *h; LwCtx *c; const LwWin *ws; LwDims d; bool ext, prof;
+    bool cleared_full = false;         // the first linearisation of a solve clears all of Hpp, the later ones its band
     void tic() { if (prof) hipEventRecord(c->ev[0], h->stream); }
     void toc(int grp) { if (prof) { hipEventRecord(c->ev[1], h->stream); hipEventSynchronize(c->ev[1]); float t = 0; hipEventElapsedTime(&t, c->ev[0], c->ev[1]); c->ms[grp] += t; c->launches[grp] += 1; } }
     dim3 grid(size_t gx, unsigned gy = 1) const { return dim3((unsigned)std::max<size_t>(gx, 1), gy, (unsigned)d.G); }
@@ -1444,8 +1471,8 @@ struct LwEnq {
     void evaluate(int which, int jac, int sk) {
         const size_t sP = d.maxP;
         if (jac) {      // one launch clears the cost and the five accumulation targets
-            const size_t tot = sP * sP + sP + 1;
-            hipLaunchKernelGGL(lw_clear, grid((tot + 1023) / 1024), dim3(256), 0, h->stream, ws, sk);
+            hipLaunchKernelGGL(lw_clear, grid(sP + 1), dim3(256), 0, h->stream, ws, cleared_full ? 0 : 1, sk);
+            cleared_full = true;
             tic();
         }
         if (d.maxNvis && jac) {                       // the rows of W, h_f, g_f: feature-major
@@ -1467,12 +1494,11 @@ struct LwEnq {
     // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in vec
     void quad(int sk) { hipLaunchKernelGGL(lw_rowdot, grid((d.maxP + d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, 0, sk); }
     void scale(int src, int sk) {
-        const size_t sP = d.maxP, sF = d.maxF, tot = sP * sP + sF * d.maxWS + sF + sP;
-        hipLaunchKernelGGL(lw_scale, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, src, sk);
+        hipLaunchKernelGGL(lw_scale, grid((size_t)d.maxP + (d.maxF + 3) / 4), dim3(256), 0, h->stream, ws, src, sk);
     }
     // one linear solve (H' + lm^2) y = g' with lm in vec: y_p -> rhs, y_f -> yf, the Cholesky's status -> info
     void linear_solve(int sk) {
-        const size_t sP = d.maxP, tot = sP * sP + sP + 1;
+        const size_t sP = d.maxP;
         if (d.maxF) {
             hipLaunchKernelGGL(lw_den, grid((d.maxF + 255) / 256), dim3(256), 0, h->stream, ws, sk);
             // the Schur reduce over the compact columns: K-split partial tiles of Wn^T Wn (+ Wn^T g_f / sqrt(den) in the diagonal tiles), summed by lw_schur_prep
@@ -1481,7 +1507,7 @@ struct LwEnq {
             hipLaunchKernelGGL(lw_syrk_mfma, grid(nt * (nt + 1) / 2, d.nks), dim3(256), 0, h->stream, ws, sk);
             toc(1);
         }
-        hipLaunchKernelGGL(lw_schur_prep, grid((tot + 255) / 256), dim3(256), 0, h->stream, ws, sk);
+        hipLaunchKernelGGL(lw_schur_prep, grid(sP + 1), dim3(256), 0, h->stream, ws, sk);
         tic();
         for (int j0 = 0; j0 < d.maxP; j0 += CH_NB) {                     // blocked Cholesky, one launch per 64-column block (panel of this column + the rest of the previous column's update)
             const int nb = std::min(CH_NB, d.maxP - j0), below = d.maxP + 1 - (j0 + nb), npanel = std::max(1, (below + CH_BELOW - 1) / CH_BELOW);
@@ -1815,6 +1841,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         w.o_pcol = off; off = lw_al(off + VB_PRIOR_LD * sizeof(int));
         w.o_kspan = off; off = lw_al(off + (size_t)std::max(w.nchunk, 1) * 2 * sizeof(int));
         w.o_fvis = off; off = lw_al(off + ((size_t)w.F + 1) * sizeof(int));
+        w.o_fspan = off; off = lw_al(off + (size_t)std::max(w.F, 1) * 2 * sizeof(int));
         w.o_fidx = off; off = lw_al(off + (size_t)std::max(w.nvis, 1) * sizeof(int));
         w.o_cslot = off; off = lw_al(off + ((size_t)(w.nvis + LW_CH - 1) / LW_CH + 1) * sizeof(int));
         w.o_prt = off; off = lw_al(off + (size_t)std::max(w.npairs_cap, 1) * 4 * sizeof(int));
@@ -1863,7 +1890,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
     const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = h->opts.cauchy_a * h->opts.cauchy_a;      // rho(s) = b log(1 + s / b), b = a^2 (ceres CauchyLoss; same as the batched path)
     std::vector<LwWin> dws(G);
     int group_nks = 4;                                 // K splits of the Schur reduce: enough workgroups for the chip from a small group's few tiles
-    { int mpc = 1; for (const LwHostWin &w : hws) mpc = std::max(mpc, w.PC); const int nt = (mpc + 63) / 64, tiles = nt * (nt + 1) / 2; group_nks = std::min(SY_KS, std::max(4, (480 + tiles * G - 1) / (tiles * G))); }
+    { int mpc = 1; for (const LwHostWin &w : hws) mpc = std::max(mpc, w.PC); const int nt = (mpc + 63) / 64, tiles = nt * (nt + 1) / 2; group_nks = std::min(SY_KS, std::max(4, (480 + tiles * G - 1) / (tiles * G))); if (const char *e = std::getenv("VILF_LW_NKS")) group_nks = std::min(SY_KS, std::max(1, std::atoi(e))); }
     std::vector<size_t> imu_at(G), x_at(G);
     { size_t a = 0, b = 0; for (int g = 0; g < G; g++) { imu_at[g] = a; x_at[g] = b; a += hws[g].nimu; b += hws[g].xo + 8; } }
     auto pack = [&](int g) {
@@ -1872,13 +1899,16 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         LwHostWin &w = hws[g];
         const vilf_window_in *in = w.in;
         const int NF = w.NF, F = w.F, nvis = w.nvis, nimu = w.nimu;
-        // the device's feature order: by start frame (counting sort, stable) — the Schur reduce runs K over the features and skips what a tile's columns cannot meet
+        // the device's feature order: by (start frame, track length) (counting sort, stable) — the Schur reduce runs K over the features in chunks and skips a chunk
+        // for the tiles its features' frames cannot meet: neighbours in this order have similar spans
         w.fdev.assign(std::max(F, 1), 0); w.fc.assign(std::max(F, 1), 0);
         {
-            std::vector<int> cnt((size_t)NF + 1, 0);
-            for (int f = 0; f < F; f++) cnt[in->feature_start_frame[f] + 1]++;
-            for (int k = 1; k <= NF; k++) cnt[k] += cnt[k - 1];
-            for (int f = 0; f < F; f++) { const int dvi = cnt[in->feature_start_frame[f]]++; w.fdev[f] = dvi; w.fc[dvi] = in->feature_const[f] ? 1 : 0; }
+            const size_t nkey = (size_t)NF * (NF + 1) + 1;
+            std::vector<int> cnt(nkey + 1, 0);
+            auto key = [&](int f) { return (size_t)in->feature_start_frame[f] * (NF + 1) + std::min(NF, std::max(0, in->feature_obs_offset[f + 1] - in->feature_obs_offset[f])); };
+            for (int f = 0; f < F; f++) cnt[key(f) + 1]++;
+            for (size_t k = 1; k <= nkey; k++) cnt[k] += cnt[k - 1];
+            for (int f = 0; f < F; f++) { const int dvi = cnt[key(f)]++; w.fdev[f] = dvi; w.fc[dvi] = in->feature_const[f] ? 1 : 0; }
         }
         // pair-sorted (lw_visual flushes one block per run of equal pairs): counting sort over the NF^2 pair keys, stable in feature order
         LwVis *vis = reinterpret_cast<LwVis *>(st + w.o_vis);
@@ -1946,12 +1976,15 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
             else lid[7 * k + 3] = 1.0;
         }
         if (F) std::memcpy(st + w.o_fconst, w.fc.data(), F);
+        int bandf = 1;
         {   // per chunk of SY_KB features (device order) the compact columns their frame spans cover; with Ex_Pose / td as variables every row also reaches the last columns
-            int *kspan = reinterpret_cast<int *>(st + w.o_kspan);
+            int *kspan = reinterpret_cast<int *>(st + w.o_kspan), *fspan = reinterpret_cast<int *>(st + w.o_fspan);
             for (int q = 0; q < w.nchunk; q++) { kspan[2 * q] = w.PC; kspan[2 * q + 1] = -1; }
             for (int f = 0; f < F; f++) {
-                if (in->feature_const[f]) continue;                       // a constant depth: no row in W
                 const int s0 = in->feature_start_frame[f], nobs = in->feature_obs_offset[f + 1] - in->feature_obs_offset[f], q = w.fdev[f] / SY_KB;
+                fspan[2 * w.fdev[f]] = 6 * s0; fspan[2 * w.fdev[f] + 1] = (nobs < 2 || in->feature_const[f]) ? 6 * s0 - 1 : 6 * (s0 + nobs - 1) + 5;      // empty span: the row is zero
+                if (nobs >= 2) bandf = std::max(bandf, nobs - 1);         // constant-depth features too: their factors still fill pose-pose blocks
+                if (in->feature_const[f]) continue;                       // a constant depth: no row in W
                 if (nobs < 2) continue;
                 kspan[2 * q] = std::min(kspan[2 * q], 6 * s0);
                 kspan[2 * q + 1] = std::max(kspan[2 * q + 1], w.PC > 6 * NF ? w.PC - 1 : 6 * (s0 + nobs - 1) + 5);      // lo > hi: nothing in this chunk
@@ -1990,7 +2023,8 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         d.NF = NF; d.F = F; d.P = w.P; d.N = w.N; d.nvis = nvis; d.nimu = nimu; d.cEx = w.cEx; d.cTd = w.cTd; d.xo = (int)w.xo; d.est_ex = est_ex ? 1 : 0; d.est_td = est_td ? 1 : 0;
         d.use_lidar = w.use_lidar ? 1 : 0; d.pn = w.pn; d.pnb = w.pnb; d.max_it = h->opts.max_num_iterations;
         d.PC = w.PC; d.WS = w.WS; d.nchunk = w.nchunk; d.nks = group_nks;
-        d.kspan = reinterpret_cast<const int *>(dev + w.o_kspan);
+        d.kspan = reinterpret_cast<const int *>(dev + w.o_kspan); d.fspan = reinterpret_cast<const int *>(dev + w.o_fspan);
+        d.bandf = (w.pn || est_ex || est_td) ? NF : std::min(NF, bandf);
         d.fvis = reinterpret_cast<const int *>(dev + w.o_fvis); d.fidx = reinterpret_cast<const int *>(dev + w.o_fidx);
         d.PS = reinterpret_cast<double *>(dev + o.PS); d.cslot = reinterpret_cast<const int *>(dev + w.o_cslot); d.prt = reinterpret_cast<const int *>(dev + w.o_prt);
         d.froff = reinterpret_cast<const int *>(dev + w.o_froff); d.frlist = reinterpret_cast<const int *>(dev + w.o_frlist); d.npairs = w.npairs;
@@ -2013,7 +2047,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         w.dw = d;
     };
     {   // a group's windows are packed by a few host threads (a stress window is ~3 MB of factor records)
-        const int nthr = (int)std::min<size_t>({(size_t)G, (size_t)8, (size_t)std::max(1u, std::thread::hardware_concurrency())});
+        const int nthr = (int)std::min<size_t>({(size_t)G, (size_t)12, (size_t)std::max(1u, std::thread::hardware_concurrency())});
         size_t tot_vis = 0;
         for (const LwHostWin &w : hws) tot_vis += w.nvis;
         if (nthr <= 1 || tot_vis < 20000) for (int g = 0; g < G; g++) pack(g);

@@ -59,17 +59,28 @@ class BackendSolver:
         self._check(self._L.vilf_window_solve(self._h, C.byref(s), C.byref(res.struct)), "vilf_window_solve")
         return res.finish()
 
-    def optimization_group(self, windows):
-        """several windows of sizes other than 11 frames (the general path) side by side in one chain of launches ≙ one optimization() each"""
+    def prepare_group(self, windows):
+        """the ctypes views of a group of windows (input structs + result buffers), built once: a caller that solves the same group repeatedly (bench) or keeps
+        its windows in C structs anyway does not pay the per-call conversion"""
         n = len(windows)
         res = [abi.WindowResult(w.n_frames, w.n_features) for w in windows]
         ins = (abi.WindowIn * n)(); outs = (abi.WindowOut * n)()
         for i, w in enumerate(windows):
             ins[i] = w.as_struct(); outs[i] = res[i].struct
-        self._check(self._L.vilf_window_solve_group(self._h, n, ins, outs), "vilf_window_solve_group")
-        for i in range(n):
-            res[i].struct = outs[i]              # the summaries were written into the array's copies (the buffers they point to are the results' own)
-        return [r.finish() for r in res]
+        return dict(n=n, ins=ins, outs=outs, res=res, windows=windows)
+
+    def solve_group(self, group, finish=True):
+        """vilf_window_solve_group on a prepared group; finish=False skips the numpy unpacking of the results (the summaries are in group["outs"][i].summary)"""
+        self._check(self._L.vilf_window_solve_group(self._h, group["n"], group["ins"], group["outs"]), "vilf_window_solve_group")
+        if not finish:
+            return group["outs"]
+        for i, r in enumerate(group["res"]):
+            r.struct = group["outs"][i]          # the summaries were written into the array's copies (the buffers they point to are the results' own)
+        return [r.finish() for r in group["res"]]
+
+    def optimization_group(self, windows):
+        """several windows of sizes other than 11 frames (the general path) side by side in one chain of launches ≙ one optimization() each"""
+        return self.solve_group(self.prepare_group(windows))
 
     def marginalize(self):
         self._check(self._L.vilf_window_marginalize(self._h), "vilf_window_marginalize")
