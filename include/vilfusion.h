@@ -189,7 +189,8 @@ const char *vilf_version(void);
 int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_window_out *out);
 /* n independent windows of sizes other than 11 frames (the general path), solved side by side in ONE chain of launches: a window's chain is ~32 small dependent
  * launches per iteration, so a group fills the chip where a single window (or one handle / stream per window) cannot. in / out: arrays of n; every out[i] needs
- * Ps / Rs / Vs / Bas / Bgs. Same results as n calls of vilf_window_solve (to the rounding of the atomics' summation order). 11-frame windows:
+ * Ps / Rs / Vs / Bas / Bgs. Same results as n calls of vilf_window_solve, bit for bit (no reduction on this path depends on the order in which workgroups finish; with
+ * options.estimate_extrinsic / estimate_td: to the rounding of the remaining atomics). 11-frame windows:
  * VILF_ERR_UNSUPPORTED (use vilf_batch_*). Returns VILF_SOLVER_ABNORMAL if any window terminated abnormally (its summary tells). */
 int vilf_window_solve_group(vilf_handle *h, int n, const vilf_window_in *in, vilf_window_out *out);
 /* estimator.cpp:863-1046: marginalization of the just-solved window (slot 0); new prior stays on device. */

@@ -23,7 +23,9 @@
 // columns after the frame blocks) and estimate_td (ProjectionTdFactor, one more column) — estimator.cpp:701-717,765-777. For an 11-frame
 // window it then also applies the slot-0 marginalization prior resident on the device (lw_prior) and writes the solved state back into the
 // batch buffers, so that vilf_window_marginalize() continues from it. Other window sizes have no prior (no device marginalization).
-// Summation order of the atomics is not fixed: results are reproducible to rounding (~1e-12 relative), not bit for bit.
+// No sum on the plain path (Ex_Pose / td constant) depends on an order the hardware picks: fixed reduction trees, host-assigned slots summed in slot order, one writer per
+// entry — a window's result is bit-reproducible, alone or in any group. The estimate_extrinsic / estimate_td variant (lw_visual_ext) and the prior (lw_prior) still add
+// their pose blocks with hardware atomics: reproducible to rounding (~1e-12 relative) there.
 // Groups: every kernel of this file takes an array of window descriptors (LwWin, one per window, resident on the device) and finds its window in blockIdx.z —
 // ONE chain of launches solves G independent windows side by side (vilf_window_solve_group; the estimate_td / estimate_extrinsic slots of vilf_batch_solve).
 // A window's chain is ~32 small dependent launches per iteration on a handful of workgroups, so a single window leaves most of the chip idle and G handles on G
@@ -66,7 +68,9 @@ struct LwWin {
     double *PS; const int *cslot, *prt, *froff, *frlist; int npairs, pad3_;
     // structure: Hpp(i, j) can be non-zero only for frames |f_i - f_j| <= bandf (feature track lengths; IMU / LiDAR factors join neighbours; NF when a prior or Ex_Pose /
     // td columns couple everything), row f of W only in the compact columns fspan[2 f] .. fspan[2 f + 1] (its frames) and the Ex_Pose / td columns at the end
-    int bandf, pad4_; const int *fspan;
+    int bandf, ncostv; const int *fspan;
+    double *costP;                                 // cost partials, one per producing workgroup: [0, ncostv) lw_visual chunks, [ncostv, ncostv + NF) frames of lw_imu_lidar,
+                                                   // [ncostv + NF] lw_prior — summed in this order by tr_cost_sum (no atomics: the cost is bit-reproducible)
     const int *fvis, *fidx;                        // CSR over the features: the factors of feature f are vis[fidx[fvis[f] .. fvis[f + 1])] (vis itself is pair-sorted)
     const int *kspan;                              // the device's feature order is by start frame (the host permutes on the way in and out); per K-chunk of SY_KB
                                                    // features: first and last compact column any of them touches
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, i
     if ((int)blockIdx.x * LW_CH >= n) return;         // the grid is sized for the group's largest window
     const double *x = which ? w.cand : w.x, *ex = x + w.xo;
     const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b;
-    double *PS = w.PS, *cost = w.scal;
+    double *PS = w.PS;
     const LwVis *vis = w.vis;
     __shared__ double s_J[LW_CH][26];                 // 24 Jacobian entries (row 0: 12, row 1: 12), r0, r1
     __shared__ double s_red[4][64];
@@ -221,7 +225,10 @@ __global__ __launch_bounds__(LW_CH) void lw_visual(const LwWin *ws, int which, i
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((tid & 63) == 0 && c != 0.0) add(cost, c);
+    __syncthreads();                                  // s_red is free again
+    if ((tid & 63) == 0) s_red[0][tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) w.costP[blockIdx.x] = s_red[0][0] + s_red[0][1];       // this workgroup's own slot: summed in slot order by tr_cost_sum
 }
 
 // The same chunked scatter with Ex_Pose and / or td as variables (estimate_extrinsic / estimate_td): 19 Jacobian columns per factor row
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int whic
     if ((int)blockIdx.x * LW_CH >= n) return;
     const double *x = which ? w.cand : w.x;
     const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b, tr_over_row = w.tr_over_row;
-    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
+    double *Hpp = w.Hpp, *gp = w.gp;
     const LwVis *vis = w.vis; const LwTd *tdr = w.tdr;
     __shared__ double s_J[LW_CH][41];                 // row 0: 19, row 1: 19, r0, r1 (+ 1 pad)
     __shared__ int s_pair[LW_CH + 1];
@@ -304,7 +311,11 @@ __global__ __launch_bounds__(LW_CH) void lw_visual_ext(const LwWin *ws, int whic
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((tid & 63) == 0 && c != 0.0) add(cost, c);
+    __syncthreads();
+    double *s_cw = &s_J[0][0];                        // the Jacobian rows are done with
+    if ((tid & 63) == 0) s_cw[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) w.costP[blockIdx.x] = s_cw[0] + s_cw[1];
 }
 // Hpp's pose-pose blocks and g_p's pose parts of the visual factors from the slots of lw_visual, every entry by ONE thread in slot order (bit-reproducible, plain
 // stores into the cleared arrays; the IMU / LiDAR / prior kernels add on top afterwards). Workgroup b < NF: frame b's diagonal block = the i-i parts of the
@@ -451,74 +462,92 @@ __global__ __launch_bounds__(256) void lw_prior(const LwWin *ws, int jac, int sk
     if (lw_skip(w, sk) || !w.pn) return;
     const int n = w.pn, P = w.P;
     const double *J = w.pJ, *r0 = w.pr0, *H0 = w.pH0, *dx = w.pdx; const int *pcol = w.pcol;
-    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
+    double *Hpp = w.Hpp, *gp = w.gp;
     __shared__ double s_r[VB_PRIOR_LD], s_dx[VB_PRIOR_LD];
     const int tid = threadIdx.x;
     for (int i = tid; i < n; i += 256) s_dx[i] = dx[i];
     __syncthreads();
     for (int k = tid; k < n; k += 256) { double s = r0[k]; for (int i = 0; i < n; i++) s += J[(size_t)k * n + i] * s_dx[i]; s_r[k] = s; }
     __syncthreads();
-    if (tid == 0) { double c = 0; for (int k = 0; k < n; k++) c += 0.5 * s_r[k] * s_r[k]; add(cost, c); }
+    if (tid == 0) { double c = 0; for (int k = 0; k < n; k++) c += 0.5 * s_r[k] * s_r[k]; w.costP[w.ncostv + w.NF] = c; }
     if (!jac) return;
     for (int i = tid; i < n; i += 256) { if (pcol[i] < 0) continue; double s = 0; for (int k = 0; k < n; k++) s += J[(size_t)k * n + i] * s_r[k]; add(gp + pcol[i], s); }
     for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e - i * n; if (pcol[i] >= 0 && pcol[j] >= 0) add(Hpp + (size_t)pcol[i] * P + pcol[j], H0[(size_t)i * VB_PRIOR_LD + j]); }
 }
-// IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair: ONE workgroup per frame pair. Lane 0 of wave
-// 0 evaluates the raw IMU residual / Jacobian into LDS, lane 0 of wave 1 the LiDAR factor; the products with sqrt_info (15 x 15 upper triangular times 15 x 31) and
-// the LiDAR J^T [J r] entries are then one lane per entry. (A lane per factor kept its 15 x 30 Jacobian in a dynamically indexed local array = scratch memory, and
-// walked the 7 k multiply-adds of S J alone: 127 us per launch, 17 launches per solve.)
-__global__ __launch_bounds__(128) void lw_imu_lidar(const LwWin *ws, int which, int jac, int sk) {
+// IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair, FRAME-major: workgroup f owns the rows of
+// frame f of Hpp and g_p and adds to them what the two factors next to the frame contribute — "prev" (pair f - 1, f: the frame is its j side) and "next" (pair f, f + 1:
+// its i side) — prev before next, IMU before LiDAR, with plain read-modify-writes: every entry has ONE writer and a fixed order, so the linearisation is bit-reproducible
+// (until round 4: a workgroup per pair and an atomic per entry; the diagonal blocks took atomics from two workgroups in either order). Each factor is evaluated by
+// both of its frames' workgroups (lane 0 of a wave each, the four evaluations side by side); the products with sqrt_info (15 x 15 upper triangular times 15 x 31) and
+// the J^T [J r] entries are one lane per entry. The pair's cost goes to the slot of the frame it is "next" of.
+__global__ __launch_bounds__(256) void lw_imu_lidar(const LwWin *ws, int which, int jac, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int k = blockIdx.x, tid = threadIdx.x, NF = w.NF, P = w.P, use_lidar = w.use_lidar;
-    if (k >= w.nimu) return;
+    const int f = blockIdx.x, tid = threadIdx.x, NF = w.NF, P = w.P, use_lidar = w.use_lidar, nimu = w.nimu;
+    if (f >= NF) return;
     const double *x = which ? w.cand : w.x, *imu_rec = w.imu, *lid = w.lid, *G = w.scal + 8, *qil = w.scal + 1, *til = w.scal + 5;
-    double *Hpp = w.Hpp, *gp = w.gp, *cost = w.scal;
-    __shared__ double s_r[16], s_J[15 * 30], s_rw[16], s_lr[8], s_lJi[36], s_lJj[36], s_jo[480];
-    const int c0 = 15 * k;
-    const double *pi = x + 7 * k, *pj = x + 7 * (k + 1), *sbi = x + 7 * NF + 9 * k, *sbj = sbi + 9;
-    const double *rec = imu_rec + (size_t)k * IMU_REC;
-    const bool has_imu = rec[287] != 0.0;
-    if (tid == 0 && has_imu) { if (jac) imu_raw_eval<true, 30, true>(pi, sbi, pj, sbj, rec, G, s_r, s_J); else imu_raw_eval<false, 30, true>(pi, sbi, pj, sbj, rec, G, s_r, s_J); }
-    if (tid == 64 && use_lidar) {
-        const double *lc = lid + 7 * (size_t)k;
-        if (jac) lidar_between_eval<true>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr, s_lJi, s_lJj); else lidar_between_eval<false>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr, s_lJi, s_lJj);
-    }
-    __syncthreads();
-    double *jo = s_jo;                                       // weighted Jacobian (15 x 30) and residual (15)
-    if (has_imu) {
-        const double *S = rec + IMU_SQRT;                    // upper-triangular sqrt_info (15 x 15, row-major)
-        for (int e = tid; e < (jac ? 465 : 15); e += 128) {
-            const int a = jac ? e / 31 : e, col = jac ? e - 31 * a : 30;
-            double sum = 0;
-            for (int m = a; m < 15; m++) sum += S[15 * a + m] * (col < 30 ? s_J[30 * m + col] : s_r[m]);
-            if (col < 30) jo[30 * a + col] = sum; else { s_rw[a] = sum; if (jac) jo[450 + a] = sum; }
+    double *Hpp = w.Hpp, *gp = w.gp;
+    __shared__ double s_r[2][16], s_J[2][15 * 30], s_rw[2][16], s_lr[2][8], s_lJi[2][36], s_lJj[2][36], s_jo[2][480];
+    // slot 0: prev (k = f - 1), slot 1: next (k = f)
+    const bool has[2] = {f >= 1 && f - 1 < nimu && (jac != 0), f < nimu};           // the cost-only pass needs each pair once: as somebody's "next"
+    bool imu_on[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; sl++) { const int k = f - 1 + sl; imu_on[sl] = has[sl] && imu_rec[(size_t)k * IMU_REC + 287] != 0.0; }
+    {
+        const int sl = (tid >> 6) & 1, k = f - 1 + sl;
+        if (has[sl]) {
+            const double *pi = x + 7 * k, *pj = x + 7 * (k + 1), *sbi = x + 7 * NF + 9 * k, *sbj = sbi + 9;
+            if ((tid == 0 || tid == 64) && imu_on[sl]) {
+                const double *rec = imu_rec + (size_t)k * IMU_REC;
+                if (jac) imu_raw_eval<true, 30, true>(pi, sbi, pj, sbj, rec, G, s_r[sl], s_J[sl]); else imu_raw_eval<false, 30, true>(pi, sbi, pj, sbj, rec, G, s_r[sl], s_J[sl]);
+            }
+            if ((tid == 128 || tid == 192) && use_lidar) {
+                const double *lc = lid + 7 * (size_t)k;
+                if (jac) lidar_between_eval<true>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr[sl], s_lJi[sl], s_lJj[sl]); else lidar_between_eval<false>(pi, pj, q_load(qil), til, q_load(lc), lc + 4, s_lr[sl], s_lJi[sl], s_lJj[sl]);
+            }
         }
     }
-    if (use_lidar && jac)
-        for (int e = tid; e < 12 * 13; e += 128) {           // LiDAR between-factor: J^T [J r] (unweighted Jacobian, weighted residual: the reference's quirk)
-            const int a = e / 13, b = e - 13 * a;
-            const double *Ja = a < 6 ? s_lJi : s_lJj; const int aa = a < 6 ? a : a - 6, ca = a < 6 ? c0 + a : c0 + 15 + a - 6;
-            double hh = 0;
-            if (b < 12) { const double *Jb = b < 6 ? s_lJi : s_lJj; const int bb = b < 6 ? b : b - 6, cb = b < 6 ? c0 + b : c0 + 15 + b - 6;
-                for (int m = 0; m < 6; m++) hh += Ja[6 * m + aa] * Jb[6 * m + bb];
-                add(Hpp + (size_t)ca * P + cb, hh);
-            } else { for (int m = 0; m < 6; m++) hh += Ja[6 * m + aa] * s_lr[m]; add(gp + ca, hh); }
-        }
     __syncthreads();
-    if (has_imu && jac)                                      // J^T [J r] of the IMU factor: one lane per (row a, column b <= 30), 15-term dot products, one atomic each
-        for (int e = tid; e < 930; e += 128) {               // (a launch of its own, reading the weighted Jacobian back from global memory, until round 3)
-            const int a = e / 31, b = e - 31 * a;
-            double sum = 0;
-            for (int m = 0; m < 15; m++) sum += jo[30 * m + a] * (b < 30 ? jo[30 * m + b] : jo[450 + m]);
-            if (sum == 0.0) continue;
-            if (b < 30) add(Hpp + (size_t)(c0 + a) * P + c0 + b, sum); else add(gp + c0 + a, sum);
+    for (int e = tid; e < 2 * 465; e += 256) {               // weighted Jacobian (15 x 30) and residual (15) of both factors
+        const int sl = e >= 465 ? 1 : 0, e1 = e - 465 * sl;
+        if (!imu_on[sl] || (!jac && e1 >= 15)) continue;
+        const double *S = imu_rec + (size_t)(f - 1 + sl) * IMU_REC + IMU_SQRT;   // upper-triangular sqrt_info (15 x 15, row-major)
+        const int a = jac ? e1 / 31 : e1, col = jac ? e1 - 31 * a : 30;
+        double sum = 0;
+        for (int m = a; m < 15; m++) sum += S[15 * a + m] * (col < 30 ? s_J[sl][30 * m + col] : s_r[sl][m]);
+        if (col < 30) s_jo[sl][30 * a + col] = sum; else { s_rw[sl][a] = sum; if (jac) s_jo[sl][450 + a] = sum; }
+    }
+    __syncthreads();
+    if (jac)
+        for (int e = tid; e < 690; e += 256) {               // row a of frame f against: its own block (b < 15), frame f + 1 (15 ..), frame f - 1 (30 ..), the gradient (e >= 675)
+            const int a = e < 675 ? (e % 225) / 15 : e - 675, b = e < 675 ? e % 15 : 0, blk = e < 675 ? e / 225 : 3;
+            double v0 = 0, v1 = 0;                           // prev's and next's contributions
+            if (blk == 0 || blk == 3) {
+                if (imu_on[0]) { double t = 0; for (int m = 0; m < 15; m++) t += s_jo[0][30 * m + 15 + a] * (blk == 0 ? s_jo[0][30 * m + 15 + b] : s_jo[0][450 + m]); v0 = t; }
+                if (imu_on[1]) { double t = 0; for (int m = 0; m < 15; m++) t += s_jo[1][30 * m + a] * (blk == 0 ? s_jo[1][30 * m + b] : s_jo[1][450 + m]); v1 = t; }
+                if (use_lidar && a < 6 && b < 6) {           // LiDAR between-factor: unweighted Jacobian, weighted residual (the reference's quirk)
+                    if (has[0]) { double t = 0; for (int m = 0; m < 6; m++) t += s_lJj[0][6 * m + a] * (blk == 0 ? s_lJj[0][6 * m + b] : s_lr[0][m]); v0 += t; }
+                    if (has[1]) { double t = 0; for (int m = 0; m < 6; m++) t += s_lJi[1][6 * m + a] * (blk == 0 ? s_lJi[1][6 * m + b] : s_lr[1][m]); v1 += t; }
+                }
+                if (!has[0] && !has[1]) continue;
+                if (blk == 0) Hpp[(size_t)(15 * f + a) * P + 15 * f + b] += v0 + v1; else gp[15 * f + a] += v0 + v1;
+            } else if (blk == 1) {                           // (f, f + 1): next's i-j block
+                if (!has[1]) continue;
+                if (imu_on[1]) { double t = 0; for (int m = 0; m < 15; m++) t += s_jo[1][30 * m + a] * s_jo[1][30 * m + 15 + b]; v1 = t; }
+                if (use_lidar && a < 6 && b < 6) { double t = 0; for (int m = 0; m < 6; m++) t += s_lJi[1][6 * m + a] * s_lJj[1][6 * m + b]; v1 += t; }
+                Hpp[(size_t)(15 * f + a) * P + 15 * (f + 1) + b] += v1;
+            } else {                                         // (f, f - 1): prev's j-i block
+                if (!has[0]) continue;
+                if (imu_on[0]) { double t = 0; for (int m = 0; m < 15; m++) t += s_jo[0][30 * m + 15 + a] * s_jo[0][30 * m + b]; v0 = t; }
+                if (use_lidar && a < 6 && b < 6) { double t = 0; for (int m = 0; m < 6; m++) t += s_lJj[0][6 * m + a] * s_lJi[0][6 * m + b]; v0 += t; }
+                Hpp[(size_t)(15 * f + a) * P + 15 * (f - 1) + b] += v0;
+            }
         }
-    if (tid == 0) {
+    if (tid == 0) {                                          // the pair (f, f + 1)'s cost
         double c = 0;
-        if (has_imu) for (int a = 0; a < 15; a++) c += 0.5 * s_rw[a] * s_rw[a];
-        if (use_lidar) for (int a = 0; a < 6; a++) c += 0.5 * s_lr[a] * s_lr[a];
-        add(cost, c);
+        if (imu_on[1]) for (int a = 0; a < 15; a++) c += 0.5 * s_rw[1][a] * s_rw[1][a];
+        if (use_lidar && has[1]) for (int a = 0; a < 6; a++) c += 0.5 * s_lr[1][a] * s_lr[1][a];
+        w.costP[w.ncostv + f] = c;
     }
 }
 // zero the accumulation targets of one linearisation that are summed into with atomics (Hpp, g_p) and the cost: four entries per thread. W, h_f and g_f are
@@ -1134,6 +1163,13 @@ __device__ __forceinline__ double tr_sum(double v, double *s_red) {       // all
     for (int k = 0; k < TR_T / 64; k++) t += s_red[k];
     return t;
 }
+// the cost of the evaluation that just ran: its producers' partials in slot order (strided partial sums, then tr_sum's fixed tree): the same bits every run
+__device__ __forceinline__ double tr_cost_sum(const LwWin &a, double *s_red) {
+    const int n = a.ncostv + a.NF + (a.pn ? 1 : 0);
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += TR_T) v += a.costP[i];
+    return tr_sum(v, s_red);
+}
 __device__ __forceinline__ double tr_max(double v, double *s_red) {
     v = vilf_wave_max64(v);
     __syncthreads();
@@ -1227,7 +1263,15 @@ __global__ __launch_bounds__(TR_T) void lw_tr_post(const LwWin *ws, int first) {
     for (int i = tid; i < a.xo + 8; i += TR_T) m = fmax(m, fabs(a.x[i] - a.cand[i]));
     m = tr_max(m, s_red);
     for (int i = tid; i < N; i += TR_T) { const double sc = a.scale[i]; a.g[i] *= sc; a.diagH[i] *= sc * sc; }
-    if (tid == 0) { c->gmax = m; c->x_cost = a.scal[0]; if (first) c->initial_cost = a.scal[0]; c->scaling_ready = 1; }
+    const double cost_now = tr_cost_sum(a, s_red);
+    if (tid == 0) { a.scal[0] = cost_now; c->gmax = m; c->x_cost = cost_now; if (first) c->initial_cost = cost_now; c->scaling_ready = 1; }
+}
+// the host loop's evaluations: the cost partials summed into scal[0]
+__global__ __launch_bounds__(TR_T) void lw_cost_sum(const LwWin *ws) {
+    const LwWin &a = ws[blockIdx.z];
+    __shared__ double s_red[TR_T / 64];
+    const double c = tr_cost_sum(a, s_red);
+    if (threadIdx.x == 0) a.scal[0] = c;
 }
 // top of an iteration (the tests of trust_region_minimizer.cc before a step) and, unless the last linear solve is reused, the vectors the dogleg needs
 __global__ __launch_bounds__(TR_T) void lw_tr_begin(const LwWin *ws) {
@@ -1363,9 +1407,11 @@ __global__ __launch_bounds__(TR_T) void lw_tr_decide(const LwWin *ws) {
     LwCtl *c = a.ctl;
     if (c->done || c->skip_eval) return;
     const int tid = threadIdx.x;
-    __syncthreads();                                            // every wave has read the flags before thread 0 may change them
+    const double cost_now = tr_cost_sum(a, s_red);              // (its barriers also mean: every wave has read the flags before thread 0 may change them)
+    __syncthreads();
     if (tid == 0) {
-        const double cand_cost = a.scal[0], cost_change = c->x_cost - cand_cost;
+        const double cand_cost = cost_now, cost_change = c->x_cost - cand_cost;
+        a.scal[0] = cost_now;
         int acc = 0;
         c->cand_cost = cand_cost;
         if (fabs(cost_change) <= 1e-6 * c->x_cost) tr_finish(c, VILF_TERM_CONVERGENCE_FUNCTION);
@@ -1488,7 +1534,7 @@ struct LwEnq {
             }
         }
         if (d.any_prior) hipLaunchKernelGGL(lw_prior, grid(1), dim3(256), 0, h->stream, ws, jac, sk);
-        hipLaunchKernelGGL(lw_imu_lidar, grid(d.maxNimu), dim3(128), 0, h->stream, ws, which, jac, sk);
+        hipLaunchKernelGGL(lw_imu_lidar, grid(d.maxNF), dim3(256), 0, h->stream, ws, which, jac, sk);
         if (jac) toc(0);
     }
     // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in vec
@@ -1578,6 +1624,7 @@ int lw_host_loop(vilf_handle *h, LwCtx *c, LwHostWin &hw, const LwWin *dws, doub
         }
         if (!jac) HIPCHECK(h, hipMemsetAsync(dw.scal, 0, 8, h->stream));
         q.evaluate(0, jac ? 1 : 0, LW_SK_NONE);
+        hipLaunchKernelGGL(lw_cost_sum, dim3(1, 1, 1), dim3(TR_T), 0, h->stream, dws);
         HIPCHECK(h, hipGetLastError());
         HIPCHECK(h, hipMemcpyAsync(&cost, dw.scal, 8, hipMemcpyDeviceToHost, h->stream));
         if (!jac) HIPCHECK(h, hipStreamSynchronize(h->stream));         // with the Jacobians: fetch_diag_grad follows and waits once for both
@@ -1853,7 +1900,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
     const size_t o_x = off; off = lw_al(off + tot_x * 8);
     const size_t n_input = off;
     const size_t o_ctl = off; off = lw_al(off + (size_t)G * sizeof(LwCtl));
-    struct WorkOff { size_t cand, Hpp, W, hf, gp, gf, S, SC, PS, rhs, tmpP, tmpF, vec, den, rsd, info, nvec, pdx; };
+    struct WorkOff { size_t costP, cand, Hpp, W, hf, gp, gf, S, SC, PS, rhs, tmpP, tmpF, vec, den, rsd, info, nvec, pdx; };
     std::vector<WorkOff> wo(G);
     for (int g = 0; g < G; g++) {
         const LwHostWin &w = hws[g];
@@ -1864,6 +1911,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         o.S = take((sP + 1) * sP * 8);
         { const size_t nt = (w.PC + 63) / 64, ntile = nt * (nt + 1) / 2; o.SC = take((size_t)SY_KS * (ntile * 4096 + nt * 64) * 8); }
         o.PS = take((size_t)std::max(w.nslots_cap, 1) * 160 * 8);
+        o.costP = take(((size_t)(w.nvis + LW_CH - 1) / LW_CH + w.NF + 2) * 8);
         o.rhs = take(sP * 8); o.tmpP = take(sP * 8); o.tmpF = take(sF * 8); o.vec = take(2 * sN * 8);
         o.den = take(sF * 8); o.rsd = take(sF * 8); o.info = take(64); o.nvec = take(7 * sN * 8); o.pdx = take(VB_PRIOR_LD * 8);
     }
@@ -1889,8 +1937,10 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
     }
     const double sqrt_info = h->opts.focal_length / 1.5, cauchy_b = h->opts.cauchy_a * h->opts.cauchy_a;      // rho(s) = b log(1 + s / b), b = a^2 (ceres CauchyLoss; same as the batched path)
     std::vector<LwWin> dws(G);
-    int group_nks = 4;                                 // K splits of the Schur reduce: enough workgroups for the chip from a small group's few tiles
-    { int mpc = 1; for (const LwHostWin &w : hws) mpc = std::max(mpc, w.PC); const int nt = (mpc + 63) / 64, tiles = nt * (nt + 1) / 2; group_nks = std::min(SY_KS, std::max(4, (480 + tiles * G - 1) / (tiles * G))); if (const char *e = std::getenv("VILF_LW_NKS")) group_nks = std::min(SY_KS, std::max(1, std::atoi(e))); }
+    // K splits of the Schur reduce: a constant — the partials are summed in split order, so a count that depended on the group would make a window's bits depend on
+    // who it is solved next to. 8 keeps a single window's reduce at 120 workgroups and costs a full group little (measured: 4 / 8 / 16 splits within 4 % at 32 windows)
+    int group_nks = 8;
+    if (const char *e = std::getenv("VILF_LW_NKS")) group_nks = std::min(SY_KS, std::max(1, std::atoi(e)));
     std::vector<size_t> imu_at(G), x_at(G);
     { size_t a = 0, b = 0; for (int g = 0; g < G; g++) { imu_at[g] = a; x_at[g] = b; a += hws[g].nimu; b += hws[g].xo + 8; } }
     auto pack = [&](int g) {
@@ -2026,7 +2076,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         d.kspan = reinterpret_cast<const int *>(dev + w.o_kspan); d.fspan = reinterpret_cast<const int *>(dev + w.o_fspan);
         d.bandf = (w.pn || est_ex || est_td) ? NF : std::min(NF, bandf);
         d.fvis = reinterpret_cast<const int *>(dev + w.o_fvis); d.fidx = reinterpret_cast<const int *>(dev + w.o_fidx);
-        d.PS = reinterpret_cast<double *>(dev + o.PS); d.cslot = reinterpret_cast<const int *>(dev + w.o_cslot); d.prt = reinterpret_cast<const int *>(dev + w.o_prt);
+        d.PS = reinterpret_cast<double *>(dev + o.PS); d.costP = reinterpret_cast<double *>(dev + o.costP); d.ncostv = (nvis + LW_CH - 1) / LW_CH; d.cslot = reinterpret_cast<const int *>(dev + w.o_cslot); d.prt = reinterpret_cast<const int *>(dev + w.o_prt);
         d.froff = reinterpret_cast<const int *>(dev + w.o_froff); d.frlist = reinterpret_cast<const int *>(dev + w.o_frlist); d.npairs = w.npairs;
         d.sqrt_info = sqrt_info; d.cauchy_b = cauchy_b; d.tr_over_row = h->opts.TR / h->opts.ROW;
         d.ctl = reinterpret_cast<LwCtl *>(dev + o_ctl) + g;
