@@ -201,6 +201,48 @@ def test_solve_to_convergence_matches_oracle(oracle):
     s.close()
 
 
+def test_live_window_lists_leave_every_result_untouched(oracle, monkeypatch):
+    """A batch in which windows stop at different iterations (half of them start at their own fixed point: FUNCTION_TOLERANCE in iteration 1; the others run the
+    budget) in an interleaved arrangement: once something has stopped, k_linearize lists the windows still running and the later launches address them through
+    that list (the finished ones' workgroups leave from the end of the grid: the saving no longer depends on where they sit in the batch). Which workgroup takes
+    which window is all that changes: every state, cost and count equal bit for bit to the run with the lists switched off (VILF_NO_LIVE_LIST)."""
+    import copy
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    made = [synth.make_window(7101 + k, o, synth.SynthConfig(n_features=70 + 5 * k)) for k in range(8)]
+    o2 = oracle.default_options(); o2.max_num_iterations = 1000
+    pre = BackendSolver(o2); pre.batch_upload([m[0] for m in made[:4]], [m[1] for m in made[:4]]); pre.batch_solve(); fixed = pre.batch_download(); pre.close()
+    wins, priors = [], []
+    for k in range(8):
+        w = made[k][0]
+        if k < 4:
+            w = copy.deepcopy(w)
+            w.para_pose = np.ascontiguousarray(np.asarray(fixed[k].para_pose).reshape(-1, 7)); w.para_speed_bias = np.ascontiguousarray(np.asarray(fixed[k].para_speed_bias).reshape(-1, 9))
+            w.para_feature = np.ascontiguousarray(fixed[k].para_feature)
+        wins.append(w); priors.append(made[k][1])
+    order = [(3 * i + i // 5) % 8 for i in range(96)]            # finished and running windows interleaved, 96 slots
+    def run():
+        s = BackendSolver(o)
+        s.batch_upload([wins[k] for k in order], [priors[k] for k in order]); s.batch_solve()
+        out = s.batch_download(); sm = [(x.num_iterations, x.num_successful_steps, x.termination, x.final_cost) for x in s.batch_summaries()]
+        s.close()
+        return out, sm
+    a, sa = run()
+    monkeypatch.setenv("VILF_NO_LIVE_LIST", "1")
+    b, sb = run()
+    monkeypatch.delenv("VILF_NO_LIVE_LIST")
+    assert sa == sb
+    its = [x[0] for x in sa]
+    assert min(its) <= 2 and max(its) == 8, its                   # windows that stop at once beside windows that use the budget
+    for x, y in zip(a, b):
+        for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "para_feature", "para_pose", "para_speed_bias"):
+            assert np.array_equal(getattr(x, key), getattr(y, key)), key
+    for slot, k in enumerate(order):                             # and each window against the oracle, whatever its neighbours did
+        if k >= 4:
+            ref = oracle.window_solve(o, wins[k], priors[k])
+            assert a[slot].summary["num_iterations"] == ref.summary["num_iterations"] and np.abs(a[slot].Ps - ref.Ps).max() < 1e-7
+
+
 def _prior_products(p):
     J0, r0, blocks = abi.prior_to_numpy(p)
     return J0.T @ J0, J0.T @ r0, blocks

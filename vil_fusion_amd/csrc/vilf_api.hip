@@ -764,8 +764,16 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
             return VILF_OK;
         }
     }
+    // live-window lists (vilf_batch.hpp): the launches of iteration i address their windows through the list k_linearize of iteration i - 1 left, once something has stopped
+    const int max_it = h->opts.max_num_iterations;
+    const bool use_live = !std::getenv("VILF_NO_LIVE_LIST") && max_it + 2 <= 64 && h->d[D_LIVE].ensure(((size_t)2 * h->B + 128) * sizeof(int));
+    auto with_lists = [&](int it) {
+        VbBatch bb = h->batch;
+        if (use_live) { bb.live_ctl = h->d[D_LIVE].as<int>(); bb.live_buf = bb.live_ctl + 128; bb.live_it = it; }
+        return bb;
+    };
     mark(3);
-    hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
+    hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, with_lists(0), 0);
     mark(0);
     hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 1);
     // options.max_solver_time (estimator.cpp:847-850: SOLVER_TIME, x 4/5 when the oldest frame is marginalized): Ceres tests the wall clock at the top of
@@ -782,12 +790,14 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
             if (el >= tlim * 4.0 / 5.0 && !stopped_old) { hipLaunchKernelGGL(k_time_limit, grid, dim3(64), 0, h->stream, h->batch, h->d[D_MFLAG].as<int>(), 1); stopped_old = true; }
         }
         mark(1);
-        if (dense) hipLaunchKernelGGL(k_solve, grid, dim3(512), h->solve_lds, h->stream, h->batch);
-        else hipLaunchKernelGGL(k_solve_sb, grid, dim3(256), h->solve_sb_lds, h->stream, h->batch);
-        mark(it + 1 == h->opts.max_num_iterations ? 2 : 0);      // kind 2 ("k_step" in the bench line): the step-only launch that ends a solve
+        const bool last = it + 1 == h->opts.max_num_iterations;
+        const VbBatch bs = with_lists(it + 1), bl = bs;
+        if (dense) hipLaunchKernelGGL(k_solve, grid, dim3(512), h->solve_lds, h->stream, bs);
+        else hipLaunchKernelGGL(k_solve_sb, grid, dim3(256), h->solve_sb_lds, h->stream, bs);
+        mark(last ? 2 : 0);      // kind 2 ("k_step" in the bench line): the step-only launch that ends a solve
         // the step of the last iteration needs no linearisation behind it (nothing solves with it): residuals only
-        if (it + 1 == h->opts.max_num_iterations) hipLaunchKernelGGL(k_linearize_last, grid, block, h->lin_lds, h->stream, h->batch);
-        else hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 0);
+        if (last) hipLaunchKernelGGL(k_linearize_last, grid, block, h->lin_lds, h->stream, bl);
+        else hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, bl, 0);
     }
     mark(3);
     hipLaunchKernelGGL(k_finalize, grid, dim3(64), 0, h->stream, h->batch);

@@ -127,6 +127,13 @@ struct VbMarg {
 struct VbBatch {
     int B, Fmax, Omax, FACmax;
     int w0;                 // first window of this launch (a batch may be enqueued in parts: window = blockIdx.x + w0)
+    // Live-window lists (converging batches): a window that has stopped leaves every later launch; with the windows addressed through a dense list of the ones still
+    // running, the finished ones' workgroups sit at the END of the grid and exit at once wherever they were in the batch (without it the saving depended on where the
+    // short workgroups fell among the long ones: 0 .. 40 %). Launches of iteration i (k_solve_sb, k_linearize; live_it = i): live_ctl[i] = 1 once any window of the
+    // batch has stopped by the end of iteration i; k_linearize of iteration i appends the windows it leaves unfinished to list i (arrival order: which workgroup takes
+    // which window is free, a window's arithmetic is untouched) only when live_ctl[i - 1] is set, and iteration i + 1 addresses its windows through list i under the
+    // same condition — a batch in which nothing has stopped pays two scalar loads per workgroup and no atomic. live_ctl: [64] flags, [64] list lengths; live_buf: 2 x B.
+    int *live_ctl, *live_buf; int live_it;
     // options
     double sqrt_info, cauchy_b, G[3];
     double qil[4], til[3];  // RIC*RCL as quaternion (xyzw), RIC*TCL+TIC (lidar_factor.h:28-29)

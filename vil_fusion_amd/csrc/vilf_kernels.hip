@@ -208,6 +208,13 @@ __device__ double prior_cost_partial(const VbBatch &b, int w, const double *s_dx
     return acc;
 }
 
+// the window of this workgroup: blockIdx.x + w0, or through the dense list of the windows still running (-1: the list is shorter than the grid)
+__device__ __forceinline__ int vb_window(const VbBatch &b) {
+    const int i = b.live_it;
+    if (!b.live_ctl || i < 3 || !b.live_ctl[i - 2]) return blockIdx.x + b.w0;      // list i - 1 exists iff something had stopped by the end of iteration i - 2
+    if ((int)blockIdx.x >= b.live_ctl[64 + i - 1]) return -1;
+    return b.live_buf[(size_t)((i - 1) & 1) * b.B + blockIdx.x];
+}
 // ------------------------------------------------------------------------------------------------------------------
 // k_linearize
 //
@@ -243,9 +250,19 @@ __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the
 // so it only takes the step: candidate, cost of every factor (residuals only), accept / reject — a ninth of the linearisations of a solve.
 template <bool JAC>
 __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_zero) {
-    const int w = blockIdx.x + b.w0, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int w = vb_window(b), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    if (w < 0) return;
     VbState *st = b.st + w;
-    if (!iteration_zero && st->done) return;
+    const int lit = b.live_it;
+    const bool lists = !iteration_zero && JAC && b.live_ctl != nullptr && lit >= 1;
+    const int stopped_before = lists ? b.live_ctl[lit - 1] : 0;          // has any window of the batch stopped by the end of the previous iteration?
+    if (!iteration_zero && st->done) { if (lists && tid == 0) b.live_ctl[lit] = 1; return; }
+    // thread 0, at the launch's exits: pass the flag on, and — once something has stopped — put this window on the next iteration's list
+    auto still_live = [&]() {
+        if (!lists) return;
+        if (st->done || stopped_before) b.live_ctl[lit] = 1;
+        if (stopped_before && !st->done) b.live_buf[(size_t)(lit & 1) * b.B + atomicAdd(b.live_ctl + 64 + lit, 1)] = w;
+    };
     // Two linearisation workspaces per window. Iteration zero fills set 0 at the initial state. Later launches ARE the trust-region step (what k_step was): they form
     // the dogleg step from the last solve, linearise at the CANDIDATE into the set that does not belong to x — the candidate's cost falls out of the same pass over
     // the factors, so there is no separate cost-only pass — and flip st->ws when the step is accepted; a rejected step leaves x, its cost and its set untouched.
@@ -318,6 +335,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             } else st->num_consecutive_invalid = 0;
             s_flagi[0] = valid;
             s_red[1] = ca; s_red[2] = cb;
+            if (!valid) still_live();                                        // an invalid step: the window goes on with a larger mu (unless that was the fifth)
         }
         __syncthreads();
         if (!s_flagi[0]) return;
@@ -737,6 +755,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             }
         }
         s_acc[0] = accept;
+        still_live();
     }
     __syncthreads();
     if (s_acc[0]) {
@@ -936,7 +955,8 @@ __device__ __forceinline__ void feature_dots(const double *W, int F, const doubl
 }
 
 extern "C" __global__ __launch_bounds__(SNT) void k_solve(VbBatch b) {
-    const int w = blockIdx.x + b.w0, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int w = vb_window(b), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    if (w < 0) return;
     VbState *st = b.st + w;
     extern __shared__ double s_dyn[];
     double *s_T = s_dyn;                      // 66 tiles * 256
@@ -1536,7 +1556,8 @@ __device__ __forceinline__ bool sb_potrf9(double *Dp, double *linv, int lane) {
 }
 // one gather entry of the chain / band tables: (meta, src0, src1, -) -> scaled value + LM term, Cauchy-point contribution
 extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
-    const int w = blockIdx.x + b.w0, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = vb_window(b), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (w < 0) return;
     VbState *st = b.st + w;
     extern __shared__ double s_dyn[];
     double *s_P = s_dyn + SB_OFF_P, *s_D = s_dyn + SB_OFF_D, *s_E = s_dyn + SB_OFF_E, *s_band = s_dyn + SB_OFF_BAND;
@@ -2231,6 +2252,7 @@ extern "C" __global__ void k_time_limit(VbBatch b, const int *mflag, int only_ma
 // reset of the per-window solver state (≙ TrustRegionMinimizer::Init + DoglegStrategy ctor) and state rewind
 extern "C" __global__ void k_reset(VbBatch b, int rewind_state) {
     const int w = blockIdx.x + b.w0, tid = threadIdx.x;
+    if (blockIdx.x == 0 && b.live_ctl && tid < 128) b.live_ctl[tid] = 0;            // the solve's live-list flags and counters (one per iteration)
     if (rewind_state) {
         if (tid < 77) b.pose[(size_t)w * 77 + tid] = b.pose_init[(size_t)w * 77 + tid];
         if (tid < 99) b.sb[(size_t)w * 99 + tid] = b.sb_init[(size_t)w * 99 + tid];
