@@ -5,7 +5,7 @@ mkdir -p gpurun_out/$T
 : > gpurun_out/$T/batch_sweep.jsonl
 for B in 1 8 64 512 2048 4096; do
   D=$B; if [ $D -gt 64 ]; then D=64; fi
-  python bench.py --windows $B --distinct $D --no-lidar-stage --no-marginalize --no-cpu-baseline --no-pcie --ragged-windows 0 --converging-windows 0 --td-windows 0 --no-latency --steps 20 --warmup 3 >> gpurun_out/$T/batch_sweep.jsonl 2>> gpurun_out/$T/batch_sweep.err
+  python bench.py --windows $B --distinct $D --no-lidar-stage --no-marginalize --no-cpu-baseline --no-pcie --ragged-windows 0 --converging-windows 0 --td-windows 0 --no-latency --no-stress-leg --steps 20 --warmup 3 >> gpurun_out/$T/batch_sweep.jsonl 2>> gpurun_out/$T/batch_sweep.err
 done
 python - <<PY
 import json
