@@ -701,8 +701,12 @@ def main():
         def f_solve_marg():
             ls.set_prior(lp_); ls.optimization(lw_); ls.marginalize()
         f_solve()
-        latency = {"window_solve_ms": med(f_solve), "window_solve_device_usec": f_solve().summary["usec_solve"], "window_solve_marginalize_ms": med(f_solve_marg),
-                   "what": "vilf_window_solve (upload + <= 8 dogleg iterations + download) and + vilf_window_marginalize of ONE 11-frame window; vilf_scan2map_step of ONE LiDAR stream (steady-state local map)"}
+
+        def f_solve_resident():                     # the running system: the prior is on the device (written by the last marginalization), nothing to import
+            return ls.optimization(lw_)
+        latency = {"window_solve_ms": med(f_solve), "window_solve_device_usec": f_solve().summary["usec_solve"], "window_solve_resident_prior_ms": med(f_solve_resident),
+                   "window_solve_marginalize_ms": med(f_solve_marg),
+                   "what": "vilf_window_solve (upload + <= 8 dogleg iterations + download) of ONE 11-frame window — with the prior imported by the call (vilf_prior_import: repeatable) and with the prior already resident on the device (the running system) — and + vilf_window_marginalize; vilf_scan2map_step of ONE LiDAR stream (steady-state local map)"}
         if raw_lidar:
             me_, ms_, scans_, pl_ = raw_lidar[0]
             m1 = Scan2Map(ls); m1.localMapInited(me_, ms_)

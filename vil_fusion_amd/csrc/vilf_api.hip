@@ -105,6 +105,27 @@ void quat_to_R(const double *q, double *R) {
 
 }  // namespace
 
+// Small batches (the reference's real-time use is ONE window per frame): the host image of an upload goes to the device in ONE copy and a kernel hands its spans
+// out to the library's arrays — the ~25 separate copies of the batched path cost 13 us each (4.5 busy + the gap to the next) before the first kernel of a solve
+// could start: 0.43 of a single window's 1.7 ms. The same backwards for the results.
+struct UpJob { const char *src; char *dst; unsigned long long bytes; };
+struct UpJobs { int n; UpJob j[40]; };
+__global__ __launch_bounds__(256) void k_copy_spans(UpJobs jobs) {
+    const UpJob jb = jobs.j[blockIdx.y];
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256, i0 = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if ((((unsigned long long)jb.src | (unsigned long long)jb.dst) & 15ull) == 0) {          // the usual case: 16-byte aligned on both sides
+        const unsigned long long n16 = jb.bytes >> 4;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(jb.src); uint4 *d4 = reinterpret_cast<uint4 *>(jb.dst);
+        for (unsigned long long i = i0; i < n16; i += stride) d4[i] = s4[i];
+        if (blockIdx.x == 0) for (unsigned long long i = (n16 << 4) + threadIdx.x; i < jb.bytes; i += 256) jb.dst[i] = jb.src[i];
+    } else if ((((unsigned long long)jb.src | (unsigned long long)jb.dst) & 7ull) == 0) {    // rows of an odd number of doubles, not the first window
+        const unsigned long long n8 = jb.bytes >> 3;
+        const unsigned long long *s8 = reinterpret_cast<const unsigned long long *>(jb.src); unsigned long long *d8 = reinterpret_cast<unsigned long long *>(jb.dst);
+        for (unsigned long long i = i0; i < n8; i += stride) d8[i] = s8[i];
+        if (blockIdx.x == 0) for (unsigned long long i = (n8 << 3) + threadIdx.x; i < jb.bytes; i += 256) jb.dst[i] = jb.src[i];
+    } else for (unsigned long long i = i0; i < jb.bytes; i += stride) jb.dst[i] = jb.src[i];
+}
+
 extern "C" const char *vilf_version(void) { return "vilfusion-hip 0.1 (gfx950)"; }
 
 extern "C" void vilf_default_options(vilf_options *o) {
@@ -424,8 +445,10 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     const bool est_td0 = h->opts.estimate_td != 0;
     int *nfeat, *nfac, *fstart, *fnobs, *fobs0, *ffac0, *facfeat, *facobs, *pairoff, *psfeat, *psobs, *psslot;
     uint8_t *fconst;
-    double *pose, *sb, *feat, *ex, *gR0, *gP0, *imu, *lidar, *cov, *facrec, *obsv = nullptr, *obstd = nullptr, *obsrow = nullptr;
+    double *pose, *sb, *feat, *ex, *gR0, *gP0, *imu, *lidar, *cov, *facrec, *obsv = nullptr, *obstd = nullptr, *obsrow = nullptr, *td_img = nullptr;
+    int *mflag_img = nullptr;
     auto carve_all = [&](Carve &cv) {          // the same sequence sizes the allocation (base = 0) and hands out the spans
+        mflag_img = cv.take<int>(sB); td_img = cv.take<double>(sB);
         nfeat = cv.take<int>(sB); nfac = cv.take<int>(sB); fstart = cv.take<int>(sB * sF); fnobs = cv.take<int>(sB * sF); fobs0 = cv.take<int>(sB * sF); ffac0 = cv.take<int>(sB * sF);
         facfeat = cv.take<int>(sB * sC); facobs = cv.take<int>(sB * sC); pairoff = cv.take<int>(sB * VB_PTAB); psfeat = cv.take<int>(sB * sC); psobs = cv.take<int>(sB * sC); psslot = cv.take<int>(sB * sC);
         fconst = cv.take<uint8_t>(sB * sF);
@@ -433,7 +456,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         imu = cv.take<double>(sB * 10 * IMU_REC); lidar = cv.take<double>(sB * 10 * 7); cov = cv.take<double>(sB * 10 * 225); facrec = cv.take<double>(sB * sC * 8);
         if (est_td0) { obsv = cv.take<double>(sB * sO * 2); obstd = cv.take<double>(sB * sO); obsrow = cv.take<double>(sB * sO); }
     };
-    { Carve sz{nullptr}; carve_all(sz); if (!h->pin_up.ensure(sz.off + 64)) { h->err = "hipHostMalloc failed (upload staging)"; return VILF_ERR_DEVICE; } }
+    size_t image_bytes = 0;
+    { Carve sz{nullptr}; carve_all(sz); image_bytes = (sz.off + 63) & ~(size_t)63; if (!h->pin_up.ensure(sz.off + 64)) { h->err = "hipHostMalloc failed (upload staging)"; return VILF_ERR_DEVICE; } }
     { Carve cv{static_cast<char *>(h->pin_up.p)}; carve_all(cv); }
     h->h_nfeat.assign(B, 0); h->h_ex.assign(sB * 7, 0.0); h->h_td.assign(B, 0.0);
     const bool est_any = h->opts.estimate_extrinsic || h->opts.estimate_td, est_td = est_td0;
@@ -541,9 +565,27 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         if (est_td) { HIPCHECK(h, upr(D_OBSV, obsv, sO * 16, w0, w1)); HIPCHECK(h, upr(D_OBSTD, obstd, sO * 8, w0, w1)); HIPCHECK(h, upr(D_OBSROW, obsrow, sO * 8, w0, w1)); }
         return VILF_OK;
     };
+    // a small batch: one copy of the whole host image + k_copy_spans (see there)
+    const bool staged = nthr <= 1 && image_bytes <= ((size_t)64 << 20) && !std::getenv("VILF_NO_STAGED_UPLOAD") && h->d[D_UPSTAGE].ensure(image_bytes + 4096);
+    UpJobs jobs; jobs.n = 0;
+    auto span = [&](int id, const void *src, size_t bytes) {          // a span of the image -> the whole of a library array
+        UpJob &jb = jobs.j[jobs.n++];
+        jb.src = h->d[D_UPSTAGE].as<char>() + (static_cast<const char *>(src) - static_cast<const char *>(h->pin_up.p)); jb.dst = static_cast<char *>(h->d[id].p); jb.bytes = bytes;
+    };
     {
         const int nchunk = (nthr > 1 && B >= 256) ? 4 : 1, csz = (B + nchunk - 1) / nchunk;      // (eight parts: no better — 200 copy calls of the main thread compete with the packers)
-        if (nthr <= 1) { for (int w = 0; w < B; w++) pack_one(w); const int rcc = copy_range(0, B); if (rcc != VILF_OK) return rcc; }
+        if (staged) {
+            for (int w = 0; w < B; w++) pack_one(w);
+            span(D_POSE, pose, sB * 77 * 8); span(D_POSE0, pose, sB * 77 * 8); span(D_SB, sb, sB * 99 * 8); span(D_SB0, sb, sB * 99 * 8);
+            span(D_FEAT, feat, sB * sF * 8); span(D_FEAT0, feat, sB * sF * 8);
+            span(D_FSTART, fstart, sB * sF * 4); span(D_FNOBS, fnobs, sB * sF * 4); span(D_FFAC0, ffac0, sB * sF * 4); span(D_FCONST, fconst, sB * sF);
+            span(D_PSSLOT, psslot, sB * sC * 4);
+            if (est_td) { span(D_FOBS0, fobs0, sB * sF * 4); span(D_PSOBS, psobs, sB * sC * 4); }
+            span(D_FACREC, facrec, sB * sC * 64);
+            span(D_IMU, imu, sB * 10 * IMU_REC * 8); span(D_LIDAR, lidar, sB * 10 * 7 * 8); span(D_COV, cov, sB * 10 * 225 * 8);
+            if (est_td) { span(D_OBSV, obsv, sB * sO * 16); span(D_OBSTD, obstd, sB * sO * 8); span(D_OBSROW, obsrow, sB * sO * 8); }
+        }
+        else if (nthr <= 1) { for (int w = 0; w < B; w++) pack_one(w); const int rcc = copy_range(0, B); if (rcc != VILF_OK) return rcc; }
         else {
             std::atomic<int> next(0);
             std::vector<std::atomic<int>> done(nchunk);
@@ -562,12 +604,22 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     }
     lap("pack + per-window copies");
     auto up = [&](int id, const void *src, size_t bytes) { return hipMemcpyAsync(h->d[id].p, src, bytes, hipMemcpyHostToDevice, h->stream); };
+    if (staged) {
+        std::memcpy(mflag_img, h->h_mflag.data(), sB * 4); std::memcpy(td_img, h->h_td.data(), sB * 8);
+        span(D_NFEAT, nfeat, sB * 4); span(D_NFAC, nfac, sB * 4); span(D_EX, ex, sB * 7 * 8); span(D_GR0, gR0, sB * 9 * 8); span(D_GP0, gP0, sB * 3 * 8);
+        span(D_PAIROFF, pairoff, sB * VB_PTAB * 4); span(D_MFLAG, mflag_img, sB * 4); span(D_TD, td_img, sB * 8);
+        HIPCHECK(h, hipMemcpyAsync(h->d[D_UPSTAGE].p, h->pin_up.p, image_bytes, hipMemcpyHostToDevice, h->stream));
+        size_t big = 0; for (int k = 0; k < jobs.n; k++) big = std::max<size_t>(big, jobs.j[k].bytes);
+        hipLaunchKernelGGL(k_copy_spans, dim3((unsigned)std::max<size_t>(1, std::min<size_t>(64, big / 65536 + 1)), (unsigned)jobs.n), dim3(256), 0, h->stream, jobs);
+        HIPCHECK(h, hipGetLastError());
+    } else {
     HIPCHECK(h, up(D_NFEAT, nfeat, sB * 4)); HIPCHECK(h, up(D_NFAC, nfac, sB * 4));
     HIPCHECK(h, up(D_EX, ex, sB * 7 * 8)); HIPCHECK(h, up(D_GR0, gR0, sB * 9 * 8)); HIPCHECK(h, up(D_GP0, gP0, sB * 3 * 8));
     HIPCHECK(h, up(D_PAIROFF, pairoff, sB * VB_PTAB * 4));
     HIPCHECK(h, up(D_MFLAG, h->h_mflag.data(), sB * 4));
     HIPCHECK(h, up(D_TD, h->h_td.data(), sB * 8));
     HIPCHECK(h, hipStreamSynchronize(h->stream));
+    }
     lap("small arrays + sync");
 
     // ---- batch descriptor -------------------------------------------------------------------------------------
@@ -865,6 +917,46 @@ extern "C" int vilf_batch_summaries(vilf_handle *h, int first, int n, vilf_summa
 extern "C" int vilf_batch_download(vilf_handle *h, int first, int n, vilf_window_out *outs) {
     if (!h || !h->resident || first < 0 || n < 0 || first + n > h->B || !outs) return VILF_ERR_INVALID_ARGUMENT;
     const size_t sF = h->batch.Fmax;
+    // a few windows (the single-window entry point): the nine result arrays are gathered on the device (k_copy_spans) and come back in ONE copy through pinned memory
+    const size_t sn0 = n, per0 = 77 + 99 + sF + 33 + 99 + 33 + 33 + 33, img0 = ((sn0 * per0 * 8 + 63) & ~(size_t)63) + sn0 * sizeof(VbState);
+    if (n <= 64 && !std::getenv("VILF_NO_STAGED_UPLOAD") && h->d[D_DNSTAGE].ensure(img0 + 256) && h->pin_down.ensure(img0 + 256)) {
+        UpJobs jobs; jobs.n = 0;
+        char *dst = h->d[D_DNSTAGE].as<char>();
+        size_t off = 0;
+        auto gather = [&](const void *src, size_t bytes) { UpJob &jb = jobs.j[jobs.n++]; jb.src = static_cast<const char *>(src); jb.dst = dst + off; jb.bytes = bytes; const size_t at = off; off += (bytes + 15) & ~(size_t)15; return at; };
+        const size_t o_pose = gather(h->batch.pose + (size_t)first * 77, sn0 * 77 * 8), o_sb = gather(h->batch.sb + (size_t)first * 99, sn0 * 99 * 8), o_feat = gather(h->batch.feat + (size_t)first * sF, sn0 * sF * 8);
+        const size_t o_ps = gather(h->batch.out_Ps + (size_t)first * 33, sn0 * 33 * 8), o_rs = gather(h->batch.out_Rs + (size_t)first * 99, sn0 * 99 * 8), o_vs = gather(h->batch.out_Vs + (size_t)first * 33, sn0 * 33 * 8);
+        const size_t o_ba = gather(h->batch.out_Bas + (size_t)first * 33, sn0 * 33 * 8), o_bg = gather(h->batch.out_Bgs + (size_t)first * 33, sn0 * 33 * 8), o_st = gather(h->batch.st + first, sn0 * sizeof(VbState));
+        hipLaunchKernelGGL(k_copy_spans, dim3(1, (unsigned)jobs.n), dim3(256), 0, h->stream, jobs);
+        HIPCHECK(h, hipGetLastError());
+        HIPCHECK(h, hipMemcpyAsync(h->pin_down.p, dst, off, hipMemcpyDeviceToHost, h->stream));
+        HIPCHECK(h, hipStreamSynchronize(h->stream));
+        solve_time_resolve(h);
+        { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
+        const char *img = static_cast<const char *>(h->pin_down.p);
+        auto dd = [&](size_t at) { return reinterpret_cast<const double *>(img + at); };
+        const VbState *st = reinterpret_cast<const VbState *>(img + o_st);
+        for (int i = 0; i < n; i++) {
+            vilf_window_out &o = outs[i];
+            const int F = h->h_nfeat[first + i];
+            if (o.para_pose) std::memcpy(o.para_pose, dd(o_pose) + (size_t)i * 77, 77 * 8);
+            if (o.para_speed_bias) std::memcpy(o.para_speed_bias, dd(o_sb) + (size_t)i * 99, 99 * 8);
+            if (o.para_feature && F) std::memcpy(o.para_feature, dd(o_feat) + (size_t)i * sF, (size_t)F * 8);
+            if (o.Ps) std::memcpy(o.Ps, dd(o_ps) + (size_t)i * 33, 33 * 8);
+            if (o.Rs) std::memcpy(o.Rs, dd(o_rs) + (size_t)i * 99, 99 * 8);
+            if (o.Vs) std::memcpy(o.Vs, dd(o_vs) + (size_t)i * 33, 33 * 8);
+            if (o.Bas) std::memcpy(o.Bas, dd(o_ba) + (size_t)i * 33, 33 * 8);
+            if (o.Bgs) std::memcpy(o.Bgs, dd(o_bg) + (size_t)i * 33, 33 * 8);
+            const double *exw = &h->h_ex[(size_t)(first + i) * 7];
+            for (int k = 0; k < 3; k++) o.tic[k] = exw[k];
+            quat_to_R(exw + 3, o.ric);
+            o.td = h->h_td[first + i];
+            o.summary.num_iterations = st[i].iteration; o.summary.num_successful_steps = st[i].num_successful; o.summary.num_linear_solves = st[i].num_linear_solves;
+            o.summary.termination = st[i].termination; o.summary.initial_cost = st[i].initial_cost; o.summary.final_cost = st[i].x_cost; o.summary.final_radius = st[i].radius;
+            o.summary.usec_solve = h->last_solve_usec;
+        }
+        return VILF_OK;
+    }
     std::vector<double> pose((size_t)n * 77), sb((size_t)n * 99), feat((size_t)n * sF), Ps((size_t)n * 33), Rs((size_t)n * 99), Vs((size_t)n * 33), Bas((size_t)n * 33), Bgs((size_t)n * 33);
     auto dn = [&](void *dst, const double *src, size_t cnt) { return hipMemcpyAsync(dst, src, cnt * 8, hipMemcpyDeviceToHost, h->stream); };
     HIPCHECK(h, dn(pose.data(), h->batch.pose + (size_t)first * 77, (size_t)n * 77));
