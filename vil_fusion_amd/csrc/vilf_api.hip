@@ -693,7 +693,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     if (rc != VILF_OK) return rc;
     hipLaunchKernelGGL(k_reset, dim3(B), dim3(VB_NT), 0, h->stream, h->batch, 0);
     HIPCHECK(h, hipGetLastError());
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    if (!(h->defer_upload_sync && staged)) HIPCHECK(h, hipStreamSynchronize(h->stream));      // (the pinned image is not touched again before the caller's own wait)
     h->resident = true;
     return VILF_OK;
 }
@@ -1043,7 +1043,9 @@ extern "C" int vilf_window_solve(vilf_handle *h, const vilf_window_in *in, vilf_
         return vilf_lw_window_solve(h, in, out, 0);
     }
     auto t0 = std::chrono::steady_clock::now();
+    h->defer_upload_sync = true;
     int rc = vilf_batch_upload(h, 1, in);
+    h->defer_upload_sync = false;
     if (rc != VILF_OK) return rc;
     if (h->opts.estimate_extrinsic || h->opts.estimate_td)      // Ex_Pose / td as variables (estimator.cpp:701-717): the general single-window path, with the slot-0 prior
         return vilf_lw_window_solve(h, in, out, 1);      // slot 0

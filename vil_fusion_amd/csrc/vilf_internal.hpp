@@ -76,6 +76,7 @@ struct vilf_handle {
     VbBatch batch;
     int B = 0;
     bool resident = false;
+    bool defer_upload_sync = false;   // vilf_window_solve: upload, solve and download are one call — the host waits once, at the download
     std::vector<vilf_prior> priors;          // per slot (host mirror)
     std::vector<char> prior_dirty;
     std::vector<char> prior_dense;           // slot's live prior (imported from the host) holds a speed-bias block other than SpeedBias[0]
