@@ -20,6 +20,7 @@
 using namespace vd;
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
 
 #define NT VB_NT
 #define VILF_MAX_FEATURES_DEV 1000
@@ -534,14 +535,16 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             x0[12] = sw * r[0]; x1[12] = sw * r[1];
             if (!fc) {
                 const double jf0 = sw * Jf[0], jf1 = sw * Jf[1];
-                double *Wr = W + (size_t)f * VB_WLD + 6 * fj;
+                // 16-byte stores (the row's six doubles start at a multiple of 48 bytes, a record at a multiple of 64): 7 store instructions per lane instead of 14 —
+                // every lane of a wave writes to lines of its own, so the instruction count is what the memory pipeline sees
+                double2_t *Wr = reinterpret_cast<double2_t *>(W + (size_t)f * VB_WLD + 6 * fj);
+                double2_t *fw = reinterpret_cast<double2_t *>(facw + (size_t)slot * VB_FACW);
 #pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    Wr[c] = x0[c] * jf0 + x1[c] * jf1;                                 // H_pf block of frame j (exclusive owner)
-                    facw[(size_t)slot * VB_FACW + c] = x0[6 + c] * jf0 + x1[6 + c] * jf1;   // partial of the anchor-frame block (one 64-byte record per factor)
+                for (int c = 0; c < 6; c += 2) {
+                    Wr[c >> 1] = double2_t{x0[c] * jf0 + x1[c] * jf1, x0[c + 1] * jf0 + x1[c + 1] * jf1};                               // H_pf block of frame j (exclusive owner)
+                    fw[c >> 1] = double2_t{x0[6 + c] * jf0 + x1[6 + c] * jf1, x0[7 + c] * jf0 + x1[7 + c] * jf1};                       // partial of the anchor-frame block (one 64-byte record per factor)
                 }
-                facw[(size_t)slot * VB_FACW + 6] = jf0 * jf0 + jf1 * jf1;
-                facw[(size_t)slot * VB_FACW + 7] = jf0 * x0[12] + jf1 * x1[12];
+                fw[3] = double2_t{jf0 * jf0 + jf1 * jf1, jf0 * x0[12] + jf1 * x1[12]};
             }
         } else {
 #pragma unroll
@@ -601,31 +604,20 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     // ---- visual pose-pose blocks (frame-block lower triangle) -> Hpp[66][36] ------------------------------------------
     // a pair without factors was never written: it reads as zero
 #define PD(p, e) pd_get(pd, s_pcn, (p), (e))
+    double v5[8]; int dst5[8];
     {
-        double *Hpp = b.Hpp + ww * 66 * 36;
         // off-diagonal frame blocks (a > bb): one load each, eight entries of a thread in flight; then the diagonal blocks: the ten pairs of a frame, all loads first
         // (a loop of dependent load -> add trips would wait for every load in turn), same order of additions
-        for (int t0 = tid; t0 < 55 * 36; t0 += 8 * NT) {
-            double v[8]; int dst[8];
+        // (the loads of this phase are issued here and their results stored AFTER the per-feature phase below: the two phases read what the chunk loop wrote through L2 and
+        // are otherwise independent — one after the other each paid its own round trips)
+        static_assert(55 * 36 <= 8 * NT, "one pass of eight entries per thread");
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int t = min(t0 + k * NT, 55 * 36 - 1), ob = t / 36, e = t - 36 * ob;       // ob-th off-diagonal block = pair (bb, a), bb < a, in pair_index order
-                int a = 1; while (a * (a + 1) / 2 <= ob) a++;
-                const int bb = ob - a * (a - 1) / 2;
-                v[k] = PD(pair_index(bb, a), 36 + e);
-                dst[k] = (t0 + k * NT < 55 * 36) ? 36 * (a * (a + 1) / 2 + bb) + e : -1;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) if (dst[k] >= 0) Hpp[dst[k]] = v[k];
-        }
-        for (int t = tid; t < VB_NF * 36; t += NT) {
-            const int a = t / 36, e = t - 36 * a;
-            double v[VB_NF - 1], s = 0;
-#pragma unroll
-            for (int k = 0; k < VB_NF - 1; k++) v[k] = (k < a) ? PD(pair_index(min(k, a - 1), a), e) : PD(pair_index(a, k + 1), 72 + e);
-#pragma unroll
-            for (int k = 0; k < VB_NF - 1; k++) s += v[k];
-            Hpp[36 * (a * (a + 1) / 2 + a) + e] = s;
+        for (int k = 0; k < 8; k++) {
+            const int t = min(tid + k * NT, 55 * 36 - 1), ob = t / 36, e = t - 36 * ob;       // ob-th off-diagonal block = pair (bb, a), bb < a, in pair_index order
+            int a = 1; while (a * (a + 1) / 2 <= ob) a++;
+            const int bb = ob - a * (a - 1) / 2;
+            v5[k] = PD(pair_index(bb, a), 36 + e);
+            dst5[k] = (tid + k * NT < 55 * 36) ? 36 * (a * (a + 1) / 2 + bb) + e : -1;
         }
     }
     LSTAMP(6);
@@ -640,9 +632,11 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             for (int t0 = 0; t0 < n; t0 += 4) {           // four factor records per trip in flight, added in factor order
                 double v[4][8];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < 4; u++) {              // a record = four 16-byte loads
+                    const double2_t *rp = reinterpret_cast<const double2_t *>(facw + (size_t)(f0 + min(t0 + u, n - 1)) * VB_FACW);
 #pragma unroll
-                    for (int c = 0; c < 8; c++) v[u][c] = facw[(size_t)(f0 + min(t0 + u, n - 1)) * VB_FACW + c];
+                    for (int c = 0; c < 4; c++) { const double2_t q2 = rp[c]; v[u][2 * c] = q2[0]; v[u][2 * c + 1] = q2[1]; }
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) if (t0 + u < n) {
 #pragma unroll
@@ -654,6 +648,20 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             for (int c = 0; c < 6; c++) Wr[6 * f_start[f] + c] = acc[c];
             Wr[VB_NPOSE] = acc[7];                      // column 66 carries g_f through the Schur MFMA
             hf[f] = acc[6]; gf[f] = acc[7];
+        }
+    }
+    {
+        double *Hpp = b.Hpp + ww * 66 * 36;
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (dst5[k] >= 0) Hpp[dst5[k]] = v5[k];
+        for (int t = tid; t < VB_NF * 36; t += NT) {
+            const int a = t / 36, e = t - 36 * a;
+            double v[VB_NF - 1], s = 0;
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) v[k] = (k < a) ? PD(pair_index(min(k, a - 1), a), e) : PD(pair_index(a, k + 1), 72 + e);
+#pragma unroll
+            for (int k = 0; k < VB_NF - 1; k++) s += v[k];
+            Hpp[36 * (a * (a + 1) / 2 + a) + e] = s;
         }
     }
     __syncthreads();

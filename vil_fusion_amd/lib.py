@@ -6,7 +6,7 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libvilfusion_hip.so")
+SO_PATH = os.environ.get("VILF_SO") or os.path.join(CSRC, "libvilfusion_hip.so")      # VILF_SO: another build of the library (same-box A/B of a kernel change: tools/)
 _lib = None
 
 EXPORTED = [
