@@ -11,7 +11,9 @@ buf = (C.c_longlong * 256)()
 L.vilf_debug_stamps_s2m.argtypes = [C.POINTER(C.c_longlong)]
 L.vilf_debug_stamps_s2m(buf)
 a = np.array(buf[:]).reshape(8, 32)
-names = {0: ("scan_voxel<24> (surf cloud)", ["bbox", "keys", "radix sort", "heads+centroids"]), 1: ("scan_voxel<32> (edge cloud)", ["bbox", "keys", "radix sort", "heads+centroids"]),
+import os
+SVP = ["bbox", "keys", "radix sort", "heads+centroids"] if os.environ.get("VILF_SV_NO_RUNS") else ["points -> runs", "keys", "radix sort", "leaf heads", "leaf sums"]     # aux: key bits, runs, leaves
+names = {0: ("scan_voxel (surf cloud)", SVP), 1: ("scan_voxel (edge cloud)", SVP),
          2: ("bucket_index surf", ["zero", "count pass", "wait", "scan", "scatter pass", "wait"]), 3: ("bucket_index edge", ["zero", "count pass", "wait", "scan", "scatter pass", "wait"]),
          4: ("map_update surf", ["tail sort", "sweep", "queued", "beyond"]), 5: ("map_update edge", ["tail sort", "sweep", "queued", "beyond"])}
 for k, (nm, ph) in names.items():

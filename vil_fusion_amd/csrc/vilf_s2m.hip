@@ -268,7 +268,7 @@ __device__ __forceinline__ void sv_run_sum(const float4 *s_tq, int b, int cnt, i
     }
 }
 template <bool K24>
-__global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet out, int cap, int *err) {
+__device__ __forceinline__ void sv_body(const int sid, const CSet &in, float inv, const CSet &out, int cap, int *err) {
     extern __shared__ unsigned int sv_lds[];
     // K24: lo16[cap] a[cap] b[cap] (u16) hi8[cap] (u8) cnt;   else: key32[cap] a[cap] b[cap] cnt      (cap is a multiple of 16)
     unsigned int *s_key = sv_lds;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
     unsigned short *s_cnt = K24 ? reinterpret_cast<unsigned short *>(s_hi + cap) : s_b + cap;     // [256 digits][16 waves]
     __shared__ float s_mm[6][16];
     __shared__ int s_w2[2][16], s_geo[8];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = in.n[sid];
     if (n > cap) return;                                   // a larger cloud: the global-sort path takes this stream (s2b_step)
     const float4 *p = in.p + (size_t)sid * in.cap;
@@ -481,6 +481,277 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
     if (blockIdx.x == S2M_STAMP_WG && tid == 0) { s2m_dbg[(K24 ? 0 : 1) * 32 + 30] = n; s2m_dbg[(K24 ? 0 : 1) * 32 + 31] = vbits; }
 #endif
     if (tid == 0) out.n[sid] = carry;
+}
+// list == nullptr: one workgroup per stream. Otherwise the streams b_scan_voxel_runs (below) handed back — list[0] of them, list[1..] — are shared out over the grid.
+template <bool K24>
+__global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet out, int cap, int *err, const int *list) {
+    if (!list) { sv_body<K24>(blockIdx.x, in, inv, out, cap, err); return; }
+    const int cnt = list[0];
+    for (int li = blockIdx.x; li < cnt; li += gridDim.x) {
+        sv_body<K24>(list[1 + li], in, inv, out, cap, err);
+        __syncthreads();                                   // the next stream rewrites the LDS state
+    }
+}
+
+// ---- pcl::VoxelGrid of a scan cloud from its RUNS --------------------------------------------------------------------------------
+// A scan arrives ring after ring, azimuth ascending: a point mostly falls into the leaf of its predecessor (KITTI-like surf clouds: ~4 points per run, ~1.5 runs
+// per leaf). A RUN — consecutive points with one leaf — is what gets sorted here, not the point: the stable sort by key of (key, first index) keeps every leaf's
+// runs in scan order, and the points of a run are consecutive in memory, so walking a leaf's runs adds its points in index order: the same serial float chain as sv_body
+// (and as pcl's accumulation), from a quarter of the sort and from coalesced reads instead of per-point gathers. The LDS holds 10 bytes per RUN (32-bit key, 16-bit
+// first index, two 16-bit index arrays) instead of 7-8 per POINT: two workgroups of eight waves per CU, one's point passes (HBM) beside the other's sort (LDS).
+// The points are read twice (runs, sums), not three times: a run is detected on ABSOLUTE leaf coordinates (kept as 16-bit offsets from the first point's leaf), the
+// bounding box is the minimum / maximum of those (floor(x * inv) is monotonic: the leaf of the smallest x is the smallest leaf), and the keys follow from both in LDS.
+// A cloud with more than rc runs (no scan order: random test clouds), a key wider than 32 bits or leaves further than 2^15 from the first point's is handed back:
+// its stream goes on `list`, which b_scan_voxel takes.
+#define SR_T 512
+#define SR_NW (SR_T / 64)
+#define SR_E 4
+#define SR_RC 7168
+#define SR_RPT (SR_RC / SR_T)              // runs per thread in the coordinate -> key pass
+#define SR_SPW (SR_RC / SR_NW / 64)        // 64-run strips of a wave's segment in the sort
+static size_t sr_lds_bytes(int rc) { return (size_t)10 * rc + 4 + 2 * 256 * SR_NW; }
+__global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv, CSet out, int maxn, int rc, int *list, int kid) {
+    extern __shared__ unsigned int sr_lds[];
+    unsigned int *s_rkey = sr_lds;                                                          // [rc]        leaf key of run r (runs in scan order); before the keys exist: the z offsets (16-bit)
+    unsigned short *s_rstart = reinterpret_cast<unsigned short *>(s_rkey + rc);             // [rc + 2]    index of its first point; [nruns] = n
+    unsigned short *s_a = s_rstart + rc + 2, *s_b = s_a + rc;                               // [rc] each   run ids, ping-pong of the sort (before: the x and y offsets; afterwards: first sorted position of every leaf)
+    unsigned short *s_cnt = s_b + rc;                                                       // [256 digits][SR_NW waves]
+    unsigned short *s_z16 = reinterpret_cast<unsigned short *>(s_rkey);
+    __shared__ int s_mm[6][SR_NW];
+    __shared__ int s_w2[2][SR_E][SR_NW], s_geo[8], s_sc[SR_NW], s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sid = blockIdx.x;
+    const int n = in.n[sid];
+    if (n > maxn) return;                                   // a larger cloud: the global-sort path takes this stream (s2b_step)
+    const float4 *p = in.p + (size_t)sid * in.cap;
+    float4 *o = out.p + (size_t)sid * out.cap;
+    if (n <= 0) { if (tid == 0) out.n[sid] = 0; return; }
+    (void)kid;
+    S2M_STAMP(kid, 0, true);
+    if (tid == 0) s_bad = 0;
+    // ---- A. one pass over the points: leaf coordinates, runs (a point whose leaf differs from its predecessor's opens one; run ids in scan order from a running count
+    // of the heads), bounding box of the leaves. The next tile's points are in flight.
+    int o0, o1, o2;
+    { const float4 q0 = p[0]; o0 = (int)floorf(__fmul_rn(q0.x, inv)) - 32768; o1 = (int)floorf(__fmul_rn(q0.y, inv)) - 32768; o2 = (int)floorf(__fmul_rn(q0.z, inv)) - 32768; }
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    int carry = 0, par = 0;
+    {
+        // (lane 0's predecessor sits in another wave: its point is requested with the tile, one lane's load of a line that is on its way anyway. A load at the point of
+        //  use would be the newest one in flight: waiting for it waits for the whole prefetch — memory returns in order — a round trip per strip, as first written)
+        float4 qn[SR_E], qpn[SR_E], qn2[SR_E], qpn2[SR_E];              // two tiles in flight: one ahead left every tile waiting a memory round trip
+#pragma unroll
+        for (int u = 0; u < SR_E; u++) {
+            const int i0 = u * SR_T + tid, i1 = SR_E * SR_T + i0;
+            qn[u] = p[min(i0, n - 1)]; qpn[u] = qn[u]; if (lane == 0) qpn[u] = p[min(max(i0 - 1, 0), n - 1)];
+            qn2[u] = p[min(i1, n - 1)]; qpn2[u] = qn2[u]; if (lane == 0) qpn2[u] = p[min(i1 - 1, n - 1)];
+        }
+        for (int t0 = 0; t0 < n; t0 += SR_E * SR_T) {
+            int lx[SR_E], ly[SR_E], lz[SR_E], head[SR_E];
+            unsigned long long hb[SR_E];
+            float4 q[SR_E], qp[SR_E];
+#pragma unroll
+            for (int u = 0; u < SR_E; u++) {
+                q[u] = qn[u]; qp[u] = qpn[u]; qn[u] = qn2[u]; qpn[u] = qpn2[u];
+                const int inx = t0 + 2 * SR_E * SR_T + u * SR_T + tid;
+                qn2[u] = p[min(inx, n - 1)];
+                if (lane == 0) qpn2[u] = p[min(inx - 1, n - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < SR_E; u++) {
+                const int i = t0 + u * SR_T + tid;
+                lx[u] = (int)floorf(__fmul_rn(q[u].x, inv)) - o0; ly[u] = (int)floorf(__fmul_rn(q[u].y, inv)) - o1; lz[u] = (int)floorf(__fmul_rn(q[u].z, inv)) - o2;
+                int px = __shfl_up(lx[u], 1, 64), py = __shfl_up(ly[u], 1, 64), pz = __shfl_up(lz[u], 1, 64);
+                if (lane == 0) { px = (int)floorf(__fmul_rn(qp[u].x, inv)) - o0; py = (int)floorf(__fmul_rn(qp[u].y, inv)) - o1; pz = (int)floorf(__fmul_rn(qp[u].z, inv)) - o2; }
+                head[u] = (i < n && (i == 0 || px != lx[u] || py != ly[u] || pz != lz[u])) ? 1 : 0;
+                hb[u] = __ballot(head[u]);
+                if (i < n) {
+                    mn[0] = min(mn[0], lx[u]); mn[1] = min(mn[1], ly[u]); mn[2] = min(mn[2], lz[u]);
+                    mx[0] = max(mx[0], lx[u]); mx[1] = max(mx[1], ly[u]); mx[2] = max(mx[2], lz[u]);
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int u = 0; u < SR_E; u++) s_w2[par][u][wave] = __popcll(hb[u]);
+            }
+            __syncthreads();
+            int base = carry;
+#pragma unroll
+            for (int u = 0; u < SR_E; u++) {
+                int off = 0, tot = 0;
+#pragma unroll
+                for (int k = 0; k < SR_NW; k++) { const int x = s_w2[par][u][k]; if (k < wave) off += x; tot += x; }
+                if (head[u]) {
+                    const int r = base + off + __popcll(hb[u] & ((1ULL << lane) - 1ULL));
+                    if (r < rc) { s_a[r] = (unsigned short)lx[u]; s_b[r] = (unsigned short)ly[u]; s_z16[r] = (unsigned short)lz[u]; s_rstart[r] = (unsigned short)(t0 + u * SR_T + tid); }
+                }
+                base += tot;
+            }
+            carry = base; par ^= 1;                        // (s_w2 is double-buffered: one barrier per tile)
+        }
+    }
+    const int nruns = carry;
+    S2M_STAMP(kid, 1, true);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int of = 32; of > 0; of >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], of, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], of, 64)); }
+        if (lane == 0) { s_mm[k][wave] = mn[k]; s_mm[3 + k][wave] = mx[k]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int vb = 0, far = 0;
+        for (int k = 0; k < 3; k++) {
+            int a = s_mm[k][0], b = s_mm[3 + k][0];
+            for (int w2 = 1; w2 < SR_NW; w2++) { a = min(a, s_mm[k][w2]); b = max(b, s_mm[3 + k][w2]); }
+            if (a < 0 || b > 65535) far = 1;                // a leaf outside the 16-bit window around the first point's
+            s_geo[k] = a; s_geo[3 + k] = sv_bits(b - a + 1);
+            vb += s_geo[3 + k];
+        }
+        s_geo[6] = vb;
+        s_bad = (far || vb > 32 || nruns > rc) ? 1 : 0;     // (a key wider than 32 bits: sv_body reports it, S2B_ERR_VOXEL)
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) list[1 + atomicAdd(list, 1)] = sid; return; }
+    const int mb0 = s_geo[0], mb1 = s_geo[1], mb2 = s_geo[2], bx = s_geo[3], by = s_geo[4], vbits = s_geo[6];
+    {   // leaf coordinates packed z | y | x (the order of pcl's leaf index), in place of the offsets: every thread's runs through registers
+        unsigned int xy[SR_RPT], zz[SR_RPT];
+#pragma unroll
+        for (int k = 0; k < SR_RPT; k++) { const int r = min(tid + SR_T * k, nruns - 1); xy[k] = (unsigned int)s_a[r] | ((unsigned int)s_b[r] << 16); zz[k] = s_z16[r]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SR_RPT; k++) {
+            const int r = tid + SR_T * k;
+            if (r < nruns) {
+                const unsigned int a = (xy[k] & 0xffffu) - (unsigned int)mb0, b = (xy[k] >> 16) - (unsigned int)mb1, c = zz[k] - (unsigned int)mb2;
+                s_rkey[r] = (bx + by < 32 ? (c << (bx + by)) : 0u) | (b << bx) | a;
+                s_a[r] = (unsigned short)r;
+            }
+        }
+        if (tid == 0) s_rstart[nruns] = (unsigned short)n;
+    }
+    __syncthreads();
+    S2M_STAMP(kid, 2, true);
+    // ---- C. stable LSD radix sort of the run ids by key, 8 bits per pass (sv_body's: every wave owns a contiguous segment and ranks a 64-lane strip by ballot matching).
+    // What the counting loop learns about a run — its id and digit (two dependent LDS reads), its rank among the strip's runs with the same digit and their number (eight
+    // ballots) — stays in registers for the scatter loop of the pass (two per strip, at most SR_SPW strips per wave): the phase is bound by instructions issued.
+    unsigned short *src = s_a, *dst = s_b;
+    {
+        const int seg = (nruns + SR_NW - 1) / SR_NW, lo = wave * seg, hi = min(nruns, lo + seg);
+        unsigned int *cnt32 = reinterpret_cast<unsigned int *>(s_cnt);
+        for (int shift = 0; shift < vbits; shift += 8) {
+            for (int t = tid; t < 128 * SR_NW; t += SR_T) cnt32[t] = 0;
+            __syncthreads();
+            unsigned int pk[SR_SPW], rk[SR_SPW];                 // id | digit << 16 | valid << 24;  rank | same-digit count << 8
+#pragma unroll
+            for (int st = 0; st < SR_SPW; st++) {
+                pk[st] = 0; rk[st] = 0;
+                if (lo + 64 * st < hi) {
+                    const int j = lo + 64 * st + lane;
+                    const bool valid = j < hi;
+                    const unsigned int idx = valid ? src[j] : 0u;
+                    const int d = valid ? (int)((s_rkey[idx] >> shift) & 255u) : 0;
+                    unsigned long long mask = __ballot(valid);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) { const unsigned long long bal = __ballot((d >> b) & 1); mask &= ((d >> b) & 1) ? bal : ~bal; }
+                    const int rank = __popcll(mask & ((1ULL << lane) - 1ULL)), same = __popcll(mask);
+                    if (valid && rank == 0) s_cnt[d * SR_NW + wave] += (unsigned short)same;
+                    pk[st] = idx | ((unsigned int)d << 16) | (valid ? 1u << 24 : 0u); rk[st] = (unsigned int)rank | ((unsigned int)same << 8);
+                }
+            }
+            __syncthreads();
+            {   // exclusive scan in (digit, wave) order: thread t owns entries 4 t .. 4 t + 3 of [digit][wave]
+                int c4[4], loc = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { c4[u] = s_cnt[4 * tid + u]; loc += c4[u]; }
+                int tot;
+                int run = block_excl_scan_nw<SR_NW>(loc, s_sc, tot);
+#pragma unroll
+                for (int u = 0; u < 4; u++) { s_cnt[4 * tid + u] = (unsigned short)run; run += c4[u]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int st = 0; st < SR_SPW; st++) {                // a wave walks its own segment in order: its counter column needs no synchronisation
+                if (lo + 64 * st < hi && (pk[st] >> 24)) {
+                    const int d = (pk[st] >> 16) & 255, rank = rk[st] & 255;
+                    const int off = s_cnt[d * SR_NW + wave];
+                    dst[off + rank] = (unsigned short)(pk[st] & 0xffffu);
+                    if (rank == 0) s_cnt[d * SR_NW + wave] = (unsigned short)(off + (rk[st] >> 8));
+                }
+            }
+            __syncthreads();
+            unsigned short *t = src; src = dst; dst = t;
+        }
+    }
+    S2M_STAMP(kid, 3, true);
+    // ---- D. leaves: the sorted position of every leaf's first run (ranks from a running count of the key changes) ...
+    carry = 0;
+    for (int t0 = 0; t0 < nruns; t0 += SR_T) {
+        const int j = t0 + tid, jc = min(j, nruns - 1);
+        const unsigned int k = s_rkey[src[jc]], kp = s_rkey[src[max(jc - 1, 0)]];
+        const int head = (j < nruns && (j == 0 || kp != k)) ? 1 : 0;
+        const unsigned long long hb = __ballot(head);
+        if (lane == 0) s_w2[par][0][wave] = __popcll(hb);
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int k2 = 0; k2 < SR_NW; k2++) { const int x = s_w2[par][0][k2]; if (k2 < wave) off += x; tot += x; }
+        if (head) dst[carry + off + __popcll(hb & ((1ULL << lane) - 1ULL))] = (unsigned short)j;
+        carry += tot; par ^= 1;
+    }
+    const int nleaf = carry;
+    __syncthreads();
+    S2M_STAMP(kid, 4, true);
+    // ... then a lane per leaf, no barrier: its runs in sorted (= scan) order, each run's points in index order, up to eight points per step — the rest of the lane's current
+    // run and, behind it, the start of the next (a batch per run: a 100-point leaf of 4-point runs took 20 steps). The loop is the same straight line for every lane (a lane
+    // without work loads point 0 again): a batch is cut by the lane's cursor and requested one step before its points are added, and the compiler can count the loads in
+    // flight (divergent per-leaf loops ended in s_waitcnt vmcnt(0) at every turn: a memory round trip per batch). A lane that completes a leaf DRAWS the next one from a
+    // counter in LDS: the phase is bound by the instructions a wave issues, and a wave runs as long as its busiest lane — with leaves dealt out in advance (lane = leaf mod
+    // 512) that was 25 steps against a mean of 10.
+    {
+        __shared__ int s_next;
+        if (tid == 0) s_next = SR_T;
+        __syncthreads();
+        int L = tid, jj = 0, j1 = 0, k = 0, e0 = 0, cnt = 0;
+        bool active = L < nleaf;
+        if (active) { jj = dst[L]; j1 = (L + 1 < nleaf) ? dst[L + 1] : nruns; }
+        struct Batch { float4 v[8]; int m, leaf, cnt; };      // m points; leaf >= 0: the batch completes that leaf (cnt points in all)
+        auto cut = [&](Batch &bt) {
+            int na = active ? e0 - k : 0;
+            if (active && na == 0 && jj < j1) { const int r = src[jj]; k = s_rstart[r]; e0 = s_rstart[r + 1]; na = e0 - k; cnt += na; jj++; }
+            na = min(na, 8);
+            const int ka = k;
+            k += na;
+            int nb = 0, kb = 0;
+            if (active && na < 8 && jj < j1) { const int r = src[jj]; k = s_rstart[r]; e0 = s_rstart[r + 1]; cnt += e0 - k; jj++; nb = min(8 - na, e0 - k); kb = k - na; k += nb; }
+            bt.m = na + nb;
+#pragma unroll
+            for (int u = 0; u < 8; u++) bt.v[u] = p[u < na ? ka + u : (u < bt.m ? kb + u : 0)];
+            bt.leaf = -1; bt.cnt = cnt;
+            if (bt.m > 0 && k >= e0 && jj >= j1) {             // the leaf is complete: the lane draws its next one
+                bt.leaf = L;
+                L = atomicAdd(&s_next, 1); active = L < nleaf; cnt = 0; k = 0; e0 = 0;
+                if (active) { jj = dst[L]; j1 = (L + 1 < nleaf) ? dst[L + 1] : nruns; }
+            }
+        };
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        Batch b0, b1;
+        cut(b0);
+        while (__any(b0.m > 0)) {
+            cut(b1);
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (u < b0.m) { acc.x = __fadd_rn(acc.x, b0.v[u].x); acc.y = __fadd_rn(acc.y, b0.v[u].y); acc.z = __fadd_rn(acc.z, b0.v[u].z); acc.w = __fadd_rn(acc.w, b0.v[u].w); }
+            if (b0.leaf >= 0) {
+                const float nn = (float)b0.cnt;
+                o[b0.leaf] = make_float4(acc.x / nn, acc.y / nn, acc.z / nn, acc.w / nn);
+                acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            b0 = b1;
+        }
+    }
+    S2M_STAMP(kid, 5, true);
+#ifdef VILF_STAMPS
+    if (blockIdx.x == S2M_STAMP_WG && tid == 0) { s2m_dbg[kid * 32 + 30] = n; s2m_dbg[kid * 32 + 31] = vbits; s2m_dbg[kid * 32 + 29] = nruns; s2m_dbg[kid * 32 + 28] = nleaf; }
+#endif
+    if (tid == 0) out.n[sid] = nleaf;
 }
 
 // ---- fused steady-state map update: crop box + voxel grid of (leaf-ordered old map ++ appended scan) in ONE pass -------------
@@ -1545,6 +1816,7 @@ struct S2B {
     DBuf nOld, mOld;                                     // map point counts before the append / surviving the crop (unsorted-map path)
     DBuf keys, keys2, vals, vals2, temp, mm, frec, fkind, pose, res, err, bits;
     DBuf map0[2], nMap0[2], pose0, muT, tileHeads;
+    DBuf svlist[2];                              // streams b_scan_voxel_runs hands back to b_scan_voxel: [0] count, [1..] stream ids
     DBuf bigmap[2]; std::vector<int> h_big[2];   // streams whose scan cloud does not fit the in-LDS voxel grid (b_scan_voxel): the global-sort path takes them as a sub-batch
     // The neighbour directory travels with its map: bstart pairs with map, bstartAlt with mapAlt (the map update writes the directory of the map it emits), dir0 with map0.
     DBuf bstartAlt[2], dir0[2], fixq[2];
@@ -1630,6 +1902,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         HIPCHECK(h, hipMemsetAsync(c->err.p, 0, (size_t)S * 4, h->stream));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS32 * 8 + 8192));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SV_MAXPTS24 * 7 + 8192));
+        HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_scan_voxel_runs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sr_lds_bytes(SR_RC)));
         HIPCHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(b_map_update<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MU_LDS_TAIL * 8 + MU_TILE * 12));
         HIPCHECK(h, hipStreamSynchronize(h->stream));
         c->h_res.assign(S, S2BRes{});
@@ -1796,8 +2069,21 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         if ((int)big.size() < S) {
             const int cap = (std::max(nmax, 1) + 15) & ~15;
             const size_t stage = (cap * 2 >= 2 * SV_T * 16) ? 0 : (size_t)2 * SV_T * 16;      // small clouds: the tile staging area gets its own LDS
-            if (cap <= SV_MAXPTS32) hipLaunchKernelGGL(b_scan_voxel<false>, dim3(S), dim3(SV_T), (size_t)cap * 8 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
-            else hipLaunchKernelGGL(b_scan_voxel<true>, dim3(S), dim3(SV_T), (size_t)cap * 7 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err);
+            // the run-sorting grid first (b_scan_voxel_runs); the streams it hands back — clouds without scan order, more than rc runs — are shared out over one workgroup
+            // per CU of the point-sorting grid. VILF_SV_NO_RUNS=1: the point-sorting grid for every stream (as before round 4); VILF_SV_RC: run capacity (tests force the hand-back with it)
+            static const bool no_runs = std::getenv("VILF_SV_NO_RUNS") != nullptr;
+            static const int rc_env = std::getenv("VILF_SV_RC") ? std::atoi(std::getenv("VILF_SV_RC")) : SR_RC;
+            const int rc = std::max(64, std::min(SR_RC, rc_env)) & ~1;
+            int *d_list = nullptr;
+            if (!no_runs) {
+                if (!c->svlist[w].ensure(((size_t)S + 1) * 4)) return VILF_ERR_DEVICE;
+                d_list = c->svlist[w].as<int>();
+                HIPCHECK(h, hipMemsetAsync(d_list, 0, 4, h->stream));
+                hipLaunchKernelGGL(b_scan_voxel_runs, dim3(S), dim3(SR_T), sr_lds_bytes(rc), h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), SV_MAXPTS24, rc, d_list, w == 1 ? 0 : 1);
+            }
+            const dim3 gsv(d_list ? (unsigned)std::min(S, 256) : (unsigned)S);
+            if (cap <= SV_MAXPTS32) hipLaunchKernelGGL(b_scan_voxel<false>, gsv, dim3(SV_T), (size_t)cap * 8 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err, d_list);
+            else hipLaunchKernelGGL(b_scan_voxel<true>, gsv, dim3(SV_T), (size_t)cap * 7 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err, d_list);
             PROF(0)
         }
         if (!big.empty()) {
