@@ -257,6 +257,51 @@ def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
 
 
 @pytest.mark.gpu
+def test_scan_voxel_grid_from_runs_and_handed_back_streams_in_one_batch(oracle):
+    """The scan voxel grid sorts RUNS of consecutive points with one leaf (b_scan_voxel_runs) and hands clouds without scan order back to the point-sorting grid
+    (b_scan_voxel): one batch holds a ring-ordered cloud (long runs, leaves of many runs, runs across the 64-lane strips and the 2048-point tiles), a random cloud
+    with more runs than the run grid holds (handed back) and a small random one (every point its own run). Down-sampled counts identical, maps bit-identical
+    to the oracle over 3 frames (the map is the voxel grid of map + scan: every centroid is a serial float sum in index order)."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
+    o = oracle.default_options()
+    o.s2m_crop_half = 30.0
+    rng = np.random.default_rng(5)
+    def rings(n_ring, n_az, jitter):
+        az = np.linspace(0, 2 * np.pi, n_az, endpoint=False)
+        pts = []
+        for r in range(n_ring):
+            rad = 4.0 + 1.3 * r + 0.5 * np.sin(3 * az + r)
+            pts.append(np.stack([rad * np.cos(az), rad * np.sin(az), -1.5 + 0.02 * r * np.cos(az), np.full_like(az, r)], 1))
+        c = np.concatenate(pts).astype(np.float32)
+        c[:, :3] += rng.normal(0, jitter, (len(c), 3)).astype(np.float32)
+        return c
+    cloud = lambda n, h: np.concatenate([rng.uniform(-h, h, (n, 3)), rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    S = 3
+    s = BackendSolver(o)
+    b = Scan2MapBatch(s, S, 64, 21000, 256, 120000)
+    refs = [oracle.OracleS2M(o) for _ in range(S)]
+    ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    for i in range(S):
+        me, ms = cloud(5, 1.0), cloud(3000, 20.0)
+        b.localMapInited(i, me, ms, ident, ident)
+        refs[i].init(me, ms); refs[i].set_pose(ident, ident)
+    for f in range(3):
+        scans = [rings(16, 1250, 0.002 * (f + 1)), cloud(12000, 20.0), cloud(3000, 20.0)]
+        e = cloud(1, 1.0)
+        want = []
+        for i in range(S):
+            b.set_scan(i, e, scans[i])
+            want.append(refs[i].step(e, scans[i]))
+        b.step()
+        got = b.results()
+        for i in range(S):
+            assert (got[i].n_edge_ds, got[i].n_surf_ds) == (want[i].n_edge_ds, want[i].n_surf_ds), (f, i)
+            assert np.array_equal(b.getMapCloud(i, 1), refs[i].get_map(1)), (f, i)
+    assert want[0].n_surf_ds < 20000 // 3 and want[1].n_surf_ds > 7168           # long runs in the ring cloud; more leaves than the run grid holds runs in the random one
+    s.close()
+
+
+@pytest.mark.gpu
 def test_voxel_index_overflow_fails_loudly(oracle):
     """a leaf so small that the scan's voxel index needs more than 32 bits (17 bits per axis here) must be reported, not silently mis-binned"""
     from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch

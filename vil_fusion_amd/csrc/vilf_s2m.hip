@@ -509,6 +509,7 @@ __global__ __launch_bounds__(SV_T) void b_scan_voxel(CSet in, float inv, CSet ou
 #define SR_RC 7168
 #define SR_RPT (SR_RC / SR_T)              // runs per thread in the coordinate -> key pass
 #define SR_SPW (SR_RC / SR_NW / 64)        // 64-run strips of a wave's segment in the sort
+__device__ float4 sr_neutral = {-0.0f, -0.0f, -0.0f, -0.0f};      // what an empty slot of a batch loads: the adds of the leaf sums are unconditional
 static size_t sr_lds_bytes(int rc) { return (size_t)10 * rc + 4 + 2 * 256 * SR_NW; }
 __global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv, CSet out, int maxn, int rc, int *list, int kid) {
     extern __shared__ unsigned int sr_lds[];
@@ -559,9 +560,11 @@ __global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv,
             for (int u = 0; u < SR_E; u++) {
                 const int i = t0 + u * SR_T + tid;
                 lx[u] = (int)floorf(__fmul_rn(q[u].x, inv)) - o0; ly[u] = (int)floorf(__fmul_rn(q[u].y, inv)) - o1; lz[u] = (int)floorf(__fmul_rn(q[u].z, inv)) - o2;
-                int px = __shfl_up(lx[u], 1, 64), py = __shfl_up(ly[u], 1, 64), pz = __shfl_up(lz[u], 1, 64);
-                if (lane == 0) { px = (int)floorf(__fmul_rn(qp[u].x, inv)) - o0; py = (int)floorf(__fmul_rn(qp[u].y, inv)) - o1; pz = (int)floorf(__fmul_rn(qp[u].z, inv)) - o2; }
-                head[u] = (i < n && (i == 0 || px != lx[u] || py != ly[u] || pz != lz[u])) ? 1 : 0;
+                // (x and y offsets as one word: exact while they fit 16 bits, and a cloud where they do not is handed back below)
+                const int xy = (lx[u] & 0xffff) | (ly[u] << 16);
+                int pxy = __shfl_up(xy, 1, 64), pz = __shfl_up(lz[u], 1, 64);
+                if (lane == 0) { pxy = (((int)floorf(__fmul_rn(qp[u].x, inv)) - o0) & 0xffff) | (((int)floorf(__fmul_rn(qp[u].y, inv)) - o1) << 16); pz = (int)floorf(__fmul_rn(qp[u].z, inv)) - o2; }
+                head[u] = (i < n && (i == 0 || pxy != xy || pz != lz[u])) ? 1 : 0;
                 hb[u] = __ballot(head[u]);
                 if (i < n) {
                     mn[0] = min(mn[0], lx[u]); mn[1] = min(mn[1], ly[u]); mn[2] = min(mn[2], lz[u]);
@@ -641,6 +644,7 @@ __global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv,
             for (int t = tid; t < 128 * SR_NW; t += SR_T) cnt32[t] = 0;
             __syncthreads();
             unsigned int pk[SR_SPW], rk[SR_SPW];                 // id | digit << 16 | valid << 24;  rank | same-digit count << 8
+            const int nbit = min(8, vbits - shift);
 #pragma unroll
             for (int st = 0; st < SR_SPW; st++) {
                 pk[st] = 0; rk[st] = 0;
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv,
                     const int d = valid ? (int)((s_rkey[idx] >> shift) & 255u) : 0;
                     unsigned long long mask = __ballot(valid);
 #pragma unroll
-                    for (int b = 0; b < 8; b++) { const unsigned long long bal = __ballot((d >> b) & 1); mask &= ((d >> b) & 1) ? bal : ~bal; }
+                    for (int b = 0; b < 8; b++) if (b < nbit) { const unsigned long long bal = __ballot((d >> b) & 1); mask &= ((d >> b) & 1) ? bal : ~bal; }     // (the last pass of a 19-bit key has three bits)
                     const int rank = __popcll(mask & ((1ULL << lane) - 1ULL)), same = __popcll(mask);
                     if (valid && rank == 0) s_cnt[d * SR_NW + wave] += (unsigned short)same;
                     pk[st] = idx | ((unsigned int)d << 16) | (valid ? 1u << 24 : 0u); rk[st] = (unsigned int)rank | ((unsigned int)same << 8);
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv,
             if (active && na < 8 && jj < j1) { const int r = src[jj]; k = s_rstart[r]; e0 = s_rstart[r + 1]; cnt += e0 - k; jj++; nb = min(8 - na, e0 - k); kb = k - na; k += nb; }
             bt.m = na + nb;
 #pragma unroll
-            for (int u = 0; u < 8; u++) bt.v[u] = p[u < na ? ka + u : (u < bt.m ? kb + u : 0)];
+            for (int u = 0; u < 8; u++) bt.v[u] = u < bt.m ? p[u < na ? ka + u : kb + u] : sr_neutral;
             bt.leaf = -1; bt.cnt = cnt;
             if (bt.m > 0 && k >= e0 && jj >= j1) {             // the leaf is complete: the lane draws its next one
                 bt.leaf = L;
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv,
         while (__any(b0.m > 0)) {
             cut(b1);
 #pragma unroll
-            for (int u = 0; u < 8; u++) if (u < b0.m) { acc.x = __fadd_rn(acc.x, b0.v[u].x); acc.y = __fadd_rn(acc.y, b0.v[u].y); acc.z = __fadd_rn(acc.z, b0.v[u].z); acc.w = __fadd_rn(acc.w, b0.v[u].w); }
+            for (int u = 0; u < 8; u++) { acc.x = __fadd_rn(acc.x, b0.v[u].x); acc.y = __fadd_rn(acc.y, b0.v[u].y); acc.z = __fadd_rn(acc.z, b0.v[u].z); acc.w = __fadd_rn(acc.w, b0.v[u].w); }      // (an empty slot holds -0: x + -0 = x, for every x)
             if (b0.leaf >= 0) {
                 const float nn = (float)b0.cnt;
                 o[b0.leaf] = make_float4(acc.x / nn, acc.y / nn, acc.z / nn, acc.w / nn);
@@ -2081,7 +2085,7 @@ static int s2b_step(vilf_handle *h, S2B *c) {
                 HIPCHECK(h, hipMemsetAsync(d_list, 0, 4, h->stream));
                 hipLaunchKernelGGL(b_scan_voxel_runs, dim3(S), dim3(SR_T), sr_lds_bytes(rc), h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), SV_MAXPTS24, rc, d_list, w == 1 ? 0 : 1);
             }
-            const dim3 gsv(d_list ? (unsigned)std::min(S, 256) : (unsigned)S);
+            const dim3 gsv(d_list ? (unsigned)std::min(S, 128) : (unsigned)S);
             if (cap <= SV_MAXPTS32) hipLaunchKernelGGL(b_scan_voxel<false>, gsv, dim3(SV_T), (size_t)cap * 8 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err, d_list);
             else hipLaunchKernelGGL(b_scan_voxel<true>, gsv, dim3(SV_T), (size_t)cap * 7 + 8192 + stage, h->stream, c->cs_scan(w), 1.0f / leaf[w], c->cs_ds(w), cap, d_err, d_list);
             PROF(0)
