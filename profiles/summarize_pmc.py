@@ -19,7 +19,7 @@ GROUPS = {   # kernel-name prefix -> bench.py launch group
     "k_marg_prepare": "k_marg_prepare", "k_marg_schur": "k_marg_schur", "k_marg_finish": "k_marg_finish", "k_mf_": "k_marg_finish", "k_prior_prep": "k_prior_prep",
     "b_minmax": "s2m_voxel_grid", "b_voxel_keys": "s2m_voxel_grid", "void b_voxel_keys": "s2m_voxel_grid", "void b_voxel_reduce": "s2m_voxel_grid",
     "void b_voxel_heads": "s2m_voxel_grid", "void b_map_update": "s2m_map_update",
-    "b_check_order": "s2m_voxel_grid", "void b_scan_voxel": "s2m_voxel_grid",
+    "b_check_order": "s2m_voxel_grid", "void b_scan_voxel": "s2m_voxel_grid", "b_scan_voxel_runs": "s2m_voxel_grid",
     "void rocprim": "s2m_radix_sort", "b_bucket_index": "s2m_neighbour_index", "b_dir_build": "s2m_neighbour_index", "b_gather_sorted": "s2m_neighbour_index",
     "b_make_cid": "s2m_neighbour_index", "b_associate": "s2m_associate", "b_solve": "s2m_lm_solve",
     "b_crop_compact": "s2m_submap", "b_transform_append": "s2m_submap", "b_bump": "s2m_submap",
