@@ -302,6 +302,50 @@ def test_scan_voxel_grid_from_runs_and_handed_back_streams_in_one_batch(oracle):
 
 
 @pytest.mark.gpu
+def test_scan_voxel_grid_sizes_around_every_boundary(oracle):
+    """Scan sizes around the 64-run strips, the 2048-point tiles, the run capacity (7168) and the layouts of the point-sorting grid, random / ring-ordered / duplicated
+    clouds, two leaf sizes, no optimisation (empty edge scans: the pose stays the identity, so every map is the voxel grid of map + scan to the bit). A batch whose
+    largest scan has 15.1 k .. 16.4 k points used to ask for more LDS than a CU has (launch failed with "invalid argument"): 16000 is among the sizes."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
+    rng = np.random.default_rng(11)
+    def rings(n, n_ring, jitter, scale):
+        n_az = max(1, n // n_ring)
+        az = np.linspace(0, 2 * np.pi, n_az, endpoint=False)
+        pts = [np.stack([scale * (4.0 + 1.3 * r + 0.5 * np.sin(3 * az + r)) * np.cos(az), scale * (4.0 + 1.3 * r + 0.5 * np.sin(3 * az + r)) * np.sin(az),
+                         -1.5 + 0.02 * r * np.cos(az), np.full_like(az, r)], 1) for r in range(n_ring)]
+        c = np.concatenate(pts)[:n].astype(np.float32)
+        c[:, :3] += rng.normal(0, jitter, (len(c), 3)).astype(np.float32)
+        return c
+    cloud = lambda n, h: np.concatenate([rng.uniform(-h, h, (n, 3)), rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+    sizes = [1, 2, 63, 64, 65, 512, 513, 2047, 2048, 2049, 4096, 7167, 7168, 7169, 8192, 15200, 16000, 16383, 16384, 20000, 21999]
+    S = 4
+    empty = np.zeros((0, 4), dtype=np.float32)
+    for leaf in (0.4, 0.8):
+        o = oracle.default_options(); o.s2m_crop_half = 60.0; o.surf_leaf_size = leaf
+        s = BackendSolver(o)
+        b = Scan2MapBatch(s, S, 64, 22064, 256, 160000)
+        refs = [oracle.OracleS2M(o) for _ in range(S)]
+        ident = np.array([0, 0, 0, 1, 0, 0, 0.0])
+        for i in range(S):
+            me, ms = cloud(5, 1.0), cloud(200, 20.0)
+            b.localMapInited(i, me, ms, ident, ident); refs[i].init(me, ms); refs[i].set_pose(ident, ident)
+        for rnd in range(6):
+            want = []
+            for i in range(S):
+                n = sizes[(4 * rnd + i + (7 if leaf > 0.5 else 0)) % len(sizes)]
+                kind = (rnd + i) % 4
+                sc = cloud(n, 20.0) if kind == 0 else rings(n, [1, 4, 16, 64][(rnd + i) % 4], 0.002 * i, 0.5 + 0.6 * i) if kind == 1 else \
+                    np.repeat(cloud(max(1, n // 7), 20.0), 7, axis=0)[:n] if kind == 2 else np.concatenate([rings(n // 2 + 1, 8, 0.002, 1.0), cloud(n - n // 2, 20.0)])[:max(n, 1)]
+                b.set_scan(i, empty, sc); want.append(refs[i].step(empty, sc))
+            b.step()
+            got = b.results()
+            for i in range(S):
+                assert got[i].n_surf_ds == want[i].n_surf_ds, (leaf, rnd, i)
+                assert np.array_equal(b.getMapCloud(i, 1), refs[i].get_map(1)), (leaf, rnd, i)
+        s.close()
+
+
+@pytest.mark.gpu
 def test_voxel_index_overflow_fails_loudly(oracle):
     """a leaf so small that the scan's voxel index needs more than 32 bits (17 bits per axis here) must be reported, not silently mis-binned"""
     from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch

@@ -2071,8 +2071,11 @@ static int s2b_step(vilf_handle *h, S2B *c) {
         std::vector<int> big;
         for (int i = 0; i < S; i++) { const int n = c->h_nScan[w][i]; if (n > SV_MAXPTS24) big.push_back(i); else nmax = std::max(nmax, n); }
         if ((int)big.size() < S) {
-            const int cap = (std::max(nmax, 1) + 15) & ~15;
-            const size_t stage = (cap * 2 >= 2 * SV_T * 16) ? 0 : (size_t)2 * SV_T * 16;      // small clouds: the tile staging area gets its own LDS
+            int cap = (std::max(nmax, 1) + 15) & ~15;
+            // small clouds: the tile staging area (32 KB) gets its own LDS — unless that would not fit (15.1 k .. 16.4 k points: the launch asked for up to 172 KB and failed with
+            // "invalid argument"; found by tools/dev_soak_voxel.py): such a batch is laid out for 16384 points, whose index buffer holds the staging area
+            if (cap * 2 < 2 * SV_T * 16 && (size_t)cap * 8 + 8192 + (size_t)2 * SV_T * 16 > (size_t)SV_MAXPTS32 * 8 + 8192) cap = SV_T * 16;
+            const size_t stage = (cap * 2 >= 2 * SV_T * 16) ? 0 : (size_t)2 * SV_T * 16;
             // the run-sorting grid first (b_scan_voxel_runs); the streams it hands back — clouds without scan order, more than rc runs — are shared out over one workgroup
             // per CU of the point-sorting grid. VILF_SV_NO_RUNS=1: the point-sorting grid for every stream (as before round 4); VILF_SV_RC: run capacity (tests force the hand-back with it)
             static const bool no_runs = std::getenv("VILF_SV_NO_RUNS") != nullptr;
