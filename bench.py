@@ -872,6 +872,7 @@ def main():
             out["single_frame_latency"] = latency
         if stress is not None:
             out["stress"] = stress
+        out["cpu_baseline"] = None                      # (N > 1, --no-cpu-baseline: the key stays, empty)
         if not args.no_cpu_baseline and world == 1:     # the CPU port is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(opts, wins[:args.distinct], priors[:args.distinct], lidar_cases, not args.no_marginalize)
         print(json.dumps(out))
