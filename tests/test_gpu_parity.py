@@ -1059,3 +1059,38 @@ def test_double2vector_euler_singular_branch_and_gauge_override(solver, oracle, 
     assert abs(sequence.R2ypr(got.Rs[0])[0] - sequence.R2ypr(Rg)[0]) < 1e-9                                # frame-0 yaw = last_R0's yaw
     assert np.abs(ref.Ps - plain_ref.Ps).max() > 1.0, "the override moved the window"
     assert np.abs(got.Ps - ref.Ps).max() < 1e-7 and np.abs(got.Rs - ref.Rs).max() < 1e-8 and np.abs(got.Vs - ref.Vs).max() < 1e-7
+
+@pytest.mark.gpu
+def test_split_linearisation_of_small_batches_is_bit_identical(oracle, opts):
+    """Batches of up to 8 windows (the real-time case is one) spread every window's linearisation over several workgroups (k_linearize_split: one per chunk of factor
+    slots, one for the IMU factors, one for the LiDAR factors + the prior's cost; the last to arrive assembles). Pair products whose factors span chunks hand their MFMA
+    accumulators from workgroup to workgroup, per-thread cost sums are re-added in the single workgroup's order: states, counts, costs and the new priors must equal the
+    one-workgroup-per-window launch (VILF_NO_LIN_SPLIT=1) to the bit — windows of mixed shape, with rejected steps, with and without prior."""
+    import os
+    from vil_fusion_amd.estimator import BackendSolver
+    rng = np.random.default_rng(21)
+    s = BackendSolver(opts)
+    try:
+        for B in (1, 3, 8):
+            wins, priors = [], []
+            for i in range(B):
+                nz = float(rng.choice([0.05, 0.2, 0.8, 2.0]))
+                c = synth.SynthConfig(n_features=int(rng.integers(3, 330)), with_prior=bool(rng.random() < 0.8), const_fraction=float(rng.choice([0.0, 0.4, 1.0])),
+                                      marginalization_flag=(0 if rng.random() < 0.7 else 1), state_noise=(nz, np.deg2rad(10.0 * nz), nz))
+                w, p, _ = synth.make_window(int(rng.integers(1, 10**6)), opts, c)
+                wins.append(w); priors.append(p)
+            got = []
+            for one_wg in (False, True):
+                if one_wg: os.environ["VILF_NO_LIN_SPLIT"] = "1"
+                else: os.environ.pop("VILF_NO_LIN_SPLIT", None)
+                s.batch_upload(wins, priors); s.batch_solve(); s.batch_marginalize()
+                got.append((s.batch_download(), s.batch_summaries(), s.batch_download_priors() if hasattr(s, "batch_download_priors") else None))
+            for i in range(B):
+                a, b_ = got[0][0][i], got[1][0][i]
+                for k in ("Ps", "Rs", "Vs", "Bas", "Bgs", "para_feature"):
+                    assert np.array_equal(getattr(a, k), getattr(b_, k)), (B, i, k)
+                sa, sb_ = got[0][1][i], got[1][1][i]
+                assert (sa.num_iterations, sa.num_successful_steps, sa.num_linear_solves, sa.final_cost, sa.termination) == (sb_.num_iterations, sb_.num_successful_steps, sb_.num_linear_solves, sb_.final_cost, sb_.termination)
+    finally:
+        os.environ.pop("VILF_NO_LIN_SPLIT", None)
+        s.close()

@@ -34,6 +34,7 @@ __global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
 __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged);
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_mf_chol(VbBatch b, VbMarg g, int n_lo, int n_hi, int disable);
+__global__ void k_linearize_split(VbBatch b, int iteration_zero);
 __global__ void k_mf_ql(VbBatch b, VbMarg g, int force_overflow);
 __global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
 #define VILF_MFA_LDS_EXTRA (4 * 64 * 8 + QL_ICAP * 2)      // k_mf_apply behind V: two staged chunks of the rotation log (MFA_CH = 64) + the 16-bit QL iteration table
@@ -184,6 +185,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
         hipFuncSetAttribute((const void *)k_mf_ql, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (MG_NK + 2) * QL_LPW * sizeof(double))) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_linearize_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_linearize_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_sb_lds) != hipSuccess) {
         delete h; return VILF_ERR_DEVICE;
@@ -819,15 +821,27 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
     // live-window lists (vilf_batch.hpp): the launches of iteration i address their windows through the list k_linearize of iteration i - 1 left, once something has stopped
     const int max_it = h->opts.max_num_iterations;
     const bool use_live = !std::getenv("VILF_NO_LIVE_LIST") && max_it + 2 <= 64 && h->d[D_LIVE].ensure(((size_t)2 * h->B + 128) * sizeof(int));
+    // small batches: every window's linearisation over several workgroups (k_linearize_split: one per factor chunk + two for the IMU / LiDAR / prior parts)
+    const int nch = h->batch.FACmax / VB_CHUNK;
+    const bool split = !dense && h->B <= VB_SPLIT_MAXB && nch >= 1 && nch <= VB_SPLIT_MAXCH && !std::getenv("VILF_NO_LIN_SPLIT") &&
+                       h->d[D_SPLITC].ensure((size_t)h->B * VB_SPLIT_CTL * sizeof(int)) && h->d[D_SPLITB].ensure((size_t)h->B * VB_SPLIT_DBL * sizeof(double));
+    if (split) HIPCHECK(h, hipMemsetAsync(h->d[D_SPLITC].p, 0, (size_t)h->B * VB_SPLIT_CTL * sizeof(int), h->stream));
     auto with_lists = [&](int it) {
         VbBatch bb = h->batch;
-        if (use_live) { bb.live_ctl = h->d[D_LIVE].as<int>(); bb.live_buf = bb.live_ctl + 128; bb.live_it = it; }
+        if (use_live && !split) { bb.live_ctl = h->d[D_LIVE].as<int>(); bb.live_buf = bb.live_ctl + 128; bb.live_it = it; }
         return bb;
+    };
+    auto linearize = [&](const VbBatch &bb0, int iteration_zero) {
+        if (split) {
+            VbBatch bb = bb0;
+            bb.split_nr = nch + 2; bb.split_ctl = h->d[D_SPLITC].as<int>(); bb.split_buf = h->d[D_SPLITB].as<double>();
+            hipLaunchKernelGGL(k_linearize_split, dim3((unsigned)(h->B * (nch + 2))), block, h->lin_lds, h->stream, bb, iteration_zero);
+        } else hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, bb0, iteration_zero);
     };
     mark(3);
     hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, with_lists(0), 0);
     mark(0);
-    hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, h->batch, 1);
+    linearize(h->batch, 1);
     // options.max_solver_time (estimator.cpp:847-850: SOLVER_TIME, x 4/5 when the oldest frame is marginalized): Ceres tests the wall clock at the top of
     // every iteration. The iterations of a batch run in lockstep, so the host waits for the stream before each one (only when the limit is on) and
     // stops the windows whose limit has passed (termination NO_CONVERGENCE, like Ceres' "maximum solver time reached").
@@ -849,7 +863,7 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
         mark(last ? 2 : 0);      // kind 2 ("k_step" in the bench line): the step-only launch that ends a solve
         // the step of the last iteration needs no linearisation behind it (nothing solves with it): residuals only
         if (last) hipLaunchKernelGGL(k_linearize_last, grid, block, h->lin_lds, h->stream, bl);
-        else hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, bl, 0);
+        else linearize(bl, 0);
     }
     mark(3);
     hipLaunchKernelGGL(k_finalize, grid, dim3(64), 0, h->stream, h->batch);

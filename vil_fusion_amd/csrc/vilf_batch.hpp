@@ -124,6 +124,12 @@ struct VbMarg {
     double *prior_H_out, *prior_g_out;   // H0 = J0^T J0, g0 = J0^T r0 of the new prior: k_mf_chol writes them itself (they ARE A and b there); k_prior_prep fills the rest
 };
 
+#define VB_SPLIT_MAXCH 12        // factor chunks a split window may have (12 x 224 slots)
+#define VB_SPLIT_MAXB 8          // largest batch that is split. Measured (tools/dev_small_batch_sweep.sh, ms per 8-iteration solve of the batch, split / one workgroup per window):
+                                 // B = 1: 1.11 / 1.33, 4: 1.16 / 1.37, 8: 1.27 / 1.37, 16: 1.51 / 1.41, 32: 2.09 / 1.46 — beyond ~100 workgroups the roles get in each other's way
+#define VB_SPLIT_CTL 64
+#define VB_SPLIT_CARRY (VB_SPLIT_MAXCH * 4 * 64 * 8)
+#define VB_SPLIT_DBL (VB_SPLIT_CARRY + (VB_SPLIT_MAXCH + 3) * 256)
 struct VbBatch {
     int B, Fmax, Omax, FACmax;
     int w0;                 // first window of this launch (a batch may be enqueued in parts: window = blockIdx.x + w0)
@@ -134,6 +140,10 @@ struct VbBatch {
     // which window is free, a window's arithmetic is untouched) only when live_ctl[i - 1] is set, and iteration i + 1 addresses its windows through list i under the
     // same condition — a batch in which nothing has stopped pays two scalar loads per workgroup and no atomic. live_ctl: [64] flags, [64] list lengths; live_buf: 2 x B.
     int *live_ctl, *live_buf; int live_it;
+    // Small batches (the real-time case is ONE window): k_linearize_split gives a window split_nr workgroups — one per chunk of VB_CHUNK factor slots, one for the IMU
+    // factors, one for the LiDAR factors and the prior's cost — and the one that arrives last assembles (vilf_kernels.hip). split_ctl: per window VB_SPLIT_CTL ints
+    // ([0] arrivals, [1 + 4 chunk + wave] "carry written"); split_buf: per window VB_SPLIT_DBL doubles (carries [chunk][wave][lane][8], cost partials [3 + chunks][256]).
+    int split_nr; int *split_ctl; double *split_buf;
     // options
     double sqrt_info, cauchy_b, G[3];
     double qil[4], til[3];  // RIC*RCL as quaternion (xyzw), RIC*TCL+TIC (lidar_factor.h:28-29)

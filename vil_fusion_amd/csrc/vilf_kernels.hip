@@ -249,10 +249,33 @@ __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the
 
 // JAC = false: the launch after the LAST solve of the iteration budget. Its linearisation would never be used (Ceres tests max_num_iterations before the gradient),
 // so it only takes the step: candidate, cost of every factor (residuals only), accept / reject — a ninth of the linearisations of a solve.
-template <bool JAC>
+template <bool JAC, bool SPLIT = false>
 __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_zero) {
-    const int w = vb_window(b), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    // SPLIT (small batches, k_linearize_split): the window's work is dealt to NR = chunks + 2 workgroups — role s < NCH evaluates the factor slots of chunk s and forms
+    // their pair products, role NCH the IMU factors, role NCH + 1 the LiDAR factors and the prior's cost; every role runs the set-up (state, candidate, tables) itself
+    // and changes nothing in VbState. The workgroup that arrives last (a counter) has the same set-up in its LDS and everything else in global memory: it applies the
+    // trust-region bookkeeping the others left undone and runs the phases behind the chunk loop. The result is the one of the single workgroup to the bit: a pair whose
+    // factors span chunks hands its MFMA accumulators from chunk to chunk (global memory + a flag, only to a HIGHER workgroup index: the dispatcher starts workgroups in
+    // order, so the writer is always running or done), and the per-thread cost sums are added up by the last workgroup in the single workgroup's order.
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int NR = SPLIT ? b.split_nr : 1, NCH = NR - 2;
+    const int w = SPLIT ? (int)blockIdx.x / NR : vb_window(b);
+    const int role = SPLIT ? (int)blockIdx.x - w * NR : 0;
     if (w < 0) return;
+    const bool do_vis = !SPLIT || role < NCH, do_imu = !SPLIT || role == NCH, do_lp = !SPLIT || role == NCH + 1;
+    int *sctl = SPLIT ? b.split_ctl + (size_t)w * VB_SPLIT_CTL : nullptr;
+    double *sbuf = SPLIT ? b.split_buf + (size_t)w * VB_SPLIT_DBL : nullptr, *scost = SPLIT ? sbuf + VB_SPLIT_CARRY : nullptr;
+    __shared__ int s_last;
+    __shared__ double s_def[2];
+    __shared__ int s_defi[2];
+    auto arrive = [&]() -> bool {                          // all threads; true in the workgroup that arrives last
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = (__hip_atomic_fetch_add(sctl, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == NR - 1) ? 1 : 0;
+        __syncthreads();
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return s_last != 0;
+    };
     VbState *st = b.st + w;
     const int lit = b.live_it;
     const bool lists = !iteration_zero && JAC && b.live_ctl != nullptr && lit >= 1;
@@ -263,6 +286,18 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         if (!lists) return;
         if (st->done || stopped_before) b.live_ctl[lit] = 1;
         if (stopped_before && !st->done) b.live_buf[(size_t)(lit & 1) * b.B + atomicAdd(b.live_ctl + 64 + lit, 1)] = w;
+    };
+    // thread 0: what the trust-region step computation writes (from s_def / s_defi): DoglegStrategy's step norm and model cost change; HandleInvalidStep + StepIsInvalid
+    auto step_bookkeeping = [&]() {
+        const int valid = s_defi[0];
+        if (!s_defi[1]) { st->dogleg_step_norm = s_def[0]; st->model_cost_change = s_def[1]; }
+        if (!valid) {
+            st->num_consecutive_invalid += 1;
+            st->mu *= 10.0;
+            st->reuse = 0;
+            st->solve_failed = 0;
+            if (st->num_consecutive_invalid >= 5) { st->done = 1; st->termination = 4; }
+        } else st->num_consecutive_invalid = 0;
     };
     // Two linearisation workspaces per window. Iteration zero fills set 0 at the initial state. Later launches ARE the trust-region step (what k_step was): they form
     // the dogleg step from the last solve, linearise at the CANDIDATE into the set that does not belong to x — the candidate's cost falls out of the same pass over
@@ -299,7 +334,9 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         if (tid == 0) {
             int valid = 1;
             double ca = 0, cb = 0;
-            if (st->solve_failed) valid = 0;
+            const int sf0 = st->solve_failed;
+            double norm0 = 0, mcc0 = 0;
+            if (sf0) valid = 0;
             else {
                 const double radius = st->radius, alpha = st->alpha;
                 const double gradient_norm = sqrt(st->grad_sqnorm), gn_norm = sqrt(st->gn_sqnorm);
@@ -316,7 +353,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
                     ca = -alpha * (1.0 - beta); cb = beta;
                     norm = sqrt(ca * ca * st->grad_sqnorm - 2 * ca * cb * st->gy + cb * cb * st->gn_sqnorm);
                 }
-                st->dogleg_step_norm = norm;
+                norm0 = norm;
                 // step = ca * v - cb * y ; model_cost_change = -step.g~ - 0.5 step^T H~ step, with (H~ + mu D^2) y = g~
                 const double mu = st->mu_used, G2 = st->grad_sqnorm;
                 const double sg = ca * G2 - cb * st->gy;
@@ -324,22 +361,20 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
                 const double yHy = st->gy - mu * st->gn_sqnorm;
                 const double sHs = ca * ca * st->Jg2 - 2 * ca * cb * vHy + cb * cb * yHy;
                 const double mcc = -sg - 0.5 * sHs;
-                st->model_cost_change = mcc;
+                mcc0 = mcc;
                 if (!(mcc > 0.0)) valid = 0;
             }
-            if (!valid) {   // HandleInvalidStep + DoglegStrategy::StepIsInvalid
-                st->num_consecutive_invalid += 1;
-                st->mu *= 10.0;
-                st->reuse = 0;
-                st->solve_failed = 0;
-                if (st->num_consecutive_invalid >= 5) { st->done = 1; st->termination = 4; }
-            } else st->num_consecutive_invalid = 0;
+            s_def[0] = norm0; s_def[1] = mcc0; s_defi[0] = valid; s_defi[1] = sf0;
+            if (!SPLIT) step_bookkeeping();                                  // (SPLIT: by the workgroup that arrives last — the others still read these fields)
             s_flagi[0] = valid;
             s_red[1] = ca; s_red[2] = cb;
-            if (!valid) still_live();                                        // an invalid step: the window goes on with a larger mu (unless that was the fifth)
+            if (!SPLIT && !valid) still_live();                              // an invalid step: the window goes on with a larger mu (unless that was the fifth)
         }
         __syncthreads();
-        if (!s_flagi[0]) return;
+        if (!s_flagi[0]) {
+            if (SPLIT) { if (arrive()) { if (tid == 0) step_bookkeeping(); if (tid < VB_SPLIT_CTL) sctl[tid] = 0; } }
+            return;
+        }
         const double ca = s_red[1], cb = s_red[2];
         const double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
         const double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
@@ -378,7 +413,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         const bool mine = lane < VB_NPAIR && (v1 >> 24) == wave && my_pcn > 0;
         cls_mask = __ballot(mine);
     }
-    if (JAC) for (int i = tid; i < 10 * 512; i += NT) s_U[i] = 0.0;
+    if (JAC && do_imu) for (int i = tid; i < 10 * 512; i += NT) s_U[i] = 0.0;
     __syncthreads();
     if (tid < VB_NF) q_toR(q_load(s_pose + 7 * tid + 3), s_R + 9 * tid);
     if (tid == 32) { q_toR(q_load(ex + 3), s_ric); s_tic[0] = ex[0]; s_tic[1] = ex[1]; s_tic[2] = ex[2]; }
@@ -393,7 +428,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
 
     double cost_local = 0;
     // ---- IMU raw (wave 3, lanes 0..9) and LiDAR between-factors (wave 1, lanes 0..9) ------------------------------
-    if (tid >= 192 && tid < 202) {
+    if (do_imu && tid >= 192 && tid < 202) {
         const int k = tid - 192;
         const double *rec = b.imu + ((size_t)w * 10 + k) * IMU_REC;
         if (rec[287] != 0.0) {
@@ -409,7 +444,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             }
         }
     }
-    if (tid >= 64 && tid < 74) {
+    if (do_lp && tid >= 64 && tid < 74) {
         const int k = tid - 64;
         if (b.use_lidar) {
             const double *lc = b.lidar + ((size_t)w * 10 + k) * 7;
@@ -426,7 +461,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     __syncthreads();
     LSTAMP(2);
     // ---- IMU: X = sqrt_info * [Jraw | r] on MFMA, in place (imu_factor.h:64,93,126,145,160) -------------------------
-    if (JAC) for (int task = wave; task < 20; task += 4) {
+    if (JAC && do_imu) for (int task = wave; task < 20; task += 4) {
         const int k = task >> 1, ct = task & 1;
         double *Xk = s_U + 512 * k;
         const double *S = b.imu + ((size_t)w * 10 + k) * IMU_REC + IMU_SQRT;
@@ -448,6 +483,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     // ---- IMU: [J r]^T [J r] on MFMA -> imuH (30x30), imug (30), cost; LiDAR blocks on the VALU ------------------------
     if (JAC) {
         double *imuH = b.imuH + ww * 9000, *imug = b.imug + ww * 300;
+        if (do_imu)
         for (int task = wave; task < 30; task += 4) {
             const int k = task / 3, tt = task - 3 * k;
             const int ti = (tt == 0) ? 0 : 1, tj = (tt == 2) ? 1 : 0;
@@ -467,6 +503,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             }
         }
         double *lidH = b.lidH + ww * 1440, *lidg = b.lidg + ww * 120;
+        if (do_lp) {
         for (int idx = tid; idx < 1440; idx += NT) {
             const int k = idx / 144, e = idx - 144 * k, p = e / 12, q = e - 12 * p;
             double s = 0;
@@ -479,9 +516,13 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             for (int row = 0; row < 6; row++) s += s_lidJ[72 * k + 12 * row + p] * s_lidr[6 * k + row];
             lidg[idx] = s;
         }
+        }
     }
-    if (tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
-    cost_local += prior_cost_partial(b, w, s_dx, tid);
+    if (SPLIT && do_imu) scost[tid] = cost_local;                          // cost partials of the roles, per thread: [0] IMU, [1] LiDAR, [2] prior, [3 + s] chunk s
+    if (SPLIT) cost_local = 0;
+    if (do_lp && tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
+    if (SPLIT && do_lp) { scost[256 + tid] = cost_local; scost[512 + tid] = prior_cost_partial(b, w, s_dx, tid); cost_local = 0; }
+    if (!SPLIT) cost_local += prior_cost_partial(b, w, s_dx, tid);
     __syncthreads();                                                       // the IMU staging area is dead: the region becomes s_X
     LSTAMP(4);
     // ---- visual factors: chunks of 256 pair-sorted factors -> LDS rows -> MFMA X^T X per pair ------------------------
@@ -512,7 +553,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             cost_local += 0.5 * rho0;
         }
     } else
-    for (int c0 = 0; c0 < nfac; c0 += VB_CHUNK) {
+    for (int c0 = SPLIT ? role * VB_CHUNK : 0; c0 < (SPLIT ? (do_vis ? min(nfac, (role + 1) * VB_CHUNK) : 0) : nfac); c0 += VB_CHUNK) {
         t_a = TICK();
         const int q = c0 + tid;
         double *x0 = s_X + (2 * min(tid, VB_CHUNK - 1)) * VB_XLD, *x1 = x0 + VB_XLD;
@@ -554,6 +595,65 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         __syncthreads();
         { long long t_b = TICK(); t_sync1 += t_b - t_a; t_a = t_b; }
         const int x0c = VB_CLS * (c0 / VB_CHUNK);                              // this chunk holds the class-local positions [x0c, x0c + VB_CLS) of every class
+        if constexpr (SPLIT) {
+            // This workgroup has ONE chunk. The pairs of this wave's class that have factors in it, in an order that keeps the chain between the chunks short: first
+            // the pair that runs on into the next chunk (its accumulators are published as soon as this chunk's rows are in), then the pairs that lie inside, last the
+            // pair that began in an earlier chunk (its accumulators come from the previous chunk's workgroup). Within a pair the rows are accumulated in the same order
+            // as by the single workgroup.
+            double *carry_out = sbuf + ((size_t)(role * 4 + wave) * 64 + lane) * 8;
+            const double *carry_in = sbuf + ((size_t)(max(role, 1) * 4 - 4 + wave) * 64 + lane) * 8;
+            int *flag_out = sctl + 1 + 4 * role + wave, *flag_in = sctl + 1 + 4 * max(role - 1, 0) + wave;
+#pragma unroll 1
+            for (int pass = 0; pass < 3; pass++) {
+                unsigned long long m = cls_mask;
+                while (m) {
+                    const int p = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                    m &= m - 1;
+                    const int pst = __builtin_amdgcn_readlane(my_pst, p), pcn_ = __builtin_amdgcn_readlane(my_pcn, p);
+                    if (pst + pcn_ <= x0c) continue;                       // finished in an earlier chunk
+                    if (pst >= x0c + VB_CLS) break;                        // begins in a later one
+                    const bool in = pst < x0c, out = pst + pcn_ > x0c + VB_CLS;
+                    if ((in ? 2 : (out ? 0 : 1)) != pass) continue;
+                    double4_t acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+                    if (in) {
+                        while (__hip_atomic_load(flag_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
+                        const double2_t *ci = reinterpret_cast<const double2_t *>(carry_in);
+                        const double2_t c0_ = ci[0], c1_ = ci[1], c2_ = ci[2], c3_ = ci[3];
+                        acc = double4_t{c0_[0], c0_[1], c1_[0], c1_[1]}; acc1 = double4_t{c2_[0], c2_[1], c3_[0], c3_[1]};
+                    }
+                    const int lo = max(pst, x0c), hi = min(pst + pcn_, x0c + VB_CLS);
+                    const int r_lo = 2 * (VB_CLS * wave + lo - x0c), r_hi = 2 * (VB_CLS * wave + hi - x0c);
+                    auto ld4 = [&](int r0, double *a) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const int row = r0 + 4 * u + (lane >> 4);
+                            const double v = s_X[min(row, 2 * VB_CHUNK - 1) * VB_XLD + (lane & 15)];
+                            a[u] = (row < r_hi && (lane & 15) < VB_XLD) ? v : 0.0;
+                        }
+                    };
+                    double a[4], an[4];
+                    ld4(r_lo, a);
+                    for (int r0 = r_lo; r0 < r_hi; r0 += 16) {
+                        ld4(r0 + 16, an);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], a[0], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], a[1], acc1, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], a[2], acc, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], a[3], acc1, 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) a[u] = an[u];
+                    }
+                    if (out) {
+                        double2_t *co = reinterpret_cast<double2_t *>(carry_out);
+                        co[0] = double2_t{acc[0], acc[1]}; co[1] = double2_t{acc[2], acc[3]}; co[2] = double2_t{acc1[0], acc1[1]}; co[3] = double2_t{acc1[2], acc1[3]};
+                        __threadfence();
+                        if (lane == 0) __hip_atomic_store(flag_out, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = acc[q4] + acc1[q4];
+                    }
+                }
+            }
+        } else
         // the pairs of this wave's class, in class-list order = ascending position: a cursor carried across the chunks stops at the first pair that starts in a later
         // chunk (walking the whole list in every chunk and skipping cost three dependent LDS reads per pair and chunk: half of this phase)
         while (mrem) {
@@ -598,6 +698,18 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         { long long t_b = TICK(); t_sync2 += t_b - t_a; t_a = t_b; }
     }
     if (JAC && b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
+    if (SPLIT) {
+        if (do_vis) scost[(3 + role) * 256 + tid] = cost_local;
+        if (!arrive()) return;
+        // the last to arrive: the trust-region bookkeeping nobody has done yet, and every thread's cost sum in the single workgroup's order (IMU, LiDAR, prior, chunk by chunk)
+        if (!iteration_zero && tid == 0) step_bookkeeping();
+        double c = 0;
+        c += __builtin_nontemporal_load(scost + tid); c += __builtin_nontemporal_load(scost + 256 + tid); c += __builtin_nontemporal_load(scost + 512 + tid);
+        for (int k = 0; k < NCH; k++) c += __builtin_nontemporal_load(scost + (3 + k) * 256 + tid);
+        cost_local = c;
+        __syncthreads();
+        if (tid < VB_SPLIT_CTL) sctl[tid] = 0;                               // the counter and the carry flags: ready for the next launch
+    }
     double gmax = 0, xsq = 0;
     if (JAC) {
     LSTAMP(5);
@@ -775,6 +887,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
 }
 extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) { linearize_body<true>(b, iteration_zero); }
 extern "C" __global__ __launch_bounds__(NT) void k_linearize_last(VbBatch b) { linearize_body<false>(b, 0); }
+extern "C" __global__ __launch_bounds__(NT) void k_linearize_split(VbBatch b, int iteration_zero) { linearize_body<true, true>(b, iteration_zero); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_solve helpers
