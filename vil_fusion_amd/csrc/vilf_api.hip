@@ -165,7 +165,9 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     h->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     if (hip_stream) { h->stream = (hipStream_t)hip_stream; h->own_stream = false; }
-    else { if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return VILF_ERR_DEVICE; } h->own_stream = true; }
+    // the library's own stream does not synchronise with the legacy default stream: two handles of one process (the estimator and the LiDAR stage, as the reference's
+    // separate nodes) run side by side — with a blocking stream every default-stream operation of the process (a torch tensor op, a hipMemcpy) serialised them
+    else { if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return VILF_ERR_DEVICE; } h->own_stream = true; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + 512 + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
     h->lin_lds = (size_t)VB_LIN_LDS_DOUBLES * sizeof(double);
@@ -274,14 +276,14 @@ static int pull_device_priors(vilf_handle *h) {
         vilf_prior &p = h->priors[w];
         std::memset(&p, 0, sizeof(p));
         int hdr[VB_PRIOR_HDR];
-        HIPCHECK(h, hipMemcpy(hdr, h->d[D_PHDR].as<int>() + (size_t)w * VB_PRIOR_HDR, sizeof(hdr), hipMemcpyDeviceToHost));
+        HIPCHECK(h, vilf_copy_sync(h, hdr, h->d[D_PHDR].as<int>() + (size_t)w * VB_PRIOR_HDR, sizeof(hdr), hipMemcpyDeviceToHost));
         p.valid = hdr[0]; p.n = hdr[1]; p.n_blocks = hdr[2]; p.m = hdr[75];
         if (p.valid) {
             std::vector<double> x0(24 * 9);
-            HIPCHECK(h, hipMemcpy(x0.data(), h->d[D_PX0].as<double>() + (size_t)w * 24 * 9, x0.size() * 8, hipMemcpyDeviceToHost));
+            HIPCHECK(h, vilf_copy_sync(h, x0.data(), h->d[D_PX0].as<double>() + (size_t)w * 24 * 9, x0.size() * 8, hipMemcpyDeviceToHost));
             for (int i = 0; i < p.n_blocks; i++) { p.block_id[i] = hdr[3 + i]; p.block_size[i] = hdr[27 + i]; p.block_idx[i] = hdr[51 + i]; for (int k = 0; k < 9; k++) p.block_x0[i][k] = x0[i * 9 + k]; }
-            HIPCHECK(h, hipMemcpy(p.linearized_jacobians, h->d[D_PJ].as<double>() + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, sizeof(double) * p.n * p.n, hipMemcpyDeviceToHost));
-            HIPCHECK(h, hipMemcpy(p.linearized_residuals, h->d[D_PR].as<double>() + (size_t)w * VB_PRIOR_LD, sizeof(double) * p.n, hipMemcpyDeviceToHost));
+            HIPCHECK(h, vilf_copy_sync(h, p.linearized_jacobians, h->d[D_PJ].as<double>() + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, sizeof(double) * p.n * p.n, hipMemcpyDeviceToHost));
+            HIPCHECK(h, vilf_copy_sync(h, p.linearized_residuals, h->d[D_PR].as<double>() + (size_t)w * VB_PRIOR_LD, sizeof(double) * p.n, hipMemcpyDeviceToHost));
         }
         h->prior_dev_newer[w] = 0;
     }
@@ -661,7 +663,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     b.out_Ps = h->d[D_OPS].as<double>(); b.out_Rs = h->d[D_ORS].as<double>(); b.out_Vs = h->d[D_OVS].as<double>();
     b.out_Bas = h->d[D_OBAS].as<double>(); b.out_Bgs = h->d[D_OBGS].as<double>();
     b.dbg = nullptr;
-    if (getenv("VILF_DEBUG_STAMPS")) { if (!h->d[D_DBG].ensure(3 * 32 * 8)) return VILF_ERR_DEVICE; hipMemset(h->d[D_DBG].p, 0, 3 * 32 * 8); b.dbg = h->d[D_DBG].as<long long>(); }
+    if (getenv("VILF_DEBUG_STAMPS")) { if (!h->d[D_DBG].ensure(3 * 32 * 8)) return VILF_ERR_DEVICE; hipMemsetAsync(h->d[D_DBG].p, 0, 3 * 32 * 8, h->stream); b.dbg = h->d[D_DBG].as<long long>(); }
 
     HIPCHECK(h, hipMemsetAsync(h->d[D_W].p, 0, 2 * sB * sF * VB_WLD * 8, h->stream));   // W rows are zero outside the rewritten ranges
     if (!h->luts_ready) {   // static scatter tables of the tile assembly (same for every window): source element -> LDS offset, -1 = not stored
@@ -682,9 +684,9 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
             lv[2 * t + 1] = (a != bb && (r >> 4) == (c >> 4)) ? off1(c, r) : 0;
         }
         if (!h->d[D_LUTI].ensure(li.size() * 4) || !h->d[D_LUTL].ensure(ll.size() * 4) || !h->d[D_LUTV].ensure(lv.size() * 4)) return VILF_ERR_DEVICE;
-        HIPCHECK(h, hipMemcpy(h->d[D_LUTI].p, li.data(), li.size() * 4, hipMemcpyHostToDevice));
-        HIPCHECK(h, hipMemcpy(h->d[D_LUTL].p, ll.data(), ll.size() * 4, hipMemcpyHostToDevice));
-        HIPCHECK(h, hipMemcpy(h->d[D_LUTV].p, lv.data(), lv.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(h, vilf_copy_sync(h, h->d[D_LUTI].p, li.data(), li.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(h, vilf_copy_sync(h, h->d[D_LUTL].p, ll.data(), ll.size() * 4, hipMemcpyHostToDevice));
+        HIPCHECK(h, vilf_copy_sync(h, h->d[D_LUTV].p, lv.data(), lv.size() * 4, hipMemcpyHostToDevice));
         h->luts_ready = true;
     }
     h->batch.lut_imu = h->d[D_LUTI].as<int>(); h->batch.lut_lid = h->d[D_LUTL].as<int>(); h->batch.lut_vis = h->d[D_LUTV].as<int>();
@@ -702,7 +704,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
 
 extern "C" int vilf_debug_stamps(vilf_handle *h, long long *out96) {
     if (!h || !h->batch.dbg) return VILF_ERR_INVALID_ARGUMENT;
-    HIPCHECK(h, hipMemcpy(out96, h->batch.dbg, 96 * 8, hipMemcpyDeviceToHost));
+    HIPCHECK(h, vilf_copy_sync(h, out96, h->batch.dbg, 96 * 8, hipMemcpyDeviceToHost));
     return VILF_OK;
 }
 

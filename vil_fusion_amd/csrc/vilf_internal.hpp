@@ -123,6 +123,12 @@ struct vilf_handle {
     LwCtx *lw = nullptr;                     // large-window solve workspace (vilf_lw.hip)
 };
 
+// a copy ordered on the handle's stream and waited for: the library's streams are non-blocking (they do not synchronise with the legacy default stream), so a plain
+// hipMemcpy would neither wait for the kernels before it nor hold back the ones after it
+static inline hipError_t vilf_copy_sync(vilf_handle *h, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(h->stream);
+}
 #define HIPCHECK(h, call)                                                                                        \
     do {                                                                                                         \
         hipError_t e_ = (call);                                                                                  \

@@ -2295,14 +2295,14 @@ extern "C" int vilf_scan2map_set_pose(vilf_handle *h, const double p[7], const d
     S2B *c = single(h);
     int rc = s2b_reserve(h, c, 1, c->capScan[0], c->capScan[1], c->capMap[0], c->capMap[1]);
     if (rc != VILF_OK) return rc;
-    HIPCHECK(h, hipMemcpy(c->pose.p, p, 56, hipMemcpyHostToDevice));
-    HIPCHECK(h, hipMemcpy(c->pose.as<double>() + 8, pl, 56, hipMemcpyHostToDevice));
+    HIPCHECK(h, vilf_copy_sync(h, c->pose.p, p, 56, hipMemcpyHostToDevice));
+    HIPCHECK(h, vilf_copy_sync(h, c->pose.as<double>() + 8, pl, 56, hipMemcpyHostToDevice));
     return VILF_OK;
 }
 
 static int s2b_get_map(vilf_handle *h, S2B *c, int sid, int which, float *out, int cap, int *n_out) {
     int n = 0;
-    if (c->S) HIPCHECK(h, hipMemcpy(&n, c->nMap[which].as<int>() + sid, 4, hipMemcpyDeviceToHost));
+    if (c->S) HIPCHECK(h, vilf_copy_sync(h, &n, c->nMap[which].as<int>() + sid, 4, hipMemcpyDeviceToHost));
     *n_out = n;
     const int k = std::min(cap, n);
     if (k > 0 && out) {
@@ -2310,11 +2310,11 @@ static int s2b_get_map(vilf_handle *h, S2B *c, int sid, int which, float *out, i
         const int m = std::min(c->order_state[which] == 1 ? n : c->h_cmn[which][sid], n);
         const float leaf = (float)(which == 0 ? h->opts.edge_leaf_size : h->opts.surf_leaf_size);
         if (m <= k) {
-            HIPCHECK(h, hipMemcpy(out, c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)k * 16, hipMemcpyDeviceToHost));
+            HIPCHECK(h, vilf_copy_sync(h, out, c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)k * 16, hipMemcpyDeviceToHost));
             s2b_host_pcl_order(out, m, leaf);
         } else {                                            // a truncated read: order the whole prefix first, then hand out its first k points
             std::vector<float> all((size_t)n * 4);
-            HIPCHECK(h, hipMemcpy(all.data(), c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)n * 16, hipMemcpyDeviceToHost));
+            HIPCHECK(h, vilf_copy_sync(h, all.data(), c->map[which].as<float4>() + (size_t)sid * c->capMap[which], (size_t)n * 16, hipMemcpyDeviceToHost));
             s2b_host_pcl_order(all.data(), m, leaf);
             std::memcpy(out, all.data(), (size_t)k * 16);
         }
