@@ -1154,19 +1154,34 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     // finished, the launches below skip those), otherwise the
     // eigen-solver of the kept block in three launches (tred2 per workgroup, the QL recurrence of every window one lane each, rotation replay +
     // prior output per workgroup); k_marg_finish (everything in one workgroup) only takes windows whose rotation log overflowed
+    // The kept-block kernels come in two LDS sizes by dimension class (n < 78: three workgroups per CU) — for a large batch. A small one (the single window of the real-time
+    // case) does not fill the device either way and takes ONE launch of each with the full LDS: four launches less in a chain of mostly empty ones (~5 us each).
+    const bool one_class = h->B <= 64;
+    const size_t lds_small = (size_t)77 * 77 * sizeof(double);
     {
         const int no_chol = std::getenv("VILF_MARG_NO_CHOL") ? 1 : 0;         // test hook: the eigen-solver for every window
-        hipLaunchKernelGGL(k_mf_chol, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, no_chol);
-        hipLaunchKernelGGL(k_mf_chol, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, no_chol);
+        if (one_class) hipLaunchKernelGGL(k_mf_chol, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 0, 1 << 30, no_chol);
+        else {
+            hipLaunchKernelGGL(k_mf_chol, grid, block, lds_small, h->stream, h->batch, g, 0, 78, no_chol);
+            hipLaunchKernelGGL(k_mf_chol, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, no_chol);
+        }
     }
-    hipLaunchKernelGGL(k_mf_tridiag, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78);
-    hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
+    if (one_class) hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 0, 1 << 30);
+    else {
+        hipLaunchKernelGGL(k_mf_tridiag, grid, block, lds_small, h->stream, h->batch, g, 0, 78);
+        hipLaunchKernelGGL(k_mf_tridiag, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30);
+    }
     hipLaunchKernelGGL(k_mf_ql, dim3((h->B + QL_LPW - 1) / QL_LPW), dim3(64), (size_t)2 * (MG_NK + 2) * QL_LPW * sizeof(double), h->stream, h->batch, g,
                        std::getenv("VILF_MARG_FORCE_QL_FALLBACK") ? 1 : 0);        // test hook
-    hipLaunchKernelGGL(k_mf_apply, grid, block, (size_t)77 * 77 * sizeof(double) + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 0, 78);
-    hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 78, 1 << 30);
-    hipLaunchKernelGGL(k_marg_finish, grid, block, (size_t)77 * 77 * sizeof(double), h->stream, h->batch, g, 0, 78, 1);
-    hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, 1);
+    if (one_class) {
+        hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 0, 1 << 30);
+        hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 0, 1 << 30, 1);
+    } else {
+        hipLaunchKernelGGL(k_mf_apply, grid, block, lds_small + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 0, 78);
+        hipLaunchKernelGGL(k_mf_apply, grid, block, h->marg_lds_finish + VILF_MFA_LDS_EXTRA, h->stream, h->batch, g, 78, 1 << 30);
+        hipLaunchKernelGGL(k_marg_finish, grid, block, lds_small, h->stream, h->batch, g, 0, 78, 1);
+        hipLaunchKernelGGL(k_marg_finish, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, 1);
+    }
     if (to_other_set) {
         hipLaunchKernelGGL(k_prior_keep, grid, block, 0, h->stream, h->batch, g);
         for (int k = 0; k < 6; k++) std::swap(h->d[live[k]], h->d[bak[k]]);
