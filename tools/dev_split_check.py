@@ -5,10 +5,10 @@ _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.inser
 import numpy as np
 from vil_fusion_amd import synth
 from vil_fusion_amd.estimator import BackendSolver
-rng = np.random.default_rng(7)
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
 s = BackendSolver(); o = s.options
 bad = 0; tot = 0
-for B in (1, 2, 3, 5, 7, 8):
+for B in (1, 2, 3, 4, 5, 6, 7, 8, 8, 8, 1, 1):
     wins, priors = [], []
     for i in range(B):
         nz = float(rng.choice([0.05, 0.2, 0.8, 2.0]))
