@@ -19,7 +19,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        so = os.path.join(ORACLE_DIR, "liboracle_vilf.so")
+        so = os.environ.get("VILO_SO") or os.path.join(ORACLE_DIR, "liboracle_vilf.so")      # VILO_SO: another build of the oracle (a sanitizer build, tools/dev_oracle_asan.sh)
         if not os.path.exists(so):
             build()
         _lib = C.CDLL(so)
