@@ -776,7 +776,9 @@ __global__ __launch_bounds__(SR_T, 4) void b_scan_voxel_runs(CSet in, float inv,
 #define MU_T 512             // two workgroups of eight waves per CU instead of one of sixteen: the sweep waits 40 % of its cycles at its three barriers per tile and another stream's
                              // workgroup fills part of them. Same-box A/B of the voxel-grid group per 4096-frame step (tools/dev_ab_mut.sh): 1024 threads 9.01 ms, 512: 8.82, 256: 8.94
 #endif
+#ifndef MU_E
 #define MU_E 2
+#endif
 #define MU_TILE (MU_T * MU_E)
 #define MU_LDS_TAIL 8192
 #define S2B_ERR_ORDER 8
@@ -880,8 +882,13 @@ __device__ __forceinline__ void mu_rare(int i, int H, int M, bool head, bool bet
         o[H + thp(jlo) - M] = make_float4(s.x / nn, s.y / nn, s.z / nn, s.w / nn); fixq[atomicAdd(s_fn, 1)] = H + thp(jlo) - M;
     }
 }
+#ifdef MU_WPE
+#define MU_LB __launch_bounds__(MU_T, MU_WPE)
+#else
+#define MU_LB __launch_bounds__(MU_T)
+#endif
 template <bool BIG>
-__global__ __launch_bounds__(MU_T) void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, int cs, CSet out, unsigned *dir_all, unsigned dtag, int *fix_all, float4 *ts_all, int ts_stride,
+__global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pose_all, double half, float inv, int cs, CSet out, unsigned *dir_all, unsigned dtag, int *fix_all, float4 *ts_all, int ts_stride,
                                                        unsigned long long *gT_all, int gT_stride, int lds_lo, int lds_cap, int *gq_all, size_t gq_stride, int *err) {
     constexpr int AXB = BIG ? 16 : 17, IDXB = BIG ? 16 : 13;
     constexpr unsigned long long LOW = (1ULL << IDXB) - 1;
@@ -1228,20 +1235,23 @@ __device__ __forceinline__ void knn_span(const unsigned *T, unsigned tag, int n,
 __device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag, int n, float inv, int cs, float qx, float qy, float qz, int pos[5], float d2[5], bool &tie) {
 #pragma unroll
     for (int k = 0; k < 5; k++) { pos[k] = -1; d2[k] = 3.0e38f; }
-    tie = false;
+    float disc = 3.0e38f;                              // the smallest distance among the candidates that were turned away or pushed out of the list
     const KnnSpans R = knn_rows(qx, qy, inv, cs);
-    // all span bounds first (independent loads), then the candidates eight at a time (clamped, unconditional loads): the lane keeps
-    // several loads in flight instead of one dependent load per candidate
+    // all span bounds first (independent loads), then the candidates eight at a time (unconditional loads): the lane keeps several loads in flight instead of
+    // one dependent load per candidate. A lane past its last candidate reads entry 0 of the array — the SAME line for every such lane of the wave: a wave walks
+    // as many rounds as its longest lane (6.4 against a mean of 1.3 for edge queries), and a load instruction costs the vector cache a cycle per distinct line
     int st[KNN_ROWS], en[KNN_ROWS];
 #pragma unroll
     for (int r = 0; r < KNN_ROWS; r++) { if (r < R.nrow) knn_span(T, tag, n, R.cylo + r, R.cxlo, R.cxhi1, st[r], en[r]); else { st[r] = 0; en[r] = 0; } }
-    // one candidate: sorted insertion with compile-time indices only (the five best stay in registers)
+    // one candidate: sorted insertion with compile-time indices only (the five best stay in registers). The distances move by median-of-three (the list is sorted:
+    // med3(d2[k - 1], d2[k], d) is the new entry k), the positions by selects; equal distances are NOT looked for here — see the end of the function
 #define KNN_TRY(M, POS) { const float4 m = (M); const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz; \
         const float d = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez)); \
         if (d <= d2[4]) { bool lt[5]; const int ps_ = (POS); \
-            _Pragma("unroll") for (int k = 0; k < 5; k++) { lt[k] = d < d2[k]; tie = tie || d == d2[k]; } \
-            _Pragma("unroll") for (int k = 4; k >= 1; k--) { d2[k] = lt[k - 1] ? d2[k - 1] : (lt[k] ? d : d2[k]); pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? ps_ : pos[k]); } \
-            if (lt[0]) { d2[0] = d; pos[0] = ps_; } } }
+            _Pragma("unroll") for (int k = 0; k < 5; k++) lt[k] = d < d2[k]; \
+            disc = __builtin_amdgcn_fmed3f(-3.0e38f, disc, lt[4] ? d2[4] : d);        /* min (fminf would canonicalise both operands first) */ \
+            _Pragma("unroll") for (int k = 4; k >= 1; k--) { pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? ps_ : pos[k]); d2[k] = __builtin_amdgcn_fmed3f(d2[k - 1], d2[k], d); } \
+            pos[0] = lt[0] ? ps_ : pos[0]; d2[0] = lt[0] ? d : d2[0]; } }
     {
         // the rows' spans are walked as ONE sequence (virtual index t -> position t + offset of its span) so that a batch never ends at a span boundary,
         // with the next batch's loads issued before this batch is ranked: the walk is bound by the latency of these gathers, not by the arithmetic
@@ -1251,19 +1261,21 @@ __device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag
         if (ntot > 0) {
             float4 cur[KNN_FL], nxt[KNN_FL];
 #pragma unroll
-            for (int u = 0; u < KNN_FL; u++) { const int t = min(u, ntot - 1); cur[u] = sorted[KNN_AT(t)]; }
+            for (int u = 0; u < KNN_FL; u++) cur[u] = sorted[u < ntot ? KNN_AT(u) : 0];
             for (int t0 = 0; t0 < ntot; t0 += KNN_FL) {
 #pragma unroll
-                for (int u = 0; u < KNN_FL; u++) { const int t = min(t0 + KNN_FL + u, ntot - 1); nxt[u] = sorted[KNN_AT(t)]; }
+                for (int u = 0; u < KNN_FL; u++) { const int t = t0 + KNN_FL + u; nxt[u] = sorted[t < ntot ? KNN_AT(t) : 0]; }
 #pragma unroll
                 for (int u = 0; u < KNN_FL; u++) {
                     const int t = t0 + u;
                     if (t >= ntot) break;
-                    KNN_TRY(cur[u], KNN_AT(t))
+                    KNN_TRY(cur[u], t)                    // the list holds the VIRTUAL index until the walk is over
                 }
 #pragma unroll
                 for (int u = 0; u < KNN_FL; u++) cur[u] = nxt[u];
             }
+#pragma unroll
+            for (int k = 0; k < 5; k++) if (pos[k] >= 0) pos[k] = KNN_AT(pos[k]);
         }
 #undef KNN_AT
     }
@@ -1282,6 +1294,11 @@ __device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag
         }
     }
 #undef KNN_TRY
+    // Equal distances change the result only (i) between neighbours of the final list (their order) or (ii) between its last entry and a candidate that is not in it
+    // (which of the two is kept): the list is strictly sorted otherwise and every other candidate is strictly farther, whatever the order they came in.
+    tie = pos[4] >= 0 && disc == d2[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) tie = tie || (pos[k + 1] >= 0 && d2[k] == d2[k + 1]);
 }
 // The same search with the reference's order of equal distances: ascending map index in PCL's order (a linear scan keeps the first of equals) — for the cell-major map
 // that is the PCL leaf key z | y | x of the candidate, then its position (points of one leaf keep their relative order); for the sorted copy of a map that is not a
@@ -1609,7 +1626,10 @@ __device__ void s2m_evaluate(const double *x, const double *frec, const unsigned
     __syncthreads();
 }
 // ONE persistent 256-thread workgroup per stream; the optimised pose is written back to the stream's pose slot.
-__global__ __launch_bounds__(S2M_NT, 2) void b_solve(double *pose_all, const double *frec_all, const int *fkind_all, int capq, const int *n_ds_edge, const int *n_ds_surf, double huber_a, int max_it, int pass, S2BRes *res) {
+#ifndef S2M_SOLVE_WPE
+#define S2M_SOLVE_WPE 2
+#endif
+__global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_all, const double *frec_all, const int *fkind_all, int capq, const int *n_ds_edge, const int *n_ds_surf, double huber_a, int max_it, int pass, S2BRes *res) {
     const int sid = blockIdx.x;
     if (!res[sid].do_opt) return;
     double *pose_in = pose_all + 24 * sid;
