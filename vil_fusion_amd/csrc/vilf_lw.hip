@@ -64,7 +64,7 @@ struct LwWin {
     int PC, WS, nchunk, nks;                       // W: F rows of WS doubles, PC = 6 NF (+ 6 Ex)(+ 1 td) of them used: compact column c <-> column lw_fullcol(c) of the reduced system
     // pose-pose blocks of the visual factors without atomics: every run of equal frame pairs inside a chunk of lw_visual owns a SLOT of PS (12 x 12 + 12 sums, stride 160);
     // lw_assemble adds the slots of a pair / of a frame's pairs in slot order. cslot: first slot of a chunk; prt: per pair {i, j, first slot, end slot}; froff / frlist:
-    // CSR per frame of (pair << 1 | 0: the frame is the pair's i, 1: its j)
+    // CSR per frame of (slot << 1 | 0: the frame is the slot's pair's i, 1: its j), pairs ascending, a pair's slots ascending
     double *PS; const int *cslot, *prt, *froff, *frlist; int npairs, pad3_;
     // structure: Hpp(i, j) can be non-zero only for frames |f_i - f_j| <= bandf (feature track lengths; IMU / LiDAR factors join neighbours; NF when a prior or Ex_Pose /
     // td columns couple everything), row f of W only in the compact columns fspan[2 f] .. fspan[2 f + 1] (its frames) and the Ex_Pose / td columns at the end
@@ -326,34 +326,31 @@ __global__ __launch_bounds__(256) void lw_assemble(const LwWin *ws, int sk) {
     const int NF = w.NF, P = w.P, tid = threadIdx.x, b = blockIdx.x;
     const double *PS = w.PS; const int *prt = w.prt;
     __shared__ double s_part[6][42];
-    __shared__ int s_sl[256];                          // the slots of this block's list (slot << 1 | kind), in list order
-    __shared__ int s_n;
+    __shared__ int s_sl[256];                          // a round of the frame's list (slot << 1 | kind), in list order
     if (b < NF) {
-        // a frame's list is a few dozen slots: six lanes per entry take every sixth slot (independent loads instead of one dependent chain of ~60: 58 us for a single
-        // window), the six partial sums are added in lane order — the same order every run
+        // a frame's list is a few dozen to a few hundred slots (slot << 1 | kind: 0 = the frame is the pair's i, 1 = its j; built by the host in pair order): six lanes
+        // per entry take every sixth slot of a round of 256, the six partial sums are added in lane order — the same order every run. The list comes through LDS
+        // with one coalesced read and a lane's loads from PS are issued sixteen at a time: until round 4 thread 0 composed the list from the pair table (two
+        // dependent loads per pair) and every slot was its own round trip — 34 us of a single stress window's iteration.
         const int u0 = w.froff[b], u1 = w.froff[b + 1];
         const int e = tid % 42, part = tid / 42, a = e < 36 ? e / 6 : e - 36, c = e < 36 ? e % 6 : 0;
         double acc = 0;
-        int u = u0, sl = u0 < u1 ? prt[4 * (w.frlist[u0] >> 1) + 2] : 0;      // thread 0's cursor through the list (rounds of 256 slots: a frame of a large window can have more)
-        for (;;) {
-            if (tid == 0) {
-                int n = 0;
-                while (u < u1 && n < 256) {
-                    const int pk = w.frlist[u], p = pk >> 1, end = prt[4 * p + 3];
-                    while (sl < end && n < 256) s_sl[n++] = (sl++ << 1) | (pk & 1);
-                    if (sl >= end) { u++; if (u < u1) sl = prt[4 * (w.frlist[u] >> 1) + 2]; }
-                }
-                s_n = n;
-            }
+        for (int base = u0; base < u1; base += 256) {
+            const int n = min(256, u1 - base);
             __syncthreads();
-            const int n = s_n;
+            if (tid < n) s_sl[tid] = w.frlist[base + tid];
+            __syncthreads();
             if (tid < 252)
-                for (int k = part; k < n; k += 6) {        // which of the six partial sums a slot joins depends only on its place in the list: the same every run
-                    const int sk2 = s_sl[k], kind = sk2 & 1, o = e < 36 ? (6 * kind + a) * 12 + 6 * kind + c : 144 + 6 * kind + a;
-                    acc += PS[(size_t)(sk2 >> 1) * 160 + o];
+                for (int k0 = part; k0 < n; k0 += 6 * 16) {
+                    double v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        const int sk2 = s_sl[min(k0 + 6 * q, n - 1)], kind = sk2 & 1, o = e < 36 ? (6 * kind + a) * 12 + 6 * kind + c : 144 + 6 * kind + a;
+                        v[q] = PS[(size_t)(sk2 >> 1) * 160 + o];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q++) if (k0 + 6 * q < n) acc += v[q];
                 }
-            __syncthreads();
-            if (n < 256) break;
         }
         if (tid < 252) s_part[part][e] = acc;
         __syncthreads();
@@ -1893,7 +1890,7 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
         w.o_cslot = off; off = lw_al(off + ((size_t)(w.nvis + LW_CH - 1) / LW_CH + 1) * sizeof(int));
         w.o_prt = off; off = lw_al(off + (size_t)std::max(w.npairs_cap, 1) * 4 * sizeof(int));
         w.o_froff = off; off = lw_al(off + ((size_t)w.NF + 1) * sizeof(int));
-        w.o_frlist = off; off = lw_al(off + (size_t)std::max(w.npairs_cap, 1) * 2 * sizeof(int));
+        w.o_frlist = off; off = lw_al(off + (size_t)std::max(w.nslots_cap, 1) * 2 * sizeof(int));
     }
     const size_t o_imu = off; off = lw_al(off + tot_imu * IMU_REC * 8);
     const size_t o_cov = off; off = lw_al(off + tot_imu * 225 * 8);
@@ -1996,10 +1993,11 @@ int vilf_lw_group_solve(vilf_handle *h, int G, const vilf_window_in *const *ins,
             if (np) prt[4 * (np - 1) + 3] = nslot;
             w.npairs = np;
             std::vector<int> cnt((size_t)NF + 1, 0);
-            for (int q = 0; q < np; q++) { cnt[prt[4 * q] + 1]++; cnt[prt[4 * q + 1] + 1]++; }
+            for (int q = 0; q < np; q++) { const int ns = prt[4 * q + 3] - prt[4 * q + 2]; cnt[prt[4 * q] + 1] += ns; cnt[prt[4 * q + 1] + 1] += ns; }
             for (int k = 1; k <= NF; k++) cnt[k] += cnt[k - 1];
             for (int k = 0; k <= NF; k++) froff[k] = cnt[k];
-            for (int q = 0; q < np; q++) { frlist[cnt[prt[4 * q]]++] = q << 1; frlist[cnt[prt[4 * q + 1]]++] = (q << 1) | 1; }
+            for (int q = 0; q < np; q++)
+                for (int sl = prt[4 * q + 2]; sl < prt[4 * q + 3]; sl++) { frlist[cnt[prt[4 * q]]++] = sl << 1; frlist[cnt[prt[4 * q + 1]]++] = (sl << 1) | 1; }
         }
         if (est_td) {                                     // projection_td_factor.cpp:6-21
             LwTd *tdrec = reinterpret_cast<LwTd *>(st + w.o_tdr);
