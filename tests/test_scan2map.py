@@ -152,6 +152,51 @@ def test_scan2map_batch_matches_single_stream_and_oracle(oracle, opts):
     s.close()
 
 
+def _lattice_scene():
+    """A ground and a few poles on a dyadic lattice (every coordinate a multiple of 1/64 m: the sums, centroids and squared distances below are exact in float), with a
+    checkerboard ripple of 1/32 m on both — the neighbours of a query still come in rings of exactly equal distance, but WHICH of them enter a fit changes the plane /
+    line. Map = the lattice; scan = the same lattice lifted by 1/16 m."""
+    g = np.arange(-8.0, 8.0, 0.5, dtype=np.float32)
+    I, J = np.meshgrid(np.arange(len(g)), np.arange(len(g)), indexing="ij")
+    surf = np.column_stack([g[I.ravel()] + 20.0, g[J.ravel()], -2.0 + ((I.ravel() + J.ravel()) % 2) / 32.0, np.ones(I.size)]).astype(np.float32)
+    zz = np.arange(-1.5, 2.5, 0.25, dtype=np.float32)
+    poles = [(16.0, -6.0), (18.0, -2.0), (22.0, 1.5), (25.0, 5.0), (19.0, 6.5)]
+    edge = np.concatenate([np.column_stack([px + (np.arange(len(zz)) % 2) / 32.0, np.full(len(zz), py), zz, np.ones(len(zz))]) for px, py in poles]).astype(np.float32)
+    lift = np.array([0.0, 0.0, 0.0625, 0.0], dtype=np.float32)
+    return edge, surf, edge + lift, surf + lift
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid_first", [False, True])
+def test_scan2map_lattice_scene_equal_distances_everywhere(oracle, opts, grid_first):
+    """Every down-sampled query of this scene sits at a centre of symmetry of the map lattice: its neighbours come in rings of EXACTLY equal float distances, so which five
+    points the search keeps — and with the ripple, which plane / line the fit returns — is decided by the reference's rule for equal distances alone (ascending map
+    index: what a linear scan keeps; b_associate_ties redoes such queries in that order). Counts, iterations, poses and maps must still equal the oracle's.
+    grid_first: a step with empty scans first — no factors, the pose stays the identity to the bit, and the map update turns the raw map into a voxel grid in the
+    library's cell-major order, where the reference's index order has to be recovered from the leaf keys. The last frame starts from an optimised (no longer dyadic)
+    pose: the ordinary path on the same scene."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2Map
+    e0, s0, e1, s1 = _lattice_scene()
+    empty = np.zeros((0, 4), dtype=np.float32)
+    ref = oracle.OracleS2M(opts); ref.init(e0, s0)
+    s = BackendSolver(opts); dev = Scan2Map(s); dev.localMapInited(e0, s0)
+    frames = ([(empty, empty)] if grid_first else []) + [(e1, s1), (e0, s0)]
+    for k, (e, sc) in enumerate(frames):
+        r = ref.step(e, sc); g = dev.optimation_processing(e, sc)
+        assert (g.n_edge_ds, g.n_surf_ds) == (r.n_edge_ds, r.n_surf_ds)
+        assert list(g.n_edge_factors) == list(r.n_edge_factors) and list(g.n_surf_factors) == list(r.n_surf_factors), f"frame {k}"
+        assert list(g.iterations) == list(r.iterations)
+        assert np.abs(np.array(g.pose_qt[:]) - np.array(r.pose_qt[:])).max() < 1e-9, f"frame {k}"
+        assert (g.map_edge_size, g.map_surf_size) == (r.map_edge_size, r.map_surf_size)
+        if len(e) == 0:
+            assert list(r.iterations) == [0, 0] and np.array_equal(np.array(g.pose_qt[:]), np.array([0, 0, 0, 1, 0, 0, 0.0]))
+        elif k == len(frames) - 2:
+            assert r.n_surf_factors[0] > 50 and r.n_edge_factors[0] > 5           # the scene does produce factors of both kinds
+    for which in (0, 1):
+        assert np.allclose(dev.getMapCloud(which), ref.get_map(which), rtol=0, atol=1e-5)
+    s.close()
+
+
 def test_oracle_grid_knn_equals_bruteforce_inside_the_gate(oracle):
     """The oracle's 1 m cell grid (what its scan-to-map step uses, like the reference's kd-tree) must return exactly the brute-force
     neighbours — indices, order and squared distances — for every query whose 5th neighbour is closer than 1 m, and agree that
