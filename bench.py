@@ -691,43 +691,48 @@ def main():
                     arr_k[i] = wins[k * half + i].as_struct()
                 parr2.append(arr_k)
 
-            def stream_of_batches(pair, rounds):
-                """rounds x 2 batches; the clock covers the uploads + solves + downloads of rounds 1 .. rounds - 1 (round 0 warms up; its downloads fall inside, uncounted)"""
-                pouts = [pair[k].batch_download_states(first=0, n=half) for k in range(2)]
-                inflight = [False, False]
+            def stream_of_batches(hl, rounds):
+                """rounds x len(hl) batches; the clock covers the uploads + solves + downloads of rounds 1 .. rounds - 1 (round 0 warms up; its downloads fall inside, uncounted)"""
+                pouts = [hl[k].batch_download_states(first=0, n=half) for k in range(len(hl))]
+                inflight = [False] * len(hl)
                 t_a = None
                 for r in range(rounds):
                     if r == 1:
                         torch.cuda.synchronize(); t_a = time.perf_counter()
-                    for k in range(2):
+                    for k in range(len(hl)):
                         if inflight[k]:
-                            pair[k].batch_download_states(first=0, n=half, out=pouts[k])
-                        pair[k]._check(pair[k]._L.vilf_batch_upload(pair[k]._h, half, parr2[k]), "vilf_batch_upload")
-                        pair[k].batch_solve(sync=False); inflight[k] = True
-                for k in range(2):
-                    pair[k].batch_download_states(first=0, n=half, out=pouts[k])
+                            hl[k].batch_download_states(first=0, n=half, out=pouts[k])
+                        hl[k]._check(hl[k]._L.vilf_batch_upload(hl[k]._h, half, parr2[k % 2]), "vilf_batch_upload")
+                        hl[k].batch_solve(sync=False); inflight[k] = True
+                for k in range(len(hl)):
+                    hl[k].batch_download_states(first=0, n=half, out=pouts[k])
                 t_b = time.perf_counter()
-                return (t_b - t_a) / (2 * (rounds - 1)), sum(x.num_iterations for x in pouts[0]["summaries"]) + sum(x.num_iterations for x in pouts[1]["summaries"])
+                return (t_b - t_a) / (len(hl) * (rounds - 1)), sum(sum(x.num_iterations for x in po["summaries"]) for po in pouts) / len(hl)
             psolver._check(psolver._L.vilf_batch_upload(psolver._h, half, parr2[0]), "vilf_batch_upload"); psolver._n = half
+            psolver.set_async_upload(True)                                       # vilf_set_async_upload: the upload returns once its copies are enqueued
             # the runtime multiplexes its streams onto a few hardware queues, and two streams on one queue run one after the other (this process holds several
-            # more handles by now): up to three candidates for the second handle, the pair whose streams do not share a queue is the one measured
-            cands, best_c = [], None
-            for _ in range(3):
+            # more handles by now): handles are added one at a time and kept only if the stream gets faster with them — up to three, from up to five candidates
+            chosen, cands, best_per = [psolver], [], 1e-3 * (pcie["upload_ms"] + pcie["solve_ms"] + pcie["download_ms"]) / 2
+            for _ in range(5):
                 hc = BackendSolver(device=local_rank)
-                hc.batch_upload(wins[half:nb], priors[half:nb])
+                hc.batch_upload(wins[half:nb] if len(chosen) % 2 else wins[:half], priors[half:nb] if len(chosen) % 2 else priors[:half])
+                hc.set_async_upload(True)
                 cands.append(hc)
-                per, _its = stream_of_batches([psolver, hc], 3)
-                if best_c is None or per < best_c[0]:
-                    best_c = (per, hc)
-                if per < 0.75 * 1e-3 * (pcie["upload_ms"] + pcie["solve_ms"]) / 2:
+                per, _its = stream_of_batches(chosen + [hc], 3)
+                if per < 0.97 * best_per:
+                    chosen.append(hc); best_per = per
+                if len(chosen) == 3:
                     break
-            per, its_round = stream_of_batches([psolver, best_c[1]], 7)
-            pcie["two_handles"] = {"value": its_round / (2 * per), "unit": "iterations/s", "windows_per_batch": half, "batches": 12, "ms_per_batch": 1e3 * per,
-                                   "what": "the same path as a stream of 1024-window batches alternating over two handles: upload (pack + H2D) of one handle's batch while the other's solve (sync = 0) is on the device; download of a handle's results before its next upload"}
+            if len(chosen) >= 2:
+                per, its_batch = stream_of_batches(chosen, 7)
+                pcie["stream_of_batches"] = {"value": its_batch / per, "unit": "iterations/s", "windows_per_batch": half, "handles": len(chosen), "batches": 6 * len(chosen), "ms_per_batch": 1e3 * per,
+                                       "what": "the same path as a stream of 1024-window batches alternating over two or three handles with vilf_set_async_upload: the host packs one handle's batch while the others' copies and solves (sync = 0) are on the device; download of a handle's results before its next upload"}
+            else:
+                pcie["stream_of_batches"] = {"error": "no second handle whose stream ran beside the first"}
             for hc in cands:
                 hc.close()
         except Exception as e_:              # a side figure: never takes the bench line down
-            pcie["two_handles"] = {"error": repr(e_)}
+            pcie["stream_of_batches"] = {"error": repr(e_)}
         psolver.close()
 
     # ---- single-frame latency: the reference's only mode is ONE window per frame (estimator_node.cpp:243-396) — through the single-window / single-stream entry

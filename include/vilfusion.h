@@ -219,6 +219,11 @@ int vilf_synchronize(vilf_handle *h);
  * lidarConstraints across (feature_tracker_node.cpp:384,524 -> estimator.cpp:689-860); with one handle per stage this orders a frame's two stages
  * without a host round trip between them. Both handles must be on the same device. */
 int vilf_wait_for(vilf_handle *h, vilf_handle *other);
+/* on != 0: vilf_batch_upload returns as soon as its copies and set-up launches are enqueued instead of waiting for them (the caller's window structs are
+ * consumed while the call packs them, as before; the library's pinned staging is protected by a wait at the start of the handle's NEXT upload). Everything
+ * that follows on the handle is ordered behind the copies on its stream. For streams of batches over two handles: while one handle's copies and solve
+ * (vilf_batch_solve with sync == 0) are on the device, the host packs the other handle's next batch — bench.py: pcie_inclusive.stream_of_batches. Default: off. */
+int vilf_set_async_upload(vilf_handle *h, int on);
 /* per-kernel timing by HIP events on the handle's stream (kind 0 linearize incl. the trust-region step, 1 reduce+solve, 2 the step-only launch that ends a solve, 3 other).
  * With sync == 0 calls the spans stay pending and are read by the next call that waits for the stream (a sync call, vilf_batch_summaries, vilf_get_profile*). */
 int vilf_set_profiling(vilf_handle *h, int on);

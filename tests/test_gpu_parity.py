@@ -318,6 +318,42 @@ def test_replicas_and_reruns_are_bit_identical(solver, opts):
     assert np.array_equal(P3, base[:8]), "threaded / chunked upload and serial upload differ"
 
 
+def test_asynchronous_upload_over_two_handles_gives_the_same_results(opts):
+    """vilf_set_async_upload: the upload returns once its copies are enqueued, the solve (sync = 0) queues behind them, and the NEXT upload of the handle waits before it
+    rewrites the pinned staging. A stream of different batches alternating over two such handles — the loop bench.py's pcie_inclusive.stream_of_batches measures — must
+    return, batch for batch, the bits of the synchronous path; so must two uploads of one handle directly after each other (the first one's copies still in flight)."""
+    from vil_fusion_amd.estimator import BackendSolver
+    nb = 320                                                                   # >= 256: host threads pack, the copies go out in quarters
+    batches = [synth.make_batch(40 + k, nb, opts, synth.SynthConfig(n_features=60 + 10 * k), distinct=16) for k in range(4)]
+    flat = lambda rs: np.stack([np.concatenate([r.Ps.ravel(), r.Rs.ravel(), r.Vs.ravel(), r.Bas.ravel(), r.Bgs.ravel()]) for r in rs])
+    ref = BackendSolver(opts)
+    want = []
+    for wins, priors in batches:
+        ref.batch_upload(wins, priors); ref.batch_solve(); want.append(flat(ref.batch_download()))
+    ref.close()
+    hs = [BackendSolver(opts), BackendSolver(opts)]
+    for h in hs:
+        h.set_async_upload(True)
+    got, pending = [None] * 4, [None, None]
+    for k, (wins, priors) in enumerate(batches):                               # batch k on handle k % 2
+        h = hs[k % 2]
+        if pending[k % 2] is not None:
+            got[pending[k % 2]] = flat(h.batch_download())
+        h.batch_upload(wins, priors); h.batch_solve(sync=False); pending[k % 2] = k
+    for j in range(2):
+        got[pending[j]] = flat(hs[j].batch_download())
+    for k in range(4):
+        assert np.array_equal(got[k], want[k]), f"batch {k}"
+    # two uploads back to back on one handle, nothing in between: the second waits for the first one's copies before it packs into the same staging
+    hs[0].batch_upload(*batches[0]); hs[0].batch_upload(*batches[3]); hs[0].batch_solve(sync=False)
+    assert np.array_equal(flat(hs[0].batch_download()), want[3])
+    hs[0].set_async_upload(False)
+    hs[0].batch_upload(*batches[1]); hs[0].batch_solve()
+    assert np.array_equal(flat(hs[0].batch_download()), want[1])
+    for h in hs:
+        h.close()
+
+
 def test_prior_factor_hook(solver, oracle, opts):
     """MarginalizationFactor::Evaluate on the device vs the oracle: residual r0 + J0 dx (quaternion sign flip) and J0 column blocks."""
     rng = np.random.default_rng(12)

@@ -241,6 +241,11 @@ int vilf_prof_flush(vilf_handle *h) {
 }
 // The work enqueued on h's stream from now on starts after everything enqueued on other's stream so far has finished: a dependency on the device, the host
 // does not wait. (The LiDAR stage and the window solve of a frame run on two handles: this orders them without a host round trip between them.)
+extern "C" int vilf_set_async_upload(vilf_handle *h, int on) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    h->async_upload = on != 0;
+    return VILF_OK;
+}
 extern "C" int vilf_wait_for(vilf_handle *h, vilf_handle *other) {
     if (!h || !other) return VILF_ERR_INVALID_ARGUMENT;
     if (h->device != other->device) { h->err = "vilf_wait_for: the handles are on different devices"; return VILF_ERR_INVALID_ARGUMENT; }
@@ -364,6 +369,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     auto t_a = tnow();
     auto lap = [&](const char *what) { if (timing) { auto t = tnow(); fprintf(stderr, "[vilf_batch_upload] %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_a).count()); t_a = t; } };
     HIPCHECK(h, hipSetDevice(h->device));
+    if (h->upload_inflight) { HIPCHECK(h, hipStreamSynchronize(h->stream)); h->upload_inflight = false; }      // vilf_set_async_upload: the last upload's copies may still read the staging
     // the device-resident priors of slots 0..B-1 survive this call unless the slot range grows (buffers may be re-allocated)
     const bool keep_priors = h->resident && B <= h->prior_slots_valid;
     if (!keep_priors) { int rcp = pull_device_priors(h); if (rcp != VILF_OK) return rcp; }
@@ -620,9 +626,10 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     HIPCHECK(h, up(D_NFEAT, nfeat, sB * 4)); HIPCHECK(h, up(D_NFAC, nfac, sB * 4));
     HIPCHECK(h, up(D_EX, ex, sB * 7 * 8)); HIPCHECK(h, up(D_GR0, gR0, sB * 9 * 8)); HIPCHECK(h, up(D_GP0, gP0, sB * 3 * 8));
     HIPCHECK(h, up(D_PAIROFF, pairoff, sB * VB_PTAB * 4));
-    HIPCHECK(h, up(D_MFLAG, h->h_mflag.data(), sB * 4));
-    HIPCHECK(h, up(D_TD, h->h_td.data(), sB * 8));
-    HIPCHECK(h, hipStreamSynchronize(h->stream));
+    std::memcpy(mflag_img, h->h_mflag.data(), sB * 4); std::memcpy(td_img, h->h_td.data(), sB * 8);      // (from the pinned image, like everything else: an asynchronous upload must not read pageable memory the next call rewrites)
+    HIPCHECK(h, up(D_MFLAG, mflag_img, sB * 4));
+    HIPCHECK(h, up(D_TD, td_img, sB * 8));
+    if (!h->async_upload) HIPCHECK(h, hipStreamSynchronize(h->stream));
     }
     lap("small arrays + sync");
 
@@ -697,7 +704,8 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     if (rc != VILF_OK) return rc;
     hipLaunchKernelGGL(k_reset, dim3(B), dim3(VB_NT), 0, h->stream, h->batch, 0);
     HIPCHECK(h, hipGetLastError());
-    if (!(h->defer_upload_sync && staged)) HIPCHECK(h, hipStreamSynchronize(h->stream));      // (the pinned image is not touched again before the caller's own wait)
+    if (h->async_upload) h->upload_inflight = true;                                              // the next upload of this handle waits before it touches the staging
+    else if (!(h->defer_upload_sync && staged)) HIPCHECK(h, hipStreamSynchronize(h->stream));      // (the pinned image is not touched again before the caller's own wait)
     h->resident = true;
     return VILF_OK;
 }

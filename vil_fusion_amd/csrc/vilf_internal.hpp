@@ -76,6 +76,7 @@ struct vilf_handle {
     VbBatch batch;
     int B = 0;
     bool resident = false;
+    bool async_upload = false, upload_inflight = false;   // vilf_set_async_upload: vilf_batch_upload does not wait for its copies; the next upload of the handle does, before it touches the staging
     bool defer_upload_sync = false;   // vilf_window_solve: upload, solve and download are one call — the host waits once, at the download
     std::vector<vilf_prior> priors;          // per slot (host mirror)
     std::vector<char> prior_dirty;

@@ -103,6 +103,10 @@ class BackendSolver:
         self._n = n
         self._shapes = [(w.n_frames, w.n_features) for w in windows]
 
+    def set_async_upload(self, on=True):
+        """vilf_set_async_upload: batch_upload returns once its copies are enqueued (streams of batches over two handles)"""
+        self._check(self._L.vilf_set_async_upload(self._h, 1 if on else 0), "vilf_set_async_upload")
+
     def batch_solve(self, sync=True):
         self._check(self._L.vilf_batch_solve(self._h, 1 if sync else 0), "vilf_batch_solve")
 

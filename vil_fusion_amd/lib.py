@@ -12,7 +12,7 @@ _lib = None
 EXPORTED = [
     "vilf_default_options", "vilf_create", "vilf_destroy", "vilf_reset", "vilf_last_error", "vilf_version",
     "vilf_window_solve", "vilf_window_solve_group", "vilf_window_marginalize", "vilf_batch_upload", "vilf_batch_solve", "vilf_batch_rewind",
-    "vilf_batch_marginalize", "vilf_batch_download", "vilf_batch_download_states", "vilf_batch_summaries", "vilf_synchronize", "vilf_wait_for", "vilf_set_profiling", "vilf_get_profile",
+    "vilf_batch_marginalize", "vilf_batch_download", "vilf_batch_download_states", "vilf_batch_summaries", "vilf_synchronize", "vilf_wait_for", "vilf_set_async_upload", "vilf_set_profiling", "vilf_get_profile",
     "vilf_batch_newest_poses_device", "vilf_prior_export", "vilf_prior_import", "vilf_eval_projection", "vilf_eval_imu", "vilf_eval_imu_raw",
     "vilf_eval_lidar_between", "vilf_eval_projection_td", "vilf_eval_prior", "vilf_eval_edge", "vilf_eval_surf", "vilf_pose_plus", "vilf_se3_plus",
     "vilf_imu_preintegrate", "vilf_imu_preintegrate_batch", "vilf_visual_imu_alignment", "vilf_posegraph_optimize", "vilf_scan2map_init", "vilf_scan2map_step", "vilf_scan2map_get_map", "vilf_scan2map_set_pose",
@@ -66,6 +66,7 @@ def lib():
     L.vilf_batch_summaries.argtypes = [vp, C.c_int, C.c_int, C.POINTER(abi.Summary)]
     L.vilf_synchronize.argtypes = [vp]
     L.vilf_wait_for.argtypes = [vp, vp]
+    L.vilf_set_async_upload.argtypes = [vp, C.c_int]
     L.vilf_set_profiling.argtypes = [vp, C.c_int]
     L.vilf_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.vilf_batch_newest_poses_device.argtypes = [vp, abi.c_double_p, vp]
