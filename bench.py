@@ -332,6 +332,77 @@ def stress_main(args):
     return 0
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start N rank processes of this script — one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, exactly what `python -m torch.distributed.run --nproc-per-node N` would give them — wait for them and pass rank 0's
+    JSON line through. The parent imports neither torch nor the library and never initialises the GPU (a process that has must not exec / fork GPU children on this
+    pool); it only counts devices through the sysfs-free, HIP-free route below when it can. With fewer than N devices visible it refuses, unless
+    VILF_BENCH_REHEARSAL=1 (every rank on cuda:0, gloo collectives: the code path, never a measurement)."""
+    import socket
+    import subprocess
+    rehearse = os.environ.get("VILF_BENCH_REHEARSAL") == "1"
+    if not rehearse:
+        try:
+            import torch                                  # device_count() reads the driver's device list without creating a context on this image
+            ndev = torch.cuda.device_count()
+        except Exception:                                 # noqa: BLE001
+            ndev = None
+        if ndev is not None and ndev < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible (VILF_BENCH_REHEARSAL=1 rehearses the {n}-rank path on one GPU)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p_ in procs[1:]:
+        try:
+            rc = max(rc, abs(p_.wait(timeout=120 if procs[0].returncode else None)))
+        except subprocess.TimeoutExpired:                 # rank 0 failed: the others wait in a collective — end exactly the children started here
+            p_.kill(); p_.wait(); rc = max(rc, 1)
+    sys.stdout.write(out0); sys.stdout.flush()
+    return rc
+
+
+def dryrun_main(args):
+    """VILF_BENCH_DRYRUN=1 (tests only, never a measurement, nothing of the product runs): the rank plumbing of `--gpus N` without a GPU — every rank joins a gloo
+    group, contributes its rows [global unit index, ...] to the pose gather (vil_fusion_amd.dist.gather_poses, the function the rehearsal mode uses), the barrier /
+    max-over-ranks timing runs as in the real line, and rank 0 prints ONE JSON line that says which ranks arrived."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from vil_fusion_amd import dist as vdist
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 4
+    rows = torch.zeros((B, 8), dtype=torch.float64); rows[:, 0] = torch.arange(rank * B, (rank + 1) * B, dtype=torch.float64); rows[:, 7] = 1.0
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    tab = rows
+    for _ in range(args.steps):
+        tab = vdist.gather_poses(rows) if world > 1 else rows
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    col = tab[:, 0].numpy()
+    if rank == 0:
+        print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t[0]) / max(args.steps, 1) * 1e3,
+                          "gather": {"through": "gloo (dry run: no GPU, no product code)", "rccl_ranks": None, "rows": int(len(col)),
+                                     "ranks_in_table": int(len(set((col // B).astype(np.int64).tolist()))),
+                                     "global_unit_order": bool(np.array_equal(col, np.arange(world * B, dtype=np.float64)))}}))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -355,6 +426,10 @@ def main():
     ap.add_argument("--no-stress-leg", dest="stress_leg", action="store_false", help="skip the compact configs[4] leg (one group of 8 stress windows, 3 solves) of the default run")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[4] instead of the headline workload: one synthetic 51-frame / ~46 k-factor window per step and GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args.gpus)                # `python bench.py --gpus N`: this process only starts the N ranks and relays rank 0's line (it never touches the GPU)
+    if os.environ.get("VILF_BENCH_DRYRUN") == "1":
+        return dryrun_main(args)
     if args.stress:
         return stress_main(args)
 
@@ -432,7 +507,7 @@ def main():
             s2m.copy_stream(i % D, i)                      # replicas of the distinct streams, copied on the device
         s2m.snapshot()
     poses = torch.zeros((B, 8), dtype=torch.float64, device="cuda")
-    stamps = np.arange(B, dtype=np.float64)
+    stamps = rank * B + np.arange(B, dtype=np.float64)     # global unit index: the gathered table must come out as 0 .. world * B - 1 (checked after the timed region)
     # N > 1: the newest-frame poses go through the library's own collective (vilf_comm_create / vilf_gather_poses = ncclCommInitRank / ncclAllGather over RCCL — what a
     # C++ / ROS estimator process per GPU would call), enqueued on the solver's stream behind the kernel that writes the rows. torch.distributed only
     # hands rank 0's communicator id to the other ranks and provides the barrier / the max-over-ranks of the timing. The one-GPU rehearsal keeps gloo (two ranks may not
@@ -440,6 +515,7 @@ def main():
     gather = None
     gathered = None
     gather_note = None
+    gather_state = {"table": None}
     if world > 1 and not rehearse:
         # every rank first checks, without any collective, that the library's own RCCL binding loads (vilf_comm_unique_id dlopens librccl); only when all do is the
         # communicator created (a collective: a rank that failed before it would leave the others waiting). Otherwise torch.distributed carries the gather and says so.
@@ -458,13 +534,15 @@ def main():
             gathered = torch.zeros((world * B, 8), dtype=torch.float64, device="cuda")
         elif gather_note is None:
             gather_note = "C-ABI RCCL binding unavailable on another rank"
+    torch.cuda.synchronize()          # `poses` / `gathered` were zero-filled on torch's stream; the library's streams are non-blocking and do not wait for it by themselves
 
     def gather_step():
         solver.newest_poses_to_device(stamps, poses.data_ptr())              # a kernel on the solver's stream, no host wait
         if gather is not None:
-            gather.gather(poses.data_ptr(), B, gathered.data_ptr(), stream=stream)
+            gather.gather_handle(solver, poses.data_ptr(), B, gathered.data_ptr())   # ncclAllGather on the SOLVER's stream: behind the kernel that wrote the rows
         else:
-            vdist.gather_poses(poses.cpu() if rehearse else poses)
+            solver.synchronize()                                                  # torch.distributed works on torch's stream: wait for the rows first
+            gather_state["table"] = vdist.gather_poses(poses.cpu() if rehearse else poses)
 
     import threading
 
@@ -544,6 +622,16 @@ def main():
                    map_points=float(np.mean([len(c[0]) + len(c[1]) for c in lidar_cases])), scan_points=float(np.mean([len(c[2][0]) + len(c[2][1]) for c in lidar_cases])),
                    map_edge_points=float(np.mean([len(c[0]) for c in lidar_cases])), map_surf_points=float(np.mean([len(c[1]) for c in lidar_cases])))
         lid.update(lidar_search_statistics(lidar_cases[:8], opts))
+    # N > 1: what the gather delivered — the table of the last step must hold every rank's rows in global unit order; the rank count comes from the communicator itself
+    gather_info = None
+    if world > 1:
+        solver.synchronize()
+        tab = gathered if gather is not None else gather_state["table"]
+        col = tab[:, 0].cpu().numpy()
+        gather_info = {"through": "vilf_gather_poses_handle (ncclAllGather on the solver's stream)" if gather is not None else ("gloo (one-GPU rehearsal)" if rehearse else "torch.distributed: " + str(gather_note)),
+                       "rccl_ranks": gather.ranks()[0] if gather is not None else None,
+                       "ranks_in_table": int(len(set((col // B).astype(np.int64).tolist()))), "rows": int(len(col)),
+                       "global_unit_order": bool(np.array_equal(col, np.arange(world * B, dtype=np.float64)))}
     t = torch.tensor([dt, float(its_local)], dtype=torch.float64, device="cpu" if rehearse else "cuda")
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -947,6 +1035,9 @@ def main():
                                     "operation costs 36 cycles and the kernels run two waves per SIMD (DESIGN.md 3c); `bound: hbm` is SURVEY 8(d)'s convention for this row",
                          "window_kernels": window_kernels},
         }
+        if gather_info is not None:
+            out["gather"] = gather_info
+            out["rccl_ranks"] = gather_info["rccl_ranks"]
         if mfma is not None:
             out["roofline_mfma"] = mfma
         if overlapped is not None:

@@ -260,6 +260,15 @@ int vilf_comm_destroy(vilf_comm *comm);
 /* local_dev8: n_local rows of 8 doubles on this rank's device; out_dev8: world_size * n_local rows, rank-major (= the global unit order
  * under contiguous sharding). Enqueued on hip_stream (NULL: default stream); the caller synchronises. Every rank passes the same n_local. */
 int vilf_gather_poses(vilf_comm *comm, void *hip_stream, const double *local_dev8, int n_local, double *out_dev8);
+/* The same gather enqueued on the stream h works on — whichever that is: the one handed to vilf_create, or the library's own. The library's own stream is
+ * NON-BLOCKING: it does not synchronise with the default (NULL) stream, so a gather enqueued on NULL is NOT ordered behind vilf_batch_newest_poses_device /
+ * an asynchronous vilf_batch_solve of such a handle. This entry point is: it runs behind everything enqueued on h so far. local_dev8 / out_dev8 must be
+ * ready (allocated and, for local_dev8, written by work on h's stream or synchronised) when the call is made. */
+int vilf_gather_poses_handle(vilf_comm *comm, vilf_handle *h, const double *local_dev8, int n_local, double *out_dev8);
+/* ranks of the communicator as RCCL reports them (ncclCommCount) and this process's rank in it (ncclCommUserRank) */
+int vilf_comm_ranks(vilf_comm *comm, int *world_size_out, int *rank_out);
+/* the hipStream_t (as void*) h enqueues its work on */
+int vilf_get_stream(vilf_handle *h, void **hip_stream_out);
 const char *vilf_comm_last_error(void);
 
 /* ---- prior import / export (tests, snapshots) ------------------------------------------ */

@@ -102,16 +102,19 @@ def _gpu_worker(rank, world, port, n_units, out_dir):
     solver.batch_upload([m[0] for m in made], [m[1] for m in made])
     solver.batch_solve()
     poses = torch.zeros((hi - lo, 8), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()                        # the zero fill ran on torch's stream; the solver's own stream is non-blocking and does not wait for it
     solver.newest_poses_to_device(np.arange(lo, hi, dtype=np.float64), poses.data_ptr())
-    torch.cuda.synchronize()
+    solver.synchronize()
     allp = vdist.gather_poses(poses.cpu(), n_units=n_units)
     np.save(os.path.join(out_dir, f"gpu_gather_{rank}.npy"), allp.numpy())
     if rank == 0:        # the C-ABI collective on a one-rank RCCL communicator: same rows out as in
         g = vdist.RcclPoseGather(1, 0, device=0)
         out = torch.zeros_like(poses)
-        g.gather(poses.data_ptr(), hi - lo, out.data_ptr())
         torch.cuda.synchronize()
+        g.gather_handle(solver, poses.data_ptr(), hi - lo, out.data_ptr())      # on the solver's stream (vilf_gather_poses_handle)
+        solver.synchronize()
         assert torch.equal(out, poses)
+        assert g.ranks() == (1, 0)
         g.close()
     solver.close()
     dist.barrier()
@@ -165,8 +168,7 @@ def _rccl_worker(rank, world, id_path, n_units, out_dir):
         uid = open(id_path, "rb").read()
     g = vdist.RcclPoseGather(world, rank, device=rank, unique_id=uid)
     assert torch.cuda.current_device() == rank, "vilf_comm_create must leave the caller's device as it was"
-    stream = torch.cuda.current_stream().cuda_stream
-    solver = BackendSolver(device=rank, stream=stream)
+    solver = BackendSolver(device=rank)             # the library's own (non-blocking) stream: the gather goes onto THAT stream, not onto the NULL stream
     opts = solver.options
     per = n_units // world                          # equal shards: one ncclAllGather, no padding
     lo, hi = rank * per, (rank + 1) * per
@@ -175,9 +177,11 @@ def _rccl_worker(rank, world, id_path, n_units, out_dir):
     solver.batch_solve(sync=False)
     poses = torch.zeros((per, 8), dtype=torch.float64, device="cuda")
     allp = torch.zeros((world * per, 8), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()                        # both zero fills done before the solver's stream writes the buffers
     solver.newest_poses_to_device(np.arange(lo, hi, dtype=np.float64), poses.data_ptr())      # enqueued behind the solve, no host wait
-    g.gather(poses.data_ptr(), per, allp.data_ptr(), stream=stream)                          # same stream: ordered behind the kernel that writes the rows
-    solver.synchronize(); torch.cuda.synchronize()
+    g.gather_handle(solver, poses.data_ptr(), per, allp.data_ptr())                          # the solver's stream: ordered behind the kernel that writes the rows
+    solver.synchronize()
+    assert g.ranks() == (world, rank)
     np.save(os.path.join(out_dir, f"rccl_gather_{rank}.npy"), allp.cpu().numpy())
     g.close(); solver.close()
 

@@ -21,6 +21,8 @@ struct Rccl {
     int (*CommDestroy)(rcclComm_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int /*ncclDataType_t*/, rcclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(rcclComm_t, int *) = nullptr;          // optional: vilf_comm_ranks falls back to what vilf_comm_create was told
+    int (*CommUserRank)(rcclComm_t, int *) = nullptr;
     bool ok = false;
     std::string err;
 };
@@ -36,6 +38,8 @@ Rccl &rccl() {
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
         r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+        r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
         if (!r.ok) r.err = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
     });
@@ -106,6 +110,28 @@ extern "C" int vilf_gather_poses(vilf_comm *c, void *hip_stream, const double *l
     const int rc = r.AllGather(local_dev8, out_dev8, (size_t)n_local * 8, 8 /* ncclFloat64 (rccl.h:467) */, c->comm, (hipStream_t)hip_stream);
     if (prev_dev >= 0 && prev_dev != c->device) (void)hipSetDevice(prev_dev);
     if (rc != 0) { g_comm_err = std::string("ncclAllGather: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"); return VILF_ERR_DEVICE; }
+    return VILF_OK;
+}
+
+// the gather on the stream the handle works on (the library's own streams are non-blocking: the NULL stream is NOT ordered behind them)
+extern "C" int vilf_gather_poses_handle(vilf_comm *c, vilf_handle *h, const double *local_dev8, int n_local, double *out_dev8) {
+    if (!h) return VILF_ERR_INVALID_ARGUMENT;
+    return vilf_gather_poses(c, (void *)h->stream, local_dev8, n_local, out_dev8);
+}
+extern "C" int vilf_get_stream(vilf_handle *h, void **hip_stream_out) {
+    if (!h || !hip_stream_out) return VILF_ERR_INVALID_ARGUMENT;
+    *hip_stream_out = (void *)h->stream;
+    return VILF_OK;
+}
+extern "C" int vilf_comm_ranks(vilf_comm *c, int *world_size_out, int *rank_out) {
+    if (!c) return VILF_ERR_INVALID_ARGUMENT;
+    Rccl &r = rccl();
+    int n = c->world, me = c->rank;
+    if (r.ok && c->comm && r.CommCount && r.CommUserRank) {
+        if (r.CommCount(c->comm, &n) != 0 || r.CommUserRank(c->comm, &me) != 0) { g_comm_err = "ncclCommCount / ncclCommUserRank failed"; return VILF_ERR_DEVICE; }
+    }
+    if (world_size_out) *world_size_out = n;
+    if (rank_out) *rank_out = me;
     return VILF_OK;
 }
 

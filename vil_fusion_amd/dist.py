@@ -62,6 +62,8 @@ class RcclPoseGather:
         self._L.vilf_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         self._L.vilf_comm_destroy.argtypes = [C.c_void_p]
         self._L.vilf_gather_poses.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self._L.vilf_gather_poses_handle.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        self._L.vilf_comm_ranks.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         if unique_id is None:
             unique_id = self.unique_id()
         self.world_size, self.rank = world_size, rank
@@ -86,6 +88,22 @@ class RcclPoseGather:
         rc = self._L.vilf_gather_poses(self._c, stream, local_dev_ptr, n_local, out_dev_ptr)
         if rc != 0:
             raise RuntimeError(f"vilf_gather_poses: {rc}: {self._L.vilf_comm_last_error().decode()}")
+
+    def gather_handle(self, solver, local_dev_ptr, n_local, out_dev_ptr):
+        """vilf_gather_poses_handle: the all-gather on the stream `solver` (a BackendSolver) enqueues its work on — ordered behind newest_poses_to_device and an
+        asynchronous batch_solve of that handle whatever stream it owns (the library's own streams are non-blocking: the NULL stream does not wait for them)."""
+        rc = self._L.vilf_gather_poses_handle(self._c, solver._h, local_dev_ptr, n_local, out_dev_ptr)
+        if rc != 0:
+            raise RuntimeError(f"vilf_gather_poses_handle: {rc}: {self._L.vilf_comm_last_error().decode()}")
+
+    def ranks(self):
+        """(world size, rank) as RCCL reports them for this communicator (ncclCommCount / ncclCommUserRank)"""
+        import ctypes as C
+        n, me = C.c_int(0), C.c_int(0)
+        rc = self._L.vilf_comm_ranks(self._c, C.byref(n), C.byref(me))
+        if rc != 0:
+            raise RuntimeError(f"vilf_comm_ranks: {rc}: {self._L.vilf_comm_last_error().decode()}")
+        return n.value, me.value
 
     def close(self):
         if self._c:

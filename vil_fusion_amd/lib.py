@@ -18,7 +18,7 @@ EXPORTED = [
     "vilf_imu_preintegrate", "vilf_imu_preintegrate_batch", "vilf_visual_imu_alignment", "vilf_posegraph_optimize", "vilf_scan2map_init", "vilf_scan2map_step", "vilf_scan2map_get_map", "vilf_scan2map_set_pose",
     "vilf_scan2map_batch_create", "vilf_scan2map_batch_init", "vilf_scan2map_batch_set_scan", "vilf_scan2map_batch_step", "vilf_scan2map_batch_snapshot",
     "vilf_scan2map_batch_rewind", "vilf_scan2map_batch_copy_stream", "vilf_scan2map_batch_results", "vilf_scan2map_batch_get_map", "vilf_get_profile_scan2map", "vilf_get_profile_marginalize", "vilf_batch_marginalize_stats", "vilf_get_profile_large_window", "vilf_lidar_extract_features", "vilf_feature_depth",
-    "vilf_comm_unique_id", "vilf_comm_create", "vilf_comm_destroy", "vilf_gather_poses", "vilf_comm_last_error",
+    "vilf_comm_unique_id", "vilf_comm_create", "vilf_comm_destroy", "vilf_gather_poses", "vilf_gather_poses_handle", "vilf_comm_ranks", "vilf_get_stream", "vilf_comm_last_error",
 ]
 
 
@@ -32,7 +32,10 @@ def build(verbose=False):
     res = os.path.join(CSRC, "kernel_resources.json")          # registers / spills / LDS per kernel from the code objects (bench.py quotes the window kernels)
     tool = os.path.join(os.path.dirname(_HERE), "tools", "kernel_resources.py")
     if os.path.exists(tool) and (not os.path.exists(res) or os.path.getmtime(res) < os.path.getmtime(SO_PATH)):
-        subprocess.run(["python3", tool, "__none__"], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        # generated next to the .so and git-ignored like it (it travels to the GPU box with the snapshot); a failure of the tool is reported, never fatal
+        r = subprocess.run(["python3", tool, "__none__"], check=False, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0 or verbose:
+            print(f"[vil_fusion_amd.build] tools/kernel_resources.py rc={r.returncode}" + (": " + r.stdout.strip()[-400:] if r.returncode != 0 else ""))
     return SO_PATH
 
 
