@@ -1130,3 +1130,42 @@ def test_split_linearisation_of_small_batches_is_bit_identical(oracle, opts):
     finally:
         os.environ.pop("VILF_NO_LIN_SPLIT", None)
         s.close()
+
+
+def test_one_launch_per_iteration_kernel_is_bit_identical(oracle, opts):
+    """k_iter (VILF_FUSED=1: trust-region step + linearisation at the candidate + accept / reject + reduce + solve of ONE window in ONE workgroup, one launch per iteration;
+    round 5's experiment — slower than the two-kernel sequence and therefore not the default) must leave every state, count and cost exactly as the two-kernel sequence
+    does: on the windows' own workspaces (VILF_NO_SLOTS=1) and, for a batch of more than 1024 windows, on the 1024 scratch slots handed out per XCD (a workgroup then
+    only ever reads what it wrote itself). Windows of mixed shape: rejected steps, constant features, with and without prior."""
+    import os
+    from vil_fusion_amd.estimator import BackendSolver
+    rng = np.random.default_rng(33)
+    made = []
+    for i in range(14):
+        nz = float(rng.choice([0.05, 0.2, 0.8, 2.0]))
+        c = synth.SynthConfig(n_features=int(rng.integers(8, 120)), with_prior=bool(rng.random() < 0.8), const_fraction=float(rng.choice([0.0, 0.4])),
+                              state_noise=(nz, np.deg2rad(10.0 * nz), nz))
+        w, p, _ = synth.make_window(int(rng.integers(1, 10**6)), opts, c)
+        made.append((w, p))
+    for nz, deg, seed in [(1.5, 15.0, 409), (3.0, 25.0, 405), (3.0, 25.0, 408), (3.0, 25.0, 431)]:      # the windows of test_rejected_steps_match_oracle
+        w, p, _ = synth.make_window(seed, opts, synth.SynthConfig(n_features=60, state_noise=(nz, np.deg2rad(deg), nz)))
+        made.append((w, p))
+    order = [(5 * i + i // 9) % len(made) for i in range(1100)]
+    s = BackendSolver(opts)
+    try:
+        got = {}
+        for mode in ("two", "fused_slots", "fused_own"):
+            os.environ.pop("VILF_FUSED", None); os.environ.pop("VILF_NO_SLOTS", None)
+            if mode != "two": os.environ["VILF_FUSED"] = "1"
+            if mode == "fused_own": os.environ["VILF_NO_SLOTS"] = "1"
+            s.batch_upload([made[k][0] for k in order], [made[k][1] for k in order]); s.batch_solve()
+            got[mode] = (s.batch_download(), [(x.num_iterations, x.num_successful_steps, x.num_linear_solves, x.final_cost, x.termination) for x in s.batch_summaries()])
+        assert any(x[0] != x[1] for x in got["two"][1]), "the batch should hold rejected steps"
+        for mode in ("fused_slots", "fused_own"):
+            assert got[mode][1] == got["two"][1], mode
+            for a, b_ in zip(got[mode][0], got["two"][0]):
+                for k in ("Ps", "Rs", "Vs", "Bas", "Bgs", "para_feature"):
+                    assert np.array_equal(getattr(a, k), getattr(b_, k)), (mode, k)
+    finally:
+        os.environ.pop("VILF_FUSED", None); os.environ.pop("VILF_NO_SLOTS", None)
+        s.close()

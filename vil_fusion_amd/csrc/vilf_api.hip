@@ -35,6 +35,7 @@ __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_mf_chol(VbBatch b, VbMarg g, int n_lo, int n_hi, int disable);
 __global__ void k_linearize_split(VbBatch b, int iteration_zero);
+__global__ void k_iter(VbBatch b, int iteration_zero, unsigned *slot_bm, int *err);
 __global__ void k_mf_ql(VbBatch b, VbMarg g, int force_overflow);
 __global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
 #define VILF_MFA_LDS_EXTRA (4 * 64 * 8 + QL_ICAP * 2)      // k_mf_apply behind V: two staged chunks of the rotation log (MFA_CH = 64) + the 16-bit QL iteration table
@@ -170,7 +171,8 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     else { if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return VILF_ERR_DEVICE; } h->own_stream = true; }
     hipEventCreate(&h->ev0); hipEventCreate(&h->ev1);
     h->solve_lds = (size_t)(66 * 256 + 6 * VB_NPAD + 512 + VILF_MAX_FEATURES) * sizeof(double) + (size_t)VILF_MAX_FEATURES * sizeof(int);
-    h->lin_lds = (size_t)VB_LIN_LDS_DOUBLES * sizeof(double);
+    h->lin_lds = (size_t)VB_LIN_LDS_BYTES;                        // factor chunk + the tables behind it (all dynamic: k_iter overlays the solve's plan on it)
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || ncu <= 0) ncu = 256; h->iter_slots = 2 * ncu; }
     h->solve_sb_lds = (size_t)SB_LDS_DOUBLES * sizeof(double);
     // occupancy experiment (tools/dev_window_occ.sh): unused extra dynamic LDS leaves ONE workgroup per CU instead of two
     if (const char *e = std::getenv("VILF_LIN_LDS_EXTRA")) h->lin_lds += (size_t)std::atoi(e);
@@ -188,6 +190,7 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
     if (hipFuncSetAttribute((const void *)k_linearize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_linearize_last, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_linearize_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lin_lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_iter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h->lin_lds, h->solve_sb_lds)) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->solve_sb_lds) != hipSuccess) {
         delete h; return VILF_ERR_DEVICE;
@@ -848,6 +851,48 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
             hipLaunchKernelGGL(k_linearize_split, dim3((unsigned)(h->B * (nch + 2))), block, h->lin_lds, h->stream, bb, iteration_zero);
         } else hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, bb0, iteration_zero);
     };
+    // One launch per iteration (k_iter: step + linearisation at the candidate + accept / reject + reduce + solve in the same persistent workgroup, the hand-over in the
+    // workgroup's own scratch slot): whenever the speed-bias-first solve applies, the batch is not split over workgroups and no host clock runs between the iterations.
+    // (tests compare it with the two-kernel sequence to the bit)
+    // MEASURED (round 5, same box, 4096 windows, ms per 8-iteration solve): two kernels 15.6, k_iter on the windows' own workspaces 16.2, k_iter on slots 17.8 — the
+    // hand-over through HBM is not what the iteration waits for (HISTORY.md). k_iter therefore stays an experiment: VILF_FUSED=1 selects it, VILF_NO_SLOTS=1 its
+    // per-window-workspace form; the default is the two-kernel sequence.
+    const bool fused = !dense && !split && !(h->opts.max_solver_time > 0) && std::getenv("VILF_FUSED") && !std::getenv("VILF_NO_FUSED") && h->d[D_ITERQ].ensure(128 * sizeof(int));
+    if (fused) {
+        const size_t iter_lds = std::max(h->lin_lds, h->solve_sb_lds);
+        // batches of more than 1024 windows work in 1024 scratch slots (the first 1024 workspaces of set 0) handed out per XCD by a bitmap: [0..31] free bits, [32] error
+        const bool slots = h->B > 1024 && !std::getenv("VILF_NO_SLOTS");
+        unsigned *bm = slots ? h->d[D_ITERQ].as<unsigned>() : nullptr;
+        if (slots) { HIPCHECK(h, hipMemsetAsync(h->d[D_ITERQ].p, 0xff, 32 * sizeof(int), h->stream)); HIPCHECK(h, hipMemsetAsync(h->d[D_ITERQ].as<int>() + 32, 0, 4 * sizeof(int), h->stream)); }
+        mark(3);
+        hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, h->batch, 0);
+        for (int it = 0; it < max_it; it++) {
+            mark(1);             // kind 1 with no kind-0 launches beside it = the iteration kernel (bench.py names it k_iter)
+            hipLaunchKernelGGL(k_iter, grid, block, iter_lds, h->stream, h->batch, it == 0 ? 1 : 0, bm, h->d[D_ITERQ].as<int>() + 32);
+        }
+        mark(2);
+        hipLaunchKernelGGL(k_linearize_last, grid, block, h->lin_lds, h->stream, h->batch);
+        mark(3);
+        hipLaunchKernelGGL(k_finalize, grid, dim3(64), 0, h->stream, h->batch);
+        if (prof) {
+            pev.push_back(vilf_prof_event(h)); ne++;
+            for (size_t i = 0; i < kinds.size(); i++) vilf_prof_span(h, pev[i], pev[i + 1], &h->kernel_ms[kinds[i]], &h->kernel_launches[kinds[i]]);
+        }
+        hipEventRecord(h->ev1, h->stream);
+        HIPCHECK(h, hipGetLastError());
+        h->solve_time_pending = true;
+        if (sync) {
+            HIPCHECK(h, hipStreamSynchronize(h->stream));
+            solve_time_resolve(h);
+            if (prof) { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }
+            if (slots) {                                 // a workgroup that found no free slot left its window untouched and said so
+                int e = 0;
+                HIPCHECK(h, hipMemcpy(&e, h->d[D_ITERQ].as<int>() + 32, sizeof(int), hipMemcpyDeviceToHost));
+                if (e) { h->err = "k_iter: more workgroups resident than workspace slots"; return VILF_ERR_DEVICE; }
+            }
+        }
+        return VILF_OK;
+    }
     mark(3);
     hipLaunchKernelGGL(k_reset, grid, block, 0, h->stream, with_lists(0), 0);
     mark(0);

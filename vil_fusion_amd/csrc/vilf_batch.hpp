@@ -32,6 +32,8 @@
 #define VB_CHUNK (4 * VB_CLS) // factor slots per LDS chunk (one per thread, threads 224..255 sit the evaluation out): 448 rows x 13 doubles = 46.6 KB
                             // -> k_linearize needs < 80 KB of LDS and two workgroups share a CU
 #define VB_LIN_LDS_DOUBLES (2 * VB_CHUNK * VB_XLD + 8)   // >= 10 * 512 (the IMU staging area that precedes the chunk loop)
+#define VB_LIN_SHARED_BYTES 33024                        // the tables behind the chunk (struct LinShared, vilf_kernels.hip): all of k_linearize's LDS is dynamic
+#define VB_LIN_LDS_BYTES (VB_LIN_LDS_DOUBLES * 8 + VB_LIN_SHARED_BYTES)
 #define VB_PTAB (2 * VB_NPAIR + 2)   // per-window pair table: [2 p] = start of pair p inside its class list, [2 p + 1] = factor count | class << 24
 #define VB_SLOT(cls, x) (VB_CHUNK * ((x) / VB_CLS) + VB_CLS * (cls) + ((x) % VB_CLS))     // class-local position -> slot of the chunk-interleaved factor arrays
 #define VB_NT 256           // threads per window workgroup

@@ -47,6 +47,9 @@ __device__ __forceinline__ int tile_index(int ta, int tb) { return ta * (ta + 1)
 // block-wide sum / max with a fixed reduction tree (deterministic)
 // block reductions of the 256-thread kernels: the fixed tree of vilf_wave_sum64 inside each wave, then the four wave results in wave order by every thread — three
 // barriers (the shared-memory halving tree they replace had ten per call)
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store in flight (s_waitcnt vmcnt(0)), which ends any prefetch
+// at the next barrier. Use only where nothing in GLOBAL memory written before it is read by another thread after it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ double block_sum(double v, double *s_red) {
     const int tid = threadIdx.x;
     v = vilf_wave_sum64(v);
@@ -249,25 +252,42 @@ __device__ __forceinline__ int pair_elem(int row, int col) {   // element of the
 
 // JAC = false: the launch after the LAST solve of the iteration budget. Its linearisation would never be used (Ceres tests max_num_iterations before the gradient),
 // so it only takes the step: candidate, cost of every factor (residuals only), accept / reject — a ninth of the linearisations of a solve.
-template <bool JAC, bool SPLIT = false>
-__device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_zero) {
+// FUSED (k_iter): the window and its workspace slot are handed in (a persistent workgroup takes windows from a queue and keeps ONE workspace for all of them);
+// iteration_zero = 2 then means "linearise at x again" (the workspace of x is gone — it was this workgroup's scratch — and an invalid step asks for another solve from it).
+// Returns 0: linearised (a solve may follow), 1: the step was invalid (nothing linearised), 2: the window had stopped before.
+// Everything that used to be static LDS lives behind the factor chunk in the dynamic region, so that a kernel that runs the solve in the same workgroup can overlay it.
+struct LinShared {
+    double pose[77], sb[99], R[99], ric[9], tic[3];
+    double lidJ[10 * 72], lidr[64], grad[176];
+    double pt[VB_NPAIR * PT_LD];
+    double dx[VB_PRIOR_LD];
+    double red[NT];
+    double def[2];
+    int pcol[VB_P], pst[VB_NPAIR], pcn[VB_NPAIR];
+    int last, defi[2];
+};
+static_assert(sizeof(LinShared) <= VB_LIN_SHARED_BYTES, "VB_LIN_SHARED_BYTES (vilf_batch.hpp) must cover LinShared");
+template <bool JAC, bool SPLIT = false, bool FUSED = false>
+__device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_zero, int w_in = 0, size_t ww_in = 0, int tid_in = 0) {
     // SPLIT (small batches, k_linearize_split): the window's work is dealt to NR = chunks + 2 workgroups — role s < NCH evaluates the factor slots of chunk s and forms
     // their pair products, role NCH the IMU factors, role NCH + 1 the LiDAR factors and the prior's cost; every role runs the set-up (state, candidate, tables) itself
     // and changes nothing in VbState. The workgroup that arrives last (a counter) has the same set-up in its LDS and everything else in global memory: it applies the
     // trust-region bookkeeping the others left undone and runs the phases behind the chunk loop. The result is the one of the single workgroup to the bit: a pair whose
     // factors span chunks hands its MFMA accumulators from chunk to chunk (global memory + a flag, only to a HIGHER workgroup index: the dispatcher starts workgroups in
     // order, so the writer is always running or done), and the per-thread cost sums are added up by the last workgroup in the single workgroup's order.
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
+    const int tid = FUSED ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR)
     const int NR = SPLIT ? b.split_nr : 1, NCH = NR - 2;
-    const int w = SPLIT ? (int)blockIdx.x / NR : vb_window(b);
+    const int w = FUSED ? w_in : (SPLIT ? (int)blockIdx.x / NR : vb_window(b));
     const int role = SPLIT ? (int)blockIdx.x - w * NR : 0;
-    if (w < 0) return;
+    if (w < 0) return 2;
     const bool do_vis = !SPLIT || role < NCH, do_imu = !SPLIT || role == NCH, do_lp = !SPLIT || role == NCH + 1;
     int *sctl = SPLIT ? b.split_ctl + (size_t)w * VB_SPLIT_CTL : nullptr;
     double *sbuf = SPLIT ? b.split_buf + (size_t)w * VB_SPLIT_DBL : nullptr, *scost = SPLIT ? sbuf + VB_SPLIT_CARRY : nullptr;
-    __shared__ int s_last;
-    __shared__ double s_def[2];
-    __shared__ int s_defi[2];
+    extern __shared__ double s_dyn[];
+    LinShared &LS = *reinterpret_cast<LinShared *>(s_dyn + LIN_LDS_DOUBLES);
+    int &s_last = LS.last;
+    double *s_def = LS.def;
+    int *s_defi = LS.defi;
     auto arrive = [&]() -> bool {                          // all threads; true in the workgroup that arrives last
         __threadfence();
         __syncthreads();
@@ -280,7 +300,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     const int lit = b.live_it;
     const bool lists = !iteration_zero && JAC && b.live_ctl != nullptr && lit >= 1;
     const int stopped_before = lists ? b.live_ctl[lit - 1] : 0;          // has any window of the batch stopped by the end of the previous iteration?
-    if (!iteration_zero && st->done) { if (lists && tid == 0) b.live_ctl[lit] = 1; return; }
+    if (!iteration_zero && st->done) { if (lists && tid == 0) b.live_ctl[lit] = 1; return 2; }
     // thread 0, at the launch's exits: pass the flag on, and — once something has stopped — put this window on the next iteration's list
     auto still_live = [&]() {
         if (!lists) return;
@@ -303,18 +323,17 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     // the dogleg step from the last solve, linearise at the CANDIDATE into the set that does not belong to x — the candidate's cost falls out of the same pass over
     // the factors, so there is no separate cost-only pass — and flip st->ws when the step is accepted; a rejected step leaves x, its cost and its set untouched.
     const int wset = iteration_zero ? 0 : (st->ws ^ 1);
-    const size_t ww = (size_t)wset * b.B + w;                               // window index inside the written set
+    const size_t ww = FUSED ? ww_in : (size_t)wset * b.B + w;              // window index inside the written set (FUSED: the workgroup's own slot)
 
-    extern __shared__ double s_dyn[];
     double *s_X = s_dyn;
     double *s_U = s_dyn;                      // the IMU staging area (10 x 512) shares the region with the factor chunk that follows it
     double *pd = b.pairD + ww * VB_NPAIR * VB_PAIRD;
-    __shared__ double s_pose[77], s_sb[99], s_R[99], s_ric[9], s_tic[3];
-    __shared__ double s_lidJ[10 * 72], s_lidr[64], s_grad[176];
-    __shared__ double s_pt[VB_NPAIR * PT_LD];
-    __shared__ double s_dx[VB_PRIOR_LD];
-    __shared__ int s_pcol[VB_P], s_pst[VB_NPAIR], s_pcn[VB_NPAIR];     // pair table: start inside the class list, factor count
-    __shared__ double s_red[NT];
+    double *s_pose = LS.pose, *s_sb = LS.sb, *s_R = LS.R, *s_ric = LS.ric, *s_tic = LS.tic;
+    double *s_lidJ = LS.lidJ, *s_lidr = LS.lidr, *s_grad = LS.grad;
+    double *s_pt = LS.pt;
+    double *s_dx = LS.dx;
+    int *s_pcol = LS.pcol, *s_pst = LS.pst, *s_pcn = LS.pcn;           // pair table: start inside the class list, factor count
+    double *s_red = LS.red;
 
     LSTAMP(0);
     const int F = b.n_feat[w], nfac = b.n_fac[w];
@@ -327,6 +346,12 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
 
     if (tid < 77) s_pose[tid] = pose_g[tid];
     if (tid < 99) s_sb[tid] = sb_g[tid];
+    if (FUSED && JAC) {
+        // the slot's W rows carry another window's feature ranges: zero the rows this window uses (coalesced 16-byte stores; the factor lanes write behind several barriers)
+        double2_t *Wz = reinterpret_cast<double2_t *>(b.W + ww * FM * VB_WLD);
+        const int nz = min((F + 3) & ~3, (int)FM) * (VB_WLD / 2);
+        for (int i = tid; i < nz; i += NT) Wz[i] = double2_t{0.0, 0.0};
+    }
     double stepsq = 0;
     if (!iteration_zero) {
         // ---- DoglegStrategy::ComputeTraditionalDoglegStep + model cost change (thread 0), then the candidate x (+) delta -----------------------------
@@ -373,8 +398,14 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         __syncthreads();
         if (!s_flagi[0]) {
             if (SPLIT) { if (arrive()) { if (tid == 0) step_bookkeeping(); if (tid < VB_SPLIT_CTL) sctl[tid] = 0; } }
-            return;
+            if (!FUSED) return 1;
+            // FUSED: the invalid step raised mu and asks for another solve from the linearisation at x — which was this workgroup's scratch and is gone. x is linearised
+            // again (s_pose / s_sb still hold x, the features are read from feat_x): the same arithmetic on the same state gives the same bits.
+            if (st->done) return 2;                        // (thread 0 wrote it before the barrier above: the fifth invalid step in a row ends the window)
+            iteration_zero = 2;
+            feat = feat_x;
         }
+        if (!iteration_zero) {
         const double ca = s_red[1], cb = s_red[2];
         const double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
         const double *grad_g = b.grad + (size_t)w * (VB_P + FM), *gn_g = b.gn + (size_t)w * (VB_P + FM);
@@ -400,6 +431,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             cfeat[f] = v;
         }
         __threadfence_block();                                               // cfeat is read back by other threads of this workgroup below (after the next barrier)
+        }
     }
     // pair table: lane p of every wave keeps pair p's start inside its class list and its factor count in registers, and the wave the set of its own class's pairs
     // as a bit mask — the chunk loop walks the mask and fetches a pair's entry with v_readlane (three dependent LDS reads per pair and chunk before)
@@ -523,13 +555,25 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     if (do_lp && tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
     if (SPLIT && do_lp) { scost[256 + tid] = cost_local; scost[512 + tid] = prior_cost_partial(b, w, s_dx, tid); cost_local = 0; }
     if (!SPLIT) cost_local += prior_cost_partial(b, w, s_dx, tid);
+    // the prior's gradient entry g0 + H0 dx of this thread's reduced variable, formed HERE (in the shadow of the IMU products, beside the prior's cost) and kept in a
+    // register until the gradient phase: there its 75-step row chain was the exposed critical path
+    double gprior = 0;
+    if (JAC && !SPLIT && tid < VB_P && s_pcol[tid] >= 0) {
+        const int pc = s_pcol[tid], n = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + 1];
+        double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
+        const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
+#pragma unroll 8
+        for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];
+        gprior = t;
+    }
     __syncthreads();                                                       // the IMU staging area is dead: the region becomes s_X
+    if (tid == 0) s_X[2 * VB_CHUNK * VB_XLD] = 0.0;                       // the zero the masked lanes of the pair products read (behind the rows; nothing else writes it)
     LSTAMP(4);
     // ---- visual factors: chunks of 256 pair-sorted factors -> LDS rows -> MFMA X^T X per pair ------------------------
     const int *f_start = b.f_start + (size_t)w * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
     const double *facrec = b.facrec + (size_t)w * FC * 8;
-    double *facw = b.facw + (size_t)w * VB_FACW * FC;
+    double *facw = b.facw + (FUSED ? ww : (size_t)w) * VB_FACW * FC;
     double *W = b.W + ww * FM * VB_WLD;
     long long t_eval = 0, t_sync1 = 0, t_mfma = 0, t_sync2 = 0, t_a = 0;
     int pe[4];
@@ -552,14 +596,24 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             cost_local += 0.5 * rho0;
         }
-    } else
-    for (int c0 = SPLIT ? role * VB_CHUNK : 0; c0 < (SPLIT ? (do_vis ? min(nfac, (role + 1) * VB_CHUNK) : 0) : nfac); c0 += VB_CHUNK) {
+    } else {
+    // one coalesced 64-byte record per factor slot (points, feature, slot, frames, const flag, null flag); only the inverse depth is a gather. The NEXT chunk's records
+    // are requested behind the evaluation (its registers are free then) and arrive under the pair products; the inverse depths follow behind the products: the
+    // evaluation of a chunk no longer starts with a trip to HBM and a dependent gather (a fifth of the chunk loop)
+    const int c_begin = SPLIT ? role * VB_CHUNK : 0, c_end = SPLIT ? (do_vis ? min(nfac, (role + 1) * VB_CHUNK) : 0) : nfac;
+    double4_t ra_n = {0, 0, 0, 0}, rb_n = {0, 0, 0, 0};
+    double fv_n = 0;
+    if (c_begin < c_end) {
+        const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)min(c_begin + tid, nfac - 1) * 8);
+        ra_n = rp[0]; rb_n = rp[1];
+        fv_n = feat[(int)(__double_as_longlong(rb_n[2]) & 0xffffffffu)];
+    }
+    for (int c0 = c_begin; c0 < c_end; c0 += VB_CHUNK) {
         t_a = TICK();
         const int q = c0 + tid;
         double *x0 = s_X + (2 * min(tid, VB_CHUNK - 1)) * VB_XLD, *x1 = x0 + VB_XLD;
-        // one coalesced 64-byte record per factor slot (points, feature, slot, frames, const flag, null flag); only the inverse depth is a gather
-        const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)min(q, nfac - 1) * 8);
-        const double4_t ra = rp[0], rb = rp[1];
+        const double4_t ra = ra_n, rb = rb_n;
+        const double fv = fv_n;
         const unsigned long long ia = __double_as_longlong(rb[2]), ib = __double_as_longlong(rb[3]);
         if (tid >= VB_CHUNK) {
         } else if (q < nfac && !((ib >> 17) & 1)) {
@@ -567,7 +621,7 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             const int f = (int)(ia & 0xffffffffu), slot = (int)(ia >> 32), fi = (int)(ib & 0xff), fj = (int)((ib >> 8) & 0xff);
             const bool fc = ((ib >> 16) & 1) != 0;
             double r[2], Ji[12], Jj[12], Jf[2];
-            projection_eval_pair<true>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, pts_i, pts_j, feat[f], b.sqrt_info, r, Ji, Jj, Jf);
+            projection_eval_pair<true>(s_pt + PT_LD * pair_index(fi, fj), s_ric, s_tic, pts_i, pts_j, fv, b.sqrt_info, r, Ji, Jj, Jf);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             cost_local += 0.5 * rho0;
@@ -592,8 +646,12 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             for (int c = 0; c < VB_XLD; c++) { x0[c] = 0; x1[c] = 0; }
         }
         { long long t_b = TICK(); t_eval += t_b - t_a; t_a = t_b; }
-        __syncthreads();
+        lds_barrier();                            // (the rows in LDS; the W / facw stores of this chunk are read after the loop, behind a full barrier)
         { long long t_b = TICK(); t_sync1 += t_b - t_a; t_a = t_b; }
+        if (c0 + VB_CHUNK < c_end) {
+            const double4_t *rp = reinterpret_cast<const double4_t *>(facrec + (size_t)min(c0 + VB_CHUNK + tid, nfac - 1) * 8);
+            ra_n = rp[0]; rb_n = rp[1];
+        }
         const int x0c = VB_CLS * (c0 / VB_CHUNK);                              // this chunk holds the class-local positions [x0c, x0c + VB_CLS) of every class
         if constexpr (SPLIT) {
             // This workgroup has ONE chunk. The pairs of this wave's class that have factors in it, in an order that keeps the chain between the chunks short: first
@@ -623,12 +681,11 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
                     }
                     const int lo = max(pst, x0c), hi = min(pst + pcn_, x0c + VB_CLS);
                     const int r_lo = 2 * (VB_CLS * wave + lo - x0c), r_hi = 2 * (VB_CLS * wave + hi - x0c);
-                    auto ld4 = [&](int r0, double *a) {
-#pragma unroll
+                    auto ld4 = [&](int r0, double *a) {            // a lane outside the pair's rows / the 13 columns reads the zero behind the chunk: the SELECT is on the address —
+#pragma unroll                                                     // a select on the loaded value is turned into a branch around the load, each with its own wait for LDS
                         for (int u = 0; u < 4; u++) {
                             const int row = r0 + 4 * u + (lane >> 4);
-                            const double v = s_X[min(row, 2 * VB_CHUNK - 1) * VB_XLD + (lane & 15)];
-                            a[u] = (row < r_hi && (lane & 15) < VB_XLD) ? v : 0.0;
+                            a[u] = s_X[(row < r_hi && (lane & 15) < VB_XLD) ? row * VB_XLD + (lane & 15) : 2 * VB_CHUNK * VB_XLD];
                         }
                     };
                     double a[4], an[4];
@@ -665,12 +722,11 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             const int r_lo = 2 * (VB_CLS * wave + lo - x0c), r_hi = 2 * (VB_CLS * wave + hi - x0c);
             // a pair that began in an earlier chunk continues in the registers it was left in (a class list is walked in order: one open pair per wave at most)
             double4_t acc = (pst < x0c) ? cacc : double4_t{0, 0, 0, 0}, acc1 = (pst < x0c) ? cacc1 : double4_t{0, 0, 0, 0};
-            auto ld4 = [&](int r0, double *a) {         // unconditional LDS reads (clamped row), masked afterwards: no exec-masked loads
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
+            auto ld4 = [&](int r0, double *a) {         // unconditional LDS reads: a lane outside the pair's rows / the 13 columns reads the zero behind the chunk. The SELECT is
+#pragma unroll                                          // on the ADDRESS: a select on the loaded value is compiled into a branch around the load — four reads, each followed by its
+                for (int u = 0; u < 4; u++) {           // own s_waitcnt lgkmcnt(0), per four MFMAs (measured: 950 cycles per group against 256 of matrix-core time)
                     const int row = r0 + 4 * u + (lane >> 4);
-                    const double v = s_X[min(row, 2 * VB_CHUNK - 1) * VB_XLD + (lane & 15)];      // columns 13..15 read into the next row: masked
-                    a[u] = (row < r_hi && (lane & 15) < VB_XLD) ? v : 0.0;
+                    a[u] = s_X[(row < r_hi && (lane & 15) < VB_XLD) ? row * VB_XLD + (lane & 15) : 2 * VB_CHUNK * VB_XLD];
                 }
             };
             double a[4], an[4];
@@ -694,13 +750,16 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
             }
         }
         { long long t_b = TICK(); t_mfma += t_b - t_a; t_a = t_b; }
-        __syncthreads();
+        if (c0 + VB_CHUNK < c_end) fv_n = feat[(int)(__double_as_longlong(rb_n[2]) & 0xffffffffu)];
+        lds_barrier();                            // (the next chunk overwrites the rows; the gather above stays in flight across it)
         { long long t_b = TICK(); t_sync2 += t_b - t_a; t_a = t_b; }
+    }
+    __syncthreads();                              // everything the chunks stored (W rows, facw records, pair products) is visible to the phases below
     }
     if (JAC && b.dbg && blockIdx.x == 0 && tid == 0) { b.dbg[64 + 16] = t_eval; b.dbg[64 + 17] = t_sync1; b.dbg[64 + 18] = t_mfma; b.dbg[64 + 19] = t_sync2; }
     if (SPLIT) {
         if (do_vis) scost[(3 + role) * 256 + tid] = cost_local;
-        if (!arrive()) return;
+        if (!arrive()) return 2;
         // the last to arrive: the trust-region bookkeeping nobody has done yet, and every thread's cost sum in the single workgroup's order (IMU, LiDAR, prior, chunk by chunk)
         if (!iteration_zero && tid == 0) step_bookkeeping();
         double c = 0;
@@ -796,7 +855,8 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         if (a >= 1) s += imug[30 * (a - 1) + 15 + l];
         if (a <= 9) s += imug[30 * a + l];
         const int pc = s_pcol[tid];
-        if (pc >= 0) {
+        if (!SPLIT) s += gprior;                       // g0 + H0 dx, formed before the chunk loop
+        else if (pc >= 0) {
             const int n = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + 1];
             double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
             const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
@@ -843,9 +903,10 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
     const double gm = block_max(gmax, s_red);
     const double xs = block_sum(xsq, s_red);
     if (iteration_zero) {
-        if (tid == 0) { st->x_cost = cost; st->gradient_max_norm = gm; st->x_norm = sqrt(xs); st->need_linearize = 0; st->reuse = 0; st->initial_cost = cost; st->ws = 0; }
+        // (iteration_zero == 2, FUSED: x was linearised AGAIN for another solve — its cost and norms are what they were)
+        if (tid == 0 && iteration_zero != 2) { st->x_cost = cost; st->gradient_max_norm = gm; st->x_norm = sqrt(xs); st->need_linearize = 0; st->reuse = 0; st->initial_cost = cost; st->ws = 0; }
         LSTAMP(9);
-        return;
+        return 0;
     }
     // ---- accept / reject (trust_region_minimizer.cc): `cost` is the cost at the candidate ---------------------------------------------------------------
     const double step_norm = sqrt(block_sum(stepsq, s_red));
@@ -884,10 +945,11 @@ __device__ __forceinline__ void linearize_body(const VbBatch &b, int iteration_z
         for (int f = tid; f < F; f += NT) feat_x[f] = cfeat[f];
     }
     LSTAMP(9);
+    return 0;
 }
-extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) { linearize_body<true>(b, iteration_zero); }
-extern "C" __global__ __launch_bounds__(NT) void k_linearize_last(VbBatch b) { linearize_body<false>(b, 0); }
-extern "C" __global__ __launch_bounds__(NT) void k_linearize_split(VbBatch b, int iteration_zero) { linearize_body<true, true>(b, iteration_zero); }
+extern "C" __global__ __launch_bounds__(NT) void k_linearize(VbBatch b, int iteration_zero) { (void)linearize_body<true>(b, iteration_zero); }
+extern "C" __global__ __launch_bounds__(NT) void k_linearize_last(VbBatch b) { (void)linearize_body<false>(b, 0); }
+extern "C" __global__ __launch_bounds__(NT) void k_linearize_split(VbBatch b, int iteration_zero) { (void)linearize_body<true, true>(b, iteration_zero); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // k_solve helpers
@@ -1604,7 +1666,7 @@ __device__ __forceinline__ void sb_acc_sub(double *s_P, double *s_t, const doubl
 // T = N_a Y_(a+1) (lane (g4, c16), element q: row g4 + 4 q) IS the B-operand layout of the next product (k-step q: row 4 q + g4), so the recurrence needs
 // no exchange and no barrier; Y_a^T Y_a of the wave's tiles accumulates alongside. M_a band_a and N_a are read-only in LDS.
 template <int WV>
-__device__ __forceinline__ void sb_y_chain(const double *s_band, const double *s_E, double4_t (&acc)[4], int lane) {
+__device__ __forceinline__ void sb_y_chain(const double *s_band, const double *s_E, const double *s_zero, double4_t (&acc)[4], int lane) {
     const int c16 = lane & 15, g4 = lane >> 4;
     double4_t t[3];
 #pragma unroll
@@ -1620,15 +1682,17 @@ __device__ __forceinline__ void sb_y_chain(const double *s_band, const double *s
 #pragma unroll
             for (int ks = 0; ks < 3; ks++) {
                 const int r = 4 * ks + g4;
-                const double v = Ba[min(r, 8) * str + max(p, 0)];
-                yo[ks][ct] = ((r < 9 && p >= 0) ? v : 0.0) - t[ct][ks];
+                // (structural zeros are read from a zero in LDS: the select sits on the ADDRESS — a select on the loaded value is compiled into a branch around the
+                //  read, every read followed by its own wait for LDS)
+                const double v = *((r < 9 && p >= 0) ? Ba + r * str + p : s_zero);
+                yo[ks][ct] = v - t[ct][ks];
             }
         }
         if (a > 1) {                                   // T of the next step first: the chain waits for it, the tile products below do not
             const double *Na = s_E + 81 * (a - 2);     // N_(a-1)
             double av[3];
 #pragma unroll
-            for (int ks = 0; ks < 3; ks++) { const int k = 4 * ks + g4; const double v = Na[9 * min(c16, 8) + min(k, 8)]; av[ks] = (c16 < 9 && k < 9) ? v : 0.0; }
+            for (int ks = 0; ks < 3; ks++) { const int k = 4 * ks + g4; av[ks] = *((c16 < 9 && k < 9) ? Na + 9 * c16 + k : s_zero); }
 #pragma unroll
             for (int ct = 0; ct < 3; ct++) t[ct] = double4_t{0, 0, 0, 0};
 #pragma unroll
@@ -1676,8 +1740,9 @@ __device__ __forceinline__ bool sb_potrf9(double *Dp, double *linv, int lane) {
     return ok;
 }
 // one gather entry of the chain / band tables: (meta, src0, src1, -) -> scaled value + LM term, Cauchy-point contribution
-extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
-    const int w = vb_window(b), tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+template <bool FUSED>
+__device__ __forceinline__ void solve_sb_body(const VbBatch &b, int w, size_t ww_in, int tid_in = 0) {
+    const int tid = FUSED ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (w < 0) return;
     VbState *st = b.st + w;
     extern __shared__ double s_dyn[];
@@ -1706,12 +1771,12 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
     STAMP(1, 0);
     const int F = b.n_feat[w];
     const size_t FM = b.Fmax;
-    const size_t ww = (size_t)st->ws * b.B + w;                             // the workspace that belongs to the current state x (k_linearize)
+    const size_t ww = FUSED ? ww_in : (size_t)st->ws * b.B + w;            // the workspace that belongs to the current state x (k_linearize; FUSED: the workgroup's slot)
     const double *Hpp = b.Hpp + ww * 66 * 36;
     const double *imuH = b.imuH + ww * 9000, *lidH = b.lidH + ww * 1440;
     const double *priorH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
     double *W = b.W + ww * FM * VB_WLD;
-    double *cf = b.cf + (size_t)w * FM;
+    double *cf = b.cf + (FUSED ? ww : (size_t)w) * FM;
     const double *hf = b.hf + ww * FM, *gf = b.gf + ww * FM;
     const uint8_t *f_const = b.f_const + (size_t)w * FM;
     double *scale_g = b.scale + (size_t)w * (VB_P + FM), *diag_g = b.diag + (size_t)w * (VB_P + FM);
@@ -1803,7 +1868,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     const int r = (meta[u] >> 14) & 255, c = (meta[u] >> 22) & 255;
                     const double val = (sv[u][0] + sv[u][1]) * s_scale[r] * s_scale[c];
                     part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
-                    s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                    s_dyn[meta[u] & 0x3fff] = val + ((r == c) ? mu : 0.0) * s_diag[r] * s_diag[r];        // (+ 0 off the diagonal: the same bits, and no branch around the s_diag reads)
                 }
             }
             bool ok = true;
@@ -1881,7 +1946,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     else raw = sf[u - KN][0] + sf[u - KN][1];
                     const double val = raw * s_scale[r] * s_scale[c];
                     part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
-                    s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                    s_dyn[meta[u] & 0x3fff] = val + ((r == c) ? mu : 0.0) * s_diag[r] * s_diag[r];        // (+ 0 off the diagonal: the same bits, and no branch around the s_diag reads)
                 }
             }
             STAMP(1, 21);
@@ -1921,7 +1986,7 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
                     const double raw = (u < KS) ? ss[u < KS ? u : 0][0] + ss[u < KS ? u : 0][1] : sb3[u >= KS ? u - KS : 0][0] + sb3[u >= KS ? u - KS : 0][1];
                     const double val = raw * s_scale[r] * s_scale[c];
                     part += ((r != c) ? 2.0 : 1.0) * s_v[r] * val * s_v[c];
-                    s_dyn[meta[u] & 0x3fff] = (r == c) ? val + mu * s_diag[r] * s_diag[r] : val;
+                    s_dyn[meta[u] & 0x3fff] = val + ((r == c) ? mu : 0.0) * s_diag[r] * s_diag[r];        // (+ 0 off the diagonal: the same bits, and no branch around the s_diag reads)
                 }
             }
             STAMP(1, 23);
@@ -2041,8 +2106,8 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         double4_t acc[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) acc[i] = double4_t{0, 0, 0, 0};
-        if (wave == 0) sb_y_chain<0>(s_band, s_E, acc, ln); else if (wave == 1) sb_y_chain<1>(s_band, s_E, acc, ln);
-        else if (wave == 2) sb_y_chain<2>(s_band, s_E, acc, ln); else sb_y_chain<3>(s_band, s_E, acc, ln);
+        if (wave == 0) sb_y_chain<0>(s_band, s_E, s_t + 79, acc, ln); else if (wave == 1) sb_y_chain<1>(s_band, s_E, s_t + 79, acc, ln);      // s_t[75..79] stay zero for the whole launch
+        else if (wave == 2) sb_y_chain<2>(s_band, s_E, s_t + 79, acc, ln); else sb_y_chain<3>(s_band, s_E, s_t + 79, acc, ln);
         STAMP(1, 5);
         // ---- P4 / P5: Cholesky of the dense block with the trailing matrix in MFMA accumulator registers ---------------------------------------------------
         // Every wave keeps its <= 4 tiles (dense - U^T U from LDS, minus its Y^T Y accumulators) in registers. Per 4-column panel: the lanes holding the
@@ -2322,6 +2387,51 @@ extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) {
         st->grad_sqnorm = G2; st->Jg2 = Jg2; st->alpha = G2 / Jg2;
         st->gy = gy; st->gn_sqnorm = gn2; st->mu = mu; st->mu_used = mu;
         st->num_linear_solves += tries; st->solve_failed = 0; st->reuse = 1; st->scaling_ready = 1;
+    }
+}
+extern "C" __global__ __launch_bounds__(SBT, 2) void k_solve_sb(VbBatch b) { solve_sb_body<false>(b, vb_window(b), 0); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_iter: ONE launch per iteration, one workgroup per window: the trust-region step + linearisation at the candidate + accept / reject (linearize_body) and — in the
+// same workgroup, behind a barrier — the reduce + solve of the new linearisation (solve_sb_body). What the two kernels handed over through per-window double-buffered
+// workspaces in HBM (W, facw, pairD, Hpp, imuH / imug, lidH / lidg, g, diagH, hf, gf, cf: ~0.5 MB per window and set, written by one launch, read by the next after 4096
+// other windows had gone through the caches) is now the WORKGROUP's scratch, consumed microseconds after it was written. For big batches the scratch is a SLOT, not the
+// window's own workspace: a workgroup takes a free slot of its XCD (bitmap in global memory, atomicAnd / atomicOr — a bounded search, nobody waits for anybody) and gives
+// it back when it ends, so the batch works in <= 1024 slots (the lowest free ones first: in practice two per CU, close to what the 4 MB L2 of an XCD and the 256 MB
+// memory-side cache hold) instead of 2 x B workspaces. A workgroup only ever reads what it has written itself in this launch (the W rows it uses are cleared first), so
+// neither another XCD's L2 nor a stale L1 line of the slot's previous user can be observed. A rejected step needs no solve (the old Gauss-Newton step is re-used with a
+// smaller radius); an INVALID step asks for another solve from the linearisation at x, which is gone: x is linearised again (same arithmetic, same state: same bits).
+// LDS: the larger of the two bodies' plans, overlaid. Launch sequence of a solve: k_iter(iteration_zero = 1), k_iter(0) x (max_iterations - 1), k_linearize_last.
+#define VB_SLOTS_PER_XCD 128
+#define VB_SLOTS (8 * VB_SLOTS_PER_XCD)
+extern "C" __global__ __launch_bounds__(NT, 2) void k_iter(VbBatch b, int iteration_zero, unsigned *slot_bm, int *err) {
+    const int w = blockIdx.x + b.w0;
+    __shared__ int s_slot;
+    if (slot_bm) {
+        if (!iteration_zero && b.st[w].done) return;                       // (before a slot is taken: a finished window costs one load)
+        if (threadIdx.x == 0) {
+            const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7);     // HW_REG_XCC_ID[3:0]: slots stay on the XCD whose L2 holds their lines
+            int slot = -1;
+            for (int attempt = 0; attempt < 8 * 4 * 64 && slot < 0; attempt++) {      // own XCD's four words first, then the others'; bounded
+                const int word = ((xcc * 4 + (attempt & 3)) + 4 * ((attempt >> 2) & 7)) & 31;
+                const unsigned v = __hip_atomic_load(slot_bm + word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!v) continue;
+                const int bit = __builtin_ctz(v);
+                if (atomicAnd(slot_bm + word, ~(1u << bit)) & (1u << bit)) slot = 32 * word + bit;
+            }
+            if (slot < 0) atomicExch(err, 1);                              // more workgroups resident than slots: cannot happen at two per CU; reported, not waited for
+            s_slot = slot;
+        }
+        __syncthreads();
+        if (s_slot < 0) return;
+    }
+    const size_t slot = slot_bm ? (size_t)s_slot : (size_t)w;
+    const int r = linearize_body<true, false, true>(b, iteration_zero ? 1 : 0, w, slot, (int)threadIdx.x);
+    __syncthreads();
+    if (r != 2) solve_sb_body<true>(b, w, slot, (int)threadIdx.x);
+    if (slot_bm) {
+        __syncthreads();                                                   // every load of the slot has returned (the barrier waits for vmcnt(0))
+        if (threadIdx.x == 0) atomicOr(slot_bm + (s_slot >> 5), 1u << (s_slot & 31));
     }
 }
 

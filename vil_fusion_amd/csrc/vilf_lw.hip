@@ -1020,6 +1020,7 @@ __device__ __forceinline__ void lw_chol_back_body(int P, const double *S, double
     // element e of a block's triangle; rows / columns past the matrix end: identity (the unrolled solve walks all 64)
     auto tri_at = [&](int bk, int e) { const int j0 = CH_NB * bk, nb = min(CH_NB, P - j0), r = e >> 6, c = e & 63; return (r < nb && c < nb) ? S[(size_t)(j0 + r) * P + j0 + c] : (r == c ? 1.0 : 0.0); };
     for (int e = tid; e < CH_NB * CH_NB; e += 1024) s_tri[(e >> 6) * CH_LD + (e & 63)] = tri_at(nblk - 1, e);
+    if (tid < CH_NB) s_tri[tid * CH_LD + CH_NB] = 0.0;       // the padding column: the zero a lane at or above the pivot reads in the solve below (never rewritten)
     __syncthreads();
     constexpr int NST = 1024 - 64, NPER = (CH_NB * CH_NB + NST - 1) / NST;
     for (int bk = nblk - 1; bk >= 0; bk--) {
@@ -1034,7 +1035,10 @@ __device__ __forceinline__ void lw_chol_back_body(int P, const double *S, double
                 for (int k = 15; k >= 0; k--) {
                     const int j = jc + k;
                     const double yj = lw_readlane(z, j) * lw_readlane(dinv, j);
-                    z = (tid == j) ? yj : ((tid < j) ? z - s_tri[j * CH_LD + tid] * yj : z);
+                    // the read is unconditional — lanes at or above the pivot read the row's zero padding, z - 0 yj = z: written as a conditional read it is compiled
+                    // into a branch around the ds_read with its own s_waitcnt, 64 dependent LDS round trips per block instead of 16 reads in flight in front of the chain
+                    const double t = s_tri[j * CH_LD + ((tid < j) ? tid : CH_NB)];
+                    z = (tid == j) ? yj : z - t * yj;
                 }
             }
             if (tid < nb) s_y[j0 + tid] = z;
