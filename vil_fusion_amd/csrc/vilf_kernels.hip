@@ -53,25 +53,25 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ double block_sum(double v, double *s_red) {
     const int tid = threadIdx.x;
     v = vilf_wave_sum64(v);
-    __syncthreads();
+    lds_barrier();
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     double r = 0;
 #pragma unroll
     for (int k = 0; k < NT / 64; k++) r += s_red[k];
-    __syncthreads();
+    lds_barrier();
     return r;
 }
 __device__ __forceinline__ double block_max(double v, double *s_red) {
     const int tid = threadIdx.x;
     v = vilf_wave_max64(v);
-    __syncthreads();
+    lds_barrier();
     if ((tid & 63) == 0) s_red[tid >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     double r = s_red[0];
 #pragma unroll
     for (int k = 1; k < NT / 64; k++) r = fmax(r, s_red[k]);
-    __syncthreads();
+    lds_barrier();
     return r;
 }
 
@@ -210,6 +210,63 @@ __device__ double prior_cost_partial(const VbBatch &b, int w, const double *s_dx
         acc += 0.5 * s * s;
     }
     return acc;
+}
+
+// The prior's two matrix-vector products, J0 dx (cost) and H0 dx (gradient), with every row dealt to THREE threads: a row is a chain of n = 75 loads from lines of its
+// own (row-per-lane access: nothing coalesces), eight in flight — ten dependent trips to L2 for a third of the workgroup while the rest waits at the next barrier. A third
+// of a row is three trips, and all 256 threads issue. The three partial sums are added in a fixed order (part 0, 1, 2). Both contain LDS-only barriers: all threads.
+// 3 n > 256 (a prior wider than 85): the row-per-thread forms.
+// (Also built and measured, same box: J0 staged in LDS for both products — 17 k cycles dearer in the cost phase than it saved in the gradient phase; both products on
+//  the matrix cores, dx in column 0 of the B operand, H0 read along its rows — 30 k cycles for the pair under load against 36 k here, 11 k against 7 k alone on the
+//  chip, 252 registers: the loads' address arithmetic at one fp64-rate VALU instruction per ~12 cycles and wave costs what the coalescing saves.)
+__device__ __forceinline__ double prior_cost_split(const VbBatch &b, int w, const double *s_dx, double *s_tmp, int tid) {
+    const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    if (!hdr[0]) return 0.0;
+    const int n = hdr[1];
+    if (3 * n > NT) return prior_cost_partial(b, w, s_dx, tid);
+    const double *J = b.prior_J + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD;
+    const int row = tid / 3, part = tid - 3 * row, per = (n + 2) / 3, c0 = part * per, c1 = min(n, c0 + per);
+    const double r0v = b.prior_r[(size_t)w * VB_PRIOR_LD + min(row, n - 1)];
+    double acc = 0;
+    if (row < n) {
+        const double *Jr = J + (size_t)row * n;
+#pragma unroll 8
+        for (int k = c0; k < c1; k++) acc += Jr[k] * s_dx[k];
+    }
+    s_tmp[tid] = acc;
+    lds_barrier();
+    double cost = 0;
+    if (row < n && part == 0) { double t = r0v; t += s_tmp[tid]; t += s_tmp[tid + 1]; t += s_tmp[tid + 2]; cost = 0.5 * t * t; }
+    lds_barrier();
+    return cost;
+}
+__device__ __forceinline__ double prior_grad_split(const VbBatch &b, int w, const double *s_dx, const int *s_pcol, double *s_tmp, int tid) {
+    const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    if (!hdr[0]) return 0.0;
+    const int n = hdr[1];
+    const int pc = (tid < VB_P) ? s_pcol[tid] : -1;
+    if (3 * n > NT) {
+        if (pc < 0) return 0.0;
+        double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
+        const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
+#pragma unroll 8
+        for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];
+        return t;
+    }
+    const int col = tid / 3, part = tid - 3 * col, per = (n + 2) / 3, c0 = part * per, c1 = min(n, c0 + per);
+    const double g0 = b.prior_g[(size_t)w * VB_PRIOR_LD + max(pc, 0)];
+    double acc = 0;
+    if (col < n) {
+        const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)col * VB_PRIOR_LD;
+#pragma unroll 8
+        for (int k = c0; k < c1; k++) acc += pH[k] * s_dx[k];
+    }
+    s_tmp[tid] = acc;
+    lds_barrier();
+    double g = 0;
+    if (pc >= 0) { g = g0; g += s_tmp[3 * pc]; g += s_tmp[3 * pc + 1]; g += s_tmp[3 * pc + 2]; }
+    lds_barrier();
+    return g;
 }
 
 // the window of this workgroup: blockIdx.x + w0, or through the dense list of the windows still running (-1: the list is shorter than the grid)
@@ -414,7 +471,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
             int a, l; unperm(tid, a, l);
             s_grad[15 * a + l] = (ca * grad_g[tid] + cb * gn_g[tid]) / diag_g[tid] * scale_g[tid];
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < VB_NF) {
             double xp[7];
             pose_plus(s_pose + 7 * tid, s_grad + 15 * tid, xp);
@@ -490,7 +547,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
             for (int e = 0; e < 6; e++) s_lidr[6 * k + e] = 0;
         }
     }
-    __syncthreads();
+    lds_barrier();
     LSTAMP(2);
     // ---- IMU: X = sqrt_info * [Jraw | r] on MFMA, in place (imu_factor.h:64,93,126,145,160) -------------------------
     if (JAC && do_imu) for (int task = wave; task < 20; task += 4) {
@@ -510,7 +567,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
 #pragma unroll
         for (int q = 0; q < 4; q++) Xk[32 * ((lane >> 4) + 4 * q) + 16 * ct + (lane & 15)] = acc[q];
     }
-    __syncthreads();
+    lds_barrier();
     LSTAMP(3);
     // ---- IMU: [J r]^T [J r] on MFMA -> imuH (30x30), imug (30), cost; LiDAR blocks on the VALU ------------------------
     if (JAC) {
@@ -534,6 +591,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
                 if (p == 30 && c == 30) cost_local += 0.5 * acc[q];
             }
         }
+        LSTAMP(10);
         double *lidH = b.lidH + ww * 1440, *lidg = b.lidg + ww * 120;
         if (do_lp) {
         for (int idx = tid; idx < 1440; idx += NT) {
@@ -553,20 +611,20 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
     if (SPLIT && do_imu) scost[tid] = cost_local;                          // cost partials of the roles, per thread: [0] IMU, [1] LiDAR, [2] prior, [3 + s] chunk s
     if (SPLIT) cost_local = 0;
     if (do_lp && tid >= 64 && tid < 74) { const int k = tid - 64; double s = 0; for (int m = 0; m < 6; m++) s += s_lidr[6 * k + m] * s_lidr[6 * k + m]; cost_local += 0.5 * s; }
-    if (SPLIT && do_lp) { scost[256 + tid] = cost_local; scost[512 + tid] = prior_cost_partial(b, w, s_dx, tid); cost_local = 0; }
-    if (!SPLIT) cost_local += prior_cost_partial(b, w, s_dx, tid);
-    // the prior's gradient entry g0 + H0 dx of this thread's reduced variable, formed HERE (in the shadow of the IMU products, beside the prior's cost) and kept in a
-    // register until the gradient phase: there its 75-step row chain was the exposed critical path
+    LSTAMP(11);
+    if (SPLIT && do_lp) { scost[256 + tid] = cost_local; cost_local = 0; }
+    // the prior: cost, and — kept in a register until the gradient phase — the gradient entry g0 + H0 dx of this thread's reduced variable (SPLIT: the cost by the
+    // LiDAR / prior role, the gradient by the workgroup that arrives last)
     double gprior = 0;
-    if (JAC && !SPLIT && tid < VB_P && s_pcol[tid] >= 0) {
-        const int pc = s_pcol[tid], n = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + 1];
-        double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
-        const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
-#pragma unroll 8
-        for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];
-        gprior = t;
+    if (!SPLIT || do_lp) {
+        const double pcost = prior_cost_split(b, w, s_dx, s_red, tid);
+        if (SPLIT) scost[512 + tid] = pcost; else cost_local += pcost;
     }
-    __syncthreads();                                                       // the IMU staging area is dead: the region becomes s_X
+    LSTAMP(12);
+    if (JAC && !SPLIT) gprior = prior_grad_split(b, w, s_dx, s_pcol, s_red, tid);
+    LSTAMP(13);
+    lds_barrier();                                                       // the IMU staging area is dead: the region becomes s_X. (LDS-only barriers from here to the end of the
+                                                                           // chunk loop: the imuH / lidH stores above drain under the visual factors instead of being waited for here)
     if (tid == 0) s_X[2 * VB_CHUNK * VB_XLD] = 0.0;                       // the zero the masked lanes of the pair products read (behind the rows; nothing else writes it)
     LSTAMP(4);
     // ---- visual factors: chunks of 256 pair-sorted factors -> LDS rows -> MFMA X^T X per pair ------------------------
@@ -768,6 +826,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
         cost_local = c;
         __syncthreads();
         if (tid < VB_SPLIT_CTL) sctl[tid] = 0;                               // the counter and the carry flags: ready for the next launch
+        if (JAC) gprior = prior_grad_split(b, w, s_dx, s_pcol, s_red, tid);
     }
     double gmax = 0, xsq = 0;
     if (JAC) {
@@ -835,7 +894,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
             Hpp[36 * (a * (a + 1) / 2 + a) + e] = s;
         }
     }
-    __syncthreads();
+    lds_barrier();
     LSTAMP(7);
     // ---- gradient g = J^T r over the reduced camera/IMU block (frame-major order) ---------------------------------
     double *gout = b.g + ww * VB_P;
@@ -855,16 +914,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
         if (a >= 1) s += imug[30 * (a - 1) + 15 + l];
         if (a <= 9) s += imug[30 * a + l];
         const int pc = s_pcol[tid];
-        if (!SPLIT) s += gprior;                       // g0 + H0 dx, formed before the chunk loop
-        else if (pc >= 0) {
-            const int n = b.prior_hdr[(size_t)w * VB_PRIOR_HDR + 1];
-            double t = b.prior_g[(size_t)w * VB_PRIOR_LD + pc];
-            const double *pH = b.prior_H + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD + (size_t)pc * VB_PRIOR_LD;
-#pragma unroll 8
-            for (int k = 0; k < n; k++) t += pH[k] * s_dx[k];     // (tried: 16 entries in flight — same time; column pc of the symmetric H0, coalesced — 17 % slower. Without this product the
-                                                                   //  phase still takes two thirds of its time: under load it waits on the memory system's queues, not on this row)
-            s += t;
-        }
+        s += gprior;                                   // the prior: g0 + H0 dx (prior_grad_split)
         // diagonal of J^T J for this reduced variable (its loads are issued before the gradient is stored: a store in between would fence them off)
         const double *imuHg = b.imuH + ww * 9000, *lidHg = b.lidH + ww * 1440;
         double dg = 0;
@@ -884,7 +934,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
         s_grad[tid] = s;
         b.diagH[ww * VB_P + tid] = dg;
     }
-    __syncthreads();
+    lds_barrier();
     // gradient_max_norm = || x - Plus(x, -g) ||_inf (trust_region_minimizer.cc), x_norm = ||x||
     if (tid < VB_NF) {
         const double *gp = s_grad + 15 * tid;
@@ -938,7 +988,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
         s_acc[0] = accept;
         still_live();
     }
-    __syncthreads();
+    lds_barrier();
     if (s_acc[0]) {
         if (tid < 77) pose_g[tid] = s_pose[tid];
         if (tid < 99) sb_g[tid] = s_sb[tid];
