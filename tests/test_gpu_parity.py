@@ -1169,3 +1169,89 @@ def test_one_launch_per_iteration_kernel_is_bit_identical(oracle, opts):
     finally:
         os.environ.pop("VILF_FUSED", None); os.environ.pop("VILF_NO_SLOTS", None)
         s.close()
+
+
+def test_split_hand_over_wait_is_bounded_and_reported(oracle, opts):
+    """k_linearize_split's consumers wait for the previous chunk's accumulators behind a flag that carries the launch's generation. The wait is BOUNDED: a producer that
+    never publishes (fault injection: VILF_SPLIT_FAULT=1 makes chunk 0 skip its flag stores) must not hang the device — the window is marked, every reader of its
+    results returns VILF_ERR_DEVICE, and the next solve on the same handle (new generation: nothing the dead hand-over left behind is mistaken for a flag) is exact."""
+    import os
+    from vil_fusion_amd.estimator import BackendSolver
+    from vil_fusion_amd.lib import VilfError
+    w, p, _ = synth.make_window(5150, opts, synth.SynthConfig(n_features=300))       # several factor chunks: pairs run on from chunk to chunk
+    ref = oracle.window_solve(opts, w, p)
+    s = BackendSolver(opts)
+    try:
+        s.batch_upload([w], [p]); s.batch_solve()
+        good = s.batch_download()[0]
+        assert good.summary["num_iterations"] == ref.summary["num_iterations"] and np.abs(good.Ps - ref.Ps).max() < 1e-7
+        os.environ["VILF_SPLIT_FAULT"] = "1"
+        s.batch_rewind(); s.batch_solve()
+        with pytest.raises(VilfError):
+            s.batch_summaries()
+        with pytest.raises(VilfError):
+            s.batch_download()
+        os.environ.pop("VILF_SPLIT_FAULT")
+        s.batch_rewind(); s.batch_solve()
+        again = s.batch_download()[0]
+        for k in ("Ps", "Rs", "Vs", "Bas", "Bgs", "para_feature"):
+            assert np.array_equal(getattr(again, k), getattr(good, k)), k
+    finally:
+        os.environ.pop("VILF_SPLIT_FAULT", None)
+        s.close()
+
+
+def test_split_linearisation_under_contention(opts):
+    """200 single-window solves (k_linearize_split: the window's chunks on several workgroups, hand-overs through generation flags) on one handle while a second handle,
+    on its own stream and host thread, keeps the device full with 2048-window batches: every one of the 200 results equals the first to the bit, nothing hangs and no
+    window is marked. (The split relies on the writer of a hand-over having the LOWER workgroup index; the wait is bounded and reported if that ever fails.)"""
+    import threading
+    from vil_fusion_amd.estimator import BackendSolver
+    w, p, _ = synth.make_window(5150, opts, synth.SynthConfig(n_features=300))
+    a = BackendSolver(opts); bsolver = BackendSolver(opts)
+    stop = threading.Event()
+    try:
+        wins, priors = synth.make_batch(77, 2048, opts, synth.SynthConfig(n_features=120), distinct=8)
+        bsolver.batch_upload(wins, priors)
+        def load():
+            while not stop.is_set():
+                bsolver.batch_rewind(); bsolver.batch_solve()
+        th = threading.Thread(target=load); th.start()
+        a.batch_upload([w], [p]); a.batch_solve()
+        first = a.batch_download()[0]
+        for _ in range(200):
+            a.batch_rewind(); a.batch_solve()
+            got = a.batch_download()[0]
+            for k in ("Ps", "Rs", "Vs", "Bas", "Bgs", "para_feature"):
+                assert np.array_equal(getattr(got, k), getattr(first, k)), k
+            assert got.summary["num_iterations"] == first.summary["num_iterations"]
+        stop.set(); th.join()
+        assert all(x.num_iterations > 0 for x in bsolver.batch_summaries())
+    finally:
+        stop.set()
+        a.close(); bsolver.close()
+
+
+def test_solve_after_a_time_limited_solve(oracle, opts):
+    """options.max_solver_time cuts a (split) solve short between two iterations (k_time_limit, termination NO_CONVERGENCE, state = last accepted point); the next solves
+    on the same handle run under the same limit and are unaffected by what the interrupted one left in the hand-over buffers: every result is a valid state of the
+    window's own iteration sequence (its cost is one of the costs the unlimited solve passes through)."""
+    import copy
+    from vil_fusion_amd.estimator import BackendSolver
+    w, p, _ = synth.make_window(5150, opts, synth.SynthConfig(n_features=300))
+    o1 = copy.deepcopy(opts); o1.max_num_iterations = 1
+    costs = []
+    for it in range(1, 9):
+        o1.max_num_iterations = it
+        costs.append(oracle.window_solve(o1, w, p).summary["final_cost"])
+    lim = copy.deepcopy(opts); lim.max_solver_time = 3e-4            # a few iterations' worth: the solve stops somewhere in the middle
+    s = BackendSolver(lim)
+    try:
+        for rep in range(6):
+            s.batch_upload([w], [p]); s.batch_solve()
+            got = s.batch_download()[0]
+            assert np.isfinite(got.Ps).all()
+            c = got.summary["final_cost"]
+            assert got.summary["num_iterations"] <= 8 and min(abs(c - x) / x for x in costs + [oracle.window_solve(opts, w, p).summary["initial_cost"]]) < 1e-6, (rep, c, costs)
+    finally:
+        s.close()

@@ -707,8 +707,9 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     if (rc != VILF_OK) return rc;
     hipLaunchKernelGGL(k_reset, dim3(B), dim3(VB_NT), 0, h->stream, h->batch, 0);
     HIPCHECK(h, hipGetLastError());
-    if (h->async_upload) h->upload_inflight = true;                                              // the next upload of this handle waits before it touches the staging
-    else if (!(h->defer_upload_sync && staged)) HIPCHECK(h, hipStreamSynchronize(h->stream));      // (the pinned image is not touched again before the caller's own wait)
+    if (h->async_upload || (h->defer_upload_sync && staged)) h->upload_inflight = true;          // the next upload of this handle waits before it touches the staging (also when
+                                                                                                 // vilf_window_solve returns early on an error, before its own wait for the stream)
+    else HIPCHECK(h, hipStreamSynchronize(h->stream));
     h->resident = true;
     return VILF_OK;
 }
@@ -848,6 +849,9 @@ extern "C" int vilf_batch_solve(vilf_handle *h, int sync) {
         if (split) {
             VbBatch bb = bb0;
             bb.split_nr = nch + 2; bb.split_ctl = h->d[D_SPLITC].as<int>(); bb.split_buf = h->d[D_SPLITB].as<double>();
+            if (++h->split_gen <= 0) h->split_gen = 1;            // the launch's generation: what its hand-over flags carry (never 0 = the cleared state)
+            bb.split_gen = h->split_gen;
+            bb.split_fault = std::getenv("VILF_SPLIT_FAULT") != nullptr;
             hipLaunchKernelGGL(k_linearize_split, dim3((unsigned)(h->B * (nch + 2))), block, h->lin_lds, h->stream, bb, iteration_zero);
         } else hipLaunchKernelGGL(k_linearize, grid, block, h->lin_lds, h->stream, bb0, iteration_zero);
     };
@@ -963,6 +967,14 @@ extern "C" int vilf_get_profile_marginalize(vilf_handle *h, double ms_out[4], lo
     return VILF_OK;
 }
 
+// a window whose kernel gave up a bounded device-side wait (VbState::dev_error): no numbers are handed out for it
+static int vb_check_dev_error(vilf_handle *h, const VbState *st, int first, int n) {
+    for (int i = 0; i < n; i++) if (st[i].dev_error) {
+        h->err = "window " + std::to_string(first + i) + ": a workgroup of k_linearize_split gave up waiting for another one's hand-over (bounded wait; the results of this solve are not valid)";
+        return VILF_ERR_DEVICE;
+    }
+    return VILF_OK;
+}
 extern "C" int vilf_batch_summaries(vilf_handle *h, int first, int n, vilf_summary *sums) {
     if (!h || !h->resident || first < 0 || n < 0 || first + n > h->B || !sums) return VILF_ERR_INVALID_ARGUMENT;
     std::vector<VbState> st(n);
@@ -970,6 +982,7 @@ extern "C" int vilf_batch_summaries(vilf_handle *h, int first, int n, vilf_summa
     HIPCHECK(h, hipStreamSynchronize(h->stream));
     solve_time_resolve(h);
     { const int rcf = vilf_prof_flush(h); if (rcf != VILF_OK) return rcf; }     // the stream is idle: pending profile spans cost nothing to read now
+    { const int rce = vb_check_dev_error(h, st.data(), first, n); if (rce != VILF_OK) return rce; }
     for (int i = 0; i < n; i++) {
         sums[i].num_iterations = st[i].iteration;
         sums[i].num_successful_steps = st[i].num_successful;
@@ -1005,6 +1018,7 @@ extern "C" int vilf_batch_download(vilf_handle *h, int first, int n, vilf_window
         const char *img = static_cast<const char *>(h->pin_down.p);
         auto dd = [&](size_t at) { return reinterpret_cast<const double *>(img + at); };
         const VbState *st = reinterpret_cast<const VbState *>(img + o_st);
+        { const int rce = vb_check_dev_error(h, st, first, n); if (rce != VILF_OK) return rce; }
         for (int i = 0; i < n; i++) {
             vilf_window_out &o = outs[i];
             const int F = h->h_nfeat[first + i];
@@ -1084,6 +1098,7 @@ extern "C" int vilf_batch_download_states(vilf_handle *h, int first, int n, doub
     if (Vs) std::memcpy(Vs, pV, sn * 33 * 8);
     if (Bas) std::memcpy(Bas, pA, sn * 33 * 8);
     if (Bgs) std::memcpy(Bgs, pG, sn * 33 * 8);
+    if (sums) { const int rce = vb_check_dev_error(h, pS, first, n); if (rce != VILF_OK) return rce; }
     if (sums) for (int i = 0; i < n; i++) {
         sums[i].num_iterations = pS[i].iteration; sums[i].num_successful_steps = pS[i].num_successful; sums[i].num_linear_solves = pS[i].num_linear_solves;
         sums[i].termination = pS[i].termination; sums[i].initial_cost = pS[i].initial_cost; sums[i].final_cost = pS[i].x_cost; sums[i].final_radius = pS[i].radius;

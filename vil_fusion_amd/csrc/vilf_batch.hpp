@@ -80,6 +80,8 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
     double model_cost_change, relative_decrease;
     int iteration, num_successful, num_linear_solves, num_consecutive_invalid;
     int termination, done, reuse, need_linearize, solve_failed, scaling_ready, started;
+    int dev_error;          // set by a kernel that gave up waiting for another workgroup (k_linearize_split's bounded carry wait): every reader of the results returns
+                            // VILF_ERR_DEVICE for this window instead of numbers computed from a carry that never came
     int ws;                 // which of the two linearisation workspaces (W, Hpp, imuH, pairD, g ...) belongs to the current state x: k_linearize writes the OTHER one at the
                             // candidate and flips this when the step is accepted
 };
@@ -130,6 +132,8 @@ struct VbMarg {
 #define VB_SPLIT_MAXB 8          // largest batch that is split. Measured (tools/dev_small_batch_sweep.sh, ms per 8-iteration solve of the batch, split / one workgroup per window):
                                  // B = 1: 1.11 / 1.33, 4: 1.16 / 1.37, 8: 1.27 / 1.37, 16: 1.51 / 1.41, 32: 2.09 / 1.46 — beyond ~100 workgroups the roles get in each other's way
 #define VB_SPLIT_CTL 64
+#define VB_SPLIT_CNT 52          // split_ctl[52 + (generation & 7)]: the arrival counter of the launch with that generation; [1 + 4 chunk + wave]: "carry written" = the generation
+#define VB_SPLIT_SPIN_MAX (1 << 20)   // bounded wait for a carry: ~2^20 x (s_sleep 1 + an L2 load) ~ 0.1 s, four orders of magnitude beyond the longest chunk; then dev_error
 #define VB_SPLIT_CARRY (VB_SPLIT_MAXCH * 4 * 64 * 8)
 #define VB_SPLIT_DBL (VB_SPLIT_CARRY + (VB_SPLIT_MAXCH + 3) * 256)
 struct VbBatch {
@@ -146,6 +150,8 @@ struct VbBatch {
     // factors, one for the LiDAR factors and the prior's cost — and the one that arrives last assembles (vilf_kernels.hip). split_ctl: per window VB_SPLIT_CTL ints
     // ([0] arrivals, [1 + 4 chunk + wave] "carry written"); split_buf: per window VB_SPLIT_DBL doubles (carries [chunk][wave][lane][8], cost partials [3 + chunks][256]).
     int split_nr; int *split_ctl; double *split_buf;
+    int split_fault;        // test hook (VILF_SPLIT_FAULT=1): chunk 0 never publishes its carries — the consumers' bounded wait must end the launch with dev_error
+    int split_gen;          // generation of this launch (host counter, never 0): flags carry it, so nothing a dead or earlier launch left behind can be mistaken for a hand-over
     // options
     double sqrt_info, cauchy_b, G[3];
     double qil[4], til[3];  // RIC*RCL as quaternion (xyzw), RIC*TCL+TIC (lidar_factor.h:28-29)

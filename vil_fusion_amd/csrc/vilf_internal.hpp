@@ -117,6 +117,7 @@ struct vilf_handle {
     double last_solve_usec = 0;
     bool solve_time_pending = false;         // the last solve was enqueued with sync == 0: ev0 / ev1 are read by the next call that waits for the stream
     size_t solve_lds = 0, lin_lds = 0, solve_sb_lds = 0;
+    int split_gen = 0;      // generation counter of the k_linearize_split launches of this handle
     int iter_slots = 512;   // resident workgroups of k_iter = workspace slots it uses (two per CU)
     bool solve_dense_fallback = false;       // a prior imported from the host holds a speed-bias block other than SpeedBias[0]: k_solve (dense) instead of k_solve_sb
     FeatCtx *feat = nullptr;                 // LiDAR feature extraction workspace (vilf_feat.hip)

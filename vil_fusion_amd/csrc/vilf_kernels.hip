@@ -348,12 +348,15 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
     auto arrive = [&]() -> bool {                          // all threads; true in the workgroup that arrives last
         __threadfence();
         __syncthreads();
-        if (tid == 0) s_last = (__hip_atomic_fetch_add(sctl, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == NR - 1) ? 1 : 0;
+        if (tid == 0) s_last = (__hip_atomic_fetch_add(sctl + VB_SPLIT_CNT + (b.split_gen & 7), 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == NR - 1) ? 1 : 0;
         __syncthreads();
         if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         return s_last != 0;
     };
     VbState *st = b.st + w;
+    // the arrival counter four generations ahead is cleared by every workgroup of this launch (idempotent; no launch in flight uses it): a launch that died half way
+    // leaves a counter that is wiped long before its slot comes round again
+    if (SPLIT && tid == 0) sctl[VB_SPLIT_CNT + ((b.split_gen + 4) & 7)] = 0;
     const int lit = b.live_it;
     const bool lists = !iteration_zero && JAC && b.live_ctl != nullptr && lit >= 1;
     const int stopped_before = lists ? b.live_ctl[lit - 1] : 0;          // has any window of the batch stopped by the end of the previous iteration?
@@ -454,7 +457,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
         }
         __syncthreads();
         if (!s_flagi[0]) {
-            if (SPLIT) { if (arrive()) { if (tid == 0) step_bookkeeping(); if (tid < VB_SPLIT_CTL) sctl[tid] = 0; } }
+            if (SPLIT) { if (arrive()) { if (tid == 0) step_bookkeeping(); } }
             if (!FUSED) return 1;
             // FUSED: the invalid step raised mu and asks for another solve from the linearisation at x — which was this workgroup's scratch and is gone. x is linearised
             // again (s_pose / s_sb still hold x, the features are read from feat_x): the same arithmetic on the same state gives the same bits.
@@ -732,10 +735,20 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
                     if ((in ? 2 : (out ? 0 : 1)) != pass) continue;
                     double4_t acc = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
                     if (in) {
-                        while (__hip_atomic_load(flag_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(1);
-                        const double2_t *ci = reinterpret_cast<const double2_t *>(carry_in);
-                        const double2_t c0_ = ci[0], c1_ = ci[1], c2_ = ci[2], c3_ = ci[3];
-                        acc = double4_t{c0_[0], c0_[1], c1_[0], c1_[1]}; acc1 = double4_t{c2_[0], c2_[1], c3_[0], c3_[1]};
+                        // bounded wait for the previous chunk's accumulators (flag = this launch's generation). The writer has the lower workgroup index and is
+                        // normally running or done; if it never publishes — not scheduled, dead — the window is marked (dev_error: the host returns VILF_ERR_DEVICE
+                        // for it) and the launch ends instead of hanging the device
+                        int spins = 0;
+                        bool got = false;
+                        for (; spins < VB_SPLIT_SPIN_MAX; spins++) {
+                            if (__hip_atomic_load(flag_in, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == b.split_gen) { got = true; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                        if (got) {
+                            const double2_t *ci = reinterpret_cast<const double2_t *>(carry_in);
+                            const double2_t c0_ = ci[0], c1_ = ci[1], c2_ = ci[2], c3_ = ci[3];
+                            acc = double4_t{c0_[0], c0_[1], c1_[0], c1_[1]}; acc1 = double4_t{c2_[0], c2_[1], c3_[0], c3_[1]};
+                        } else if (lane == 0) __hip_atomic_store(&st->dev_error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     const int lo = max(pst, x0c), hi = min(pst + pcn_, x0c + VB_CLS);
                     const int r_lo = 2 * (VB_CLS * wave + lo - x0c), r_hi = 2 * (VB_CLS * wave + hi - x0c);
@@ -761,7 +774,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
                         double2_t *co = reinterpret_cast<double2_t *>(carry_out);
                         co[0] = double2_t{acc[0], acc[1]}; co[1] = double2_t{acc[2], acc[3]}; co[2] = double2_t{acc1[0], acc1[1]}; co[3] = double2_t{acc1[2], acc1[3]};
                         __threadfence();
-                        if (lane == 0) __hip_atomic_store(flag_out, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0 && !(b.split_fault && role == 0)) __hip_atomic_store(flag_out, b.split_gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                     } else {
 #pragma unroll
                         for (int q4 = 0; q4 < 4; q4++) if (pe[q4] >= 0) pd[p * VB_PAIRD + pe[q4]] = acc[q4] + acc1[q4];
@@ -825,7 +838,6 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
         for (int k = 0; k < NCH; k++) c += __builtin_nontemporal_load(scost + (3 + k) * 256 + tid);
         cost_local = c;
         __syncthreads();
-        if (tid < VB_SPLIT_CTL) sctl[tid] = 0;                               // the counter and the carry flags: ready for the next launch
         if (JAC) gprior = prior_grad_split(b, w, s_dx, s_pcol, s_red, tid);
     }
     double gmax = 0, xsq = 0;
@@ -2546,7 +2558,7 @@ extern "C" __global__ void k_reset(VbBatch b, int rewind_state) {
         s.x_norm = 0; s.gradient_max_norm = 1e300; s.grad_sqnorm = 0; s.Jg2 = 0; s.gy = 0; s.gn_sqnorm = 0; s.mu_used = 1e-8;
         s.model_cost_change = 0; s.relative_decrease = 0;
         s.iteration = 0; s.num_successful = 0; s.num_linear_solves = 0; s.num_consecutive_invalid = 0;
-        s.termination = 0; s.done = 0; s.reuse = 0; s.need_linearize = 1; s.solve_failed = 0; s.scaling_ready = 0; s.started = 1; s.ws = 0;
+        s.termination = 0; s.done = 0; s.reuse = 0; s.need_linearize = 1; s.solve_failed = 0; s.scaling_ready = 0; s.started = 1; s.ws = 0; s.dev_error = 0;
         b.st[w] = s;
     }
 }
