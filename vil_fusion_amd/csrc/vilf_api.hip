@@ -36,6 +36,7 @@ __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_mf_chol(VbBatch b, VbMarg g, int n_lo, int n_hi, int disable);
 __global__ void k_linearize_split(VbBatch b, int iteration_zero);
 __global__ void k_iter(VbBatch b, int iteration_zero, unsigned *slot_bm, int *err);
+__global__ void k_sb_table(int *tab);
 __global__ void k_mf_ql(VbBatch b, VbMarg g, int force_overflow);
 __global__ void k_mf_apply(VbBatch b, VbMarg g, int n_lo, int n_hi);
 #define VILF_MFA_LDS_EXTRA (4 * 64 * 8 + QL_ICAP * 2)      // k_mf_apply behind V: two staged chunks of the rotation log (MFA_CH = 64) + the 16-bit QL iteration table
@@ -196,6 +197,10 @@ extern "C" int vilf_create(const vilf_options *opts, int device, void *hip_strea
         delete h; return VILF_ERR_DEVICE;
     }
     std::memset(&h->batch, 0, sizeof(h->batch));
+    // k_solve_sb's gather index table: decoded once on the device (the same arithmetic the kernel used to run per launch), read by every solve
+    if (!h->d[D_SBTAB].ensure((size_t)23 * 256 * 16)) { delete h; return VILF_ERR_DEVICE; }
+    hipLaunchKernelGGL(k_sb_table, dim3(1), dim3(256), 0, h->stream, h->d[D_SBTAB].as<int>());
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { delete h; return VILF_ERR_DEVICE; }
     *out = h;
     return VILF_OK;
 }
@@ -700,6 +705,7 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
         h->luts_ready = true;
     }
     h->batch.lut_imu = h->d[D_LUTI].as<int>(); h->batch.lut_lid = h->d[D_LUTL].as<int>(); h->batch.lut_vis = h->d[D_LUTV].as<int>();
+    h->batch.sb_tab = h->d[D_SBTAB].as<int>();
     const int nimu = B * 10;
     hipLaunchKernelGGL(k_imu_prep, dim3((nimu + 3) / 4), dim3(64), 0, h->stream, nimu, h->d[D_COV].as<double>(), h->d[D_WORK].as<double>(), h->d[D_IMU].as<double>());
     HIPCHECK(h, hipGetLastError());

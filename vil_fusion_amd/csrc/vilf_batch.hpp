@@ -178,6 +178,7 @@ struct VbBatch {
     const double *facrec;   // [B][FACmax][8]: per pair-sorted factor {pts_i[3], pts_j[3], (feature | slot << 32), (frame_i | frame_j << 8 | const << 16)} — one
                             // coalesced 64-byte record instead of five dependent gathers
     const double *imu, *lidar;
+    const int *sb_tab;      // k_solve_sb's gather index table (k_sb_table, built once per handle): SB_TAB_ROWS int4 rows x 256 threads
     const int *lut_imu, *lut_lid, *lut_vis;   // static scatter tables: source element -> LDS tile offset (or -1)
     double *cf;             // [B][Fmax] per-feature Schur coefficient s_f / sqrt(h~_f'), then W_f . (S y)_p (k_solve_sb)
     const int *prior_hdr;

@@ -29,7 +29,7 @@ enum {
     D_PHDR, D_PX0, D_PJ, D_PR, D_PH, D_PG, D_FACW, D_HPP, D_W, D_HF, D_GF, D_IMUH, D_IMUG, D_LIDH, D_LIDG, D_G, D_DIAGH,
     D_SCALE, D_DIAG, D_GRAD, D_GN, D_ST, D_OPS, D_ORS, D_OVS, D_OBAS, D_OBGS, D_COV, D_WORK, D_HOOK, D_DBG, D_LUTI, D_LUTL, D_LUTV,
     D_MFLAG, D_MINFO, D_MF0, D_MSTP, D_MSTS, D_MSTF, D_MSTE, D_MBUF, D_MHD, D_MGD, D_MWF, D_MHF, D_MGF, D_MAMM, D_MX, D_MROT, D_MLAM, D_MAR, D_MBR, D_QLV, D_QLD, D_QLLOG, D_QLIT, D_QLINFO,
-    D_PAIRD, D_FACREC, D_CF, D_STAMPS, D_LIVE, D_ITERQ, D_SPLITC, D_SPLITB, D_UPSTAGE, D_DNSTAGE, D_OBSV, D_OBSTD, D_OBSROW, D_TD, D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0,      // priors as uploaded (restored by vilf_batch_rewind after a marginalization)
+    D_PAIRD, D_FACREC, D_CF, D_STAMPS, D_LIVE, D_ITERQ, D_SBTAB, D_SPLITC, D_SPLITB, D_UPSTAGE, D_DNSTAGE, D_OBSV, D_OBSTD, D_OBSROW, D_TD, D_PHDR0, D_PX00, D_PJ0, D_PR0, D_PH0, D_PG0,      // priors as uploaded (restored by vilf_batch_rewind after a marginalization)
     D_COUNT
 };
 

@@ -1802,6 +1802,75 @@ __device__ __forceinline__ bool sb_potrf9(double *Dp, double *linv, int lane) {
     return ok;
 }
 // one gather entry of the chain / band tables: (meta, src0, src1, -) -> scaled value + LM term, Cauchy-point contribution
+// ---- the gather's index table --------------------------------------------------------------------------------------------------------------------------
+// Which sources a destination entry of the dense block / band / chain blocks adds up is the same for every window: it is decoded ONCE (k_sb_table, at vilf_create) into
+// a table the solve reads with coalesced 16-byte loads — 23 per thread, always L2 hits — instead of ~2000 integer instructions per thread and launch (divisions by
+// 36 / 81 / 243 / 27, a triangular root: 35 k of the 53 k cycles of the gather at one VALU instruction per ~12 cycles and wave). Layout: int4 rows [k][256 threads];
+// waves 0..2, A part: 4 x (meta, Hpp, imu0, imu1, lid0, lid1), 9 x (meta, Hpp) in rows 0..10; B part: 4 x (meta, imu), 13 x (meta, imu0, imu1) in rows 11..22;
+// wave 3 (its 64 lanes at threads 192..255): 13 x (meta, imu0, imu1), 12 x (meta, imu) in rows 0..15. meta = LDS offset | r << 14 | c << 22, bit 31 = "no such entry"
+// (r, c stay valid: the prior's column lookup is issued for every entry); a source index of -1 = absent (the buffer load returns zero).
+#define SB_TAB_ROWS 23
+#define SB_META(off, r, c, on) (((off) & 0x3fff) | ((r) << 14) | ((c) << 22) | ((on) ? 0 : (int)0x80000000))
+extern "C" __global__ __launch_bounds__(256) void k_sb_table(int *tab) {
+    const int tid = threadIdx.x, td = tid, ln = tid & 63;
+    int t[SB_TAB_ROWS * 4];
+    for (int k = 0; k < SB_TAB_ROWS * 4; k++) t[k] = -1;
+    if (tid >= 192) {
+        for (int u = 0; u < 13; u++) {          // D_a[i][j], j <= i: IMU factor a-1 rows 21.. (+ factor a rows 6..)
+            const int q = min(ln + 64 * u, 809), a1 = q / 81, rem = q - 81 * a1, i = rem / 9, j = rem - 9 * i;
+            const bool on = ln + 64 * u < 810 && j <= i;
+            t[3 * u] = SB_META(SB_OFF_D + q, VB_NPOSE + 9 + 9 * a1 + i, VB_NPOSE + 9 + 9 * a1 + j, on);
+            t[3 * u + 1] = 900 * a1 + 30 * (21 + i) + 21 + j;
+            t[3 * u + 2] = a1 + 1 <= 9 ? 900 * (a1 + 1) + 30 * (6 + i) + 6 + j : -1;
+        }
+        for (int u = 0; u < 12; u++) {          // E_a[i][j] = H(SpeedBias[a+1], SpeedBias[a]): IMU factor a, rows 21.., columns 6..
+            const int q = min(ln + 64 * u, 728), a1 = q / 81, rem = q - 81 * a1, i = rem / 9, j = rem - 9 * i;
+            t[39 + 2 * u] = SB_META(SB_OFF_E + q, VB_NPOSE + 18 + 9 * a1 + i, VB_NPOSE + 9 + 9 * a1 + j, ln + 64 * u < 729);
+            t[39 + 2 * u + 1] = 900 * (a1 + 1) + 30 * (21 + i) + 6 + j;
+        }
+    } else {
+        for (int u = 0; u < 4; u++) {           // pose blocks on / next to the diagonal (21 blocks): visual + IMU (<= 2) + LiDAR (<= 2) + prior
+            const int q = min(td + 192 * u, 755), nb = q / 36, e = q - 36 * nb, l1 = e / 6, l2 = e - 6 * l1;
+            const bool dg = nb < 11;
+            const int A = dg ? nb : nb - 10, Bf = dg ? nb : nb - 11, r = 6 * A + l1, c = 6 * Bf + l2;
+            const int i0 = dg ? 900 * (A - 1) + 30 * (15 + l1) + 15 + l2 : 900 * Bf + 30 * (15 + l1) + l2, i1i = 900 * A + 30 * l1 + l2;
+            const int j0 = dg ? 144 * (A - 1) + 12 * (6 + l1) + 6 + l2 : 144 * Bf + 12 * (6 + l1) + l2, j1 = 144 * A + 12 * l1 + l2;
+            const bool h0 = !dg || A >= 1, h1 = dg && A <= 9;
+            t[6 * u] = SB_META(SB_OFF_P + sb_prow(r) + c, r, c, td + 192 * u < 756 && c <= r);
+            t[6 * u + 1] = 36 * (A * (A + 1) / 2 + Bf) + e;
+            t[6 * u + 2] = h0 ? i0 : -1; t[6 * u + 3] = h1 ? i1i : -1; t[6 * u + 4] = h0 ? j0 : -1; t[6 * u + 5] = h1 ? j1 : -1;
+        }
+        for (int u = 0; u < 9; u++) {           // the other 45 pose blocks: visual + prior
+            const int q = min(td + 192 * u, 1619), fb = q / 36, e = q - 36 * fb, l1 = e / 6, l2 = e - 6 * l1;
+            int A2 = 0; while ((A2 + 1) * (A2 + 2) / 2 <= fb) A2++;
+            const int Bf = fb - A2 * (A2 + 1) / 2, A = A2 + 2, r = 6 * A + l1, c = 6 * Bf + l2;
+            t[24 + 2 * u] = SB_META(SB_OFF_P + sb_prow(r) + c, r, c, td + 192 * u < 1620);
+            t[24 + 2 * u + 1] = 36 * (A * (A + 1) / 2 + Bf) + e;
+        }
+        for (int u = 0; u < 4; u++) {           // SpeedBias[0] rows of the dense block: IMU factor 0 (rows 6 + i) + prior
+            const int q = min(td + 192 * u, 674), i = q / 75, c = q - 75 * i, r = VB_NPOSE + i, Bf = c / 6, l2 = c - 6 * Bf;
+            const int src = (c < VB_NPOSE) ? 30 * (6 + i) + (Bf == 0 ? l2 : 15 + l2) : 30 * (6 + i) + 6 + (c - VB_NPOSE);
+            const bool hs = c >= VB_NPOSE || Bf <= 1;
+            t[44 + 2 * u] = SB_META(SB_OFF_P + sb_prow(r) + c, r, c, td + 192 * u < 675 && c <= r);
+            t[44 + 2 * u + 1] = hs ? src : -1;
+        }
+        for (int u = 0; u < 13; u++) {          // band_a[i][pos]: SpeedBias[a] x (Pose a-1 | Pose a | Pose a+1 | SpeedBias[0] for a = 1)
+            const int q = min(td + 192 * u, 2429), a1 = q / 243, rem = q - 243 * a1, i = rem / 27, pos = rem - 27 * i, a = a1 + 1;
+            const int seg = pos / 6, m = pos - 6 * seg;            // seg 0: Pose a-1, 1: Pose a, 2: Pose a+1, 3..4: SpeedBias[0]
+            const bool on = td + 192 * u < 2430 && (seg < 2 || (seg == 2 && a <= 9) || (seg >= 3 && a == 1));
+            int s0, s1 = -1, c165;
+            if (seg == 0) { s0 = 900 * a1 + 30 * (21 + i) + m; c165 = 6 * a1 + m; }
+            else if (seg == 1) { s0 = 900 * a1 + 30 * (21 + i) + 15 + m; s1 = (a <= 9) ? 900 * a + 30 * (6 + i) + m : -1; c165 = 6 * a + m; }
+            else if (seg == 2) { s0 = 900 * min(a, 9) + 30 * (6 + i) + 15 + m; c165 = 6 * (a + 1) + m; }
+            else { s0 = 30 * (21 + i) + 6 + (pos - 18); c165 = VB_NPOSE + (pos - 18); }
+            t[52 + 3 * u] = SB_META(SB_OFF_BAND + SB_BOFF(a) + i * SB_BSTR(a) + pos, VB_NPOSE + 9 * a + i, c165, on);
+            t[52 + 3 * u + 1] = on ? s0 : -1;
+            t[52 + 3 * u + 2] = s1;
+        }
+    }
+    for (int k = 0; k < SB_TAB_ROWS; k++) for (int j = 0; j < 4; j++) tab[((size_t)k * 256 + tid) * 4 + j] = t[4 * k + j];
+}
+
 template <bool FUSED>
 __device__ __forceinline__ void solve_sb_body(const VbBatch &b, int w, size_t ww_in, int tid_in = 0) {
     const int tid = FUSED ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1909,20 +1978,23 @@ __device__ __forceinline__ void solve_sb_body(const VbBatch &b, int w, size_t ww
             // would be one more dependent global round trip, ~3 us each here), all loads of the lane in flight at once
             {
                 double sv[25][2]; int meta[25];
+                int ti[64];
+                {
+                    const int4 *tp = reinterpret_cast<const int4 *>(b.sb_tab) + td;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) { const int4 v = tp[k * 256]; ti[4 * k] = v.x; ti[4 * k + 1] = v.y; ti[4 * k + 2] = v.z; ti[4 * k + 3] = v.w; }
+                }
 #pragma unroll
                 for (int u = 0; u < 13; u++) {          // D_a[i][j], j <= i: IMU factor a-1 rows 21.. (+ factor a rows 6..)
-                    const int q = min(ln + 64 * u, 809), a1 = q / 81, rem = q - 81 * a1, i = rem / 9, j = rem - 9 * i;
-                    const bool on = ln + 64 * u < 810 && j <= i;
-                    sv[u][0] = sb_bload(rImu, 900 * a1 + 30 * (21 + i) + 21 + j);
-                    sv[u][1] = sb_bload(rImu, a1 + 1 <= 9 ? 900 * (a1 + 1) + 30 * (6 + i) + 6 + j : -1);
-                    meta[u] = on ? ((SB_OFF_D + q) | ((VB_NPOSE + 9 + 9 * a1 + i) << 14) | ((VB_NPOSE + 9 + 9 * a1 + j) << 22)) : -1;
+                    sv[u][0] = sb_bload(rImu, ti[3 * u + 1]);
+                    sv[u][1] = sb_bload(rImu, ti[3 * u + 2]);
+                    meta[u] = ti[3 * u];
                 }
 #pragma unroll
                 for (int u = 0; u < 12; u++) {          // E_a[i][j] = H(SpeedBias[a+1], SpeedBias[a]): IMU factor a, rows 21.., columns 6..
-                    const int q = min(ln + 64 * u, 728), a1 = q / 81, rem = q - 81 * a1, i = rem / 9, j = rem - 9 * i;
-                    sv[13 + u][0] = sb_bload(rImu, 900 * (a1 + 1) + 30 * (21 + i) + 6 + j);
+                    sv[13 + u][0] = sb_bload(rImu, ti[39 + 2 * u + 1]);
                     sv[13 + u][1] = 0.0;
-                    meta[13 + u] = (ln + 64 * u < 729) ? ((SB_OFF_E + q) | ((VB_NPOSE + 18 + 9 * a1 + i) << 14) | ((VB_NPOSE + 9 + 9 * a1 + j) << 22)) : -1;
+                    meta[13 + u] = ti[39 + 2 * u];
                 }
 #pragma unroll
                 for (int u = 0; u < 25; u++) {
@@ -1966,37 +2038,38 @@ __device__ __forceinline__ void solve_sb_body(const VbBatch &b, int w, size_t ww
             }
             if (!ok && ln == 0) s_flag[2] = 0;
         } else {
-            // dense block and band: gather assembly by the 192 threads of waves 0..2. One thread per DESTINATION entry; the entry decodes its source indices itself
-            // (no table: a table read would be one more dependent global round trip, ~3 us each here) and every load of the thread is in flight at once.
+            // dense block and band: gather assembly by the 192 threads of waves 0..2. One thread per DESTINATION entry; which sources it adds up comes from the
+            // index table (k_sb_table: coalesced 16-byte loads, L2 hits; the part-B rows are requested before part A's sources so that they arrive under them),
+            // every load of the thread in flight at once.
+            // (requesting the rows before the set-up in front of the loop, to have them arrive under it, made the compiler hold all 92 registers across the
+            //  factorisation: 151 spills)
+            int tb[48];
             {
                 constexpr int KN = 4, KF = 9, KT = KN + KF;
                 double sn[KN][6], sf[KF][2];
                 int meta[KT];
+                int ti[44];
+                {
+                    const int4 *tp = reinterpret_cast<const int4 *>(b.sb_tab) + td;
+#pragma unroll
+                    for (int k = 0; k < 11; k++) { const int4 v = tp[k * 256]; ti[4 * k] = v.x; ti[4 * k + 1] = v.y; ti[4 * k + 2] = v.z; ti[4 * k + 3] = v.w; }
+#pragma unroll
+                    for (int k = 0; k < 12; k++) { const int4 v = tp[(11 + k) * 256]; tb[4 * k] = v.x; tb[4 * k + 1] = v.y; tb[4 * k + 2] = v.z; tb[4 * k + 3] = v.w; }
+                }
 #pragma unroll
                 for (int u = 0; u < KN; u++) {           // pose blocks on / next to the diagonal (21 blocks): visual + IMU (<= 2) + LiDAR (<= 2) + prior
-                    const int q = min(td + 192 * u, 755), nb = q / 36, e = q - 36 * nb, l1 = e / 6, l2 = e - 6 * l1;
-                    const bool dg = nb < 11;
-                    const int A = dg ? nb : nb - 10, Bf = dg ? nb : nb - 11, r = 6 * A + l1, c = 6 * Bf + l2;
-                    const int i0 = dg ? 900 * (A - 1) + 30 * (15 + l1) + 15 + l2 : 900 * Bf + 30 * (15 + l1) + l2, i1i = 900 * A + 30 * l1 + l2;
-                    const int j0 = dg ? 144 * (A - 1) + 12 * (6 + l1) + 6 + l2 : 144 * Bf + 12 * (6 + l1) + l2, j1 = 144 * A + 12 * l1 + l2;
-                    const bool h0 = !dg || A >= 1, h1 = dg && A <= 9;
-                    const int pr = s_pcp[r], pc = s_pcp[c];
-                    sn[u][0] = sb_bload(rHpp, 36 * (A * (A + 1) / 2 + Bf) + e);
-                    sn[u][1] = sb_bload(rImu, h0 ? i0 : -1); sn[u][2] = sb_bload(rImu, h1 ? i1i : -1); sn[u][3] = sb_bload(rLid, h0 ? j0 : -1); sn[u][4] = sb_bload(rLid, h1 ? j1 : -1);
+                    const int m = ti[6 * u], pr = s_pcp[(m >> 14) & 255], pc = s_pcp[(m >> 22) & 255];
+                    sn[u][0] = sb_bload(rHpp, ti[6 * u + 1]);
+                    sn[u][1] = sb_bload(rImu, ti[6 * u + 2]); sn[u][2] = sb_bload(rImu, ti[6 * u + 3]); sn[u][3] = sb_bload(rLid, ti[6 * u + 4]); sn[u][4] = sb_bload(rLid, ti[6 * u + 5]);
                     sn[u][5] = sb_bload(rPri, (pr >= 0 && pc >= 0) ? pr * VB_PRIOR_LD + pc : -1);
-                    meta[u] = (td + 192 * u < 756 && c <= r) ? ((SB_OFF_P + sb_prow(r) + c) | (r << 14) | (c << 22)) : -1;
+                    meta[u] = m;
                 }
 #pragma unroll
                 for (int u = 0; u < KF; u++) {           // the other 45 pose blocks: visual + prior
-                    const int q = min(td + 192 * u, 1619), fb = q / 36, e = q - 36 * fb, l1 = e / 6, l2 = e - 6 * l1;
-                    int A2 = (int)((sqrtf(8.0f * (float)fb + 1.0f) - 1.0f) * 0.5f);
-                    if (A2 * (A2 + 1) / 2 > fb) A2--;
-                    if ((A2 + 1) * (A2 + 2) / 2 <= fb) A2++;
-                    const int Bf = fb - A2 * (A2 + 1) / 2, A = A2 + 2, r = 6 * A + l1, c = 6 * Bf + l2;
-                    const int pr = s_pcp[r], pc = s_pcp[c];
-                    sf[u][0] = sb_bload(rHpp, 36 * (A * (A + 1) / 2 + Bf) + e);
+                    const int m = ti[24 + 2 * u], pr = s_pcp[(m >> 14) & 255], pc = s_pcp[(m >> 22) & 255];
+                    sf[u][0] = sb_bload(rHpp, ti[24 + 2 * u + 1]);
                     sf[u][1] = sb_bload(rPri, (pr >= 0 && pc >= 0) ? pr * VB_PRIOR_LD + pc : -1);
-                    meta[KN + u] = (td + 192 * u < 1620) ? ((SB_OFF_P + sb_prow(r) + c) | (r << 14) | (c << 22)) : -1;
+                    meta[KN + u] = m;
                 }
                 STAMP(1, 20);
 #pragma unroll
@@ -2018,27 +2091,16 @@ __device__ __forceinline__ void solve_sb_body(const VbBatch &b, int w, size_t ww
                 int meta[KT];
 #pragma unroll
                 for (int u = 0; u < KS; u++) {           // SpeedBias[0] rows of the dense block: IMU factor 0 (rows 6 + i) + prior
-                    const int q = min(td + 192 * u, 674), i = q / 75, c = q - 75 * i, r = VB_NPOSE + i, Bf = c / 6, l2 = c - 6 * Bf;
-                    const int src = (c < VB_NPOSE) ? 30 * (6 + i) + (Bf == 0 ? l2 : 15 + l2) : 30 * (6 + i) + 6 + (c - VB_NPOSE);
-                    const bool hs = c >= VB_NPOSE || Bf <= 1;
-                    const int pr = s_pcp[r], pc = s_pcp[min(c, VB_P - 1)];
-                    ss[u][0] = sb_bload(rImu, hs ? src : -1);
+                    const int m = tb[2 * u], pr = s_pcp[(m >> 14) & 255], pc = s_pcp[(m >> 22) & 255];
+                    ss[u][0] = sb_bload(rImu, tb[2 * u + 1]);
                     ss[u][1] = sb_bload(rPri, (pr >= 0 && pc >= 0) ? pr * VB_PRIOR_LD + pc : -1);
-                    meta[u] = (td + 192 * u < 675 && c <= r) ? ((SB_OFF_P + sb_prow(r) + c) | (r << 14) | (c << 22)) : -1;
+                    meta[u] = m;
                 }
 #pragma unroll
                 for (int u = 0; u < KB2; u++) {          // band_a[i][pos]: SpeedBias[a] x (Pose a-1 | Pose a | Pose a+1 | SpeedBias[0] for a = 1)
-                    const int q = min(td + 192 * u, 2429), a1 = q / 243, rem = q - 243 * a1, i = rem / 27, pos = rem - 27 * i, a = a1 + 1;
-                    const int seg = pos / 6, m = pos - 6 * seg;            // seg 0: Pose a-1, 1: Pose a, 2: Pose a+1, 3..4: SpeedBias[0]
-                    const bool on = td + 192 * u < 2430 && (seg < 2 || (seg == 2 && a <= 9) || (seg >= 3 && a == 1));
-                    int s0, s1 = -1, c165;
-                    if (seg == 0) { s0 = 900 * a1 + 30 * (21 + i) + m; c165 = 6 * a1 + m; }
-                    else if (seg == 1) { s0 = 900 * a1 + 30 * (21 + i) + 15 + m; s1 = (a <= 9) ? 900 * a + 30 * (6 + i) + m : -1; c165 = 6 * a + m; }
-                    else if (seg == 2) { s0 = 900 * min(a, 9) + 30 * (6 + i) + 15 + m; c165 = 6 * (a + 1) + m; }
-                    else { s0 = 30 * (21 + i) + 6 + (pos - 18); c165 = VB_NPOSE + (pos - 18); }
-                    sb3[u][0] = sb_bload(rImu, on ? s0 : -1);
-                    sb3[u][1] = sb_bload(rImu, s1);
-                    meta[KS + u] = on ? ((SB_OFF_BAND + SB_BOFF(a) + i * SB_BSTR(a) + pos) | ((VB_NPOSE + 9 * a + i) << 14) | (c165 << 22)) : -1;
+                    sb3[u][0] = sb_bload(rImu, tb[8 + 3 * u + 1]);
+                    sb3[u][1] = sb_bload(rImu, tb[8 + 3 * u + 2]);
+                    meta[KS + u] = tb[8 + 3 * u];
                 }
                 STAMP(1, 22);
 #pragma unroll

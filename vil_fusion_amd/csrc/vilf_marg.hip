@@ -342,10 +342,17 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
-            for (int k = 0; k < 12; k++) { Mb[(size_t)slot * MG_MROW + (k)] = sw * Ji[k]; Mb[(size_t)slot * MG_MROW + (12 + k)] = sw * Jj[k]; Mb[(size_t)slot * MG_MROW + (24 + k)] = sw * Jex[k]; }
-            Mb[(size_t)slot * MG_MROW + (36)] = sw * Jf[0]; Mb[(size_t)slot * MG_MROW + (37)] = sw * Jf[1];
-            Mb[(size_t)slot * MG_MROW + (38)] = sw * r[0]; Mb[(size_t)slot * MG_MROW + (39)] = sw * r[1];
-            Mb[(size_t)slot * MG_MROW + (40)] = sw * Jtd[0]; Mb[(size_t)slot * MG_MROW + (41)] = sw * Jtd[1];
+            // the 42-double row as 21 16-byte stores (a row starts at a multiple of 336 bytes): every lane writes to lines of its own, so the number of store
+            // instructions is what the memory pipeline sees — 42 eight-byte stores before
+            {
+                typedef double mg_double2 __attribute__((ext_vector_type(2)));
+                mg_double2 *row2 = reinterpret_cast<mg_double2 *>(Mb + (size_t)slot * MG_MROW);
+#pragma unroll
+                for (int k = 0; k < 12; k += 2) { row2[k >> 1] = mg_double2{sw * Ji[k], sw * Ji[k + 1]}; row2[6 + (k >> 1)] = mg_double2{sw * Jj[k], sw * Jj[k + 1]}; row2[12 + (k >> 1)] = mg_double2{sw * Jex[k], sw * Jex[k + 1]}; }
+                row2[18] = mg_double2{sw * Jf[0], sw * Jf[1]};
+                row2[19] = mg_double2{sw * r[0], sw * r[1]};
+                row2[20] = mg_double2{sw * Jtd[0], sw * Jtd[1]};
+            }
         }
     }
     __syncthreads();
