@@ -163,7 +163,11 @@ def stress_leg(local_rank, n_windows=8, steps=3):
                              "TFLOPs_issued": issued_schur * n_windows * nsol / syrk_s / 1e12, "frac_of_fp64_mfma_peak_issued": issued_schur * n_windows * nsol / syrk_s / 1e12 / 78.6,
                              "frac_of_fp64_mfma_peak_algorithmic": alg_schur * n_windows * nsol / syrk_s / 1e12 / 78.6},
             "cholesky_flop_per_window_iteration": P ** 3 / 3.0 + 2.0 * P * P,
-            "what": "configs[4]: vilf_window_solve_group of %d independent 51-frame windows (host buffers in / out, pack + upload inside), general path (vilf_lw.hip)" % n_windows}
+            "cholesky": {"launches": nsol, "ms_per_factorisation_of_all_windows": prof["lw_cholesky"]["ms"] / nsol,
+                         "TFLOPs": (P ** 3 / 3.0 + 2.0 * P * P) * n_windows * nsol / max(prof["lw_cholesky"]["ms"] * 1e-3, 1e-12) / 1e12,
+                         "frac_of_fp64_mfma_peak": (P ** 3 / 3.0 + 2.0 * P * P) * n_windows * nsol / max(prof["lw_cholesky"]["ms"] * 1e-3, 1e-12) / 1e12 / 78.6},
+            "distinct_windows": len(distinct),
+            "what": "configs[4]: vilf_window_solve_group of %d independent 51-frame windows (%d distinct synthetic windows, replicated: ~40 s of host ray casting each), host buffers in / out, pack + upload inside, general path (vilf_lw.hip)" % (n_windows, len(distinct))}
 
 
 def schur_flops(w, kb=32):
@@ -321,6 +325,18 @@ def stress_main(args):
             if best["value"] > out["value"]:          # the aggregate over independent windows on one GPU is the throughput figure; the single-window line stays beside it
                 out["value"] = best["value"]; out["ms_per_step"] = best["ms_per_solve_of_all_windows"]
                 out["config"]["parallelism"] = f"{world} GPU x {best['windows']} independent windows at once (" + ("vilf_window_solve_group: one chain of launches" if best["mode"] == "group" else "one handle / HIP stream / host thread each") + ")"
+                # the roofline of the line describes the configuration `value` is quoted on: the GROUP's flops over the group's launches (round 4 divided ONE window's
+                # flops by a 32-window launch and printed 0.0044 for what is 0.088); the single window's figures stay under roofline.single_window
+                if "cholesky" in best and "schur_reduce" in best:
+                    rf = out["roofline"]
+                    rf["single_window"] = {"kernel": rf["kernel"], "achieved": rf["achieved"], "frac": rf["frac"], "avg_launch_ms": rf["avg_launch_ms"], "groups": rf.pop("groups")}
+                    dm = best["kernels_ms_per_group_solve"]
+                    use_chol = dm["lw_cholesky"] >= dm["lw_schur_syrk"]
+                    a = best["cholesky"]["TFLOPs"] if use_chol else best["schur_reduce"]["TFLOPs_issued"]
+                    rf.update({"kernel": names["lw_cholesky" if use_chol else "lw_schur_syrk"] + f" — group of {best['windows']} windows", "achieved": a, "frac": a / 78.6,
+                               "flop_per_launch": ((P ** 3 / 3.0 + 2.0 * P * P) * best["windows"]) if use_chol else best["schur_reduce"]["issued_flop_per_launch"],
+                               "avg_launch_ms": (best["cholesky"]["ms_per_factorisation_of_all_windows"] if use_chol else best["schur_reduce"]["ms_per_launch"]),
+                               "windows_per_launch": best["windows"]})
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib
@@ -621,10 +637,10 @@ def main():
                    lm_iterations=float(np.mean([r.iterations[0] + r.iterations[1] for r in rs])),
                    map_points=float(np.mean([len(c[0]) + len(c[1]) for c in lidar_cases])), scan_points=float(np.mean([len(c[2][0]) + len(c[2][1]) for c in lidar_cases])),
                    map_edge_points=float(np.mean([len(c[0]) for c in lidar_cases])), map_surf_points=float(np.mean([len(c[1]) for c in lidar_cases])))
-        # scan clouds beyond the in-LDS voxel grid's capacity (22 000 points, SV_MAXPTS24 in vilf_s2m.hip) take the global-sort path (b_voxel_keys + a radix sort of
+        # scan clouds beyond the in-LDS voxel grid's capacity (22 112 points, SV_MAXPTS24 in vilf_s2m.hip) take the global-sort path (b_voxel_keys + a radix sort of
         # (key, index) + heads + reduce) in EVERY step: that is what the s2m_radix_sort group of the timed region is
         lid["scan_surf_points_max"] = int(max(len(c[2][1]) for c in lidar_cases)); lid["scan_edge_points_max"] = int(max(len(c[2][0]) for c in lidar_cases))
-        lid["oversized_scan_clouds"] = int(sum(1 for c in lidar_cases for k in (0, 1) if len(c[2][k]) > 22000)); lid["distinct_scenes"] = len(lidar_cases)
+        lid["oversized_scan_clouds"] = int(sum(1 for c in lidar_cases for k in (0, 1) if len(c[2][k]) > 22112)); lid["distinct_scenes"] = len(lidar_cases)
         lid.update(lidar_search_statistics(lidar_cases[:8], opts))
     # N > 1: what the gather delivered — the table of the last step must hold every rank's rows in global unit order; the rank count comes from the communicator itself
     gather_info = None
@@ -805,12 +821,14 @@ def main():
             # the runtime multiplexes its streams onto a few hardware queues, and two streams on one queue run one after the other (this process holds several
             # more handles by now): handles are added one at a time and kept only if the stream gets faster with them — up to three, from up to five candidates
             chosen, cands, best_per = [psolver], [], 1e-3 * (pcie["upload_ms"] + pcie["solve_ms"] + pcie["download_ms"]) / 2
+            tried_per = []                                                       # every configuration tried, kept or not (ms per batch): the figure below is a selection
             for _ in range(5):
                 hc = BackendSolver(device=local_rank)
                 hc.batch_upload(wins[half:nb] if len(chosen) % 2 else wins[:half], priors[half:nb] if len(chosen) % 2 else priors[:half])
                 hc.set_async_upload(True)
                 cands.append(hc)
                 per, _its = stream_of_batches(chosen + [hc], 3)
+                tried_per.append({"handles": len(chosen) + 1, "ms_per_batch": 1e3 * per, "kept": bool(per < 0.97 * best_per)})
                 if per < 0.97 * best_per:
                     chosen.append(hc); best_per = per
                 if len(chosen) == 3:
@@ -818,6 +836,7 @@ def main():
             if len(chosen) >= 2:
                 per, its_batch = stream_of_batches(chosen, 7)
                 pcie["stream_of_batches"] = {"value": its_batch / per, "unit": "iterations/s", "windows_per_batch": half, "handles": len(chosen), "batches": 6 * len(chosen), "ms_per_batch": 1e3 * per,
+                                       "selection": {"rule": "handles added one at a time, one kept only if the stream gets >= 3 % faster with it (two streams on one hardware queue run one after the other)", "tried": tried_per},
                                        "what": "the same path as a stream of 1024-window batches alternating over two or three handles with vilf_set_async_upload: the host packs one handle's batch while the others' copies and solves (sync = 0) are on the device; download of a handle's results before its next upload"}
             else:
                 pcie["stream_of_batches"] = {"error": "no second handle whose stream ran beside the first"}
@@ -871,6 +890,7 @@ def main():
             #  processes, and no such collision.)
             best = None
             tried_ = []
+            tried_ms = []
             for _try in range(2):
                 lh = BackendSolver(device=local_rank)
                 sb1 = Scan2MapBatch(lh, 1, len(scans_[0][0]) + len(scans_[1][0]) + 64, len(scans_[0][1]) + len(scans_[1][1]) + 64, len(me_) + len(scans_[0][0]) + 64, len(ms_) + len(scans_[0][1]) + 64)
@@ -889,11 +909,13 @@ def main():
                 both = 1e3 * (time.perf_counter() - t_) / nfr
                 if best is None or both < best[0]:
                     best = (both, alone)
+                tried_ms.append({"frame_overlapped_ms": both, "scan_to_map_alone_ms": alone})
                 tried_.append(lh)                                 # the first handle stays open while the second is tried (its stream keeps its queue)
             for lh in tried_:
                 lh.close()
             latency["scan_to_map_frame_median_ms"] = best[1]
             latency["frame_overlapped_ms"] = best[0]
+            latency["frame_overlapped_selection"] = {"rule": "the better of two LiDAR handles (the other one's stream shares a hardware queue with the estimator's)", "tried": tried_ms}
             latency["what"] += "; frame_overlapped_ms: 40 frames of window solve (resident prior) + marginalization on one handle / host thread while 40 scan-to-map steps of one stream run on another handle / thread — the reference's separate nodes; wall time per frame"
         ls.close()
 
@@ -949,6 +971,15 @@ def main():
                 "s2m_map_update": B * (nm * 32 + nq * 16),               # the two map updates: old map + registered scan in, new map out (+ 4 B per occupied cell: the directory)
                 "s2m_lm_solve": B * nq * 64.0 * 2 * 5,                   # factor records (one 64-byte sector each), 2 passes x 5 evaluations
                 "s2m_submap": B * nq * 16 * 2})                         # transform + append of the registered scan (crop and grid are in s2m_voxel_grid)
+        survey_knn = None
+        if lid is not None:
+            # SURVEY 8(d)'s own price of the association, beside the design's: N_q (12 + 27 c 16) per pass with c = 2 points per 1 m cell, 2 passes, + the map hash
+            # build N_map 16 2 (this design builds no hash: the map is its own index) — printed so that the s2m_associate fraction can be read against either
+            sb = B * (2 * nq * (12 + 27 * 2.0 * 16) + nm * 16 * 2)
+            t_as = prof["s2m_associate"]["ms"] / args.steps * 1e-3
+            survey_knn = {"formula": "2 passes x N_q (12 + 27 x 2 x 16) + N_map x 16 x 2 (SURVEY.md 8(d))", "bytes_per_step": sb,
+                          "achieved_GBps_on_survey_bytes": sb / max(t_as, 1e-12) / 1e9, "frac_of_hbm_peak_on_survey_bytes": sb / max(t_as, 1e-12) / 1e9 / 8000.0,
+                          "design_bytes_per_step": alg["s2m_associate"], "note": "the design's bytes (rows of cells actually walked, candidates actually read, counted on the host from the maps) are what the kernels_achieved_GBps entry is priced on"}
         workload_tag = ("lidar+" if lid is not None else "") + "solve" + ("" if args.no_marginalize else "+marginalize")
         dom = max(alg, key=lambda k: prof[k]["ms"])
         avg_ms = prof[dom]["ms"] / max(prof[dom]["launches"], 1)
@@ -1001,16 +1032,20 @@ def main():
         # oversized scans (none in this workload: the launches counted are set-up), k_prior_prep skips every window whose prior is unchanged, and the LM solve re-reads
         # its factor records from L2 (PMC: 3.96 GB per launch at the HBM interface against 5 x the record bytes priced)
         n_over = lid["oversized_scan_clouds"] if lid is not None else 0
-        not_priced = {"s2m_radix_sort": (f"inside the timed region: {n_over} of {2 * lid['distinct_scenes']} scan clouds of the distinct scenes exceed the in-LDS voxel grid (22 000 points) and take "
+        not_priced = {"s2m_radix_sort": (f"inside the timed region: {n_over} of {2 * lid['distinct_scenes']} scan clouds of the distinct scenes exceed the in-LDS voxel grid (22 112 points) and take "
                                          "the global-sort path every step (b_voxel_keys, the vendor radix sort, heads + reduce); priced per launch it is a set-up-sized group, not a stream of the map's bytes"
                                          if n_over else "no launch in the timed region (no scan cloud exceeds the in-LDS voxel grid)"), "k_prior_prep": "skips windows whose prior is unchanged: no fixed byte count per launch",
                       "s2m_lm_solve": "factor records are re-read from L2 across the 5 evaluations: algorithmic bytes are not HBM bytes here"}
         window_kernels = None
         try:                                   # registers / spills / LDS of the two window kernels, from the code objects of the shipped library (tools/kernel_resources.py at build time)
             kr = json.load(open(os.path.join(ROOT, "vil_fusion_amd", "csrc", "kernel_resources.json")))
-            dyn = {"k_linearize": 46.6e3, "k_solve_sb": 78.0e3}
+            import ctypes as _C
+            _l3 = (_C.c_int * 3)()
+            solver._L.vilf_debug_lds_bytes.argtypes = [_C.c_void_p, _C.POINTER(_C.c_int)]
+            solver._L.vilf_debug_lds_bytes(solver._h, _l3)
+            dyn = {"k_linearize": int(_l3[0]), "k_solve_sb": int(_l3[1]), "k_solve": None}          # the launch's dynamic LDS, from the library (k_linearize's LDS is all dynamic since round 5)
             window_kernels = {k: {"vgpr": kr[k]["vgpr"], "vgpr_spills": kr[k]["vgpr_spills"], "scratch_bytes_per_lane": kr[k]["scratch_bytes_per_lane"],
-                                  "static_lds_bytes": kr[k]["static_lds_bytes"], "waves_per_simd_by_registers": kr[k]["waves_per_simd_by_registers"]} for k in ("k_linearize", "k_solve_sb", "k_solve")}
+                                  "static_lds_bytes": kr[k]["static_lds_bytes"], "dynamic_lds_bytes": dyn.get(k), "waves_per_simd_by_registers": kr[k]["waves_per_simd_by_registers"]} for k in ("k_linearize", "k_solve_sb", "k_solve")}
         except Exception:
             window_kernels = None
         it_ms = sum(prof[k]["ms"] for k in ("k_linearize", "k_solve", "k_step")) / max(prof["k_solve"]["launches"], 1)
@@ -1037,7 +1072,7 @@ def main():
                          "kernels_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
                          "kernels_achieved_GBps": {k: alg[k] / (prof[k]["ms"] / args.steps) / 1e6 for k in alg
                                                    if prof[k]["launches"] > 0 and prof[k]["ms"] > 0 and k not in not_priced},
-                         "kernels_not_priced": not_priced,
+                         "kernels_not_priced": not_priced, "s2m_associate_on_survey_8d_bytes": survey_knn,
                          "binding": "fp64 issue + dependent latency, not HBM: one iteration is ~9 MFLOP per 388 KB (23 flop/B against a machine balance of 9.8), every dependent fp64 "
                                     "operation costs 36 cycles and the kernels run two waves per SIMD (DESIGN.md 3c); `bound: hbm` is SURVEY 8(d)'s convention for this row",
                          "window_kernels": window_kernels},

@@ -136,7 +136,9 @@ def test_free_running_trajectories_stay_within_the_oracles_own_divergence(oracle
                   f"{a.summaries[first]['final_cost']:.6f}; oracle {b.summaries[first]['num_iterations']}, termination {b.summaries[first]['termination']}, cost "
                   f"{b.summaries[first]['final_cost']:.6f}; |dP| there {dP[first]:.2e} m")
             assert first >= 20, (i, first)                # nothing but accumulated divergence moves a count
-        assert dP.max() <= max(10 * envelope, 1e-4) and dP.max() < 0.5, (i, dP.max(), envelope)
+        # measured (rounds 4 and 5): 1e-3 ... 2.7e-2 m per segment after ~500 m, the oracle's own 1e-13-perturbed twin 1e-3 ... 3e-2 m; the absolute cap is the largest
+        # measured value x 3 (it was 0.5 m)
+        assert dP.max() <= max(10 * envelope, 1e-4) and dP.max() < 0.1, f"segment {i}: max|dP| {dP.max():.3e} m after {len(a.trajectory)} frames; the oracle's own divergence under a 1e-13 m perturbation: {envelope:.3e} m (cap: 10 x that, and 0.1 m)"
         sequence.write_tum(str(tmp_path / f"vins_result_no_loop_{i}.txt"), a.trajectory)
         rows = np.loadtxt(str(tmp_path / f"vins_result_no_loop_{i}.txt"))
         assert rows.shape == (len(a.trajectory), 8)

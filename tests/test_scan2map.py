@@ -266,7 +266,7 @@ def test_map_update_crop_duplicates_and_large_tails(oracle, n_scan, leaf):
     (the fused update's global-memory variant). Maps must stay bit-identical to the oracle over 5 frames; the first frame also
     exercises the unsorted-map path. The scan sizes / leaf sizes also walk the scan voxel grid through its variants: 32-bit keys in LDS
     (3000 points; leaf 0.02 m: 30 key bits = 4 radix passes), the 24-bit layout (20500 points; leaf 0.02 m: top key byte recomputed from
-    the points), the global-sort path (24000 points) and a batch whose streams split between the two (22150, 22050 and 21950 points: the in-LDS grid holds 22000)."""
+    the points), the global-sort path (24000 points) and a batch whose streams split between the two (22150, 22050 and 21950 points: the in-LDS grid holds 22112)."""
     from vil_fusion_amd.estimator import BackendSolver, Scan2MapBatch
     o = oracle.default_options()
     o.s2m_crop_half = 6.0
@@ -448,3 +448,34 @@ def test_local_map_orders_uploads_and_stream_copies(oracle, opts):
     for which in (0, 1):
         assert np.array_equal(b.getMapCloud(2, which), ref.get_map(which)) and np.array_equal(b.getMapCloud(1, which), ref.get_map(which))
     s.close()
+
+
+@pytest.mark.gpu
+def test_lidar_sequences_soak_frame_by_frame(oracle):
+    """Promoted from tools/dev_soak_s2m_seq.py (round 4: 440 frames, 0 mismatches): LiDAR sequences of varied geometry (16 / 32 / 64 rings, 450 / 900 / 1800 azimuths,
+    4 .. 8 frames) through the HIP scan-to-map path and the oracle frame by frame, the local maps evolving through voxel grid, association, LM solve, append, crop and map
+    update: down-sampled counts, factor counts, LM iterations and map sizes identical in every frame, poses to 1e-9, map shapes equal at the end (a map row may differ in
+    a last bit where an optimised pose differs in its last bits)."""
+    from vil_fusion_amd.estimator import BackendSolver, Scan2Map
+    rng = np.random.default_rng(5)
+    o = oracle.default_options()
+    frames = 0
+    worst = 0.0
+    for case in range(10):
+        rings = int(rng.choice([16, 32, 64])); az = int(rng.choice([450, 900, 1800])); n = int(rng.integers(4, 9)); seed = int(rng.integers(1, 10000))
+        scans, _poses = synth.make_lidar_sequence(seed, n, rings=rings, azimuths=az)
+        ref = oracle.OracleS2M(o); ref.init(*scans[0])
+        s = BackendSolver(o)
+        try:
+            dev = Scan2Map(s); dev.localMapInited(*scans[0])
+            for k in range(1, n):
+                r = ref.step(*scans[k]); g = dev.optimation_processing(*scans[k]); frames += 1
+                assert (r.n_edge_ds, r.n_surf_ds, list(r.n_edge_factors), list(r.n_surf_factors), list(r.iterations), r.map_edge_size, r.map_surf_size) == \
+                       (g.n_edge_ds, g.n_surf_ds, list(g.n_edge_factors), list(g.n_surf_factors), list(g.iterations), g.map_edge_size, g.map_surf_size), (case, rings, az, k)
+                dp = float(np.abs(np.array(r.pose_qt[:]) - np.array(g.pose_qt[:])).max()); worst = max(worst, dp)
+                assert dp <= 1e-9, (case, rings, az, k, dp)
+            for which in (0, 1):
+                assert ref.get_map(which).shape == dev.getMapCloud(which).shape, (case, which)
+        finally:
+            s.close()
+    print(f"{frames} frames, worst |dpose| {worst:.2e}")

@@ -25,7 +25,7 @@ if os.environ.get("VILF_DEBUG_STAMPS"):
 if os.environ.get("VILF_DEBUG_STAMPS"):
     v = a[0]
     if v[10] and v[13]:
-        print("linearize [3->4] detail: IMU JtJ", int(v[10] - v[3]), "lidH/lidg", int(v[11] - v[10]), "prior cost", int(v[12] - v[11]), "prior gradient", int(v[13] - v[12]), "barrier", int(v[4] - v[13]))
+        print("linearize [3->4] detail: IMU JtJ", int(v[10] - v[3]), "lidH/lidg", int(v[11] - v[10]), "prior cost + gradient", int(v[13] - v[11]), "barrier", int(v[4] - v[13]))
 if os.environ.get("VILF_DEBUG_STAMPS") and not os.environ.get("VILF_SOLVE_DENSE"):
     v = a[1]
     names = ["prologue", "setup", "P1 gather(w0)", "P2 reduce||chain", "P2b acc store+sums", "P3 Y chain+syrk", "-", "P4+P5 dense chol (MFMA)", "P6 dense backsub", "P6 chain (wave0)", "P6 wait dots+x", "P7"]

@@ -720,6 +720,13 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     return VILF_OK;
 }
 
+// dynamic LDS the window kernels are launched with (bytes): [0] k_linearize / k_linearize_split / k_linearize_last, [1] k_solve_sb, [2] k_iter. Diagnostic (bench.py
+// quotes them beside the registers it reads from the code objects); not part of include/vilfusion.h.
+extern "C" int vilf_debug_lds_bytes(vilf_handle *h, int out3[3]) {
+    if (!h || !out3) return VILF_ERR_INVALID_ARGUMENT;
+    out3[0] = (int)h->lin_lds; out3[1] = (int)h->solve_sb_lds; out3[2] = (int)std::max(h->lin_lds, h->solve_sb_lds);
+    return VILF_OK;
+}
 extern "C" int vilf_debug_stamps(vilf_handle *h, long long *out96) {
     if (!h || !h->batch.dbg) return VILF_ERR_INVALID_ARGUMENT;
     HIPCHECK(h, vilf_copy_sync(h, out96, h->batch.dbg, 96 * 8, hipMemcpyDeviceToHost));

@@ -269,6 +269,60 @@ __device__ __forceinline__ double prior_grad_split(const VbBatch &b, int w, cons
     return g;
 }
 
+// The prior through J0 alone, every load coalesced: t = r0 + J0 dx with a WAVE per row (lanes = columns: two loads of consecutive addresses, a fixed-tree wave sum),
+// cost 0.5 |t|^2; the gradient as Ceres forms it, J0^T t, with a LANE per column and the rows dealt to three waves (a load = consecutive columns of one row). Against
+// the row-per-thread forms (prior_cost_split / prior_grad_split: every lane on a line of its own, J0 AND H0 = 90 KB per window and launch) this is a sixth of the
+// requests and half the bytes — under a full device the two products took 36 k of k_linearize's 250 k cycles, 7 k alone on the chip: they wait for the memory system,
+// and what loads it is the number of requests. n <= 85 (three partial sums of n columns in 256 doubles); wider priors: the split forms.
+// s_t: >= 85 doubles (t, kept for the gradient). Contains LDS-only barriers: all threads.
+template <bool GRAD>
+__device__ __forceinline__ void prior_products_j(const VbBatch &b, int w, const double *s_dx, const int *s_pcol, double *s_tmp, double *s_t, int tid, double &cost, double &gprior) {
+    cost = 0.0; gprior = 0.0;
+    const int *hdr = b.prior_hdr + (size_t)w * VB_PRIOR_HDR;
+    if (!hdr[0]) return;
+    const int n = hdr[1];
+    if (n > 85) {
+        cost = prior_cost_split(b, w, s_dx, s_tmp, tid);
+        if (GRAD) gprior = prior_grad_split(b, w, s_dx, s_pcol, s_tmp, tid);
+        return;
+    }
+    const double *J = b.prior_J + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *r0 = b.prior_r + (size_t)w * VB_PRIOR_LD;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = min(lane, n - 1), c1 = min(lane + 64, n - 1);
+    const double dx0 = s_dx[lane], dx1 = s_dx[lane + 64];               // zero from n on (prior_setup): a clamped column adds nothing
+    const double r0v = r0[min(wave + 4 * min(lane, 31), n - 1)];         // lane k holds r0 of this wave's k-th row
+    {
+        double a0[6], a1[6];
+#pragma unroll 1
+        for (int rb = wave; rb < n; rb += 24) {                          // six rows of the wave at a time: their twelve loads in flight
+#pragma unroll
+            for (int u = 0; u < 6; u++) { const double *Jr = J + (size_t)min(rb + 4 * u, n - 1) * n; a0[u] = Jr[c0]; a1[u] = Jr[c1]; }
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const int r = rb + 4 * u;
+                const double sum = vilf_wave_sum64(a0[u] * dx0 + a1[u] * dx1);
+                const double t = readlane_f64(r0v, (r - wave) >> 2) + sum;
+                if (r < n && lane == 0) { s_t[r] = t; cost += 0.5 * t * t; }
+            }
+        }
+    }
+    if (GRAD) {
+        lds_barrier();
+        const int pc = (tid < VB_P) ? s_pcol[tid] : -1;
+        if (wave < 3) {
+            const int per = (n + 2) / 3, ra = wave * per, rb = min(n, ra + per);
+            double g0 = 0, g1 = 0;
+#pragma unroll 8
+            for (int r = ra; r < rb; r++) { const double t = s_t[r]; const double *Jr = J + (size_t)r * n; g0 += Jr[c0] * t; g1 += Jr[c1] * t; }
+            s_tmp[85 * wave + c0] = g0;                                    // (clamped columns rewrite column n - 1 with its own value: lane n - 1 - 64 / the lanes >= n hold the same sum)
+            if (lane + 64 < n) s_tmp[85 * wave + lane + 64] = g1;
+        }
+        lds_barrier();
+        if (pc >= 0) { double g = s_tmp[pc]; g += s_tmp[85 + pc]; g += s_tmp[170 + pc]; gprior = g; }
+        lds_barrier();
+    }
+}
+
 // the window of this workgroup: blockIdx.x + w0, or through the dense list of the windows still running (-1: the list is shorter than the grid)
 __device__ __forceinline__ int vb_window(const VbBatch &b) {
     const int i = b.live_it;
@@ -620,11 +674,10 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
     // LiDAR / prior role, the gradient by the workgroup that arrives last)
     double gprior = 0;
     if (!SPLIT || do_lp) {
-        const double pcost = prior_cost_split(b, w, s_dx, s_red, tid);
+        double pcost;
+        prior_products_j<(JAC && !SPLIT)>(b, w, s_dx, s_pcol, s_red, s_grad, tid, pcost, gprior);
         if (SPLIT) scost[512 + tid] = pcost; else cost_local += pcost;
     }
-    LSTAMP(12);
-    if (JAC && !SPLIT) gprior = prior_grad_split(b, w, s_dx, s_pcol, s_red, tid);
     LSTAMP(13);
     lds_barrier();                                                       // the IMU staging area is dead: the region becomes s_X. (LDS-only barriers from here to the end of the
                                                                            // chunk loop: the imuH / lidH stores above drain under the visual factors instead of being waited for here)
@@ -838,7 +891,7 @@ __device__ __forceinline__ int linearize_body(const VbBatch &b, int iteration_ze
         for (int k = 0; k < NCH; k++) c += __builtin_nontemporal_load(scost + (3 + k) * 256 + tid);
         cost_local = c;
         __syncthreads();
-        if (JAC) gprior = prior_grad_split(b, w, s_dx, s_pcol, s_red, tid);
+        if (JAC) { double pc_unused; prior_products_j<true>(b, w, s_dx, s_pcol, s_red, s_grad, tid, pc_unused, gprior); }      // (t = r0 + J0 dx is formed again here: the gradient needs it)
     }
     double gmax = 0, xsq = 0;
     if (JAC) {

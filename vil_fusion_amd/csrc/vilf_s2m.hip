@@ -233,7 +233,8 @@ __global__ __launch_bounds__(S2B_VT) void b_crop_compact(CSet map, const double 
 // stable: every wave owns a contiguous segment and ranks a 64-lane strip by ballot matching), and each leaf is summed in index order.
 #define SV_T 1024
 #define SV_MAXPTS32 19200              // 32-bit keys: 8 bytes of LDS per point
-#define SV_MAXPTS24 22000              // 24 stored key bits: 7 bytes per point (a wider key's top byte is recomputed from the point when needed)
+#define SV_MAXPTS24 22112              // 24 stored key bits: 7 bytes per point (a wider key's top byte is recomputed from the point when needed): 7 x 22112 + 8192 + 736 B of static LDS = 163 712 of the CU's 163 840 bytes
+                                       // (22000 until round 5: the bench's largest surf cloud has 22015 points and took the global-sort path — the vendor radix sort — in every step)
 __device__ __forceinline__ int sv_bits(int v) { return v <= 1 ? 0 : 32 - __clz(v - 1); }     // bits for values 0 .. v-1
 // c += s_tq[b], s_tq[b + 1], ... (cnt points, in this order: the serial float chain pcl's accumulation defines). The next eight points are already on their way from
 // LDS while eight are added, so a leaf of a few hundred near-range points costs a few cycles per point instead of an LDS round trip.
