@@ -106,7 +106,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     __shared__ double s_pm[10 * MG_PAIRM];
     __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_pcl[VB_NPAIR];     // pair table: start inside the class list, factor count, class
     __shared__ double s_td;
-    __shared__ double s_rows[MG_GCH * MG_MROW];                  // factor rows of the pair products; afterwards the rank -> feature table of the arrow rows
+    __shared__ __attribute__((aligned(16))) double s_rows[MG_GCH * MG_MROW];                  // factor rows of the pair products; afterwards the rank -> feature table of the arrow rows
     __shared__ int s_slots[MG_SLOTS], s_pend[10];                 // Mbuf row of the t-th start-frame-0 factor (evaluation order = pair order); cumulative factor count per pair
     int *info = g.info + (size_t)w * MG_INFO;
     const int F = b.n_feat[w];
@@ -388,27 +388,32 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             MG_ACC(0);
             {   // all of the thread's loads of the chunk in flight at once (a plain loop waited for every load before issuing the next: sixteen memory round trips per chunk):
                 // first the row indices (LDS), then the loads, then the stores
-                constexpr int NLD = (MG_GCH * MG_MROW + NT - 1) / NT;
+                // (16 bytes per load: a row is 21 of them, rows start at multiples of 336 bytes — half the load and LDS-store instructions of the 8-byte form)
+                typedef double mg_double2 __attribute__((ext_vector_type(2)));
+                constexpr int RW2 = MG_MROW / 2, NLD = (MG_GCH * RW2 + NT - 1) / NT;
+                static_assert(MG_MROW % 2 == 0, "rows as 16-byte pieces");
                 int off[NLD];
-                double vals[NLD];
+                mg_double2 vals[NLD];
                 if (t0 + nr <= MG_SLOTS) {
 #pragma unroll
-                    for (int k = 0; k < NLD; k++) { const int idx = min(tid + NT * k, nr * MG_MROW - 1), r = idx / MG_MROW; off[k] = s_slots[t0 + r] * MG_MROW + (idx - MG_MROW * r); }
+                    for (int k = 0; k < NLD; k++) { const int idx = min(tid + NT * k, nr * RW2 - 1), r = idx / RW2; off[k] = s_slots[t0 + r] * RW2 + (idx - RW2 * r); }
                 } else {
 #pragma unroll 1
                     for (int k = 0; k < NLD; k++) {
-                        const int idx = min(tid + NT * k, nr * MG_MROW - 1), r = idx / MG_MROW;
+                        const int idx = min(tid + NT * k, nr * RW2 - 1), r = idx / RW2;
                         int rem = t0 + r, q = 0;
                         for (int kk = 0; kk < 10; kk++) { const int pj = pair_index_c(0, kk + 1), nseg = s_pcn[pj]; if (rem >= 0) { if (rem < nseg) { q = VB_SLOT(s_pcl[pj], s_pst[pj] + rem); rem = -1; } else rem -= nseg; } }
-                        const int o = ps_slot[q] * MG_MROW + (idx - MG_MROW * r);
+                        const int o = ps_slot[q] * RW2 + (idx - RW2 * r);
 #pragma unroll
                         for (int k2 = 0; k2 < NLD; k2++) if (k2 == k) off[k2] = o;
                     }
                 }
+                const mg_double2 *Mb2 = reinterpret_cast<const mg_double2 *>(Mb);
+                mg_double2 *s_rows2 = reinterpret_cast<mg_double2 *>(s_rows);
 #pragma unroll
-                for (int k = 0; k < NLD; k++) vals[k] = Mb[(size_t)off[k]];
+                for (int k = 0; k < NLD; k++) vals[k] = Mb2[(size_t)off[k]];
 #pragma unroll
-                for (int k = 0; k < NLD; k++) { const int idx = tid + NT * k; if (idx < nr * MG_MROW) s_rows[idx] = vals[k]; }
+                for (int k = 0; k < NLD; k++) { const int idx = tid + NT * k; if (idx < nr * RW2) s_rows2[idx] = vals[k]; }
             }
             MG_ACC(1);
             __syncthreads();
@@ -633,6 +638,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
     if (!exact) {
         double *s_S = s_dyn, *s_Y = s_S + MG_MD * MG_MD, *s_ih = s_Y + MG_MD * (MG_NK + 1), *s_red = s_ih + VILF_MAX_FEATURES_DEV;   // [md][md], [md][XL], [mf], [NT]
         __shared__ int s_ok;
+        __shared__ double s_linv[MG_MD + 3];                       // 1 / L_jj of the arrow Cholesky
         if (tid == 0) s_ok = (md > 0 && md <= MG_MD && mf <= VILF_MAX_FEATURES_DEV && md + n + 1 <= 16 * 7) ? 1 : 0;      // C = 7 x 7 tiles (the reference's prior: n <= 76)
         __syncthreads();
         for (int f = tid; f < mf; f += NT) { const double h = hfm[f]; if (!(h > 0.0)) s_ok = 0; s_ih[f] = 1.0 / h; }
@@ -682,9 +688,12 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                 }
             __syncthreads();
             for (int j = 0; j < md; j++) {                      // in-place lower Cholesky of S (md <= 21)
-                if (tid == 0) { const double d = s_S[j * md + j]; if (!(d > 0.0)) s_ok = 0; s_S[j * md + j] = sqrt(d > 0.0 ? d : 1.0); }
+                // 1 / L_jj by v_rsq_f64 + two Newton steps, kept for the triangular solves below: the IEEE square root here, the division per entry of the column and
+                // the 21 divisions in every chain of Z = L^-1 Y / the trace were ~12 dependent fp64 operations each (this arrow Cholesky is the library's own form;
+                // last-bit differences only)
+                if (tid == 0) { const double d = s_S[j * md + j]; if (!(d > 0.0)) s_ok = 0; const double dd = d > 0.0 ? d : 1.0, inv = rsqrt_nr(dd); s_S[j * md + j] = dd * inv; s_linv[j] = inv; }
                 __syncthreads();
-                if (tid > j && tid < md) s_S[tid * md + j] /= s_S[j * md + j];
+                if (tid > j && tid < md) s_S[tid * md + j] *= s_linv[j];
                 __syncthreads();
                 for (int e = tid; e < md * md; e += NT) { const int r = e / md, c = e - md * r; if (c > j && r >= c) s_S[e] -= s_S[r * md + j] * s_S[c * md + j]; }
                 __syncthreads();
@@ -694,7 +703,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
         if (s_ok) {
             // Z = L^-1 Y (one column per thread), trace(Amm^-1) = |L^-1|_F^2 + sum_f (1/h_f + |L^-1 w_f|^2 / h_f^2)
             for (int k = tid; k < XL; k += NT)
-                for (int i = 0; i < md; i++) { double v = s_Y[i * XL + k]; for (int t = 0; t < i; t++) v -= s_S[i * md + t] * s_Y[t * XL + k]; s_Y[i * XL + k] = v / s_S[i * md + i]; }
+                for (int i = 0; i < md; i++) { double v = s_Y[i * XL + k]; for (int t = 0; t < i; t++) v -= s_S[i * md + t] * s_Y[t * XL + k]; s_Y[i * XL + k] = v * s_linv[i]; }
             double tr = 0;
             for (int c = tid; c < md + mf; c += NT) {
                 double z[MG_MD];                                   // compile-time indices only (fully unrolled, guarded by md): the vector stays in registers
@@ -705,7 +714,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                         double v = (c < md) ? (i == c ? 1.0 : 0.0) : Wf[(size_t)(c - md) * MG_ND + i];
 #pragma unroll
                         for (int t = 0; t < i; t++) v -= s_S[i * md + t] * z[t];
-                        z[i] = v / s_S[i * md + i];
+                        z[i] = v / s_S[i * md + i];            // (a multiplication by the kept 1 / L_ii here took the kernel from 168 to 210 registers — three workgroups per CU to two)
                         sq += z[i] * z[i];
                     }
                 }
@@ -1113,9 +1122,12 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, 
     for (int j = 0; j < n; j++) {
         // phase 1: column j of L and row j of X. Every thread takes the pivot from LDS itself (no broadcast phase).
         const double d = V[j * N + j];
-        const double l = sqrt(d > 0.0 ? d : 1.0), linv = 1.0 / l;
+        // 1 / sqrt(d) by v_rsq_f64 + two Newton steps, the column scaled by a multiplication: an IEEE square root, a division for 1 / l and a division per entry were
+        // ~35 dependent fp64 operations at 36 cycles each at the head of every one of the n columns (this Cholesky form is this library's own — the reference's
+        // eigen-decomposition is the fallback — and the results differ in the last bit only)
+        const double dd = d > 0.0 ? d : 1.0, linv = rsqrt_nr(dd), l = dd * linv;
         if (tid < n) {
-            if (tid != j) V[tid * N + j] /= l;                   // tid > j: L[tid][j]; tid < j: X[j][tid] (stored transposed)
+            if (tid != j) V[tid * N + j] *= linv;                // tid > j: L[tid][j]; tid < j: X[j][tid] (stored transposed)
             else { s_dg[j] = l; if (!(d > 0.0)) s_ok = 0; }
         }
         __syncthreads();
