@@ -479,3 +479,32 @@ def test_lidar_sequences_soak_frame_by_frame(oracle):
         finally:
             s.close()
     print(f"{frames} frames, worst |dpose| {worst:.2e}")
+
+
+@pytest.mark.gpu
+def test_library_radix_sort_is_a_stable_sort():
+    """vilf_sort.hip (the library's own LSD radix sort of (key, value) pairs in global memory: tile histograms, one scan, stable scatter — it replaced the vendor sort on
+    the unordered-map / oversized-scan / feature-extraction paths) against numpy's stable argsort: 32- and 64-bit keys, bit counts that are not multiples of eight,
+    sizes around the tile (2048) and scan-chunk boundaries, many duplicates (stability: the values are the input positions), bits above `bits` ignored."""
+    from vil_fusion_amd.estimator import BackendSolver
+    solver = BackendSolver()
+    L = solver._L
+    L.vilf_debug_sort_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9)
+    for key64, bits in ((0, 7), (0, 19), (0, 32), (1, 33), (1, 45), (1, 64)):
+        for n in (1, 255, 2047, 2048, 2049, 40000, 300001):
+            dt = np.uint64 if key64 else np.uint32
+            hi = min(bits, 12) if n > 1000 else bits                       # few distinct digits in the long arrays: long runs of equal keys
+            keys = rng.integers(0, 2 ** min(hi, 62), size=n, dtype=np.uint64)
+            if bits > 12 and n > 1000:
+                keys |= rng.integers(0, 2 ** 6, size=n, dtype=np.uint64) << np.uint64(bits - 6)       # and the top digit in play
+            junk = rng.integers(0, 16, size=n, dtype=np.uint64) << np.uint64(bits) if bits < (64 if key64 else 32) - 4 else np.zeros(n, dtype=np.uint64)
+            full = (keys | junk).astype(dt)
+            vals = np.arange(n, dtype=np.int32)
+            ko = np.zeros(n, dtype=dt); vo = np.zeros(n, dtype=np.int32)
+            rc = L.vilf_debug_sort_pairs(solver._h, full.ctypes.data, vals.ctypes.data, n, bits, key64, ko.ctypes.data, vo.ctypes.data)
+            assert rc == 0
+            order = np.argsort(keys, kind="stable")
+            assert np.array_equal(vo, order.astype(np.int32)), (key64, bits, n)
+            assert np.array_equal(ko, full[order]), (key64, bits, n)
+    solver.close()

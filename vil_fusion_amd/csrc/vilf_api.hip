@@ -13,6 +13,7 @@
 #include <thread>
 #include <atomic>
 #include "vilf_internal.hpp"
+#include "vilf_sort.hpp"
 
 #define IMU_REC 288
 #define IMU_SQRT 62
@@ -720,6 +721,25 @@ extern "C" int vilf_batch_upload(vilf_handle *h, int B, const vilf_window_in *wi
     return VILF_OK;
 }
 
+// the library's radix sort (vilf_sort.hip) through host buffers — a test hook (tests/test_scan2map.py compares it with a stable host sort); not part of include/vilfusion.h.
+// keys: n values of 4 (key64 == 0) or 8 bytes; the low `bits` bits are sorted, equal keys keep their order.
+extern "C" int vilf_debug_sort_pairs(vilf_handle *h, const void *keys, const int *vals, size_t n, int bits, int key64, void *keys_out, int *vals_out) {
+    if (!h || !keys || !vals || !keys_out || !vals_out || n == 0) return VILF_ERR_INVALID_ARGUMENT;
+    const size_t kb = key64 ? 8 : 4, tb = vilf_sort_temp_bytes(n, kb);
+    void *dk = nullptr, *dk2 = nullptr, *dv = nullptr, *dv2 = nullptr, *dt = nullptr;
+    int rc = VILF_OK;
+    if (hipMalloc(&dk, n * kb) != hipSuccess || hipMalloc(&dk2, n * kb) != hipSuccess || hipMalloc(&dv, n * 4) != hipSuccess || hipMalloc(&dv2, n * 4) != hipSuccess || hipMalloc(&dt, tb) != hipSuccess) rc = VILF_ERR_DEVICE;
+    if (rc == VILF_OK && (hipMemcpyAsync(dk, keys, n * kb, hipMemcpyHostToDevice, h->stream) != hipSuccess || hipMemcpyAsync(dv, vals, n * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess)) rc = VILF_ERR_DEVICE;
+    if (rc == VILF_OK) {
+        const int r = key64 ? vilf_sort_pairs_u64(h->stream, dt, tb, (const unsigned long long *)dk, (unsigned long long *)dk2, (const int *)dv, (int *)dv2, n, bits)
+                            : vilf_sort_pairs_u32(h->stream, dt, tb, (const unsigned *)dk, (unsigned *)dk2, (const int *)dv, (int *)dv2, n, bits);
+        if (r != 0) rc = VILF_ERR_DEVICE;
+    }
+    if (rc == VILF_OK && (hipMemcpyAsync(keys_out, dk2, n * kb, hipMemcpyDeviceToHost, h->stream) != hipSuccess || hipMemcpyAsync(vals_out, dv2, n * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                          hipStreamSynchronize(h->stream) != hipSuccess)) rc = VILF_ERR_DEVICE;
+    hipFree(dk); hipFree(dk2); hipFree(dv); hipFree(dv2); hipFree(dt);
+    return rc;
+}
 // dynamic LDS the window kernels are launched with (bytes): [0] k_linearize / k_linearize_split / k_linearize_last, [1] k_solve_sb, [2] k_iter. Diagnostic (bench.py
 // quotes them beside the registers it reads from the code objects); not part of include/vilfusion.h.
 extern "C" int vilf_debug_lds_bytes(vilf_handle *h, int out3[3]) {

@@ -18,7 +18,7 @@
 #include <cstring>
 #include <string.h>
 #include <cmath>
-#include <rocprim/rocprim.hpp>
+#include "vilf_sort.hpp"
 #include "vilf_internal.hpp"
 
 #define FE_SEC 6
@@ -262,8 +262,7 @@ extern "C" int vilf_lidar_extract_features(vilf_handle *h, const float *xyzi, in
             !c->curv.ensure(sn * 8) || !c->rstart.ensure((n_scans + 2) * 4) || !c->etmp.ensure((size_t)nsec * 20 * 16) || !c->stmp.ensure((size_t)nsec * FE_MAXSEC * 16) ||
             !c->ecnt.ensure(nsec * 4) || !c->scnt.ensure(nsec * 4) || !c->eoff.ensure(nsec * 4) || !c->soff.ensure(nsec * 4) || !c->oute.ensure((size_t)nsec * 20 * 16) ||
             !c->outs.ensure(sn * 16) || !c->tot.ensure(64)) { h->err = "hipMalloc failed (feature extraction)"; return VILF_ERR_DEVICE; }
-        size_t need = 0;
-        rocprim::radix_sort_pairs(nullptr, need, c->keys.as<unsigned int>(), c->keys2.as<unsigned int>(), c->vals.as<int>(), c->vals2.as<int>(), sn, 0, 7, h->stream);
+        const size_t need = vilf_sort_temp_bytes(sn, 4);
         if (!c->temp.ensure(need + 256)) return VILF_ERR_DEVICE;
         c->temp_bytes = c->temp.cap;
         c->cap = n; c->scans = n_scans;
@@ -273,7 +272,7 @@ extern "C" int vilf_lidar_extract_features(vilf_handle *h, const float *xyzi, in
     HIPCHECK(h, hipMemsetAsync(c->tot.p, 0, 64, h->stream));
     hipLaunchKernelGGL(fe_ring, grd, blk, 0, h->stream, c->pts.as<float4>(), n, n_scans, min_range, max_range, c->keys.as<unsigned int>(), c->vals.as<int>());
     size_t tb = c->temp_bytes;
-    HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, c->keys.as<unsigned int>(), c->keys2.as<unsigned int>(), c->vals.as<int>(), c->vals2.as<int>(), sn, 0, 7, h->stream));
+    if (vilf_sort_pairs_u32(h->stream, c->temp.p, tb, c->keys.as<unsigned int>(), c->keys2.as<unsigned int>(), c->vals.as<int>(), c->vals2.as<int>(), sn, 7) != 0) { h->err = "feature extraction: radix sort failed"; return VILF_ERR_DEVICE; }
     hipLaunchKernelGGL(fe_ring_bounds, grd1, blk, 0, h->stream, c->keys2.as<unsigned int>(), n, n_scans, c->rstart.as<int>());
     hipLaunchKernelGGL(fe_gather_curv, grd, blk, 0, h->stream, c->pts.as<float4>(), c->vals2.as<int>(), c->rstart.as<int>(), n, n_scans, c->rpts.as<float4>());
     hipLaunchKernelGGL(fe_curv, grd, blk, 0, h->stream, c->rpts.as<float4>(), c->keys2.as<unsigned int>(), c->rstart.as<int>(), n, n_scans, c->curv.as<double>());

@@ -24,7 +24,7 @@
 #include <climits>
 #include <algorithm>
 #include <utility>
-#include <rocprim/rocprim.hpp>
+#include "vilf_sort.hpp"
 #include "vilf_internal.hpp"
 #include "vilf_device.hpp"
 
@@ -1963,9 +1963,7 @@ static int s2b_reserve(vilf_handle *h, S2B *c, int S, int capScanE, int capScanS
         if (!c->frec.ensure((size_t)S * capq * S2M_FREC * 8) || !c->fkind.ensure((size_t)S * capq * 4)) return VILF_ERR_DEVICE;
         if (n > c->work_n) {
             if (!c->keys.ensure(n * 8) || !c->keys2.ensure(n * 8) || !c->vals.ensure(n * 4) || !c->vals2.ensure(n * 4)) return VILF_ERR_DEVICE;
-            size_t need = 0;
-            rocprim::radix_sort_pairs(nullptr, need, c->keys.as<unsigned long long>(), c->keys2.as<unsigned long long>(), c->vals.as<int>(), c->vals2.as<int>(), n, 0, 64, h->stream);
-            need += 256;
+            const size_t need = vilf_sort_temp_bytes(n, 8) + 256;
             if (!c->temp.ensure(need)) return VILF_ERR_DEVICE;
             c->temp_bytes = c->temp.cap;
             c->work_n = n;
@@ -2002,12 +2000,12 @@ static int s2b_sort_keys(vilf_handle *h, S2B *c, CSet in, float leaf, int cs, in
         unsigned int *k1 = c->keys.as<unsigned int>(), *k2 = c->keys2.as<unsigned int>();
         hipLaunchKernelGGL(b_voxel_keys<unsigned int>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits, cs);
         PROF(0)
-        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
+        if (vilf_sort_pairs_u32(h->stream, c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, kbits) != 0) { h->err = "scan2map: radix sort failed"; return VILF_ERR_DEVICE; }
     } else {
         unsigned long long *k1 = c->keys.as<unsigned long long>(), *k2 = c->keys2.as<unsigned long long>();
         hipLaunchKernelGGL(b_voxel_keys<unsigned long long>, GRID2(in.cap, S), 0, h->stream, in, inv, c->mm.as<MinMax>(), k1, c->vals.as<int>(), c->err.as<int>(), vbits, cs);
         PROF(0)
-        HIPCHECK(h, rocprim::radix_sort_pairs(c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, 0, kbits, h->stream));
+        if (vilf_sort_pairs_u64(h->stream, c->temp.p, tb, k1, k2, c->vals.as<int>(), c->vals2.as<int>(), (size_t)S * in.cap, kbits) != 0) { h->err = "scan2map: radix sort failed"; return VILF_ERR_DEVICE; }
     }
     PROF(1)
     return VILF_OK;
