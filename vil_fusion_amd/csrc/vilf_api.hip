@@ -35,6 +35,7 @@ __global__ void k_marg_schur(VbBatch b, VbMarg g, int exact);
 __global__ void k_marg_finish(VbBatch b, VbMarg g, int n_lo, int n_hi, int only_flagged);
 __global__ void k_mf_tridiag(VbBatch b, VbMarg g, int n_lo, int n_hi);
 __global__ void k_mf_chol(VbBatch b, VbMarg g, int n_lo, int n_hi, int disable);
+__global__ void k_mf_chol_tiles(VbBatch b, VbMarg g, int disable);
 __global__ void k_linearize_split(VbBatch b, int iteration_zero);
 __global__ void k_iter(VbBatch b, int iteration_zero, unsigned *slot_bm, int *err);
 __global__ void k_sb_table(int *tab);
@@ -1261,9 +1262,14 @@ extern "C" int vilf_batch_marginalize(vilf_handle *h, int sync) {
     const size_t lds_small = (size_t)77 * 77 * sizeof(double);
     {
         const int no_chol = std::getenv("VILF_MARG_NO_CHOL") ? 1 : 0;         // test hook: the eigen-solver for every window
-        if (one_class) hipLaunchKernelGGL(k_mf_chol, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 0, 1 << 30, no_chol);
+        // n <= 75 (every prior the reference produces without td): the augmented factorisation on the matrix cores (k_mf_chol_tiles, 34 KB of LDS); wider kept blocks:
+        // the column-by-column kernel. VILF_MARG_CHOL_COLUMNS=1: the column kernel for every size (tests compare the two forms).
+        const bool tiles = !std::getenv("VILF_MARG_CHOL_COLUMNS");
+        const int lo = tiles ? SB_ND + 1 : 0;
+        if (tiles) hipLaunchKernelGGL(k_mf_chol_tiles, grid, block, (size_t)(SB_NR * (SB_NR + 1) / 2 + 2 * 4 * 160 + 16) * sizeof(double), h->stream, h->batch, g, no_chol);
+        if (one_class) hipLaunchKernelGGL(k_mf_chol, grid, block, h->marg_lds_finish, h->stream, h->batch, g, lo, 1 << 30, no_chol);
         else {
-            hipLaunchKernelGGL(k_mf_chol, grid, block, lds_small, h->stream, h->batch, g, 0, 78, no_chol);
+            hipLaunchKernelGGL(k_mf_chol, grid, block, lds_small, h->stream, h->batch, g, lo, 78, no_chol);
             hipLaunchKernelGGL(k_mf_chol, grid, block, h->marg_lds_finish, h->stream, h->batch, g, 78, 1 << 30, no_chol);
         }
     }

@@ -1106,6 +1106,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, 
     const int *info = g.info + (size_t)w * MG_INFO;
     int *qi = g.qlInfo + (size_t)w * 4;
     if (info[0] != 0) { if (tid == 0 && n_lo == 0) qi[3] = 0; return; }     // no new prior for this window: the flag must not keep an earlier call's value (k_prior_prep reads it)
+                                                                            // (n_lo > 0 in the first launch: k_mf_chol_tiles ran before and has cleared it)
     if (info[3] < n_lo || info[3] >= n_hi) return;
     if (disable) { if (tid == 0) qi[3] = 0; return; }          // test hook: every window through the eigen-solver
     extern __shared__ double s_dyn[];
@@ -1181,6 +1182,141 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, 
     double *Ho = g.prior_H_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *go = g.prior_g_out + (size_t)w * VB_PRIOR_LD;
     for (int e = tid; e < n * n; e += NT) { const int i = e / n, j = e - n * i; Ho[i * VB_PRIOR_LD + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]); }
     if (tid < n) go[tid] = s_br[tid];
+    mf_table(b, g, w, n, nb, info);
+    if (tid == 0) qi[3] = 1;
+}
+
+// ---- the kept block's Cholesky form for n <= 75, on the matrix cores (round 5) ---------------------------------------------------------------------------------------
+// k_mf_chol above is a column-by-column Cholesky that carries X = L^-1 along (for the guard trace(A^-1) = |L^-1|_F^2 and r0 = L^-1 b): two barriers and two passes over
+// the trailing matrix per column, 410 k cycles per window. This kernel factors the AUGMENTED matrix [A; b^T; I] the way k_solve_sb factors its dense block: the trailing
+// matrix lives in MFMA accumulator tiles (16 x 16, ten per wave), per 4-column panel the panel's columns go through LDS, a thread per ROW factors the 4 x 4 diagonal block
+// itself and solves its own row strip, and the rank-4 update is one MFMA per tile. The rows under A are right-hand sides: row 75 = b^T comes out as (L^-1 b)^T = r0, the
+// identity rows 80 + c as row c of L^-T — their squares are summed where the row threads produce them: |L^-1|_F^2 without ever storing L^-1. n < 75 is padded with an
+// identity block (pivots 1, no coupling). Same guard, same outputs as k_mf_chol (J0 = L^T, r0, H0 = A, g0 = b, block table); a window that fails the guard is left to the
+// eigen-solver launches exactly as before. ~34 KB of LDS: four workgroups per CU.
+#define MFT_ROWS 160                                      // 80 (A, b, padding) + 80 (identity rows, padding)
+#define MFT_NT10 10                                       // tiles per wave: 40 = 15 (rows 0..79, lower) + 25 (rows 80..159, all five column tiles)
+#define MFT_LDS_DOUBLES (SB_NR * (SB_NR + 1) / 2 + 2 * 4 * MFT_ROWS + 16)
+extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, VbMarg g, int disable) {
+    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int *info = g.info + (size_t)w * MG_INFO;
+    int *qi = g.qlInfo + (size_t)w * 4;
+    if (info[0] != 0) { if (tid == 0) qi[3] = 0; return; }       // no new prior for this window: the flag must not keep an earlier call's value (k_prior_prep reads it)
+    if (info[3] > SB_ND) return;                                  // wider kept blocks: k_mf_chol
+    if (disable) { if (tid == 0) qi[3] = 0; return; }             // test hook: every window through the eigen-solver
+    extern __shared__ double s_dyn[];
+    double *s_P = s_dyn, *s_pan = s_P + SB_NR * (SB_NR + 1) / 2, *s_lp = s_pan + 4 * MFT_ROWS;      // packed lower rows 0..75; the panel's columns [row][4]; the panel's factor rows [row][4]
+    __shared__ double s_red[NT / 64];
+    __shared__ int s_ok;
+    const int n = info[3], nb = info[5];
+    const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
+    auto prow = [](int r) { return r * (r + 1) / 2; };
+    // the packed lower triangle: A symmetrised (as k_mf_chol), identity padding for rows n..74, row 75 = b
+    for (int e = tid; e < SB_NR * (SB_NR + 1) / 2; e += NT) {
+        int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        if (prow(r) > e) r--;
+        if (prow(r + 1) <= e) r++;
+        const int c = e - prow(r);
+        double v;
+        if (r < n) v = 0.5 * (Ar[r * MG_NK + c] + Ar[c * MG_NK + r]);
+        else if (r < SB_ND) v = (c == r) ? 1.0 : 0.0;
+        else v = (c < n) ? br[c] : 0.0;                           // (75, 75) = 0: the right-hand side row's own diagonal is not a pivot
+        s_P[e] = v;
+    }
+    if (tid == 0) s_ok = 1;
+    for (int e = tid; e < 4 * MFT_ROWS; e += NT) { s_pan[e] = 0.0; s_lp[e] = 0.0; }
+    __syncthreads();
+    // this wave's ten tiles: tile k = wave + 4 i of the list (R, C), R = 0..9, C = 0..min(R, 4)
+    int tR[MFT_NT10], tC[MFT_NT10];
+#pragma unroll
+    for (int i = 0; i < MFT_NT10; i++) {
+        const int k = wave + 4 * i;
+        int R, C;
+        if (k < 15) { R = 0; while ((R + 1) * (R + 2) / 2 <= k) R++; C = k - R * (R + 1) / 2; }
+        else { R = 5 + (k - 15) / 5; C = (k - 15) % 5; }
+        tR[i] = R; tC[i] = C;
+    }
+    const int c16 = lane & 15, g4 = lane >> 4;
+    typedef double mft_double4 __attribute__((ext_vector_type(4)));
+    mft_double4 T[MFT_NT10];
+#pragma unroll
+    for (int i = 0; i < MFT_NT10; i++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = 16 * tR[i] + g4 + 4 * q, c = 16 * tC[i] + c16;
+            double v = 0.0;
+            if (r < SB_NR) { if (c <= r) v = s_P[prow(r) + c]; }                    // A, padding, b
+            else if (r >= 80 && r - 80 == c && c < SB_ND) v = 1.0;                  // the identity rows
+            T[i][q] = v;
+        }
+    __syncthreads();
+    double sq = 0.0;                                                               // this thread's row of L^-T, squared (rows 80 ..)
+#pragma unroll 1
+    for (int bj = 0; bj < 19; bj++) {
+        const int j0 = 4 * bj, tc = bj >> 2, sp = bj & 3;
+        // 1. the panel's four columns, rows >= j0, to LDS
+        if ((c16 >> 2) == sp) {
+#pragma unroll
+            for (int i = 0; i < MFT_NT10; i++)
+                if (tC[i] == tc) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const int r = 16 * tR[i] + g4 + 4 * q; if (r >= j0) s_pan[4 * r + (c16 & 3)] = T[i][q]; }
+                }
+        }
+        __syncthreads();
+        // 2. one thread per row: Cholesky of the diagonal block, the row's strip of the factor (k_solve_sb's step, rows 76 .. 159 are right-hand sides / padding)
+        if (tid >= j0 && tid < MFT_ROWS) {
+            const double *dg = s_pan + 4 * j0, *rp = s_pan + 4 * tid;
+            const double d00 = dg[0], d10 = dg[4], d11 = dg[5], d20 = dg[8], d21 = dg[9], d22 = dg[10], d30 = dg[12], d31 = dg[13], d32 = dg[14], d33 = dg[15];
+            const double r0v = rp[0], r1v = rp[1], r2v = rp[2], r3v = rp[3];
+            const double i0 = rsqrt_h3(d00), l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+            const double t11 = d11 - l10 * l10, i1 = rsqrt_h3(t11), l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+            const double t22 = d22 - l20 * l20 - l21 * l21, i2 = rsqrt_h3(t22), l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+            const double t33 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+            const bool last = j0 + 3 >= SB_ND;                   // panel 18: column 75 is the right-hand side row's own diagonal — not a pivot
+            const double i3 = last ? 0.0 : rsqrt_h3(t33);
+            const double x0 = r0v * i0, x1 = (r1v - x0 * l10) * i1, x2 = (r2v - x0 * l20 - x1 * l21) * i2, x3 = (r3v - x0 * l30 - x1 * l31 - x2 * l32) * i3;
+            const int k = tid - j0;                               // rows of the diagonal block keep their lower part only
+            if (tid < SB_NR) {
+                double *Lr = s_P + prow(tid) + j0;
+                Lr[0] = x0;
+                if (k >= 1) Lr[1] = x1;
+                if (k >= 2) Lr[2] = x2;
+                if (k >= 3 && j0 + 3 < SB_ND) Lr[3] = x3;
+            }
+            double *lp = s_lp + 4 * tid;
+            lp[0] = x0; lp[1] = (k >= 1) ? x1 : 0.0; lp[2] = (k >= 2) ? x2 : 0.0; lp[3] = (k >= 3) ? x3 : 0.0;
+            if (tid >= 80) sq += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;                       // (x3 = 0 in the last panel)
+            if (k == 0 && (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || (!last && !(t33 > 0.0)))) s_ok = 0;
+        }
+        __syncthreads();
+        // 3. rank-4 update of the tiles that reach beyond the panel: one MFMA each
+#pragma unroll
+        for (int i = 0; i < MFT_NT10; i++)
+            if (16 * tC[i] + 15 >= j0 + 4) {
+                const double av = -s_lp[4 * (16 * tR[i] + c16) + g4], bv = s_lp[4 * min(16 * tC[i] + c16, 79) + g4];
+                T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T[i], 0, 0, 0);
+            }
+    }
+    __syncthreads();
+    if (!s_ok) { if (tid == 0) qi[3] = 0; return; }
+    // trace(A^-1) = |L^-1|_F^2 (the padding's identity rows contribute 75 - n ones: taken off)
+    sq = mg_wave_sum(sq);
+    if (lane == 0) s_red[wave] = sq;
+    __syncthreads();
+    double trc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NT / 64; k++) trc += s_red[k];
+    trc -= (double)(SB_ND - n);
+    if (!(trc < 1e8)) { if (tid == 0) qi[3] = 0; return; }
+    // the new prior: linearized_jacobians = L^T (leading dimension n), linearized_residuals = L^-1 b = row 75 of the factor
+    double *Jo = g.prior_J_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *ro = g.prior_r_out + (size_t)w * VB_PRIOR_LD;
+    for (int e = tid; e < n * n; e += NT) { const int i = e / n, k = e - n * i; Jo[e] = k >= i ? s_P[prow(k) + i] : 0.0; }
+    if (tid < n) ro[tid] = s_P[prow(SB_ND) + tid];
+    // H0 = J0^T J0 = L L^T = A and g0 = J0^T r0 = b: written from the kept block itself, k_prior_prep skips this window
+    double *Ho = g.prior_H_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *go = g.prior_g_out + (size_t)w * VB_PRIOR_LD;
+    for (int e = tid; e < n * n; e += NT) { const int i = e / n, j = e - n * i; Ho[i * VB_PRIOR_LD + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]); }
+    if (tid < n) go[tid] = br[tid];
     mf_table(b, g, w, n, nb, info);
     if (tid == 0) qi[3] = 1;
 }
