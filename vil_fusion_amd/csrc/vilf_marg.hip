@@ -106,6 +106,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     __shared__ double s_pm[10 * MG_PAIRM];
     __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_pcl[VB_NPAIR];     // pair table: start inside the class list, factor count, class
     __shared__ double s_td;
+    __shared__ double s_zero;                                    // a zero in LDS: what a masked lane of the pair products reads
     __shared__ __attribute__((aligned(16))) double s_rows[MG_GCH * MG_MROW];                  // factor rows of the pair products; afterwards the rank -> feature table of the arrow rows
     __shared__ int s_slots[MG_SLOTS], s_pend[10];                 // Mbuf row of the t-th start-frame-0 factor (evaluation order = pair order); cumulative factor count per pair
     int *info = g.info + (size_t)w * MG_INFO;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
 
     // ---- start-frame-0 features: rank (order of appearance) and longest track, all threads ----------------------------------
     __shared__ int s_fw[NT / 64], s_mf, s_maxobs;
-    if (tid == 0) { s_mf = 0; s_maxobs = 0; }
+    if (tid == 0) { s_mf = 0; s_maxobs = 0; s_zero = 0.0; }
     __syncthreads();
     MG_STAMP(0, 2);
     if (mode == 0) {
@@ -371,16 +372,25 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         // (1,0), (1,1), one per wave; a k-step is four X rows = two factors read from the staged chunk. (A thread per entry summing over the rows spent 250 k cycles per
         // window in LDS reads.) The accumulators live across chunks and are flushed where a pair ends.
         const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15, l4 = lane >> 4;
-        const int ti = wave == 0 ? 0 : 1, tj = wave == 2 ? 1 : 0, sub = l4 & 1;
+        // The ten pairs are dealt to the four waves (pair jj -> wave jj & 3: the counts fall with j, so the deal is even enough), and a wave forms ALL THREE tiles of its
+        // pairs: the operands of column tile 0 and 1 are read once per k-step and feed three MFMAs ((0,0) = a0 a0, (1,0) = a1 a0, (1,1) = a1 a1), three independent
+        // accumulators keep the matrix core busy, the fourth wave works too, and nothing crosses waves. (Until round 5: a wave per tile over all pairs — two LDS reads per
+        // MFMA, one dependent accumulator chain per wave, one wave idle: 84 k cycles of a 450 k-cycle launch.) A tile entry is the same sum over the pair's rows in order.
+        const int sub = l4 & 1;
         auto comp_of = [&](int c) -> int { return c < 18 ? 12 * (c / 6) + (c % 6) + 6 * sub : (c == 18 ? 40 + sub : (c == 19 ? 38 + sub : -1)); };      // X column -> Mbuf row component
-        const int compA = comp_of(16 * ti + l16), compB = comp_of(16 * tj + l16);
-        mgp_double4 T = {0.0, 0.0, 0.0, 0.0};
-        int jj = 0;
+        const int comp0 = comp_of(l16), comp1 = comp_of(16 + l16);
+        mgp_double4 T00 = {0.0, 0.0, 0.0, 0.0}, T10 = {0.0, 0.0, 0.0, 0.0}, T11 = {0.0, 0.0, 0.0, 0.0};
+        int jj = wave;                                           // this wave's current pair (0, jj + 1)
         auto flush = [&]() {
 #pragma unroll
-            for (int q = 0; q < 4; q++) { const int uu = 16 * ti + l4 + 4 * q, vv = 16 * tj + l16; if (uu < 20 && vv <= uu) s_pm[jj * MG_PAIRM + 20 * vv + uu] = T[q]; }
-            T = mgp_double4{0.0, 0.0, 0.0, 0.0};
-            jj++;
+            for (int q = 0; q < 4; q++) {
+                const int u0 = l4 + 4 * q, u1 = 16 + l4 + 4 * q, v0 = l16, v1 = 16 + l16;
+                if (v0 <= u0) s_pm[jj * MG_PAIRM + 20 * v0 + u0] = T00[q];
+                if (u1 < 20) s_pm[jj * MG_PAIRM + 20 * v0 + u1] = T10[q];
+                if (u1 < 20 && v1 <= u1) s_pm[jj * MG_PAIRM + 20 * v1 + u1] = T11[q];
+            }
+            T00 = mgp_double4{0.0, 0.0, 0.0, 0.0}; T10 = T00; T11 = T00;
+            jj += 4;
         };
         MG_ACC_DECL
         for (int t0 = 0; t0 < ntot; t0 += MG_GCH) {
@@ -418,31 +428,33 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             MG_ACC(1);
             __syncthreads();
             MG_ACC(2);
-            if (wave < 3) {
-                int r = 0;
-                while (r < nr) {
-                    while (jj < 10 && t0 + r >= s_pend[jj]) flush();                   // pairs that ended (or are empty) before this row
-                    const int rend = min(nr, s_pend[jj] - t0);                        // this pair's rows inside the chunk: [r, rend)
-                    for (int fr0 = r; fr0 < rend; fr0 += 8) {                        // four k-steps (eight factors) per trip: their eight LDS reads first, then the MFMAs
-                        double av[4], bv[4];
+            while (jj < 10) {                                    // this wave's pairs that have rows in the chunk (or end empty in front of it)
+                const int ps = jj ? s_pend[jj - 1] : 0, pe = s_pend[jj];
+                if (pe > ps && ps >= t0 + nr) break;                                  // begins in a later chunk
+                const int lo = max(ps, t0) - t0, hi = min(pe, t0 + nr) - t0;         // the pair's rows inside the chunk: [lo, hi)
+                for (int fr0 = lo; fr0 < hi; fr0 += 8) {                             // four k-steps (eight factors) per trip: their eight LDS reads first, then the twelve MFMAs
+                    double a0[4], a1[4];
 #pragma unroll
-                        for (int k4 = 0; k4 < 4; k4++) {
-                            const int fr = fr0 + 2 * k4 + (l4 >> 1), frc = min(fr, rend - 1);
-                            const double a_ = s_rows[frc * MG_MROW + max(compA, 0)], b_ = s_rows[frc * MG_MROW + max(compB, 0)];
-                            av[k4] = (fr < rend && compA >= 0) ? a_ : 0.0; bv[k4] = (fr < rend && compB >= 0) ? b_ : 0.0;
-                        }
-#pragma unroll
-                        for (int k4 = 0; k4 < 4; k4++) T = __builtin_amdgcn_mfma_f64_16x16x4f64(av[k4], bv[k4], T, 0, 0, 0);
+                    for (int k4 = 0; k4 < 4; k4++) {                                  // (rows past the pair's end and the columns 20 .. 31 read a zero: the select sits on the address)
+                        const int fr = fr0 + 2 * k4 + (l4 >> 1);
+                        a0[k4] = *((fr < hi) ? s_rows + fr * MG_MROW + comp0 : &s_zero);
+                        a1[k4] = *((fr < hi && comp1 >= 0) ? s_rows + fr * MG_MROW + comp1 : &s_zero);
                     }
-                    r = rend;
+#pragma unroll
+                    for (int k4 = 0; k4 < 4; k4++) {
+                        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[k4], a0[k4], T00, 0, 0, 0);
+                        T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k4], a0[k4], T10, 0, 0, 0);
+                        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[k4], a1[k4], T11, 0, 0, 0);
+                    }
                 }
+                if (pe <= t0 + nr) flush(); else break;                               // the pair ends in this chunk / runs on into the next one
             }
             MG_ACC(3);
             __syncthreads();
             MG_ACC(4);
         }
         MG_ACC_OUT(0);
-        if (wave < 3) while (jj < 10) flush();
+        while (jj < 10) flush();
     }
     __syncthreads();
     MG_STAMP(0, 15);
