@@ -1639,7 +1639,6 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
     const int n_edge_q = n_ds_edge[sid], n_surf_q = n_ds_surf[sid];
     S2BRes *out = res + sid;
     __shared__ double s_red[S2M_NW * 28], s_ev[28], s_cand[28], s_x[7], s_c[7], s_scale[6], s_diag[6], s_step[6];
-    __shared__ double Hs[36], L[36], gs[6], y[6];          // thread 0's 6 x 6 workspace lives in LDS: it must not set the kernel's register count
     __shared__ int s_ctl[4];
     const int tid = threadIdx.x, nfac = n_edge_q + n_surf_q;
     if (tid < 7) s_x[tid] = pose_in[tid];
@@ -1671,18 +1670,24 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
     const int ev_ne = use_list ? tne : min(n_edge_q, nfac), ev_n = use_list ? tne + tns : nfac;
     __syncthreads();
     s2m_evaluate<true>(s_x, frec, list, ev_ne, ev_n, huber_a, s_red, s_ev);
-    // thread-0 scalars of the trust-region loop (trust_region_minimizer.cc + levenberg_marquardt_strategy.cc)
+    // wave-0 scalars of the trust-region loop (trust_region_minimizer.cc + levenberg_marquardt_strategy.cc)
     double x_cost = s_ev[27], radius = 1e4, decrease_factor = 2.0, x_norm = 0, mcc = 0;
     bool reuse_diagonal = false;
     int iteration = 0, invalid = 0;
     if (tid == 0) {
         for (int c = 0; c < 6; c++) { const int dd = c * (c + 1) / 2 + c; s_scale[c] = 1.0 / (1.0 + sqrt(s_ev[dd])); }
-        for (int k = 0; k < 7; k++) x_norm += s_x[k] * s_x[k];
-        x_norm = sqrt(x_norm);
     }
+    for (int k = 0; k < 7; k++) x_norm += s_x[k] * s_x[k];
+    x_norm = sqrt(x_norm);
     __syncthreads();
     for (;;) {
-        if (tid == 0) {
+        // The trust-region step of an iteration, by WAVE 0 (every lane runs the scalar part with the same values; LDS is written by one lane). The 6 x 6 part —
+        // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system: Cholesky, two triangular solves, the model cost change — has a lane per ROW in registers
+        // and passes pivots / solved entries between lanes by v_readlane. Until round 5 thread 0 did it alone on 6 x 6 arrays in LDS (so that they would not set the
+        // kernel's register count): some 400 dependent LDS round trips and 35 IEEE divisions / square roots per iteration, ~45 k cycles of a ~70 k-cycle iteration — the
+        // larger part of b_solve. Every entry sees the same operations in the same order as before (left- and right-looking Cholesky subtract the same products in
+        // the same k order): results to the bit.
+        if (wave_ == 0) {
             int go = 1;
             if (iteration >= max_it) go = 0;
             else {
@@ -1696,42 +1701,83 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
             int valid = 0;
             if (go) {
                 iteration++;
-                // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system
-                for (int a = 0; a < 6; a++) { gs[a] = s_ev[21 + a] * s_scale[a]; for (int b2 = 0; b2 <= a; b2++) { const double v = s_ev[a * (a + 1) / 2 + b2] * s_scale[a] * s_scale[b2]; Hs[6 * a + b2] = v; Hs[6 * b2 + a] = v; } }
-                if (!reuse_diagonal) for (int c = 0; c < 6; c++) s_diag[c] = fmin(fmax(Hs[7 * c], 1e-6), 1e32);
-                for (int k = 0; k < 36; k++) L[k] = Hs[k];
-                for (int c = 0; c < 6; c++) L[7 * c] += s_diag[c] / radius;
+                const int r = min(lane_, 5);                       // lane r < 6 = row r (lanes 6 .. 63 shadow row 5)
+                double hs[6], v[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) { const int a = r > c ? r : c, b2 = r > c ? c : r; hs[c] = s_ev[a * (a + 1) / 2 + b2] * s_scale[a] * s_scale[b2]; }
+                const double gs_r = s_ev[21 + r] * s_scale[r];
+                double dr = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) if (c == r) dr = hs[c];
+                dr = reuse_diagonal ? s_diag[r] : fmin(fmax(dr, 1e-6), 1e32);
+                if (!reuse_diagonal && lane_ < 6) s_diag[r] = dr;
+#pragma unroll
+                for (int c = 0; c < 6; c++) v[c] = hs[c];
+                {
+                    const double addv = dr / radius;
+#pragma unroll
+                    for (int c = 0; c < 6; c++) if (c == r) v[c] += addv;
+                }
                 bool ok = true;
-                for (int j = 0; j < 6 && ok; j++) {
-                    double sd = L[7 * j];
-                    for (int k = 0; k < j; k++) sd -= L[6 * j + k] * L[6 * j + k];
-                    if (!(sd > 0)) { ok = false; break; }
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    if (!ok) continue;
+                    const double sd = readlane_f64(v[j], j);
+                    if (!(sd > 0)) { ok = false; continue; }
                     const double l = sqrt(sd);
-                    L[7 * j] = l;
-                    for (int i = j + 1; i < 6; i++) { double t = L[6 * i + j]; for (int k = 0; k < j; k++) t -= L[6 * i + k] * L[6 * j + k]; L[6 * i + j] = t / l; }
+                    const double lij = (r == j) ? l : v[j] / l;
+                    v[j] = lij;
+#pragma unroll
+                    for (int c = j + 1; c < 6; c++) { const double lcj = readlane_f64(lij, c); v[c] = v[c] - lij * lcj; }
                 }
                 reuse_diagonal = true;
                 if (ok) {
-                    for (int i = 0; i < 6; i++) { double sd = gs[i]; for (int k = 0; k < i; k++) sd -= L[6 * i + k] * y[k]; y[i] = sd / L[7 * i]; }
-                    for (int i = 5; i >= 0; i--) { double sd = y[i]; for (int k = i + 1; k < 6; k++) sd -= L[6 * k + i] * y[k]; y[i] = sd / L[7 * i]; }
+                    double acc = gs_r, yv = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {                 // forward: y[k] = (gs[k] - sum_(t < k) L[k][t] y[t]) / L[k][k]
+                        const double yk = readlane_f64(acc, k) / readlane_f64(v[k], k);
+                        if (r == k) yv = yk;
+                        acc = acc - v[k] * yk;
+                    }
+                    double yb[6];
+#pragma unroll
+                    for (int i = 5; i >= 0; i--) {                // backward: y[i] = (y[i] - sum_(k > i) L[k][i] y[k]) / L[i][i], k ascending
+                        double sd = readlane_f64(yv, i);
+#pragma unroll
+                        for (int k = i + 1; k < 6; k++) sd = sd - readlane_f64(v[i], k) * yb[k];
+                        yb[i] = sd / readlane_f64(v[i], i);
+                    }
+                    double step[6];
+#pragma unroll
+                    for (int a = 0; a < 6; a++) step[a] = -yb[a];
+                    if (lane_ == 0) {
+#pragma unroll
+                        for (int a = 0; a < 6; a++) s_step[a] = step[a];
+                    }
+                    double t_r = 0;
+#pragma unroll
+                    for (int b2 = 0; b2 < 6; b2++) t_r += hs[b2] * step[b2];
                     double sg = 0, sHs = 0;
-                    for (int a = 0; a < 6; a++) s_step[a] = -y[a];
-                    for (int a = 0; a < 6; a++) { sg += s_step[a] * gs[a]; double t = 0; for (int b2 = 0; b2 < 6; b2++) t += Hs[6 * a + b2] * s_step[b2]; sHs += s_step[a] * t; }
+#pragma unroll
+                    for (int a = 0; a < 6; a++) { sg += step[a] * readlane_f64(gs_r, a); sHs += step[a] * readlane_f64(t_r, a); }
                     mcc = -sg - 0.5 * sHs;
                     if (mcc > 0) valid = 1;
+                    if (valid) {
+                        double d[6];
+#pragma unroll
+                        for (int c = 0; c < 6; c++) d[c] = step[c] * s_scale[c];
+                        double xc[7];
+                        se3_plus(s_x, d, xc);
+                        if (lane_ == 0) { for (int k = 0; k < 7; k++) s_c[k] = xc[k]; }
+                    }
                 }
                 if (!valid) {   // StepIsInvalid -> StepRejected(0)
                     invalid++;
                     radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
                     if (invalid >= 5) go = 0;
-                } else {
-                    invalid = 0;
-                    double d[6];
-                    for (int c = 0; c < 6; c++) d[c] = s_step[c] * s_scale[c];
-                    se3_plus(s_x, d, s_c);
-                }
+                } else invalid = 0;
             }
-            s_ctl[0] = go; s_ctl[1] = valid; s_ctl[2] = (iteration >= max_it) ? 1 : 0;
+            if (lane_ == 0) { s_ctl[0] = go; s_ctl[1] = valid; s_ctl[2] = (iteration >= max_it) ? 1 : 0; }
         }
         __syncthreads();
         const int go = s_ctl[0], valid = s_ctl[1], last = s_ctl[2];
@@ -1743,10 +1789,10 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
         // ... except at the last iteration of the budget: nothing would use that linearisation, the cost alone decides the step
         if (last) s2m_evaluate<false>(s_c, frec, list, ev_ne, ev_n, huber_a, s_red, s_cand);
         else s2m_evaluate<true>(s_c, frec, list, ev_ne, ev_n, huber_a, s_red, s_cand);
-        if (tid == 0) {
+        if (wave_ == 0) {                  // (uniform over the wave, like the step above: its scalars — radius, x_cost, x_norm ... — live in every lane of wave 0)
             const double cand = s_cand[27];
-            double sn = 0;
-            for (int k = 0; k < 7; k++) sn += (s_x[k] - s_c[k]) * (s_x[k] - s_c[k]);
+            double sn = 0, xc[7];
+            for (int k = 0; k < 7; k++) { xc[k] = s_c[k]; sn += (s_x[k] - xc[k]) * (s_x[k] - xc[k]); }
             int stop = 0, accept = 0;
             if (sqrt(sn) <= 1e-8 * (x_norm + 1e-8)) stop = 1;
             else if (fabs(x_cost - cand) <= 1e-6 * x_cost) stop = 1;
@@ -1757,12 +1803,12 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
                     radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rd - 1.0, 3));
                     radius = fmin(1e16, radius);
                     decrease_factor = 2.0; reuse_diagonal = false;
-                    for (int k = 0; k < 7; k++) s_x[k] = s_c[k];
-                    x_norm = 0; for (int k = 0; k < 7; k++) x_norm += s_x[k] * s_x[k];
+                    x_norm = 0; for (int k = 0; k < 7; k++) x_norm += xc[k] * xc[k];
                     x_norm = sqrt(x_norm);
+                    x_cost = cand;
                 } else { radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true; }
             }
-            s_ctl[2] = stop; s_ctl[3] = accept;
+            if (lane_ == 0) { s_ctl[2] = stop; s_ctl[3] = accept; }
         }
         __syncthreads();
         const int stop = s_ctl[2], accept = s_ctl[3];
@@ -1770,8 +1816,8 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
         if (stop) break;
         if (accept) {     // a rejected step keeps the linearisation at x (s_ev) for the next ComputeStep
             if (tid < 28) s_ev[tid] = s_cand[tid];
+            if (tid < 7) s_x[tid] = s_c[tid];
             __syncthreads();
-            if (tid == 0) x_cost = s_ev[27];
         }
     }
     if (tid == 0) {
