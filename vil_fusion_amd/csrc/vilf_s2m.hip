@@ -31,10 +31,10 @@
 // In-kernel phase stamps: diagnostic build only (make DEFS=-DVILF_STAMPS); workgroup S2M_STAMP_WG of a launch writes them, and only when
 // its stream is a big one (the short launches of a size class would overwrite the interesting ones otherwise).
 #ifdef VILF_STAMPS
-__device__ long long s2m_dbg[8 * 32];
+__device__ long long s2m_dbg[9 * 32];
 #define S2M_STAMP_WG 1500
 #define S2M_STAMP(kid, i, cond) do { if (blockIdx.x == S2M_STAMP_WG && threadIdx.x == 0 && (cond)) s2m_dbg[(kid) * 32 + (i)] = __builtin_readcyclecounter(); } while (0)
-extern "C" int vilf_debug_stamps_s2m(long long *out256) { return hipMemcpyFromSymbol(out256, HIP_SYMBOL(s2m_dbg), sizeof(long long) * 8 * 32) == hipSuccess ? 0 : -1; }
+extern "C" int vilf_debug_stamps_s2m(long long *out288) { return hipMemcpyFromSymbol(out288, HIP_SYMBOL(s2m_dbg), sizeof(long long) * 9 * 32) == hipSuccess ? 0 : -1; }
 #define S2M_ACC_DECL long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long acc_last = __builtin_readcyclecounter();
 #define S2M_ACC(i) do { const long long now_ = __builtin_readcyclecounter(); acc_t[i] += now_ - acc_last; acc_last = now_; } while (0)
 #define S2M_ACC_OUT(kid) do { if (blockIdx.x == S2M_STAMP_WG && threadIdx.x == 0) for (int i_ = 0; i_ < 8; i_++) s2m_dbg[(kid) * 32 + 16 + i_] = acc_t[i_]; } while (0)
@@ -989,11 +989,11 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
     unsigned long long *s_key = s_T + (BIG ? 0 : lds_cap);
     int *s_te = reinterpret_cast<int *>(s_key + MU_TILE);
     int *gq = gq_all + (size_t)sid * gq_stride;      // queue of uncommon points in global memory (4 ints each: index | head bit 30 | between bit 29, H, M, lower bound in the tail): room for every old point
-    __shared__ int s_qn, s_fn;
+    __shared__ int s_qn, s_fn, s_jlo;
     __shared__ unsigned long long s_nk;
     if (tid == 0) { s_qn = 0; s_fn = 0; }
     constexpr unsigned long long SVB = 1ULL << 63;
-    int carryH = 0, carryM = 0, carryTE = 0;
+    int carryH = 0, carryM = 0, carryTE = 0, carryJ = 0;
     unsigned long long carryK = 0;
     float4 qn[MU_E], qn2[MU_E];                                     // two tiles of points in flight: one tile ahead leaves the sweep waiting a memory round trip per tile
 #pragma unroll
@@ -1043,10 +1043,23 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
         {   // lower bound of every old key in the sorted tail. The tail array is padded with ~0 to the power of two P2, so the search is the branch-free halving
             // form: one LDS read, one 64-bit compare and one conditional add per step and chain (the sweep is bound by VALU issue — sixteen waves share four
             // SIMDs — and the textbook lo / hi / mid form cost four times the instructions)
+            // Round 5: the search runs over a WINDOW of the tail. Both sequences ascend, so every key of this tile has its lower bound at or behind the previous
+            // tile's last one (carryJ), and at or before the first tail entry whose leaf is >= this tile's last key: the first of four power-of-two windows behind
+            // carryJ that ends on such an entry is taken (four uniform LDS reads; a tile of 2048 old points meets ~130 tail entries: 8 steps instead of 12).
+            // A full tile only (a partial one carries ~0 keys), the whole padded array otherwise. Same lower bounds, fewer steps.
             unsigned long long kk[MU_E];
+            int W = P2, jb = 0;
+            if (t0 + MU_TILE <= nOld && carryJ + 64 <= P2) {
+                const unsigned long long kl = (lastK & ~SVB) << IDXB;
+                const unsigned long long e0 = T[carryJ + 63], e1 = T[min(carryJ + 127, P2 - 1)], e2 = T[min(carryJ + 255, P2 - 1)], e3 = T[min(carryJ + 511, P2 - 1)];
+                if (e0 >= kl) { W = 64; jb = carryJ; }
+                else if (carryJ + 128 <= P2 && e1 >= kl) { W = 128; jb = carryJ; }
+                else if (carryJ + 256 <= P2 && e2 >= kl) { W = 256; jb = carryJ; }
+                else if (carryJ + 512 <= P2 && e3 >= kl) { W = 512; jb = carryJ; }
+            }
 #pragma unroll
-            for (int u = 0; u < MU_E; u++) { lo[u] = 0; kk[u] = key[u] << IDXB; }
-            for (int half = P2 >> 1; half > 0; half >>= 1) {
+            for (int u = 0; u < MU_E; u++) { lo[u] = jb; kk[u] = key[u] << IDXB; }
+            for (int half = W >> 1; half > 0; half >>= 1) {
                 unsigned long long tv[MU_E];
 #pragma unroll
                 for (int u = 0; u < MU_E; u++) tv[u] = T[lo[u] + half - 1];
@@ -1062,6 +1075,7 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
                 if (tm) cm |= 1u << u;
                 tb[u] = thp(lo[u]);                                  // tail leaves before this key
                 s_te[u * MU_T + tid] = tb[u] + (tm ? 1 : 0);         // ... up to and including it
+                if (u == MU_E - 1 && tid == MU_T - 1) s_jlo = lo[u];
                 const bool head = (hm >> u) & 1;
                 flag[u] = (head ? 1 : 0) | ((head && tm) ? (1 << 16) : 0);
             }
@@ -1111,7 +1125,7 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
         }
         const int nextTE = s_te[MU_TILE - 1];
         carryH += base & 0xffff; carryM += base >> 16;
-        carryTE = nextTE; carryK = lastK;
+        carryTE = nextTE; carryK = lastK; carryJ = min(s_jlo, P2 - 1);
         S2M_ACC(6);
         __syncthreads();                                             // s_key / s_te / s_w are rewritten by the next tile
         S2M_ACC(7);
@@ -1641,6 +1655,9 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
     __shared__ double s_red[S2M_NW * 28], s_ev[28], s_cand[28], s_x[7], s_c[7], s_scale[6], s_diag[6], s_step[6];
     __shared__ int s_ctl[4];
     const int tid = threadIdx.x, nfac = n_edge_q + n_surf_q;
+#ifdef VILF_STAMPS
+    const long long sb_t0 = __builtin_readcyclecounter();
+#endif
     if (tid < 7) s_x[tid] = pose_in[tid];
     // The valid factors' slots as a compact list in LDS (about a third of the queries have no valid factor; the five sweeps of a pass are bound by the traffic of the
     // records): every thread counts the edge / plane factors of its contiguous slice of the slots, a block scan gives the offsets, a second walk over the slice fills
@@ -1669,7 +1686,17 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
     const unsigned short *list = use_list ? s_list : nullptr;
     const int ev_ne = use_list ? tne : min(n_edge_q, nfac), ev_n = use_list ? tne + tns : nfac;
     __syncthreads();
+#ifdef VILF_STAMPS
+    long long sb_t1 = __builtin_readcyclecounter(), sb_step = 0, sb_eval = 0, sb_tail = 0, sb_t;
+#define SB_T0() sb_t = __builtin_readcyclecounter()
+#define SB_ADD(v) v += __builtin_readcyclecounter() - sb_t
+#else
+#define SB_T0() do { } while (0)
+#define SB_ADD(v) do { } while (0)
+#endif
+    SB_T0();
     s2m_evaluate<true>(s_x, frec, list, ev_ne, ev_n, huber_a, s_red, s_ev);
+    SB_ADD(sb_eval);
     // wave-0 scalars of the trust-region loop (trust_region_minimizer.cc + levenberg_marquardt_strategy.cc)
     double x_cost = s_ev[27], radius = 1e4, decrease_factor = 2.0, x_norm = 0, mcc = 0;
     bool reuse_diagonal = false;
@@ -1681,6 +1708,7 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
     x_norm = sqrt(x_norm);
     __syncthreads();
     for (;;) {
+        SB_T0();
         // The trust-region step of an iteration, by WAVE 0 (every lane runs the scalar part with the same values; LDS is written by one lane). The 6 x 6 part —
         // LevenbergMarquardtStrategy::ComputeStep on the Jacobi-scaled system: Cholesky, two triangular solves, the model cost change — has a lane per ROW in registers
         // and passes pivots / solved entries between lanes by v_readlane. Until round 5 thread 0 did it alone on 6 x 6 arrays in LDS (so that they would not set the
@@ -1782,13 +1810,17 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
         __syncthreads();
         const int go = s_ctl[0], valid = s_ctl[1], last = s_ctl[2];
         __syncthreads();
+        SB_ADD(sb_step);
         if (!go) break;
         if (!valid) continue;
+        SB_T0();
         // cost AND linearisation at the candidate in one sweep over the factor records: an accepted step (the usual case) then needs no
         // second sweep; a rejected one leaves s_ev (the linearisation at x) untouched
         // ... except at the last iteration of the budget: nothing would use that linearisation, the cost alone decides the step
         if (last) s2m_evaluate<false>(s_c, frec, list, ev_ne, ev_n, huber_a, s_red, s_cand);
         else s2m_evaluate<true>(s_c, frec, list, ev_ne, ev_n, huber_a, s_red, s_cand);
+        SB_ADD(sb_eval);
+        SB_T0();
         if (wave_ == 0) {                  // (uniform over the wave, like the step above: its scalars — radius, x_cost, x_norm ... — live in every lane of wave 0)
             const double cand = s_cand[27];
             double sn = 0, xc[7];
@@ -1819,7 +1851,14 @@ __global__ __launch_bounds__(S2M_NT, S2M_SOLVE_WPE) void b_solve(double *pose_al
             if (tid < 7) s_x[tid] = s_c[tid];
             __syncthreads();
         }
+        SB_ADD(sb_tail);
     }
+#ifdef VILF_STAMPS
+    if (blockIdx.x == S2M_STAMP_WG && tid == 0 && pass == 0) {
+        s2m_dbg[8 * 32 + 0] = __builtin_readcyclecounter() - sb_t0; s2m_dbg[8 * 32 + 1] = sb_t1 - sb_t0; s2m_dbg[8 * 32 + 2] = sb_eval; s2m_dbg[8 * 32 + 3] = sb_step; s2m_dbg[8 * 32 + 4] = sb_tail;
+        s2m_dbg[8 * 32 + 5] = iteration; s2m_dbg[8 * 32 + 6] = ev_n; s2m_dbg[8 * 32 + 7] = nfac;
+    }
+#endif
     if (tid == 0) {
         for (int k = 0; k < 7; k++) pose_in[k] = s_x[k];
         out->cost[pass] = x_cost; out->its[pass] = iteration; out->nfe[pass] = tne; out->nfs[pass] = tns;
