@@ -13,6 +13,9 @@
 
 #define VD __device__ __forceinline__
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store in flight (s_waitcnt vmcnt(0)), which ends any prefetch
+// at the next barrier. Use only where nothing in GLOBAL memory written before it is read by another thread after it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // Sum over the 64 lanes of a wave, the total in every lane, as a fixed binary tree: lane pairs, quads, half rows, rows (DPP: quad_perm, row_half_mirror, row_mirror),
 // then the four row sums as (r0 + r1) + (r2 + r3) through v_readlane. At every stage all lanes of a group hold the same group sum, so every lane ends with the same
 // bits. ~150 cycles instead of ~800 for a butterfly of six ds_bpermute round trips (three of these per Householder step of the marginalization, 28 per evaluation

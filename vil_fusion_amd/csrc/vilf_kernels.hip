@@ -47,9 +47,6 @@ __device__ __forceinline__ int tile_index(int ta, int tb) { return ta * (ta + 1)
 // block-wide sum / max with a fixed reduction tree (deterministic)
 // block reductions of the 256-thread kernels: the fixed tree of vilf_wave_sum64 inside each wave, then the four wave results in wave order by every thread — three
 // barriers (the shared-memory halving tree they replace had ten per call)
-// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global load and store in flight (s_waitcnt vmcnt(0)), which ends any prefetch
-// at the next barrier. Use only where nothing in GLOBAL memory written before it is read by another thread after it.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ double block_sum(double v, double *s_red) {
     const int tid = threadIdx.x;
     v = vilf_wave_sum64(v);

@@ -916,6 +916,145 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
     int P2 = 2;
     while (P2 < nt) P2 <<= 1;
     int myvalid = 0;
+    // Round 5: tails of up to MU_RADIX points (every stream of the steady state) are sorted by a stable LSD radix sort on a COMPACT key instead of the 78-step bitonic
+    // network on 64-bit words (22 % of the kernel): the key's fields cy | cx | iz | lows are taken relative to their minima over the tail and packed into the bits
+    // their ranges need (a scan inside the crop box: 7 + 7 + 5 + 2 cs bits), one more bit on top marks the points the crop or the grid rejects, so they sort behind
+    // the rest. Three 8-bit passes of sv_runs' ballot-matching sort (b_scan_voxel_runs, C) over 16-bit indices; equal keys keep their index order = the order of
+    // the (key << IDXB | index) words the network sorted. T[] is composed from the sorted indices and the fields at the end: the same array, to the bit.
+    constexpr int NW = MU_T / 64, MU_RADIX = 4096, RK = MU_RADIX / MU_T;
+    __shared__ int s_mm[6][NW], s_geo[8];
+    bool radix = !BIG && nt <= MU_RADIX && nt <= lds_cap;
+    if (radix) {
+        unsigned long long kf[RK];
+        unsigned vm = 0;
+        const int fb = AXB - cs;                                                       // bits of a cell coordinate
+        int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-1, -1, -1};
+#pragma unroll
+        for (int k = 0; k < RK; k++) {
+            const int j = tid + MU_T * k;
+            kf[k] = 0;
+            if (j < nt) {
+                const float4 q = p[nOld + j];
+                unsigned long long kk;
+                if (mu_inside(q, box)) {
+                    if (mu_leaf<AXB>(q, inv, cs, kk)) {
+                        kf[k] = kk; vm |= 1u << k; myvalid++;
+                        const int f0 = (int)(kk >> (2 * AXB + cs)), f1 = (int)((kk >> (AXB + 2 * cs)) & ((1ULL << fb) - 1ULL)), f2 = (int)((kk >> (2 * cs)) & ((1ULL << AXB) - 1ULL));
+                        mn[0] = min(mn[0], f0); mx[0] = max(mx[0], f0); mn[1] = min(mn[1], f1); mx[1] = max(mx[1], f1); mn[2] = min(mn[2], f2); mx[2] = max(mx[2], f2);
+                    } else bad |= S2B_ERR_VOXEL;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int of = 32; of > 0; of >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], of, 64)); mx[k] = max(mx[k], __shfl_xor(mx[k], of, 64)); }
+            if (lane == 0) { s_mm[k][wave] = mn[k]; s_mm[3 + k][wave] = mx[k]; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int vb = 2 * cs;
+            for (int k = 0; k < 3; k++) {
+                int a = s_mm[k][0], b = s_mm[3 + k][0];
+                for (int w2 = 1; w2 < NW; w2++) { a = min(a, s_mm[k][w2]); b = max(b, s_mm[3 + k][w2]); }
+                if (b < a) { a = 0; b = 0; }                                           // no valid tail point
+                int nb = 0;
+                while (((b - a) >> nb) != 0) nb++;
+                s_geo[k] = a; s_geo[3 + k] = nb; vb += nb;
+            }
+            s_geo[6] = vb;
+        }
+        __syncthreads();
+        const int vbits = s_geo[6];
+        radix = vbits <= 31;                                                           // (never more inside a crop box; the network below takes such a tail)
+        if (radix) {
+            unsigned int *s_rkey = reinterpret_cast<unsigned int *>(s_T);
+            unsigned short *src = reinterpret_cast<unsigned short *>(s_T) + 2 * lds_cap, *dst = src + lds_cap;
+            unsigned short *s_cnt = reinterpret_cast<unsigned short *>(s_T + lds_cap);           // [256 digits][NW waves]: the sweep's key tile, not in use yet
+            const int m0 = s_geo[0], m1 = s_geo[1], m2 = s_geo[2], b1 = s_geo[4], b2 = s_geo[5];
+#pragma unroll
+            for (int k = 0; k < RK; k++) {
+                const int j = tid + MU_T * k;
+                if (j < nt) {
+                    const unsigned long long kk = kf[k];
+                    const unsigned f0 = (unsigned)((int)(kk >> (2 * AXB + cs)) - m0), f1 = (unsigned)((int)((kk >> (AXB + 2 * cs)) & ((1ULL << fb) - 1ULL)) - m1),
+                                   f2 = (unsigned)((int)((kk >> (2 * cs)) & ((1ULL << AXB) - 1ULL)) - m2), lw = (unsigned)(kk & ((1ULL << (2 * cs)) - 1ULL));
+                    s_rkey[j] = ((vm >> k) & 1u) ? ((((f0 << b1) | f1) << b2 | f2) << (2 * cs)) | lw : (1u << vbits);
+                    src[j] = (unsigned short)j;
+                }
+            }
+            const int seg = (nt + NW - 1) / NW, lo = wave * seg, hi = min(nt, lo + seg);
+            unsigned int *cnt32 = reinterpret_cast<unsigned int *>(s_cnt);
+            for (int shift = 0; shift < vbits + 1; shift += 8) {
+                for (int t = tid; t < 128 * NW; t += MU_T) cnt32[t] = 0;
+                __syncthreads();
+                unsigned int pk[RK], rk[RK];                     // index | digit << 16 | valid << 24;  rank | same-digit count << 8
+                const int nbit = min(8, vbits + 1 - shift);
+#pragma unroll
+                for (int st = 0; st < RK; st++) {
+                    pk[st] = 0; rk[st] = 0;
+                    if (lo + 64 * st < hi) {
+                        const int j = lo + 64 * st + lane;
+                        const bool valid = j < hi;
+                        const unsigned int idx = valid ? src[j] : 0u;
+                        const int d = valid ? (int)((s_rkey[idx] >> shift) & 255u) : 0;
+                        unsigned long long mask = __ballot(valid);
+#pragma unroll
+                        for (int b = 0; b < 8; b++) if (b < nbit) { const unsigned long long bal = __ballot((d >> b) & 1); mask &= ((d >> b) & 1) ? bal : ~bal; }
+                        const int rank = __popcll(mask & ((1ULL << lane) - 1ULL)), same = __popcll(mask);
+                        if (valid && rank == 0) s_cnt[d * NW + wave] += (unsigned short)same;
+                        pk[st] = idx | ((unsigned int)d << 16) | (valid ? 1u << 24 : 0u); rk[st] = (unsigned int)rank | ((unsigned int)same << 8);
+                    }
+                }
+                __syncthreads();
+                {   // exclusive scan in (digit, wave) order: thread t owns entries 4 t .. 4 t + 3 of [digit][wave] (256 NW / MU_T = 4)
+                    int c4[4], loc = 0;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { c4[u] = s_cnt[4 * tid + u]; loc += c4[u]; }
+                    int tot;
+                    int run = block_excl_scan_nw<NW>(loc, s_w[0], tot);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { s_cnt[4 * tid + u] = (unsigned short)run; run += c4[u]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int st = 0; st < RK; st++) {                // a wave walks its own segment in order: its counter column needs no synchronisation
+                    if (lo + 64 * st < hi && (pk[st] >> 24)) {
+                        const int d = (pk[st] >> 16) & 255, rank = rk[st] & 255;
+                        const int off = s_cnt[d * NW + wave];
+                        dst[off + rank] = (unsigned short)(pk[st] & 0xffffu);
+                        if (rank == 0) s_cnt[d * NW + wave] = (unsigned short)(off + (rk[st] >> 8));
+                    }
+                }
+                __syncthreads();
+                unsigned short *t = src; src = dst; dst = t;
+            }
+            // T[j] = (full key << IDXB) | index in sorted order; the rejected points (behind the valid ones) and the padding up to P2: ~0
+            int ntv0;
+            { int tot; block_excl_scan_nw<NW>(myvalid, s_w[0], tot); ntv0 = tot; }
+            unsigned int ri[RK], rv[RK];
+#pragma unroll
+            for (int k = 0; k < RK; k++) { const int j = tid + MU_T * k; ri[k] = j < ntv0 ? src[j] : 0u; rv[k] = j < ntv0 ? s_rkey[ri[k]] : 0u; }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RK; k++) {
+                const int j = tid + MU_T * k;
+                if (j < P2) {
+                    unsigned long long w = ~0ULL;
+                    if (j < ntv0) {
+                        const unsigned long long c = rv[k];
+                        const unsigned long long lw = c & ((1ULL << (2 * cs)) - 1ULL), f2 = ((c >> (2 * cs)) & ((1ULL << b2) - 1ULL)) + (unsigned long long)m2,
+                                                 f1 = ((c >> (2 * cs + b2)) & ((1ULL << b1) - 1ULL)) + (unsigned long long)m1, f0 = (c >> (2 * cs + b2 + b1)) + (unsigned long long)m0;
+                        const unsigned long long kk = (f0 << (2 * AXB + cs)) | (f1 << (AXB + 2 * cs)) | (f2 << (2 * cs)) | lw;
+                        w = (kk << IDXB) | (unsigned long long)ri[k];
+                    }
+                    T[j] = w;
+                }
+            }
+            __syncthreads();
+        } else myvalid = 0;
+    }
+    if (!radix) {
     for (int j = tid; j < P2; j += MU_T) {
         unsigned long long w = ~0ULL;
         if (j < nt) {
@@ -926,7 +1065,9 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
         T[j] = w;
     }
     __syncthreads();
-    if (!BIG && P2 >= 2 * MU_T) {
+    }
+    if (radix) { }
+    else if (!BIG && P2 >= 2 * MU_T) {
         // bitonic network with every wave owning a contiguous block of ppw pairs = 2 ppw elements: a step whose partner distance j is <= ppw stays inside the
         // blocks, so it needs no workgroup barrier (LDS accesses of one wave are ordered) — 68 of the 78 steps of a 4096-entry sort
         const int ppw = (P2 >> 1) / (MU_T / 64);
@@ -1018,7 +1159,7 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
         }
         if (tid == 0) { unsigned long long kx; mu_leaf<AXB>(qn[0], inv, cs, kx); s_nk = kx; }
         S2M_ACC(1);
-        __syncthreads();
+        lds_barrier();               // (the three barriers of the tile loop order LDS only — s_key / s_te / s_w; the points requested two tiles ahead and this tile's stores stay in flight across them: the map and the queue are read again only behind the full barrier that follows the loop)
         S2M_ACC(2);
         const unsigned long long lastK = s_key[MU_TILE - 1];
 #pragma unroll
@@ -1090,7 +1231,7 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
             for (int u = 0; u < MU_E; u++) s_w[u][wave] = incl[u];
         }
         S2M_ACC(4);
-        __syncthreads();
+        lds_barrier();
         S2M_ACC(5);
         int base = 0;
 #pragma unroll
@@ -1127,7 +1268,7 @@ __global__ MU_LB void b_map_update(CSet map, const int *n_old, const double *pos
         carryH += base & 0xffff; carryM += base >> 16;
         carryTE = nextTE; carryK = lastK; carryJ = min(s_jlo, P2 - 1);
         S2M_ACC(6);
-        __syncthreads();                                             // s_key / s_te / s_w are rewritten by the next tile
+        lds_barrier();                                               // s_key / s_te / s_w are rewritten by the next tile
         S2M_ACC(7);
     }
     S2M_ACC_OUT(skid);
