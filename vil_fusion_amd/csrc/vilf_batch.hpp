@@ -98,7 +98,8 @@ struct VbState {            // per-window trust-region state (ceres TrustRegionM
 #define QL_ICAP 768          // QL iterations logged per window
 #define QL_LPW 16           // windows per wave of k_mf_ql (8: faster at 2048 windows, slower at 4096)
 #define MG_SLOTS 1024       // start-frame-0 factor rows whose Mbuf index is kept in LDS by k_marg_prepare (beyond: looked up again)
-#define MG_GCH 96           // factor rows staged per chunk in the pair gather of k_marg_prepare (32 KB of LDS)
+#define MG_GCH 80           // factor rows staged per chunk in the pair gather of k_marg_prepare (27 KB of LDS; 96 until the per-wave partial products needed 6.7 KB)
+#define MG_PTRI 210         // entries of the packed lower triangle of a 20 x 20 pair product
 #define MG_MLDS 136         // largest Amm held in LDS by the Jacobi eigen-solver
 #define MG_INFO 128         // per window: [0] status [1] md [2] mf [3] n [4] m [5] nblocks [6] M(padded) [8..31] shifted ids [32..55] sizes
                             //             [56..79] idx [80..103] original ids

@@ -107,6 +107,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     __shared__ int s_off_pose[VB_NF], s_off_sb[2], s_off_ex, s_off_td, s_pmap[VB_PRIOR_LD], s_hdr[8], s_pst[VB_NPAIR], s_pcn[VB_NPAIR], s_pcl[VB_NPAIR];     // pair table: start inside the class list, factor count, class
     __shared__ double s_td;
     __shared__ double s_zero;                                    // a zero in LDS: what a masked lane of the pair products reads
+    __shared__ double s_part[4 * MG_PTRI];                       // the four waves' partial pair products (packed lower triangle of 20 x 20)
     __shared__ __attribute__((aligned(16))) double s_rows[MG_GCH * MG_MROW];                  // factor rows of the pair products; afterwards the rank -> feature table of the arrow rows
     __shared__ int s_slots[MG_SLOTS], s_pend[10];                 // Mbuf row of the t-th start-frame-0 factor (evaluation order = pair order); cumulative factor count per pair
     int *info = g.info + (size_t)w * MG_INFO;
@@ -372,25 +373,33 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         // (1,0), (1,1), one per wave; a k-step is four X rows = two factors read from the staged chunk. (A thread per entry summing over the rows spent 250 k cycles per
         // window in LDS reads.) The accumulators live across chunks and are flushed where a pair ends.
         const int wave = tid >> 6, lane = tid & 63, l16 = lane & 15, l4 = lane >> 4;
-        // The ten pairs are dealt to the four waves (pair jj -> wave jj & 3: the counts fall with j, so the deal is even enough), and a wave forms ALL THREE tiles of its
-        // pairs: the operands of column tile 0 and 1 are read once per k-step and feed three MFMAs ((0,0) = a0 a0, (1,0) = a1 a0, (1,1) = a1 a1), three independent
-        // accumulators keep the matrix core busy, the fourth wave works too, and nothing crosses waves. (Until round 5: a wave per tile over all pairs — two LDS reads per
-        // MFMA, one dependent accumulator chain per wave, one wave idle: 84 k cycles of a 450 k-cycle launch.) A tile entry is the same sum over the pair's rows in order.
+        // All four waves work on the SAME pair: the pair's rows inside the chunk are dealt to the waves in trips of eight factors (four k-steps), a wave forms ALL THREE
+        // tiles of its trips — the operands of column tile 0 and 1 are read once per k-step and feed three MFMAs ((0,0) = a0 a0, (1,0) = a1 a0, (1,1) = a1 a1), three
+        // independent accumulators — and where the pair ends the four partial sums meet in LDS and are added in wave order. (Round 5, first form: whole pairs dealt to
+        // the waves — a chunk of 96 rows holds one to three pairs, so one to three waves worked and the rest waited: the barrier behind the MFMAs cost as much as the
+        // MFMAs. Until round 5: a wave per tile over all pairs.) An entry is a fixed-order sum over the pair's rows: same bits on every run.
         const int sub = l4 & 1;
         auto comp_of = [&](int c) -> int { return c < 18 ? 12 * (c / 6) + (c % 6) + 6 * sub : (c == 18 ? 40 + sub : (c == 19 ? 38 + sub : -1)); };      // X column -> Mbuf row component
         const int comp0 = comp_of(l16), comp1 = comp_of(16 + l16);
         mgp_double4 T00 = {0.0, 0.0, 0.0, 0.0}, T10 = {0.0, 0.0, 0.0, 0.0}, T11 = {0.0, 0.0, 0.0, 0.0};
-        int jj = wave;                                           // this wave's current pair (0, jj + 1)
-        auto flush = [&]() {
+        int jj = 0;                                              // the current pair (0, jj + 1), the same in every wave
+        int pu = 0;                                              // thread e < 210 adds entry e of the packed triangle: (pu, pv), pv <= pu
+        while ((pu + 1) * (pu + 2) / 2 <= min(tid, MG_PTRI - 1)) pu++;
+        const int pv = min(tid, MG_PTRI - 1) - pu * (pu + 1) / 2;
+        auto flush = [&]() {                                     // collective (two barriers)
+            double *mine = s_part + wave * MG_PTRI;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int u0 = l4 + 4 * q, u1 = 16 + l4 + 4 * q, v0 = l16, v1 = 16 + l16;
-                if (v0 <= u0) s_pm[jj * MG_PAIRM + 20 * v0 + u0] = T00[q];
-                if (u1 < 20) s_pm[jj * MG_PAIRM + 20 * v0 + u1] = T10[q];
-                if (u1 < 20 && v1 <= u1) s_pm[jj * MG_PAIRM + 20 * v1 + u1] = T11[q];
+                if (v0 <= u0) mine[u0 * (u0 + 1) / 2 + v0] = T00[q];
+                if (u1 < 20) mine[u1 * (u1 + 1) / 2 + v0] = T10[q];
+                if (u1 < 20 && v1 <= u1) mine[u1 * (u1 + 1) / 2 + v1] = T11[q];
             }
             T00 = mgp_double4{0.0, 0.0, 0.0, 0.0}; T10 = T00; T11 = T00;
-            jj += 4;
+            __syncthreads();
+            if (tid < MG_PTRI) s_pm[jj * MG_PAIRM + 20 * pv + pu] = ((s_part[tid] + s_part[MG_PTRI + tid]) + s_part[2 * MG_PTRI + tid]) + s_part[3 * MG_PTRI + tid];
+            __syncthreads();
+            jj++;
         };
         MG_ACC_DECL
         for (int t0 = 0; t0 < ntot; t0 += MG_GCH) {
@@ -428,11 +437,11 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
             MG_ACC(1);
             __syncthreads();
             MG_ACC(2);
-            while (jj < 10) {                                    // this wave's pairs that have rows in the chunk (or end empty in front of it)
+            while (jj < 10) {                                    // the pairs that have rows in the chunk (or end empty in front of it)
                 const int ps = jj ? s_pend[jj - 1] : 0, pe = s_pend[jj];
                 if (pe > ps && ps >= t0 + nr) break;                                  // begins in a later chunk
                 const int lo = max(ps, t0) - t0, hi = min(pe, t0 + nr) - t0;         // the pair's rows inside the chunk: [lo, hi)
-                for (int fr0 = lo; fr0 < hi; fr0 += 8) {                             // four k-steps (eight factors) per trip: their eight LDS reads first, then the twelve MFMAs
+                for (int fr0 = lo + 8 * wave; fr0 < hi; fr0 += 32) {                 // four k-steps (eight factors) per trip: their eight LDS reads first, then the twelve MFMAs; trips dealt to the waves
                     double a0[4], a1[4];
 #pragma unroll
                     for (int k4 = 0; k4 < 4; k4++) {                                  // (rows past the pair's end and the columns 20 .. 31 read a zero: the select sits on the address)
