@@ -396,46 +396,52 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
                 if (u1 < 20 && v1 <= u1) mine[u1 * (u1 + 1) / 2 + v1] = T11[q];
             }
             T00 = mgp_double4{0.0, 0.0, 0.0, 0.0}; T10 = T00; T11 = T00;
-            __syncthreads();
+            lds_barrier();
             if (tid < MG_PTRI) s_pm[jj * MG_PAIRM + 20 * pv + pu] = ((s_part[tid] + s_part[MG_PTRI + tid]) + s_part[2 * MG_PTRI + tid]) + s_part[3 * MG_PTRI + tid];
-            __syncthreads();
+            lds_barrier();
             jj++;
         };
+        // The chunk's rows: all of the thread's loads in flight at once (a plain loop waited for every load before issuing the next: sixteen memory round trips per
+        // chunk) — first the row indices (LDS), then the loads (16 bytes each: a row is 21 of them, rows start at multiples of 336 bytes). The loads of chunk t + 1
+        // are issued BEFORE the products of chunk t and land in LDS behind them (round 5; the barriers of the loop order LDS only, so they do not wait for them).
+        typedef double mg_double2 __attribute__((ext_vector_type(2)));
+        constexpr int RW2 = MG_MROW / 2, NLD = (MG_GCH * RW2 + NT - 1) / NT;
+        static_assert(MG_MROW % 2 == 0, "rows as 16-byte pieces");
+        mg_double2 vals[NLD];
+        auto request = [&](int t0) {
+            const int nr = min(MG_GCH, ntot - t0);
+            int off[NLD];
+            if (t0 + nr <= MG_SLOTS) {
+#pragma unroll
+                for (int k = 0; k < NLD; k++) { const int idx = min(tid + NT * k, nr * RW2 - 1), r = idx / RW2; off[k] = s_slots[t0 + r] * RW2 + (idx - RW2 * r); }
+            } else {
+#pragma unroll 1
+                for (int k = 0; k < NLD; k++) {
+                    const int idx = min(tid + NT * k, nr * RW2 - 1), r = idx / RW2;
+                    int rem = t0 + r, q = 0;
+                    for (int kk = 0; kk < 10; kk++) { const int pj = pair_index_c(0, kk + 1), nseg = s_pcn[pj]; if (rem >= 0) { if (rem < nseg) { q = VB_SLOT(s_pcl[pj], s_pst[pj] + rem); rem = -1; } else rem -= nseg; } }
+                    const int o = ps_slot[q] * RW2 + (idx - RW2 * r);
+#pragma unroll
+                    for (int k2 = 0; k2 < NLD; k2++) if (k2 == k) off[k2] = o;
+                }
+            }
+            const mg_double2 *Mb2 = reinterpret_cast<const mg_double2 *>(Mb);
+#pragma unroll
+            for (int k = 0; k < NLD; k++) vals[k] = Mb2[(size_t)off[k]];
+        };
         MG_ACC_DECL
+        if (ntot > 0) request(0);
         for (int t0 = 0; t0 < ntot; t0 += MG_GCH) {
             const int nr = min(MG_GCH, ntot - t0);
             MG_ACC(0);
-            {   // all of the thread's loads of the chunk in flight at once (a plain loop waited for every load before issuing the next: sixteen memory round trips per chunk):
-                // first the row indices (LDS), then the loads, then the stores
-                // (16 bytes per load: a row is 21 of them, rows start at multiples of 336 bytes — half the load and LDS-store instructions of the 8-byte form)
-                typedef double mg_double2 __attribute__((ext_vector_type(2)));
-                constexpr int RW2 = MG_MROW / 2, NLD = (MG_GCH * RW2 + NT - 1) / NT;
-                static_assert(MG_MROW % 2 == 0, "rows as 16-byte pieces");
-                int off[NLD];
-                mg_double2 vals[NLD];
-                if (t0 + nr <= MG_SLOTS) {
-#pragma unroll
-                    for (int k = 0; k < NLD; k++) { const int idx = min(tid + NT * k, nr * RW2 - 1), r = idx / RW2; off[k] = s_slots[t0 + r] * RW2 + (idx - RW2 * r); }
-                } else {
-#pragma unroll 1
-                    for (int k = 0; k < NLD; k++) {
-                        const int idx = min(tid + NT * k, nr * RW2 - 1), r = idx / RW2;
-                        int rem = t0 + r, q = 0;
-                        for (int kk = 0; kk < 10; kk++) { const int pj = pair_index_c(0, kk + 1), nseg = s_pcn[pj]; if (rem >= 0) { if (rem < nseg) { q = VB_SLOT(s_pcl[pj], s_pst[pj] + rem); rem = -1; } else rem -= nseg; } }
-                        const int o = ps_slot[q] * RW2 + (idx - RW2 * r);
-#pragma unroll
-                        for (int k2 = 0; k2 < NLD; k2++) if (k2 == k) off[k2] = o;
-                    }
-                }
-                const mg_double2 *Mb2 = reinterpret_cast<const mg_double2 *>(Mb);
+            {
                 mg_double2 *s_rows2 = reinterpret_cast<mg_double2 *>(s_rows);
-#pragma unroll
-                for (int k = 0; k < NLD; k++) vals[k] = Mb2[(size_t)off[k]];
 #pragma unroll
                 for (int k = 0; k < NLD; k++) { const int idx = tid + NT * k; if (idx < nr * RW2) s_rows2[idx] = vals[k]; }
             }
             MG_ACC(1);
-            __syncthreads();
+            lds_barrier();
+            if (t0 + MG_GCH < ntot) request(t0 + MG_GCH);
             MG_ACC(2);
             while (jj < 10) {                                    // the pairs that have rows in the chunk (or end empty in front of it)
                 const int ps = jj ? s_pend[jj - 1] : 0, pe = s_pend[jj];
@@ -459,7 +465,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
                 if (pe <= t0 + nr) flush(); else break;                               // the pair ends in this chunk / runs on into the next one
             }
             MG_ACC(3);
-            __syncthreads();
+            lds_barrier();
             MG_ACC(4);
         }
         MG_ACC_OUT(0);
