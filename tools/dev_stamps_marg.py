@@ -16,3 +16,7 @@ idx = [i for i in range(32) if v[i]]
 print("k_marg_prepare stamps:", [(idx[k + 1], int(v[idx[k + 1]] - v[idx[k]])) for k in range(len(idx) - 1)], "total", int(v[idx[-1]] - v[idx[0]]))
 print("pair-loop sums (thread 0): top, stage, barrier, mfma, barrier:", [int(x) for x in a[0][24:30]])
 print("tred2 Householder loop sums (thread 0): phaseA, barrier waits, matvec, phaseB, rank2, tail:", [int(x) for x in a[1][24:30]])
+v = a[2]
+nm = ["1/h", "arrow rows x MFMA", "S, Y -> LDS", "Cholesky of S", "Z = L^-1 Y", "trace chains", "reduce + guard", "Z^T Z (MFMA)", "Arr, br out"]
+st = [int(v[i]) for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)]
+if st[0]: print("k_marg_schur fast path:", {nm[i]: st[i + 1] - st[i] for i in range(9)}, "total", st[-1] - st[0])

@@ -666,10 +666,12 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
         double *s_S = s_dyn, *s_Y = s_S + MG_MD * MG_MD, *s_ih = s_Y + MG_MD * (MG_NK + 1), *s_red = s_ih + VILF_MAX_FEATURES_DEV;   // [md][md], [md][XL], [mf], [NT]
         __shared__ int s_ok;
         __shared__ double s_linv[MG_MD + 3];                       // 1 / L_jj of the arrow Cholesky
+        MG_STAMP(2, 0);
         if (tid == 0) s_ok = (md > 0 && md <= MG_MD && mf <= VILF_MAX_FEATURES_DEV && md + n + 1 <= 16 * 7) ? 1 : 0;      // C = 7 x 7 tiles (the reference's prior: n <= 76)
         __syncthreads();
         for (int f = tid; f < mf; f += NT) { const double h = hfm[f]; if (!(h > 0.0)) s_ok = 0; s_ih[f] = 1.0 / h; }
         __syncthreads();
+        MG_STAMP(2, 1);
         // Every product of the fast path with the arrow rows is a block of ONE symmetric matrix C = R^T diag(1 / h_f) R, R = [W_f (md + n columns) | g_f]: the md x md block
         // of S, the md x (n + 1) block of Y and the feature part of Arr and b_r. C (<= 112 x 112, 28 lower 16 x 16 tiles, seven per wave) is accumulated by
         // v_mfma_f64_16x16x4_f64 over the features, the rows staged through LDS 16 at a time. (Three scalar loops used to read every row from global memory once per
@@ -687,13 +689,27 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
         const int RW = md + n + 1, lane = tid & 63, l16 = lane & 15, l4 = lane >> 4;
         double *s_w = s_red + NT;                                   // [MG_FCH][MG_RWP]
         if (s_ok) {
-            for (int f0 = 0; f0 < mf; f0 += MG_FCH) {
-                __syncthreads();
-                for (int e = tid; e < MG_FCH * MG_RWP; e += NT) {
-                    const int f = e / MG_RWP, c = e - MG_RWP * f;
-                    s_w[e] = (f0 + f < mf && c < RW) ? ((c < RW - 1) ? Wf[(size_t)(f0 + f) * MG_ND + c] : gfm[f0 + f]) : 0.0;
+            // (round 5) the rows of chunk t + 1 are requested before the products of chunk t and go to LDS behind them; the loop's barriers order LDS only. Until then
+            // every chunk of sixteen rows was a full memory round trip in front of 28 MFMAs: fifteen trips per window, the larger part of the launch.
+            constexpr int NLD = (MG_FCH * MG_RWP + NT - 1) / NT;
+            double vals[NLD];
+            auto request = [&](int f0) {
+#pragma unroll
+                for (int k = 0; k < NLD; k++) {
+                    const int e = tid + NT * k, f = e / MG_RWP, c = e - MG_RWP * f;
+                    const bool in = e < MG_FCH * MG_RWP && f0 + f < mf && c < RW;
+                    const double *src = in ? ((c < RW - 1) ? Wf + (size_t)(f0 + f) * MG_ND + c : gfm + f0 + f) : gfm;      // (a dead entry reads a live word and is zeroed below: no branch around the load)
+                    const double v = *src;
+                    vals[k] = in ? v : 0.0;
                 }
-                __syncthreads();
+            };
+            if (mf > 0) request(0);
+            for (int f0 = 0; f0 < mf; f0 += MG_FCH) {
+                lds_barrier();
+#pragma unroll
+                for (int k = 0; k < NLD; k++) { const int e = tid + NT * k; if (e < MG_FCH * MG_RWP) s_w[e] = vals[k]; }
+                lds_barrier();
+                if (f0 + MG_FCH < mf) request(f0 + MG_FCH);
 #pragma unroll
                 for (int ks = 0; ks < MG_FCH / 4; ks++) {
                     const int k = 4 * ks + l4;
@@ -704,6 +720,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                 }
             }
             __syncthreads();
+            MG_STAMP(2, 2);
             // S = 0.5 (Hdd + Hdd^T) - C_dd and Y = [Hdr | g_d] - C_d,(r | rhs) to LDS; the rest of C stays in the tiles for Arr below. Element q of a tile: row l4 + 4 q, column l16.
 #pragma unroll
             for (int t = 0; t < 7; t++)
@@ -714,6 +731,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                     else if (lo < md && hi < RW) { const int k = hi - md; s_Y[lo * XL + k] = ((k < n) ? Hd[lo * MG_ND + md + k] : gd[lo]) - T[t][q]; }
                 }
             __syncthreads();
+            MG_STAMP(2, 3);
             for (int j = 0; j < md; j++) {                      // in-place lower Cholesky of S (md <= 21)
                 // 1 / L_jj by v_rsq_f64 + two Newton steps, kept for the triangular solves below: the IEEE square root here, the division per entry of the column and
                 // the 21 divisions in every chain of Z = L^-1 Y / the trace were ~12 dependent fp64 operations each (this arrow Cholesky is the library's own form;
@@ -728,9 +746,11 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
         }
         __syncthreads();
         if (s_ok) {
+            MG_STAMP(2, 4);
             // Z = L^-1 Y (one column per thread), trace(Amm^-1) = |L^-1|_F^2 + sum_f (1/h_f + |L^-1 w_f|^2 / h_f^2)
             for (int k = tid; k < XL; k += NT)
                 for (int i = 0; i < md; i++) { double v = s_Y[i * XL + k]; for (int t = 0; t < i; t++) v -= s_S[i * md + t] * s_Y[t * XL + k]; s_Y[i * XL + k] = v * s_linv[i]; }
+            MG_STAMP(2, 5);
             double tr = 0;
             for (int c = tid; c < md + mf; c += NT) {
                 double z[MG_MD];                                   // compile-time indices only (fully unrolled, guarded by md): the vector stays in registers
@@ -747,6 +767,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                 }
                 tr += (c < md) ? sq : s_ih[c - md] + sq * s_ih[c - md] * s_ih[c - md];
             }
+            MG_STAMP(2, 6);
             s_red[tid] = tr;
             __syncthreads();
             for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) s_red[tid] += s_red[tid + st]; __syncthreads(); }
@@ -755,6 +776,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
         }
         if (s_ok) {
             double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
+            MG_STAMP(2, 7);
             // Arr - (feature part, in the tiles) - Z^T Z: the second product by MFMA too (K = md, rows of Z = L^-1 Y from LDS, shifted by md against the tile grid)
 #pragma unroll
             for (int ks = 0; ks < (MG_MD + 3) / 4; ks++) {
@@ -766,6 +788,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                     T[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(za, zb, T[t], 0, 0, 0);
                 }
             }
+            MG_STAMP(2, 8);
 #pragma unroll
             for (int t = 0; t < 7; t++)
 #pragma unroll
@@ -776,6 +799,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                     if (i < n) { if (j < n) Ar[i * MG_NK + j] = Hd[(md + i) * MG_ND + md + j] - sacc; else br[i] = gd[md + i] - sacc; }
                     if (tti[t] != ttj[t] && j < n) { if (i < n) Ar[j * MG_NK + i] = Hd[(md + j) * MG_ND + md + i] - sacc; else br[j] = gd[md + j] - sacc; }
                 }
+            MG_STAMP(2, 9);
             if (tid == 0) info[7] = 0;
             return;
         }
