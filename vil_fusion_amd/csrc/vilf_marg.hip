@@ -626,7 +626,7 @@ extern "C" __global__ __launch_bounds__(NT, 2) void k_marg_prepare(VbBatch b, Vb
 extern "C" __global__ __launch_bounds__(NT) void k_marg_prepare_td(VbBatch b, VbMarg g) { marg_prepare_body<true>(b, g); }
 
 typedef double mg_double4 __attribute__((ext_vector_type(4)));
-extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg g, int exact) {
+extern "C" __global__ __launch_bounds__(NT, 3) void k_marg_schur(VbBatch b, VbMarg g, int exact) {
     const int w = blockIdx.x, tid = threadIdx.x;
     int *info = g.info + (size_t)w * MG_INFO;
     if (info[0] != 0) return;
@@ -732,41 +732,89 @@ extern "C" __global__ __launch_bounds__(NT) void k_marg_schur(VbBatch b, VbMarg 
                 }
             __syncthreads();
             MG_STAMP(2, 3);
-            for (int j = 0; j < md; j++) {                      // in-place lower Cholesky of S (md <= 21)
-                // 1 / L_jj by v_rsq_f64 + two Newton steps, kept for the triangular solves below: the IEEE square root here, the division per entry of the column and
-                // the 21 divisions in every chain of Z = L^-1 Y / the trace were ~12 dependent fp64 operations each (this arrow Cholesky is the library's own form;
-                // last-bit differences only)
-                if (tid == 0) { const double d = s_S[j * md + j]; if (!(d > 0.0)) s_ok = 0; const double dd = d > 0.0 ? d : 1.0, inv = rsqrt_nr(dd); s_S[j * md + j] = dd * inv; s_linv[j] = inv; }
-                __syncthreads();
-                if (tid > j && tid < md) s_S[tid * md + j] *= s_linv[j];
-                __syncthreads();
-                for (int e = tid; e < md * md; e += NT) { const int r = e / md, c = e - md * r; if (c > j && r >= c) s_S[e] -= s_S[r * md + j] * s_S[c * md + j]; }
-                __syncthreads();
-            }
         }
-        __syncthreads();
-        if (s_ok) {
-            MG_STAMP(2, 4);
-            // Z = L^-1 Y (one column per thread), trace(Amm^-1) = |L^-1|_F^2 + sum_f (1/h_f + |L^-1 w_f|^2 / h_f^2)
-            for (int k = tid; k < XL; k += NT)
-                for (int i = 0; i < md; i++) { double v = s_Y[i * XL + k]; for (int t = 0; t < i; t++) v -= s_S[i * md + t] * s_Y[t * XL + k]; s_Y[i * XL + k] = v * s_linv[i]; }
-            MG_STAMP(2, 5);
-            double tr = 0;
-            for (int c = tid; c < md + mf; c += NT) {
-                double z[MG_MD];                                   // compile-time indices only (fully unrolled, guarded by md): the vector stays in registers
-                double sq = 0;
+        // ---- Cholesky of S, Z = L^-1 Y and the trace guard as ONE column-by-column elimination over "items", a thread each, the item's md entries in registers:
+        //   items 0 .. md - 1            the rows of S            -> L (row r: entries 0 .. r)
+        //   md .. md + XL - 1            the columns of Y         -> Z = L^-1 Y
+        //   then md unit vectors e_c                              -> columns of L^-1 (their squares: |L^-1|_F^2)
+        //   then the mf arrow rows w_f                            -> L^-1 w_f (trace(Amm^-1) = |L^-1|_F^2 + sum_f (1 / h_f + |L^-1 w_f|^2 / h_f^2))
+        // Step j: the S rows publish column j (row j's entry = the pivot), ONE barrier, then every item does z_j *= 1 / sqrt(pivot) and z_c -= z_j L_cj for c > j — its
+        // 20 - j multiply-adds are independent, their operands broadcast LDS reads. Until round 5 these were three phases: an in-place Cholesky with three barriers per
+        // column (63), then a thread per column of Y and a thread per trace column each running the row-oriented substitution — 220 DEPENDENT multiply-adds with an LDS read
+        // in front of every one: 27 + 27 + 26 k cycles of a 200 k-cycle launch. Every entry sees the same operations in the same order (the trace now multiplies by
+        // 1 / L_jj where it divided: it is only compared with 1e8). Items beyond the 256 threads run the same elimination afterwards with the finished L.
+        __shared__ double s_col[2][MG_MD + 3];
+        double tr = 0;
+        if (s_ok) {                                                  // (uniform: the flag was last written in front of a barrier)
+            const int n_items = md + XL + md + mf;
+            double z[MG_MD];
+            auto load_item = [&](int item) {
 #pragma unroll
                 for (int i = 0; i < MG_MD; i++) {
+                    double v = 0.0;
                     if (i < md) {
-                        double v = (c < md) ? (i == c ? 1.0 : 0.0) : Wf[(size_t)(c - md) * MG_ND + i];
+                        if (item < md) v = (i <= item) ? s_S[item * md + i] : 0.0;
+                        else if (item < md + XL) v = s_Y[i * XL + (item - md)];
+                        else if (item < md + XL + md) v = (i == item - md - XL) ? 1.0 : 0.0;
+                        else if (item < n_items) v = Wf[(size_t)(item - md - XL - md) * MG_ND + i];
+                    }
+                    z[i] = v;
+                }
+            };
+            auto store_item = [&](int item) {
+                if (item < md) {
 #pragma unroll
-                        for (int t = 0; t < i; t++) v -= s_S[i * md + t] * z[t];
-                        z[i] = v / s_S[i * md + i];            // (a multiplication by the kept 1 / L_ii here took the kernel from 168 to 210 registers — three workgroups per CU to two)
-                        sq += z[i] * z[i];
+                    for (int i = 0; i < MG_MD; i++) if (i <= item) s_S[item * md + i] = z[i];
+                } else if (item < md + XL) {
+#pragma unroll
+                    for (int i = 0; i < MG_MD; i++) if (i < md) s_Y[i * XL + (item - md)] = z[i];
+                } else if (item < n_items) {
+                    double sq = 0;
+#pragma unroll
+                    for (int i = 0; i < MG_MD; i++) if (i < md) sq += z[i] * z[i];
+                    const int f = item - md - XL - md;
+                    tr += (f < 0) ? sq : s_ih[f] + sq * s_ih[f] * s_ih[f];
+                }
+            };
+            load_item(tid);
+            if (tid < md) s_col[0][tid] = z[0];
+            bool okp = true;
+#pragma unroll
+            for (int j = 0; j < MG_MD; j++) {
+                if (j < md) {                                       // (uniform)
+                    __syncthreads();
+                    const double *col = s_col[j & 1];
+                    const double piv = col[j];
+                    okp = okp && (piv > 0.0);
+                    const double inv = rsqrt_nr(piv > 0.0 ? piv : 1.0);
+                    if (tid == 0) s_linv[j] = inv;
+                    const double zj = z[j] * inv;
+                    z[j] = zj;
+#pragma unroll
+                    for (int c = j + 1; c < MG_MD; c++) if (c < md) z[c] -= zj * (col[c] * inv);
+                    if (j + 1 < MG_MD) { if (tid < md && tid >= j + 1) s_col[(j + 1) & 1][tid] = z[j + 1]; }
+                }
+            }
+            if (!okp && tid == 0) s_ok = 0;
+            __syncthreads();
+            if (s_ok) store_item(tid);
+            __syncthreads();
+            if (s_ok && tid + NT < n_items) {                        // the items beyond the first 256: L is complete (s_S, s_linv)
+                load_item(tid + NT);
+#pragma unroll
+                for (int j = 0; j < MG_MD; j++) {
+                    if (j < md) {
+                        const double zj = z[j] * s_linv[j];
+                        z[j] = zj;
+#pragma unroll
+                        for (int c = j + 1; c < MG_MD; c++) if (c < md) z[c] -= zj * s_S[c * md + j];
                     }
                 }
-                tr += (c < md) ? sq : s_ih[c - md] + sq * s_ih[c - md] * s_ih[c - md];
+                store_item(tid + NT);
             }
+        }
+        if (s_ok) {
+            MG_STAMP(2, 5);
             MG_STAMP(2, 6);
             s_red[tid] = tr;
             __syncthreads();
