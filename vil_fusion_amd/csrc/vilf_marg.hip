@@ -669,9 +669,6 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_marg_schur(VbBatch b, VbMa
         MG_STAMP(2, 0);
         if (tid == 0) s_ok = (md > 0 && md <= MG_MD && mf <= VILF_MAX_FEATURES_DEV && md + n + 1 <= 16 * 7) ? 1 : 0;      // C = 7 x 7 tiles (the reference's prior: n <= 76)
         __syncthreads();
-        for (int f = tid; f < mf; f += NT) { const double h = hfm[f]; if (!(h > 0.0)) s_ok = 0; s_ih[f] = 1.0 / h; }
-        __syncthreads();
-        MG_STAMP(2, 1);
         // Every product of the fast path with the arrow rows is a block of ONE symmetric matrix C = R^T diag(1 / h_f) R, R = [W_f (md + n columns) | g_f]: the md x md block
         // of S, the md x (n + 1) block of Y and the feature part of Arr and b_r. C (<= 112 x 112, 28 lower 16 x 16 tiles, seven per wave) is accumulated by
         // v_mfma_f64_16x16x4_f64 over the features, the rows staged through LDS 16 at a time. (Three scalar loops used to read every row from global memory once per
@@ -688,22 +685,36 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_marg_schur(VbBatch b, VbMa
         }
         const int RW = md + n + 1, lane = tid & 63, l16 = lane & 15, l4 = lane >> 4;
         double *s_w = s_red + NT;                                   // [MG_FCH][MG_RWP]
-        if (s_ok) {
-            // (round 5) the rows of chunk t + 1 are requested before the products of chunk t and go to LDS behind them; the loop's barriers order LDS only. Until then
-            // every chunk of sixteen rows was a full memory round trip in front of 28 MFMAs: fifteen trips per window, the larger part of the launch.
-            constexpr int NLD = (MG_FCH * MG_RWP + NT - 1) / NT;
-            double vals[NLD];
-            auto request = [&](int f0) {
+        // (round 5) the rows of chunk t + 1 are requested before the products of chunk t and go to LDS behind them; the loop's barriers order LDS only. Until then
+        // every chunk of sixteen rows was a full memory round trip in front of 28 MFMAs: fifteen trips per window, the larger part of the launch.
+        constexpr int NLD = (MG_FCH * MG_RWP + NT - 1) / NT;
+        double vals[NLD];
+        auto request = [&](int f0) {
 #pragma unroll
-                for (int k = 0; k < NLD; k++) {
-                    const int e = tid + NT * k, f = e / MG_RWP, c = e - MG_RWP * f;
-                    const bool in = e < MG_FCH * MG_RWP && f0 + f < mf && c < RW;
-                    const double *src = in ? ((c < RW - 1) ? Wf + (size_t)(f0 + f) * MG_ND + c : gfm + f0 + f) : gfm;      // (a dead entry reads a live word and is zeroed below: no branch around the load)
-                    const double v = *src;
-                    vals[k] = in ? v : 0.0;
-                }
-            };
-            if (mf > 0) request(0);
+            for (int k = 0; k < NLD; k++) {
+                const int e = tid + NT * k, f = e / MG_RWP, c = e - MG_RWP * f;
+                const bool in = e < MG_FCH * MG_RWP && f0 + f < mf && c < RW;
+                const double *src = in ? ((c < RW - 1) ? Wf + (size_t)(f0 + f) * MG_ND + c : gfm + f0 + f) : gfm;      // (a dead entry reads a live word and is zeroed below: no branch around the load)
+                const double v = *src;
+                vals[k] = in ? v : 0.0;
+            }
+        };
+        if (mf > 0 && s_ok) request(0);             // the first chunk's trip runs under the 1 / h and the S, Y fills that follow
+        for (int f = tid; f < mf; f += NT) { const double h = hfm[f]; if (!(h > 0.0)) s_ok = 0; s_ih[f] = 1.0 / h; }
+        // the dense part of S and Y goes to LDS now — 0.5 (Hdd + Hdd^T) and [Hdr | g_d], a thread per entry, coalesced along a row — so that its memory trip runs under
+        // the product loop; the tiles subtract their part of C in place afterwards. (Until round 5 every accumulator element fetched its own entries behind the loop,
+        // a branch and a trip each: 30 k cycles.)
+        if (s_ok) {
+            const int XLc = n + 1;
+            for (int e = tid; e < md * (md + XLc); e += NT) {
+                const int i = e / (md + XLc), c = e - (md + XLc) * i;
+                if (c < md) s_S[i * md + c] = 0.5 * (Hd[min(i, c) * MG_ND + max(i, c)] + Hd[max(i, c) * MG_ND + min(i, c)]);
+                else { const int k = c - md; s_Y[i * XLc + k] = (k < n) ? Hd[i * MG_ND + md + k] : gd[i]; }
+            }
+        }
+        __syncthreads();
+        MG_STAMP(2, 1);
+        if (s_ok) {
             for (int f0 = 0; f0 < mf; f0 += MG_FCH) {
                 lds_barrier();
 #pragma unroll
@@ -727,8 +738,9 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_marg_schur(VbBatch b, VbMa
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int r = 16 * tti[t] + l4 + 4 * q, c = 16 * ttj[t] + l16, lo = min(r, c), hi = max(r, c);
-                    if (hi < md) { const double v = 0.5 * (Hd[lo * MG_ND + hi] + Hd[hi * MG_ND + lo]) - T[t][q]; s_S[r * md + c] = v; s_S[c * md + r] = v; }
-                    else if (lo < md && hi < RW) { const int k = hi - md; s_Y[lo * XL + k] = ((k < n) ? Hd[lo * MG_ND + md + k] : gd[lo]) - T[t][q]; }
+                    if (r < c) continue;                                      // a diagonal tile holds (r, c) and (c, r): the lower one acts
+                    if (hi < md) { const double v = s_S[r * md + c] - T[t][q]; s_S[r * md + c] = v; s_S[c * md + r] = v; }
+                    else if (lo < md && hi < RW) { const int k = hi - md; s_Y[lo * XL + k] -= T[t][q]; }
                 }
             __syncthreads();
             MG_STAMP(2, 3);
@@ -838,15 +850,26 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_marg_schur(VbBatch b, VbMa
             }
             MG_STAMP(2, 8);
 #pragma unroll
-            for (int t = 0; t < 7; t++)
+            for (int t = 0; t < 7; t++) {
+                // the tile's entries of Hd / g_d first, all eight in flight (a dead element reads a live word: no branch around a load), then the stores
+                double ha[4], hb[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int i = 16 * tti[t] + l4 + 4 * q - md, j = 16 * ttj[t] + l16 - md;       // C index -> kept index (n = the right-hand side column / row)
+                    const bool in = !(i < 0 || j < 0 || i > n || j > n);
+                    const bool a_on = in && i < n, b_on = in && tti[t] != ttj[t] && j < n;
+                    ha[q] = *(a_on ? ((j < n) ? Hd + (md + i) * MG_ND + md + j : gd + md + i) : gd);
+                    hb[q] = *(b_on ? ((i < n) ? Hd + (md + j) * MG_ND + md + i : gd + md + j) : gd);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int i = 16 * tti[t] + l4 + 4 * q - md, j = 16 * ttj[t] + l16 - md;
                     if (i < 0 || j < 0 || i > n || j > n) continue;
                     const double sacc = T[t][q];
-                    if (i < n) { if (j < n) Ar[i * MG_NK + j] = Hd[(md + i) * MG_ND + md + j] - sacc; else br[i] = gd[md + i] - sacc; }
-                    if (tti[t] != ttj[t] && j < n) { if (i < n) Ar[j * MG_NK + i] = Hd[(md + j) * MG_ND + md + i] - sacc; else br[j] = gd[md + j] - sacc; }
+                    if (i < n) { if (j < n) Ar[i * MG_NK + j] = ha[q] - sacc; else br[i] = ha[q] - sacc; }
+                    if (tti[t] != ttj[t] && j < n) { if (i < n) Ar[j * MG_NK + i] = hb[q] - sacc; else br[j] = hb[q] - sacc; }
                 }
+            }
             MG_STAMP(2, 9);
             if (tid == 0) info[7] = 0;
             return;
