@@ -1333,17 +1333,37 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
     const int n = info[3], nb = info[5];
     const double *Ar = g.Ar + (size_t)w * MG_NK * MG_NK, *br = g.br + (size_t)w * MG_NK;
     auto prow = [](int r) { return r * (r + 1) / 2; };
-    // the packed lower triangle: A symmetrised (as k_mf_chol), identity padding for rows n..74, row 75 = b
-    for (int e = tid; e < SB_NR * (SB_NR + 1) / 2; e += NT) {
-        int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        if (prow(r) > e) r--;
-        if (prow(r + 1) <= e) r++;
-        const int c = e - prow(r);
-        double v;
-        if (r < n) v = 0.5 * (Ar[r * MG_NK + c] + Ar[c * MG_NK + r]);
-        else if (r < SB_ND) v = (c == r) ? 1.0 : 0.0;
-        else v = (c < n) ? br[c] : 0.0;                           // (75, 75) = 0: the right-hand side row's own diagonal is not a pivot
-        s_P[e] = v;
+    // the packed lower triangle: A symmetrised (as k_mf_chol), identity padding for rows n..74, row 75 = b. The thread's twelve entries: both loads of every entry in flight
+    // at once (a dead entry reads a live word), then the stores — and H0 = A, g0 = b go out from here, symmetrised entry by entry, instead of from a second pass over A behind
+    // the factorisation (whose loop of two loads and a store per trip was a memory round trip per entry: the larger part of this kernel until round 5). A window that fails
+    // the guard below is taken by the eigen-solver launches, whose k_prior_prep rewrites H0 and g0.
+    double *Ho = g.prior_H_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *go = g.prior_g_out + (size_t)w * VB_PRIOR_LD;
+    {
+        constexpr int NPK = (SB_NR * (SB_NR + 1) / 2 + NT - 1) / NT;
+        double va[NPK], vb[NPK];
+        int rr[NPK], cc[NPK];
+#pragma unroll
+        for (int k = 0; k < NPK; k++) {
+            const int e = min(tid + NT * k, SB_NR * (SB_NR + 1) / 2 - 1);
+            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            if (prow(r) > e) r--;
+            if (prow(r + 1) <= e) r++;
+            const int c = e - prow(r);
+            rr[k] = r; cc[k] = c;
+            va[k] = *((r < n) ? Ar + r * MG_NK + c : ((r >= SB_ND && c < n) ? br + c : br));
+            vb[k] = *((r < n) ? Ar + c * MG_NK + r : br);
+        }
+#pragma unroll
+        for (int k = 0; k < NPK; k++) {
+            const int e = tid + NT * k, r = rr[k], c = cc[k];
+            if (e < SB_NR * (SB_NR + 1) / 2) {
+                double v;
+                if (r < n) { v = 0.5 * (va[k] + vb[k]); Ho[r * VB_PRIOR_LD + c] = v; Ho[c * VB_PRIOR_LD + r] = v; }
+                else if (r < SB_ND) v = (c == r) ? 1.0 : 0.0;
+                else { v = (c < n) ? va[k] : 0.0; if (c < n) go[c] = v; }       // (75, 75) = 0: the right-hand side row's own diagonal is not a pivot
+                s_P[e] = v;
+            }
+        }
     }
     if (tid == 0) s_ok = 1;
     for (int e = tid; e < 4 * MFT_ROWS; e += NT) { s_pan[e] = 0.0; s_lp[e] = 0.0; }
@@ -1433,12 +1453,18 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
     if (!(trc < 1e8)) { if (tid == 0) qi[3] = 0; return; }
     // the new prior: linearized_jacobians = L^T (leading dimension n), linearized_residuals = L^-1 b = row 75 of the factor
     double *Jo = g.prior_J_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *ro = g.prior_r_out + (size_t)w * VB_PRIOR_LD;
-    for (int e = tid; e < n * n; e += NT) { const int i = e / n, k = e - n * i; Jo[e] = k >= i ? s_P[prow(k) + i] : 0.0; }
+    // (the entries above the diagonal read a zero that lives in LDS: a select on the loaded value is compiled into a branch around the read, a round trip per entry)
+    if (tid == 0) s_pan[0] = 0.0;
+    __syncthreads();
+    for (int e0 = 0; e0 < n * n; e0 += 8 * NT) {
+        double jv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int e = min(e0 + NT * u + tid, n * n - 1), i = e / n, k = e - n * i; jv[u] = *((k >= i) ? s_P + prow(k) + i : s_pan); }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int e = e0 + NT * u + tid; if (e < n * n) Jo[e] = jv[u]; }
+    }
     if (tid < n) ro[tid] = s_P[prow(SB_ND) + tid];
-    // H0 = J0^T J0 = L L^T = A and g0 = J0^T r0 = b: written from the kept block itself, k_prior_prep skips this window
-    double *Ho = g.prior_H_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *go = g.prior_g_out + (size_t)w * VB_PRIOR_LD;
-    for (int e = tid; e < n * n; e += NT) { const int i = e / n, j = e - n * i; Ho[i * VB_PRIOR_LD + j] = 0.5 * (Ar[i * MG_NK + j] + Ar[j * MG_NK + i]); }
-    if (tid < n) go[tid] = br[tid];
+    // (H0 = J0^T J0 = L L^T = A and g0 = J0^T r0 = b went out with the fill at the top: k_prior_prep skips this window)
     mf_table(b, g, w, n, nb, info);
     if (tid == 0) qi[3] = 1;
 }
