@@ -20,3 +20,5 @@ v = a[2]
 nm = ["1/h", "arrow rows x MFMA", "S, Y -> LDS", "Cholesky of S", "Z = L^-1 Y", "trace chains", "reduce + guard", "Z^T Z (MFMA)", "Arr, br out"]
 st = [int(v[i]) for i in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)]
 if st[0]: print("k_marg_schur fast path:", {nm[i]: st[i + 1] - st[i] for i in range(9)}, "total", st[-1] - st[0])
+v = a[3]
+if v[0]: print("k_mf_chol_tiles:", {"fill + H0 out": int(v[1] - v[0]), "tiles from LDS": int(v[2] - v[1]), "19 panels": int(v[3] - v[2]), "guard + J0, r0 out": int(v[4] - v[3]), "block table": int(v[5] - v[4])}, "panel-loop sums (thread 0): rank-4 MFMAs, panel -> LDS, barrier, row factor, barrier:", [int(x) for x in v[24:30]])

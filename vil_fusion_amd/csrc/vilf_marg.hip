@@ -1319,7 +1319,7 @@ extern "C" __global__ __launch_bounds__(NT) void k_mf_chol(VbBatch b, VbMarg g, 
 #define MFT_ROWS 160                                      // 80 (A, b, padding) + 80 (identity rows, padding)
 #define MFT_NT10 10                                       // tiles per wave: 40 = 15 (rows 0..79, lower) + 25 (rows 80..159, all five column tiles)
 #define MFT_LDS_DOUBLES (SB_NR * (SB_NR + 1) / 2 + 2 * 4 * MFT_ROWS + 16)
-extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, VbMarg g, int disable) {
+extern "C" __global__ __launch_bounds__(NT, 2) void k_mf_chol_tiles(VbBatch b, VbMarg g, int disable) {
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int *info = g.info + (size_t)w * MG_INFO;
     int *qi = g.qlInfo + (size_t)w * 4;
@@ -1338,6 +1338,7 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
     // the factorisation (whose loop of two loads and a store per trip was a memory round trip per entry: the larger part of this kernel until round 5). A window that fails
     // the guard below is taken by the eigen-solver launches, whose k_prior_prep rewrites H0 and g0.
     double *Ho = g.prior_H_out + (size_t)w * VB_PRIOR_LD * VB_PRIOR_LD, *go = g.prior_g_out + (size_t)w * VB_PRIOR_LD;
+    MG_STAMP(3, 0);
     {
         constexpr int NPK = (SB_NR * (SB_NR + 1) / 2 + NT - 1) / NT;
         double va[NPK], vb[NPK];
@@ -1368,6 +1369,7 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
     if (tid == 0) s_ok = 1;
     for (int e = tid; e < 4 * MFT_ROWS; e += NT) { s_pan[e] = 0.0; s_lp[e] = 0.0; }
     __syncthreads();
+    MG_STAMP(3, 1);
     // this wave's ten tiles: tile k = wave + 4 i of the list (R, C), R = 0..9, C = 0..min(R, 4)
     int tR[MFT_NT10], tC[MFT_NT10];
 #pragma unroll
@@ -1393,8 +1395,11 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
         }
     __syncthreads();
     double sq = 0.0;                                                               // this thread's row of L^-T, squared (rows 80 ..)
+    MG_STAMP(3, 2);
+    MG_ACC_DECL
 #pragma unroll 1
     for (int bj = 0; bj < 19; bj++) {
+        MG_ACC(0);
         const int j0 = 4 * bj, tc = bj >> 2, sp = bj & 3;
         // 1. the panel's four columns, rows >= j0, to LDS
         if ((c16 >> 2) == sp) {
@@ -1405,7 +1410,9 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
                     for (int q = 0; q < 4; q++) { const int r = 16 * tR[i] + g4 + 4 * q; if (r >= j0) s_pan[4 * r + (c16 & 3)] = T[i][q]; }
                 }
         }
+        MG_ACC(1);
         __syncthreads();
+        MG_ACC(2);
         // 2. one thread per row: Cholesky of the diagonal block, the row's strip of the factor (k_solve_sb's step, rows 76 .. 159 are right-hand sides / padding)
         if (tid >= j0 && tid < MFT_ROWS) {
             const double *dg = s_pan + 4 * j0, *rp = s_pan + 4 * tid;
@@ -1431,7 +1438,9 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
             if (tid >= 80) sq += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;                       // (x3 = 0 in the last panel)
             if (k == 0 && (!(d00 > 0.0) || !(t11 > 0.0) || !(t22 > 0.0) || (!last && !(t33 > 0.0)))) s_ok = 0;
         }
+        MG_ACC(3);
         __syncthreads();
+        MG_ACC(4);
         // 3. rank-4 update of the tiles that reach beyond the panel: one MFMA each
 #pragma unroll
         for (int i = 0; i < MFT_NT10; i++)
@@ -1440,7 +1449,9 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
                 T[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, T[i], 0, 0, 0);
             }
     }
+    MG_ACC_OUT(3);
     __syncthreads();
+    MG_STAMP(3, 3);
     if (!s_ok) { if (tid == 0) qi[3] = 0; return; }
     // trace(A^-1) = |L^-1|_F^2 (the padding's identity rows contribute 75 - n ones: taken off)
     sq = mg_wave_sum(sq);
@@ -1465,7 +1476,9 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_mf_chol_tiles(VbBatch b, V
     }
     if (tid < n) ro[tid] = s_P[prow(SB_ND) + tid];
     // (H0 = J0^T J0 = L L^T = A and g0 = J0^T r0 = b went out with the fill at the top: k_prior_prep skips this window)
+    MG_STAMP(3, 4);
     mf_table(b, g, w, n, nb, info);
+    MG_STAMP(3, 5);
     if (tid == 0) qi[3] = 1;
 }
 
