@@ -374,28 +374,40 @@ __global__ __launch_bounds__(256) void lw_assemble(const LwWin *ws, int sk) {
 // (frame j observes the feature once), the pose_i block (every factor shares the start frame), the Ex_Pose / td blocks, h_f and g_f are wave sums in a fixed tree.
 // The row is composed in LDS (zeros elsewhere) and written out whole: nothing to clear beforehand, one coalesced row store, bit-reproducible. Until round 4 these
 // were 14 hardware atomics per factor from the pair-major kernel, 64 different rows per wave instruction: 0.6 of the 2.5 ms of an iteration of 32 stress windows.
-template <bool EXT>
+// GRP = lanes per feature: 64 (a wave per feature, blocks of 64 factors for longer tracks) or 16 — four features per wave, for windows of up to 17 frames (a track
+// has at most NF - 1 factors): an 11-frame window's features have ~7 factors, a wave per feature ran with a tenth of its lanes (round 5; the estimate_td batches). The
+// group sums are the first four stages of the wave sum's tree (DPP inside a row of 16 lanes): the same bits as the 64-lane sum of a feature whose other rows are zero.
+template <int GRP>
+__device__ __forceinline__ double lw_group_sum(double v) {
+    if (GRP == 64) return vilf_wave_sum64(v);
+    v += vilf_dpp_f64<0xB1>(v); v += vilf_dpp_f64<0x4E>(v); v += vilf_dpp_f64<0x141>(v); v += vilf_dpp_f64<0x140>(v);
+    return v;
+}
+template <bool EXT, int GRP>
 __global__ __launch_bounds__(256) void lw_feature_rows(const LwWin *ws, int which, int sk) {
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;
     extern __shared__ double s_rows[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, f = blockIdx.x * 4 + wave, NF = w.NF, WS = w.WS, PC = w.PC;
-    if (f >= w.F) return;                             // whole waves leave: no workgroup barrier below
-    double *row = s_rows + (size_t)wave * WS;
-    for (int c = lane; c < WS; c += 64) row[c] = 0.0;
+    constexpr int FPW = 64 / GRP;                      // features per wave
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane / GRP, l = lane % GRP, f0 = (blockIdx.x * 4 + wave) * FPW, f = f0 + g, NF = w.NF, WS = w.WS, PC = w.PC;
+    if (f0 >= w.F) return;                            // whole waves leave: no workgroup barrier below
+    double *rows = s_rows + (size_t)wave * FPW * WS, *row = rows + (size_t)g * WS;
+    for (int c = lane; c < FPW * WS; c += 64) rows[c] = 0.0;
     __builtin_amdgcn_wave_barrier();
     double hacc = 0, gacc = 0;
-    if (!w.fconst[f]) {
+    const bool fok = f < w.F && !w.fconst[f];
+    {
         const double *x = which ? w.cand : w.x, *ex = x + w.xo;
         const double sqrt_info = w.sqrt_info, cauchy_b = w.cauchy_b;
-        const int n0 = w.fvis[f], n1 = w.fvis[f + 1];
-        const double inv_dep = x[16 * NF + f];
+        const int n0 = fok ? w.fvis[f] : 0, n1 = fok ? w.fvis[f + 1] : 0;
+        const double inv_dep = x[16 * NF + min(f, w.F - 1)];
         double ric[9];
         q_toR(q_load(ex + 3), ric);
         double iacc[6] = {0, 0, 0, 0, 0, 0}, eacc[7] = {0, 0, 0, 0, 0, 0, 0};
         int fi = 0;
-        for (int base = n0; base < n1; base += 64) {
-            const int t = base + lane;
+        const int nblk = (GRP == 64) ? (n1 - n0 + 63) / 64 : 1;      // (GRP 16: the host chose it because no track of the group is longer)
+        for (int bk = 0; bk < nblk; bk++) {
+            const int t = n0 + bk * GRP + l;
             const bool act = t < n1;
             double wi_[6] = {0, 0, 0, 0, 0, 0}, we_[7] = {0, 0, 0, 0, 0, 0, 0}, hh = 0, gg = 0;
             if (act) {
@@ -412,30 +424,29 @@ __global__ __launch_bounds__(256) void lw_feature_rows(const LwWin *ws, int whic
                 } else projection_eval<true>(pi, Ri, pj, Rj, ric, ex, v.pi, v.pj, inv_dep, sqrt_info, r, Ji, Jj, Jf);
                 double rho0, sw;
                 cauchy(r[0] * r[0] + r[1] * r[1], cauchy_b, rho0, sw);
-                const double f0 = sw * sw * Jf[0], f1 = sw * sw * Jf[1];          // (sw J)^T (sw Jf): both factors of the product carry the corrector's sqrt(rho')
-                hh = f0 * Jf[0] + f1 * Jf[1];
-                gg = f0 * r[0] + f1 * r[1];
+                const double f0_ = sw * sw * Jf[0], f1_ = sw * sw * Jf[1];          // (sw J)^T (sw Jf): both factors of the product carry the corrector's sqrt(rho')
+                hh = f0_ * Jf[0] + f1_ * Jf[1];
+                gg = f0_ * r[0] + f1_ * r[1];
 #pragma unroll
-                for (int a = 0; a < 6; a++) { wi_[a] = Ji[a] * f0 + Ji[6 + a] * f1; row[6 * v.j + a] = Jj[a] * f0 + Jj[6 + a] * f1; }
+                for (int a = 0; a < 6; a++) { wi_[a] = Ji[a] * f0_ + Ji[6 + a] * f1_; row[6 * v.j + a] = Jj[a] * f0_ + Jj[6 + a] * f1_; }
                 if (EXT) {
                     if (w.cEx >= 0) {
 #pragma unroll
-                        for (int a = 0; a < 6; a++) we_[a] = Jex[a] * f0 + Jex[6 + a] * f1;
+                        for (int a = 0; a < 6; a++) we_[a] = Jex[a] * f0_ + Jex[6 + a] * f1_;
                     }
-                    if (w.cTd >= 0) we_[6] = Jtd[0] * f0 + Jtd[1] * f1;
+                    if (w.cTd >= 0) we_[6] = Jtd[0] * f0_ + Jtd[1] * f1_;
                 }
             }
-            hacc += vilf_wave_sum64(hh); gacc += vilf_wave_sum64(gg);
+            hacc += lw_group_sum<GRP>(hh); gacc += lw_group_sum<GRP>(gg);
 #pragma unroll
-            for (int a = 0; a < 6; a++) iacc[a] += vilf_wave_sum64(wi_[a]);
+            for (int a = 0; a < 6; a++) iacc[a] += lw_group_sum<GRP>(wi_[a]);
             if (EXT) {
 #pragma unroll
-                for (int a = 0; a < 7; a++) eacc[a] += vilf_wave_sum64(we_[a]);
+                for (int a = 0; a < 7; a++) eacc[a] += lw_group_sum<GRP>(we_[a]);
             }
         }
-        fi = __builtin_amdgcn_readfirstlane(fi);      // the start frame: every factor of the feature has it (lane 0 of the last block is active)
         __builtin_amdgcn_wave_barrier();
-        if (lane == 0 && n1 > n0) {
+        if (l == 0 && n1 > n0) {                      // the start frame: every factor of the feature has it, and the group's first lane is active in every block
 #pragma unroll
             for (int a = 0; a < 6; a++) row[6 * fi + a] = iacc[a];
             if (EXT) {
@@ -447,10 +458,11 @@ __global__ __launch_bounds__(256) void lw_feature_rows(const LwWin *ws, int whic
             }
         }
     }
-    if (lane == 0) { w.hf[f] = hacc; w.gf[f] = gacc; }
+    if (l == 0 && f < w.F) { w.hf[f] = hacc; w.gf[f] = gacc; }
     __builtin_amdgcn_wave_barrier();
-    double *dst = w.W + (size_t)f * WS;
-    for (int c = lane; c < WS; c += 64) dst[c] = row[c];
+    double *dst = w.W + (size_t)f0 * WS;
+    const int cnt = min(FPW, w.F - f0) * WS;
+    for (int c = lane; c < cnt; c += 64) dst[c] = rows[c];
 }
 // MarginalizationFactor (marginalization_factor.cpp:333-381) of an 11-frame window: r = r0 + J0 dx with dx from lw_tr_* / the host (n <= 96 entries),
 // J0^T J0 from k_prior_prep; pcol maps a prior column to its column of the reduced system (-1: block constant in this solve)
@@ -1523,9 +1535,14 @@ struct LwEnq {
             tic();
         }
         if (d.maxNvis && jac) {                       // the rows of W, h_f, g_f: feature-major
-            const size_t lds = 4 * (size_t)d.maxWS * 8;
-            if (ext) hipLaunchKernelGGL(lw_feature_rows<true>, grid((d.maxF + 3) / 4), dim3(256), lds, h->stream, ws, which, sk);
-            else hipLaunchKernelGGL(lw_feature_rows<false>, grid((d.maxF + 3) / 4), dim3(256), lds, h->stream, ws, which, sk);
+            // windows of up to 17 frames (tracks of up to 16 factors): four features per wave
+            const bool g16 = d.maxNF <= 17;
+            const int fpb = g16 ? 16 : 4;               // features per workgroup
+            const size_t lds = (size_t)fpb * d.maxWS * 8;
+            if (ext) { if (g16) hipLaunchKernelGGL((lw_feature_rows<true, 16>), grid((d.maxF + fpb - 1) / fpb), dim3(256), lds, h->stream, ws, which, sk);
+                       else hipLaunchKernelGGL((lw_feature_rows<true, 64>), grid((d.maxF + fpb - 1) / fpb), dim3(256), lds, h->stream, ws, which, sk); }
+            else { if (g16) hipLaunchKernelGGL((lw_feature_rows<false, 16>), grid((d.maxF + fpb - 1) / fpb), dim3(256), lds, h->stream, ws, which, sk);
+                   else hipLaunchKernelGGL((lw_feature_rows<false, 64>), grid((d.maxF + fpb - 1) / fpb), dim3(256), lds, h->stream, ws, which, sk); }
         }
         if (d.maxNvis) {
             if (ext) hipLaunchKernelGGL(lw_visual_ext, grid((d.maxNvis + LW_CH - 1) / LW_CH), dim3(LW_CH), 0, h->stream, ws, which, jac, sk);
