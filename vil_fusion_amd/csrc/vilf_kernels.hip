@@ -2198,21 +2198,24 @@ __device__ __forceinline__ void solve_sb_body(const VbBatch &b, int w, size_t ww
         __syncthreads();
         STAMP(1, 3);
         // ---- P2b: dense -= U^T U, the three K partials in wave order (fixed order of the additions) ----------------------------------------------------
-#pragma unroll 1
-        for (int turn = 0; turn < 3; turn++) {
-            if (wave == turn) {          // tile order of sb_t15_a / sb_t15_b, three tiles per round
-                sb_acc_sub<3, 0x110, 0x100>(s_P, s_t, &acc15[0], ln, true, s_pan);      // (0,0) (1,0) (1,1)
-                __builtin_amdgcn_sched_barrier(0);
-                sb_acc_sub<3, 0x222, 0x210>(s_P, s_t, &acc15[3], ln, true, s_pan);      // (2,0) (2,1) (2,2)
-                __builtin_amdgcn_sched_barrier(0);
-                sb_acc_sub<3, 0x333, 0x210>(s_P, s_t, &acc15[6], ln, true, s_pan);      // (3,0) (3,1) (3,2)
-                __builtin_amdgcn_sched_barrier(0);
-                sb_acc_sub<3, 0x443, 0x103>(s_P, s_t, &acc15[9], ln, true, s_pan);      // (3,3) (4,0) (4,1)
-                __builtin_amdgcn_sched_barrier(0);
-                sb_acc_sub<3, 0x444, 0x432>(s_P, s_t, &acc15[12], ln, true, s_pan);     // (4,2) (4,3) (4,4)
-            }
-            __syncthreads();
+        // A wave's fifteen tiles go in five groups of three (tile order of sb_t15_a / sb_t15_b); wave w subtracts group g in phase g + w: every entry still sees wave 0,
+        // then 1, then 2, but the waves work at the same time on different groups — seven short phases instead of three turns of a whole wave each (round 5: the turns
+        // were 26 k of the kernel's 224 k cycles, one SIMD at work, the read-modify-write of a group being LDS latency + index arithmetic, not LDS bandwidth).
+#define SB_P2B_GROUP(G) do { \
+            if ((G) == 0) sb_acc_sub<3, 0x110, 0x100>(s_P, s_t, &acc15[0], ln, true, s_pan);       /* (0,0) (1,0) (1,1) */ \
+            else if ((G) == 1) sb_acc_sub<3, 0x222, 0x210>(s_P, s_t, &acc15[3], ln, true, s_pan);  /* (2,0) (2,1) (2,2) */ \
+            else if ((G) == 2) sb_acc_sub<3, 0x333, 0x210>(s_P, s_t, &acc15[6], ln, true, s_pan);  /* (3,0) (3,1) (3,2) */ \
+            else if ((G) == 3) sb_acc_sub<3, 0x443, 0x103>(s_P, s_t, &acc15[9], ln, true, s_pan);  /* (3,3) (4,0) (4,1) */ \
+            else sb_acc_sub<3, 0x444, 0x432>(s_P, s_t, &acc15[12], ln, true, s_pan);               /* (4,2) (4,3) (4,4) */ \
+        } while (0)
+#pragma unroll
+        for (int ph = 0; ph < 7; ph++) {
+            if (wave == 0) { if (ph < 5) SB_P2B_GROUP(ph); }
+            else if (wave == 1) { if (ph >= 1 && ph < 6) SB_P2B_GROUP(ph - 1); }
+            else if (wave == 2) { if (ph >= 2) SB_P2B_GROUP(ph - 2); }
+            lds_barrier();
         }
+#undef SB_P2B_GROUP
         STAMP(1, 26);
         // M_a = L_a^-1 over L_a, band_a <- M_a band_a, N_a = M_a B_(a+1)^T over B_(a+1): every later use of the chain is a product
         {
