@@ -660,6 +660,31 @@ def test_general_path_is_bit_reproducible(oracle):
     assert np.array_equal(grp[0].Ps, grp[2].Ps)
 
 
+def test_feature_rows_four_per_wave_give_the_same_bits_as_a_wave_per_feature(oracle, monkeypatch):
+    """lw_feature_rows deals FOUR features to a wave (16 lanes each) for windows of up to 17 frames — a track has at most 16 factors there — and a wave per feature
+    otherwise; the 16-lane sums are the first four stages of the wave sum's tree, so a 13-frame window must come out bit for bit the same through both
+    (VILF_LW_FEATURE_WAVES=1 forces the wave-per-feature form)."""
+    from vil_fusion_amd.estimator import BackendSolver
+    o = oracle.default_options()
+    o.window_size = 12
+    win, _, _ = synth.make_window(611, o, synth.SynthConfig(n_frames=13, n_features=150, with_prior=False))
+    def run():
+        s = BackendSolver(o)
+        try:
+            return s.optimization(win)
+        finally:
+            s.close()
+    a = run()
+    monkeypatch.setenv("VILF_LW_FEATURE_WAVES", "1")
+    b = run()
+    for key in ("Ps", "Rs", "Vs", "Bas", "Bgs", "para_feature", "para_pose", "para_speed_bias"):
+        assert np.array_equal(getattr(a, key), getattr(b, key)), key
+    for key in ("initial_cost", "final_cost", "final_radius", "num_iterations", "num_successful_steps"):
+        assert a.summary[key] == b.summary[key], key
+    ref = oracle.window_solve(o, win, None)
+    assert a.summary["num_iterations"] == ref.summary["num_iterations"] and np.abs(a.Ps - ref.Ps).max() < 1e-6
+
+
 @pytest.mark.parametrize("noise,deg,seed", [(1.5, 15.0, 500), (3.0, 25.0, 502), (3.0, 25.0, 503)])
 def test_large_window_device_trust_region_loop(oracle, monkeypatch, noise, deg, seed):
     """The general single-window path keeps its trust-region loop on the device (lw_tr_*: every iteration enqueued at once, skip flags instead of host decisions).

@@ -1572,7 +1572,7 @@ struct LwEnq {
         }
         if (d.maxNvis && jac) {                       // the rows of W, h_f, g_f: feature-major
             // windows of up to 17 frames (tracks of up to 16 factors): four features per wave
-            const bool g16 = d.maxNF <= 17;
+            const bool g16 = d.maxNF <= 17 && !std::getenv("VILF_LW_FEATURE_WAVES");      // (test hook: a wave per feature for every window size — the two forms give the same bits)
             const int fpb = g16 ? 16 : 4;               // features per workgroup
             const size_t lds = (size_t)fpb * d.maxWS * 8;
             if (ext) { if (g16) hipLaunchKernelGGL((lw_feature_rows<true, 16>), grid((d.maxF + fpb - 1) / fpb), dim3(256), lds, h->stream, ws, which, sk);
