@@ -420,7 +420,7 @@ __device__ __forceinline__ double lw_group_sum(double v) {
     return v;
 }
 template <bool EXT, int GRP>
-__global__ __launch_bounds__(256) void lw_feature_rows(const LwWin *ws, int which, int sk) {
+__global__ __launch_bounds__(256, 2) void lw_feature_rows(const LwWin *ws, int which, int sk) {      // (two workgroups per CU: the estimate_td form would take 258 registers and run one)
     const LwWin &w = ws[blockIdx.z];
     if (lw_skip(w, sk)) return;
     extern __shared__ double s_rows[];
@@ -502,9 +502,8 @@ __global__ __launch_bounds__(256) void lw_feature_rows(const LwWin *ws, int whic
 }
 // MarginalizationFactor (marginalization_factor.cpp:333-381) of an 11-frame window: r = r0 + J0 dx with dx from lw_tr_* / the host (n <= 96 entries),
 // J0^T J0 from k_prior_prep; pcol maps a prior column to its column of the reduced system (-1: block constant in this solve)
-__global__ __launch_bounds__(256) void lw_prior(const LwWin *ws, int jac, int sk) {
-    const LwWin &w = ws[blockIdx.z];
-    if (lw_skip(w, sk) || !w.pn) return;
+__device__ __forceinline__ void lw_prior_body(const LwWin &w, int jac) {
+    if (!w.pn) return;
     const int n = w.pn, P = w.P;
     const double *J = w.pJ, *r0 = w.pr0, *H0 = w.pH0, *dx = w.pdx; const int *pcol = w.pcol;
     double *Hpp = w.Hpp, *gp = w.gp;
@@ -519,16 +518,24 @@ __global__ __launch_bounds__(256) void lw_prior(const LwWin *ws, int jac, int sk
     for (int i = tid; i < n; i += 256) { if (pcol[i] < 0) continue; double s = 0; for (int k = 0; k < n; k++) s += J[(size_t)k * n + i] * s_r[k]; add(gp + pcol[i], s); }
     for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e - i * n; if (pcol[i] >= 0 && pcol[j] >= 0) add(Hpp + (size_t)pcol[i] * P + pcol[j], H0[(size_t)i * VB_PRIOR_LD + j]); }
 }
+__global__ __launch_bounds__(256) void lw_prior(const LwWin *ws, int jac, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;
+    lw_prior_body(w, jac);
+}
 // IMUFactor between frames k, k + 1 (rec[287] = 0: skipped, sum_dt > 10 s) and the LiDAR between-factor of the same pair, FRAME-major: workgroup f owns the rows of
 // frame f of Hpp and g_p and adds to them what the two factors next to the frame contribute — "prev" (pair f - 1, f: the frame is its j side) and "next" (pair f, f + 1:
 // its i side) — prev before next, IMU before LiDAR, with plain read-modify-writes: every entry has ONE writer and a fixed order, so the linearisation is bit-reproducible
 // (until round 4: a workgroup per pair and an atomic per entry; the diagonal blocks took atomics from two workgroups in either order). Each factor is evaluated by
 // both of its frames' workgroups (lane 0 of a wave each, the four evaluations side by side); the products with sqrt_info (15 x 15 upper triangular times 15 x 31) and
 // the J^T [J r] entries are one lane per entry. The pair's cost goes to the slot of the frame it is "next" of.
-__global__ __launch_bounds__(256) void lw_imu_lidar(const LwWin *ws, int which, int jac, int sk) {
-    const LwWin &w = ws[blockIdx.z];
-    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
-    const int f = blockIdx.x, tid = threadIdx.x, NF = w.NF, P = w.P, use_lidar = w.use_lidar, nimu = w.nimu;
+// ATOMIC: the adds into Hpp / g_p as atomics — the estimate_extrinsic / estimate_td solves run this body in ONE launch with the prior's (lw_imu_lidar_prior: their
+// accumulation is not ordered anyway, lw_visual_ext and lw_prior add with atomics), which hides the prior's 30 us behind the IMU factors' 35 (round 5)
+template <bool ATOMIC>
+__device__ __forceinline__ void lw_acc(double *p, double v) { if (ATOMIC) add(p, v); else *p += v; }
+template <bool ATOMIC>
+__device__ __forceinline__ void lw_imu_lidar_body(const LwWin &w, int which, int jac, int f) {
+    const int tid = threadIdx.x, NF = w.NF, P = w.P, use_lidar = w.use_lidar, nimu = w.nimu;
     if (f >= NF) return;
     const double *x = which ? w.cand : w.x, *imu_rec = w.imu, *lid = w.lid, *G = w.scal + 8, *qil = w.scal + 1, *til = w.scal + 5;
     double *Hpp = w.Hpp, *gp = w.gp;
@@ -575,17 +582,17 @@ __global__ __launch_bounds__(256) void lw_imu_lidar(const LwWin *ws, int which, 
                     if (has[1]) { double t = 0; for (int m = 0; m < 6; m++) t += s_lJi[1][6 * m + a] * (blk == 0 ? s_lJi[1][6 * m + b] : s_lr[1][m]); v1 += t; }
                 }
                 if (!has[0] && !has[1]) continue;
-                if (blk == 0) Hpp[(size_t)(15 * f + a) * P + 15 * f + b] += v0 + v1; else gp[15 * f + a] += v0 + v1;
+                if (blk == 0) lw_acc<ATOMIC>(Hpp + (size_t)(15 * f + a) * P + 15 * f + b, v0 + v1); else lw_acc<ATOMIC>(gp + 15 * f + a, v0 + v1);
             } else if (blk == 1) {                           // (f, f + 1): next's i-j block
                 if (!has[1]) continue;
                 if (imu_on[1]) { double t = 0; for (int m = 0; m < 15; m++) t += s_jo[1][30 * m + a] * s_jo[1][30 * m + 15 + b]; v1 = t; }
                 if (use_lidar && a < 6 && b < 6) { double t = 0; for (int m = 0; m < 6; m++) t += s_lJi[1][6 * m + a] * s_lJj[1][6 * m + b]; v1 += t; }
-                Hpp[(size_t)(15 * f + a) * P + 15 * (f + 1) + b] += v1;
+                lw_acc<ATOMIC>(Hpp + (size_t)(15 * f + a) * P + 15 * (f + 1) + b, v1);
             } else {                                         // (f, f - 1): prev's j-i block
                 if (!has[0]) continue;
                 if (imu_on[0]) { double t = 0; for (int m = 0; m < 15; m++) t += s_jo[0][30 * m + 15 + a] * s_jo[0][30 * m + b]; v0 = t; }
                 if (use_lidar && a < 6 && b < 6) { double t = 0; for (int m = 0; m < 6; m++) t += s_lJj[0][6 * m + a] * s_lJi[0][6 * m + b]; v0 += t; }
-                Hpp[(size_t)(15 * f + a) * P + 15 * (f - 1) + b] += v0;
+                lw_acc<ATOMIC>(Hpp + (size_t)(15 * f + a) * P + 15 * (f - 1) + b, v0);
             }
         }
     if (tid == 0) {                                          // the pair (f, f + 1)'s cost
@@ -594,6 +601,18 @@ __global__ __launch_bounds__(256) void lw_imu_lidar(const LwWin *ws, int which, 
         if (use_lidar && has[1]) for (int a = 0; a < 6; a++) c += 0.5 * s_lr[1][a] * s_lr[1][a];
         w.costP[w.ncostv + f] = c;
     }
+}
+__global__ __launch_bounds__(256) void lw_imu_lidar(const LwWin *ws, int which, int jac, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;                       // device trust-region loop: this part of the iteration is not needed
+    lw_imu_lidar_body<false>(w, which, jac, (int)blockIdx.x);
+}
+// workgroups 0 .. maxNF - 1: the IMU / LiDAR factors of a frame (atomic adds); the last workgroup: the window's prior
+__global__ __launch_bounds__(256) void lw_imu_lidar_prior(const LwWin *ws, int which, int jac, int sk) {
+    const LwWin &w = ws[blockIdx.z];
+    if (lw_skip(w, sk)) return;
+    if (blockIdx.x + 1 == gridDim.x) lw_prior_body(w, jac);
+    else lw_imu_lidar_body<true>(w, which, jac, (int)blockIdx.x);
 }
 // zero the accumulation targets of one linearisation that are summed into with atomics (Hpp, g_p) and the cost: four entries per thread. W, h_f and g_f are
 // written whole by lw_feature_rows.
@@ -1587,8 +1606,11 @@ struct LwEnq {
                 if (jac) hipLaunchKernelGGL(lw_assemble, grid(d.maxNF + d.maxNpairs), dim3(256), 0, h->stream, ws, sk);
             }
         }
-        if (d.any_prior) hipLaunchKernelGGL(lw_prior, grid(1), dim3(256), 0, h->stream, ws, jac, sk);
-        hipLaunchKernelGGL(lw_imu_lidar, grid(d.maxNF), dim3(256), 0, h->stream, ws, which, jac, sk);
+        if (ext && d.any_prior) hipLaunchKernelGGL(lw_imu_lidar_prior, grid(d.maxNF + 1), dim3(256), 0, h->stream, ws, which, jac, sk);
+        else {
+            if (d.any_prior) hipLaunchKernelGGL(lw_prior, grid(1), dim3(256), 0, h->stream, ws, jac, sk);
+            hipLaunchKernelGGL(lw_imu_lidar, grid(d.maxNF), dim3(256), 0, h->stream, ws, which, jac, sk);
+        }
         if (jac) toc(0);
     }
     // Hpp v_p -> tmpP, W_f . v_p -> tmpF for the vector in vec
