@@ -811,18 +811,21 @@ extern "C" __global__ __launch_bounds__(NT, 3) void k_marg_schur(VbBatch b, VbMa
             __syncthreads();
             if (s_ok) store_item(tid);
             __syncthreads();
-            if (s_ok && tid + NT < n_items) {                        // the items beyond the first 256: L is complete (s_S, s_linv)
-                load_item(tid + NT);
+            if (s_ok) {
+#pragma unroll 1
+                for (int item = tid + NT; item < n_items; item += NT) {      // the items beyond the first 256: L is complete (s_S, s_linv)
+                    load_item(item);
 #pragma unroll
-                for (int j = 0; j < MG_MD; j++) {
-                    if (j < md) {
-                        const double zj = z[j] * s_linv[j];
-                        z[j] = zj;
+                    for (int j = 0; j < MG_MD; j++) {
+                        if (j < md) {
+                            const double zj = z[j] * s_linv[j];
+                            z[j] = zj;
 #pragma unroll
-                        for (int c = j + 1; c < MG_MD; c++) if (c < md) z[c] -= zj * s_S[c * md + j];
+                            for (int c = j + 1; c < MG_MD; c++) if (c < md) z[c] -= zj * s_S[c * md + j];
+                        }
                     }
+                    store_item(item);
                 }
-                store_item(tid + NT);
             }
         }
         if (s_ok) {
