@@ -1370,7 +1370,9 @@ __global__ void b_gather_sorted(CSet in, const int *vals_all, float4 *sorted_all
     q.w = __int_as_float(v);
     sorted_all[base + i] = q;
 }
+#ifndef KNN_FL
 #define KNN_FL 8            // candidates in flight per lane and round
+#endif
 #define KNN_ROWS 4          // rows of cells walked as one sequence (cells of >= 2/3 m: at most four rows)
 struct KnnSpans { int nrow, cylo, cxlo, cxhi1; };
 __device__ __forceinline__ KnnSpans knn_rows(float qx, float qy, float inv, int cs) {
