@@ -1388,6 +1388,12 @@ __device__ __forceinline__ void knn_span(const unsigned *T, unsigned tag, int n,
     const bool ok = (a & 0xff000000u) == tag && (b & 0xff000000u) == tag && sa <= sb && sb <= n;
     st = ok ? sa : 0; en = ok ? sb : 0;
 }
+typedef unsigned knn_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 knn_bload(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    const knn_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 0);
+    float4 r; r.x = __uint_as_float(v.x); r.y = __uint_as_float(v.y); r.z = __uint_as_float(v.z); r.w = __uint_as_float(v.w);
+    return r;
+}
 // exact 5-NN within the rows of cells around the query: pos[] = positions in the cell-major array, ordered by squared distance; candidates at exactly equal distances are
 // ordered by position here and reported through `tie` — b_associate_ties then redoes the query with the reference order (rare)
 __device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag, int n, float inv, int cs, float qx, float qy, float qz, int pos[5], float d2[5], bool &tie) {
@@ -1417,12 +1423,16 @@ __device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag
         const int o0 = st[0], o1 = st[1] - n0, o2 = st[2] - n01, o3 = st[3] - n012;
 #define KNN_AT(t) ((t) + ((t) < n0 ? o0 : ((t) < n01 ? o1 : ((t) < n012 ? o2 : o3))))
         if (ntot > 0) {
+            // the candidates through a buffer resource over the stream's map (round 5): a 32-bit byte offset instead of a 64-bit address per load (the kernel is bound by
+            // instructions issued), and a lane past its last candidate asks for an offset beyond the buffer — the load returns zeros without touching memory
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sorted, 0, n * 16, 0x00027000);
+#define KNN_LD(t) knn_bload(rs, (t) < ntot ? 16u * (unsigned)KNN_AT(t) : 0x7ffffff0u)
             float4 cur[KNN_FL], nxt[KNN_FL];
 #pragma unroll
-            for (int u = 0; u < KNN_FL; u++) cur[u] = sorted[u < ntot ? KNN_AT(u) : 0];
+            for (int u = 0; u < KNN_FL; u++) cur[u] = KNN_LD(u);
             for (int t0 = 0; t0 < ntot; t0 += KNN_FL) {
 #pragma unroll
-                for (int u = 0; u < KNN_FL; u++) { const int t = t0 + KNN_FL + u; nxt[u] = sorted[t < ntot ? KNN_AT(t) : 0]; }
+                for (int u = 0; u < KNN_FL; u++) { const int t = t0 + KNN_FL + u; nxt[u] = KNN_LD(t); }
 #pragma unroll
                 for (int u = 0; u < KNN_FL; u++) {
                     const int t = t0 + u;
@@ -1435,6 +1445,7 @@ __device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag
 #pragma unroll
             for (int k = 0; k < 5; k++) if (pos[k] >= 0) pos[k] = KNN_AT(pos[k]);
         }
+#undef KNN_LD
 #undef KNN_AT
     }
     for (int r = KNN_ROWS; r < R.nrow; r++) {          // cells smaller than 2/3 m: the further rows one by one
