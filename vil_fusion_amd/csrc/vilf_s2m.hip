@@ -1435,9 +1435,20 @@ __device__ void knn5_cells(const float4 *sorted, const unsigned *T, unsigned tag
                 for (int u = 0; u < KNN_FL; u++) { const int t = t0 + KNN_FL + u; nxt[u] = KNN_LD(t); }
 #pragma unroll
                 for (int u = 0; u < KNN_FL; u++) {
+                    // a slot past the lane's last candidate holds zeros (the buffer load's answer): its distance is replaced by +inf, which no list admits — a select
+                    // instead of the chain of nested `break`s (an exec-mask save, a branch and a restore per slot: the kernel is bound by instructions issued)
                     const int t = t0 + u;
-                    if (t >= ntot) break;
-                    KNN_TRY(cur[u], t)                    // the list holds the VIRTUAL index until the walk is over
+                    const float4 m = cur[u];
+                    const float ex = m.x - qx, ey = m.y - qy, ez = m.z - qz;
+                    const float dd = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+                    const float d = t < ntot ? dd : __builtin_inff();
+                    if (d <= d2[4]) { bool lt[5];                 // (KNN_TRY's insertion; the list holds the VIRTUAL index until the walk is over)
+#pragma unroll
+                        for (int k = 0; k < 5; k++) lt[k] = d < d2[k];
+                        disc = __builtin_amdgcn_fmed3f(-3.0e38f, disc, lt[4] ? d2[4] : d);
+#pragma unroll
+                        for (int k = 4; k >= 1; k--) { pos[k] = lt[k - 1] ? pos[k - 1] : (lt[k] ? t : pos[k]); d2[k] = __builtin_amdgcn_fmed3f(d2[k - 1], d2[k], d); }
+                        pos[0] = lt[0] ? t : pos[0]; d2[0] = lt[0] ? d : d2[0]; }
                 }
 #pragma unroll
                 for (int u = 0; u < KNN_FL; u++) cur[u] = nxt[u];
