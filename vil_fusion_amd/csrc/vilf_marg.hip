@@ -549,16 +549,18 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
         // with some twenty dependent loads each was 75 k cycles. Same sums in the same order.
         double *Wf = g.Wf + (size_t)w * FM * MG_ND, *hfm = g.hfm + (size_t)w * FM, *gfm = g.gfm + (size_t)w * FM;
         const int mfw = s_hdr[2];
-        int *s_frk = reinterpret_cast<int *>(s_rows);                       // rank -> feature (capacity 2 * MG_GCH * MG_MROW ints)
-        constexpr int FRK_CAP = 2 * MG_GCH * MG_MROW;
+        // rank -> feature, and the feature's factor count and first Mbuf row beside it (round 5: the two loops below fetched them from global memory in front of the rows
+        // they address — two dependent trips per pass of a thread, 27 passes): three tables of FRK_CAP ints in the staging area of the pair products
+        constexpr int FRK_CAP = 2 * MG_GCH * MG_MROW / 3;
+        int *s_frk = reinterpret_cast<int *>(s_rows), *s_fnf = s_frk + FRK_CAP, *s_ff0 = s_fnf + FRK_CAP;
         __syncthreads();
-        for (int f = tid; f < F; f += NT) { const int rk = f0rank[f]; if (rk >= 0 && rk < FRK_CAP) s_frk[rk] = f; }
+        for (int f = tid; f < F; f += NT) { const int rk = f0rank[f]; if (rk >= 0 && rk < FRK_CAP) { s_frk[rk] = f; s_fnf[rk] = f_nobs[f] - 1; s_ff0[rk] = f_fac0[f]; } }
         for (int e = tid; e < mfw * nd; e += NT) { const int rk = e / nd; Wf[(size_t)rk * MG_ND + (e - nd * rk)] = 0.0; }
         __syncthreads();
         if (mfw <= FRK_CAP) {
             const double *__restrict__ Mr = Mb;
             for (int e = tid; e < mfw * 15; e += NT) {
-                const int rk = e / 15, c = e - 15 * rk, f = s_frk[rk], nf = f_nobs[f] - 1, f0 = f_fac0[f];
+                const int rk = e / 15, c = e - 15 * rk, nf = s_fnf[rk], f0 = s_ff0[rk];
                 const int ca = c == 0 ? 36 : (c == 1 ? 38 : (c == 2 ? 40 : (c < 9 ? c - 3 : 24 + c - 9))), cb = c < 3 ? ca + 1 : ca + 6;
                 double a4[10][4];
 #pragma unroll
@@ -577,7 +579,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
                 double a4[4][4]; int dst[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int e = min(e0 + k * NT, mfw * 60 - 1), rk = e / 60, rem = e - 60 * rk, t = rem / 6, c = rem - 6 * t, f = s_frk[rk], nf = f_nobs[f] - 1, f0 = f_fac0[f];
+                    const int e = min(e0 + k * NT, mfw * 60 - 1), rk = e / 60, rem = e - 60 * rk, t = rem / 6, c = rem - 6 * t, nf = s_fnf[rk], f0 = s_ff0[rk];
                     const double *row = Mr + (size_t)(f0 + min(t, max(nf - 1, 0))) * MG_MROW;
                     a4[k][0] = row[36]; a4[k][1] = row[37]; a4[k][2] = row[12 + c]; a4[k][3] = row[18 + c];
                     dst[k] = (e0 + k * NT < mfw * 60 && t < nf) ? rk * MG_ND + s_off_pose[1 + t] + c : -1;
