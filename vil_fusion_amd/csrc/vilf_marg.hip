@@ -137,7 +137,9 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
     }
     for (int f = tid; f < F; f += NT) {
         const double est = 1.0 / b.feat[(size_t)w * FM + f];
-        st_feat[f] = est > 0 ? 1.0 / est : 1.0 / g.init_depth;
+        const double v = est > 0 ? 1.0 / est : 1.0 / g.init_depth;
+        st_feat[f] = v;
+        if (f < MG_GCH * MG_MROW) s_rows[f] = v;       // (a copy in the pair products' staging area, idle until then: the factor evaluation below reads it behind the factor's record — from global memory that was a second dependent trip per factor)
     }
     if (tid < VB_NPAIR) { const int *pt = b.pair_off + (size_t)w * VB_PTAB; const int v1 = pt[2 * tid + 1]; s_pst[tid] = pt[2 * tid]; s_pcn[tid] = v1 & 0xffffff; s_pcl[tid] = v1 >> 24; }
     __syncthreads();
@@ -341,7 +343,7 @@ __device__ __forceinline__ void marg_prepare_body(const VbBatch &b, const VbMarg
                 projection_td_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, vi, vj, s_td, b.obs_ctd[(size_t)w * b.Omax + oi], b.obs_ctd[(size_t)w * b.Omax + oj],
                                          b.obs_row[(size_t)w * b.Omax + oi] - b.row_half, b.obs_row[(size_t)w * b.Omax + oj] - b.row_half, b.tr_over_row, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex, Jtd);
             } else
-            projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
+            projection_eval<true>(s_pose, s_R, s_pose + 7 * fj, s_R + 9 * fj, s_ric, s_ex, pts_i, pts_j, f < MG_GCH * MG_MROW ? s_rows[f] : st_feat[f], b.sqrt_info, r, Ji, Jj, Jf, Jex);
             double rho0, sw;
             cauchy(r[0] * r[0] + r[1] * r[1], b.cauchy_b, rho0, sw);
             // the 42-double row as 21 16-byte stores (a row starts at a multiple of 336 bytes): every lane writes to lines of its own, so the number of store
